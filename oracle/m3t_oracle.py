@@ -1,0 +1,586 @@
+"""CPU ORACLE for the M3T hot path -- TEST INFRASTRUCTURE, NOT THE PRODUCT.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module.  Nothing under m3f.pytorch_amd/ imports it: the product path is the HIP
+library (m3f.pytorch_amd/csrc, C-ABI in include/m3t_hip.h) and fails loudly without it.
+
+What this is: an explicit-math numpy restatement (forward AND hand-derived backward)
+of the reference's forward/backward hot path.  Every function cites the reference
+file:line it restates (paths relative to the reference repo root).
+
+Where the arithmetic really lives: the reference is pure Python on third-party
+`torch` (nn.GRU, weight_norm(nn.Conv1d), nn.Linear, F.softmax, nn.BatchNorm2d ...),
+which is NOT under the reference tree and is not even pinned in its requirements.txt
+(requirements.txt:1-4).  The cell equations below are therefore the published torch
+definitions (torch.nn.GRU docs: gate order [r; z; n], n = tanh(W_in x + b_in +
+r * (W_hn h + b_hn))), anchored on the reference's own call sites.
+
+Pinning: the reference ships no tests/golden vectors.  The oracle is
+pinned against outputs of the reference itself, imported in the build container
+under torch 2.10.0 (CPU): tests/golden/gen_golden.py generated tests/golden/*.npz
+(inputs, weights, outputs, input- and parameter-gradients), and
+tests/test_oracle_golden.py checks every function here against them.
+
+All functions take/return numpy arrays; parameter dicts use the reference's
+state_dict key names.  dtype defaults to float64 (a tighter checker than fp32).
+"""
+import numpy as np
+
+F64 = np.float64
+
+
+def _sig(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+# --------------------------------------------------------------------------- linear
+def linear_fwd(x, w, b=None):
+    """nn.Linear: y = x W^T + b (used at models/rnn.py:22-55, models/model.py:88)."""
+    y = x @ w.T
+    if b is not None:
+        y = y + b
+    return y
+
+
+def linear_bwd(dy, x, w, has_bias=True):
+    x2 = x.reshape(-1, x.shape[-1])
+    dy2 = dy.reshape(-1, dy.shape[-1])
+    dx = (dy2 @ w).reshape(x.shape)
+    dw = dy2.T @ x2
+    db = dy2.sum(0) if has_bias else None
+    return dx, dw, db
+
+
+# --------------------------------------------------------------------------- BiGRU
+def _gru_dir_fwd(x, w_ih, w_hh, b_ih, b_hh, reverse):
+    """One direction of one layer of nn.GRU(batch_first=True) (models/rnn.py:17,75).
+    x [B,T,I] -> out [B,T,H]; h0 = 0; the reverse direction scans t = T-1 .. 0."""
+    B, T, _ = x.shape
+    H = w_hh.shape[1]
+    gi = x @ w_ih.T + b_ih                       # [B,T,3H], gate order r,z,n
+    out = np.zeros((B, T, H), x.dtype)
+    r_s = np.zeros((B, T, H), x.dtype)
+    z_s = np.zeros_like(r_s)
+    n_s = np.zeros_like(r_s)
+    hn_s = np.zeros_like(r_s)                    # W_hn h + b_hn (needed by backward)
+    h = np.zeros((B, H), x.dtype)
+    order = range(T - 1, -1, -1) if reverse else range(T)
+    for t in order:
+        gh = h @ w_hh.T + b_hh
+        r = _sig(gi[:, t, :H] + gh[:, :H])
+        z = _sig(gi[:, t, H:2 * H] + gh[:, H:2 * H])
+        n = np.tanh(gi[:, t, 2 * H:] + r * gh[:, 2 * H:])
+        h = (1.0 - z) * n + z * h
+        out[:, t] = h
+        r_s[:, t], z_s[:, t], n_s[:, t], hn_s[:, t] = r, z, n, gh[:, 2 * H:]
+    return out, h, (x, out, r_s, z_s, n_s, hn_s, reverse)
+
+
+def _gru_dir_bwd(dout, dh_last, cache, w_ih, w_hh):
+    """BPTT of _gru_dir_fwd (autograd of nn.GRU at models/rnn.py:75)."""
+    x, out, r_s, z_s, n_s, hn_s, reverse = cache
+    B, T, H = out.shape
+    dx = np.zeros_like(x)
+    dw_ih = np.zeros_like(w_ih)
+    dw_hh = np.zeros_like(w_hh)
+    db_ih = np.zeros(3 * H, x.dtype)
+    db_hh = np.zeros(3 * H, x.dtype)
+    dh = np.zeros((B, H), x.dtype) if dh_last is None else dh_last.copy()
+    order = list(range(T - 1, -1, -1) if reverse else range(T))
+    for idx in range(T - 1, -1, -1):
+        t = order[idx]
+        h_prev = out[:, order[idx - 1]] if idx > 0 else np.zeros((B, H), x.dtype)
+        r, z, n, hn = r_s[:, t], z_s[:, t], n_s[:, t], hn_s[:, t]
+        dht = dout[:, t] + dh
+        dn_pre = dht * (1.0 - z) * (1.0 - n * n)
+        dz_pre = dht * (h_prev - n) * z * (1.0 - z)
+        dr_pre = dn_pre * hn * r * (1.0 - r)
+        dgi = np.concatenate([dr_pre, dz_pre, dn_pre], 1)
+        dgh = np.concatenate([dr_pre, dz_pre, dn_pre * r], 1)
+        dh = dht * z + dgh @ w_hh
+        dx[:, t] = dgi @ w_ih
+        dw_ih += dgi.T @ x[:, t]
+        dw_hh += dgh.T @ h_prev
+        db_ih += dgi.sum(0)
+        db_hh += dgh.sum(0)
+    return dx, dw_ih, dw_hh, db_ih, db_hh
+
+
+def _sfx(layer, d):
+    return "l%d%s" % (layer, "_reverse" if d else "")
+
+
+def bigru_fwd(x, p, num_layers, prefix="gru."):
+    """Stacked bidirectional GRU, nn.GRU(I,H,L,batch_first=True,bidirectional=True)
+    (models/rnn.py:17).  Layer l>0 consumes concat[fwd,bwd] of layer l-1; no
+    inter-layer dropout.  Returns out [B,T,2H], h_n [2L,B,H], caches."""
+    caches, hs, inp = [], [], x
+    for l in range(num_layers):
+        outs = []
+        for d in (0, 1):
+            s = _sfx(l, d)
+            o, h, c = _gru_dir_fwd(inp, p[prefix + "weight_ih_" + s], p[prefix + "weight_hh_" + s],
+                                   p[prefix + "bias_ih_" + s], p[prefix + "bias_hh_" + s], bool(d))
+            outs.append(o); hs.append(h); caches.append(c)
+        inp = np.concatenate(outs, -1)
+    return inp, np.stack(hs, 0), caches
+
+
+def bigru_bwd(dout, caches, p, num_layers, prefix="gru.", dh_n=None):
+    grads = {}
+    H = caches[0][1].shape[-1]
+    d_in = dout
+    for l in range(num_layers - 1, -1, -1):
+        dx_sum = None
+        for d in (0, 1):
+            s = _sfx(l, d)
+            dhl = None if dh_n is None else dh_n[2 * l + d]
+            dx, dwi, dwh, dbi, dbh = _gru_dir_bwd(d_in[..., d * H:(d + 1) * H], dhl, caches[2 * l + d],
+                                                  p[prefix + "weight_ih_" + s], p[prefix + "weight_hh_" + s])
+            grads[prefix + "weight_ih_" + s] = dwi
+            grads[prefix + "weight_hh_" + s] = dwh
+            grads[prefix + "bias_ih_" + s] = dbi
+            grads[prefix + "bias_hh_" + s] = dbh
+            dx_sum = dx if dx_sum is None else dx_sum + dx
+        d_in = dx_sum
+    return d_in, grads
+
+
+def _fc_names(num_fcs, dropout):
+    """Key layout of GRU.fc (models/rnn.py:20-55): nFC=1 'fc'; nFC=2 fc.0, fc.2
+    (fc.0, fc.3 with dropout); nFC=3 fc.0, fc.2, fc.4 (fc.0, fc.3, fc.6 with dropout)."""
+    if num_fcs == 1:
+        return ["fc"]
+    step = 3 if dropout else 2
+    return ["fc.%d" % (i * step) for i in range(num_fcs)]
+
+
+def gru_module_fwd(x, p, num_layers, num_classes, num_fcs=1, dropout=False):
+    """models.rnn.GRU.forward (models/rnn.py:71-81), eval-mode dropout (identity)."""
+    out, h_n, caches = bigru_fwd(x, p, num_layers)
+    fc_cache = []
+    y = out
+    if num_classes > 0:
+        names = _fc_names(num_fcs, dropout)
+        for i, nm in enumerate(names):
+            a = linear_fwd(y, p[nm + ".weight"], p[nm + ".bias"])
+            last = i == len(names) - 1
+            fc_cache.append((nm, y, a))
+            y = a if last else np.maximum(a, 0.0)
+    return y, h_n, (caches, fc_cache)
+
+
+def gru_module_bwd(dy, cache, p, num_layers, dh_n=None):
+    caches, fc_cache = cache
+    grads = {}
+    d = dy
+    for i in range(len(fc_cache) - 1, -1, -1):
+        nm, xin, a = fc_cache[i]
+        if i != len(fc_cache) - 1:
+            d = d * (a > 0)
+        d, dw, db = linear_bwd(d, xin, p[nm + ".weight"])
+        grads[nm + ".weight"], grads[nm + ".bias"] = dw, db
+    dx, g = bigru_bwd(d, caches, p, num_layers, dh_n=dh_n)
+    grads.update(g)
+    return dx, grads
+
+
+# --------------------------------------------------------------------------- TCN
+def weight_norm_fwd(v, g):
+    """torch.nn.utils.weight_norm(dim=0) as applied at models/tcn.py:19-20,25-26:
+    w = g * v / ||v||, norm over (C_in,k) per output channel; g is [C_out,1,1]."""
+    nrm = np.sqrt((v * v).sum(axis=(1, 2), keepdims=True))
+    return g * v / nrm, nrm
+
+
+def weight_norm_bwd(dw, v, g, nrm):
+    dot = (dw * v).sum(axis=(1, 2), keepdims=True)
+    dg = dot / nrm
+    dv = g / nrm * (dw - v * dot / (nrm * nrm))
+    return dv, dg
+
+
+def causal_conv1d_fwd(x, w, b, dilation):
+    """Conv1d(padding=(k-1)d, dilation=d) followed by Chomp1d((k-1)d)
+    (models/tcn.py:7-13,19-21): y[b,co,t] = b[co] + sum_{ci,j} w[co,ci,j] x[b,ci,t-(k-1-j)d]
+    with x[.,.,<0] = 0.  x [B,C_in,T] channel-first."""
+    B, Ci, T = x.shape
+    Co, _, K = w.shape
+    y = np.zeros((B, Co, T), x.dtype) + (0 if b is None else b[None, :, None])
+    for j in range(K):
+        s = (K - 1 - j) * dilation
+        if s >= T:
+            continue
+        y[:, :, s:] += np.einsum("oc,bct->bot", w[:, :, j], x[:, :, :T - s])
+    return y
+
+
+def causal_conv1d_bwd(dy, x, w, dilation):
+    B, Ci, T = x.shape
+    Co, _, K = w.shape
+    dx = np.zeros_like(x)
+    dw = np.zeros_like(w)
+    for j in range(K):
+        s = (K - 1 - j) * dilation
+        if s >= T:
+            continue
+        dx[:, :, :T - s] += np.einsum("oc,bot->bct", w[:, :, j], dy[:, :, s:])
+        dw[:, :, j] = np.einsum("bot,bct->oc", dy[:, :, s:], x[:, :, :T - s])
+    db = dy.sum(axis=(0, 2))
+    return dx, dw, db
+
+
+def temporal_block_fwd(x, p, pre, dilation, masks=None):
+    """models.tcn.TemporalBlock.forward (models/tcn.py:43-46): relu(net(x) + res).
+    `masks` = (m1, m2) are optional pre-scaled dropout masks (train mode,
+    models/tcn.py:23,29); None = eval mode."""
+    w1, n1 = weight_norm_fwd(p[pre + "conv1.weight_v"], p[pre + "conv1.weight_g"])
+    w2, n2 = weight_norm_fwd(p[pre + "conv2.weight_v"], p[pre + "conv2.weight_g"])
+    a1 = causal_conv1d_fwd(x, w1, p[pre + "conv1.bias"], dilation)
+    h1 = np.maximum(a1, 0)
+    if masks is not None:
+        h1 = h1 * masks[0]
+    a2 = causal_conv1d_fwd(h1, w2, p[pre + "conv2.bias"], dilation)
+    h2 = np.maximum(a2, 0)
+    if masks is not None:
+        h2 = h2 * masks[1]
+    has_ds = (pre + "downsample.weight") in p
+    res = causal_conv1d_fwd(x, p[pre + "downsample.weight"], p[pre + "downsample.bias"], 1) if has_ds else x
+    s = h2 + res
+    y = np.maximum(s, 0)
+    return y, (x, w1, n1, w2, n2, a1, h1, a2, s, has_ds, masks)
+
+
+def temporal_block_bwd(dy, cache, p, pre, dilation):
+    x, w1, n1, w2, n2, a1, h1, a2, s, has_ds, masks = cache
+    g = {}
+    ds = dy * (s > 0)
+    dh2 = ds if masks is None else ds * masks[1]
+    da2 = dh2 * (a2 > 0)
+    dh1, dw2, db2 = causal_conv1d_bwd(da2, h1, w2, dilation)
+    if masks is not None:
+        dh1 = dh1 * masks[0]
+    da1 = dh1 * (a1 > 0)
+    dx, dw1, db1 = causal_conv1d_bwd(da1, x, w1, dilation)
+    g[pre + "conv1.weight_v"], g[pre + "conv1.weight_g"] = weight_norm_bwd(
+        dw1, p[pre + "conv1.weight_v"], p[pre + "conv1.weight_g"], n1)
+    g[pre + "conv2.weight_v"], g[pre + "conv2.weight_g"] = weight_norm_bwd(
+        dw2, p[pre + "conv2.weight_v"], p[pre + "conv2.weight_g"], n2)
+    g[pre + "conv1.bias"], g[pre + "conv2.bias"] = db1, db2
+    if has_ds:
+        dxr, dwd, dbd = causal_conv1d_bwd(ds, x, p[pre + "downsample.weight"], 1)
+        g[pre + "downsample.weight"], g[pre + "downsample.bias"] = dwd, dbd
+        dx = dx + dxr
+    else:
+        dx = dx + ds
+    return dx, g
+
+
+def tcn_fwd(x, p, num_levels, masks=None, prefix="network."):
+    """models.tcn.TemporalConvNet.forward (models/tcn.py:49-64): block i has
+    dilation 2**i (tcn.py:55) and left padding (k-1)*2**i (tcn.py:59)."""
+    caches = []
+    for i in range(num_levels):
+        x, c = temporal_block_fwd(x, p, "%s%d." % (prefix, i), 2 ** i, None if masks is None else masks[i])
+        caches.append(c)
+    return x, caches
+
+
+def tcn_bwd(dy, caches, p, prefix="network."):
+    grads = {}
+    for i in range(len(caches) - 1, -1, -1):
+        dy, g = temporal_block_bwd(dy, caches[i], p, "%s%d." % (prefix, i), 2 ** i)
+        grads.update(g)
+    return dy, grads
+
+
+# --------------------------------------------------------------------------- AttFusion
+def att_fuse_core_fwd(s_v, s_a, x_v, x_a):
+    """The reduction of models/att_fusion.py:21-25 given the raw scorer outputs:
+    h = softmax([sigmoid(s_v), sigmoid(s_a)]); f = h0 * x_v + h1 * x_a.
+    Softmax index 0 is VIDEO."""
+    hv, ha = _sig(s_v), _sig(s_a)
+    m = np.maximum(hv, ha)
+    ev, ea = np.exp(hv - m), np.exp(ha - m)
+    w0, w1 = ev / (ev + ea), ea / (ev + ea)
+    return w0 * x_v + w1 * x_a, (hv, ha, w0, w1, x_v, x_a)
+
+
+def att_fuse_core_bwd(df, cache):
+    hv, ha, w0, w1, x_v, x_a = cache
+    dx_v, dx_a = w0 * df, w1 * df
+    dw0 = (df * x_v).sum(-1, keepdims=True)
+    dw1 = (df * x_a).sum(-1, keepdims=True)
+    dot = w0 * dw0 + w1 * dw1
+    dhv, dha = w0 * (dw0 - dot), w1 * (dw1 - dot)
+    return dhv * hv * (1 - hv), dha * ha * (1 - ha), dx_v, dx_a
+
+
+def att_fusion_fwd(x_a, x_v, p):
+    """models.att_fusion.AttFusion.forward(x_a, x_v) (models/att_fusion.py:18-27).
+    Argument order is (audio, video); proj_v only when the dims differ (:11-13,19-20);
+    scorers are GRU(D0,hidden,1,1,1) (:15-16)."""
+    use_proj = "proj_v.weight" in p
+    xv_in = x_v
+    if use_proj:
+        x_v = linear_fwd(x_v, p["proj_v.weight"], p["proj_v.bias"])
+    pv = {k[len("scorer_v."):]: v for k, v in p.items() if k.startswith("scorer_v.")}
+    pa = {k[len("scorer_a."):]: v for k, v in p.items() if k.startswith("scorer_a.")}
+    s_v, _, cv = gru_module_fwd(x_v, pv, 1, 1, 1)
+    s_a, _, ca = gru_module_fwd(x_a, pa, 1, 1, 1)
+    f, cf = att_fuse_core_fwd(s_v, s_a, x_v, x_a)
+    return f, (use_proj, xv_in, pv, pa, cv, ca, cf)
+
+
+def att_fusion_bwd(df, cache, p):
+    use_proj, xv_in, pv, pa, cv, ca, cf = cache
+    ds_v, ds_a, dx_v, dx_a = att_fuse_core_bwd(df, cf)
+    dxv2, gv = gru_module_bwd(ds_v, cv, pv, 1)
+    dxa2, ga = gru_module_bwd(ds_a, ca, pa, 1)
+    dx_v, dx_a = dx_v + dxv2, dx_a + dxa2
+    grads = {"scorer_v." + k: v for k, v in gv.items()}
+    grads.update({"scorer_a." + k: v for k, v in ga.items()})
+    if use_proj:
+        dx_v, dw, db = linear_bwd(dx_v, xv_in, p["proj_v.weight"])
+        grads["proj_v.weight"], grads["proj_v.bias"] = dw, db
+    return dx_a, dx_v, grads
+
+
+# --------------------------------------------------------------------------- CBAM
+def channel_gate_fwd(x, p, pre="ChannelGate."):
+    """models.cbam.ChannelGate.forward (models/cbam.py:51-58): avg & max over H,W,
+    SHARED mlp Linear(C,C/r)-ReLU-Linear(C/r,C) (cbam.py:44-49, keys mlp.1 / mlp.3),
+    scale = sigmoid(mlp(avg)+mlp(max)); y = x * scale."""
+    N, C, H, W = x.shape
+    flat = x.reshape(N, C, H * W)
+    avg, mx = flat.mean(-1), flat.max(-1)
+    arg = flat.argmax(-1)
+    w1, b1, w2, b2 = (p[pre + "mlp.1.weight"], p[pre + "mlp.1.bias"],
+                      p[pre + "mlp.3.weight"], p[pre + "mlp.3.bias"])
+    ha, hm = avg @ w1.T + b1, mx @ w1.T + b1
+    att = np.maximum(ha, 0) @ w2.T + b2 + np.maximum(hm, 0) @ w2.T + b2
+    s = _sig(att)
+    return x * s[:, :, None, None], (x, avg, mx, arg, ha, hm, s)
+
+
+def channel_gate_bwd(dy, cache, p, pre="ChannelGate."):
+    x, avg, mx, arg, ha, hm, s = cache
+    N, C, H, W = x.shape
+    w1, w2 = p[pre + "mlp.1.weight"], p[pre + "mlp.3.weight"]
+    dx = dy * s[:, :, None, None]
+    ds = (dy * x).sum(axis=(2, 3))
+    datt = ds * s * (1 - s)
+    g = {}
+    ra, rm = np.maximum(ha, 0), np.maximum(hm, 0)
+    g[pre + "mlp.3.weight"] = datt.T @ ra + datt.T @ rm
+    g[pre + "mlp.3.bias"] = 2 * datt.sum(0)
+    dha = (datt @ w2) * (ha > 0)
+    dhm = (datt @ w2) * (hm > 0)
+    g[pre + "mlp.1.weight"] = dha.T @ avg + dhm.T @ mx
+    g[pre + "mlp.1.bias"] = dha.sum(0) + dhm.sum(0)
+    davg, dmx = dha @ w1, dhm @ w1
+    dxf = dx.reshape(N, C, H * W)
+    dxf += davg[:, :, None] / (H * W)
+    n_i, c_i = np.meshgrid(np.arange(N), np.arange(C), indexing="ij")
+    dxf[n_i, c_i, arg] += dmx
+    return dxf.reshape(N, C, H, W), g
+
+
+def _conv2d_same(x, w):
+    """Conv2d(2,1,5,padding=2,bias=False) (models/cbam.py:84-85 via BasicConv :19)."""
+    N, Ci, H, W = x.shape
+    K = w.shape[-1]
+    pd = K // 2
+    xp = np.pad(x, ((0, 0), (0, 0), (pd, pd), (pd, pd)))
+    y = np.zeros((N, 1, H, W), x.dtype)
+    for c in range(Ci):
+        for i in range(K):
+            for j in range(K):
+                y[:, 0] += w[0, c, i, j] * xp[:, c, i:i + H, j:j + W]
+    return y
+
+
+def _conv2d_same_bwd(dy, x, w):
+    N, Ci, H, W = x.shape
+    K = w.shape[-1]
+    pd = K // 2
+    xp = np.pad(x, ((0, 0), (0, 0), (pd, pd), (pd, pd)))
+    dxp = np.zeros_like(xp)
+    dw = np.zeros_like(w)
+    for c in range(Ci):
+        for i in range(K):
+            for j in range(K):
+                dw[0, c, i, j] = (dy[:, 0] * xp[:, c, i:i + H, j:j + W]).sum()
+                dxp[:, c, i:i + H, j:j + W] += w[0, c, i, j] * dy[:, 0]
+    return dxp[:, :, pd:pd + H, pd:pd + W], dw
+
+
+def spatial_gate_fwd(x, p, training, pre="SpatialGate."):
+    """models.cbam.SpatialGate.forward (models/cbam.py:87-92): ChannelPool order is
+    (max, mean) (cbam.py:67-71); 5x5 conv 2->1 no bias; BatchNorm2d(1, eps 1e-5,
+    momentum 0.01) (cbam.py:20); sigmoid; x * scale.  Returns also the updated
+    running stats (train mode: biased var for normalisation, unbiased for running)."""
+    N, C, H, W = x.shape
+    cmax, carg = x.max(1), x.argmax(1)
+    cmean = x.mean(1)
+    comp = np.stack([cmax, cmean], 1)
+    w = p[pre + "spatial.conv.weight"]
+    c = _conv2d_same(comp, w)
+    gamma, beta = p[pre + "spatial.bn.weight"], p[pre + "spatial.bn.bias"]
+    eps, mom = 1e-5, 0.01
+    if training:
+        mu, var = c.mean(), c.var()
+        cnt = c.size
+        new_rm = (1 - mom) * p[pre + "spatial.bn.running_mean"] + mom * mu
+        new_rv = (1 - mom) * p[pre + "spatial.bn.running_var"] + mom * var * cnt / max(cnt - 1, 1)
+    else:
+        mu, var = p[pre + "spatial.bn.running_mean"][0], p[pre + "spatial.bn.running_var"][0]
+        new_rm, new_rv = p[pre + "spatial.bn.running_mean"], p[pre + "spatial.bn.running_var"]
+    inv = 1.0 / np.sqrt(var + eps)
+    xh = (c - mu) * inv
+    s = _sig(xh * gamma[0] + beta[0])
+    y = x * s
+    return y, (x, carg, comp, w, xh, inv, s, gamma, training), (np.atleast_1d(new_rm), np.atleast_1d(new_rv))
+
+
+def spatial_gate_bwd(dy, cache, pre="SpatialGate."):
+    x, carg, comp, w, xh, inv, s, gamma, training = cache
+    N, C, H, W = x.shape
+    g = {}
+    dx = dy * s
+    ds = (dy * x).sum(1, keepdims=True)
+    dbn = ds * s * (1 - s)
+    g[pre + "spatial.bn.weight"] = np.atleast_1d((dbn * xh).sum())
+    g[pre + "spatial.bn.bias"] = np.atleast_1d(dbn.sum())
+    dxh = dbn * gamma[0]
+    if training:
+        m = dxh.size
+        dc = inv * (dxh - dxh.mean() - xh * (dxh * xh).sum() / m)
+    else:
+        dc = dxh * inv
+    dcomp, dw = _conv2d_same_bwd(dc, comp, w)
+    g[pre + "spatial.conv.weight"] = dw
+    dx = dx + dcomp[:, 1:2] / C
+    n_i, h_i, w_i = np.meshgrid(np.arange(N), np.arange(H), np.arange(W), indexing="ij")
+    dx[n_i, carg, h_i, w_i] += dcomp[:, 0]
+    return dx, g
+
+
+def cbam_fwd(x, p, training, pre=""):
+    """models.cbam.CBAM.forward (models/cbam.py:107-111): ChannelGate then SpatialGate."""
+    y1, c1 = channel_gate_fwd(x, p, pre + "ChannelGate.")
+    y2, c2, stats = spatial_gate_fwd(y1, p, training, pre + "SpatialGate.")
+    return y2, (c1, c2), stats
+
+
+def cbam_bwd(dy, cache, p, pre=""):
+    c1, c2 = cache
+    d1, g2 = spatial_gate_bwd(dy, c2, pre + "SpatialGate.")
+    dx, g1 = channel_gate_bwd(d1, c1, p, pre + "ChannelGate.")
+    g1.update(g2)
+    return dx, g1
+
+
+# --------------------------------------------------------------------------- losses
+def concordance_cc2(r1, r2):
+    """models.utils.concordance_cc2 (models/utils.py:6-17) on flat vectors:
+    ccc = 2*mean((r1-m1)(r2-m2)) / (var(r1)+var(r2)+(m1-m2)^2) where torch's
+    Tensor.var is UNBIASED (N-1) while the covariance is BIASED (N)."""
+    n = r1.size
+    m1, m2 = r1.mean(), r2.mean()
+    cov = ((r1 - m1) * (r2 - m2)).mean()
+    v1 = ((r1 - m1) ** 2).sum() / (n - 1)
+    v2 = ((r2 - m2) ** 2).sum() / (n - 1)
+    return 2 * cov / (v1 + v2 + (m1 - m2) ** 2)
+
+
+def ccc_loss_fwd_bwd(y_hat, y):
+    """AffWild2VA.ccc_loss (models/model.py:132-133): 1 - ccc over the WHOLE
+    flattened batch.  Returns (loss, dloss/dy_hat)."""
+    x, t = y_hat.reshape(-1), y.reshape(-1)
+    n = x.size
+    mx, mt = x.mean(), t.mean()
+    cov = ((x - mx) * (t - mt)).mean()
+    vx = ((x - mx) ** 2).sum() / (n - 1)
+    vt = ((t - mt) ** 2).sum() / (n - 1)
+    den = vx + vt + (mx - mt) ** 2
+    ccc = 2 * cov / den
+    dccc = 2 * (t - mt) / (n * den) - (2 * cov / den ** 2) * (2 * (x - mx) / (n - 1) + 2 * (mx - mt) / n)
+    return 1 - ccc, (-dccc).reshape(y_hat.shape)
+
+
+def masked_ce_fwd_bwd(logits, labels, mask):
+    """AffWild2VA.ce_loss (models/model.py:139-141): per-row cross entropy times mask,
+    mean over ALL B*T rows (not the valid count).  Returns (loss, dloss/dlogits)."""
+    lg = logits.reshape(-1, logits.shape[-1])
+    lb = labels.reshape(-1)
+    mk = mask.reshape(-1).astype(lg.dtype)
+    m = lg.max(-1, keepdims=True)
+    lse = m[:, 0] + np.log(np.exp(lg - m).sum(-1))
+    rows = np.arange(lg.shape[0])
+    ce = lse - lg[rows, lb]
+    loss = (ce * mk).mean()
+    sm = np.exp(lg - lse[:, None])
+    sm[rows, lb] -= 1.0
+    return loss, (sm * (mk / lg.shape[0])[:, None]).reshape(logits.shape)
+
+
+def training_loss_fwd_bwd(y_hat, valence, arousal, class_expr=None, expr_valid=None,
+                          loss_lambda=0.5, mtl=True):
+    """Loss assembly of AffWild2VA.training_step (models/model.py:146-182), 'ccc'
+    / 'ccc_mtl': valence = y_hat[...,7] (mtl) or [...,-2]; arousal = y_hat[...,-1];
+    loss = lam*L_v + (1-lam)*L_a (+ 0.8 * masked CE over y_hat[...,:7] when any
+    expr label is valid, :173-177).  Returns (loss, parts, dloss/dy_hat)."""
+    iv = 7 if mtl else y_hat.shape[-1] - 2
+    ia = y_hat.shape[-1] - 1
+    lv, gv = ccc_loss_fwd_bwd(y_hat[..., iv], valence)
+    la, ga = ccc_loss_fwd_bwd(y_hat[..., ia], arousal)
+    loss = loss_lambda * lv + (1 - loss_lambda) * la
+    dy = np.zeros_like(y_hat)
+    dy[..., iv] += loss_lambda * gv
+    dy[..., ia] += (1 - loss_lambda) * ga
+    parts = {"loss_v": lv, "loss_a": la}
+    if mtl and expr_valid is not None and expr_valid.sum() > 0:
+        le, ge = masked_ce_fwd_bwd(y_hat[..., :7], class_expr, expr_valid)
+        loss = loss + 0.8 * le
+        dy[..., :7] += 0.8 * ge
+        parts["loss_expr"] = le
+    return loss, parts, dy
+
+
+# --------------------------------------------------------------------------- C3 graph
+def av_feature_graph_fwd(x_a, x_v, p, num_hidden=512):
+    """Feature-level restatement of AffWild2VA.forward, audiovisual/attention
+    (models/model.py:108-118) with the conv towers replaced by given features
+    (SURVEY.md section 8(d) config C3): audio GRU -> [B,T,512]; gru_v, gru_a on the SAME
+    visual features (mirrors `se_features` passed twice, model.py:111) -> cat
+    [B,T,4*num_hidden]; proj_v; AttFusion; fusion GRU with 2-layer FC head."""
+    sub = lambda pre: {k[len(pre):]: v for k, v in p.items() if k.startswith(pre)}
+    a, _, ca = gru_module_fwd(x_a, sub("audio."), 2, -1)
+    v1, _, cv1 = gru_module_fwd(x_v, sub("visual.gru_v."), 2, -1)
+    v2, _, cv2 = gru_module_fwd(x_v, sub("visual.gru_a."), 2, -1)
+    vc = np.concatenate([v1, v2], -1)
+    vp = linear_fwd(vc, p["proj_v.weight"], p["proj_v.bias"])
+    f, cf = att_fusion_fwd(a, vp, sub("att_fuse."))
+    nfc = sum(1 for k in p if k.startswith("fusion.fc") and k.endswith("weight"))
+    y, _, cy = gru_module_fwd(f, sub("fusion."), 2, p[[k for k in p if k.startswith("fusion.fc")][-1]].shape[0], nfc)
+    return y, (ca, cv1, cv2, vc, cf, cy, sub)
+
+
+def av_feature_graph_bwd(dy, cache, p):
+    ca, cv1, cv2, vc, cf, cy, sub = cache
+    grads = {}
+    H = vc.shape[-1] // 2
+    df, g = gru_module_bwd(dy, cy, sub("fusion."), 2)
+    grads.update({"fusion." + k: v for k, v in g.items()})
+    da, dvp, g = att_fusion_bwd(df, cf, sub("att_fuse."))
+    grads.update({"att_fuse." + k: v for k, v in g.items()})
+    dvc, dw, db = linear_bwd(dvp, vc, p["proj_v.weight"])
+    grads["proj_v.weight"], grads["proj_v.bias"] = dw, db
+    dxv1, g = gru_module_bwd(dvc[..., :H], cv1, sub("visual.gru_v."), 2)
+    grads.update({"visual.gru_v." + k: v for k, v in g.items()})
+    dxv2, g = gru_module_bwd(dvc[..., H:], cv2, sub("visual.gru_a."), 2)
+    grads.update({"visual.gru_a." + k: v for k, v in g.items()})
+    dxa, g = gru_module_bwd(da, ca, sub("audio."), 2)
+    grads.update({"audio." + k: v for k, v in g.items()})
+    return dxa, dxv1 + dxv2, grads

@@ -1,0 +1,371 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE itself (imported read-only from
+/root/reference) on CPU under this container's torch.  Runs ONLY in the build
+container; the GPU box never sees the reference.  Fixtures are data only: inputs,
+weights (or the seed of the frozen recipe that regenerates them), outputs, gradients.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py
+"""
+import os
+import sys
+import types
+import argparse
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.dont_write_bytecode = True
+REF = os.environ.get("M3T_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+
+# models/model.py imports cv2 (via models/dataset.py) and pytorch_lightning, both absent here.
+sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+_pl = types.ModuleType("pytorch_lightning")
+_pl.LightningModule = nn.Module
+_pl.data_loader = lambda f: f
+sys.modules.setdefault("pytorch_lightning", _pl)
+
+import warnings
+warnings.filterwarnings("ignore")
+
+from models.rnn import GRU                                   # noqa: E402  (reference)
+from models.tcn import TemporalConvNet                        # noqa: E402
+from models.att_fusion import AttFusion                       # noqa: E402
+from models.cbam import CBAM                                  # noqa: E402
+from models.resnet import ResNet, BasicBlock                  # noqa: E402
+from models.utils import concordance_cc2                      # noqa: E402
+from models.model import AffWild2VA                           # noqa: E402
+from models.backbone import VA_3DVGGM_Split, VA_3DResNet      # noqa: E402
+
+from recipe import fill_module, named_tensors, draw, grad_digest  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print("wrote %-28s %7.1f KB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+def pack_params(mod, prefix="p."):
+    return {prefix + k: v for k, v in named_tensors(mod).items()}
+
+
+def pack_grads(mod, prefix="g."):
+    return {prefix + n: p.grad.detach().numpy().copy() for n, p in mod.named_parameters() if p.grad is not None}
+
+
+def hp(**kw):
+    parser = AffWild2VA.add_model_specific_args(argparse.ArgumentParser(add_help=False))
+    ns = parser.parse_args([])
+    for k, v in kw.items():
+        setattr(ns, k, v)
+    return ns
+
+
+# ------------------------------------------------------------------ small, fully stored
+def case_gru(name, args, B, T, seed, return_h=False):
+    rs = np.random.RandomState(seed)
+    m = fill_module(GRU(*args, return_h=return_h), seed + 1).eval()
+    x = torch.from_numpy(draw(rs, (B, T, args[0]))).requires_grad_(True)
+    out = m(x)
+    arrs = {}
+    if return_h:
+        y, h = out
+        ct_h = torch.from_numpy(draw(rs, tuple(h.shape)))
+        arrs.update(h=h.detach().numpy(), ct_h=ct_h.numpy())
+    else:
+        y = out
+    ct = torch.from_numpy(draw(rs, tuple(y.shape)))
+    loss = (y * ct).sum() + ((h * ct_h).sum() if return_h else 0)
+    loss.backward()
+    save(name, x=x.detach().numpy(), y=y.detach().numpy(), ct=ct.numpy(), dx=x.grad.numpy(),
+         args=np.array(list(args) + [int(return_h)]), **arrs, **pack_params(m), **pack_grads(m))
+
+
+def case_tcn(name, num_inputs, channels, k, B, T, seed):
+    rs = np.random.RandomState(seed)
+    m = fill_module(TemporalConvNet(num_inputs, channels, k), seed + 1).eval()   # eval: dropout off
+    x = torch.from_numpy(draw(rs, (B, num_inputs, T))).requires_grad_(True)
+    y = m(x)
+    ct = torch.from_numpy(draw(rs, tuple(y.shape)))
+    (y * ct).sum().backward()
+    sd_keys = np.array(sorted(m.state_dict().keys()))
+    save(name, x=x.detach().numpy(), y=y.detach().numpy(), ct=ct.numpy(), dx=x.grad.numpy(),
+         args=np.array([num_inputs, k] + list(channels)), state_dict_keys=sd_keys,
+         **pack_params(m), **pack_grads(m))
+
+
+def case_attfusion(name, dims, hidden, B, T, seed):
+    rs = np.random.RandomState(seed)
+    m = fill_module(AttFusion(dims, hidden), seed + 1).eval()
+    xa = torch.from_numpy(draw(rs, (B, T, dims[0]))).requires_grad_(True)
+    xv = torch.from_numpy(draw(rs, (B, T, dims[1]))).requires_grad_(True)
+    y = m(xa, xv)
+    ct = torch.from_numpy(draw(rs, tuple(y.shape)))
+    (y * ct).sum().backward()
+    save(name, x_a=xa.detach().numpy(), x_v=xv.detach().numpy(), y=y.detach().numpy(), ct=ct.numpy(),
+         dx_a=xa.grad.numpy(), dx_v=xv.grad.numpy(), args=np.array(list(dims) + [hidden]),
+         **pack_params(m), **pack_grads(m))
+
+
+def case_cbam(name, C, N, H, W, seed, training):
+    rs = np.random.RandomState(seed)
+    m = fill_module(CBAM(C), seed + 1)
+    m.train(training)
+    before = named_tensors(m)
+    x = torch.from_numpy(draw(rs, (N, C, H, W))).requires_grad_(True)
+    y = m(x)
+    ct = torch.from_numpy(draw(rs, tuple(y.shape)))
+    (y * ct).sum().backward()
+    after = named_tensors(m)
+    save(name, x=x.detach().numpy(), y=y.detach().numpy(), ct=ct.numpy(), dx=x.grad.numpy(),
+         training=np.array(int(training)),
+         running_mean_after=after["SpatialGate.spatial.bn.running_mean"],
+         running_var_after=after["SpatialGate.spatial.bn.running_var"],
+         **{"p." + k: v for k, v in before.items()}, **pack_grads(m))
+
+
+def case_losses(name, seed):
+    rs = np.random.RandomState(seed)
+    model = AffWild2VA(hp(modality="audio", loss="ccc_mtl"))
+    B, T = 3, 50
+    y_hat = torch.from_numpy(draw(rs, (B, T, 9))).requires_grad_(True)
+    val = torch.from_numpy(draw(rs, (B, T), "uniform_pm1"))
+    aro = torch.from_numpy(draw(rs, (B, T), "uniform_pm1"))
+    expr = torch.from_numpy(rs.randint(0, 7, (B, T)).astype(np.int64))
+    valid = torch.from_numpy(rs.uniform(size=(B, T)) < 0.7)
+    ccc_v = concordance_cc2(y_hat[..., 7].reshape(-1), val.reshape(-1), "none").squeeze()
+    l_v = model.ccc_loss(y_hat[..., 7], val)
+    l_a = model.ccc_loss(y_hat[..., -1], aro)
+    l_e = model.ce_loss(y_hat[..., :7], expr, valid)
+    loss = 0.5 * l_v + 0.5 * l_a + 0.8 * l_e
+    loss.backward()
+    save(name, y_hat=y_hat.detach().numpy(), valence=val.numpy(), arousal=aro.numpy(), class_expr=expr.numpy(),
+         expr_valid=valid.numpy(), ccc_v=ccc_v.detach().numpy(), loss_v=l_v.detach().numpy(),
+         loss_a=l_a.detach().numpy(), loss_expr=l_e.detach().numpy(), loss=loss.detach().numpy(),
+         dy_hat=y_hat.grad.numpy())
+
+
+def case_resnet_cbam(name, seed, training):
+    """ResNet v1 [1,1,1,1] with CBAM on small maps (models/resnet.py:59-124)."""
+    rs = np.random.RandomState(seed)
+    m = fill_module(ResNet(BasicBlock, [1, 1, 1, 1], use_cbam=True), seed + 1)
+    m.train(training)
+    before = named_tensors(m)
+    x = torch.from_numpy(draw(rs, (3, 64, 16, 16))).requires_grad_(True)
+    y = m(x)
+    ct = torch.from_numpy(draw(rs, tuple(y.shape)))
+    (y * ct).sum().backward()
+    grads = {"gd." + n: grad_digest(p.grad.numpy()) for n, p in m.named_parameters() if p.grad is not None}
+    save(name, seed=np.array(seed), training=np.array(int(training)), x=x.detach().numpy(), y=y.detach().numpy(),
+         ct=ct.numpy(), dx=x.grad.numpy(), param_names=np.array(sorted(before.keys())), **grads)
+
+
+# ------------------------------------------------------------------ full-size, recipe weights
+class RefAVFeatureGraph(nn.Module):
+    """Config C3/C4 of SURVEY.md section 8(d): AffWild2VA.forward audiovisual/attention
+    (reference models/model.py:108-118) with the conv towers replaced by pre-computed
+    features, assembled from the reference's own classes with AffWild2VA's attribute names."""
+
+    def __init__(self, d_a=128, d_v=256, num_hidden=512):
+        super().__init__()
+        self.audio = GRU(d_a, 256, 2, -1, 2)
+        self.visual = nn.Module()
+        self.visual.gru_v = GRU(d_v, num_hidden, 2, -1, 2)
+        self.visual.gru_a = GRU(d_v, num_hidden, 2, -1, 2)
+        self.proj_v = nn.Linear(num_hidden * 4, 512)
+        self.att_fuse = AttFusion([512, 512], 128)
+        self.fusion = GRU(512, num_hidden, 2, 9, 2)
+
+    def forward(self, x_a, x_v):
+        a = self.audio(x_a)
+        v = torch.cat((self.visual.gru_v(x_v), self.visual.gru_a(x_v)), dim=-1)
+        v = self.proj_v(v)
+        return self.fusion(self.att_fuse(a, v))
+
+
+def _mtl_loss(model, y_hat, val, aro, expr, valid):
+    l_v = model.ccc_loss(y_hat[..., 7], val)
+    l_a = model.ccc_loss(y_hat[..., -1], aro)
+    loss = 0.5 * l_v + 0.5 * l_a
+    loss = loss + 0.8 * model.ce_loss(y_hat[..., :7], expr, valid)
+    return loss, l_v, l_a
+
+
+def case_c3(name, B, T, seed, d_a=128, d_v=256, nh=512):
+    rs = np.random.RandomState(seed)
+    m = fill_module(RefAVFeatureGraph(d_a, d_v, nh), seed + 1).eval()
+    lossmod = AffWild2VA(hp(modality="audio", loss="ccc_mtl"))
+    xa = torch.from_numpy(draw(rs, (B, T, d_a))).requires_grad_(True)
+    xv = torch.from_numpy(draw(rs, (B, T, d_v))).requires_grad_(True)
+    val = torch.from_numpy(draw(rs, (B, T), "uniform_pm1"))
+    aro = torch.from_numpy(draw(rs, (B, T), "uniform_pm1"))
+    expr = torch.from_numpy(rs.randint(0, 7, (B, T)).astype(np.int64))
+    valid = torch.from_numpy(rs.uniform(size=(B, T)) < 0.7)
+    y = m(xa, xv)
+    loss, l_v, l_a = _mtl_loss(lossmod, y, val, aro, expr, valid)
+    loss.backward()
+    ccc_v = concordance_cc2(y[..., 7].reshape(-1), val.reshape(-1), "none").squeeze()
+    ccc_a = concordance_cc2(y[..., -1].reshape(-1), aro.reshape(-1), "none").squeeze()
+    grads = {"gd." + n: grad_digest(p.grad.numpy()) for n, p in m.named_parameters()}
+    save(name, seed=np.array(seed), dims=np.array([B, T, d_a, d_v, nh]), y=y.detach().numpy(),
+         loss=loss.detach().numpy(), loss_v=l_v.detach().numpy(), loss_a=l_a.detach().numpy(),
+         ccc_v=ccc_v.detach().numpy(), ccc_a=ccc_a.detach().numpy(),
+         dx_a=grad_digest(xa.grad.numpy()), dx_v=grad_digest(xv.grad.numpy()),
+         dx_a_full=xa.grad.numpy()[:, ::25], dx_v_full=xv.grad.numpy()[:, ::25], **grads)
+
+
+class RefTcnHead(nn.Module):
+    """Config C1: TemporalConvNet(128,[512,512],3) + Linear(512,2) composed exactly as
+    VA_3DVGGM's tcn back-end (reference models/backbone.py:107-111,139-141)."""
+
+    def __init__(self, d_in=128, hidden=512, levels=2):
+        super().__init__()
+        self.tcn = nn.ModuleList([TemporalConvNet(d_in, [hidden] * levels, 3), nn.Linear(hidden, 2)])
+
+    def forward(self, x):
+        x = self.tcn[0](x).transpose(1, 2).contiguous()
+        return self.tcn[1](x)
+
+
+class RefTcnGru(nn.Module):
+    """Config C2: TemporalConvNet(256,[512,512],3) -> transpose -> GRU(512,512,2,2,2)."""
+
+    def __init__(self, d_in=256, hidden=512):
+        super().__init__()
+        self.tcn = TemporalConvNet(d_in, [hidden, hidden], 3)
+        self.gru = GRU(hidden, hidden, 2, 2, 2)
+
+    def forward(self, x):
+        return self.gru(self.tcn(x).transpose(1, 2))
+
+
+def case_seq_model(name, ctor, in_shape, seed, ccc_out=True):
+    rs = np.random.RandomState(seed)
+    m = fill_module(ctor(), seed + 1).eval()
+    lossmod = AffWild2VA(hp(modality="audio", loss="ccc"))
+    x = torch.from_numpy(draw(rs, in_shape)).requires_grad_(True)
+    y = m(x)
+    B, T = y.shape[0], y.shape[1]
+    val = torch.from_numpy(draw(rs, (B, T), "uniform_pm1"))
+    aro = torch.from_numpy(draw(rs, (B, T), "uniform_pm1"))
+    l_v = lossmod.ccc_loss(y[..., -2], val)
+    l_a = lossmod.ccc_loss(y[..., -1], aro)
+    loss = 0.5 * l_v + 0.5 * l_a
+    loss.backward()
+    grads = {"gd." + n: grad_digest(p.grad.numpy()) for n, p in m.named_parameters()}
+    save(name, seed=np.array(seed), in_shape=np.array(in_shape), y=y.detach().numpy(), loss=loss.detach().numpy(),
+         dx=grad_digest(x.grad.numpy()), dx_full=x.grad.numpy()[:, :, ::10] if x.dim() == 3 else x.grad.numpy(),
+         **grads)
+
+
+def case_affwild_audio(name, seed):
+    """Config C1 reference-faithful variant: AffWild2VA(modality='audio', loss='ccc_mtl')
+    = GRU(200,256,2,9,2) on [4,100,200]; training_step (reference models/model.py:146-218)."""
+    rs = np.random.RandomState(seed)
+    m = fill_module(AffWild2VA(hp(modality="audio", loss="ccc_mtl")), seed + 1).eval()
+    B, T = 4, 100
+    batch = {
+        "audio": torch.from_numpy(draw(rs, (B, T, 200))),
+        "label_valence": torch.from_numpy(draw(rs, (B, T), "uniform_pm1")),
+        "label_arousal": torch.from_numpy(draw(rs, (B, T), "uniform_pm1")),
+        "class_expr": torch.from_numpy(rs.randint(0, 7, (B, T)).astype(np.int64)),
+        "expr_valid": torch.from_numpy(rs.uniform(size=(B, T)) < 0.7),
+    }
+    y = m(batch)
+    out = m.training_step(batch, 0)
+    out["loss"].backward()
+    grads = {"gd." + n: grad_digest(p.grad.numpy()) for n, p in m.named_parameters()}
+    save(name, seed=np.array(seed), y=y.detach().numpy(), loss=out["loss"].detach().numpy(),
+         loss_v=out["log"]["loss_v"].detach().numpy(), loss_a=out["log"]["loss_a"].detach().numpy(),
+         loss_expr=out["log"]["loss_expr"].detach().numpy(), acc_expr=np.array(out["progress_bar"]["acc_expr"]),
+         param_names=np.array(sorted(n for n, _ in m.named_parameters())), **grads)
+
+
+def case_affwild_av(name, seed, B=2, T=4):
+    """Config C5 (tiny): full AffWild2VA audiovisual/attention/v2p_split/ccc_mtl on raw
+    112x112 frames (reference models/model.py:101-118, models/backbone.py:273-295)."""
+    rs = np.random.RandomState(seed)
+    m = fill_module(AffWild2VA(hp(modality="audiovisual", fusion_type="attention", loss="ccc_mtl", window=T)),
+                    seed + 1).eval()
+    batch = {
+        "video": torch.from_numpy(rs.randint(0, 256, (B, 3, T, 112, 112)).astype(np.float32)),
+        "se_features": torch.from_numpy(draw(rs, (B, 512, T))),
+        "audio": torch.from_numpy(draw(rs, (B, T, 200))),
+        "label_valence": torch.from_numpy(draw(rs, (B, T), "uniform_pm1")),
+        "label_arousal": torch.from_numpy(draw(rs, (B, T), "uniform_pm1")),
+        "class_expr": torch.from_numpy(rs.randint(0, 7, (B, T)).astype(np.int64)),
+        "expr_valid": torch.from_numpy(rs.uniform(size=(B, T)) < 0.7),
+    }
+    y = m(batch)
+    out = m.training_step(batch, 0)
+    out["loss"].backward()
+    grads = {"gd." + n: grad_digest(p.grad.numpy()) for n, p in m.named_parameters() if p.grad is not None}
+    save(name, seed=np.array(seed), dims=np.array([B, T]), y=y.detach().numpy(), loss=out["loss"].detach().numpy(),
+         param_names=np.array(sorted(n for n, _ in m.named_parameters())),
+         state_dict_keys=np.array(sorted(m.state_dict().keys())), **grads)
+
+
+def case_resnet3d(name, seed, B=2, T=3):
+    """VA_3DResNet(resnet_ver='v1', use_cbam=True) visual-only (SURVEY 8(d) C5 alt),
+    eval mode, 112x112 input (reference models/backbone.py:314-355)."""
+    rs = np.random.RandomState(seed)
+    m = fill_module(VA_3DResNet(frameLen=T, resnet_ver="v1", use_cbam=True, nClasses=2, nFCs=2), seed + 1).eval()
+    x = torch.from_numpy(rs.randint(0, 256, (B, 3, T, 112, 112)).astype(np.float32))
+    x = ((x - 127.5) / 127.5).requires_grad_(True)
+    y = m(x)
+    ct = torch.from_numpy(draw(rs, tuple(y.shape)))
+    (y * ct).sum().backward()
+    grads = {"gd." + n: grad_digest(p.grad.numpy()) for n, p in m.named_parameters() if p.grad is not None}
+    save(name, seed=np.array(seed), dims=np.array([B, T]), y=y.detach().numpy(), ct=ct.numpy(),
+         dx=grad_digest(x.grad.numpy()), param_names=np.array(sorted(n for n, _ in m.named_parameters())), **grads)
+
+
+def main():
+    only = set(sys.argv[1:])
+
+    def want(n):
+        return not only or n in only
+
+    if want("gru"):
+        case_gru("gru_small", (24, 16, 2, 3, 2), 3, 13, 100)
+        case_gru("gru_nofc_h", (12, 8, 2, -1), 2, 9, 110, return_h=True)
+        case_gru("gru_fc3", (10, 8, 1, 2, 3), 2, 7, 120)
+        case_gru("gru_scorer", (10, 8, 1, 1, 1), 4, 11, 130)
+        case_gru("gru_t1", (6, 8, 2, 2, 2), 2, 1, 140)
+    if want("tcn"):
+        case_tcn("tcn_small", 8, [12, 12], 3, 2, 20, 200)
+        case_tcn("tcn_k2_deep", 6, [6, 6, 6], 2, 3, 17, 210)
+        case_tcn("tcn_short", 5, [7, 7, 7], 3, 2, 5, 220)      # T < receptive field
+    if want("att"):
+        case_attfusion("attfusion_same", [12, 12], 6, 3, 10, 300)
+        case_attfusion("attfusion_proj", [12, 20], 6, 2, 9, 310)
+    if want("cbam"):
+        case_cbam("cbam_train", 32, 4, 7, 7, 400, True)
+        case_cbam("cbam_eval", 32, 3, 5, 6, 410, False)
+        case_cbam("cbam_c64", 64, 2, 14, 14, 420, True)
+    if want("loss"):
+        case_losses("losses", 500)
+    if want("resnet"):
+        case_resnet_cbam("resnet_cbam_eval", 600, False)
+        case_resnet_cbam("resnet_cbam_train", 610, True)
+    if want("c1"):
+        case_seq_model("c1_tcn_head", lambda: RefTcnHead(128, 512, 2), (4, 128, 100), 700)
+        case_affwild_audio("c1_affwild_audio", 710)
+    if want("c2"):
+        case_seq_model("c2_tcn_gru", lambda: RefTcnGru(256, 512), (2, 256, 300), 720)
+    if want("c3"):
+        case_c3("c3_av_graph", 2, 300, 12345)
+        case_c3("c3_av_graph_small", 3, 17, 800, d_a=10, d_v=12, nh=512)
+    if want("c5"):
+        case_affwild_av("c5_affwild_av", 900)
+        case_resnet3d("c5_resnet3d_cbam", 910)
+
+
+if __name__ == "__main__":
+    main()

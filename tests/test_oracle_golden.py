@@ -1,0 +1,152 @@
+"""Pins the numpy oracle (oracle/m3t_oracle.py) against golden vectors produced by the
+reference itself (tests/golden/gen_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import m3t_oracle as O
+
+TOL = 2e-5   # goldens are fp32 torch outputs; oracle runs in fp64
+
+
+def P(g, dtype=np.float64):
+    return {k[2:]: v.astype(dtype) for k, v in g.items() if k.startswith("p.")}
+
+
+def G(g):
+    return {k[2:]: v for k, v in g.items() if k.startswith("g.")}
+
+
+def close(a, b, tol=TOL, what=""):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = np.abs(a - b).max() if a.size else 0.0
+    scale = max(1.0, np.abs(b).max() if b.size else 1.0)
+    assert err <= tol * scale, "%s: max abs err %.3e (scale %.2f)" % (what, err, scale)
+
+
+@pytest.mark.parametrize("name", ["gru_small", "gru_nofc_h", "gru_fc3", "gru_scorer", "gru_t1"])
+def test_gru(name):
+    g = load_golden(name)
+    I, H, L, nC, nFC, ret_h = [int(v) for v in g["args"][:6]] if len(g["args"]) == 6 else (
+        int(g["args"][0]), int(g["args"][1]), int(g["args"][2]), int(g["args"][3]), 1, int(g["args"][4]))
+    p = P(g)
+    y, h_n, cache = O.gru_module_fwd(g["x"].astype(np.float64), p, L, nC, nFC)
+    close(y, g["y"], what="y")
+    dh = None
+    if ret_h:
+        close(h_n, g["h"], what="h_n")
+        dh = g["ct_h"].astype(np.float64)
+    dx, grads = O.gru_module_bwd(g["ct"].astype(np.float64), cache, p, L, dh_n=dh)
+    close(dx, g["dx"], what="dx")
+    ref = G(g)
+    assert set(ref) == set(grads)
+    for k in ref:
+        close(grads[k], ref[k], what=k)
+
+
+@pytest.mark.parametrize("name", ["tcn_small", "tcn_k2_deep", "tcn_short"])
+def test_tcn(name):
+    g = load_golden(name)
+    levels = len(g["args"]) - 2
+    p = P(g)
+    y, caches = O.tcn_fwd(g["x"].astype(np.float64), p, levels)
+    close(y, g["y"], what="y")
+    dx, grads = O.tcn_bwd(g["ct"].astype(np.float64), caches, p)
+    close(dx, g["dx"], what="dx")
+    ref = G(g)
+    assert set(ref) == set(grads)
+    for k in ref:
+        close(grads[k], ref[k], what=k)
+
+
+@pytest.mark.parametrize("name", ["attfusion_same", "attfusion_proj"])
+def test_att_fusion(name):
+    g = load_golden(name)
+    p = P(g)
+    y, cache = O.att_fusion_fwd(g["x_a"].astype(np.float64), g["x_v"].astype(np.float64), p)
+    close(y, g["y"], what="y")
+    dxa, dxv, grads = O.att_fusion_bwd(g["ct"].astype(np.float64), cache, p)
+    close(dxa, g["dx_a"], what="dx_a")
+    close(dxv, g["dx_v"], what="dx_v")
+    ref = G(g)
+    assert set(ref) == set(grads)
+    for k in ref:
+        close(grads[k], ref[k], what=k)
+
+
+@pytest.mark.parametrize("name", ["cbam_train", "cbam_eval", "cbam_c64"])
+def test_cbam(name):
+    g = load_golden(name)
+    p = P(g)
+    training = bool(g["training"])
+    y, cache, (rm, rv) = O.cbam_fwd(g["x"].astype(np.float64), p, training)
+    close(y, g["y"], what="y")
+    close(rm, g["running_mean_after"], what="running_mean")
+    close(rv, g["running_var_after"], what="running_var")
+    dx, grads = O.cbam_bwd(g["ct"].astype(np.float64), cache, p)
+    close(dx, g["dx"], what="dx")
+    ref = G(g)
+    assert set(ref) == set(grads)
+    for k in ref:
+        close(grads[k], ref[k], what=k)
+
+
+def test_losses():
+    g = load_golden("losses")
+    yh = g["y_hat"].astype(np.float64)
+    ccc = O.concordance_cc2(yh[..., 7].reshape(-1), g["valence"].astype(np.float64).reshape(-1))
+    close(ccc, g["ccc_v"], what="ccc")
+    loss, parts, dy = O.training_loss_fwd_bwd(yh, g["valence"].astype(np.float64), g["arousal"].astype(np.float64),
+                                              g["class_expr"], g["expr_valid"])
+    close(parts["loss_v"], g["loss_v"], what="loss_v")
+    close(parts["loss_a"], g["loss_a"], what="loss_a")
+    close(parts["loss_expr"], g["loss_expr"], what="loss_expr")
+    close(loss, g["loss"], what="loss")
+    close(dy, g["dy_hat"], tol=1e-6, what="dy_hat")
+
+
+def test_ccc_unbiased_var_biased_cov_quirk():
+    """models/utils.py:13-14: var is unbiased (N-1), covariance biased (N)."""
+    rs = np.random.RandomState(0)
+    a, b = rs.randn(50), rs.randn(50)
+    quirk = O.concordance_cc2(a, b)
+    allbiased = 2 * np.mean((a - a.mean()) * (b - b.mean())) / (a.var() + b.var() + (a.mean() - b.mean()) ** 2)
+    assert abs(quirk - allbiased) > 1e-4
+
+
+def _c3_params(seed, d_a, d_v, nh):
+    """Regenerate the recipe weights of the C3 graph WITHOUT the reference: the recipe
+    walks sorted parameter names, so a name->shape table is enough."""
+    from golden.recipe import c3_param_shapes, fill_by_shapes
+    return fill_by_shapes(c3_param_shapes(d_a, d_v, nh), seed + 1)
+
+
+@pytest.mark.parametrize("name", ["c3_av_graph_small", "c3_av_graph"])
+def test_c3_graph(name):
+    from golden.recipe import draw, grad_digest
+    g = load_golden(name)
+    B, T, d_a, d_v, nh = [int(v) for v in g["dims"]]
+    seed = int(g["seed"])
+    p = {k: v.astype(np.float64) for k, v in _c3_params(seed, d_a, d_v, nh).items()}
+    rs = np.random.RandomState(seed)
+    xa = draw(rs, (B, T, d_a)).astype(np.float64)
+    xv = draw(rs, (B, T, d_v)).astype(np.float64)
+    val = draw(rs, (B, T), "uniform_pm1").astype(np.float64)
+    aro = draw(rs, (B, T), "uniform_pm1").astype(np.float64)
+    expr = rs.randint(0, 7, (B, T)).astype(np.int64)
+    valid = rs.uniform(size=(B, T)) < 0.7
+    y, cache = O.av_feature_graph_fwd(xa, xv, p)
+    close(y, g["y"], tol=5e-5, what="y")
+    loss, parts, dy = O.training_loss_fwd_bwd(y, val, aro, expr, valid)
+    close(loss, g["loss"], tol=5e-5, what="loss")
+    assert round(float(1 - parts["loss_v"]), 3) == round(float(g["ccc_v"]), 3)
+    assert round(float(1 - parts["loss_a"]), 3) == round(float(g["ccc_a"]), 3)
+    dxa, dxv, grads = O.av_feature_graph_bwd(dy, cache, p)
+    close(dxa[:, ::25], g["dx_a_full"], tol=5e-5, what="dx_a")
+    close(dxv[:, ::25], g["dx_v_full"], tol=5e-5, what="dx_v")
+    for k, v in grads.items():
+        ref = g["gd." + k]
+        got = grad_digest(v)
+        assert abs(got[0] - ref[0]) <= 2e-4 * max(1.0, ref[0]), (k, got[0], ref[0])
+        close(got[2:], ref[2:], tol=2e-4, what=k)
