@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py -- clips/sec of the M3T A+V hot path (forward + loss + backward [+ gradient
+all-reduce + clip]) on synthetic 300-frame clips, BASELINE.json's metric.
+
+Workload: feature-level audiovisual/attention graph --
+audio GRU(128,256,2) | gru_v,gru_a GRU(256,512,2) | proj_v 2048->512 | AttFusion([512,512],128) |
+fusion GRU(512,512,2,9,2) -- with the ccc_mtl training loss, 32 clips x 300 frames per GPU, fp32.
+One process per GPU (torchrun), clips sharded across ranks (weak scaling), one flat-buffer RCCL
+all-reduce of the gradients per step.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "m3f.pytorch_amd"), os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_* = vector fp32 rate
+HBM_PEAK_GBS = 8000.0
+
+
+def synth_batch(B, T, d_a, d_v, device, rank):
+    """np.random.RandomState(12345) (the reference's default --seed, train.py:49); each rank draws its own shard."""
+    rs = np.random.RandomState(12345 + rank)
+    f = lambda a: torch.from_numpy(a).to(device)
+    return dict(
+        x_v=f(rs.standard_normal((B, T, d_v)).astype(np.float32)),
+        x_a=f(rs.standard_normal((B, T, d_a)).astype(np.float32)),
+        valence=f(rs.uniform(-1, 1, (B, T)).astype(np.float32)),
+        arousal=f(rs.uniform(-1, 1, (B, T)).astype(np.float32)),
+        class_expr=f(rs.randint(0, 7, (B, T)).astype(np.int64)),
+        expr_valid=f(rs.uniform(size=(B, T)) < 0.7),
+    )
+
+
+def cpu_baseline(B, T, d_a, d_v, budget_s=20.0):
+    """The same workload from stock torch CPU ops (== the reference's CPU path, oracle/torch_ref.py),
+    timed on this box's host cores on a bounded sample (B clips per iteration)."""
+    from oracle import torch_ref as R
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(12345)
+    m = R.RefAVFeatureGraph(d_a, d_v, 512)
+    b = synth_batch(B, T, d_a, d_v, "cpu", 0)
+
+    def it():
+        for p in m.parameters():
+            p.grad = None
+        y = m(b["x_a"], b["x_v"])
+        R.mtl_loss(y, b["valence"], b["arousal"], b["class_expr"], b["expr_valid"]).backward()
+
+    it()                                    # warm-up
+    n, t0 = 0, time.perf_counter()
+    while n < 3 or (time.perf_counter() - t0 < budget_s and n < 10):
+        it()
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    return {"value": round(B / dt, 3), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d iterations of fwd+loss+bwd on %d clips x %d frames (stock torch CPU ops, fp32, %.2f s/iter)"
+                      % (n, B, T, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
+    ap.add_argument("--frames", type=int, default=300)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-clips", type=int, default=8)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    from m3t.workloads import AVFeatureGraph
+    from m3t.ddp import FlatGradDDP
+    from m3t import ops
+
+    B, T, d_a, d_v = args.batch, args.frames, 128, 256
+    torch.manual_seed(12345)                       # identical replicas on every rank
+    model = AVFeatureGraph(d_a, d_v, 512).to(device)
+    n_params = sum(p.numel() for p in model.parameters())
+    ddp = FlatGradDDP(model, bucket_order=[list(model.fusion.parameters()),
+                                           list(model.att_fuse.parameters()) + list(model.proj_v.parameters()),
+                                           list(model.visual.parameters()) + list(model.audio.parameters())],
+                      max_norm=1.0)
+    batch = synth_batch(B, T, d_a, d_v, device, rank)
+
+    def step():
+        ddp.zero_grad()
+        y = model(batch["x_a"], batch["x_v"])
+        loss, _ = ops.va_loss(y, batch["valence"], batch["arousal"], batch["class_expr"], batch["expr_valid"],
+                              iv=7, ia=8, n_expr=7, w_v=0.5, w_a=0.5, expr_w=0.8)
+        loss.backward()
+        ddp.finish()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ops.PROFILE.clear()
+    ops.PROFILE_ON[0] = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    ops.PROFILE_ON[0] = False
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- roofline of the dominant kernel, from HIP events recorded on the launch stream in the timed region
+    kern = {}
+    for rec in ops.PROFILE:
+        k = kern.setdefault(rec["kernel"], {"ms": 0.0, "launches": 0, "flops": 0.0})
+        k["ms"] += rec["start"].elapsed_time(rec["end"])
+        k["launches"] += rec["launches"]
+        k["flops"] += rec["flops"]
+    step_ms = dt / args.steps * 1e3
+    roofline, breakdown = None, {}
+    for name, k in kern.items():
+        breakdown[name] = {"ms_per_step": round(k["ms"] / args.steps, 3), "launches_per_step": k["launches"] // args.steps,
+                           "avg_launch_us": round(1e3 * k["ms"] / max(1, k["launches"]), 3)}
+    if kern:
+        name = max(kern, key=lambda n: kern[n]["ms"])
+        k = kern[name]
+        achieved = k["flops"] / (k["ms"] * 1e-3) / 1e12
+        roofline = {"kernel": name, "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "avg_launch_us": breakdown[name]["avg_launch_us"],
+                    "flops_per_launch": round(k["flops"] / max(1, k["launches"])),
+                    "share_of_step": round(k["ms"] / args.steps / step_ms, 3)}
+
+    if rank == 0:
+        clips = B * world * args.steps
+        out = {
+            "metric": "clips/sec (300-frame A+V, fwd+bwd)", "value": round(clips / dt, 2), "unit": "clips/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C3/C4 feature-level A+V att_fusion graph (SURVEY 8(d)): audio GRU(128,256,2) | "
+                                   "gru_v,gru_a GRU(256,512,2) | proj_v | AttFusion([512,512],128) | "
+                                   "fusion GRU(512,512,2,9,2); ccc_mtl loss; fwd+bwd+grad-clip"
+                                   + ("+RCCL all-reduce" if world > 1 else ""),
+                       "clips_per_gpu": B, "global_batch": B * world, "frames": T, "d_audio": d_a, "d_video": d_v,
+                       "params": n_params, "parallelism": "dp%d" % world},
+            "loss": round(float(loss), 6),
+            "grad_norm": round(float(ddp.last_norm), 6),
+            "roofline": roofline,
+            "kernels": breakdown,
+            "memory_roofline_frac": round((clips / dt) * 66.15e6 / (HBM_PEAK_GBS * 1e9 * world), 5),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_clips, T, d_a, d_v)
+            out["speedup_vs_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,202 @@
+/*
+ * m3t_hip.h -- C ABI of libm3t_hip.so: the MI355X (gfx950) kernels behind the M3T
+ * (sailordiary/m3f.pytorch) forward/backward hot path.
+ *
+ * The reference has no native code and no operator registry: every function below
+ * replaces a stock torch op that a reference module calls (cited per entry, paths
+ * relative to the reference root).  The host side (the models package under m3f.pytorch_amd) keeps the
+ * reference's Python module API and binds these entry points with ctypes
+ * (INTEGRATION.md shows the stub a maintainer would add to the reference itself).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 unless stated; tensors are row-major;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); all work is
+ *     enqueued on it, nothing synchronises, no allocation happens inside a call;
+ *   - return value: 0 on success, otherwise a hipError_t (launch/config error) or
+ *     M3T_EINVAL for bad arguments.  The caller raises;
+ *   - kernels are deterministic: fixed reduction order, no floating-point atomics.
+ */
+#ifndef M3T_HIP_H
+#define M3T_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define M3T_EINVAL 10001
+#define M3T_MAX_SCANS 8
+
+/* library / device info: returns the ABI version; arch string copied to `arch` if non-null */
+int m3t_version(void);
+int m3t_device_arch(char* arch, int cap);
+
+/* ---------------------------------------------------------------------------------
+ * Dense contraction on fp32 MFMA (v_mfma_f32_32x32x2_f32), exact fp32:
+ *   C[M,N] (ldc) = act( alpha-free  op(A)[M,K] * op(B)[K,N] + bias[N] ) (+ C if accumulate)
+ * transA=0: A stored [M][K] (lda)   transA=1: A stored [K][M] (lda)
+ * transB=0: B stored [K][N] (ldb)   transB=1: B stored [N][K] (ldb)  <- nn.Linear weight
+ * act: 0 none, 1 ReLU.  bias may be NULL.
+ * seg_len>0 (only with transA=1, transB=0): the reduction index k walks SEGMENTS:
+ *   storage row of A = (k / seg_len) * seg_stride + k % seg_len + a_off, same for B
+ *   with b_off (used for dW_hh = sum_t dgh_t^T h_{t-1}: per-clip shifted rows).
+ * ws/ws_bytes: optional split-K workspace (deterministic slab reduction); may be NULL.
+ * Replaces: nn.Linear (models/rnn.py:22-55, models/model.py:88, models/att_fusion.py:13),
+ * the input projections W_ih x inside nn.GRU (models/rnn.py:17,75) and their autograd. */
+int m3t_sgemm(int transA, int transB, int M, int N, int K,
+              const float* A, int lda, const float* B, int ldb,
+              float* C, int ldc, const float* bias, int act, int accumulate,
+              int seg_len, int seg_stride, int a_off, int b_off,
+              float* ws, size_t ws_bytes, void* stream);
+
+/* out[n] (+)= sum_m X[m*ld + n], m<M, n<N  (bias gradients); ws optional (tall inputs) */
+int m3t_colsum(const float* X, int M, int N, int ld, float* out, int accumulate,
+               float* ws, size_t ws_bytes, void* stream);
+
+/* dst[c][r] = src[r][c]  (src [R][C] with lds, dst [C][R] with ldd) */
+int m3t_transpose(const float* src, int R, int C, int lds, float* dst, int ldd, void* stream);
+
+/* y = relu'(a) * dy elementwise: dy[i] = a[i] > 0 ? dy[i] : 0 over n elements (in place on dy) */
+int m3t_relu_bwd(const float* a, float* dy, size_t n, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * BiGRU recurrence (the T-step scan inside nn.GRU, models/rnn.py:17,75).
+ * One call advances up to M3T_MAX_SCANS INDEPENDENT direction-scans (both directions
+ * of a layer; the same layer of independent stacks) in lock-step: one launch per
+ * time step covers all of them.  Gate order [r;z;n] (torch):
+ *   r = sig(xr + Whr h + bhr); z = sig(xz + Whz h + bhz); n = tanh(xn + r*(Whn h + bhn))
+ *   h' = (1-z)*n + z*h ; h0 = 0 ; reverse scans run t = T-1 .. 0.
+ * xproj already contains W_ih x + b_ih (m3t_sgemm). */
+typedef struct {
+    const float* xproj;  /* [B,T,ldx]; this scan reads columns [xoff, xoff+3H)            */
+    const float* w_hh;   /* [3H,H]                                                         */
+    const float* b_hh;   /* [3H]                                                           */
+    float* out;          /* [B,T,ldo]; h_t written to columns [ooff, ooff+H)               */
+    float* gates;        /* [B,T,4H] saved r,z,n,(Whn h + bhn) for backward; NULL = skip   */
+    float* h_n;          /* [B,H] final hidden state (NULL = skip)                         */
+    int H, reverse, ldx, xoff, ldo, ooff;
+} m3t_gru_fwd_desc;
+
+int m3t_gru_scan_fwd(const m3t_gru_fwd_desc* scans, int n_scans, int B, int T, void* stream);
+
+/* BPTT of the scans above (autograd of nn.GRU).  Per scan:
+ *   dgx[B,T,ldg][goff..goff+3H) = grad wrt xproj  = (dr~, dz~, dn~)
+ *   dgh[B,T,3H]                 = grad wrt W_hh h + b_hh = (dr~, dz~, dn~ * r)
+ * The caller finishes with m3t_sgemm / m3t_colsum: dW_hh = sum dgh_t^T h_{t-1},
+ * db_hh = colsum(dgh), dW_ih = dgx^T x, db_ih = colsum(dgx), dx = dgx W_ih. */
+typedef struct {
+    const float* dout;    /* [B,T,ldo]: grad wrt out, columns [ooff, ooff+H)               */
+    const float* out;     /* forward h_t, same layout                                      */
+    const float* gates;   /* [B,T,4H] from forward                                         */
+    const float* w_hh_t;  /* [H,3H] = W_hh transposed (m3t_transpose)                      */
+    const float* dh_n;    /* [B,H] grad wrt final hidden state, or NULL                    */
+    float* dgx;           /* [B,T,ldg], columns [goff, goff+3H)                            */
+    float* dgh;           /* [B,T,3H]                                                      */
+    float* dh;            /* [B,H] scratch: running dL/dh_t                                */
+    int H, reverse, ldo, ooff, ldg, goff;
+} m3t_gru_bwd_desc;
+
+int m3t_gru_scan_bwd(const m3t_gru_bwd_desc* scans, int n_scans, int B, int T, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Attention-fusion reduction (models/att_fusion.py:21-25) on [B*T] frames of D floats:
+ *   w = softmax([sigmoid(s_v), sigmoid(s_a)]);  f = w0 * x_v + w1 * x_a   (index 0 = VIDEO)
+ * s_v, s_a: [rows] raw scorer outputs. */
+int m3t_att_fuse_fwd(const float* s_v, const float* s_a, const float* x_v, const float* x_a,
+                     float* f, int rows, int D, void* stream);
+int m3t_att_fuse_bwd(const float* df, const float* s_v, const float* s_a,
+                     const float* x_v, const float* x_a,
+                     float* ds_v, float* ds_a, float* dx_v, float* dx_a,
+                     int rows, int D, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Loss of AffWild2VA.training_step (models/model.py:132-141,146-182), forward and
+ * gradient in one pass over y_hat [rows, C]:
+ *   L = w_v * (1 - ccc(y[:,iv], valence)) + w_a * (1 - ccc(y[:,ia], arousal))
+ *       + expr_w * mean_rows( CE(y[:, :n_expr], class_expr) * expr_valid )     (n_expr>0)
+ * (training_step uses w_v = loss_lambda, w_a = 1 - loss_lambda, expr_w = 0.8; a zero weight
+ * skips its term entirely)
+ * ccc per models/utils.py:6-17 (unbiased variance, biased covariance).  With
+ * use_mse!=0 the two ccc terms become mean squared errors (models/model.py:143-144).
+ * The CE term is dropped when no row is valid (model.py:173-174) -- decided on device.
+ * out_scalars[8] = {loss, loss_v, loss_a, loss_expr, n_valid, n_correct, ccc_v, ccc_a};
+ * dy [rows, C] receives dL/dy_hat (fully written).  class_expr int64, expr_valid uint8. */
+int m3t_va_loss(const float* y_hat, int rows, int C, int iv, int ia,
+                const float* valence, const float* arousal,
+                const int64_t* class_expr, const uint8_t* expr_valid, int n_expr,
+                float w_v, float w_a, float expr_w, int use_mse,
+                float* out_scalars, float* dy, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * TCN (models/tcn.py).  Activations are channel-last [B,T,C] inside the library.
+ * weight-norm reparametrisation (torch.nn.utils.weight_norm at models/tcn.py:19-20):
+ *   w[co][ci][j] = g[co] * v[co][ci][j] / ||v[co]||;  output layout w_t[j][co][ci]
+ *   (tap-major, so each tap is a K-contiguous [C_out,C_in] matrix); norm[co] saved. */
+int m3t_weight_norm_fwd(const float* v, const float* g, float* w_t, float* norm,
+                        int Co, int Ci, int K, void* stream);
+/* dw_t [K][Co][Ci] -> dv [Co][Ci][K], dg [Co] */
+int m3t_weight_norm_bwd(const float* dw_t, const float* v, const float* g, const float* norm,
+                        float* dv, float* dg, int Co, int Ci, int K, void* stream);
+
+/* Dilated causal conv (Conv1d(pad=(k-1)d, dil=d) + Chomp1d, models/tcn.py:7-13,19-21),
+ * channel-last, left zero padding, halo staged in LDS:
+ *   y[b,t,co] = act( bias[co] + sum_{j,ci} w_t[j][co][ci] * x[b, t-(K-1-j)*d, ci] (+ res[b,t,co]) )
+ * act: 0 none, 1 ReLU, 2 ReLU(ReLU(conv) + res) (the block output, models/tcn.py:46);
+ * pre (optional, [B,T,Co]) receives the pre-activation conv output (+bias) for backward.
+ * drop_mask (optional, [B,T,Co], already scaled by 1/(1-p)) multiplies the ReLU output
+ * (nn.Dropout after relu1/relu2 in train mode, models/tcn.py:23,29); NULL in eval mode.
+ * anticausal!=0 flips the time direction (x[b, t+(K-1-j)*d]) -- the data-gradient conv. */
+int m3t_causal_conv_fwd(const float* x, const float* w_t, const float* bias, const float* res,
+                        const float* drop_mask, float* y, float* pre,
+                        int B, int T, int Ci, int Co, int K, int dilation,
+                        int act, int anticausal, void* stream);
+/* dw_t[j][co][ci] = sum_{b,t} dy[b,t,co] * x[b, t-(K-1-j)*d, ci] */
+int m3t_causal_conv_wgrad(const float* dy, const float* x, float* dw_t,
+                          int B, int T, int Ci, int Co, int K, int dilation,
+                          float* ws, size_t ws_bytes, void* stream);
+/* [B,C,T] <-> [B,T,C] */
+int m3t_bct_to_btc(const float* src, float* dst, int B, int C, int T, void* stream);
+int m3t_btc_to_bct(const float* src, float* dst, int B, int T, int C, void* stream);
+/* out[i] = s[i] > 0 ? dy[i] * (mul ? mul[i] : 1) : 0   (ReLU / dropout gradient masks) */
+int m3t_mask_pos(const float* s, const float* dy, const float* mul, float* out, size_t n, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * CBAM (models/cbam.py), x [N,C,H,W] contiguous.
+ * Channel gate (cbam.py:51-58): avg+max over H*W per (n,c) by wavefront shuffles,
+ * shared MLP C -> C/r -> C, sigmoid, scale.  pooled [N,2,C] (avg,max), argmax [N,C] int32,
+ * hidden [N,2,Cr] pre-ReLU, scale [N,C] are saved for backward. */
+int m3t_cbam_channel_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                         float* y, float* pooled, int32_t* argmax, float* hidden, float* scale,
+                         int N, int C, int Cr, int HW, void* stream);
+int m3t_cbam_channel_bwd(const float* dy, const float* x, const float* w1, const float* w2,
+                         const float* pooled, const int32_t* argmax, const float* hidden, const float* scale,
+                         float* dx, float* dw1, float* db1, float* dw2, float* db2,
+                         int N, int C, int Cr, int HW, float* ws, size_t ws_bytes, void* stream);
+/* Spatial gate (cbam.py:61-92): per-pixel (max,mean) over C -> 5x5 conv 2->1 (pad 2) ->
+ * BatchNorm2d(1) (training: batch statistics, running stats updated with `momentum`,
+ * unbiased running variance) -> sigmoid -> scale.
+ * bn = {gamma, beta}; running = {mean, var} (updated in place when training).
+ * saved: comp [N,2,HW], cargmax [N,HW] int32, xhat [N,HW], stats[2] = {mean, invstd}, scale [N,HW]. */
+int m3t_cbam_spatial_fwd(const float* x, const float* conv_w, const float* bn, float* running,
+                         float* y, float* comp, int32_t* cargmax, float* xhat, float* stats, float* scale,
+                         int N, int C, int H, int W, int training, float momentum, float eps,
+                         float* ws, size_t ws_bytes, void* stream);
+int m3t_cbam_spatial_bwd(const float* dy, const float* x, const float* conv_w, const float* bn,
+                         const float* comp, const int32_t* cargmax, const float* xhat, const float* stats,
+                         const float* scale, float* dx, float* dconv_w, float* dbn,
+                         int N, int C, int H, int W, int training, float* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Data-parallel helpers (train.py:32-41: DDP mean of gradients + clip_grad_norm_(1.0)).
+ * After the RCCL all-reduce(sum) of the flat gradient buffer: one pass computes
+ * sum(g^2) of g/world (partials[blocks] + final), a second scales by
+ * (1/world) * min(1, max_norm/(norm+1e-6)).  norm_out[0] = total norm (pre-clip). */
+int m3t_grad_norm_scale(float* flat, size_t n, float inv_world, float max_norm,
+                        float* norm_out, float* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* M3T_HIP_H */

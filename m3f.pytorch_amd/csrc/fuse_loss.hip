@@ -1,0 +1,270 @@
+// HBM-bound kernels of the path: the attention-fusion reduction (models/att_fusion.py:21-25),
+// the VA training loss with its gradient (models/model.py:132-182, models/utils.py:6-17) and
+// the data-parallel gradient post-processing (train.py:35).  One wavefront per [B,T,C] frame
+// row, float4 (16 B/lane) accesses, wavefront-shuffle reductions, no atomics.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ void fuse_weights(float sv, float sa, float& hv, float& ha, float& w0, float& w1) {
+    hv = 1.f / (1.f + expf(-sv));
+    ha = 1.f / (1.f + expf(-sa));
+    const float m = fmaxf(hv, ha);
+    const float ev = expf(hv - m), ea = expf(ha - m);
+    const float inv = 1.f / (ev + ea);
+    w0 = ev * inv;
+    w1 = ea * inv;
+}
+
+__global__ __launch_bounds__(256) void att_fuse_fwd_kernel(const float* __restrict__ s_v, const float* __restrict__ s_a,
+                                                           const float* __restrict__ x_v, const float* __restrict__ x_a,
+                                                           float* __restrict__ f, int rows, int D, int vec) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float hv, ha, w0, w1;
+    fuse_weights(s_v[row], s_a[row], hv, ha, w0, w1);
+    const size_t base = (size_t)row * D;
+    if (vec) {
+        const float4* pv = reinterpret_cast<const float4*>(x_v + base);
+        const float4* pa = reinterpret_cast<const float4*>(x_a + base);
+        float4* pf = reinterpret_cast<float4*>(f + base);
+        for (int i = lane; i < (D >> 2); i += 64) {
+            const float4 v = pv[i], a = pa[i];
+            pf[i] = make_float4(w0 * v.x + w1 * a.x, w0 * v.y + w1 * a.y, w0 * v.z + w1 * a.z, w0 * v.w + w1 * a.w);
+        }
+    } else {
+        for (int i = lane; i < D; i += 64) f[base + i] = w0 * x_v[base + i] + w1 * x_a[base + i];
+    }
+}
+
+__global__ __launch_bounds__(256) void att_fuse_bwd_kernel(const float* __restrict__ df, const float* __restrict__ s_v,
+                                                           const float* __restrict__ s_a, const float* __restrict__ x_v,
+                                                           const float* __restrict__ x_a, float* __restrict__ ds_v,
+                                                           float* __restrict__ ds_a, float* __restrict__ dx_v,
+                                                           float* __restrict__ dx_a, int rows, int D, int vec) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float hv, ha, w0, w1;
+    fuse_weights(s_v[row], s_a[row], hv, ha, w0, w1);
+    const size_t base = (size_t)row * D;
+    float d0 = 0.f, d1 = 0.f;
+    if (vec) {
+        const float4* pg = reinterpret_cast<const float4*>(df + base);
+        const float4* pv = reinterpret_cast<const float4*>(x_v + base);
+        const float4* pa = reinterpret_cast<const float4*>(x_a + base);
+        float4* qv = reinterpret_cast<float4*>(dx_v + base);
+        float4* qa = reinterpret_cast<float4*>(dx_a + base);
+        for (int i = lane; i < (D >> 2); i += 64) {
+            const float4 g = pg[i], v = pv[i], a = pa[i];
+            d0 += g.x * v.x + g.y * v.y + g.z * v.z + g.w * v.w;
+            d1 += g.x * a.x + g.y * a.y + g.z * a.z + g.w * a.w;
+            qv[i] = make_float4(w0 * g.x, w0 * g.y, w0 * g.z, w0 * g.w);
+            qa[i] = make_float4(w1 * g.x, w1 * g.y, w1 * g.z, w1 * g.w);
+        }
+    } else {
+        for (int i = lane; i < D; i += 64) {
+            const float g = df[base + i];
+            d0 += g * x_v[base + i];
+            d1 += g * x_a[base + i];
+            dx_v[base + i] = w0 * g;
+            dx_a[base + i] = w1 * g;
+        }
+    }
+    d0 = wave_sum(d0);
+    d1 = wave_sum(d1);
+    if (lane == 0) {
+        const float dot = w0 * d0 + w1 * d1;
+        ds_v[row] = w0 * (d0 - dot) * hv * (1.f - hv);
+        ds_a[row] = w1 * (d1 - dot) * ha * (1.f - ha);
+    }
+}
+
+// ------------------------------------------------------------------------------ VA loss
+struct CccStats { float mx, mt, cov, vx, vt, den, ccc; };
+
+__global__ __launch_bounds__(1024) void va_loss_kernel(const float* __restrict__ y, int rows, int C, int iv, int ia,
+                                                       const float* __restrict__ val, const float* __restrict__ aro,
+                                                       const int64_t* __restrict__ cls, const uint8_t* __restrict__ valid,
+                                                       int n_expr, float wv, float wa, float expr_w, int use_mse,
+                                                       float* __restrict__ out, float* __restrict__ dy) {
+    __shared__ float red[16];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const float invn = 1.f / (float)rows;
+    // pass 1: means
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int i = tid; i < rows; i += nt) {
+        s0 += y[(size_t)i * C + iv]; s1 += val[i];
+        s2 += y[(size_t)i * C + ia]; s3 += aro[i];
+    }
+    const float mxv = block_sum(s0, red) * invn, mtv = block_sum(s1, red) * invn;
+    const float mxa = block_sum(s2, red) * invn, mta = block_sum(s3, red) * invn;
+    // pass 2: centred second moments (or squared errors)
+    float cv = 0.f, xv = 0.f, tv = 0.f, ca = 0.f, xa = 0.f, ta = 0.f, ev = 0.f, ea = 0.f;
+    for (int i = tid; i < rows; i += nt) {
+        const float a = y[(size_t)i * C + iv], b = val[i];
+        const float c = y[(size_t)i * C + ia], e = aro[i];
+        cv += (a - mxv) * (b - mtv); xv += (a - mxv) * (a - mxv); tv += (b - mtv) * (b - mtv);
+        ca += (c - mxa) * (e - mta); xa += (c - mxa) * (c - mxa); ta += (e - mta) * (e - mta);
+        ev += (a - b) * (a - b); ea += (c - e) * (c - e);
+    }
+    cv = block_sum(cv, red); xv = block_sum(xv, red); tv = block_sum(tv, red);
+    ca = block_sum(ca, red); xa = block_sum(xa, red); ta = block_sum(ta, red);
+    ev = block_sum(ev, red); ea = block_sum(ea, red);
+    const float nm1 = 1.f / (float)(rows > 1 ? rows - 1 : 1);
+    const float covv = cv * invn, covA = ca * invn;
+    const float denv = xv * nm1 + tv * nm1 + (mxv - mtv) * (mxv - mtv);
+    const float dena = xa * nm1 + ta * nm1 + (mxa - mta) * (mxa - mta);
+    const float cccv = 2.f * covv / denv, ccca = 2.f * covA / dena;
+    // pass 3: masked cross entropy on the first n_expr logits
+    float ce = 0.f, nvalid = 0.f, ncorrect = 0.f;
+    if (n_expr > 0) {
+        for (int i = tid; i < rows; i += nt) {
+            if (!valid[i]) continue;
+            const float* l = y + (size_t)i * C;
+            float m = l[0];
+            int am = 0;
+            for (int k = 1; k < n_expr; ++k)
+                if (l[k] > m) { m = l[k]; am = k; }
+            float se = 0.f;
+            for (int k = 0; k < n_expr; ++k) se += expf(l[k] - m);
+            const int lab = (int)cls[i];
+            ce += m + logf(se) - l[lab];
+            nvalid += 1.f;
+            ncorrect += (am == lab) ? 1.f : 0.f;
+        }
+        ce = block_sum(ce, red); nvalid = block_sum(nvalid, red); ncorrect = block_sum(ncorrect, red);
+    }
+    const float loss_e = ce * invn;
+    const bool use_e = n_expr > 0 && nvalid > 0.f;
+    const float lv = wv == 0.f ? 0.f : (use_mse ? ev * invn : 1.f - cccv);
+    const float la = wa == 0.f ? 0.f : (use_mse ? ea * invn : 1.f - ccca);
+    if (tid == 0) {
+        out[0] = wv * lv + wa * la + (use_e ? expr_w * loss_e : 0.f);
+        out[1] = lv; out[2] = la; out[3] = loss_e; out[4] = nvalid; out[5] = ncorrect; out[6] = cccv; out[7] = ccca;
+    }
+    // gradient
+    for (int i = tid; i < rows; i += nt) {
+        float* g = dy + (size_t)i * C;
+        const float* l = y + (size_t)i * C;
+        for (int k = 0; k < C; ++k) g[k] = 0.f;
+        if (use_e && valid[i]) {
+            float m = l[0];
+            for (int k = 1; k < n_expr; ++k) m = fmaxf(m, l[k]);
+            float se = 0.f;
+            for (int k = 0; k < n_expr; ++k) se += expf(l[k] - m);
+            const float sc = expr_w * invn;
+            const int lab = (int)cls[i];
+            for (int k = 0; k < n_expr; ++k) g[k] = sc * (expf(l[k] - m) / se - (k == lab ? 1.f : 0.f));
+        }
+        const float a = l[iv], b = val[i], c = l[ia], e = aro[i];
+        float gv, ga;
+        if (use_mse) {
+            gv = 2.f * (a - b) * invn;
+            ga = 2.f * (c - e) * invn;
+        } else {
+            const float dcv = 2.f * (b - mtv) * invn / denv -
+                              (2.f * covv / (denv * denv)) * (2.f * (a - mxv) * nm1 + 2.f * (mxv - mtv) * invn);
+            const float dca = 2.f * (e - mta) * invn / dena -
+                              (2.f * covA / (dena * dena)) * (2.f * (c - mxa) * nm1 + 2.f * (mxa - mta) * invn);
+            gv = -dcv;
+            ga = -dca;
+        }
+        if (wv != 0.f) g[iv] += wv * gv;
+        if (wa != 0.f) g[ia] += wa * ga;
+    }
+}
+
+// ------------------------------------------------------------------------------ DDP helpers
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, size_t n, float* __restrict__ part) {
+    __shared__ float red[16];
+    float s = 0.f;
+    const size_t n4 = n >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = g4[i];
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    if (blockIdx.x == 0)
+        for (size_t i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) s += g[i] * g[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void norm_scale_kernel(float* __restrict__ g, size_t n, const float* __restrict__ part,
+                                                         int nparts, float inv_world, float max_norm,
+                                                         float* __restrict__ norm_out) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += blockDim.x) s += part[i];
+    s = block_sum(s, red);
+    const float norm = sqrtf(s) * inv_world;            // norm of the averaged gradient
+    float coef = max_norm > 0.f ? max_norm / (norm + 1e-6f) : 1.f;   // max_norm <= 0: no clipping
+    coef = coef < 1.f ? coef : 1.f;
+    const float sc = inv_world * coef;
+    if (blockIdx.x == 0 && threadIdx.x == 0) norm_out[0] = norm;
+    if (sc == 1.f) return;
+    const size_t n4 = n >> 2;
+    float4* g4 = reinterpret_cast<float4*>(g);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 v = g4[i];
+        v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+        g4[i] = v;
+    }
+    if (blockIdx.x == 0)
+        for (size_t i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) g[i] *= sc;
+}
+
+}  // namespace
+
+extern "C" int m3t_att_fuse_fwd(const float* s_v, const float* s_a, const float* x_v, const float* x_a, float* f,
+                                int rows, int D, void* stream) {
+    if (rows <= 0 || D <= 0) return 0;
+    if (!s_v || !s_a || !x_v || !x_a || !f) return M3T_EINVAL;
+    const int vec = (D % 4 == 0) && (((uintptr_t)x_v | (uintptr_t)x_a | (uintptr_t)f) % 16 == 0);
+    att_fuse_fwd_kernel<<<cdiv(rows, 4), 256, 0, (hipStream_t)stream>>>(s_v, s_a, x_v, x_a, f, rows, D, vec);
+    M3T_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int m3t_att_fuse_bwd(const float* df, const float* s_v, const float* s_a, const float* x_v, const float* x_a,
+                                float* ds_v, float* ds_a, float* dx_v, float* dx_a, int rows, int D, void* stream) {
+    if (rows <= 0 || D <= 0) return 0;
+    if (!df || !s_v || !s_a || !x_v || !x_a || !ds_v || !ds_a || !dx_v || !dx_a) return M3T_EINVAL;
+    const int vec = (D % 4 == 0) &&
+                    (((uintptr_t)x_v | (uintptr_t)x_a | (uintptr_t)df | (uintptr_t)dx_v | (uintptr_t)dx_a) % 16 == 0);
+    att_fuse_bwd_kernel<<<cdiv(rows, 4), 256, 0, (hipStream_t)stream>>>(df, s_v, s_a, x_v, x_a, ds_v, ds_a, dx_v, dx_a,
+                                                                         rows, D, vec);
+    M3T_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int m3t_va_loss(const float* y_hat, int rows, int C, int iv, int ia, const float* valence,
+                           const float* arousal, const int64_t* class_expr, const uint8_t* expr_valid, int n_expr,
+                           float w_v, float w_a, float expr_w, int use_mse, float* out_scalars, float* dy,
+                           void* stream) {
+    if (rows <= 0 || C <= 0 || iv < 0 || ia < 0 || iv >= C || ia >= C || n_expr > C) return M3T_EINVAL;
+    if (!y_hat || !valence || !arousal || !out_scalars || !dy) return M3T_EINVAL;
+    if (n_expr > 0 && (!class_expr || !expr_valid)) return M3T_EINVAL;
+    va_loss_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(y_hat, rows, C, iv, ia, valence, arousal, class_expr, expr_valid,
+                                                        n_expr, w_v, w_a, expr_w, use_mse, out_scalars, dy);
+    M3T_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int m3t_grad_norm_scale(float* flat, size_t n, float inv_world, float max_norm, float* norm_out, float* ws,
+                                   size_t ws_bytes, void* stream) {
+    if (n == 0) return 0;
+    if (!flat || !norm_out || !ws || ((uintptr_t)flat % 16) != 0) return M3T_EINVAL;
+    int blocks = (int)((n / 4 + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    if (ws_bytes < (size_t)blocks * sizeof(float)) return M3T_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    sumsq_partial_kernel<<<blocks, 256, 0, s>>>(flat, n, ws);
+    M3T_LAUNCH_CHECK();
+    norm_scale_kernel<<<blocks, 256, 0, s>>>(flat, n, ws, blocks, inv_world, max_norm, norm_out);
+    M3T_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,362 @@
+// fp32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, bit-equal to
+// an fmaf chain, 256 FLOP/clk/CU).  128x128x16 block tile, 4 waves in 2x2, each wave a
+// 64x64 sub-tile = 2x2 MFMA tiles; operands staged k-major in LDS (row stride 132 floats:
+// conflict-free 32-lane fragment reads, 2-way (free) transposing writes); global loads
+// for tile k+1 are issued before the MFMAs of tile k (register prefetch, double LDS buffer).
+// Split-K goes through fp32 slabs + a fixed-order reduce: deterministic, no atomics.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16, LDT = 132;
+
+struct GemmParams {
+    const float* A; const float* B; float* C; const float* bias; float* ws;
+    int M, N, K, lda, ldb, ldc;
+    int act, accumulate, splits, kchunk;
+    int seg_len, seg_stride, a_off, b_off;
+    int vecA, vecB;
+};
+
+__device__ __forceinline__ int seg_row(int k, int seg_len, int seg_stride, int off) {
+    return seg_len > 0 ? (k / seg_len) * seg_stride + (k % seg_len) + off : k;
+}
+
+// Storage [rows][K] (K contiguous): thread loads 2 x float4 along K, LDS image is k-major.
+__device__ __forceinline__ void load_kc(const float* __restrict__ src, int ld, int rows, int row0,
+                                        int k0, int k_end, int vec, float4 (&r)[2]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = row0 + (tid >> 2) + 64 * i;
+        const int k = k0 + (tid & 3) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < rows) {
+            const float* p = src + (size_t)row * ld + k;
+            if (vec && k + 3 < k_end) {
+                v = *reinterpret_cast<const float4*>(p);
+            } else {
+                if (k + 0 < k_end) v.x = p[0];
+                if (k + 1 < k_end) v.y = p[1];
+                if (k + 2 < k_end) v.z = p[2];
+                if (k + 3 < k_end) v.w = p[3];
+            }
+        }
+        r[i] = v;
+    }
+}
+__device__ __forceinline__ void store_kc(float* __restrict__ S, const float4 (&r)[2]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (tid >> 2) + 64 * i;
+        const int kc = (tid & 3) * 4;
+        S[(kc + 0) * LDT + row] = r[i].x;
+        S[(kc + 1) * LDT + row] = r[i].y;
+        S[(kc + 2) * LDT + row] = r[i].z;
+        S[(kc + 3) * LDT + row] = r[i].w;
+    }
+}
+// Storage [K][cols] (cols contiguous): thread loads 2 x float4 along cols.
+__device__ __forceinline__ void load_mc(const float* __restrict__ src, int ld, int cols, int col0,
+                                        int k0, int k_end, int vec, int seg_len, int seg_stride, int off,
+                                        float4 (&r)[2]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int k = k0 + (tid >> 5) + 8 * i;
+        const int c = col0 + (tid & 31) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < k_end) {
+            const float* p = src + (size_t)seg_row(k, seg_len, seg_stride, off) * ld + c;
+            if (vec && c + 3 < cols) {
+                v = *reinterpret_cast<const float4*>(p);
+            } else {
+                if (c + 0 < cols) v.x = p[0];
+                if (c + 1 < cols) v.y = p[1];
+                if (c + 2 < cols) v.z = p[2];
+                if (c + 3 < cols) v.w = p[3];
+            }
+        }
+        r[i] = v;
+    }
+}
+__device__ __forceinline__ void store_mc(float* __restrict__ S, const float4 (&r)[2]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int kk = (tid >> 5) + 8 * i;
+        const int c = (tid & 31) * 4;
+        *reinterpret_cast<float4*>(&S[kk * LDT + c]) = r[i];
+    }
+}
+
+template <int TA, int TB>
+__global__ __launch_bounds__(256) void sgemm_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) float As[2][BK * LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDT];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int bm = blockIdx.y * BM, bn = blockIdx.x * BN;
+    const int k_begin = blockIdx.z * p.kchunk;
+    const int k_end = min(p.K, k_begin + p.kchunk);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[2], rb[2];
+    auto gload = [&](int k0) {
+        if (TA == 0) load_kc(p.A, p.lda, p.M, bm, k0, k_end, p.vecA, ra);
+        else load_mc(p.A, p.lda, p.M, bm, k0, k_end, p.vecA, p.seg_len, p.seg_stride, p.a_off, ra);
+        if (TB == 1) load_kc(p.B, p.ldb, p.N, bn, k0, k_end, p.vecB, rb);
+        else load_mc(p.B, p.ldb, p.N, bn, k0, k_end, p.vecB, p.seg_len, p.seg_stride, p.b_off, rb);
+    };
+    auto sstore = [&](int buf) {
+        if (TA == 0) store_kc(As[buf], ra); else store_mc(As[buf], ra);
+        if (TB == 1) store_kc(Bs[buf], rb); else store_mc(Bs[buf], rb);
+    };
+
+    const int ntiles = (k_end - k_begin + BK - 1) / BK;
+    if (ntiles > 0) {
+        gload(k_begin);
+        sstore(0);
+    }
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < ntiles) gload(k_begin + (t + 1) * BK);
+        const float* a_s = As[cur] + wm * 64 + l31;
+        const float* b_s = Bs[cur] + wn * 64 + l31;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const float a0 = a_s[(kk + hi) * LDT], a1 = a_s[(kk + hi) * LDT + 32];
+            const float b0 = b_s[(kk + hi) * LDT], b1 = b_s[(kk + hi) * LDT + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (t + 1 < ntiles) sstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const bool direct = p.splits == 1;
+    float* dst = direct ? p.C : p.ws + (size_t)blockIdx.z * p.M * p.N;
+    const int ldd = direct ? p.ldc : p.N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = bn + wn * 64 + j * 32 + l31;
+            if (col >= p.N) continue;
+            const float bv = (direct && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = bm + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (row >= p.M) continue;
+                float v = acc[i][j][r];
+                float* q = dst + (size_t)row * ldd + col;
+                if (direct) {
+                    v += bv;
+                    if (p.act == 1) v = fmaxf(v, 0.f);
+                    if (p.accumulate) v += *q;
+                }
+                *q = v;
+            }
+        }
+}
+
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, const float* __restrict__ bias,
+                                     int M, int N, int ldc, int splits, int act, int accumulate) {
+    const size_t total = (size_t)M * N;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / N), n = (int)(i % N);
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += ws[(size_t)k * total + i];
+        if (bias) s += bias[n];
+        if (act == 1) s = fmaxf(s, 0.f);
+        float* q = C + (size_t)m * ldc + n;
+        if (accumulate) s += *q;
+        *q = s;
+    }
+}
+
+__global__ void colsum_kernel(const float* __restrict__ X, int M, int N, int ld, float* __restrict__ out, int accumulate) {
+    // block = 256 threads = 32 columns x 8 row-lanes; fixed-order LDS tree over the 8 partials
+    __shared__ float red[8][33];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int rl = threadIdx.x >> 5;
+    float s = 0.f;
+    if (c < N)
+        for (int m = rl; m < M; m += 8) s += X[(size_t)m * ld + c];
+    red[rl][threadIdx.x & 31] = s;
+    __syncthreads();
+    if (rl == 0 && c < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += red[i][threadIdx.x & 31];
+        out[c] = accumulate ? out[c] + t : t;
+    }
+}
+
+// Two-stage column sum for tall matrices: stage 1 partial sums per row-chunk, stage 2 = colsum over partials.
+__global__ void colsum_partial_kernel(const float* __restrict__ X, int M, int N, int ld, float* __restrict__ part, int rows_per) {
+    __shared__ float red[8][33];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int rl = threadIdx.x >> 5;
+    const int m0 = blockIdx.y * rows_per, m1 = min(M, m0 + rows_per);
+    float s = 0.f;
+    if (c < N)
+        for (int m = m0 + rl; m < m1; m += 8) s += X[(size_t)m * ld + c];
+    red[rl][threadIdx.x & 31] = s;
+    __syncthreads();
+    if (rl == 0 && c < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += red[i][threadIdx.x & 31];
+        part[(size_t)blockIdx.y * N + c] = t;
+    }
+}
+
+__global__ void transpose_kernel(const float* __restrict__ src, int R, int C, int lds_, float* __restrict__ dst, int ldd) {
+    __shared__ float tile[32][33];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? src[(size_t)r * lds_ + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < C && r < R) dst[(size_t)c * ldd + r] = tile[tx][i];
+    }
+}
+
+__global__ void relu_bwd_kernel(const float* __restrict__ a, float* __restrict__ dy, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        if (!(a[i] > 0.f)) dy[i] = 0.f;
+}
+
+__global__ void mask_pos_kernel(const float* __restrict__ s, const float* __restrict__ dy, const float* __restrict__ mul,
+                                float* __restrict__ out, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = s[i] > 0.f ? (mul ? dy[i] * mul[i] : dy[i]) : 0.f;
+}
+
+}  // namespace
+
+extern "C" int m3t_sgemm(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                         float* C, int ldc, const float* bias, int act, int accumulate, int seg_len, int seg_stride,
+                         int a_off, int b_off, float* ws, size_t ws_bytes, void* stream) {
+    if (M <= 0 || N <= 0) return 0;
+    if (K < 0 || !A || !B || !C) return M3T_EINVAL;
+    if (seg_len > 0 && !(transA == 1 && transB == 0)) return M3T_EINVAL;
+    GemmParams p;
+    p.A = A; p.B = B; p.C = C; p.bias = bias; p.ws = ws;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.act = act; p.accumulate = accumulate;
+    p.seg_len = seg_len; p.seg_stride = seg_stride; p.a_off = a_off; p.b_off = b_off;
+    p.vecA = (lda % 4 == 0) && ((uintptr_t)A % 16 == 0);
+    p.vecB = (ldb % 4 == 0) && ((uintptr_t)B % 16 == 0);
+    const int tm = cdiv(M, BM), tn = cdiv(N, BN);
+    const int tiles = tm * tn;
+    int splits = 1;
+    if (ws && tiles < 192 && K >= 256) {
+        splits = 512 / tiles;
+        if (splits > K / 64) splits = K / 64;
+        const size_t cap = ws_bytes / ((size_t)M * N * sizeof(float));
+        if ((size_t)splits > cap) splits = (int)cap;
+        if (splits < 1) splits = 1;
+    }
+    int kchunk = cdiv(cdiv(K, splits), BK) * BK;
+    if (kchunk < BK) kchunk = BK;
+    splits = K > 0 ? cdiv(K, kchunk) : 1;
+    p.splits = splits; p.kchunk = kchunk;
+    dim3 grid(tn, tm, splits), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (transA == 0 && transB == 1) sgemm_kernel<0, 1><<<grid, block, 0, s>>>(p);
+    else if (transA == 0 && transB == 0) sgemm_kernel<0, 0><<<grid, block, 0, s>>>(p);
+    else if (transA == 1 && transB == 0) sgemm_kernel<1, 0><<<grid, block, 0, s>>>(p);
+    else sgemm_kernel<1, 1><<<grid, block, 0, s>>>(p);
+    M3T_LAUNCH_CHECK();
+    if (splits > 1) {
+        const size_t total = (size_t)M * N;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        splitk_reduce_kernel<<<blocks, 256, 0, s>>>(ws, C, bias, M, N, ldc, splits, act, accumulate);
+        M3T_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int m3t_colsum(const float* X, int M, int N, int ld, float* out, int accumulate, float* ws, size_t ws_bytes,
+                          void* stream) {
+    if (N <= 0) return 0;
+    if (!X || !out) return M3T_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    int chunks = cdiv(M, 128);
+    if (chunks > 128) chunks = 128;
+    if (!ws || ws_bytes < (size_t)chunks * N * sizeof(float) || chunks <= 1) {
+        colsum_kernel<<<cdiv(N, 32), 256, 0, s>>>(X, M, N, ld, out, accumulate);
+        M3T_LAUNCH_CHECK();
+        return 0;
+    }
+    // tall matrix: per-row-chunk partials, then a fixed-order sum of the partials
+    const int rows_per = cdiv(M, chunks);
+    colsum_partial_kernel<<<dim3(cdiv(N, 32), chunks), 256, 0, s>>>(X, M, N, ld, ws, rows_per);
+    M3T_LAUNCH_CHECK();
+    colsum_kernel<<<cdiv(N, 32), 256, 0, s>>>(ws, chunks, N, N, out, accumulate);
+    M3T_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int m3t_transpose(const float* src, int R, int C, int lds_, float* dst, int ldd, void* stream) {
+    if (R <= 0 || C <= 0) return 0;
+    transpose_kernel<<<dim3(cdiv(C, 32), cdiv(R, 32)), 256, 0, (hipStream_t)stream>>>(src, R, C, lds_, dst, ldd);
+    M3T_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int m3t_relu_bwd(const float* a, float* dy, size_t n, void* stream) {
+    if (n == 0) return 0;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    relu_bwd_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(a, dy, n);
+    M3T_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int m3t_mask_pos(const float* s, const float* dy, const float* mul, float* out, size_t n, void* stream) {
+    if (n == 0) return 0;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    mask_pos_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(s, dy, mul, out, n);
+    M3T_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int m3t_version(void) { return 1; }
+
+extern "C" int m3t_device_arch(char* arch, int cap) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) return (int)e;
+    if (arch && cap > 0) {
+        int i = 0;
+        for (; i < cap - 1 && prop.gcnArchName[i]; ++i) arch[i] = prop.gcnArchName[i];
+        arch[i] = 0;
+    }
+    return 0;
+}

@@ -1,0 +1,319 @@
+// TCN kernels (models/tcn.py) for gfx950, channel-last [B,T,C] activations.
+//   * weight-norm reparametrisation and its gradient (per-output-channel norms by one
+//     wavefront per channel);
+//   * the dilated causal convolution as an implicit GEMM on fp32 MFMA 32x32x2: the
+//     (b,t) rows are flattened to M = B*T; a workgroup stages rows [m0-halo, m0+128) of a
+//     16-channel slab ONCE in LDS (the dilated temporal receptive field) and every tap j
+//     reads its shifted window from that image -- no im2col, no chomp copy, no padded
+//     copy; taps that would cross t<0 (or a clip boundary) are masked per row;
+//     bias, ReLU and the residual add + ReLU of the block are fused in the epilogue;
+//   * the same kernel run anti-causally with the [co][ci] weight read as [K][N] is the
+//     data gradient; the weight gradient is K segment-mapped TN GEMMs (m3t_sgemm).
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16, LDB = 132;
+
+struct ConvParams {
+    const float* x; const float* w_t; const float* bias; const float* res; const float* mask; float* y; float* pre;
+    int B, T, Ci, Co, K, dil, act, anti, halo, lda, w_kn, vecx, vecw;
+};
+
+// dynamic LDS: As[BK][lda] (lda = BM + halo + pad), Bs[K][BK][LDB]
+template <int WKN>
+__global__ __launch_bounds__(256) void causal_conv_kernel(ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Bs = smem + BK * p.lda;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int M = p.B * p.T;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int halo = p.halo;
+    // LDS image row r (0 .. BM+halo-1) holds source row  m0 - halo + r  (causal)
+    //                                              or     m0 + r          (anti-causal)
+    const int src0 = p.anti ? m0 : m0 - halo;
+    const int nrows = BM + halo;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // per-lane time index of its two A-fragment rows
+    int trow[2];
+    bool mrow[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wm * 64 + i * 32 + l31;
+        mrow[i] = m < M;
+        trow[i] = m % p.T;
+    }
+
+    for (int c0 = 0; c0 < p.Ci; c0 += BK) {
+        // ---- stage x rows (transposed to k-major) ----
+        for (int idx = tid; idx < nrows * 4; idx += 256) {
+            const int r = idx >> 2, kc = (idx & 3) * 4;
+            const int m = src0 + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m >= 0 && m < M) {
+                const float* q = p.x + (size_t)m * p.Ci + c0 + kc;
+                const int nv = p.Ci - (c0 + kc);
+                if (p.vecx && nv >= 4) v = *reinterpret_cast<const float4*>(q);
+                else {
+                    if (nv > 0) v.x = q[0];
+                    if (nv > 1) v.y = q[1];
+                    if (nv > 2) v.z = q[2];
+                    if (nv > 3) v.w = q[3];
+                }
+            }
+            As[(kc + 0) * p.lda + r] = v.x;
+            As[(kc + 1) * p.lda + r] = v.y;
+            As[(kc + 2) * p.lda + r] = v.z;
+            As[(kc + 3) * p.lda + r] = v.w;
+        }
+        // ---- stage the K weight taps of this channel slab ----
+        for (int j = 0; j < p.K; ++j) {
+            float* Bj = Bs + j * BK * LDB;
+            if (WKN == 0) {
+                // w_t[j][n][ci]: K(=ci)-contiguous rows -> transpose into k-major
+                const float* wj = p.w_t + (size_t)j * p.Co * p.Ci;
+                for (int idx = tid; idx < BN * 4; idx += 256) {
+                    const int r = idx >> 2, kc = (idx & 3) * 4;
+                    const int n = n0 + r;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (n < p.Co) {
+                        const float* q = wj + (size_t)n * p.Ci + c0 + kc;
+                        const int nv = p.Ci - (c0 + kc);
+                        if (p.vecw && nv >= 4) v = *reinterpret_cast<const float4*>(q);
+                        else {
+                            if (nv > 0) v.x = q[0];
+                            if (nv > 1) v.y = q[1];
+                            if (nv > 2) v.z = q[2];
+                            if (nv > 3) v.w = q[3];
+                        }
+                    }
+                    Bj[(kc + 0) * LDB + r] = v.x;
+                    Bj[(kc + 1) * LDB + r] = v.y;
+                    Bj[(kc + 2) * LDB + r] = v.z;
+                    Bj[(kc + 3) * LDB + r] = v.w;
+                }
+            } else {
+                // data gradient: reduce over the weight's [co] rows, output its [ci] columns:
+                // w_t[j][k=co][n=ci] is N-contiguous.  Here p.Ci = #rows(co) and p.Co = #cols(ci).
+                const float* wj = p.w_t + (size_t)j * p.Ci * p.Co;
+                for (int idx = tid; idx < BK * 32; idx += 256) {
+                    const int kk = idx >> 5, c = (idx & 31) * 4;
+                    const int k = c0 + kk, n = n0 + c;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (k < p.Ci) {
+                        const float* q = wj + (size_t)k * p.Co + n;
+                        const int nv = p.Co - n;
+                        if (p.vecw && nv >= 4) v = *reinterpret_cast<const float4*>(q);
+                        else {
+                            if (nv > 0) v.x = q[0];
+                            if (nv > 1) v.y = q[1];
+                            if (nv > 2) v.z = q[2];
+                            if (nv > 3) v.w = q[3];
+                        }
+                    }
+                    *reinterpret_cast<float4*>(&Bj[kk * LDB + c]) = v;
+                }
+            }
+        }
+        __syncthreads();
+        for (int j = 0; j < p.K; ++j) {
+            const int sft = (p.K - 1 - j) * p.dil;
+            // image row of A-fragment row i for this tap
+            const int roff = p.anti ? sft : halo - sft;
+            bool ok[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) ok[i] = mrow[i] && (p.anti ? (trow[i] + sft < p.T) : (trow[i] >= sft));
+            const float* a_s = As + wm * 64 + l31 + roff;
+            const float* b_s = Bs + j * BK * LDB + wn * 64 + l31;
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 2) {
+                const float a0 = ok[0] ? a_s[(kk + hi) * p.lda] : 0.f;
+                const float a1 = ok[1] ? a_s[(kk + hi) * p.lda + 32] : 0.f;
+                const float b0 = b_s[(kk + hi) * LDB], b1 = b_s[(kk + hi) * LDB + 32];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + l31;
+            if (col >= p.Co) continue;
+            const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (row >= M) continue;
+                const size_t o = (size_t)row * p.Co + col;
+                float v = acc[i][j][r] + bv;
+                if (p.pre) p.pre[o] = v;
+                const float mk = p.mask ? p.mask[o] : 1.f;
+                if (p.act == 1) v = fmaxf(v, 0.f) * mk;
+                else if (p.act == 2) v = fmaxf(fmaxf(v, 0.f) * mk + p.res[o], 0.f);
+                else if (p.res) v += p.res[o];
+                p.y[o] = v;
+            }
+        }
+}
+
+// one wavefront per output channel: norm over (Ci,K); writes tap-major w_t[j][co][ci]
+__global__ __launch_bounds__(256) void weight_norm_fwd_kernel(const float* __restrict__ v, const float* __restrict__ g,
+                                                              float* __restrict__ w_t, float* __restrict__ norm, int Co,
+                                                              int Ci, int K) {
+    const int lane = threadIdx.x & 63;
+    const int co = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (co >= Co) return;
+    const float* vp = v + (size_t)co * Ci * K;
+    float s = 0.f;
+    for (int i = lane; i < Ci * K; i += 64) s += vp[i] * vp[i];
+    s = wave_sum(s);
+    const float nrm = sqrtf(s);
+    const float sc = g[co] / nrm;
+    if (lane == 0) norm[co] = nrm;
+    for (int i = lane; i < Ci * K; i += 64) {
+        const int ci = i / K, j = i % K;
+        w_t[((size_t)j * Co + co) * Ci + ci] = vp[i] * sc;
+    }
+}
+
+__global__ __launch_bounds__(256) void weight_norm_bwd_kernel(const float* __restrict__ dw_t, const float* __restrict__ v,
+                                                              const float* __restrict__ g, const float* __restrict__ norm,
+                                                              float* __restrict__ dv, float* __restrict__ dg, int Co, int Ci,
+                                                              int K) {
+    const int lane = threadIdx.x & 63;
+    const int co = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (co >= Co) return;
+    const float* vp = v + (size_t)co * Ci * K;
+    float dot = 0.f;
+    for (int i = lane; i < Ci * K; i += 64) {
+        const int ci = i / K, j = i % K;
+        dot += dw_t[((size_t)j * Co + co) * Ci + ci] * vp[i];
+    }
+    dot = wave_sum(dot);
+    const float nrm = norm[co], gg = g[co];
+    if (lane == 0) dg[co] = dot / nrm;
+    const float a = gg / nrm, b = dot / (nrm * nrm);
+    for (int i = lane; i < Ci * K; i += 64) {
+        const int ci = i / K, j = i % K;
+        dv[(size_t)co * Ci * K + i] = a * (dw_t[((size_t)j * Co + co) * Ci + ci] - vp[i] * b);
+    }
+}
+
+// batched [R][C] -> [C][R] through a padded LDS tile (both sides coalesced)
+__global__ __launch_bounds__(256) void batched_transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int R,
+                                                                int C) {
+    __shared__ float tile[32][33];
+    const size_t boff = (size_t)blockIdx.z * R * C;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? src[boff + (size_t)r * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < C && r < R) dst[boff + (size_t)c * R + r] = tile[tx][i];
+    }
+}
+
+}  // namespace
+
+extern "C" int m3t_weight_norm_fwd(const float* v, const float* g, float* w_t, float* norm, int Co, int Ci, int K,
+                                   void* stream) {
+    if (Co <= 0 || Ci <= 0 || K <= 0 || !v || !g || !w_t || !norm) return M3T_EINVAL;
+    weight_norm_fwd_kernel<<<cdiv(Co, 4), 256, 0, (hipStream_t)stream>>>(v, g, w_t, norm, Co, Ci, K);
+    M3T_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int m3t_weight_norm_bwd(const float* dw_t, const float* v, const float* g, const float* norm, float* dv,
+                                   float* dg, int Co, int Ci, int K, void* stream) {
+    if (Co <= 0 || Ci <= 0 || K <= 0 || !dw_t || !v || !g || !norm || !dv || !dg) return M3T_EINVAL;
+    weight_norm_bwd_kernel<<<cdiv(Co, 4), 256, 0, (hipStream_t)stream>>>(dw_t, v, g, norm, dv, dg, Co, Ci, K);
+    M3T_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int m3t_causal_conv_fwd(const float* x, const float* w_t, const float* bias, const float* res,
+                                   const float* drop_mask, float* y, float* pre, int B, int T, int Ci, int Co, int K,
+                                   int dilation, int act, int anticausal, void* stream) {
+    if (B <= 0 || T <= 0) return 0;
+    if (Ci <= 0 || Co <= 0 || K <= 0 || dilation <= 0 || !x || !w_t || !y) return M3T_EINVAL;
+    if (act == 2 && !res) return M3T_EINVAL;
+    ConvParams p;
+    p.x = x; p.w_t = w_t; p.bias = bias; p.res = res; p.mask = drop_mask; p.y = y; p.pre = pre;
+    p.B = B; p.T = T; p.Ci = Ci; p.Co = Co; p.K = K; p.dil = dilation; p.act = act; p.anti = anticausal;
+    const int halo = (K - 1) * dilation;
+    p.halo = halo;
+    p.lda = ((BM + halo - 4 + 31) / 32) * 32 + 4;   // == 4 (mod 32): 2-way (free) transposing LDS writes
+    p.vecx = (Ci % 4 == 0) && ((uintptr_t)x % 16 == 0);
+    p.w_kn = anticausal ? 1 : 0;
+    p.vecw = anticausal ? ((Co % 4 == 0) && ((uintptr_t)w_t % 16 == 0)) : ((Ci % 4 == 0) && ((uintptr_t)w_t % 16 == 0));
+    const size_t lds = ((size_t)BK * p.lda + (size_t)K * BK * LDB) * sizeof(float);
+    if (lds > 160 * 1024) return M3T_EINVAL;
+    dim3 grid(cdiv(Co, BN), cdiv(B * T, BM));
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e;
+    if (anticausal) {
+        e = hipFuncSetAttribute((const void*)causal_conv_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        causal_conv_kernel<1><<<grid, 256, lds, s>>>(p);
+    } else {
+        e = hipFuncSetAttribute((const void*)causal_conv_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        causal_conv_kernel<0><<<grid, 256, lds, s>>>(p);
+    }
+    M3T_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int m3t_causal_conv_wgrad(const float* dy, const float* x, float* dw_t, int B, int T, int Ci, int Co, int K,
+                                     int dilation, float* ws, size_t ws_bytes, void* stream) {
+    if (Ci <= 0 || Co <= 0 || K <= 0 || !dy || !x || !dw_t) return M3T_EINVAL;
+    for (int j = 0; j < K; ++j) {
+        const int sft = (K - 1 - j) * dilation;
+        float* out = dw_t + (size_t)j * Co * Ci;
+        if (sft >= T) {
+            hipError_t e = hipMemsetAsync(out, 0, (size_t)Co * Ci * sizeof(float), (hipStream_t)stream);
+            if (e != hipSuccess) return (int)e;
+            continue;
+        }
+        // dw_t[j][co][ci] = sum_b sum_{t>=sft} dy[b,t,co] * x[b,t-sft,ci]
+        const int rc = m3t_sgemm(1, 0, Co, Ci, B * (T - sft), dy, Co, x, Ci, out, Ci, nullptr, 0, 0, T - sft, T, sft, 0,
+                                 ws, ws_bytes, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+extern "C" int m3t_bct_to_btc(const float* src, float* dst, int B, int C, int T, void* stream) {
+    if (B <= 0 || C <= 0 || T <= 0) return 0;
+    batched_transpose_kernel<<<dim3(cdiv(T, 32), cdiv(C, 32), B), 256, 0, (hipStream_t)stream>>>(src, dst, C, T);
+    M3T_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int m3t_btc_to_bct(const float* src, float* dst, int B, int T, int C, void* stream) {
+    if (B <= 0 || C <= 0 || T <= 0) return 0;
+    batched_transpose_kernel<<<dim3(cdiv(C, 32), cdiv(T, 32), B), 256, 0, (hipStream_t)stream>>>(src, dst, T, C);
+    M3T_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,83 @@
+"""ctypes binding of libm3t_hip.so -- the exact C ABI declared in include/m3t_hip.h."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libm3t_hip.so")
+CSRC_DIR = os.path.join(os.path.dirname(_HERE), "csrc")
+
+M3T_EINVAL = 10001
+M3T_MAX_SCANS = 8
+
+_f = C.c_void_p      # device pointer
+_i = C.c_int
+_z = C.c_size_t
+_s = C.c_void_p      # hipStream_t
+
+
+class GruFwdDesc(C.Structure):
+    _fields_ = [("xproj", _f), ("w_hh", _f), ("b_hh", _f), ("out", _f), ("gates", _f), ("h_n", _f),
+                ("H", _i), ("reverse", _i), ("ldx", _i), ("xoff", _i), ("ldo", _i), ("ooff", _i)]
+
+
+class GruBwdDesc(C.Structure):
+    _fields_ = [("dout", _f), ("out", _f), ("gates", _f), ("w_hh_t", _f), ("dh_n", _f),
+                ("dgx", _f), ("dgh", _f), ("dh", _f),
+                ("H", _i), ("reverse", _i), ("ldo", _i), ("ooff", _i), ("ldg", _i), ("goff", _i)]
+
+
+# name -> argtypes; the test-suite checks that every symbol of include/m3t_hip.h is here and exported.
+SIGNATURES = {
+    "m3t_version": [],
+    "m3t_device_arch": [C.c_char_p, _i],
+    "m3t_sgemm": [_i, _i, _i, _i, _i, _f, _i, _f, _i, _f, _i, _f, _i, _i, _i, _i, _i, _i, _f, _z, _s],
+    "m3t_colsum": [_f, _i, _i, _i, _f, _i, _f, _z, _s],
+    "m3t_transpose": [_f, _i, _i, _i, _f, _i, _s],
+    "m3t_relu_bwd": [_f, _f, _z, _s],
+    "m3t_gru_scan_fwd": [C.POINTER(GruFwdDesc), _i, _i, _i, _s],
+    "m3t_gru_scan_bwd": [C.POINTER(GruBwdDesc), _i, _i, _i, _s],
+    "m3t_att_fuse_fwd": [_f, _f, _f, _f, _f, _i, _i, _s],
+    "m3t_att_fuse_bwd": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _s],
+    "m3t_va_loss": [_f, _i, _i, _i, _i, _f, _f, _f, _f, _i, C.c_float, C.c_float, C.c_float, _i, _f, _f, _s],
+    "m3t_weight_norm_fwd": [_f, _f, _f, _f, _i, _i, _i, _s],
+    "m3t_weight_norm_bwd": [_f, _f, _f, _f, _f, _f, _i, _i, _i, _s],
+    "m3t_causal_conv_fwd": [_f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _s],
+    "m3t_causal_conv_wgrad": [_f, _f, _f, _i, _i, _i, _i, _i, _i, _f, _z, _s],
+    "m3t_bct_to_btc": [_f, _f, _i, _i, _i, _s],
+    "m3t_btc_to_bct": [_f, _f, _i, _i, _i, _s],
+    "m3t_mask_pos": [_f, _f, _f, _f, _z, _s],
+    "m3t_cbam_channel_fwd": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _s],
+    "m3t_cbam_channel_bwd": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _f, _z, _s],
+    "m3t_cbam_spatial_fwd": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, C.c_float, C.c_float, _f, _z, _s],
+    "m3t_cbam_spatial_bwd": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _z, _s],
+    "m3t_grad_norm_scale": [_f, _z, C.c_float, C.c_float, _f, _f, _z, _s],
+}
+
+_lib = None
+
+
+class M3THipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libm3t_hip.so.  Fails loudly: there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise M3THipError(
+            "libm3t_hip.so not found at %s -- build it with `make -C %s` (or __graft_entry__.build()). "
+            "The M3T hot path has no CPU/eager fallback." % (LIB_PATH, CSRC_DIR))
+    lib = C.CDLL(LIB_PATH)
+    for name, argt in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = ABI mismatch: loud by design
+        fn.argtypes = argt
+        fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise M3THipError("%s failed with code %d%s" % (what, rc, " (M3T_EINVAL: bad arguments)" if rc == M3T_EINVAL else " (hipError_t)"))

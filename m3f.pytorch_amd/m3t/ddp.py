@@ -1,0 +1,94 @@
+"""Clip-level data parallelism: one process per GPU, RCCL all-reduce of ONE flat fp32 gradient
+buffer over xGMI, then the global-norm clip -- what the reference gets from Lightning's
+`distributed_backend='ddp'` + `gradient_clip_val=1.0` (reference train.py:32-41) and
+`DistributedSampler` (reference models/model.py:416-418).
+
+Design: parameters' .grad tensors are VIEWS into one contiguous buffer, so
+the ~100 small gradient tensors of the AV graph cost one (or a few, bucketed) collectives
+instead of one each; buckets follow the order in which backward finishes sub-modules, and each
+bucket's all-reduce is issued from a post-accumulate hook so it overlaps the rest of backward;
+the 1/world scaling and the clip coefficient are applied by one fused HIP pass
+(m3t_grad_norm_scale).  There is no other collective on the path (no SyncBN, as the reference).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_indices(n_items, rank, world_size):
+    """DistributedSampler(shuffle=False) semantics: pad to a multiple of world_size by wrapping,
+    then rank r takes indices r, r+world, ..."""
+    idx = list(range(n_items))
+    total = ((n_items + world_size - 1) // world_size) * world_size
+    idx += idx[: total - n_items]
+    return idx[rank:total:world_size]
+
+
+class FlatGradDDP:
+    def __init__(self, module, bucket_order=None, max_norm=1.0, process_group=None, finalize=None):
+        """bucket_order: list of lists of parameters, in the order backward completes them
+        (default: one bucket per top-level child, reversed registration order).
+        finalize(flat, world_size, max_norm) -> norm tensor; default = fused HIP kernel."""
+        self.module = module
+        self.max_norm = max_norm
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        params = [p for p in module.parameters() if p.requires_grad]
+        if bucket_order is None:
+            seen, bucket_order = set(), []
+            for child in reversed(list(module.children())):
+                b = [p for p in child.parameters() if p.requires_grad and id(p) not in seen]
+                seen.update(id(p) for p in b)
+                if b:
+                    bucket_order.append(b)
+            rest = [p for p in params if id(p) not in seen]
+            if rest:
+                bucket_order.append(rest)
+        self.buckets = bucket_order
+        n = sum(p.numel() for b in self.buckets for p in b)
+        assert n == sum(p.numel() for p in params), "buckets must cover every trainable parameter exactly once"
+        dev = params[0].device
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.ranges, off = [], 0
+        self._pending = []
+        for bi, b in enumerate(self.buckets):
+            start = off
+            for p in b:
+                p.grad = self.flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+            self.ranges.append((start, off))
+        self._left = [0] * len(self.buckets)
+        self._handles = []
+        if self.world > 1:
+            for bi, b in enumerate(self.buckets):
+                for p in b:
+                    p.register_post_accumulate_grad_hook(self._make_hook(bi))
+        if finalize is None:
+            from . import ops
+            finalize = ops.grad_norm_scale_
+        self._finalize = finalize
+        self.last_norm = None
+
+    def _make_hook(self, bi):
+        def hook(_p):
+            self._left[bi] -= 1
+            if self._left[bi] == 0:
+                s, e = self.ranges[bi]
+                self._handles.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        return hook
+
+    def zero_grad(self):
+        self.flat.zero_()
+        self._left = [len(b) for b in self.buckets]
+        self._handles = []
+
+    def finish(self):
+        """Call after backward: waits for the bucket all-reduces, then averages + clips in place."""
+        if self.world > 1:
+            for bi, left in enumerate(self._left):      # parameters that received no gradient this step
+                if left > 0:
+                    s, e = self.ranges[bi]
+                    self._handles.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            for h in self._handles:
+                h.wait()
+        self.last_norm = self._finalize(self.flat, self.world, self.max_norm)
+        return self.last_norm

@@ -1,0 +1,622 @@
+"""torch.autograd Functions over the C ABI of libm3t_hip.so.
+
+torch is plumbing here: device memory (caching allocator), the current HIP stream and
+autograd bookkeeping.  All arithmetic of the hot path happens in the HIP library; there
+is no CPU or eager fallback -- a CPU tensor or a missing library raises.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import GruFwdDesc, GruBwdDesc, M3T_MAX_SCANS, M3THipError
+
+_WS = {}
+_WS_MIN = 64 << 20
+
+# Optional launch-stream timing (bench.py): when PROFILE_ON[0] is set, every scan / GEMM call is
+# bracketed by HIP events on the stream the kernels are launched on.
+PROFILE = []
+PROFILE_ON = [False]
+
+
+class _Timed:
+    def __init__(self, kernel, launches, flops):
+        self.rec = None
+        if PROFILE_ON[0]:
+            self.rec = {"kernel": kernel, "launches": launches, "flops": float(flops),
+                        "start": torch.cuda.Event(enable_timing=True), "end": torch.cuda.Event(enable_timing=True)}
+
+    def __enter__(self):
+        if self.rec is not None:
+            self.rec["start"].record(torch.cuda.current_stream())
+        return self
+
+    def __exit__(self, *exc):
+        if self.rec is not None:
+            self.rec["end"].record(torch.cuda.current_stream())
+            PROFILE.append(self.rec)
+        return False
+
+
+def lib():
+    return _lib.load()
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(t, name="tensor"):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise M3THipError("%s must be a device (HIP) tensor: the M3T hot path has no CPU fallback" % name)
+    if t.dtype != torch.float32:
+        raise M3THipError("%s must be float32, got %s" % (name, t.dtype))
+    if not t.is_contiguous():
+        raise M3THipError("%s must be contiguous" % name)
+    return t
+
+
+def _p(t, off=0):
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr() + 4 * off)
+
+
+def workspace(device, nbytes=_WS_MIN):
+    """Per-device scratch for split-K slabs / partial sums.  All users run on the current
+    stream, so stream order serialises reuse."""
+    key = (device.type, device.index)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty(max(nbytes, _WS_MIN) // 4, dtype=torch.float32, device=device)
+        _WS[key] = ws
+    return ws
+
+
+# ----------------------------------------------------------------------------- raw wrappers
+def sgemm(transA, transB, M, N, K, A, a_off, lda, B, b_off, ldb, Cm, c_off, ldc, bias=None, act=0,
+          accumulate=False, seg=(0, 0, 0, 0), use_ws=True):
+    ws = workspace(Cm.device) if use_ws else None
+    with _Timed("sgemm_kernel", 1, 2.0 * M * N * K):
+        rc = lib().m3t_sgemm(transA, transB, M, N, K, _p(A, a_off), lda, _p(B, b_off), ldb, _p(Cm, c_off), ldc,
+                             _p(bias), act, int(accumulate), seg[0], seg[1], seg[2], seg[3],
+                             _p(ws), (ws.numel() * 4) if ws is not None else 0, _stream())
+    _lib.check(rc, "m3t_sgemm")
+
+
+def colsum(X, x_off, M, N, ld, out, accumulate=False):
+    ws = workspace(out.device)
+    rc = lib().m3t_colsum(_p(X, x_off), M, N, ld, _p(out), int(accumulate), _p(ws), ws.numel() * 4, _stream())
+    _lib.check(rc, "m3t_colsum")
+
+
+def transpose2d(src):
+    R, Cc = src.shape
+    dst = torch.empty(Cc, R, dtype=src.dtype, device=src.device)
+    _lib.check(lib().m3t_transpose(_p(src), R, Cc, Cc, _p(dst), R, _stream()), "m3t_transpose")
+    return dst
+
+
+def mask_pos(s, dy, mul=None):
+    out = torch.empty_like(dy)
+    _lib.check(lib().m3t_mask_pos(_p(s), _p(dy), _p(mul), _p(out), dy.numel(), _stream()), "m3t_mask_pos")
+    return out
+
+
+# ----------------------------------------------------------------------------- Linear
+class _Linear(torch.autograd.Function):
+    """y = act(x W^T + b) on the fp32-MFMA GEMM; replaces nn.Linear (+ReLU) call sites
+    (reference models/rnn.py:22-55, models/model.py:88, models/att_fusion.py:13)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act):
+        x = _req(x.contiguous(), "x"); _req(w, "weight")
+        K = x.shape[-1]
+        N = w.shape[0]
+        M = x.numel() // K
+        y = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
+        sgemm(0, 1, M, N, K, x, 0, K, w, 0, K, y, 0, N, bias=b, act=act)
+        ctx.save_for_backward(x, w, y if act else None)
+        ctx.act, ctx.has_bias = act, b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        dy = _req(dy.contiguous(), "dy")
+        if ctx.act:
+            dy = mask_pos(y, dy)
+        K, N = x.shape[-1], w.shape[0]
+        M = x.numel() // K
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            sgemm(0, 0, M, K, N, dy, 0, N, w, 0, K, dx, 0, K)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            sgemm(1, 0, N, K, M, dy, 0, N, x, 0, K, dw, 0, K)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(N, dtype=x.dtype, device=x.device)
+            colsum(dy, 0, M, N, N, db)
+        return dx, dw, db, None
+
+
+def linear(x, w, b=None, act=0):
+    return _Linear.apply(x, w, b, act)
+
+
+# ----------------------------------------------------------------------------- BiGRU
+def _scan_fwd(descs, B, T):
+    for i in range(0, len(descs), M3T_MAX_SCANS):
+        chunk = descs[i:i + M3T_MAX_SCANS]
+        arr = (GruFwdDesc * len(chunk))(*chunk)
+        flops = (T - 1) * sum(2.0 * B * 3 * d.H * d.H for d in chunk)
+        with _Timed("gru_step_fwd_kernel", T, flops):
+            rc = lib().m3t_gru_scan_fwd(arr, len(chunk), B, T, _stream())
+        _lib.check(rc, "m3t_gru_scan_fwd")
+
+
+def _scan_bwd(descs, B, T):
+    for i in range(0, len(descs), M3T_MAX_SCANS):
+        chunk = descs[i:i + M3T_MAX_SCANS]
+        arr = (GruBwdDesc * len(chunk))(*chunk)
+        flops = (T - 1) * sum(2.0 * B * 3 * d.H * d.H for d in chunk)
+        with _Timed("gru_step_bwd_kernel", T, flops):
+            rc = lib().m3t_gru_scan_bwd(arr, len(chunk), B, T, _stream())
+        _lib.check(rc, "m3t_gru_scan_bwd")
+
+
+def _vp(t, off=0):
+    return t.data_ptr() + 4 * off if t is not None else None
+
+
+class _MultiBiGRU(torch.autograd.Function):
+    """Several independent stacked bidirectional GRUs (same B, T, depth) advanced together:
+    per layer, one input-projection GEMM per direction, then ONE grouped scan over every
+    (stack, direction).  Replaces nn.GRU(batch_first=True, bidirectional=True) at reference
+    models/rnn.py:17,75 (and its autograd).  tensors = per stack: x, then per layer, per
+    direction: w_ih, w_hh, b_ih, b_hh.  Returns per stack: out [B,T,2H], h_n [2L,B,H]."""
+
+    @staticmethod
+    def forward(ctx, n_stacks, L, *tensors):
+        per = 1 + 8 * L
+        assert len(tensors) == n_stacks * per
+        xs, params = [], []
+        for s in range(n_stacks):
+            xs.append(_req(tensors[s * per].contiguous(), "x"))
+            params.append([_req(t, "gru parameter") for t in tensors[s * per + 1:(s + 1) * per]])
+        B, T = xs[0].shape[0], xs[0].shape[1]
+        dev = xs[0].device
+        Hs = [params[s][1].shape[1] for s in range(n_stacks)]
+        saved = []       # per layer, per stack: out, gates (inputs of layer 0 are the x's)
+        h_ns = [torch.empty(2 * L, B, Hs[s], dtype=torch.float32, device=dev) for s in range(n_stacks)]
+        inps = xs
+        for l in range(L):
+            descs, outs, keep = [], [], []
+            for s in range(n_stacks):
+                H, inp = Hs[s], inps[s]
+                if inp.shape[0] != B or inp.shape[1] != T:
+                    raise M3THipError("grouped GRU stacks must share batch and length")
+                I = inp.shape[-1]
+                xproj = torch.empty(B, T, 6 * H, dtype=torch.float32, device=dev)
+                out = torch.empty(B, T, 2 * H, dtype=torch.float32, device=dev)
+                gates = torch.empty(2, B, T, 4 * H, dtype=torch.float32, device=dev)
+                for d in (0, 1):
+                    w_ih, w_hh, b_ih, b_hh = params[s][(2 * l + d) * 4:(2 * l + d) * 4 + 4]
+                    sgemm(0, 1, B * T, 3 * H, I, inp, 0, I, w_ih, 0, I, xproj, d * 3 * H, 6 * H, bias=b_ih, use_ws=False)
+                    descs.append(GruFwdDesc(_vp(xproj), _vp(w_hh), _vp(b_hh), _vp(out), _vp(gates, d * B * T * 4 * H),
+                                            _vp(h_ns[s], (2 * l + d) * B * H), H, d, 6 * H, d * 3 * H, 2 * H, d * H))
+                saved += [out, gates]
+                outs.append(out)
+                keep.append(xproj)     # must outlive the scan enqueue (stream-ordered allocator reuse)
+            _scan_fwd(descs, B, T)
+            del keep
+            inps = outs
+        ctx.n_stacks, ctx.L, ctx.Hs, ctx.B, ctx.T = n_stacks, L, Hs, B, T
+        ctx.save_for_backward(*(list(tensors) + saved))
+        result = []
+        for s in range(n_stacks):
+            result += [inps[s], h_ns[s]]
+        return tuple(result)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        n_stacks, L, Hs, B, T = ctx.n_stacks, ctx.L, ctx.Hs, ctx.B, ctx.T
+        per = 1 + 8 * L
+        st = ctx.saved_tensors
+        tensors, acts = st[:n_stacks * per], st[n_stacks * per:]
+        params = [list(tensors[s * per + 1:(s + 1) * per]) for s in range(n_stacks)]
+        xs = [tensors[s * per].contiguous() for s in range(n_stacks)]
+
+        def layer_io(l, s):   # (input, out, gates) of stack s at layer l
+            out, gates = acts[(l * n_stacks + s) * 2], acts[(l * n_stacks + s) * 2 + 1]
+            inp = xs[s] if l == 0 else acts[((l - 1) * n_stacks + s) * 2]
+            return inp, out, gates
+
+        dev = params[0][0].device
+        out_grads = [None] * (n_stacks * per)
+        douts, dhns = [], []
+        for s in range(n_stacks):
+            g, gh = grads[2 * s], grads[2 * s + 1]
+            douts.append(torch.zeros(B, T, 2 * Hs[s], dtype=torch.float32, device=dev) if g is None
+                         else _req(g.contiguous(), "dout"))
+            dhns.append(None if gh is None else _req(gh.contiguous(), "dh_n"))
+        for l in range(L - 1, -1, -1):
+            descs, work = [], []
+            for s in range(n_stacks):
+                H = Hs[s]
+                inp, out, gates = layer_io(l, s)
+                dgx = torch.empty(B, T, 6 * H, dtype=torch.float32, device=dev)
+                dgh = torch.empty(2, B, T, 3 * H, dtype=torch.float32, device=dev)
+                dh = torch.empty(2, B, H, dtype=torch.float32, device=dev)
+                whts = []
+                for d in (0, 1):
+                    w_hh = params[s][(2 * l + d) * 4 + 1]
+                    wht = transpose2d(w_hh)
+                    whts.append(wht)
+                    descs.append(GruBwdDesc(_vp(douts[s]), _vp(out), _vp(gates, d * B * T * 4 * H), _vp(wht),
+                                            _vp(dhns[s], (2 * l + d) * B * H) if dhns[s] is not None else None,
+                                            _vp(dgx), _vp(dgh, d * B * T * 3 * H), _vp(dh, d * B * H),
+                                            H, d, 2 * H, d * H, 6 * H, d * 3 * H))
+                work.append((inp, out, dgx, dgh, dh, whts))
+            _scan_bwd(descs, B, T)
+            new_douts = []
+            for s in range(n_stacks):
+                H = Hs[s]
+                inp, out, dgx, dgh, dh, whts = work[s]
+                I = inp.shape[-1]
+                base = s * per + 1 + (2 * l) * 4
+                for d in (0, 1):
+                    w_ih, w_hh = params[s][(2 * l + d) * 4], params[s][(2 * l + d) * 4 + 1]
+                    dw_ih, dw_hh = torch.empty_like(w_ih), torch.empty_like(w_hh)
+                    db_ih = torch.empty(3 * H, dtype=torch.float32, device=dev)
+                    db_hh = torch.empty(3 * H, dtype=torch.float32, device=dev)
+                    goff = d * B * T * 3 * H
+                    if T > 1:
+                        # dW_hh = sum_{b,t} dgh[b,t]^T h_{prev}(b,t): forward pairs (t, t-1), reverse pairs (t, t+1)
+                        a_off, b_off = (1, 0) if d == 0 else (0, 1)
+                        sgemm(1, 0, 3 * H, H, B * (T - 1), dgh, goff, 3 * H, out, d * H, 2 * H, dw_hh, 0, H,
+                              seg=(T - 1, T, a_off, b_off))
+                    else:
+                        dw_hh.zero_()
+                    colsum(dgh, goff, B * T, 3 * H, 3 * H, db_hh)
+                    sgemm(1, 0, 3 * H, I, B * T, dgx, d * 3 * H, 6 * H, inp, 0, I, dw_ih, 0, I)
+                    colsum(dgx, d * 3 * H, B * T, 3 * H, 6 * H, db_ih)
+                    out_grads[base + d * 4: base + d * 4 + 4] = [dw_ih, dw_hh, db_ih, db_hh]
+                need_dx = l > 0 or ctx.needs_input_grad[2 + s * per]
+                if need_dx:
+                    dinp = torch.empty_like(inp)
+                    for d in (0, 1):
+                        w_ih = params[s][(2 * l + d) * 4]
+                        sgemm(0, 0, B * T, I, 3 * H, dgx, d * 3 * H, 6 * H, w_ih, 0, I, dinp, 0, I,
+                              accumulate=(d == 1), use_ws=False)
+                    new_douts.append(dinp)
+                else:
+                    new_douts.append(None)
+            douts = new_douts     # (grads wrt h_n of lower layers are picked by index inside the descs)
+        for s in range(n_stacks):
+            out_grads[s * per] = douts[s]
+        return (None, None) + tuple(out_grads)
+
+
+def multi_bigru(stacks):
+    """stacks: list of (x [B,T,I], flat_params [w_ih,w_hh,b_ih,b_hh per (layer,dir)], L).
+    Returns list of (out [B,T,2H], h_n [2L,B,H])."""
+    L = stacks[0][2]
+    flat = []
+    for x, prm, l in stacks:
+        if l != L:
+            raise M3THipError("grouped GRU stacks must have the same depth")
+        flat.append(x)
+        flat.extend(prm)
+    res = _MultiBiGRU.apply(len(stacks), L, *flat)
+    return [(res[2 * i], res[2 * i + 1]) for i in range(len(stacks))]
+
+
+# ----------------------------------------------------------------------------- AttFusion reduction
+class _AttFuse(torch.autograd.Function):
+    """softmax([sigmoid(s_v), sigmoid(s_a)]) weighted sum (reference models/att_fusion.py:21-25)."""
+
+    @staticmethod
+    def forward(ctx, s_v, s_a, x_v, x_a):
+        s_v, s_a = _req(s_v.contiguous(), "s_v"), _req(s_a.contiguous(), "s_a")
+        x_v, x_a = _req(x_v.contiguous(), "x_v"), _req(x_a.contiguous(), "x_a")
+        D = x_v.shape[-1]
+        rows = x_v.numel() // D
+        if x_a.shape != x_v.shape or s_v.numel() != rows or s_a.numel() != rows:
+            raise M3THipError("att_fuse: shape mismatch")
+        f = torch.empty_like(x_v)
+        _lib.check(lib().m3t_att_fuse_fwd(_p(s_v), _p(s_a), _p(x_v), _p(x_a), _p(f), rows, D, _stream()), "m3t_att_fuse_fwd")
+        ctx.save_for_backward(s_v, s_a, x_v, x_a)
+        return f
+
+    @staticmethod
+    def backward(ctx, df):
+        s_v, s_a, x_v, x_a = ctx.saved_tensors
+        df = _req(df.contiguous(), "df")
+        D = x_v.shape[-1]
+        rows = x_v.numel() // D
+        ds_v, ds_a = torch.empty_like(s_v), torch.empty_like(s_a)
+        dx_v, dx_a = torch.empty_like(x_v), torch.empty_like(x_a)
+        _lib.check(lib().m3t_att_fuse_bwd(_p(df), _p(s_v), _p(s_a), _p(x_v), _p(x_a), _p(ds_v), _p(ds_a), _p(dx_v),
+                                          _p(dx_a), rows, D, _stream()), "m3t_att_fuse_bwd")
+        return ds_v, ds_a, dx_v, dx_a
+
+
+def att_fuse(s_v, s_a, x_v, x_a):
+    return _AttFuse.apply(s_v, s_a, x_v, x_a)
+
+
+# ----------------------------------------------------------------------------- VA loss
+class _VALoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y_hat, valence, arousal, class_expr, expr_valid, iv, ia, n_expr, w_v, w_a, expr_w, use_mse):
+        y = _req(y_hat.contiguous(), "y_hat")
+        Cc = y.shape[-1]
+        rows = y.numel() // Cc
+        val = _req(valence.contiguous().float(), "valence")
+        aro = _req(arousal.contiguous().float(), "arousal")
+        cls = vld = None
+        if n_expr > 0:
+            cls = class_expr.contiguous().long()
+            vld = expr_valid.contiguous().to(torch.uint8)
+            if not cls.is_cuda or not vld.is_cuda:
+                raise M3THipError("labels must be device tensors")
+        stats = torch.empty(8, dtype=torch.float32, device=y.device)
+        dy = torch.empty_like(y)
+        rc = lib().m3t_va_loss(_p(y), rows, Cc, iv, ia, _p(val), _p(aro),
+                               C.c_void_p(cls.data_ptr()) if cls is not None else None,
+                               C.c_void_p(vld.data_ptr()) if vld is not None else None,
+                               n_expr, w_v, w_a, expr_w, int(use_mse), _p(stats), _p(dy), _stream())
+        _lib.check(rc, "m3t_va_loss")
+        ctx.save_for_backward(dy)
+        ctx.mark_non_differentiable(stats)
+        return stats[0], stats
+
+    @staticmethod
+    def backward(ctx, g_loss, g_stats):
+        (dy,) = ctx.saved_tensors
+        return (dy * g_loss,) + (None,) * 11
+
+
+def va_loss(y_hat, valence, arousal, class_expr=None, expr_valid=None, iv=None, ia=None, n_expr=0,
+            w_v=0.5, w_a=0.5, expr_w=0.8, use_mse=False):
+    """Loss of AffWild2VA.training_step (reference models/model.py:146-182).  Returns
+    (loss, stats[8]) with stats = loss, loss_v, loss_a, loss_expr, n_valid, n_correct, ccc_v, ccc_a."""
+    Cc = y_hat.shape[-1]
+    iv = Cc - 2 if iv is None else iv
+    ia = Cc - 1 if ia is None else ia
+    return _VALoss.apply(y_hat, valence, arousal, class_expr, expr_valid, iv, ia, n_expr, float(w_v), float(w_a),
+                         float(expr_w), bool(use_mse))
+
+
+# ----------------------------------------------------------------------------- TCN
+class _BctToBtc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _req(x.contiguous(), "x")
+        B, Cc, T = x.shape
+        y = torch.empty(B, T, Cc, dtype=x.dtype, device=x.device)
+        _lib.check(lib().m3t_bct_to_btc(_p(x), _p(y), B, Cc, T, _stream()), "m3t_bct_to_btc")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _BtcToBct.apply(dy)
+
+
+class _BtcToBct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _req(x.contiguous(), "x")
+        B, T, Cc = x.shape
+        y = torch.empty(B, Cc, T, dtype=x.dtype, device=x.device)
+        _lib.check(lib().m3t_btc_to_bct(_p(x), _p(y), B, T, Cc, _stream()), "m3t_btc_to_bct")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _BctToBtc.apply(dy)
+
+
+def bct_to_btc(x):
+    return _BctToBtc.apply(x)
+
+
+def btc_to_bct(x):
+    return _BtcToBct.apply(x)
+
+
+def _conv(x, w_t, bias, res, mask, pre, B, T, Ci, Co, K, dil, act, anti):
+    y = torch.empty(B, T, Co, dtype=torch.float32, device=x.device)
+    rc = lib().m3t_causal_conv_fwd(_p(x), _p(w_t), _p(bias), _p(res), _p(mask), _p(y), _p(pre), B, T, Ci, Co, K, dil,
+                                   act, anti, _stream())
+    _lib.check(rc, "m3t_causal_conv_fwd")
+    return y
+
+
+class _TemporalBlock(torch.autograd.Function):
+    """One TemporalBlock (reference models/tcn.py:16-46) on channel-last activations:
+    weight-norm -> dilated causal conv + bias + ReLU [+dropout mask] -> same again ->
+    + residual (identity or 1x1 conv) -> ReLU, with bias/ReLU/residual fused in the conv epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, v1, g1, b1, v2, g2, b2, wd, bd, dilation, m1, m2):
+        x = _req(x.contiguous(), "x")
+        for t in (v1, g1, b1, v2, g2, b2):
+            _req(t, "tcn parameter")
+        B, T, Ci = x.shape
+        Co, _, K = v1.shape
+        dev = x.device
+        w1t = torch.empty(K, Co, Ci, dtype=torch.float32, device=dev)
+        w2t = torch.empty(K, Co, Co, dtype=torch.float32, device=dev)
+        n1 = torch.empty(Co, dtype=torch.float32, device=dev)
+        n2 = torch.empty(Co, dtype=torch.float32, device=dev)
+        _lib.check(lib().m3t_weight_norm_fwd(_p(v1), _p(g1), _p(w1t), _p(n1), Co, Ci, K, _stream()), "m3t_weight_norm_fwd")
+        _lib.check(lib().m3t_weight_norm_fwd(_p(v2), _p(g2), _p(w2t), _p(n2), Co, Co, K, _stream()), "m3t_weight_norm_fwd")
+        h1 = _conv(x, w1t, b1, None, m1, None, B, T, Ci, Co, K, dilation, 1, 0)
+        if wd is not None:
+            res = torch.empty(B, T, Co, dtype=torch.float32, device=dev)
+            sgemm(0, 1, B * T, Co, Ci, x, 0, Ci, wd, 0, Ci, res, 0, Co, bias=bd)
+        else:
+            res = x
+        a2 = torch.empty(B, T, Co, dtype=torch.float32, device=dev)
+        y = _conv(h1, w2t, b2, res, m2, a2, B, T, Co, Co, K, dilation, 2, 0)
+        ctx.save_for_backward(x, v1, g1, v2, g2, wd, w1t, w2t, n1, n2, h1, a2, y, m1, m2)
+        ctx.dil = dilation
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, v1, g1, v2, g2, wd, w1t, w2t, n1, n2, h1, a2, y, m1, m2 = ctx.saved_tensors
+        dy = _req(dy.contiguous(), "dy")
+        B, T, Ci = x.shape
+        Co, _, K = v1.shape
+        dil, dev = ctx.dil, x.device
+        ws = workspace(dev)
+        ds = mask_pos(y, dy)                         # through the block's output ReLU
+        da2 = mask_pos(a2, ds, m2)                   # through dropout2 + relu2
+        dh1 = _conv(da2, w2t, None, None, None, None, B, T, Co, Co, K, dil, 0, 1)
+        da1 = mask_pos(h1, dh1, m1)                  # h1 > 0 <=> a1 > 0 (dropout keeps the sign)
+        dw2t = torch.empty_like(w2t)
+        dw1t = torch.empty_like(w1t)
+        _lib.check(lib().m3t_causal_conv_wgrad(_p(da2), _p(h1), _p(dw2t), B, T, Co, Co, K, dil, _p(ws), ws.numel() * 4,
+                                               _stream()), "m3t_causal_conv_wgrad")
+        _lib.check(lib().m3t_causal_conv_wgrad(_p(da1), _p(x), _p(dw1t), B, T, Ci, Co, K, dil, _p(ws), ws.numel() * 4,
+                                               _stream()), "m3t_causal_conv_wgrad")
+        db1 = torch.empty(Co, dtype=torch.float32, device=dev)
+        db2 = torch.empty(Co, dtype=torch.float32, device=dev)
+        colsum(da1, 0, B * T, Co, Co, db1)
+        colsum(da2, 0, B * T, Co, Co, db2)
+        dv1, dg1 = torch.empty_like(v1), torch.empty_like(g1)
+        dv2, dg2 = torch.empty_like(v2), torch.empty_like(g2)
+        _lib.check(lib().m3t_weight_norm_bwd(_p(dw1t), _p(v1), _p(g1), _p(n1), _p(dv1), _p(dg1), Co, Ci, K, _stream()),
+                   "m3t_weight_norm_bwd")
+        _lib.check(lib().m3t_weight_norm_bwd(_p(dw2t), _p(v2), _p(g2), _p(n2), _p(dv2), _p(dg2), Co, Co, K, _stream()),
+                   "m3t_weight_norm_bwd")
+        dwd = dbd = None
+        if wd is None:
+            dx = _conv(da1, w1t, None, ds, None, None, B, T, Co, Ci, K, dil, 0, 1)      # + identity residual
+        else:
+            dx = _conv(da1, w1t, None, None, None, None, B, T, Co, Ci, K, dil, 0, 1)
+            sgemm(0, 0, B * T, Ci, Co, ds, 0, Co, wd, 0, Ci, dx, 0, Ci, accumulate=True, use_ws=False)
+            dwd = torch.empty_like(wd)
+            sgemm(1, 0, Co, Ci, B * T, ds, 0, Co, x, 0, Ci, dwd, 0, Ci)
+            dbd = torch.empty(Co, dtype=torch.float32, device=dev)
+            colsum(ds, 0, B * T, Co, Co, dbd)
+        return dx, dv1, dg1, db1, dv2, dg2, db2, dwd, dbd, None, None, None
+
+
+def temporal_block(x_btc, v1, g1, b1, v2, g2, b2, wd, bd, dilation, m1=None, m2=None):
+    return _TemporalBlock.apply(x_btc, v1, g1, b1, v2, g2, b2, wd, bd, dilation, m1, m2)
+
+
+# ----------------------------------------------------------------------------- CBAM
+class _ChannelGate(torch.autograd.Function):
+    """models.cbam.ChannelGate (reference models/cbam.py:33-58) on [N,C,H,W]."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        x = _req(x.contiguous(), "x")
+        for t in (w1, b1, w2, b2):
+            _req(t, "cbam parameter")
+        N, Cc, H, W = x.shape
+        Cr = w1.shape[0]
+        dev = x.device
+        y = torch.empty_like(x)
+        pooled = torch.empty(N, 2, Cc, dtype=torch.float32, device=dev)
+        argmax = torch.empty(N, Cc, dtype=torch.int32, device=dev)
+        hidden = torch.empty(N, 2, Cr, dtype=torch.float32, device=dev)
+        scale = torch.empty(N, Cc, dtype=torch.float32, device=dev)
+        rc = lib().m3t_cbam_channel_fwd(_p(x), _p(w1), _p(b1), _p(w2), _p(b2), _p(y), _p(pooled),
+                                        C.c_void_p(argmax.data_ptr()), _p(hidden), _p(scale), N, Cc, Cr, H * W, _stream())
+        _lib.check(rc, "m3t_cbam_channel_fwd")
+        ctx.save_for_backward(x, w1, w2, pooled, argmax, hidden, scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, w2, pooled, argmax, hidden, scale = ctx.saved_tensors
+        dy = _req(dy.contiguous(), "dy")
+        N, Cc, H, W = x.shape
+        Cr = w1.shape[0]
+        dev = x.device
+        dx = torch.empty_like(x)
+        dw1, dw2 = torch.empty_like(w1), torch.empty_like(w2)
+        db1 = torch.empty(Cr, dtype=torch.float32, device=dev)
+        db2 = torch.empty(Cc, dtype=torch.float32, device=dev)
+        ws = workspace(dev, N * (Cc + 3 * Cr) * 4 + (32 << 20))
+        rc = lib().m3t_cbam_channel_bwd(_p(dy), _p(x), _p(w1), _p(w2), _p(pooled), C.c_void_p(argmax.data_ptr()),
+                                        _p(hidden), _p(scale), _p(dx), _p(dw1), _p(db1), _p(dw2), _p(db2),
+                                        N, Cc, Cr, H * W, _p(ws), ws.numel() * 4, _stream())
+        _lib.check(rc, "m3t_cbam_channel_bwd")
+        return dx, dw1, db1, dw2, db2
+
+
+class _SpatialGate(torch.autograd.Function):
+    """models.cbam.SpatialGate (reference models/cbam.py:74-92): ChannelPool(max,mean) ->
+    Conv2d(2,1,5,pad 2) -> BatchNorm2d(1) -> sigmoid -> scale."""
+
+    @staticmethod
+    def forward(ctx, x, conv_w, bn_w, bn_b, running_mean, running_var, training, momentum, eps):
+        x = _req(x.contiguous(), "x")
+        _req(conv_w, "conv weight")
+        N, Cc, H, W = x.shape
+        dev = x.device
+        bn = torch.cat([bn_w.reshape(1), bn_b.reshape(1)]).contiguous()
+        running = torch.cat([running_mean.reshape(1), running_var.reshape(1)]).contiguous()
+        y = torch.empty_like(x)
+        comp = torch.empty(N, 2, H * W, dtype=torch.float32, device=dev)
+        cargmax = torch.empty(N, H * W, dtype=torch.int32, device=dev)
+        xhat = torch.empty(N, H * W, dtype=torch.float32, device=dev)
+        stats = torch.empty(2, dtype=torch.float32, device=dev)
+        scale = torch.empty(N, H * W, dtype=torch.float32, device=dev)
+        ws = workspace(dev)
+        rc = lib().m3t_cbam_spatial_fwd(_p(x), _p(conv_w), _p(bn), _p(running), _p(y), _p(comp),
+                                        C.c_void_p(cargmax.data_ptr()), _p(xhat), _p(stats), _p(scale), N, Cc, H, W,
+                                        int(training), float(momentum), float(eps), _p(ws), ws.numel() * 4, _stream())
+        _lib.check(rc, "m3t_cbam_spatial_fwd")
+        if training:
+            with torch.no_grad():
+                running_mean.copy_(running[0:1])
+                running_var.copy_(running[1:2])
+        ctx.save_for_backward(x, conv_w, bn, comp, cargmax, xhat, stats, scale)
+        ctx.training = bool(training)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, conv_w, bn, comp, cargmax, xhat, stats, scale = ctx.saved_tensors
+        dy = _req(dy.contiguous(), "dy")
+        N, Cc, H, W = x.shape
+        dev = x.device
+        dx = torch.empty_like(x)
+        dconv = torch.empty_like(conv_w)
+        dbn = torch.empty(2, dtype=torch.float32, device=dev)
+        ws = workspace(dev, 2 * N * H * W * 4 + (16 << 20))
+        rc = lib().m3t_cbam_spatial_bwd(_p(dy), _p(x), _p(conv_w), _p(bn), _p(comp), C.c_void_p(cargmax.data_ptr()),
+                                        _p(xhat), _p(stats), _p(scale), _p(dx), _p(dconv), _p(dbn), N, Cc, H, W,
+                                        int(ctx.training), _p(ws), ws.numel() * 4, _stream())
+        _lib.check(rc, "m3t_cbam_spatial_bwd")
+        return dx, dconv, dbn[0:1].clone(), dbn[1:2].clone(), None, None, None, None, None
+
+
+def channel_gate(x, w1, b1, w2, b2):
+    return _ChannelGate.apply(x, w1, b1, w2, b2)
+
+
+def spatial_gate(x, conv_w, bn_w, bn_b, running_mean, running_var, training, momentum=0.01, eps=1e-5):
+    return _SpatialGate.apply(x, conv_w, bn_w, bn_b, running_mean, running_var, training, momentum, eps)
+
+
+# ----------------------------------------------------------------------------- DDP helper
+def grad_norm_scale_(flat, world_size, max_norm):
+    """In place: flat <- flat/world * min(1, max_norm/(||flat/world|| + 1e-6)).  Returns the norm (device scalar)."""
+    _req(flat, "flat gradient buffer")
+    norm = torch.empty(1, dtype=torch.float32, device=flat.device)
+    ws = workspace(flat.device)
+    rc = lib().m3t_grad_norm_scale(_p(flat), flat.numel(), 1.0 / float(world_size), float(max_norm), _p(norm), _p(ws),
+                                   ws.numel() * 4, _stream())
+    _lib.check(rc, "m3t_grad_norm_scale")
+    return norm

@@ -1,0 +1,60 @@
+"""Benchmark / parity workloads assembled from the drop-in modules.
+
+These are the reference's own graphs with the conv towers replaced by pre-computed per-frame
+features -- exactly what BASELINE.json's configs describe ("precomputed 256-d SENet feats",
+"256-d video + 128-d audio").  Attribute names follow AffWild2VA so state_dict keys line up.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from models.rnn import GRU, run_grus
+from models.att_fusion import AttFusion
+from models.tcn import TemporalConvNet
+
+
+class AVFeatureGraph(nn.Module):
+    """Config C3/C4: AffWild2VA.forward, audiovisual/attention (reference models/model.py:108-118)
+    on feature inputs: audio GRU(d_a,256,2) | gru_v, gru_a GRU(d_v,H,2) on the SAME visual features
+    (mirrors `se_features` passed twice, model.py:111) -> cat -> proj_v Linear(4H,512) ->
+    AttFusion([512,512],128) -> fusion GRU(512,H,2,9,2)."""
+
+    def __init__(self, d_a=128, d_v=256, num_hidden=512, fc_outputs=9, num_fc_layers=2):
+        super().__init__()
+        self.audio = GRU(d_a, 256, 2, -1, num_fc_layers)
+        self.visual = nn.Module()
+        self.visual.gru_v = GRU(d_v, num_hidden, 2, -1, num_fc_layers)
+        self.visual.gru_a = GRU(d_v, num_hidden, 2, -1, num_fc_layers)
+        self.proj_v = nn.Linear(num_hidden * 4, 512)
+        self.att_fuse = AttFusion([512, 512], 128)
+        self.fusion = GRU(512, num_hidden, 2, fc_outputs, num_fc_layers)
+
+    def forward(self, x_a, x_v):
+        a, v1, v2 = run_grus([self.audio, self.visual.gru_v, self.visual.gru_a], [x_a, x_v, x_v])
+        v = ops.linear(torch.cat((v1, v2), dim=-1), self.proj_v.weight, self.proj_v.bias, 0)
+        return self.fusion(self.att_fuse(a, v))
+
+
+class TcnHead(nn.Module):
+    """Config C1: TemporalConvNet(d_in,[H]*L,3) + Linear(H,2) composed as VA_3DVGGM's tcn back-end
+    (reference models/backbone.py:107-111,139-141).  Input channel-first [B,d_in,T]."""
+
+    def __init__(self, d_in=128, hidden=512, levels=2):
+        super().__init__()
+        self.tcn = nn.ModuleList([TemporalConvNet(d_in, [hidden] * levels, 3), nn.Linear(hidden, 2)])
+
+    def forward(self, x):
+        h = self.tcn[0].forward_btc(ops.bct_to_btc(x))
+        return ops.linear(h, self.tcn[1].weight, self.tcn[1].bias, 0)
+
+
+class TcnGru(nn.Module):
+    """Config C2: TemporalConvNet(d_in,[H,H],3) -> GRU(H,H,2,2,2).  Input channel-first [B,d_in,T]."""
+
+    def __init__(self, d_in=256, hidden=512):
+        super().__init__()
+        self.tcn = TemporalConvNet(d_in, [hidden, hidden], 3)
+        self.gru = GRU(hidden, hidden, 2, 2, 2)
+
+    def forward(self, x):
+        return self.gru(self.tcn.forward_btc(ops.bct_to_btc(x)))

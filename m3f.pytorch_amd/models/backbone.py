@@ -1,0 +1,199 @@
+"""models.backbone -- visual front-ends + temporal back-ends, MI355X-native temporal part.
+
+API/state-dict compatible with the reference's models/backbone.py for the classes on the
+north_star path: `VA_3DVGGM` (:62-161), `VA_3DVGGM_Split` (:164-311, the default
+`--backbone v2p_split`) and `VA_3DResNet` (:314-372).  The 3-D conv stems stay on
+PyTorch-ROCm (MIOpen) ops; the temporal back-ends (BiGRU stacks, TCN) and the
+CBAM gates inside the ResNet run in the HIP library.  `VA_3DDenseNet` / `VA_VGGFace` are
+out of scope (not reachable from AffWild2VA.forward).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from m3t import ops
+from .resnet import ResNet, ResNetV2, BasicBlock, BasicBlockV2
+from .rnn import GRU, run_grus
+from .tcn import TemporalConvNet, WeightNormConv1d
+
+
+def _norm3d(kind, channels):
+    return nn.BatchNorm3d(channels) if kind == 'bn' else nn.GroupNorm(32, channels)
+
+
+def _vgg_group(idx, norm):
+    """Layer group `conv{idx}` of the VGG-M style stem (reference backbone.py:73-103,179-184,243-271)."""
+    if idx == 1:
+        return [nn.Conv3d(3, 64, 3, stride=(1, 2, 2), padding=(1, 0, 0)), _norm3d(norm, 64), nn.ReLU(True),
+                nn.MaxPool3d(kernel_size=(1, 2, 2), stride=(1, 2, 2))]
+    cin, cout, pool = {2: (64, 128, True), 3: (128, 256, True), 4: (256, 512, False), 5: (512, 512, False)}[idx]
+    mods = [nn.Conv3d(cin, cout, 3, 1, padding=(1, 0, 0)), _norm3d(norm, cout), nn.ReLU(True)]
+    if pool:
+        mods.append(nn.MaxPool3d(kernel_size=(1, 2, 2), stride=(1, 2, 2)))
+    return mods
+
+
+def _init_like_reference(net):
+    """reference `_initialize_weights` (backbone.py:147-161): Conv3d ~ N(0, sqrt(2/(k^3*C_out))), zero bias;
+    Conv1d kaiming-normal (a no-op draw for weight-normed convs, whose `.weight` is recomputed);
+    BatchNorm3d/1d -> (1, 0)."""
+    for m in net.modules():
+        if isinstance(m, nn.Conv3d):
+            n = m.kernel_size[0] * m.kernel_size[1] * m.kernel_size[2] * m.out_channels
+            m.weight.data.normal_(0, math.sqrt(2.0 / n))
+            if m.bias is not None:
+                m.bias.data.zero_()
+        elif isinstance(m, WeightNormConv1d):
+            nn.init.kaiming_normal_(torch.empty_like(m.weight_v))
+        elif isinstance(m, nn.Conv1d):
+            nn.init.kaiming_normal_(m.weight)
+        elif isinstance(m, (nn.BatchNorm3d, nn.BatchNorm1d)):
+            m.weight.data.fill_(1)
+            m.bias.data.zero_()
+
+
+def _simple_tcn(in_dim, hidden, k, pad):
+    return nn.Sequential(nn.Conv1d(in_dim, hidden, k, 1, pad), nn.BatchNorm1d(512), nn.ReLU(True),
+                         nn.Conv1d(hidden, hidden, k, 1, pad), nn.BatchNorm1d(512), nn.ReLU(True))
+
+
+def _squeeze_hw(x):
+    """[B,C,T,1,1] -> [B,C,T] (the reference's bare .squeeze() also drops B or T when they are 1)."""
+    return x.flatten(3).squeeze(-1)
+
+
+class VA_3DVGGM(nn.Module):
+    def __init__(self, inputDim=512, hiddenDim=512, nLayers=2, nClasses=2, frameLen=16, backend='gru', norm_layer='bn',
+                 nFCs=1):
+        super().__init__()
+        self.inputDim, self.hiddenDim, self.nClasses = inputDim, hiddenDim, nClasses
+        self.frameLen, self.nLayers, self.backend, self.nFCs = frameLen, nLayers, backend, nFCs
+        stem = []
+        for g in range(1, 6):
+            stem += _vgg_group(g, norm_layer)
+        self.v2p = nn.Sequential(*stem)
+        if backend == 'gru':
+            self.gru = GRU(inputDim, hiddenDim, nLayers, nClasses, nFCs)
+        elif backend == 'tcn':
+            self.tcn = nn.ModuleList([TemporalConvNet(inputDim, [hiddenDim] * nLayers, 3), nn.Linear(hiddenDim, 2)])
+        elif backend == 'tcn_simple':
+            self.tcn = nn.ModuleList([_simple_tcn(inputDim, hiddenDim, 3, 1), nn.Linear(hiddenDim, 2)])
+        elif backend == 'fc':
+            self.fc = nn.Sequential(nn.Linear(512, hiddenDim), nn.ReLU(True), nn.Linear(hiddenDim, nClasses))
+        _init_like_reference(self)
+
+    def temporal(self, feats):
+        """feats channel-first [B,512,T] -> predictions (the part after the conv stem, backbone.py:136-145)."""
+        if self.backend == 'gru':
+            return self.gru(ops.bct_to_btc(feats))
+        if self.backend == 'tcn':
+            h = self.tcn[0].forward_btc(ops.bct_to_btc(feats))         # stays channel-last: no transpose back
+            return ops.linear(h, self.tcn[1].weight, self.tcn[1].bias, 0)
+        if self.backend == 'tcn_simple':
+            h = ops.bct_to_btc(self.tcn[0](feats))
+            return ops.linear(h, self.tcn[1].weight, self.tcn[1].bias, 0)
+        if self.backend == 'fc':
+            h = ops.bct_to_btc(feats)
+            h = ops.linear(h, self.fc[0].weight, self.fc[0].bias, 1)
+            return ops.linear(h, self.fc[2].weight, self.fc[2].bias, 0).mean(dim=1)
+        return feats
+
+    def forward(self, x):
+        return self.temporal(_squeeze_hw(self.v2p(x)))
+
+
+class VA_3DVGGM_Split(nn.Module):
+    def __init__(self, inputDim=512, hiddenDim=512, nLayers=2, frameLen=16, nClasses=2, backend='gru', norm_layer='bn',
+                 split_layer=5, nFCs=1, use_mtl=False):
+        super().__init__()
+        self.inputDim, self.hiddenDim, self.frameLen, self.nLayers = inputDim, hiddenDim, frameLen, nLayers
+        self.nClasses, self.backend, self.split_layer = nClasses, backend, split_layer
+        self.norm_layer, self.nFCs, self.use_mtl = norm_layer, nFCs, use_mtl
+        assert split_layer >= 2, 'degenerate multi-tower structure'
+        shared, v_priv, a_priv = _vgg_group(1, norm_layer), [], []
+        for g in range(2, 6):
+            if split_layer >= g:
+                shared += _vgg_group(g, norm_layer)
+            else:                      # construction order V then A per group, as the reference (RNG order)
+                v_priv += _vgg_group(g, norm_layer)
+                a_priv += _vgg_group(g, norm_layer)
+        self.shared = nn.Sequential(*shared)
+        if split_layer != 5:
+            self.v_private = nn.Sequential(*v_priv)
+            self.a_private = nn.Sequential(*a_priv)
+        if backend == 'gru':
+            if split_layer == 5:
+                self.gru = GRU(inputDim + 512 + 512, hiddenDim, nLayers, nClasses, nFCs)
+            else:
+                # mtl: V tower -> 7 expr logits + valence (nClasses-1), A tower -> arousal (1); -1/-2 => no FC
+                self.gru_v = GRU(inputDim + 512, hiddenDim, nLayers, nClasses - 1, nFCs)
+                self.gru_a = GRU(inputDim + 512, hiddenDim, nLayers, min(nClasses, 1), nFCs)
+        elif backend == 'tcn_simple' and split_layer != 5:
+            self.tcn_v = nn.ModuleList([_simple_tcn(inputDim + 512, hiddenDim, 5, 2)])
+            self.tcn_a = nn.ModuleList([_simple_tcn(inputDim + 512, hiddenDim, 5, 2)])
+            if use_mtl:
+                if nClasses > 0:
+                    self.tcn_v.append(nn.Linear(hiddenDim, nClasses - 1))
+                    self.tcn_a.append(nn.Linear(hiddenDim, 1))
+            else:
+                self.tcn_v.append(nn.Linear(hiddenDim, 1))
+                self.tcn_a.append(nn.Linear(hiddenDim, 1))
+        _init_like_reference(self)
+
+    def features(self, x, se, au):
+        """Conv towers + feature concat -> the two channel-last [B,T,1024] GRU inputs (split_layer != 5)."""
+        x = self.shared(x)
+        x_v = torch.cat((_squeeze_hw(self.v_private(x)), se), dim=1)    # valence tower | SENet feats
+        x_a = torch.cat((_squeeze_hw(self.a_private(x)), au), dim=1)    # arousal tower | (TCAE-AU or SENet) feats
+        return x_v, x_a
+
+    def forward(self, x, se, au):
+        if self.split_layer != 5:
+            x_v, x_a = self.features(x, se, au)
+            if self.backend == 'gru':
+                y_v, y_a = run_grus([self.gru_v, self.gru_a], [ops.bct_to_btc(x_v), ops.bct_to_btc(x_a)])
+                return torch.cat((y_v, y_a), dim=-1)
+            if self.backend.startswith('tcn'):
+                h_v = ops.bct_to_btc(self.tcn_v[0](x_v))
+                h_a = ops.bct_to_btc(self.tcn_a[0](x_a))
+                y_v = ops.linear(h_v, self.tcn_v[1].weight, self.tcn_v[1].bias, 0)
+                y_a = ops.linear(h_a, self.tcn_a[1].weight, self.tcn_a[1].bias, 0)
+                return torch.cat((y_v, y_a), dim=-1)
+            return None
+        x = torch.cat((_squeeze_hw(self.shared(x)), se, au), dim=1)
+        if self.backend == 'gru':
+            x = self.gru(ops.bct_to_btc(x))
+        return x
+
+
+class VA_3DResNet(nn.Module):
+    def __init__(self, inputDim=512, hiddenDim=512, nLayers=2, nClasses=2, frameLen=16, backend='gru', use_cbam=False,
+                 resnet_ver='v2', resnet_depth=18, frontend_agg_mode='ap', nFCs=1):
+        super().__init__()
+        self.inputDim, self.hiddenDim, self.nClasses = inputDim, hiddenDim, nClasses
+        self.frameLen, self.nLayers, self.backend, self.nFCs = frameLen, nLayers, backend, nFCs
+        self.c3d = nn.Sequential(
+            nn.Conv3d(3, 64, kernel_size=(5, 7, 7), stride=(1, 2, 2), padding=(2, 3, 3), bias=False),
+            nn.BatchNorm3d(64), nn.ReLU(True),
+            nn.MaxPool3d(kernel_size=(1, 3, 3), stride=(1, 2, 2), padding=(0, 1, 1)))
+        assert resnet_depth in [18, 34] and resnet_ver in ['v1', 'v2'], \
+            'unsupported ResNet configuration: {}, {}'.format(resnet_depth, resnet_ver)
+        cfg = [2, 2, 2, 2] if resnet_depth == 18 else [3, 4, 6, 3]
+        if resnet_ver == 'v2':
+            self.resnet = ResNetV2(BasicBlockV2, cfg, inputDim, zero_init_residual=False, agg_mode=frontend_agg_mode,
+                                   fmap_out_size=3, use_cbam=use_cbam)
+        else:
+            self.resnet = ResNet(BasicBlock, cfg, inputDim, zero_init_residual=True, agg_mode=frontend_agg_mode,
+                                 fmap_out_size=3, use_cbam=use_cbam)
+        if backend == 'gru':
+            self.gru = GRU(inputDim, hiddenDim, nLayers, nClasses, nFCs)
+        _init_like_reference(self)
+
+    def forward(self, x):
+        x = self.c3d(x)                                            # [B,64,T,h,w]
+        x = x.transpose(1, 2).reshape(-1, 64, x.size(3), x.size(4))  # fold T into the batch: per-frame ResNet
+        x = self.resnet(x).view(-1, self.frameLen, self.inputDim)
+        if self.backend == 'gru':
+            x = self.gru(x)
+        return x

@@ -1,0 +1,202 @@
+"""models.model -- the M3T valence-arousal task module, MI355X-native hot path.
+
+Drop-in for the reference's models/model.py:27-493 (`AffWild2VA`): same constructor
+(`hparams` namespace with the reference's flags, `add_model_specific_args`), same sub-module
+attribute names (`visual`, `audio`, `proj_v`, `att_fuse`, `fusion`) and therefore the same
+state_dict keys, same `forward(batch: dict)`, loss helpers and `training_step` return dict.
+
+What runs where: every BiGRU / FC / fusion / loss op is a HIP kernel behind the C ABI
+(include/m3t_hip.h).  Independent BiGRU stacks are advanced together (audio + the two visual
+towers; the two fusion scorers) so that one launch per time step covers all of them.  The
+3-D conv stem of the visual tower stays on PyTorch-ROCm ops.  If pytorch_lightning is
+installed the class derives from pl.LightningModule exactly as the reference does; without it
+(this image) it is a plain nn.Module with the same hooks.
+
+Out of scope here (SURVEY.md section 8(f) "next" rows): dataloaders (need the Aff-Wild2 dataset and
+cv2), validation/test window stitching, the LR range finder, `--fusion_type att_dec`.
+"""
+from argparse import ArgumentParser
+
+import torch
+import torch.nn as nn
+from torch.nn import functional as F
+
+from m3t import ops
+from .backbone import VA_3DResNet, VA_3DVGGM, VA_3DVGGM_Split
+from .rnn import GRU, run_grus
+from .att_fusion import AttFusion
+from .utils import concordance_cc2, mse  # noqa: F401  (re-exported like the reference)
+
+try:  # pragma: no cover - pytorch_lightning is absent in the build image
+    import pytorch_lightning as pl
+    _Base = pl.LightningModule
+except Exception:  # noqa: BLE001
+    pl = None
+    _Base = nn.Module
+
+
+class AffWild2VA(_Base):
+
+    def __init__(self, hparams):
+        super().__init__()
+        try:
+            self.hparams = hparams
+        except AttributeError:      # newer Lightning: hparams is a read-only property
+            self.save_hyperparameters(hparams)
+        hp = hparams
+        use_mtl = 'mtl' in hp.loss
+        fc_outputs = 9 if use_mtl else 2          # 7 expression logits + valence + arousal (model.py:35)
+        av = hp.modality == 'audiovisual'
+        enc_classes = -1 if av else fc_outputs    # AV encoders emit raw 2H features (model.py:36-39)
+
+        if 'visual' in hp.modality:
+            common = dict(hiddenDim=hp.num_hidden, frameLen=hp.window, backend=hp.backend, nClasses=enc_classes,
+                          nFCs=hp.num_fc_layers)
+            if hp.backbone == 'resnet':
+                self.visual = VA_3DResNet(resnet_ver='v1', **common)
+            elif hp.backbone == 'v2p':
+                self.visual = VA_3DVGGM(**common)
+            elif hp.backbone == 'v2p_split':
+                self.visual = VA_3DVGGM_Split(split_layer=hp.split_layer, use_mtl=use_mtl, **common)
+            else:
+                raise NotImplementedError("backbone '%s' is outside the MI355X hot path (SURVEY.md section 2.1)" % hp.backbone)
+        if 'audio' in hp.modality:
+            self.audio = GRU(200, 256, 2, enc_classes, hp.num_fc_layers)
+        if av:
+            self.proj_v = nn.Linear(hp.num_hidden * (2 if hp.split_layer == 5 else 4), 512)
+            if hp.fusion_type == 'attention':
+                self.att_fuse = AttFusion([512, 512], 128)
+                self.fusion = GRU(512, hp.num_hidden, 2, fc_outputs, hp.num_fc_layers)
+            elif hp.fusion_type == 'concat':
+                self.fusion = GRU(512 * 2, hp.num_hidden, 2, fc_outputs, hp.num_fc_layers)
+            else:
+                raise NotImplementedError("fusion_type '%s' is outside the MI355X hot path" % hp.fusion_type)
+        self.history = {'lr': [], 'loss': []}
+
+    # ------------------------------------------------------------------ forward
+    def _encode_av(self, batch, x):
+        """audio encoder || visual towers: one grouped scan per layer when the visual back-end is the
+        split GRU pair (the default), otherwise module by module."""
+        se = batch['se_features']
+        vis = self.visual
+        if isinstance(vis, VA_3DVGGM_Split) and vis.split_layer != 5 and vis.backend == 'gru':
+            x_v, x_a = vis.features(x, se, se)      # `se_features` passed twice, as model.py:111
+            a, v1, v2 = run_grus([self.audio, vis.gru_v, vis.gru_a],
+                                 [batch['audio'], ops.bct_to_btc(x_v), ops.bct_to_btc(x_a)])
+            return a, torch.cat((v1, v2), dim=-1)
+        return self.audio(batch['audio']), vis(x, se, se)
+
+    def forward(self, batch):
+        hp = self.hparams
+        if hp.modality == 'audio':
+            return self.audio(batch['audio'])
+        x = (batch['video'] - 127.5) / 127.5            # to [-1, 1] (model.py:106)
+        if 'audio' in hp.modality:
+            audio_feats, video_feats = self._encode_av(batch, x)
+            video_feats = ops.linear(video_feats, self.proj_v.weight, self.proj_v.bias, 0)
+            if hp.fusion_type == 'attention':
+                return self.fusion(self.att_fuse(audio_feats, video_feats))
+            return self.fusion(torch.cat((audio_feats, video_feats), dim=-1))
+        return self.visual(x, batch['se_features'], batch['se_features'])
+
+    # ------------------------------------------------------------------ losses (fused HIP kernel)
+    def ccc_loss(self, y_hat, y):
+        loss, _ = ops.va_loss(y_hat.reshape(-1, 1), y.reshape(-1), y.reshape(-1), iv=0, ia=0, w_v=1.0, w_a=0.0,
+                              expr_w=0.0)
+        return loss
+
+    def mse_loss(self, y_hat, y):
+        loss, _ = ops.va_loss(y_hat.reshape(-1, 1), y.reshape(-1), y.reshape(-1), iv=0, ia=0, w_v=1.0, w_a=0.0,
+                              expr_w=0.0, use_mse=True)
+        return loss
+
+    def ce_loss(self, y_hat, y, mask):
+        lg = y_hat.reshape(-1, y_hat.size(-1))
+        zeros = lg.new_zeros(lg.size(0))
+        loss, stats = ops.va_loss(lg, zeros, zeros, y.reshape(-1), mask.reshape(-1), iv=0, ia=0,
+                                  n_expr=lg.size(-1), w_v=0.0, w_a=0.0, expr_w=1.0)
+        return loss
+
+    def bce_loss(self, y_hat, y, mask):     # AU branch: commented out upstream (model.py:184-199); host ops
+        loss = F.binary_cross_entropy_with_logits(y_hat.view(-1), y.view(-1), reduction='none')
+        return (loss * mask.view(-1).float()).mean()
+
+    def va_objective(self, y_hat, batch):
+        """Whole training objective in one kernel launch: returns (loss, stats) where stats =
+        [loss, loss_v, loss_a, loss_expr, n_valid, n_correct, ccc_v, ccc_a] on the device."""
+        hp = self.hparams
+        mtl = 'mtl' in hp.loss
+        if 'mse' not in hp.loss:
+            assert 'ccc' in hp.loss, 'invalid loss specification'
+        C_ = y_hat.size(-1)
+        return ops.va_loss(y_hat, batch['label_valence'], batch['label_arousal'],
+                           batch['class_expr'] if mtl else None, batch['expr_valid'] if mtl else None,
+                           iv=7 if mtl else C_ - 2, ia=C_ - 1, n_expr=7 if mtl else 0,
+                           w_v=hp.loss_lambda, w_a=1 - hp.loss_lambda, expr_w=0.8, use_mse='mse' in hp.loss)
+
+    def training_step(self, batch, batch_idx):
+        y_hat = self.forward(batch)
+        loss, stats = self.va_objective(y_hat, batch)
+        s = stats.tolist()      # ONE host sync (the reference has two .item() syncs, model.py:173,181)
+        loss_v, loss_a = stats[1], stats[2]
+        progress = {'loss_v': loss_v, 'loss_a': loss_a, 'loss': loss}
+        log = {'loss_v': loss_v, 'loss_a': loss_a, 'loss': loss}
+        if 'mtl' in self.hparams.loss and s[4] > 0:
+            log['loss_expr'] = progress['loss_expr'] = stats[3]
+            progress['acc_expr'] = s[5] / s[4]
+        if getattr(self.hparams, 'test_lr', False):
+            raise NotImplementedError("LR range finder (models/lr_finder.py) is out of scope")
+        return {'loss': loss, 'progress_bar': progress, 'log': log}
+
+    def on_batch_end(self):
+        if getattr(self.hparams, 'scheduler', None) == 'cyclic' and hasattr(self, 'cyclic_scheduler'):
+            self.cyclic_scheduler.step()
+
+    # ------------------------------------------------------------------ optimisation (host glue)
+    def configure_optimizers(self):
+        hp = self.hparams
+        if hp.freeze_enc:
+            for p in self.parameters():
+                p.requires_grad = False
+            live = [self.fusion, self.proj_v] + ([self.att_fuse] if hp.fusion_type == 'attention' else [])
+            for m in live:
+                for p in m.parameters():
+                    p.requires_grad = True
+        params = [p for p in self.parameters() if p.requires_grad]
+        if hp.optimizer == 'adam':
+            opt = torch.optim.Adam(params, lr=hp.learning_rate, weight_decay=1e-4)
+        elif hp.optimizer == 'sgd':
+            opt = torch.optim.SGD(params, lr=hp.learning_rate, momentum=0.9, weight_decay=5e-4)
+        else:
+            raise ValueError(hp.optimizer)
+        if hp.scheduler == 'cyclic':
+            self.cyclic_scheduler = torch.optim.lr_scheduler.CyclicLR(
+                opt, hp.min_lr, hp.learning_rate, step_size_up=5000, cycle_momentum=hp.optimizer == 'sgd')
+            return opt
+        if hp.scheduler == 'exp':
+            return [opt], [torch.optim.lr_scheduler.ExponentialLR(opt, hp.decay_factor)]
+        if hp.scheduler == 'plateau':
+            return [opt], [torch.optim.lr_scheduler.ReduceLROnPlateau(opt, factor=hp.decay_factor, patience=3,
+                                                                      min_lr=1e-6)]
+        return opt
+
+    @staticmethod
+    def add_model_specific_args(parent_parser):
+        """The reference's flags with the reference's defaults (model.py:448-493)."""
+        parser = ArgumentParser(parents=[parent_parser])
+        flags = [
+            ('--backbone', 'v2p_split', str), ('--backend', 'gru', str), ('--modality', 'visual', str),
+            ('--fusion_type', 'concat', str), ('--mode', 'video', str), ('--window', 32, int),
+            ('--windows_per_epoch', 200, int), ('--learning_rate', 5e-5, float), ('--min_lr', 1e-8, float),
+            ('--decay_factor', 0.5, float), ('--batch_size', 96, int), ('--optimizer', 'adam', str),
+            ('--scheduler', 'plateau', str), ('--loss', 'ccc_mtl', str), ('--loss_lambda', 0.5, float),
+            ('--num_hidden', 512, int), ('--split_layer', 3, int), ('--num_fc_layers', 2, int),
+            ('--dataset_path', '/.data/zhangyuanhang/Aff-Wild2', str), ('--release', 'vipl', str),
+            ('--input_size', 256, int), ('--checkpoint_path', '.', str), ('--workers', 8, int),
+            ('--max_nb_epochs', 30, int),
+        ]
+        for name, default, typ in flags:
+            parser.add_argument(name, default=default, type=typ)
+        for name in ('--freeze_enc', '--resample', '--test_lr', '--test_on_val', '--cutout', '--distributed'):
+            parser.add_argument(name, action='store_true', default=False)
+        return parser

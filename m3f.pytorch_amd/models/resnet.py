@@ -1,0 +1,159 @@
+"""models.resnet -- per-frame ResNet-18/34 feature extractor with optional CBAM gating.
+
+API/state-dict compatible with the reference's models/resnet.py:18-124 (`BasicBlock`,
+`ResNet`, v1) and :127-251 (`BasicBlockV2`, `ResNetV2`).  The dense 2-D convolutions and
+BatchNorm2d stay on PyTorch-ROCm (MIOpen) ops -- SURVEY.md section 2.2: north_star names only the
+gating / TCN / GRU / fusion kernels as hand-written -- while every CBAM gate inside the
+blocks runs in the HIP library (models.cbam).
+"""
+import torch.nn as nn
+
+from .cbam import CBAM
+
+
+def conv3x3(in_planes, out_planes, stride=1):
+    return nn.Conv2d(in_planes, out_planes, 3, stride, 1, bias=False)
+
+
+def conv1x1(in_planes, out_planes, stride=1):
+    return nn.Conv2d(in_planes, out_planes, 1, stride, bias=False)
+
+
+class BasicBlock(nn.Module):
+    """conv-bn-relu-conv-bn -> [CBAM] -> + identity -> relu (CBAM sits BEFORE the residual add,
+    reference resnet.py:50-53)."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, use_cbam=False):
+        super().__init__()
+        self.conv1, self.bn1 = conv3x3(inplanes, planes, stride), nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2, self.bn2 = conv3x3(planes, planes), nn.BatchNorm2d(planes)
+        self.downsample, self.stride = downsample, stride
+        self.cbam = CBAM(planes) if use_cbam else None
+
+    def forward(self, x):
+        shortcut = x if self.downsample is None else self.downsample(x)
+        y = self.bn2(self.conv2(self.relu(self.bn1(self.conv1(x)))))
+        if self.cbam is not None:
+            y = self.cbam(y)
+        return self.relu(y + shortcut)
+
+
+class BasicBlockV2(nn.Module):
+    """Pre-activation block (reference resnet.py:127-173)."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, is_first_block_of_first_layer=False,
+                 use_cbam=False):
+        super().__init__()
+        self.is_first_block_of_first_layer = is_first_block_of_first_layer
+        if not is_first_block_of_first_layer:
+            self.bn1 = nn.BatchNorm2d(inplanes)
+        self.conv1 = conv3x3(inplanes, planes, stride)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv2 = conv3x3(planes, planes)
+        self.relu = nn.ReLU(True)
+        self.downsample, self.stride = downsample, stride
+        self.cbam = CBAM(planes) if use_cbam else None
+
+    def forward(self, x):
+        pre = x if self.is_first_block_of_first_layer else self.relu(self.bn1(x))
+        shortcut = x if self.downsample is None else self.downsample(pre)
+        y = self.conv2(self.relu(self.bn2(self.conv1(pre))))
+        if self.cbam is not None:
+            y = self.cbam(y)
+        return y + shortcut
+
+
+def _init_trunk(net):
+    for m in net.modules():
+        if isinstance(m, nn.Conv2d):
+            nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        elif isinstance(m, nn.BatchNorm2d):
+            nn.init.constant_(m.weight, 1)
+            nn.init.constant_(m.bias, 0)
+    # CBAM: the spatial gate's BN gamma starts at 0 => scale = sigmoid(0) = 0.5 (reference resnet.py:81-85)
+    for name, p in net.named_parameters():
+        if name.endswith("weight") and "bn" in name and "SpatialGate" in name:
+            nn.init.constant_(p, 0)
+
+
+class _Trunk(nn.Module):
+    widths = (64, 128, 256, 512)
+
+    def _stages(self, block, layers, use_cbam):
+        self.inplanes = 64
+        for i, (w, n) in enumerate(zip(self.widths, layers)):
+            setattr(self, "layer%d" % (i + 1), self._make_layer(block, w, n, stride=1 if i == 0 else 2, use_cbam=use_cbam))
+
+    def _run_stages(self, x):
+        for i in range(4):
+            x = getattr(self, "layer%d" % (i + 1))(x)
+        return x
+
+
+class ResNet(_Trunk):
+    def __init__(self, block, layers, num_classes=256, zero_init_residual=True, agg_mode="ap", fmap_out_size=3,
+                 use_cbam=False):
+        super().__init__()
+        self.agg_mode = agg_mode
+        self._stages(block, layers, use_cbam)
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+        self.fc = nn.Linear(512 * fmap_out_size * fmap_out_size, num_classes)   # unused in 'ap' mode (as reference)
+        _init_trunk(self)
+        if zero_init_residual:
+            for m in self.modules():
+                if isinstance(m, BasicBlock):
+                    nn.init.constant_(m.bn2.weight, 0)
+
+    def _make_layer(self, block, planes, blocks, stride=1, use_cbam=False):
+        down = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            down = nn.Sequential(conv1x1(self.inplanes, planes * block.expansion, stride),
+                                 nn.BatchNorm2d(planes * block.expansion))
+        seq = [block(self.inplanes, planes, stride, down, use_cbam=use_cbam)]
+        self.inplanes = planes * block.expansion
+        seq += [block(self.inplanes, planes, use_cbam=use_cbam) for _ in range(1, blocks)]
+        return nn.Sequential(*seq)
+
+    def forward(self, x):
+        x = self._run_stages(x)
+        if self.agg_mode == "ap":
+            x = self.avgpool(x).flatten(1)
+        if self.agg_mode == "fc":
+            x = self.fc(x.flatten(1))
+        return x
+
+
+class ResNetV2(_Trunk):
+    def __init__(self, block, layers, num_classes=256, zero_init_residual=False, agg_mode="ap", fmap_out_size=3,
+                 use_cbam=False):
+        super().__init__()
+        self.agg_mode = agg_mode
+        self._stages(block, layers, use_cbam)
+        self.bn5 = nn.BatchNorm2d(self.inplanes)
+        self.relu5 = nn.ReLU(True)
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+        self.fc = nn.Linear(512 * fmap_out_size * fmap_out_size, num_classes)
+        _init_trunk(self)
+        if zero_init_residual:
+            for m in self.modules():
+                if isinstance(m, BasicBlockV2):
+                    nn.init.constant_(m.bn1.weight, 0)
+
+    def _make_layer(self, block, planes, blocks, stride=1, use_cbam=False):
+        down = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            down = nn.Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False)
+        seq = [block(self.inplanes, planes, stride, down, stride == 1, use_cbam=use_cbam)]
+        self.inplanes = planes * block.expansion
+        seq += [block(self.inplanes, planes, use_cbam=use_cbam) for _ in range(1, blocks)]
+        return nn.Sequential(*seq)
+
+    def forward(self, x):
+        x = self.relu5(self.bn5(self._run_stages(x)))
+        x = self.avgpool(x).flatten(1)       # the reference pools (twice in 'ap' mode: idempotent) then flattens
+        if self.agg_mode == "fc":
+            x = self.fc(x)
+        return x

@@ -326,6 +326,20 @@ def case_resnet3d(name, seed, B=2, T=3):
          dx=grad_digest(x.grad.numpy()), param_names=np.array(sorted(n for n, _ in m.named_parameters())), **grads)
 
 
+def case_init_digests(name):
+    """Initial weights of the reference constructors under torch.manual_seed(12345) (the
+    reference's default --seed, train.py:49), as digests: pins the RNG-order of the init recipes."""
+    out = {}
+    ctors = {"gru": lambda: GRU(24, 16, 2, 3, 2), "tcn": lambda: TemporalConvNet(8, [12, 12], 3),
+             "att": lambda: AttFusion([12, 20], 6), "cbam": lambda: CBAM(32)}
+    for tag, ctor in ctors.items():
+        torch.manual_seed(12345)
+        m = ctor()
+        for n, p in m.named_parameters():
+            out["%s.%s" % (tag, n)] = grad_digest(p.detach().numpy())
+    save(name, **out)
+
+
 def main():
     only = set(sys.argv[1:])
 
@@ -362,6 +376,8 @@ def main():
     if want("c3"):
         case_c3("c3_av_graph", 2, 300, 12345)
         case_c3("c3_av_graph_small", 3, 17, 800, d_a=10, d_v=12, nh=512)
+    if want("init"):
+        case_init_digests("init_digests")
     if want("c5"):
         case_affwild_av("c5_affwild_av", 900)
         case_resnet3d("c5_resnet3d_cbam", 910)

@@ -1,0 +1,477 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Every test drives the HIP kernels through
+the C ABI (ctypes) and checks them against (a) golden vectors produced by the reference
+itself (tests/golden) and (b) the numpy oracle on fresh seeded inputs.
+Tolerance: north_star demands VA outputs within 1e-4 (fp32) of the reference."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from golden.recipe import (fill_module, fill_by_shapes, draw, grad_digest, c3_param_shapes)
+from oracle import m3t_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+DEV = "cuda:0"
+
+
+def close(a, b, tol=TOL, what=""):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    a, b = a.astype(np.float64), b.astype(np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = float(np.abs(a - b).max()) if a.size else 0.0
+    scale = max(1.0, float(np.abs(b).max()) if b.size else 1.0)
+    assert err <= tol * scale, "%s: max abs err %.3e (scale %.2f, tol %.1e)" % (what, err, scale, tol)
+
+
+def dev(a, grad=False):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    return t.requires_grad_(True) if grad else t
+
+
+def load_params(module, g, prefix="p."):
+    with torch.no_grad():
+        for n, t in list(module.named_parameters()) + list(module.named_buffers()):
+            if t.dtype.is_floating_point:
+                t.copy_(torch.from_numpy(g[prefix + n]))
+    return module
+
+
+def check_grads(module, g, tol=TOL, prefix="g."):
+    names = [k[len(prefix):] for k in g if k.startswith(prefix)]
+    got = dict(module.named_parameters())
+    assert sorted(names) == sorted(n for n, p in got.items() if p.grad is not None)
+    for n in names:
+        close(got[n].grad, g[prefix + n], tol, n)
+
+
+def check_digests(named_grads, g, tol=3e-4, prefix="gd."):
+    for n, grad in named_grads:
+        ref = g[prefix + n]
+        got = grad_digest(grad.detach().cpu().numpy())
+        assert abs(got[0] - ref[0]) <= tol * max(1.0, ref[0]), (n, got[0], ref[0])
+        scale = max(1.0, float(np.abs(ref[2:]).max()))
+        assert float(np.abs(got[2:] - ref[2:]).max()) <= tol * scale, (n, got[2:], ref[2:])
+
+
+# ------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (33, 9, 17), (128, 128, 16), (300, 257, 130), (1024, 96, 2048), (64, 48, 9600)])
+@pytest.mark.parametrize("tA,tB", [(0, 1), (0, 0), (1, 0), (1, 1)])
+def test_sgemm(M, N, K, tA, tB):
+    from m3t import ops
+    rs = np.random.RandomState(M * 7 + N * 3 + K + tA * 2 + tB)
+    A = rs.standard_normal((K, M) if tA else (M, K)).astype(np.float32)
+    B = rs.standard_normal((N, K) if tB else (K, N)).astype(np.float32)
+    bias = rs.standard_normal(N).astype(np.float32)
+    C0 = rs.standard_normal((M, N)).astype(np.float32)
+    ref = (A.T if tA else A).astype(np.float64) @ (B.T if tB else B).astype(np.float64)
+    dA, dB, dbias = dev(A), dev(B), dev(bias)
+    out = torch.empty(M, N, device=DEV)
+    ops.sgemm(tA, tB, M, N, K, dA, 0, A.shape[1], dB, 0, B.shape[1], out, 0, N)
+    close(out, ref, 2e-5 * max(1, K ** 0.5 / 8), "plain")
+    out2 = dev(C0.copy())
+    ops.sgemm(tA, tB, M, N, K, dA, 0, A.shape[1], dB, 0, B.shape[1], out2, 0, N, bias=dbias, act=1, accumulate=True)
+    close(out2, np.maximum(ref + bias, 0) + C0, 2e-5 * max(1, K ** 0.5 / 8), "bias+relu+acc")
+
+
+def test_sgemm_strided_and_segmented():
+    """column-sliced operands (lda/ldc > width) and the per-clip segment map used for dW_hh."""
+    from m3t import ops
+    rs = np.random.RandomState(5)
+    B_, T, H = 3, 7, 20
+    dgh = rs.standard_normal((B_, T, 3 * H)).astype(np.float32)
+    out = rs.standard_normal((B_, T, 2 * H)).astype(np.float32)
+    for d, (a_off, b_off) in enumerate([(1, 0), (0, 1)]):
+        ref = np.zeros((3 * H, H))
+        for b in range(B_):
+            for t in range(T):
+                tp = t - 1 if d == 0 else t + 1
+                if 0 <= tp < T:
+                    ref += np.outer(dgh[b, t], out[b, tp, d * H:(d + 1) * H])
+        got = torch.empty(3 * H, H, device=DEV)
+        ops.sgemm(1, 0, 3 * H, H, B_ * (T - 1), dev(dgh), 0, 3 * H, dev(out), d * H, 2 * H, got, 0, H,
+                  seg=(T - 1, T, a_off, b_off))
+        close(got, ref, 1e-5, "dW_hh dir %d" % d)
+
+
+def test_colsum_transpose():
+    from m3t import ops
+    rs = np.random.RandomState(6)
+    X = rs.standard_normal((9600, 70)).astype(np.float32)
+    out = torch.empty(40, device=DEV)
+    ops.colsum(dev(X), 10, 9600, 40, 70, out)
+    close(out, X[:, 10:50].astype(np.float64).sum(0), 2e-5, "colsum")
+    S = rs.standard_normal((37, 65)).astype(np.float32)
+    close(ops.transpose2d(dev(S)), S.T, 0, "transpose")
+
+
+# ------------------------------------------------------------------------------ GRU
+@pytest.mark.parametrize("name", ["gru_small", "gru_nofc_h", "gru_fc3", "gru_scorer", "gru_t1"])
+def test_gru_golden(name):
+    from models.rnn import GRU
+    g = load_golden(name)
+    a = [int(v) for v in g["args"]]
+    (I, H, L, nC), nFC, ret_h = a[:4], (a[4] if len(a) == 6 else 1), a[-1]
+    m = load_params(GRU(I, H, L, nC, nFC, return_h=bool(ret_h)), g).to(DEV)
+    x = dev(g["x"], True)
+    out = m(x)
+    if ret_h:
+        y, h = out
+        close(h, g["h"], TOL, "h_n")
+        loss = (y * dev(g["ct"])).sum() + (h * dev(g["ct_h"])).sum()
+    else:
+        y = out
+        loss = (y * dev(g["ct"])).sum()
+    close(y, g["y"], TOL, "y")
+    loss.backward()
+    close(x.grad, g["dx"], TOL, "dx")
+    check_grads(m, g)
+
+
+@pytest.mark.parametrize("B,T,I,H,L", [(5, 33, 40, 48, 2), (32, 20, 64, 128, 1), (37, 6, 30, 20, 2), (2, 50, 12, 256, 1)])
+def test_gru_vs_oracle(B, T, I, H, L):
+    """fresh seeded inputs, shapes that exercise row/unit masking (B>32, H%16!=0, H%4!=0 is excluded by torch shapes)."""
+    from models.rnn import GRU
+    rs = np.random.RandomState(B + T + I + H)
+    m = fill_module(GRU(I, H, L, 3, 2), 77).to(DEV)
+    xn = draw(rs, (B, T, I))
+    ct = draw(rs, (B, T, 3))
+    p = {n: t.detach().cpu().numpy().astype(np.float64) for n, t in m.named_parameters()}
+    y_ref, _, cache = O.gru_module_fwd(xn.astype(np.float64), p, L, 3, 2)
+    dx_ref, g_ref = O.gru_module_bwd(ct.astype(np.float64), cache, p, L)
+    x = dev(xn, True)
+    y = m(x)
+    close(y, y_ref, TOL, "y")
+    (y * dev(ct)).sum().backward()
+    close(x.grad, dx_ref, TOL, "dx")
+    for n, prm in m.named_parameters():
+        close(prm.grad, g_ref[n], 2e-4, n)
+
+
+def test_grouped_grus_equal_separate():
+    """one grouped scan over several modules == module-by-module scans, bit for bit."""
+    from models.rnn import GRU, run_grus
+    torch.manual_seed(3)
+    a, b = GRU(24, 32, 2, -1).to(DEV), GRU(10, 16, 2, 4, 2).to(DEV)
+    xa, xb = torch.randn(4, 15, 24, device=DEV), torch.randn(4, 15, 10, device=DEV)
+    ya, yb = run_grus([a, b], [xa, xb])
+    assert torch.equal(ya, a(xa)) and torch.equal(yb, b(xb))
+
+
+# ------------------------------------------------------------------------------ TCN
+@pytest.mark.parametrize("name", ["tcn_small", "tcn_k2_deep", "tcn_short"])
+def test_tcn_golden(name):
+    from models.tcn import TemporalConvNet
+    g = load_golden(name)
+    a = [int(v) for v in g["args"]]
+    m = load_params(TemporalConvNet(a[0], a[2:], a[1]), g).to(DEV).eval()
+    x = dev(g["x"], True)
+    y = m(x)
+    close(y, g["y"], TOL, "y")
+    (y * dev(g["ct"])).sum().backward()
+    close(x.grad, g["dx"], TOL, "dx")
+    check_grads(m, g)
+
+
+def test_tcn_vs_oracle_full_width():
+    from models.tcn import TemporalConvNet
+    rs = np.random.RandomState(11)
+    m = fill_module(TemporalConvNet(128, [512, 512], 3), 12).to(DEV).eval()
+    xn, ct = draw(rs, (3, 128, 100)), draw(rs, (3, 512, 100))
+    p = {n: t.detach().cpu().numpy().astype(np.float64) for n, t in m.named_parameters()}
+    y_ref, caches = O.tcn_fwd(xn.astype(np.float64), p, 2)
+    dx_ref, g_ref = O.tcn_bwd(ct.astype(np.float64), caches, p)
+    x = dev(xn, True)
+    y = m(x)
+    close(y, y_ref, TOL, "y")
+    (y * dev(ct)).sum().backward()
+    close(x.grad, dx_ref, TOL, "dx")
+    for n, prm in m.named_parameters():
+        close(prm.grad, g_ref[n], 2e-4, n)
+
+
+def test_tcn_train_mode_dropout_runs():
+    from models.tcn import TemporalConvNet
+    torch.manual_seed(0)
+    m = TemporalConvNet(16, [32, 32], 3).to(DEV).train()
+    x = torch.randn(2, 16, 40, device=DEV, requires_grad=True)
+    y = m(x)
+    y.sum().backward()
+    assert torch.isfinite(y).all() and torch.isfinite(x.grad).all()
+    assert not torch.equal(y, m(x))          # fresh masks every call
+
+
+# ------------------------------------------------------------------------------ AttFusion
+@pytest.mark.parametrize("name", ["attfusion_same", "attfusion_proj"])
+def test_att_fusion_golden(name):
+    from models.att_fusion import AttFusion
+    g = load_golden(name)
+    a = [int(v) for v in g["args"]]
+    m = load_params(AttFusion([a[0], a[1]], a[2]), g).to(DEV)
+    xa, xv = dev(g["x_a"], True), dev(g["x_v"], True)
+    y = m(xa, xv)
+    close(y, g["y"], TOL, "y")
+    (y * dev(g["ct"])).sum().backward()
+    close(xa.grad, g["dx_a"], TOL, "dx_a")
+    close(xv.grad, g["dx_v"], TOL, "dx_v")
+    check_grads(m, g)
+
+
+def test_att_fuse_kernel_vs_oracle_wide():
+    from m3t import ops
+    rs = np.random.RandomState(21)
+    rows, D = 1000, 512
+    sv, sa = draw(rs, (rows, 1)), draw(rs, (rows, 1))
+    xv, xa, ct = draw(rs, (rows, D)), draw(rs, (rows, D)), draw(rs, (rows, D))
+    f_ref, cache = O.att_fuse_core_fwd(*(a.astype(np.float64) for a in (sv, sa, xv, xa)))
+    ref = O.att_fuse_core_bwd(ct.astype(np.float64), cache)
+    t = [dev(a, True) for a in (sv, sa, xv, xa)]
+    f = ops.att_fuse(*t)
+    close(f, f_ref, 1e-5, "f")
+    (f * dev(ct)).sum().backward()
+    for got, want, nm in zip(t, ref, ("ds_v", "ds_a", "dx_v", "dx_a")):
+        close(got.grad, want, 1e-5, nm)
+    w0 = (f - t[3]).detach() / (t[2] - t[3]).detach()          # convex weights confined to [0.269, 0.731]
+    assert float(w0.min()) > 0.26 and float(w0.max()) < 0.74
+
+
+# ------------------------------------------------------------------------------ CBAM
+@pytest.mark.parametrize("name", ["cbam_train", "cbam_eval", "cbam_c64"])
+def test_cbam_golden(name):
+    from models.cbam import CBAM
+    g = load_golden(name)
+    C_ = g["x"].shape[1]
+    m = load_params(CBAM(C_), g).to(DEV)
+    m.train(bool(g["training"]))
+    x = dev(g["x"], True)
+    y = m(x)
+    close(y, g["y"], TOL, "y")
+    close(m.SpatialGate.spatial.bn.running_mean, g["running_mean_after"], 1e-5, "running_mean")
+    close(m.SpatialGate.spatial.bn.running_var, g["running_var_after"], 1e-5, "running_var")
+    (y * dev(g["ct"])).sum().backward()
+    close(x.grad, g["dx"], TOL, "dx")
+    check_grads(m, g)
+
+
+@pytest.mark.parametrize("name", ["resnet_cbam_eval", "resnet_cbam_train"])
+def test_resnet_cbam_golden(name):
+    from models.resnet import ResNet, BasicBlock
+    g = load_golden(name)
+    m = fill_module(ResNet(BasicBlock, [1, 1, 1, 1], use_cbam=True), int(g["seed"]) + 1).to(DEV)
+    m.train(bool(g["training"]))
+    x = dev(g["x"], True)
+    y = m(x)
+    close(y, g["y"], 2e-4, "y")
+    (y * dev(g["ct"])).sum().backward()
+    close(x.grad, g["dx"], 5e-4, "dx")
+    check_digests([(n, p.grad) for n, p in m.named_parameters() if p.grad is not None], g, tol=1e-3)
+
+
+# ------------------------------------------------------------------------------ loss
+def test_losses_golden():
+    from m3t import ops
+    g = load_golden("losses")
+    y = dev(g["y_hat"], True)
+    loss, stats = ops.va_loss(y, dev(g["valence"]), dev(g["arousal"]), dev(g["class_expr"]), dev(g["expr_valid"]),
+                              iv=7, ia=8, n_expr=7)
+    s = stats.cpu().numpy()
+    close(loss, g["loss"], 1e-5, "loss")
+    close(s[1], g["loss_v"], 1e-5, "loss_v"); close(s[2], g["loss_a"], 1e-5, "loss_a"); close(s[3], g["loss_expr"], 1e-5, "ce")
+    close(s[6], g["ccc_v"], 1e-5, "ccc_v")
+    assert int(s[4]) == int(g["expr_valid"].sum())
+    loss.backward()
+    close(y.grad, g["dy_hat"], 1e-6, "dy_hat")
+
+
+def test_loss_helper_methods_and_no_valid_rows():
+    from models.model import AffWild2VA
+    g = load_golden("losses")
+    m = AffWild2VA(_hp(modality="audio"))
+    yh = dev(g["y_hat"])
+    close(m.ccc_loss(yh[..., 7].contiguous(), dev(g["valence"])), g["loss_v"], 1e-5, "ccc_loss")
+    close(m.ce_loss(yh[..., :7].contiguous(), dev(g["class_expr"]), dev(g["expr_valid"])), g["loss_expr"], 1e-5, "ce_loss")
+    from m3t import ops
+    none_valid = torch.zeros_like(dev(g["expr_valid"]))
+    loss, stats = ops.va_loss(yh, dev(g["valence"]), dev(g["arousal"]), dev(g["class_expr"]), none_valid, iv=7, ia=8, n_expr=7)
+    close(loss, 0.5 * g["loss_v"] + 0.5 * g["loss_a"], 1e-5, "loss without expr term (model.py:173-174)")
+
+
+# ------------------------------------------------------------------------------ configs
+def _hp(**kw):
+    from models.model import AffWild2VA
+    ns = AffWild2VA.add_model_specific_args(argparse.ArgumentParser(add_help=False)).parse_args([])
+    for k, v in kw.items():
+        setattr(ns, k, v)
+    return ns
+
+
+def _c3_inputs(seed, B, T, d_a, d_v):
+    rs = np.random.RandomState(seed)
+    xa, xv = draw(rs, (B, T, d_a)), draw(rs, (B, T, d_v))
+    val, aro = draw(rs, (B, T), "uniform_pm1"), draw(rs, (B, T), "uniform_pm1")
+    expr = rs.randint(0, 7, (B, T)).astype(np.int64)
+    valid = rs.uniform(size=(B, T)) < 0.7
+    return xa, xv, val, aro, expr, valid
+
+
+@pytest.mark.parametrize("name", ["c3_av_graph_small", "c3_av_graph"])
+def test_c3_graph_golden(name):
+    """Config C3/C4 (the bench workload) against the reference's own forward/backward: outputs
+    within 1e-4, CCC identical to 3 d.p., gradient digests."""
+    from m3t.workloads import AVFeatureGraph
+    from m3t import ops
+    g = load_golden(name)
+    B, T, d_a, d_v, nh = [int(v) for v in g["dims"]]
+    seed = int(g["seed"])
+    m = fill_module(AVFeatureGraph(d_a, d_v, nh), seed + 1).to(DEV)
+    xa, xv, val, aro, expr, valid = _c3_inputs(seed, B, T, d_a, d_v)
+    txa, txv = dev(xa, True), dev(xv, True)
+    y = m(txa, txv)
+    close(y, g["y"], TOL, "y")
+    loss, stats = ops.va_loss(y, dev(val), dev(aro), dev(expr), dev(valid), iv=7, ia=8, n_expr=7)
+    close(loss, g["loss"], TOL, "loss")
+    s = stats.cpu().numpy()
+    assert round(float(s[6]), 3) == round(float(g["ccc_v"]), 3)
+    assert round(float(s[7]), 3) == round(float(g["ccc_a"]), 3)
+    loss.backward()
+    close(txa.grad[:, ::25], g["dx_a_full"], TOL, "dx_a")
+    close(txv.grad[:, ::25], g["dx_v_full"], TOL, "dx_v")
+    check_digests(list((n, p.grad) for n, p in m.named_parameters()), g)
+
+
+def test_c1_tcn_head_golden():
+    from m3t.workloads import TcnHead
+    from m3t import ops
+    g = load_golden("c1_tcn_head")
+    seed = int(g["seed"])
+    m = fill_module(TcnHead(128, 512, 2), seed + 1).to(DEV).eval()
+    rs = np.random.RandomState(seed)
+    x = dev(draw(rs, tuple(int(v) for v in g["in_shape"])), True)
+    y = m(x)
+    close(y, g["y"], TOL, "y")
+    B, T = y.shape[:2]
+    val, aro = draw(rs, (B, T), "uniform_pm1"), draw(rs, (B, T), "uniform_pm1")
+    loss, _ = ops.va_loss(y, dev(val), dev(aro))
+    close(loss, g["loss"], TOL, "loss")
+    loss.backward()
+    close(x.grad[:, :, ::10], g["dx_full"], TOL, "dx")
+    check_digests(list((n, p.grad) for n, p in m.named_parameters()), g)
+
+
+def test_c2_tcn_gru_golden():
+    from m3t.workloads import TcnGru
+    from m3t import ops
+    g = load_golden("c2_tcn_gru")
+    seed = int(g["seed"])
+    m = fill_module(TcnGru(256, 512), seed + 1).to(DEV).eval()
+    rs = np.random.RandomState(seed)
+    x = dev(draw(rs, tuple(int(v) for v in g["in_shape"])), True)
+    y = m(x)
+    close(y, g["y"], TOL, "y")
+    B, T = y.shape[:2]
+    val, aro = draw(rs, (B, T), "uniform_pm1"), draw(rs, (B, T), "uniform_pm1")
+    loss, _ = ops.va_loss(y, dev(val), dev(aro))
+    close(loss, g["loss"], TOL, "loss")
+    loss.backward()
+    close(x.grad[:, :, ::10], g["dx_full"], TOL, "dx")
+    check_digests(list((n, p.grad) for n, p in m.named_parameters()), g)
+
+
+def _affwild_batch(rs, B, T, video=False):
+    batch = {}
+    if video:
+        batch["video"] = dev(rs.randint(0, 256, (B, 3, T, 112, 112)).astype(np.float32))
+        batch["se_features"] = dev(draw(rs, (B, 512, T)))
+    batch["audio"] = dev(draw(rs, (B, T, 200)))
+    batch["label_valence"] = dev(draw(rs, (B, T), "uniform_pm1"))
+    batch["label_arousal"] = dev(draw(rs, (B, T), "uniform_pm1"))
+    batch["class_expr"] = dev(rs.randint(0, 7, (B, T)).astype(np.int64))
+    batch["expr_valid"] = dev(rs.uniform(size=(B, T)) < 0.7)
+    return batch
+
+
+def test_c1_affwild_audio_training_step_golden():
+    from models.model import AffWild2VA
+    g = load_golden("c1_affwild_audio")
+    seed = int(g["seed"])
+    m = fill_module(AffWild2VA(_hp(modality="audio", loss="ccc_mtl")), seed + 1).to(DEV).eval()
+    batch = _affwild_batch(np.random.RandomState(seed), 4, 100)
+    close(m(batch), g["y"], TOL, "y")
+    out = m.training_step(batch, 0)
+    close(out["loss"], g["loss"], TOL, "loss")
+    close(out["log"]["loss_v"], g["loss_v"], TOL, "loss_v")
+    close(out["log"]["loss_expr"], g["loss_expr"], TOL, "loss_expr")
+    assert abs(out["progress_bar"]["acc_expr"] - float(g["acc_expr"])) < 1e-6
+    out["loss"].backward()
+    check_digests(list((n, p.grad) for n, p in m.named_parameters()), g)
+
+
+def test_c5_affwild_av_golden():
+    """Full AffWild2VA audiovisual/attention/v2p_split on raw frames (conv stem on MIOpen)."""
+    from models.model import AffWild2VA
+    g = load_golden("c5_affwild_av")
+    seed = int(g["seed"])
+    B, T = [int(v) for v in g["dims"]]
+    m = fill_module(AffWild2VA(_hp(modality="audiovisual", fusion_type="attention", loss="ccc_mtl", window=T)),
+                    seed + 1).to(DEV).eval()
+    batch = _affwild_batch(np.random.RandomState(seed), B, T, video=True)
+    close(m(batch), g["y"], 2e-4, "y")
+    out = m.training_step(batch, 0)
+    close(out["loss"], g["loss"], 2e-4, "loss")
+    out["loss"].backward()
+    check_digests([(n, p.grad) for n, p in m.named_parameters() if p.grad is not None], g, tol=2e-3)
+
+
+def test_c5_resnet3d_cbam_golden():
+    from models.backbone import VA_3DResNet
+    g = load_golden("c5_resnet3d_cbam")
+    seed = int(g["seed"])
+    B, T = [int(v) for v in g["dims"]]
+    m = fill_module(VA_3DResNet(frameLen=T, resnet_ver="v1", use_cbam=True, nClasses=2, nFCs=2), seed + 1).to(DEV).eval()
+    rs = np.random.RandomState(seed)
+    x = dev(rs.randint(0, 256, (B, 3, T, 112, 112)).astype(np.float32))
+    x = ((x - 127.5) / 127.5).requires_grad_(True)
+    y = m(x)
+    close(y, g["y"], 2e-4, "y")
+    (y * dev(g["ct"])).sum().backward()
+    check_digests([(n, p.grad) for n, p in m.named_parameters() if p.grad is not None], g, tol=2e-3)
+
+
+# ------------------------------------------------------------------------------ full-size properties
+def test_full_size_properties_c3():
+    """BASELINE size (B=32, T=300): determinism, clip independence (permutation equivariance),
+    exact linearity of the backward pass in the cotangent."""
+    from m3t.workloads import AVFeatureGraph
+    torch.manual_seed(12345)
+    m = AVFeatureGraph().to(DEV)
+    xa = torch.randn(32, 300, 128, device=DEV)
+    xv = torch.randn(32, 300, 256, device=DEV, requires_grad=True)
+    y1 = m(xa, xv)
+    y2 = m(xa, xv)
+    assert torch.equal(y1, y2), "forward is not deterministic"
+    assert torch.isfinite(y1).all()
+    perm = torch.randperm(32, device=DEV)
+    y3 = m(xa[perm].contiguous(), xv[perm].contiguous())
+    assert torch.equal(y3, y1[perm]), "clips are not independent"
+    ct = torch.randn_like(y1)
+    (g1,) = torch.autograd.grad(y1, xv, ct, retain_graph=True)
+    (g2,) = torch.autograd.grad(y1, xv, 2 * ct)
+    assert torch.equal(2 * g1, g2), "backward is not linear in the cotangent"
+
+
+def test_time_reversal_symmetry_of_bigru():
+    """swap forward/reverse weights + reverse time => output halves swap and time reverses."""
+    from models.rnn import GRU
+    torch.manual_seed(5)
+    a = GRU(16, 32, 1, -1).to(DEV)
+    b = GRU(16, 32, 1, -1).to(DEV)
+    with torch.no_grad():
+        for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+            getattr(b.gru, k + "_l0").copy_(getattr(a.gru, k + "_l0_reverse"))
+            getattr(b.gru, k + "_l0_reverse").copy_(getattr(a.gru, k + "_l0"))
+    x = torch.randn(3, 21, 16, device=DEV)
+    ya, yb = a(x), b(x.flip(1).contiguous())
+    assert torch.equal(ya[..., :32], yb.flip(1)[..., 32:]) and torch.equal(ya[..., 32:], yb.flip(1)[..., :32])
