@@ -65,6 +65,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch must load ITS bundled HIP runtime (libamdhip64.so.7, same SONAME as /opt/rocm's) before this
+    # library is mapped: whichever copy is mapped first serves both, and torch cannot find the GPU on the other one.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise M3THipError(
             "libm3t_hip.so not found at %s -- build it with `make -C %s` (or __graft_entry__.build()). "
