@@ -79,7 +79,11 @@ typedef struct {
     int H, reverse, ldx, xoff, ldo, ooff;
 } m3t_gru_fwd_desc;
 
-int m3t_gru_scan_fwd(const m3t_gru_fwd_desc* scans, int n_scans, int B, int T, void* stream);
+/* ws (optional, 16-B aligned): scratch for the fragment-ordered fast path -- per scan 3*H*H floats of re-laid
+ * weights + 2 * ceil32(B) * H floats of ping-pong state; without it (or when H % 16 != 0) a slower kernel that
+ * reads the row-major operands directly is used.  Results are identical either way. */
+int m3t_gru_scan_fwd(const m3t_gru_fwd_desc* scans, int n_scans, int B, int T,
+                     float* ws, size_t ws_bytes, void* stream);
 
 /* BPTT of the scans above (autograd of nn.GRU).  Per scan:
  *   dgx[B,T,ldg][goff..goff+3H) = grad wrt xproj  = (dr~, dz~, dn~)
@@ -98,7 +102,9 @@ typedef struct {
     int H, reverse, ldo, ooff, ldg, goff;
 } m3t_gru_bwd_desc;
 
-int m3t_gru_scan_bwd(const m3t_gru_bwd_desc* scans, int n_scans, int B, int T, void* stream);
+/* ws as above: per scan 3*H*H + 2 * ceil32(B) * 3H floats. */
+int m3t_gru_scan_bwd(const m3t_gru_bwd_desc* scans, int n_scans, int B, int T,
+                     float* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * Attention-fusion reduction (models/att_fusion.py:21-25) on [B*T] frames of D floats:

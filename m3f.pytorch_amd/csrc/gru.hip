@@ -6,9 +6,10 @@
 //     every independent stack), so the chip sees sum_s (H_s/16) x ceil(B/32) workgroups;
 //   * a workgroup owns 16 hidden units of one scan: the three gate columns r,z,n of those
 //     units (a [32 x 48] tile of h_{t-1} W_hh^T, K = H) on fp32 MFMA 16x16x4 (exact fp32),
-//     K split over its 4 waves, operands loaded straight to registers as float4 along K
-//     (W_hh stays L2/MALL-resident across the T launches), fixed-order LDS reduction, then
-//     the gate math for its own units -- so gates never travel through HBM un-fused.
+//     K split over its 8 waves, operands loaded straight to registers as float4 along K with
+//     EVERY load of the pass in flight before the first MFMA (one L2 round trip per step, not
+//     one per k-chunk; W_hh stays L2/MALL-resident across the T launches), fixed-order LDS
+//     reduction, then the gate math for its own units -- gates never travel un-fused.
 // Backward runs the same structure in reverse time: dh_{t} = dout_t + z_{t+1} dh_{t+1}
 // + dgh_{t+1} W_hh, with the matmul of step t+1 and the gate derivative of step t fused
 // in one launch; dW_hh / dW_ih / dx are left to big GEMMs after the scan.
@@ -16,8 +17,12 @@
 
 namespace {
 
-constexpr int UB = 16;   // hidden units per workgroup
-constexpr int RB = 32;   // batch rows per workgroup
+constexpr int UB = 16;        // hidden units per workgroup
+constexpr int RB = 32;        // batch rows per workgroup
+constexpr int NW = 8;         // waves per workgroup (512 threads): K is split 8 ways
+constexpr int NT = NW * 64;
+constexpr int CF = 4;         // k-chunks (16 wide) a wave keeps in flight, forward  (covers H  <= 512 in one pass)
+constexpr int CB = 12;        // k-chunks a wave keeps in flight, backward            (covers 3H <= 1536 in one pass)
 
 struct FwdGroup {
     m3t_gru_fwd_desc d[M3T_MAX_SCANS];
@@ -40,39 +45,265 @@ __device__ __forceinline__ float4 ld4(const float* __restrict__ p, int nvalid, b
     return v;
 }
 
-// acc[rt][ct] += A[rows r0+16rt.., K] * Bt[cols.., K]^T on MFMA 16x16x4, this wave taking
-// the 16-wide k chunks c = wave, wave+4, ...  A row stride lda, Bt row stride ldb (both K-contiguous).
-template <int CT>
-__device__ __forceinline__ void wave_mma(const float* __restrict__ A, size_t lda, const bool (&arow_ok)[2],
-                                         const size_t (&arow_off)[2], const float* __restrict__ Bt, size_t ldb,
-                                         const bool (&brow_ok)[CT], const size_t (&brow_off)[CT], int K, bool vecA,
-                                         bool vecB, int wave, int lane, f32x4 (&acc)[2][CT]) {
+// acc[rt][ct] += A[2 row tiles, K] * Bt[CT col tiles, K]^T on fp32 MFMA 16x16x4.  Wave w owns the 16-wide
+// k chunks c = w, w+NW, ...  All of a pass's loads (NC chunks x (2+CT) float4 per lane) are issued before the
+// first MFMA so ONE L2 round trip covers the pass instead of one per chunk.
+// FAST: K % 16 == 0 and 16-B aligned rows -- no predicates (out-of-range rows/cols are clamped by the caller
+// and their results discarded).
+template <int CT, int NC, bool FAST>
+__device__ __forceinline__ void wave_mma(const float* __restrict__ A, const size_t (&arow)[2], const bool (&aok)[2],
+                                         const float* __restrict__ Bt, const size_t (&brow)[CT], const bool (&bok)[CT],
+                                         int K, bool vecA, bool vecB, int wave, int lane, f32x4 (&acc)[2][CT]) {
     const int kq = (lane >> 4) * 4;
     const int nchunks = (K + 15) >> 4;
-    for (int c = wave; c < nchunks; c += 4) {
-        const int kk = c * 16 + kq;
-        const int nv = K - kk;
-        float4 a[2], b[CT];
+    for (int c0 = wave; c0 < nchunks; c0 += NW * NC) {
+        float4 a[NC][2], b[NC][CT];
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-            a[rt] = (arow_ok[rt] && nv > 0) ? ld4(A + arow_off[rt] + kk, nv, vecA) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < NC; ++i) {
+            const int c = c0 + i * NW;
+            const int kk = c * 16 + kq;
+            if (FAST) {
+                if (c < nchunks) {
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-            b[ct] = (brow_ok[ct] && nv > 0) ? ld4(Bt + brow_off[ct] + kk, nv, vecB) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int rt = 0; rt < 2; ++rt) a[i][rt] = *reinterpret_cast<const float4*>(A + arow[rt] + kk);
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+                    for (int ct = 0; ct < CT; ++ct) b[i][ct] = *reinterpret_cast<const float4*>(Bt + brow[ct] + kk);
+                }
+            } else {
+                const int nv = c < nchunks ? K - kk : 0;
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].x, b[ct].x, acc[rt][ct], 0, 0, 0);
-                acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].y, b[ct].y, acc[rt][ct], 0, 0, 0);
-                acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].z, b[ct].z, acc[rt][ct], 0, 0, 0);
-                acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].w, b[ct].w, acc[rt][ct], 0, 0, 0);
+                for (int rt = 0; rt < 2; ++rt)
+                    a[i][rt] = (aok[rt] && nv > 0) ? ld4(A + arow[rt] + kk, nv, vecA) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+                    b[i][ct] = (bok[ct] && nv > 0) ? ld4(Bt + brow[ct] + kk, nv, vecB) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
+        }
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            if (FAST && c0 + i * NW >= nchunks) break;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][rt].x, b[i][ct].x, acc[rt][ct], 0, 0, 0);
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][rt].y, b[i][ct].y, acc[rt][ct], 0, 0, 0);
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][rt].z, b[i][ct].z, acc[rt][ct], 0, 0, 0);
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][rt].w, b[i][ct].w, acc[rt][ct], 0, 0, 0);
+                }
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void gru_step_fwd_kernel(FwdGroup g, int B, int T, int step) {
-    __shared__ float red[4][3][RB][UB];   // [wave][gate][row][unit], 24 KiB
+// ------------------------------------------------------------------------------------------------
+// Fragment-ordered fast path.  A wave's MFMA 16x16x4 operand for a 16-wide k chunk is, per lane,
+// (row|col = lane&15, k = 4*(lane>>4) .. +3): read from row-major [rows][K] storage that is 16 rows x 64 B per
+// wave instruction, which the vector memory path serves at about HALF the rate of a contiguous 1 KiB request
+// (measured: 36 vs 73 GB/s per CU, tools/patprobe.hip).  So both operands are kept in the exact order the lanes
+// consume them -- value(lane, e) at [chunk][tile][lane][e] -- and every operand load is one coalesced 1 KiB
+// wave instruction:
+//   wfrag : W_hh re-laid once per call by a prep kernel            [unit-block][chunk][gate tile][lane][4]
+//   hfrag : h_t, written by the gate-math epilogue of step t in    [row-block][chunk][row tile][lane][4]
+//           addition to out[b,t,:] (ping-pong by step parity): each workgroup owns exactly chunk == its unit-block,
+//           i.e. one contiguous 2 KiB piece.
+// Backward mirrors it with dgh_t (3H wide) and W_hh^T.
+__global__ void wfrag_fwd_prep_kernel(const float* __restrict__ w_hh, float* __restrict__ wfrag, int H) {
+    const int nch = H >> 4;
+    const size_t total = (size_t)3 * H * H;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int e = i & 3, l = (i >> 2) & 63;
+        size_t r = i >> 8;
+        const int ct = r % 3; r /= 3;
+        const int c = r % nch, ub = r / nch;
+        wfrag[i] = w_hh[((size_t)ct * H + ub * 16 + (l & 15)) * H + c * 16 + (l >> 4) * 4 + e];
+    }
+}
+// wtfrag[ub][c][lane][e] = W_hh[k = 16c + 4*(lane>>4) + e][ub*16 + (lane&15)] = w_hh_t[ub*16 + (lane&15)][k]
+__global__ void wfrag_bwd_prep_kernel(const float* __restrict__ w_hh_t, float* __restrict__ wtfrag, int H) {
+    const int nch = (3 * H) >> 4;
+    const size_t total = (size_t)3 * H * H;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int e = i & 3, l = (i >> 2) & 63;
+        const size_t r = i >> 8;
+        const int c = r % nch, ub = r / nch;
+        wtfrag[i] = w_hh_t[((size_t)ub * 16 + (l & 15)) * 3 * H + c * 16 + (l >> 4) * 4 + e];
+    }
+}
+
+struct FragPtrs {
+    float* wfrag[M3T_MAX_SCANS];    // fragment-ordered weights
+    float* xfrag[M3T_MAX_SCANS];    // 2 ping-pong buffers of fragment-ordered h_t (fwd) / dgh_t (bwd)
+    size_t xstride[M3T_MAX_SCANS];  // floats per ping-pong buffer
+};
+
+// NC = chunks per wave kept in flight; CT = column tiles.  A frag: [chunk][2 row tiles][64][4]; B frag: [chunk][CT][64][4]
+template <int CT, int NC>
+__device__ __forceinline__ void wave_mma_frag(const float4* __restrict__ Af, const float4* __restrict__ Bf, int nchunks,
+                                              int wave, int lane, f32x4 (&acc)[2][CT]) {
+    for (int c0 = wave; c0 < nchunks; c0 += NW * NC) {
+        float4 a[NC][2], b[NC][CT];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c = c0 + i * NW;
+            if (c < nchunks) {
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) a[i][rt] = Af[((size_t)c * 2 + rt) * 64 + lane];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) b[i][ct] = Bf[((size_t)c * CT + ct) * 64 + lane];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            if (c0 + i * NW >= nchunks) break;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][rt].x, b[i][ct].x, acc[rt][ct], 0, 0, 0);
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][rt].y, b[i][ct].y, acc[rt][ct], 0, 0, 0);
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][rt].z, b[i][ct].z, acc[rt][ct], 0, 0, 0);
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][rt].w, b[i][ct].w, acc[rt][ct], 0, 0, 0);
+                }
+        }
+    }
+}
+
+__global__ __launch_bounds__(NT) void gru_step_fwd_frag_kernel(FwdGroup g, FragPtrs fp, int B, int T, int step) {
+    __shared__ float red[NW][3][RB][UB];   // 48 KiB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int s = 0;
+    while (s + 1 < g.n && (int)blockIdx.x >= g.blk_start[s + 1]) ++s;
+    const m3t_gru_fwd_desc d = g.d[s];
+    const int H = d.H, nch = H >> 4;
+    const int ub = (int)blockIdx.x - g.blk_start[s];
+    const int j0 = ub * UB, r0 = blockIdx.y * RB;
+    const int t = d.reverse ? T - 1 - step : step;
+    const int tp = d.reverse ? t + 1 : t - 1;
+    const bool has_prev = step > 0;
+    const float* hin = fp.xfrag[s] + (size_t)((step + 1) & 1) * fp.xstride[s] + (size_t)blockIdx.y * RB * H;
+    float* hout = fp.xfrag[s] + (size_t)(step & 1) * fp.xstride[s] + (size_t)blockIdx.y * RB * H;
+
+    const int prow = tid >> 4, pu = tid & 15;
+    const int pb = r0 + prow, pj = j0 + pu;
+    const bool pok = pb < B;
+    float xr = 0.f, xz = 0.f, xn = 0.f, hprev = 0.f;
+    const float br = d.b_hh[pj], bz = d.b_hh[H + pj], bn = d.b_hh[2 * H + pj];
+    if (pok) {
+        const float* xp = d.xproj + ((size_t)pb * T + t) * d.ldx + d.xoff;
+        xr = xp[pj]; xz = xp[H + pj]; xn = xp[2 * H + pj];
+        if (has_prev) hprev = d.out[((size_t)pb * T + tp) * d.ldo + d.ooff + pj];
+    }
+    if (has_prev) {
+        f32x4 acc[2][3];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        wave_mma_frag<3, CF>(reinterpret_cast<const float4*>(hin),
+                             reinterpret_cast<const float4*>(fp.wfrag[s] + (size_t)ub * nch * 3 * 256), nch, wave, lane, acc);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[wave][ct][rt * 16 + (lane >> 4) * 4 + r][lane & 15] = acc[rt][ct][r];
+    }
+    __syncthreads();
+    float hr = br, hz = bz, hn = bn;
+    if (has_prev) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            hr += red[w][0][prow][pu];
+            hz += red[w][1][prow][pu];
+            hn += red[w][2][prow][pu];
+        }
+    }
+    const float r = 1.f / (1.f + expf(-(xr + hr)));
+    const float z = 1.f / (1.f + expf(-(xz + hz)));
+    const float n = tanhf(xn + r * hn);
+    const float h = n + z * (hprev - n);
+    // fragment-ordered copy for the next step: chunk == ub, tile = prow>>4, lane = (pu>>2)*16 + (prow&15), e = pu&3
+    hout[(((size_t)ub * 2 + (prow >> 4)) * 64 + (pu >> 2) * 16 + (prow & 15)) * 4 + (pu & 3)] = pok ? h : 0.f;
+    if (!pok) return;
+    d.out[((size_t)pb * T + t) * d.ldo + d.ooff + pj] = h;
+    if (d.gates) {
+        float* gp = d.gates + ((size_t)pb * T + t) * 4 * H;
+        gp[pj] = r; gp[H + pj] = z; gp[2 * H + pj] = n; gp[3 * H + pj] = hn;
+    }
+    if (d.h_n && step == T - 1) d.h_n[(size_t)pb * H + pj] = h;
+}
+
+__global__ __launch_bounds__(NT) void gru_step_bwd_frag_kernel(BwdGroup g, FragPtrs fp, int B, int T, int step) {
+    __shared__ float red[NW][RB][UB];   // 16 KiB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int s = 0;
+    while (s + 1 < g.n && (int)blockIdx.x >= g.blk_start[s + 1]) ++s;
+    const m3t_gru_bwd_desc d = g.d[s];
+    const int H = d.H, H3 = 3 * d.H, nchh = H >> 4, nch = H3 >> 4;
+    const int ub = (int)blockIdx.x - g.blk_start[s];
+    const int j0 = ub * UB, r0 = blockIdx.y * RB;
+    const int t = d.reverse ? step : T - 1 - step;
+    const int tn = d.reverse ? t - 1 : t + 1;
+    const int tp = d.reverse ? t + 1 : t - 1;
+    const bool has_next = step > 0, has_prev = step < T - 1;
+    const float* gin = fp.xfrag[s] + (size_t)((step + 1) & 1) * fp.xstride[s] + (size_t)blockIdx.y * RB * H3;
+    float* gout = fp.xfrag[s] + (size_t)(step & 1) * fp.xstride[s] + (size_t)blockIdx.y * RB * H3;
+
+    const int prow = tid >> 4, pu = tid & 15;
+    const int pb = r0 + prow, pj = j0 + pu;
+    const bool pok = pb < B;
+    float dout = 0.f, gr = 0.f, gz = 0.f, gn = 0.f, ghn = 0.f, hprev = 0.f, zn = 0.f, dhn = 0.f;
+    if (pok) {
+        dout = d.dout[((size_t)pb * T + t) * d.ldo + d.ooff + pj];
+        const float* gp = d.gates + ((size_t)pb * T + t) * 4 * H;
+        gr = gp[pj]; gz = gp[H + pj]; gn = gp[2 * H + pj]; ghn = gp[3 * H + pj];
+        if (has_prev) hprev = d.out[((size_t)pb * T + tp) * d.ldo + d.ooff + pj];
+        if (has_next) {
+            zn = d.gates[((size_t)pb * T + tn) * 4 * H + H + pj];
+            dhn = d.dh[(size_t)pb * H + pj];
+        } else if (d.dh_n) {
+            dhn = d.dh_n[(size_t)pb * H + pj];
+        }
+    }
+    if (has_next) {
+        f32x4 acc[2][1];
+        acc[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc[1][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        wave_mma_frag<1, CB>(reinterpret_cast<const float4*>(gin),
+                             reinterpret_cast<const float4*>(fp.wfrag[s] + (size_t)ub * nch * 256), nch, wave, lane, acc);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][rt * 16 + (lane >> 4) * 4 + r][lane & 15] = acc[rt][0][r];
+    }
+    __syncthreads();
+    float carry = dhn;
+    if (has_next) {
+        float mm = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) mm += red[w][prow][pu];
+        carry = dhn * zn + mm;
+    }
+    const float dht = dout + carry;
+    const float dn = dht * (1.f - gz) * (1.f - gn * gn);
+    const float dz = dht * (hprev - gn) * gz * (1.f - gz);
+    const float dr = dn * ghn * gr * (1.f - gr);
+    // fragment-ordered dgh for the next launch: gate g lives in chunk g*(H/16) + ub
+    const size_t fo = ((size_t)(prow >> 4) * 64 + (pu >> 2) * 16 + (prow & 15)) * 4 + (pu & 3);
+    gout[((size_t)(0 * nchh + ub) * 2) * 256 + fo] = pok ? dr : 0.f;
+    gout[((size_t)(1 * nchh + ub) * 2) * 256 + fo] = pok ? dz : 0.f;
+    gout[((size_t)(2 * nchh + ub) * 2) * 256 + fo] = pok ? dn * gr : 0.f;
+    if (!pok) return;
+    float* gx = d.dgx + ((size_t)pb * T + t) * d.ldg + d.goff;
+    gx[pj] = dr; gx[H + pj] = dz; gx[2 * H + pj] = dn;
+    float* gh = d.dgh + ((size_t)pb * T + t) * H3;
+    gh[pj] = dr; gh[H + pj] = dz; gh[2 * H + pj] = dn * gr;
+    d.dh[(size_t)pb * H + pj] = dht;
+}
+
+template <bool FAST>
+__global__ __launch_bounds__(NT) void gru_step_fwd_kernel(FwdGroup g, int B, int T, int step) {
+    __shared__ float red[NW][3][RB][UB];   // [wave][gate][row][unit], 48 KiB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int s = 0;
     while (s + 1 < g.n && (int)blockIdx.x >= g.blk_start[s + 1]) ++s;
@@ -83,6 +314,18 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(FwdGroup g, int B, in
     const int t = d.reverse ? T - 1 - step : step;
     const int tp = d.reverse ? t + 1 : t - 1;
     const bool has_prev = step > 0;
+
+    // this thread's gate-math element; its inputs are requested before the matmul so they ride under it
+    const int prow = tid >> 4, pu = tid & 15;
+    const int pb = r0 + prow, pj = j0 + pu;
+    const bool pok = pb < B && pj < H;
+    float xr = 0.f, xz = 0.f, xn = 0.f, br = 0.f, bz = 0.f, bn = 0.f, hprev = 0.f;
+    if (pok) {
+        const float* xp = d.xproj + ((size_t)pb * T + t) * d.ldx + d.xoff;
+        xr = xp[pj]; xz = xp[H + pj]; xn = xp[2 * H + pj];
+        br = d.b_hh[pj]; bz = d.b_hh[H + pj]; bn = d.b_hh[2 * H + pj];
+        if (has_prev) hprev = d.out[((size_t)pb * T + tp) * d.ldo + d.ooff + pj];
+    }
 
     if (has_prev) {
         f32x4 acc[2][3];
@@ -96,17 +339,17 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(FwdGroup g, int B, in
         for (int rt = 0; rt < 2; ++rt) {
             const int row = r0 + rt * 16 + (lane & 15);
             aok[rt] = row < B;
-            aoff[rt] = ((size_t)row * T + tp) * d.ldo + d.ooff;
+            aoff[rt] = ((size_t)(FAST ? min(row, B - 1) : row) * T + tp) * d.ldo + d.ooff;
         }
 #pragma unroll
         for (int ct = 0; ct < 3; ++ct) {
             const int j = j0 + (lane & 15);
             bok[ct] = j < H;
-            boff[ct] = ((size_t)ct * H + j) * H;
+            boff[ct] = ((size_t)ct * H + (FAST ? min(j, H - 1) : j)) * H;
         }
         const bool vecA = ((d.ldo | d.ooff) & 3) == 0 && ((uintptr_t)d.out & 15) == 0;
         const bool vecB = (H & 3) == 0 && ((uintptr_t)d.w_hh & 15) == 0;
-        wave_mma<3>(d.out, 0, aok, aoff, d.w_hh, 0, bok, boff, H, vecA, vecB, wave, lane, acc);
+        wave_mma<3, CF, FAST>(d.out, aoff, aok, d.w_hh, boff, bok, H, vecA, vecB, wave, lane, acc);
         // C/D map 16x16: col = lane&15, row = (lane>>4)*4 + reg
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
@@ -116,38 +359,32 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(FwdGroup g, int B, in
                 for (int r = 0; r < 4; ++r) red[wave][ct][rt * 16 + (lane >> 4) * 4 + r][lane & 15] = acc[rt][ct][r];
     }
     __syncthreads();
+    if (!pok) return;
+    float hr = 0.f, hz = 0.f, hn = 0.f;
+    if (has_prev) {
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const int p = tid + e * 256;
-        const int row = p >> 4, u = p & 15;
-        const int b = r0 + row, j = j0 + u;
-        if (b >= B || j >= H) continue;
-        float hr = 0.f, hz = 0.f, hn = 0.f, hprev = 0.f;
-        if (has_prev) {
-            hr = (red[0][0][row][u] + red[1][0][row][u]) + (red[2][0][row][u] + red[3][0][row][u]);
-            hz = (red[0][1][row][u] + red[1][1][row][u]) + (red[2][1][row][u] + red[3][1][row][u]);
-            hn = (red[0][2][row][u] + red[1][2][row][u]) + (red[2][2][row][u] + red[3][2][row][u]);
-            hprev = d.out[((size_t)b * T + tp) * d.ldo + d.ooff + j];
+        for (int w = 0; w < NW; ++w) {      // fixed order: deterministic
+            hr += red[w][0][prow][pu];
+            hz += red[w][1][prow][pu];
+            hn += red[w][2][prow][pu];
         }
-        hr += d.b_hh[j];
-        hz += d.b_hh[H + j];
-        hn += d.b_hh[2 * H + j];
-        const float* xp = d.xproj + ((size_t)b * T + t) * d.ldx + d.xoff;
-        const float r = 1.f / (1.f + expf(-(xp[j] + hr)));
-        const float z = 1.f / (1.f + expf(-(xp[H + j] + hz)));
-        const float n = tanhf(xp[2 * H + j] + r * hn);
-        const float h = n + z * (hprev - n);
-        d.out[((size_t)b * T + t) * d.ldo + d.ooff + j] = h;
-        if (d.gates) {
-            float* gp = d.gates + ((size_t)b * T + t) * 4 * H;
-            gp[j] = r; gp[H + j] = z; gp[2 * H + j] = n; gp[3 * H + j] = hn;
-        }
-        if (d.h_n && step == T - 1) d.h_n[(size_t)b * H + j] = h;
     }
+    hr += br; hz += bz; hn += bn;
+    const float r = 1.f / (1.f + expf(-(xr + hr)));
+    const float z = 1.f / (1.f + expf(-(xz + hz)));
+    const float n = tanhf(xn + r * hn);
+    const float h = n + z * (hprev - n);
+    d.out[((size_t)pb * T + t) * d.ldo + d.ooff + pj] = h;
+    if (d.gates) {
+        float* gp = d.gates + ((size_t)pb * T + t) * 4 * H;
+        gp[pj] = r; gp[H + pj] = z; gp[2 * H + pj] = n; gp[3 * H + pj] = hn;
+    }
+    if (d.h_n && step == T - 1) d.h_n[(size_t)pb * H + pj] = h;
 }
 
-__global__ __launch_bounds__(256) void gru_step_bwd_kernel(BwdGroup g, int B, int T, int step) {
-    __shared__ float red[4][RB][UB];   // 8 KiB
+template <bool FAST>
+__global__ __launch_bounds__(NT) void gru_step_bwd_kernel(BwdGroup g, int B, int T, int step) {
+    __shared__ float red[NW][RB][UB];   // 16 KiB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int s = 0;
     while (s + 1 < g.n && (int)blockIdx.x >= g.blk_start[s + 1]) ++s;
@@ -160,6 +397,23 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(BwdGroup g, int B, in
     const int tp = d.reverse ? t + 1 : t - 1;                // forward predecessor (h_{t-1})
     const bool has_next = step > 0, has_prev = step < T - 1;
 
+    const int prow = tid >> 4, pu = tid & 15;
+    const int pb = r0 + prow, pj = j0 + pu;
+    const bool pok = pb < B && pj < H;
+    float dout = 0.f, gr = 0.f, gz = 0.f, gn = 0.f, ghn = 0.f, hprev = 0.f, zn = 0.f, dhn = 0.f;
+    if (pok) {
+        dout = d.dout[((size_t)pb * T + t) * d.ldo + d.ooff + pj];
+        const float* gp = d.gates + ((size_t)pb * T + t) * 4 * H;
+        gr = gp[pj]; gz = gp[H + pj]; gn = gp[2 * H + pj]; ghn = gp[3 * H + pj];
+        if (has_prev) hprev = d.out[((size_t)pb * T + tp) * d.ldo + d.ooff + pj];
+        if (has_next) {
+            zn = d.gates[((size_t)pb * T + tn) * 4 * H + H + pj];
+            dhn = d.dh[(size_t)pb * H + pj];
+        } else if (d.dh_n) {
+            dhn = d.dh_n[(size_t)pb * H + pj];
+        }
+    }
+
     if (has_next) {
         f32x4 acc[2][1];
         acc[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -170,52 +424,43 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(BwdGroup g, int B, in
         for (int rt = 0; rt < 2; ++rt) {
             const int row = r0 + rt * 16 + (lane & 15);
             aok[rt] = row < B;
-            aoff[rt] = ((size_t)row * T + tn) * H3;
+            aoff[rt] = ((size_t)(FAST ? min(row, B - 1) : row) * T + tn) * H3;
         }
         const int j = j0 + (lane & 15);
         bok[0] = j < H;
-        boff[0] = (size_t)j * H3;
+        boff[0] = (size_t)(FAST ? min(j, H - 1) : j) * H3;
         const bool vecA = (H3 & 3) == 0 && ((uintptr_t)d.dgh & 15) == 0;
         const bool vecB = (H3 & 3) == 0 && ((uintptr_t)d.w_hh_t & 15) == 0;
-        wave_mma<1>(d.dgh, 0, aok, aoff, d.w_hh_t, 0, bok, boff, H3, vecA, vecB, wave, lane, acc);
+        wave_mma<1, CB, FAST>(d.dgh, aoff, aok, d.w_hh_t, boff, bok, H3, vecA, vecB, wave, lane, acc);
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[wave][rt * 16 + (lane >> 4) * 4 + r][lane & 15] = acc[rt][0][r];
     }
     __syncthreads();
+    if (!pok) return;
+    float carry = dhn;                       // has_next: dL/dh_{tn} total; else grad wrt the final hidden state
+    if (has_next) {
+        float mm = 0.f;
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const int p = tid + e * 256;
-        const int row = p >> 4, u = p & 15;
-        const int b = r0 + row, j = j0 + u;
-        if (b >= B || j >= H) continue;
-        float carry;
-        if (has_next) {
-            const float mm = (red[0][row][u] + red[1][row][u]) + (red[2][row][u] + red[3][row][u]);
-            const float zn = d.gates[((size_t)b * T + tn) * 4 * H + H + j];
-            carry = d.dh[(size_t)b * H + j] * zn + mm;
-        } else {
-            carry = d.dh_n ? d.dh_n[(size_t)b * H + j] : 0.f;
-        }
-        const float dht = d.dout[((size_t)b * T + t) * d.ldo + d.ooff + j] + carry;
-        const float* gp = d.gates + ((size_t)b * T + t) * 4 * H;
-        const float r = gp[j], z = gp[H + j], n = gp[2 * H + j], hn = gp[3 * H + j];
-        const float hprev = has_prev ? d.out[((size_t)b * T + tp) * d.ldo + d.ooff + j] : 0.f;
-        const float dn = dht * (1.f - z) * (1.f - n * n);
-        const float dz = dht * (hprev - n) * z * (1.f - z);
-        const float dr = dn * hn * r * (1.f - r);
-        float* gx = d.dgx + ((size_t)b * T + t) * d.ldg + d.goff;
-        gx[j] = dr; gx[H + j] = dz; gx[2 * H + j] = dn;
-        float* gh = d.dgh + ((size_t)b * T + t) * H3;
-        gh[j] = dr; gh[H + j] = dz; gh[2 * H + j] = dn * r;
-        d.dh[(size_t)b * H + j] = dht;
+        for (int w = 0; w < NW; ++w) mm += red[w][prow][pu];
+        carry = dhn * zn + mm;
     }
+    const float dht = dout + carry;
+    const float dn = dht * (1.f - gz) * (1.f - gn * gn);
+    const float dz = dht * (hprev - gn) * gz * (1.f - gz);
+    const float dr = dn * ghn * gr * (1.f - gr);
+    float* gx = d.dgx + ((size_t)pb * T + t) * d.ldg + d.goff;
+    gx[pj] = dr; gx[H + pj] = dz; gx[2 * H + pj] = dn;
+    float* gh = d.dgh + ((size_t)pb * T + t) * H3;
+    gh[pj] = dr; gh[H + pj] = dz; gh[2 * H + pj] = dn * gr;
+    d.dh[(size_t)pb * H + pj] = dht;
 }
 
 }  // namespace
 
-extern "C" int m3t_gru_scan_fwd(const m3t_gru_fwd_desc* scans, int n_scans, int B, int T, void* stream) {
+extern "C" int m3t_gru_scan_fwd(const m3t_gru_fwd_desc* scans, int n_scans, int B, int T, float* ws, size_t ws_bytes,
+                                void* stream) {
     if (n_scans <= 0 || B <= 0 || T <= 0) return 0;
     if (n_scans > M3T_MAX_SCANS || !scans) return M3T_EINVAL;
     FwdGroup g;
@@ -230,12 +475,45 @@ extern "C" int m3t_gru_scan_fwd(const m3t_gru_fwd_desc* scans, int n_scans, int 
     for (int i = n_scans; i <= M3T_MAX_SCANS; ++i) g.blk_start[i] = blocks;
     dim3 grid(blocks, cdiv(B, RB));
     hipStream_t s = (hipStream_t)stream;
-    for (int step = 0; step < T; ++step) gru_step_fwd_kernel<<<grid, 256, 0, s>>>(g, B, T, step);
+    bool fast = true;     // every scan: H % 16 == 0 and float4-aligned operands
+    for (int i = 0; i < n_scans; ++i) {
+        const m3t_gru_fwd_desc& d = scans[i];
+        fast = fast && (d.H % 16 == 0) && ((d.ldo | d.ooff) % 4 == 0) && ((uintptr_t)d.out % 16 == 0) &&
+               ((uintptr_t)d.w_hh % 16 == 0);
+    }
+    // fragment-ordered path: needs H % 16 == 0 and workspace for re-laid weights + ping-pong h fragments
+    bool frag = ws != nullptr && ((uintptr_t)ws % 16 == 0);
+    size_t need = 0;
+    const size_t bpad = (size_t)cdiv(B, RB) * RB;
+    for (int i = 0; i < n_scans; ++i) {
+        frag = frag && scans[i].H % 16 == 0;
+        need += (size_t)3 * scans[i].H * scans[i].H + 2 * bpad * scans[i].H;
+    }
+    if (frag && need * sizeof(float) <= ws_bytes) {
+        FragPtrs fp;
+        float* p = ws;
+        for (int i = 0; i < n_scans; ++i) {
+            const int H = scans[i].H;
+            fp.wfrag[i] = p; p += (size_t)3 * H * H;
+            fp.xfrag[i] = p; fp.xstride[i] = bpad * H; p += 2 * bpad * H;
+            int blk = (3 * H * H + 255) / 256;
+            if (blk > 1024) blk = 1024;
+            wfrag_fwd_prep_kernel<<<blk, 256, 0, s>>>(scans[i].w_hh, fp.wfrag[i], H);
+        }
+        for (int step = 0; step < T; ++step) gru_step_fwd_frag_kernel<<<grid, NT, 0, s>>>(g, fp, B, T, step);
+        M3T_LAUNCH_CHECK();
+        return 0;
+    }
+    if (fast)
+        for (int step = 0; step < T; ++step) gru_step_fwd_kernel<true><<<grid, NT, 0, s>>>(g, B, T, step);
+    else
+        for (int step = 0; step < T; ++step) gru_step_fwd_kernel<false><<<grid, NT, 0, s>>>(g, B, T, step);
     M3T_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int m3t_gru_scan_bwd(const m3t_gru_bwd_desc* scans, int n_scans, int B, int T, void* stream) {
+extern "C" int m3t_gru_scan_bwd(const m3t_gru_bwd_desc* scans, int n_scans, int B, int T, float* ws, size_t ws_bytes,
+                                void* stream) {
     if (n_scans <= 0 || B <= 0 || T <= 0) return 0;
     if (n_scans > M3T_MAX_SCANS || !scans) return M3T_EINVAL;
     BwdGroup g;
@@ -251,7 +529,37 @@ extern "C" int m3t_gru_scan_bwd(const m3t_gru_bwd_desc* scans, int n_scans, int 
     for (int i = n_scans; i <= M3T_MAX_SCANS; ++i) g.blk_start[i] = blocks;
     dim3 grid(blocks, cdiv(B, RB));
     hipStream_t s = (hipStream_t)stream;
-    for (int step = 0; step < T; ++step) gru_step_bwd_kernel<<<grid, 256, 0, s>>>(g, B, T, step);
+    bool fast = true;
+    for (int i = 0; i < n_scans; ++i) {
+        const m3t_gru_bwd_desc& d = scans[i];
+        fast = fast && (d.H % 16 == 0) && ((uintptr_t)d.dgh % 16 == 0) && ((uintptr_t)d.w_hh_t % 16 == 0);
+    }
+    bool frag = ws != nullptr && ((uintptr_t)ws % 16 == 0);
+    size_t need = 0;
+    const size_t bpad = (size_t)cdiv(B, RB) * RB;
+    for (int i = 0; i < n_scans; ++i) {
+        frag = frag && scans[i].H % 16 == 0;
+        need += (size_t)3 * scans[i].H * scans[i].H + 2 * bpad * 3 * scans[i].H;
+    }
+    if (frag && need * sizeof(float) <= ws_bytes) {
+        FragPtrs fp;
+        float* p = ws;
+        for (int i = 0; i < n_scans; ++i) {
+            const int H = scans[i].H;
+            fp.wfrag[i] = p; p += (size_t)3 * H * H;
+            fp.xfrag[i] = p; fp.xstride[i] = bpad * 3 * H; p += 2 * bpad * 3 * H;
+            int blk = (3 * H * H + 255) / 256;
+            if (blk > 1024) blk = 1024;
+            wfrag_bwd_prep_kernel<<<blk, 256, 0, s>>>(scans[i].w_hh_t, fp.wfrag[i], H);
+        }
+        for (int step = 0; step < T; ++step) gru_step_bwd_frag_kernel<<<grid, NT, 0, s>>>(g, fp, B, T, step);
+        M3T_LAUNCH_CHECK();
+        return 0;
+    }
+    if (fast)
+        for (int step = 0; step < T; ++step) gru_step_bwd_kernel<true><<<grid, NT, 0, s>>>(g, B, T, step);
+    else
+        for (int step = 0; step < T; ++step) gru_step_bwd_kernel<false><<<grid, NT, 0, s>>>(g, B, T, step);
     M3T_LAUNCH_CHECK();
     return 0;
 }

@@ -34,8 +34,8 @@ SIGNATURES = {
     "m3t_colsum": [_f, _i, _i, _i, _f, _i, _f, _z, _s],
     "m3t_transpose": [_f, _i, _i, _i, _f, _i, _s],
     "m3t_relu_bwd": [_f, _f, _z, _s],
-    "m3t_gru_scan_fwd": [C.POINTER(GruFwdDesc), _i, _i, _i, _s],
-    "m3t_gru_scan_bwd": [C.POINTER(GruBwdDesc), _i, _i, _i, _s],
+    "m3t_gru_scan_fwd": [C.POINTER(GruFwdDesc), _i, _i, _i, _f, _z, _s],
+    "m3t_gru_scan_bwd": [C.POINTER(GruBwdDesc), _i, _i, _i, _f, _z, _s],
     "m3t_att_fuse_fwd": [_f, _f, _f, _f, _f, _i, _i, _s],
     "m3t_att_fuse_bwd": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _s],
     "m3t_va_loss": [_f, _i, _i, _i, _i, _f, _f, _f, _f, _i, C.c_float, C.c_float, C.c_float, _i, _f, _f, _s],

@@ -153,7 +153,8 @@ def _scan_fwd(descs, B, T):
         arr = (GruFwdDesc * len(chunk))(*chunk)
         flops = (T - 1) * sum(2.0 * B * 3 * d.H * d.H for d in chunk)
         with _Timed("gru_step_fwd_kernel", T, flops):
-            rc = lib().m3t_gru_scan_fwd(arr, len(chunk), B, T, _stream())
+            ws = workspace(torch.device("cuda", torch.cuda.current_device()))
+            rc = lib().m3t_gru_scan_fwd(arr, len(chunk), B, T, _p(ws), ws.numel() * 4, _stream())
         _lib.check(rc, "m3t_gru_scan_fwd")
 
 
@@ -163,7 +164,8 @@ def _scan_bwd(descs, B, T):
         arr = (GruBwdDesc * len(chunk))(*chunk)
         flops = (T - 1) * sum(2.0 * B * 3 * d.H * d.H for d in chunk)
         with _Timed("gru_step_bwd_kernel", T, flops):
-            rc = lib().m3t_gru_scan_bwd(arr, len(chunk), B, T, _stream())
+            ws = workspace(torch.device("cuda", torch.cuda.current_device()))
+            rc = lib().m3t_gru_scan_bwd(arr, len(chunk), B, T, _p(ws), ws.numel() * 4, _stream())
         _lib.check(rc, "m3t_gru_scan_bwd")
 
 

@@ -1,0 +1,112 @@
+"""N>1 data-parallel path on CPU: world_size-2 gloo processes exercise the flat-buffer bucketing,
+the hook-driven async all-reduce and the DistributedSampler-style sharding of m3t.ddp.  The fused
+HIP norm/scale kernel is swapped for an equivalent torch finalize here (CPU has no HIP); the kernel
+itself is covered by tests/test_gpu_ddp.py on one GPU."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+from m3t.ddp import FlatGradDDP, shard_indices
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def torch_finalize(flat, world, max_norm):
+    flat.mul_(1.0 / world)
+    norm = flat.norm()
+    if max_norm > 0:
+        flat.mul_(torch.clamp(max_norm / (norm + 1e-6), max=1.0))
+    return norm
+
+
+def _net():
+    torch.manual_seed(7)
+    return nn.Sequential(nn.Linear(6, 16), nn.Tanh(), nn.Linear(16, 8), nn.Tanh(), nn.Linear(8, 2))
+
+
+def _data():
+    g = torch.Generator().manual_seed(11)
+    return torch.randn(8, 6, generator=g), torch.randn(8, 2, generator=g)
+
+
+def _worker(rank, world, port, max_norm, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    net = _net()
+    ddp = FlatGradDDP(net, max_norm=max_norm, finalize=torch_finalize)
+    assert ddp.world == world and len(ddp.buckets) == 3
+    x, y = _data()
+    idx = shard_indices(x.shape[0], rank, world)
+    for _ in range(2):                      # two steps: zero_grad must reset the hook counters
+        ddp.zero_grad()
+        ((net(x[idx]) - y[idx]) ** 2).mean().backward()
+        norm = ddp.finish()
+    for p in net.parameters():              # .grad must still be views of the flat buffer
+        assert p.grad.data_ptr() >= ddp.flat.data_ptr()
+        assert p.grad.data_ptr() < ddp.flat.data_ptr() + ddp.flat.numel() * 4
+    out_q.put((rank, ddp.flat.tolist(), float(norm)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("max_norm", [0.0, 0.05])
+def test_two_rank_gradients_equal_mean_of_shard_gradients(max_norm):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, max_norm, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    res = [(r, torch.tensor(f), n) for r, f, n in res]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process reference: mean over ranks of the per-shard mean losses (what DDP optimises)
+    net = _net()
+    x, y = _data()
+    loss = sum(((net(x[shard_indices(8, r, world)]) - y[shard_indices(8, r, world)]) ** 2).mean() for r in range(world)) / world
+    loss.backward()
+    order = [p for child in reversed(list(net.children())) for p in child.parameters()]
+    ref = torch.cat([p.grad.reshape(-1) for p in order])
+    norm = ref.norm()
+    if max_norm > 0:
+        ref = ref * torch.clamp(max_norm / (norm + 1e-6), max=1.0)
+    for rank, flat, n in res:
+        assert torch.allclose(flat, ref, atol=1e-6), rank
+        assert abs(n - float(norm)) < 1e-5
+    assert torch.equal(res[0][1], res[1][1])       # replicas stay identical
+
+
+def test_shard_indices_distributed_sampler_semantics():
+    assert shard_indices(8, 0, 2) == [0, 2, 4, 6] and shard_indices(8, 1, 2) == [1, 3, 5, 7]
+    assert shard_indices(5, 0, 2) == [0, 2, 4] and shard_indices(5, 1, 2) == [1, 3, 0]     # wraps to pad
+    from torch.utils.data.distributed import DistributedSampler
+    ds = list(range(11))
+    for r in range(4):
+        assert shard_indices(11, r, 4) == list(DistributedSampler(ds, num_replicas=4, rank=r, shuffle=False))
+
+
+def test_single_process_flat_views_and_accumulation():
+    net = _net()
+    ddp = FlatGradDDP(net, max_norm=0.0, finalize=torch_finalize)
+    x, y = _data()
+    ddp.zero_grad()
+    ((net(x) - y) ** 2).mean().backward()
+    ddp.finish()
+    ref = _net()
+    ((ref(x) - y) ** 2).mean().backward()
+    for a, b in zip(net.parameters(), ref.parameters()):
+        assert torch.allclose(a.grad, b.grad, atol=1e-7)
+    assert abs(float(ddp.flat.norm()) - float(torch.cat([p.grad.reshape(-1) for p in ref.parameters()]).norm())) < 1e-6
