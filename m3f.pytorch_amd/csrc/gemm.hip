@@ -91,7 +91,22 @@ __device__ __forceinline__ void store_mc(float* __restrict__ S, const float4 (&r
     }
 }
 
-template <int TA, int TB>
+// unguarded variants for the interior fast path (M,N % 128 == 0, K-range % 16 == 0, 16-B aligned rows)
+__device__ __forceinline__ void load_kc_fast(const float* __restrict__ src, int ld, int row0, int k0, float4 (&r)[2]) {
+    const int tid = threadIdx.x;
+    const float* p = src + (size_t)(row0 + (tid >> 2)) * ld + k0 + (tid & 3) * 4;
+    r[0] = *reinterpret_cast<const float4*>(p);
+    r[1] = *reinterpret_cast<const float4*>(p + (size_t)64 * ld);
+}
+__device__ __forceinline__ void load_mc_fast(const float* __restrict__ src, int ld, int col0, int k0, int seg_len,
+                                             int seg_stride, int off, float4 (&r)[2]) {
+    const int tid = threadIdx.x;
+    const int k = k0 + (tid >> 5), c = col0 + (tid & 31) * 4;
+    r[0] = *reinterpret_cast<const float4*>(src + (size_t)seg_row(k, seg_len, seg_stride, off) * ld + c);
+    r[1] = *reinterpret_cast<const float4*>(src + (size_t)seg_row(k + 8, seg_len, seg_stride, off) * ld + c);
+}
+
+template <int TA, int TB, bool FAST, bool SEG = false>
 __global__ __launch_bounds__(256) void sgemm_kernel(GemmParams p) {
     __shared__ __attribute__((aligned(16))) float As[2][BK * LDT];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDT];
@@ -99,7 +114,14 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int bm = blockIdx.y * BM, bn = blockIdx.x * BN;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (private L2s), so give each XCD a
+    // CONTIGUOUS run of tiles (column tile fastest): neighbours then share their A row-panel in that XCD's L2.
+    // Bijective for any tile count; placement only affects speed.
+    const int tn_ = gridDim.x, nt_ = gridDim.x * gridDim.y;
+    const int lin = blockIdx.y * tn_ + blockIdx.x;
+    const int xq = nt_ >> 3, xr = nt_ & 7, xcd = lin & 7, slot = lin >> 3;
+    const int til = xcd * xq + min(xcd, xr) + slot;
+    const int bm = (til / tn_) * BM, bn = (til % tn_) * BN;
     const int k_begin = blockIdx.z * p.kchunk;
     const int k_end = min(p.K, k_begin + p.kchunk);
 
@@ -112,11 +134,49 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GemmParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[2], rb[2];
+    // fast path: per-thread operand pointers, advanced by one k-tile per iteration (no per-tile index math)
+    const float* pa0 = nullptr; const float* pb0 = nullptr;
+    size_t a_step = 0, b_step = 0, a_second = 0, b_second = 0;
+    if (FAST && !SEG) {
+        if (TA == 0) { pa0 = p.A + (size_t)(bm + (tid >> 2)) * p.lda + k_begin + (tid & 3) * 4; a_step = BK; a_second = (size_t)64 * p.lda; }
+        else { pa0 = p.A + (size_t)(k_begin + (tid >> 5)) * p.lda + bm + (tid & 31) * 4; a_step = (size_t)BK * p.lda; a_second = (size_t)8 * p.lda; }
+        if (TB == 1) { pb0 = p.B + (size_t)(bn + (tid >> 2)) * p.ldb + k_begin + (tid & 3) * 4; b_step = BK; b_second = (size_t)64 * p.ldb; }
+        else { pb0 = p.B + (size_t)(k_begin + (tid >> 5)) * p.ldb + bn + (tid & 31) * 4; b_step = (size_t)BK * p.ldb; b_second = (size_t)8 * p.ldb; }
+    }
+    // segmented reduction rows (dW_hh): (segment, offset) of this thread's two k rows, advanced incrementally
+    int sq0 = 0, sr0 = 0, sq1 = 0, sr1 = 0;
+    if (FAST && SEG) {
+        const int ka = k_begin + (tid >> 5), kb = ka + 8;
+        sq0 = ka / p.seg_len; sr0 = ka % p.seg_len;
+        sq1 = kb / p.seg_len; sr1 = kb % p.seg_len;
+    }
     auto gload = [&](int k0) {
-        if (TA == 0) load_kc(p.A, p.lda, p.M, bm, k0, k_end, p.vecA, ra);
-        else load_mc(p.A, p.lda, p.M, bm, k0, k_end, p.vecA, p.seg_len, p.seg_stride, p.a_off, ra);
-        if (TB == 1) load_kc(p.B, p.ldb, p.N, bn, k0, k_end, p.vecB, rb);
-        else load_mc(p.B, p.ldb, p.N, bn, k0, k_end, p.vecB, p.seg_len, p.seg_stride, p.b_off, rb);
+        if (FAST && SEG && TA == 1 && TB == 0) {
+            const int c = (tid & 31) * 4;
+            const size_t r0a = (size_t)sq0 * p.seg_stride + sr0, r1a = (size_t)sq1 * p.seg_stride + sr1;
+            ra[0] = *reinterpret_cast<const float4*>(p.A + (r0a + p.a_off) * p.lda + bm + c);
+            ra[1] = *reinterpret_cast<const float4*>(p.A + (r1a + p.a_off) * p.lda + bm + c);
+            rb[0] = *reinterpret_cast<const float4*>(p.B + (r0a + p.b_off) * p.ldb + bn + c);
+            rb[1] = *reinterpret_cast<const float4*>(p.B + (r1a + p.b_off) * p.ldb + bn + c);
+            sr0 += BK; if (sr0 >= p.seg_len) { sr0 -= p.seg_len; ++sq0; }
+            sr1 += BK; if (sr1 >= p.seg_len) { sr1 -= p.seg_len; ++sq1; }
+        } else if (FAST && !SEG) {
+            ra[0] = *reinterpret_cast<const float4*>(pa0);
+            ra[1] = *reinterpret_cast<const float4*>(pa0 + a_second);
+            rb[0] = *reinterpret_cast<const float4*>(pb0);
+            rb[1] = *reinterpret_cast<const float4*>(pb0 + b_second);
+            pa0 += a_step; pb0 += b_step;
+        } else if (FAST) {
+            if (TA == 0) load_kc_fast(p.A, p.lda, bm, k0, ra);
+            else load_mc_fast(p.A, p.lda, bm, k0, p.seg_len, p.seg_stride, p.a_off, ra);
+            if (TB == 1) load_kc_fast(p.B, p.ldb, bn, k0, rb);
+            else load_mc_fast(p.B, p.ldb, bn, k0, p.seg_len, p.seg_stride, p.b_off, rb);
+        } else {
+            if (TA == 0) load_kc(p.A, p.lda, p.M, bm, k0, k_end, p.vecA, ra);
+            else load_mc(p.A, p.lda, p.M, bm, k0, k_end, p.vecA, p.seg_len, p.seg_stride, p.a_off, ra);
+            if (TB == 1) load_kc(p.B, p.ldb, p.N, bn, k0, k_end, p.vecB, rb);
+            else load_mc(p.B, p.ldb, p.N, bn, k0, k_end, p.vecB, p.seg_len, p.seg_stride, p.b_off, rb);
+        }
     };
     auto sstore = [&](int buf) {
         if (TA == 0) store_kc(As[buf], ra); else store_mc(As[buf], ra);
@@ -132,16 +192,22 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GemmParams p) {
     for (int t = 0; t < ntiles; ++t) {
         const int cur = t & 1;
         if (t + 1 < ntiles) gload(k_begin + (t + 1) * BK);
-        const float* a_s = As[cur] + wm * 64 + l31;
-        const float* b_s = Bs[cur] + wn * 64 + l31;
+        const float* a_s = As[cur] + wm * 64 + l31 + hi * LDT;
+        const float* b_s = Bs[cur] + wn * 64 + l31 + hi * LDT;
+        // all 32 fragment reads of the tile are issued up front; the MFMAs then drain them in order
+        float fa[BK / 2][2], fb[BK / 2][2];
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            const float a0 = a_s[(kk + hi) * LDT], a1 = a_s[(kk + hi) * LDT + 32];
-            const float b0 = b_s[(kk + hi) * LDT], b1 = b_s[(kk + hi) * LDT + 32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        for (int q = 0; q < BK / 2; ++q) {
+            fa[q][0] = a_s[2 * q * LDT]; fa[q][1] = a_s[2 * q * LDT + 32];
+            fb[q][0] = b_s[2 * q * LDT]; fb[q][1] = b_s[2 * q * LDT + 32];
+        }
+        __builtin_amdgcn_sched_barrier(0);     // keep the reads ahead of the MFMAs (hipcc would sink each next to its use)
+#pragma unroll
+        for (int q = 0; q < BK / 2; ++q) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][0], fb[q][0], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][0], fb[q][1], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][1], fb[q][0], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][1], fb[q][1], acc[1][1], 0, 0, 0);
         }
         if (t + 1 < ntiles) sstore(cur ^ 1);
         __syncthreads();
@@ -156,12 +222,12 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int col = bn + wn * 64 + j * 32 + l31;
-            if (col >= p.N) continue;
+            if (!FAST && col >= p.N) continue;
             const float bv = (direct && p.bias) ? p.bias[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = bm + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (row >= p.M) continue;
+                if (!FAST && row >= p.M) continue;
                 float v = acc[i][j][r];
                 float* q = dst + (size_t)row * ldd + col;
                 if (direct) {
@@ -269,13 +335,18 @@ extern "C" int m3t_sgemm(int transA, int transB, int M, int N, int K, const floa
     p.vecB = (ldb % 4 == 0) && ((uintptr_t)B % 16 == 0);
     const int tm = cdiv(M, BM), tn = cdiv(N, BN);
     const int tiles = tm * tn;
+    // split-K choice by a small cost model (ns): a CU works through its co-resident blocks at ~0.39 TFLOP/s
+    // (84 ns per k per 128x128 block; 1.3x slower when it holds a single block), slabs cost their HBM traffic.
     int splits = 1;
-    if (ws && tiles < 192 && K >= 256) {
-        splits = 512 / tiles;
-        if (splits > K / 64) splits = K / 64;
+    if (ws && K >= 512) {
         const size_t cap = ws_bytes / ((size_t)M * N * sizeof(float));
-        if ((size_t)splits > cap) splits = (int)cap;
-        if (splits < 1) splits = 1;
+        double best = 1e30;
+        for (int sp = 1; sp <= 96 && sp <= K / 96 && (sp == 1 || (size_t)sp <= cap); ++sp) {
+            const int rounds = cdiv(tiles * sp, 256);
+            double t = (double)rounds * ((double)K / sp) * 84.0 * (rounds == 1 ? 1.3 : 1.0);
+            if (sp > 1) t += (double)(sp + 2) * M * N * 4.0 / 3000.0 + 3000.0;
+            if (t < best) { best = t; splits = sp; }
+        }
     }
     int kchunk = cdiv(cdiv(K, splits), BK) * BK;
     if (kchunk < BK) kchunk = BK;
@@ -283,10 +354,19 @@ extern "C" int m3t_sgemm(int transA, int transB, int M, int N, int K, const floa
     p.splits = splits; p.kchunk = kchunk;
     dim3 grid(tn, tm, splits), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (transA == 0 && transB == 1) sgemm_kernel<0, 1><<<grid, block, 0, s>>>(p);
-    else if (transA == 0 && transB == 0) sgemm_kernel<0, 0><<<grid, block, 0, s>>>(p);
-    else if (transA == 1 && transB == 0) sgemm_kernel<1, 0><<<grid, block, 0, s>>>(p);
-    else sgemm_kernel<1, 1><<<grid, block, 0, s>>>(p);
+    const bool fast = (M % BM == 0) && (N % BN == 0) && (K % BK == 0) && K > 0 && p.vecA && p.vecB;
+#define M3T_GEMM_LAUNCH(TA_, TB_)                                                 \
+    do {                                                                          \
+        if (fast && seg_len >= BK) sgemm_kernel<TA_, TB_, true, true><<<grid, block, 0, s>>>(p); \
+        else if (seg_len > 0) sgemm_kernel<TA_, TB_, false><<<grid, block, 0, s>>>(p);           \
+        else if (fast) sgemm_kernel<TA_, TB_, true><<<grid, block, 0, s>>>(p);    \
+        else sgemm_kernel<TA_, TB_, false><<<grid, block, 0, s>>>(p);             \
+    } while (0)
+    if (transA == 0 && transB == 1) M3T_GEMM_LAUNCH(0, 1);
+    else if (transA == 0 && transB == 0) M3T_GEMM_LAUNCH(0, 0);
+    else if (transA == 1 && transB == 0) M3T_GEMM_LAUNCH(1, 0);
+    else M3T_GEMM_LAUNCH(1, 1);
+#undef M3T_GEMM_LAUNCH
     M3T_LAUNCH_CHECK();
     if (splits > 1) {
         const size_t total = (size_t)M * N;

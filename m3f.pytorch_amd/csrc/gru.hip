@@ -459,11 +459,94 @@ __global__ __launch_bounds__(NT) void gru_step_bwd_kernel(BwdGroup g, int B, int
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------
+// hipGraph replay of a whole T-launch scan.  The T step kernels of a call differ only in `step`, and in a
+// training loop the same (pointers, shapes) recur every iteration (caching allocator), so a call is captured
+// once into a graph (stream capture, thread-local mode), instantiated, and replayed afterwards: one
+// hipGraphLaunch instead of T launches.  Keyed by the exact argument bytes; small LRU; M3T_GRAPH=0 disables.
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+namespace {
+
+struct GraphEntry {
+    std::vector<unsigned char> key;
+    hipGraphExec_t exec;
+    unsigned long long stamp;
+};
+std::mutex g_graph_mu;
+std::vector<GraphEntry> g_graphs;
+unsigned long long g_graph_clock = 0;
+constexpr size_t kMaxGraphs = 96;
+
+bool graphs_enabled() {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = std::getenv("M3T_GRAPH");
+        on = (e && e[0] == '0') ? 0 : 1;
+    }
+    return on == 1;
+}
+
+template <typename Launch>
+int replay_or_capture(const std::vector<unsigned char>& key, hipStream_t s, Launch&& launch_all) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone || !graphs_enabled()) {
+        launch_all();            // already inside somebody else's capture (or disabled): plain launches
+        return (int)hipGetLastError();
+    }
+    std::lock_guard<std::mutex> lk(g_graph_mu);
+    for (auto& e : g_graphs)
+        if (e.key == key) {
+            e.stamp = ++g_graph_clock;
+            return (int)hipGraphLaunch(e.exec, s);
+        }
+    hipGraph_t graph = nullptr;
+    hipError_t err = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+    if (err != hipSuccess) {     // capture unavailable on this stream: fall back to plain launches
+        (void)hipGetLastError();
+        launch_all();
+        return (int)hipGetLastError();
+    }
+    launch_all();
+    err = hipStreamEndCapture(s, &graph);
+    if (err != hipSuccess || !graph) return (int)(err != hipSuccess ? err : hipErrorUnknown);
+    hipGraphExec_t exec = nullptr;
+    err = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (err != hipSuccess) return (int)err;
+    if (g_graphs.size() >= kMaxGraphs) {
+        size_t victim = 0;
+        for (size_t i = 1; i < g_graphs.size(); ++i)
+            if (g_graphs[i].stamp < g_graphs[victim].stamp) victim = i;
+        (void)hipGraphExecDestroy(g_graphs[victim].exec);
+        g_graphs.erase(g_graphs.begin() + victim);
+    }
+    g_graphs.push_back({key, exec, ++g_graph_clock});
+    return (int)hipGraphLaunch(exec, s);
+}
+
+template <typename G>
+std::vector<unsigned char> make_key(int kind, const G& g, const FragPtrs* fp, int B, int T, int variant) {
+    std::vector<unsigned char> k(sizeof(int) * 4 + sizeof(G) + (fp ? sizeof(FragPtrs) : 0));
+    unsigned char* p = k.data();
+    const int hdr[4] = {kind, B, T, variant};
+    std::memcpy(p, hdr, sizeof(hdr)); p += sizeof(hdr);
+    std::memcpy(p, &g, sizeof(G)); p += sizeof(G);
+    if (fp) std::memcpy(p, fp, sizeof(FragPtrs));
+    return k;
+}
+
+}  // namespace
+
 extern "C" int m3t_gru_scan_fwd(const m3t_gru_fwd_desc* scans, int n_scans, int B, int T, float* ws, size_t ws_bytes,
                                 void* stream) {
     if (n_scans <= 0 || B <= 0 || T <= 0) return 0;
     if (n_scans > M3T_MAX_SCANS || !scans) return M3T_EINVAL;
     FwdGroup g;
+    std::memset(&g, 0, sizeof(g));
     g.n = n_scans;
     int blocks = 0;
     for (int i = 0; i < n_scans; ++i) {
@@ -491,18 +574,22 @@ extern "C" int m3t_gru_scan_fwd(const m3t_gru_fwd_desc* scans, int n_scans, int 
     }
     if (frag && need * sizeof(float) <= ws_bytes) {
         FragPtrs fp;
+        std::memset(&fp, 0, sizeof(fp));
         float* p = ws;
         for (int i = 0; i < n_scans; ++i) {
             const int H = scans[i].H;
             fp.wfrag[i] = p; p += (size_t)3 * H * H;
             fp.xfrag[i] = p; fp.xstride[i] = bpad * H; p += 2 * bpad * H;
-            int blk = (3 * H * H + 255) / 256;
-            if (blk > 1024) blk = 1024;
-            wfrag_fwd_prep_kernel<<<blk, 256, 0, s>>>(scans[i].w_hh, fp.wfrag[i], H);
         }
-        for (int step = 0; step < T; ++step) gru_step_fwd_frag_kernel<<<grid, NT, 0, s>>>(g, fp, B, T, step);
-        M3T_LAUNCH_CHECK();
-        return 0;
+        return replay_or_capture(make_key(1, g, &fp, B, T, 0), s, [&]() {
+            for (int i = 0; i < n_scans; ++i) {
+                const int H = scans[i].H;
+                int blk = (3 * H * H + 255) / 256;
+                if (blk > 1024) blk = 1024;
+                wfrag_fwd_prep_kernel<<<blk, 256, 0, s>>>(scans[i].w_hh, fp.wfrag[i], H);
+            }
+            for (int step = 0; step < T; ++step) gru_step_fwd_frag_kernel<<<grid, NT, 0, s>>>(g, fp, B, T, step);
+        });
     }
     if (fast)
         for (int step = 0; step < T; ++step) gru_step_fwd_kernel<true><<<grid, NT, 0, s>>>(g, B, T, step);
@@ -517,6 +604,7 @@ extern "C" int m3t_gru_scan_bwd(const m3t_gru_bwd_desc* scans, int n_scans, int 
     if (n_scans <= 0 || B <= 0 || T <= 0) return 0;
     if (n_scans > M3T_MAX_SCANS || !scans) return M3T_EINVAL;
     BwdGroup g;
+    std::memset(&g, 0, sizeof(g));
     g.n = n_scans;
     int blocks = 0;
     for (int i = 0; i < n_scans; ++i) {
@@ -543,18 +631,22 @@ extern "C" int m3t_gru_scan_bwd(const m3t_gru_bwd_desc* scans, int n_scans, int 
     }
     if (frag && need * sizeof(float) <= ws_bytes) {
         FragPtrs fp;
+        std::memset(&fp, 0, sizeof(fp));
         float* p = ws;
         for (int i = 0; i < n_scans; ++i) {
             const int H = scans[i].H;
             fp.wfrag[i] = p; p += (size_t)3 * H * H;
             fp.xfrag[i] = p; fp.xstride[i] = bpad * 3 * H; p += 2 * bpad * 3 * H;
-            int blk = (3 * H * H + 255) / 256;
-            if (blk > 1024) blk = 1024;
-            wfrag_bwd_prep_kernel<<<blk, 256, 0, s>>>(scans[i].w_hh_t, fp.wfrag[i], H);
         }
-        for (int step = 0; step < T; ++step) gru_step_bwd_frag_kernel<<<grid, NT, 0, s>>>(g, fp, B, T, step);
-        M3T_LAUNCH_CHECK();
-        return 0;
+        return replay_or_capture(make_key(2, g, &fp, B, T, 0), s, [&]() {
+            for (int i = 0; i < n_scans; ++i) {
+                const int H = scans[i].H;
+                int blk = (3 * H * H + 255) / 256;
+                if (blk > 1024) blk = 1024;
+                wfrag_bwd_prep_kernel<<<blk, 256, 0, s>>>(scans[i].w_hh_t, fp.wfrag[i], H);
+            }
+            for (int step = 0; step < T; ++step) gru_step_bwd_frag_kernel<<<grid, NT, 0, s>>>(g, fp, B, T, step);
+        });
     }
     if (fast)
         for (int step = 0; step < T; ++step) gru_step_bwd_kernel<true><<<grid, NT, 0, s>>>(g, B, T, step);

@@ -18,6 +18,18 @@ _WS_MIN = 64 << 20
 # bracketed by HIP events on the stream the kernels are launched on.
 PROFILE = []
 PROFILE_ON = [False]
+PROFILE_GEMM = [False]      # ~90 extra event pairs per step: off unless asked for
+
+
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NULL = _Null()
 
 
 class _Timed:
@@ -78,7 +90,7 @@ def workspace(device, nbytes=_WS_MIN):
 def sgemm(transA, transB, M, N, K, A, a_off, lda, B, b_off, ldb, Cm, c_off, ldc, bias=None, act=0,
           accumulate=False, seg=(0, 0, 0, 0), use_ws=True):
     ws = workspace(Cm.device) if use_ws else None
-    with _Timed("sgemm_kernel", 1, 2.0 * M * N * K):
+    with _Timed("sgemm_kernel", 1, 2.0 * M * N * K) if PROFILE_GEMM[0] else _NULL:
         rc = lib().m3t_sgemm(transA, transB, M, N, K, _p(A, a_off), lda, _p(B, b_off), ldb, _p(Cm, c_off), ldc,
                              _p(bias), act, int(accumulate), seg[0], seg[1], seg[2], seg[3],
                              _p(ws), (ws.numel() * 4) if ws is not None else 0, _stream())
@@ -206,7 +218,7 @@ class _MultiBiGRU(torch.autograd.Function):
                 gates = torch.empty(2, B, T, 4 * H, dtype=torch.float32, device=dev)
                 for d in (0, 1):
                     w_ih, w_hh, b_ih, b_hh = params[s][(2 * l + d) * 4:(2 * l + d) * 4 + 4]
-                    sgemm(0, 1, B * T, 3 * H, I, inp, 0, I, w_ih, 0, I, xproj, d * 3 * H, 6 * H, bias=b_ih, use_ws=False)
+                    sgemm(0, 1, B * T, 3 * H, I, inp, 0, I, w_ih, 0, I, xproj, d * 3 * H, 6 * H, bias=b_ih)
                     descs.append(GruFwdDesc(_vp(xproj), _vp(w_hh), _vp(b_hh), _vp(out), _vp(gates, d * B * T * 4 * H),
                                             _vp(h_ns[s], (2 * l + d) * B * H), H, d, 6 * H, d * 3 * H, 2 * H, d * H))
                 saved += [out, gates]
@@ -292,7 +304,7 @@ class _MultiBiGRU(torch.autograd.Function):
                     for d in (0, 1):
                         w_ih = params[s][(2 * l + d) * 4]
                         sgemm(0, 0, B * T, I, 3 * H, dgx, d * 3 * H, 6 * H, w_ih, 0, I, dinp, 0, I,
-                              accumulate=(d == 1), use_ws=False)
+                              accumulate=(d == 1))
                     new_douts.append(dinp)
                 else:
                     new_douts.append(None)
