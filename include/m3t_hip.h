@@ -28,6 +28,9 @@ extern "C" {
 
 #define M3T_EINVAL 10001
 #define M3T_MAX_SCANS 8
+/* m3t_sgemm flags: BACKGROUND caps residency at one workgroup per CU (for GEMMs that run on a side stream
+ * beside the latency-critical recurrence, e.g. weight gradients) */
+#define M3T_GEMM_BACKGROUND 1
 
 /* library / device info: returns the ABI version; arch string copied to `arch` if non-null */
 int m3t_version(void);
@@ -43,13 +46,14 @@ int m3t_device_arch(char* arch, int cap);
  *   storage row of A = (k / seg_len) * seg_stride + k % seg_len + a_off, same for B
  *   with b_off (used for dW_hh = sum_t dgh_t^T h_{t-1}: per-clip shifted rows).
  * ws/ws_bytes: optional split-K workspace (deterministic slab reduction); may be NULL.
+ * flags: 0 or M3T_GEMM_BACKGROUND.
  * Replaces: nn.Linear (models/rnn.py:22-55, models/model.py:88, models/att_fusion.py:13),
  * the input projections W_ih x inside nn.GRU (models/rnn.py:17,75) and their autograd. */
 int m3t_sgemm(int transA, int transB, int M, int N, int K,
               const float* A, int lda, const float* B, int ldb,
               float* C, int ldc, const float* bias, int act, int accumulate,
               int seg_len, int seg_stride, int a_off, int b_off,
-              float* ws, size_t ws_bytes, void* stream);
+              float* ws, size_t ws_bytes, int flags, void* stream);
 
 /* out[n] (+)= sum_m X[m*ld + n], m<M, n<N  (bias gradients); ws optional (tall inputs) */
 int m3t_colsum(const float* X, int M, int N, int ld, float* out, int accumulate,

@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void spatial_bwd_dx_kernel(const float* __rest
 }  // namespace
 
 extern "C" int m3t_sgemm(int, int, int, int, int, const float*, int, const float*, int, float*, int, const float*, int, int,
-                         int, int, int, int, float*, size_t, void*);
+                         int, int, int, int, float*, size_t, int, void*);
 extern "C" int m3t_colsum(const float*, int, int, int, float*, int, float*, size_t, void*);
 
 extern "C" int m3t_cbam_channel_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
@@ -406,12 +406,12 @@ extern "C" int m3t_cbam_channel_bwd(const float* dy, const float* x, const float
     M3T_LAUNCH_CHECK();
     int rc;
     // dW2[C,Cr] = datt^T R ; db2 = 2 * colsum(datt)
-    if ((rc = m3t_sgemm(1, 0, C, Cr, N, g_datt, C, g_r, Cr, dw2, Cr, nullptr, 0, 0, 0, 0, 0, 0, rest, rest_bytes, stream))) return rc;
+    if ((rc = m3t_sgemm(1, 0, C, Cr, N, g_datt, C, g_r, Cr, dw2, Cr, nullptr, 0, 0, 0, 0, 0, 0, rest, rest_bytes, 0, stream))) return rc;
     if ((rc = m3t_colsum(g_datt, N, C, C, db2, 0, rest, rest_bytes, stream))) return rc;
     if ((rc = m3t_colsum(g_datt, N, C, C, db2, 1, rest, rest_bytes, stream))) return rc;
     // dW1[Cr,C] = dha^T avg + dhm^T max ; db1 = colsum(dha) + colsum(dhm)
-    if ((rc = m3t_sgemm(1, 0, Cr, C, N, g_dh, 2 * Cr, pooled, 2 * C, dw1, C, nullptr, 0, 0, 0, 0, 0, 0, rest, rest_bytes, stream))) return rc;
-    if ((rc = m3t_sgemm(1, 0, Cr, C, N, g_dh + Cr, 2 * Cr, pooled + C, 2 * C, dw1, C, nullptr, 0, 1, 0, 0, 0, 0, rest, rest_bytes, stream))) return rc;
+    if ((rc = m3t_sgemm(1, 0, Cr, C, N, g_dh, 2 * Cr, pooled, 2 * C, dw1, C, nullptr, 0, 0, 0, 0, 0, 0, rest, rest_bytes, 0, stream))) return rc;
+    if ((rc = m3t_sgemm(1, 0, Cr, C, N, g_dh + Cr, 2 * Cr, pooled + C, 2 * C, dw1, C, nullptr, 0, 1, 0, 0, 0, 0, rest, rest_bytes, 0, stream))) return rc;
     if ((rc = m3t_colsum(g_dh, N, Cr, 2 * Cr, db1, 0, rest, rest_bytes, stream))) return rc;
     if ((rc = m3t_colsum(g_dh + Cr, N, Cr, 2 * Cr, db1, 1, rest, rest_bytes, stream))) return rc;
     return 0;

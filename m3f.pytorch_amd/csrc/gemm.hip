@@ -5,6 +5,7 @@
 // for tile k+1 are issued before the MFMAs of tile k (register prefetch, double LDS buffer).
 // Split-K goes through fp32 slabs + a fixed-order reduce: deterministic, no atomics.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -320,9 +321,22 @@ __global__ void mask_pos_kernel(const float* __restrict__ s, const float* __rest
 
 }  // namespace
 
+int m3t_sgemm_x6_launch(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                        float* C, int ldc, const float* bias, int act, int accumulate, int seg_len, int seg_stride,
+                        int a_off, int b_off, float* ws, int splits, int kchunk, size_t dyn_lds, hipStream_t s);
+
+static bool x6_enabled() {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("M3T_GEMM_X6");
+        on = (e && e[0] == '0') ? 0 : 1;
+    }
+    return on == 1;
+}
+
 extern "C" int m3t_sgemm(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                          float* C, int ldc, const float* bias, int act, int accumulate, int seg_len, int seg_stride,
-                         int a_off, int b_off, float* ws, size_t ws_bytes, void* stream) {
+                         int a_off, int b_off, float* ws, size_t ws_bytes, int flags, void* stream) {
     if (M <= 0 || N <= 0) return 0;
     if (K < 0 || !A || !B || !C) return M3T_EINVAL;
     if (seg_len > 0 && !(transA == 1 && transB == 0)) return M3T_EINVAL;
@@ -335,6 +349,11 @@ extern "C" int m3t_sgemm(int transA, int transB, int M, int N, int K, const floa
     p.vecB = (ldb % 4 == 0) && ((uintptr_t)B % 16 == 0);
     const int tm = cdiv(M, BM), tn = cdiv(N, BN);
     const int tiles = tm * tn;
+    // interior shapes go to the bf16x6 kernel (fp32-accurate, 2.67x the fp32 MFMA rate): gemm_x6.hip
+    const bool x6 = x6_enabled() && (M % 128 == 0) && (N % 128 == 0) && (K % 32 == 0) && K > 0 && p.vecA && p.vecB &&
+                    (seg_len == 0 || seg_len >= 32);
+    const double ns_per_k = x6 ? 36.0 : 84.0;
+    const int kq = x6 ? 32 : BK;
     // split-K choice by a small cost model (ns): a CU works through its co-resident blocks at ~0.39 TFLOP/s
     // (84 ns per k per 128x128 block; 1.3x slower when it holds a single block), slabs cost their HBM traffic.
     int splits = 1;
@@ -343,24 +362,41 @@ extern "C" int m3t_sgemm(int transA, int transB, int M, int N, int K, const floa
         double best = 1e30;
         for (int sp = 1; sp <= 96 && sp <= K / 96 && (sp == 1 || (size_t)sp <= cap); ++sp) {
             const int rounds = cdiv(tiles * sp, 256);
-            double t = (double)rounds * ((double)K / sp) * 84.0 * (rounds == 1 ? 1.3 : 1.0);
+            double t = (double)rounds * ((double)K / sp) * ns_per_k * (rounds == 1 ? 1.3 : 1.0);
             if (sp > 1) t += (double)(sp + 2) * M * N * 4.0 / 3000.0 + 3000.0;
             if (t < best) { best = t; splits = sp; }
         }
     }
-    int kchunk = cdiv(cdiv(K, splits), BK) * BK;
-    if (kchunk < BK) kchunk = BK;
+    int kchunk = cdiv(cdiv(K, splits), kq) * kq;
+    if (kchunk < kq) kchunk = kq;
     splits = K > 0 ? cdiv(K, kchunk) : 1;
     p.splits = splits; p.kchunk = kchunk;
     dim3 grid(tn, tm, splits), block(256);
     hipStream_t s = (hipStream_t)stream;
+    if (x6) {
+        const size_t dyn6 = (flags & M3T_GEMM_BACKGROUND) ? (size_t)40 * 1024 : 0;
+        const int rc = m3t_sgemm_x6_launch(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, seg_len,
+                                           seg_stride, a_off, b_off, ws, splits, kchunk, dyn6, s);
+        if (rc) return rc;
+        if (splits > 1) {
+            const size_t total = (size_t)M * N;
+            int blocks = (int)((total + 255) / 256);
+            if (blocks > 2048) blocks = 2048;
+            splitk_reduce_kernel<<<blocks, 256, 0, s>>>(ws, C, bias, M, N, ldc, splits, act, accumulate);
+            M3T_LAUNCH_CHECK();
+        }
+        return 0;
+    }
     const bool fast = (M % BM == 0) && (N % BN == 0) && (K % BK == 0) && K > 0 && p.vecA && p.vecB;
+    // M3T_GEMM_BACKGROUND: an (unused) dynamic-LDS request of 56 KiB caps residency at ONE workgroup per CU, so a
+    // latency-critical kernel on another stream (the GRU scans) still finds room on every CU.
+    const size_t dyn = (flags & M3T_GEMM_BACKGROUND) ? (size_t)56 * 1024 + 0 : 0;
 #define M3T_GEMM_LAUNCH(TA_, TB_)                                                 \
     do {                                                                          \
-        if (fast && seg_len >= BK) sgemm_kernel<TA_, TB_, true, true><<<grid, block, 0, s>>>(p); \
-        else if (seg_len > 0) sgemm_kernel<TA_, TB_, false><<<grid, block, 0, s>>>(p);           \
-        else if (fast) sgemm_kernel<TA_, TB_, true><<<grid, block, 0, s>>>(p);    \
-        else sgemm_kernel<TA_, TB_, false><<<grid, block, 0, s>>>(p);             \
+        if (fast && seg_len >= BK) sgemm_kernel<TA_, TB_, true, true><<<grid, block, dyn, s>>>(p); \
+        else if (seg_len > 0) sgemm_kernel<TA_, TB_, false><<<grid, block, dyn, s>>>(p);           \
+        else if (fast) sgemm_kernel<TA_, TB_, true><<<grid, block, dyn, s>>>(p);    \
+        else sgemm_kernel<TA_, TB_, false><<<grid, block, dyn, s>>>(p);             \
     } while (0)
     if (transA == 0 && transB == 1) M3T_GEMM_LAUNCH(0, 1);
     else if (transA == 0 && transB == 0) M3T_GEMM_LAUNCH(0, 0);

@@ -1,0 +1,250 @@
+// fp32-accurate GEMM on the bf16 matrix pipe ("bf16x6").
+// gfx950 has no reduced-precision fast path for fp32 inputs (no xf32/TF32): v_mfma_f32_*_f32 runs at the vector
+// rate, 1/16 of the bf16 MFMA rate.  Each fp32 operand is therefore split EXACTLY into three bf16 terms
+// (a = a1 + a2 + a3, 24 significant bits) while its tile is written to LDS, and a product is the six bf16 MFMAs
+// whose weight is >= 2^-16 (a1b1, a1b2, a2b1, a1b3, a2b2, a3b1; the dropped terms are <= 2^-24 relative), all
+// accumulated in fp32, smallest first.  Error vs an fp64 reference: ~1e-6 absolute on O(1) outputs at K = 1024 --
+// the same as a plain fp32 fmaf chain (tools/x6_accuracy.py); cost: 6 x 16-deep bf16 MFMAs instead of 8 x 2-deep
+// fp32 ones per 16 k = 2.67x the fp32 MFMA rate (~420 TFLOP/s ceiling), deterministic.
+//
+// Tile: 128 x 128 x 32, 4 waves (2 x 2), each wave 64 x 64 = 2 x 2 v_mfma_f32_32x32x16_bf16 tiles.
+// LDS (single buffer, 48 KiB -> 3 workgroups/CU): per operand and split, [k-half 2][k-quad 4][128 rows][4 k] bf16,
+// i.e. 8 B per (row, k-quad) and rows contiguous inside a k-quad plane.  A fragment (row = lane&31,
+// k = 8*(lane>>5)..+7) is two conflict-free ds_read_b64 (32 lanes x 8 B contiguous each); a thread that loaded a
+// float4 along the ROW dimension (row-contiguous operands) writes its 4 rows of one k-quad as 32 contiguous
+// bytes, so both operand layouts store without bank conflicts.  Global loads of tile t+1 stay in flight in
+// registers while tile t is multiplied.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int XM = 128, XN = 128, XK = 32;
+constexpr int SPLIT_BYTES = 2 * XM * 32;           // one split of one operand: 2 k-halves x 128 rows x 32 B = 8 KiB
+constexpr int OPER_BYTES = 3 * SPLIT_BYTES;        // 24 KiB
+
+struct X6Params {
+    const float* A; const float* B; float* C; const float* bias; float* ws;
+    int M, N, K, lda, ldb, ldc;
+    int act, accumulate, splits, kchunk;
+    int seg_len, seg_stride, a_off, b_off;
+};
+
+__device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
+    h = (__bf16)x;
+    const float r1 = x - (float)h;
+    m = (__bf16)r1;
+    const float r2 = r1 - (float)m;
+    l = (__bf16)r2;
+}
+
+// ---- K-contiguous operand ([rows][K]): thread = (row = tid>>1, k-half = tid&1) holds 16 consecutive k
+__device__ __forceinline__ void kc_load(const float* __restrict__ p, float4 (&r)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = reinterpret_cast<const float4*>(p)[i];
+}
+__device__ __forceinline__ void kc_store(unsigned char* __restrict__ S, const float4 (&r)[4]) {
+    const int tid = threadIdx.x;
+    const int row = tid >> 1, kh = tid & 1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                     // k-quad q of this half = r[q]
+        const float v[4] = {r[q].x, r[q].y, r[q].z, r[q].w};
+        bf16x4 o[3];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            __bf16 h, m, l;
+            split3(v[e], h, m, l);
+            o[0][e] = h; o[1][e] = m; o[2][e] = l;
+        }
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+            *reinterpret_cast<bf16x4*>(S + s * SPLIT_BYTES + ((kh * 4 + q) * XM + row) * 8) = o[s];
+    }
+}
+// ---- row-contiguous operand ([K][rows]): thread = (k-quad = tid>>5 (4 k), 4 rows at (tid&31)*4): a 4x4 block
+__device__ __forceinline__ void mc_store(unsigned char* __restrict__ S, const float4 (&r)[4]) {
+    const int tid = threadIdx.x;
+    const int kq = tid >> 5, row0 = (tid & 31) * 4;   // k-quad kq of the 32-k tile: half = kq>>2, quad = kq&3
+    bf16x8 o[3][2];                                   // [split][row pair]: rows (row0, row0+1), (row0+2, row0+3)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                     // row row0 + i: its 4 k values are component i of r[0..3]
+        const float v[4] = {i == 0 ? r[0].x : i == 1 ? r[0].y : i == 2 ? r[0].z : r[0].w,
+                            i == 0 ? r[1].x : i == 1 ? r[1].y : i == 2 ? r[1].z : r[1].w,
+                            i == 0 ? r[2].x : i == 1 ? r[2].y : i == 2 ? r[2].z : r[2].w,
+                            i == 0 ? r[3].x : i == 1 ? r[3].y : i == 2 ? r[3].z : r[3].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            __bf16 h, m, l;
+            split3(v[e], h, m, l);
+            o[0][i >> 1][(i & 1) * 4 + e] = h;
+            o[1][i >> 1][(i & 1) * 4 + e] = m;
+            o[2][i >> 1][(i & 1) * 4 + e] = l;
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {                     // 4 rows x 8 B = 32 contiguous bytes per split
+        unsigned char* q = S + s * SPLIT_BYTES + (kq * XM + row0) * 8;
+        *reinterpret_cast<bf16x8*>(q) = o[s][0];
+        *reinterpret_cast<bf16x8*>(q + 16) = o[s][1];
+    }
+}
+
+template <int TA, int TB, bool SEG>
+__global__ __launch_bounds__(256) void sgemm_x6_kernel(X6Params p) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * OPER_BYTES];   // A | B, 48 KiB
+    unsigned char* As = lds;
+    unsigned char* Bs = lds + OPER_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    const int tn_ = gridDim.x, nt_ = gridDim.x * gridDim.y;
+    const int lin = blockIdx.y * tn_ + blockIdx.x;
+    const int xq = nt_ >> 3, xr = nt_ & 7, xcd = lin & 7, slot = lin >> 3;
+    const int til = xcd * xq + min(xcd, xr) + slot;           // XCD-contiguous tile order (see gemm.hip)
+    const int bm = (til / tn_) * XM, bn = (til % tn_) * XN;
+    const int k_begin = blockIdx.z * p.kchunk;
+    const int k_end = min(p.K, k_begin + p.kchunk);
+    const int ntiles = (k_end - k_begin) / XK;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // per-thread operand pointers
+    const float* pa; const float* pb;
+    size_t a_step, b_step, a_krow = 0, b_krow = 0;
+    if (TA == 0) { pa = p.A + (size_t)(bm + (tid >> 1)) * p.lda + k_begin + (tid & 1) * 16; a_step = XK; }
+    else { pa = p.A + (size_t)(k_begin + (tid >> 5) * 4) * p.lda + bm + (tid & 31) * 4; a_step = (size_t)XK * p.lda; a_krow = p.lda; }
+    if (TB == 1) { pb = p.B + (size_t)(bn + (tid >> 1)) * p.ldb + k_begin + (tid & 1) * 16; b_step = XK; }
+    else { pb = p.B + (size_t)(k_begin + (tid >> 5) * 4) * p.ldb + bn + (tid & 31) * 4; b_step = (size_t)XK * p.ldb; b_krow = p.ldb; }
+    // segmented reduction rows (dW_hh): (segment, offset) of this thread's first k row, advanced per tile
+    int sq = 0, sr = 0;
+    if (SEG) {
+        const int k = k_begin + (tid >> 5) * 4;
+        sq = k / p.seg_len; sr = k % p.seg_len;
+    }
+
+    float4 ra[4], rb[4];
+    auto gload = [&]() {
+        if (SEG) {   // TA == 1 && TB == 0: both operands row-contiguous, k rows through the segment map
+            int q = sq, r = sr;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const size_t row = (size_t)q * p.seg_stride + r;
+                ra[e] = *reinterpret_cast<const float4*>(p.A + (row + p.a_off) * p.lda + bm + (tid & 31) * 4);
+                rb[e] = *reinterpret_cast<const float4*>(p.B + (row + p.b_off) * p.ldb + bn + (tid & 31) * 4);
+                if (++r >= p.seg_len) { r = 0; ++q; }
+            }
+            sr += XK;
+            while (sr >= p.seg_len) { sr -= p.seg_len; ++sq; }
+        } else {
+            if (TA == 0) kc_load(pa, ra);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ra[e] = *reinterpret_cast<const float4*>(pa + e * a_krow);
+            }
+            if (TB == 1) kc_load(pb, rb);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rb[e] = *reinterpret_cast<const float4*>(pb + e * b_krow);
+            }
+            pa += a_step; pb += b_step;
+        }
+    };
+    auto sstore = [&]() {
+        if (TA == 0) kc_store(As, ra); else mc_store(As, ra);
+        if (TB == 1) kc_store(Bs, rb); else mc_store(Bs, rb);
+    };
+
+    if (ntiles > 0) { gload(); sstore(); }
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) gload();
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            bf16x8 fa[3][2], fb[3][2];
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const unsigned char* qa = As + s * SPLIT_BYTES + ((kh * 4 + 2 * hi) * XM + wm * 64 + i * 32 + l31) * 8;
+                    const unsigned char* qb = Bs + s * SPLIT_BYTES + ((kh * 4 + 2 * hi) * XN + wn * 64 + i * 32 + l31) * 8;
+                    const bf16x4 a0 = *reinterpret_cast<const bf16x4*>(qa), a1 = *reinterpret_cast<const bf16x4*>(qa + XM * 8);
+                    const bf16x4 b0 = *reinterpret_cast<const bf16x4*>(qb), b1 = *reinterpret_cast<const bf16x4*>(qb + XN * 8);
+                    fa[s][i] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    fb[s][i] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    f32x16 c = acc[i][j];      // smallest terms first
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2][i], fb[0][j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[1][j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[2][j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[0][j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[1][j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[0][j], c, 0, 0, 0);
+                    acc[i][j] = c;
+                }
+        }
+        __syncthreads();                       // everyone is done reading this tile
+        if (t + 1 < ntiles) {
+            sstore();
+            __syncthreads();
+        }
+    }
+
+    const bool direct = p.splits == 1;
+    float* dst = direct ? p.C : p.ws + (size_t)blockIdx.z * p.M * p.N;
+    const int ldd = direct ? p.ldc : p.N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = bn + wn * 64 + j * 32 + l31;
+            const float bv = (direct && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = bm + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                float v = acc[i][j][r];
+                float* q = dst + (size_t)row * ldd + col;
+                if (direct) {
+                    v += bv;
+                    if (p.act == 1) v = fmaxf(v, 0.f);
+                    if (p.accumulate) v += *q;
+                }
+                *q = v;
+            }
+        }
+}
+
+}  // namespace
+
+// Launches the bf16x6 kernel; the caller (m3t_sgemm) has verified: M % 128 == 0, N % 128 == 0, K % 32 == 0,
+// kchunk % 32 == 0, 16-B aligned operands with ld % 4 == 0, and seg_len >= 32 when segmented.
+int m3t_sgemm_x6_launch(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                        float* C, int ldc, const float* bias, int act, int accumulate, int seg_len, int seg_stride,
+                        int a_off, int b_off, float* ws, int splits, int kchunk, size_t dyn_lds, hipStream_t s) {
+    X6Params p;
+    p.A = A; p.B = B; p.C = C; p.bias = bias; p.ws = ws;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.act = act; p.accumulate = accumulate; p.splits = splits; p.kchunk = kchunk;
+    p.seg_len = seg_len; p.seg_stride = seg_stride; p.a_off = a_off; p.b_off = b_off;
+    dim3 grid(N / XN, M / XM, splits), block(256);
+    if (seg_len > 0) sgemm_x6_kernel<1, 0, true><<<grid, block, dyn_lds, s>>>(p);
+    else if (transA == 0 && transB == 1) sgemm_x6_kernel<0, 1, false><<<grid, block, dyn_lds, s>>>(p);
+    else if (transA == 0 && transB == 0) sgemm_x6_kernel<0, 0, false><<<grid, block, dyn_lds, s>>>(p);
+    else if (transA == 1 && transB == 0) sgemm_x6_kernel<1, 0, false><<<grid, block, dyn_lds, s>>>(p);
+    else sgemm_x6_kernel<1, 1, false><<<grid, block, dyn_lds, s>>>(p);
+    hipError_t e = hipGetLastError();
+    return (int)e;
+}

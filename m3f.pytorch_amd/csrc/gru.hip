@@ -136,18 +136,19 @@ struct FragPtrs {
     size_t xstride[M3T_MAX_SCANS];  // floats per ping-pong buffer
 };
 
-// NC = chunks per wave kept in flight; CT = column tiles.  A frag: [chunk][2 row tiles][64][4]; B frag: [chunk][CT][64][4]
-template <int CT, int NC>
+// NC = chunks per wave kept in flight; CT = column tiles; RT = row tiles.
+// A frag: [chunk][RT row tiles][64][4]; B frag: [chunk][CT][64][4]
+template <int CT, int NC, int RT>
 __device__ __forceinline__ void wave_mma_frag(const float4* __restrict__ Af, const float4* __restrict__ Bf, int nchunks,
-                                              int wave, int lane, f32x4 (&acc)[2][CT]) {
+                                              int wave, int lane, f32x4 (&acc)[RT][CT]) {
     for (int c0 = wave; c0 < nchunks; c0 += NW * NC) {
-        float4 a[NC][2], b[NC][CT];
+        float4 a[NC][RT], b[NC][CT];
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
             const int c = c0 + i * NW;
             if (c < nchunks) {
 #pragma unroll
-                for (int rt = 0; rt < 2; ++rt) a[i][rt] = Af[((size_t)c * 2 + rt) * 64 + lane];
+                for (int rt = 0; rt < RT; ++rt) a[i][rt] = Af[((size_t)c * RT + rt) * 64 + lane];
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) b[i][ct] = Bf[((size_t)c * CT + ct) * 64 + lane];
             }
@@ -156,7 +157,7 @@ __device__ __forceinline__ void wave_mma_frag(const float4* __restrict__ Af, con
         for (int i = 0; i < NC; ++i) {
             if (c0 + i * NW >= nchunks) break;
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
+            for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
                     acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][rt].x, b[i][ct].x, acc[rt][ct], 0, 0, 0);
@@ -168,47 +169,55 @@ __device__ __forceinline__ void wave_mma_frag(const float4* __restrict__ Af, con
     }
 }
 
+// RT row tiles per workgroup: RT = 2 covers 32 batch rows, RT = 1 covers 16 (twice the workgroups, half the MFMA
+// chain each -- used when the level would otherwise leave most CUs idle).  Always 8 waves: K is split 8 ways.
+template <int RT>
 __global__ __launch_bounds__(NT) void gru_step_fwd_frag_kernel(FwdGroup g, FragPtrs fp, int B, int T, int step) {
-    __shared__ float red[NW][3][RB][UB];   // 48 KiB
+    constexpr int ROWS = 16 * RT;
+    __shared__ float red[NW][3][ROWS][UB];   // 48 / 24 KiB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int s = 0;
     while (s + 1 < g.n && (int)blockIdx.x >= g.blk_start[s + 1]) ++s;
     const m3t_gru_fwd_desc d = g.d[s];
     const int H = d.H, nch = H >> 4;
-    const int ub = (int)blockIdx.x - g.blk_start[s];
-    const int j0 = ub * UB, r0 = blockIdx.y * RB;
+    const int local = (int)blockIdx.x - g.blk_start[s];
+    const int ub = local % nch, rb = local / nch;     // unit block fastest: workgroups sharing a W slice sit nch apart
+    const int j0 = ub * UB, r0 = rb * ROWS;
     const int t = d.reverse ? T - 1 - step : step;
     const int tp = d.reverse ? t + 1 : t - 1;
     const bool has_prev = step > 0;
-    const float* hin = fp.xfrag[s] + (size_t)((step + 1) & 1) * fp.xstride[s] + (size_t)blockIdx.y * RB * H;
-    float* hout = fp.xfrag[s] + (size_t)(step & 1) * fp.xstride[s] + (size_t)blockIdx.y * RB * H;
+    const float* hin = fp.xfrag[s] + (size_t)((step + 1) & 1) * fp.xstride[s] + (size_t)rb * ROWS * H;
+    float* hout = fp.xfrag[s] + (size_t)(step & 1) * fp.xstride[s] + (size_t)rb * ROWS * H;
 
+    const bool pw = tid < ROWS * UB;             // gate-math threads
     const int prow = tid >> 4, pu = tid & 15;
     const int pb = r0 + prow, pj = j0 + pu;
-    const bool pok = pb < B;
-    float xr = 0.f, xz = 0.f, xn = 0.f, hprev = 0.f;
-    const float br = d.b_hh[pj], bz = d.b_hh[H + pj], bn = d.b_hh[2 * H + pj];
+    const bool pok = pw && pb < B;
+    float xr = 0.f, xz = 0.f, xn = 0.f, hprev = 0.f, br = 0.f, bz = 0.f, bn = 0.f;
+    if (pw) { br = d.b_hh[pj]; bz = d.b_hh[H + pj]; bn = d.b_hh[2 * H + pj]; }
     if (pok) {
         const float* xp = d.xproj + ((size_t)pb * T + t) * d.ldx + d.xoff;
         xr = xp[pj]; xz = xp[H + pj]; xn = xp[2 * H + pj];
         if (has_prev) hprev = d.out[((size_t)pb * T + tp) * d.ldo + d.ooff + pj];
     }
     if (has_prev) {
-        f32x4 acc[2][3];
+        f32x4 acc[RT][3];
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int ct = 0; ct < 3; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        wave_mma_frag<3, CF>(reinterpret_cast<const float4*>(hin),
-                             reinterpret_cast<const float4*>(fp.wfrag[s] + (size_t)ub * nch * 3 * 256), nch, wave, lane, acc);
+        wave_mma_frag<3, CF, RT>(reinterpret_cast<const float4*>(hin),
+                                 reinterpret_cast<const float4*>(fp.wfrag[s] + (size_t)ub * nch * 3 * 256), nch, wave, lane,
+                                 acc);
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) red[wave][ct][rt * 16 + (lane >> 4) * 4 + r][lane & 15] = acc[rt][ct][r];
     }
     __syncthreads();
+    if (!pw) return;
     float hr = br, hz = bz, hn = bn;
     if (has_prev) {
 #pragma unroll
@@ -223,7 +232,7 @@ __global__ __launch_bounds__(NT) void gru_step_fwd_frag_kernel(FwdGroup g, FragP
     const float n = tanhf(xn + r * hn);
     const float h = n + z * (hprev - n);
     // fragment-ordered copy for the next step: chunk == ub, tile = prow>>4, lane = (pu>>2)*16 + (prow&15), e = pu&3
-    hout[(((size_t)ub * 2 + (prow >> 4)) * 64 + (pu >> 2) * 16 + (prow & 15)) * 4 + (pu & 3)] = pok ? h : 0.f;
+    hout[(((size_t)ub * RT + (prow >> 4)) * 64 + (pu >> 2) * 16 + (prow & 15)) * 4 + (pu & 3)] = pok ? h : 0.f;
     if (!pok) return;
     d.out[((size_t)pb * T + t) * d.ldo + d.ooff + pj] = h;
     if (d.gates) {
@@ -233,25 +242,29 @@ __global__ __launch_bounds__(NT) void gru_step_fwd_frag_kernel(FwdGroup g, FragP
     if (d.h_n && step == T - 1) d.h_n[(size_t)pb * H + pj] = h;
 }
 
+template <int RT>
 __global__ __launch_bounds__(NT) void gru_step_bwd_frag_kernel(BwdGroup g, FragPtrs fp, int B, int T, int step) {
-    __shared__ float red[NW][RB][UB];   // 16 KiB
+    constexpr int ROWS = 16 * RT;
+    __shared__ float red[NW][ROWS][UB];   // 16 / 8 KiB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int s = 0;
     while (s + 1 < g.n && (int)blockIdx.x >= g.blk_start[s + 1]) ++s;
     const m3t_gru_bwd_desc d = g.d[s];
     const int H = d.H, H3 = 3 * d.H, nchh = H >> 4, nch = H3 >> 4;
-    const int ub = (int)blockIdx.x - g.blk_start[s];
-    const int j0 = ub * UB, r0 = blockIdx.y * RB;
+    const int local = (int)blockIdx.x - g.blk_start[s];
+    const int ub = local % nchh, rb = local / nchh;
+    const int j0 = ub * UB, r0 = rb * ROWS;
     const int t = d.reverse ? step : T - 1 - step;
     const int tn = d.reverse ? t - 1 : t + 1;
     const int tp = d.reverse ? t + 1 : t - 1;
     const bool has_next = step > 0, has_prev = step < T - 1;
-    const float* gin = fp.xfrag[s] + (size_t)((step + 1) & 1) * fp.xstride[s] + (size_t)blockIdx.y * RB * H3;
-    float* gout = fp.xfrag[s] + (size_t)(step & 1) * fp.xstride[s] + (size_t)blockIdx.y * RB * H3;
+    const float* gin = fp.xfrag[s] + (size_t)((step + 1) & 1) * fp.xstride[s] + (size_t)rb * ROWS * H3;
+    float* gout = fp.xfrag[s] + (size_t)(step & 1) * fp.xstride[s] + (size_t)rb * ROWS * H3;
 
+    const bool pw = tid < ROWS * UB;
     const int prow = tid >> 4, pu = tid & 15;
     const int pb = r0 + prow, pj = j0 + pu;
-    const bool pok = pb < B;
+    const bool pok = pw && pb < B;
     float dout = 0.f, gr = 0.f, gz = 0.f, gn = 0.f, ghn = 0.f, hprev = 0.f, zn = 0.f, dhn = 0.f;
     if (pok) {
         dout = d.dout[((size_t)pb * T + t) * d.ldo + d.ooff + pj];
@@ -266,17 +279,18 @@ __global__ __launch_bounds__(NT) void gru_step_bwd_frag_kernel(BwdGroup g, FragP
         }
     }
     if (has_next) {
-        f32x4 acc[2][1];
-        acc[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        acc[1][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        wave_mma_frag<1, CB>(reinterpret_cast<const float4*>(gin),
-                             reinterpret_cast<const float4*>(fp.wfrag[s] + (size_t)ub * nch * 256), nch, wave, lane, acc);
+        f32x4 acc[RT][1];
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+        for (int rt = 0; rt < RT; ++rt) acc[rt][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        wave_mma_frag<1, CB, RT>(reinterpret_cast<const float4*>(gin),
+                                 reinterpret_cast<const float4*>(fp.wfrag[s] + (size_t)ub * nch * 256), nch, wave, lane, acc);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[wave][rt * 16 + (lane >> 4) * 4 + r][lane & 15] = acc[rt][0][r];
     }
     __syncthreads();
+    if (!pw) return;
     float carry = dhn;
     if (has_next) {
         float mm = 0.f;
@@ -290,9 +304,9 @@ __global__ __launch_bounds__(NT) void gru_step_bwd_frag_kernel(BwdGroup g, FragP
     const float dr = dn * ghn * gr * (1.f - gr);
     // fragment-ordered dgh for the next launch: gate g lives in chunk g*(H/16) + ub
     const size_t fo = ((size_t)(prow >> 4) * 64 + (pu >> 2) * 16 + (prow & 15)) * 4 + (pu & 3);
-    gout[((size_t)(0 * nchh + ub) * 2) * 256 + fo] = pok ? dr : 0.f;
-    gout[((size_t)(1 * nchh + ub) * 2) * 256 + fo] = pok ? dz : 0.f;
-    gout[((size_t)(2 * nchh + ub) * 2) * 256 + fo] = pok ? dn * gr : 0.f;
+    gout[((size_t)(0 * nchh + ub) * RT) * 256 + fo] = pok ? dr : 0.f;
+    gout[((size_t)(1 * nchh + ub) * RT) * 256 + fo] = pok ? dz : 0.f;
+    gout[((size_t)(2 * nchh + ub) * RT) * 256 + fo] = pok ? dn * gr : 0.f;
     if (!pok) return;
     float* gx = d.dgx + ((size_t)pb * T + t) * d.ldg + d.goff;
     gx[pj] = dr; gx[H + pj] = dz; gx[2 * H + pj] = dn;
@@ -528,6 +542,44 @@ int replay_or_capture(const std::vector<unsigned char>& key, hipStream_t s, Laun
     return (int)hipGraphLaunch(exec, s);
 }
 
+// Launch plan of a level.  Workgroups are issued heaviest scan first (largest H), so when a level has more
+// workgroups than CUs the ones that double up on a CU are the light ones.  Row tiles per workgroup (RT = 2: 32
+// rows, RT = 1: 16 rows, twice the workgroups at half the MFMA chain) are chosen by simulating the dispatcher's
+// round-robin over 256 CUs with cost(workgroup) ~ fixed + RT * H/512.  M3T_SCAN_RT=1|2 overrides (tuning).
+struct ScanPlan { int order[M3T_MAX_SCANS]; int rt; };
+
+ScanPlan plan_level(const int* Hs, int n, int B) {
+    ScanPlan p;
+    for (int i = 0; i < n; ++i) p.order[i] = i;
+    for (int i = 1; i < n; ++i)          // stable insertion sort by H, descending
+        for (int j = i; j > 0 && Hs[p.order[j]] > Hs[p.order[j - 1]]; --j) {
+            const int tmp = p.order[j]; p.order[j] = p.order[j - 1]; p.order[j - 1] = tmp;
+        }
+    static int forced = -1;
+    if (forced < 0) {
+        const char* e = std::getenv("M3T_SCAN_RT");
+        forced = e ? std::atoi(e) : 0;
+    }
+    if (forced == 1 || forced == 2) { p.rt = forced; return p; }
+    if (B <= 16) { p.rt = 1; return p; }
+    double best = 1e30;
+    p.rt = 2;
+    for (int rt = 2; rt >= 1; --rt) {
+        double load[256] = {0};
+        int cu = 0;
+        for (int i = 0; i < n; ++i) {
+            const int H = Hs[p.order[i]];
+            const int wgs = cdiv(H, 16) * cdiv(B, 16 * rt);
+            const double cost = 0.35 + rt * (double)H / 512.0;
+            for (int w = 0; w < wgs; ++w) { load[cu] += cost; cu = (cu + 1) & 255; }
+        }
+        double mx = 0;
+        for (int c = 0; c < 256; ++c) mx = load[c] > mx ? load[c] : mx;
+        if (mx < best - 1e-9) { best = mx; p.rt = rt; }
+    }
+    return p;
+}
+
 template <typename G>
 std::vector<unsigned char> make_key(int kind, const G& g, const FragPtrs* fp, int B, int T, int variant) {
     std::vector<unsigned char> k(sizeof(int) * 4 + sizeof(G) + (fp ? sizeof(FragPtrs) : 0));
@@ -568,27 +620,42 @@ extern "C" int m3t_gru_scan_fwd(const m3t_gru_fwd_desc* scans, int n_scans, int 
     bool frag = ws != nullptr && ((uintptr_t)ws % 16 == 0);
     size_t need = 0;
     const size_t bpad = (size_t)cdiv(B, RB) * RB;
+    int Hs[M3T_MAX_SCANS];
     for (int i = 0; i < n_scans; ++i) {
+        Hs[i] = scans[i].H;
         frag = frag && scans[i].H % 16 == 0;
         need += (size_t)3 * scans[i].H * scans[i].H + 2 * bpad * scans[i].H;
     }
     if (frag && need * sizeof(float) <= ws_bytes) {
+        const ScanPlan plan = plan_level(Hs, n_scans, B);
+        const int rt = plan.rt, nrb = cdiv(B, 16 * rt);
+        FwdGroup fg;
         FragPtrs fp;
+        std::memset(&fg, 0, sizeof(fg));
         std::memset(&fp, 0, sizeof(fp));
+        fg.n = n_scans;
         float* p = ws;
+        int nblk = 0;
         for (int i = 0; i < n_scans; ++i) {
-            const int H = scans[i].H;
-            fp.wfrag[i] = p; p += (size_t)3 * H * H;
-            fp.xfrag[i] = p; fp.xstride[i] = bpad * H; p += 2 * bpad * H;
+            const m3t_gru_fwd_desc& d = scans[plan.order[i]];
+            fg.d[i] = d;
+            fg.blk_start[i] = nblk;
+            nblk += (d.H / 16) * nrb;
+            fp.wfrag[i] = p; p += (size_t)3 * d.H * d.H;
+            fp.xfrag[i] = p; fp.xstride[i] = bpad * d.H; p += 2 * bpad * d.H;
         }
-        return replay_or_capture(make_key(1, g, &fp, B, T, 0), s, [&]() {
+        for (int i = n_scans; i <= M3T_MAX_SCANS; ++i) fg.blk_start[i] = nblk;
+        return replay_or_capture(make_key(1, fg, &fp, B, T, rt), s, [&]() {
             for (int i = 0; i < n_scans; ++i) {
-                const int H = scans[i].H;
+                const int H = fg.d[i].H;
                 int blk = (3 * H * H + 255) / 256;
                 if (blk > 1024) blk = 1024;
-                wfrag_fwd_prep_kernel<<<blk, 256, 0, s>>>(scans[i].w_hh, fp.wfrag[i], H);
+                wfrag_fwd_prep_kernel<<<blk, 256, 0, s>>>(fg.d[i].w_hh, fp.wfrag[i], H);
             }
-            for (int step = 0; step < T; ++step) gru_step_fwd_frag_kernel<<<grid, NT, 0, s>>>(g, fp, B, T, step);
+            if (rt == 2)
+                for (int step = 0; step < T; ++step) gru_step_fwd_frag_kernel<2><<<nblk, NT, 0, s>>>(fg, fp, B, T, step);
+            else
+                for (int step = 0; step < T; ++step) gru_step_fwd_frag_kernel<1><<<nblk, NT, 0, s>>>(fg, fp, B, T, step);
         });
     }
     if (fast)
@@ -625,27 +692,42 @@ extern "C" int m3t_gru_scan_bwd(const m3t_gru_bwd_desc* scans, int n_scans, int 
     bool frag = ws != nullptr && ((uintptr_t)ws % 16 == 0);
     size_t need = 0;
     const size_t bpad = (size_t)cdiv(B, RB) * RB;
+    int Hs[M3T_MAX_SCANS];
     for (int i = 0; i < n_scans; ++i) {
+        Hs[i] = scans[i].H;
         frag = frag && scans[i].H % 16 == 0;
         need += (size_t)3 * scans[i].H * scans[i].H + 2 * bpad * 3 * scans[i].H;
     }
     if (frag && need * sizeof(float) <= ws_bytes) {
+        const ScanPlan plan = plan_level(Hs, n_scans, B);
+        const int rt = plan.rt, nrb = cdiv(B, 16 * rt);
+        BwdGroup bg;
         FragPtrs fp;
+        std::memset(&bg, 0, sizeof(bg));
         std::memset(&fp, 0, sizeof(fp));
+        bg.n = n_scans;
         float* p = ws;
+        int nblk = 0;
         for (int i = 0; i < n_scans; ++i) {
-            const int H = scans[i].H;
-            fp.wfrag[i] = p; p += (size_t)3 * H * H;
-            fp.xfrag[i] = p; fp.xstride[i] = bpad * 3 * H; p += 2 * bpad * 3 * H;
+            const m3t_gru_bwd_desc& d = scans[plan.order[i]];
+            bg.d[i] = d;
+            bg.blk_start[i] = nblk;
+            nblk += (d.H / 16) * nrb;
+            fp.wfrag[i] = p; p += (size_t)3 * d.H * d.H;
+            fp.xfrag[i] = p; fp.xstride[i] = bpad * 3 * d.H; p += 2 * bpad * 3 * d.H;
         }
-        return replay_or_capture(make_key(2, g, &fp, B, T, 0), s, [&]() {
+        for (int i = n_scans; i <= M3T_MAX_SCANS; ++i) bg.blk_start[i] = nblk;
+        return replay_or_capture(make_key(2, bg, &fp, B, T, rt), s, [&]() {
             for (int i = 0; i < n_scans; ++i) {
-                const int H = scans[i].H;
+                const int H = bg.d[i].H;
                 int blk = (3 * H * H + 255) / 256;
                 if (blk > 1024) blk = 1024;
-                wfrag_bwd_prep_kernel<<<blk, 256, 0, s>>>(scans[i].w_hh_t, fp.wfrag[i], H);
+                wfrag_bwd_prep_kernel<<<blk, 256, 0, s>>>(bg.d[i].w_hh_t, fp.wfrag[i], H);
             }
-            for (int step = 0; step < T; ++step) gru_step_bwd_frag_kernel<<<grid, NT, 0, s>>>(g, fp, B, T, step);
+            if (rt == 2)
+                for (int step = 0; step < T; ++step) gru_step_bwd_frag_kernel<2><<<nblk, NT, 0, s>>>(bg, fp, B, T, step);
+            else
+                for (int step = 0; step < T; ++step) gru_step_bwd_frag_kernel<1><<<nblk, NT, 0, s>>>(bg, fp, B, T, step);
         });
     }
     if (fast)

@@ -298,7 +298,7 @@ extern "C" int m3t_causal_conv_wgrad(const float* dy, const float* x, float* dw_
         }
         // dw_t[j][co][ci] = sum_b sum_{t>=sft} dy[b,t,co] * x[b,t-sft,ci]
         const int rc = m3t_sgemm(1, 0, Co, Ci, B * (T - sft), dy, Co, x, Ci, out, Ci, nullptr, 0, 0, T - sft, T, sft, 0,
-                                 ws, ws_bytes, stream);
+                                 ws, ws_bytes, 0, stream);
         if (rc) return rc;
     }
     return 0;

@@ -30,7 +30,7 @@ class GruBwdDesc(C.Structure):
 SIGNATURES = {
     "m3t_version": [],
     "m3t_device_arch": [C.c_char_p, _i],
-    "m3t_sgemm": [_i, _i, _i, _i, _i, _f, _i, _f, _i, _f, _i, _f, _i, _i, _i, _i, _i, _i, _f, _z, _s],
+    "m3t_sgemm": [_i, _i, _i, _i, _i, _f, _i, _f, _i, _f, _i, _f, _i, _i, _i, _i, _i, _i, _f, _z, _i, _s],
     "m3t_colsum": [_f, _i, _i, _i, _f, _i, _f, _z, _s],
     "m3t_transpose": [_f, _i, _i, _i, _f, _i, _s],
     "m3t_relu_bwd": [_f, _f, _z, _s],

@@ -75,10 +75,30 @@ def _p(t, off=0):
     return C.c_void_p(t.data_ptr() + 4 * off)
 
 
-def workspace(device, nbytes=_WS_MIN):
-    """Per-device scratch for split-K slabs / partial sums.  All users run on the current
-    stream, so stream order serialises reuse."""
+# ---- side stream: independent light-weight stacks run beside the main chain (see _stream_groups) -------------
+_SIDE = {}
+# measured neutral on C3 (the light chain slows the heavy one by what it saves): opt-in via M3T_SIDE_STREAM=1
+_SIDE_ENABLED = __import__("os").environ.get("M3T_SIDE_STREAM", "0") == "1"
+
+
+def side_stream(device):
     key = (device.type, device.index)
+    st = _SIDE.get(key)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _SIDE[key] = st
+    return st
+
+
+def _ws_tag(device):
+    st = _SIDE.get((device.type, device.index))
+    return "side" if st is not None and torch.cuda.current_stream(device) == st else "main"
+
+
+def workspace(device, nbytes=_WS_MIN, tag=None):
+    """Per-device, per-stream scratch (split-K slabs, partial sums, scan fragments).  One buffer per stream role
+    (main / side), so stream order serialises reuse."""
+    key = (device.type, device.index, tag or _ws_tag(device))
     ws = _WS.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
         ws = torch.empty(max(nbytes, _WS_MIN) // 4, dtype=torch.float32, device=device)
@@ -88,12 +108,12 @@ def workspace(device, nbytes=_WS_MIN):
 
 # ----------------------------------------------------------------------------- raw wrappers
 def sgemm(transA, transB, M, N, K, A, a_off, lda, B, b_off, ldb, Cm, c_off, ldc, bias=None, act=0,
-          accumulate=False, seg=(0, 0, 0, 0), use_ws=True):
+          accumulate=False, seg=(0, 0, 0, 0), use_ws=True, background=False):
     ws = workspace(Cm.device) if use_ws else None
     with _Timed("sgemm_kernel", 1, 2.0 * M * N * K) if PROFILE_GEMM[0] else _NULL:
         rc = lib().m3t_sgemm(transA, transB, M, N, K, _p(A, a_off), lda, _p(B, b_off), ldb, _p(Cm, c_off), ldc,
                              _p(bias), act, int(accumulate), seg[0], seg[1], seg[2], seg[3],
-                             _p(ws), (ws.numel() * 4) if ws is not None else 0, _stream())
+                             _p(ws), (ws.numel() * 4) if ws is not None else 0, 1 if background else 0, _stream())
     _lib.check(rc, "m3t_sgemm")
 
 
@@ -185,10 +205,26 @@ def _vp(t, off=0):
     return t.data_ptr() + 4 * off if t is not None else None
 
 
+def _stream_groups(Hs, B):
+    """Split independent stacks over (main, side) streams.  When the widest stacks alone give the scan launch about
+    one 16-row workgroup per CU (>= 192 of 256), narrower stacks sharing that launch would double up on CUs and
+    stretch every step (measured +2.5 us/step for audio H=256 beside 4 x H=512); they run as their own launches
+    on a side stream instead -- both chains are latency-bound and overlap."""
+    if not _SIDE_ENABLED:
+        return [("main", list(range(len(Hs))))]
+    hmax = max(Hs)
+    heavy = [i for i, h in enumerate(Hs) if h == hmax]
+    light = [i for i, h in enumerate(Hs) if h != hmax]
+    wgs = sum(2 * (Hs[i] // 16) * ((B + 15) // 16) for i in heavy)
+    if light and wgs >= 192:
+        return [("side", light), ("main", heavy)]
+    return [("main", list(range(len(Hs))))]
+
+
 class _MultiBiGRU(torch.autograd.Function):
     """Several independent stacked bidirectional GRUs (same B, T, depth) advanced together:
     per layer, one input-projection GEMM per direction, then ONE grouped scan over every
-    (stack, direction).  Replaces nn.GRU(batch_first=True, bidirectional=True) at reference
+    (stack, direction) of a stream group.  Replaces nn.GRU(batch_first=True, bidirectional=True) at reference
     models/rnn.py:17,75 (and its autograd).  tensors = per stack: x, then per layer, per
     direction: w_ih, w_hh, b_ih, b_hh.  Returns per stack: out [B,T,2H], h_n [2L,B,H]."""
 
@@ -202,36 +238,50 @@ class _MultiBiGRU(torch.autograd.Function):
             params.append([_req(t, "gru parameter") for t in tensors[s * per + 1:(s + 1) * per]])
         B, T = xs[0].shape[0], xs[0].shape[1]
         dev = xs[0].device
+        for x in xs:
+            if x.shape[0] != B or x.shape[1] != T:
+                raise M3THipError("grouped GRU stacks must share batch and length")
         Hs = [params[s][1].shape[1] for s in range(n_stacks)]
-        saved = []       # per layer, per stack: out, gates (inputs of layer 0 are the x's)
-        h_ns = [torch.empty(2 * L, B, Hs[s], dtype=torch.float32, device=dev) for s in range(n_stacks)]
-        inps = xs
-        for l in range(L):
-            descs, outs, keep = [], [], []
-            for s in range(n_stacks):
-                H, inp = Hs[s], inps[s]
-                if inp.shape[0] != B or inp.shape[1] != T:
-                    raise M3THipError("grouped GRU stacks must share batch and length")
-                I = inp.shape[-1]
-                xproj = torch.empty(B, T, 6 * H, dtype=torch.float32, device=dev)
-                out = torch.empty(B, T, 2 * H, dtype=torch.float32, device=dev)
-                gates = torch.empty(2, B, T, 4 * H, dtype=torch.float32, device=dev)
-                for d in (0, 1):
-                    w_ih, w_hh, b_ih, b_hh = params[s][(2 * l + d) * 4:(2 * l + d) * 4 + 4]
-                    sgemm(0, 1, B * T, 3 * H, I, inp, 0, I, w_ih, 0, I, xproj, d * 3 * H, 6 * H, bias=b_ih)
-                    descs.append(GruFwdDesc(_vp(xproj), _vp(w_hh), _vp(b_hh), _vp(out), _vp(gates, d * B * T * 4 * H),
-                                            _vp(h_ns[s], (2 * l + d) * B * H), H, d, 6 * H, d * 3 * H, 2 * H, d * H))
-                saved += [out, gates]
-                outs.append(out)
-                keep.append(xproj)     # must outlive the scan enqueue (stream-ordered allocator reuse)
-            _scan_fwd(descs, B, T)
-            del keep
-            inps = outs
+        new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        # every buffer is allocated on the caller's stream; side-stream work is fenced by wait_stream on both ends
+        h_ns = [new(2 * L, B, Hs[s]) for s in range(n_stacks)]
+        outs = [[new(B, T, 2 * Hs[s]) for s in range(n_stacks)] for _ in range(L)]
+        gates = [[new(2, B, T, 4 * Hs[s]) for s in range(n_stacks)] for _ in range(L)]
+        xprojs = [[new(B, T, 6 * Hs[s]) for s in range(n_stacks)] for _ in range(L)]
+        main = torch.cuda.current_stream()
+        groups = _stream_groups(Hs, B)
+        for kind, idxs in groups:
+            stream = main
+            if kind == "side":
+                stream = side_stream(dev)
+                stream.wait_stream(main)
+            with torch.cuda.stream(stream):
+                for l in range(L):
+                    descs = []
+                    for s in idxs:
+                        H = Hs[s]
+                        inp = xs[s] if l == 0 else outs[l - 1][s]
+                        I = inp.shape[-1]
+                        for d in (0, 1):
+                            w_ih, w_hh, b_ih, b_hh = params[s][(2 * l + d) * 4:(2 * l + d) * 4 + 4]
+                            sgemm(0, 1, B * T, 3 * H, I, inp, 0, I, w_ih, 0, I, xprojs[l][s], d * 3 * H, 6 * H, bias=b_ih)
+                            descs.append(GruFwdDesc(_vp(xprojs[l][s]), _vp(w_hh), _vp(b_hh), _vp(outs[l][s]),
+                                                    _vp(gates[l][s], d * B * T * 4 * H), _vp(h_ns[s], (2 * l + d) * B * H),
+                                                    H, d, 6 * H, d * 3 * H, 2 * H, d * H))
+                    _scan_fwd(descs, B, T)
+        for kind, _ in groups:
+            if kind == "side":
+                main.wait_stream(side_stream(dev))
+        del xprojs
         ctx.n_stacks, ctx.L, ctx.Hs, ctx.B, ctx.T = n_stacks, L, Hs, B, T
+        saved = []
+        for l in range(L):
+            for s in range(n_stacks):
+                saved += [outs[l][s], gates[l][s]]
         ctx.save_for_backward(*(list(tensors) + saved))
         result = []
         for s in range(n_stacks):
-            result += [inps[s], h_ns[s]]
+            result += [outs[L - 1][s], h_ns[s]]
         return tuple(result)
 
     @staticmethod
@@ -244,11 +294,12 @@ class _MultiBiGRU(torch.autograd.Function):
         xs = [tensors[s * per].contiguous() for s in range(n_stacks)]
 
         def layer_io(l, s):   # (input, out, gates) of stack s at layer l
-            out, gates = acts[(l * n_stacks + s) * 2], acts[(l * n_stacks + s) * 2 + 1]
+            out, gts = acts[(l * n_stacks + s) * 2], acts[(l * n_stacks + s) * 2 + 1]
             inp = xs[s] if l == 0 else acts[((l - 1) * n_stacks + s) * 2]
-            return inp, out, gates
+            return inp, out, gts
 
         dev = params[0][0].device
+        new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
         out_grads = [None] * (n_stacks * per)
         douts, dhns = [], []
         for s in range(n_stacks):
@@ -256,61 +307,71 @@ class _MultiBiGRU(torch.autograd.Function):
             douts.append(torch.zeros(B, T, 2 * Hs[s], dtype=torch.float32, device=dev) if g is None
                          else _req(g.contiguous(), "dout"))
             dhns.append(None if gh is None else _req(gh.contiguous(), "dh_n"))
-        for l in range(L - 1, -1, -1):
-            descs, work = [], []
-            for s in range(n_stacks):
-                H = Hs[s]
-                inp, out, gates = layer_io(l, s)
-                dgx = torch.empty(B, T, 6 * H, dtype=torch.float32, device=dev)
-                dgh = torch.empty(2, B, T, 3 * H, dtype=torch.float32, device=dev)
-                dh = torch.empty(2, B, H, dtype=torch.float32, device=dev)
-                whts = []
-                for d in (0, 1):
-                    w_hh = params[s][(2 * l + d) * 4 + 1]
-                    wht = transpose2d(w_hh)
-                    whts.append(wht)
-                    descs.append(GruBwdDesc(_vp(douts[s]), _vp(out), _vp(gates, d * B * T * 4 * H), _vp(wht),
-                                            _vp(dhns[s], (2 * l + d) * B * H) if dhns[s] is not None else None,
-                                            _vp(dgx), _vp(dgh, d * B * T * 3 * H), _vp(dh, d * B * H),
-                                            H, d, 2 * H, d * H, 6 * H, d * 3 * H))
-                work.append((inp, out, dgx, dgh, dh, whts))
-            _scan_bwd(descs, B, T)
-            new_douts = []
-            for s in range(n_stacks):
-                H = Hs[s]
-                inp, out, dgx, dgh, dh, whts = work[s]
-                I = inp.shape[-1]
-                base = s * per + 1 + (2 * l) * 4
+        # all scratch and result buffers on the caller's stream (see forward)
+        dgx = [[new(B, T, 6 * Hs[s]) for s in range(n_stacks)] for _ in range(L)]
+        dgh = [[new(2, B, T, 3 * Hs[s]) for s in range(n_stacks)] for _ in range(L)]
+        dh = [[new(2, B, Hs[s]) for s in range(n_stacks)] for _ in range(L)]
+        wht = [[[new(Hs[s], 3 * Hs[s]) for _ in (0, 1)] for s in range(n_stacks)] for _ in range(L)]
+        need_dx = [[l > 0 or ctx.needs_input_grad[2 + s * per] for s in range(n_stacks)] for l in range(L)]
+        dinp = [[torch.empty_like(layer_io(l, s)[0]) if need_dx[l][s] else None for s in range(n_stacks)] for l in range(L)]
+        for s in range(n_stacks):
+            for l in range(L):
                 for d in (0, 1):
                     w_ih, w_hh = params[s][(2 * l + d) * 4], params[s][(2 * l + d) * 4 + 1]
-                    dw_ih, dw_hh = torch.empty_like(w_ih), torch.empty_like(w_hh)
-                    db_ih = torch.empty(3 * H, dtype=torch.float32, device=dev)
-                    db_hh = torch.empty(3 * H, dtype=torch.float32, device=dev)
-                    goff = d * B * T * 3 * H
-                    if T > 1:
-                        # dW_hh = sum_{b,t} dgh[b,t]^T h_{prev}(b,t): forward pairs (t, t-1), reverse pairs (t, t+1)
-                        a_off, b_off = (1, 0) if d == 0 else (0, 1)
-                        sgemm(1, 0, 3 * H, H, B * (T - 1), dgh, goff, 3 * H, out, d * H, 2 * H, dw_hh, 0, H,
-                              seg=(T - 1, T, a_off, b_off))
-                    else:
-                        dw_hh.zero_()
-                    colsum(dgh, goff, B * T, 3 * H, 3 * H, db_hh)
-                    sgemm(1, 0, 3 * H, I, B * T, dgx, d * 3 * H, 6 * H, inp, 0, I, dw_ih, 0, I)
-                    colsum(dgx, d * 3 * H, B * T, 3 * H, 6 * H, db_ih)
-                    out_grads[base + d * 4: base + d * 4 + 4] = [dw_ih, dw_hh, db_ih, db_hh]
-                need_dx = l > 0 or ctx.needs_input_grad[2 + s * per]
-                if need_dx:
-                    dinp = torch.empty_like(inp)
-                    for d in (0, 1):
-                        w_ih = params[s][(2 * l + d) * 4]
-                        sgemm(0, 0, B * T, I, 3 * H, dgx, d * 3 * H, 6 * H, w_ih, 0, I, dinp, 0, I,
-                              accumulate=(d == 1))
-                    new_douts.append(dinp)
-                else:
-                    new_douts.append(None)
-            douts = new_douts     # (grads wrt h_n of lower layers are picked by index inside the descs)
+                    base = s * per + 1 + (2 * l + d) * 4
+                    out_grads[base:base + 4] = [torch.empty_like(w_ih), torch.empty_like(w_hh),
+                                                new(3 * Hs[s]), new(3 * Hs[s])]
+        main = torch.cuda.current_stream()
+        groups = _stream_groups(Hs, B)
+        for kind, idxs in groups:
+            stream = main
+            if kind == "side":
+                stream = side_stream(dev)
+                stream.wait_stream(main)
+            with torch.cuda.stream(stream):
+                cur = {s: douts[s] for s in idxs}
+                for l in range(L - 1, -1, -1):
+                    descs = []
+                    for s in idxs:
+                        H = Hs[s]
+                        inp, out, gts = layer_io(l, s)
+                        for d in (0, 1):
+                            w_hh = params[s][(2 * l + d) * 4 + 1]
+                            _lib.check(lib().m3t_transpose(_p(w_hh), 3 * H, H, H, _p(wht[l][s][d]), 3 * H, _stream()),
+                                       "m3t_transpose")
+                            descs.append(GruBwdDesc(_vp(cur[s]), _vp(out), _vp(gts, d * B * T * 4 * H), _vp(wht[l][s][d]),
+                                                    _vp(dhns[s], (2 * l + d) * B * H) if dhns[s] is not None else None,
+                                                    _vp(dgx[l][s]), _vp(dgh[l][s], d * B * T * 3 * H), _vp(dh[l][s], d * B * H),
+                                                    H, d, 2 * H, d * H, 6 * H, d * 3 * H))
+                    _scan_bwd(descs, B, T)
+                    for s in idxs:
+                        H = Hs[s]
+                        inp, out, gts = layer_io(l, s)
+                        I = inp.shape[-1]
+                        if need_dx[l][s]:          # critical path first: feeds the next level's scan
+                            for d in (0, 1):
+                                sgemm(0, 0, B * T, I, 3 * H, dgx[l][s], d * 3 * H, 6 * H, params[s][(2 * l + d) * 4], 0, I,
+                                      dinp[l][s], 0, I, accumulate=(d == 1))
+                            cur[s] = dinp[l][s]
+                        for d in (0, 1):
+                            base = s * per + 1 + (2 * l + d) * 4
+                            dw_ih, dw_hh, db_ih, db_hh = out_grads[base:base + 4]
+                            goff = d * B * T * 3 * H
+                            if T > 1:
+                                # dW_hh = sum_{b,t} dgh[b,t]^T h_prev(b,t): forward pairs (t, t-1), reverse pairs (t, t+1)
+                                a_off, b_off = (1, 0) if d == 0 else (0, 1)
+                                sgemm(1, 0, 3 * H, H, B * (T - 1), dgh[l][s], goff, 3 * H, out, d * H, 2 * H, dw_hh, 0, H,
+                                      seg=(T - 1, T, a_off, b_off))
+                            else:
+                                dw_hh.zero_()
+                            colsum(dgh[l][s], goff, B * T, 3 * H, 3 * H, db_hh)
+                            sgemm(1, 0, 3 * H, I, B * T, dgx[l][s], d * 3 * H, 6 * H, inp, 0, I, dw_ih, 0, I)
+                            colsum(dgx[l][s], d * 3 * H, B * T, 3 * H, 6 * H, db_ih)
+        for kind, _ in groups:
+            if kind == "side":
+                main.wait_stream(side_stream(dev))
         for s in range(n_stacks):
-            out_grads[s * per] = douts[s]
+            out_grads[s * per] = dinp[0][s]
         return (None, None) + tuple(out_grads)
 
 
