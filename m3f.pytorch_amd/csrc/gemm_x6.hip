@@ -8,7 +8,7 @@
 // fp32 ones per 16 k = 2.67x the fp32 MFMA rate (~420 TFLOP/s ceiling), deterministic.
 //
 // Tile: 128 x 128 x 32, 4 waves (2 x 2), each wave 64 x 64 = 2 x 2 v_mfma_f32_32x32x16_bf16 tiles.
-// LDS (single buffer, 48 KiB -> 3 workgroups/CU): per operand and split, [k-half 2][k-quad 4][128 rows][4 k] bf16,
+// LDS (single buffer, 48.8 KiB -> 3 workgroups/CU): per operand and split, [k-half 2][k-quad 4][128 rows][4 k] bf16,
 // i.e. 8 B per (row, k-quad) and rows contiguous inside a k-quad plane.  A fragment (row = lane&31,
 // k = 8*(lane>>5)..+7) is two conflict-free ds_read_b64 (32 lanes x 8 B contiguous each); a thread that loaded a
 // float4 along the ROW dimension (row-contiguous operands) writes its 4 rows of one k-quad as 32 contiguous
@@ -22,8 +22,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int XM = 128, XN = 128, XK = 32;
-constexpr int SPLIT_BYTES = 2 * XM * 32;           // one split of one operand: 2 k-halves x 128 rows x 32 B = 8 KiB
-constexpr int OPER_BYTES = 3 * SPLIT_BYTES;        // 24 KiB
+constexpr int PLANE = XM * 8 + 16;                 // one k-quad plane: 128 rows x 8 B (+16 B: conflict-free K-contiguous stores)
+constexpr int SPLIT_BYTES = 8 * PLANE;             // one split of one operand: 2 k-halves x 4 k-quads
+constexpr int OPER_BYTES = 3 * SPLIT_BYTES;        // 24.4 KiB
 
 struct X6Params {
     const float* A; const float* B; float* C; const float* bias; float* ws;
@@ -40,17 +41,18 @@ __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l)
     l = (__bf16)r2;
 }
 
-// ---- K-contiguous operand ([rows][K]): thread = (row = tid>>1, k-half = tid&1) holds 16 consecutive k
-__device__ __forceinline__ void kc_load(const float* __restrict__ p, float4 (&r)[4]) {
+// ---- K-contiguous operand ([rows][K]): 8 lanes cover one row's 32 k (a full 128-B line); thread = (k-quad c =
+// tid&7, rows (tid>>3) + 32 i): every wave load instruction fetches 8 whole lines
+__device__ __forceinline__ void kc_load(const float* __restrict__ p, size_t ld, float4 (&r)[4]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) r[i] = reinterpret_cast<const float4*>(p)[i];
+    for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const float4*>(p + (size_t)i * 32 * ld);
 }
 __device__ __forceinline__ void kc_store(unsigned char* __restrict__ S, const float4 (&r)[4]) {
     const int tid = threadIdx.x;
-    const int row = tid >> 1, kh = tid & 1;
+    const int c = tid & 7, r0 = tid >> 3;            // plane index c = (k-half, k-quad) of the 32-k tile
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {                     // k-quad q of this half = r[q]
-        const float v[4] = {r[q].x, r[q].y, r[q].z, r[q].w};
+    for (int i = 0; i < 4; ++i) {
+        const float v[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
         bf16x4 o[3];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -60,7 +62,7 @@ __device__ __forceinline__ void kc_store(unsigned char* __restrict__ S, const fl
         }
 #pragma unroll
         for (int s = 0; s < 3; ++s)
-            *reinterpret_cast<bf16x4*>(S + s * SPLIT_BYTES + ((kh * 4 + q) * XM + row) * 8) = o[s];
+            *reinterpret_cast<bf16x4*>(S + s * SPLIT_BYTES + c * PLANE + (r0 + 32 * i) * 8) = o[s];
     }
 }
 // ---- row-contiguous operand ([K][rows]): thread = (k-quad = tid>>5 (4 k), 4 rows at (tid&31)*4): a 4x4 block
@@ -85,7 +87,7 @@ __device__ __forceinline__ void mc_store(unsigned char* __restrict__ S, const fl
     }
 #pragma unroll
     for (int s = 0; s < 3; ++s) {                     // 4 rows x 8 B = 32 contiguous bytes per split
-        unsigned char* q = S + s * SPLIT_BYTES + (kq * XM + row0) * 8;
+        unsigned char* q = S + s * SPLIT_BYTES + kq * PLANE + row0 * 8;
         *reinterpret_cast<bf16x8*>(q) = o[s][0];
         *reinterpret_cast<bf16x8*>(q + 16) = o[s][1];
     }
@@ -120,9 +122,9 @@ __global__ __launch_bounds__(256) void sgemm_x6_kernel(X6Params p) {
     // per-thread operand pointers
     const float* pa; const float* pb;
     size_t a_step, b_step, a_krow = 0, b_krow = 0;
-    if (TA == 0) { pa = p.A + (size_t)(bm + (tid >> 1)) * p.lda + k_begin + (tid & 1) * 16; a_step = XK; }
+    if (TA == 0) { pa = p.A + (size_t)(bm + (tid >> 3)) * p.lda + k_begin + (tid & 7) * 4; a_step = XK; }
     else { pa = p.A + (size_t)(k_begin + (tid >> 5) * 4) * p.lda + bm + (tid & 31) * 4; a_step = (size_t)XK * p.lda; a_krow = p.lda; }
-    if (TB == 1) { pb = p.B + (size_t)(bn + (tid >> 1)) * p.ldb + k_begin + (tid & 1) * 16; b_step = XK; }
+    if (TB == 1) { pb = p.B + (size_t)(bn + (tid >> 3)) * p.ldb + k_begin + (tid & 7) * 4; b_step = XK; }
     else { pb = p.B + (size_t)(k_begin + (tid >> 5) * 4) * p.ldb + bn + (tid & 31) * 4; b_step = (size_t)XK * p.ldb; b_krow = p.ldb; }
     // segmented reduction rows (dW_hh): (segment, offset) of this thread's first k row, advanced per tile
     int sq = 0, sr = 0;
@@ -145,12 +147,12 @@ __global__ __launch_bounds__(256) void sgemm_x6_kernel(X6Params p) {
             sr += XK;
             while (sr >= p.seg_len) { sr -= p.seg_len; ++sq; }
         } else {
-            if (TA == 0) kc_load(pa, ra);
+            if (TA == 0) kc_load(pa, p.lda, ra);
             else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) ra[e] = *reinterpret_cast<const float4*>(pa + e * a_krow);
             }
-            if (TB == 1) kc_load(pb, rb);
+            if (TB == 1) kc_load(pb, p.ldb, rb);
             else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) rb[e] = *reinterpret_cast<const float4*>(pb + e * b_krow);
@@ -167,6 +169,7 @@ __global__ __launch_bounds__(256) void sgemm_x6_kernel(X6Params p) {
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
         if (t + 1 < ntiles) gload();
+        __builtin_amdgcn_sched_barrier(0);     // the prefetch stays in flight: nothing that consumes it may be hoisted here
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
             bf16x8 fa[3][2], fb[3][2];
@@ -174,10 +177,10 @@ __global__ __launch_bounds__(256) void sgemm_x6_kernel(X6Params p) {
             for (int s = 0; s < 3; ++s)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const unsigned char* qa = As + s * SPLIT_BYTES + ((kh * 4 + 2 * hi) * XM + wm * 64 + i * 32 + l31) * 8;
-                    const unsigned char* qb = Bs + s * SPLIT_BYTES + ((kh * 4 + 2 * hi) * XN + wn * 64 + i * 32 + l31) * 8;
-                    const bf16x4 a0 = *reinterpret_cast<const bf16x4*>(qa), a1 = *reinterpret_cast<const bf16x4*>(qa + XM * 8);
-                    const bf16x4 b0 = *reinterpret_cast<const bf16x4*>(qb), b1 = *reinterpret_cast<const bf16x4*>(qb + XN * 8);
+                    const unsigned char* qa = As + s * SPLIT_BYTES + (kh * 4 + 2 * hi) * PLANE + (wm * 64 + i * 32 + l31) * 8;
+                    const unsigned char* qb = Bs + s * SPLIT_BYTES + (kh * 4 + 2 * hi) * PLANE + (wn * 64 + i * 32 + l31) * 8;
+                    const bf16x4 a0 = *reinterpret_cast<const bf16x4*>(qa), a1 = *reinterpret_cast<const bf16x4*>(qa + PLANE);
+                    const bf16x4 b0 = *reinterpret_cast<const bf16x4*>(qb), b1 = *reinterpret_cast<const bf16x4*>(qb + PLANE);
                     fa[s][i] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
                     fb[s][i] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
@@ -196,6 +199,7 @@ __global__ __launch_bounds__(256) void sgemm_x6_kernel(X6Params p) {
                     acc[i][j] = c;
                 }
         }
+        __builtin_amdgcn_sched_barrier(0);     // bf16 splitting of the next tile happens after this tile's MFMAs
         __syncthreads();                       // everyone is done reading this tile
         if (t + 1 < ntiles) {
             sstore();

@@ -67,7 +67,7 @@ def time_call(fn, descs, cls, reps=5):
 
 lib = _lib.load()
 levels = {"enc (4x512+2x256)": [512, 512, 256], "fusion (2x512)": [512], "scorers (4x128)": [128, 128],
-          "one 512 pair": [512], "4x512": [512, 512], "8x512": [512, 512, 512, 512], "2x256": [256]}
+          "one 512 pair": [512], "4x512": [512, 512], "8x512": [512, 512, 512, 512], "2x256": [256], "tiny 2x16": [16], "2x64": [64]}
 print("B=%d T=%d" % (B, T))
 for name, Hs in levels.items():
     d, k = fwd_group(Hs)
