@@ -106,10 +106,17 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # M3T_BENCH_BACKEND=gloo + M3T_BENCH_ONE_DEVICE=1 let the N>1 code path be exercised on a 1-GPU box
+    # (all ranks on cuda:0, gloo all-reduce); the real multi-GPU run uses RCCL ("nccl"), one GPU per rank.
+    backend = os.environ.get("M3T_BENCH_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("M3T_BENCH_ONE_DEVICE") == "1" else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from m3t.workloads import AVFeatureGraph
     from m3t.ddp import FlatGradDDP
@@ -172,8 +179,17 @@ def main():
         name = max(kern, key=lambda n: kern[n]["ms"])
         k = kern[name]
         achieved = k["flops"] / (k["ms"] * 1e-3) / 1e12
+        traffic = None      # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*pmc_traffic.json)
+        try:
+            import glob
+            pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))[-1]))["kernels"]
+            hits = [v for k, v in pm.items() if k.startswith(name.replace("_kernel", "")) and "hbm_bytes_per_launch" in v]
+            if hits:
+                traffic = int(sum(h["hbm_bytes_per_launch"] * h["launches"] for h in hits) / sum(h["launches"] for h in hits))
+        except Exception:  # noqa: BLE001
+            traffic = None
         roofline = {"kernel": name, "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                     "avg_launch_us": breakdown[name]["avg_launch_us"],
                     "flops_per_launch": round(k["flops"] / max(1, k["launches"])),
                     "share_of_step": round(k["ms"] / args.steps / step_ms, 3)}

@@ -34,3 +34,23 @@ def test_flat_ddp_single_gpu_matches_plain_autograd():
     b(x).square().mean().backward()
     for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
         assert torch.allclose(p.grad, q.grad, atol=1e-7), n
+
+
+def test_bench_two_ranks_on_one_gpu_gloo():
+    """The N>1 bench path (torchrun launch, flat-buffer bucketed all-reduce, barrier/max timing, rank-0 JSON)
+    on the single GPU of the test box: both ranks on cuda:0, gloo instead of RCCL."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, M3T_BENCH_BACKEND="gloo", M3T_BENCH_ONE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29531", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "4", "--frames", "40"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["value"] > 0
+    assert d["cpu_baseline"] is None and d["scaling"] == "weak"
