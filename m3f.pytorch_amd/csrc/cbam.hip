@@ -45,6 +45,32 @@ __global__ __launch_bounds__(256) void channel_fwd_kernel(const float* __restric
     float* s_h = sm + 3 * C;      // [2*Cr]
     const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* xb = x + (size_t)n * C * HW;
+    if (HW <= 32) {
+        // small maps (e.g. 4x4 at the last ResNet stage): a wavefront squeezes 64/g planes at once, g = pow2 >= H*W
+        int g = 4;
+        while (g < HW) g <<= 1;
+        const int per = 64 / g, sub = lane % g, pi = lane / g;
+        for (int c0 = wave * per; c0 < C; c0 += 4 * per) {
+            const int c = c0 + pi;
+            const bool ok = c < C && sub < HW;
+            const float v = ok ? xb[(size_t)c * HW + sub] : -INFINITY;
+            float sum = ok ? v : 0.f, mx = v;
+            int am = ok ? sub : 0x7fffffff;
+            for (int o = g >> 1; o > 0; o >>= 1) {
+                sum += __shfl_xor(sum, o, 64);
+                const float ov = __shfl_xor(mx, o, 64);
+                const int oi = __shfl_xor(am, o, 64);
+                if (ov > mx || (ov == mx && oi < am)) { mx = ov; am = oi; }
+            }
+            if (sub == 0 && c < C) {
+                const float avg = sum / (float)HW;
+                s_avg[c] = avg; s_max[c] = mx;
+                pooled[((size_t)n * 2 + 0) * C + c] = avg;
+                pooled[((size_t)n * 2 + 1) * C + c] = mx;
+                argmax[(size_t)n * C + c] = am;
+            }
+        }
+    } else
     for (int c = wave; c < C; c += 4) {
         const float* pl = xb + (size_t)c * HW;
         float sum = 0.f, mx = -INFINITY;
@@ -65,14 +91,18 @@ __global__ __launch_bounds__(256) void channel_fwd_kernel(const float* __restric
         }
     }
     __syncthreads();
-    for (int j = tid; j < 2 * Cr; j += 256) {
+    // hidden = W1 [Cr,C] x pooled: one WAVEFRONT per output (coalesced reads of the W1 row, shuffle reduction)
+    for (int j = wave; j < 2 * Cr; j += 4) {
         const int which = j / Cr, r = j % Cr;
         const float* src = which ? s_max : s_avg;
         const float* wr = w1 + (size_t)r * C;
-        float h = b1[r];
-        for (int c = 0; c < C; ++c) h += wr[c] * src[c];
-        hidden[((size_t)n * 2 + which) * Cr + r] = h;
-        s_h[j] = fmaxf(h, 0.f);
+        float h = 0.f;
+        for (int c = lane; c < C; c += 64) h += wr[c] * src[c];
+        h = wave_sum(h) + b1[r];
+        if (lane == 0) {
+            hidden[((size_t)n * 2 + which) * Cr + r] = h;
+            s_h[j] = fmaxf(h, 0.f);
+        }
     }
     __syncthreads();
     for (int c = tid; c < C; c += 256) {
@@ -114,6 +144,23 @@ __global__ __launch_bounds__(256) void channel_bwd_kernel(const float* __restric
     const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* xb = x + (size_t)n * C * HW;
     const float* gb = dy + (size_t)n * C * HW;
+    if (HW <= 32) {
+        int g = 4;
+        while (g < HW) g <<= 1;
+        const int per = 64 / g, sub = lane % g, pi = lane / g;
+        for (int c0 = wave * per; c0 < C; c0 += 4 * per) {
+            const int c = c0 + pi;
+            const bool ok = c < C && sub < HW;
+            float ds = ok ? gb[(size_t)c * HW + sub] * xb[(size_t)c * HW + sub] : 0.f;
+            for (int o = g >> 1; o > 0; o >>= 1) ds += __shfl_xor(ds, o, 64);
+            if (sub == 0 && c < C) {
+                const float sc = scale[(size_t)n * C + c];
+                const float da = ds * sc * (1.f - sc);
+                s_datt[c] = da;
+                g_datt[(size_t)n * C + c] = da;
+            }
+        }
+    } else
     for (int c = wave; c < C; c += 4) {
         const float* pl = xb + (size_t)c * HW;
         const float* gl = gb + (size_t)c * HW;
@@ -128,10 +175,17 @@ __global__ __launch_bounds__(256) void channel_bwd_kernel(const float* __restric
         }
     }
     __syncthreads();
+    // g[r] = sum_c datt[c] * W2[c][r]: the C range is split over the 4 waves (coalesced W2 reads), partials in LDS
+    float* s_part = s_davg;                     // [4][Cr] scratch (s_davg/s_dmax are written later)
+    if (lane < Cr) {
+        float g = 0.f;
+        for (int c = wave; c < C; c += 4) g += s_datt[c] * w2[(size_t)c * Cr + lane];
+        s_part[wave * Cr + lane] = g;
+    }
+    __syncthreads();
     for (int j = tid; j < 2 * Cr; j += 256) {
         const int which = j / Cr, r = j % Cr;
-        float g = 0.f;
-        for (int c = 0; c < C; ++c) g += s_datt[c] * w2[(size_t)c * Cr + r];
+        const float g = (s_part[r] + s_part[Cr + r]) + (s_part[2 * Cr + r] + s_part[3 * Cr + r]);
         const float h = hidden[((size_t)n * 2 + which) * Cr + r];
         const float dh = h > 0.f ? g : 0.f;
         s_dh[j] = dh;
@@ -165,9 +219,10 @@ __global__ __launch_bounds__(256) void channel_bwd_kernel(const float* __restric
 
 // ------------------------------------------------------------------ spatial gate
 __global__ __launch_bounds__(256) void spatial_compress_kernel(const float* __restrict__ x, float* __restrict__ comp,
-                                                               int32_t* __restrict__ cargmax, int C, int HW) {
-    const int n = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= HW) return;
+                                                               int32_t* __restrict__ cargmax, int N, int C, int HW) {
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;      // flattened (frame, pixel): full waves for any H*W
+    if (gid >= (size_t)N * HW) return;
+    const int n = (int)(gid / HW), p = (int)(gid % HW);
     const float* xb = x + (size_t)n * C * HW + p;
     float mx = -INFINITY, sum = 0.f;
     int am = 0;
@@ -182,13 +237,14 @@ __global__ __launch_bounds__(256) void spatial_compress_kernel(const float* __re
 }
 
 __global__ __launch_bounds__(256) void spatial_conv_kernel(const float* __restrict__ comp, const float* __restrict__ w,
-                                                           float* __restrict__ conv, double* __restrict__ part, int H,
-                                                           int W) {
+                                                           float* __restrict__ conv, double* __restrict__ part, int N,
+                                                           int H, int W) {
     __shared__ double red[8];
     const int HW = H * W;
-    const int n = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int n = (int)(gid / HW), p = (int)(gid % HW);
     double s1 = 0.0, s2 = 0.0;
-    if (p < HW) {
+    if (gid < (size_t)N * HW) {
         const int h = p / W, ww = p % W;
         float acc = 0.f;
         for (int ch = 0; ch < 2; ++ch) {
@@ -209,8 +265,7 @@ __global__ __launch_bounds__(256) void spatial_conv_kernel(const float* __restri
     s1 = block_sum_d(s1, red);
     s2 = block_sum_d(s2, red);
     if (threadIdx.x == 0) {
-        const size_t b = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-        part[2 * b] = s1; part[2 * b + 1] = s2;
+        part[2 * (size_t)blockIdx.x] = s1; part[2 * (size_t)blockIdx.x + 1] = s2;
     }
 }
 
@@ -242,11 +297,12 @@ __global__ __launch_bounds__(256) void spatial_stats_kernel(const double* __rest
 
 __global__ __launch_bounds__(256) void spatial_apply_kernel(const float* __restrict__ x, const float* __restrict__ bn,
                                                             const float* __restrict__ stats, float* __restrict__ xhat,
-                                                            float* __restrict__ scale, float* __restrict__ y, int C,
-                                                            int HW) {
-    const int n = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= HW) return;
-    const size_t o = (size_t)n * HW + p;
+                                                            float* __restrict__ scale, float* __restrict__ y, int N,
+                                                            int C, int HW) {
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (size_t)N * HW) return;
+    const int n = (int)(gid / HW), p = (int)(gid % HW);
+    const size_t o = gid;
     const float xh = (xhat[o] - stats[0]) * stats[1];     // xhat holds the raw conv output on entry
     xhat[o] = xh;
     const float s = 1.f / (1.f + expf(-(xh * bn[0] + bn[1])));
@@ -258,12 +314,13 @@ __global__ __launch_bounds__(256) void spatial_apply_kernel(const float* __restr
 
 __global__ __launch_bounds__(256) void spatial_bwd_ds_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                              const float* __restrict__ scale, const float* __restrict__ xhat,
-                                                             float* __restrict__ dbn, double* __restrict__ part, int C,
-                                                             int HW) {
+                                                             float* __restrict__ dbn, double* __restrict__ part, int N,
+                                                             int C, int HW) {
     __shared__ double red[8];
-    const int n = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int n = (int)(gid / HW), p = (int)(gid % HW);
     double s1 = 0.0, s2 = 0.0;
-    if (p < HW) {
+    if (gid < (size_t)N * HW) {
         const float* xb = x + (size_t)n * C * HW + p;
         const float* gb = dy + (size_t)n * C * HW + p;
         float ds = 0.f;
@@ -277,8 +334,7 @@ __global__ __launch_bounds__(256) void spatial_bwd_ds_kernel(const float* __rest
     s1 = block_sum_d(s1, red);
     s2 = block_sum_d(s2, red);
     if (threadIdx.x == 0) {
-        const size_t b = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-        part[2 * b] = s1; part[2 * b + 1] = s2;
+        part[2 * (size_t)blockIdx.x] = s1; part[2 * (size_t)blockIdx.x + 1] = s2;
     }
 }
 
@@ -338,10 +394,11 @@ __global__ __launch_bounds__(64) void spatial_bwd_dw_final_kernel(const double* 
 __global__ __launch_bounds__(256) void spatial_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ dc,
                                                              const float* __restrict__ w, const float* __restrict__ scale,
                                                              const int32_t* __restrict__ cargmax, float* __restrict__ dx,
-                                                             int C, int H, int W) {
+                                                             int N, int C, int H, int W) {
     const int HW = H * W;
-    const int n = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= HW) return;
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (size_t)N * HW) return;
+    const int n = (int)(gid / HW), p = (int)(gid % HW);
     const int h = p / W, ww = p % W;
     const float* dcn = dc + (size_t)n * HW;
     float dmax = 0.f, dmean = 0.f;
@@ -427,16 +484,16 @@ extern "C" int m3t_cbam_spatial_fwd(const float* x, const float* conv_w, const f
         return M3T_EINVAL;
     const int HW = H * W;
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid(cdiv(HW, 256), N);
+    const int nblk = (int)(((size_t)N * HW + 255) / 256);
     double* part = reinterpret_cast<double*>(ws);      // fp64 (sum, sumsq) per block
-    if (ws_bytes < (size_t)grid.x * grid.y * 2 * sizeof(double) || ((uintptr_t)ws & 7) != 0) return M3T_EINVAL;
-    spatial_compress_kernel<<<grid, 256, 0, s>>>(x, comp, cargmax, C, HW);
+    if (ws_bytes < (size_t)nblk * 2 * sizeof(double) || ((uintptr_t)ws & 7) != 0) return M3T_EINVAL;
+    spatial_compress_kernel<<<nblk, 256, 0, s>>>(x, comp, cargmax, N, C, HW);
     M3T_LAUNCH_CHECK();
-    spatial_conv_kernel<<<grid, 256, 0, s>>>(comp, conv_w, xhat, part, H, W);
+    spatial_conv_kernel<<<nblk, 256, 0, s>>>(comp, conv_w, xhat, part, N, H, W);
     M3T_LAUNCH_CHECK();
-    spatial_stats_kernel<<<1, 256, 0, s>>>(part, grid.x * grid.y, (double)N * HW, running, stats, training, momentum, eps);
+    spatial_stats_kernel<<<1, 256, 0, s>>>(part, nblk, (double)N * HW, running, stats, training, momentum, eps);
     M3T_LAUNCH_CHECK();
-    spatial_apply_kernel<<<grid, 256, 0, s>>>(x, bn, stats, xhat, scale, y, C, HW);
+    spatial_apply_kernel<<<nblk, 256, 0, s>>>(x, bn, stats, xhat, scale, y, N, C, HW);
     M3T_LAUNCH_CHECK();
     return 0;
 }
@@ -452,8 +509,7 @@ extern "C" int m3t_cbam_spatial_bwd(const float* dy, const float* x, const float
     const int HW = H * W;
     const size_t total = (size_t)N * HW;
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid(cdiv(HW, 256), N);
-    const size_t nblk = (size_t)grid.x * grid.y;
+    const size_t nblk = (total + 255) / 256;
     int chunks = (int)((total + 16383) / 16384);
     if (chunks > 256) chunks = 256;
     const int per_chunk = (int)((total + chunks - 1) / chunks);
@@ -466,7 +522,7 @@ extern "C" int m3t_cbam_spatial_bwd(const float* dy, const float* x, const float
     float* g_dc = ws + total;
     double* part = reinterpret_cast<double*>(ws + off);
     double* dwpart = part + 2 * nblk;
-    spatial_bwd_ds_kernel<<<grid, 256, 0, s>>>(dy, x, scale, xhat, g_dbn, part, C, HW);
+    spatial_bwd_ds_kernel<<<(int)nblk, 256, 0, s>>>(dy, x, scale, xhat, g_dbn, part, N, C, HW);
     M3T_LAUNCH_CHECK();
     sum_pairs_kernel<<<1, 256, 0, s>>>(part, (int)nblk, dbn);
     M3T_LAUNCH_CHECK();
@@ -478,7 +534,7 @@ extern "C" int m3t_cbam_spatial_bwd(const float* dy, const float* x, const float
     M3T_LAUNCH_CHECK();
     spatial_bwd_dw_final_kernel<<<50, 64, 0, s>>>(dwpart, chunks, dconv_w);
     M3T_LAUNCH_CHECK();
-    spatial_bwd_dx_kernel<<<grid, 256, 0, s>>>(dy, g_dc, conv_w, scale, cargmax, dx, C, H, W);
+    spatial_bwd_dx_kernel<<<(int)nblk, 256, 0, s>>>(dy, g_dc, conv_w, scale, cargmax, dx, N, C, H, W);
     M3T_LAUNCH_CHECK();
     return 0;
 }
