@@ -695,3 +695,46 @@ def grad_norm_scale_(flat, world_size, max_norm):
                                    ws.numel() * 4, _stream())
     _lib.check(rc, "m3t_grad_norm_scale")
     return norm
+
+
+# ----------------------------------------------------------------------------- Conv3d weight gradient
+class _Conv3dGemmWgrad(torch.autograd.Function):
+    """Conv3d of the visual stems (reference models/backbone.py:73-103,179-271,327-332): forward and the data
+    gradient stay on PyTorch-ROCm/MIOpen, but the WEIGHT gradient is computed as one
+    fp32-accurate GEMM on the bf16 matrix pipe (m3t_sgemm, K = N*T'*H'*W' positions) over an explicit patch
+    matrix: MIOpen's fp32 conv3d bwd-weight kernel ran at ~1 TFLOP/s on these shapes (138 ms per call, 88 % of a
+    full AffWild2VA step on MI355X)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, padding):
+        y = torch.conv3d(x, w, b, stride, padding)
+        ctx.save_for_backward(x, w)
+        ctx.stride, ctx.padding, ctx.has_bias = stride, padding, b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        st, pd = ctx.stride, ctx.padding
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.ops.aten.convolution_backward(dy, x, w, None, list(st), list(pd), [1, 1, 1], False, [0, 0, 0], 1,
+                                                     [True, False, False])[0]
+        Co, Ci, kt, kh, kw = w.shape
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dy_cl = _req(dy.permute(0, 2, 3, 4, 1).contiguous(), "dy")          # [N,T',H',W',Co] = [rows, Co]
+            rows = dy_cl.numel() // Co
+        if ctx.needs_input_grad[1]:
+            xp = torch.nn.functional.pad(x, (pd[2], pd[2], pd[1], pd[1], pd[0], pd[0])) if any(pd) else x
+            pat = xp.unfold(2, kt, st[0]).unfold(3, kh, st[1]).unfold(4, kw, st[2])   # [N,Ci,T',H',W',kt,kh,kw] (view)
+            pat = _req(pat.permute(0, 2, 3, 4, 1, 5, 6, 7).reshape(rows, Ci * kt * kh * kw), "patches")
+            dw = torch.empty_like(w)
+            sgemm(1, 0, Co, Ci * kt * kh * kw, rows, dy_cl, 0, Co, pat, 0, Ci * kt * kh * kw, dw, 0, Ci * kt * kh * kw)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(Co, dtype=torch.float32, device=dy.device)
+            colsum(dy_cl, 0, rows, Co, Co, db)
+        return dx, dw, db, None, None
+
+
+def conv3d(x, w, b, stride, padding):
+    return _Conv3dGemmWgrad.apply(x, w, b, tuple(stride), tuple(padding))

@@ -18,6 +18,18 @@ from .rnn import GRU, run_grus
 from .tcn import TemporalConvNet, WeightNormConv1d
 
 
+class Conv3d(nn.Conv3d):
+    """nn.Conv3d (same parameters / state_dict keys) whose weight gradient runs on the HIP GEMM (m3t.ops.conv3d);
+    forward and data gradient stay on MIOpen.  Falls back to the stock op for configurations it does not cover."""
+
+    def forward(self, x):
+        if (x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and self.weight.requires_grad
+                and self.groups == 1 and tuple(self.dilation) == (1, 1, 1) and self.padding_mode == "zeros"
+                and isinstance(self.padding, tuple)):
+            return ops.conv3d(x, self.weight, self.bias, self.stride, self.padding)
+        return super().forward(x)
+
+
 def _norm3d(kind, channels):
     return nn.BatchNorm3d(channels) if kind == 'bn' else nn.GroupNorm(32, channels)
 
@@ -25,10 +37,10 @@ def _norm3d(kind, channels):
 def _vgg_group(idx, norm):
     """Layer group `conv{idx}` of the VGG-M style stem (reference backbone.py:73-103,179-184,243-271)."""
     if idx == 1:
-        return [nn.Conv3d(3, 64, 3, stride=(1, 2, 2), padding=(1, 0, 0)), _norm3d(norm, 64), nn.ReLU(True),
+        return [Conv3d(3, 64, 3, stride=(1, 2, 2), padding=(1, 0, 0)), _norm3d(norm, 64), nn.ReLU(True),
                 nn.MaxPool3d(kernel_size=(1, 2, 2), stride=(1, 2, 2))]
     cin, cout, pool = {2: (64, 128, True), 3: (128, 256, True), 4: (256, 512, False), 5: (512, 512, False)}[idx]
-    mods = [nn.Conv3d(cin, cout, 3, 1, padding=(1, 0, 0)), _norm3d(norm, cout), nn.ReLU(True)]
+    mods = [Conv3d(cin, cout, 3, 1, padding=(1, 0, 0)), _norm3d(norm, cout), nn.ReLU(True)]
     if pool:
         mods.append(nn.MaxPool3d(kernel_size=(1, 2, 2), stride=(1, 2, 2)))
     return mods
@@ -174,7 +186,7 @@ class VA_3DResNet(nn.Module):
         self.inputDim, self.hiddenDim, self.nClasses = inputDim, hiddenDim, nClasses
         self.frameLen, self.nLayers, self.backend, self.nFCs = frameLen, nLayers, backend, nFCs
         self.c3d = nn.Sequential(
-            nn.Conv3d(3, 64, kernel_size=(5, 7, 7), stride=(1, 2, 2), padding=(2, 3, 3), bias=False),
+            Conv3d(3, 64, kernel_size=(5, 7, 7), stride=(1, 2, 2), padding=(2, 3, 3), bias=False),
             nn.BatchNorm3d(64), nn.ReLU(True),
             nn.MaxPool3d(kernel_size=(1, 3, 3), stride=(1, 2, 2), padding=(0, 1, 1)))
         assert resnet_depth in [18, 34] and resnet_ver in ['v1', 'v2'], \

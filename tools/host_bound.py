@@ -33,3 +33,14 @@ for prof in (False, True):
     torch.cuda.synchronize()
     tot = time.perf_counter() - t0
     print("profile=%s: enqueue %.2f ms/step, wall %.2f ms/step" % (prof, enq / 5 * 1e3, tot / 5 * 1e3))
+
+import cProfile, pstats, io
+pr = cProfile.Profile()
+torch.cuda.synchronize()
+pr.enable()
+for _ in range(5): step()
+pr.disable()
+torch.cuda.synchronize()
+sio = io.StringIO()
+pstats.Stats(pr, stream=sio).sort_stats("tottime").print_stats(14)
+print(sio.getvalue()[:3500])
