@@ -206,6 +206,15 @@ int m3t_cbam_spatial_bwd(const float* dy, const float* x, const float* conv_w, c
 int m3t_grad_norm_scale(float* flat, size_t n, float inv_world, float max_norm,
                         float* norm_out, float* ws, size_t ws_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------
+ * Optimizer steps over the flat parameter / gradient buffers (reference
+ * models/model.py:388-394).  torch.optim semantics: Adam(lr, betas, eps, weight_decay as L2 on the gradient,
+ * bias-corrected, `step` counts from 1); SGD(momentum, weight_decay), dampening 0, no Nesterov. */
+int m3t_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int step, void* stream);
+int m3t_sgd_step(float* p, const float* g, float* buf, size_t n, float lr, float momentum, float weight_decay,
+                 int step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

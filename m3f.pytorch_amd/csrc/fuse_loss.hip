@@ -3,6 +3,7 @@
 // the data-parallel gradient post-processing (train.py:35).  One wavefront per [B,T,C] frame
 // row, float4 (16 B/lane) accesses, wavefront-shuffle reductions, no atomics.
 #include "common.h"
+#include <cmath>
 
 namespace {
 
@@ -216,7 +217,70 @@ __global__ __launch_bounds__(256) void norm_scale_kernel(float* __restrict__ g, 
         for (size_t i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) g[i] *= sc;
 }
 
+// ------------------------------------------------------------------------------ optimizers (flat buffers)
+// torch.optim.Adam semantics (reference models/model.py:388-390: Adam(lr, weight_decay=1e-4), L2 added to the gradient)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps,
+                                                   float wd, float inv_bc1, float inv_sqrt_bc2) {
+    const size_t n4 = n >> 2;
+    float4* p4 = reinterpret_cast<float4*>(p);
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    float4* m4 = reinterpret_cast<float4*>(m);
+    float4* v4 = reinterpret_cast<float4*>(v);
+    auto upd = [&](float& pp, float gg, float& mm, float& vv) {
+        gg += wd * pp;
+        mm = b1 * mm + (1.f - b1) * gg;
+        vv = b2 * vv + (1.f - b2) * gg * gg;
+        pp -= lr * inv_bc1 * mm / (sqrtf(vv) * inv_sqrt_bc2 + eps);
+    };
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 pp = p4[i], mm = m4[i], vv = v4[i];
+        const float4 gg = g4[i];
+        upd(pp.x, gg.x, mm.x, vv.x); upd(pp.y, gg.y, mm.y, vv.y); upd(pp.z, gg.z, mm.z, vv.z); upd(pp.w, gg.w, mm.w, vv.w);
+        p4[i] = pp; m4[i] = mm; v4[i] = vv;
+    }
+    if (blockIdx.x == 0)
+        for (size_t i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) upd(p[i], g[i], m[i], v[i]);
+}
+
+// torch.optim.SGD(momentum, weight_decay) semantics (reference models/model.py:392-394), dampening 0, no nesterov
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                                  size_t n, float lr, float momentum, float wd, int first) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float gg = g[i] + wd * p[i];
+        const float b = first ? gg : momentum * buf[i] + gg;
+        buf[i] = b;
+        p[i] -= lr * b;
+    }
+}
+
 }  // namespace
+
+extern "C" int m3t_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                             float eps, float weight_decay, int step, void* stream) {
+    if (n == 0) return 0;
+    if (!p || !g || !m || !v || step < 1 || (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16) != 0)
+        return M3T_EINVAL;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    int blocks = (int)((n / 4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    adam_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, (float)(1.0 / bc1),
+                                                         (float)(1.0 / sqrt(bc2)));
+    M3T_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int m3t_sgd_step(float* p, const float* g, float* buf, size_t n, float lr, float momentum, float weight_decay,
+                            int step, void* stream) {
+    if (n == 0) return 0;
+    if (!p || !g || !buf || step < 1) return M3T_EINVAL;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    sgd_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(p, g, buf, n, lr, momentum, weight_decay, step == 1);
+    M3T_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int m3t_att_fuse_fwd(const float* s_v, const float* s_a, const float* x_v, const float* x_a, float* f,
                                 int rows, int D, void* stream) {

@@ -24,7 +24,8 @@ def shard_indices(n_items, rank, world_size):
 
 
 class FlatGradDDP:
-    def __init__(self, module, bucket_order=None, max_norm=1.0, process_group=None, finalize=None):
+    def __init__(self, module, bucket_order=None, max_norm=1.0, process_group=None, finalize=None,
+                 flatten_params=False):
         """bucket_order: list of lists of parameters, in the order backward completes them
         (default: one bucket per top-level child, reversed registration order).
         finalize(flat, world_size, max_norm) -> norm tensor; default = fused HIP kernel."""
@@ -56,6 +57,19 @@ class FlatGradDDP:
                 p.grad = self.flat[off:off + p.numel()].view_as(p)
                 off += p.numel()
             self.ranges.append((start, off))
+        # optionally the parameters themselves become views of one flat buffer (same order as the gradients),
+        # so an optimizer step is ONE kernel over (flat_params, flat)
+        self.flat_params = None
+        if flatten_params:
+            self.flat_params = torch.empty(n, dtype=torch.float32, device=dev)
+            off = 0
+            with torch.no_grad():
+                for b in self.buckets:
+                    for p in b:
+                        view = self.flat_params[off:off + p.numel()].view_as(p)
+                        view.copy_(p.data)
+                        p.data = view
+                        off += p.numel()
         self._left = [0] * len(self.buckets)
         self._handles = []
         if self.world > 1:

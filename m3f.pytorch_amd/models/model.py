@@ -12,8 +12,8 @@ towers; the two fusion scorers) so that one launch per time step covers all of t
 installed the class derives from pl.LightningModule exactly as the reference does; without it
 (this image) it is a plain nn.Module with the same hooks.
 
-Out of scope here (SURVEY.md section 8(f) "next" rows): dataloaders (need the Aff-Wild2 dataset and
-cv2), validation/test window stitching, the LR range finder, `--fusion_type att_dec`.
+Validation/test window stitching is host glue in m3t/stitch.py.  Out of scope: dataloaders
+(need the Aff-Wild2 dataset and cv2), the LR range finder, `--fusion_type att_dec`.
 """
 from argparse import ArgumentParser
 
@@ -147,6 +147,48 @@ class AffWild2VA(_Base):
         if getattr(self.hparams, 'test_lr', False):
             raise NotImplementedError("LR range finder (models/lr_finder.py) is out of scope")
         return {'loss': loss, 'progress_bar': progress, 'log': log}
+
+    # ------------------------------------------------------------------ evaluation glue (host ops)
+    def _window_outputs(self, batch, with_gt):
+        y_hat = self.forward(batch).detach().cpu()
+        v_hat, a_hat = y_hat[..., -2], y_hat[..., -1]
+        lens = batch['length']
+        n = lens.size(0)
+        out = {'v_pred': [v_hat[i][:lens[i]] for i in range(n)], 'a_pred': [a_hat[i][:lens[i]] for i in range(n)],
+               'vid_names': batch['vid_name'], 'start_frames': batch['start'].cpu()}
+        if with_gt:
+            v, a = batch['label_valence'].cpu(), batch['label_arousal'].cpu()
+            out['v_gt'] = [v[i][:lens[i]] for i in range(n)]
+            out['a_gt'] = [a[i][:lens[i]] for i in range(n)]
+        return out
+
+    def validation_step(self, batch, batch_idx):
+        with torch.no_grad():
+            return self._window_outputs(batch, True)
+
+    def validation_end(self, outputs):
+        from m3t import stitch
+        m = stitch.val_metrics(outputs)
+        gt_v, gt_a, pred_v, pred_a = stitch.stitch_val(outputs, self.hparams.window, self.hparams.test_on_val)
+        torch.save({'valence_gt': gt_v, 'arousal_gt': gt_a, 'valence_pred': pred_v, 'arousal_pred': pred_a},
+                   'predictions_val.pt')
+        return {'val_loss': m['val_loss'],
+                'progress_bar': {'val_ccc_v': m['val_ccc_v'], 'val_ccc_a': m['val_ccc_a']},
+                'log': dict(m)}
+
+    def test_step(self, batch, batch_idx):
+        if self.hparams.test_on_val:
+            return self.validation_step(batch, batch_idx)
+        with torch.no_grad():
+            return self._window_outputs(batch, False)
+
+    def test_end(self, outputs):
+        if self.hparams.test_on_val:
+            return self.validation_end(outputs)
+        from m3t import stitch
+        pred_v, pred_a = stitch.stitch_test(outputs, self.hparams.window)
+        torch.save({'valence_pred': pred_v, 'arousal_pred': pred_a}, 'predictions_test.pt')
+        return {}
 
     def on_batch_end(self):
         if getattr(self.hparams, 'scheduler', None) == 'cyclic' and hasattr(self, 'cyclic_scheduler'):

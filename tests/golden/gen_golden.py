@@ -340,6 +340,69 @@ def case_init_digests(name):
     save(name, **out)
 
 
+def _stitch_outputs(rs, window, with_gt):
+    """Synthetic validation/test step outputs: 3 videos, windows at stride window/2, ragged last windows."""
+    vids = {"vidA": 37, "vidB": 16, "vidC": 25}
+    items = []
+    for name, n in vids.items():
+        for st in range(0, n, window // 2):
+            ln = min(window, n - st)
+            it = {"name": name, "start": st, "v_pred": draw(rs, (ln,)), "a_pred": draw(rs, (ln,))}
+            if with_gt:
+                it["v_gt"] = draw(rs, (ln,), "uniform_pm1")
+                it["a_gt"] = draw(rs, (ln,), "uniform_pm1")
+            items.append(it)
+    order = rs.permutation(len(items))          # batches arrive shuffled across videos
+    items = [items[i] for i in order]
+    outputs = []
+    for i in range(0, len(items), 4):
+        chunk = items[i:i + 4]
+        out = {"vid_names": [c["name"] for c in chunk], "start_frames": torch.tensor([c["start"] for c in chunk]),
+               "v_pred": [torch.from_numpy(c["v_pred"]) for c in chunk], "a_pred": [torch.from_numpy(c["a_pred"]) for c in chunk]}
+        if with_gt:
+            out["v_gt"] = [torch.from_numpy(c["v_gt"]) for c in chunk]
+            out["a_gt"] = [torch.from_numpy(c["a_gt"]) for c in chunk]
+        outputs.append(out)
+    return outputs, items
+
+
+def case_stitch(name, seed):
+    """validation_end / test_end of the reference (models/model.py:248-373) on synthetic window outputs."""
+    import tempfile
+    window = 8
+    arrs = {"window": np.array(window)}
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            for mode in ("test", "val_cat", "val_overlap"):
+                rs = np.random.RandomState(seed + len(mode))
+                with_gt = mode != "test"
+                outputs, items = _stitch_outputs(rs, window, with_gt)
+                model = AffWild2VA(hp(modality="audio", window=window, test_on_val=(mode == "val_overlap")))
+                if mode == "test":
+                    model.test_end(outputs)
+                    res = torch.load("predictions_test.pt")
+                else:
+                    ret = model.validation_end(outputs)
+                    res = torch.load("predictions_val.pt")
+                    for k in ("val_ccc_v", "val_ccc_a", "val_mse_v", "val_mse_a", "val_loss"):
+                        arrs["%s.metric.%s" % (mode, k)] = np.array(float(ret["log"][k]))
+                for key, per_video in res.items():
+                    for vid, t in per_video.items():
+                        arrs["%s.out.%s.%s" % (mode, key, vid)] = t.numpy()
+                arrs["%s.n_items" % mode] = np.array(len(items))
+                for i, it in enumerate(items):
+                    arrs["%s.in.%d.name" % (mode, i)] = np.array(it["name"])
+                    arrs["%s.in.%d.start" % (mode, i)] = np.array(it["start"])
+                    for k in ("v_pred", "a_pred", "v_gt", "a_gt"):
+                        if k in it:
+                            arrs["%s.in.%d.%s" % (mode, i, k)] = it[k]
+        finally:
+            os.chdir(cwd)
+    save(name, **arrs)
+
+
 def main():
     only = set(sys.argv[1:])
 
@@ -378,6 +441,8 @@ def main():
         case_c3("c3_av_graph_small", 3, 17, 800, d_a=10, d_v=12, nh=512)
     if want("init"):
         case_init_digests("init_digests")
+    if want("stitch"):
+        case_stitch("stitch", 1000)
     if want("c5"):
         case_affwild_av("c5_affwild_av", 900)
         case_resnet3d("c5_resnet3d_cbam", 910)
