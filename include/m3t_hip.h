@@ -166,6 +166,35 @@ int m3t_causal_conv_fwd(const float* x, const float* w_t, const float* bias, con
 int m3t_causal_conv_wgrad(const float* dy, const float* x, float* dw_t,
                           int B, int T, int Ci, int Co, int K, int dilation,
                           float* ws, size_t ws_bytes, void* stream);
+/* General 1-D conv over channel-last rows with `lead` frames of look-ahead (0 <= lead <= (K-1)*d):
+ *   y[b,t,co] = act( bias[co] + sum_{j,ci} w_t[j][co][ci] * x[b, t + lead - (K-1-j)*d, ci] ... )
+ * lead = 0 is m3t_causal_conv_fwd; lead = pad is nn.Conv1d(k, stride 1, padding=pad) with 2*pad = (K-1)*d --
+ * the `tcn_simple` back-end's Conv1d(.,.,5,1,2) / Conv1d(.,.,3,1,1) (reference models/backbone.py:107-111,
+ * 214-231).  anticausal != 0 flips time (x[b, t - lead + (K-1-j)*d]): the data gradient. */
+int m3t_conv1d_fwd(const float* x, const float* w_t, const float* bias, const float* res,
+                   const float* drop_mask, float* y, float* pre,
+                   int B, int T, int Ci, int Co, int K, int dilation, int lead,
+                   int act, int anticausal, void* stream);
+/* dw_t[j][co][ci] = sum_{b,t} dy[b,t,co] * x[b, t + lead - (K-1-j)*d, ci] */
+int m3t_conv1d_wgrad(const float* dy, const float* x, float* dw_t,
+                     int B, int T, int Ci, int Co, int K, int dilation, int lead,
+                     float* ws, size_t ws_bytes, void* stream);
+
+/* BatchNorm1d (+ optional fused ReLU) over channel-last rows x [M = B*T, C]
+ * (nn.BatchNorm1d(512) + nn.ReLU(True) of `tcn_simple`, reference models/backbone.py:108-110, 217-222).
+ * training != 0: batch statistics (biased variance for normalisation; run_mean/run_var, when given, are
+ * updated in place with `momentum` and the unbiased variance, as torch); training == 0: running statistics.
+ * save_mean / save_invstd [C] receive the statistics used (needed by the backward).
+ * ws: m3t_bn_rows_ws_bytes(M, C) bytes, 8-byte aligned (fp64 per-chunk partial sums, fixed-order reduce). */
+size_t m3t_bn_rows_ws_bytes(int M, int C);
+int m3t_bn_rows_fwd(const float* x, int M, int C, const float* gamma, const float* beta,
+                    float* run_mean, float* run_var, float momentum, float eps, int training, int relu,
+                    float* y, float* save_mean, float* save_invstd, float* ws, size_t ws_bytes, void* stream);
+/* g = dy * (y > 0) when relu; dbeta = sum g, dgamma = sum g*xhat,
+ * training: dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat));  eval: dx = g*gamma*invstd */
+int m3t_bn_rows_bwd(const float* dy, const float* x, const float* y, const float* gamma,
+                    const float* save_mean, const float* save_invstd, int M, int C, int training, int relu,
+                    float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes, void* stream);
 /* [B,C,T] <-> [B,T,C] */
 int m3t_bct_to_btc(const float* src, float* dst, int B, int C, int T, void* stream);
 int m3t_btc_to_bct(const float* src, float* dst, int B, int T, int C, void* stream);

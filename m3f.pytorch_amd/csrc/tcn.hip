@@ -17,7 +17,7 @@ constexpr int BM = 128, BN = 128, BK = 16, LDB = 132;
 
 struct ConvParams {
     const float* x; const float* w_t; const float* bias; const float* res; const float* mask; float* y; float* pre;
-    int B, T, Ci, Co, K, dil, act, anti, halo, lda, w_kn, vecx, vecw;
+    int B, T, Ci, Co, K, dil, act, anti, halo, lead, lda, w_kn, vecx, vecw;
 };
 
 // dynamic LDS: As[BK][lda] (lda = BM + halo + pad), Bs[K][BK][LDB]
@@ -32,9 +32,11 @@ __global__ __launch_bounds__(256) void causal_conv_kernel(ConvParams p) {
     const int M = p.B * p.T;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int halo = p.halo;
-    // LDS image row r (0 .. BM+halo-1) holds source row  m0 - halo + r  (causal)
-    //                                              or     m0 + r          (anti-causal)
-    const int src0 = p.anti ? m0 : m0 - halo;
+    // tap j of output row t reads source time  t + off_j,  off_j = lead - sft_j  (forward; lead = 0: causal)
+    //                                                      off_j = sft_j - lead  (time-flipped: the data gradient)
+    // LDS image row r (0 .. BM+halo-1) holds source row  m0 + minoff + r,  minoff = min_j off_j
+    const int minoff = p.anti ? -p.lead : p.lead - halo;
+    const int src0 = m0 + minoff;
     const int nrows = BM + halo;
 
     f32x16 acc[2][2];
@@ -130,10 +132,11 @@ __global__ __launch_bounds__(256) void causal_conv_kernel(ConvParams p) {
         for (int j = 0; j < p.K; ++j) {
             const int sft = (p.K - 1 - j) * p.dil;
             // image row of A-fragment row i for this tap
-            const int roff = p.anti ? sft : halo - sft;
+            const int off = p.anti ? sft - p.lead : p.lead - sft;
+            const int roff = off - minoff;
             bool ok[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) ok[i] = mrow[i] && (p.anti ? (trow[i] + sft < p.T) : (trow[i] >= sft));
+            for (int i = 0; i < 2; ++i) ok[i] = mrow[i] && (unsigned)(trow[i] + off) < (unsigned)p.T;
             const float* a_s = As + wm * 64 + l31 + roff;
             const float* b_s = Bs + j * BK * LDB + wn * 64 + l31;
 #pragma unroll
@@ -252,15 +255,16 @@ extern "C" int m3t_weight_norm_bwd(const float* dw_t, const float* v, const floa
     return 0;
 }
 
-extern "C" int m3t_causal_conv_fwd(const float* x, const float* w_t, const float* bias, const float* res,
-                                   const float* drop_mask, float* y, float* pre, int B, int T, int Ci, int Co, int K,
-                                   int dilation, int act, int anticausal, void* stream) {
+extern "C" int m3t_conv1d_fwd(const float* x, const float* w_t, const float* bias, const float* res,
+                              const float* drop_mask, float* y, float* pre, int B, int T, int Ci, int Co, int K,
+                              int dilation, int lead, int act, int anticausal, void* stream) {
     if (B <= 0 || T <= 0) return 0;
     if (Ci <= 0 || Co <= 0 || K <= 0 || dilation <= 0 || !x || !w_t || !y) return M3T_EINVAL;
+    if (lead < 0 || lead > (K - 1) * dilation) return M3T_EINVAL;
     if (act == 2 && !res) return M3T_EINVAL;
     ConvParams p;
     p.x = x; p.w_t = w_t; p.bias = bias; p.res = res; p.mask = drop_mask; p.y = y; p.pre = pre;
-    p.B = B; p.T = T; p.Ci = Ci; p.Co = Co; p.K = K; p.dil = dilation; p.act = act; p.anti = anticausal;
+    p.B = B; p.T = T; p.Ci = Ci; p.Co = Co; p.K = K; p.dil = dilation; p.act = act; p.anti = anticausal; p.lead = lead;
     const int halo = (K - 1) * dilation;
     p.halo = halo;
     p.lda = ((BM + halo - 4 + 31) / 32) * 32 + 4;   // == 4 (mod 32): 2-way (free) transposing LDS writes
@@ -285,23 +289,36 @@ extern "C" int m3t_causal_conv_fwd(const float* x, const float* w_t, const float
     return 0;
 }
 
-extern "C" int m3t_causal_conv_wgrad(const float* dy, const float* x, float* dw_t, int B, int T, int Ci, int Co, int K,
-                                     int dilation, float* ws, size_t ws_bytes, void* stream) {
+extern "C" int m3t_causal_conv_fwd(const float* x, const float* w_t, const float* bias, const float* res,
+                                   const float* drop_mask, float* y, float* pre, int B, int T, int Ci, int Co, int K,
+                                   int dilation, int act, int anticausal, void* stream) {
+    return m3t_conv1d_fwd(x, w_t, bias, res, drop_mask, y, pre, B, T, Ci, Co, K, dilation, 0, act, anticausal, stream);
+}
+
+extern "C" int m3t_conv1d_wgrad(const float* dy, const float* x, float* dw_t, int B, int T, int Ci, int Co, int K,
+                                int dilation, int lead, float* ws, size_t ws_bytes, void* stream) {
     if (Ci <= 0 || Co <= 0 || K <= 0 || !dy || !x || !dw_t) return M3T_EINVAL;
+    if (lead < 0 || lead > (K - 1) * dilation) return M3T_EINVAL;
     for (int j = 0; j < K; ++j) {
-        const int sft = (K - 1 - j) * dilation;
+        const int off = lead - (K - 1 - j) * dilation;     // x row = dy row + off
+        const int aoff = off < 0 ? -off : 0, boff = off > 0 ? off : 0, span = aoff + boff;
         float* out = dw_t + (size_t)j * Co * Ci;
-        if (sft >= T) {
+        if (span >= T || B <= 0) {
             hipError_t e = hipMemsetAsync(out, 0, (size_t)Co * Ci * sizeof(float), (hipStream_t)stream);
             if (e != hipSuccess) return (int)e;
             continue;
         }
-        // dw_t[j][co][ci] = sum_b sum_{t>=sft} dy[b,t,co] * x[b,t-sft,ci]
-        const int rc = m3t_sgemm(1, 0, Co, Ci, B * (T - sft), dy, Co, x, Ci, out, Ci, nullptr, 0, 0, T - sft, T, sft, 0,
+        // dw_t[j][co][ci] = sum_b sum_t dy[b,t,co] * x[b,t+off,ci] over the t with both rows inside the clip
+        const int rc = m3t_sgemm(1, 0, Co, Ci, B * (T - span), dy, Co, x, Ci, out, Ci, nullptr, 0, 0, T - span, T, aoff, boff,
                                  ws, ws_bytes, 0, stream);
         if (rc) return rc;
     }
     return 0;
+}
+
+extern "C" int m3t_causal_conv_wgrad(const float* dy, const float* x, float* dw_t, int B, int T, int Ci, int Co, int K,
+                                     int dilation, float* ws, size_t ws_bytes, void* stream) {
+    return m3t_conv1d_wgrad(dy, x, dw_t, B, T, Ci, Co, K, dilation, 0, ws, ws_bytes, stream);
 }
 
 extern "C" int m3t_bct_to_btc(const float* src, float* dst, int B, int C, int T, void* stream) {

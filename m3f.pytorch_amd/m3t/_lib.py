@@ -43,6 +43,11 @@ SIGNATURES = {
     "m3t_weight_norm_bwd": [_f, _f, _f, _f, _f, _f, _i, _i, _i, _s],
     "m3t_causal_conv_fwd": [_f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _s],
     "m3t_causal_conv_wgrad": [_f, _f, _f, _i, _i, _i, _i, _i, _i, _f, _z, _s],
+    "m3t_conv1d_fwd": [_f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _s],
+    "m3t_conv1d_wgrad": [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _z, _s],
+    "m3t_bn_rows_ws_bytes": [_i, _i],
+    "m3t_bn_rows_fwd": [_f, _i, _i, _f, _f, _f, _f, C.c_float, C.c_float, _i, _i, _f, _f, _f, _f, _z, _s],
+    "m3t_bn_rows_bwd": [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _f, _f, _f, _f, _z, _s],
     "m3t_bct_to_btc": [_f, _f, _i, _i, _i, _s],
     "m3t_btc_to_bct": [_f, _f, _i, _i, _i, _s],
     "m3t_mask_pos": [_f, _f, _f, _f, _z, _s],
@@ -54,6 +59,8 @@ SIGNATURES = {
     "m3t_adam_step": [_f, _f, _f, _f, _z, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _i, _s],
     "m3t_sgd_step": [_f, _f, _f, _z, C.c_float, C.c_float, C.c_float, _i, _s],
 }
+
+RESTYPES = {"m3t_bn_rows_ws_bytes": C.c_size_t}
 
 _lib = None
 
@@ -78,7 +85,7 @@ def load():
     for name, argt in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here = ABI mismatch: loud by design
         fn.argtypes = argt
-        fn.restype = C.c_int
+        fn.restype = RESTYPES.get(name, C.c_int)
     _lib = lib
     return lib
 

@@ -5,6 +5,7 @@ autograd bookkeeping.  All arithmetic of the hot path happens in the HIP library
 is no CPU or eager fallback -- a CPU tensor or a missing library raises.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -585,6 +586,85 @@ class _TemporalBlock(torch.autograd.Function):
 
 def temporal_block(x_btc, v1, g1, b1, v2, g2, b2, wd, bd, dilation, m1=None, m2=None):
     return _TemporalBlock.apply(x_btc, v1, g1, b1, v2, g2, b2, wd, bd, dilation, m1, m2)
+
+
+class _ConvBnRelu(torch.autograd.Function):
+    """nn.Conv1d(C_in, C_out, k, 1, pad) -> nn.BatchNorm1d -> nn.ReLU on channel-last rows: one stage of the
+    `tcn_simple` back-end (reference models/backbone.py:107-112, 214-222).  The conv is the implicit-GEMM kernel of
+    the TCN with `lead = pad` frames of look-ahead; BatchNorm runs over the [B*T, C] rows (column statistics).
+    running_mean / running_var are updated in place in training mode, as nn.BatchNorm1d does."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, gamma, beta, run_mean, run_var, pad, training, momentum, eps):
+        x = _req(x.contiguous(), "x")
+        for t in (w, gamma, beta, run_mean, run_var):
+            _req(t, "tcn_simple parameter")
+        B, T, Ci = x.shape
+        Co, _, K = w.shape
+        if 2 * pad != K - 1:
+            raise M3THipError("tcn_simple conv needs 2*padding == kernel_size-1 (got k=%d, pad=%d)" % (K, pad))
+        dev = x.device
+        w_t = transpose2d(w.detach().view(Co * Ci, K)).view(K, Co, Ci)          # tap-major [K][Co][Ci]
+        a = torch.empty(B, T, Co, dtype=torch.float32, device=dev)
+        rc = lib().m3t_conv1d_fwd(_p(x), _p(w_t), _p(b), None, None, _p(a), None, B, T, Ci, Co, K, 1, pad, 0, 0, _stream())
+        _lib.check(rc, "m3t_conv1d_fwd")
+        y = torch.empty_like(a)
+        mean = torch.empty(Co, dtype=torch.float32, device=dev)
+        invstd = torch.empty(Co, dtype=torch.float32, device=dev)
+        ws = workspace(dev)
+        rc = lib().m3t_bn_rows_fwd(_p(a), B * T, Co, _p(gamma), _p(beta), _p(run_mean), _p(run_var), float(momentum),
+                                   float(eps), int(training), 1, _p(y), _p(mean), _p(invstd), _p(ws), ws.numel() * 4,
+                                   _stream())
+        _lib.check(rc, "m3t_bn_rows_fwd")
+        ctx.save_for_backward(x, w_t, a, y, gamma, mean, invstd)
+        ctx.cfg = (pad, int(training), b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w_t, a, y, gamma, mean, invstd = ctx.saved_tensors
+        pad, training, has_bias = ctx.cfg
+        dy = _req(dy.contiguous(), "dy")
+        B, T, Ci = x.shape
+        K, Co, _ = w_t.shape
+        dev = x.device
+        ws = workspace(dev)
+        da = torch.empty_like(a)
+        dgamma = torch.empty(Co, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(Co, dtype=torch.float32, device=dev)
+        rc = lib().m3t_bn_rows_bwd(_p(dy), _p(a), _p(y), _p(gamma), _p(mean), _p(invstd), B * T, Co, training, 1, _p(da),
+                                   _p(dgamma), _p(dbeta), _p(ws), ws.numel() * 4, _stream())
+        _lib.check(rc, "m3t_bn_rows_bwd")
+        dx = torch.empty_like(x)
+        rc = lib().m3t_conv1d_fwd(_p(da), _p(w_t), None, None, None, _p(dx), None, B, T, Co, Ci, K, 1, pad, 0, 1, _stream())
+        _lib.check(rc, "m3t_conv1d_fwd (data gradient)")
+        dw_t = torch.empty_like(w_t)
+        rc = lib().m3t_conv1d_wgrad(_p(da), _p(x), _p(dw_t), B, T, Ci, Co, K, 1, pad, _p(ws), ws.numel() * 4, _stream())
+        _lib.check(rc, "m3t_conv1d_wgrad")
+        dw = transpose2d(dw_t.view(K, Co * Ci)).view(Co, Ci, K)
+        db = None
+        if has_bias:
+            db = torch.empty(Co, dtype=torch.float32, device=dev)
+            colsum(da, 0, B * T, Co, Co, db)
+        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None
+
+
+def simple_tcn(x_btc, seq):
+    """Run the reference's `tcn_simple` nn.Sequential(Conv1d, BatchNorm1d, ReLU, Conv1d, BatchNorm1d, ReLU)
+    (models/backbone.py:107-112, 214-222) on channel-last [B,T,C] activations with the HIP kernels; the
+    Sequential only holds the parameters/buffers (state_dict contract)."""
+    h = x_btc
+    for ci in (0, 3):
+        conv, bn = seq[ci], seq[ci + 1]
+        if conv.stride[0] != 1 or conv.dilation[0] != 1 or conv.groups != 1:
+            raise M3THipError("tcn_simple: only stride-1, undilated, ungrouped Conv1d is built")
+        training = bn.training or bn.running_mean is None
+        if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        mom = 0.1 if bn.momentum is None else bn.momentum
+        h = _ConvBnRelu.apply(h, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                              conv.padding[0], training, mom, bn.eps)
+    return h
 
 
 # ----------------------------------------------------------------------------- CBAM

@@ -103,7 +103,7 @@ class VA_3DVGGM(nn.Module):
             h = self.tcn[0].forward_btc(ops.bct_to_btc(feats))         # stays channel-last: no transpose back
             return ops.linear(h, self.tcn[1].weight, self.tcn[1].bias, 0)
         if self.backend == 'tcn_simple':
-            h = ops.bct_to_btc(self.tcn[0](feats))
+            h = ops.simple_tcn(ops.bct_to_btc(feats), self.tcn[0])      # Conv1d/BN1d/ReLU x2 on the HIP kernels
             return ops.linear(h, self.tcn[1].weight, self.tcn[1].bias, 0)
         if self.backend == 'fc':
             h = ops.bct_to_btc(feats)
@@ -167,8 +167,8 @@ class VA_3DVGGM_Split(nn.Module):
                 y_v, y_a = run_grus([self.gru_v, self.gru_a], [ops.bct_to_btc(x_v), ops.bct_to_btc(x_a)])
                 return torch.cat((y_v, y_a), dim=-1)
             if self.backend.startswith('tcn'):
-                h_v = ops.bct_to_btc(self.tcn_v[0](x_v))
-                h_a = ops.bct_to_btc(self.tcn_a[0](x_a))
+                h_v = ops.simple_tcn(ops.bct_to_btc(x_v), self.tcn_v[0])
+                h_a = ops.simple_tcn(ops.bct_to_btc(x_a), self.tcn_a[0])
                 y_v = ops.linear(h_v, self.tcn_v[1].weight, self.tcn_v[1].bias, 0)
                 y_a = ops.linear(h_a, self.tcn_a[1].weight, self.tcn_a[1].bias, 0)
                 return torch.cat((y_v, y_a), dim=-1)

@@ -294,6 +294,95 @@ def tcn_bwd(dy, caches, p, prefix="network."):
     return dy, grads
 
 
+# --------------------------------------------------------------------------- tcn_simple
+def conv1d_same_fwd(x, w, b, pad):
+    """nn.Conv1d(C_in, C_out, k, 1, pad) with 2*pad = k-1 (models/backbone.py:107,215:
+    Conv1d(.,.,3,1,1) / Conv1d(.,.,5,1,2)): y[b,co,t] = b[co] + sum_{ci,j} w[co,ci,j] x[b,ci,t+j-pad],
+    zero outside [0,T).  x [B,C_in,T] channel-first."""
+    B, Ci, T = x.shape
+    Co, _, K = w.shape
+    y = np.zeros((B, Co, T), x.dtype) + (0 if b is None else b[None, :, None])
+    for j in range(K):
+        o = j - pad                               # source time = t + o
+        lo, hi = max(0, -o), min(T, T - o)        # output times with the source inside the clip
+        if hi > lo:
+            y[:, :, lo:hi] += np.einsum("oc,bct->bot", w[:, :, j], x[:, :, lo + o:hi + o])
+    return y
+
+
+def conv1d_same_bwd(dy, x, w, pad):
+    B, Ci, T = x.shape
+    Co, _, K = w.shape
+    dx = np.zeros_like(x)
+    dw = np.zeros_like(w)
+    for j in range(K):
+        o = j - pad
+        lo, hi = max(0, -o), min(T, T - o)
+        if hi > lo:
+            dx[:, :, lo + o:hi + o] += np.einsum("oc,bot->bct", w[:, :, j], dy[:, :, lo:hi])
+            dw[:, :, j] = np.einsum("bot,bct->oc", dy[:, :, lo:hi], x[:, :, lo + o:hi + o])
+    return dx, dw, dy.sum(axis=(0, 2))
+
+
+def batchnorm1d_fwd(x, gamma, beta, run_mean, run_var, training, momentum=0.1, eps=1e-5):
+    """nn.BatchNorm1d on [B,C,T] (models/backbone.py:108,216): per-channel statistics over (B,T);
+    training: biased batch variance normalises, running stats take the unbiased one (torch
+    semantics).  Returns y, cache, (new_run_mean, new_run_var)."""
+    n = x.shape[0] * x.shape[2]
+    if training:
+        mu = x.mean(axis=(0, 2))
+        var = x.var(axis=(0, 2))
+        new_rm = (1 - momentum) * run_mean + momentum * mu
+        new_rv = (1 - momentum) * run_var + momentum * var * n / max(n - 1, 1)
+    else:
+        mu, var, new_rm, new_rv = run_mean, run_var, run_mean, run_var
+    invstd = 1.0 / np.sqrt(var + eps)
+    xh = (x - mu[None, :, None]) * invstd[None, :, None]
+    y = xh * gamma[None, :, None] + beta[None, :, None]
+    return y, (xh, invstd, gamma, training), (new_rm, new_rv)
+
+
+def batchnorm1d_bwd(dy, cache):
+    xh, invstd, gamma, training = cache
+    dbeta = dy.sum(axis=(0, 2))
+    dgamma = (dy * xh).sum(axis=(0, 2))
+    if training:
+        n = dy.shape[0] * dy.shape[2]
+        dx = (gamma * invstd)[None, :, None] * (dy - dbeta[None, :, None] / n - xh * dgamma[None, :, None] / n)
+    else:
+        dx = dy * (gamma * invstd)[None, :, None]
+    return dx, dgamma, dbeta
+
+
+def simple_tcn_fwd(x, p, pad, training, prefix=""):
+    """The `tcn_simple` back-end body (models/backbone.py:107-111 k=3 / 214-222 k=5):
+    Sequential(Conv1d, BatchNorm1d(512), ReLU, Conv1d, BatchNorm1d(512), ReLU); x [B,C,T].
+    Sequential indices: 0 conv, 1 bn, 3 conv, 4 bn.  Returns y, caches, {running-stat name: new value}."""
+    caches, stats = [], {}
+    for ci, bi in ((0, 1), (3, 4)):
+        w, b = p["%s%d.weight" % (prefix, ci)], p["%s%d.bias" % (prefix, ci)]
+        a = conv1d_same_fwd(x, w, b, pad)
+        z, bc, (rm, rv) = batchnorm1d_fwd(a, p["%s%d.weight" % (prefix, bi)], p["%s%d.bias" % (prefix, bi)],
+                                          p["%s%d.running_mean" % (prefix, bi)], p["%s%d.running_var" % (prefix, bi)],
+                                          training)
+        stats["%s%d.running_mean" % (prefix, bi)], stats["%s%d.running_var" % (prefix, bi)] = rm, rv
+        y = np.maximum(z, 0)
+        caches.append((x, w, z, bc))
+        x = y
+    return x, caches, stats
+
+
+def simple_tcn_bwd(dy, caches, pad, prefix=""):
+    g = {}
+    for (ci, bi), (x, w, z, bc) in zip(((3, 4), (0, 1)), caches[::-1]):
+        dz = dy * (z > 0)
+        da, dgam, dbet = batchnorm1d_bwd(dz, bc)
+        dy, dw, db = conv1d_same_bwd(da, x, w, pad)
+        g["%s%d.weight" % (prefix, bi)], g["%s%d.bias" % (prefix, bi)] = dgam, dbet
+        g["%s%d.weight" % (prefix, ci)], g["%s%d.bias" % (prefix, ci)] = dw, db
+    return dy, g
+
+
 # --------------------------------------------------------------------------- AttFusion
 def att_fuse_core_fwd(s_v, s_a, x_v, x_a):
     """The reduction of models/att_fusion.py:21-25 given the raw scorer outputs:

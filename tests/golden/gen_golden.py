@@ -100,6 +100,34 @@ def case_tcn(name, num_inputs, channels, k, B, T, seed):
          **pack_params(m), **pack_grads(m))
 
 
+def case_tcn_simple(name, which, in_dim, B, T, seed, training):
+    """The `tcn_simple` temporal back-end exactly as the reference builds and calls it:
+    which='split' -> VA_3DVGGM_Split.tcn_v (Conv1d k=5 pad=2, models/backbone.py:212-238,285-286),
+    which='vggm'  -> VA_3DVGGM.tcn (Conv1d k=3 pad=1, models/backbone.py:106-113,139-141).
+    BatchNorm1d(512) is hard-wired, so hiddenDim = 512; only this sub-module is filled and run."""
+    from models.backbone import VA_3DVGGM
+    rs = np.random.RandomState(seed)
+    if which == "split":
+        host = VA_3DVGGM_Split(inputDim=in_dim - 512, hiddenDim=512, backend="tcn_simple", split_layer=3,
+                               use_mtl=True, nClasses=8)
+        m = host.tcn_v
+    else:
+        host = VA_3DVGGM(inputDim=in_dim, hiddenDim=512, backend="tcn_simple")
+        m = host.tcn
+    fill_module(m, seed + 1)
+    m.train(training)
+    x = torch.from_numpy(draw(rs, (B, in_dim, T))).requires_grad_(True)
+    h = m[0](x)
+    y = m[1](h.transpose(1, 2).contiguous())
+    ct = torch.from_numpy(draw(rs, tuple(y.shape)))
+    (y * ct).sum().backward()
+    grads = {"gd." + n: grad_digest(p.grad.numpy()) for n, p in m.named_parameters() if p.grad is not None}
+    stats = {"rs." + n: b.detach().numpy().copy() for n, b in m.named_buffers() if b.dtype.is_floating_point}
+    save(name, seed=np.array(seed), dims=np.array([B, in_dim, T, int(training)]), x=x.detach().numpy(),
+         y=y.detach().numpy(), ct=ct.numpy(), dx=x.grad.numpy(), state_dict_keys=np.array(sorted(m.state_dict().keys())),
+         **grads, **stats)
+
+
 def case_attfusion(name, dims, hidden, B, T, seed):
     rs = np.random.RandomState(seed)
     m = fill_module(AttFusion(dims, hidden), seed + 1).eval()
@@ -419,6 +447,10 @@ def main():
         case_tcn("tcn_small", 8, [12, 12], 3, 2, 20, 200)
         case_tcn("tcn_k2_deep", 6, [6, 6, 6], 2, 3, 17, 210)
         case_tcn("tcn_short", 5, [7, 7, 7], 3, 2, 5, 220)      # T < receptive field
+    if want("tcn_simple"):
+        case_tcn_simple("tcn_simple_split_train", "split", 528, 3, 11, 230, True)
+        case_tcn_simple("tcn_simple_split_eval", "split", 528, 2, 3, 240, False)     # T < kernel
+        case_tcn_simple("tcn_simple_vggm_train", "vggm", 24, 2, 9, 250, True)
     if want("att"):
         case_attfusion("attfusion_same", [12, 12], 6, 3, 10, 300)
         case_attfusion("attfusion_proj", [12, 20], 6, 2, 9, 310)

@@ -103,6 +103,20 @@ def tcn_shapes(prefix, num_inputs, channels, k):
     return s
 
 
+def simple_tcn_shapes(in_dim, k, n_out, hidden=512):
+    """ModuleList([Sequential(Conv1d, BN1d, ReLU, Conv1d, BN1d, ReLU), Linear]) of the `tcn_simple`
+    back-end (reference models/backbone.py:106-113, 212-238); floating tensors only."""
+    s = {}
+    for ci, bi, cin in ((0, 1, in_dim), (3, 4, hidden)):
+        s["0.%d.weight" % ci] = (hidden, cin, k)
+        s["0.%d.bias" % ci] = (hidden,)
+        for leaf in ("weight", "bias", "running_mean", "running_var"):
+            s["0.%d.%s" % (bi, leaf)] = (hidden,)
+    s["1.weight"] = (n_out, hidden)
+    s["1.bias"] = (n_out,)
+    return s
+
+
 def att_fusion_shapes(prefix, dims, hidden):
     s = {}
     if dims[0] != dims[1]:

@@ -59,7 +59,7 @@ def check_digests(named_grads, g, tol=3e-4, prefix="gd."):
 
 # ------------------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("M,N,K", [(1, 1, 1), (33, 9, 17), (128, 128, 16), (300, 257, 130), (1024, 96, 2048), (64, 48, 9600),
-                                   (128, 128, 32), (256, 384, 512), (1152, 256, 4096)])   # last three: bf16x6 path
+                                   (128, 128, 32), (256, 384, 512), (1152, 256, 4096), (9600, 512, 1024)])   # last four: bf16x6 path
 @pytest.mark.parametrize("tA,tB", [(0, 1), (0, 0), (1, 0), (1, 1)])
 def test_sgemm(M, N, K, tA, tB):
     from m3t import ops
@@ -175,6 +175,61 @@ def test_tcn_golden(name):
     (y * dev(g["ct"])).sum().backward()
     close(x.grad, g["dx"], TOL, "dx")
     check_grads(m, g)
+
+
+@pytest.mark.parametrize("name,which,k,n_out", [("tcn_simple_split_train", "split", 5, 7),
+                                                 ("tcn_simple_split_eval", "split", 5, 7),
+                                                 ("tcn_simple_vggm_train", "vggm", 3, 2)])
+def test_tcn_simple_golden(name, which, k, n_out):
+    """`tcn_simple` back-end (Conv1d same-padding + BatchNorm1d + ReLU twice, Linear) against the reference's own
+    module in train and eval mode, called the way models/backbone.py:139-141 / 285-286 call it."""
+    from models.backbone import VA_3DVGGM, VA_3DVGGM_Split
+    from m3t import ops
+    g = load_golden(name)
+    B, in_dim, T, training = [int(v) for v in g["dims"]]
+    if which == "split":
+        host = VA_3DVGGM_Split(inputDim=in_dim - 512, hiddenDim=512, backend="tcn_simple", split_layer=3, use_mtl=True,
+                               nClasses=8)
+        m = host.tcn_v
+    else:
+        host = VA_3DVGGM(inputDim=in_dim, hiddenDim=512, backend="tcn_simple")
+        m = host.tcn
+    assert sorted(m.state_dict().keys()) == list(g["state_dict_keys"])
+    fill_module(m, int(g["seed"]) + 1)
+    m = m.to(DEV).train(bool(training))
+    x = dev(g["x"], True)
+    y = ops.linear(ops.simple_tcn(ops.bct_to_btc(x), m[0]), m[1].weight, m[1].bias, 0)
+    close(y, g["y"], TOL, "y")
+    (y * dev(g["ct"])).sum().backward()
+    close(x.grad, g["dx"], TOL, "dx")
+    for n, b in m.named_buffers():
+        if b.dtype.is_floating_point:
+            close(b, g["rs." + n], TOL, n)
+    assert int(m[0][1].num_batches_tracked) == int(training)
+    check_digests([(n, prm.grad) for n, prm in m.named_parameters()], g)
+
+
+def test_tcn_simple_vs_oracle_full_width():
+    """Conv1d(1024,512,5,1,2)+BN+ReLU x2 at B=8 x T=300 (the v2p_split back-end's width) against the numpy oracle."""
+    import torch.nn as nn
+    from m3t import ops
+    rs = np.random.RandomState(21)
+    seq = nn.Sequential(nn.Conv1d(1024, 512, 5, 1, 2), nn.BatchNorm1d(512), nn.ReLU(True),
+                        nn.Conv1d(512, 512, 5, 1, 2), nn.BatchNorm1d(512), nn.ReLU(True))
+    fill_module(seq, 22).to(DEV).train()
+    p = {n: t.detach().cpu().numpy().astype(np.float64) for n, t in list(seq.named_parameters()) + list(seq.named_buffers())}
+    xn, ct = draw(rs, (8, 1024, 300)), draw(rs, (8, 512, 300))
+    y_ref, caches, stats = O.simple_tcn_fwd(xn.astype(np.float64), p, 2, True)
+    dx_ref, g_ref = O.simple_tcn_bwd(ct.astype(np.float64), caches, 2)
+    x = dev(xn, True)
+    y = ops.btc_to_bct(ops.simple_tcn(ops.bct_to_btc(x), seq))
+    close(y, y_ref, TOL, "y")
+    (y * dev(ct)).sum().backward()
+    close(x.grad, dx_ref, 2e-4, "dx")
+    for n, prm in seq.named_parameters():
+        close(prm.grad, g_ref[n], 3e-4, n)
+    for n, v in stats.items():
+        close(dict(seq.named_buffers())[n], v, TOL, n)
 
 
 def test_tcn_vs_oracle_full_width():

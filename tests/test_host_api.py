@@ -18,7 +18,7 @@ from golden.recipe import c3_param_shapes, gru_shapes, tcn_shapes, att_fusion_sh
 def _header_symbols():
     txt = open(os.path.join(ROOT, "include", "m3t_hip.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\bint\s+(m3t_\w+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(?:int|size_t)\s+(m3t_\w+)\s*\(", txt)))
 
 
 def test_library_exports_every_header_symbol():

@@ -60,6 +60,33 @@ def test_tcn(name):
         close(grads[k], ref[k], what=k)
 
 
+@pytest.mark.parametrize("name,k,n_out", [("tcn_simple_split_train", 5, 7), ("tcn_simple_split_eval", 5, 7),
+                                           ("tcn_simple_vggm_train", 3, 2)])
+def test_tcn_simple(name, k, n_out):
+    """tcn_simple back-end (Conv1d same-padding + BatchNorm1d + ReLU, twice, then Linear) against the
+    reference module run in train and eval mode; weights regenerated from the frozen recipe."""
+    from golden.recipe import fill_by_shapes, simple_tcn_shapes, grad_digest
+    g = load_golden(name)
+    B, in_dim, T, training = [int(v) for v in g["dims"]]
+    shapes = simple_tcn_shapes(in_dim, k, n_out)
+    assert sorted(list(shapes) + ["0.1.num_batches_tracked", "0.4.num_batches_tracked"]) == list(g["state_dict_keys"])
+    p = {n: v.astype(np.float64) for n, v in fill_by_shapes(shapes, int(g["seed"]) + 1).items()}
+    h, caches, stats = O.simple_tcn_fwd(g["x"].astype(np.float64), p, (k - 1) // 2, bool(training), prefix="0.")
+    y = O.linear_fwd(h.transpose(0, 2, 1), p["1.weight"], p["1.bias"])
+    close(y, g["y"], what="y")
+    for n, v in stats.items():
+        close(v, g["rs." + n], what=n)
+    dh, dw, db = O.linear_bwd(g["ct"].astype(np.float64), h.transpose(0, 2, 1), p["1.weight"])
+    dx, grads = O.simple_tcn_bwd(dh.transpose(0, 2, 1), caches, (k - 1) // 2, prefix="0.")
+    close(dx, g["dx"], what="dx")
+    grads["1.weight"], grads["1.bias"] = dw, db
+    assert set("gd." + n for n in grads) == set(kk for kk in g if kk.startswith("gd."))
+    for n, v in grads.items():
+        ref, got = g["gd." + n], grad_digest(v)
+        assert abs(got[0] - ref[0]) <= 5e-5 * max(1.0, ref[0]), (n, got[0], ref[0])
+        close(got[2:], ref[2:], tol=5e-5, what=n)
+
+
 @pytest.mark.parametrize("name", ["attfusion_same", "attfusion_proj"])
 def test_att_fusion(name):
     g = load_golden(name)
