@@ -110,6 +110,10 @@ def main():
     # (all ranks on cuda:0, gloo all-reduce); the real multi-GPU run uses RCCL ("nccl"), one GPU per rank.
     backend = os.environ.get("M3T_BENCH_BACKEND", "nccl")
     dev_index = 0 if os.environ.get("M3T_BENCH_ONE_DEVICE") == "1" else local_rank
+    if os.environ.get("M3T_BENCH_ONE_DEVICE") == "1" and world > 1:
+        # several processes on ONE device: persistent scan launches of different processes could each hold part of the
+        # chip while waiting for the rest of their grid -- take the launch-per-step scans (include/m3t_hip.h)
+        os.environ["M3T_SCAN_PERSIST"] = "0"
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     if world > 1:

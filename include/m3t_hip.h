@@ -28,6 +28,8 @@ extern "C" {
 
 #define M3T_EINVAL 10001
 #define M3T_MAX_SCANS 8
+#define M3T_ESPIN 10002          /* a persistent scan gave up waiting for a peer workgroup (see m3t_gru_scan_fwd) */
+#define M3T_SCAN_NO_PERSIST 1    /* m3t_gru_scan_* flags: take the launch-per-step path */
 /* m3t_sgemm flags: BACKGROUND caps residency at one workgroup per CU (for GEMMs that run on a side stream
  * beside the latency-critical recurrence, e.g. weight gradients) */
 #define M3T_GEMM_BACKGROUND 1
@@ -83,11 +85,17 @@ typedef struct {
     int H, reverse, ldx, xoff, ldo, ooff;
 } m3t_gru_fwd_desc;
 
-/* ws (optional, 16-B aligned): scratch for the fragment-ordered fast path -- per scan 3*H*H floats of re-laid
- * weights + 2 * ceil32(B) * H floats of ping-pong state; without it (or when H % 16 != 0) a slower kernel that
- * reads the row-major operands directly is used.  Results are identical either way. */
+/* ws (optional, 16-B aligned): scratch for the fragment-ordered fast paths -- per scan 3*H*H floats of re-laid
+ * weights + 4 * ceil32(B) * H floats of ping-pong state / exchange granules; without it (or when H % 16 != 0) a
+ * slower kernel that reads the row-major operands directly is used.  Results are identical on every path.
+ * Execution: when every H of the level is a multiple of 128 (<= 512) and the level fits the chip at one workgroup
+ * per CU, ONE persistent launch runs all T steps (W_hh held in registers, h_t exchanged between CUs through tagged
+ * granules); otherwise one launch per time step.  A persistent launch needs all its workgroups resident: never run
+ * two of them concurrently on one device (flags = M3T_SCAN_NO_PERSIST for scans issued on a side stream; env
+ * M3T_SCAN_PERSIST=0 disables globally).  Its waits are bounded: if one expires the scan's results are invalid and
+ * the NEXT m3t_gru_scan_* call returns M3T_ESPIN. */
 int m3t_gru_scan_fwd(const m3t_gru_fwd_desc* scans, int n_scans, int B, int T,
-                     float* ws, size_t ws_bytes, void* stream);
+                     float* ws, size_t ws_bytes, int flags, void* stream);
 
 /* BPTT of the scans above (autograd of nn.GRU).  Per scan:
  *   dgx[B,T,ldg][goff..goff+3H) = grad wrt xproj  = (dr~, dz~, dn~)
@@ -106,9 +114,16 @@ typedef struct {
     int H, reverse, ldo, ooff, ldg, goff;
 } m3t_gru_bwd_desc;
 
-/* ws as above: per scan 3*H*H + 2 * ceil32(B) * 3H floats. */
+/* Number of persistent scan launches this process has issued so far (tests use it to assert which path ran). */
+int m3t_gru_persist_count(void);
+/* With env M3T_SCAN_PROF=1: s_memtime cycles that workgroup 0 / lane 0 of the LAST persistent launch spent per phase,
+ * summed over its T steps: [0] step top, [1] gather (wait for peers), [2] MFMA + LDS partials, [3] barrier,
+ * [4] reduce + gate math + publish, [5] stores.  Synchronises the device.  M3T_EINVAL when profiling is off. */
+int m3t_gru_persist_profile(unsigned long long* out6);
+
+/* ws as above: per scan 3*H*H + 8 * ceil32(B) * H floats; flags as above. */
 int m3t_gru_scan_bwd(const m3t_gru_bwd_desc* scans, int n_scans, int B, int T,
-                     float* ws, size_t ws_bytes, void* stream);
+                     float* ws, size_t ws_bytes, int flags, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * Attention-fusion reduction (models/att_fusion.py:21-25) on [B*T] frames of D floats:

@@ -13,27 +13,14 @@
 // Backward runs the same structure in reverse time: dh_{t} = dout_t + z_{t+1} dh_{t+1}
 // + dgh_{t+1} W_hh, with the matmul of step t+1 and the gate derivative of step t fused
 // in one launch; dW_hh / dW_ih / dx are left to big GEMMs after the scan.
-#include "common.h"
+#include "gru_common.h"
+
+using namespace m3t_gru;
 
 namespace {
 
-constexpr int UB = 16;        // hidden units per workgroup
-constexpr int RB = 32;        // batch rows per workgroup
-constexpr int NW = 8;         // waves per workgroup (512 threads): K is split 8 ways
-constexpr int NT = NW * 64;
 constexpr int CF = 4;         // k-chunks (16 wide) a wave keeps in flight, forward  (covers H  <= 512 in one pass)
 constexpr int CB = 12;        // k-chunks a wave keeps in flight, backward            (covers 3H <= 1536 in one pass)
-
-struct FwdGroup {
-    m3t_gru_fwd_desc d[M3T_MAX_SCANS];
-    int blk_start[M3T_MAX_SCANS + 1];
-    int n;
-};
-struct BwdGroup {
-    m3t_gru_bwd_desc d[M3T_MAX_SCANS];
-    int blk_start[M3T_MAX_SCANS + 1];
-    int n;
-};
 
 __device__ __forceinline__ float4 ld4(const float* __restrict__ p, int nvalid, bool vec) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -130,12 +117,6 @@ __global__ void wfrag_bwd_prep_kernel(const float* __restrict__ w_hh_t, float* _
     }
 }
 
-struct FragPtrs {
-    float* wfrag[M3T_MAX_SCANS];    // fragment-ordered weights
-    float* xfrag[M3T_MAX_SCANS];    // 2 ping-pong buffers of fragment-ordered h_t (fwd) / dgh_t (bwd)
-    size_t xstride[M3T_MAX_SCANS];  // floats per ping-pong buffer
-};
-
 // NC = chunks per wave kept in flight; CT = column tiles; RT = row tiles.
 // A frag: [chunk][RT row tiles][64][4]; B frag: [chunk][CT][64][4]
 template <int CT, int NC, int RT>
@@ -227,10 +208,8 @@ __global__ __launch_bounds__(NT) void gru_step_fwd_frag_kernel(FwdGroup g, FragP
             hn += red[w][2][prow][pu];
         }
     }
-    const float r = 1.f / (1.f + expf(-(xr + hr)));
-    const float z = 1.f / (1.f + expf(-(xz + hz)));
-    const float n = tanhf(xn + r * hn);
-    const float h = n + z * (hprev - n);
+    const GateFwd c = gru_cell_fwd(xr, xz, xn, hr, hz, hn, hprev);
+    const float r = c.r, z = c.z, n = c.n, h = c.h;
     // fragment-ordered copy for the next step: chunk == ub, tile = prow>>4, lane = (pu>>2)*16 + (prow&15), e = pu&3
     hout[(((size_t)ub * RT + (prow >> 4)) * 64 + (pu >> 2) * 16 + (prow & 15)) * 4 + (pu & 3)] = pok ? h : 0.f;
     if (!pok) return;
@@ -291,27 +270,23 @@ __global__ __launch_bounds__(NT) void gru_step_bwd_frag_kernel(BwdGroup g, FragP
     }
     __syncthreads();
     if (!pw) return;
-    float carry = dhn;
+    float mm = 0.f;
     if (has_next) {
-        float mm = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) mm += red[w][prow][pu];
-        carry = dhn * zn + mm;
     }
-    const float dht = dout + carry;
-    const float dn = dht * (1.f - gz) * (1.f - gn * gn);
-    const float dz = dht * (hprev - gn) * gz * (1.f - gz);
-    const float dr = dn * ghn * gr * (1.f - gr);
+    const GateBwd c = gru_cell_bwd(dout, dhn, zn, mm, has_next, gr, gz, gn, ghn, hprev);
+    const float dht = c.dht, dn = c.dn, dz = c.dz, dr = c.dr;
     // fragment-ordered dgh for the next launch: gate g lives in chunk g*(H/16) + ub
     const size_t fo = ((size_t)(prow >> 4) * 64 + (pu >> 2) * 16 + (prow & 15)) * 4 + (pu & 3);
     gout[((size_t)(0 * nchh + ub) * RT) * 256 + fo] = pok ? dr : 0.f;
     gout[((size_t)(1 * nchh + ub) * RT) * 256 + fo] = pok ? dz : 0.f;
-    gout[((size_t)(2 * nchh + ub) * RT) * 256 + fo] = pok ? dn * gr : 0.f;
+    gout[((size_t)(2 * nchh + ub) * RT) * 256 + fo] = pok ? c.dnr : 0.f;
     if (!pok) return;
     float* gx = d.dgx + ((size_t)pb * T + t) * d.ldg + d.goff;
     gx[pj] = dr; gx[H + pj] = dz; gx[2 * H + pj] = dn;
     float* gh = d.dgh + ((size_t)pb * T + t) * H3;
-    gh[pj] = dr; gh[H + pj] = dz; gh[2 * H + pj] = dn * gr;
+    gh[pj] = dr; gh[H + pj] = dz; gh[2 * H + pj] = c.dnr;
     d.dh[(size_t)pb * H + pj] = dht;
 }
 
@@ -384,10 +359,8 @@ __global__ __launch_bounds__(NT) void gru_step_fwd_kernel(FwdGroup g, int B, int
         }
     }
     hr += br; hz += bz; hn += bn;
-    const float r = 1.f / (1.f + expf(-(xr + hr)));
-    const float z = 1.f / (1.f + expf(-(xz + hz)));
-    const float n = tanhf(xn + r * hn);
-    const float h = n + z * (hprev - n);
+    const GateFwd c = gru_cell_fwd(xr, xz, xn, hr, hz, hn, hprev);
+    const float r = c.r, z = c.z, n = c.n, h = c.h;
     d.out[((size_t)pb * T + t) * d.ldo + d.ooff + pj] = h;
     if (d.gates) {
         float* gp = d.gates + ((size_t)pb * T + t) * 4 * H;
@@ -453,21 +426,17 @@ __global__ __launch_bounds__(NT) void gru_step_bwd_kernel(BwdGroup g, int B, int
     }
     __syncthreads();
     if (!pok) return;
-    float carry = dhn;                       // has_next: dL/dh_{tn} total; else grad wrt the final hidden state
+    float mm = 0.f;                          // has_next: dhn is dL/dh_{tn} total; else grad wrt the final hidden state
     if (has_next) {
-        float mm = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) mm += red[w][prow][pu];
-        carry = dhn * zn + mm;
     }
-    const float dht = dout + carry;
-    const float dn = dht * (1.f - gz) * (1.f - gn * gn);
-    const float dz = dht * (hprev - gn) * gz * (1.f - gz);
-    const float dr = dn * ghn * gr * (1.f - gr);
+    const GateBwd c = gru_cell_bwd(dout, dhn, zn, mm, has_next, gr, gz, gn, ghn, hprev);
+    const float dht = c.dht, dn = c.dn, dz = c.dz, dr = c.dr;
     float* gx = d.dgx + ((size_t)pb * T + t) * d.ldg + d.goff;
     gx[pj] = dr; gx[H + pj] = dz; gx[2 * H + pj] = dn;
     float* gh = d.dgh + ((size_t)pb * T + t) * H3;
-    gh[pj] = dr; gh[H + pj] = dz; gh[2 * H + pj] = dn * gr;
+    gh[pj] = dr; gh[H + pj] = dz; gh[2 * H + pj] = c.dnr;
     d.dh[(size_t)pb * H + pj] = dht;
 }
 
@@ -580,6 +549,15 @@ ScanPlan plan_level(const int* Hs, int n, int B) {
     return p;
 }
 
+// floats reserved per scan for the per-step ping-pong state fragments; large enough for the persistent exchange
+// granules too (8 B per h value forward, 16 B per (row, unit) backward), so either path can use the region
+size_t xfrag_floats(int H, int B, bool backward) {
+    const size_t bpad = (size_t)cdiv(B, RB) * RB;
+    const size_t step = 2 * bpad * (size_t)H * (backward ? 3 : 1);
+    const size_t ex = (persist_exchange_bytes(H, B, backward) + 3) / 4;
+    return ((step > ex ? step : ex) + 3) & ~(size_t)3;
+}
+
 template <typename G>
 std::vector<unsigned char> make_key(int kind, const G& g, const FragPtrs* fp, int B, int T, int variant) {
     std::vector<unsigned char> k(sizeof(int) * 4 + sizeof(G) + (fp ? sizeof(FragPtrs) : 0));
@@ -594,8 +572,9 @@ std::vector<unsigned char> make_key(int kind, const G& g, const FragPtrs* fp, in
 }  // namespace
 
 extern "C" int m3t_gru_scan_fwd(const m3t_gru_fwd_desc* scans, int n_scans, int B, int T, float* ws, size_t ws_bytes,
-                                void* stream) {
+                                int flags, void* stream) {
     if (n_scans <= 0 || B <= 0 || T <= 0) return 0;
+    if (persist_poll_error()) return M3T_ESPIN;
     if (n_scans > M3T_MAX_SCANS || !scans) return M3T_EINVAL;
     FwdGroup g;
     std::memset(&g, 0, sizeof(g));
@@ -624,7 +603,7 @@ extern "C" int m3t_gru_scan_fwd(const m3t_gru_fwd_desc* scans, int n_scans, int 
     for (int i = 0; i < n_scans; ++i) {
         Hs[i] = scans[i].H;
         frag = frag && scans[i].H % 16 == 0;
-        need += (size_t)3 * scans[i].H * scans[i].H + 2 * bpad * scans[i].H;
+        need += (size_t)3 * scans[i].H * scans[i].H + xfrag_floats(scans[i].H, B, false);
     }
     if (frag && need * sizeof(float) <= ws_bytes) {
         const ScanPlan plan = plan_level(Hs, n_scans, B);
@@ -642,9 +621,20 @@ extern "C" int m3t_gru_scan_fwd(const m3t_gru_fwd_desc* scans, int n_scans, int 
             fg.blk_start[i] = nblk;
             nblk += (d.H / 16) * nrb;
             fp.wfrag[i] = p; p += (size_t)3 * d.H * d.H;
-            fp.xfrag[i] = p; fp.xstride[i] = bpad * d.H; p += 2 * bpad * d.H;
+            fp.xfrag[i] = p; fp.xstride[i] = bpad * d.H; p += xfrag_floats(d.H, B, false);
         }
         for (int i = n_scans; i <= M3T_MAX_SCANS; ++i) fg.blk_start[i] = nblk;
+        if (!(flags & M3T_SCAN_NO_PERSIST) && persist_fwd_check(fg, B, T)) {
+            // one launch for all T steps: W_hh in registers, h_t exchanged through tagged granules (gru_persist.hip)
+            for (int i = 0; i < n_scans; ++i) {
+                const int H = fg.d[i].H;
+                int blk = (3 * H * H + 255) / 256;
+                if (blk > 1024) blk = 1024;
+                wfrag_fwd_prep_kernel<<<blk, 256, 0, s>>>(fg.d[i].w_hh, fp.wfrag[i], H);
+            }
+            M3T_LAUNCH_CHECK();
+            return persist_fwd_launch(fg, fp, B, T, s);
+        }
         return replay_or_capture(make_key(1, fg, &fp, B, T, rt), s, [&]() {
             for (int i = 0; i < n_scans; ++i) {
                 const int H = fg.d[i].H;
@@ -667,8 +657,9 @@ extern "C" int m3t_gru_scan_fwd(const m3t_gru_fwd_desc* scans, int n_scans, int 
 }
 
 extern "C" int m3t_gru_scan_bwd(const m3t_gru_bwd_desc* scans, int n_scans, int B, int T, float* ws, size_t ws_bytes,
-                                void* stream) {
+                                int flags, void* stream) {
     if (n_scans <= 0 || B <= 0 || T <= 0) return 0;
+    if (persist_poll_error()) return M3T_ESPIN;
     if (n_scans > M3T_MAX_SCANS || !scans) return M3T_EINVAL;
     BwdGroup g;
     std::memset(&g, 0, sizeof(g));
@@ -696,7 +687,7 @@ extern "C" int m3t_gru_scan_bwd(const m3t_gru_bwd_desc* scans, int n_scans, int 
     for (int i = 0; i < n_scans; ++i) {
         Hs[i] = scans[i].H;
         frag = frag && scans[i].H % 16 == 0;
-        need += (size_t)3 * scans[i].H * scans[i].H + 2 * bpad * 3 * scans[i].H;
+        need += (size_t)3 * scans[i].H * scans[i].H + xfrag_floats(scans[i].H, B, true);
     }
     if (frag && need * sizeof(float) <= ws_bytes) {
         const ScanPlan plan = plan_level(Hs, n_scans, B);
@@ -714,9 +705,19 @@ extern "C" int m3t_gru_scan_bwd(const m3t_gru_bwd_desc* scans, int n_scans, int 
             bg.blk_start[i] = nblk;
             nblk += (d.H / 16) * nrb;
             fp.wfrag[i] = p; p += (size_t)3 * d.H * d.H;
-            fp.xfrag[i] = p; fp.xstride[i] = bpad * 3 * d.H; p += 2 * bpad * 3 * d.H;
+            fp.xfrag[i] = p; fp.xstride[i] = bpad * 3 * d.H; p += xfrag_floats(d.H, B, true);
         }
         for (int i = n_scans; i <= M3T_MAX_SCANS; ++i) bg.blk_start[i] = nblk;
+        if (!(flags & M3T_SCAN_NO_PERSIST) && persist_bwd_check(bg, B, T)) {
+            for (int i = 0; i < n_scans; ++i) {
+                const int H = bg.d[i].H;
+                int blk = (3 * H * H + 255) / 256;
+                if (blk > 1024) blk = 1024;
+                wfrag_bwd_prep_kernel<<<blk, 256, 0, s>>>(bg.d[i].w_hh_t, fp.wfrag[i], H);
+            }
+            M3T_LAUNCH_CHECK();
+            return persist_bwd_launch(bg, fp, B, T, s);
+        }
         return replay_or_capture(make_key(2, bg, &fp, B, T, rt), s, [&]() {
             for (int i = 0; i < n_scans; ++i) {
                 const int H = bg.d[i].H;

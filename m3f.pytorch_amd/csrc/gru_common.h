@@ -1,0 +1,70 @@
+// Types shared by the per-step (gru.hip) and persistent (gru_persist.hip) BiGRU scan kernels.
+#pragma once
+#include "common.h"
+
+namespace m3t_gru {
+
+constexpr int UB = 16;        // hidden units per workgroup
+constexpr int RB = 32;        // batch rows per workgroup (per-step fallback kernels)
+constexpr int NW = 8;         // waves per workgroup (512 threads): K is split 8 ways
+constexpr int NT = NW * 64;
+
+struct FwdGroup {
+    m3t_gru_fwd_desc d[M3T_MAX_SCANS];
+    int blk_start[M3T_MAX_SCANS + 1];
+    int n;
+};
+struct BwdGroup {
+    m3t_gru_bwd_desc d[M3T_MAX_SCANS];
+    int blk_start[M3T_MAX_SCANS + 1];
+    int n;
+};
+struct FragPtrs {
+    float* wfrag[M3T_MAX_SCANS];    // fragment-ordered weights
+    float* xfrag[M3T_MAX_SCANS];    // 2 ping-pong buffers of fragment-ordered h_t (fwd) / dgh_t (bwd)
+    size_t xstride[M3T_MAX_SCANS];  // floats per ping-pong buffer
+};
+
+// The cell arithmetic, shared by every scan kernel.  Contraction is pinned (explicit fmaf, fp contract off) so that the
+// per-step, fragment-ordered and persistent kernels give bit-identical results whatever hipcc fuses around them.
+struct GateFwd { float r, z, n, h; };
+__device__ __forceinline__ GateFwd gru_cell_fwd(float xr, float xz, float xn, float hr, float hz, float hn, float hprev) {
+#pragma clang fp contract(off)
+    GateFwd o;
+    o.r = 1.f / (1.f + expf(-(xr + hr)));
+    o.z = 1.f / (1.f + expf(-(xz + hz)));
+    o.n = tanhf(fmaf(o.r, hn, xn));
+    o.h = fmaf(o.z, hprev - o.n, o.n);          // (1-z)*n + z*h
+    return o;
+}
+// dh_next/z_next: dL/dh and update gate of the step processed before (time t+1 of a forward-direction scan);
+// mm = (dgh_{t+1} W_hh)[unit].  Returns dL/dh_t and the gate gradients (dnr = dn * r feeds W_hn).
+struct GateBwd { float dht, dr, dz, dn, dnr; };
+__device__ __forceinline__ GateBwd gru_cell_bwd(float dout, float dh_next, float z_next, float mm, bool has_next, float gr,
+                                                float gz, float gn, float ghn, float hprev) {
+#pragma clang fp contract(off)
+    GateBwd o;
+    const float carry = has_next ? fmaf(dh_next, z_next, mm) : dh_next;
+    o.dht = dout + carry;
+    o.dn = o.dht * (1.f - gz) * fmaf(-gn, gn, 1.f);
+    o.dz = o.dht * (hprev - gn) * gz * (1.f - gz);
+    o.dr = o.dn * ghn * gr * (1.f - gr);
+    o.dnr = o.dn * gr;
+    return o;
+}
+
+// Persistent scans (gru_persist.hip): one launch runs all T steps of a level.  *_check says whether the level is
+// eligible (H in {128,256,384,512}, the grid fits the chip at one workgroup per CU, M3T_SCAN_PERSIST != 0); *_launch
+// needs fp.wfrag already filled by the prep kernels (stream order) and uses fp.xfrag[i] as the exchange buffer
+// (persist_exchange_bytes() bytes each, 16-B aligned).
+size_t persist_exchange_bytes(int H, int B, bool backward);
+bool persist_enabled();
+int persist_poll_error();       // step+1 of a scan that hit its spin limit since the last poll, else 0
+bool persist_fwd_check(const FwdGroup& g, int B, int T);
+bool persist_bwd_check(const BwdGroup& g, int B, int T);
+int persist_fwd_launch(const FwdGroup& g, const FragPtrs& fp, int B, int T, hipStream_t s);
+int persist_bwd_launch(const BwdGroup& g, const FragPtrs& fp, int B, int T, hipStream_t s);
+int persist_launch_count();
+int persist_profile(unsigned long long* out6);
+
+}  // namespace m3t_gru

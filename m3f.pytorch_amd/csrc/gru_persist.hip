@@ -1,0 +1,550 @@
+// Persistent BiGRU scans for gfx950: ONE launch runs all T steps of a level.
+//
+// Why: in the launch-per-step structure (gru.hip) every step re-reads the workgroup's W_hh slice (96 KB at H = 512)
+// through a cold L2 and pays the kernel boundary; measured 6.1 / 6.9 us per step (fwd / bwd) at H = 512.  Here a
+// workgroup keeps its W_hh fragments in REGISTERS for the whole scan (48 VGPRs per lane) and only h_t (fwd) or
+// dgh_t (bwd) crosses CUs each step.
+//
+// The exchange (measured alone in tools/persist_probe.hip: 2.0-2.1 us per step for 32 producers -> 32 consumers,
+// 64-128 KB gathered per workgroup, no torn granule in 4e10): no grid barrier and no flags.  Every value travels in a
+// tagged granule written by ONE naturally aligned agent-scope (sc1, write-through) store and read by agent-scope
+// loads:  forward  8 B  {h, tag};   backward 16 B {dr, dz, dn*r, tag};   tag = step + 1, two slots ping-pong by step
+// parity (a producer can only overwrite slot p after every consumer of its group has finished reading it, because its
+// own next step needs all of their next granules).  A consumer simply re-reads its granules until all tags match.
+// Correctness never depends on placement; speed does a little: a group (one scan x one 16-row block, all unit
+// blocks) is mapped to blockIdx % G so that it sits on one XCD when G is a multiple of 8.
+//
+// Residency: every workgroup of the grid must be resident at once (the kernel is launched only when the grid fits the
+// CUs at the occupancy HIP reports, and never concurrently with another persistent scan: m3t.ops keeps them on the
+// main stream).  Every spin is bounded; a workgroup that gives up raises a sticky host-visible error word and the
+// scan finishes with garbage, which the next scan call reports as M3T_ESPIN.
+//
+// Arithmetic: the same fp32 MFMA 16x16x4 chain, k order, LDS reduction order and gate math as the per-step kernels,
+// so results are bit-identical to them (tests assert equality).
+#include "gru_common.h"
+#include <cstdlib>
+#include <cstring>
+
+namespace m3t_gru {
+
+namespace {
+
+constexpr int SPIN_LIMIT = 1 << 21;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct ExPtrs {
+    void* gran[M3T_MAX_SCANS];       // exchange granules: [2 slots][row block][unit block][RT*256]
+    size_t slot[M3T_MAX_SCANS];      // granules per slot
+    unsigned long long* prof;        // optional in-kernel stamps (M3T_SCAN_PROF=1): 8 phase sums of workgroup 0, wave 0
+};
+
+// phase stamps: s_memtime deltas accumulated by one lane; a uniform scalar branch when profiling is off
+#define M3T_STAMP(i)                                                         \
+    do {                                                                     \
+        if (stamp) { const long long now = clock64(); psum[i] += now - last; last = now; } \
+    } while (0)
+
+__device__ __forceinline__ void raise_spin(unsigned* err, int step) {
+    __hip_atomic_store(err, (unsigned)step + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Vector-memory operations of a wave retire in issue order, so the per-step order is chosen so that the gather's
+// vmcnt(0) never waits for an HBM miss: gather (loads only) -> wait -> [stores of the PREVIOUS step, prefetch of the
+// NEXT step's inputs] -> MFMA -> LDS partials -> barrier -> reduce + gate math -> publish.
+// The gather is inline asm (all loads of the pass in flight, one explicit wait) so that hipcc does not serialise it.
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int NC, int RT>      // NC = H / 128 = k-chunks per wave;  RT = 16-row tiles per workgroup
+__global__ __launch_bounds__(NT) void gru_persist_fwd_kernel(FwdGroup g, FragPtrs fp, ExPtrs ex, int B, int T, int G, int nrb,
+                                                             unsigned* err) {
+    constexpr int ROWS = 16 * RT;
+    constexpr int NB = RT == 1 ? 2 : 1;                // RT = 1: double-buffered by step parity, one barrier per step
+    constexpr int H = 128 * NC, nch = H >> 4;
+    __shared__ float red[NB][NW][3][ROWS][UB + 1];     // 51 KiB either way (static LDS limit 64 KiB); +1: conflict-free reads
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gid = (int)blockIdx.x % G, ub = (int)blockIdx.x / G;
+    const int s = gid / nrb, rb = gid % nrb;
+    const m3t_gru_fwd_desc d = g.d[s];
+    const int j0 = ub * UB, r0 = rb * ROWS;
+
+    // this workgroup's W_hh fragments stay in registers for all T steps
+    float4 wf[NC][3];
+    {
+        const float4* Wf = reinterpret_cast<const float4*>(fp.wfrag[s] + (size_t)ub * nch * 3 * 256);
+#pragma unroll
+        for (int m = 0; m < NC; ++m)
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct) wf[m][ct] = Wf[((size_t)(wave + m * NW) * 3 + ct) * 64 + lane];
+    }
+    // gate-math threads, one (row, unit) each, numbered in GRANULE order: thread i owns granule i of the workgroup's
+    // tile, so a wave publishes 64 consecutive granules = whole 128-B lines.  (A wave publishing 16 separate 32-B
+    // pieces -- the (row, unit) numbering of the per-step kernels -- doubles the exchange time: write-through partial
+    // lines, tools/persist_probe.hip.)  granule (rt*4 + e)*64 + l  <->  row rt*16 + (l & 15), unit 4*(l >> 4) + e
+    const bool pw = tid < ROWS * UB;
+    const int prow = (tid >> 8) * 16 + (tid & 15), pu = ((tid >> 4) & 3) * 4 + ((tid >> 6) & 3);
+    const int pb = r0 + prow, pj = j0 + pu;
+    const bool pok = pw && pb < B;
+    float br = 0.f, bz = 0.f, bn = 0.f, hprev = 0.f;
+    if (pw) { br = d.b_hh[pj]; bz = d.b_hh[H + pj]; bn = d.b_hh[2 * H + pj]; }
+
+    constexpr size_t TILE = (size_t)RT * 256;          // granules one workgroup publishes per step
+    unsigned long long* gran = reinterpret_cast<unsigned long long*>(ex.gran[s]);
+    const size_t slot = ex.slot[s];
+    const size_t grp = (size_t)rb * nch * TILE;
+    const size_t pub = grp + (size_t)ub * TILE + tid;
+    bool dead = false;
+    const bool stamp = ex.prof != nullptr && blockIdx.x == 0 && tid == 0;
+    long long psum[6] = {0, 0, 0, 0, 0, 0}, last = stamp ? clock64() : 0;
+
+    // x-projection rows of this thread's clip, one step ahead
+    const float* xrow = d.xproj + (size_t)pb * T * d.ldx + d.xoff + pj;
+    const ptrdiff_t xstep = d.reverse ? -(ptrdiff_t)d.ldx : (ptrdiff_t)d.ldx;
+    const float* xp = xrow + (d.reverse ? (size_t)(T - 1) * d.ldx : 0);
+    float xr = 0.f, xz = 0.f, xn = 0.f;
+    if (pok) { xr = xp[0]; xz = xp[H]; xn = xp[2 * H]; }
+    float s_r = 0.f, s_z = 0.f, s_n = 0.f, s_hn = 0.f;     // previous step's gates, stored one step late
+    // everything loaded so far is in registers before the loop: hipcc then places no vmcnt wait for the weight
+    // fragments inside the step (one there would also wait for the step's HBM prefetch and stores)
+    __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
+
+    for (int step = 0; step < T; ++step) {
+        const int t = d.reverse ? T - 1 - step : step;
+        M3T_STAMP(0);
+        f32x4 acc[RT][3];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        unsigned long long v[NC][RT][4];
+        if (step > 0) {
+            const unsigned tag = (unsigned)step;       // h_{step-1} carries tag (step-1)+1
+            const unsigned long long* src = gran + (size_t)((step - 1) & 1) * slot + grp + (size_t)wave * TILE + lane;
+            int spins = 0;
+            for (;;) {
+#pragma unroll
+                for (int m = 0; m < NC; ++m)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const unsigned long long* q = src + (size_t)m * NW * TILE + (rt * 4 + e) * 64;
+                            asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(v[m][rt][e]) : "v"(q) : "memory");
+                        }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                bool ok = true;
+#pragma unroll
+                for (int m = 0; m < NC; ++m)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            asm volatile("" : "+v"(v[m][rt][e]));          // defined only after the wait above
+                            ok = ok && ((unsigned)(v[m][rt][e] >> 32) == tag);
+                        }
+                if (__all(ok) || dead) break;
+                if (++spins > SPIN_LIMIT) { dead = true; if (lane == 0) raise_spin(err, step); break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        M3T_STAMP(1);
+        // off the chain: last step's results to HBM, next step's inputs from HBM
+        float nxr = 0.f, nxz = 0.f, nxn = 0.f;
+        if (pok) {
+            if (step > 0) {
+                const int tl = d.reverse ? t + 1 : t - 1;
+                d.out[((size_t)pb * T + tl) * d.ldo + d.ooff + pj] = hprev;
+                if (d.gates) {
+                    float* gp = d.gates + ((size_t)pb * T + tl) * 4 * H;
+                    gp[pj] = s_r; gp[H + pj] = s_z; gp[2 * H + pj] = s_n; gp[3 * H + pj] = s_hn;
+                }
+            }
+            if (step + 1 < T) {
+                xp += xstep;
+                nxr = xp[0]; nxz = xp[H]; nxn = xp[2 * H];
+            }
+        }
+        if (step > 0) {
+#pragma unroll
+            for (int m = 0; m < NC; ++m)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < 3; ++ct) {
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float((unsigned)v[m][rt][0]), wf[m][ct].x, acc[rt][ct], 0, 0, 0);
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float((unsigned)v[m][rt][1]), wf[m][ct].y, acc[rt][ct], 0, 0, 0);
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float((unsigned)v[m][rt][2]), wf[m][ct].z, acc[rt][ct], 0, 0, 0);
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float((unsigned)v[m][rt][3]), wf[m][ct].w, acc[rt][ct], 0, 0, 0);
+                    }
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[step & (NB - 1)][wave][ct][rt * 16 + (lane >> 4) * 4 + r][lane & 15] = acc[rt][ct][r];
+        }
+        M3T_STAMP(2);
+        __syncthreads();
+        M3T_STAMP(3);
+        if (pw) {
+            float hr = br, hz = bz, hn = bn;
+            if (step > 0) {
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    hr += red[step & (NB - 1)][w][0][prow][pu];
+                    hz += red[step & (NB - 1)][w][1][prow][pu];
+                    hn += red[step & (NB - 1)][w][2][prow][pu];
+                }
+            }
+            const GateFwd c = gru_cell_fwd(xr, xz, xn, hr, hz, hn, hprev);
+            const float r = c.r, z = c.z, n = c.n, h = c.h;
+            if (step + 1 < T) {                        // publish: the only store on the chain
+                const unsigned long long gq = ((unsigned long long)((unsigned)step + 1u) << 32) | __float_as_uint(pok ? h : 0.f);
+                __hip_atomic_store(gran + (size_t)(step & 1) * slot + pub, gq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            hprev = h; s_r = r; s_z = z; s_n = n; s_hn = hn;
+        }
+        M3T_STAMP(4);
+        xr = nxr; xz = nxz; xn = nxn;
+        if (NB == 1) __syncthreads();
+        M3T_STAMP(5);
+    }
+    if (pok) {                                         // the last step's results
+        const int tl = d.reverse ? 0 : T - 1;
+        d.out[((size_t)pb * T + tl) * d.ldo + d.ooff + pj] = hprev;
+        if (d.gates) {
+            float* gp = d.gates + ((size_t)pb * T + tl) * 4 * H;
+            gp[pj] = s_r; gp[H + pj] = s_z; gp[2 * H + pj] = s_n; gp[3 * H + pj] = s_hn;
+        }
+        if (d.h_n) d.h_n[(size_t)pb * H + pj] = hprev;
+    }
+    if (stamp)
+        for (int i = 0; i < 6; ++i) ex.prof[i] = (unsigned long long)psum[i];
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+template <int NC, int RT>
+__global__ __launch_bounds__(NT) void gru_persist_bwd_kernel(BwdGroup g, FragPtrs fp, ExPtrs ex, int B, int T, int G, int nrb,
+                                                             unsigned* err) {
+    constexpr int ROWS = 16 * RT;
+    constexpr int H = 128 * NC, H3 = 3 * H, nchh = H >> 4, nch = H3 >> 4;
+    __shared__ float red[2][NW][ROWS][UB + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gid = (int)blockIdx.x % G, ub = (int)blockIdx.x / G;
+    const int s = gid / nrb, rb = gid % nrb;
+    const m3t_gru_bwd_desc d = g.d[s];
+    const int j0 = ub * UB, r0 = rb * ROWS;
+
+    // W_hh^T fragments of this workgroup's 16 output units: chunk c = gate*nchh + (wave + 8m)
+    float4 wt[3][NC];
+    {
+        const float4* Wt = reinterpret_cast<const float4*>(fp.wfrag[s] + (size_t)ub * nch * 256);
+#pragma unroll
+        for (int gt = 0; gt < 3; ++gt)
+#pragma unroll
+            for (int m = 0; m < NC; ++m) wt[gt][m] = Wt[(size_t)(gt * nchh + wave + m * NW) * 64 + lane];
+    }
+    const bool pw = tid < ROWS * UB;                   // granule-order numbering, as in the forward kernel
+    const int prow = (tid >> 8) * 16 + (tid & 15), pu = ((tid >> 4) & 3) * 4 + ((tid >> 6) & 3);
+    const int pb = r0 + prow, pj = j0 + pu;
+    const bool pok = pw && pb < B;
+    float dh_carry = 0.f, z_next = 0.f;                // dh_{t+1} and z_{t+1} of this thread's (row, unit)
+    if (pok && d.dh_n) dh_carry = d.dh_n[(size_t)pb * H + pj];
+
+    constexpr size_t TILE = (size_t)RT * 256;
+    u32x4* gran = reinterpret_cast<u32x4*>(ex.gran[s]);
+    const size_t slot = ex.slot[s];
+    const size_t grp = (size_t)rb * nchh * TILE;
+    const size_t pub = grp + (size_t)ub * TILE + tid;
+    bool dead = false;
+    const bool stamp = ex.prof != nullptr && blockIdx.x == 0 && tid == 0;
+    long long psum[6] = {0, 0, 0, 0, 0, 0}, last = stamp ? clock64() : 0;
+
+    // this step's saved activations, one step ahead
+    float dout = 0.f, gr = 0.f, gz = 0.f, gn = 0.f, ghn = 0.f, hprev = 0.f;
+    auto load_step = [&](int step, float& o_dout, float& o_gr, float& o_gz, float& o_gn, float& o_ghn, float& o_hprev) {
+        const int t = d.reverse ? step : T - 1 - step;
+        const int tp = d.reverse ? t + 1 : t - 1;
+        o_dout = d.dout[((size_t)pb * T + t) * d.ldo + d.ooff + pj];
+        const float* gp = d.gates + ((size_t)pb * T + t) * 4 * H;
+        o_gr = gp[pj]; o_gz = gp[H + pj]; o_gn = gp[2 * H + pj]; o_ghn = gp[3 * H + pj];
+        o_hprev = step < T - 1 ? d.out[((size_t)pb * T + tp) * d.ldo + d.ooff + pj] : 0.f;
+    };
+    if (pok) load_step(0, dout, gr, gz, gn, ghn, hprev);
+    float s_dr = 0.f, s_dz = 0.f, s_dn = 0.f, s_dnr = 0.f;     // previous step's gate gradients, stored one step late
+    __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0): see the forward kernel
+
+    for (int step = 0; step < T; ++step) {
+        const int t = d.reverse ? step : T - 1 - step;
+        const bool has_next = step > 0;
+        M3T_STAMP(0);
+        f32x4 acc[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        u32x4 v[NC][RT][4];
+        if (has_next) {
+            const unsigned tag = (unsigned)step;
+            const u32x4* src = gran + (size_t)((step - 1) & 1) * slot + grp + (size_t)wave * TILE + lane;
+            int spins = 0;
+            for (;;) {
+#pragma unroll
+                for (int m = 0; m < NC; ++m)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const u32x4* q = src + (size_t)m * NW * TILE + (rt * 4 + e) * 64;
+                            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[m][rt][e]) : "v"(q) : "memory");
+                        }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                bool ok = true;
+#pragma unroll
+                for (int m = 0; m < NC; ++m)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            asm volatile("" : "+v"(v[m][rt][e]));          // defined only after the wait above
+                            ok = ok && (v[m][rt][e].w == tag);
+                        }
+                if (__all(ok) || dead) break;
+                if (++spins > SPIN_LIMIT) { dead = true; if (lane == 0) raise_spin(err, step); break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        M3T_STAMP(1);
+        float ndout = 0.f, ngr = 0.f, ngz = 0.f, ngn = 0.f, nghn = 0.f, nhprev = 0.f;
+        if (pok) {
+            if (has_next) {
+                const int tl = d.reverse ? t - 1 : t + 1;
+                float* gx = d.dgx + ((size_t)pb * T + tl) * d.ldg + d.goff;
+                gx[pj] = s_dr; gx[H + pj] = s_dz; gx[2 * H + pj] = s_dn;
+                float* gh = d.dgh + ((size_t)pb * T + tl) * H3;
+                gh[pj] = s_dr; gh[H + pj] = s_dz; gh[2 * H + pj] = s_dnr;
+            }
+            if (step + 1 < T) load_step(step + 1, ndout, ngr, ngz, ngn, nghn, nhprev);
+        }
+        if (has_next) {
+#pragma unroll
+            for (int gt = 0; gt < 3; ++gt)             // ascending chunk order gate*nchh + wave + 8m: as the per-step kernel
+#pragma unroll
+                for (int m = 0; m < NC; ++m)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[m][rt][0][gt]), wt[gt][m].x, acc[rt], 0, 0, 0);
+                        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[m][rt][1][gt]), wt[gt][m].y, acc[rt], 0, 0, 0);
+                        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[m][rt][2][gt]), wt[gt][m].z, acc[rt], 0, 0, 0);
+                        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[m][rt][3][gt]), wt[gt][m].w, acc[rt], 0, 0, 0);
+                    }
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[step & 1][wave][rt * 16 + (lane >> 4) * 4 + r][lane & 15] = acc[rt][r];
+        }
+        M3T_STAMP(2);
+        __syncthreads();
+        M3T_STAMP(3);
+        if (pw) {
+            float mm = 0.f;
+            if (has_next) {
+#pragma unroll
+                for (int w = 0; w < NW; ++w) mm += red[step & 1][w][prow][pu];
+            }
+            const GateBwd c = gru_cell_bwd(dout, dh_carry, z_next, mm, has_next, gr, gz, gn, ghn, hprev);
+            const float dht = c.dht, dn = c.dn, dz = c.dz, dr = c.dr;
+            if (step + 1 < T) {
+                u32x4 gq;
+                gq.x = __float_as_uint(pok ? dr : 0.f); gq.y = __float_as_uint(pok ? dz : 0.f);
+                gq.z = __float_as_uint(pok ? c.dnr : 0.f); gq.w = (unsigned)step + 1u;
+                u32x4* q = gran + (size_t)(step & 1) * slot + pub;
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(q), "v"(gq) : "memory");
+            }
+            dh_carry = dht; z_next = gz;
+            s_dr = dr; s_dz = dz; s_dn = dn; s_dnr = c.dnr;
+        }
+        M3T_STAMP(4);
+        dout = ndout; gr = ngr; gz = ngz; gn = ngn; ghn = nghn; hprev = nhprev;
+        M3T_STAMP(5);
+    }
+    if (pok) {
+        const int tl = d.reverse ? T - 1 : 0;
+        float* gx = d.dgx + ((size_t)pb * T + tl) * d.ldg + d.goff;
+        gx[pj] = s_dr; gx[H + pj] = s_dz; gx[2 * H + pj] = s_dn;
+        float* gh = d.dgh + ((size_t)pb * T + tl) * H3;
+        gh[pj] = s_dr; gh[H + pj] = s_dz; gh[2 * H + pj] = s_dnr;
+        d.dh[(size_t)pb * H + pj] = dh_carry;
+    }
+    if (stamp)
+        for (int i = 0; i < 6; ++i) ex.prof[i] = (unsigned long long)psum[i];
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+unsigned long long* g_prof = nullptr;   // device buffer of phase stamps when M3T_SCAN_PROF=1
+int g_launches = 0;                 // persistent launches issued by this process (m3t_gru_persist_count)
+unsigned* g_err_host = nullptr;     // host-mapped error word (device writes, host polls without a sync)
+unsigned* g_err_dev = nullptr;
+
+bool ensure_err_word() {
+    if (g_err_host) return true;
+    void* h = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return false; }
+    std::memset(h, 0, 64);
+    void* dptr = nullptr;
+    if (hipHostGetDevicePointer(&dptr, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); return false; }
+    g_err_host = static_cast<unsigned*>(h);
+    g_err_dev = static_cast<unsigned*>(dptr);
+    return true;
+}
+
+int device_cus() {
+    static int cus = -1;
+    if (cus < 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); cus = 0; }
+        else cus = prop.multiProcessorCount;
+    }
+    return cus;
+}
+
+// workgroups of `kernel` that can be resident at once, conservatively (the occupancy API can read one high near an
+// SGPR allocation edge -- MI355X_MICROARCH.md, "Residency and cooperative launch" -- so two per CU are only
+// assumed when it reports three)
+template <typename K>
+int resident_capacity(K kernel) {
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, NT, 0) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    const int per_cu = occ >= 3 ? 2 : (occ >= 1 ? 1 : 0);
+    return per_cu * device_cus();
+}
+
+struct Shape { int nc, rt, G, nrb, grid; };
+
+// every scan of the level has the same H = 128 * NC (NC = 1..4: the k-chunks per wave are compile-time, so the gather
+// and the MFMA chain are straight-line code); RT = 1 when the 16-row grid fits one workgroup per CU, else 2
+template <typename D>
+bool level_shape(const D* d, int n, int B, Shape& sh) {
+    const int maxh = d[0].H;
+    if (maxh % 128 != 0 || maxh > 512) return false;
+    for (int i = 1; i < n; ++i)
+        if (d[i].H != maxh) return false;
+    sh.nc = maxh / 128;
+    sh.rt = 0;
+    for (int rt = 1; rt <= 2; ++rt) {
+        const int nrb = cdiv(B, 16 * rt), G = n * nrb, grid = G * (maxh / 16);
+        if (grid <= device_cus()) { sh.rt = rt; sh.nrb = nrb; sh.G = G; sh.grid = grid; break; }
+    }
+    return sh.rt != 0;
+}
+
+typedef void (*FwdKernel)(FwdGroup, FragPtrs, ExPtrs, int, int, int, int, unsigned*);
+typedef void (*BwdKernel)(BwdGroup, FragPtrs, ExPtrs, int, int, int, int, unsigned*);
+
+FwdKernel pick_fwd(const Shape& sh) {
+    static const FwdKernel k[2][4] = {
+        {gru_persist_fwd_kernel<1, 1>, gru_persist_fwd_kernel<2, 1>, gru_persist_fwd_kernel<3, 1>, gru_persist_fwd_kernel<4, 1>},
+        {gru_persist_fwd_kernel<1, 2>, gru_persist_fwd_kernel<2, 2>, gru_persist_fwd_kernel<3, 2>, gru_persist_fwd_kernel<4, 2>}};
+    return k[sh.rt - 1][sh.nc - 1];
+}
+BwdKernel pick_bwd(const Shape& sh) {
+    static const BwdKernel k[2][4] = {
+        {gru_persist_bwd_kernel<1, 1>, gru_persist_bwd_kernel<2, 1>, gru_persist_bwd_kernel<3, 1>, gru_persist_bwd_kernel<4, 1>},
+        {gru_persist_bwd_kernel<1, 2>, gru_persist_bwd_kernel<2, 2>, gru_persist_bwd_kernel<3, 2>, gru_persist_bwd_kernel<4, 2>}};
+    return k[sh.rt - 1][sh.nc - 1];
+}
+
+template <typename G>
+void fill_exchange(const G& g, const FragPtrs& fp, const Shape& sh, size_t gran_bytes, ExPtrs& ex, size_t (&bytes)[M3T_MAX_SCANS]) {
+    std::memset(&ex, 0, sizeof(ex));
+    static int prof_on = -1;
+    if (prof_on < 0) {
+        const char* e = std::getenv("M3T_SCAN_PROF");
+        prof_on = (e && e[0] == '1') ? 1 : 0;
+        if (prof_on && hipMalloc(reinterpret_cast<void**>(&g_prof), 64) != hipSuccess) { (void)hipGetLastError(); g_prof = nullptr; }
+    }
+    ex.prof = g_prof;
+    for (int i = 0; i < g.n; ++i) {
+        ex.gran[i] = fp.xfrag[i];
+        ex.slot[i] = (size_t)sh.nrb * (g.d[i].H / 16) * sh.rt * 256;
+        bytes[i] = 2 * ex.slot[i] * gran_bytes;
+    }
+}
+
+}  // namespace
+
+bool persist_enabled() {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = std::getenv("M3T_SCAN_PERSIST");
+        on = (e && e[0] == '0') ? 0 : 1;
+    }
+    return on == 1;
+}
+
+int persist_poll_error() {
+    if (!g_err_host) return 0;
+    return (int)__atomic_exchange_n(g_err_host, 0u, __ATOMIC_RELAXED);
+}
+
+size_t persist_exchange_bytes(int H, int B, bool backward) {
+    const size_t rows = (size_t)cdiv(B, 32) * 32;       // covers the RT = 1 and RT = 2 row blocking
+    return 2 * rows * (size_t)H * (backward ? 16 : 8);
+}
+
+bool persist_fwd_check(const FwdGroup& g, int B, int T) {
+    Shape sh;
+    return persist_enabled() && T >= 2 && level_shape(g.d, g.n, B, sh) && ensure_err_word() &&
+           sh.grid <= resident_capacity(pick_fwd(sh));
+}
+
+bool persist_bwd_check(const BwdGroup& g, int B, int T) {
+    Shape sh;
+    return persist_enabled() && T >= 2 && level_shape(g.d, g.n, B, sh) && ensure_err_word() &&
+           sh.grid <= resident_capacity(pick_bwd(sh));
+}
+
+int persist_fwd_launch(const FwdGroup& g, const FragPtrs& fp, int B, int T, hipStream_t s) {
+    Shape sh;
+    if (!level_shape(g.d, g.n, B, sh) || !ensure_err_word()) return M3T_EINVAL;
+    ExPtrs ex;
+    size_t bytes[M3T_MAX_SCANS];
+    fill_exchange(g, fp, sh, 8, ex, bytes);
+    for (int i = 0; i < g.n; ++i) {
+        const hipError_t e = hipMemsetAsync(ex.gran[i], 0, bytes[i], s);     // no stale tag may match
+        if (e != hipSuccess) return (int)e;
+    }
+    ++g_launches;
+    hipLaunchKernelGGL(pick_fwd(sh), dim3(sh.grid), dim3(NT), 0, s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
+    M3T_LAUNCH_CHECK();
+    return 0;
+}
+
+int persist_bwd_launch(const BwdGroup& g, const FragPtrs& fp, int B, int T, hipStream_t s) {
+    Shape sh;
+    if (!level_shape(g.d, g.n, B, sh) || !ensure_err_word()) return M3T_EINVAL;
+    ExPtrs ex;
+    size_t bytes[M3T_MAX_SCANS];
+    fill_exchange(g, fp, sh, 16, ex, bytes);
+    for (int i = 0; i < g.n; ++i) {
+        const hipError_t e = hipMemsetAsync(ex.gran[i], 0, bytes[i], s);
+        if (e != hipSuccess) return (int)e;
+    }
+    ++g_launches;
+    hipLaunchKernelGGL(pick_bwd(sh), dim3(sh.grid), dim3(NT), 0, s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
+    M3T_LAUNCH_CHECK();
+    return 0;
+}
+
+int persist_launch_count() { return g_launches; }
+
+int persist_profile(unsigned long long* out6) {
+    if (!g_prof || !out6) return M3T_EINVAL;
+    return (int)hipMemcpy(out6, g_prof, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+}
+
+}  // namespace m3t_gru
+
+extern "C" int m3t_gru_persist_count(void) { return m3t_gru::persist_launch_count(); }
+
+extern "C" int m3t_gru_persist_profile(unsigned long long* out6) {
+    return m3t_gru::persist_profile(out6);
+}

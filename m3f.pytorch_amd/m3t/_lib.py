@@ -7,6 +7,8 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libm3t_hip.so")
 CSRC_DIR = os.path.join(os.path.dirname(_HERE), "csrc")
 
 M3T_EINVAL = 10001
+M3T_ESPIN = 10002
+M3T_SCAN_NO_PERSIST = 1
 M3T_MAX_SCANS = 8
 
 _f = C.c_void_p      # device pointer
@@ -34,8 +36,10 @@ SIGNATURES = {
     "m3t_colsum": [_f, _i, _i, _i, _f, _i, _f, _z, _s],
     "m3t_transpose": [_f, _i, _i, _i, _f, _i, _s],
     "m3t_relu_bwd": [_f, _f, _z, _s],
-    "m3t_gru_scan_fwd": [C.POINTER(GruFwdDesc), _i, _i, _i, _f, _z, _s],
-    "m3t_gru_scan_bwd": [C.POINTER(GruBwdDesc), _i, _i, _i, _f, _z, _s],
+    "m3t_gru_scan_fwd": [C.POINTER(GruFwdDesc), _i, _i, _i, _f, _z, _i, _s],
+    "m3t_gru_scan_bwd": [C.POINTER(GruBwdDesc), _i, _i, _i, _f, _z, _i, _s],
+    "m3t_gru_persist_count": [],
+    "m3t_gru_persist_profile": [C.c_void_p],
     "m3t_att_fuse_fwd": [_f, _f, _f, _f, _f, _i, _i, _s],
     "m3t_att_fuse_bwd": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _s],
     "m3t_va_loss": [_f, _i, _i, _i, _i, _f, _f, _f, _f, _i, C.c_float, C.c_float, C.c_float, _i, _f, _f, _s],

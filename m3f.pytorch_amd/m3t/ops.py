@@ -180,14 +180,24 @@ def linear(x, w, b=None, act=0):
 
 
 # ----------------------------------------------------------------------------- BiGRU
+SCAN_PER_STEP = [False]     # tests/benchmarks: force the launch-per-step scan path
+
+
+def _scan_flags(device):
+    """A persistent scan launch needs every workgroup resident, so two of them must never run concurrently on one
+    device: scans issued on the side stream take the launch-per-step path (include/m3t_hip.h, m3t_gru_scan_fwd)."""
+    return _lib.M3T_SCAN_NO_PERSIST if (SCAN_PER_STEP[0] or _ws_tag(device) == "side") else 0
+
+
 def _scan_fwd(descs, B, T):
     for i in range(0, len(descs), M3T_MAX_SCANS):
         chunk = descs[i:i + M3T_MAX_SCANS]
         arr = (GruFwdDesc * len(chunk))(*chunk)
         flops = (T - 1) * sum(2.0 * B * 3 * d.H * d.H for d in chunk)
         with _Timed("gru_step_fwd_kernel", T, flops):
-            ws = workspace(torch.device("cuda", torch.cuda.current_device()))
-            rc = lib().m3t_gru_scan_fwd(arr, len(chunk), B, T, _p(ws), ws.numel() * 4, _stream())
+            dev = torch.device("cuda", torch.cuda.current_device())
+            ws = workspace(dev)
+            rc = lib().m3t_gru_scan_fwd(arr, len(chunk), B, T, _p(ws), ws.numel() * 4, _scan_flags(dev), _stream())
         _lib.check(rc, "m3t_gru_scan_fwd")
 
 
@@ -197,8 +207,9 @@ def _scan_bwd(descs, B, T):
         arr = (GruBwdDesc * len(chunk))(*chunk)
         flops = (T - 1) * sum(2.0 * B * 3 * d.H * d.H for d in chunk)
         with _Timed("gru_step_bwd_kernel", T, flops):
-            ws = workspace(torch.device("cuda", torch.cuda.current_device()))
-            rc = lib().m3t_gru_scan_bwd(arr, len(chunk), B, T, _p(ws), ws.numel() * 4, _stream())
+            dev = torch.device("cuda", torch.cuda.current_device())
+            ws = workspace(dev)
+            rc = lib().m3t_gru_scan_bwd(arr, len(chunk), B, T, _p(ws), ws.numel() * 4, _scan_flags(dev), _stream())
         _lib.check(rc, "m3t_gru_scan_bwd")
 
 

@@ -152,6 +152,66 @@ def test_gru_vs_oracle(B, T, I, H, L):
         close(prm.grad, g_ref[n], 2e-4, n)
 
 
+@pytest.mark.parametrize("B,T,I,H,L", [(5, 9, 20, 128, 2), (32, 40, 24, 256, 2), (19, 23, 16, 512, 1), (32, 12, 32, 384, 1),
+                                       (40, 6, 16, 128, 1)])
+def test_gru_persistent_scan_equals_per_step(B, T, I, H, L):
+    """The persistent scan (one launch for all T steps, W_hh in registers, tagged-granule exchange between CUs)
+    must take over for H % 128 == 0 levels and reproduce the launch-per-step kernels bit for bit (same MFMA chain and
+    reduction order), forward and backward, and both must match the oracle."""
+    from models.rnn import GRU
+    from m3t import ops, _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(B * 3 + T + H)
+    m = fill_module(GRU(I, H, L, 3, 2), 78).to(DEV)
+    xn, ct = draw(rs, (B, T, I)), draw(rs, (B, T, 3))
+
+    def run(per_step):
+        ops.SCAN_PER_STEP[0] = per_step
+        try:
+            m.zero_grad()
+            x = dev(xn, True)
+            n0 = lib.m3t_gru_persist_count()
+            y = m(x)
+            (y * dev(ct)).sum().backward()
+            torch.cuda.synchronize()
+            launches = lib.m3t_gru_persist_count() - n0
+            return y.detach().clone(), x.grad.clone(), {n: prm.grad.clone() for n, prm in m.named_parameters()}, launches
+        finally:
+            ops.SCAN_PER_STEP[0] = False
+
+    y1, dx1, g1, n1 = run(False)
+    y0, dx0, g0, n0 = run(True)
+    assert n0 == 0 and n1 == 2 * L, (n0, n1)            # one persistent launch per layer, forward and backward
+    assert torch.equal(y1, y0) and torch.equal(dx1, dx0)
+    for n in g0:
+        assert torch.equal(g1[n], g0[n]), n
+    p = {n: t.detach().cpu().numpy().astype(np.float64) for n, t in m.named_parameters()}
+    y_ref, _, cache = O.gru_module_fwd(xn.astype(np.float64), p, L, 3, 2)
+    dx_ref, g_ref = O.gru_module_bwd(ct.astype(np.float64), cache, p, L)
+    close(y1, y_ref, TOL, "y")
+    close(dx1, dx_ref, TOL, "dx")
+    for n in g1:
+        close(g1[n], g_ref[n], 2e-4, n)
+
+
+def test_gru_persistent_scan_repeatable_and_long():
+    """T = 300 at the C3 width (4 x H=512 scans = 256 workgroups, the whole chip): two runs are bit-identical and no
+    wait expires (a later scan call would raise M3T_ESPIN)."""
+    from models.rnn import GRU, run_grus
+    from m3t import _lib
+    lib = _lib.load()
+    torch.manual_seed(5)
+    a, b = GRU(64, 512, 1, -1).to(DEV), GRU(48, 512, 1, -1).to(DEV)
+    xa, xb = torch.randn(32, 300, 64, device=DEV), torch.randn(32, 300, 48, device=DEV)
+    n0 = lib.m3t_gru_persist_count()
+    ya, yb = run_grus([a, b], [xa, xb])
+    ya2, yb2 = run_grus([a, b], [xa, xb])
+    torch.cuda.synchronize()
+    assert lib.m3t_gru_persist_count() - n0 == 2
+    assert torch.equal(ya, ya2) and torch.equal(yb, yb2)
+    assert torch.isfinite(ya).all() and float(ya.detach().abs().max()) <= 1.0
+
+
 def test_grouped_grus_equal_separate():
     """one grouped scan over several modules == module-by-module scans, bit for bit."""
     from models.rnn import GRU, run_grus

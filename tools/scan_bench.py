@@ -54,22 +54,34 @@ def time_call(fn, descs, cls, reps=5):
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     ws = ops.workspace(torch.device(dev)) if os.environ.get("NOWS") is None else None
     wsp, wsb = (C.c_void_p(ws.data_ptr()), ws.numel() * 4) if ws is not None else (None, 0)
-    fn(arr, len(descs), B, T, wsp, wsb, s)
+    flags = int(os.environ.get('SCAN_FLAGS', '0'))
+    rc = fn(arr, len(descs), B, T, wsp, wsb, flags, s)
+    assert rc == 0, rc
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        fn(arr, len(descs), B, T, wsp, wsb, s)
+        fn(arr, len(descs), B, T, wsp, wsb, flags, s)
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps / T * 1e3     # us per step launch
+    us = e0.elapsed_time(e1) / reps / T * 1e3     # us per step launch
+    if os.environ.get("M3T_SCAN_PROF") == "1":
+        buf = (C.c_ulonglong * 6)()
+        if lib.m3t_gru_persist_profile(buf) == 0:
+            tot = float(sum(buf)) or 1.0
+            names = ["top", "gather", "mfma", "barrier", "gates+publish", "stores"]
+            print("      stamps (share of the step, x %.2f us): " % us + "  ".join("%s %.0f%%" % (n, 100.0 * v / tot) for n, v in zip(names, buf)))
+    return us
 
 
 lib = _lib.load()
 levels = {"enc (4x512+2x256)": [512, 512, 256], "fusion (2x512)": [512], "scorers (4x128)": [128, 128],
           "one 512 pair": [512], "4x512": [512, 512], "8x512": [512, 512, 512, 512], "2x256": [256], "tiny 2x16": [16], "2x64": [64]}
 print("B=%d T=%d" % (B, T))
+only = os.environ.get('ONLY')
 for name, Hs in levels.items():
+    if only and name != only:
+        continue
     d, k = fwd_group(Hs)
     tf = time_call(lib.m3t_gru_scan_fwd, d, GruFwdDesc)
     flops = sum(2.0 * B * 3 * H * H * 2 for H in Hs)
