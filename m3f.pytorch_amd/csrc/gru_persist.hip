@@ -48,10 +48,10 @@ __device__ __forceinline__ void raise_spin(unsigned* err, int step) {
     __hip_atomic_store(err, (unsigned)step + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// Vector-memory operations of a wave retire in issue order, so the per-step order is chosen so that the gather's
-// vmcnt(0) never waits for an HBM miss: gather (loads only) -> wait -> [stores of the PREVIOUS step, prefetch of the
-// NEXT step's inputs] -> MFMA -> LDS partials -> barrier -> reduce + gate math -> publish.
-// The gather is inline asm (all loads of the pass in flight, one explicit wait) so that hipcc does not serialise it.
+// Order of a step: gather (loads only, inline asm: all loads of the pass in flight, ONE explicit wait -- left to
+// hipcc the loads were issued and waited for in groups) -> MFMA -> LDS partials -> barrier -> reduce + cell math ->
+// publish -> [results to HBM, next step's inputs from HBM].  The HBM traffic is issued after the publish, so it is in
+// flight while the peers' granules travel and is never waited for on the chain.
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int NC, int RT>      // NC = H / 128 = k-chunks per wave;  RT = 16-row tiles per workgroup
@@ -96,29 +96,23 @@ __global__ __launch_bounds__(NT) void gru_persist_fwd_kernel(FwdGroup g, FragPtr
     const bool stamp = ex.prof != nullptr && blockIdx.x == 0 && tid == 0;
     long long psum[6] = {0, 0, 0, 0, 0, 0}, last = stamp ? clock64() : 0;
 
-    // x-projection rows of this thread's clip, one step ahead
-    const float* xrow = d.xproj + (size_t)pb * T * d.ldx + d.xoff + pj;
+    // x-projection of the step: loaded at the END of the previous step (after the publish), so it is in flight during
+    // the gather and never on the chain
+    const float* xp = d.xproj + (size_t)pb * T * d.ldx + d.xoff + pj + (d.reverse ? (size_t)(T - 1) * d.ldx : 0);
     const ptrdiff_t xstep = d.reverse ? -(ptrdiff_t)d.ldx : (ptrdiff_t)d.ldx;
-    const float* xp = xrow + (d.reverse ? (size_t)(T - 1) * d.ldx : 0);
     float xr = 0.f, xz = 0.f, xn = 0.f;
     if (pok) { xr = xp[0]; xz = xp[H]; xn = xp[2 * H]; }
-    float s_r = 0.f, s_z = 0.f, s_n = 0.f, s_hn = 0.f;     // previous step's gates, stored one step late
     // everything loaded so far is in registers before the loop: hipcc then places no vmcnt wait for the weight
-    // fragments inside the step (one there would also wait for the step's HBM prefetch and stores)
+    // fragments inside the step
     __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
 
     for (int step = 0; step < T; ++step) {
         const int t = d.reverse ? T - 1 - step : step;
         M3T_STAMP(0);
-        f32x4 acc[RT][3];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int ct = 0; ct < 3; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        unsigned long long v[NC][RT][4];
         if (step > 0) {
             const unsigned tag = (unsigned)step;       // h_{step-1} carries tag (step-1)+1
             const unsigned long long* src = gran + (size_t)((step - 1) & 1) * slot + grp + (size_t)wave * TILE + lane;
+            unsigned long long v[NC][RT][4];
             int spins = 0;
             for (;;) {
 #pragma unroll
@@ -145,25 +139,12 @@ __global__ __launch_bounds__(NT) void gru_persist_fwd_kernel(FwdGroup g, FragPtr
                 if (++spins > SPIN_LIMIT) { dead = true; if (lane == 0) raise_spin(err, step); break; }
                 __builtin_amdgcn_s_sleep(1);
             }
-        }
-        M3T_STAMP(1);
-        // off the chain: last step's results to HBM, next step's inputs from HBM
-        float nxr = 0.f, nxz = 0.f, nxn = 0.f;
-        if (pok) {
-            if (step > 0) {
-                const int tl = d.reverse ? t + 1 : t - 1;
-                d.out[((size_t)pb * T + tl) * d.ldo + d.ooff + pj] = hprev;
-                if (d.gates) {
-                    float* gp = d.gates + ((size_t)pb * T + tl) * 4 * H;
-                    gp[pj] = s_r; gp[H + pj] = s_z; gp[2 * H + pj] = s_n; gp[3 * H + pj] = s_hn;
-                }
-            }
-            if (step + 1 < T) {
-                xp += xstep;
-                nxr = xp[0]; nxz = xp[H]; nxn = xp[2 * H];
-            }
-        }
-        if (step > 0) {
+            M3T_STAMP(1);
+            f32x4 acc[RT][3];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int m = 0; m < NC; ++m)
 #pragma unroll
@@ -196,26 +177,27 @@ __global__ __launch_bounds__(NT) void gru_persist_fwd_kernel(FwdGroup g, FragPtr
                 }
             }
             const GateFwd c = gru_cell_fwd(xr, xz, xn, hr, hz, hn, hprev);
-            const float r = c.r, z = c.z, n = c.n, h = c.h;
             if (step + 1 < T) {                        // publish: the only store on the chain
-                const unsigned long long gq = ((unsigned long long)((unsigned)step + 1u) << 32) | __float_as_uint(pok ? h : 0.f);
+                const unsigned long long gq = ((unsigned long long)((unsigned)step + 1u) << 32) | __float_as_uint(pok ? c.h : 0.f);
                 __hip_atomic_store(gran + (size_t)(step & 1) * slot + pub, gq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            hprev = h; s_r = r; s_z = z; s_n = n; s_hn = hn;
+            M3T_STAMP(4);
+            hprev = c.h;
+            if (pok) {                                 // off the chain: results to HBM, next step's inputs from HBM
+                d.out[((size_t)pb * T + t) * d.ldo + d.ooff + pj] = c.h;
+                if (d.gates) {
+                    float* gp = d.gates + ((size_t)pb * T + t) * 4 * H;
+                    gp[pj] = c.r; gp[H + pj] = c.z; gp[2 * H + pj] = c.n; gp[3 * H + pj] = hn;
+                }
+                if (d.h_n && step == T - 1) d.h_n[(size_t)pb * H + pj] = c.h;
+                if (step + 1 < T) {
+                    xp += xstep;
+                    xr = xp[0]; xz = xp[H]; xn = xp[2 * H];
+                }
+            }
         }
-        M3T_STAMP(4);
-        xr = nxr; xz = nxz; xn = nxn;
         if (NB == 1) __syncthreads();
         M3T_STAMP(5);
-    }
-    if (pok) {                                         // the last step's results
-        const int tl = d.reverse ? 0 : T - 1;
-        d.out[((size_t)pb * T + tl) * d.ldo + d.ooff + pj] = hprev;
-        if (d.gates) {
-            float* gp = d.gates + ((size_t)pb * T + tl) * 4 * H;
-            gp[pj] = s_r; gp[H + pj] = s_z; gp[2 * H + pj] = s_n; gp[3 * H + pj] = s_hn;
-        }
-        if (d.h_n) d.h_n[(size_t)pb * H + pj] = hprev;
     }
     if (stamp)
         for (int i = 0; i < 6; ++i) ex.prof[i] = (unsigned long long)psum[i];
@@ -259,31 +241,27 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd_kernel(BwdGroup g, FragPtr
     const bool stamp = ex.prof != nullptr && blockIdx.x == 0 && tid == 0;
     long long psum[6] = {0, 0, 0, 0, 0, 0}, last = stamp ? clock64() : 0;
 
-    // this step's saved activations, one step ahead
+    // this step's saved activations: loaded at the END of the previous step (after the publish)
     float dout = 0.f, gr = 0.f, gz = 0.f, gn = 0.f, ghn = 0.f, hprev = 0.f;
-    auto load_step = [&](int step, float& o_dout, float& o_gr, float& o_gz, float& o_gn, float& o_ghn, float& o_hprev) {
+    auto load_step = [&](int step) {
         const int t = d.reverse ? step : T - 1 - step;
         const int tp = d.reverse ? t + 1 : t - 1;
-        o_dout = d.dout[((size_t)pb * T + t) * d.ldo + d.ooff + pj];
+        dout = d.dout[((size_t)pb * T + t) * d.ldo + d.ooff + pj];
         const float* gp = d.gates + ((size_t)pb * T + t) * 4 * H;
-        o_gr = gp[pj]; o_gz = gp[H + pj]; o_gn = gp[2 * H + pj]; o_ghn = gp[3 * H + pj];
-        o_hprev = step < T - 1 ? d.out[((size_t)pb * T + tp) * d.ldo + d.ooff + pj] : 0.f;
+        gr = gp[pj]; gz = gp[H + pj]; gn = gp[2 * H + pj]; ghn = gp[3 * H + pj];
+        hprev = step < T - 1 ? d.out[((size_t)pb * T + tp) * d.ldo + d.ooff + pj] : 0.f;
     };
-    if (pok) load_step(0, dout, gr, gz, gn, ghn, hprev);
-    float s_dr = 0.f, s_dz = 0.f, s_dn = 0.f, s_dnr = 0.f;     // previous step's gate gradients, stored one step late
+    if (pok) load_step(0);
     __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0): see the forward kernel
 
     for (int step = 0; step < T; ++step) {
         const int t = d.reverse ? step : T - 1 - step;
         const bool has_next = step > 0;
         M3T_STAMP(0);
-        f32x4 acc[RT];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        u32x4 v[NC][RT][4];
         if (has_next) {
             const unsigned tag = (unsigned)step;
             const u32x4* src = gran + (size_t)((step - 1) & 1) * slot + grp + (size_t)wave * TILE + lane;
+            u32x4 v[NC][RT][4];
             int spins = 0;
             for (;;) {
 #pragma unroll
@@ -310,20 +288,10 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd_kernel(BwdGroup g, FragPtr
                 if (++spins > SPIN_LIMIT) { dead = true; if (lane == 0) raise_spin(err, step); break; }
                 __builtin_amdgcn_s_sleep(1);
             }
-        }
-        M3T_STAMP(1);
-        float ndout = 0.f, ngr = 0.f, ngz = 0.f, ngn = 0.f, nghn = 0.f, nhprev = 0.f;
-        if (pok) {
-            if (has_next) {
-                const int tl = d.reverse ? t - 1 : t + 1;
-                float* gx = d.dgx + ((size_t)pb * T + tl) * d.ldg + d.goff;
-                gx[pj] = s_dr; gx[H + pj] = s_dz; gx[2 * H + pj] = s_dn;
-                float* gh = d.dgh + ((size_t)pb * T + tl) * H3;
-                gh[pj] = s_dr; gh[H + pj] = s_dz; gh[2 * H + pj] = s_dnr;
-            }
-            if (step + 1 < T) load_step(step + 1, ndout, ngr, ngz, ngn, nghn, nhprev);
-        }
-        if (has_next) {
+            M3T_STAMP(1);
+            f32x4 acc[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int gt = 0; gt < 3; ++gt)             // ascending chunk order gate*nchh + wave + 8m: as the per-step kernel
 #pragma unroll
@@ -350,28 +318,25 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd_kernel(BwdGroup g, FragPtr
                 for (int w = 0; w < NW; ++w) mm += red[step & 1][w][prow][pu];
             }
             const GateBwd c = gru_cell_bwd(dout, dh_carry, z_next, mm, has_next, gr, gz, gn, ghn, hprev);
-            const float dht = c.dht, dn = c.dn, dz = c.dz, dr = c.dr;
             if (step + 1 < T) {
                 u32x4 gq;
-                gq.x = __float_as_uint(pok ? dr : 0.f); gq.y = __float_as_uint(pok ? dz : 0.f);
+                gq.x = __float_as_uint(pok ? c.dr : 0.f); gq.y = __float_as_uint(pok ? c.dz : 0.f);
                 gq.z = __float_as_uint(pok ? c.dnr : 0.f); gq.w = (unsigned)step + 1u;
                 u32x4* q = gran + (size_t)(step & 1) * slot + pub;
                 asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(q), "v"(gq) : "memory");
             }
-            dh_carry = dht; z_next = gz;
-            s_dr = dr; s_dz = dz; s_dn = dn; s_dnr = c.dnr;
+            M3T_STAMP(4);
+            dh_carry = c.dht; z_next = gz;
+            if (pok) {
+                float* gx = d.dgx + ((size_t)pb * T + t) * d.ldg + d.goff;
+                gx[pj] = c.dr; gx[H + pj] = c.dz; gx[2 * H + pj] = c.dn;
+                float* gh = d.dgh + ((size_t)pb * T + t) * H3;
+                gh[pj] = c.dr; gh[H + pj] = c.dz; gh[2 * H + pj] = c.dnr;
+                if (step == T - 1) d.dh[(size_t)pb * H + pj] = c.dht;
+                if (step + 1 < T) load_step(step + 1);
+            }
         }
-        M3T_STAMP(4);
-        dout = ndout; gr = ngr; gz = ngz; gn = ngn; ghn = nghn; hprev = nhprev;
         M3T_STAMP(5);
-    }
-    if (pok) {
-        const int tl = d.reverse ? T - 1 : 0;
-        float* gx = d.dgx + ((size_t)pb * T + tl) * d.ldg + d.goff;
-        gx[pj] = s_dr; gx[H + pj] = s_dz; gx[2 * H + pj] = s_dn;
-        float* gh = d.dgh + ((size_t)pb * T + tl) * H3;
-        gh[pj] = s_dr; gh[H + pj] = s_dz; gh[2 * H + pj] = s_dnr;
-        d.dh[(size_t)pb * H + pj] = dh_carry;
     }
     if (stamp)
         for (int i = 0; i < 6; ++i) ex.prof[i] = (unsigned long long)psum[i];

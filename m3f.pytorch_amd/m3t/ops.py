@@ -79,7 +79,8 @@ def _p(t, off=0):
 # ---- side stream: independent light-weight stacks run beside the main chain (see _stream_groups) -------------
 _SIDE = {}
 # measured +9% on C3 (969 vs 886 clips/s): the light chain and its GEMMs hide beside the heavy one; M3T_SIDE_STREAM=0 disables
-_SIDE_ENABLED = __import__("os").environ.get("M3T_SIDE_STREAM", "1") == "1"
+_SIDE_ENABLED = os.environ.get("M3T_SIDE_STREAM", "1") == "1"
+_PERSIST_ENABLED = os.environ.get("M3T_SCAN_PERSIST", "1") != "0"
 
 
 def side_stream(device):
@@ -222,6 +223,11 @@ def _stream_groups(Hs, B):
     one 16-row workgroup per CU (>= 192 of 256), narrower stacks sharing that launch would double up on CUs and
     stretch every step (measured +2.5 us/step for audio H=256 beside 4 x H=512); they run as their own launches
     on a side stream instead -- both chains are latency-bound and overlap."""
+    if _PERSIST_ENABLED and not SCAN_PER_STEP[0] and len(set(Hs)) > 1 and all(h % 128 == 0 and h <= 512 for h in Hs):
+        # persistent scans (one launch per level, csrc/gru_persist.hip) need one H per launch and must not overlap each
+        # other: one group per H, back to back on the main stream (a persistent launch holds every CU, so a
+        # launch-per-step chain on the side stream would only run before or after it anyway)
+        return [("main", [i for i, h in enumerate(Hs) if h == hh]) for hh in sorted(set(Hs), reverse=True)]
     if not _SIDE_ENABLED:
         return [("main", list(range(len(Hs))))]
     hmax = max(Hs)

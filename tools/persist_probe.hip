@@ -34,7 +34,14 @@ __global__ __launch_bounds__(512) void persist(unsigned long long* gran, int NG,
 #pragma unroll
             for (int c = 0; c < NL; ++c) {
                 const int u = wave * PER_WAVE + c / 4;
-                v[c] = __hip_atomic_load(src + (size_t)u * GRAN + (c % 4) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long* q = src + (size_t)u * GRAN + (c % 4) * 64 + lane;
+                if (WORK == -2) asm volatile("global_load_dwordx2 %0, %1, off sc0" : "=v"(v[c]) : "v"(q) : "memory");   // L2-coherent only (same XCD)
+                else v[c] = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (WORK == -2) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int c = 0; c < NL; ++c) asm volatile("" : "+v"(v[c]));
             }
 #pragma unroll
             for (int c = 0; c < NL; ++c) ok = ok && ((unsigned)(v[c] >> 32) == tag);
@@ -61,7 +68,8 @@ __global__ __launch_bounds__(512) void persist(unsigned long long* gran, int NG,
             const unsigned long long g = ((unsigned long long)(tag + 1u) << 32) | __float_as_uint(r);
             // WORK == -1: the scattered publish map of a (row, unit) thread layout (16 x 32-byte pieces per wave)
             const int pos = WORK == -1 ? ((threadIdx.x & 3) * 64 + ((threadIdx.x & 15) >> 2) * 16 + (threadIdx.x >> 4)) : threadIdx.x;
-            __hip_atomic_store(dst + pos, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (WORK == -2) { unsigned long long* q = dst + pos; asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(q), "v"(g) : "memory"); }
+            else __hip_atomic_store(dst + pos, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
     }
@@ -209,6 +217,8 @@ int main() {
     run<32, 0, 600>(8, T);
     run<8, 0, 0>(2, T);
     run<32, 0, -1>(8, T);
+    run<32, 0, -2>(8, T);
+    run<32, 0, -2>(8, 20000);
     run<32, 0, -1>(4, T);
     run16<32>(8, T);
     run16<32>(8, 20000);
