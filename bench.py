@@ -170,15 +170,17 @@ def main():
     # ---- roofline of the dominant kernel, from HIP events recorded on the launch stream in the timed region
     kern = {}
     for rec in ops.PROFILE:
-        k = kern.setdefault(rec["kernel"], {"ms": 0.0, "launches": 0, "flops": 0.0})
+        k = kern.setdefault(rec["kernel"], {"ms": 0.0, "launches": 0, "flops": 0.0, "steps": 0})
         k["ms"] += rec["start"].elapsed_time(rec["end"])
         k["launches"] += rec["launches"]
         k["flops"] += rec["flops"]
+        k["steps"] += rec.get("steps", rec["launches"])
     step_ms = dt / args.steps * 1e3
     roofline, breakdown = None, {}
     for name, k in kern.items():
         breakdown[name] = {"ms_per_step": round(k["ms"] / args.steps, 3), "launches_per_step": k["launches"] // args.steps,
-                           "avg_launch_us": round(1e3 * k["ms"] / max(1, k["launches"]), 3)}
+                           "avg_launch_us": round(1e3 * k["ms"] / max(1, k["launches"]), 3),
+                           "us_per_time_step": round(1e3 * k["ms"] / max(1, k["steps"]), 3)}
     if kern:
         name = max(kern, key=lambda n: kern[n]["ms"])
         k = kern[name]

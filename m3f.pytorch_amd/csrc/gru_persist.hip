@@ -118,12 +118,15 @@ __global__ __launch_bounds__(NT) void gru_persist_fwd_kernel(FwdGroup g, FragPtr
 #pragma unroll
                 for (int m = 0; m < NC; ++m)
 #pragma unroll
-                    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const unsigned long long* q = src + (size_t)m * NW * TILE + (rt * 4 + e) * 64;
-                            asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(v[m][rt][e]) : "v"(q) : "memory");
-                        }
+                    for (int rt = 0; rt < RT; ++rt) {          // one address per (chunk, row tile); e by immediate offset
+                        const unsigned long long* q = src + (size_t)m * NW * TILE + rt * 256;
+                        asm volatile("global_load_dwordx2 %0, %4, off sc1\n\t"
+                                     "global_load_dwordx2 %1, %4, off offset:512 sc1\n\t"
+                                     "global_load_dwordx2 %2, %4, off offset:1024 sc1\n\t"
+                                     "global_load_dwordx2 %3, %4, off offset:1536 sc1"
+                                     : "=&v"(v[m][rt][0]), "=&v"(v[m][rt][1]), "=&v"(v[m][rt][2]), "=&v"(v[m][rt][3])
+                                     : "v"(q) : "memory");
+                    }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 bool ok = true;
 #pragma unroll
@@ -267,12 +270,15 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd_kernel(BwdGroup g, FragPtr
 #pragma unroll
                 for (int m = 0; m < NC; ++m)
 #pragma unroll
-                    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const u32x4* q = src + (size_t)m * NW * TILE + (rt * 4 + e) * 64;
-                            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[m][rt][e]) : "v"(q) : "memory");
-                        }
+                    for (int rt = 0; rt < RT; ++rt) {
+                        const u32x4* q = src + (size_t)m * NW * TILE + rt * 256;
+                        asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
+                                     "global_load_dwordx4 %1, %4, off offset:1024 sc1\n\t"
+                                     "global_load_dwordx4 %2, %4, off offset:2048 sc1\n\t"
+                                     "global_load_dwordx4 %3, %4, off offset:3072 sc1"
+                                     : "=&v"(v[m][rt][0]), "=&v"(v[m][rt][1]), "=&v"(v[m][rt][2]), "=&v"(v[m][rt][3])
+                                     : "v"(q) : "memory");
+                    }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 bool ok = true;
 #pragma unroll

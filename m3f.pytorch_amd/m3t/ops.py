@@ -195,10 +195,13 @@ def _scan_fwd(descs, B, T):
         chunk = descs[i:i + M3T_MAX_SCANS]
         arr = (GruFwdDesc * len(chunk))(*chunk)
         flops = (T - 1) * sum(2.0 * B * 3 * d.H * d.H for d in chunk)
-        with _Timed("gru_step_fwd_kernel", T, flops):
+        with _Timed("gru_step_fwd_kernel", T, flops) as tm:
             dev = torch.device("cuda", torch.cuda.current_device())
             ws = workspace(dev)
+            n0 = lib().m3t_gru_persist_count() if tm.rec is not None else 0
             rc = lib().m3t_gru_scan_fwd(arr, len(chunk), B, T, _p(ws), ws.numel() * 4, _scan_flags(dev), _stream())
+            if tm.rec is not None and lib().m3t_gru_persist_count() != n0:      # one launch ran all T steps
+                tm.rec.update(kernel="gru_persist_fwd_kernel", launches=1, steps=T)
         _lib.check(rc, "m3t_gru_scan_fwd")
 
 
@@ -207,10 +210,13 @@ def _scan_bwd(descs, B, T):
         chunk = descs[i:i + M3T_MAX_SCANS]
         arr = (GruBwdDesc * len(chunk))(*chunk)
         flops = (T - 1) * sum(2.0 * B * 3 * d.H * d.H for d in chunk)
-        with _Timed("gru_step_bwd_kernel", T, flops):
+        with _Timed("gru_step_bwd_kernel", T, flops) as tm:
             dev = torch.device("cuda", torch.cuda.current_device())
             ws = workspace(dev)
+            n0 = lib().m3t_gru_persist_count() if tm.rec is not None else 0
             rc = lib().m3t_gru_scan_bwd(arr, len(chunk), B, T, _p(ws), ws.numel() * 4, _scan_flags(dev), _stream())
+            if tm.rec is not None and lib().m3t_gru_persist_count() != n0:
+                tm.rec.update(kernel="gru_persist_bwd_kernel", launches=1, steps=T)
         _lib.check(rc, "m3t_gru_scan_bwd")
 
 
