@@ -5,11 +5,18 @@ buffer over xGMI, then the global-norm clip -- what the reference gets from Ligh
 
 Design: parameters' .grad tensors are VIEWS into one contiguous buffer, so
 the ~100 small gradient tensors of the AV graph cost one (or a few, bucketed) collectives
-instead of one each; buckets follow the order in which backward finishes sub-modules, and each
-bucket's all-reduce is issued from a post-accumulate hook so it overlaps the rest of backward;
-the 1/world scaling and the clip coefficient are applied by one fused HIP pass
-(m3t_grad_norm_scale).  There is no other collective on the path (no SyncBN, as the reference).
+instead of one each.  Two schedules:
+  * overlap=False (default while the persistent GRU scans are enabled): ONE all-reduce of the whole flat buffer after
+    backward.  A persistent scan launch needs every workgroup of its grid resident; an RCCL kernel that holds a few
+    CUs while it waits for its peers on other GPUs could keep part of a scan grid off the chip on one GPU while the
+    mirror-image happens on another -- a cross-GPU cycle.  Keeping collectives and scans disjoint in time rules it
+    out by construction (106 MB at xGMI rates is ~1 ms per step, less than the persistent scans save).
+  * overlap=True (launch-per-step scans, M3T_SCAN_PERSIST=0): buckets follow the order in which backward finishes
+    sub-modules, and each bucket's all-reduce is issued from a post-accumulate hook so it overlaps the rest of backward.
+The 1/world scaling and the clip coefficient are applied by one fused HIP pass (m3t_grad_norm_scale).  There is no
+other collective on the path (no SyncBN, as the reference).
 """
+import os
 import torch
 import torch.distributed as dist
 
@@ -25,11 +32,12 @@ def shard_indices(n_items, rank, world_size):
 
 class FlatGradDDP:
     def __init__(self, module, bucket_order=None, max_norm=1.0, process_group=None, finalize=None,
-                 flatten_params=False):
+                 flatten_params=False, overlap=None):
         """bucket_order: list of lists of parameters, in the order backward completes them
         (default: one bucket per top-level child, reversed registration order).
         finalize(flat, world_size, max_norm) -> norm tensor; default = fused HIP kernel."""
         self.module = module
+        self.overlap = (os.environ.get("M3T_SCAN_PERSIST", "1") == "0") if overlap is None else bool(overlap)
         self.max_norm = max_norm
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
@@ -85,7 +93,7 @@ class FlatGradDDP:
     def _make_hook(self, bi):
         def hook(_p):
             self._left[bi] -= 1
-            if self._left[bi] == 0:
+            if self._left[bi] == 0 and self.overlap:
                 s, e = self.ranges[bi]
                 self._handles.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
         return hook
@@ -97,7 +105,9 @@ class FlatGradDDP:
 
     def finish(self):
         """Call after backward: waits for the bucket all-reduces, then averages + clips in place."""
-        if self.world > 1:
+        if self.world > 1 and not self.overlap:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.pg)
+        elif self.world > 1:
             for bi, left in enumerate(self._left):      # parameters that received no gradient this step
                 if left > 0:
                     s, e = self.ranges[bi]

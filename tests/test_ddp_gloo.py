@@ -40,12 +40,12 @@ def _data():
     return torch.randn(8, 6, generator=g), torch.randn(8, 2, generator=g)
 
 
-def _worker(rank, world, port, max_norm, out_q):
+def _worker(rank, world, port, max_norm, overlap, out_q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     net = _net()
-    ddp = FlatGradDDP(net, max_norm=max_norm, finalize=torch_finalize)
-    assert ddp.world == world and len(ddp.buckets) == 3
+    ddp = FlatGradDDP(net, max_norm=max_norm, finalize=torch_finalize, overlap=overlap)
+    assert ddp.world == world and len(ddp.buckets) == 3 and ddp.overlap == overlap
     x, y = _data()
     idx = shard_indices(x.shape[0], rank, world)
     for _ in range(2):                      # two steps: zero_grad must reset the hook counters
@@ -60,12 +60,14 @@ def _worker(rank, world, port, max_norm, out_q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("max_norm", [0.0, 0.05])
-def test_two_rank_gradients_equal_mean_of_shard_gradients(max_norm):
+@pytest.mark.parametrize("max_norm,overlap", [(0.0, True), (0.05, True), (0.05, False)])
+def test_two_rank_gradients_equal_mean_of_shard_gradients(max_norm, overlap):
+    """both schedules: bucketed all-reduces overlapped with backward, and one all-reduce after backward (the default
+    while the persistent scans are enabled)"""
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, max_norm, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, max_norm, overlap, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
