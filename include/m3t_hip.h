@@ -259,6 +259,21 @@ int m3t_adam_step(float* p, const float* g, float* m, float* v, size_t n, float 
 int m3t_sgd_step(float* p, const float* g, float* buf, size_t n, float lr, float momentum, float weight_decay,
                  int step, void* stream);
 
+/* ---------------------------------------------------------------------------------
+ * Post-processing of prediction tracks (reference models/utils.py:20-33,
+ * get_smoothed_ccc.py:13-28, create_submission.py:30-38).
+ * n_tracks tracks are concatenated in x; track i = x[offsets[i] .. offsets[i+1]) (offsets: n_tracks+1 int64 on the
+ * device).  mode 0 = scipy.signal.wiener(track, window), mode 1 = scipy.signal.medfilt(track, window): centred odd
+ * window (<= 129), zero padding, fp64 arithmetic on the fp32 input (squares rounded to fp32 first, as scipy does);
+ * y (fp64) has the layout of x. */
+int m3t_smooth_tracks(const float* x, const long long* offsets, int n_tracks, int window, int mode, double* y,
+                      void* stream);
+/* out2[0] = numpy-style CCC (biased variances) of p against g over the frames with g >= -1 (and g2 >= -1 when g2 is
+ * given): models/utils.py:20-22 as driven by get_smoothed_ccc.py:19-21; p_unbiased != 0 uses the unbiased variance
+ * for p (what the reference computes when the smoothed track is a torch tensor).  out2[1] = number of valid frames. */
+int m3t_ccc_masked(const double* p, const float* g, const float* g2, long long n, int p_unbiased, double* out2,
+                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -673,3 +673,53 @@ def av_feature_graph_bwd(dy, cache, p):
     dxa, g = gru_module_bwd(da, ca, sub("audio."), 2)
     grads.update({"audio." + k: v for k, v in g.items()})
     return dxa, dxv1 + dxv2, grads
+
+
+# --------------------------------------------------------------------------- post-processing
+# The reference calls scipy.signal.wiener / medfilt (third-party, unpinned: requirements.txt has no scipy line;
+# models/utils.py:2,29-33).  Restated here from scipy's published algorithm (scipy/signal/_signaltools.py, `wiener`,
+# `medfilt`), pinned by tests/golden/postproc.npz, which was produced by the reference's own smooth_predictions
+# under scipy 1.15.3.
+def _window_sums(x, window):
+    """sum of x over the centred odd window, zero padded ('same' correlation with ones)."""
+    n, h = x.shape[0], window // 2
+    c = np.concatenate([[0.0], np.cumsum(np.concatenate([np.zeros(h), x.astype(F64), np.zeros(h)]))])
+    return c[window:window + n] - c[:n]
+
+
+def wiener1d(x, window):
+    """scipy.signal.wiener(x, window) on a 1-D signal: local mean/variance over the zero-padded window, noise = mean
+    local variance, out = mean + (1 - noise/var)(x - mean) where var >= noise, else the local mean.  x**2 is taken in
+    the INPUT dtype before the fp64 window sum, as scipy does (fp32 predictions -> fp32 squares)."""
+    x = np.asarray(x)
+    lmean = _window_sums(x, window) / window
+    lvar = _window_sums(x ** 2, window) / window - lmean ** 2
+    noise = lvar.mean()
+    with np.errstate(divide="ignore", invalid="ignore"):
+        res = (x - lmean) * (1 - noise / lvar) + lmean
+    return np.where(lvar < noise, lmean, res)
+
+
+def medfilt1d(x, window):
+    """scipy.signal.medfilt(x, window): median of the zero-padded centred window."""
+    x = np.asarray(x)
+    n, h = x.shape[0], window // 2
+    xp = np.concatenate([np.zeros(h, x.dtype), x, np.zeros(h, x.dtype)])
+    return np.array([np.sort(xp[i:i + window])[h] for i in range(n)], x.dtype)
+
+
+def smooth_predictions(preds, window=13, mode="wiener"):
+    """models/utils.py:29-33 on a 1-D prediction track."""
+    return medfilt1d(preds, window) if mode == "median" else wiener1d(preds, window)
+
+
+def concordance_cc2_np(r1, r2, r1_unbiased=False):
+    """models/utils.py:20-22: numpy CCC with BIASED variances (np.var), unlike the torch loss (a-12 quirk).
+    Dtypes are left as given (the reference mixes fp64 smoothed predictions with fp32 labels: the label mean and
+    variance are fp32 reductions).
+    r1_unbiased: get_smoothed_ccc.py:7-20 feeds it predictions loaded from predictions_val.pt -- torch tensors -- and
+    np.apply_along_axis hands a torch tensor back, so `r1.var()` there is TORCH's unbiased variance while `r2.var()`
+    (numpy labels) stays biased.  The golden vectors pin this mixed form."""
+    r1, r2 = np.asarray(r1), np.asarray(r2)
+    cov = ((r1 - r1.mean()) * (r2 - r2.mean())).mean()
+    return 2 * cov / (r1.var(ddof=1 if r1_unbiased else 0) + r2.var() + (r1.mean() - r2.mean()) ** 2)

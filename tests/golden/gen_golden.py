@@ -431,6 +431,68 @@ def case_stitch(name, seed):
     save(name, **arrs)
 
 
+def case_postproc(name, seed):
+    """f-4 post-processing: the reference's own smooth_predictions / concordance_cc2_np
+    (models/utils.py:20-33) driven as get_smoothed_ccc.py:7-28 and create_submission.py:14-39 drive them."""
+    import tempfile
+    _mpl = types.ModuleType("matplotlib")
+    _mpl.pyplot = types.ModuleType("matplotlib.pyplot")
+    sys.modules.setdefault("matplotlib", _mpl)
+    sys.modules.setdefault("matplotlib.pyplot", _mpl.pyplot)
+    from models.utils import smooth_predictions, concordance_cc2_np      # reference
+    import create_submission                                              # reference
+    rs = np.random.RandomState(seed)
+    vids = {"vidA": 120, "vidB": 40, "vidC": 9, "vidD": 301}            # vidC is shorter than both windows
+    arrs = {"names": np.array(list(vids))}
+    pred, gt = {"valence": {}, "arousal": {}}, {"valence": {}, "arousal": {}}
+    for v, n in vids.items():
+        for k in ("valence", "arousal"):
+            walk = np.cumsum(rs.standard_normal(n) * 0.05) + 0.3 * rs.standard_normal(n)
+            pred[k][v] = torch.from_numpy(np.tanh(walk).astype(np.float32))
+            g = rs.uniform(-1, 1, n).astype(np.float32)
+            g[rs.uniform(size=n) < 0.1] = -5.0                           # unannotated frames (get_smoothed_ccc.py:19)
+            gt[k][v] = torch.from_numpy(g)
+            arrs["pred.%s.%s" % (k, v)] = pred[k][v].numpy()
+            arrs["gt.%s.%s" % (k, v)] = g
+    # smoothing as called by the reference scripts
+    for v in vids:
+        for k in ("valence", "arousal"):
+            arrs["wiener35.%s.%s" % (k, v)] = smooth_predictions(pred[k][v], 35, mode="wiener")
+            arrs["wiener13.%s.%s" % (k, v)] = smooth_predictions(pred[k][v].numpy())
+            arrs["median13.%s.%s" % (k, v)] = smooth_predictions(pred[k][v].numpy(), 13, mode="median")
+    # get_smoothed_ccc.py:13-28
+    allp, allg = {"valence": [], "arousal": []}, {"valence": [], "arousal": []}
+    for v in vids:
+        pv, pa = arrs["wiener35.valence." + v], arrs["wiener35.arousal." + v]
+        gv, ga = gt["valence"][v].numpy(), gt["arousal"][v].numpy()
+        valid = (gv >= -1) & (ga >= -1)
+        arrs["ccc.valence." + v] = np.array(concordance_cc2_np(pv[valid], gv[valid]))
+        arrs["ccc.arousal." + v] = np.array(concordance_cc2_np(pa[valid], ga[valid]))
+        allp["valence"].append(pv[valid]); allp["arousal"].append(pa[valid])
+        allg["valence"].append(gv[valid]); allg["arousal"].append(ga[valid])
+    for k in ("valence", "arousal"):
+        arrs["ccc_all." + k] = np.array(concordance_cc2_np(np.concatenate(allp[k]), np.concatenate(allg[k])))
+    # create_submission.py:14-39 with a 2-model ensemble
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            second = {k: {v: torch.from_numpy((pred[k][v].numpy() * 0.8 + 0.05).astype(np.float32)) for v in vids} for k in pred}
+            for v in vids:
+                for k in ("valence", "arousal"):
+                    arrs["pred2.%s.%s" % (k, v)] = second[k][v].numpy()
+            torch.save({"valence_pred": pred["valence"], "arousal_pred": pred["arousal"]}, "m1.pt")
+            torch.save({"valence_pred": second["valence"], "arousal_pred": second["arousal"]}, "m2.pt")
+            open("videos.txt", "w").write("\n".join(vids) + "\n")
+            open("scores.txt", "w").write("m1.pt\nm2.pt\n")
+            create_submission.run_ensemble(open("videos.txt"), open("scores.txt"))
+            for v in vids:
+                arrs["submission." + v] = np.array(open(os.path.join("VA-Track", v + ".txt")).read())
+        finally:
+            os.chdir(cwd)
+    save(name, **arrs)
+
+
 def main():
     only = set(sys.argv[1:])
 
@@ -475,6 +537,8 @@ def main():
         case_init_digests("init_digests")
     if want("stitch"):
         case_stitch("stitch", 1000)
+    if want("postproc"):
+        case_postproc("postproc", 1100)
     if want("c5"):
         case_affwild_av("c5_affwild_av", 900)
         case_resnet3d("c5_resnet3d_cbam", 910)

@@ -177,3 +177,25 @@ def test_c3_graph(name):
         got = grad_digest(v)
         assert abs(got[0] - ref[0]) <= 2e-4 * max(1.0, ref[0]), (k, got[0], ref[0])
         close(got[2:], ref[2:], tol=2e-4, what=k)
+
+
+def test_postproc_smoothing_and_ccc():
+    """f-4: Wiener-35 / Wiener-13 / median-13 smoothing and the numpy CCC report against the reference's own functions."""
+    g = load_golden("postproc")
+    names = [str(n) for n in g["names"]]
+    allp, allg = {"valence": [], "arousal": []}, {"valence": [], "arousal": []}
+    for v in names:
+        sm = {}
+        for k in ("valence", "arousal"):
+            p = g["pred.%s.%s" % (k, v)]
+            sm[k] = O.smooth_predictions(p, 35, "wiener")
+            close(sm[k], g["wiener35.%s.%s" % (k, v)], tol=1e-6, what="wiener35 " + v)
+            close(O.smooth_predictions(p), g["wiener13.%s.%s" % (k, v)], tol=1e-6, what="wiener13 " + v)
+            close(O.smooth_predictions(p, 13, "median"), g["median13.%s.%s" % (k, v)], tol=0, what="median13 " + v)
+        gv, ga = g["gt.valence." + v], g["gt.arousal." + v]
+        valid = (gv >= -1) & (ga >= -1)
+        for k, gg in (("valence", gv), ("arousal", ga)):
+            close(O.concordance_cc2_np(sm[k][valid], gg[valid], r1_unbiased=True), g["ccc.%s.%s" % (k, v)], tol=1e-12, what="ccc " + v)
+            allp[k].append(sm[k][valid]); allg[k].append(gg[valid])
+    for k in ("valence", "arousal"):
+        close(O.concordance_cc2_np(np.concatenate(allp[k]), np.concatenate(allg[k])), g["ccc_all." + k], tol=1e-12, what="ccc_all")
