@@ -30,9 +30,15 @@ extern "C" {
 #define M3T_MAX_SCANS 8
 #define M3T_ESPIN 10002          /* a persistent scan gave up waiting for a peer workgroup (see m3t_gru_scan_fwd) */
 #define M3T_SCAN_NO_PERSIST 1    /* m3t_gru_scan_* flags: take the launch-per-step path */
+#define M3T_BF16 2               /* precision flag shared by m3t_sgemm (= M3T_GEMM_BF16), m3t_conv1d_* and m3t_gru_scan_*:
+                                  * matmul operands rounded to bf16 (nearest even), fp32 accumulate, fp32 state/epilogue */
 /* m3t_sgemm flags: BACKGROUND caps residency at one workgroup per CU (for GEMMs that run on a side stream
  * beside the latency-critical recurrence, e.g. weight gradients) */
 #define M3T_GEMM_BACKGROUND 1
+/* mixed precision (config C2 of BASELINE.json: "bf16, fp32 accumulate, fp32 master weights"): both operands are rounded
+ * to bf16 (nearest even) before the product, accumulation and epilogue stay fp32.  Interior shapes then run ONE bf16
+ * MFMA per tile step instead of the six of the fp32-accurate path. */
+#define M3T_GEMM_BF16 2
 
 /* library / device info: returns the ABI version; arch string copied to `arch` if non-null */
 int m3t_version(void);
@@ -48,7 +54,7 @@ int m3t_device_arch(char* arch, int cap);
  *   storage row of A = (k / seg_len) * seg_stride + k % seg_len + a_off, same for B
  *   with b_off (used for dW_hh = sum_t dgh_t^T h_{t-1}: per-clip shifted rows).
  * ws/ws_bytes: optional split-K workspace (deterministic slab reduction); may be NULL.
- * flags: 0 or M3T_GEMM_BACKGROUND.
+ * flags: 0, M3T_GEMM_BACKGROUND, M3T_GEMM_BF16 (or both).
  * Replaces: nn.Linear (models/rnn.py:22-55, models/model.py:88, models/att_fusion.py:13),
  * the input projections W_ih x inside nn.GRU (models/rnn.py:17,75) and their autograd. */
 int m3t_sgemm(int transA, int transB, int M, int N, int K,
@@ -185,15 +191,16 @@ int m3t_causal_conv_wgrad(const float* dy, const float* x, float* dw_t,
  *   y[b,t,co] = act( bias[co] + sum_{j,ci} w_t[j][co][ci] * x[b, t + lead - (K-1-j)*d, ci] ... )
  * lead = 0 is m3t_causal_conv_fwd; lead = pad is nn.Conv1d(k, stride 1, padding=pad) with 2*pad = (K-1)*d --
  * the `tcn_simple` back-end's Conv1d(.,.,5,1,2) / Conv1d(.,.,3,1,1) (reference models/backbone.py:107-111,
- * 214-231).  anticausal != 0 flips time (x[b, t - lead + (K-1-j)*d]): the data gradient. */
+ * 214-231).  anticausal != 0 flips time (x[b, t - lead + (K-1-j)*d]): the data gradient.
+ * flags: 0 or M3T_BF16 (x and w rounded to bf16 while staged; fp32 accumulate and epilogue). */
 int m3t_conv1d_fwd(const float* x, const float* w_t, const float* bias, const float* res,
                    const float* drop_mask, float* y, float* pre,
                    int B, int T, int Ci, int Co, int K, int dilation, int lead,
-                   int act, int anticausal, void* stream);
+                   int act, int anticausal, int flags, void* stream);
 /* dw_t[j][co][ci] = sum_{b,t} dy[b,t,co] * x[b, t + lead - (K-1-j)*d, ci] */
 int m3t_conv1d_wgrad(const float* dy, const float* x, float* dw_t,
                      int B, int T, int Ci, int Co, int K, int dilation, int lead,
-                     float* ws, size_t ws_bytes, void* stream);
+                     float* ws, size_t ws_bytes, int flags, void* stream);
 
 /* BatchNorm1d (+ optional fused ReLU) over channel-last rows x [M = B*T, C]
  * (nn.BatchNorm1d(512) + nn.ReLU(True) of `tcn_simple`, reference models/backbone.py:108-110, 217-222).

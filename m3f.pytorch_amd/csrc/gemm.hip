@@ -16,6 +16,7 @@ struct GemmParams {
     int M, N, K, lda, ldb, ldc;
     int act, accumulate, splits, kchunk;
     int seg_len, seg_stride, a_off, b_off;
+    int bf16;          // round both operands to bf16 (nearest even) before the product: the mixed-precision mode
     int vecA, vecB;
 };
 
@@ -90,6 +91,14 @@ __device__ __forceinline__ void store_mc(float* __restrict__ S, const float4 (&r
         const int c = (tid & 31) * 4;
         *reinterpret_cast<float4*>(&S[kk * LDT + c]) = r[i];
     }
+}
+
+// mixed-precision mode on this kernel: bf16 x bf16 products are exact in fp32, so rounding the operands and running
+// the fp32 MFMA gives exactly what a bf16 MFMA with fp32 accumulation gives
+__device__ __forceinline__ float rbf(float x) { return (float)(__bf16)x; }
+__device__ __forceinline__ void round_bf16(float4 (&r)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { r[i].x = rbf(r[i].x); r[i].y = rbf(r[i].y); r[i].z = rbf(r[i].z); r[i].w = rbf(r[i].w); }
 }
 
 // unguarded variants for the interior fast path (M,N % 128 == 0, K-range % 16 == 0, 16-B aligned rows)
@@ -180,6 +189,7 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GemmParams p) {
         }
     };
     auto sstore = [&](int buf) {
+        if (p.bf16) { round_bf16(ra); round_bf16(rb); }
         if (TA == 0) store_kc(As[buf], ra); else store_mc(As[buf], ra);
         if (TB == 1) store_kc(Bs[buf], rb); else store_mc(Bs[buf], rb);
     };
@@ -323,7 +333,8 @@ __global__ void mask_pos_kernel(const float* __restrict__ s, const float* __rest
 
 int m3t_sgemm_x6_launch(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                         float* C, int ldc, const float* bias, int act, int accumulate, int seg_len, int seg_stride,
-                        int a_off, int b_off, float* ws, int splits, int kchunk, size_t dyn_lds, hipStream_t s);
+                        int a_off, int b_off, float* ws, int splits, int kchunk, size_t dyn_lds, int bf16_operands,
+                        hipStream_t s);
 
 static bool x6_enabled() {
     static int on = -1;
@@ -345,6 +356,7 @@ extern "C" int m3t_sgemm(int transA, int transB, int M, int N, int K, const floa
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.act = act; p.accumulate = accumulate;
     p.seg_len = seg_len; p.seg_stride = seg_stride; p.a_off = a_off; p.b_off = b_off;
+    p.bf16 = (flags & M3T_GEMM_BF16) ? 1 : 0;
     p.vecA = (lda % 4 == 0) && ((uintptr_t)A % 16 == 0);
     p.vecB = (ldb % 4 == 0) && ((uintptr_t)B % 16 == 0);
     const int tm = cdiv(M, BM), tn = cdiv(N, BN);
@@ -352,7 +364,7 @@ extern "C" int m3t_sgemm(int transA, int transB, int M, int N, int K, const floa
     // interior shapes go to the bf16x6 kernel (fp32-accurate, 2.67x the fp32 MFMA rate): gemm_x6.hip
     const bool x6 = x6_enabled() && (M % 128 == 0) && (N % 128 == 0) && (K % 32 == 0) && K > 0 && p.vecA && p.vecB &&
                     (seg_len == 0 || seg_len >= 32);
-    const double ns_per_k = x6 ? 36.0 : 84.0;
+    const double ns_per_k = x6 ? (p.bf16 ? 14.0 : 36.0) : 84.0;
     const int kq = x6 ? 32 : BK;
     // split-K choice by a small cost model (ns): a CU works through its co-resident blocks at ~0.39 TFLOP/s
     // (84 ns per k per 128x128 block; 1.3x slower when it holds a single block), slabs cost their HBM traffic.
@@ -376,7 +388,7 @@ extern "C" int m3t_sgemm(int transA, int transB, int M, int N, int K, const floa
     if (x6) {
         const size_t dyn6 = (flags & M3T_GEMM_BACKGROUND) ? (size_t)40 * 1024 : 0;
         const int rc = m3t_sgemm_x6_launch(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, seg_len,
-                                           seg_stride, a_off, b_off, ws, splits, kchunk, dyn6, s);
+                                           seg_stride, a_off, b_off, ws, splits, kchunk, dyn6, p.bf16, s);
         if (rc) return rc;
         if (splits > 1) {
             const size_t total = (size_t)M * N;

@@ -47,6 +47,7 @@ __device__ __forceinline__ void kc_load(const float* __restrict__ p, size_t ld, 
 #pragma unroll
     for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const float4*>(p + (size_t)i * 32 * ld);
 }
+template <int NS>
 __device__ __forceinline__ void kc_store(unsigned char* __restrict__ S, const float4 (&r)[4]) {
     const int tid = threadIdx.x;
     const int c = tid & 7, r0 = tid >> 3;            // plane index c = (k-half, k-quad) of the 32-k tile
@@ -61,11 +62,12 @@ __device__ __forceinline__ void kc_store(unsigned char* __restrict__ S, const fl
             o[0][e] = h; o[1][e] = m; o[2][e] = l;
         }
 #pragma unroll
-        for (int s = 0; s < 3; ++s)
+        for (int s = 0; s < NS; ++s)
             *reinterpret_cast<bf16x4*>(S + s * SPLIT_BYTES + c * PLANE + (r0 + 32 * i) * 8) = o[s];
     }
 }
 // ---- row-contiguous operand ([K][rows]): thread = (k-quad = tid>>5 (4 k), 4 rows at (tid&31)*4): a 4x4 block
+template <int NS>
 __device__ __forceinline__ void mc_store(unsigned char* __restrict__ S, const float4 (&r)[4]) {
     const int tid = threadIdx.x;
     const int kq = tid >> 5, row0 = (tid & 31) * 4;   // k-quad kq of the 32-k tile: half = kq>>2, quad = kq&3
@@ -86,14 +88,16 @@ __device__ __forceinline__ void mc_store(unsigned char* __restrict__ S, const fl
         }
     }
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {                     // 4 rows x 8 B = 32 contiguous bytes per split
+    for (int s = 0; s < NS; ++s) {                    // 4 rows x 8 B = 32 contiguous bytes per split
         unsigned char* q = S + s * SPLIT_BYTES + kq * PLANE + row0 * 8;
         *reinterpret_cast<bf16x8*>(q) = o[s][0];
         *reinterpret_cast<bf16x8*>(q + 16) = o[s][1];
     }
 }
 
-template <int TA, int TB, bool SEG>
+// NS = 3: fp32-accurate product from 3 bf16 terms per operand (6 MFMAs per tile step);
+// NS = 1: plain bf16 operands (round to nearest even), fp32 accumulate -- the mixed-precision mode (M3T_GEMM_BF16)
+template <int TA, int TB, bool SEG, int NS>
 __global__ __launch_bounds__(256) void sgemm_x6_kernel(X6Params p) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * OPER_BYTES];   // A | B, 48 KiB
     unsigned char* As = lds;
@@ -161,8 +165,8 @@ __global__ __launch_bounds__(256) void sgemm_x6_kernel(X6Params p) {
         }
     };
     auto sstore = [&]() {
-        if (TA == 0) kc_store(As, ra); else mc_store(As, ra);
-        if (TB == 1) kc_store(Bs, rb); else mc_store(Bs, rb);
+        if (TA == 0) kc_store<NS>(As, ra); else mc_store<NS>(As, ra);
+        if (TB == 1) kc_store<NS>(Bs, rb); else mc_store<NS>(Bs, rb);
     };
 
     if (ntiles > 0) { gload(); sstore(); }
@@ -172,9 +176,9 @@ __global__ __launch_bounds__(256) void sgemm_x6_kernel(X6Params p) {
         __builtin_amdgcn_sched_barrier(0);     // the prefetch stays in flight: nothing that consumes it may be hoisted here
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
-            bf16x8 fa[3][2], fb[3][2];
+            bf16x8 fa[NS][2], fb[NS][2];
 #pragma unroll
-            for (int s = 0; s < 3; ++s)
+            for (int s = 0; s < NS; ++s)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const unsigned char* qa = As + s * SPLIT_BYTES + (kh * 4 + 2 * hi) * PLANE + (wm * 64 + i * 32 + l31) * 8;
@@ -190,11 +194,13 @@ __global__ __launch_bounds__(256) void sgemm_x6_kernel(X6Params p) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     f32x16 c = acc[i][j];      // smallest terms first
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2][i], fb[0][j], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[1][j], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[2][j], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[0][j], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[1][j], c, 0, 0, 0);
+                    if (NS == 3) {
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[NS - 1][i], fb[0][j], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[NS / 2][i], fb[NS / 2][j], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[NS - 1][j], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[NS / 2][i], fb[0][j], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[NS / 2][j], c, 0, 0, 0);
+                    }
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[0][j], c, 0, 0, 0);
                     acc[i][j] = c;
                 }
@@ -237,18 +243,25 @@ __global__ __launch_bounds__(256) void sgemm_x6_kernel(X6Params p) {
 // kchunk % 32 == 0, 16-B aligned operands with ld % 4 == 0, and seg_len >= 32 when segmented.
 int m3t_sgemm_x6_launch(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                         float* C, int ldc, const float* bias, int act, int accumulate, int seg_len, int seg_stride,
-                        int a_off, int b_off, float* ws, int splits, int kchunk, size_t dyn_lds, hipStream_t s) {
+                        int a_off, int b_off, float* ws, int splits, int kchunk, size_t dyn_lds, int bf16_operands,
+                        hipStream_t s) {
     X6Params p;
     p.A = A; p.B = B; p.C = C; p.bias = bias; p.ws = ws;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.act = act; p.accumulate = accumulate; p.splits = splits; p.kchunk = kchunk;
     p.seg_len = seg_len; p.seg_stride = seg_stride; p.a_off = a_off; p.b_off = b_off;
     dim3 grid(N / XN, M / XM, splits), block(256);
-    if (seg_len > 0) sgemm_x6_kernel<1, 0, true><<<grid, block, dyn_lds, s>>>(p);
-    else if (transA == 0 && transB == 1) sgemm_x6_kernel<0, 1, false><<<grid, block, dyn_lds, s>>>(p);
-    else if (transA == 0 && transB == 0) sgemm_x6_kernel<0, 0, false><<<grid, block, dyn_lds, s>>>(p);
-    else if (transA == 1 && transB == 0) sgemm_x6_kernel<1, 0, false><<<grid, block, dyn_lds, s>>>(p);
-    else sgemm_x6_kernel<1, 1, false><<<grid, block, dyn_lds, s>>>(p);
+#define M3T_X6_DISPATCH(NS_)                                                                                        \
+    do {                                                                                                           \
+        if (seg_len > 0) sgemm_x6_kernel<1, 0, true, NS_><<<grid, block, dyn_lds, s>>>(p);                         \
+        else if (transA == 0 && transB == 1) sgemm_x6_kernel<0, 1, false, NS_><<<grid, block, dyn_lds, s>>>(p);   \
+        else if (transA == 0 && transB == 0) sgemm_x6_kernel<0, 0, false, NS_><<<grid, block, dyn_lds, s>>>(p);   \
+        else if (transA == 1 && transB == 0) sgemm_x6_kernel<1, 0, false, NS_><<<grid, block, dyn_lds, s>>>(p);   \
+        else sgemm_x6_kernel<1, 1, false, NS_><<<grid, block, dyn_lds, s>>>(p);                                    \
+    } while (0)
+    if (bf16_operands) M3T_X6_DISPATCH(1);
+    else M3T_X6_DISPATCH(3);
+#undef M3T_X6_DISPATCH
     hipError_t e = hipGetLastError();
     return (int)e;
 }

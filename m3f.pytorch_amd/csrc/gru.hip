@@ -40,7 +40,7 @@ __device__ __forceinline__ float4 ld4(const float* __restrict__ p, int nvalid, b
 template <int CT, int NC, bool FAST>
 __device__ __forceinline__ void wave_mma(const float* __restrict__ A, const size_t (&arow)[2], const bool (&aok)[2],
                                          const float* __restrict__ Bt, const size_t (&brow)[CT], const bool (&bok)[CT],
-                                         int K, bool vecA, bool vecB, int wave, int lane, f32x4 (&acc)[2][CT]) {
+                                         int K, bool vecA, bool vecB, int wave, int lane, f32x4 (&acc)[2][CT], bool bf = false) {
     const int kq = (lane >> 4) * 4;
     const int nchunks = (K + 15) >> 4;
     for (int c0 = wave; c0 < nchunks; c0 += NW * NC) {
@@ -64,6 +64,15 @@ __device__ __forceinline__ void wave_mma(const float* __restrict__ A, const size
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
                     b[i][ct] = (bok[ct] && nv > 0) ? ld4(Bt + brow[ct] + kk, nv, vecB) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        if (bf) {
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) a[i][rt] = rbf4(a[i][rt]);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) b[i][ct] = rbf4(b[i][ct]);
             }
         }
 #pragma unroll
@@ -94,7 +103,7 @@ __device__ __forceinline__ void wave_mma(const float* __restrict__ A, const size
 //           addition to out[b,t,:] (ping-pong by step parity): each workgroup owns exactly chunk == its unit-block,
 //           i.e. one contiguous 2 KiB piece.
 // Backward mirrors it with dgh_t (3H wide) and W_hh^T.
-__global__ void wfrag_fwd_prep_kernel(const float* __restrict__ w_hh, float* __restrict__ wfrag, int H) {
+__global__ void wfrag_fwd_prep_kernel(const float* __restrict__ w_hh, float* __restrict__ wfrag, int H, int bf16) {
     const int nch = H >> 4;
     const size_t total = (size_t)3 * H * H;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -102,18 +111,20 @@ __global__ void wfrag_fwd_prep_kernel(const float* __restrict__ w_hh, float* __r
         size_t r = i >> 8;
         const int ct = r % 3; r /= 3;
         const int c = r % nch, ub = r / nch;
-        wfrag[i] = w_hh[((size_t)ct * H + ub * 16 + (l & 15)) * H + c * 16 + (l >> 4) * 4 + e];
+        const float v = w_hh[((size_t)ct * H + ub * 16 + (l & 15)) * H + c * 16 + (l >> 4) * 4 + e];
+        wfrag[i] = bf16 ? rbf(v) : v;
     }
 }
 // wtfrag[ub][c][lane][e] = W_hh[k = 16c + 4*(lane>>4) + e][ub*16 + (lane&15)] = w_hh_t[ub*16 + (lane&15)][k]
-__global__ void wfrag_bwd_prep_kernel(const float* __restrict__ w_hh_t, float* __restrict__ wtfrag, int H) {
+__global__ void wfrag_bwd_prep_kernel(const float* __restrict__ w_hh_t, float* __restrict__ wtfrag, int H, int bf16) {
     const int nch = (3 * H) >> 4;
     const size_t total = (size_t)3 * H * H;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int e = i & 3, l = (i >> 2) & 63;
         const size_t r = i >> 8;
         const int c = r % nch, ub = r / nch;
-        wtfrag[i] = w_hh_t[((size_t)ub * 16 + (l & 15)) * 3 * H + c * 16 + (l >> 4) * 4 + e];
+        const float v = w_hh_t[((size_t)ub * 16 + (l & 15)) * 3 * H + c * 16 + (l >> 4) * 4 + e];
+        wtfrag[i] = bf16 ? rbf(v) : v;
     }
 }
 
@@ -211,7 +222,7 @@ __global__ __launch_bounds__(NT) void gru_step_fwd_frag_kernel(FwdGroup g, FragP
     const GateFwd c = gru_cell_fwd(xr, xz, xn, hr, hz, hn, hprev);
     const float r = c.r, z = c.z, n = c.n, h = c.h;
     // fragment-ordered copy for the next step: chunk == ub, tile = prow>>4, lane = (pu>>2)*16 + (prow&15), e = pu&3
-    hout[(((size_t)ub * RT + (prow >> 4)) * 64 + (pu >> 2) * 16 + (prow & 15)) * 4 + (pu & 3)] = pok ? h : 0.f;
+    hout[(((size_t)ub * RT + (prow >> 4)) * 64 + (pu >> 2) * 16 + (prow & 15)) * 4 + (pu & 3)] = pok ? (g.bf16 ? rbf(h) : h) : 0.f;
     if (!pok) return;
     d.out[((size_t)pb * T + t) * d.ldo + d.ooff + pj] = h;
     if (d.gates) {
@@ -279,9 +290,9 @@ __global__ __launch_bounds__(NT) void gru_step_bwd_frag_kernel(BwdGroup g, FragP
     const float dht = c.dht, dn = c.dn, dz = c.dz, dr = c.dr;
     // fragment-ordered dgh for the next launch: gate g lives in chunk g*(H/16) + ub
     const size_t fo = ((size_t)(prow >> 4) * 64 + (pu >> 2) * 16 + (prow & 15)) * 4 + (pu & 3);
-    gout[((size_t)(0 * nchh + ub) * RT) * 256 + fo] = pok ? dr : 0.f;
-    gout[((size_t)(1 * nchh + ub) * RT) * 256 + fo] = pok ? dz : 0.f;
-    gout[((size_t)(2 * nchh + ub) * RT) * 256 + fo] = pok ? c.dnr : 0.f;
+    gout[((size_t)(0 * nchh + ub) * RT) * 256 + fo] = pok ? (g.bf16 ? rbf(dr) : dr) : 0.f;
+    gout[((size_t)(1 * nchh + ub) * RT) * 256 + fo] = pok ? (g.bf16 ? rbf(dz) : dz) : 0.f;
+    gout[((size_t)(2 * nchh + ub) * RT) * 256 + fo] = pok ? (g.bf16 ? rbf(c.dnr) : c.dnr) : 0.f;
     if (!pok) return;
     float* gx = d.dgx + ((size_t)pb * T + t) * d.ldg + d.goff;
     gx[pj] = dr; gx[H + pj] = dz; gx[2 * H + pj] = dn;
@@ -338,7 +349,7 @@ __global__ __launch_bounds__(NT) void gru_step_fwd_kernel(FwdGroup g, int B, int
         }
         const bool vecA = ((d.ldo | d.ooff) & 3) == 0 && ((uintptr_t)d.out & 15) == 0;
         const bool vecB = (H & 3) == 0 && ((uintptr_t)d.w_hh & 15) == 0;
-        wave_mma<3, CF, FAST>(d.out, aoff, aok, d.w_hh, boff, bok, H, vecA, vecB, wave, lane, acc);
+        wave_mma<3, CF, FAST>(d.out, aoff, aok, d.w_hh, boff, bok, H, vecA, vecB, wave, lane, acc, g.bf16 != 0);
         // C/D map 16x16: col = lane&15, row = (lane>>4)*4 + reg
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
@@ -418,7 +429,7 @@ __global__ __launch_bounds__(NT) void gru_step_bwd_kernel(BwdGroup g, int B, int
         boff[0] = (size_t)(FAST ? min(j, H - 1) : j) * H3;
         const bool vecA = (H3 & 3) == 0 && ((uintptr_t)d.dgh & 15) == 0;
         const bool vecB = (H3 & 3) == 0 && ((uintptr_t)d.w_hh_t & 15) == 0;
-        wave_mma<1, CB, FAST>(d.dgh, aoff, aok, d.w_hh_t, boff, bok, H3, vecA, vecB, wave, lane, acc);
+        wave_mma<1, CB, FAST>(d.dgh, aoff, aok, d.w_hh_t, boff, bok, H3, vecA, vecB, wave, lane, acc, g.bf16 != 0);
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -579,6 +590,7 @@ extern "C" int m3t_gru_scan_fwd(const m3t_gru_fwd_desc* scans, int n_scans, int 
     FwdGroup g;
     std::memset(&g, 0, sizeof(g));
     g.n = n_scans;
+    g.bf16 = (flags & M3T_BF16) ? 1 : 0;
     int blocks = 0;
     for (int i = 0; i < n_scans; ++i) {
         if (scans[i].H <= 0 || !scans[i].xproj || !scans[i].w_hh || !scans[i].b_hh || !scans[i].out) return M3T_EINVAL;
@@ -613,6 +625,7 @@ extern "C" int m3t_gru_scan_fwd(const m3t_gru_fwd_desc* scans, int n_scans, int 
         std::memset(&fg, 0, sizeof(fg));
         std::memset(&fp, 0, sizeof(fp));
         fg.n = n_scans;
+        fg.bf16 = g.bf16;
         float* p = ws;
         int nblk = 0;
         for (int i = 0; i < n_scans; ++i) {
@@ -630,7 +643,7 @@ extern "C" int m3t_gru_scan_fwd(const m3t_gru_fwd_desc* scans, int n_scans, int 
                 const int H = fg.d[i].H;
                 int blk = (3 * H * H + 255) / 256;
                 if (blk > 1024) blk = 1024;
-                wfrag_fwd_prep_kernel<<<blk, 256, 0, s>>>(fg.d[i].w_hh, fp.wfrag[i], H);
+                wfrag_fwd_prep_kernel<<<blk, 256, 0, s>>>(fg.d[i].w_hh, fp.wfrag[i], H, fg.bf16);
             }
             M3T_LAUNCH_CHECK();
             return persist_fwd_launch(fg, fp, B, T, s);
@@ -640,7 +653,7 @@ extern "C" int m3t_gru_scan_fwd(const m3t_gru_fwd_desc* scans, int n_scans, int 
                 const int H = fg.d[i].H;
                 int blk = (3 * H * H + 255) / 256;
                 if (blk > 1024) blk = 1024;
-                wfrag_fwd_prep_kernel<<<blk, 256, 0, s>>>(fg.d[i].w_hh, fp.wfrag[i], H);
+                wfrag_fwd_prep_kernel<<<blk, 256, 0, s>>>(fg.d[i].w_hh, fp.wfrag[i], H, fg.bf16);
             }
             if (rt == 2)
                 for (int step = 0; step < T; ++step) gru_step_fwd_frag_kernel<2><<<nblk, NT, 0, s>>>(fg, fp, B, T, step);
@@ -664,6 +677,7 @@ extern "C" int m3t_gru_scan_bwd(const m3t_gru_bwd_desc* scans, int n_scans, int 
     BwdGroup g;
     std::memset(&g, 0, sizeof(g));
     g.n = n_scans;
+    g.bf16 = (flags & M3T_BF16) ? 1 : 0;
     int blocks = 0;
     for (int i = 0; i < n_scans; ++i) {
         const m3t_gru_bwd_desc& d = scans[i];
@@ -697,6 +711,7 @@ extern "C" int m3t_gru_scan_bwd(const m3t_gru_bwd_desc* scans, int n_scans, int 
         std::memset(&bg, 0, sizeof(bg));
         std::memset(&fp, 0, sizeof(fp));
         bg.n = n_scans;
+        bg.bf16 = g.bf16;
         float* p = ws;
         int nblk = 0;
         for (int i = 0; i < n_scans; ++i) {
@@ -713,7 +728,7 @@ extern "C" int m3t_gru_scan_bwd(const m3t_gru_bwd_desc* scans, int n_scans, int 
                 const int H = bg.d[i].H;
                 int blk = (3 * H * H + 255) / 256;
                 if (blk > 1024) blk = 1024;
-                wfrag_bwd_prep_kernel<<<blk, 256, 0, s>>>(bg.d[i].w_hh_t, fp.wfrag[i], H);
+                wfrag_bwd_prep_kernel<<<blk, 256, 0, s>>>(bg.d[i].w_hh_t, fp.wfrag[i], H, bg.bf16);
             }
             M3T_LAUNCH_CHECK();
             return persist_bwd_launch(bg, fp, B, T, s);
@@ -723,7 +738,7 @@ extern "C" int m3t_gru_scan_bwd(const m3t_gru_bwd_desc* scans, int n_scans, int 
                 const int H = bg.d[i].H;
                 int blk = (3 * H * H + 255) / 256;
                 if (blk > 1024) blk = 1024;
-                wfrag_bwd_prep_kernel<<<blk, 256, 0, s>>>(bg.d[i].w_hh_t, fp.wfrag[i], H);
+                wfrag_bwd_prep_kernel<<<blk, 256, 0, s>>>(bg.d[i].w_hh_t, fp.wfrag[i], H, bg.bf16);
             }
             if (rt == 2)
                 for (int step = 0; step < T; ++step) gru_step_bwd_frag_kernel<2><<<nblk, NT, 0, s>>>(bg, fp, B, T, step);

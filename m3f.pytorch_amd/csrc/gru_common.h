@@ -13,12 +13,19 @@ struct FwdGroup {
     m3t_gru_fwd_desc d[M3T_MAX_SCANS];
     int blk_start[M3T_MAX_SCANS + 1];
     int n;
+    int bf16;     // M3T_BF16: the recurrent product takes bf16-rounded h_{t-1} and W_hh (fp32 accumulate, fp32 state)
 };
 struct BwdGroup {
     m3t_gru_bwd_desc d[M3T_MAX_SCANS];
     int blk_start[M3T_MAX_SCANS + 1];
     int n;
+    int bf16;     // M3T_BF16: dgh_{t+1} and W_hh rounded to bf16 in the recurrent product
 };
+
+// bf16 x bf16 products are exact in fp32: rounding the operands and using the fp32 MFMA is exactly a bf16 MFMA with
+// fp32 accumulation
+__device__ __forceinline__ float rbf(float x) { return (float)(__bf16)x; }
+__device__ __forceinline__ float4 rbf4(float4 v) { return make_float4(rbf(v.x), rbf(v.y), rbf(v.z), rbf(v.w)); }
 struct FragPtrs {
     float* wfrag[M3T_MAX_SCANS];    // fragment-ordered weights
     float* xfrag[M3T_MAX_SCANS];    // 2 ping-pong buffers of fragment-ordered h_t (fwd) / dgh_t (bwd)

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(NT) void gru_persist_fwd_kernel(FwdGroup g, FragPtr
 #pragma unroll
         for (int m = 0; m < NC; ++m)
 #pragma unroll
-            for (int ct = 0; ct < 3; ++ct) wf[m][ct] = Wf[((size_t)(wave + m * NW) * 3 + ct) * 64 + lane];
+            for (int ct = 0; ct < 3; ++ct) wf[m][ct] = Wf[((size_t)(wave + m * NW) * 3 + ct) * 64 + lane];     // already bf16-rounded by the prep kernel in M3T_BF16 mode
     }
     // gate-math threads, one (row, unit) each, numbered in GRANULE order: thread i owns granule i of the workgroup's
     // tile, so a wave publishes 64 consecutive granules = whole 128-B lines.  (A wave publishing 16 separate 32-B
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(NT) void gru_persist_fwd_kernel(FwdGroup g, FragPtr
             }
             const GateFwd c = gru_cell_fwd(xr, xz, xn, hr, hz, hn, hprev);
             if (step + 1 < T) {                        // publish: the only store on the chain
-                const unsigned long long gq = ((unsigned long long)((unsigned)step + 1u) << 32) | __float_as_uint(pok ? c.h : 0.f);
+                const unsigned long long gq = ((unsigned long long)((unsigned)step + 1u) << 32) | __float_as_uint(pok ? (g.bf16 ? rbf(c.h) : c.h) : 0.f);
                 __hip_atomic_store(gran + (size_t)(step & 1) * slot + pub, gq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             M3T_STAMP(4);
@@ -326,8 +326,9 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd_kernel(BwdGroup g, FragPtr
             const GateBwd c = gru_cell_bwd(dout, dh_carry, z_next, mm, has_next, gr, gz, gn, ghn, hprev);
             if (step + 1 < T) {
                 u32x4 gq;
-                gq.x = __float_as_uint(pok ? c.dr : 0.f); gq.y = __float_as_uint(pok ? c.dz : 0.f);
-                gq.z = __float_as_uint(pok ? c.dnr : 0.f); gq.w = (unsigned)step + 1u;
+                const bool bf = g.bf16 != 0;
+                gq.x = __float_as_uint(pok ? (bf ? rbf(c.dr) : c.dr) : 0.f); gq.y = __float_as_uint(pok ? (bf ? rbf(c.dz) : c.dz) : 0.f);
+                gq.z = __float_as_uint(pok ? (bf ? rbf(c.dnr) : c.dnr) : 0.f); gq.w = (unsigned)step + 1u;
                 u32x4* q = gran + (size_t)(step & 1) * slot + pub;
                 asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(q), "v"(gq) : "memory");
             }

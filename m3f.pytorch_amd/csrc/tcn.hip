@@ -15,9 +15,14 @@ namespace {
 
 constexpr int BM = 128, BN = 128, BK = 16, LDB = 132;
 
+// M3T_BF16: operands rounded to bf16 while they are staged; products of bf16 values are exact in fp32, so the fp32
+// MFMA then computes exactly a bf16 MFMA with fp32 accumulation
+__device__ __forceinline__ float rbf(float x) { return (float)(__bf16)x; }
+__device__ __forceinline__ float4 rbf4(float4 v) { return make_float4(rbf(v.x), rbf(v.y), rbf(v.z), rbf(v.w)); }
+
 struct ConvParams {
     const float* x; const float* w_t; const float* bias; const float* res; const float* mask; float* y; float* pre;
-    int B, T, Ci, Co, K, dil, act, anti, halo, lead, lda, w_kn, vecx, vecw;
+    int B, T, Ci, Co, K, dil, act, anti, halo, lead, lda, w_kn, vecx, vecw, bf16;
 };
 
 // dynamic LDS: As[BK][lda] (lda = BM + halo + pad), Bs[K][BK][LDB]
@@ -74,6 +79,7 @@ __global__ __launch_bounds__(256) void causal_conv_kernel(ConvParams p) {
                     if (nv > 3) v.w = q[3];
                 }
             }
+            if (p.bf16) v = rbf4(v);
             As[(kc + 0) * p.lda + r] = v.x;
             As[(kc + 1) * p.lda + r] = v.y;
             As[(kc + 2) * p.lda + r] = v.z;
@@ -100,6 +106,7 @@ __global__ __launch_bounds__(256) void causal_conv_kernel(ConvParams p) {
                             if (nv > 3) v.w = q[3];
                         }
                     }
+                    if (p.bf16) v = rbf4(v);
                     Bj[(kc + 0) * LDB + r] = v.x;
                     Bj[(kc + 1) * LDB + r] = v.y;
                     Bj[(kc + 2) * LDB + r] = v.z;
@@ -124,6 +131,7 @@ __global__ __launch_bounds__(256) void causal_conv_kernel(ConvParams p) {
                             if (nv > 3) v.w = q[3];
                         }
                     }
+                    if (p.bf16) v = rbf4(v);
                     *reinterpret_cast<float4*>(&Bj[kk * LDB + c]) = v;
                 }
             }
@@ -257,14 +265,14 @@ extern "C" int m3t_weight_norm_bwd(const float* dw_t, const float* v, const floa
 
 extern "C" int m3t_conv1d_fwd(const float* x, const float* w_t, const float* bias, const float* res,
                               const float* drop_mask, float* y, float* pre, int B, int T, int Ci, int Co, int K,
-                              int dilation, int lead, int act, int anticausal, void* stream) {
+                              int dilation, int lead, int act, int anticausal, int flags, void* stream) {
     if (B <= 0 || T <= 0) return 0;
     if (Ci <= 0 || Co <= 0 || K <= 0 || dilation <= 0 || !x || !w_t || !y) return M3T_EINVAL;
     if (lead < 0 || lead > (K - 1) * dilation) return M3T_EINVAL;
     if (act == 2 && !res) return M3T_EINVAL;
     ConvParams p;
     p.x = x; p.w_t = w_t; p.bias = bias; p.res = res; p.mask = drop_mask; p.y = y; p.pre = pre;
-    p.B = B; p.T = T; p.Ci = Ci; p.Co = Co; p.K = K; p.dil = dilation; p.act = act; p.anti = anticausal; p.lead = lead;
+    p.B = B; p.T = T; p.Ci = Ci; p.Co = Co; p.K = K; p.dil = dilation; p.act = act; p.anti = anticausal; p.lead = lead; p.bf16 = (flags & M3T_BF16) ? 1 : 0;
     const int halo = (K - 1) * dilation;
     p.halo = halo;
     p.lda = ((BM + halo - 4 + 31) / 32) * 32 + 4;   // == 4 (mod 32): 2-way (free) transposing LDS writes
@@ -292,11 +300,11 @@ extern "C" int m3t_conv1d_fwd(const float* x, const float* w_t, const float* bia
 extern "C" int m3t_causal_conv_fwd(const float* x, const float* w_t, const float* bias, const float* res,
                                    const float* drop_mask, float* y, float* pre, int B, int T, int Ci, int Co, int K,
                                    int dilation, int act, int anticausal, void* stream) {
-    return m3t_conv1d_fwd(x, w_t, bias, res, drop_mask, y, pre, B, T, Ci, Co, K, dilation, 0, act, anticausal, stream);
+    return m3t_conv1d_fwd(x, w_t, bias, res, drop_mask, y, pre, B, T, Ci, Co, K, dilation, 0, act, anticausal, 0, stream);
 }
 
 extern "C" int m3t_conv1d_wgrad(const float* dy, const float* x, float* dw_t, int B, int T, int Ci, int Co, int K,
-                                int dilation, int lead, float* ws, size_t ws_bytes, void* stream) {
+                                int dilation, int lead, float* ws, size_t ws_bytes, int flags, void* stream) {
     if (Ci <= 0 || Co <= 0 || K <= 0 || !dy || !x || !dw_t) return M3T_EINVAL;
     if (lead < 0 || lead > (K - 1) * dilation) return M3T_EINVAL;
     for (int j = 0; j < K; ++j) {
@@ -310,7 +318,7 @@ extern "C" int m3t_conv1d_wgrad(const float* dy, const float* x, float* dw_t, in
         }
         // dw_t[j][co][ci] = sum_b sum_t dy[b,t,co] * x[b,t+off,ci] over the t with both rows inside the clip
         const int rc = m3t_sgemm(1, 0, Co, Ci, B * (T - span), dy, Co, x, Ci, out, Ci, nullptr, 0, 0, T - span, T, aoff, boff,
-                                 ws, ws_bytes, 0, stream);
+                                 ws, ws_bytes, (flags & M3T_BF16) ? M3T_GEMM_BF16 : 0, stream);
         if (rc) return rc;
     }
     return 0;
@@ -318,7 +326,7 @@ extern "C" int m3t_conv1d_wgrad(const float* dy, const float* x, float* dw_t, in
 
 extern "C" int m3t_causal_conv_wgrad(const float* dy, const float* x, float* dw_t, int B, int T, int Ci, int Co, int K,
                                      int dilation, float* ws, size_t ws_bytes, void* stream) {
-    return m3t_conv1d_wgrad(dy, x, dw_t, B, T, Ci, Co, K, dilation, 0, ws, ws_bytes, stream);
+    return m3t_conv1d_wgrad(dy, x, dw_t, B, T, Ci, Co, K, dilation, 0, ws, ws_bytes, 0, stream);
 }
 
 extern "C" int m3t_bct_to_btc(const float* src, float* dst, int B, int C, int T, void* stream) {

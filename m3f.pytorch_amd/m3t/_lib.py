@@ -9,6 +9,7 @@ CSRC_DIR = os.path.join(os.path.dirname(_HERE), "csrc")
 M3T_EINVAL = 10001
 M3T_ESPIN = 10002
 M3T_SCAN_NO_PERSIST = 1
+M3T_BF16 = 2
 M3T_MAX_SCANS = 8
 
 _f = C.c_void_p      # device pointer
@@ -47,8 +48,8 @@ SIGNATURES = {
     "m3t_weight_norm_bwd": [_f, _f, _f, _f, _f, _f, _i, _i, _i, _s],
     "m3t_causal_conv_fwd": [_f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _s],
     "m3t_causal_conv_wgrad": [_f, _f, _f, _i, _i, _i, _i, _i, _i, _f, _z, _s],
-    "m3t_conv1d_fwd": [_f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _s],
-    "m3t_conv1d_wgrad": [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _z, _s],
+    "m3t_conv1d_fwd": [_f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _s],
+    "m3t_conv1d_wgrad": [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _z, _i, _s],
     "m3t_bn_rows_ws_bytes": [_i, _i],
     "m3t_bn_rows_fwd": [_f, _i, _i, _f, _f, _f, _f, C.c_float, C.c_float, _i, _i, _f, _f, _f, _f, _z, _s],
     "m3t_bn_rows_bwd": [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _f, _f, _f, _f, _z, _s],

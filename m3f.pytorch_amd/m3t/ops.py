@@ -109,13 +109,40 @@ def workspace(device, nbytes=_WS_MIN, tag=None):
 
 
 # ----------------------------------------------------------------------------- raw wrappers
+# ---- arithmetic mode of the dense contractions --------------------------------------------------------------------
+# "fp32" (default): fp32-accurate everywhere (what the reference computes).  "bf16": BASELINE.json config C2 -- every
+# matmul / conv / recurrent-product operand (activation, weight, gradient) is rounded to bf16, accumulation, state,
+# biases, gate math, normalisation and the loss stay fp32, parameters stay fp32 ("master weights").  An autograd
+# Function records the mode of its forward and uses it for its backward.
+_PREC = [0]
+
+
+class precision:
+    """`with ops.precision("bf16"): y = model(x)` -- context manager selecting the arithmetic mode."""
+
+    def __init__(self, mode):
+        if mode not in ("fp32", "bf16"):
+            raise ValueError("precision mode must be 'fp32' or 'bf16'")
+        self.flag = _lib.M3T_BF16 if mode == "bf16" else 0
+
+    def __enter__(self):
+        self.prev = _PREC[0]
+        _PREC[0] = self.flag
+        return self
+
+    def __exit__(self, *exc):
+        _PREC[0] = self.prev
+        return False
+
+
 def sgemm(transA, transB, M, N, K, A, a_off, lda, B, b_off, ldb, Cm, c_off, ldc, bias=None, act=0,
-          accumulate=False, seg=(0, 0, 0, 0), use_ws=True, background=False):
+          accumulate=False, seg=(0, 0, 0, 0), use_ws=True, background=False, prec=None):
     ws = workspace(Cm.device) if use_ws else None
+    flags = (1 if background else 0) | (_PREC[0] if prec is None else prec)
     with _Timed("sgemm_kernel", 1, 2.0 * M * N * K) if PROFILE_GEMM[0] else _NULL:
         rc = lib().m3t_sgemm(transA, transB, M, N, K, _p(A, a_off), lda, _p(B, b_off), ldb, _p(Cm, c_off), ldc,
                              _p(bias), act, int(accumulate), seg[0], seg[1], seg[2], seg[3],
-                             _p(ws), (ws.numel() * 4) if ws is not None else 0, 1 if background else 0, _stream())
+                             _p(ws), (ws.numel() * 4) if ws is not None else 0, flags, _stream())
     _lib.check(rc, "m3t_sgemm")
 
 
@@ -150,7 +177,8 @@ class _Linear(torch.autograd.Function):
         N = w.shape[0]
         M = x.numel() // K
         y = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
-        sgemm(0, 1, M, N, K, x, 0, K, w, 0, K, y, 0, N, bias=b, act=act)
+        ctx.prec = _PREC[0]
+        sgemm(0, 1, M, N, K, x, 0, K, w, 0, K, y, 0, N, bias=b, act=act, prec=ctx.prec)
         ctx.save_for_backward(x, w, y if act else None)
         ctx.act, ctx.has_bias = act, b is not None
         return y
@@ -166,10 +194,10 @@ class _Linear(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            sgemm(0, 0, M, K, N, dy, 0, N, w, 0, K, dx, 0, K)
+            sgemm(0, 0, M, K, N, dy, 0, N, w, 0, K, dx, 0, K, prec=ctx.prec)
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
-            sgemm(1, 0, N, K, M, dy, 0, N, x, 0, K, dw, 0, K)
+            sgemm(1, 0, N, K, M, dy, 0, N, x, 0, K, dw, 0, K, prec=ctx.prec)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = torch.empty(N, dtype=x.dtype, device=x.device)
             colsum(dy, 0, M, N, N, db)
@@ -190,7 +218,7 @@ def _scan_flags(device):
     return _lib.M3T_SCAN_NO_PERSIST if (SCAN_PER_STEP[0] or _ws_tag(device) == "side") else 0
 
 
-def _scan_fwd(descs, B, T):
+def _scan_fwd(descs, B, T, prec=0):
     for i in range(0, len(descs), M3T_MAX_SCANS):
         chunk = descs[i:i + M3T_MAX_SCANS]
         arr = (GruFwdDesc * len(chunk))(*chunk)
@@ -199,13 +227,13 @@ def _scan_fwd(descs, B, T):
             dev = torch.device("cuda", torch.cuda.current_device())
             ws = workspace(dev)
             n0 = lib().m3t_gru_persist_count() if tm.rec is not None else 0
-            rc = lib().m3t_gru_scan_fwd(arr, len(chunk), B, T, _p(ws), ws.numel() * 4, _scan_flags(dev), _stream())
+            rc = lib().m3t_gru_scan_fwd(arr, len(chunk), B, T, _p(ws), ws.numel() * 4, _scan_flags(dev) | prec, _stream())
             if tm.rec is not None and lib().m3t_gru_persist_count() != n0:      # one launch ran all T steps
                 tm.rec.update(kernel="gru_persist_fwd_kernel", launches=1, steps=T)
         _lib.check(rc, "m3t_gru_scan_fwd")
 
 
-def _scan_bwd(descs, B, T):
+def _scan_bwd(descs, B, T, prec=0):
     for i in range(0, len(descs), M3T_MAX_SCANS):
         chunk = descs[i:i + M3T_MAX_SCANS]
         arr = (GruBwdDesc * len(chunk))(*chunk)
@@ -214,7 +242,7 @@ def _scan_bwd(descs, B, T):
             dev = torch.device("cuda", torch.cuda.current_device())
             ws = workspace(dev)
             n0 = lib().m3t_gru_persist_count() if tm.rec is not None else 0
-            rc = lib().m3t_gru_scan_bwd(arr, len(chunk), B, T, _p(ws), ws.numel() * 4, _scan_flags(dev), _stream())
+            rc = lib().m3t_gru_scan_bwd(arr, len(chunk), B, T, _p(ws), ws.numel() * 4, _scan_flags(dev) | prec, _stream())
             if tm.rec is not None and lib().m3t_gru_persist_count() != n0:
                 tm.rec.update(kernel="gru_persist_bwd_kernel", launches=1, steps=T)
         _lib.check(rc, "m3t_gru_scan_bwd")
@@ -273,6 +301,7 @@ class _MultiBiGRU(torch.autograd.Function):
         gates = [[new(2, B, T, 4 * Hs[s]) for s in range(n_stacks)] for _ in range(L)]
         xprojs = [[new(B, T, 6 * Hs[s]) for s in range(n_stacks)] for _ in range(L)]
         main = torch.cuda.current_stream()
+        prec = _PREC[0]
         groups = _stream_groups(Hs, B)
         for kind, idxs in groups:
             stream = main
@@ -288,16 +317,16 @@ class _MultiBiGRU(torch.autograd.Function):
                         I = inp.shape[-1]
                         for d in (0, 1):
                             w_ih, w_hh, b_ih, b_hh = params[s][(2 * l + d) * 4:(2 * l + d) * 4 + 4]
-                            sgemm(0, 1, B * T, 3 * H, I, inp, 0, I, w_ih, 0, I, xprojs[l][s], d * 3 * H, 6 * H, bias=b_ih)
+                            sgemm(0, 1, B * T, 3 * H, I, inp, 0, I, w_ih, 0, I, xprojs[l][s], d * 3 * H, 6 * H, bias=b_ih, prec=prec)
                             descs.append(GruFwdDesc(_vp(xprojs[l][s]), _vp(w_hh), _vp(b_hh), _vp(outs[l][s]),
                                                     _vp(gates[l][s], d * B * T * 4 * H), _vp(h_ns[s], (2 * l + d) * B * H),
                                                     H, d, 6 * H, d * 3 * H, 2 * H, d * H))
-                    _scan_fwd(descs, B, T)
+                    _scan_fwd(descs, B, T, prec)
         for kind, _ in groups:
             if kind == "side":
                 main.wait_stream(side_stream(dev))
         del xprojs
-        ctx.n_stacks, ctx.L, ctx.Hs, ctx.B, ctx.T = n_stacks, L, Hs, B, T
+        ctx.n_stacks, ctx.L, ctx.Hs, ctx.B, ctx.T, ctx.prec = n_stacks, L, Hs, B, T, prec
         saved = []
         for l in range(L):
             for s in range(n_stacks):
@@ -367,7 +396,7 @@ class _MultiBiGRU(torch.autograd.Function):
                                                     _vp(dhns[s], (2 * l + d) * B * H) if dhns[s] is not None else None,
                                                     _vp(dgx[l][s]), _vp(dgh[l][s], d * B * T * 3 * H), _vp(dh[l][s], d * B * H),
                                                     H, d, 2 * H, d * H, 6 * H, d * 3 * H))
-                    _scan_bwd(descs, B, T)
+                    _scan_bwd(descs, B, T, ctx.prec)
                     for s in idxs:
                         H = Hs[s]
                         inp, out, gts = layer_io(l, s)
@@ -375,7 +404,7 @@ class _MultiBiGRU(torch.autograd.Function):
                         if need_dx[l][s]:          # critical path first: feeds the next level's scan
                             for d in (0, 1):
                                 sgemm(0, 0, B * T, I, 3 * H, dgx[l][s], d * 3 * H, 6 * H, params[s][(2 * l + d) * 4], 0, I,
-                                      dinp[l][s], 0, I, accumulate=(d == 1))
+                                      dinp[l][s], 0, I, accumulate=(d == 1), prec=ctx.prec)
                             cur[s] = dinp[l][s]
                         for d in (0, 1):
                             base = s * per + 1 + (2 * l + d) * 4
@@ -385,11 +414,11 @@ class _MultiBiGRU(torch.autograd.Function):
                                 # dW_hh = sum_{b,t} dgh[b,t]^T h_prev(b,t): forward pairs (t, t-1), reverse pairs (t, t+1)
                                 a_off, b_off = (1, 0) if d == 0 else (0, 1)
                                 sgemm(1, 0, 3 * H, H, B * (T - 1), dgh[l][s], goff, 3 * H, out, d * H, 2 * H, dw_hh, 0, H,
-                                      seg=(T - 1, T, a_off, b_off))
+                                      seg=(T - 1, T, a_off, b_off), prec=ctx.prec)
                             else:
                                 dw_hh.zero_()
                             colsum(dgh[l][s], goff, B * T, 3 * H, 3 * H, db_hh)
-                            sgemm(1, 0, 3 * H, I, B * T, dgx[l][s], d * 3 * H, 6 * H, inp, 0, I, dw_ih, 0, I)
+                            sgemm(1, 0, 3 * H, I, B * T, dgx[l][s], d * 3 * H, 6 * H, inp, 0, I, dw_ih, 0, I, prec=ctx.prec)
                             colsum(dgx[l][s], d * 3 * H, B * T, 3 * H, 6 * H, db_ih)
         for kind, _ in groups:
             if kind == "side":
@@ -527,11 +556,11 @@ def btc_to_bct(x):
     return _BtcToBct.apply(x)
 
 
-def _conv(x, w_t, bias, res, mask, pre, B, T, Ci, Co, K, dil, act, anti):
+def _conv(x, w_t, bias, res, mask, pre, B, T, Ci, Co, K, dil, act, anti, prec=0):
     y = torch.empty(B, T, Co, dtype=torch.float32, device=x.device)
-    rc = lib().m3t_causal_conv_fwd(_p(x), _p(w_t), _p(bias), _p(res), _p(mask), _p(y), _p(pre), B, T, Ci, Co, K, dil,
-                                   act, anti, _stream())
-    _lib.check(rc, "m3t_causal_conv_fwd")
+    rc = lib().m3t_conv1d_fwd(_p(x), _p(w_t), _p(bias), _p(res), _p(mask), _p(y), _p(pre), B, T, Ci, Co, K, dil, 0,
+                              act, anti, prec, _stream())
+    _lib.check(rc, "m3t_conv1d_fwd")
     return y
 
 
@@ -554,14 +583,15 @@ class _TemporalBlock(torch.autograd.Function):
         n2 = torch.empty(Co, dtype=torch.float32, device=dev)
         _lib.check(lib().m3t_weight_norm_fwd(_p(v1), _p(g1), _p(w1t), _p(n1), Co, Ci, K, _stream()), "m3t_weight_norm_fwd")
         _lib.check(lib().m3t_weight_norm_fwd(_p(v2), _p(g2), _p(w2t), _p(n2), Co, Co, K, _stream()), "m3t_weight_norm_fwd")
-        h1 = _conv(x, w1t, b1, None, m1, None, B, T, Ci, Co, K, dilation, 1, 0)
+        prec = ctx.prec = _PREC[0]
+        h1 = _conv(x, w1t, b1, None, m1, None, B, T, Ci, Co, K, dilation, 1, 0, prec)
         if wd is not None:
             res = torch.empty(B, T, Co, dtype=torch.float32, device=dev)
-            sgemm(0, 1, B * T, Co, Ci, x, 0, Ci, wd, 0, Ci, res, 0, Co, bias=bd)
+            sgemm(0, 1, B * T, Co, Ci, x, 0, Ci, wd, 0, Ci, res, 0, Co, bias=bd, prec=prec)
         else:
             res = x
         a2 = torch.empty(B, T, Co, dtype=torch.float32, device=dev)
-        y = _conv(h1, w2t, b2, res, m2, a2, B, T, Co, Co, K, dilation, 2, 0)
+        y = _conv(h1, w2t, b2, res, m2, a2, B, T, Co, Co, K, dilation, 2, 0, prec)
         ctx.save_for_backward(x, v1, g1, v2, g2, wd, w1t, w2t, n1, n2, h1, a2, y, m1, m2)
         ctx.dil = dilation
         return y
@@ -572,18 +602,18 @@ class _TemporalBlock(torch.autograd.Function):
         dy = _req(dy.contiguous(), "dy")
         B, T, Ci = x.shape
         Co, _, K = v1.shape
-        dil, dev = ctx.dil, x.device
+        dil, dev, prec = ctx.dil, x.device, ctx.prec
         ws = workspace(dev)
         ds = mask_pos(y, dy)                         # through the block's output ReLU
         da2 = mask_pos(a2, ds, m2)                   # through dropout2 + relu2
-        dh1 = _conv(da2, w2t, None, None, None, None, B, T, Co, Co, K, dil, 0, 1)
+        dh1 = _conv(da2, w2t, None, None, None, None, B, T, Co, Co, K, dil, 0, 1, prec)
         da1 = mask_pos(h1, dh1, m1)                  # h1 > 0 <=> a1 > 0 (dropout keeps the sign)
         dw2t = torch.empty_like(w2t)
         dw1t = torch.empty_like(w1t)
-        _lib.check(lib().m3t_causal_conv_wgrad(_p(da2), _p(h1), _p(dw2t), B, T, Co, Co, K, dil, _p(ws), ws.numel() * 4,
-                                               _stream()), "m3t_causal_conv_wgrad")
-        _lib.check(lib().m3t_causal_conv_wgrad(_p(da1), _p(x), _p(dw1t), B, T, Ci, Co, K, dil, _p(ws), ws.numel() * 4,
-                                               _stream()), "m3t_causal_conv_wgrad")
+        _lib.check(lib().m3t_conv1d_wgrad(_p(da2), _p(h1), _p(dw2t), B, T, Co, Co, K, dil, 0, _p(ws), ws.numel() * 4, prec,
+                                          _stream()), "m3t_conv1d_wgrad")
+        _lib.check(lib().m3t_conv1d_wgrad(_p(da1), _p(x), _p(dw1t), B, T, Ci, Co, K, dil, 0, _p(ws), ws.numel() * 4, prec,
+                                          _stream()), "m3t_conv1d_wgrad")
         db1 = torch.empty(Co, dtype=torch.float32, device=dev)
         db2 = torch.empty(Co, dtype=torch.float32, device=dev)
         colsum(da1, 0, B * T, Co, Co, db1)
@@ -596,12 +626,12 @@ class _TemporalBlock(torch.autograd.Function):
                    "m3t_weight_norm_bwd")
         dwd = dbd = None
         if wd is None:
-            dx = _conv(da1, w1t, None, ds, None, None, B, T, Co, Ci, K, dil, 0, 1)      # + identity residual
+            dx = _conv(da1, w1t, None, ds, None, None, B, T, Co, Ci, K, dil, 0, 1, prec)      # + identity residual
         else:
-            dx = _conv(da1, w1t, None, None, None, None, B, T, Co, Ci, K, dil, 0, 1)
-            sgemm(0, 0, B * T, Ci, Co, ds, 0, Co, wd, 0, Ci, dx, 0, Ci, accumulate=True, use_ws=False)
+            dx = _conv(da1, w1t, None, None, None, None, B, T, Co, Ci, K, dil, 0, 1, prec)
+            sgemm(0, 0, B * T, Ci, Co, ds, 0, Co, wd, 0, Ci, dx, 0, Ci, accumulate=True, use_ws=False, prec=prec)
             dwd = torch.empty_like(wd)
-            sgemm(1, 0, Co, Ci, B * T, ds, 0, Co, x, 0, Ci, dwd, 0, Ci)
+            sgemm(1, 0, Co, Ci, B * T, ds, 0, Co, x, 0, Ci, dwd, 0, Ci, prec=prec)
             dbd = torch.empty(Co, dtype=torch.float32, device=dev)
             colsum(ds, 0, B * T, Co, Co, dbd)
         return dx, dv1, dg1, db1, dv2, dg2, db2, dwd, dbd, None, None, None
@@ -629,7 +659,8 @@ class _ConvBnRelu(torch.autograd.Function):
         dev = x.device
         w_t = transpose2d(w.detach().view(Co * Ci, K)).view(K, Co, Ci)          # tap-major [K][Co][Ci]
         a = torch.empty(B, T, Co, dtype=torch.float32, device=dev)
-        rc = lib().m3t_conv1d_fwd(_p(x), _p(w_t), _p(b), None, None, _p(a), None, B, T, Ci, Co, K, 1, pad, 0, 0, _stream())
+        prec = _PREC[0]
+        rc = lib().m3t_conv1d_fwd(_p(x), _p(w_t), _p(b), None, None, _p(a), None, B, T, Ci, Co, K, 1, pad, 0, 0, prec, _stream())
         _lib.check(rc, "m3t_conv1d_fwd")
         y = torch.empty_like(a)
         mean = torch.empty(Co, dtype=torch.float32, device=dev)
@@ -640,13 +671,13 @@ class _ConvBnRelu(torch.autograd.Function):
                                    _stream())
         _lib.check(rc, "m3t_bn_rows_fwd")
         ctx.save_for_backward(x, w_t, a, y, gamma, mean, invstd)
-        ctx.cfg = (pad, int(training), b is not None)
+        ctx.cfg = (pad, int(training), b is not None, prec)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w_t, a, y, gamma, mean, invstd = ctx.saved_tensors
-        pad, training, has_bias = ctx.cfg
+        pad, training, has_bias, prec = ctx.cfg
         dy = _req(dy.contiguous(), "dy")
         B, T, Ci = x.shape
         K, Co, _ = w_t.shape
@@ -659,10 +690,10 @@ class _ConvBnRelu(torch.autograd.Function):
                                    _p(dgamma), _p(dbeta), _p(ws), ws.numel() * 4, _stream())
         _lib.check(rc, "m3t_bn_rows_bwd")
         dx = torch.empty_like(x)
-        rc = lib().m3t_conv1d_fwd(_p(da), _p(w_t), None, None, None, _p(dx), None, B, T, Co, Ci, K, 1, pad, 0, 1, _stream())
+        rc = lib().m3t_conv1d_fwd(_p(da), _p(w_t), None, None, None, _p(dx), None, B, T, Co, Ci, K, 1, pad, 0, 1, prec, _stream())
         _lib.check(rc, "m3t_conv1d_fwd (data gradient)")
         dw_t = torch.empty_like(w_t)
-        rc = lib().m3t_conv1d_wgrad(_p(da), _p(x), _p(dw_t), B, T, Ci, Co, K, 1, pad, _p(ws), ws.numel() * 4, _stream())
+        rc = lib().m3t_conv1d_wgrad(_p(da), _p(x), _p(dw_t), B, T, Ci, Co, K, 1, pad, _p(ws), ws.numel() * 4, prec, _stream())
         _lib.check(rc, "m3t_conv1d_wgrad")
         dw = transpose2d(dw_t.view(K, Co * Ci)).view(Co, Ci, K)
         db = None

@@ -33,10 +33,44 @@ def _sig(x):
     return 1.0 / (1.0 + np.exp(-x))
 
 
+# --------------------------------------------------------------------------- mixed precision (config C2)
+# BASELINE.json config C2 asks for "bf16 activations/weights, fp32 accumulate, fp32 master weights".  The reference has
+# no such mode (it is fp32 only), so there is nothing to pin against: the build DEFINES it as "every operand of a
+# matmul / conv / recurrent product is rounded to bf16 (nearest even); everything else stays fp32" and this switch
+# makes the oracle emulate exactly that, so the HIP path can be checked against it at fp32-accumulation tolerance.
+_BF16_OPERANDS = [False]
+
+
+class matmul_precision:
+    def __init__(self, mode):
+        assert mode in ("fp32", "bf16")
+        self.on = mode == "bf16"
+
+    def __enter__(self):
+        self.prev = _BF16_OPERANDS[0]
+        _BF16_OPERANDS[0] = self.on
+
+    def __exit__(self, *exc):
+        _BF16_OPERANDS[0] = self.prev
+        return False
+
+
+def bf16_round(a):
+    """round to nearest-even bf16 (through fp32), returned in the input dtype"""
+    a = np.asarray(a)
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32).astype(a.dtype).reshape(a.shape)
+
+
+def _R(a):
+    return bf16_round(a) if _BF16_OPERANDS[0] else a
+
+
 # --------------------------------------------------------------------------- linear
 def linear_fwd(x, w, b=None):
     """nn.Linear: y = x W^T + b (used at models/rnn.py:22-55, models/model.py:88)."""
-    y = x @ w.T
+    y = _R(x) @ _R(w).T
     if b is not None:
         y = y + b
     return y
@@ -45,8 +79,8 @@ def linear_fwd(x, w, b=None):
 def linear_bwd(dy, x, w, has_bias=True):
     x2 = x.reshape(-1, x.shape[-1])
     dy2 = dy.reshape(-1, dy.shape[-1])
-    dx = (dy2 @ w).reshape(x.shape)
-    dw = dy2.T @ x2
+    dx = (_R(dy2) @ _R(w)).reshape(x.shape)
+    dw = _R(dy2).T @ _R(x2)
     db = dy2.sum(0) if has_bias else None
     return dx, dw, db
 
@@ -57,7 +91,7 @@ def _gru_dir_fwd(x, w_ih, w_hh, b_ih, b_hh, reverse):
     x [B,T,I] -> out [B,T,H]; h0 = 0; the reverse direction scans t = T-1 .. 0."""
     B, T, _ = x.shape
     H = w_hh.shape[1]
-    gi = x @ w_ih.T + b_ih                       # [B,T,3H], gate order r,z,n
+    gi = _R(x) @ _R(w_ih).T + b_ih               # [B,T,3H], gate order r,z,n
     out = np.zeros((B, T, H), x.dtype)
     r_s = np.zeros((B, T, H), x.dtype)
     z_s = np.zeros_like(r_s)
@@ -66,7 +100,7 @@ def _gru_dir_fwd(x, w_ih, w_hh, b_ih, b_hh, reverse):
     h = np.zeros((B, H), x.dtype)
     order = range(T - 1, -1, -1) if reverse else range(T)
     for t in order:
-        gh = h @ w_hh.T + b_hh
+        gh = _R(h) @ _R(w_hh).T + b_hh
         r = _sig(gi[:, t, :H] + gh[:, :H])
         z = _sig(gi[:, t, H:2 * H] + gh[:, H:2 * H])
         n = np.tanh(gi[:, t, 2 * H:] + r * gh[:, 2 * H:])
@@ -97,10 +131,10 @@ def _gru_dir_bwd(dout, dh_last, cache, w_ih, w_hh):
         dr_pre = dn_pre * hn * r * (1.0 - r)
         dgi = np.concatenate([dr_pre, dz_pre, dn_pre], 1)
         dgh = np.concatenate([dr_pre, dz_pre, dn_pre * r], 1)
-        dh = dht * z + dgh @ w_hh
-        dx[:, t] = dgi @ w_ih
-        dw_ih += dgi.T @ x[:, t]
-        dw_hh += dgh.T @ h_prev
+        dh = dht * z + _R(dgh) @ _R(w_hh)
+        dx[:, t] = _R(dgi) @ _R(w_ih)
+        dw_ih += _R(dgi).T @ _R(x[:, t])
+        dw_hh += _R(dgh).T @ _R(h_prev)
         db_ih += dgi.sum(0)
         db_hh += dgh.sum(0)
     return dx, dw_ih, dw_hh, db_ih, db_hh
@@ -211,7 +245,7 @@ def causal_conv1d_fwd(x, w, b, dilation):
         s = (K - 1 - j) * dilation
         if s >= T:
             continue
-        y[:, :, s:] += np.einsum("oc,bct->bot", w[:, :, j], x[:, :, :T - s])
+        y[:, :, s:] += np.einsum("oc,bct->bot", _R(w[:, :, j]), _R(x[:, :, :T - s]))
     return y
 
 
@@ -224,8 +258,8 @@ def causal_conv1d_bwd(dy, x, w, dilation):
         s = (K - 1 - j) * dilation
         if s >= T:
             continue
-        dx[:, :, :T - s] += np.einsum("oc,bot->bct", w[:, :, j], dy[:, :, s:])
-        dw[:, :, j] = np.einsum("bot,bct->oc", dy[:, :, s:], x[:, :, :T - s])
+        dx[:, :, :T - s] += np.einsum("oc,bot->bct", _R(w[:, :, j]), _R(dy[:, :, s:]))
+        dw[:, :, j] = np.einsum("bot,bct->oc", _R(dy[:, :, s:]), _R(x[:, :, :T - s]))
     db = dy.sum(axis=(0, 2))
     return dx, dw, db
 
@@ -306,7 +340,7 @@ def conv1d_same_fwd(x, w, b, pad):
         o = j - pad                               # source time = t + o
         lo, hi = max(0, -o), min(T, T - o)        # output times with the source inside the clip
         if hi > lo:
-            y[:, :, lo:hi] += np.einsum("oc,bct->bot", w[:, :, j], x[:, :, lo + o:hi + o])
+            y[:, :, lo:hi] += np.einsum("oc,bct->bot", _R(w[:, :, j]), _R(x[:, :, lo + o:hi + o]))
     return y
 
 
@@ -319,8 +353,8 @@ def conv1d_same_bwd(dy, x, w, pad):
         o = j - pad
         lo, hi = max(0, -o), min(T, T - o)
         if hi > lo:
-            dx[:, :, lo + o:hi + o] += np.einsum("oc,bot->bct", w[:, :, j], dy[:, :, lo:hi])
-            dw[:, :, j] = np.einsum("bot,bct->oc", dy[:, :, lo:hi], x[:, :, lo + o:hi + o])
+            dx[:, :, lo + o:hi + o] += np.einsum("oc,bot->bct", _R(w[:, :, j]), _R(dy[:, :, lo:hi]))
+            dw[:, :, j] = np.einsum("bot,bct->oc", _R(dy[:, :, lo:hi]), _R(x[:, :, lo + o:hi + o]))
     return dx, dw, dy.sum(axis=(0, 2))
 
 

@@ -33,7 +33,15 @@ def secondary():
     m = TcnHead(128, 512, 2).to(dev).eval(); x = torch.randn(32, 128, 300, device=dev)
     ms = timeit(step(m, x)); print("C1 TcnHead  B=32 T=300: %.2f ms/step  %.0f clips/s  (%.1f TF/s alg.)" % (ms, 32 / ms * 1e3, 32 * 1.573e9 * 3 / ms / 1e9))
     m = TcnGru(256, 512).to(dev).eval(); x = torch.randn(32, 256, 300, device=dev)
-    ms = timeit(step(m, x)); print("C2 TcnGru   B=32 T=300: %.2f ms/step  %.0f clips/s" % (ms, 32 / ms * 1e3))
+    ms = timeit(step(m, x)); print("C2 TcnGru   B=32 T=300 fp32: %.2f ms/step  %.0f clips/s" % (ms, 32 / ms * 1e3))
+    from m3t import ops
+
+    def step_bf16():
+        with ops.precision("bf16"):
+            step(m, x)()
+    ms = timeit(step_bf16); print("C2 TcnGru   B=32 T=300 bf16 operands (BASELINE configs[1]): %.2f ms/step  %.0f clips/s" % (ms, 32 / ms * 1e3))
+    x = torch.randn(256, 256, 300, device=dev)
+    ms = timeit(step_bf16, 3); print("C2 TcnGru   B=256 T=300 bf16 operands: %.2f ms/step  %.0f clips/s" % (ms, 256 / ms * 1e3))
     for (C, HW, N) in ((64, 28, 2048), (128, 14, 2048), (256, 7, 2048), (512, 4, 2048)):
         m = CBAM(C).to(dev).train(); x = torch.randn(N, C, HW, HW, device=dev, requires_grad=True)
         ms = timeit(step(m, x))
