@@ -3,6 +3,9 @@
 // of its group published in the previous step (GS x 256 granules = 64 KB at GS=32), reduces across its 8 waves
 // through LDS, and publishes its own 256 granules.  No barrier, no flags: a granule is one naturally aligned
 // 8-byte agent-scope store, the tag is the step number; two slots ping-pong.  Spins are bounded.
+// (Tried and dropped: an XCD-local variant -- groups on one XCD via blockIdx % 8, which tools/xcc_probe.hip shows is a
+// stable map, workgroup-scope (sc0) stores/loads through the shared L2 -- ran 1.5 us per step when it worked and hit the
+// spin limit on other runs: not a reliable publish, as the guide's "XCD-local ending" warning says.)
 //   hipcc -O3 --offload-arch=gfx950 tools/persist_probe.hip -o tools/bin/persist_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -34,14 +37,7 @@ __global__ __launch_bounds__(512) void persist(unsigned long long* gran, int NG,
 #pragma unroll
             for (int c = 0; c < NL; ++c) {
                 const int u = wave * PER_WAVE + c / 4;
-                const unsigned long long* q = src + (size_t)u * GRAN + (c % 4) * 64 + lane;
-                if (WORK == -2) asm volatile("global_load_dwordx2 %0, %1, off sc0" : "=v"(v[c]) : "v"(q) : "memory");   // L2-coherent only (same XCD)
-                else v[c] = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (WORK == -2) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int c = 0; c < NL; ++c) asm volatile("" : "+v"(v[c]));
+                v[c] = __hip_atomic_load(src + (size_t)u * GRAN + (c % 4) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
 #pragma unroll
             for (int c = 0; c < NL; ++c) ok = ok && ((unsigned)(v[c] >> 32) == tag);
@@ -68,8 +64,7 @@ __global__ __launch_bounds__(512) void persist(unsigned long long* gran, int NG,
             const unsigned long long g = ((unsigned long long)(tag + 1u) << 32) | __float_as_uint(r);
             // WORK == -1: the scattered publish map of a (row, unit) thread layout (16 x 32-byte pieces per wave)
             const int pos = WORK == -1 ? ((threadIdx.x & 3) * 64 + ((threadIdx.x & 15) >> 2) * 16 + (threadIdx.x >> 4)) : threadIdx.x;
-            if (WORK == -2) { unsigned long long* q = dst + pos; asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(q), "v"(g) : "memory"); }
-            else __hip_atomic_store(dst + pos, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dst + pos, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
     }
@@ -217,8 +212,6 @@ int main() {
     run<32, 0, 600>(8, T);
     run<8, 0, 0>(2, T);
     run<32, 0, -1>(8, T);
-    run<32, 0, -2>(8, T);
-    run<32, 0, -2>(8, 20000);
     run<32, 0, -1>(4, T);
     run16<32>(8, T);
     run16<32>(8, 20000);
