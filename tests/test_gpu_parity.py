@@ -194,6 +194,44 @@ def test_gru_persistent_scan_equals_per_step(B, T, I, H, L):
         close(g1[n], g_ref[n], 2e-4, n)
 
 
+def test_gru_persistent_scan_final_state_and_its_gradient():
+    """h_n out of the persistent forward scan and dL/dh_n into the persistent backward scan (return_h=True, the
+    scorer configuration of AttFusion): equal to the launch-per-step path bit for bit and to the oracle."""
+    from models.rnn import GRU
+    from m3t import ops, _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(44)
+    B, T, I, H, L = 21, 11, 12, 128, 2
+    m = fill_module(GRU(I, H, L, -1, return_h=True), 79).to(DEV)
+    xn, ct, cth = draw(rs, (B, T, I)), draw(rs, (B, T, 2 * H)), draw(rs, (2 * L, B, H))
+    res = []
+    for per_step in (False, True):
+        ops.SCAN_PER_STEP[0] = per_step
+        try:
+            m.zero_grad()
+            x = dev(xn, True)
+            n0 = lib.m3t_gru_persist_count()
+            y, h = m(x)
+            ((y * dev(ct)).sum() + (h * dev(cth)).sum()).backward()
+            torch.cuda.synchronize()
+            res.append((y.detach().clone(), h.detach().clone(), x.grad.clone(), [p.grad.clone() for p in m.parameters()],
+                        lib.m3t_gru_persist_count() - n0))
+        finally:
+            ops.SCAN_PER_STEP[0] = False
+    assert res[0][4] == 2 * L and res[1][4] == 0
+    for a, b in zip(res[0][:3], res[1][:3]):
+        assert torch.equal(a, b)
+    assert all(torch.equal(a, b) for a, b in zip(res[0][3], res[1][3]))
+    p = {n: t.detach().cpu().numpy().astype(np.float64) for n, t in m.named_parameters()}
+    out_ref, hn_ref, caches = O.bigru_fwd(xn.astype(np.float64), p, L)
+    close(res[0][0], out_ref, TOL, "y")
+    close(res[0][1], hn_ref, TOL, "h_n")
+    dx_ref, g_ref = O.bigru_bwd(ct.astype(np.float64), caches, p, L, dh_n=cth.astype(np.float64))
+    close(res[0][2], dx_ref, TOL, "dx")
+    for (n, _), gr in zip(m.named_parameters(), res[0][3]):
+        close(gr, g_ref[n], 2e-4, n)
+
+
 def test_gru_persistent_scan_repeatable_and_long():
     """T = 300 at the C3 width (4 x H=512 scans = 256 workgroups, the whole chip): two runs are bit-identical and no
     wait expires (a later scan call would raise M3T_ESPIN)."""
