@@ -281,6 +281,24 @@ int m3t_smooth_tracks(const float* x, const long long* offsets, int n_tracks, in
 int m3t_ccc_masked(const double* p, const float* g, const float* g2, long long n, int p_unbiased, double* out2,
                    void* stream);
 
+/* ---------------------------------------------------------------------------------
+ * Audio front-end: the glue kernels of the log-Mel pipeline that the reference runs offline with
+ * librosa (process/extract_melspec.py:13-20) and the context stacking of models/dataset.py:83-95.  The DFT and the
+ * mel projection themselves are m3t_sgemm calls (see m3t/audio.py).
+ * frames[f][k] = window[k] * ypad[f*hop + k], ypad = y with n_fft/2 samples of padding per side
+ * (pad_mode 0 zeros, 1 reflect); n_frames = 1 + n / hop. */
+int m3t_frame_window(const float* y, long long n, int n_fft, int hop, int pad_mode, const float* window,
+                     float* frames, long long n_frames, void* stream);
+/* spec [n_frames][2*bins] = (re | im) -> power [n_frames][bins] = re^2 + im^2 */
+int m3t_power_spectrum(const float* spec, long long n_frames, int bins, float* power, void* stream);
+/* librosa.power_to_db(S, ref=1.0, amin, top_db): 10 log10(max(amin, S)), floored at (max - top_db) when top_db >= 0.
+ * ws: >= 2 KiB of scratch. */
+int m3t_power_to_db(const float* s, long long n, float amin, float top_db, float* out, float* ws, size_t ws_bytes,
+                    void* stream);
+/* out [w_len][width*n_mels]: row i = mel rows (start+i)*step .. +width concatenated, zero rows past the end */
+int m3t_stack_context(const float* mel, long long n_rows, int n_mels, long long start, int w_len, int step, int width,
+                      float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,6 +62,10 @@ SIGNATURES = {
     "m3t_cbam_spatial_bwd": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _z, _s],
     "m3t_smooth_tracks": [_f, _f, _i, _i, _i, _f, _s],
     "m3t_ccc_masked": [_f, _f, _f, C.c_longlong, _i, _f, _s],
+    "m3t_frame_window": [_f, C.c_longlong, _i, _i, _i, _f, _f, C.c_longlong, _s],
+    "m3t_power_spectrum": [_f, C.c_longlong, _i, _f, _s],
+    "m3t_power_to_db": [_f, C.c_longlong, C.c_float, C.c_float, _f, _f, _z, _s],
+    "m3t_stack_context": [_f, C.c_longlong, _i, C.c_longlong, _i, _i, _i, _f, _s],
     "m3t_grad_norm_scale": [_f, _z, C.c_float, C.c_float, _f, _f, _z, _s],
     "m3t_adam_step": [_f, _f, _f, _f, _z, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _i, _s],
     "m3t_sgd_step": [_f, _f, _f, _z, C.c_float, C.c_float, C.c_float, _i, _s],

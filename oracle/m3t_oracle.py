@@ -757,3 +757,46 @@ def concordance_cc2_np(r1, r2, r1_unbiased=False):
     r1, r2 = np.asarray(r1), np.asarray(r2)
     cov = ((r1 - r1.mean()) * (r2 - r2.mean())).mean()
     return 2 * cov / (r1.var(ddof=1 if r1_unbiased else 0) + r2.var() + (r1.mean() - r2.mean()) ** 2)
+
+
+# --------------------------------------------------------------------------- audio front-end
+# PARITY UNPINNED for melspec_db: the reference calls librosa (process/extract_melspec.py:13-20), a third-party
+# dependency with no pinned version (requirements.txt) that is absent from this image, so no reference output can be
+# generated here.  Restated from librosa's published algorithm (librosa.feature.melspectrogram / filters.mel /
+# power_to_db defaults of 0.10: periodic Hann window centred in n_fft, center=True with zero padding, power 2,
+# Slaney filterbank, ref 1.0, amin 1e-10, top_db 80).  load_audio IS pinned (golden audio_stack.npz from the
+# reference's models/dataset.py:83-95).
+def melspec_db(y, fps=30.0, pad_mode="constant", top_db=80.0, sr=16000, n_fft=512, win_length=400, n_mels=40):
+    y = np.asarray(y, F64)
+    hop = int(1 / 3 * 1 / fps * 16000)
+    win = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(win_length) / win_length)
+    lp = (n_fft - win_length) // 2
+    win = np.concatenate([np.zeros(lp), win, np.zeros(n_fft - win_length - lp)])
+    yp = np.pad(y, n_fft // 2, mode=pad_mode)
+    nf = 1 + (yp.shape[0] - n_fft) // hop
+    frames = np.stack([yp[f * hop:f * hop + n_fft] * win for f in range(nf)])
+    power = np.abs(np.fft.rfft(frames, axis=1)) ** 2
+    # Slaney mel filterbank
+    logstep = np.log(6.4) / 27.0
+    h2m = lambda f: np.where(np.asarray(f, F64) >= 1000.0, 15.0 + np.log(np.maximum(f, 1e-300) / 1000.0) / logstep, np.asarray(f, F64) * 3 / 200.0)
+    m2h = lambda m: np.where(m >= 15.0, 1000.0 * np.exp(logstep * (m - 15.0)), m * 200.0 / 3)
+    freqs = np.linspace(0, sr / 2.0, 1 + n_fft // 2)
+    mel_f = m2h(np.linspace(h2m(0.0), h2m(sr / 2.0), n_mels + 2))
+    fdiff = np.diff(mel_f)
+    ramps = mel_f[:, None] - freqs[None, :]
+    fb = np.stack([np.maximum(0, np.minimum(-ramps[i] / fdiff[i], ramps[i + 2] / fdiff[i + 1])) for i in range(n_mels)])
+    fb *= (2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels]))[:, None]
+    mel = power @ fb.T
+    db = 10.0 * np.log10(np.maximum(1e-10, mel)) - 10.0 * np.log10(np.maximum(1e-10, 1.0))
+    return np.maximum(db, db.max() - top_db) if top_db is not None else db
+
+
+def load_audio(mel_spec, start_idx, w_len):
+    """models/dataset.py:83-95 (context width 2: five mel frames per video frame, three mel frames per video frame)."""
+    rows = []
+    for i in range(w_len):
+        w = mel_spec[(start_idx + i) * 3:(start_idx + i) * 3 + 5]
+        if len(w) < 5:
+            w = np.pad(w, ((0, 5 - len(w)), (0, 0)), "constant")
+        rows.append(w.reshape(-1))
+    return np.stack(rows)

@@ -493,6 +493,22 @@ def case_postproc(name, seed):
     save(name, **arrs)
 
 
+def case_audio_stack(name, seed):
+    """models/dataset.py:83-95 load_audio: the 5-frame mel context stacked per video frame, incl. the zero-padded tail."""
+    import tempfile
+    from models.dataset import load_audio       # reference (cv2 stubbed above)
+    rs = np.random.RandomState(seed)
+    mel = (rs.standard_normal((47, 40)) * 20 - 40).astype(np.float32)
+    arrs = {"mel": mel}
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "mel.npy")
+        np.save(path, mel)
+        for tag, (start, w_len) in {"head": (0, 8), "mid": (5, 6), "tail": (11, 8), "past": (16, 3)}.items():
+            arrs["args." + tag] = np.array([start, w_len])
+            arrs["out." + tag] = load_audio(path, start, w_len)
+    save(name, **arrs)
+
+
 def main():
     only = set(sys.argv[1:])
 
@@ -537,6 +553,8 @@ def main():
         case_init_digests("init_digests")
     if want("stitch"):
         case_stitch("stitch", 1000)
+    if want("audio"):
+        case_audio_stack("audio_stack", 1200)
     if want("postproc"):
         case_postproc("postproc", 1100)
     if want("c5"):

@@ -199,3 +199,26 @@ def test_postproc_smoothing_and_ccc():
             allp[k].append(sm[k][valid]); allg[k].append(gg[valid])
     for k in ("valence", "arousal"):
         close(O.concordance_cc2_np(np.concatenate(allp[k]), np.concatenate(allg[k])), g["ccc_all." + k], tol=1e-12, what="ccc_all")
+
+
+def test_audio_context_stacking():
+    """f-3 (pinned half): models/dataset.py:83-95 load_audio on a 47-frame mel track, incl. windows that run past its end"""
+    g = load_golden("audio_stack")
+    for tag in ("head", "mid", "tail", "past"):
+        start, w_len = [int(v) for v in g["args." + tag]]
+        close(O.load_audio(g["mel"], start, w_len), g["out." + tag], tol=0, what=tag)
+
+
+def test_melspec_oracle_known_answers():
+    """f-3 (UNPINNED half: librosa is absent): sanity known-answers of the restated log-Mel pipeline -- frame count,
+    silence -> the amin floor, a pure tone peaks in the mel band that contains it, dynamic range capped at top_db."""
+    sr, fps = 16000, 30.0
+    hop = int(1 / 3 * 1 / fps * 16000)
+    t = np.arange(sr) / sr
+    db = O.melspec_db(np.sin(2 * np.pi * 1000.0 * t), fps)
+    assert db.shape == (1 + sr // hop, 40)
+    mid = db[10:-10]
+    peak = np.bincount(mid.argmax(1)).argmax()
+    assert 13 <= peak <= 16, peak                               # 1 kHz = mel 15 of the Slaney scale: band 14/15 of 40 up to 8 kHz
+    assert db.max() - db.min() <= 80.0 + 1e-9
+    assert np.allclose(O.melspec_db(np.zeros(4000), fps), -100.0)   # 10 log10(amin = 1e-10)
