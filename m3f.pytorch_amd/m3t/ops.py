@@ -81,6 +81,9 @@ _SIDE = {}
 # measured +9% on C3 (969 vs 886 clips/s): the light chain and its GEMMs hide beside the heavy one; M3T_SIDE_STREAM=0 disables
 _SIDE_ENABLED = os.environ.get("M3T_SIDE_STREAM", "1") == "1"
 _PERSIST_ENABLED = os.environ.get("M3T_SCAN_PERSIST", "1") != "0"
+# two H-groups of persistent scans (e.g. gru_v|gru_a H=512 and audio H=256): the light group's scans and GEMMs go to the
+# side stream, fenced by events so that no two persistent scans ever overlap, and run beside the heavy group's GEMMs
+_INTERLEAVE = os.environ.get("M3T_SCAN_INTERLEAVE", "1") != "0"
 
 
 def side_stream(device):
@@ -212,10 +215,16 @@ def linear(x, w, b=None, act=0):
 SCAN_PER_STEP = [False]     # tests/benchmarks: force the launch-per-step scan path
 
 
+_FENCED = [False]     # set by the interleaved schedule of _MultiBiGRU: its side-stream scans are fenced by events
+
+
 def _scan_flags(device):
     """A persistent scan launch needs every workgroup resident, so two of them must never run concurrently on one
-    device: scans issued on the side stream take the launch-per-step path (include/m3t_hip.h, m3t_gru_scan_fwd)."""
-    return _lib.M3T_SCAN_NO_PERSIST if (SCAN_PER_STEP[0] or _ws_tag(device) == "side") else 0
+    device: scans issued on the side stream take the launch-per-step path (include/m3t_hip.h, m3t_gru_scan_fwd) --
+    unless the caller fences them against every other scan with events (the interleaved schedule of _MultiBiGRU)."""
+    if SCAN_PER_STEP[0] or (_ws_tag(device) == "side" and not _FENCED[0]):
+        return _lib.M3T_SCAN_NO_PERSIST
+    return 0
 
 
 def _scan_fwd(descs, B, T, prec=0):
@@ -273,6 +282,11 @@ def _stream_groups(Hs, B):
     return [("main", list(range(len(Hs))))]
 
 
+def _interleaved(groups):
+    return (_INTERLEAVE and _PERSIST_ENABLED and not SCAN_PER_STEP[0] and len(groups) == 2
+            and all(kind == "main" for kind, _ in groups))
+
+
 class _MultiBiGRU(torch.autograd.Function):
     """Several independent stacked bidirectional GRUs (same B, T, depth) advanced together:
     per layer, one input-projection GEMM per direction, then ONE grouped scan over every
@@ -303,28 +317,64 @@ class _MultiBiGRU(torch.autograd.Function):
         main = torch.cuda.current_stream()
         prec = _PREC[0]
         groups = _stream_groups(Hs, B)
-        for kind, idxs in groups:
-            stream = main
-            if kind == "side":
-                stream = side_stream(dev)
-                stream.wait_stream(main)
-            with torch.cuda.stream(stream):
+
+        def level_fwd(l, idxs, scan):
+            """scan=False: the input projections of layer l for the stacks idxs; scan=True: their grouped scan"""
+            descs = []
+            for s in idxs:
+                H = Hs[s]
+                inp = xs[s] if l == 0 else outs[l - 1][s]
+                I = inp.shape[-1]
+                for d in (0, 1):
+                    w_ih, w_hh, b_ih, b_hh = params[s][(2 * l + d) * 4:(2 * l + d) * 4 + 4]
+                    if not scan:
+                        sgemm(0, 1, B * T, 3 * H, I, inp, 0, I, w_ih, 0, I, xprojs[l][s], d * 3 * H, 6 * H, bias=b_ih, prec=prec)
+                    else:
+                        descs.append(GruFwdDesc(_vp(xprojs[l][s]), _vp(w_hh), _vp(b_hh), _vp(outs[l][s]),
+                                                _vp(gates[l][s], d * B * T * 4 * H), _vp(h_ns[s], (2 * l + d) * B * H),
+                                                H, d, 6 * H, d * 3 * H, 2 * H, d * H))
+            if scan:
+                _scan_fwd(descs, B, T, prec)
+
+        if _interleaved(groups):
+            # heavy group on the main stream, light group on the side stream; persistent scans strictly alternate
+            # (events), so the light scan of layer l runs beside the heavy input projections of layer l+1
+            heavy, light = groups[0][1], groups[1][1]
+            side = side_stream(dev)
+            side.wait_stream(main)
+            ev_light = None
+            _FENCED[0] = True
+            try:
                 for l in range(L):
-                    descs = []
-                    for s in idxs:
-                        H = Hs[s]
-                        inp = xs[s] if l == 0 else outs[l - 1][s]
-                        I = inp.shape[-1]
-                        for d in (0, 1):
-                            w_ih, w_hh, b_ih, b_hh = params[s][(2 * l + d) * 4:(2 * l + d) * 4 + 4]
-                            sgemm(0, 1, B * T, 3 * H, I, inp, 0, I, w_ih, 0, I, xprojs[l][s], d * 3 * H, 6 * H, bias=b_ih, prec=prec)
-                            descs.append(GruFwdDesc(_vp(xprojs[l][s]), _vp(w_hh), _vp(b_hh), _vp(outs[l][s]),
-                                                    _vp(gates[l][s], d * B * T * 4 * H), _vp(h_ns[s], (2 * l + d) * B * H),
-                                                    H, d, 6 * H, d * 3 * H, 2 * H, d * H))
-                    _scan_fwd(descs, B, T, prec)
-        for kind, _ in groups:
-            if kind == "side":
-                main.wait_stream(side_stream(dev))
+                    level_fwd(l, heavy, False)
+                    with torch.cuda.stream(side):
+                        level_fwd(l, light, False)
+                    if ev_light is not None:
+                        main.wait_event(ev_light)
+                    level_fwd(l, heavy, True)
+                    ev_heavy = torch.cuda.Event()
+                    ev_heavy.record(main)
+                    side.wait_event(ev_heavy)
+                    with torch.cuda.stream(side):
+                        level_fwd(l, light, True)
+                        ev_light = torch.cuda.Event()
+                        ev_light.record(side)
+            finally:
+                _FENCED[0] = False
+            main.wait_stream(side)
+        else:
+            for kind, idxs in groups:
+                stream = main
+                if kind == "side":
+                    stream = side_stream(dev)
+                    stream.wait_stream(main)
+                with torch.cuda.stream(stream):
+                    for l in range(L):
+                        level_fwd(l, idxs, False)
+                        level_fwd(l, idxs, True)
+            for kind, _ in groups:
+                if kind == "side":
+                    main.wait_stream(side_stream(dev))
         del xprojs
         ctx.n_stacks, ctx.L, ctx.Hs, ctx.B, ctx.T, ctx.prec = n_stacks, L, Hs, B, T, prec
         saved = []
@@ -376,53 +426,87 @@ class _MultiBiGRU(torch.autograd.Function):
                                                 new(3 * Hs[s]), new(3 * Hs[s])]
         main = torch.cuda.current_stream()
         groups = _stream_groups(Hs, B)
-        for kind, idxs in groups:
-            stream = main
-            if kind == "side":
-                stream = side_stream(dev)
-                stream.wait_stream(main)
-            with torch.cuda.stream(stream):
-                cur = {s: douts[s] for s in idxs}
+        cur = {s: douts[s] for s in range(n_stacks)}
+        prec = ctx.prec
+
+        def level_scan(l, idxs):
+            descs = []
+            for s in idxs:
+                H = Hs[s]
+                inp, out, gts = layer_io(l, s)
+                for d in (0, 1):
+                    w_hh = params[s][(2 * l + d) * 4 + 1]
+                    _lib.check(lib().m3t_transpose(_p(w_hh), 3 * H, H, H, _p(wht[l][s][d]), 3 * H, _stream()),
+                               "m3t_transpose")
+                    descs.append(GruBwdDesc(_vp(cur[s]), _vp(out), _vp(gts, d * B * T * 4 * H), _vp(wht[l][s][d]),
+                                            _vp(dhns[s], (2 * l + d) * B * H) if dhns[s] is not None else None,
+                                            _vp(dgx[l][s]), _vp(dgh[l][s], d * B * T * 3 * H), _vp(dh[l][s], d * B * H),
+                                            H, d, 2 * H, d * H, 6 * H, d * 3 * H))
+            _scan_bwd(descs, B, T, prec)
+
+        def level_gemms(l, idxs):
+            for s in idxs:
+                H = Hs[s]
+                inp, out, gts = layer_io(l, s)
+                I = inp.shape[-1]
+                if need_dx[l][s]:          # critical path first: feeds the next level's scan
+                    for d in (0, 1):
+                        sgemm(0, 0, B * T, I, 3 * H, dgx[l][s], d * 3 * H, 6 * H, params[s][(2 * l + d) * 4], 0, I,
+                              dinp[l][s], 0, I, accumulate=(d == 1), prec=prec)
+                    cur[s] = dinp[l][s]
+                for d in (0, 1):
+                    base = s * per + 1 + (2 * l + d) * 4
+                    dw_ih, dw_hh, db_ih, db_hh = out_grads[base:base + 4]
+                    goff = d * B * T * 3 * H
+                    if T > 1:
+                        # dW_hh = sum_{b,t} dgh[b,t]^T h_prev(b,t): forward pairs (t, t-1), reverse pairs (t, t+1)
+                        a_off, b_off = (1, 0) if d == 0 else (0, 1)
+                        sgemm(1, 0, 3 * H, H, B * (T - 1), dgh[l][s], goff, 3 * H, out, d * H, 2 * H, dw_hh, 0, H,
+                              seg=(T - 1, T, a_off, b_off), prec=prec)
+                    else:
+                        dw_hh.zero_()
+                    colsum(dgh[l][s], goff, B * T, 3 * H, 3 * H, db_hh)
+                    sgemm(1, 0, 3 * H, I, B * T, dgx[l][s], d * 3 * H, 6 * H, inp, 0, I, dw_ih, 0, I, prec=prec)
+                    colsum(dgx[l][s], d * 3 * H, B * T, 3 * H, 6 * H, db_ih)
+
+        if _interleaved(groups):
+            # as in forward: the light group's backward scans run on the side stream beside the heavy group's GEMMs
+            # (data and weight gradients), persistent scans strictly alternating
+            heavy, light = groups[0][1], groups[1][1]
+            side = side_stream(dev)
+            side.wait_stream(main)
+            ev_light = None
+            _FENCED[0] = True
+            try:
                 for l in range(L - 1, -1, -1):
-                    descs = []
-                    for s in idxs:
-                        H = Hs[s]
-                        inp, out, gts = layer_io(l, s)
-                        for d in (0, 1):
-                            w_hh = params[s][(2 * l + d) * 4 + 1]
-                            _lib.check(lib().m3t_transpose(_p(w_hh), 3 * H, H, H, _p(wht[l][s][d]), 3 * H, _stream()),
-                                       "m3t_transpose")
-                            descs.append(GruBwdDesc(_vp(cur[s]), _vp(out), _vp(gts, d * B * T * 4 * H), _vp(wht[l][s][d]),
-                                                    _vp(dhns[s], (2 * l + d) * B * H) if dhns[s] is not None else None,
-                                                    _vp(dgx[l][s]), _vp(dgh[l][s], d * B * T * 3 * H), _vp(dh[l][s], d * B * H),
-                                                    H, d, 2 * H, d * H, 6 * H, d * 3 * H))
-                    _scan_bwd(descs, B, T, ctx.prec)
-                    for s in idxs:
-                        H = Hs[s]
-                        inp, out, gts = layer_io(l, s)
-                        I = inp.shape[-1]
-                        if need_dx[l][s]:          # critical path first: feeds the next level's scan
-                            for d in (0, 1):
-                                sgemm(0, 0, B * T, I, 3 * H, dgx[l][s], d * 3 * H, 6 * H, params[s][(2 * l + d) * 4], 0, I,
-                                      dinp[l][s], 0, I, accumulate=(d == 1), prec=ctx.prec)
-                            cur[s] = dinp[l][s]
-                        for d in (0, 1):
-                            base = s * per + 1 + (2 * l + d) * 4
-                            dw_ih, dw_hh, db_ih, db_hh = out_grads[base:base + 4]
-                            goff = d * B * T * 3 * H
-                            if T > 1:
-                                # dW_hh = sum_{b,t} dgh[b,t]^T h_prev(b,t): forward pairs (t, t-1), reverse pairs (t, t+1)
-                                a_off, b_off = (1, 0) if d == 0 else (0, 1)
-                                sgemm(1, 0, 3 * H, H, B * (T - 1), dgh[l][s], goff, 3 * H, out, d * H, 2 * H, dw_hh, 0, H,
-                                      seg=(T - 1, T, a_off, b_off), prec=ctx.prec)
-                            else:
-                                dw_hh.zero_()
-                            colsum(dgh[l][s], goff, B * T, 3 * H, 3 * H, db_hh)
-                            sgemm(1, 0, 3 * H, I, B * T, dgx[l][s], d * 3 * H, 6 * H, inp, 0, I, dw_ih, 0, I, prec=ctx.prec)
-                            colsum(dgx[l][s], d * 3 * H, B * T, 3 * H, 6 * H, db_ih)
-        for kind, _ in groups:
-            if kind == "side":
-                main.wait_stream(side_stream(dev))
+                    if ev_light is not None:
+                        main.wait_event(ev_light)
+                    level_scan(l, heavy)
+                    ev_heavy = torch.cuda.Event()
+                    ev_heavy.record(main)
+                    level_gemms(l, heavy)
+                    side.wait_event(ev_heavy)
+                    with torch.cuda.stream(side):
+                        level_scan(l, light)
+                        ev_light = torch.cuda.Event()
+                        ev_light.record(side)
+                        level_gemms(l, light)
+            finally:
+                _FENCED[0] = False
+            main.wait_stream(side)
+        else:
+            for kind, idxs in groups:
+                stream = main
+                if kind == "side":
+                    stream = side_stream(dev)
+                    stream.wait_stream(main)
+                with torch.cuda.stream(stream):
+                    for l in range(L - 1, -1, -1):
+                        level_scan(l, idxs)
+                        level_gemms(l, idxs)
+            for kind, _ in groups:
+                if kind == "side":
+                    main.wait_stream(side_stream(dev))
         for s in range(n_stacks):
             out_grads[s * per] = dinp[0][s]
         return (None, None) + tuple(out_grads)

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Per-stream timeline of the big kernels of the last bench step from a rocprofv3 --kernel-trace sqlite db."""
+import collections
+import re
+import sqlite3
+import sys
+
+db = sqlite3.connect(sys.argv[1])
+rows = list(db.cursor().execute("select name, start, end, stream_id from kernels order by start"))
+loss = [i for i, r in enumerate(rows) if "va_loss" in r[0]]
+seg = rows[loss[-2]:loss[-1]]
+
+
+def short(n):
+    n = re.sub(r"\(anonymous namespace\)::|void |m3t_gru::", "", n)
+    return n[:44]
+
+
+base = seg[0][1]
+out = []
+for n, s, e, st in seg:
+    k = (short(n), st)
+    if out and out[-1][0] == k and s - out[-1][2] < 20000:
+        out[-1][2] = e; out[-1][3] += 1; out[-1][4] += e - s
+    else:
+        out.append([k, s, e, 1, e - s])
+thr = float(sys.argv[2]) if len(sys.argv) > 2 else 150e3
+for k, s, e, c, busy in out:
+    if busy > thr:
+        print("st%d  %8.3f -> %8.3f ms  n=%4d busy %7.3f  %s" % (k[1], (s - base) / 1e6, (e - base) / 1e6, c, busy / 1e6, k[0]))
+print("step span %.3f ms" % ((seg[-1][2] - base) / 1e6))
