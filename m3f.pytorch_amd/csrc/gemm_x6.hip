@@ -15,6 +15,7 @@
 // bytes, so both operand layouts store without bank conflicts.  Global loads of tile t+1 stay in flight in
 // registers while tile t is multiplied.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -41,6 +42,30 @@ __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l)
     l = (__bf16)r2;
 }
 
+// The same exact split on a PAIR of values with packed instructions: one v_cvt_pk_bf16_f32 rounds both (nearest even),
+// the two bf16 are widened back with a shift / a mask, one v_pk_add_f32 forms both remainders.  9 VALU instructions per
+// pair for all three terms, against ~17 per ELEMENT when hipcc scalarises split3 -- the splitting, not the MFMAs, was
+// what bounded this kernel.  o[s] = the pair's term s, packed (first value in the low half).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+template <int NS>
+__device__ __forceinline__ void split3_pair(f32x2 v, unsigned (&o)[3]) {
+    const bf16x2 h = __builtin_convertvector(v, bf16x2);
+    o[0] = __builtin_bit_cast(unsigned, h);
+    if (NS == 1) return;
+    f32x2 hf;
+    hf.x = __uint_as_float(o[0] << 16); hf.y = __uint_as_float(o[0] & 0xffff0000u);
+    const f32x2 r1 = v - hf;
+    const bf16x2 m = __builtin_convertvector(r1, bf16x2);
+    o[1] = __builtin_bit_cast(unsigned, m);
+    f32x2 mf;
+    mf.x = __uint_as_float(o[1] << 16); mf.y = __uint_as_float(o[1] & 0xffff0000u);
+    const f32x2 r2 = r1 - mf;
+    const bf16x2 l = __builtin_convertvector(r2, bf16x2);
+    o[2] = __builtin_bit_cast(unsigned, l);
+}
+
 // ---- K-contiguous operand ([rows][K]): 8 lanes cover one row's 32 k (a full 128-B line); thread = (k-quad c =
 // tid&7, rows (tid>>3) + 32 i): every wave load instruction fetches 8 whole lines
 __device__ __forceinline__ void kc_load(const float* __restrict__ p, size_t ld, float4 (&r)[4]) {
@@ -49,49 +74,45 @@ __device__ __forceinline__ void kc_load(const float* __restrict__ p, size_t ld, 
 }
 template <int NS>
 __device__ __forceinline__ void kc_store(unsigned char* __restrict__ S, const float4 (&r)[4]) {
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x & 255;
     const int c = tid & 7, r0 = tid >> 3;            // plane index c = (k-half, k-quad) of the 32-k tile
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float v[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
-        bf16x4 o[3];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            __bf16 h, m, l;
-            split3(v[e], h, m, l);
-            o[0][e] = h; o[1][e] = m; o[2][e] = l;
-        }
+        unsigned lo[3], hi2[3];                      // k pairs (0,1) and (2,3) of this row
+        split3_pair<NS>((f32x2){r[i].x, r[i].y}, lo);
+        split3_pair<NS>((f32x2){r[i].z, r[i].w}, hi2);
 #pragma unroll
         for (int s = 0; s < NS; ++s)
-            *reinterpret_cast<bf16x4*>(S + s * SPLIT_BYTES + c * PLANE + (r0 + 32 * i) * 8) = o[s];
+            *reinterpret_cast<u32x2*>(S + s * SPLIT_BYTES + c * PLANE + (r0 + 32 * i) * 8) = (u32x2){lo[s], hi2[s]};
     }
 }
 // ---- row-contiguous operand ([K][rows]): thread = (k-quad = tid>>5 (4 k), 4 rows at (tid&31)*4): a 4x4 block
 template <int NS>
 __device__ __forceinline__ void mc_store(unsigned char* __restrict__ S, const float4 (&r)[4]) {
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x & 255;
     const int kq = tid >> 5, row0 = (tid & 31) * 4;   // k-quad kq of the 32-k tile: half = kq>>2, quad = kq&3
-    bf16x8 o[3][2];                                   // [split][row pair]: rows (row0, row0+1), (row0+2, row0+3)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 o[3][2];                                    // [split][row pair]: rows (row0, row0+1), (row0+2, row0+3)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {                     // row row0 + i: its 4 k values are component i of r[0..3]
-        const float v[4] = {i == 0 ? r[0].x : i == 1 ? r[0].y : i == 2 ? r[0].z : r[0].w,
-                            i == 0 ? r[1].x : i == 1 ? r[1].y : i == 2 ? r[1].z : r[1].w,
-                            i == 0 ? r[2].x : i == 1 ? r[2].y : i == 2 ? r[2].z : r[2].w,
-                            i == 0 ? r[3].x : i == 1 ? r[3].y : i == 2 ? r[3].z : r[3].w};
+        const float v0 = i == 0 ? r[0].x : i == 1 ? r[0].y : i == 2 ? r[0].z : r[0].w;
+        const float v1 = i == 0 ? r[1].x : i == 1 ? r[1].y : i == 2 ? r[1].z : r[1].w;
+        const float v2 = i == 0 ? r[2].x : i == 1 ? r[2].y : i == 2 ? r[2].z : r[2].w;
+        const float v3 = i == 0 ? r[3].x : i == 1 ? r[3].y : i == 2 ? r[3].z : r[3].w;
+        unsigned lo[3], hi2[3];
+        split3_pair<NS>((f32x2){v0, v1}, lo);
+        split3_pair<NS>((f32x2){v2, v3}, hi2);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            __bf16 h, m, l;
-            split3(v[e], h, m, l);
-            o[0][i >> 1][(i & 1) * 4 + e] = h;
-            o[1][i >> 1][(i & 1) * 4 + e] = m;
-            o[2][i >> 1][(i & 1) * 4 + e] = l;
+        for (int s = 0; s < NS; ++s) {
+            o[s][i >> 1][(i & 1) * 2 + 0] = lo[s];
+            o[s][i >> 1][(i & 1) * 2 + 1] = hi2[s];
         }
     }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {                    // 4 rows x 8 B = 32 contiguous bytes per split
         unsigned char* q = S + s * SPLIT_BYTES + kq * PLANE + row0 * 8;
-        *reinterpret_cast<bf16x8*>(q) = o[s][0];
-        *reinterpret_cast<bf16x8*>(q + 16) = o[s][1];
+        *reinterpret_cast<u32x4*>(q) = o[s][0];
+        *reinterpret_cast<u32x4*>(q + 16) = o[s][1];
     }
 }
 
