@@ -1,15 +1,17 @@
-// BiGRU recurrence for gfx950.  The T-step dependency chain is cut at every time step
-// (one launch per step: an RNN step is an all-to-all seam -- every hidden unit of h_t needs
-// all of h_{t-1} -- and on MI355X a kernel boundary (~1.5 us) is cheaper than an in-launch
-// cross-CU exchange, MI355X_MICROARCH.md price list).  What one launch does:
+// BiGRU recurrence for gfx950: entry points, launch planning, and the LAUNCH-PER-STEP kernels.
+// Default path since the persistent scans exist (gru_persist.hip: one launch per level, W_hh in registers, h_t exchanged
+// between CUs as tagged granules): this file's step kernels now serve the levels that path does not take -- H not a
+// multiple of 128 or above 512, levels that do not fit the chip at one workgroup per CU, scans issued on a side
+// stream without fencing, M3T_SCAN_PERSIST=0 -- and are the reference the persistent kernels are tested against bit
+// for bit.  What one step launch does:
 //   * it advances ALL independent direction-scans of the level at once (both directions,
 //     every independent stack), so the chip sees sum_s (H_s/16) x ceil(B/32) workgroups;
 //   * a workgroup owns 16 hidden units of one scan: the three gate columns r,z,n of those
 //     units (a [32 x 48] tile of h_{t-1} W_hh^T, K = H) on fp32 MFMA 16x16x4 (exact fp32),
 //     K split over its 8 waves, operands loaded straight to registers as float4 along K with
 //     EVERY load of the pass in flight before the first MFMA (one L2 round trip per step, not
-//     one per k-chunk; W_hh stays L2/MALL-resident across the T launches), fixed-order LDS
-//     reduction, then the gate math for its own units -- gates never travel un-fused.
+//     one per k-chunk), fixed-order LDS reduction, then the cell math for its own units --
+//     gates never travel un-fused.  The T launches of a call are replayed as one hipGraph.
 // Backward runs the same structure in reverse time: dh_{t} = dout_t + z_{t+1} dh_{t+1}
 // + dgh_{t+1} W_hh, with the matmul of step t+1 and the gate derivative of step t fused
 // in one launch; dW_hh / dW_ih / dx are left to big GEMMs after the scan.
