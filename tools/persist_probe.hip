@@ -5,7 +5,8 @@
 // 8-byte agent-scope store, the tag is the step number; two slots ping-pong.  Spins are bounded.
 // (Tried and dropped: an XCD-local variant -- groups on one XCD via blockIdx % 8, which tools/xcc_probe.hip shows is a
 // stable map, workgroup-scope (sc0) stores/loads through the shared L2 -- ran 1.5 us per step when it worked and hit the
-// spin limit on other runs: not a reliable publish, as the guide's "XCD-local ending" warning says.)
+// spin limit on other runs -- also with an explicit `buffer_inv sc0` before every poll and plain loads/stores: not a
+// reliable publish, as the guide's "XCD-local ending" warning says.)
 //   hipcc -O3 --offload-arch=gfx950 tools/persist_probe.hip -o tools/bin/persist_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
