@@ -30,6 +30,8 @@ extern "C" {
 #define M3T_MAX_SCANS 8
 #define M3T_ESPIN 10002          /* a persistent scan gave up waiting for a peer workgroup (see m3t_gru_scan_fwd) */
 #define M3T_SCAN_NO_PERSIST 1    /* m3t_gru_scan_* flags: take the launch-per-step path */
+#define M3T_SCAN_FP32 4          /* m3t_gru_scan_fwd flags: keep the recurrent product on fp32 MFMAs (bit-identical to the
+                                  * launch-per-step kernels) instead of the fp32-accurate bf16x6 form */
 #define M3T_BF16 2               /* precision flag shared by m3t_sgemm (= M3T_GEMM_BF16), m3t_conv1d_* and m3t_gru_scan_*:
                                   * matmul operands rounded to bf16 (nearest even), fp32 accumulate, fp32 state/epilogue */
 /* m3t_sgemm flags: BACKGROUND caps residency at one workgroup per CU (for GEMMs that run on a side stream
@@ -93,7 +95,9 @@ typedef struct {
 
 /* ws (optional, 16-B aligned): scratch for the fragment-ordered fast paths -- per scan 3*H*H floats of re-laid
  * weights + 4 * ceil32(B) * H floats of ping-pong state / exchange granules; without it (or when H % 16 != 0) a
- * slower kernel that reads the row-major operands directly is used.  Results are identical on every path.
+ * slower kernel that reads the row-major operands directly is used.  Results are identical on every path, except that the persistent FORWARD scan
+ * at H = 256 / 512 runs its recurrent product as bf16x6 (fp32-accurate, ~1e-6 from the fp32-MFMA kernels; flag
+ * M3T_SCAN_FP32 or env M3T_SCAN_X6=0 keeps fp32 MFMAs and bit-identity).
  * Execution: when every H of the level is a multiple of 128 (<= 512) and the level fits the chip at one workgroup
  * per CU, ONE persistent launch runs all T steps (W_hh held in registers, h_t exchanged between CUs through tagged
  * granules); otherwise one launch per time step.  A persistent launch needs all its workgroups resident: never run

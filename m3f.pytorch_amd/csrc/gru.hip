@@ -617,7 +617,7 @@ extern "C" int m3t_gru_scan_fwd(const m3t_gru_fwd_desc* scans, int n_scans, int 
     for (int i = 0; i < n_scans; ++i) {
         Hs[i] = scans[i].H;
         frag = frag && scans[i].H % 16 == 0;
-        need += (size_t)3 * scans[i].H * scans[i].H + xfrag_floats(scans[i].H, B, false);
+        need += (size_t)5 * scans[i].H * scans[i].H + xfrag_floats(scans[i].H, B, false);   // 5 H^2: fp32 or bf16x3 fragments
     }
     if (frag && need * sizeof(float) <= ws_bytes) {
         const ScanPlan plan = plan_level(Hs, n_scans, B);
@@ -635,20 +635,22 @@ extern "C" int m3t_gru_scan_fwd(const m3t_gru_fwd_desc* scans, int n_scans, int 
             fg.d[i] = d;
             fg.blk_start[i] = nblk;
             nblk += (d.H / 16) * nrb;
-            fp.wfrag[i] = p; p += (size_t)3 * d.H * d.H;
+            fp.wfrag[i] = p; p += (size_t)5 * d.H * d.H;
             fp.xfrag[i] = p; fp.xstride[i] = bpad * d.H; p += xfrag_floats(d.H, B, false);
         }
         for (int i = n_scans; i <= M3T_MAX_SCANS; ++i) fg.blk_start[i] = nblk;
         if (!(flags & M3T_SCAN_NO_PERSIST) && persist_fwd_check(fg, B, T)) {
             // one launch for all T steps: W_hh in registers, h_t exchanged through tagged granules (gru_persist.hip)
-            for (int i = 0; i < n_scans; ++i) {
-                const int H = fg.d[i].H;
-                int blk = (3 * H * H + 255) / 256;
-                if (blk > 1024) blk = 1024;
-                wfrag_fwd_prep_kernel<<<blk, 256, 0, s>>>(fg.d[i].w_hh, fp.wfrag[i], H, fg.bf16);
+            if (!persist_fwd_uses_x6(fg, B, T, flags)) {
+                for (int i = 0; i < n_scans; ++i) {
+                    const int H = fg.d[i].H;
+                    int blk = (3 * H * H + 255) / 256;
+                    if (blk > 1024) blk = 1024;
+                    wfrag_fwd_prep_kernel<<<blk, 256, 0, s>>>(fg.d[i].w_hh, fp.wfrag[i], H, fg.bf16);
+                }
+                M3T_LAUNCH_CHECK();
             }
-            M3T_LAUNCH_CHECK();
-            return persist_fwd_launch(fg, fp, B, T, s);
+            return persist_fwd_launch(fg, fp, B, T, flags, s);
         }
         return replay_or_capture(make_key(1, fg, &fp, B, T, rt), s, [&]() {
             for (int i = 0; i < n_scans; ++i) {

@@ -206,6 +206,209 @@ __global__ __launch_bounds__(NT) void gru_persist_fwd_kernel(FwdGroup g, FragPtr
         for (int i = 0; i < 6; ++i) ex.prof[i] = (unsigned long long)psum[i];
 }
 
+// ------------------------------------------------------------------------------------------------ forward, bf16x6
+// The recurrent product of the forward scan on the bf16 matrix pipe, still fp32-accurate: h and W_hh are each split
+// exactly into three bf16 terms and a product is the six MFMAs of weight >= 2^-16 (as the GEMM, gemm_x6.hip).  Why
+// here: at H = 512 the 48 fp32 MFMAs of a wave (two waves share a SIMD) were ~1.5 us of a ~4.5 us step; the 36
+// v_mfma_f32_16x16x32_bf16 that replace them cost a third of that.  The split of h is done ONCE by the producer: a
+// granule is {h1, h2, h3, tag} (3 x bf16 + a 16-bit tag in 8 bytes), so the consumer only re-pairs 16-bit halves
+// (v_perm_b32) into MFMA operands; W_hh is split by the prep kernel into the B-operand order and lives in 72 VGPRs.
+// Per wave: chunks c = wave + 8m; MFMA k-step s uses chunks m = 2s (k-groups 0,1) and 2s+1 (k-groups 2,3), lane
+// (row = lane & 15, q = lane >> 4) holding units 8(q&1) .. +7 of its chunk.  Granule i of a workgroup's tile:
+// j = i >> 5, half = (i >> 4) & 1, row = i & 15  <->  unit 8*half + j: a load of step j reads 32 consecutive granules
+// from each of two producers.  Only the backward scan needs the launch-per-step kernels' bit pattern; results here
+// agree with them to fp32 rounding (~1e-6), not bit for bit (M3T_SCAN_FP32 forces the fp32-MFMA kernel).
+typedef __bf16 pbf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned pu32x4 __attribute__((ext_vector_type(4)));
+
+// wfrag6[ub][wave][s][ct][t][lane][8 bf16]: split t of W_hh[ct*H + ub*16 + (lane&15)][unit(wave, s, lane>>4, e)]
+__global__ void wfrag6_prep_kernel(const float* __restrict__ w_hh, unsigned short* __restrict__ wf, int H) {
+    const int nch = H >> 4, ks = nch >> 4;            // ks = k-steps per wave = NC / 2
+    const size_t total = (size_t)3 * H * H;           // one thread per weight: writes its three terms
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int e = i & 7, l = (i >> 3) & 63;
+        size_t r = i >> 9;
+        const int ct = r % 3; r /= 3;
+        const int s = r % ks; r /= ks;
+        const int w = r % NW, ub = r / NW;
+        const int q = l >> 4;
+        const int unit = 16 * (w + NW * (2 * s + (q >> 1))) + 8 * (q & 1) + e;
+        const float x = w_hh[((size_t)ct * H + ub * 16 + (l & 15)) * H + unit];
+        const __bf16 b1 = (__bf16)x;
+        const float r1 = x - (float)b1;
+        const __bf16 b2 = (__bf16)r1;
+        const __bf16 b3 = (__bf16)(r1 - (float)b2);
+        const size_t base = ((((size_t)(ub * NW + w) * ks + s) * 3 + ct) * 3) * 512 + (size_t)l * 8 + e;
+        wf[base] = __builtin_bit_cast(unsigned short, b1);
+        wf[base + 512] = __builtin_bit_cast(unsigned short, b2);
+        wf[base + 1024] = __builtin_bit_cast(unsigned short, b3);
+    }
+}
+
+template <int NC>
+__global__ __launch_bounds__(NT) void gru_persist_fwd6_kernel(FwdGroup g, FragPtrs fp, ExPtrs ex, int B, int T, int G, int nrb,
+                                                              unsigned* err) {
+    constexpr int ROWS = 16, KS = NC / 2;
+    constexpr int H = 128 * NC, nch = H >> 4;
+    __shared__ float red[2][NW][3][ROWS][UB + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gid = (int)blockIdx.x % G, ub = (int)blockIdx.x / G;
+    const int s = gid / nrb, rb = gid % nrb;
+    const m3t_gru_fwd_desc d = g.d[s];
+    const int j0 = ub * UB, r0 = rb * ROWS;
+
+    pbf16x8 wf[KS][3][3];                              // [k-step][gate tile][term]
+    {
+        const pu32x4* Wf = reinterpret_cast<const pu32x4*>(fp.wfrag[s]) + ((size_t)(ub * NW + wave) * KS * 9) * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < KS; ++k)
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) wf[k][ct][t] = __builtin_bit_cast(pbf16x8, Wf[((k * 3 + ct) * 3 + t) * 64]);
+    }
+    // cell-math threads in granule order (see the header): granule tid <-> row tid & 15, unit 8*((tid>>4)&1) + (tid>>5)
+    const bool pw = tid < ROWS * UB;
+    const int prow = tid & 15, pu = ((tid >> 4) & 1) * 8 + ((tid >> 5) & 7);
+    const int pb = r0 + prow, pj = j0 + pu;
+    const bool pok = pw && pb < B;
+    float br = 0.f, bz = 0.f, bn = 0.f, hprev = 0.f;
+    if (pw) { br = d.b_hh[pj]; bz = d.b_hh[H + pj]; bn = d.b_hh[2 * H + pj]; }
+
+    constexpr size_t TILE = 256;
+    unsigned long long* gran = reinterpret_cast<unsigned long long*>(ex.gran[s]);
+    const size_t slot = ex.slot[s];
+    const size_t grp = (size_t)rb * nch * TILE;
+    const size_t pub = grp + (size_t)ub * TILE + tid;
+    // this lane's gather base inside a producer tile: chunk m = 2s + (q >> 1); granule (q & 1) * 16 + row, + 32 j
+    const int q = lane >> 4;
+    const size_t lane_off = (size_t)(wave + NW * (q >> 1)) * TILE + (q & 1) * 16 + (lane & 15);
+    bool dead = false;
+    const bool stamp = ex.prof != nullptr && blockIdx.x == 0 && tid == 0;
+    long long psum[6] = {0, 0, 0, 0, 0, 0}, last = stamp ? clock64() : 0;
+
+    const float* xp = d.xproj + (size_t)pb * T * d.ldx + d.xoff + pj + (d.reverse ? (size_t)(T - 1) * d.ldx : 0);
+    const ptrdiff_t xstep = d.reverse ? -(ptrdiff_t)d.ldx : (ptrdiff_t)d.ldx;
+    float xr = 0.f, xz = 0.f, xn = 0.f;
+    if (pok) { xr = xp[0]; xz = xp[H]; xn = xp[2 * H]; }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): see gru_persist_fwd_kernel
+
+    for (int step = 0; step < T; ++step) {
+        const int t = d.reverse ? T - 1 - step : step;
+        M3T_STAMP(0);
+        if (step > 0) {
+            const unsigned tag = (unsigned)step & 0xffffu;
+            const unsigned long long* src = gran + (size_t)((step - 1) & 1) * slot + grp + lane_off;
+            unsigned long long v[KS][8];
+            int spins = 0;
+            for (;;) {
+#pragma unroll
+                for (int k = 0; k < KS; ++k) {
+                    const unsigned long long* qp = src + (size_t)(2 * k) * NW * TILE;
+                    asm volatile("global_load_dwordx2 %0, %8, off sc1\n\t"
+                                 "global_load_dwordx2 %1, %8, off offset:256 sc1\n\t"
+                                 "global_load_dwordx2 %2, %8, off offset:512 sc1\n\t"
+                                 "global_load_dwordx2 %3, %8, off offset:768 sc1\n\t"
+                                 "global_load_dwordx2 %4, %8, off offset:1024 sc1\n\t"
+                                 "global_load_dwordx2 %5, %8, off offset:1280 sc1\n\t"
+                                 "global_load_dwordx2 %6, %8, off offset:1536 sc1\n\t"
+                                 "global_load_dwordx2 %7, %8, off offset:1792 sc1"
+                                 : "=&v"(v[k][0]), "=&v"(v[k][1]), "=&v"(v[k][2]), "=&v"(v[k][3]), "=&v"(v[k][4]),
+                                   "=&v"(v[k][5]), "=&v"(v[k][6]), "=&v"(v[k][7])
+                                 : "v"(qp) : "memory");
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                bool ok = true;
+#pragma unroll
+                for (int k = 0; k < KS; ++k)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        asm volatile("" : "+v"(v[k][j]));
+                        ok = ok && ((unsigned)(v[k][j] >> 48) == tag);
+                    }
+                if (__all(ok) || dead) break;
+                if (++spins > SPIN_LIMIT) { dead = true; if (lane == 0) raise_spin(err, step); break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            M3T_STAMP(1);
+            f32x4 acc[3];
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+                pu32x4 a1, a2, a3;                         // the three terms of 8 consecutive units, paired into dwords
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const unsigned lo0 = (unsigned)v[k][2 * jj], lo1 = (unsigned)v[k][2 * jj + 1];
+                    const unsigned hi0 = (unsigned)(v[k][2 * jj] >> 32), hi1 = (unsigned)(v[k][2 * jj + 1] >> 32);
+                    a1[jj] = __builtin_amdgcn_perm(lo1, lo0, 0x05040100u);
+                    a2[jj] = __builtin_amdgcn_perm(lo1, lo0, 0x07060302u);
+                    a3[jj] = __builtin_amdgcn_perm(hi1, hi0, 0x05040100u);
+                }
+                const pbf16x8 A1 = __builtin_bit_cast(pbf16x8, a1), A2 = __builtin_bit_cast(pbf16x8, a2),
+                              A3 = __builtin_bit_cast(pbf16x8, a3);
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) {           // smallest terms first
+                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A3, wf[k][ct][0], acc[ct], 0, 0, 0);
+                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2, wf[k][ct][1], acc[ct], 0, 0, 0);
+                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1, wf[k][ct][2], acc[ct], 0, 0, 0);
+                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2, wf[k][ct][0], acc[ct], 0, 0, 0);
+                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1, wf[k][ct][1], acc[ct], 0, 0, 0);
+                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1, wf[k][ct][0], acc[ct], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[step & 1][wave][ct][(lane >> 4) * 4 + r][lane & 15] = acc[ct][r];
+        }
+        M3T_STAMP(2);
+        __syncthreads();
+        M3T_STAMP(3);
+        if (pw) {
+            float hr = br, hz = bz, hn = bn;
+            if (step > 0) {
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    hr += red[step & 1][w][0][prow][pu];
+                    hz += red[step & 1][w][1][prow][pu];
+                    hn += red[step & 1][w][2][prow][pu];
+                }
+            }
+            const GateFwd c = gru_cell_fwd(xr, xz, xn, hr, hz, hn, hprev);
+            if (step + 1 < T) {
+                const float hv = pok ? c.h : 0.f;
+                const __bf16 h1 = (__bf16)hv;
+                const float r1 = hv - (float)h1;
+                const __bf16 h2 = (__bf16)r1;
+                const __bf16 h3 = (__bf16)(r1 - (float)h2);
+                const unsigned long long gq = (unsigned long long)__builtin_bit_cast(unsigned short, h1) |
+                                              ((unsigned long long)__builtin_bit_cast(unsigned short, h2) << 16) |
+                                              ((unsigned long long)__builtin_bit_cast(unsigned short, h3) << 32) |
+                                              ((unsigned long long)(((unsigned)step + 1u) & 0xffffu) << 48);
+                __hip_atomic_store(gran + (size_t)(step & 1) * slot + pub, gq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            M3T_STAMP(4);
+            hprev = c.h;
+            if (pok) {
+                d.out[((size_t)pb * T + t) * d.ldo + d.ooff + pj] = c.h;
+                if (d.gates) {
+                    float* gp = d.gates + ((size_t)pb * T + t) * 4 * H;
+                    gp[pj] = c.r; gp[H + pj] = c.z; gp[2 * H + pj] = c.n; gp[3 * H + pj] = hn;
+                }
+                if (d.h_n && step == T - 1) d.h_n[(size_t)pb * H + pj] = c.h;
+                if (step + 1 < T) {
+                    xp += xstep;
+                    xr = xp[0]; xz = xp[H]; xn = xp[2 * H];
+                }
+            }
+        }
+        M3T_STAMP(5);
+    }
+    if (stamp)
+        for (int i = 0; i < 6; ++i) ex.prof[i] = (unsigned long long)psum[i];
+}
+
 // ------------------------------------------------------------------------------------------------ backward
 template <int NC, int RT>
 __global__ __launch_bounds__(NT) void gru_persist_bwd_kernel(BwdGroup g, FragPtrs fp, ExPtrs ex, int B, int T, int G, int nrb,
@@ -462,6 +665,22 @@ size_t persist_exchange_bytes(int H, int B, bool backward) {
     return 2 * rows * (size_t)H * (backward ? 16 : 8);
 }
 
+static bool x6_scan_enabled() {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = std::getenv("M3T_SCAN_X6");
+        on = (e && e[0] == '0') ? 0 : 1;
+    }
+    return on == 1;
+}
+
+// the forward recurrent product runs as bf16x6 (gru_persist_fwd6_kernel) for H = 256 / 512 at 16 rows per workgroup
+bool persist_fwd_uses_x6(const FwdGroup& g, int B, int T, int flags) {
+    Shape sh;
+    if ((flags & M3T_SCAN_FP32) || g.bf16 || !x6_scan_enabled() || T >= 65535 || !level_shape(g.d, g.n, B, sh)) return false;
+    return sh.rt == 1 && (sh.nc == 2 || sh.nc == 4);
+}
+
 bool persist_fwd_check(const FwdGroup& g, int B, int T) {
     Shape sh;
     return persist_enabled() && T >= 2 && level_shape(g.d, g.n, B, sh) && ensure_err_word() &&
@@ -474,7 +693,7 @@ bool persist_bwd_check(const BwdGroup& g, int B, int T) {
            sh.grid <= resident_capacity(pick_bwd(sh));
 }
 
-int persist_fwd_launch(const FwdGroup& g, const FragPtrs& fp, int B, int T, hipStream_t s) {
+int persist_fwd_launch(const FwdGroup& g, const FragPtrs& fp, int B, int T, int flags, hipStream_t s) {
     Shape sh;
     if (!level_shape(g.d, g.n, B, sh) || !ensure_err_word()) return M3T_EINVAL;
     ExPtrs ex;
@@ -485,6 +704,19 @@ int persist_fwd_launch(const FwdGroup& g, const FragPtrs& fp, int B, int T, hipS
         if (e != hipSuccess) return (int)e;
     }
     ++g_launches;
+    if (persist_fwd_uses_x6(g, B, T, flags)) {
+        for (int i = 0; i < g.n; ++i) {                                      // W_hh -> bf16x3 B-operand fragments
+            const int H = g.d[i].H;
+            int blk = (3 * H * H + 255) / 256;
+            if (blk > 1024) blk = 1024;
+            wfrag6_prep_kernel<<<blk, 256, 0, s>>>(g.d[i].w_hh, reinterpret_cast<unsigned short*>(fp.wfrag[i]), H);
+        }
+        M3T_LAUNCH_CHECK();
+        if (sh.nc == 2) hipLaunchKernelGGL(gru_persist_fwd6_kernel<2>, dim3(sh.grid), dim3(NT), 0, s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
+        else hipLaunchKernelGGL(gru_persist_fwd6_kernel<4>, dim3(sh.grid), dim3(NT), 0, s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
+        M3T_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(pick_fwd(sh), dim3(sh.grid), dim3(NT), 0, s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
     M3T_LAUNCH_CHECK();
     return 0;

@@ -213,6 +213,7 @@ def linear(x, w, b=None, act=0):
 
 # ----------------------------------------------------------------------------- BiGRU
 SCAN_PER_STEP = [False]     # tests/benchmarks: force the launch-per-step scan path
+SCAN_FP32 = [False]         # tests: keep the persistent forward scan on fp32 MFMAs (bit-identical to the per-step kernels)
 
 
 _FENCED = [False]     # set by the interleaved schedule of _MultiBiGRU: its side-stream scans are fenced by events
@@ -224,7 +225,7 @@ def _scan_flags(device):
     unless the caller fences them against every other scan with events (the interleaved schedule of _MultiBiGRU)."""
     if SCAN_PER_STEP[0] or (_ws_tag(device) == "side" and not _FENCED[0]):
         return _lib.M3T_SCAN_NO_PERSIST
-    return 0
+    return _lib.M3T_SCAN_FP32 if SCAN_FP32[0] else 0
 
 
 def _scan_fwd(descs, B, T, prec=0):

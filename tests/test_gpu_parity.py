@@ -152,12 +152,15 @@ def test_gru_vs_oracle(B, T, I, H, L):
         close(prm.grad, g_ref[n], 2e-4, n)
 
 
+@pytest.mark.parametrize("exact", [True, False])
 @pytest.mark.parametrize("B,T,I,H,L", [(5, 9, 20, 128, 2), (32, 40, 24, 256, 2), (19, 23, 16, 512, 1), (32, 12, 32, 384, 1),
                                        (40, 6, 16, 128, 1)])
-def test_gru_persistent_scan_equals_per_step(B, T, I, H, L):
+def test_gru_persistent_scan_equals_per_step(B, T, I, H, L, exact):
     """The persistent scan (one launch for all T steps, W_hh in registers, tagged-granule exchange between CUs)
-    must take over for H % 128 == 0 levels and reproduce the launch-per-step kernels bit for bit (same MFMA chain and
-    reduction order), forward and backward, and both must match the oracle."""
+    must take over for H % 128 == 0 levels.  exact=True (flag M3T_SCAN_FP32: fp32 MFMAs everywhere): it reproduces the
+    launch-per-step kernels bit for bit, forward and backward (same MFMA chain and reduction order).  exact=False (the
+    default): the forward recurrent product at H = 256 / 512 runs as bf16x6 -- fp32-accurate, equal to the per-step
+    result to fp32 rounding.  Both must match the oracle."""
     from models.rnn import GRU
     from m3t import ops, _lib
     lib = _lib.load()
@@ -166,7 +169,7 @@ def test_gru_persistent_scan_equals_per_step(B, T, I, H, L):
     xn, ct = draw(rs, (B, T, I)), draw(rs, (B, T, 3))
 
     def run(per_step):
-        ops.SCAN_PER_STEP[0] = per_step
+        ops.SCAN_PER_STEP[0], ops.SCAN_FP32[0] = per_step, exact
         try:
             m.zero_grad()
             x = dev(xn, True)
@@ -177,14 +180,21 @@ def test_gru_persistent_scan_equals_per_step(B, T, I, H, L):
             launches = lib.m3t_gru_persist_count() - n0
             return y.detach().clone(), x.grad.clone(), {n: prm.grad.clone() for n, prm in m.named_parameters()}, launches
         finally:
-            ops.SCAN_PER_STEP[0] = False
+            ops.SCAN_PER_STEP[0], ops.SCAN_FP32[0] = False, False
 
     y1, dx1, g1, n1 = run(False)
     y0, dx0, g0, n0 = run(True)
     assert n0 == 0 and n1 == 2 * L, (n0, n1)            # one persistent launch per layer, forward and backward
-    assert torch.equal(y1, y0) and torch.equal(dx1, dx0)
-    for n in g0:
-        assert torch.equal(g1[n], g0[n]), n
+    if exact or H in (128, 384):                         # those widths always take the fp32-MFMA kernel
+        assert torch.equal(y1, y0) and torch.equal(dx1, dx0)
+        for n in g0:
+            assert torch.equal(g1[n], g0[n]), n
+    else:
+        close(y1, y0, 3e-6, "y vs per-step")
+        close(dx1, dx0, 3e-6, "dx vs per-step")
+        for n in g0:
+            close(g1[n], g0[n], 1e-5, n + " vs per-step")
+        assert not torch.equal(y1, y0)                   # it really is the other arithmetic
     p = {n: t.detach().cpu().numpy().astype(np.float64) for n, t in m.named_parameters()}
     y_ref, _, cache = O.gru_module_fwd(xn.astype(np.float64), p, L, 3, 2)
     dx_ref, g_ref = O.gru_module_bwd(ct.astype(np.float64), cache, p, L)
