@@ -88,7 +88,7 @@ typedef struct {
     const float* w_hh;   /* [3H,H]                                                         */
     const float* b_hh;   /* [3H]                                                           */
     float* out;          /* [B,T,ldo]; h_t written to columns [ooff, ooff+H)               */
-    float* gates;        /* [B,T,4H] saved r,z,n,(Whn h + bhn) for backward; NULL = skip   */
+    float* gates;        /* [B,T,H,4] saved (r,z,n,Whn h + bhn) per unit for backward (16-B aligned); NULL = skip */
     float* h_n;          /* [B,H] final hidden state (NULL = skip)                         */
     int H, reverse, ldx, xoff, ldo, ooff;
 } m3t_gru_fwd_desc;
@@ -115,7 +115,7 @@ int m3t_gru_scan_fwd(const m3t_gru_fwd_desc* scans, int n_scans, int B, int T,
 typedef struct {
     const float* dout;    /* [B,T,ldo]: grad wrt out, columns [ooff, ooff+H)               */
     const float* out;     /* forward h_t, same layout                                      */
-    const float* gates;   /* [B,T,4H] from forward                                         */
+    const float* gates;   /* [B,T,H,4] from forward                                        */
     const float* w_hh_t;  /* [H,3H] = W_hh transposed (m3t_transpose)                      */
     const float* dh_n;    /* [B,H] grad wrt final hidden state, or NULL                    */
     float* dgx;           /* [B,T,ldg], columns [goff, goff+3H)                            */

@@ -229,7 +229,7 @@ __global__ __launch_bounds__(NT) void gru_step_fwd_frag_kernel(FwdGroup g, FragP
     d.out[((size_t)pb * T + t) * d.ldo + d.ooff + pj] = h;
     if (d.gates) {
         float* gp = d.gates + ((size_t)pb * T + t) * 4 * H;
-        gp[pj] = r; gp[H + pj] = z; gp[2 * H + pj] = n; gp[3 * H + pj] = hn;
+        *reinterpret_cast<float4*>(gp + 4 * (size_t)pj) = make_float4(r, z, n, hn);
     }
     if (d.h_n && step == T - 1) d.h_n[(size_t)pb * H + pj] = h;
 }
@@ -261,10 +261,10 @@ __global__ __launch_bounds__(NT) void gru_step_bwd_frag_kernel(BwdGroup g, FragP
     if (pok) {
         dout = d.dout[((size_t)pb * T + t) * d.ldo + d.ooff + pj];
         const float* gp = d.gates + ((size_t)pb * T + t) * 4 * H;
-        gr = gp[pj]; gz = gp[H + pj]; gn = gp[2 * H + pj]; ghn = gp[3 * H + pj];
+        { const float4 g4 = *reinterpret_cast<const float4*>(gp + 4 * (size_t)pj); gr = g4.x; gz = g4.y; gn = g4.z; ghn = g4.w; }
         if (has_prev) hprev = d.out[((size_t)pb * T + tp) * d.ldo + d.ooff + pj];
         if (has_next) {
-            zn = d.gates[((size_t)pb * T + tn) * 4 * H + H + pj];
+            zn = d.gates[((size_t)pb * T + tn) * 4 * H + 4 * (size_t)pj + 1];
             dhn = d.dh[(size_t)pb * H + pj];
         } else if (d.dh_n) {
             dhn = d.dh_n[(size_t)pb * H + pj];
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(NT) void gru_step_fwd_kernel(FwdGroup g, int B, int
     d.out[((size_t)pb * T + t) * d.ldo + d.ooff + pj] = h;
     if (d.gates) {
         float* gp = d.gates + ((size_t)pb * T + t) * 4 * H;
-        gp[pj] = r; gp[H + pj] = z; gp[2 * H + pj] = n; gp[3 * H + pj] = hn;
+        *reinterpret_cast<float4*>(gp + 4 * (size_t)pj) = make_float4(r, z, n, hn);
     }
     if (d.h_n && step == T - 1) d.h_n[(size_t)pb * H + pj] = h;
 }
@@ -404,10 +404,10 @@ __global__ __launch_bounds__(NT) void gru_step_bwd_kernel(BwdGroup g, int B, int
     if (pok) {
         dout = d.dout[((size_t)pb * T + t) * d.ldo + d.ooff + pj];
         const float* gp = d.gates + ((size_t)pb * T + t) * 4 * H;
-        gr = gp[pj]; gz = gp[H + pj]; gn = gp[2 * H + pj]; ghn = gp[3 * H + pj];
+        { const float4 g4 = *reinterpret_cast<const float4*>(gp + 4 * (size_t)pj); gr = g4.x; gz = g4.y; gn = g4.z; ghn = g4.w; }
         if (has_prev) hprev = d.out[((size_t)pb * T + tp) * d.ldo + d.ooff + pj];
         if (has_next) {
-            zn = d.gates[((size_t)pb * T + tn) * 4 * H + H + pj];
+            zn = d.gates[((size_t)pb * T + tn) * 4 * H + 4 * (size_t)pj + 1];
             dhn = d.dh[(size_t)pb * H + pj];
         } else if (d.dh_n) {
             dhn = d.dh_n[(size_t)pb * H + pj];

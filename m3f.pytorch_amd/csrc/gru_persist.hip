@@ -190,7 +190,7 @@ __global__ __launch_bounds__(NT) void gru_persist_fwd_kernel(FwdGroup g, FragPtr
                 d.out[((size_t)pb * T + t) * d.ldo + d.ooff + pj] = c.h;
                 if (d.gates) {
                     float* gp = d.gates + ((size_t)pb * T + t) * 4 * H;
-                    gp[pj] = c.r; gp[H + pj] = c.z; gp[2 * H + pj] = c.n; gp[3 * H + pj] = hn;
+                    *reinterpret_cast<float4*>(gp + 4 * (size_t)pj) = make_float4(c.r, c.z, c.n, hn);
                 }
                 if (d.h_n && step == T - 1) d.h_n[(size_t)pb * H + pj] = c.h;
                 if (step + 1 < T) {
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(NT) void gru_persist_fwd6_kernel(FwdGroup g, FragPt
                 d.out[((size_t)pb * T + t) * d.ldo + d.ooff + pj] = c.h;
                 if (d.gates) {
                     float* gp = d.gates + ((size_t)pb * T + t) * 4 * H;
-                    gp[pj] = c.r; gp[H + pj] = c.z; gp[2 * H + pj] = c.n; gp[3 * H + pj] = hn;
+                    *reinterpret_cast<float4*>(gp + 4 * (size_t)pj) = make_float4(c.r, c.z, c.n, hn);
                 }
                 if (d.h_n && step == T - 1) d.h_n[(size_t)pb * H + pj] = c.h;
                 if (step + 1 < T) {
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd_kernel(BwdGroup g, FragPtr
         const int tp = d.reverse ? t + 1 : t - 1;
         dout = d.dout[((size_t)pb * T + t) * d.ldo + d.ooff + pj];
         const float* gp = d.gates + ((size_t)pb * T + t) * 4 * H;
-        gr = gp[pj]; gz = gp[H + pj]; gn = gp[2 * H + pj]; ghn = gp[3 * H + pj];
+        { const float4 g4 = *reinterpret_cast<const float4*>(gp + 4 * (size_t)pj); gr = g4.x; gz = g4.y; gn = g4.z; ghn = g4.w; }
         hprev = step < T - 1 ? d.out[((size_t)pb * T + tp) * d.ldo + d.ooff + pj] : 0.f;
     };
     if (pok) load_step(0);
