@@ -83,7 +83,7 @@ __device__ __forceinline__ u32x4 ld16_sc1(const u32x4* p) {
     return v;
 }
 
-template <int GS>
+template <int GS, int DUP>
 __global__ __launch_bounds__(512) void persist16(u32x4* gran, int NG, int T, int* err, int* torn, float* out) {
     __shared__ float red[8][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -96,20 +96,21 @@ __global__ __launch_bounds__(512) void persist16(u32x4* gran, int NG, int T, int
     int ntorn = 0;
     for (int t = 0; t < T && !dead; ++t) {
         const unsigned tag = (unsigned)t + 1u;
+        const size_t plane = (size_t)2 * NG * GS * GRAN;          // DUP planes, each laid out like the single-granule case
         const u32x4* src = gran + ((size_t)(t & 1) * NG + group) * GS * GRAN;
-        u32x4 v[NL];
+        u32x4 v[NL * DUP];
         int spins = 0;
         for (;;) {
             bool ok = true;
 #pragma unroll
-            for (int c = 0; c < NL; ++c) {
-                const int u = wave * PER_WAVE + c / 4;
-                const u32x4* q = src + (size_t)u * GRAN + (c % 4) * 64 + lane;
+            for (int c = 0; c < NL * DUP; ++c) {
+                const int u = wave * PER_WAVE + (c / DUP) / 4;
+                const u32x4* q = src + (size_t)(c % DUP) * plane + (size_t)u * GRAN + ((c / DUP) % 4) * 64 + lane;
                 asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[c]) : "v"(q) : "memory");
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int c = 0; c < NL; ++c) {
+            for (int c = 0; c < NL * DUP; ++c) {
                 asm volatile("" : "+v"(v[c]));       // values are defined only after the wait above
                 ok = ok && (v[c].w == tag);
             }
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(512) void persist16(u32x4* gran, int NG, int T, int
         }
         float s = 0.f;
 #pragma unroll
-        for (int c = 0; c < NL; ++c) {
+        for (int c = 0; c < NL * DUP; ++c) {
             const float a = __uint_as_float(v[c].x), b = __uint_as_float(v[c].y), cc = __uint_as_float(v[c].z);
             if (!dead && (b != a + 1.0f || cc != a + 2.0f)) ++ntorn;
             s += a;
@@ -135,7 +136,8 @@ __global__ __launch_bounds__(512) void persist16(u32x4* gran, int NG, int T, int
             u32x4* dst = gran + ((size_t)((t + 1) & 1) * NG + group) * GS * GRAN + (size_t)member * GRAN + threadIdx.x;
             u32x4 g;
             g.x = __float_as_uint(r); g.y = __float_as_uint(r + 1.0f); g.z = __float_as_uint(r + 2.0f); g.w = tag + 1u;
-            asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(g) : "memory");
+#pragma unroll
+            for (int dd = 0; dd < DUP; ++dd) { u32x4* q = dst + (size_t)dd * plane; asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(q), "v"(g) : "memory"); }
         }
         __syncthreads();
     }
@@ -143,13 +145,14 @@ __global__ __launch_bounds__(512) void persist16(u32x4* gran, int NG, int T, int
     if (threadIdx.x == 0) out[bid] = keep;
 }
 
-template <int GS>
+template <int GS, int DUP = 1>
 int run16(int NG, int T) {
-    const size_t n = (size_t)2 * NG * GS * GRAN;
+    const size_t n = (size_t)2 * NG * GS * GRAN * DUP;
     u32x4* gran; int* err; float* out;
     CK(hipMalloc(&gran, n * 16)); CK(hipMalloc(&err, 8)); CK(hipMalloc(&out, 4 * NG * GS));
     std::vector<unsigned> init(n * 4, 0u);
-    for (size_t i = 0; i < (size_t)NG * GS * GRAN; ++i) {
+    for (size_t i = 0; i < n; ++i) {
+        if ((i % ((size_t)2 * NG * GS * GRAN)) >= (size_t)NG * GS * GRAN) continue;      // slot 0 of every plane
         init[4 * i] = 0x3f800000u; init[4 * i + 1] = 0x40000000u; init[4 * i + 2] = 0x40400000u; init[4 * i + 3] = 1u;   // 1,2,3,tag 1
     }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -159,7 +162,7 @@ int run16(int NG, int T) {
         CK(hipMemset(err, 0, 8));
         CK(hipDeviceSynchronize());
         hipEventRecord(e0);
-        persist16<GS><<<NG * GS, 512>>>(gran, NG, T, err, err + 1, out);
+        persist16<GS, DUP><<<NG * GS, 512>>>(gran, NG, T, err, err + 1, out);
         hipEventRecord(e1);
         CK(hipEventSynchronize(e1));
         float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -167,7 +170,7 @@ int run16(int NG, int T) {
         CK(hipMemcpy(h_err, err, 8, hipMemcpyDeviceToHost));
         if (h_err[0] || h_err[1]) break;
     }
-    printf("16B granules GS=%d NG=%d T=%d: %.2f us/step  torn=%d%s\n", GS, NG, T, best * 1e3f / T, h_err[1],
+    printf("%dx16B granules GS=%d NG=%d T=%d: %.2f us/step  torn=%d%s\n", DUP, GS, NG, T, best * 1e3f / T, h_err[1],
            h_err[0] ? "  ** SPIN LIMIT HIT **" : "");
     hipFree(gran); hipFree(err); hipFree(out);
     return 0;
@@ -219,5 +222,7 @@ int main() {
     run16<32>(4, T);
     run16<16>(8, T);
     run16<8>(2, T);
+    run16<32, 2>(8, T);
+    run16<32, 2>(4, T);
     return 0;
 }
