@@ -121,6 +121,9 @@ typedef struct {
     float* dgx;           /* [B,T,ldg], columns [goff, goff+3H)                            */
     float* dgh;           /* [B,T,3H]                                                      */
     float* dh;            /* [B,H] scratch: running dL/dh_t                                */
+    float* db_part;       /* optional [B,4,H] scratch: per-clip sums over t of (dr~, dz~, dn~, dn~*r); with it the  */
+    float* db_ih;         /* scan also delivers db_ih [3H] = sum_b (dr~,dz~,dn~) and db_hh [3H] = sum_b (dr~,dz~,   */
+    float* db_hh;         /* dn~*r) -- the bias gradients, without a pass over dgx / dgh (all three NULL = skip)    */
     int H, reverse, ldo, ooff, ldg, goff;
 } m3t_gru_bwd_desc;
 

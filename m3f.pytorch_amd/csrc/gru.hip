@@ -301,6 +301,11 @@ __global__ __launch_bounds__(NT) void gru_step_bwd_frag_kernel(BwdGroup g, FragP
     float* gh = d.dgh + ((size_t)pb * T + t) * H3;
     gh[pj] = dr; gh[H + pj] = dz; gh[2 * H + pj] = c.dnr;
     d.dh[(size_t)pb * H + pj] = dht;
+    if (d.db_part) {                       // bias-gradient partials of this clip, accumulated across the step launches
+        float* q = d.db_part + (size_t)pb * 4 * H + pj;
+        if (step == 0) { q[0] = dr; q[H] = dz; q[2 * H] = dn; q[3 * H] = c.dnr; }
+        else { q[0] += dr; q[H] += dz; q[2 * H] += dn; q[3 * H] += c.dnr; }
+    }
 }
 
 template <bool FAST>
@@ -451,6 +456,28 @@ __global__ __launch_bounds__(NT) void gru_step_bwd_kernel(BwdGroup g, int B, int
     float* gh = d.dgh + ((size_t)pb * T + t) * H3;
     gh[pj] = dr; gh[H + pj] = dz; gh[2 * H + pj] = c.dnr;
     d.dh[(size_t)pb * H + pj] = dht;
+    if (d.db_part) {                       // bias-gradient partials of this clip, accumulated across the step launches
+        float* q = d.db_part + (size_t)pb * 4 * H + pj;
+        if (step == 0) { q[0] = dr; q[H] = dz; q[2 * H] = dn; q[3 * H] = c.dnr; }
+        else { q[0] += dr; q[H] += dz; q[2 * H] += dn; q[3 * H] += c.dnr; }
+    }
+}
+
+// db_ih[g*H + j] = sum_b part[b][g][j] (g = r,z,n); db_hh = the same with the n block taken from part[b][3] (dn*r).
+// One thread per (scan, unit); B terms in a fixed order.
+struct BiasFinish { const float* part[M3T_MAX_SCANS]; float* db_ih[M3T_MAX_SCANS]; float* db_hh[M3T_MAX_SCANS]; int H[M3T_MAX_SCANS]; int n; };
+__global__ void gru_bias_finish_kernel(BiasFinish f, int B) {
+    const int s = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= f.n || !f.part[s] || j >= f.H[s]) return;
+    const int H = f.H[s];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float* q = f.part[s] + (size_t)b * 4 * H + j;
+        a0 += q[0]; a1 += q[H]; a2 += q[2 * H]; a3 += q[3 * H];
+    }
+    if (f.db_ih[s]) { f.db_ih[s][j] = a0; f.db_ih[s][H + j] = a1; f.db_ih[s][2 * H + j] = a2; }
+    if (f.db_hh[s]) { f.db_hh[s][j] = a0; f.db_hh[s][H + j] = a1; f.db_hh[s][2 * H + j] = a3; }
 }
 
 }  // namespace
@@ -673,8 +700,8 @@ extern "C" int m3t_gru_scan_fwd(const m3t_gru_fwd_desc* scans, int n_scans, int 
     return 0;
 }
 
-extern "C" int m3t_gru_scan_bwd(const m3t_gru_bwd_desc* scans, int n_scans, int B, int T, float* ws, size_t ws_bytes,
-                                int flags, void* stream) {
+static int scan_bwd_impl(const m3t_gru_bwd_desc* scans, int n_scans, int B, int T, float* ws, size_t ws_bytes, int flags,
+                         void* stream) {
     if (n_scans <= 0 || B <= 0 || T <= 0) return 0;
     if (persist_poll_error()) return M3T_ESPIN;
     if (n_scans > M3T_MAX_SCANS || !scans) return M3T_EINVAL;
@@ -755,5 +782,27 @@ extern "C" int m3t_gru_scan_bwd(const m3t_gru_bwd_desc* scans, int n_scans, int 
     else
         for (int step = 0; step < T; ++step) gru_step_bwd_kernel<false><<<grid, NT, 0, s>>>(g, B, T, step);
     M3T_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int m3t_gru_scan_bwd(const m3t_gru_bwd_desc* scans, int n_scans, int B, int T, float* ws, size_t ws_bytes,
+                                int flags, void* stream) {
+    const int rc = scan_bwd_impl(scans, n_scans, B, T, ws, ws_bytes, flags, stream);
+    if (rc || n_scans <= 0 || B <= 0 || T <= 0) return rc;
+    BiasFinish f;
+    std::memset(&f, 0, sizeof(f));
+    f.n = n_scans;
+    int maxh = 0;
+    bool any = false;
+    for (int i = 0; i < n_scans; ++i) {
+        const m3t_gru_bwd_desc& d = scans[i];
+        if ((d.db_ih || d.db_hh) && !d.db_part) return M3T_EINVAL;
+        f.part[i] = d.db_part; f.db_ih[i] = d.db_ih; f.db_hh[i] = d.db_hh; f.H[i] = d.H;
+        if (d.db_part && (d.db_ih || d.db_hh)) { any = true; maxh = d.H > maxh ? d.H : maxh; }
+    }
+    if (any) {
+        gru_bias_finish_kernel<<<dim3(cdiv(maxh, 128), n_scans), 128, 0, (hipStream_t)stream>>>(f, B);
+        M3T_LAUNCH_CHECK();
+    }
     return 0;
 }

@@ -436,6 +436,7 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd_kernel(BwdGroup g, FragPtr
     const int pb = r0 + prow, pj = j0 + pu;
     const bool pok = pw && pb < B;
     float dh_carry = 0.f, z_next = 0.f;                // dh_{t+1} and z_{t+1} of this thread's (row, unit)
+    float sb_r = 0.f, sb_z = 0.f, sb_n = 0.f, sb_nr = 0.f;   // sums over t of the gate gradients: the bias gradients of this clip
     if (pok && d.dh_n) dh_carry = d.dh_n[(size_t)pb * H + pj];
 
     constexpr size_t TILE = (size_t)RT * 256;
@@ -537,6 +538,7 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd_kernel(BwdGroup g, FragPtr
             }
             M3T_STAMP(4);
             dh_carry = c.dht; z_next = gz;
+            sb_r += c.dr; sb_z += c.dz; sb_n += c.dn; sb_nr += c.dnr;
             if (pok) {
                 float* gx = d.dgx + ((size_t)pb * T + t) * d.ldg + d.goff;
                 gx[pj] = c.dr; gx[H + pj] = c.dz; gx[2 * H + pj] = c.dn;
@@ -547,6 +549,10 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd_kernel(BwdGroup g, FragPtr
             }
         }
         M3T_STAMP(5);
+    }
+    if (pok && d.db_part) {
+        float* q = d.db_part + (size_t)pb * 4 * H + pj;
+        q[0] = sb_r; q[H] = sb_z; q[2 * H] = sb_n; q[3 * H] = sb_nr;
     }
     if (stamp)
         for (int i = 0; i < 6; ++i) ex.prof[i] = (unsigned long long)psum[i];

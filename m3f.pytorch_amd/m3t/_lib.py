@@ -26,7 +26,7 @@ class GruFwdDesc(C.Structure):
 
 class GruBwdDesc(C.Structure):
     _fields_ = [("dout", _f), ("out", _f), ("gates", _f), ("w_hh_t", _f), ("dh_n", _f),
-                ("dgx", _f), ("dgh", _f), ("dh", _f),
+                ("dgx", _f), ("dgh", _f), ("dh", _f), ("db_part", _f), ("db_ih", _f), ("db_hh", _f),
                 ("H", _i), ("reverse", _i), ("ldo", _i), ("ooff", _i), ("ldg", _i), ("goff", _i)]
 
 

@@ -415,6 +415,7 @@ class _MultiBiGRU(torch.autograd.Function):
         dgx = [[new(B, T, 6 * Hs[s]) for s in range(n_stacks)] for _ in range(L)]
         dgh = [[new(2, B, T, 3 * Hs[s]) for s in range(n_stacks)] for _ in range(L)]
         dh = [[new(2, B, Hs[s]) for s in range(n_stacks)] for _ in range(L)]
+        dbp = [[new(2, B, 4, Hs[s]) for s in range(n_stacks)] for _ in range(L)]      # per-clip bias-gradient sums (scan output)
         wht = [[[new(Hs[s], 3 * Hs[s]) for _ in (0, 1)] for s in range(n_stacks)] for _ in range(L)]
         need_dx = [[l > 0 or ctx.needs_input_grad[2 + s * per] for s in range(n_stacks)] for l in range(L)]
         dinp = [[torch.empty_like(layer_io(l, s)[0]) if need_dx[l][s] else None for s in range(n_stacks)] for l in range(L)]
@@ -439,9 +440,11 @@ class _MultiBiGRU(torch.autograd.Function):
                     w_hh = params[s][(2 * l + d) * 4 + 1]
                     _lib.check(lib().m3t_transpose(_p(w_hh), 3 * H, H, H, _p(wht[l][s][d]), 3 * H, _stream()),
                                "m3t_transpose")
+                    base = s * per + 1 + (2 * l + d) * 4
                     descs.append(GruBwdDesc(_vp(cur[s]), _vp(out), _vp(gts, d * B * T * 4 * H), _vp(wht[l][s][d]),
                                             _vp(dhns[s], (2 * l + d) * B * H) if dhns[s] is not None else None,
                                             _vp(dgx[l][s]), _vp(dgh[l][s], d * B * T * 3 * H), _vp(dh[l][s], d * B * H),
+                                            _vp(dbp[l][s], d * B * 4 * H), _vp(out_grads[base + 2]), _vp(out_grads[base + 3]),
                                             H, d, 2 * H, d * H, 6 * H, d * 3 * H))
             _scan_bwd(descs, B, T, prec)
 
@@ -457,7 +460,7 @@ class _MultiBiGRU(torch.autograd.Function):
                     cur[s] = dinp[l][s]
                 for d in (0, 1):
                     base = s * per + 1 + (2 * l + d) * 4
-                    dw_ih, dw_hh, db_ih, db_hh = out_grads[base:base + 4]
+                    dw_ih, dw_hh = out_grads[base:base + 2]      # the bias gradients come out of the scan itself
                     goff = d * B * T * 3 * H
                     if T > 1:
                         # dW_hh = sum_{b,t} dgh[b,t]^T h_prev(b,t): forward pairs (t, t-1), reverse pairs (t, t+1)
@@ -466,9 +469,7 @@ class _MultiBiGRU(torch.autograd.Function):
                               seg=(T - 1, T, a_off, b_off), prec=prec)
                     else:
                         dw_hh.zero_()
-                    colsum(dgh[l][s], goff, B * T, 3 * H, 3 * H, db_hh)
                     sgemm(1, 0, 3 * H, I, B * T, dgx[l][s], d * 3 * H, 6 * H, inp, 0, I, dw_ih, 0, I, prec=prec)
-                    colsum(dgx[l][s], d * 3 * H, B * T, 3 * H, 6 * H, db_ih)
 
         if _interleaved(groups):
             # as in forward: the light group's backward scans run on the side stream beside the heavy group's GEMMs

@@ -43,7 +43,7 @@ def bwd_group(Hs):
             wt = torch.randn(H, 3 * H, device=dev) / H ** 0.5
             keep.append(wt)
             descs.append(GruBwdDesc(dout.data_ptr(), out.data_ptr(), gates.data_ptr() + 4 * d * B * T * 4 * H, wt.data_ptr(), None,
-                                    dgx.data_ptr(), dgh.data_ptr() + 4 * d * B * T * 3 * H, dh.data_ptr() + 4 * d * B * H,
+                                    dgx.data_ptr(), dgh.data_ptr() + 4 * d * B * T * 3 * H, dh.data_ptr() + 4 * d * B * H, None, None, None,
                                     H, d, 2 * H, d * H, 6 * H, d * 3 * H))
         keep += [dout, out, gates, dgx, dgh, dh]
     return descs, keep
