@@ -35,10 +35,26 @@ def test_library_version_and_loader():
     assert lib.m3t_version() == 1
 
 
-def test_desc_struct_layout_matches_header():
-    # 6 pointers + 6 ints / 8 pointers + 6 ints, natural alignment
-    assert ctypes.sizeof(_lib.GruFwdDesc) == 6 * 8 + 6 * 4
-    assert ctypes.sizeof(_lib.GruBwdDesc) == 8 * 8 + 6 * 4
+def test_desc_struct_layout_matches_header(tmp_path):
+    """The ctypes descriptor structures against the C compiler's view of include/m3t_hip.h: size and every field offset."""
+    import subprocess
+    fields = {"m3t_gru_fwd_desc": [f[0] for f in _lib.GruFwdDesc._fields_],
+              "m3t_gru_bwd_desc": [f[0] for f in _lib.GruBwdDesc._fields_]}
+    src = ["#include <stdio.h>", "#include <stddef.h>", '#include "m3t_hip.h"', "int main(void) {"]
+    for st, names in fields.items():
+        src.append('printf("%s %%zu\\n", sizeof(%s));' % (st, st))
+        for n in names:
+            src.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (st, n, st, n))
+    src += ["return 0;", "}"]
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)])
+    got = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for st, cls in (("m3t_gru_fwd_desc", _lib.GruFwdDesc), ("m3t_gru_bwd_desc", _lib.GruBwdDesc)):
+        assert int(got[st]) == ctypes.sizeof(cls), st
+        for n in fields[st]:
+            assert int(got["%s.%s" % (st, n)]) == getattr(cls, n).offset, (st, n)
 
 
 def test_no_cpu_fallback():
