@@ -215,8 +215,8 @@ __global__ __launch_bounds__(NT) void gru_persist_fwd_kernel(FwdGroup g, FragPtr
 // (v_perm_b32) into MFMA operands; W_hh is split by the prep kernel into the B-operand order and lives in 72 VGPRs.
 // Per wave: chunks c = wave + 8m; MFMA k-step s uses chunks m = 2s (k-groups 0,1) and 2s+1 (k-groups 2,3), lane
 // (row = lane & 15, q = lane >> 4) holding units 8(q&1) .. +7 of its chunk.  Granule i of a workgroup's tile:
-// j = i >> 5, half = (i >> 4) & 1, row = i & 15  <->  unit 8*half + j: a load of step j reads 32 consecutive granules
-// from each of two producers.  Only the backward scan needs the launch-per-step kernels' bit pattern; results here
+// jp = i >> 6, hr = (i >> 1) & 31, jlo = i & 1  <->  row hr & 15, unit 8*(hr >> 4) + 2*jp + jlo: one 16-byte load takes
+// the granules of two adjacent units, and a wave instruction reads 512 contiguous bytes from each of two producers.  Only the backward scan needs the launch-per-step kernels' bit pattern; results here
 // agree with them to fp32 rounding (~1e-6), not bit for bit (M3T_SCAN_FP32 forces the fp32-MFMA kernel).
 typedef __bf16 pbf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned pu32x4 __attribute__((ext_vector_type(4)));
@@ -267,9 +267,10 @@ __global__ __launch_bounds__(NT) void gru_persist_fwd6_kernel(FwdGroup g, FragPt
 #pragma unroll
                 for (int t = 0; t < 3; ++t) wf[k][ct][t] = __builtin_bit_cast(pbf16x8, Wf[((k * 3 + ct) * 3 + t) * 64]);
     }
-    // cell-math threads in granule order (see the header): granule tid <-> row tid & 15, unit 8*((tid>>4)&1) + (tid>>5)
+    // cell-math threads in granule order (see the header): granule tid = jp*64 + hr*2 + jlo  <->  row hr & 15,
+    // unit 8*(hr >> 4) + 2*jp + jlo
     const bool pw = tid < ROWS * UB;
-    const int prow = tid & 15, pu = ((tid >> 4) & 1) * 8 + ((tid >> 5) & 7);
+    const int prow = (tid >> 1) & 15, pu = ((tid >> 5) & 1) * 8 + 2 * ((tid >> 6) & 3) + (tid & 1);
     const int pb = r0 + prow, pj = j0 + pu;
     const bool pok = pw && pb < B;
     float br = 0.f, bz = 0.f, bn = 0.f, hprev = 0.f;
@@ -280,9 +281,9 @@ __global__ __launch_bounds__(NT) void gru_persist_fwd6_kernel(FwdGroup g, FragPt
     const size_t slot = ex.slot[s];
     const size_t grp = (size_t)rb * nch * TILE;
     const size_t pub = grp + (size_t)ub * TILE + tid;
-    // this lane's gather base inside a producer tile: chunk m = 2s + (q >> 1); granule (q & 1) * 16 + row, + 32 j
+    // this lane's gather base inside a producer tile: chunk m = 2s + (q >> 1); granule pair 2*hr + 64 jp, hr = (q&1)*16 + row
     const int q = lane >> 4;
-    const size_t lane_off = (size_t)(wave + NW * (q >> 1)) * TILE + (q & 1) * 16 + (lane & 15);
+    const size_t lane_off = (size_t)(wave + NW * (q >> 1)) * TILE + 2 * ((q & 1) * 16 + (lane & 15));
     bool dead = false;
     const bool stamp = ex.prof != nullptr && blockIdx.x == 0 && tid == 0;
     long long psum[6] = {0, 0, 0, 0, 0, 0}, last = stamp ? clock64() : 0;
@@ -299,22 +300,19 @@ __global__ __launch_bounds__(NT) void gru_persist_fwd6_kernel(FwdGroup g, FragPt
         if (step > 0) {
             const unsigned tag = (unsigned)step & 0xffffu;
             const unsigned long long* src = gran + (size_t)((step - 1) & 1) * slot + grp + lane_off;
-            unsigned long long v[KS][8];
+            pu32x4 v[KS][4];                               // [k-step][unit pair jp] = {lo(j0), hi(j0), lo(j1), hi(j1)}
             int spins = 0;
             for (;;) {
+                // ONE 16-byte load takes two adjacent granules: the exchange is priced per load instruction, not per byte
+                // (tools/persist_probe.hip: 8 dwordx4 instead of 16 dwordx2 loads = 1.63 vs 2.03 us per step)
 #pragma unroll
                 for (int k = 0; k < KS; ++k) {
                     const unsigned long long* qp = src + (size_t)(2 * k) * NW * TILE;
-                    asm volatile("global_load_dwordx2 %0, %8, off sc1\n\t"
-                                 "global_load_dwordx2 %1, %8, off offset:256 sc1\n\t"
-                                 "global_load_dwordx2 %2, %8, off offset:512 sc1\n\t"
-                                 "global_load_dwordx2 %3, %8, off offset:768 sc1\n\t"
-                                 "global_load_dwordx2 %4, %8, off offset:1024 sc1\n\t"
-                                 "global_load_dwordx2 %5, %8, off offset:1280 sc1\n\t"
-                                 "global_load_dwordx2 %6, %8, off offset:1536 sc1\n\t"
-                                 "global_load_dwordx2 %7, %8, off offset:1792 sc1"
-                                 : "=&v"(v[k][0]), "=&v"(v[k][1]), "=&v"(v[k][2]), "=&v"(v[k][3]), "=&v"(v[k][4]),
-                                   "=&v"(v[k][5]), "=&v"(v[k][6]), "=&v"(v[k][7])
+                    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
+                                 "global_load_dwordx4 %1, %4, off offset:512 sc1\n\t"
+                                 "global_load_dwordx4 %2, %4, off offset:1024 sc1\n\t"
+                                 "global_load_dwordx4 %3, %4, off offset:1536 sc1"
+                                 : "=&v"(v[k][0]), "=&v"(v[k][1]), "=&v"(v[k][2]), "=&v"(v[k][3])
                                  : "v"(qp) : "memory");
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -322,9 +320,9 @@ __global__ __launch_bounds__(NT) void gru_persist_fwd6_kernel(FwdGroup g, FragPt
 #pragma unroll
                 for (int k = 0; k < KS; ++k)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        asm volatile("" : "+v"(v[k][j]));
-                        ok = ok && ((unsigned)(v[k][j] >> 48) == tag);
+                    for (int jp = 0; jp < 4; ++jp) {
+                        asm volatile("" : "+v"(v[k][jp]));
+                        ok = ok && ((v[k][jp].y >> 16) == tag) && ((v[k][jp].w >> 16) == tag);
                     }
                 if (__all(ok) || dead) break;
                 if (++spins > SPIN_LIMIT) { dead = true; if (lane == 0) raise_spin(err, step); break; }
@@ -339,11 +337,9 @@ __global__ __launch_bounds__(NT) void gru_persist_fwd6_kernel(FwdGroup g, FragPt
                 pu32x4 a1, a2, a3;                         // the three terms of 8 consecutive units, paired into dwords
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
-                    const unsigned lo0 = (unsigned)v[k][2 * jj], lo1 = (unsigned)v[k][2 * jj + 1];
-                    const unsigned hi0 = (unsigned)(v[k][2 * jj] >> 32), hi1 = (unsigned)(v[k][2 * jj + 1] >> 32);
-                    a1[jj] = __builtin_amdgcn_perm(lo1, lo0, 0x05040100u);
-                    a2[jj] = __builtin_amdgcn_perm(lo1, lo0, 0x07060302u);
-                    a3[jj] = __builtin_amdgcn_perm(hi1, hi0, 0x05040100u);
+                    a1[jj] = __builtin_amdgcn_perm(v[k][jj].z, v[k][jj].x, 0x05040100u);
+                    a2[jj] = __builtin_amdgcn_perm(v[k][jj].z, v[k][jj].x, 0x07060302u);
+                    a3[jj] = __builtin_amdgcn_perm(v[k][jj].w, v[k][jj].y, 0x05040100u);
                 }
                 const pbf16x8 A1 = __builtin_bit_cast(pbf16x8, a1), A2 = __builtin_bit_cast(pbf16x8, a2),
                               A3 = __builtin_bit_cast(pbf16x8, a3);

@@ -35,10 +35,30 @@ __global__ __launch_bounds__(512) void persist(unsigned long long* gran, int NG,
         int spins = 0;
         for (;;) {
             bool ok = true;
+            if (WORK == -4) {
+                // same 8-byte granules, gathered by HALF as many instructions: each lane takes two adjacent granules with one
+                // dwordx4 load (is the exchange priced per instruction or per byte?)
+                typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+                u32x4_ w[NL / 2];
+#pragma unroll
+                for (int c = 0; c < NL / 2; ++c) {
+                    const int u = wave * PER_WAVE + c / 2;
+                    const u32x4_* q = reinterpret_cast<const u32x4_*>(src + (size_t)u * GRAN + (c % 2) * 128) + lane;
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(w[c]) : "v"(q) : "memory");
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int c = 0; c < NL / 2; ++c) {
+                    asm volatile("" : "+v"(w[c]));
+                    v[2 * c] = ((unsigned long long)w[c].y << 32) | w[c].x;
+                    v[2 * c + 1] = ((unsigned long long)w[c].w << 32) | w[c].z;
+                }
+            } else {
 #pragma unroll
             for (int c = 0; c < NL; ++c) {
                 const int u = wave * PER_WAVE + c / 4;
                 v[c] = __hip_atomic_load(src + (size_t)u * GRAN + (c % 4) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             }
 #pragma unroll
             for (int c = 0; c < NL; ++c) ok = ok && ((unsigned)(v[c] >> 32) == tag);
@@ -216,6 +236,9 @@ int main() {
     run<32, 0, 600>(8, T);
     run<8, 0, 0>(2, T);
     run<32, 0, -1>(8, T);
+    run<32, 0, -4>(8, T);
+    run<32, 0, -4>(4, T);
+    run<16, 0, -4>(8, T);
     run<32, 0, -1>(4, T);
     run16<32>(8, T);
     run16<32>(8, 20000);
