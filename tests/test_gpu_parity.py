@@ -154,7 +154,8 @@ def test_gru_vs_oracle(B, T, I, H, L):
 
 @pytest.mark.parametrize("exact", [True, False])
 @pytest.mark.parametrize("B,T,I,H,L", [(5, 9, 20, 128, 2), (32, 40, 24, 256, 2), (19, 23, 16, 512, 1), (32, 12, 32, 384, 1),
-                                       (40, 6, 16, 128, 1)])
+                                       (40, 6, 16, 128, 1), (1, 2, 8, 128, 1), (33, 5, 12, 256, 1), (48, 4, 16, 512, 1),
+                                       (64, 3, 16, 512, 1), (100, 3, 8, 512, 1)])
 def test_gru_persistent_scan_equals_per_step(B, T, I, H, L, exact):
     """The persistent scan (one launch for all T steps, W_hh in registers, tagged-granule exchange between CUs)
     must take over for H % 128 == 0 levels.  exact=True (flag M3T_SCAN_FP32: fp32 MFMAs everywhere): it reproduces the
@@ -185,7 +186,8 @@ def test_gru_persistent_scan_equals_per_step(B, T, I, H, L, exact):
     y1, dx1, g1, n1 = run(False)
     y0, dx0, g0, n0 = run(True)
     assert n0 == 0 and n1 == 2 * L, (n0, n1)            # one persistent launch per layer, forward and backward
-    if exact or H in (128, 384):                         # those widths always take the fp32-MFMA kernel
+    rt2 = 2 * ((B + 15) // 16) * (H // 16) > 256         # 16-row grid too large for the chip: 32-row workgroups, fp32 MFMAs
+    if exact or H in (128, 384) or rt2:                  # those always take the fp32-MFMA kernel
         assert torch.equal(y1, y0) and torch.equal(dx1, dx0)
         for n in g0:
             assert torch.equal(g1[n], g0[n]), n
