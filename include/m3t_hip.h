@@ -41,6 +41,11 @@ extern "C" {
  * to bf16 (nearest even) before the product, accumulation and epilogue stay fp32.  Interior shapes then run ONE bf16
  * MFMA per tile step instead of the six of the fp32-accurate path. */
 #define M3T_GEMM_BF16 2
+/* the caller promises that nothing else shares the chip while this GEMM runs: the cost model may then pick the
+ * 256 x 256-tile kernel (gemm_x6c.hip: one 512-thread workgroup with ~240 VGPRs per CU, 10-20 % faster on shapes that
+ * fill whole rounds of 256 CUs).  Without the flag the 128 x 128-tile kernels run: their workgroups leave room on a CU
+ * for a persistent scan or a second GEMM on another stream -- beside those the big tile was measured to LOSE. */
+#define M3T_GEMM_EXCLUSIVE 8
 
 /* library / device info: returns the ABI version; arch string copied to `arch` if non-null */
 int m3t_version(void);
@@ -56,7 +61,7 @@ int m3t_device_arch(char* arch, int cap);
  *   storage row of A = (k / seg_len) * seg_stride + k % seg_len + a_off, same for B
  *   with b_off (used for dW_hh = sum_t dgh_t^T h_{t-1}: per-clip shifted rows).
  * ws/ws_bytes: optional split-K workspace (deterministic slab reduction); may be NULL.
- * flags: 0, M3T_GEMM_BACKGROUND, M3T_GEMM_BF16 (or both).
+ * flags: 0 or any of M3T_GEMM_BACKGROUND, M3T_GEMM_BF16, M3T_GEMM_EXCLUSIVE.
  * Replaces: nn.Linear (models/rnn.py:22-55, models/model.py:88, models/att_fusion.py:13),
  * the input projections W_ih x inside nn.GRU (models/rnn.py:17,75) and their autograd. */
 int m3t_sgemm(int transA, int transB, int M, int N, int K,
@@ -64,6 +69,11 @@ int m3t_sgemm(int transA, int transB, int M, int N, int K,
               float* C, int ldc, const float* bias, int act, int accumulate,
               int seg_len, int seg_stride, int a_off, int b_off,
               float* ws, size_t ws_bytes, int flags, void* stream);
+
+/* Which kernel m3t_sgemm would run for a call of this shape (all operands 16-B aligned, ld % 4 == 0) and how many
+ * split-K slabs: *kernel = 0 fp32-MFMA tile kernel, 1 bf16x6 128 x 128 tile, 2 bf16x6 256 x 256 tile (only with
+ * M3T_GEMM_EXCLUSIVE).  For tools and tests; no device work. */
+int m3t_sgemm_plan(int transA, int M, int N, int K, int seg_len, size_t ws_bytes, int flags, int* kernel, int* splits);
 
 /* out[n] (+)= sum_m X[m*ld + n], m<M, n<N  (bias gradients); ws optional (tall inputs) */
 int m3t_colsum(const float* X, int M, int N, int ld, float* out, int accumulate,
@@ -129,6 +139,12 @@ typedef struct {
 
 /* Number of persistent scan launches this process has issued so far (tests use it to assert which path ran). */
 int m3t_gru_persist_count(void);
+/* Ordering between scans on different streams without holding back their preparation: the NEXT m3t_gru_scan_fwd /
+ * m3t_gru_scan_bwd call of the calling thread makes its stream wait for `event` (a hipEvent_t) right before it launches
+ * its scan kernel(s); the weight re-layout kernels and memsets it issues first run as soon as the stream allows.  Used
+ * by the host schedule that alternates the persistent scans of two streams (they must never run at the same time).
+ * The event is consumed by that call (also when it fails).  Returns 0. */
+int m3t_gru_scan_after(void* event);
 /* With env M3T_SCAN_PROF=1: s_memtime cycles that workgroup 0 / lane 0 of the LAST persistent launch spent per phase,
  * summed over its T steps: [0] step top, [1] gather (wait for peers), [2] MFMA + LDS partials, [3] barrier,
  * [4] reduce + gate math + publish, [5] stores.  Synchronises the device.  M3T_EINVAL when profiling is off. */

@@ -5,6 +5,7 @@
 // for tile k+1 are issued before the MFMAs of tile k (register prefetch, double LDS buffer).
 // Split-K goes through fp32 slabs + a fixed-order reduce: deterministic, no atomics.
 #include "common.h"
+#include <cstdio>
 #include <cstdlib>
 
 namespace {
@@ -336,6 +337,19 @@ int m3t_sgemm_x6_launch(int transA, int transB, int M, int N, int K, const float
                         int a_off, int b_off, float* ws, int splits, int kchunk, size_t dyn_lds, int bf16_operands,
                         hipStream_t s);
 
+int m3t_sgemm_x6c_launch(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                         float* C, int ldc, const float* bias, int act, int accumulate, int seg_len, int seg_stride,
+                         int a_off, int b_off, float* ws, int splits, int kchunk, int bf16_operands, hipStream_t s);
+
+static int x6c_mode() {            // M3T_GEMM_X6C: 0 never, 1 always (where eligible), unset/2 by the cost model
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("M3T_GEMM_X6C");
+        on = e ? atoi(e) : 2;
+    }
+    return on;
+}
+
 static bool x6_enabled() {
     static int on = -1;
     if (on < 0) {
@@ -343,6 +357,72 @@ static bool x6_enabled() {
         on = (e && e[0] == '0') ? 0 : 1;
     }
     return on == 1;
+}
+
+// Kernel and split-K choice of one m3t_sgemm call.  kernel: 0 fp32-MFMA (gemm.hip), 1 bf16x6 128-tile (gemm_x6.hip),
+// 2 bf16x6 256-tile (gemm_x6c.hip).
+struct GemmPlan { int kernel, splits, kchunk; };
+
+static GemmPlan plan_gemm(int transA, int M, int N, int K, int seg_len, bool vec, size_t ws_bytes, int flags) {
+    GemmPlan g;
+    const int bf16 = (flags & M3T_GEMM_BF16) ? 1 : 0;
+    const int tiles = cdiv(M, BM) * cdiv(N, BN);
+    // interior shapes go to the bf16x6 kernels (fp32-accurate, 2.67x the fp32 MFMA rate)
+    const bool x6 = x6_enabled() && (M % 128 == 0) && (N % 128 == 0) && (K % 32 == 0) && K > 0 && vec &&
+                    (seg_len == 0 || seg_len >= 32);
+    const double ns_per_k = x6 ? (bf16 ? 14.0 : 36.0) : 84.0;
+    const int kq = x6 ? 32 : BK;
+    // split-K choice by a small cost model (ns): a CU works through its co-resident blocks at ~0.39 TFLOP/s
+    // (84 ns per k per 128x128 block; 1.3x slower when it holds a single block), slabs cost their HBM traffic.
+    int splits = 1;
+    const size_t cap = ws_bytes / ((size_t)M * N * sizeof(float));
+    if (ws_bytes && K >= 512) {
+        double best = 1e30;
+        for (int sp = 1; sp <= 96 && sp <= K / 96 && (sp == 1 || (size_t)sp <= cap); ++sp) {
+            const int rounds = cdiv(tiles * sp, 256);
+            double t = (double)rounds * ((double)K / sp) * ns_per_k * (rounds == 1 ? 1.3 : 1.0);
+            if (sp > 1) t += (double)(sp + 2) * M * N * 4.0 / 3000.0 + 3000.0;
+            if (t < best) { best = t; splits = sp; }
+        }
+    }
+    // 256 x 256 tiles (gemm_x6c.hip), one workgroup per CU, only for callers that have the chip to themselves
+    // (M3T_GEMM_EXCLUSIVE).  Which kernel: calibrated time models (us) of both, fitted to tools/gemm_bench.py on MI355X --
+    // x6c: 17 + rounds x (13 + 0.130 K/split); x6: 12 + 1.2 x its model above (x 1.12 with a row-contiguous A); slabs:
+    // 0.3 x their traffic at 3 TB/s + 3.  x6c needs a grid that fills whole rounds of 256 CUs: M = 9600 is 37.5 tiles, so
+    // N = 1536 (228 tiles) suits it and N = 1024 / 2048 (152 / 304) do not.
+    if (x6 && x6c_mode() != 0 && (flags & M3T_GEMM_EXCLUSIVE) && !(flags & M3T_GEMM_BACKGROUND)) {
+        const int tiles_b = cdiv(M, 256) * cdiv(N, 256);
+        const double per_k = bf16 ? 0.052 : 0.130;
+        const double slab = (double)M * N * 4.0 / 3000.0 / 1e3;          // us per slab pass
+        int sb = 1;
+        double best_b = 1e30;
+        for (int sp = 1; sp <= 96 && (sp == 1 || (K >= 512 && sp <= K / 96 && (size_t)sp <= cap)); ++sp) {
+            const int rounds = cdiv(tiles_b * sp, 256);
+            double t = 17.0 + rounds * (13.0 + ((double)K / sp) * per_k);
+            if (sp > 1) t += 0.3 * (sp + 2) * slab + 3.0;
+            if (t < best_b) { best_b = t; sb = sp; }
+        }
+        const int rounds = cdiv(tiles * splits, 256);
+        double best_a = 12.0 + 1.2 * rounds * ((double)K / splits) * ns_per_k * 1e-3 * (rounds == 1 ? 1.3 : 1.0) * (transA ? 1.12 : 1.0);
+        if (splits > 1) best_a += 0.3 * (splits + 2) * slab + 3.0;
+        if (x6c_mode() == 1 || best_b < best_a) {
+            int kc = cdiv(cdiv(K, sb), 32) * 32;
+            if (kc < 32) kc = 32;
+            g.kernel = 2; g.kchunk = kc; g.splits = cdiv(K, kc);
+            return g;
+        }
+    }
+    int kchunk = cdiv(cdiv(K, splits), kq) * kq;
+    if (kchunk < kq) kchunk = kq;
+    g.kernel = x6 ? 1 : 0; g.kchunk = kchunk; g.splits = K > 0 ? cdiv(K, kchunk) : 1;
+    return g;
+}
+
+extern "C" int m3t_sgemm_plan(int transA, int M, int N, int K, int seg_len, size_t ws_bytes, int flags, int* kernel, int* splits) {
+    if (M <= 0 || N <= 0 || K < 0 || !kernel || !splits) return M3T_EINVAL;
+    const GemmPlan g = plan_gemm(transA, M, N, K, seg_len, true, ws_bytes, flags);
+    *kernel = g.kernel; *splits = g.splits;
+    return 0;
 }
 
 extern "C" int m3t_sgemm(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
@@ -360,35 +440,19 @@ extern "C" int m3t_sgemm(int transA, int transB, int M, int N, int K, const floa
     p.vecA = (lda % 4 == 0) && ((uintptr_t)A % 16 == 0);
     p.vecB = (ldb % 4 == 0) && ((uintptr_t)B % 16 == 0);
     const int tm = cdiv(M, BM), tn = cdiv(N, BN);
-    const int tiles = tm * tn;
-    // interior shapes go to the bf16x6 kernel (fp32-accurate, 2.67x the fp32 MFMA rate): gemm_x6.hip
-    const bool x6 = x6_enabled() && (M % 128 == 0) && (N % 128 == 0) && (K % 32 == 0) && K > 0 && p.vecA && p.vecB &&
-                    (seg_len == 0 || seg_len >= 32);
-    const double ns_per_k = x6 ? (p.bf16 ? 14.0 : 36.0) : 84.0;
-    const int kq = x6 ? 32 : BK;
-    // split-K choice by a small cost model (ns): a CU works through its co-resident blocks at ~0.39 TFLOP/s
-    // (84 ns per k per 128x128 block; 1.3x slower when it holds a single block), slabs cost their HBM traffic.
-    int splits = 1;
-    if (ws && K >= 512) {
-        const size_t cap = ws_bytes / ((size_t)M * N * sizeof(float));
-        double best = 1e30;
-        for (int sp = 1; sp <= 96 && sp <= K / 96 && (sp == 1 || (size_t)sp <= cap); ++sp) {
-            const int rounds = cdiv(tiles * sp, 256);
-            double t = (double)rounds * ((double)K / sp) * ns_per_k * (rounds == 1 ? 1.3 : 1.0);
-            if (sp > 1) t += (double)(sp + 2) * M * N * 4.0 / 3000.0 + 3000.0;
-            if (t < best) { best = t; splits = sp; }
-        }
-    }
-    int kchunk = cdiv(cdiv(K, splits), kq) * kq;
-    if (kchunk < kq) kchunk = kq;
-    splits = K > 0 ? cdiv(K, kchunk) : 1;
+    const GemmPlan g = plan_gemm(transA, M, N, K, seg_len, p.vecA && p.vecB, ws ? ws_bytes : 0, flags);
+    const int splits = g.splits, kchunk = g.kchunk;
     p.splits = splits; p.kchunk = kchunk;
-    dim3 grid(tn, tm, splits), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (x6) {
-        const size_t dyn6 = (flags & M3T_GEMM_BACKGROUND) ? (size_t)40 * 1024 : 0;
-        const int rc = m3t_sgemm_x6_launch(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, seg_len,
-                                           seg_stride, a_off, b_off, ws, splits, kchunk, dyn6, p.bf16, s);
+    if (g.kernel != 0) {
+        int rc;
+        if (g.kernel == 2)
+            rc = m3t_sgemm_x6c_launch(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, seg_len, seg_stride,
+                                      a_off, b_off, ws, splits, kchunk, p.bf16, s);
+        else
+            rc = m3t_sgemm_x6_launch(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, seg_len, seg_stride,
+                                     a_off, b_off, ws, splits, kchunk, (flags & M3T_GEMM_BACKGROUND) ? (size_t)40 * 1024 : 0,
+                                     p.bf16, s);
         if (rc) return rc;
         if (splits > 1) {
             const size_t total = (size_t)M * N;
@@ -399,6 +463,7 @@ extern "C" int m3t_sgemm(int transA, int transB, int M, int N, int K, const floa
         }
         return 0;
     }
+    dim3 grid(tn, tm, splits), block(256);
     const bool fast = (M % BM == 0) && (N % BN == 0) && (K % BK == 0) && K > 0 && p.vecA && p.vecB;
     // M3T_GEMM_BACKGROUND: an (unused) dynamic-LDS request of 56 KiB caps residency at ONE workgroup per CU, so a
     // latency-critical kernel on another stream (the GRU scans) still finds room on every CU.

@@ -8,12 +8,14 @@
 // fp32 ones per 16 k = 2.67x the fp32 MFMA rate (~420 TFLOP/s ceiling), deterministic.
 //
 // Tile: 128 x 128 x 32, 4 waves (2 x 2), each wave 64 x 64 = 2 x 2 v_mfma_f32_32x32x16_bf16 tiles.
-// LDS (single buffer, 48.8 KiB -> 3 workgroups/CU): per operand and split, [k-half 2][k-quad 4][128 rows][4 k] bf16,
-// i.e. 8 B per (row, k-quad) and rows contiguous inside a k-quad plane.  A fragment (row = lane&31,
-// k = 8*(lane>>5)..+7) is two conflict-free ds_read_b64 (32 lanes x 8 B contiguous each); a thread that loaded a
-// float4 along the ROW dimension (row-contiguous operands) writes its 4 rows of one k-quad as 32 contiguous
-// bytes, so both operand layouts store without bank conflicts.  Global loads of tile t+1 stay in flight in
-// registers while tile t is multiplied.
+// LDS (single buffer, 49.5 KiB -> 3 workgroups/CU): per operand and split, [k-octet 4][128 rows][8 k] bf16: one
+// 16-B record per (row, k-octet), rows contiguous inside a plane, planes padded by 64 B.  A fragment (row = lane&31,
+// k = 8*(lane>>5)..+7) is ONE conflict-free ds_read_b128 straight into the MFMA operand registers (two 8-B reads per
+// fragment made hipcc pair the reads ACROSS fragments into ds_read2_b64 and reassemble them with 72 v_mov per K-step).
+// K-contiguous operands store 8 B per thread (4 rows x 8 k-quads per half-wave = all 64 banks once); row-contiguous
+// operands hold (4 rows, one k-quad) per thread, and the lane 32 away holds the other k-quad of the same octet: two
+// v_permlane32_swap per split and dword pair leave every lane with two complete 16-B records (32 contiguous bytes).
+// Global loads of tile t+1 stay in flight in registers while tile t is multiplied.
 #include "common.h"
 #include <cstdlib>
 
@@ -23,9 +25,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int XM = 128, XN = 128, XK = 32;
-constexpr int PLANE = XM * 8 + 16;                 // one k-quad plane: 128 rows x 8 B (+16 B: conflict-free K-contiguous stores)
-constexpr int SPLIT_BYTES = 8 * PLANE;             // one split of one operand: 2 k-halves x 4 k-quads
-constexpr int OPER_BYTES = 3 * SPLIT_BYTES;        // 24.4 KiB
+constexpr int PLANE = XM * 16 + 64;                // one k-octet plane: 128 rows x 16 B (+64 B: conflict-free K-contiguous stores)
+constexpr int SPLIT_BYTES = 4 * PLANE;             // one split of one operand: 4 k-octets
+constexpr int OPER_BYTES = 3 * SPLIT_BYTES;        // 24.75 KiB
 
 struct X6Params {
     const float* A; const float* B; float* C; const float* bias; float* ws;
@@ -75,7 +77,7 @@ __device__ __forceinline__ void kc_load(const float* __restrict__ p, size_t ld, 
 template <int NS>
 __device__ __forceinline__ void kc_store(unsigned char* __restrict__ S, const float4 (&r)[4]) {
     const int tid = threadIdx.x & 255;
-    const int c = tid & 7, r0 = tid >> 3;            // plane index c = (k-half, k-quad) of the 32-k tile
+    const int c = tid & 7, r0 = tid >> 3;            // k-quad c of the 32-k tile: octet c >> 1, half c & 1
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         unsigned lo[3], hi2[3];                      // k pairs (0,1) and (2,3) of this row
@@ -83,43 +85,45 @@ __device__ __forceinline__ void kc_store(unsigned char* __restrict__ S, const fl
         split3_pair<NS>((f32x2){r[i].z, r[i].w}, hi2);
 #pragma unroll
         for (int s = 0; s < NS; ++s)
-            *reinterpret_cast<u32x2*>(S + s * SPLIT_BYTES + c * PLANE + (r0 + 32 * i) * 8) = (u32x2){lo[s], hi2[s]};
+            *reinterpret_cast<u32x2*>(S + s * SPLIT_BYTES + (c >> 1) * PLANE + (r0 + 32 * i) * 16 + (c & 1) * 8) = (u32x2){lo[s], hi2[s]};
     }
 }
-// ---- row-contiguous operand ([K][rows]): thread = (k-quad = tid>>5 (4 k), 4 rows at (tid&31)*4): a 4x4 block
+// ---- row-contiguous operand ([K][rows]): thread = (k-quad = tid>>5 (4 k), 4 rows at (tid&31)*4): a 4x4 block.
+// Lanes l and l+32 of a wave hold the two k-quads of ONE octet (octet = wave) for the same rows; after the swaps the
+// lower lane owns the complete records of rows 0, 1 and the upper lane those of rows 2, 3.
 template <int NS>
 __device__ __forceinline__ void mc_store(unsigned char* __restrict__ S, const float4 (&r)[4]) {
     const int tid = threadIdx.x & 255;
-    const int kq = tid >> 5, row0 = (tid & 31) * 4;   // k-quad kq of the 32-k tile: half = kq>>2, quad = kq&3
+    const int wave = tid >> 6, h = (tid >> 5) & 1, row0 = (tid & 31) * 4;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 o[3][2];                                    // [split][row pair]: rows (row0, row0+1), (row0+2, row0+3)
+    unsigned lo[4][3], hi2[4][3];                     // [row][split]: k pairs (0,1) and (2,3) of this thread's k-quad
 #pragma unroll
     for (int i = 0; i < 4; ++i) {                     // row row0 + i: its 4 k values are component i of r[0..3]
         const float v0 = i == 0 ? r[0].x : i == 1 ? r[0].y : i == 2 ? r[0].z : r[0].w;
         const float v1 = i == 0 ? r[1].x : i == 1 ? r[1].y : i == 2 ? r[1].z : r[1].w;
         const float v2 = i == 0 ? r[2].x : i == 1 ? r[2].y : i == 2 ? r[2].z : r[2].w;
         const float v3 = i == 0 ? r[3].x : i == 1 ? r[3].y : i == 2 ? r[3].z : r[3].w;
-        unsigned lo[3], hi2[3];
-        split3_pair<NS>((f32x2){v0, v1}, lo);
-        split3_pair<NS>((f32x2){v2, v3}, hi2);
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            o[s][i >> 1][(i & 1) * 2 + 0] = lo[s];
-            o[s][i >> 1][(i & 1) * 2 + 1] = hi2[s];
-        }
+        split3_pair<NS>((f32x2){v0, v1}, lo[i]);
+        split3_pair<NS>((f32x2){v2, v3}, hi2[i]);
     }
+    unsigned char* q = S + wave * PLANE + (row0 + 2 * h) * 16;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {                    // 4 rows x 8 B = 32 contiguous bytes per split
-        unsigned char* q = S + s * SPLIT_BYTES + kq * PLANE + row0 * 8;
-        *reinterpret_cast<u32x4*>(q) = o[s][0];
-        *reinterpret_cast<u32x4*>(q + 16) = o[s][1];
+    for (int s = 0; s < NS; ++s) {
+        // permlane32_swap(a, b): a's upper half <-> b's lower half.  lower lanes: (own row 0 | partner's row 0);
+        // upper lanes: (partner's row 2 | own row 2) -- in both cases (.x, .y) = (even k-quad, odd k-quad)
+        const u32x2 e0 = __builtin_amdgcn_permlane32_swap(lo[0][s], lo[2][s], false, false);
+        const u32x2 e1 = __builtin_amdgcn_permlane32_swap(hi2[0][s], hi2[2][s], false, false);
+        const u32x2 f0 = __builtin_amdgcn_permlane32_swap(lo[1][s], lo[3][s], false, false);
+        const u32x2 f1 = __builtin_amdgcn_permlane32_swap(hi2[1][s], hi2[3][s], false, false);
+        *reinterpret_cast<u32x4*>(q + s * SPLIT_BYTES) = (u32x4){e0.x, e1.x, e0.y, e1.y};
+        *reinterpret_cast<u32x4*>(q + s * SPLIT_BYTES + 16) = (u32x4){f0.x, f1.x, f0.y, f1.y};
     }
 }
 
 // NS = 3: fp32-accurate product from 3 bf16 terms per operand (6 MFMAs per tile step);
 // NS = 1: plain bf16 operands (round to nearest even), fp32 accumulate -- the mixed-precision mode (M3T_GEMM_BF16)
 template <int TA, int TB, bool SEG, int NS>
-__global__ __launch_bounds__(256) void sgemm_x6_kernel(X6Params p) {
+__global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * OPER_BYTES];   // A | B, 48 KiB
     unsigned char* As = lds;
     unsigned char* Bs = lds + OPER_BYTES;
@@ -202,12 +206,8 @@ __global__ __launch_bounds__(256) void sgemm_x6_kernel(X6Params p) {
             for (int s = 0; s < NS; ++s)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const unsigned char* qa = As + s * SPLIT_BYTES + (kh * 4 + 2 * hi) * PLANE + (wm * 64 + i * 32 + l31) * 8;
-                    const unsigned char* qb = Bs + s * SPLIT_BYTES + (kh * 4 + 2 * hi) * PLANE + (wn * 64 + i * 32 + l31) * 8;
-                    const bf16x4 a0 = *reinterpret_cast<const bf16x4*>(qa), a1 = *reinterpret_cast<const bf16x4*>(qa + PLANE);
-                    const bf16x4 b0 = *reinterpret_cast<const bf16x4*>(qb), b1 = *reinterpret_cast<const bf16x4*>(qb + PLANE);
-                    fa[s][i] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
-                    fb[s][i] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    fa[s][i] = *reinterpret_cast<const bf16x8*>(As + s * SPLIT_BYTES + (kh * 2 + hi) * PLANE + (wm * 64 + i * 32 + l31) * 16);
+                    fb[s][i] = *reinterpret_cast<const bf16x8*>(Bs + s * SPLIT_BYTES + (kh * 2 + hi) * PLANE + (wn * 64 + i * 32 + l31) * 16);
                 }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

@@ -613,6 +613,7 @@ std::vector<unsigned char> make_key(int kind, const G& g, const FragPtrs* fp, in
 
 extern "C" int m3t_gru_scan_fwd(const m3t_gru_fwd_desc* scans, int n_scans, int B, int T, float* ws, size_t ws_bytes,
                                 int flags, void* stream) {
+    AfterGuard after_guard;      // a pending m3t_gru_scan_after event never outlives this call
     if (n_scans <= 0 || B <= 0 || T <= 0) return 0;
     if (persist_poll_error()) return M3T_ESPIN;
     if (n_scans > M3T_MAX_SCANS || !scans) return M3T_EINVAL;
@@ -679,6 +680,7 @@ extern "C" int m3t_gru_scan_fwd(const m3t_gru_fwd_desc* scans, int n_scans, int 
             }
             return persist_fwd_launch(fg, fp, B, T, flags, s);
         }
+        { const int e = persist_take_after(s); if (e) return e; }
         return replay_or_capture(make_key(1, fg, &fp, B, T, rt), s, [&]() {
             for (int i = 0; i < n_scans; ++i) {
                 const int H = fg.d[i].H;
@@ -692,6 +694,7 @@ extern "C" int m3t_gru_scan_fwd(const m3t_gru_fwd_desc* scans, int n_scans, int 
                 for (int step = 0; step < T; ++step) gru_step_fwd_frag_kernel<1><<<nblk, NT, 0, s>>>(fg, fp, B, T, step);
         });
     }
+    { const int e = persist_take_after(s); if (e) return e; }
     if (fast)
         for (int step = 0; step < T; ++step) gru_step_fwd_kernel<true><<<grid, NT, 0, s>>>(g, B, T, step);
     else
@@ -702,6 +705,7 @@ extern "C" int m3t_gru_scan_fwd(const m3t_gru_fwd_desc* scans, int n_scans, int 
 
 static int scan_bwd_impl(const m3t_gru_bwd_desc* scans, int n_scans, int B, int T, float* ws, size_t ws_bytes, int flags,
                          void* stream) {
+    AfterGuard after_guard;
     if (n_scans <= 0 || B <= 0 || T <= 0) return 0;
     if (persist_poll_error()) return M3T_ESPIN;
     if (n_scans > M3T_MAX_SCANS || !scans) return M3T_EINVAL;
@@ -764,6 +768,7 @@ static int scan_bwd_impl(const m3t_gru_bwd_desc* scans, int n_scans, int B, int 
             M3T_LAUNCH_CHECK();
             return persist_bwd_launch(bg, fp, B, T, s);
         }
+        { const int e = persist_take_after(s); if (e) return e; }
         return replay_or_capture(make_key(2, bg, &fp, B, T, rt), s, [&]() {
             for (int i = 0; i < n_scans; ++i) {
                 const int H = bg.d[i].H;
@@ -777,6 +782,7 @@ static int scan_bwd_impl(const m3t_gru_bwd_desc* scans, int n_scans, int B, int 
                 for (int step = 0; step < T; ++step) gru_step_bwd_frag_kernel<1><<<nblk, NT, 0, s>>>(bg, fp, B, T, step);
         });
     }
+    { const int e = persist_take_after(s); if (e) return e; }
     if (fast)
         for (int step = 0; step < T; ++step) gru_step_bwd_kernel<true><<<grid, NT, 0, s>>>(g, B, T, step);
     else

@@ -76,6 +76,12 @@ __device__ __forceinline__ GateBwd gru_cell_bwd(float dout, float dh_next, float
 // (persist_exchange_bytes() bytes each, 16-B aligned).
 size_t persist_exchange_bytes(int H, int B, bool backward);
 bool persist_enabled();
+// m3t_gru_scan_after: an event the NEXT scan call of this thread waits for right before its scan kernels (its preparation
+// kernels and memsets are not held back).  take: make stream s wait for it (if set) and clear it; drop: clear it.
+void persist_set_after(hipEvent_t ev);
+int persist_take_after(hipStream_t s);
+void persist_drop_after();
+struct AfterGuard { ~AfterGuard() { persist_drop_after(); } };
 int persist_poll_error();       // step+1 of a scan that hit its spin limit since the last poll, else 0
 bool persist_fwd_check(const FwdGroup& g, int B, int T);
 bool persist_bwd_check(const BwdGroup& g, int B, int T);

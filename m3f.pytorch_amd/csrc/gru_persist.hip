@@ -706,7 +706,9 @@ int persist_fwd_launch(const FwdGroup& g, const FragPtrs& fp, int B, int T, int 
         if (e != hipSuccess) return (int)e;
     }
     ++g_launches;
-    if (persist_fwd_uses_x6(g, B, T, flags)) {
+    const bool x6 = persist_fwd_uses_x6(g, B, T, flags);
+    if (!x6) { const int e = persist_take_after(s); if (e) return e; }
+    if (x6) {
         for (int i = 0; i < g.n; ++i) {                                      // W_hh -> bf16x3 B-operand fragments
             const int H = g.d[i].H;
             int blk = (3 * H * H + 255) / 256;
@@ -714,6 +716,7 @@ int persist_fwd_launch(const FwdGroup& g, const FragPtrs& fp, int B, int T, int 
             wfrag6_prep_kernel<<<blk, 256, 0, s>>>(g.d[i].w_hh, reinterpret_cast<unsigned short*>(fp.wfrag[i]), H);
         }
         M3T_LAUNCH_CHECK();
+        { const int e = persist_take_after(s); if (e) return e; }
         if (sh.nc == 2) hipLaunchKernelGGL(gru_persist_fwd6_kernel<2>, dim3(sh.grid), dim3(NT), 0, s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
         else hipLaunchKernelGGL(gru_persist_fwd6_kernel<4>, dim3(sh.grid), dim3(NT), 0, s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
         M3T_LAUNCH_CHECK();
@@ -735,9 +738,20 @@ int persist_bwd_launch(const BwdGroup& g, const FragPtrs& fp, int B, int T, hipS
         if (e != hipSuccess) return (int)e;
     }
     ++g_launches;
+    { const int e = persist_take_after(s); if (e) return e; }
     hipLaunchKernelGGL(pick_bwd(sh), dim3(sh.grid), dim3(NT), 0, s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
     M3T_LAUNCH_CHECK();
     return 0;
+}
+
+static thread_local hipEvent_t g_after = nullptr;
+void persist_set_after(hipEvent_t ev) { g_after = ev; }
+void persist_drop_after() { g_after = nullptr; }
+int persist_take_after(hipStream_t s) {
+    if (!g_after) return 0;
+    const hipError_t e = hipStreamWaitEvent(s, g_after, 0);
+    g_after = nullptr;
+    return (int)e;
 }
 
 int persist_launch_count() { return g_launches; }
@@ -750,6 +764,11 @@ int persist_profile(unsigned long long* out6) {
 }  // namespace m3t_gru
 
 extern "C" int m3t_gru_persist_count(void) { return m3t_gru::persist_launch_count(); }
+
+extern "C" int m3t_gru_scan_after(void* event) {
+    m3t_gru::persist_set_after((hipEvent_t)event);
+    return 0;
+}
 
 extern "C" int m3t_gru_persist_profile(unsigned long long* out6) {
     return m3t_gru::persist_profile(out6);

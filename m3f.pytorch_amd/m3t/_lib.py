@@ -10,6 +10,7 @@ M3T_EINVAL = 10001
 M3T_ESPIN = 10002
 M3T_SCAN_NO_PERSIST = 1
 M3T_BF16 = 2
+M3T_GEMM_EXCLUSIVE = 8
 M3T_SCAN_FP32 = 4
 M3T_MAX_SCANS = 8
 
@@ -35,12 +36,14 @@ SIGNATURES = {
     "m3t_version": [],
     "m3t_device_arch": [C.c_char_p, _i],
     "m3t_sgemm": [_i, _i, _i, _i, _i, _f, _i, _f, _i, _f, _i, _f, _i, _i, _i, _i, _i, _i, _f, _z, _i, _s],
+    "m3t_sgemm_plan": [_i, _i, _i, _i, _i, _z, _i, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "m3t_colsum": [_f, _i, _i, _i, _f, _i, _f, _z, _s],
     "m3t_transpose": [_f, _i, _i, _i, _f, _i, _s],
     "m3t_relu_bwd": [_f, _f, _z, _s],
     "m3t_gru_scan_fwd": [C.POINTER(GruFwdDesc), _i, _i, _i, _f, _z, _i, _s],
     "m3t_gru_scan_bwd": [C.POINTER(GruBwdDesc), _i, _i, _i, _f, _z, _i, _s],
     "m3t_gru_persist_count": [],
+    "m3t_gru_scan_after": [C.c_void_p],
     "m3t_gru_persist_profile": [C.c_void_p],
     "m3t_att_fuse_fwd": [_f, _f, _f, _f, _f, _i, _i, _s],
     "m3t_att_fuse_bwd": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _s],

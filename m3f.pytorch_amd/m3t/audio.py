@@ -94,11 +94,11 @@ def melspec_db(y, fps=30.0, pad_mode="constant", top_db=80.0):
     _lib.check(lib().m3t_frame_window(_p(y), n, N_FFT, hop, 1 if pad_mode == "reflect" else 0, _p(win), _p(frames), nf,
                                       _stream()), "m3t_frame_window")
     spec = torch.empty(nf, 2 * bins, dtype=torch.float32, device=dev)
-    sgemm(0, 0, nf, 2 * bins, N_FFT, frames, 0, N_FFT, dft, 0, 2 * bins, spec, 0, 2 * bins, prec=0)
+    sgemm(0, 0, nf, 2 * bins, N_FFT, frames, 0, N_FFT, dft, 0, 2 * bins, spec, 0, 2 * bins, prec=0, exclusive=True)
     power = torch.empty(nf, bins, dtype=torch.float32, device=dev)
     _lib.check(lib().m3t_power_spectrum(_p(spec), nf, bins, _p(power), _stream()), "m3t_power_spectrum")
     mel = torch.empty(nf, N_MELS, dtype=torch.float32, device=dev)
-    sgemm(0, 0, nf, N_MELS, bins, power, 0, bins, melT, 0, N_MELS, mel, 0, N_MELS, prec=0)
+    sgemm(0, 0, nf, N_MELS, bins, power, 0, bins, melT, 0, N_MELS, mel, 0, N_MELS, prec=0, exclusive=True)
     out = torch.empty_like(mel)
     ws = workspace(dev)
     _lib.check(lib().m3t_power_to_db(_p(mel), mel.numel(), 1e-10, float(top_db), _p(out), _p(ws), ws.numel() * 4, _stream()),

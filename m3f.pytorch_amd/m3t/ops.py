@@ -86,6 +86,13 @@ _PERSIST_ENABLED = os.environ.get("M3T_SCAN_PERSIST", "1") != "0"
 _INTERLEAVE = os.environ.get("M3T_SCAN_INTERLEAVE", "1") != "0"
 
 
+# weight-gradient GEMMs of a GRU level (dW_ih, dW_hh) feed nothing but the optimizer: they leave the scan -> dX -> scan
+# chain for a third stream and run beside the next level's scan (M3T_WGRAD_STREAM=0: in line, as before)
+_WGRAD = {}
+_WGRAD_ENABLED = os.environ.get("M3T_WGRAD_STREAM", "1") != "0"
+_WGRAD_BACKGROUND = os.environ.get("M3T_WGRAD_BACKGROUND", "0") == "1"
+
+
 def side_stream(device):
     key = (device.type, device.index)
     st = _SIDE.get(key)
@@ -95,14 +102,27 @@ def side_stream(device):
     return st
 
 
+def wgrad_stream(device):
+    key = (device.type, device.index)
+    st = _WGRAD.get(key)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _WGRAD[key] = st
+    return st
+
+
 def _ws_tag(device):
+    cur = torch.cuda.current_stream(device)
     st = _SIDE.get((device.type, device.index))
-    return "side" if st is not None and torch.cuda.current_stream(device) == st else "main"
+    if st is not None and cur == st:
+        return "side"
+    st = _WGRAD.get((device.type, device.index))
+    return "wgrad" if st is not None and cur == st else "main"
 
 
 def workspace(device, nbytes=_WS_MIN, tag=None):
     """Per-device, per-stream scratch (split-K slabs, partial sums, scan fragments).  One buffer per stream role
-    (main / side), so stream order serialises reuse."""
+    (main / side / wgrad), so stream order serialises reuse."""
     key = (device.type, device.index, tag or _ws_tag(device))
     ws = _WS.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
@@ -139,14 +159,22 @@ class precision:
 
 
 def sgemm(transA, transB, M, N, K, A, a_off, lda, B, b_off, ldb, Cm, c_off, ldc, bias=None, act=0,
-          accumulate=False, seg=(0, 0, 0, 0), use_ws=True, background=False, prec=None):
+          accumulate=False, seg=(0, 0, 0, 0), use_ws=True, background=False, prec=None, exclusive=False):
     ws = workspace(Cm.device) if use_ws else None
-    flags = (1 if background else 0) | (_PREC[0] if prec is None else prec)
+    flags = (1 if background else 0) | (_PREC[0] if prec is None else prec) | (_lib.M3T_GEMM_EXCLUSIVE if exclusive else 0)
     with _Timed("sgemm_kernel", 1, 2.0 * M * N * K) if PROFILE_GEMM[0] else _NULL:
         rc = lib().m3t_sgemm(transA, transB, M, N, K, _p(A, a_off), lda, _p(B, b_off), ldb, _p(Cm, c_off), ldc,
                              _p(bias), act, int(accumulate), seg[0], seg[1], seg[2], seg[3],
                              _p(ws), (ws.numel() * 4) if ws is not None else 0, flags, _stream())
     _lib.check(rc, "m3t_sgemm")
+
+
+def sgemm_plan(transA, M, N, K, seg_len=0, exclusive=False, prec=None, ws_bytes=_WS_MIN):
+    """(kernel, splits) m3t_sgemm would use: kernel 0 fp32-MFMA, 1 bf16x6 128-tile, 2 bf16x6 256-tile."""
+    k, sp = C.c_int(0), C.c_int(0)
+    flags = (_PREC[0] if prec is None else prec) | (_lib.M3T_GEMM_EXCLUSIVE if exclusive else 0)
+    _lib.check(lib().m3t_sgemm_plan(transA, M, N, K, seg_len, ws_bytes, flags, C.byref(k), C.byref(sp)), "m3t_sgemm_plan")
+    return k.value, sp.value
 
 
 def colsum(X, x_off, M, N, ld, out, accumulate=False):
@@ -181,7 +209,7 @@ class _Linear(torch.autograd.Function):
         M = x.numel() // K
         y = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
         ctx.prec = _PREC[0]
-        sgemm(0, 1, M, N, K, x, 0, K, w, 0, K, y, 0, N, bias=b, act=act, prec=ctx.prec)
+        sgemm(0, 1, M, N, K, x, 0, K, w, 0, K, y, 0, N, bias=b, act=act, prec=ctx.prec, exclusive=True)
         ctx.save_for_backward(x, w, y if act else None)
         ctx.act, ctx.has_bias = act, b is not None
         return y
@@ -197,10 +225,10 @@ class _Linear(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            sgemm(0, 0, M, K, N, dy, 0, N, w, 0, K, dx, 0, K, prec=ctx.prec)
+            sgemm(0, 0, M, K, N, dy, 0, N, w, 0, K, dx, 0, K, prec=ctx.prec, exclusive=True)
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
-            sgemm(1, 0, N, K, M, dy, 0, N, x, 0, K, dw, 0, K, prec=ctx.prec)
+            sgemm(1, 0, N, K, M, dy, 0, N, x, 0, K, dw, 0, K, prec=ctx.prec, exclusive=True)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = torch.empty(N, dtype=x.dtype, device=x.device)
             colsum(dy, 0, M, N, N, db)
@@ -228,7 +256,20 @@ def _scan_flags(device):
     return _lib.M3T_SCAN_FP32 if SCAN_FP32[0] else 0
 
 
-def _scan_fwd(descs, B, T, prec=0):
+_DEFER_FENCE = os.environ.get("M3T_SCAN_DEFER_FENCE", "1") != "0"
+
+
+def _scan_after(ev):
+    """the next scan call launches its scan kernels only after torch event `ev` (its preparation is not held back;
+    M3T_SCAN_DEFER_FENCE=0: the whole call waits)"""
+    if ev is not None:
+        if _DEFER_FENCE:
+            _lib.check(lib().m3t_gru_scan_after(C.c_void_p(ev.cuda_event)), "m3t_gru_scan_after")
+        else:
+            torch.cuda.current_stream().wait_event(ev)
+
+
+def _scan_fwd(descs, B, T, prec=0, after=None):
     for i in range(0, len(descs), M3T_MAX_SCANS):
         chunk = descs[i:i + M3T_MAX_SCANS]
         arr = (GruFwdDesc * len(chunk))(*chunk)
@@ -237,13 +278,14 @@ def _scan_fwd(descs, B, T, prec=0):
             dev = torch.device("cuda", torch.cuda.current_device())
             ws = workspace(dev)
             n0 = lib().m3t_gru_persist_count() if tm.rec is not None else 0
+            _scan_after(after if i == 0 else None)
             rc = lib().m3t_gru_scan_fwd(arr, len(chunk), B, T, _p(ws), ws.numel() * 4, _scan_flags(dev) | prec, _stream())
             if tm.rec is not None and lib().m3t_gru_persist_count() != n0:      # one launch ran all T steps
                 tm.rec.update(kernel="gru_persist_fwd_kernel", launches=1, steps=T)
         _lib.check(rc, "m3t_gru_scan_fwd")
 
 
-def _scan_bwd(descs, B, T, prec=0):
+def _scan_bwd(descs, B, T, prec=0, after=None):
     for i in range(0, len(descs), M3T_MAX_SCANS):
         chunk = descs[i:i + M3T_MAX_SCANS]
         arr = (GruBwdDesc * len(chunk))(*chunk)
@@ -252,6 +294,7 @@ def _scan_bwd(descs, B, T, prec=0):
             dev = torch.device("cuda", torch.cuda.current_device())
             ws = workspace(dev)
             n0 = lib().m3t_gru_persist_count() if tm.rec is not None else 0
+            _scan_after(after if i == 0 else None)
             rc = lib().m3t_gru_scan_bwd(arr, len(chunk), B, T, _p(ws), ws.numel() * 4, _scan_flags(dev) | prec, _stream())
             if tm.rec is not None and lib().m3t_gru_persist_count() != n0:
                 tm.rec.update(kernel="gru_persist_bwd_kernel", launches=1, steps=T)
@@ -319,8 +362,11 @@ class _MultiBiGRU(torch.autograd.Function):
         prec = _PREC[0]
         groups = _stream_groups(Hs, B)
 
-        def level_fwd(l, idxs, scan):
-            """scan=False: the input projections of layer l for the stacks idxs; scan=True: their grouped scan"""
+        alone = not _interleaved(groups) and all(kind == "main" for kind, _ in groups)   # nothing runs beside these GEMMs
+
+        def level_fwd(l, idxs, scan, after=None):
+            """scan=False: the input projections of layer l for the stacks idxs; scan=True: their grouped scan (its scan
+            kernels fenced behind the event `after`)"""
             descs = []
             for s in idxs:
                 H = Hs[s]
@@ -329,13 +375,14 @@ class _MultiBiGRU(torch.autograd.Function):
                 for d in (0, 1):
                     w_ih, w_hh, b_ih, b_hh = params[s][(2 * l + d) * 4:(2 * l + d) * 4 + 4]
                     if not scan:
-                        sgemm(0, 1, B * T, 3 * H, I, inp, 0, I, w_ih, 0, I, xprojs[l][s], d * 3 * H, 6 * H, bias=b_ih, prec=prec)
+                        sgemm(0, 1, B * T, 3 * H, I, inp, 0, I, w_ih, 0, I, xprojs[l][s], d * 3 * H, 6 * H, bias=b_ih, prec=prec,
+                              exclusive=alone)
                     else:
                         descs.append(GruFwdDesc(_vp(xprojs[l][s]), _vp(w_hh), _vp(b_hh), _vp(outs[l][s]),
                                                 _vp(gates[l][s], d * B * T * 4 * H), _vp(h_ns[s], (2 * l + d) * B * H),
                                                 H, d, 6 * H, d * 3 * H, 2 * H, d * H))
             if scan:
-                _scan_fwd(descs, B, T, prec)
+                _scan_fwd(descs, B, T, prec, after)
 
         if _interleaved(groups):
             # heavy group on the main stream, light group on the side stream; persistent scans strictly alternate
@@ -350,14 +397,11 @@ class _MultiBiGRU(torch.autograd.Function):
                     level_fwd(l, heavy, False)
                     with torch.cuda.stream(side):
                         level_fwd(l, light, False)
-                    if ev_light is not None:
-                        main.wait_event(ev_light)
-                    level_fwd(l, heavy, True)
+                    level_fwd(l, heavy, True, ev_light)
                     ev_heavy = torch.cuda.Event()
                     ev_heavy.record(main)
-                    side.wait_event(ev_heavy)
                     with torch.cuda.stream(side):
-                        level_fwd(l, light, True)
+                        level_fwd(l, light, True, ev_heavy)
                         ev_light = torch.cuda.Event()
                         ev_light.record(side)
             finally:
@@ -431,7 +475,7 @@ class _MultiBiGRU(torch.autograd.Function):
         cur = {s: douts[s] for s in range(n_stacks)}
         prec = ctx.prec
 
-        def level_scan(l, idxs):
+        def level_scan(l, idxs, after=None):
             descs = []
             for s in idxs:
                 H = Hs[s]
@@ -446,18 +490,24 @@ class _MultiBiGRU(torch.autograd.Function):
                                             _vp(dgx[l][s]), _vp(dgh[l][s], d * B * T * 3 * H), _vp(dh[l][s], d * B * H),
                                             _vp(dbp[l][s], d * B * 4 * H), _vp(out_grads[base + 2]), _vp(out_grads[base + 3]),
                                             H, d, 2 * H, d * H, 6 * H, d * 3 * H))
-            _scan_bwd(descs, B, T, prec)
+            _scan_bwd(descs, B, T, prec, after)
 
-        def level_gemms(l, idxs):
+        def level_dx(l, idxs):           # on the chain: feeds the next level's scan
             for s in idxs:
                 H = Hs[s]
                 inp, out, gts = layer_io(l, s)
                 I = inp.shape[-1]
-                if need_dx[l][s]:          # critical path first: feeds the next level's scan
+                if need_dx[l][s]:
                     for d in (0, 1):
                         sgemm(0, 0, B * T, I, 3 * H, dgx[l][s], d * 3 * H, 6 * H, params[s][(2 * l + d) * 4], 0, I,
                               dinp[l][s], 0, I, accumulate=(d == 1), prec=prec)
                     cur[s] = dinp[l][s]
+
+        def level_dw(l, idxs, background=False):           # off the chain: only the optimizer reads these
+            for s in idxs:
+                H = Hs[s]
+                inp, out, gts = layer_io(l, s)
+                I = inp.shape[-1]
                 for d in (0, 1):
                     base = s * per + 1 + (2 * l + d) * 4
                     dw_ih, dw_hh = out_grads[base:base + 2]      # the bias gradients come out of the scan itself
@@ -466,14 +516,33 @@ class _MultiBiGRU(torch.autograd.Function):
                         # dW_hh = sum_{b,t} dgh[b,t]^T h_prev(b,t): forward pairs (t, t-1), reverse pairs (t, t+1)
                         a_off, b_off = (1, 0) if d == 0 else (0, 1)
                         sgemm(1, 0, 3 * H, H, B * (T - 1), dgh[l][s], goff, 3 * H, out, d * H, 2 * H, dw_hh, 0, H,
-                              seg=(T - 1, T, a_off, b_off), prec=prec)
+                              seg=(T - 1, T, a_off, b_off), prec=prec, background=background)
                     else:
                         dw_hh.zero_()
-                    sgemm(1, 0, 3 * H, I, B * T, dgx[l][s], d * 3 * H, 6 * H, inp, 0, I, dw_ih, 0, I, prec=prec)
+                    sgemm(1, 0, 3 * H, I, B * T, dgx[l][s], d * 3 * H, 6 * H, inp, 0, I, dw_ih, 0, I, prec=prec,
+                          background=background)
+
+        wg = wgrad_stream(dev) if _WGRAD_ENABLED else None
+        if wg is not None:
+            wg.wait_stream(main)
+
+        def level_gemms(l, idxs):
+            """after the scan of (l, idxs) on the current stream: dX in line, dW on the weight-gradient stream"""
+            if wg is None:
+                level_dx(l, idxs)
+                level_dw(l, idxs)
+                return
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            wg.wait_event(ev)
+            with torch.cuda.stream(wg):
+                level_dw(l, idxs, _WGRAD_BACKGROUND)
+            level_dx(l, idxs)
 
         if _interleaved(groups):
             # as in forward: the light group's backward scans run on the side stream beside the heavy group's GEMMs
-            # (data and weight gradients), persistent scans strictly alternating
+            # (data gradients; the weight gradients of both groups trail on their own stream), persistent scans
+            # strictly alternating
             heavy, light = groups[0][1], groups[1][1]
             side = side_stream(dev)
             side.wait_stream(main)
@@ -481,15 +550,12 @@ class _MultiBiGRU(torch.autograd.Function):
             _FENCED[0] = True
             try:
                 for l in range(L - 1, -1, -1):
-                    if ev_light is not None:
-                        main.wait_event(ev_light)
-                    level_scan(l, heavy)
+                    level_scan(l, heavy, ev_light)
                     ev_heavy = torch.cuda.Event()
                     ev_heavy.record(main)
                     level_gemms(l, heavy)
-                    side.wait_event(ev_heavy)
                     with torch.cuda.stream(side):
-                        level_scan(l, light)
+                        level_scan(l, light, ev_heavy)
                         ev_light = torch.cuda.Event()
                         ev_light.record(side)
                         level_gemms(l, light)
@@ -509,6 +575,8 @@ class _MultiBiGRU(torch.autograd.Function):
             for kind, _ in groups:
                 if kind == "side":
                     main.wait_stream(side_stream(dev))
+        if wg is not None:
+            main.wait_stream(wg)
         for s in range(n_stacks):
             out_grads[s * per] = dinp[0][s]
         return (None, None) + tuple(out_grads)
