@@ -444,18 +444,32 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd_kernel(BwdGroup g, FragPtr
     const bool stamp = ex.prof != nullptr && blockIdx.x == 0 && tid == 0;
     long long psum[6] = {0, 0, 0, 0, 0, 0}, last = stamp ? clock64() : 0;
 
-    // this step's saved activations: loaded at the END of the previous step (after the publish)
-    float dout = 0.f, gr = 0.f, gz = 0.f, gn = 0.f, ghn = 0.f, hprev = 0.f;
-    auto load_step = [&](int step) {
-        const int t = d.reverse ? step : T - 1 - step;
-        const int tp = d.reverse ? t + 1 : t - 1;
-        dout = d.dout[((size_t)pb * T + t) * d.ldo + d.ooff + pj];
-        const float* gp = d.gates + ((size_t)pb * T + t) * 4 * H;
-        { const float4 g4 = *reinterpret_cast<const float4*>(gp + 4 * (size_t)pj); gr = g4.x; gz = g4.y; gn = g4.z; ghn = g4.w; }
-        hprev = step < T - 1 ? d.out[((size_t)pb * T + tp) * d.ldo + d.ooff + pj] : 0.f;
-    };
-    if (pok) load_step(0);
-    __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0): see the forward kernel
+    // this step's saved activations: loaded at the END of the previous step (after the publish) by inline asm, so that
+    // hipcc neither waits for them nor copies them there (it did: a vmcnt(0) + v_mov at the bottom of the step put the
+    // whole HBM round trip of the step's stores and loads on the chain, 2.4 of 5 us).  They are defined by the vmcnt(0)
+    // of the next gather (vector-memory operations retire in order) and laundered there.  The loads are UNCONDITIONAL
+    // (every thread, every step; lanes past the batch / the last step re-read a valid address): a conditional
+    // definition would let the compiler merge old and new values with copies that read the registers in flight.
+    float dout, hprev;
+    f32x4 g4;                                          // (r, z, n, W_hn h + b_hn) of this (row, unit, t)
+    const int pbc = pb < B ? pb : B - 1;
+    const float* pd0 = d.dout + (size_t)pbc * T * d.ldo + d.ooff + pj;
+    const float* pg0 = d.gates + (size_t)pbc * T * 4 * H + 4 * (size_t)pj;
+    const float* ph0 = d.out + (size_t)pbc * T * d.ldo + d.ooff + pj;
+#define M3T_BWD_LOAD_STEP(step_)                                                                                      \
+    do {                                                                                                               \
+        const int ls_ = (step_) < T ? (step_) : T - 1;                                                                 \
+        const int lt_ = d.reverse ? ls_ : T - 1 - ls_;                                                                 \
+        const int ltp_ = ls_ < T - 1 ? (d.reverse ? lt_ + 1 : lt_ - 1) : lt_;                                          \
+        asm volatile("global_load_dword %0, %3, off\n\t"                                                               \
+                     "global_load_dwordx4 %1, %4, off\n\t"                                                             \
+                     "global_load_dword %2, %5, off"                                                                   \
+                     : "=&v"(dout), "=&v"(g4), "=&v"(hprev)                                                            \
+                     : "v"(pd0 + (size_t)lt_ * d.ldo), "v"(pg0 + (size_t)lt_ * 4 * H), "v"(ph0 + (size_t)ltp_ * d.ldo)  \
+                     : "memory");                                                                                      \
+    } while (0)
+    M3T_BWD_LOAD_STEP(0);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(dout), "+v"(g4), "+v"(hprev) :: "memory");
 
     for (int step = 0; step < T; ++step) {
         const int t = d.reverse ? step : T - 1 - step;
@@ -494,6 +508,7 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd_kernel(BwdGroup g, FragPtr
                 if (++spins > SPIN_LIMIT) { dead = true; if (lane == 0) raise_spin(err, step); break; }
                 __builtin_amdgcn_s_sleep(1);
             }
+            asm volatile("" : "+v"(dout), "+v"(g4), "+v"(hprev));      // this step's activations: complete since the vmcnt(0) above
             M3T_STAMP(1);
             f32x4 acc[RT];
 #pragma unroll
@@ -523,7 +538,8 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd_kernel(BwdGroup g, FragPtr
 #pragma unroll
                 for (int w = 0; w < NW; ++w) mm += red[step & 1][w][prow][pu];
             }
-            const GateBwd c = gru_cell_bwd(dout, dh_carry, z_next, mm, has_next, gr, gz, gn, ghn, hprev);
+            const float gr = g4.x, gz = g4.y, gn = g4.z, ghn = g4.w;
+            const GateBwd c = gru_cell_bwd(dout, dh_carry, z_next, mm, has_next, gr, gz, gn, ghn, step < T - 1 ? hprev : 0.f);
             if (step + 1 < T) {
                 u32x4 gq;
                 const bool bf = g.bf16 != 0;
@@ -541,11 +557,12 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd_kernel(BwdGroup g, FragPtr
                 float* gh = d.dgh + ((size_t)pb * T + t) * H3;
                 gh[pj] = c.dr; gh[H + pj] = c.dz; gh[2 * H + pj] = c.dnr;
                 if (step == T - 1) d.dh[(size_t)pb * H + pj] = c.dht;
-                if (step + 1 < T) load_step(step + 1);
             }
         }
+        M3T_BWD_LOAD_STEP(step + 1);
         M3T_STAMP(5);
     }
+#undef M3T_BWD_LOAD_STEP
     if (pok && d.db_part) {
         float* q = d.db_part + (size_t)pb * 4 * H + pj;
         q[0] = sb_r; q[H] = sb_z; q[2 * H] = sb_n; q[3 * H] = sb_nr;

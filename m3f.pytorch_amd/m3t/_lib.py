@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libm3t_hip.so")
+# M3T_LIB_PATH: another build of the same library (A/B runs of kernel variants in tools/); default: the in-tree build
+LIB_PATH = os.environ.get("M3T_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libm3t_hip.so")
 CSRC_DIR = os.path.join(os.path.dirname(_HERE), "csrc")
 
 M3T_EINVAL = 10001
