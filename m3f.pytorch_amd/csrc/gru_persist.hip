@@ -444,19 +444,25 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd_kernel(BwdGroup g, FragPtr
     const bool stamp = ex.prof != nullptr && blockIdx.x == 0 && tid == 0;
     long long psum[6] = {0, 0, 0, 0, 0, 0}, last = stamp ? clock64() : 0;
 
-    // this step's saved activations: loaded at the END of the previous step (after the publish) by inline asm, so that
-    // hipcc neither waits for them nor copies them there (it did: a vmcnt(0) + v_mov at the bottom of the step put the
-    // whole HBM round trip of the step's stores and loads on the chain, 2.4 of 5 us).  They are defined by the vmcnt(0)
-    // of the next gather (vector-memory operations retire in order) and laundered there.  The loads are UNCONDITIONAL
-    // (every thread, every step; lanes past the batch / the last step re-read a valid address): a conditional
-    // definition would let the compiler merge old and new values with copies that read the registers in flight.
-    float dout, hprev;
-    f32x4 g4;                                          // (r, z, n, W_hn h + b_hn) of this (row, unit, t)
+    // HBM traffic of a step and the chain.  Vector-memory operations retire in order, so everything a wave has issued
+    // before its gather loads sits in front of the gather's vmcnt(0): with the step's six result stores and the next
+    // step's three activation loads issued after the publish (the natural place), every step waited ~0.7 us for each
+    // group (tools/scan_bench.py ablation), and hipcc added a vmcnt(0) + register copies at the bottom of the step on
+    // top (2.4 of 5 us, in-kernel stamps).  Now: the results of step t are kept in registers and stored, and the
+    // activations of step t+1 are requested, right AFTER the gather of step t has completed -- they have the whole
+    // step (MFMAs, barrier, cell math, publish, the peers' latency) to retire before the next gather waits, and between
+    // the publish and the next gather a wave has nothing outstanding but the publish itself.  Two register sets (A for
+    // even steps, B for odd ones; the loop body is included twice) hold the activations; the loads are inline asm,
+    // UNCONDITIONAL (every thread, every step; lanes past the batch and the step past the end re-read a valid address):
+    // compiler-visible or conditional definitions make hipcc wait for them or merge them with copies that read
+    // registers still in flight.  A set is defined by the vmcnt(0) of the gather that precedes its use and laundered there.
+    float doutA, hprevA, doutB, hprevB;
+    f32x4 g4A, g4B;                                    // (r, z, n, W_hn h + b_hn) of this (row, unit, t)
     const int pbc = pb < B ? pb : B - 1;
     const float* pd0 = d.dout + (size_t)pbc * T * d.ldo + d.ooff + pj;
     const float* pg0 = d.gates + (size_t)pbc * T * 4 * H + 4 * (size_t)pj;
     const float* ph0 = d.out + (size_t)pbc * T * d.ldo + d.ooff + pj;
-#define M3T_BWD_LOAD_STEP(step_)                                                                                      \
+#define M3T_BWD_LOAD_STEP(step_, DOUT, G4, HPREV)                                                                     \
     do {                                                                                                               \
         const int ls_ = (step_) < T ? (step_) : T - 1;                                                                 \
         const int lt_ = d.reverse ? ls_ : T - 1 - ls_;                                                                 \
@@ -464,105 +470,42 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd_kernel(BwdGroup g, FragPtr
         asm volatile("global_load_dword %0, %3, off\n\t"                                                               \
                      "global_load_dwordx4 %1, %4, off\n\t"                                                             \
                      "global_load_dword %2, %5, off"                                                                   \
-                     : "=&v"(dout), "=&v"(g4), "=&v"(hprev)                                                            \
+                     : "=&v"(DOUT), "=&v"(G4), "=&v"(HPREV)                                                            \
                      : "v"(pd0 + (size_t)lt_ * d.ldo), "v"(pg0 + (size_t)lt_ * 4 * H), "v"(ph0 + (size_t)ltp_ * d.ldo)  \
                      : "memory");                                                                                      \
     } while (0)
-    M3T_BWD_LOAD_STEP(0);
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(dout), "+v"(g4), "+v"(hprev) :: "memory");
+    M3T_BWD_LOAD_STEP(0, doutA, g4A, hprevA);
+    M3T_BWD_LOAD_STEP(1, doutB, g4B, hprevB);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(doutA), "+v"(g4A), "+v"(hprevA), "+v"(doutB), "+v"(g4B), "+v"(hprevB) :: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0), visible to hipcc: no wait for the weight fragments inside the loop
+    float st_dr = 0.f, st_dz = 0.f, st_dn = 0.f, st_dnr = 0.f;     // results of the previous step, stored after this step's gather
+    auto store_results = [&](int step_of) {
+        const int t = d.reverse ? step_of : T - 1 - step_of;
+        float* gx = d.dgx + ((size_t)pb * T + t) * d.ldg + d.goff;
+        gx[pj] = st_dr; gx[H + pj] = st_dz; gx[2 * H + pj] = st_dn;
+        float* gh = d.dgh + ((size_t)pb * T + t) * H3;
+        gh[pj] = st_dr; gh[H + pj] = st_dz; gh[2 * H + pj] = st_dnr;
+    };
 
-    for (int step = 0; step < T; ++step) {
-        const int t = d.reverse ? step : T - 1 - step;
-        const bool has_next = step > 0;
-        M3T_STAMP(0);
-        if (has_next) {
-            const unsigned tag = (unsigned)step;
-            const u32x4* src = gran + (size_t)((step - 1) & 1) * slot + grp + (size_t)wave * TILE + lane;
-            u32x4 v[NC][RT][4];
-            int spins = 0;
-            for (;;) {
-#pragma unroll
-                for (int m = 0; m < NC; ++m)
-#pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) {
-                        const u32x4* q = src + (size_t)m * NW * TILE + rt * 256;
-                        asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
-                                     "global_load_dwordx4 %1, %4, off offset:1024 sc1\n\t"
-                                     "global_load_dwordx4 %2, %4, off offset:2048 sc1\n\t"
-                                     "global_load_dwordx4 %3, %4, off offset:3072 sc1"
-                                     : "=&v"(v[m][rt][0]), "=&v"(v[m][rt][1]), "=&v"(v[m][rt][2]), "=&v"(v[m][rt][3])
-                                     : "v"(q) : "memory");
-                    }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                bool ok = true;
-#pragma unroll
-                for (int m = 0; m < NC; ++m)
-#pragma unroll
-                    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            asm volatile("" : "+v"(v[m][rt][e]));          // defined only after the wait above
-                            ok = ok && (v[m][rt][e].w == tag);
-                        }
-                if (__all(ok) || dead) break;
-                if (++spins > SPIN_LIMIT) { dead = true; if (lane == 0) raise_spin(err, step); break; }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            asm volatile("" : "+v"(dout), "+v"(g4), "+v"(hprev));      // this step's activations: complete since the vmcnt(0) above
-            M3T_STAMP(1);
-            f32x4 acc[RT];
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int gt = 0; gt < 3; ++gt)             // ascending chunk order gate*nchh + wave + 8m: as the per-step kernel
-#pragma unroll
-                for (int m = 0; m < NC; ++m)
-#pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) {
-                        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[m][rt][0][gt]), wt[gt][m].x, acc[rt], 0, 0, 0);
-                        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[m][rt][1][gt]), wt[gt][m].y, acc[rt], 0, 0, 0);
-                        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[m][rt][2][gt]), wt[gt][m].z, acc[rt], 0, 0, 0);
-                        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[m][rt][3][gt]), wt[gt][m].w, acc[rt], 0, 0, 0);
-                    }
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) red[step & 1][wave][rt * 16 + (lane >> 4) * 4 + r][lane & 15] = acc[rt][r];
-        }
-        M3T_STAMP(2);
-        __syncthreads();
-        M3T_STAMP(3);
-        if (pw) {
-            float mm = 0.f;
-            if (has_next) {
-#pragma unroll
-                for (int w = 0; w < NW; ++w) mm += red[step & 1][w][prow][pu];
-            }
-            const float gr = g4.x, gz = g4.y, gn = g4.z, ghn = g4.w;
-            const GateBwd c = gru_cell_bwd(dout, dh_carry, z_next, mm, has_next, gr, gz, gn, ghn, step < T - 1 ? hprev : 0.f);
-            if (step + 1 < T) {
-                u32x4 gq;
-                const bool bf = g.bf16 != 0;
-                gq.x = __float_as_uint(pok ? (bf ? rbf(c.dr) : c.dr) : 0.f); gq.y = __float_as_uint(pok ? (bf ? rbf(c.dz) : c.dz) : 0.f);
-                gq.z = __float_as_uint(pok ? (bf ? rbf(c.dnr) : c.dnr) : 0.f); gq.w = (unsigned)step + 1u;
-                u32x4* q = gran + (size_t)(step & 1) * slot + pub;
-                asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(q), "v"(gq) : "memory");
-            }
-            M3T_STAMP(4);
-            dh_carry = c.dht; z_next = gz;
-            sb_r += c.dr; sb_z += c.dz; sb_n += c.dn; sb_nr += c.dnr;
-            if (pok) {
-                float* gx = d.dgx + ((size_t)pb * T + t) * d.ldg + d.goff;
-                gx[pj] = c.dr; gx[H + pj] = c.dz; gx[2 * H + pj] = c.dn;
-                float* gh = d.dgh + ((size_t)pb * T + t) * H3;
-                gh[pj] = c.dr; gh[H + pj] = c.dz; gh[2 * H + pj] = c.dnr;
-                if (step == T - 1) d.dh[(size_t)pb * H + pj] = c.dht;
-            }
-        }
-        M3T_BWD_LOAD_STEP(step + 1);
-        M3T_STAMP(5);
+    for (int step2 = 0; step2 < T; step2 += 2) {
+#define STEPV step2
+#define CUR(x) x##A
+#define NXT(x) x##B
+#include "gru_persist_bwd_step.inc"
+#undef STEPV
+#undef CUR
+#undef NXT
+        if (step2 + 1 >= T) break;
+#define STEPV (step2 + 1)
+#define CUR(x) x##B
+#define NXT(x) x##A
+#include "gru_persist_bwd_step.inc"
+#undef STEPV
+#undef CUR
+#undef NXT
     }
 #undef M3T_BWD_LOAD_STEP
+    if (pok) d.dh[(size_t)pb * H + pj] = dh_carry;
     if (pok && d.db_part) {
         float* q = d.db_part + (size_t)pb * 4 * H + pj;
         q[0] = sb_r; q[H] = sb_z; q[2 * H] = sb_n; q[3 * H] = sb_nr;
