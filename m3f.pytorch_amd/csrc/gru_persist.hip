@@ -288,119 +288,44 @@ __global__ __launch_bounds__(NT) void gru_persist_fwd6_kernel(FwdGroup g, FragPt
     const bool stamp = ex.prof != nullptr && blockIdx.x == 0 && tid == 0;
     long long psum[6] = {0, 0, 0, 0, 0, 0}, last = stamp ? clock64() : 0;
 
-    const float* xp = d.xproj + (size_t)pb * T * d.ldx + d.xoff + pj + (d.reverse ? (size_t)(T - 1) * d.ldx : 0);
-    const ptrdiff_t xstep = d.reverse ? -(ptrdiff_t)d.ldx : (ptrdiff_t)d.ldx;
-    float xr = 0.f, xz = 0.f, xn = 0.f;
-    if (pok) { xr = xp[0]; xz = xp[H]; xn = xp[2 * H]; }
+    // x-projection of the step in (xr, xz, xn).  The next step's is requested right after this step's gather has
+    // completed (nothing else outstanding then) and has the rest of the step to arrive: loaded after the publish it sat
+    // in front of the next gather's vmcnt(0) (vector-memory operations retire in order).  Inline asm, unconditional
+    // (lanes past the batch and the step past the end re-read a valid address), defined by the next gather's vmcnt(0)
+    // and laundered there -- as in the backward kernel below, compiler-visible loads made hipcc wait for them mid-step.
+    float xrA, xzA, xnA, xrB, xzB, xnB;               // two register sets: even / odd steps (the loop body is included twice)
+    const float* xq = d.xproj + (size_t)(pb < B ? pb : B - 1) * T * d.ldx + d.xoff + pj;
+#define M3T_FWD_LOAD_X(step_, XR, XZ, XN)                                                                             \
+    do {                                                                                                               \
+        const int ls_ = (step_) < T ? (step_) : T - 1;                                                                 \
+        const float* xa_ = xq + (size_t)(d.reverse ? T - 1 - ls_ : ls_) * d.ldx;                                       \
+        asm volatile("global_load_dword %0, %3, off\n\t"                                                               \
+                     "global_load_dword %1, %4, off\n\t"                                                               \
+                     "global_load_dword %2, %5, off"                                                                   \
+                     : "=&v"(XR), "=&v"(XZ), "=&v"(XN) : "v"(xa_), "v"(xa_ + H), "v"(xa_ + 2 * H) : "memory");         \
+    } while (0)
+    M3T_FWD_LOAD_X(0, xrA, xzA, xnA);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(xrA), "+v"(xzA), "+v"(xnA) :: "memory");
     __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): see gru_persist_fwd_kernel
 
-    for (int step = 0; step < T; ++step) {
-        const int t = d.reverse ? T - 1 - step : step;
-        M3T_STAMP(0);
-        if (step > 0) {
-            const unsigned tag = (unsigned)step & 0xffffu;
-            const unsigned long long* src = gran + (size_t)((step - 1) & 1) * slot + grp + lane_off;
-            pu32x4 v[KS][4];                               // [k-step][unit pair jp] = {lo(j0), hi(j0), lo(j1), hi(j1)}
-            int spins = 0;
-            for (;;) {
-                // ONE 16-byte load takes two adjacent granules: the exchange is priced per load instruction, not per byte
-                // (tools/persist_probe.hip: 8 dwordx4 instead of 16 dwordx2 loads = 1.63 vs 2.03 us per step)
-#pragma unroll
-                for (int k = 0; k < KS; ++k) {
-                    const unsigned long long* qp = src + (size_t)(2 * k) * NW * TILE;
-                    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
-                                 "global_load_dwordx4 %1, %4, off offset:512 sc1\n\t"
-                                 "global_load_dwordx4 %2, %4, off offset:1024 sc1\n\t"
-                                 "global_load_dwordx4 %3, %4, off offset:1536 sc1"
-                                 : "=&v"(v[k][0]), "=&v"(v[k][1]), "=&v"(v[k][2]), "=&v"(v[k][3])
-                                 : "v"(qp) : "memory");
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                bool ok = true;
-#pragma unroll
-                for (int k = 0; k < KS; ++k)
-#pragma unroll
-                    for (int jp = 0; jp < 4; ++jp) {
-                        asm volatile("" : "+v"(v[k][jp]));
-                        ok = ok && ((v[k][jp].y >> 16) == tag) && ((v[k][jp].w >> 16) == tag);
-                    }
-                if (__all(ok) || dead) break;
-                if (++spins > SPIN_LIMIT) { dead = true; if (lane == 0) raise_spin(err, step); break; }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            M3T_STAMP(1);
-            f32x4 acc[3];
-#pragma unroll
-            for (int ct = 0; ct < 3; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int k = 0; k < KS; ++k) {
-                pu32x4 a1, a2, a3;                         // the three terms of 8 consecutive units, paired into dwords
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    a1[jj] = __builtin_amdgcn_perm(v[k][jj].z, v[k][jj].x, 0x05040100u);
-                    a2[jj] = __builtin_amdgcn_perm(v[k][jj].z, v[k][jj].x, 0x07060302u);
-                    a3[jj] = __builtin_amdgcn_perm(v[k][jj].w, v[k][jj].y, 0x05040100u);
-                }
-                const pbf16x8 A1 = __builtin_bit_cast(pbf16x8, a1), A2 = __builtin_bit_cast(pbf16x8, a2),
-                              A3 = __builtin_bit_cast(pbf16x8, a3);
-#pragma unroll
-                for (int ct = 0; ct < 3; ++ct) {           // smallest terms first
-                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A3, wf[k][ct][0], acc[ct], 0, 0, 0);
-                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2, wf[k][ct][1], acc[ct], 0, 0, 0);
-                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1, wf[k][ct][2], acc[ct], 0, 0, 0);
-                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2, wf[k][ct][0], acc[ct], 0, 0, 0);
-                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1, wf[k][ct][1], acc[ct], 0, 0, 0);
-                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1, wf[k][ct][0], acc[ct], 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int ct = 0; ct < 3; ++ct)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) red[step & 1][wave][ct][(lane >> 4) * 4 + r][lane & 15] = acc[ct][r];
-        }
-        M3T_STAMP(2);
-        __syncthreads();
-        M3T_STAMP(3);
-        if (pw) {
-            float hr = br, hz = bz, hn = bn;
-            if (step > 0) {
-#pragma unroll
-                for (int w = 0; w < NW; ++w) {
-                    hr += red[step & 1][w][0][prow][pu];
-                    hz += red[step & 1][w][1][prow][pu];
-                    hn += red[step & 1][w][2][prow][pu];
-                }
-            }
-            const GateFwd c = gru_cell_fwd(xr, xz, xn, hr, hz, hn, hprev);
-            if (step + 1 < T) {
-                const float hv = pok ? c.h : 0.f;
-                const __bf16 h1 = (__bf16)hv;
-                const float r1 = hv - (float)h1;
-                const __bf16 h2 = (__bf16)r1;
-                const __bf16 h3 = (__bf16)(r1 - (float)h2);
-                const unsigned long long gq = (unsigned long long)__builtin_bit_cast(unsigned short, h1) |
-                                              ((unsigned long long)__builtin_bit_cast(unsigned short, h2) << 16) |
-                                              ((unsigned long long)__builtin_bit_cast(unsigned short, h3) << 32) |
-                                              ((unsigned long long)(((unsigned)step + 1u) & 0xffffu) << 48);
-                __hip_atomic_store(gran + (size_t)(step & 1) * slot + pub, gq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            M3T_STAMP(4);
-            hprev = c.h;
-            if (pok) {
-                d.out[((size_t)pb * T + t) * d.ldo + d.ooff + pj] = c.h;
-                if (d.gates) {
-                    float* gp = d.gates + ((size_t)pb * T + t) * 4 * H;
-                    *reinterpret_cast<float4*>(gp + 4 * (size_t)pj) = make_float4(c.r, c.z, c.n, hn);
-                }
-                if (d.h_n && step == T - 1) d.h_n[(size_t)pb * H + pj] = c.h;
-                if (step + 1 < T) {
-                    xp += xstep;
-                    xr = xp[0]; xz = xp[H]; xn = xp[2 * H];
-                }
-            }
-        }
-        M3T_STAMP(5);
+    for (int step2 = 0; step2 < T; step2 += 2) {
+#define STEPV step2
+#define CUR(x) x##A
+#define NXT(x) x##B
+#include "gru_persist_fwd6_step.inc"
+#undef STEPV
+#undef CUR
+#undef NXT
+        if (step2 + 1 >= T) break;
+#define STEPV (step2 + 1)
+#define CUR(x) x##B
+#define NXT(x) x##A
+#include "gru_persist_fwd6_step.inc"
+#undef STEPV
+#undef CUR
+#undef NXT
     }
+#undef M3T_FWD_LOAD_X
     if (stamp)
         for (int i = 0; i < 6; ++i) ex.prof[i] = (unsigned long long)psum[i];
 }
@@ -475,8 +400,7 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd_kernel(BwdGroup g, FragPtr
                      : "memory");                                                                                      \
     } while (0)
     M3T_BWD_LOAD_STEP(0, doutA, g4A, hprevA);
-    M3T_BWD_LOAD_STEP(1, doutB, g4B, hprevB);
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(doutA), "+v"(g4A), "+v"(hprevA), "+v"(doutB), "+v"(g4B), "+v"(hprevB) :: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(doutA), "+v"(g4A), "+v"(hprevA) :: "memory");
     __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0), visible to hipcc: no wait for the weight fragments inside the loop
     float st_dr = 0.f, st_dz = 0.f, st_dn = 0.f, st_dnr = 0.f;     // results of the previous step, stored after this step's gather
     auto store_results = [&](int step_of) {

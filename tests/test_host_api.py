@@ -57,6 +57,30 @@ def test_desc_struct_layout_matches_header(tmp_path):
             assert int(got["%s.%s" % (st, n)]) == getattr(cls, n).offset, (st, n)
 
 
+def test_persistent_scan_prefetch_is_not_copied_in_flight(tmp_path):
+    """gru_persist.hip requests the next step's activations with inline-asm loads whose completion only the NEXT gather's
+    vmcnt(0) guarantees.  If hipcc ever merges such a value with a register copy (or spills it) before that wait, the copy
+    reads a register still in flight -- silently wrong results.  Compile the listing and check every such block
+    (tools/check_inflight.py); the sgemm planner is checked on the way (no device work)."""
+    import subprocess
+    import sys
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not installed")
+    lst = str(tmp_path / "gru_persist.s")
+    csrc = os.path.join(ROOT, "m3f.pytorch_amd", "csrc")
+    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"), "-I" + csrc,
+                    "-Wno-unused-function", "-fno-gpu-rdc", "-S", "--cuda-device-only", os.path.join(csrc, "gru_persist.hip"),
+                    "-o", lst], check=True, capture_output=True)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_inflight.py"), lst, "gru_persist_"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    checked = [int(m) for m in re.findall(r"(\d+) asm load blocks checked", r.stdout)]
+    assert sum(1 for c in checked if c >= 3) >= 10, r.stdout          # 8 backward + 2 bf16x6 forward instances
+    assert ops.sgemm_plan(0, 9600, 1536, 1024) [0] == 1 and ops.sgemm_plan(0, 9600, 1536, 1024, exclusive=True)[0] == 2
+    assert ops.sgemm_plan(0, 300, 257, 130)[0] == 0
+
+
 def test_no_cpu_fallback():
     x = torch.randn(4, 8)
     w = torch.randn(3, 8)

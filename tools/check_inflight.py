@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Static check of a hipcc -S listing: after every inline-asm block of plain (non-sc1) global loads in a kernel, no
-instruction may touch the loaded registers before the next `s_waitcnt vmcnt(0)` (linear order, wrapping once at the
-loop back edge).  Guards the asm-prefetch idiom of gru_persist.hip against compiler-inserted copies.
+register copy or spill (v_mov / v_accvgpr_write / scratch_store) may read the loaded registers before the next
+`s_waitcnt vmcnt(0)` (linear order, wrapping once at the loop back edge) -- the signature of hipcc merging an old and a new
+value of an asm-defined variable.  Guards the asm-prefetch idiom of gru_persist.hip (tests/test_host_api.py runs it).
 usage: check_inflight.py listing.s [kernel-name-substring]"""
 import re
 import sys
@@ -52,7 +53,8 @@ for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
             l = lines[k].strip()
             if l.startswith("s_waitcnt") and "vmcnt(0)" in l:
                 break
-            if l and not l.startswith(";") and not l.startswith(".") and regs(l) & dst:
+            is_copy = l.startswith(("v_mov_b", "v_accvgpr_write", "scratch_store", "v_pk_mov"))
+            if is_copy and "," in l and regs(l.split(",", 1)[1]) & dst:       # a compiler copy / spill READING them
                 print("%s: line %d touches in-flight v%s: %s" % (name[:60], k + 1, sorted(regs(l) & dst), l))
                 bad += 1
             k += 1
