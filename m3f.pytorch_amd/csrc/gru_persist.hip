@@ -96,112 +96,46 @@ __global__ __launch_bounds__(NT) void gru_persist_fwd_kernel(FwdGroup g, FragPtr
     const bool stamp = ex.prof != nullptr && blockIdx.x == 0 && tid == 0;
     long long psum[6] = {0, 0, 0, 0, 0, 0}, last = stamp ? clock64() : 0;
 
-    // x-projection of the step: loaded at the END of the previous step (after the publish), so it is in flight during
-    // the gather and never on the chain
-    const float* xp = d.xproj + (size_t)pb * T * d.ldx + d.xoff + pj + (d.reverse ? (size_t)(T - 1) * d.ldx : 0);
-    const ptrdiff_t xstep = d.reverse ? -(ptrdiff_t)d.ldx : (ptrdiff_t)d.ldx;
-    float xr = 0.f, xz = 0.f, xn = 0.f;
-    if (pok) { xr = xp[0]; xz = xp[H]; xn = xp[2 * H]; }
+    // x-projection of the step.  The next step's is requested right after this step's gather has completed (nothing else
+    // outstanding then) and has the rest of the step to arrive: requested after the publish it sat in front of the next
+    // gather's vmcnt(0) (vector-memory operations retire in order).  Inline asm, unconditional (lanes past the batch
+    // and the step past the end re-read a valid address), two register sets (A: even steps, B: odd; the loop body is
+    // included twice), defined by the next gather's vmcnt(0) and laundered there -- see gru_persist_bwd_kernel.
+    float xrA, xzA, xnA, xrB, xzB, xnB;
+    const float* xq = d.xproj + (size_t)(pb < B ? pb : B - 1) * T * d.ldx + d.xoff + pj;
+#define M3T_FWD_LOAD_X(step_, XR, XZ, XN)                                                                             \
+    do {                                                                                                               \
+        const int ls_ = (step_) < T ? (step_) : T - 1;                                                                 \
+        const float* xa_ = xq + (size_t)(d.reverse ? T - 1 - ls_ : ls_) * d.ldx;                                       \
+        asm volatile("global_load_dword %0, %3, off\n\t"                                                               \
+                     "global_load_dword %1, %4, off\n\t"                                                               \
+                     "global_load_dword %2, %5, off"                                                                   \
+                     : "=&v"(XR), "=&v"(XZ), "=&v"(XN) : "v"(xa_), "v"(xa_ + H), "v"(xa_ + 2 * H) : "memory");         \
+    } while (0)
+    M3T_FWD_LOAD_X(0, xrA, xzA, xnA);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(xrA), "+v"(xzA), "+v"(xnA) :: "memory");
     // everything loaded so far is in registers before the loop: hipcc then places no vmcnt wait for the weight
     // fragments inside the step
     __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
 
-    for (int step = 0; step < T; ++step) {
-        const int t = d.reverse ? T - 1 - step : step;
-        M3T_STAMP(0);
-        if (step > 0) {
-            const unsigned tag = (unsigned)step;       // h_{step-1} carries tag (step-1)+1
-            const unsigned long long* src = gran + (size_t)((step - 1) & 1) * slot + grp + (size_t)wave * TILE + lane;
-            unsigned long long v[NC][RT][4];
-            int spins = 0;
-            for (;;) {
-#pragma unroll
-                for (int m = 0; m < NC; ++m)
-#pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) {          // one address per (chunk, row tile); e by immediate offset
-                        const unsigned long long* q = src + (size_t)m * NW * TILE + rt * 256;
-                        asm volatile("global_load_dwordx2 %0, %4, off sc1\n\t"
-                                     "global_load_dwordx2 %1, %4, off offset:512 sc1\n\t"
-                                     "global_load_dwordx2 %2, %4, off offset:1024 sc1\n\t"
-                                     "global_load_dwordx2 %3, %4, off offset:1536 sc1"
-                                     : "=&v"(v[m][rt][0]), "=&v"(v[m][rt][1]), "=&v"(v[m][rt][2]), "=&v"(v[m][rt][3])
-                                     : "v"(q) : "memory");
-                    }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                bool ok = true;
-#pragma unroll
-                for (int m = 0; m < NC; ++m)
-#pragma unroll
-                    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            asm volatile("" : "+v"(v[m][rt][e]));          // defined only after the wait above
-                            ok = ok && ((unsigned)(v[m][rt][e] >> 32) == tag);
-                        }
-                if (__all(ok) || dead) break;
-                if (++spins > SPIN_LIMIT) { dead = true; if (lane == 0) raise_spin(err, step); break; }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            M3T_STAMP(1);
-            f32x4 acc[RT][3];
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                for (int ct = 0; ct < 3; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int m = 0; m < NC; ++m)
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                    for (int ct = 0; ct < 3; ++ct) {
-                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float((unsigned)v[m][rt][0]), wf[m][ct].x, acc[rt][ct], 0, 0, 0);
-                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float((unsigned)v[m][rt][1]), wf[m][ct].y, acc[rt][ct], 0, 0, 0);
-                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float((unsigned)v[m][rt][2]), wf[m][ct].z, acc[rt][ct], 0, 0, 0);
-                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float((unsigned)v[m][rt][3]), wf[m][ct].w, acc[rt][ct], 0, 0, 0);
-                    }
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                for (int ct = 0; ct < 3; ++ct)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) red[step & (NB - 1)][wave][ct][rt * 16 + (lane >> 4) * 4 + r][lane & 15] = acc[rt][ct][r];
-        }
-        M3T_STAMP(2);
-        __syncthreads();
-        M3T_STAMP(3);
-        if (pw) {
-            float hr = br, hz = bz, hn = bn;
-            if (step > 0) {
-#pragma unroll
-                for (int w = 0; w < NW; ++w) {
-                    hr += red[step & (NB - 1)][w][0][prow][pu];
-                    hz += red[step & (NB - 1)][w][1][prow][pu];
-                    hn += red[step & (NB - 1)][w][2][prow][pu];
-                }
-            }
-            const GateFwd c = gru_cell_fwd(xr, xz, xn, hr, hz, hn, hprev);
-            if (step + 1 < T) {                        // publish: the only store on the chain
-                const unsigned long long gq = ((unsigned long long)((unsigned)step + 1u) << 32) | __float_as_uint(pok ? (g.bf16 ? rbf(c.h) : c.h) : 0.f);
-                __hip_atomic_store(gran + (size_t)(step & 1) * slot + pub, gq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            M3T_STAMP(4);
-            hprev = c.h;
-            if (pok) {                                 // off the chain: results to HBM, next step's inputs from HBM
-                d.out[((size_t)pb * T + t) * d.ldo + d.ooff + pj] = c.h;
-                if (d.gates) {
-                    float* gp = d.gates + ((size_t)pb * T + t) * 4 * H;
-                    *reinterpret_cast<float4*>(gp + 4 * (size_t)pj) = make_float4(c.r, c.z, c.n, hn);
-                }
-                if (d.h_n && step == T - 1) d.h_n[(size_t)pb * H + pj] = c.h;
-                if (step + 1 < T) {
-                    xp += xstep;
-                    xr = xp[0]; xz = xp[H]; xn = xp[2 * H];
-                }
-            }
-        }
-        if (NB == 1) __syncthreads();
-        M3T_STAMP(5);
+    for (int step2 = 0; step2 < T; step2 += 2) {
+#define STEPV step2
+#define CUR(x) x##A
+#define NXT(x) x##B
+#include "gru_persist_fwd_step.inc"
+#undef STEPV
+#undef CUR
+#undef NXT
+        if (step2 + 1 >= T) break;
+#define STEPV (step2 + 1)
+#define CUR(x) x##B
+#define NXT(x) x##A
+#include "gru_persist_fwd_step.inc"
+#undef STEPV
+#undef CUR
+#undef NXT
     }
+#undef M3T_FWD_LOAD_X
     if (stamp)
         for (int i = 0; i < 6; ++i) ex.prof[i] = (unsigned long long)psum[i];
 }
