@@ -35,10 +35,28 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 struct ExPtrs {
     void* gran[M3T_MAX_SCANS];       // exchange granules: [2 slots][row block][unit block][RT*256]
     size_t slot[M3T_MAX_SCANS];      // granules per slot
+    int poll_fixed;                  // >= 0: fixed poll delay (x 64 cycles); < 0: adapted per workgroup
     unsigned long long* prof;        // optional in-kernel stamps (M3T_SCAN_PROF=1): 8 phase sums of workgroup 0, wave 0
 };
 
 // phase stamps: s_memtime deltas accumulated by one lane; a uniform scalar branch when profiling is off
+// Polling for the peers' granules.  A gather attempt is a full round trip (~1 us) and the next attempt is only issued
+// when it has returned, so an attempt that leaves just before the data becomes visible costs a whole extra round trip --
+// and the attempt issued right after a workgroup's own publish is always that attempt (the peers are still in their cell
+// phase).  Every wave therefore sleeps `poll_delay` x 64 cycles before its first attempt.  Measured with fixed delays
+// (M3T_SCAN_POLL_FWD6 / _FWD / _BWD = n, tools/scan_bench.py, H=512, three boxes): bf16x6 forward 3.1 -> 2.3 us per step
+// at 16-24 units; backward 4.8-5.1 -> 3.9-4.7 at 12-18 (the gain varies from box to box, it was never negative); fp32
+// forward 4.9 -> 4.2-4.4 at 12-18, nothing at H=128; all worse again beyond ~24.  Policy:
+//   * bf16x6 forward: adaptive, one delay per workgroup (the step ends when the slowest of the 8 waves has its data, so
+//     per-wave controllers that each sit at their own edge fail somewhere almost every step): a wave whose first attempt
+//     failed sets a flag in LDS, after the step's barrier every wave reads it and moves the common delay +2 on a failure,
+//     -1 every eighth step otherwise.  It finds the best fixed value (2.3 / 2.6 / 1.76 us at 2x512 / 4x512 / 2x256).
+//   * backward and fp32 forward: fixed (12 units; 0 for the fp32 forward at H=128).  The same controller over-sleeps
+//     them (5.1 us), as do its variants (per-wave; waves without cell math aligned to the workgroup's publish first; a
+//     hill-climb on the s_memtime of 8-step windows is too noisy within 300 steps) -- the failure flag does not say
+//     what a failure cost there.
+constexpr int POLL_DELAY_INIT = 8, POLL_DELAY_MAX = 64;
+
 #define M3T_STAMP(i)                                                         \
     do {                                                                     \
         if (stamp) { const long long now = clock64(); psum[i] += now - last; last = now; } \
@@ -93,6 +111,9 @@ __global__ __launch_bounds__(NT) void gru_persist_fwd_kernel(FwdGroup g, FragPtr
     const size_t grp = (size_t)rb * nch * TILE;
     const size_t pub = grp + (size_t)ub * TILE + tid;
     bool dead = false;
+    int poll_delay = ex.poll_fixed >= 0 ? ex.poll_fixed : POLL_DELAY_INIT;
+    __shared__ unsigned poll_fail[2];                  // by step parity
+    if (tid < 2) poll_fail[tid] = 0;                   // first read after the first barrier
     const bool stamp = ex.prof != nullptr && blockIdx.x == 0 && tid == 0;
     long long psum[6] = {0, 0, 0, 0, 0, 0}, last = stamp ? clock64() : 0;
 
@@ -219,6 +240,9 @@ __global__ __launch_bounds__(NT) void gru_persist_fwd6_kernel(FwdGroup g, FragPt
     const int q = lane >> 4;
     const size_t lane_off = (size_t)(wave + NW * (q >> 1)) * TILE + 2 * ((q & 1) * 16 + (lane & 15));
     bool dead = false;
+    int poll_delay = ex.poll_fixed >= 0 ? ex.poll_fixed : POLL_DELAY_INIT;
+    __shared__ unsigned poll_fail[2];                  // by step parity
+    if (tid < 2) poll_fail[tid] = 0;                   // first read after the first barrier
     const bool stamp = ex.prof != nullptr && blockIdx.x == 0 && tid == 0;
     long long psum[6] = {0, 0, 0, 0, 0, 0}, last = stamp ? clock64() : 0;
 
@@ -300,6 +324,9 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd_kernel(BwdGroup g, FragPtr
     const size_t grp = (size_t)rb * nchh * TILE;
     const size_t pub = grp + (size_t)ub * TILE + tid;
     bool dead = false;
+    int poll_delay = ex.poll_fixed >= 0 ? ex.poll_fixed : POLL_DELAY_INIT;
+    __shared__ unsigned poll_fail[2];                  // by step parity
+    if (tid < 2) poll_fail[tid] = 0;                   // first read after the first barrier
     const bool stamp = ex.prof != nullptr && blockIdx.x == 0 && tid == 0;
     long long psum[6] = {0, 0, 0, 0, 0, 0}, last = stamp ? clock64() : 0;
 
@@ -447,6 +474,12 @@ BwdKernel pick_bwd(const Shape& sh) {
     return k[sh.rt - 1][sh.nc - 1];
 }
 
+// M3T_SCAN_POLL_<kind>=n: fixed poll delay for the kernels of that kind (FWD6, FWD, BWD), default per-kind policy below
+static int poll_env(const char* name, int dflt) {
+    const char* e = std::getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
 template <typename G>
 void fill_exchange(const G& g, const FragPtrs& fp, const Shape& sh, size_t gran_bytes, ExPtrs& ex, size_t (&bytes)[M3T_MAX_SCANS]) {
     std::memset(&ex, 0, sizeof(ex));
@@ -457,6 +490,7 @@ void fill_exchange(const G& g, const FragPtrs& fp, const Shape& sh, size_t gran_
         if (prof_on && hipMalloc(reinterpret_cast<void**>(&g_prof), 64) != hipSuccess) { (void)hipGetLastError(); g_prof = nullptr; }
     }
     ex.prof = g_prof;
+    ex.poll_fixed = -1;
     for (int i = 0; i < g.n; ++i) {
         ex.gran[i] = fp.xfrag[i];
         ex.slot[i] = (size_t)sh.nrb * (g.d[i].H / 16) * sh.rt * 256;
@@ -519,6 +553,10 @@ int persist_fwd_launch(const FwdGroup& g, const FragPtrs& fp, int B, int T, int 
     ExPtrs ex;
     size_t bytes[M3T_MAX_SCANS];
     fill_exchange(g, fp, sh, 8, ex, bytes);
+    {
+        static const int p6 = poll_env("M3T_SCAN_POLL_FWD6", -1), p32 = poll_env("M3T_SCAN_POLL_FWD", -2);
+        ex.poll_fixed = persist_fwd_uses_x6(g, B, T, flags) ? p6 : (p32 != -2 ? p32 : (sh.nc == 1 ? 0 : 12));
+    }
     for (int i = 0; i < g.n; ++i) {
         const hipError_t e = hipMemsetAsync(ex.gran[i], 0, bytes[i], s);     // no stale tag may match
         if (e != hipSuccess) return (int)e;
@@ -551,6 +589,10 @@ int persist_bwd_launch(const BwdGroup& g, const FragPtrs& fp, int B, int T, hipS
     ExPtrs ex;
     size_t bytes[M3T_MAX_SCANS];
     fill_exchange(g, fp, sh, 16, ex, bytes);
+    {
+        static const int pb = poll_env("M3T_SCAN_POLL_BWD", 12);
+        ex.poll_fixed = pb;
+    }
     for (int i = 0; i < g.n; ++i) {
         const hipError_t e = hipMemsetAsync(ex.gran[i], 0, bytes[i], s);
         if (e != hipSuccess) return (int)e;
