@@ -18,6 +18,41 @@ _WS_MIN = 64 << 20
 # Optional launch-stream timing (bench.py): when PROFILE_ON[0] is set, every scan / GEMM call is
 # bracketed by HIP events on the stream the kernels are launched on.
 PROFILE = []
+
+# ---- gradient sinks: where a parameter's gradient lives (a view of the flat gradient buffer of m3t.ddp.FlatGradDDP).
+# A backward that finds a sink for a parameter writes the gradient THERE and returns None for it, so autograd launches no
+# AccumulateGrad add (48 small kernels per C3 step).  Only the first gradient of a parameter per step goes this way (a
+# second use of the same parameter falls back to a returned tensor, which autograd adds onto it); a sink is only used
+# while the registered parameter object is alive and its .grad still IS the registered view (someone who resets the
+# grads to None gets the ordinary path).  Armed per step by FlatGradDDP.zero_grad(), after it has zeroed the buffer.
+import weakref
+
+_GRAD_SINKS = {}            # id(parameter) -> [weakref(parameter), view, armed]
+
+
+def register_grad_sink(param, view):
+    _GRAD_SINKS[id(param)] = [weakref.ref(param), view, False]
+
+
+def clear_grad_sinks():
+    _GRAD_SINKS.clear()
+
+
+def arm_grad_sinks():
+    for e in _GRAD_SINKS.values():
+        e[2] = True
+
+
+def _take_sink(param):
+    """the sink view for the parameter object `param` if this is its first gradient of the step, else None"""
+    e = _GRAD_SINKS.get(id(param))
+    if e is None or not e[2]:
+        return None
+    ref = e[0]()
+    if ref is not param or param.grad is None or param.grad.data_ptr() != e[1].data_ptr() or param.grad.shape != param.shape:
+        return None
+    e[2] = False
+    return e[1]
 PROFILE_ON = [False]
 PROFILE_GEMM = [False]      # ~90 extra event pairs per step: off unless asked for
 
@@ -212,6 +247,8 @@ class _Linear(torch.autograd.Function):
         sgemm(0, 1, M, N, K, x, 0, K, w, 0, K, y, 0, N, bias=b, act=act, prec=ctx.prec, exclusive=True)
         ctx.save_for_backward(x, w, y if act else None)
         ctx.act, ctx.has_bias = act, b is not None
+        ctx.bias_ref = b if (b is not None and id(b) in _GRAD_SINKS) else None
+        ctx.weight_ref = w if id(w) in _GRAD_SINKS else None
         return y
 
     @staticmethod
@@ -227,11 +264,17 @@ class _Linear(torch.autograd.Function):
             dx = torch.empty_like(x)
             sgemm(0, 0, M, K, N, dy, 0, N, w, 0, K, dx, 0, K, prec=ctx.prec, exclusive=True)
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(w)
+            sink = _take_sink(ctx.weight_ref) if ctx.weight_ref is not None else None
+            dw = sink if sink is not None else torch.empty_like(w)
             sgemm(1, 0, N, K, M, dy, 0, N, x, 0, K, dw, 0, K, prec=ctx.prec, exclusive=True)
+            if sink is not None:
+                dw = None                                  # written in place: nothing for autograd to accumulate
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = torch.empty(N, dtype=x.dtype, device=x.device)
+            sink = _take_sink(ctx.bias_ref) if ctx.bias_ref is not None else None
+            db = sink if sink is not None else torch.empty(N, dtype=x.dtype, device=x.device)
             colsum(dy, 0, M, N, N, db)
+            if sink is not None:
+                db = None
         return dx, dw, db, None
 
 
@@ -460,6 +503,7 @@ class _MultiBiGRU(torch.autograd.Function):
         dev = params[0][0].device
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
         out_grads = [None] * (n_stacks * per)
+        sunk = [False] * (n_stacks * per)
         douts, dhns = [], []
         for s in range(n_stacks):
             g, gh = grads[2 * s], grads[2 * s + 1]
@@ -479,8 +523,10 @@ class _MultiBiGRU(torch.autograd.Function):
                 for d in (0, 1):
                     w_ih, w_hh = params[s][(2 * l + d) * 4], params[s][(2 * l + d) * 4 + 1]
                     base = s * per + 1 + (2 * l + d) * 4
-                    out_grads[base:base + 4] = [torch.empty_like(w_ih), torch.empty_like(w_hh),
-                                                new(3 * Hs[s]), new(3 * Hs[s])]
+                    for j, prm in enumerate(params[s][(2 * l + d) * 4:(2 * l + d) * 4 + 4]):
+                        sink = _take_sink(prm)             # gradient written straight into the flat buffer
+                        out_grads[base + j] = sink if sink is not None else torch.empty_like(prm)
+                        sunk[base + j] = sink is not None
         main = torch.cuda.current_stream()
         groups = _stream_groups(Hs, B)
         cur = {s: douts[s] for s in range(n_stacks)}
@@ -590,7 +636,7 @@ class _MultiBiGRU(torch.autograd.Function):
             main.wait_stream(wg)
         for s in range(n_stacks):
             out_grads[s * per] = dinp[0][s]
-        return (None, None) + tuple(out_grads)
+        return (None, None) + tuple(None if sunk[i] else g for i, g in enumerate(out_grads))
 
 
 def multi_bigru(stacks):

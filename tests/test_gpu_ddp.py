@@ -36,6 +36,52 @@ def test_flat_ddp_single_gpu_matches_plain_autograd():
         assert torch.allclose(p.grad, q.grad, atol=1e-7), n
 
 
+def test_gradient_sinks_match_autograd_accumulation():
+    """m3t.ops writes GRU / Linear weight gradients straight into FlatGradDDP's flat buffer (no AccumulateGrad kernels).
+    Same gradients as the ordinary path; a parameter used twice in one graph (second gradient must be ADDED), a
+    parameter nothing touches (must read zero, not last step's value), and grads reset to None by the user (sinks must
+    stand down) all behave."""
+    from m3t import ops
+    from m3t.ddp import FlatGradDDP
+    from models.rnn import GRU
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.gru = GRU(12, 16, 2, 3, 2)
+            self.unused = torch.nn.Parameter(torch.ones(5))
+
+        def forward(self, x):
+            return self.gru(x) + 0.5 * self.gru(x.flip(1))          # every parameter of the GRU is used twice
+
+    torch.manual_seed(3)
+    a, b = Net().to("cuda:0"), Net().to("cuda:0")
+    b.load_state_dict(a.state_dict())
+    x = torch.randn(4, 9, 12, device="cuda:0")
+    ddp = FlatGradDDP(a, max_norm=0.0)
+    assert ddp.sinks and len(ops._GRAD_SINKS) == len(list(a.parameters()))
+    for _ in range(3):                                               # stale values of earlier steps must not leak
+        ddp.zero_grad()
+        a(x).square().mean().backward()
+        ddp.finish()
+    assert not any(e[2] for k, e in ops._GRAD_SINKS.items() if e[0]() is not a.unused), "a GRU sink was not used"
+    b(x).square().mean().backward()
+    for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        if q.grad is None:
+            assert float(p.grad.abs().max()) == 0.0, n
+        else:
+            assert torch.allclose(p.grad, q.grad, atol=1e-7), n
+    # the user drops the flat views: the sinks stand down and autograd allocates ordinary grads
+    for p in a.parameters():
+        p.grad = None
+    ops.arm_grad_sinks()
+    a(x).square().mean().backward()
+    for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        if q.grad is not None:
+            assert p.grad is not None and torch.allclose(p.grad, q.grad, atol=1e-7), n
+    ops.clear_grad_sinks()
+
+
 def test_bench_two_ranks_on_one_gpu_gloo():
     """The N>1 bench path (torchrun launch, flat-buffer bucketed all-reduce, barrier/max timing, rank-0 JSON)
     on the single GPU of the test box: both ranks on cuda:0, gloo instead of RCCL."""
