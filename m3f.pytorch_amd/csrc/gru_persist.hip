@@ -36,6 +36,7 @@ struct ExPtrs {
     void* gran[M3T_MAX_SCANS];       // exchange granules: [2 slots][row block][unit block][RT*256]
     size_t slot[M3T_MAX_SCANS];      // granules per slot
     int poll_fixed;                  // >= 0: fixed poll delay (x 64 cycles); < 0: adapted per workgroup
+    int poll_align;                  // 1: waves without cell math count the delay from the workgroup's publish
     unsigned long long* prof;        // optional in-kernel stamps (M3T_SCAN_PROF=1): 8 phase sums of workgroup 0, wave 0
 };
 
@@ -51,7 +52,12 @@ struct ExPtrs {
 //     per-wave controllers that each sit at their own edge fail somewhere almost every step): a wave whose first attempt
 //     failed sets a flag in LDS, after the step's barrier every wave reads it and moves the common delay +2 on a failure,
 //     -1 every eighth step otherwise.  It finds the best fixed value (2.3 / 2.6 / 1.76 us at 2x512 / 4x512 / 2x256).
-//   * backward and fp32 forward: fixed (12 units; 0 for the fp32 forward at H=128).  The same controller over-sleeps
+//   * backward and fp32 forward: fixed (12 units; 0 for the fp32 forward at H=128); in the backward scan the four waves
+//     that do no cell math arrive at the gather a cell phase early, and their first attempt then fails and their second
+//     returns after the cell-math waves' well-timed first one (in-kernel stamps: the cell-math waves waited 0.84 us at
+//     the step's barrier): they first wait in LDS for thread 0's "published" mark, so every wave counts the delay from
+//     the workgroup's own publish (M3T_SCAN_POLL_ALIGN; backward 4.7 -> 4.2 us per step on the boxes where it was not
+//     already there; no gain for the adaptive bf16x6 forward, which finds a delay that suits its early waves).  The same controller over-sleeps
 //     them (5.1 us), as do its variants (per-wave; waves without cell math aligned to the workgroup's publish first; a
 //     hill-climb on the s_memtime of 8-step windows is too noisy within 300 steps) -- the failure flag does not say
 //     what a failure cost there.
@@ -113,6 +119,8 @@ __global__ __launch_bounds__(NT) void gru_persist_fwd_kernel(FwdGroup g, FragPtr
     bool dead = false;
     int poll_delay = ex.poll_fixed >= 0 ? ex.poll_fixed : POLL_DELAY_INIT;
     __shared__ unsigned poll_fail[2];                  // by step parity
+    __shared__ int pub_step;                           // steps this workgroup has published (thread 0)
+    if (tid == 0) pub_step = 0;
     if (tid < 2) poll_fail[tid] = 0;                   // first read after the first barrier
     const bool stamp = ex.prof != nullptr && blockIdx.x == 0 && tid == 0;
     long long psum[6] = {0, 0, 0, 0, 0, 0}, last = stamp ? clock64() : 0;
@@ -242,6 +250,8 @@ __global__ __launch_bounds__(NT) void gru_persist_fwd6_kernel(FwdGroup g, FragPt
     bool dead = false;
     int poll_delay = ex.poll_fixed >= 0 ? ex.poll_fixed : POLL_DELAY_INIT;
     __shared__ unsigned poll_fail[2];                  // by step parity
+    __shared__ int pub_step;                           // steps this workgroup has published (thread 0)
+    if (tid == 0) pub_step = 0;
     if (tid < 2) poll_fail[tid] = 0;                   // first read after the first barrier
     const bool stamp = ex.prof != nullptr && blockIdx.x == 0 && tid == 0;
     long long psum[6] = {0, 0, 0, 0, 0, 0}, last = stamp ? clock64() : 0;
@@ -326,6 +336,8 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd_kernel(BwdGroup g, FragPtr
     bool dead = false;
     int poll_delay = ex.poll_fixed >= 0 ? ex.poll_fixed : POLL_DELAY_INIT;
     __shared__ unsigned poll_fail[2];                  // by step parity
+    __shared__ int pub_step;                           // steps this workgroup has published (thread 0)
+    if (tid == 0) pub_step = 0;
     if (tid < 2) poll_fail[tid] = 0;                   // first read after the first barrier
     const bool stamp = ex.prof != nullptr && blockIdx.x == 0 && tid == 0;
     long long psum[6] = {0, 0, 0, 0, 0, 0}, last = stamp ? clock64() : 0;
@@ -491,6 +503,7 @@ void fill_exchange(const G& g, const FragPtrs& fp, const Shape& sh, size_t gran_
     }
     ex.prof = g_prof;
     ex.poll_fixed = -1;
+    ex.poll_align = 0;
     for (int i = 0; i < g.n; ++i) {
         ex.gran[i] = fp.xfrag[i];
         ex.slot[i] = (size_t)sh.nrb * (g.d[i].H / 16) * sh.rt * 256;
@@ -556,6 +569,8 @@ int persist_fwd_launch(const FwdGroup& g, const FragPtrs& fp, int B, int T, int 
     {
         static const int p6 = poll_env("M3T_SCAN_POLL_FWD6", -1), p32 = poll_env("M3T_SCAN_POLL_FWD", -2);
         ex.poll_fixed = persist_fwd_uses_x6(g, B, T, flags) ? p6 : (p32 != -2 ? p32 : (sh.nc == 1 ? 0 : 12));
+        static const int al = poll_env("M3T_SCAN_POLL_ALIGN", 6);     // bit 0: bf16x6 forward, 1: fp32 forward, 2: backward
+        ex.poll_align = persist_fwd_uses_x6(g, B, T, flags) ? (al & 1) : ((al >> 1) & 1);
     }
     for (int i = 0; i < g.n; ++i) {
         const hipError_t e = hipMemsetAsync(ex.gran[i], 0, bytes[i], s);     // no stale tag may match
@@ -590,8 +605,9 @@ int persist_bwd_launch(const BwdGroup& g, const FragPtrs& fp, int B, int T, hipS
     size_t bytes[M3T_MAX_SCANS];
     fill_exchange(g, fp, sh, 16, ex, bytes);
     {
-        static const int pb = poll_env("M3T_SCAN_POLL_BWD", 12);
+        static const int pb = poll_env("M3T_SCAN_POLL_BWD", 12), al = poll_env("M3T_SCAN_POLL_ALIGN", 6);
         ex.poll_fixed = pb;
+        ex.poll_align = (al >> 2) & 1;
     }
     for (int i = 0; i < g.n; ++i) {
         const hipError_t e = hipMemsetAsync(ex.gran[i], 0, bytes[i], s);
