@@ -185,7 +185,7 @@ typedef __bf16 pbf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned pu32x4 __attribute__((ext_vector_type(4)));
 
 // wfrag6[ub][wave][s][ct][t][lane][8 bf16]: split t of W_hh[ct*H + ub*16 + (lane&15)][unit(wave, s, lane>>4, e)]
-__global__ void wfrag6_prep_kernel(const float* __restrict__ w_hh, unsigned short* __restrict__ wf, int H) {
+__global__ void wfrag6_prep_kernel(const float* __restrict__ w_hh, unsigned short* __restrict__ wf, int H, int bf16) {
     const int nch = H >> 4, ks = nch >> 4;            // ks = k-steps per wave = NC / 2
     const size_t total = (size_t)3 * H * H;           // one thread per weight: writes its three terms
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -196,7 +196,8 @@ __global__ void wfrag6_prep_kernel(const float* __restrict__ w_hh, unsigned shor
         const int w = r % NW, ub = r / NW;
         const int q = l >> 4;
         const int unit = 16 * (w + NW * (2 * s + (q >> 1))) + 8 * (q & 1) + e;
-        const float x = w_hh[((size_t)ct * H + ub * 16 + (l & 15)) * H + unit];
+        float x = w_hh[((size_t)ct * H + ub * 16 + (l & 15)) * H + unit];
+        if (bf16) x = rbf(x);                         // mixed-precision mode: the operand IS its first term, the other two are zero
         const __bf16 b1 = (__bf16)x;
         const float r1 = x - (float)b1;
         const __bf16 b2 = (__bf16)r1;
@@ -544,7 +545,9 @@ static bool x6_scan_enabled() {
 // the forward recurrent product runs as bf16x6 (gru_persist_fwd6_kernel) for H = 256 / 512 at 16 rows per workgroup
 bool persist_fwd_uses_x6(const FwdGroup& g, int B, int T, int flags) {
     Shape sh;
-    if ((flags & M3T_SCAN_FP32) || g.bf16 || !x6_scan_enabled() || T >= 65535 || !level_shape(g.d, g.n, B, sh)) return false;
+    // (in the bf16 mode the same kernel runs on operands that ARE bf16: h and W_hh are rounded first, their second and
+    // third terms are zero, and what is left of the six products is the one bf16 product with fp32 accumulation)
+    if ((flags & M3T_SCAN_FP32) || !x6_scan_enabled() || T >= 65535 || !level_shape(g.d, g.n, B, sh)) return false;
     return sh.rt == 1 && (sh.nc == 2 || sh.nc == 4);
 }
 
@@ -584,7 +587,7 @@ int persist_fwd_launch(const FwdGroup& g, const FragPtrs& fp, int B, int T, int 
             const int H = g.d[i].H;
             int blk = (3 * H * H + 255) / 256;
             if (blk > 1024) blk = 1024;
-            wfrag6_prep_kernel<<<blk, 256, 0, s>>>(g.d[i].w_hh, reinterpret_cast<unsigned short*>(fp.wfrag[i]), H);
+            wfrag6_prep_kernel<<<blk, 256, 0, s>>>(g.d[i].w_hh, reinterpret_cast<unsigned short*>(fp.wfrag[i]), H, g.bf16);
         }
         M3T_LAUNCH_CHECK();
         { const int e = persist_take_after(s); if (e) return e; }

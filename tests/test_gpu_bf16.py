@@ -76,15 +76,21 @@ def test_gru_bf16_vs_emulating_oracle(B, T, I, H, L, tol):
 
 
 def test_gru_bf16_persistent_equals_per_step():
-    """in bf16 mode too, the persistent scan reproduces the launch-per-step kernels bit for bit (long, wide scan)"""
+    """in bf16 mode too, the persistent scan on fp32 MFMAs (SCAN_FP32) reproduces the launch-per-step kernels bit for bit
+    (long, wide scan); the default persistent forward scan runs the same bf16 product on the bf16 matrix pipe (one term of
+    the bf16x6 kernel) and differs only by fp32 accumulation order, i.e. by occasional bf16 rounding flips downstream"""
     from models.rnn import GRU
     from m3t import ops
     rs = np.random.RandomState(3)
     m = fill_module(GRU(16, 256, 2, 3, 2), 92).to(DEV)
     xn, ct = draw(rs, (32, 40, 16)), draw(rs, (32, 40, 3))
+    x = dev(xn)
+    with torch.no_grad(), ops.precision("bf16"):
+        y_default = m(x)
     res = []
     for per_step in (False, True):
         ops.SCAN_PER_STEP[0] = per_step
+        ops.SCAN_FP32[0] = True
         try:
             m.zero_grad()
             x = dev(xn, True)
@@ -94,8 +100,10 @@ def test_gru_bf16_persistent_equals_per_step():
             res.append((y.detach().clone(), x.grad.clone(), [p.grad.clone() for p in m.parameters()]))
         finally:
             ops.SCAN_PER_STEP[0] = False
+            ops.SCAN_FP32[0] = False
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     assert all(torch.equal(a, b) for a, b in zip(res[0][2], res[1][2]))
+    close(y_default, res[0][0].cpu().numpy(), 5e-3, "bf16x1 forward scan vs fp32-MFMA forward scan (bf16 mode)")
 
 
 def test_tcn_bf16_vs_emulating_oracle():
