@@ -759,14 +759,14 @@ static int scan_bwd_impl(const m3t_gru_bwd_desc* scans, int n_scans, int B, int 
         }
         for (int i = n_scans; i <= M3T_MAX_SCANS; ++i) bg.blk_start[i] = nblk;
         if (!(flags & M3T_SCAN_NO_PERSIST) && persist_bwd_check(bg, B, T)) {
-            for (int i = 0; i < n_scans; ++i) {
+            for (int i = 0; i < n_scans && !persist_bwd_uses_16(bg, B, T, flags); ++i) {
                 const int H = bg.d[i].H;
                 int blk = (3 * H * H + 255) / 256;
                 if (blk > 1024) blk = 1024;
                 wfrag_bwd_prep_kernel<<<blk, 256, 0, s>>>(bg.d[i].w_hh_t, fp.wfrag[i], H, bg.bf16);
             }
             M3T_LAUNCH_CHECK();
-            return persist_bwd_launch(bg, fp, B, T, s);
+            return persist_bwd_launch(bg, fp, B, T, flags, s);
         }
         { const int e = persist_take_after(s); if (e) return e; }
         return replay_or_capture(make_key(2, bg, &fp, B, T, rt), s, [&]() {

@@ -299,6 +299,143 @@ __global__ __launch_bounds__(NT) void gru_persist_fwd6_kernel(FwdGroup g, FragPt
         for (int i = 0; i < 6; ++i) ex.prof[i] = (unsigned long long)psum[i];
 }
 
+// ------------------------------------------------------------------------------------------------ backward, bf16 mode
+// M3T_BF16: every operand of the recurrent product is bf16 by definition of the mode, so the exchange shrinks to the
+// forward scan's -- an 8-byte granule {bf16 dr, bf16 dz, bf16 dn*r, tag16} in the forward kernel's tile order, 8 instead of
+// 16 gather loads per lane -- and the product runs on the bf16 matrix pipe: per k-step of 32 units three
+// v_mfma_f32_16x16x32_bf16 (one per gate; 6 per wave at H = 512 instead of 48 fp32 MFMAs), fp32 accumulate.  Same values
+// as the fp32-MFMA kernel on rounded operands up to accumulation order (M3T_SCAN_FP32 keeps that kernel and bit-identity
+// with the launch-per-step path).  Everything else -- cell math, bias sums, prefetch, poll delay -- is the kernel below.
+__global__ void wfrag_bwd16_prep_kernel(const float* __restrict__ w_hh_t, unsigned short* __restrict__ wf, int H) {
+    const int ks = H >> 8;                            // k-steps per wave = NC / 2
+    const size_t total = (size_t)3 * H * H;           // [ub][wave][k-step][gate][lane][8]
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int e = i & 7, l = (i >> 3) & 63;
+        size_t r = i >> 9;
+        const int gt = r % 3; r /= 3;
+        const int sk = r % ks; r /= ks;
+        const int w = r % NW, ub = r / NW;
+        const int q = l >> 4;
+        const int unit = 16 * (w + NW * (2 * sk + (q >> 1))) + 8 * (q & 1) + e;       // the forward kernel's k order
+        const float x = rbf(w_hh_t[((size_t)ub * 16 + (l & 15)) * 3 * H + (size_t)gt * H + unit]);
+        wf[i] = (unsigned short)(__float_as_uint(x) >> 16);
+    }
+}
+
+template <int NC>
+__global__ __launch_bounds__(NT) void gru_persist_bwd16_kernel(BwdGroup g, FragPtrs fp, ExPtrs ex, int B, int T, int G, int nrb,
+                                                             unsigned* err) {
+    constexpr int ROWS = 16, RT = 1, KS = NC / 2;
+    constexpr int H = 128 * NC, H3 = 3 * H, nchh = H >> 4;
+    __shared__ float red[2][NW][ROWS][UB + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gid = (int)blockIdx.x % G, ub = (int)blockIdx.x / G;
+    const int s = gid / nrb, rb = gid % nrb;
+    const m3t_gru_bwd_desc d = g.d[s];
+    const int j0 = ub * UB, r0 = rb * ROWS;
+
+    pbf16x8 wb[KS][3];                                 // [k-step][gate]: W_hh rows (gate, 32 units of the k-step) x this workgroup's 16 units
+    {
+        const pu32x4* Wf = reinterpret_cast<const pu32x4*>(fp.wfrag[s]) + ((size_t)(ub * NW + wave) * KS * 3) * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < KS; ++k)
+#pragma unroll
+            for (int gt = 0; gt < 3; ++gt) wb[k][gt] = __builtin_bit_cast(pbf16x8, Wf[(k * 3 + gt) * 64]);
+    }
+    const bool pw = tid < ROWS * UB;                   // granule order of the bf16x6 forward kernel: granule tid = jp*64 + hr*2 + jlo
+    const int prow = (tid >> 1) & 15, pu = ((tid >> 5) & 1) * 8 + 2 * ((tid >> 6) & 3) + (tid & 1);
+    const int pb = r0 + prow, pj = j0 + pu;
+    const bool pok = pw && pb < B;
+    float dh_carry = 0.f, z_next = 0.f;                // dh_{t+1} and z_{t+1} of this thread's (row, unit)
+    float sb_r = 0.f, sb_z = 0.f, sb_n = 0.f, sb_nr = 0.f;   // sums over t of the gate gradients: the bias gradients of this clip
+    if (pok && d.dh_n) dh_carry = d.dh_n[(size_t)pb * H + pj];
+
+    constexpr size_t TILE = (size_t)RT * 256;
+    unsigned long long* gran = reinterpret_cast<unsigned long long*>(ex.gran[s]);
+    const int q = lane >> 4;
+    const size_t lane_off = (size_t)(wave + NW * (q >> 1)) * TILE + 2 * ((q & 1) * 16 + (lane & 15));
+    const size_t slot = ex.slot[s];
+    const size_t grp = (size_t)rb * nchh * TILE;
+    const size_t pub = grp + (size_t)ub * TILE + tid;
+    bool dead = false;
+    int poll_delay = ex.poll_fixed >= 0 ? ex.poll_fixed : POLL_DELAY_INIT;
+    __shared__ unsigned poll_fail[2];                  // by step parity
+    __shared__ int pub_step;                           // steps this workgroup has published (thread 0)
+    if (tid == 0) pub_step = 0;
+    if (tid < 2) poll_fail[tid] = 0;                   // first read after the first barrier
+    const bool stamp = ex.prof != nullptr && blockIdx.x == 0 && tid == 0;
+    long long psum[6] = {0, 0, 0, 0, 0, 0}, last = stamp ? clock64() : 0;
+
+    // HBM traffic of a step and the chain.  Vector-memory operations retire in order, so everything a wave has issued
+    // before its gather loads sits in front of the gather's vmcnt(0): with the step's six result stores and the next
+    // step's three activation loads issued after the publish (the natural place), every step waited ~0.7 us for each
+    // group (tools/scan_bench.py ablation), and hipcc added a vmcnt(0) + register copies at the bottom of the step on
+    // top (2.4 of 5 us, in-kernel stamps).  Now: the results of step t are kept in registers and stored, and the
+    // activations of step t+1 are requested, right AFTER the gather of step t has completed -- they have the whole
+    // step (MFMAs, barrier, cell math, publish, the peers' latency) to retire before the next gather waits, and between
+    // the publish and the next gather a wave has nothing outstanding but the publish itself.  Two register sets (A for
+    // even steps, B for odd ones; the loop body is included twice) hold the activations; the loads are inline asm,
+    // UNCONDITIONAL (every thread, every step; lanes past the batch and the step past the end re-read a valid address):
+    // compiler-visible or conditional definitions make hipcc wait for them or merge them with copies that read
+    // registers still in flight.  A set is defined by the vmcnt(0) of the gather that precedes its use and laundered there.
+    float doutA, hprevA, doutB, hprevB;
+    f32x4 g4A, g4B;                                    // (r, z, n, W_hn h + b_hn) of this (row, unit, t)
+    const int pbc = pb < B ? pb : B - 1;
+    const float* pd0 = d.dout + (size_t)pbc * T * d.ldo + d.ooff + pj;
+    const float* pg0 = d.gates + (size_t)pbc * T * 4 * H + 4 * (size_t)pj;
+    const float* ph0 = d.out + (size_t)pbc * T * d.ldo + d.ooff + pj;
+#define M3T_BWD_LOAD_STEP(step_, DOUT, G4, HPREV)                                                                     \
+    do {                                                                                                               \
+        const int ls_ = (step_) < T ? (step_) : T - 1;                                                                 \
+        const int lt_ = d.reverse ? ls_ : T - 1 - ls_;                                                                 \
+        const int ltp_ = ls_ < T - 1 ? (d.reverse ? lt_ + 1 : lt_ - 1) : lt_;                                          \
+        asm volatile("global_load_dword %0, %3, off\n\t"                                                               \
+                     "global_load_dwordx4 %1, %4, off\n\t"                                                             \
+                     "global_load_dword %2, %5, off"                                                                   \
+                     : "=&v"(DOUT), "=&v"(G4), "=&v"(HPREV)                                                            \
+                     : "v"(pd0 + (size_t)lt_ * d.ldo), "v"(pg0 + (size_t)lt_ * 4 * H), "v"(ph0 + (size_t)ltp_ * d.ldo)  \
+                     : "memory");                                                                                      \
+    } while (0)
+    M3T_BWD_LOAD_STEP(0, doutA, g4A, hprevA);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(doutA), "+v"(g4A), "+v"(hprevA) :: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0), visible to hipcc: no wait for the weight fragments inside the loop
+    float st_dr = 0.f, st_dz = 0.f, st_dn = 0.f, st_dnr = 0.f;     // results of the previous step, stored after this step's gather
+    auto store_results = [&](int step_of) {
+        const int t = d.reverse ? step_of : T - 1 - step_of;
+        float* gx = d.dgx + ((size_t)pb * T + t) * d.ldg + d.goff;
+        gx[pj] = st_dr; gx[H + pj] = st_dz; gx[2 * H + pj] = st_dn;
+        float* gh = d.dgh + ((size_t)pb * T + t) * H3;
+        gh[pj] = st_dr; gh[H + pj] = st_dz; gh[2 * H + pj] = st_dnr;
+    };
+
+    for (int step2 = 0; step2 < T; step2 += 2) {
+#define STEPV step2
+#define CUR(x) x##A
+#define NXT(x) x##B
+#include "gru_persist_bwd16_step.inc"
+#undef STEPV
+#undef CUR
+#undef NXT
+        if (step2 + 1 >= T) break;
+#define STEPV (step2 + 1)
+#define CUR(x) x##B
+#define NXT(x) x##A
+#include "gru_persist_bwd16_step.inc"
+#undef STEPV
+#undef CUR
+#undef NXT
+    }
+#undef M3T_BWD_LOAD_STEP
+    if (pok) d.dh[(size_t)pb * H + pj] = dh_carry;
+    if (pok && d.db_part) {
+        float* q = d.db_part + (size_t)pb * 4 * H + pj;
+        q[0] = sb_r; q[H] = sb_z; q[2 * H] = sb_n; q[3 * H] = sb_nr;
+    }
+    if (stamp)
+        for (int i = 0; i < 6; ++i) ex.prof[i] = (unsigned long long)psum[i];
+}
+
+
 // ------------------------------------------------------------------------------------------------ backward
 template <int NC, int RT>
 __global__ __launch_bounds__(NT) void gru_persist_bwd_kernel(BwdGroup g, FragPtrs fp, ExPtrs ex, int B, int T, int G, int nrb,
@@ -563,6 +700,14 @@ bool persist_bwd_check(const BwdGroup& g, int B, int T) {
            sh.grid <= resident_capacity(pick_bwd(sh));
 }
 
+// the backward scan of the bf16 mode runs on the bf16 matrix pipe with 8-byte granules (gru_persist_bwd16_kernel) for
+// H = 256 / 512 at 16 rows per workgroup; M3T_SCAN_FP32 keeps the fp32-MFMA kernel (bit-identical to the per-step path)
+bool persist_bwd_uses_16(const BwdGroup& g, int B, int T, int flags) {
+    Shape sh;
+    if (!g.bf16 || (flags & M3T_SCAN_FP32) || !x6_scan_enabled() || T >= 65535 || !level_shape(g.d, g.n, B, sh)) return false;
+    return sh.rt == 1 && (sh.nc == 2 || sh.nc == 4);
+}
+
 int persist_fwd_launch(const FwdGroup& g, const FragPtrs& fp, int B, int T, int flags, hipStream_t s) {
     Shape sh;
     if (!level_shape(g.d, g.n, B, sh) || !ensure_err_word()) return M3T_EINVAL;
@@ -601,12 +746,13 @@ int persist_fwd_launch(const FwdGroup& g, const FragPtrs& fp, int B, int T, int 
     return 0;
 }
 
-int persist_bwd_launch(const BwdGroup& g, const FragPtrs& fp, int B, int T, hipStream_t s) {
+int persist_bwd_launch(const BwdGroup& g, const FragPtrs& fp, int B, int T, int flags, hipStream_t s) {
     Shape sh;
     if (!level_shape(g.d, g.n, B, sh) || !ensure_err_word()) return M3T_EINVAL;
     ExPtrs ex;
     size_t bytes[M3T_MAX_SCANS];
-    fill_exchange(g, fp, sh, 16, ex, bytes);
+    const bool b16 = persist_bwd_uses_16(g, B, T, flags);
+    fill_exchange(g, fp, sh, b16 ? 8 : 16, ex, bytes);
     {
         static const int pb = poll_env("M3T_SCAN_POLL_BWD", 12), al = poll_env("M3T_SCAN_POLL_ALIGN", 6);
         ex.poll_fixed = pb;
@@ -617,6 +763,20 @@ int persist_bwd_launch(const BwdGroup& g, const FragPtrs& fp, int B, int T, hipS
         if (e != hipSuccess) return (int)e;
     }
     ++g_launches;
+    if (b16) {
+        for (int i = 0; i < g.n; ++i) {                                      // W_hh^T -> bf16 B-operand fragments
+            const int H = g.d[i].H;
+            int blk = (3 * H * H + 255) / 256;
+            if (blk > 1024) blk = 1024;
+            wfrag_bwd16_prep_kernel<<<blk, 256, 0, s>>>(g.d[i].w_hh_t, reinterpret_cast<unsigned short*>(fp.wfrag[i]), H);
+        }
+        M3T_LAUNCH_CHECK();
+        { const int e = persist_take_after(s); if (e) return e; }
+        if (sh.nc == 2) hipLaunchKernelGGL(gru_persist_bwd16_kernel<2>, dim3(sh.grid), dim3(NT), 0, s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
+        else hipLaunchKernelGGL(gru_persist_bwd16_kernel<4>, dim3(sh.grid), dim3(NT), 0, s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
+        M3T_LAUNCH_CHECK();
+        return 0;
+    }
     { const int e = persist_take_after(s); if (e) return e; }
     hipLaunchKernelGGL(pick_bwd(sh), dim3(sh.grid), dim3(NT), 0, s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
     M3T_LAUNCH_CHECK();
