@@ -3,12 +3,13 @@ the C ABI (ctypes) and checks them against (a) golden vectors produced by the re
 itself (tests/golden) and (b) the numpy oracle on fresh seeded inputs.
 Tolerance: north_star demands VA outputs within 1e-4 (fp32) of the reference."""
 import argparse
+import os
 
 import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden
+from conftest import load_golden, ROOT
 from golden.recipe import (fill_module, fill_by_shapes, draw, grad_digest, c3_param_shapes)
 from oracle import m3t_oracle as O
 
@@ -685,3 +686,36 @@ def test_time_reversal_symmetry_of_bigru():
     x = torch.randn(3, 21, 16, device=DEV)
     ya, yb = a(x), b(x.flip(1).contiguous())
     assert torch.equal(ya[..., :32], yb.flip(1)[..., 32:]) and torch.equal(ya[..., 32:], yb.flip(1)[..., :32])
+
+
+def test_scan_results_do_not_depend_on_the_poll_policy():
+    """the sleep before a persistent scan's first gather attempt (adaptive / fixed / none, aligned or not) is timing only:
+    forward outputs and every gradient are bit-identical under all of them (the policy is read once per process, hence
+    the subprocesses)"""
+    import hashlib
+    import subprocess
+    import sys
+    code = r"""
+import sys, hashlib
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, torch
+from golden.recipe import fill_module, draw
+from models.rnn import GRU
+rs = np.random.RandomState(5)
+h = hashlib.sha256()
+for H in (128, 256):
+    m = fill_module(GRU(24, H, 2, 3, 2), 7).to("cuda:0")
+    x = torch.from_numpy(draw(rs, (20, 33, 24))).to("cuda:0").requires_grad_(True)
+    y = m(x)
+    (y * torch.from_numpy(draw(rs, (20, 33, 3))).to("cuda:0")).sum().backward()
+    for t in [y, x.grad] + [p.grad for p in m.parameters()]:
+        h.update(t.detach().cpu().numpy().tobytes())
+print("DIGEST", h.hexdigest())
+""" % (os.path.join(ROOT, "m3f.pytorch_amd"), os.path.join(ROOT, "tests"), ROOT)
+    digests = []
+    for extra in ({}, {"M3T_SCAN_POLL_FWD6": "0", "M3T_SCAN_POLL_FWD": "5", "M3T_SCAN_POLL_BWD": "0", "M3T_SCAN_POLL_ALIGN": "0"},
+                  {"M3T_SCAN_POLL_FWD6": "20", "M3T_SCAN_POLL_BWD": "-1", "M3T_SCAN_POLL_ALIGN": "7"}):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-1500:]
+        digests.append([l for l in out.stdout.splitlines() if l.startswith("DIGEST")][-1])
+    assert digests[0] == digests[1] == digests[2], digests
