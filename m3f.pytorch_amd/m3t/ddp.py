@@ -116,6 +116,8 @@ class FlatGradDDP:
 
     def finish(self):
         """Call after backward: waits for the bucket all-reduces, then averages + clips in place."""
+        from . import ops
+        ops.join_wgrad(self.flat.device)          # weight-gradient GEMMs that write straight into the flat buffer
         if self.world > 1 and not self.overlap:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.pg)
         elif self.world > 1:

@@ -137,6 +137,22 @@ def side_stream(device):
     return st
 
 
+_WGRAD_DEFER_JOIN = os.environ.get("M3T_WGRAD_DEFER_JOIN", "1") != "0"
+_LINEAR_OFF_CHAIN = os.environ.get("M3T_LINEAR_WGRAD", "1") != "0"
+_WGRAD_PENDING = {}
+
+
+def join_wgrad(device=None):
+    """make the current stream wait for weight-gradient GEMMs still running on their own stream (left unjoined by a GRU
+    backward whose gradients all went into gradient sinks); FlatGradDDP.finish() calls it before it touches the buffer"""
+    for key, pending in list(_WGRAD_PENDING.items()):
+        if pending and (device is None or key == (device.type, device.index)):
+            st = _WGRAD.get(key)
+            if st is not None:
+                torch.cuda.current_stream(torch.device(key[0], key[1])).wait_stream(st)
+            _WGRAD_PENDING[key] = False
+
+
 def wgrad_stream(device):
     key = (device.type, device.index)
     st = _WGRAD.get(key)
@@ -263,18 +279,36 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             sgemm(0, 0, M, K, N, dy, 0, N, w, 0, K, dx, 0, K, prec=ctx.prec, exclusive=True)
+        w_sink = _take_sink(ctx.weight_ref) if (ctx.needs_input_grad[1] and ctx.weight_ref is not None) else None
+        b_sink = _take_sink(ctx.bias_ref) if (ctx.has_bias and ctx.needs_input_grad[2] and ctx.bias_ref is not None) else None
+        # gradients that go straight into the flat buffer feed nothing on the chain: they run on the weight-gradient stream
+        # (joined by FlatGradDDP.finish(), see join_wgrad) beside whatever backward does next
+        off_chain = torch.cuda.stream(wgrad_stream(x.device)) if (_WGRAD_ENABLED and _WGRAD_DEFER_JOIN and _LINEAR_OFF_CHAIN and x.is_cuda) else None
+        if off_chain is not None and (w_sink is not None or b_sink is not None):
+            wg = wgrad_stream(x.device)
+            wg.wait_stream(torch.cuda.current_stream())
         if ctx.needs_input_grad[1]:
-            sink = _take_sink(ctx.weight_ref) if ctx.weight_ref is not None else None
-            dw = sink if sink is not None else torch.empty_like(w)
-            sgemm(1, 0, N, K, M, dy, 0, N, x, 0, K, dw, 0, K, prec=ctx.prec, exclusive=True)
-            if sink is not None:
-                dw = None                                  # written in place: nothing for autograd to accumulate
+            if w_sink is not None and off_chain is not None:
+                with off_chain:
+                    sgemm(1, 0, N, K, M, dy, 0, N, x, 0, K, w_sink, 0, K, prec=ctx.prec)
+            else:
+                dw = w_sink if w_sink is not None else torch.empty_like(w)
+                sgemm(1, 0, N, K, M, dy, 0, N, x, 0, K, dw, 0, K, prec=ctx.prec, exclusive=True)
+                if w_sink is not None:
+                    dw = None                              # written in place: nothing for autograd to accumulate
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            sink = _take_sink(ctx.bias_ref) if ctx.bias_ref is not None else None
-            db = sink if sink is not None else torch.empty(N, dtype=x.dtype, device=x.device)
-            colsum(dy, 0, M, N, N, db)
-            if sink is not None:
-                db = None
+            if b_sink is not None and off_chain is not None:
+                with off_chain:
+                    colsum(dy, 0, M, N, N, b_sink)
+            else:
+                db = b_sink if b_sink is not None else torch.empty(N, dtype=x.dtype, device=x.device)
+                colsum(dy, 0, M, N, N, db)
+                if b_sink is not None:
+                    db = None
+        if off_chain is not None and (w_sink is not None or b_sink is not None):
+            dy.record_stream(wg)
+            x.record_stream(wg)
+            _WGRAD_PENDING[(x.device.type, x.device.index)] = True
         return dx, dw, db, None
 
 
@@ -633,7 +667,18 @@ class _MultiBiGRU(torch.autograd.Function):
                 if kind == "side":
                     main.wait_stream(side_stream(dev))
         if wg is not None:
-            main.wait_stream(wg)
+            weights_sunk = all(sunk[s * per + 1 + (2 * l + d) * 4 + j] for s in range(n_stacks) for l in range(L) for d in (0, 1) for j in (0, 1))
+            if _WGRAD_DEFER_JOIN and weights_sunk:
+                # every weight gradient goes straight into the flat gradient buffer, which nobody reads before
+                # FlatGradDDP.finish(): leave the weight-gradient stream running (join_wgrad() there) instead of waiting
+                # for its tail here.  What it still reads must outlive this call on ITS stream.
+                for l in range(L):
+                    for s in range(n_stacks):
+                        for t in (dgx[l][s], dgh[l][s]) + tuple(layer_io(l, s)[:2]):
+                            t.record_stream(wg)
+                _WGRAD_PENDING[(dev.type, dev.index)] = True
+            else:
+                main.wait_stream(wg)
         for s in range(n_stacks):
             out_grads[s * per] = dinp[0][s]
         return (None, None) + tuple(None if sunk[i] else g for i, g in enumerate(out_grads))
