@@ -624,6 +624,31 @@ BwdKernel pick_bwd(const Shape& sh) {
     return k[sh.rt - 1][sh.nc - 1];
 }
 
+static int poll_env_early(const char* name, int dflt) {
+    const char* e = std::getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+// A scan launch that leaves most of the chip free (a light level: <= 96 workgroups) asks for enough unused dynamic LDS that
+// no GEMM workgroup fits beside one of its workgroups on a CU: co-resident GEMM waves take issue slots and LDS bandwidth
+// from a latency-bound scan (audio backward scan beside the weight-gradient GEMMs: 1.8 instead of 0.75 ms), and the
+// GEMMs have the other CUs.  M3T_SCAN_EXCLUSIVE_CU=0 turns it off.
+template <typename K>
+static size_t exclusive_lds(K kernel, int grid) {
+    static const int on = poll_env_early("M3T_SCAN_EXCLUSIVE_CU", 1);
+    if (!on || grid > 96) return 0;
+    hipFuncAttributes a;
+    if (hipFuncGetAttributes(&a, reinterpret_cast<const void*>(kernel)) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    const size_t want = (size_t)152 * 1024;
+    if (a.sharedSizeBytes >= want) return 0;
+    const size_t dyn = want - a.sharedSizeBytes;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return dyn;
+}
+
 // M3T_SCAN_POLL_<kind>=n: fixed poll delay for the kernels of that kind (FWD6, FWD, BWD), default per-kind policy below
 static int poll_env(const char* name, int dflt) {
     const char* e = std::getenv(name);
@@ -736,12 +761,12 @@ int persist_fwd_launch(const FwdGroup& g, const FragPtrs& fp, int B, int T, int 
         }
         M3T_LAUNCH_CHECK();
         { const int e = persist_take_after(s); if (e) return e; }
-        if (sh.nc == 2) hipLaunchKernelGGL(gru_persist_fwd6_kernel<2>, dim3(sh.grid), dim3(NT), 0, s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
-        else hipLaunchKernelGGL(gru_persist_fwd6_kernel<4>, dim3(sh.grid), dim3(NT), 0, s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
+        if (sh.nc == 2) hipLaunchKernelGGL(gru_persist_fwd6_kernel<2>, dim3(sh.grid), dim3(NT), exclusive_lds(gru_persist_fwd6_kernel<2>, sh.grid), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
+        else hipLaunchKernelGGL(gru_persist_fwd6_kernel<4>, dim3(sh.grid), dim3(NT), exclusive_lds(gru_persist_fwd6_kernel<4>, sh.grid), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
         M3T_LAUNCH_CHECK();
         return 0;
     }
-    hipLaunchKernelGGL(pick_fwd(sh), dim3(sh.grid), dim3(NT), 0, s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
+    hipLaunchKernelGGL(pick_fwd(sh), dim3(sh.grid), dim3(NT), exclusive_lds(pick_fwd(sh), sh.grid), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
     M3T_LAUNCH_CHECK();
     return 0;
 }
@@ -772,13 +797,13 @@ int persist_bwd_launch(const BwdGroup& g, const FragPtrs& fp, int B, int T, int 
         }
         M3T_LAUNCH_CHECK();
         { const int e = persist_take_after(s); if (e) return e; }
-        if (sh.nc == 2) hipLaunchKernelGGL(gru_persist_bwd16_kernel<2>, dim3(sh.grid), dim3(NT), 0, s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
-        else hipLaunchKernelGGL(gru_persist_bwd16_kernel<4>, dim3(sh.grid), dim3(NT), 0, s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
+        if (sh.nc == 2) hipLaunchKernelGGL(gru_persist_bwd16_kernel<2>, dim3(sh.grid), dim3(NT), exclusive_lds(gru_persist_bwd16_kernel<2>, sh.grid), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
+        else hipLaunchKernelGGL(gru_persist_bwd16_kernel<4>, dim3(sh.grid), dim3(NT), exclusive_lds(gru_persist_bwd16_kernel<4>, sh.grid), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
         M3T_LAUNCH_CHECK();
         return 0;
     }
     { const int e = persist_take_after(s); if (e) return e; }
-    hipLaunchKernelGGL(pick_bwd(sh), dim3(sh.grid), dim3(NT), 0, s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
+    hipLaunchKernelGGL(pick_bwd(sh), dim3(sh.grid), dim3(NT), exclusive_lds(pick_bwd(sh), sh.grid), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
     M3T_LAUNCH_CHECK();
     return 0;
 }
