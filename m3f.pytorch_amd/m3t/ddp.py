@@ -53,31 +53,40 @@ class FlatGradDDP:
             if rest:
                 bucket_order.append(rest)
         self.buckets = bucket_order
-        n = sum(p.numel() for b in self.buckets for p in b)
-        assert n == sum(p.numel() for p in params), "buckets must cover every trainable parameter exactly once"
+        assert sum(p.numel() for b in self.buckets for p in b) == sum(p.numel() for p in params), \
+            "buckets must cover every trainable parameter exactly once"
         dev = params[0].device
+        # every parameter's slice starts on a 128-byte boundary (a 9-element bias would otherwise misalign everything behind
+        # it: kernels that write gradients in place -- gradient sinks -- take their float4 paths only on aligned outputs);
+        # the padding stays zero, so norms and all-reduces are unaffected
+        pad = lambda k: (k + 31) // 32 * 32
+        self.offsets, off = {}, 0
+        for b in self.buckets:
+            for p in b:
+                self.offsets[id(p)] = off
+                off = pad(off + p.numel())
+        n = off
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.ranges, off = [], 0
+        self.ranges = []
         self._pending = []
         for bi, b in enumerate(self.buckets):
-            start = off
+            start = self.offsets[id(b[0])]
             for p in b:
-                p.grad = self.flat[off:off + p.numel()].view_as(p)
-                off += p.numel()
-            self.ranges.append((start, off))
+                o = self.offsets[id(p)]
+                p.grad = self.flat[o:o + p.numel()].view_as(p)
+            self.ranges.append((start, pad(self.offsets[id(b[-1])] + b[-1].numel())))
         # optionally the parameters themselves become views of one flat buffer (same order as the gradients),
         # so an optimizer step is ONE kernel over (flat_params, flat)
         self.flat_params = None
         if flatten_params:
-            self.flat_params = torch.empty(n, dtype=torch.float32, device=dev)
-            off = 0
+            self.flat_params = torch.zeros(n, dtype=torch.float32, device=dev)
             with torch.no_grad():
                 for b in self.buckets:
                     for p in b:
-                        view = self.flat_params[off:off + p.numel()].view_as(p)
+                        o = self.offsets[id(p)]
+                        view = self.flat_params[o:o + p.numel()].view_as(p)
                         view.copy_(p.data)
                         p.data = view
-                        off += p.numel()
         self._left = [0] * len(self.buckets)
         self._handles = []
         if self.world > 1:

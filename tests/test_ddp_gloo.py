@@ -55,7 +55,13 @@ def _worker(rank, world, port, max_norm, overlap, out_q):
     for p in net.parameters():              # .grad must still be views of the flat buffer
         assert p.grad.data_ptr() >= ddp.flat.data_ptr()
         assert p.grad.data_ptr() < ddp.flat.data_ptr() + ddp.flat.numel() * 4
-    out_q.put((rank, ddp.flat.tolist(), float(norm)))
+    packed = torch.cat([p.grad.reshape(-1) for b in ddp.buckets for p in b])      # the slices without their alignment padding
+    gap = torch.ones(ddp.flat.numel(), dtype=torch.bool)
+    for b in ddp.buckets:
+        for p in b:
+            gap[ddp.offsets[id(p)]:ddp.offsets[id(p)] + p.numel()] = False
+    assert not gap.any() or float(ddp.flat[gap].abs().max()) == 0.0                 # the alignment padding stays zero
+    out_q.put((rank, packed.tolist(), float(norm)))
     dist.barrier()
     dist.destroy_process_group()
 
