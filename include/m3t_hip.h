@@ -30,6 +30,8 @@ extern "C" {
 #define M3T_MAX_SCANS 8
 #define M3T_ESPIN 10002          /* a persistent scan gave up waiting for a peer workgroup (see m3t_gru_scan_fwd) */
 #define M3T_SCAN_NO_PERSIST 1    /* m3t_gru_scan_* flags: take the launch-per-step path */
+#define M3T_SCAN_WHH 8           /* m3t_gru_scan_bwd flags: every desc.w_hh_t points at the UNtransposed parameter w_hh [3H][H] (saves the caller
+                                  * a transpose per direction in front of the scan); needs H % 16 == 0 and the workspace, else M3T_EINVAL */
 #define M3T_SCAN_FP32 4          /* m3t_gru_scan_fwd flags: keep the recurrent product on fp32 MFMAs (bit-identical to the
                                   * launch-per-step kernels) instead of the fp32-accurate bf16x6 form */
 #define M3T_BF16 2               /* precision flag shared by m3t_sgemm (= M3T_GEMM_BF16), m3t_conv1d_* and m3t_gru_scan_*:

@@ -130,6 +130,19 @@ __global__ void wfrag_bwd_prep_kernel(const float* __restrict__ w_hh_t, float* _
     }
 }
 
+// the same fragments straight from the untransposed parameter w_hh [3H][H] (M3T_SCAN_WHH): W_hh[k][j] = w_hh[k*H + j]
+__global__ void wfrag_bwd_direct_kernel(const float* __restrict__ w_hh, float* __restrict__ wtfrag, int H, int bf16) {
+    const int nch = (3 * H) >> 4;
+    const size_t total = (size_t)3 * H * H;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int e = i & 3, l = (i >> 2) & 63;
+        const size_t r = i >> 8;
+        const int c = r % nch, ub = r / nch;
+        const float v = w_hh[((size_t)c * 16 + (l >> 4) * 4 + e) * H + ub * 16 + (l & 15)];
+        wtfrag[i] = bf16 ? rbf(v) : v;
+    }
+}
+
 // NC = chunks per wave kept in flight; CT = column tiles; RT = row tiles.
 // A frag: [chunk][RT row tiles][64][4]; B frag: [chunk][CT][64][4]
 template <int CT, int NC, int RT>
@@ -738,6 +751,8 @@ static int scan_bwd_impl(const m3t_gru_bwd_desc* scans, int n_scans, int B, int 
         frag = frag && scans[i].H % 16 == 0;
         need += (size_t)3 * scans[i].H * scans[i].H + xfrag_floats(scans[i].H, B, true);
     }
+    const bool whh = (flags & M3T_SCAN_WHH) != 0;      // desc.w_hh_t is the untransposed parameter w_hh [3H][H]
+    if (whh && !(frag && need * sizeof(float) <= ws_bytes)) return M3T_EINVAL;
     if (frag && need * sizeof(float) <= ws_bytes) {
         const ScanPlan plan = plan_level(Hs, n_scans, B);
         const int rt = plan.rt, nrb = cdiv(B, 16 * rt);
@@ -763,7 +778,8 @@ static int scan_bwd_impl(const m3t_gru_bwd_desc* scans, int n_scans, int B, int 
                 const int H = bg.d[i].H;
                 int blk = (3 * H * H + 255) / 256;
                 if (blk > 1024) blk = 1024;
-                wfrag_bwd_prep_kernel<<<blk, 256, 0, s>>>(bg.d[i].w_hh_t, fp.wfrag[i], H, bg.bf16);
+                if (whh) wfrag_bwd_direct_kernel<<<blk, 256, 0, s>>>(bg.d[i].w_hh_t, fp.wfrag[i], H, bg.bf16);
+                else wfrag_bwd_prep_kernel<<<blk, 256, 0, s>>>(bg.d[i].w_hh_t, fp.wfrag[i], H, bg.bf16);
             }
             M3T_LAUNCH_CHECK();
             return persist_bwd_launch(bg, fp, B, T, flags, s);
@@ -774,7 +790,8 @@ static int scan_bwd_impl(const m3t_gru_bwd_desc* scans, int n_scans, int B, int 
                 const int H = bg.d[i].H;
                 int blk = (3 * H * H + 255) / 256;
                 if (blk > 1024) blk = 1024;
-                wfrag_bwd_prep_kernel<<<blk, 256, 0, s>>>(bg.d[i].w_hh_t, fp.wfrag[i], H, bg.bf16);
+                if (whh) wfrag_bwd_direct_kernel<<<blk, 256, 0, s>>>(bg.d[i].w_hh_t, fp.wfrag[i], H, bg.bf16);
+                else wfrag_bwd_prep_kernel<<<blk, 256, 0, s>>>(bg.d[i].w_hh_t, fp.wfrag[i], H, bg.bf16);
             }
             if (rt == 2)
                 for (int step = 0; step < T; ++step) gru_step_bwd_frag_kernel<2><<<nblk, NT, 0, s>>>(bg, fp, B, T, step);

@@ -306,7 +306,7 @@ __global__ __launch_bounds__(NT) void gru_persist_fwd6_kernel(FwdGroup g, FragPt
 // v_mfma_f32_16x16x32_bf16 (one per gate; 6 per wave at H = 512 instead of 48 fp32 MFMAs), fp32 accumulate.  Same values
 // as the fp32-MFMA kernel on rounded operands up to accumulation order (M3T_SCAN_FP32 keeps that kernel and bit-identity
 // with the launch-per-step path).  Everything else -- cell math, bias sums, prefetch, poll delay -- is the kernel below.
-__global__ void wfrag_bwd16_prep_kernel(const float* __restrict__ w_hh_t, unsigned short* __restrict__ wf, int H) {
+__global__ void wfrag_bwd16_prep_kernel(const float* __restrict__ w_hh_t, unsigned short* __restrict__ wf, int H, int direct) {
     const int ks = H >> 8;                            // k-steps per wave = NC / 2
     const size_t total = (size_t)3 * H * H;           // [ub][wave][k-step][gate][lane][8]
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -317,7 +317,9 @@ __global__ void wfrag_bwd16_prep_kernel(const float* __restrict__ w_hh_t, unsign
         const int w = r % NW, ub = r / NW;
         const int q = l >> 4;
         const int unit = 16 * (w + NW * (2 * sk + (q >> 1))) + 8 * (q & 1) + e;       // the forward kernel's k order
-        const float x = rbf(w_hh_t[((size_t)ub * 16 + (l & 15)) * 3 * H + (size_t)gt * H + unit]);
+        // direct: the pointer is the untransposed parameter w_hh [3H][H] (M3T_SCAN_WHH)
+        const float x = rbf(direct ? w_hh_t[((size_t)gt * H + unit) * H + ub * 16 + (l & 15)]
+                                   : w_hh_t[((size_t)ub * 16 + (l & 15)) * 3 * H + (size_t)gt * H + unit]);
         wf[i] = (unsigned short)(__float_as_uint(x) >> 16);
     }
 }
@@ -793,7 +795,7 @@ int persist_bwd_launch(const BwdGroup& g, const FragPtrs& fp, int B, int T, int 
             const int H = g.d[i].H;
             int blk = (3 * H * H + 255) / 256;
             if (blk > 1024) blk = 1024;
-            wfrag_bwd16_prep_kernel<<<blk, 256, 0, s>>>(g.d[i].w_hh_t, reinterpret_cast<unsigned short*>(fp.wfrag[i]), H);
+            wfrag_bwd16_prep_kernel<<<blk, 256, 0, s>>>(g.d[i].w_hh_t, reinterpret_cast<unsigned short*>(fp.wfrag[i]), H, (flags & M3T_SCAN_WHH) ? 1 : 0);
         }
         M3T_LAUNCH_CHECK();
         { const int e = persist_take_after(s); if (e) return e; }

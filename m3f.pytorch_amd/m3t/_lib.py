@@ -13,6 +13,7 @@ M3T_SCAN_NO_PERSIST = 1
 M3T_BF16 = 2
 M3T_GEMM_EXCLUSIVE = 8
 M3T_SCAN_FP32 = 4
+M3T_SCAN_WHH = 8
 M3T_MAX_SCANS = 8
 
 _f = C.c_void_p      # device pointer

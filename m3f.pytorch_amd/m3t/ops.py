@@ -549,7 +549,9 @@ class _MultiBiGRU(torch.autograd.Function):
         dgh = [[new(2, B, T, 3 * Hs[s]) for s in range(n_stacks)] for _ in range(L)]
         dh = [[new(2, B, Hs[s]) for s in range(n_stacks)] for _ in range(L)]
         dbp = [[new(2, B, 4, Hs[s]) for s in range(n_stacks)] for _ in range(L)]      # per-clip bias-gradient sums (scan output)
-        wht = [[[new(Hs[s], 3 * Hs[s]) for _ in (0, 1)] for s in range(n_stacks)] for _ in range(L)]
+        # H % 16 == 0 everywhere: the scans build their weight fragments straight from w_hh (no transposes in front of them)
+        direct_whh = all(h % 16 == 0 for h in Hs) and all(p.is_contiguous() for prm in params for p in prm)
+        wht = [[[None if direct_whh else new(Hs[s], 3 * Hs[s]) for _ in (0, 1)] for s in range(n_stacks)] for _ in range(L)]
         need_dx = [[l > 0 or ctx.needs_input_grad[2 + s * per] for s in range(n_stacks)] for l in range(L)]
         dinp = [[torch.empty_like(layer_io(l, s)[0]) if need_dx[l][s] else None for s in range(n_stacks)] for l in range(L)]
         for s in range(n_stacks):
@@ -573,15 +575,17 @@ class _MultiBiGRU(torch.autograd.Function):
                 inp, out, gts = layer_io(l, s)
                 for d in (0, 1):
                     w_hh = params[s][(2 * l + d) * 4 + 1]
-                    _lib.check(lib().m3t_transpose(_p(w_hh), 3 * H, H, H, _p(wht[l][s][d]), 3 * H, _stream()),
-                               "m3t_transpose")
+                    if not direct_whh:
+                        _lib.check(lib().m3t_transpose(_p(w_hh), 3 * H, H, H, _p(wht[l][s][d]), 3 * H, _stream()),
+                                   "m3t_transpose")
                     base = s * per + 1 + (2 * l + d) * 4
-                    descs.append(GruBwdDesc(_vp(cur[s]), _vp(out), _vp(gts, d * B * T * 4 * H), _vp(wht[l][s][d]),
+                    descs.append(GruBwdDesc(_vp(cur[s]), _vp(out), _vp(gts, d * B * T * 4 * H),
+                                            _vp(w_hh if direct_whh else wht[l][s][d]),
                                             _vp(dhns[s], (2 * l + d) * B * H) if dhns[s] is not None else None,
                                             _vp(dgx[l][s]), _vp(dgh[l][s], d * B * T * 3 * H), _vp(dh[l][s], d * B * H),
                                             _vp(dbp[l][s], d * B * 4 * H), _vp(out_grads[base + 2]), _vp(out_grads[base + 3]),
                                             H, d, 2 * H, d * H, 6 * H, d * 3 * H))
-            _scan_bwd(descs, B, T, prec, after)
+            _scan_bwd(descs, B, T, prec | (_lib.M3T_SCAN_WHH if direct_whh else 0), after)
 
         def level_dx(l, idxs):           # on the chain: feeds the next level's scan
             for s in idxs:
