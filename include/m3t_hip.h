@@ -147,6 +147,10 @@ int m3t_gru_persist_count(void);
  * by the host schedule that alternates the persistent scans of two streams (they must never run at the same time).
  * The event is consumed by that call (also when it fails).  Returns 0. */
 int m3t_gru_scan_after(void* event);
+/* Timing hook: the NEXT m3t_gru_scan_fwd / m3t_gru_scan_bwd call of the calling thread records `start` right before and
+ * `end` right after its scan kernel(s) on its stream (two hipEvent_t created with timing enabled) -- not around its weight
+ * re-layout kernels, memsets or the m3t_gru_scan_after fence.  bench.py's roofline.achieved uses it.  Returns 0. */
+int m3t_gru_scan_events(void* start, void* end);
 /* With env M3T_SCAN_PROF=1: s_memtime cycles that workgroup 0 / lane 0 of the LAST persistent launch spent per phase,
  * summed over its T steps: [0] step top, [1] gather (wait for peers), [2] MFMA + LDS partials, [3] barrier,
  * [4] reduce + gate math + publish, [5] stores.  Synchronises the device.  M3T_EINVAL when profiling is off. */

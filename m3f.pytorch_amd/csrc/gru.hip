@@ -694,6 +694,8 @@ extern "C" int m3t_gru_scan_fwd(const m3t_gru_fwd_desc* scans, int n_scans, int 
             return persist_fwd_launch(fg, fp, B, T, flags, s);
         }
         { const int e = persist_take_after(s); if (e) return e; }
+        persist_record_start(s);
+        struct EndRec { hipStream_t s; ~EndRec() { persist_record_end(s); } } end_rec{s};
         return replay_or_capture(make_key(1, fg, &fp, B, T, rt), s, [&]() {
             for (int i = 0; i < n_scans; ++i) {
                 const int H = fg.d[i].H;
@@ -708,6 +710,8 @@ extern "C" int m3t_gru_scan_fwd(const m3t_gru_fwd_desc* scans, int n_scans, int 
         });
     }
     { const int e = persist_take_after(s); if (e) return e; }
+    persist_record_start(s);
+    struct EndRec2 { hipStream_t s; ~EndRec2() { persist_record_end(s); } } end_rec2{s};
     if (fast)
         for (int step = 0; step < T; ++step) gru_step_fwd_kernel<true><<<grid, NT, 0, s>>>(g, B, T, step);
     else
@@ -785,6 +789,8 @@ static int scan_bwd_impl(const m3t_gru_bwd_desc* scans, int n_scans, int B, int 
             return persist_bwd_launch(bg, fp, B, T, flags, s);
         }
         { const int e = persist_take_after(s); if (e) return e; }
+        persist_record_start(s);
+        struct EndRec { hipStream_t s; ~EndRec() { persist_record_end(s); } } end_rec{s};
         return replay_or_capture(make_key(2, bg, &fp, B, T, rt), s, [&]() {
             for (int i = 0; i < n_scans; ++i) {
                 const int H = bg.d[i].H;
@@ -800,6 +806,8 @@ static int scan_bwd_impl(const m3t_gru_bwd_desc* scans, int n_scans, int B, int 
         });
     }
     { const int e = persist_take_after(s); if (e) return e; }
+    persist_record_start(s);
+    struct EndRec2 { hipStream_t s; ~EndRec2() { persist_record_end(s); } } end_rec2{s};
     if (fast)
         for (int step = 0; step < T; ++step) gru_step_bwd_kernel<true><<<grid, NT, 0, s>>>(g, B, T, step);
     else

@@ -81,7 +81,13 @@ bool persist_enabled();
 void persist_set_after(hipEvent_t ev);
 int persist_take_after(hipStream_t s);
 void persist_drop_after();
-struct AfterGuard { ~AfterGuard() { persist_drop_after(); } };
+// m3t_gru_scan_events: a (start, end) hipEvent pair the NEXT scan call records right around its scan kernel(s) -- not around
+// its preparation kernels, memsets and fences -- so that a caller's timing is the kernel's, as rocprofv3 reports it
+void persist_set_events(hipEvent_t start, hipEvent_t end);
+void persist_record_start(hipStream_t s);
+void persist_record_end(hipStream_t s);
+void persist_drop_events();
+struct AfterGuard { ~AfterGuard() { persist_drop_after(); persist_drop_events(); } };
 int persist_poll_error();       // step+1 of a scan that hit its spin limit since the last poll, else 0
 bool persist_fwd_check(const FwdGroup& g, int B, int T);
 bool persist_bwd_check(const BwdGroup& g, int B, int T);

@@ -763,12 +763,16 @@ int persist_fwd_launch(const FwdGroup& g, const FragPtrs& fp, int B, int T, int 
         }
         M3T_LAUNCH_CHECK();
         { const int e = persist_take_after(s); if (e) return e; }
+        persist_record_start(s);
         if (sh.nc == 2) hipLaunchKernelGGL(gru_persist_fwd6_kernel<2>, dim3(sh.grid), dim3(NT), exclusive_lds(gru_persist_fwd6_kernel<2>, sh.grid), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
         else hipLaunchKernelGGL(gru_persist_fwd6_kernel<4>, dim3(sh.grid), dim3(NT), exclusive_lds(gru_persist_fwd6_kernel<4>, sh.grid), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
+        persist_record_end(s);
         M3T_LAUNCH_CHECK();
         return 0;
     }
+    persist_record_start(s);
     hipLaunchKernelGGL(pick_fwd(sh), dim3(sh.grid), dim3(NT), exclusive_lds(pick_fwd(sh), sh.grid), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
+    persist_record_end(s);
     M3T_LAUNCH_CHECK();
     return 0;
 }
@@ -799,16 +803,26 @@ int persist_bwd_launch(const BwdGroup& g, const FragPtrs& fp, int B, int T, int 
         }
         M3T_LAUNCH_CHECK();
         { const int e = persist_take_after(s); if (e) return e; }
+        persist_record_start(s);
         if (sh.nc == 2) hipLaunchKernelGGL(gru_persist_bwd16_kernel<2>, dim3(sh.grid), dim3(NT), exclusive_lds(gru_persist_bwd16_kernel<2>, sh.grid), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
         else hipLaunchKernelGGL(gru_persist_bwd16_kernel<4>, dim3(sh.grid), dim3(NT), exclusive_lds(gru_persist_bwd16_kernel<4>, sh.grid), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
+        persist_record_end(s);
         M3T_LAUNCH_CHECK();
         return 0;
     }
     { const int e = persist_take_after(s); if (e) return e; }
+    persist_record_start(s);
     hipLaunchKernelGGL(pick_bwd(sh), dim3(sh.grid), dim3(NT), exclusive_lds(pick_bwd(sh), sh.grid), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
+    persist_record_end(s);
     M3T_LAUNCH_CHECK();
     return 0;
 }
+
+static thread_local hipEvent_t g_ev_start = nullptr, g_ev_end = nullptr;
+void persist_set_events(hipEvent_t a, hipEvent_t b) { g_ev_start = a; g_ev_end = b; }
+void persist_drop_events() { g_ev_start = g_ev_end = nullptr; }
+void persist_record_start(hipStream_t s) { if (g_ev_start) { (void)hipEventRecord(g_ev_start, s); g_ev_start = nullptr; } }
+void persist_record_end(hipStream_t s) { if (g_ev_end) { (void)hipEventRecord(g_ev_end, s); g_ev_end = nullptr; } }
 
 static thread_local hipEvent_t g_after = nullptr;
 void persist_set_after(hipEvent_t ev) { g_after = ev; }
@@ -830,6 +844,11 @@ int persist_profile(unsigned long long* out6) {
 }  // namespace m3t_gru
 
 extern "C" int m3t_gru_persist_count(void) { return m3t_gru::persist_launch_count(); }
+
+extern "C" int m3t_gru_scan_events(void* start, void* end) {
+    m3t_gru::persist_set_events((hipEvent_t)start, (hipEvent_t)end);
+    return 0;
+}
 
 extern "C" int m3t_gru_scan_after(void* event) {
     m3t_gru::persist_set_after((hipEvent_t)event);

@@ -46,6 +46,7 @@ SIGNATURES = {
     "m3t_gru_scan_bwd": [C.POINTER(GruBwdDesc), _i, _i, _i, _f, _z, _i, _s],
     "m3t_gru_persist_count": [],
     "m3t_gru_scan_after": [C.c_void_p],
+    "m3t_gru_scan_events": [C.c_void_p, C.c_void_p],
     "m3t_gru_persist_profile": [C.c_void_p],
     "m3t_att_fuse_fwd": [_f, _f, _f, _f, _f, _i, _i, _s],
     "m3t_att_fuse_bwd": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _s],

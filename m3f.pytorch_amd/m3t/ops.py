@@ -69,20 +69,30 @@ _NULL = _Null()
 
 
 class _Timed:
-    def __init__(self, kernel, launches, flops):
+    """HIP-event timing of a launch on the current stream (bench.py).  kernel_side=True: the events are handed to the C
+    call (m3t_gru_scan_events), which records them right around its scan kernel(s) instead of around the whole call."""
+
+    def __init__(self, kernel, launches, flops, kernel_side=False):
         self.rec = None
+        self.kernel_side = kernel_side
         if PROFILE_ON[0]:
             self.rec = {"kernel": kernel, "launches": launches, "flops": float(flops),
                         "start": torch.cuda.Event(enable_timing=True), "end": torch.cuda.Event(enable_timing=True)}
 
     def __enter__(self):
         if self.rec is not None:
-            self.rec["start"].record(torch.cuda.current_stream())
+            st = torch.cuda.current_stream()
+            self.rec["start"].record(st)
+            if self.kernel_side:
+                self.rec["end"].record(st)          # materialises the handle; the C call records both again
+                _lib.check(lib().m3t_gru_scan_events(C.c_void_p(self.rec["start"].cuda_event), C.c_void_p(self.rec["end"].cuda_event)),
+                           "m3t_gru_scan_events")
         return self
 
     def __exit__(self, *exc):
         if self.rec is not None:
-            self.rec["end"].record(torch.cuda.current_stream())
+            if not self.kernel_side:
+                self.rec["end"].record(torch.cuda.current_stream())
             PROFILE.append(self.rec)
         return False
 
@@ -346,22 +356,12 @@ def _scan_after(ev):
             torch.cuda.current_stream().wait_event(ev)
 
 
-def _fence_now_if_timed(after):
-    """bench.py times scan launches with HIP events around the call: a fence deferred into the call would be counted as
-    kernel time, so while profiling is on the whole call waits instead"""
-    if after is not None and PROFILE_ON[0]:
-        torch.cuda.current_stream().wait_event(after)
-        return None
-    return after
-
-
 def _scan_fwd(descs, B, T, prec=0, after=None):
-    after = _fence_now_if_timed(after)
     for i in range(0, len(descs), M3T_MAX_SCANS):
         chunk = descs[i:i + M3T_MAX_SCANS]
         arr = (GruFwdDesc * len(chunk))(*chunk)
         flops = (T - 1) * sum(2.0 * B * 3 * d.H * d.H for d in chunk)
-        with _Timed("gru_step_fwd_kernel", T, flops) as tm:
+        with _Timed("gru_step_fwd_kernel", T, flops, kernel_side=True) as tm:
             dev = torch.device("cuda", torch.cuda.current_device())
             ws = workspace(dev)
             n0 = lib().m3t_gru_persist_count() if tm.rec is not None else 0
@@ -373,12 +373,11 @@ def _scan_fwd(descs, B, T, prec=0, after=None):
 
 
 def _scan_bwd(descs, B, T, prec=0, after=None):
-    after = _fence_now_if_timed(after)
     for i in range(0, len(descs), M3T_MAX_SCANS):
         chunk = descs[i:i + M3T_MAX_SCANS]
         arr = (GruBwdDesc * len(chunk))(*chunk)
         flops = (T - 1) * sum(2.0 * B * 3 * d.H * d.H for d in chunk)
-        with _Timed("gru_step_bwd_kernel", T, flops) as tm:
+        with _Timed("gru_step_bwd_kernel", T, flops, kernel_side=True) as tm:
             dev = torch.device("cuda", torch.cuda.current_device())
             ws = workspace(dev)
             n0 = lib().m3t_gru_persist_count() if tm.rec is not None else 0
