@@ -122,28 +122,20 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from m3t.workloads import AVFeatureGraph
-    from m3t.ddp import FlatGradDDP
+    from m3t.workloads import AVFeatureGraph, make_c3_step
     from m3t import ops
 
     B, T, d_a, d_v = args.batch, args.frames, 128, 256
     torch.manual_seed(12345)                       # identical replicas on every rank
     model = AVFeatureGraph(d_a, d_v, 512).to(device)
     n_params = sum(p.numel() for p in model.parameters())
-    ddp = FlatGradDDP(model, bucket_order=[list(model.fusion.parameters()),
-                                           list(model.att_fuse.parameters()) + list(model.proj_v.parameters()),
-                                           list(model.visual.parameters()) + list(model.audio.parameters())],
-                      max_norm=1.0)
     batch = synth_batch(B, T, d_a, d_v, device, rank)
+    # the step (m3t/workloads.py): zero_grad -> forward -> ccc_mtl loss -> backward -> all-reduce (N > 1) + 1/N + clip 1.0.
+    # tests/test_gpu_bench_path.py runs this same function at B=32 x T=300 against a reference-generated golden.
+    ddp, step_fn = make_c3_step(model, batch, max_norm=1.0)
 
     def step():
-        ddp.zero_grad()
-        y = model(batch["x_a"], batch["x_v"])
-        loss, _ = ops.va_loss(y, batch["valence"], batch["arousal"], batch["class_expr"], batch["expr_valid"],
-                              iv=7, ia=8, n_expr=7, w_v=0.5, w_a=0.5, expr_w=0.8)
-        loss.backward()
-        ddp.finish()
-        return loss
+        return step_fn()[0]
 
     def fence():
         torch.cuda.synchronize()

@@ -34,6 +34,8 @@ extern "C" {
                                   * a transpose per direction in front of the scan); needs H % 16 == 0 and the workspace, else M3T_EINVAL */
 #define M3T_SCAN_FP32 4          /* m3t_gru_scan_fwd flags: keep the recurrent product on fp32 MFMAs (bit-identical to the
                                   * launch-per-step kernels) instead of the fp32-accurate bf16x6 form */
+#define M3T_SCAN_FAULT 16        /* m3t_gru_scan_* flags, FAULT INJECTION for tests: workgroup 0 of a persistent launch stays silent at step T/2,
+                                  * so its peers run into their spin limit (env M3T_SCAN_SPIN_LIMIT lowers it) and the error path below runs */
 #define M3T_BF16 2               /* precision flag shared by m3t_sgemm (= M3T_GEMM_BF16), m3t_conv1d_* and m3t_gru_scan_*:
                                   * matmul operands rounded to bf16 (nearest even), fp32 accumulate, fp32 state/epilogue */
 /* m3t_sgemm flags: BACKGROUND caps residency at one workgroup per CU (for GEMMs that run on a side stream
@@ -114,8 +116,15 @@ typedef struct {
  * per CU, ONE persistent launch runs all T steps (W_hh held in registers, h_t exchanged between CUs through tagged
  * granules); otherwise one launch per time step.  A persistent launch needs all its workgroups resident: never run
  * two of them concurrently on one device (flags = M3T_SCAN_NO_PERSIST for scans issued on a side stream; env
- * M3T_SCAN_PERSIST=0 disables globally).  Its waits are bounded: if one expires the scan's results are invalid and
- * the NEXT m3t_gru_scan_* call returns M3T_ESPIN. */
+ * M3T_SCAN_PERSIST=0 disables globally).  One process per device: the first process that launches a persistent scan on a
+ * GPU takes an advisory lock (/tmp/m3t_persist_<pci-bus-id>.lock, held until it exits); any other process on that GPU
+ * silently gets the launch-per-step path (env M3T_SCAN_LOCK=0 disables the guard).
+ * Error model.  Every wait of a persistent scan is bounded (M3T_SCAN_SPIN_LIMIT gather attempts, default 2^21 ~ 2 s).  A
+ * workgroup whose wait expires raises a sticky host-visible error word and the scan finishes with INVALID results.  The
+ * word is reported by (a) m3t_gru_poll_error() -- call it after synchronising, before results are trusted; (b) the next
+ * m3t_gru_scan_* call, which returns M3T_ESPIN; (c) m3t_grad_norm_scale, which reads the word ON THE DEVICE in stream order:
+ * it then zeroes the gradient buffer and returns norm = NaN, and m3t_adam_step / m3t_sgd_step skip an update whose
+ * `guard` scalar is not finite -- a dead scan can never reach the parameters, with no host synchronisation. */
 int m3t_gru_scan_fwd(const m3t_gru_fwd_desc* scans, int n_scans, int B, int T,
                      float* ws, size_t ws_bytes, int flags, void* stream);
 
@@ -141,6 +150,9 @@ typedef struct {
 
 /* Number of persistent scan launches this process has issued so far (tests use it to assert which path ran). */
 int m3t_gru_persist_count(void);
+/* 0, or (step + 1) of a persistent scan that gave up waiting since the last call (reading clears the word).  The word is
+ * host-mapped: no synchronisation happens here, so synchronise the scan's stream first if the answer must cover it. */
+int m3t_gru_poll_error(void);
 /* Ordering between scans on different streams without holding back their preparation: the NEXT m3t_gru_scan_fwd /
  * m3t_gru_scan_bwd call of the calling thread makes its stream wait for `event` (a hipEvent_t) right before it launches
  * its scan kernel(s); the weight re-layout kernels and memsets it issues first run as soon as the stream allows.  Used
@@ -187,7 +199,11 @@ int m3t_va_loss(const float* y_hat, int rows, int C, int iv, int ia,
                 const float* valence, const float* arousal,
                 const int64_t* class_expr, const uint8_t* expr_valid, int n_expr,
                 float w_v, float w_a, float expr_w, int use_mse,
-                float* out_scalars, float* dy, void* stream);
+                float* out_scalars, float* dy, float* ws, size_t ws_bytes, void* stream);
+/* ws: 32 floats per 256 rows (m3t_va_loss_ws_bytes).  With it, rows > 1024 run as three short grid-wide launches
+ * (sums -> centred moments -> closed form + gradient; per-block partials reduced in a fixed order by every block); without
+ * it, or for rows <= 1024, one workgroup does all passes. */
+size_t m3t_va_loss_ws_bytes(int rows);
 
 /* ---------------------------------------------------------------------------------
  * TCN (models/tcn.py).  Activations are channel-last [B,T,C] inside the library.
@@ -291,9 +307,12 @@ int m3t_grad_norm_scale(float* flat, size_t n, float inv_world, float max_norm,
  * models/model.py:388-394).  torch.optim semantics: Adam(lr, betas, eps, weight_decay as L2 on the gradient,
  * bias-corrected, `step` counts from 1); SGD(momentum, weight_decay), dampening 0, no Nesterov. */
 int m3t_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
-                  float eps, float weight_decay, int step, void* stream);
+                  float eps, float weight_decay, int step, const float* guard, void* stream);
 int m3t_sgd_step(float* p, const float* g, float* buf, size_t n, float lr, float momentum, float weight_decay,
-                 int step, void* stream);
+                 int step, const float* guard, void* stream);
+/* guard: optional device scalar (the norm m3t_grad_norm_scale returned).  When it is not finite the kernel changes
+ * nothing (parameters and optimizer state keep their values): a step whose gradients came from a failed scan, or
+ * overflowed, is skipped on the device. */
 
 /* ---------------------------------------------------------------------------------
  * Post-processing of prediction tracks (reference models/utils.py:20-33,

@@ -2,7 +2,7 @@
 // the VA training loss with its gradient (models/model.py:132-182, models/utils.py:6-17) and
 // the data-parallel gradient post-processing (train.py:35).  One wavefront per [B,T,C] frame
 // row, float4 (16 B/lane) accesses, wavefront-shuffle reductions, no atomics.
-#include "common.h"
+#include "gru_common.h"
 #include <cmath>
 
 namespace {
@@ -177,6 +177,135 @@ __global__ __launch_bounds__(1024) void va_loss_kernel(const float* __restrict__
     }
 }
 
+// The same loss as three short grid-wide launches for B*T in the thousands (one workgroup took 141 us on 9600 rows,
+// un-overlappable between forward and backward).  256 rows per block, one row per thread; per-block partial sums go to
+// ws and are reduced in a fixed order by EVERY block of the next launch (deterministic, no atomics).
+//   part A [nb][8]: sum y_v, sum val, sum y_a, sum aro, CE sum, n_valid, n_correct, -
+//   part B [nb][8]: centred co-moments cv xv tv ca xa ta and squared errors ev ea
+constexpr int LB = 256;
+
+__device__ __forceinline__ void reduce_parts(const float* __restrict__ part, int nb, float* tot /* LDS [8] */) {
+    // threads 0..7 each add one column over the blocks in block order
+    if (threadIdx.x < 8) {
+        float s = 0.f;
+        for (int b = 0; b < nb; ++b) s += part[(size_t)b * 8 + threadIdx.x];
+        tot[threadIdx.x] = s;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(LB) void va_loss_sums_kernel(const float* __restrict__ y, int rows, int C, int iv, int ia,
+                                                          const float* __restrict__ val, const float* __restrict__ aro,
+                                                          const int64_t* __restrict__ cls, const uint8_t* __restrict__ valid,
+                                                          int n_expr, float* __restrict__ partA) {
+    __shared__ float red[16];
+    const int i = blockIdx.x * LB + threadIdx.x;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, ce = 0.f, nvalid = 0.f, ncorrect = 0.f;
+    if (i < rows) {
+        const float* l = y + (size_t)i * C;
+        s0 = l[iv]; s1 = val[i]; s2 = l[ia]; s3 = aro[i];
+        if (n_expr > 0 && valid[i]) {
+            float m = l[0];
+            int am = 0;
+            for (int k = 1; k < n_expr; ++k)
+                if (l[k] > m) { m = l[k]; am = k; }
+            float se = 0.f;
+            for (int k = 0; k < n_expr; ++k) se += expf(l[k] - m);
+            const int lab = (int)cls[i];
+            ce = m + logf(se) - l[lab];
+            nvalid = 1.f;
+            ncorrect = (am == lab) ? 1.f : 0.f;
+        }
+    }
+    s0 = block_sum(s0, red); s1 = block_sum(s1, red); s2 = block_sum(s2, red); s3 = block_sum(s3, red);
+    ce = block_sum(ce, red); nvalid = block_sum(nvalid, red); ncorrect = block_sum(ncorrect, red);
+    if (threadIdx.x == 0) {
+        float* q = partA + (size_t)blockIdx.x * 8;
+        q[0] = s0; q[1] = s1; q[2] = s2; q[3] = s3; q[4] = ce; q[5] = nvalid; q[6] = ncorrect; q[7] = 0.f;
+    }
+}
+
+__global__ __launch_bounds__(LB) void va_loss_moments_kernel(const float* __restrict__ y, int rows, int C, int iv, int ia,
+                                                             const float* __restrict__ val, const float* __restrict__ aro,
+                                                             const float* __restrict__ partA, float* __restrict__ partB) {
+    __shared__ float red[16];
+    __shared__ float tot[8];
+    reduce_parts(partA, gridDim.x, tot);
+    const float invn = 1.f / (float)rows;
+    const float mxv = tot[0] * invn, mtv = tot[1] * invn, mxa = tot[2] * invn, mta = tot[3] * invn;
+    const int i = blockIdx.x * LB + threadIdx.x;
+    float cv = 0.f, xv = 0.f, tv = 0.f, ca = 0.f, xa = 0.f, ta = 0.f, ev = 0.f, ea = 0.f;
+    if (i < rows) {
+        const float a = y[(size_t)i * C + iv], b = val[i];
+        const float c = y[(size_t)i * C + ia], e = aro[i];
+        cv = (a - mxv) * (b - mtv); xv = (a - mxv) * (a - mxv); tv = (b - mtv) * (b - mtv);
+        ca = (c - mxa) * (e - mta); xa = (c - mxa) * (c - mxa); ta = (e - mta) * (e - mta);
+        ev = (a - b) * (a - b); ea = (c - e) * (c - e);
+    }
+    cv = block_sum(cv, red); xv = block_sum(xv, red); tv = block_sum(tv, red);
+    ca = block_sum(ca, red); xa = block_sum(xa, red); ta = block_sum(ta, red);
+    ev = block_sum(ev, red); ea = block_sum(ea, red);
+    if (threadIdx.x == 0) {
+        float* q = partB + (size_t)blockIdx.x * 8;
+        q[0] = cv; q[1] = xv; q[2] = tv; q[3] = ca; q[4] = xa; q[5] = ta; q[6] = ev; q[7] = ea;
+    }
+}
+
+__global__ __launch_bounds__(LB) void va_loss_grad_kernel(const float* __restrict__ y, int rows, int C, int iv, int ia,
+                                                          const float* __restrict__ val, const float* __restrict__ aro,
+                                                          const int64_t* __restrict__ cls, const uint8_t* __restrict__ valid,
+                                                          int n_expr, float wv, float wa, float expr_w, int use_mse,
+                                                          const float* __restrict__ partA, const float* __restrict__ partB,
+                                                          float* __restrict__ out, float* __restrict__ dy) {
+    __shared__ float ta_[8], tb_[8];
+    reduce_parts(partA, gridDim.x, ta_);
+    reduce_parts(partB, gridDim.x, tb_);
+    const float invn = 1.f / (float)rows;
+    const float mxv = ta_[0] * invn, mtv = ta_[1] * invn, mxa = ta_[2] * invn, mta = ta_[3] * invn;
+    const float nm1 = 1.f / (float)(rows > 1 ? rows - 1 : 1);
+    const float covv = tb_[0] * invn, covA = tb_[3] * invn;
+    const float denv = tb_[1] * nm1 + tb_[2] * nm1 + (mxv - mtv) * (mxv - mtv);
+    const float dena = tb_[4] * nm1 + tb_[5] * nm1 + (mxa - mta) * (mxa - mta);
+    const float cccv = 2.f * covv / denv, ccca = 2.f * covA / dena;
+    const float loss_e = ta_[4] * invn, nvalid = ta_[5];
+    const bool use_e = n_expr > 0 && nvalid > 0.f;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const float lv = wv == 0.f ? 0.f : (use_mse ? tb_[6] * invn : 1.f - cccv);
+        const float la = wa == 0.f ? 0.f : (use_mse ? tb_[7] * invn : 1.f - ccca);
+        out[0] = wv * lv + wa * la + (use_e ? expr_w * loss_e : 0.f);
+        out[1] = lv; out[2] = la; out[3] = loss_e; out[4] = nvalid; out[5] = ta_[6]; out[6] = cccv; out[7] = ccca;
+    }
+    const int i = blockIdx.x * LB + threadIdx.x;
+    if (i >= rows) return;
+    float* g = dy + (size_t)i * C;
+    const float* l = y + (size_t)i * C;
+    for (int k = 0; k < C; ++k) g[k] = 0.f;
+    if (use_e && valid[i]) {
+        float m = l[0];
+        for (int k = 1; k < n_expr; ++k) m = fmaxf(m, l[k]);
+        float se = 0.f;
+        for (int k = 0; k < n_expr; ++k) se += expf(l[k] - m);
+        const float sc = expr_w * invn;
+        const int lab = (int)cls[i];
+        for (int k = 0; k < n_expr; ++k) g[k] = sc * (expf(l[k] - m) / se - (k == lab ? 1.f : 0.f));
+    }
+    const float a = l[iv], b = val[i], c = l[ia], e = aro[i];
+    float gv, ga;
+    if (use_mse) {
+        gv = 2.f * (a - b) * invn;
+        ga = 2.f * (c - e) * invn;
+    } else {
+        const float dcv = 2.f * (b - mtv) * invn / denv -
+                          (2.f * covv / (denv * denv)) * (2.f * (a - mxv) * nm1 + 2.f * (mxv - mtv) * invn);
+        const float dca = 2.f * (e - mta) * invn / dena -
+                          (2.f * covA / (dena * dena)) * (2.f * (c - mxa) * nm1 + 2.f * (mxa - mta) * invn);
+        gv = -dcv;
+        ga = -dca;
+    }
+    if (wv != 0.f) g[iv] += wv * gv;
+    if (wa != 0.f) g[ia] += wa * ga;
+}
+
 // ------------------------------------------------------------------------------ DDP helpers
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, size_t n, float* __restrict__ part) {
     __shared__ float red[16];
@@ -195,16 +324,26 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restr
 
 __global__ __launch_bounds__(256) void norm_scale_kernel(float* __restrict__ g, size_t n, const float* __restrict__ part,
                                                          int nparts, float inv_world, float max_norm,
-                                                         float* __restrict__ norm_out) {
+                                                         float* __restrict__ norm_out, const unsigned* __restrict__ scan_err) {
     __shared__ float red[16];
+    __shared__ unsigned bad_s;
+    // a persistent GRU scan that gave up (gru_persist.hip) left garbage in these gradients: the host-mapped error word is
+    // read here, in stream order behind that scan -- no host synchronisation -- and turns the step into a no-op:
+    // gradients zeroed, norm = NaN (m3t_adam_step / m3t_sgd_step skip on a non-finite guard)
+    if (threadIdx.x == 0) bad_s = scan_err ? __hip_atomic_load(scan_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
     float s = 0.f;
     for (int i = threadIdx.x; i < nparts; i += blockDim.x) s += part[i];
-    s = block_sum(s, red);
-    const float norm = sqrtf(s) * inv_world;            // norm of the averaged gradient
+    s = block_sum(s, red);                               // (its barriers also publish bad_s)
+    const bool bad = bad_s != 0u;
+    const float norm = bad ? __builtin_nanf("") : sqrtf(s) * inv_world;            // norm of the averaged gradient
     float coef = max_norm > 0.f ? max_norm / (norm + 1e-6f) : 1.f;   // max_norm <= 0: no clipping
     coef = coef < 1.f ? coef : 1.f;
-    const float sc = inv_world * coef;
+    const float sc = bad ? 0.f : inv_world * coef;
     if (blockIdx.x == 0 && threadIdx.x == 0) norm_out[0] = norm;
+    if (bad) {
+        for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) g[i] = 0.f;
+        return;
+    }
     if (sc == 1.f) return;
     const size_t n4 = n >> 2;
     float4* g4 = reinterpret_cast<float4*>(g);
@@ -221,7 +360,8 @@ __global__ __launch_bounds__(256) void norm_scale_kernel(float* __restrict__ g, 
 // torch.optim.Adam semantics (reference models/model.py:388-390: Adam(lr, weight_decay=1e-4), L2 added to the gradient)
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps,
-                                                   float wd, float inv_bc1, float inv_sqrt_bc2) {
+                                                   float wd, float inv_bc1, float inv_sqrt_bc2, const float* __restrict__ guard) {
+    if (guard && !isfinite(guard[0])) return;          // skipped step: gradients came from a failed scan or overflowed
     const size_t n4 = n >> 2;
     float4* p4 = reinterpret_cast<float4*>(p);
     const float4* g4 = reinterpret_cast<const float4*>(g);
@@ -245,7 +385,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 
 // torch.optim.SGD(momentum, weight_decay) semantics (reference models/model.py:392-394), dampening 0, no nesterov
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
-                                                  size_t n, float lr, float momentum, float wd, int first) {
+                                                  size_t n, float lr, float momentum, float wd, int first,
+                                                  const float* __restrict__ guard) {
+    if (guard && !isfinite(guard[0])) return;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float gg = g[i] + wd * p[i];
         const float b = first ? gg : momentum * buf[i] + gg;
@@ -257,7 +399,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
 }  // namespace
 
 extern "C" int m3t_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
-                             float eps, float weight_decay, int step, void* stream) {
+                             float eps, float weight_decay, int step, const float* guard, void* stream) {
     if (n == 0) return 0;
     if (!p || !g || !m || !v || step < 1 || (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16) != 0)
         return M3T_EINVAL;
@@ -266,18 +408,18 @@ extern "C" int m3t_adam_step(float* p, const float* g, float* m, float* v, size_
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     adam_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, (float)(1.0 / bc1),
-                                                         (float)(1.0 / sqrt(bc2)));
+                                                         (float)(1.0 / sqrt(bc2)), guard);
     M3T_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int m3t_sgd_step(float* p, const float* g, float* buf, size_t n, float lr, float momentum, float weight_decay,
-                            int step, void* stream) {
+                            int step, const float* guard, void* stream) {
     if (n == 0) return 0;
     if (!p || !g || !buf || step < 1) return M3T_EINVAL;
     int blocks = (int)((n + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    sgd_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(p, g, buf, n, lr, momentum, weight_decay, step == 1);
+    sgd_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(p, g, buf, n, lr, momentum, weight_decay, step == 1, guard);
     M3T_LAUNCH_CHECK();
     return 0;
 }
@@ -304,13 +446,27 @@ extern "C" int m3t_att_fuse_bwd(const float* df, const float* s_v, const float* 
     return 0;
 }
 
+extern "C" size_t m3t_va_loss_ws_bytes(int rows) { return rows > 0 ? (size_t)cdiv(rows, LB) * 16 * sizeof(float) : 0; }
+
 extern "C" int m3t_va_loss(const float* y_hat, int rows, int C, int iv, int ia, const float* valence,
                            const float* arousal, const int64_t* class_expr, const uint8_t* expr_valid, int n_expr,
                            float w_v, float w_a, float expr_w, int use_mse, float* out_scalars, float* dy,
-                           void* stream) {
+                           float* ws, size_t ws_bytes, void* stream) {
     if (rows <= 0 || C <= 0 || iv < 0 || ia < 0 || iv >= C || ia >= C || n_expr > C) return M3T_EINVAL;
     if (!y_hat || !valence || !arousal || !out_scalars || !dy) return M3T_EINVAL;
     if (n_expr > 0 && (!class_expr || !expr_valid)) return M3T_EINVAL;
+    if (rows > 1024 && ws && ws_bytes >= m3t_va_loss_ws_bytes(rows)) {
+        const int nb = cdiv(rows, LB);
+        float* partA = ws;
+        float* partB = ws + (size_t)nb * 8;
+        hipStream_t s = (hipStream_t)stream;
+        va_loss_sums_kernel<<<nb, LB, 0, s>>>(y_hat, rows, C, iv, ia, valence, arousal, class_expr, expr_valid, n_expr, partA);
+        va_loss_moments_kernel<<<nb, LB, 0, s>>>(y_hat, rows, C, iv, ia, valence, arousal, partA, partB);
+        va_loss_grad_kernel<<<nb, LB, 0, s>>>(y_hat, rows, C, iv, ia, valence, arousal, class_expr, expr_valid, n_expr, w_v, w_a,
+                                             expr_w, use_mse, partA, partB, out_scalars, dy);
+        M3T_LAUNCH_CHECK();
+        return 0;
+    }
     va_loss_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(y_hat, rows, C, iv, ia, valence, arousal, class_expr, expr_valid,
                                                         n_expr, w_v, w_a, expr_w, use_mse, out_scalars, dy);
     M3T_LAUNCH_CHECK();
@@ -328,7 +484,7 @@ extern "C" int m3t_grad_norm_scale(float* flat, size_t n, float inv_world, float
     hipStream_t s = (hipStream_t)stream;
     sumsq_partial_kernel<<<blocks, 256, 0, s>>>(flat, n, ws);
     M3T_LAUNCH_CHECK();
-    norm_scale_kernel<<<blocks, 256, 0, s>>>(flat, n, ws, blocks, inv_world, max_norm, norm_out);
+    norm_scale_kernel<<<blocks, 256, 0, s>>>(flat, n, ws, blocks, inv_world, max_norm, norm_out, m3t_gru::persist_error_word_dev());
     M3T_LAUNCH_CHECK();
     return 0;
 }

@@ -89,6 +89,7 @@ void persist_record_end(hipStream_t s);
 void persist_drop_events();
 struct AfterGuard { ~AfterGuard() { persist_drop_after(); persist_drop_events(); } };
 int persist_poll_error();       // step+1 of a scan that hit its spin limit since the last poll, else 0
+const unsigned* persist_error_word_dev();   // device address of the (host-mapped) error word, or nullptr before the first persistent scan
 bool persist_fwd_check(const FwdGroup& g, int B, int T);
 bool persist_bwd_check(const BwdGroup& g, int B, int T);
 bool persist_fwd_uses_x6(const FwdGroup& g, int B, int T, int flags);   // then wfrag holds bf16x3 fragments (18 H^2 bytes), filled by the launch itself

@@ -22,14 +22,19 @@
 // Arithmetic: the same fp32 MFMA 16x16x4 chain, k order, LDS reduction order and gate math as the per-step kernels,
 // so results are bit-identical to them (tests assert equality).
 #include "gru_common.h"
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fcntl.h>
+#include <sys/file.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 namespace m3t_gru {
 
 namespace {
 
-constexpr int SPIN_LIMIT = 1 << 21;
+constexpr int SPIN_LIMIT_DEFAULT = 1 << 21;     // gather attempts (~1 us each) before a workgroup gives up; env M3T_SCAN_SPIN_LIMIT
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct ExPtrs {
@@ -37,6 +42,8 @@ struct ExPtrs {
     size_t slot[M3T_MAX_SCANS];      // granules per slot
     int poll_fixed;                  // >= 0: fixed poll delay (x 64 cycles); < 0: adapted per workgroup
     int poll_align;                  // 1: waves without cell math count the delay from the workgroup's publish
+    int spin_limit;                  // gather attempts before a workgroup gives up (raises the error word, finishes with garbage)
+    int fault_step;                  // fault injection (flag M3T_SCAN_FAULT): workgroup 0 does not publish this step; -1 = never
     unsigned long long* prof;        // optional in-kernel stamps (M3T_SCAN_PROF=1): 8 phase sums of workgroup 0, wave 0
 };
 
@@ -669,6 +676,9 @@ void fill_exchange(const G& g, const FragPtrs& fp, const Shape& sh, size_t gran_
     ex.prof = g_prof;
     ex.poll_fixed = -1;
     ex.poll_align = 0;
+    static const int spin_limit = poll_env_early("M3T_SCAN_SPIN_LIMIT", SPIN_LIMIT_DEFAULT);
+    ex.spin_limit = spin_limit > 0 ? spin_limit : SPIN_LIMIT_DEFAULT;
+    ex.fault_step = -1;
     for (int i = 0; i < g.n; ++i) {
         ex.gran[i] = fp.xfrag[i];
         ex.slot[i] = (size_t)sh.nrb * (g.d[i].H / 16) * sh.rt * 256;
@@ -690,6 +700,39 @@ bool persist_enabled() {
 int persist_poll_error() {
     if (!g_err_host) return 0;
     return (int)__atomic_exchange_n(g_err_host, 0u, __ATOMIC_RELAXED);
+}
+
+const unsigned* persist_error_word_dev() { return g_err_dev; }
+
+// Single owner per GPU.  A persistent launch needs its whole grid resident, so two processes that both run persistent
+// scans on one device can each hold part of the chip while waiting for the rest (both would spin to the limit and fail
+// with M3T_ESPIN).  The first process to get here takes an exclusive advisory lock on /tmp/m3t_persist_<pci-bus-id>.lock
+// and keeps it for its lifetime; any other process on that device falls back to the launch-per-step scans (same results,
+// no residency requirement).  M3T_SCAN_LOCK=0 turns the guard off (e.g. a parent that holds the lock but is idle while
+// its child runs).  If the lock file cannot be opened at all the guard stands down rather than disable the fast path.
+bool persist_owner() {
+    static int state[64];      // per device: 0 unknown, 1 owner, 2 not the owner
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return true; }
+    if (dev < 0 || dev >= 64) return true;
+    if (state[dev]) return state[dev] == 1;
+    const char* e = std::getenv("M3T_SCAN_LOCK");
+    if (e && e[0] == '0') { state[dev] = 1; return true; }
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, sizeof(bus) - 1, dev) != hipSuccess) { (void)hipGetLastError(); std::snprintf(bus, sizeof(bus), "dev%d", dev); }
+    for (char* c = bus; *c; ++c)
+        if (*c == ':' || *c == '/') *c = '_';
+    char path[160];
+    std::snprintf(path, sizeof(path), "/tmp/m3t_persist_%s.lock", bus);
+    const int fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+    if (fd < 0) { state[dev] = 1; return true; }
+    (void)fchmod(fd, 0666);
+    if (flock(fd, LOCK_EX | LOCK_NB) == 0) { state[dev] = 1; return true; }      // fd stays open: the lock lives as long as the process
+    close(fd);
+    state[dev] = 2;
+    std::fprintf(stderr, "m3t: another process owns the persistent GRU scans of GPU %s (%s); this process uses the "
+                         "launch-per-step scans\n", bus, path);
+    return false;
 }
 
 size_t persist_exchange_bytes(int H, int B, bool backward) {
@@ -718,13 +761,13 @@ bool persist_fwd_uses_x6(const FwdGroup& g, int B, int T, int flags) {
 bool persist_fwd_check(const FwdGroup& g, int B, int T) {
     Shape sh;
     return persist_enabled() && T >= 2 && level_shape(g.d, g.n, B, sh) && ensure_err_word() &&
-           sh.grid <= resident_capacity(pick_fwd(sh));
+           sh.grid <= resident_capacity(pick_fwd(sh)) && persist_owner();
 }
 
 bool persist_bwd_check(const BwdGroup& g, int B, int T) {
     Shape sh;
     return persist_enabled() && T >= 2 && level_shape(g.d, g.n, B, sh) && ensure_err_word() &&
-           sh.grid <= resident_capacity(pick_bwd(sh));
+           sh.grid <= resident_capacity(pick_bwd(sh)) && persist_owner();
 }
 
 // the backward scan of the bf16 mode runs on the bf16 matrix pipe with 8-byte granules (gru_persist_bwd16_kernel) for
@@ -741,6 +784,7 @@ int persist_fwd_launch(const FwdGroup& g, const FragPtrs& fp, int B, int T, int 
     ExPtrs ex;
     size_t bytes[M3T_MAX_SCANS];
     fill_exchange(g, fp, sh, 8, ex, bytes);
+    if (flags & M3T_SCAN_FAULT) ex.fault_step = T / 2;
     {
         static const int p6 = poll_env("M3T_SCAN_POLL_FWD6", -1), p32 = poll_env("M3T_SCAN_POLL_FWD", -2);
         ex.poll_fixed = persist_fwd_uses_x6(g, B, T, flags) ? p6 : (p32 != -2 ? p32 : (sh.nc == 1 ? 0 : 12));
@@ -784,6 +828,7 @@ int persist_bwd_launch(const BwdGroup& g, const FragPtrs& fp, int B, int T, int 
     size_t bytes[M3T_MAX_SCANS];
     const bool b16 = persist_bwd_uses_16(g, B, T, flags);
     fill_exchange(g, fp, sh, b16 ? 8 : 16, ex, bytes);
+    if (flags & M3T_SCAN_FAULT) ex.fault_step = T / 2;
     {
         static const int pb = poll_env("M3T_SCAN_POLL_BWD", 12), al = poll_env("M3T_SCAN_POLL_ALIGN", 6);
         ex.poll_fixed = pb;
@@ -844,6 +889,8 @@ int persist_profile(unsigned long long* out6) {
 }  // namespace m3t_gru
 
 extern "C" int m3t_gru_persist_count(void) { return m3t_gru::persist_launch_count(); }
+
+extern "C" int m3t_gru_poll_error(void) { return m3t_gru::persist_poll_error(); }
 
 extern "C" int m3t_gru_scan_events(void* start, void* end) {
     m3t_gru::persist_set_events((hipEvent_t)start, (hipEvent_t)end);

@@ -14,6 +14,7 @@ M3T_BF16 = 2
 M3T_GEMM_EXCLUSIVE = 8
 M3T_SCAN_FP32 = 4
 M3T_SCAN_WHH = 8
+M3T_SCAN_FAULT = 16
 M3T_MAX_SCANS = 8
 
 _f = C.c_void_p      # device pointer
@@ -45,12 +46,14 @@ SIGNATURES = {
     "m3t_gru_scan_fwd": [C.POINTER(GruFwdDesc), _i, _i, _i, _f, _z, _i, _s],
     "m3t_gru_scan_bwd": [C.POINTER(GruBwdDesc), _i, _i, _i, _f, _z, _i, _s],
     "m3t_gru_persist_count": [],
+    "m3t_gru_poll_error": [],
     "m3t_gru_scan_after": [C.c_void_p],
     "m3t_gru_scan_events": [C.c_void_p, C.c_void_p],
     "m3t_gru_persist_profile": [C.c_void_p],
     "m3t_att_fuse_fwd": [_f, _f, _f, _f, _f, _i, _i, _s],
     "m3t_att_fuse_bwd": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _s],
-    "m3t_va_loss": [_f, _i, _i, _i, _i, _f, _f, _f, _f, _i, C.c_float, C.c_float, C.c_float, _i, _f, _f, _s],
+    "m3t_va_loss": [_f, _i, _i, _i, _i, _f, _f, _f, _f, _i, C.c_float, C.c_float, C.c_float, _i, _f, _f, _f, _z, _s],
+    "m3t_va_loss_ws_bytes": [_i],
     "m3t_weight_norm_fwd": [_f, _f, _f, _f, _i, _i, _i, _s],
     "m3t_weight_norm_bwd": [_f, _f, _f, _f, _f, _f, _i, _i, _i, _s],
     "m3t_causal_conv_fwd": [_f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _s],
@@ -74,11 +77,11 @@ SIGNATURES = {
     "m3t_power_to_db": [_f, C.c_longlong, C.c_float, C.c_float, _f, _f, _z, _s],
     "m3t_stack_context": [_f, C.c_longlong, _i, C.c_longlong, _i, _i, _i, _f, _s],
     "m3t_grad_norm_scale": [_f, _z, C.c_float, C.c_float, _f, _f, _z, _s],
-    "m3t_adam_step": [_f, _f, _f, _f, _z, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _i, _s],
-    "m3t_sgd_step": [_f, _f, _f, _z, C.c_float, C.c_float, C.c_float, _i, _s],
+    "m3t_adam_step": [_f, _f, _f, _f, _z, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _i, _f, _s],
+    "m3t_sgd_step": [_f, _f, _f, _z, C.c_float, C.c_float, C.c_float, _i, _f, _s],
 }
 
-RESTYPES = {"m3t_bn_rows_ws_bytes": C.c_size_t}
+RESTYPES = {"m3t_bn_rows_ws_bytes": C.c_size_t, "m3t_va_loss_ws_bytes": C.c_size_t}
 
 _lib = None
 
@@ -110,4 +113,17 @@ def load():
 
 def check(rc, what):
     if rc != 0:
-        raise M3THipError("%s failed with code %d%s" % (what, rc, " (M3T_EINVAL: bad arguments)" if rc == M3T_EINVAL else " (hipError_t)"))
+        note = {M3T_EINVAL: " (M3T_EINVAL: bad arguments)",
+                M3T_ESPIN: " (M3T_ESPIN: an earlier persistent GRU scan gave up waiting for a peer workgroup; its results are invalid)"}
+        raise M3THipError("%s failed with code %d%s" % (what, rc, note.get(rc, " (hipError_t)")))
+
+
+def poll_scan_error(what="persistent GRU scan"):
+    """Raise M3THipError if a persistent scan has hit its spin limit since the last poll (include/m3t_hip.h, error model).
+    No synchronisation happens here: synchronise first when the answer must cover work still in flight."""
+    if _lib is None:
+        return
+    step = _lib.m3t_gru_poll_error()
+    if step:
+        raise M3THipError("%s: a workgroup gave up waiting for its peers at step %d (M3T_ESPIN); outputs and gradients of "
+                          "that scan are invalid -- is another process running persistent scans on this GPU?" % (what, step - 1))

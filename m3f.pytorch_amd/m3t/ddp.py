@@ -41,7 +41,16 @@ class FlatGradDDP:
         self.max_norm = max_norm
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        if self.world > 1:
+            # replicas must start identical: torch DDP (what Lightning's 'ddp' wraps the reference in, train.py:40)
+            # broadcasts rank 0's parameters and buffers at construction; so does this.  Frozen parameters and buffers
+            # (BatchNorm running statistics) included.
+            self.broadcast_state()
         params = [p for p in module.parameters() if p.requires_grad]
+        if bucket_order is not None:
+            # parameters frozen before construction (freeze_enc, reference models/model.py:377-386) drop out of the buckets
+            bucket_order = [[p for p in b if p.requires_grad] for b in bucket_order]
+            bucket_order = [b for b in bucket_order if b]
         if bucket_order is None:
             seen, bucket_order = set(), []
             for child in reversed(list(module.children())):
@@ -107,6 +116,14 @@ class FlatGradDDP:
                 for p in b:
                     ops.register_grad_sink(p, p.grad)
 
+    def broadcast_state(self, src=0):
+        """rank `src`'s parameters and buffers to every rank (construction, and after a checkpoint is loaded on one rank)"""
+        if self.world <= 1:
+            return
+        with torch.no_grad():
+            for t in list(self.module.parameters()) + list(self.module.buffers()):
+                dist.broadcast(t.data, src=dist.get_global_rank(self.pg, src) if self.pg is not None else src, group=self.pg)
+
     def _make_hook(self, bi):
         def hook(_p):
             self._left[bi] -= 1
@@ -137,4 +154,9 @@ class FlatGradDDP:
             for h in self._handles:
                 h.wait()
         self.last_norm = self._finalize(self.flat, self.world, self.max_norm)
+        # a persistent GRU scan that died leaves garbage gradients.  Two nets: the finalize kernel reads the scan error
+        # word on the device, in stream order (gradients zeroed, norm = NaN, the fused optimizer steps skip on a
+        # non-finite norm) -- and this poll of the same word raises as soon as the failure is visible to the host
+        # (no synchronisation here: at the latest on the next step's finish()).
+        ops.poll_scan_error()
         return self.last_norm

@@ -291,6 +291,12 @@ class _Linear(torch.autograd.Function):
             sgemm(0, 0, M, K, N, dy, 0, N, w, 0, K, dx, 0, K, prec=ctx.prec, exclusive=True)
         w_sink = _take_sink(ctx.weight_ref) if (ctx.needs_input_grad[1] and ctx.weight_ref is not None) else None
         b_sink = _take_sink(ctx.bias_ref) if (ctx.has_bias and ctx.needs_input_grad[2] and ctx.bias_ref is not None) else None
+        if (ctx.needs_input_grad[1] and ctx.weight_ref is not None and w_sink is None) or \
+                (ctx.has_bias and ctx.needs_input_grad[2] and ctx.bias_ref is not None and b_sink is None):
+            # a sink exists but was already taken this step (the parameter is used twice in the graph, or gradients are being
+            # accumulated over several backward passes): autograd will ADD the tensor returned below onto the slice on this
+            # stream, while the first use may still be writing that slice on the weight-gradient stream -- order them
+            join_wgrad(x.device)
         # gradients that go straight into the flat buffer feed nothing on the chain: they run on the weight-gradient stream
         # (joined by FlatGradDDP.finish(), see join_wgrad) beside whatever backward does next
         off_chain = torch.cuda.stream(wgrad_stream(x.device)) if (_WGRAD_ENABLED and _WGRAD_DEFER_JOIN and _LINEAR_OFF_CHAIN and x.is_cuda) else None
@@ -328,6 +334,7 @@ def linear(x, w, b=None, act=0):
 
 # ----------------------------------------------------------------------------- BiGRU
 SCAN_PER_STEP = [False]     # tests/benchmarks: force the launch-per-step scan path
+SCAN_FAULT = [False]        # tests: fault injection (M3T_SCAN_FAULT), see include/m3t_hip.h
 SCAN_FP32 = [False]         # tests: keep the persistent forward scan on fp32 MFMAs (bit-identical to the per-step kernels)
 
 
@@ -340,7 +347,15 @@ def _scan_flags(device):
     unless the caller fences them against every other scan with events (the interleaved schedule of _MultiBiGRU)."""
     if SCAN_PER_STEP[0] or (_ws_tag(device) == "side" and not _FENCED[0]):
         return _lib.M3T_SCAN_NO_PERSIST
-    return _lib.M3T_SCAN_FP32 if SCAN_FP32[0] else 0
+    return (_lib.M3T_SCAN_FP32 if SCAN_FP32[0] else 0) | (_lib.M3T_SCAN_FAULT if SCAN_FAULT[0] else 0)
+
+
+def poll_scan_error(sync=False):
+    """raise M3THipError if a persistent scan has died since the last poll (sync=True: wait for the device first, so the
+    answer covers everything issued so far)"""
+    if sync:
+        torch.cuda.synchronize()
+    _lib.poll_scan_error()
 
 
 _DEFER_FENCE = os.environ.get("M3T_SCAN_DEFER_FENCE", "1") != "0"
@@ -752,10 +767,11 @@ class _VALoss(torch.autograd.Function):
                 raise M3THipError("labels must be device tensors")
         stats = torch.empty(8, dtype=torch.float32, device=y.device)
         dy = torch.empty_like(y)
+        ws = workspace(y.device)
         rc = lib().m3t_va_loss(_p(y), rows, Cc, iv, ia, _p(val), _p(aro),
                                C.c_void_p(cls.data_ptr()) if cls is not None else None,
                                C.c_void_p(vld.data_ptr()) if vld is not None else None,
-                               n_expr, w_v, w_a, expr_w, int(use_mse), _p(stats), _p(dy), _stream())
+                               n_expr, w_v, w_a, expr_w, int(use_mse), _p(stats), _p(dy), _p(ws), ws.numel() * 4, _stream())
         _lib.check(rc, "m3t_va_loss")
         ctx.save_for_backward(dy)
         ctx.mark_non_differentiable(stats)

@@ -58,3 +58,50 @@ class TcnGru(nn.Module):
 
     def forward(self, x):
         return self.gru(self.tcn.forward_btc(ops.bct_to_btc(x)))
+
+
+# ---------------------------------------------------------------------------------------------- the timed step
+# ONE definition of "a step" for bench.py, tools/aux_bench.py and the full-size parity tests (tests/test_gpu_bench_path.py):
+# what the test pins against the reference-generated goldens is, line for line, what the bench times.
+def c3_bucket_order(model):
+    """gradient buckets of the C3/C4 graph in the order backward finishes them (fusion -> att_fuse + proj_v -> encoders)"""
+    return [list(model.fusion.parameters()),
+            list(model.att_fuse.parameters()) + list(model.proj_v.parameters()),
+            list(model.visual.parameters()) + list(model.audio.parameters())]
+
+
+def make_c3_step(model, batch, max_norm=1.0, **ddp_kw):
+    """(ddp, step) for the C3/C4 workload: zero_grad -> forward -> ccc_mtl loss (valence = output 7, arousal = output 8,
+    reference models/model.py:153,164,176-177) -> backward -> FlatGradDDP.finish() (gradient all-reduce for N > 1, 1/N,
+    clip at max_norm: reference train.py:35).  batch: dict x_a [B,T,d_a], x_v [B,T,d_v], valence, arousal, class_expr,
+    expr_valid (device tensors).  step() returns (loss, stats, y)."""
+    from .ddp import FlatGradDDP
+    ddp = FlatGradDDP(model, bucket_order=c3_bucket_order(model), max_norm=max_norm, **ddp_kw)
+
+    def step():
+        ddp.zero_grad()
+        y = model(batch["x_a"], batch["x_v"])
+        loss, stats = ops.va_loss(y, batch["valence"], batch["arousal"], batch["class_expr"], batch["expr_valid"],
+                                  iv=7, ia=8, n_expr=7, w_v=0.5, w_a=0.5, expr_w=0.8)
+        loss.backward()
+        ddp.finish()
+        return loss, stats, y
+
+    return ddp, step
+
+
+def make_seq_step(model, x, valence, arousal, max_norm=1.0, **ddp_kw):
+    """(ddp, step) for the single-input sequence workloads (C1 TcnHead, C2 TcnGru): `ccc` loss on the last two outputs
+    (reference models/model.py:153-164 with loss='ccc'), FlatGradDDP over one bucket."""
+    from .ddp import FlatGradDDP
+    ddp = FlatGradDDP(model, bucket_order=[list(model.parameters())], max_norm=max_norm, **ddp_kw)
+
+    def step():
+        ddp.zero_grad()
+        y = model(x)
+        loss, stats = ops.va_loss(y, valence, arousal)
+        loss.backward()
+        ddp.finish()
+        return loss, stats, y
+
+    return ddp, step

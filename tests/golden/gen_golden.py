@@ -225,7 +225,7 @@ def _mtl_loss(model, y_hat, val, aro, expr, valid):
     return loss, l_v, l_a
 
 
-def case_c3(name, B, T, seed, d_a=128, d_v=256, nh=512):
+def case_c3(name, B, T, seed, d_a=128, d_v=256, nh=512, with_norm=False):
     rs = np.random.RandomState(seed)
     m = fill_module(RefAVFeatureGraph(d_a, d_v, nh), seed + 1).eval()
     lossmod = AffWild2VA(hp(modality="audio", loss="ccc_mtl"))
@@ -241,11 +241,17 @@ def case_c3(name, B, T, seed, d_a=128, d_v=256, nh=512):
     ccc_v = concordance_cc2(y[..., 7].reshape(-1), val.reshape(-1), "none").squeeze()
     ccc_a = concordance_cc2(y[..., -1].reshape(-1), aro.reshape(-1), "none").squeeze()
     grads = {"gd." + n: grad_digest(p.grad.numpy()) for n, p in m.named_parameters()}
+    if with_norm:
+        # what Lightning's gradient_clip_val=1.0 computes (reference train.py:35): the global L2 norm of all gradients
+        gn = torch.nn.utils.clip_grad_norm_(list(m.parameters()), 1.0)
+        grads["grad_norm"] = np.array(float(gn))
+        grads.update({"gdc." + n: grad_digest(p.grad.numpy()) for n, p in m.named_parameters()})      # after the clip
     save(name, seed=np.array(seed), dims=np.array([B, T, d_a, d_v, nh]), y=y.detach().numpy(),
          loss=loss.detach().numpy(), loss_v=l_v.detach().numpy(), loss_a=l_a.detach().numpy(),
          ccc_v=ccc_v.detach().numpy(), ccc_a=ccc_a.detach().numpy(),
          dx_a=grad_digest(xa.grad.numpy()), dx_v=grad_digest(xv.grad.numpy()),
-         dx_a_full=xa.grad.numpy()[:, ::25], dx_v_full=xv.grad.numpy()[:, ::25], **grads)
+         dx_a_full=xa.grad.numpy()[:, ::(60 if with_norm else 25)], dx_v_full=xv.grad.numpy()[:, ::(60 if with_norm else 25)],
+         dx_t_stride=np.array(60 if with_norm else 25), **grads)
 
 
 class RefTcnHead(nn.Module):
@@ -273,7 +279,7 @@ class RefTcnGru(nn.Module):
         return self.gru(self.tcn(x).transpose(1, 2))
 
 
-def case_seq_model(name, ctor, in_shape, seed, ccc_out=True):
+def case_seq_model(name, ctor, in_shape, seed, ccc_out=True, with_norm=False):
     rs = np.random.RandomState(seed)
     m = fill_module(ctor(), seed + 1).eval()
     lossmod = AffWild2VA(hp(modality="audio", loss="ccc"))
@@ -287,8 +293,12 @@ def case_seq_model(name, ctor, in_shape, seed, ccc_out=True):
     loss = 0.5 * l_v + 0.5 * l_a
     loss.backward()
     grads = {"gd." + n: grad_digest(p.grad.numpy()) for n, p in m.named_parameters()}
+    if with_norm:
+        gn = torch.nn.utils.clip_grad_norm_(list(m.parameters()), 1.0)
+        grads["grad_norm"] = np.array(float(gn))
     save(name, seed=np.array(seed), in_shape=np.array(in_shape), y=y.detach().numpy(), loss=loss.detach().numpy(),
-         dx=grad_digest(x.grad.numpy()), dx_full=x.grad.numpy()[:, :, ::10] if x.dim() == 3 else x.grad.numpy(),
+         dx=grad_digest(x.grad.numpy()),
+         dx_full=(x.grad.numpy()[:, ::4, ::30] if with_norm else x.grad.numpy()[:, :, ::10]) if x.dim() == 3 else x.grad.numpy(),
          **grads)
 
 
@@ -549,6 +559,11 @@ def main():
     if want("c3"):
         case_c3("c3_av_graph", 2, 300, 12345)
         case_c3("c3_av_graph_small", 3, 17, 800, d_a=10, d_v=12, nh=512)
+    if want("b32"):
+        # BASELINE size: exactly the batch bench.py times (32 clips x 300 frames per GPU); y + gradient digests + the
+        # clip norm only (weights and inputs are regenerated from the seed)
+        case_c3("c3_av_graph_b32", 32, 300, 12345, with_norm=True)
+        case_seq_model("c2_tcn_gru_b32", lambda: RefTcnGru(256, 512), (32, 256, 300), 12345, with_norm=True)
     if want("init"):
         case_init_digests("init_digests")
     if want("stitch"):

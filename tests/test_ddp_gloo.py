@@ -118,3 +118,76 @@ def test_single_process_flat_views_and_accumulation():
     for a, b in zip(net.parameters(), ref.parameters()):
         assert torch.allclose(a.grad, b.grad, atol=1e-7)
     assert abs(float(ddp.flat.norm()) - float(torch.cat([p.grad.reshape(-1) for p in ref.parameters()]).norm())) < 1e-6
+
+
+def _bcast_worker(rank, world, port, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)                       # replicas that would silently diverge
+    net = nn.Sequential(nn.Linear(6, 16), nn.BatchNorm1d(16), nn.Tanh(), nn.Linear(16, 2))
+    with torch.no_grad():
+        net[1].running_mean.add_(float(rank + 1))
+    net[3].weight.requires_grad = False                 # frozen parameters are synchronised too
+    ddp = FlatGradDDP(net, max_norm=0.0, finalize=torch_finalize, flatten_params=True)
+    state = torch.cat([t.detach().reshape(-1).float() for t in list(net.parameters()) + list(net.buffers())])
+    # the parameters are views of the flat buffer AND were broadcast
+    assert all(p.data_ptr() >= ddp.flat_params.data_ptr() for p in net.parameters() if p.requires_grad)
+    out_q.put((rank, state.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_construction_broadcasts_rank0_parameters_and_buffers():
+    """torch DDP (the reference's Lightning 'ddp' backend, train.py:40) broadcasts rank 0's state at construction; ranks
+    that seed differently must still start as identical replicas"""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bcast_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0] == res[1]
+    torch.manual_seed(100)
+    ref = nn.Sequential(nn.Linear(6, 16), nn.BatchNorm1d(16), nn.Tanh(), nn.Linear(16, 2))
+    assert torch.allclose(torch.tensor(res[1][:6 * 16]), ref[0].weight.detach().reshape(-1))     # rank 0's values won
+
+
+def test_trainer_epoch_schedulers_and_freeze_enc_host_logic(tmp_path):
+    """m3t.trainer on CPU (no optimizer step is taken: the fused kernels need a GPU): freeze_enc happens before the flat
+    buffers are built, plateau / exp schedules follow torch's own scheduler classes as the reference configures them
+    (models/model.py:399-407), best-val_loss bookkeeping."""
+    import argparse
+    from models.model import AffWild2VA
+    from m3t.trainer import Trainer
+    ns = AffWild2VA.add_model_specific_args(argparse.ArgumentParser(add_help=False)).parse_args([])
+    ns.modality, ns.fusion_type, ns.loss, ns.freeze_enc, ns.window = "audiovisual", "attention", "ccc_mtl", True, 4
+    ns.checkpoint_path = None
+    model = AffWild2VA(ns)
+    tr = Trainer.from_hparams(model, ns)
+    live = set(id(p) for m in (model.fusion, model.proj_v, model.att_fuse) for p in m.parameters())
+    assert all(p.requires_grad == (id(p) in live) for p in model.parameters())
+    assert sum(p.numel() for b in tr.ddp.buckets for p in b) == sum(p.numel() for p in model.parameters() if id(p) in live)
+    assert tr.ddp.flat.numel() < 0.25 * sum(p.numel() for p in model.parameters())      # the frozen encoders are outside
+    # plateau (the default): x0.5 after 3 epochs without improvement beyond the best, floor 1e-6
+    ref_opt = torch.optim.Adam([nn.Parameter(torch.zeros(1))], lr=ns.learning_rate, weight_decay=1e-4)
+    ref_s = torch.optim.lr_scheduler.ReduceLROnPlateau(ref_opt, factor=ns.decay_factor, patience=3, min_lr=1e-6)
+    losses = [1.0, 0.9, 0.95, 0.93, 0.92, 0.91, 0.905, 0.95, 0.96, 0.97, 0.98, 0.99, 1.0, 1.0, 1.0, 1.0]
+    best = float("inf")
+    for v in losses:
+        improved = tr.end_epoch(v)
+        ref_s.step(v)
+        assert improved == (v < best)
+        best = min(best, v)
+        assert tr.lr == ref_opt.param_groups[0]["lr"]
+    assert tr.lr < ns.learning_rate and tr.best_val_loss == min(losses) and tr.epoch == len(losses)
+    # exp: lr * decay_factor^epoch
+    ns2 = argparse.Namespace(**vars(ns))
+    ns2.scheduler, ns2.freeze_enc = "exp", False
+    tr2 = Trainer.from_hparams(AffWild2VA(ns2), ns2)
+    for e in range(1, 5):
+        tr2.end_epoch(None)
+        assert abs(tr2.lr - ns.learning_rate * ns.decay_factor ** e) < 1e-12

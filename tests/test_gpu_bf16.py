@@ -79,7 +79,7 @@ for M, N, K, tA, tB in ((9600, 1536, 512, 0, 1), (1536, 512, 9600, 1, 0), (2048,
     worst = max(worst, err / (2e-5 * max(1, K ** 0.5 / 8)))
 print("WORST", worst)
 """ % (os.path.join(root, "m3f.pytorch_amd"), root)
-    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, M3T_GEMM_X6C="1"), capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, M3T_GEMM_X6C="1", M3T_SCAN_LOCK="0"), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-1500:]
     worst = float([l for l in out.stdout.splitlines() if l.startswith("WORST")][-1].split()[1])
     assert worst <= 1.0, worst

@@ -100,3 +100,38 @@ def test_bench_two_ranks_on_one_gpu_gloo():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["value"] > 0
     assert d["cpu_baseline"] is None and d["scaling"] == "weak"
+
+
+def test_shared_linear_weight_with_deferred_sink_write():
+    """one nn.Linear weight used twice in a graph: the first backward node writes its gradient into the sink on the
+    weight-gradient stream (joined only in finish()), the second returns a tensor that autograd ADDS onto the same slice on
+    the main stream -- the two must be ordered (m3t.ops._Linear joins the stream when the sink is already taken).  Also two
+    backward passes without zero_grad in between (gradient accumulation)."""
+    from m3t import ops
+    from m3t.ddp import FlatGradDDP
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Linear(512, 512)
+
+        def forward(self, x):
+            h = ops.linear(x, self.lin.weight, self.lin.bias, 1)
+            return ops.linear(h, self.lin.weight, self.lin.bias, 0)
+
+    torch.manual_seed(2)
+    a, b = Net().to("cuda:0"), Net().to("cuda:0")
+    b.load_state_dict(a.state_dict())
+    x = torch.randn(9600, 512, device="cuda:0")
+    ddp = FlatGradDDP(a, max_norm=0.0)
+    for _ in range(3):
+        ddp.zero_grad()
+        a(x).square().mean().backward()
+        a(x).square().mean().backward()          # accumulation: second pass finds the sinks taken
+        ddp.finish()
+    for _ in range(2):
+        b(x).square().mean().backward()
+    torch.cuda.synchronize()
+    for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        assert torch.allclose(p.grad, q.grad, rtol=2e-5, atol=1e-7), (n, float((p.grad - q.grad).abs().max()))
+    ops.clear_grad_sinks()

@@ -1,0 +1,177 @@
+"""Error model of the persistent scans (include/m3t_hip.h): a dead scan is impossible to miss and cannot reach the
+parameters; one process per GPU owns the persistent path.  Every case runs in a FRESH child process: the error word, the
+spin limit and the ownership lock are per-process state.  M3T_SCAN_FAULT (fault injection) makes workgroup 0 of every
+persistent launch stay silent at step T/2, so its peers run into M3T_SCAN_SPIN_LIMIT (lowered here: the default is ~2 s)."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+_HEAD = r"""
+import sys
+for p in (%r, %r, %r):
+    sys.path.insert(0, p)
+import numpy as np, torch
+from m3t import ops, _lib
+""" % (os.path.join(ROOT, "m3f.pytorch_amd"), os.path.join(ROOT, "tests"), ROOT)
+
+
+def _run(code, **env):
+    e = dict(os.environ, M3T_SCAN_LOCK="0", **env)       # the parent pytest process may hold the ownership lock and is idle
+    e.update(env)
+    return subprocess.run([sys.executable, "-c", _HEAD + code], env=e, capture_output=True, text=True, timeout=600)
+
+
+def test_dead_forward_scan_is_reported_by_poll():
+    code = r"""
+from models.rnn import GRU
+torch.manual_seed(0)
+m = GRU(24, 128, 1, -1).to("cuda:0")
+x = torch.randn(16, 40, 24, device="cuda:0")
+n0 = _lib.load().m3t_gru_persist_count()
+ops.SCAN_FAULT[0] = True
+with torch.no_grad():
+    y = m(x)
+assert _lib.load().m3t_gru_persist_count() == n0 + 1, "the persistent path did not run"
+print("LAUNCHED", flush=True)
+ops.poll_scan_error(sync=True)        # must raise M3THipError (M3T_ESPIN): the process exits non-zero
+print("NOT-REPORTED", flush=True)
+"""
+    out = _run(code, M3T_SCAN_SPIN_LIMIT="3000")
+    assert "LAUNCHED" in out.stdout, out.stderr[-1500:]
+    assert out.returncode != 0 and "NOT-REPORTED" not in out.stdout
+    assert "M3T_ESPIN" in out.stderr and "M3THipError" in out.stderr
+
+
+def test_dead_scan_is_reported_by_the_next_scan_call():
+    code = r"""
+from models.rnn import GRU
+torch.manual_seed(0)
+m = GRU(24, 256, 2, 3, 2).to("cuda:0")
+x = torch.randn(16, 40, 24, device="cuda:0", requires_grad=True)
+ops.SCAN_FAULT[0] = True
+y = m(x)                                  # layer 0 dies; layer 1's call may or may not see it yet
+ops.SCAN_FAULT[0] = False
+torch.cuda.synchronize()
+try:
+    m(x)                                  # the first scan call after the failure became visible returns M3T_ESPIN
+except _lib.M3THipError as e:
+    assert "M3T_ESPIN" in str(e), str(e)
+    print("ESPIN-RETURNED", flush=True)
+y2 = m(x)                                 # the word is cleared by the report: the path works again
+torch.cuda.synchronize()
+ops.poll_scan_error()
+assert torch.isfinite(y2).all()
+print("RECOVERED", flush=True)
+"""
+    out = _run(code, M3T_SCAN_SPIN_LIMIT="3000")
+    assert out.returncode == 0, out.stderr[-1500:]
+    assert "ESPIN-RETURNED" in out.stdout and "RECOVERED" in out.stdout
+
+
+def test_dead_scan_never_reaches_the_parameters():
+    """Trainer.step with a dying backward/forward scan: the finalize kernel reads the error word on the device (gradients
+    zeroed, norm NaN), the fused Adam step skips itself, and the host raises at the next poll -- parameters and optimizer
+    state are exactly what they were."""
+    code = r"""
+import argparse
+from models.model import AffWild2VA
+from m3t.trainer import Trainer
+ns = AffWild2VA.add_model_specific_args(argparse.ArgumentParser(add_help=False)).parse_args([])
+ns.modality, ns.loss, ns.learning_rate, ns.scheduler = "audio", "ccc_mtl", 1e-3, "none"
+torch.manual_seed(1)
+model = AffWild2VA(ns).to("cuda:0")
+tr = Trainer.from_hparams(model, ns)
+rs = np.random.RandomState(0)
+f = lambda a: torch.from_numpy(a).to("cuda:0")
+B, T = 8, 40
+batch = {"audio": f(rs.standard_normal((B, T, 200)).astype(np.float32)),
+         "label_valence": f(rs.uniform(-1, 1, (B, T)).astype(np.float32)), "label_arousal": f(rs.uniform(-1, 1, (B, T)).astype(np.float32)),
+         "class_expr": f(rs.randint(0, 7, (B, T)).astype(np.int64)), "expr_valid": f(rs.uniform(size=(B, T)) < 0.7)}
+p0 = tr.ddp.flat_params.clone()
+tr.step(batch)
+torch.cuda.synchronize()
+assert not torch.equal(p0, tr.ddp.flat_params), "a healthy step must move the parameters"
+p1, m1, v1, t1 = tr.ddp.flat_params.clone(), tr.opt.m.clone(), tr.opt.v.clone(), tr.opt.t
+n0 = _lib.load().m3t_gru_persist_count()
+ops.SCAN_FAULT[0] = True
+raised = False
+try:
+    out = tr.step(batch)
+    torch.cuda.synchronize()
+    assert not np.isfinite(float(out["grad_norm"])), "the norm of a poisoned step must be NaN"
+except _lib.M3THipError:
+    raised = True                          # (the failure became visible to the host inside the step already)
+ops.SCAN_FAULT[0] = False
+torch.cuda.synchronize()
+assert _lib.load().m3t_gru_persist_count() > n0
+assert torch.equal(p1, tr.ddp.flat_params), "a dead scan reached the parameters"
+assert torch.equal(m1, tr.opt.m) and torch.equal(v1, tr.opt.v)
+if not raised:
+    try:
+        tr.step(batch)
+    except _lib.M3THipError as e:
+        raised = "M3T_ESPIN" in str(e)
+    torch.cuda.synchronize()
+    assert torch.equal(p1, tr.ddp.flat_params)
+assert raised, "the failure was never raised on the host"
+try:
+    tr.save_checkpoint("/tmp/m3t_should_not_exist.ckpt")     # clean again: saving works
+    print("SAVED", flush=True)
+finally:
+    import os
+    if os.path.exists("/tmp/m3t_should_not_exist.ckpt"):
+        os.remove("/tmp/m3t_should_not_exist.ckpt")
+print("PARAMETERS-INTACT", flush=True)
+"""
+    out = _run(code, M3T_SCAN_SPIN_LIMIT="3000")
+    assert out.returncode == 0, (out.stdout[-500:], out.stderr[-2500:])
+    assert "PARAMETERS-INTACT" in out.stdout
+
+
+def test_second_process_on_a_gpu_gets_the_launch_per_step_scans():
+    """one owner of the persistent scans per GPU (advisory lock on /tmp/m3t_persist_<pci-bus-id>.lock): this process takes
+    the lock by running a persistent scan, a second process on the same GPU must fall back to the launch-per-step path
+    (bit-identical results at H=128) instead of spinning against it"""
+    for p in (os.path.join(ROOT, "m3f.pytorch_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import hashlib
+    from m3t import _lib
+    from models.rnn import GRU
+    lib = _lib.load()
+    torch.manual_seed(9)
+    m = GRU(24, 128, 2, 3, 2).to("cuda:0")
+    x = torch.randn(16, 33, 24, device="cuda:0")
+    n0 = lib.m3t_gru_persist_count()
+    with torch.no_grad():
+        y = m(x)
+    torch.cuda.synchronize()
+    if os.environ.get("M3T_SCAN_LOCK") == "0" or lib.m3t_gru_persist_count() == n0:
+        pytest.skip("this process does not own the persistent scans (lock disabled or held elsewhere)")
+    mine = hashlib.sha256(y.cpu().numpy().tobytes()).hexdigest()
+    code = r"""
+import hashlib
+from models.rnn import GRU
+torch.manual_seed(9)
+m = GRU(24, 128, 2, 3, 2).to("cuda:0")
+x = torch.randn(16, 33, 24, device="cuda:0")
+with torch.no_grad():
+    y = m(x)
+torch.cuda.synchronize()
+print("COUNT", _lib.load().m3t_gru_persist_count())
+print("DIGEST", hashlib.sha256(y.cpu().numpy().tobytes()).hexdigest())
+"""
+    e = dict(os.environ)
+    e.pop("M3T_SCAN_LOCK", None)
+    out = subprocess.run([sys.executable, "-c", _HEAD + code], env=e, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-1500:]
+    assert "COUNT 0" in out.stdout, out.stdout
+    assert "another process owns the persistent GRU scans" in out.stderr
+    assert ("DIGEST " + mine) in out.stdout, "fallback results differ from the owner's persistent scans"

@@ -715,7 +715,9 @@ print("DIGEST", h.hexdigest())
     digests = []
     for extra in ({}, {"M3T_SCAN_POLL_FWD6": "0", "M3T_SCAN_POLL_FWD": "5", "M3T_SCAN_POLL_BWD": "0", "M3T_SCAN_POLL_ALIGN": "0"},
                   {"M3T_SCAN_POLL_FWD6": "20", "M3T_SCAN_POLL_BWD": "-1", "M3T_SCAN_POLL_ALIGN": "7"}):
-        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
+        # (M3T_SCAN_LOCK=0: this pytest process may own the GPU's persistent-scan lock and is idle while the child runs)
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, M3T_SCAN_LOCK="0", **extra), capture_output=True,
+                             text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-1500:]
         digests.append([l for l in out.stdout.splitlines() if l.startswith("DIGEST")][-1])
     assert digests[0] == digests[1] == digests[2], digests
