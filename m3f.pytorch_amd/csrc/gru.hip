@@ -753,7 +753,7 @@ static int scan_bwd_impl(const m3t_gru_bwd_desc* scans, int n_scans, int B, int 
     for (int i = 0; i < n_scans; ++i) {
         Hs[i] = scans[i].H;
         frag = frag && scans[i].H % 16 == 0;
-        need += (size_t)3 * scans[i].H * scans[i].H + xfrag_floats(scans[i].H, B, true);
+        need += (size_t)5 * scans[i].H * scans[i].H + xfrag_floats(scans[i].H, B, true);   // 5 H^2: fp32 (3 H^2) or bf16x3 (4.5 H^2) fragments
     }
     const bool whh = (flags & M3T_SCAN_WHH) != 0;      // desc.w_hh_t is the untransposed parameter w_hh [3H][H]
     if (whh && !(frag && need * sizeof(float) <= ws_bytes)) return M3T_EINVAL;
@@ -773,12 +773,12 @@ static int scan_bwd_impl(const m3t_gru_bwd_desc* scans, int n_scans, int B, int 
             bg.d[i] = d;
             bg.blk_start[i] = nblk;
             nblk += (d.H / 16) * nrb;
-            fp.wfrag[i] = p; p += (size_t)3 * d.H * d.H;
+            fp.wfrag[i] = p; p += (size_t)5 * d.H * d.H;
             fp.xfrag[i] = p; fp.xstride[i] = bpad * 3 * d.H; p += xfrag_floats(d.H, B, true);
         }
         for (int i = n_scans; i <= M3T_MAX_SCANS; ++i) bg.blk_start[i] = nblk;
         if (!(flags & M3T_SCAN_NO_PERSIST) && persist_bwd_check(bg, B, T)) {
-            for (int i = 0; i < n_scans && !persist_bwd_uses_16(bg, B, T, flags); ++i) {
+            for (int i = 0; i < n_scans && !persist_bwd_uses_16(bg, B, T, flags) && !persist_bwd_uses_x6(bg, B, T, flags); ++i) {
                 const int H = bg.d[i].H;
                 int blk = (3 * H * H + 255) / 256;
                 if (blk > 1024) blk = 1024;

@@ -94,6 +94,7 @@ bool persist_fwd_check(const FwdGroup& g, int B, int T);
 bool persist_bwd_check(const BwdGroup& g, int B, int T);
 bool persist_fwd_uses_x6(const FwdGroup& g, int B, int T, int flags);   // then wfrag holds bf16x3 fragments (18 H^2 bytes), filled by the launch itself
 int persist_fwd_launch(const FwdGroup& g, const FragPtrs& fp, int B, int T, int flags, hipStream_t s);
+bool persist_bwd_uses_x6(const BwdGroup& g, int B, int T, int flags);   // fp32-accurate bf16x6 backward: wfrag holds bf16x3 fragments (18 H^2 bytes), filled by the launch itself
 bool persist_bwd_uses_16(const BwdGroup& g, int B, int T, int flags);   // bf16 mode: wfrag holds bf16 fragments, filled by the launch itself
 int persist_bwd_launch(const BwdGroup& g, const FragPtrs& fp, int B, int T, int flags, hipStream_t s);
 int persist_launch_count();

@@ -558,6 +558,184 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd_kernel(BwdGroup g, FragPtr
         for (int i = 0; i < 6; ++i) ex.prof[i] = (unsigned long long)psum[i];
 }
 
+// ------------------------------------------------------------------------------------------------ backward, bf16x6
+// The recurrent product of the backward scan, dh_t = dgh_{t+1} W_hh (K = 3H), on the bf16 matrix pipe and still fp32-accurate:
+// at H = 512 a SIMD spent 96 fp32 MFMAs x 32 cycles = 3072 cycles per step on it (in-kernel stamps: MFMA 0.8 us + 1.2 us at
+// the barrier waiting for the partner wave's MFMAs, of a 4.1 us step).  The three gate gradients of a unit do not fit a 16-byte
+// granule once split in three (18 B + tag), so the CONSUMER splits: the granules stay {dr, dz, dn*r, tag} in fp32, and each
+// lane splits its 48 gathered values exactly into three bf16 terms (truncation split, ~11 VALU operations per pair of values)
+// while the partner wave of its SIMD multiplies -- vector and matrix instructions of different waves issue side by side.  Per
+// wave 36 v_mfma_f32_16x16x32_bf16 (6 products of weight >= 2^-16 per 32-deep k-step, smallest first) replace 48 fp32 MFMAs
+// at half their cycles each.  W_hh is split by the prep kernel into the B-operand order (72 VGPRs).  Results agree with the
+// fp32-MFMA kernel to fp32 rounding (M3T_SCAN_FP32 / M3T_SCAN_X6=0 keep that kernel and bit-identity with the per-step path).
+// wfrag[ub][wave][ks = gate*KS + h][term][lane][8]: term t of W_hh[gate*H + 16*(wave + 8*(2h + (e>>2))) + 4*(lane>>4) + (e&3)][ub*16 + (lane&15)]
+__global__ void wfrag_bwd6_prep_kernel(const float* __restrict__ w, unsigned short* __restrict__ wf, int H, int direct) {
+    const int ksn = 3 * (H >> 8);                     // k-steps per wave
+    const size_t total = (size_t)3 * H * H;           // one thread per weight: writes its three terms
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int e = i & 7, l = (i >> 3) & 63;
+        size_t r = i >> 9;
+        const int ks = r % ksn; r /= ksn;
+        const int wv = r % NW, ub = r / NW;
+        const int gt = ks / (H >> 8), h = ks % (H >> 8);
+        const int unit = 16 * (wv + NW * (2 * h + (e >> 2))) + 4 * (l >> 4) + (e & 3);
+        // direct: the untransposed parameter w_hh [3H][H] (M3T_SCAN_WHH); else w_hh_t [H][3H]
+        const float x = direct ? w[((size_t)gt * H + unit) * H + ub * 16 + (l & 15)]
+                               : w[((size_t)ub * 16 + (l & 15)) * 3 * H + (size_t)gt * H + unit];
+        const __bf16 b1 = (__bf16)x;
+        const float r1 = x - (float)b1;
+        const __bf16 b2 = (__bf16)r1;
+        const __bf16 b3 = (__bf16)(r1 - (float)b2);
+        const size_t base = ((((size_t)(ub * NW + wv) * ksn + ks) * 3)) * 512 + (size_t)l * 8 + e;
+        wf[base] = __builtin_bit_cast(unsigned short, b1);
+        wf[base + 512] = __builtin_bit_cast(unsigned short, b2);
+        wf[base + 1024] = __builtin_bit_cast(unsigned short, b3);
+    }
+}
+
+// Exact three-term split of a PAIR of fp32 values into packed bf16 pairs (first value in the low half).
+//   VAR 0: truncation -- t = upper half of the bits (v_perm packs a pair), remainder by one v_sub against the masked value:
+//          2 and + 2 sub per term and pair, 3 perm: 11 VALU instructions per pair
+//   VAR 1: the same with the mask in a register (no 32-bit literal in the v_and encodings)
+//   VAR 2: round to nearest even with v_cvt_pk_bf16_f32 + packed subtraction, as the GEMM's split3_pair: 9 per pair
+typedef float pf32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 pbf16x2 __attribute__((ext_vector_type(2)));
+template <int VAR>
+__device__ __forceinline__ void bwd6_split_pair(unsigned x0, unsigned x1, unsigned& o1, unsigned& o2, unsigned& o3, unsigned tmask) {
+    if (VAR == 2) {
+        const pf32x2 v = {__uint_as_float(x0), __uint_as_float(x1)};
+        o1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, pbf16x2));
+        const pf32x2 hf = {__uint_as_float(o1 << 16), __uint_as_float(o1 & 0xffff0000u)};
+        const pf32x2 r1 = v - hf;
+        o2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, pbf16x2));
+        const pf32x2 mf = {__uint_as_float(o2 << 16), __uint_as_float(o2 & 0xffff0000u)};
+        const pf32x2 r2 = r1 - mf;
+        o3 = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, pbf16x2));
+    } else {
+        const unsigned msk = VAR == 1 ? tmask : 0xffff0000u;
+        const float r0 = __uint_as_float(x0) - __uint_as_float(x0 & msk);
+        const float r1 = __uint_as_float(x1) - __uint_as_float(x1 & msk);
+        const float s0 = r0 - __uint_as_float(__float_as_uint(r0) & msk);
+        const float s1 = r1 - __uint_as_float(__float_as_uint(r1) & msk);
+        o1 = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
+        o2 = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
+        o3 = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+    }
+}
+
+template <int NC, int VAR>
+__global__ __launch_bounds__(NT) void gru_persist_bwd6_kernel(BwdGroup g, FragPtrs fp, ExPtrs ex, int B, int T, int G, int nrb,
+                                                             unsigned* err) {
+    constexpr int RT = 1, ROWS = 16, KS = NC / 2;
+    constexpr int H = 128 * NC, H3 = 3 * H, nchh = H >> 4;
+    __shared__ float red[2][NW][ROWS][UB + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gid = (int)blockIdx.x % G, ub = (int)blockIdx.x / G;
+    const int s = gid / nrb, rb = gid % nrb;
+    const m3t_gru_bwd_desc d = g.d[s];
+    const int j0 = ub * UB, r0 = rb * ROWS;
+
+    unsigned tmask;                                    // 0xffff0000 in a scalar register the compiler cannot fold back into literals
+    asm volatile("s_mov_b32 %0, 0xffff0000" : "=s"(tmask));
+    pbf16x8 wb[3 * KS][3];                             // [k-step = gate*KS + h][term]: 72 VGPRs at H = 512
+    {
+        const pu32x4* Wf = reinterpret_cast<const pu32x4*>(fp.wfrag[s]) + ((size_t)(ub * NW + wave) * 3 * KS * 3) * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < 3 * KS; ++k)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) wb[k][t] = __builtin_bit_cast(pbf16x8, Wf[(k * 3 + t) * 64]);
+    }
+    const bool pw = tid < ROWS * UB;                   // granule-order numbering, as in the forward kernel
+    const int prow = (tid >> 8) * 16 + (tid & 15), pu = ((tid >> 4) & 3) * 4 + ((tid >> 6) & 3);
+    const int pb = r0 + prow, pj = j0 + pu;
+    const bool pok = pw && pb < B;
+    float dh_carry = 0.f, z_next = 0.f;                // dh_{t+1} and z_{t+1} of this thread's (row, unit)
+    float sb_r = 0.f, sb_z = 0.f, sb_n = 0.f, sb_nr = 0.f;   // sums over t of the gate gradients: the bias gradients of this clip
+    if (pok && d.dh_n) dh_carry = d.dh_n[(size_t)pb * H + pj];
+
+    constexpr size_t TILE = (size_t)RT * 256;
+    u32x4* gran = reinterpret_cast<u32x4*>(ex.gran[s]);
+    const size_t slot = ex.slot[s];
+    const size_t grp = (size_t)rb * nchh * TILE;
+    const size_t pub = grp + (size_t)ub * TILE + tid;
+    bool dead = false;
+    int poll_delay = ex.poll_fixed >= 0 ? ex.poll_fixed : POLL_DELAY_INIT;
+    __shared__ unsigned poll_fail[2];                  // by step parity
+    __shared__ int pub_step;                           // steps this workgroup has published (thread 0)
+    if (tid == 0) pub_step = 0;
+    if (tid < 2) poll_fail[tid] = 0;                   // first read after the first barrier
+    const bool stamp = ex.prof != nullptr && blockIdx.x == 0 && tid == 0;
+    long long psum[6] = {0, 0, 0, 0, 0, 0}, last = stamp ? clock64() : 0;
+
+    // HBM traffic of a step and the chain.  Vector-memory operations retire in order, so everything a wave has issued
+    // before its gather loads sits in front of the gather's vmcnt(0): with the step's six result stores and the next
+    // step's three activation loads issued after the publish (the natural place), every step waited ~0.7 us for each
+    // group (tools/scan_bench.py ablation), and hipcc added a vmcnt(0) + register copies at the bottom of the step on
+    // top (2.4 of 5 us, in-kernel stamps).  Now: the results of step t are kept in registers and stored, and the
+    // activations of step t+1 are requested, right AFTER the gather of step t has completed -- they have the whole
+    // step (MFMAs, barrier, cell math, publish, the peers' latency) to retire before the next gather waits, and between
+    // the publish and the next gather a wave has nothing outstanding but the publish itself.  Two register sets (A for
+    // even steps, B for odd ones; the loop body is included twice) hold the activations; the loads are inline asm,
+    // UNCONDITIONAL (every thread, every step; lanes past the batch and the step past the end re-read a valid address):
+    // compiler-visible or conditional definitions make hipcc wait for them or merge them with copies that read
+    // registers still in flight.  A set is defined by the vmcnt(0) of the gather that precedes its use and laundered there.
+    float doutA, hprevA, doutB, hprevB;
+    f32x4 g4A, g4B;                                    // (r, z, n, W_hn h + b_hn) of this (row, unit, t)
+    const int pbc = pb < B ? pb : B - 1;
+    const float* pd0 = d.dout + (size_t)pbc * T * d.ldo + d.ooff + pj;
+    const float* pg0 = d.gates + (size_t)pbc * T * 4 * H + 4 * (size_t)pj;
+    const float* ph0 = d.out + (size_t)pbc * T * d.ldo + d.ooff + pj;
+#define M3T_BWD_LOAD_STEP(step_, DOUT, G4, HPREV)                                                                     \
+    do {                                                                                                               \
+        const int ls_ = (step_) < T ? (step_) : T - 1;                                                                 \
+        const int lt_ = d.reverse ? ls_ : T - 1 - ls_;                                                                 \
+        const int ltp_ = ls_ < T - 1 ? (d.reverse ? lt_ + 1 : lt_ - 1) : lt_;                                          \
+        asm volatile("global_load_dword %0, %3, off\n\t"                                                               \
+                     "global_load_dwordx4 %1, %4, off\n\t"                                                             \
+                     "global_load_dword %2, %5, off"                                                                   \
+                     : "=&v"(DOUT), "=&v"(G4), "=&v"(HPREV)                                                            \
+                     : "v"(pd0 + (size_t)lt_ * d.ldo), "v"(pg0 + (size_t)lt_ * 4 * H), "v"(ph0 + (size_t)ltp_ * d.ldo)  \
+                     : "memory");                                                                                      \
+    } while (0)
+    M3T_BWD_LOAD_STEP(0, doutA, g4A, hprevA);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(doutA), "+v"(g4A), "+v"(hprevA) :: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0), visible to hipcc: no wait for the weight fragments inside the loop
+    float st_dr = 0.f, st_dz = 0.f, st_dn = 0.f, st_dnr = 0.f;     // results of the previous step, stored after this step's gather
+    auto store_results = [&](int step_of) {
+        const int t = d.reverse ? step_of : T - 1 - step_of;
+        float* gx = d.dgx + ((size_t)pb * T + t) * d.ldg + d.goff;
+        gx[pj] = st_dr; gx[H + pj] = st_dz; gx[2 * H + pj] = st_dn;
+        float* gh = d.dgh + ((size_t)pb * T + t) * H3;
+        gh[pj] = st_dr; gh[H + pj] = st_dz; gh[2 * H + pj] = st_dnr;
+    };
+
+    for (int step2 = 0; step2 < T; step2 += 2) {
+#define STEPV step2
+#define CUR(x) x##A
+#define NXT(x) x##B
+#include "gru_persist_bwd6_step.inc"
+#undef STEPV
+#undef CUR
+#undef NXT
+        if (step2 + 1 >= T) break;
+#define STEPV (step2 + 1)
+#define CUR(x) x##B
+#define NXT(x) x##A
+#include "gru_persist_bwd6_step.inc"
+#undef STEPV
+#undef CUR
+#undef NXT
+    }
+#undef M3T_BWD_LOAD_STEP
+    if (pok) d.dh[(size_t)pb * H + pj] = dh_carry;
+    if (pok && d.db_part) {
+        float* q = d.db_part + (size_t)pb * 4 * H + pj;
+        q[0] = sb_r; q[H] = sb_z; q[2 * H] = sb_n; q[3 * H] = sb_nr;
+    }
+    if (stamp)
+        for (int i = 0; i < 6; ++i) ex.prof[i] = (unsigned long long)psum[i];
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 unsigned long long* g_prof = nullptr;   // device buffer of phase stamps when M3T_SCAN_PROF=1
 int g_launches = 0;                 // persistent launches issued by this process (m3t_gru_persist_count)
@@ -778,6 +956,15 @@ bool persist_bwd_uses_16(const BwdGroup& g, int B, int T, int flags) {
     return sh.rt == 1 && (sh.nc == 2 || sh.nc == 4);
 }
 
+// the fp32-accurate backward scan runs its recurrent product as bf16x6 (gru_persist_bwd6_kernel) for H = 256 / 512 at 16
+// rows per workgroup; M3T_SCAN_FP32 / M3T_SCAN_X6=0 keep the fp32-MFMA kernel (bit-identical to the per-step path)
+bool persist_bwd_uses_x6(const BwdGroup& g, int B, int T, int flags) {
+    Shape sh;
+    static const int bwd_on = poll_env_early("M3T_SCAN_BWD_X6", 1);      // 0: fp32 MFMAs in the backward scan only (A/B runs)
+    if (!bwd_on || g.bf16 || (flags & M3T_SCAN_FP32) || !x6_scan_enabled() || !level_shape(g.d, g.n, B, sh)) return false;
+    return sh.rt == 1 && (sh.nc == 2 || sh.nc == 4);
+}
+
 int persist_fwd_launch(const FwdGroup& g, const FragPtrs& fp, int B, int T, int flags, hipStream_t s) {
     Shape sh;
     if (!level_shape(g.d, g.n, B, sh) || !ensure_err_word()) return M3T_EINVAL;
@@ -851,6 +1038,25 @@ int persist_bwd_launch(const BwdGroup& g, const FragPtrs& fp, int B, int T, int 
         persist_record_start(s);
         if (sh.nc == 2) hipLaunchKernelGGL(gru_persist_bwd16_kernel<2>, dim3(sh.grid), dim3(NT), exclusive_lds(gru_persist_bwd16_kernel<2>, sh.grid), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
         else hipLaunchKernelGGL(gru_persist_bwd16_kernel<4>, dim3(sh.grid), dim3(NT), exclusive_lds(gru_persist_bwd16_kernel<4>, sh.grid), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
+        persist_record_end(s);
+        M3T_LAUNCH_CHECK();
+        return 0;
+    }
+    if (persist_bwd_uses_x6(g, B, T, flags)) {
+        for (int i = 0; i < g.n; ++i) {                                      // W_hh -> bf16x3 B-operand fragments
+            const int H = g.d[i].H;
+            int blk = (3 * H * H + 255) / 256;
+            if (blk > 1024) blk = 1024;
+            wfrag_bwd6_prep_kernel<<<blk, 256, 0, s>>>(g.d[i].w_hh_t, reinterpret_cast<unsigned short*>(fp.wfrag[i]), H, (flags & M3T_SCAN_WHH) ? 1 : 0);
+        }
+        M3T_LAUNCH_CHECK();
+        { const int e = persist_take_after(s); if (e) return e; }
+        persist_record_start(s);
+        static const int var = poll_env("M3T_SCAN_BWD6_VAR", 0);
+        static const BwdKernel k6[2][3] = {{gru_persist_bwd6_kernel<2, 0>, gru_persist_bwd6_kernel<2, 1>, gru_persist_bwd6_kernel<2, 2>},
+                                           {gru_persist_bwd6_kernel<4, 0>, gru_persist_bwd6_kernel<4, 1>, gru_persist_bwd6_kernel<4, 2>}};
+        const BwdKernel kk = k6[sh.nc == 4][var >= 0 && var <= 2 ? var : 0];
+        hipLaunchKernelGGL(kk, dim3(sh.grid), dim3(NT), exclusive_lds(kk, sh.grid), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
         persist_record_end(s);
         M3T_LAUNCH_CHECK();
         return 0;

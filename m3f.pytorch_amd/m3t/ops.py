@@ -157,19 +157,32 @@ def join_wgrad(device=None):
     backward whose gradients all went into gradient sinks); FlatGradDDP.finish() calls it before it touches the buffer"""
     for key, pending in list(_WGRAD_PENDING.items()):
         if pending and (device is None or key == (device.type, device.index)):
-            st = _WGRAD.get(key)
-            if st is not None:
+            for st in _WGRAD.get(key) or []:
                 torch.cuda.current_stream(torch.device(key[0], key[1])).wait_stream(st)
             _WGRAD_PENDING[key] = False
 
 
-def wgrad_stream(device):
+# Weight-gradient streams.  The weight-gradient GEMMs of a level are independent of each other and mostly small (audio dW_hh:
+# 768 x 256 x 9600 = 12 output tiles x split-K), so one stream runs them back to back at 30-40 TFLOP/s each: the tail of
+# backward after the last scan is ~1 ms of them (profiles/r02_timeline_*.txt).  Dealing them round-robin over TWO streams
+# (M3T_WGRAD_STREAMS=2, each stream with its own split-K workspace) was measured and is NOT the default: the tail shrinks,
+# but the extra concurrent GEMM stream takes CUs from the data-gradient GEMMs that sit on the scan chain and stretches the
+# scans it runs beside (interleaved A/B, 4 runs each, median ms per step: 17.21 with one stream, 17.77 with two).
+_N_WGRAD = max(1, int(os.environ.get("M3T_WGRAD_STREAMS", "1")))
+
+
+def wgrad_stream(device, i=0):
     key = (device.type, device.index)
-    st = _WGRAD.get(key)
-    if st is None:
-        st = torch.cuda.Stream(device=device)
-        _WGRAD[key] = st
-    return st
+    sts = _WGRAD.get(key)
+    if sts is None:
+        sts = [torch.cuda.Stream(device=device) for _ in range(_N_WGRAD)]
+        _WGRAD[key] = sts
+    return sts[i % len(sts)]
+
+
+def wgrad_streams(device):
+    wgrad_stream(device)
+    return _WGRAD[(device.type, device.index)]
 
 
 def _ws_tag(device):
@@ -177,8 +190,10 @@ def _ws_tag(device):
     st = _SIDE.get((device.type, device.index))
     if st is not None and cur == st:
         return "side"
-    st = _WGRAD.get((device.type, device.index))
-    return "wgrad" if st is not None and cur == st else "main"
+    for i, st in enumerate(_WGRAD.get((device.type, device.index)) or []):
+        if cur == st:
+            return "wgrad%d" % i
+    return "main"
 
 
 def workspace(device, nbytes=_WS_MIN, tag=None):
@@ -299,9 +314,9 @@ class _Linear(torch.autograd.Function):
             join_wgrad(x.device)
         # gradients that go straight into the flat buffer feed nothing on the chain: they run on the weight-gradient stream
         # (joined by FlatGradDDP.finish(), see join_wgrad) beside whatever backward does next
-        off_chain = torch.cuda.stream(wgrad_stream(x.device)) if (_WGRAD_ENABLED and _WGRAD_DEFER_JOIN and _LINEAR_OFF_CHAIN and x.is_cuda) else None
+        wg = wgrad_stream(x.device, _LINEAR_RR[0]) if (_WGRAD_ENABLED and _WGRAD_DEFER_JOIN and _LINEAR_OFF_CHAIN and x.is_cuda) else None
+        off_chain = torch.cuda.stream(wg) if wg is not None else None
         if off_chain is not None and (w_sink is not None or b_sink is not None):
-            wg = wgrad_stream(x.device)
             wg.wait_stream(torch.cuda.current_stream())
         if ctx.needs_input_grad[1]:
             if w_sink is not None and off_chain is not None:
@@ -325,7 +340,11 @@ class _Linear(torch.autograd.Function):
             dy.record_stream(wg)
             x.record_stream(wg)
             _WGRAD_PENDING[(x.device.type, x.device.index)] = True
+            _LINEAR_RR[0] += 1
         return dx, dw, db, None
+
+
+_LINEAR_RR = [0]      # round-robin over the weight-gradient streams
 
 
 def linear(x, w, b=None, act=0):
@@ -612,7 +631,12 @@ class _MultiBiGRU(torch.autograd.Function):
                               dinp[l][s], 0, I, accumulate=(d == 1), prec=prec)
                     cur[s] = dinp[l][s]
 
+        wgs = wgrad_streams(dev) if _WGRAD_ENABLED else None
+        rr = [0]
+
         def level_dw(l, idxs, background=False):           # off the chain: only the optimizer reads these
+            """the weight-gradient GEMMs of (l, idxs); with weight-gradient streams: dealt round-robin over them (the GEMMs are
+            independent of each other; every stream has waited for the scan)"""
             for s in idxs:
                 H = Hs[s]
                 inp, out, gts = layer_io(l, s)
@@ -621,31 +645,36 @@ class _MultiBiGRU(torch.autograd.Function):
                     base = s * per + 1 + (2 * l + d) * 4
                     dw_ih, dw_hh = out_grads[base:base + 2]      # the bias gradients come out of the scan itself
                     goff = d * B * T * 3 * H
-                    if T > 1:
-                        # dW_hh = sum_{b,t} dgh[b,t]^T h_prev(b,t): forward pairs (t, t-1), reverse pairs (t, t+1)
-                        a_off, b_off = (1, 0) if d == 0 else (0, 1)
-                        sgemm(1, 0, 3 * H, H, B * (T - 1), dgh[l][s], goff, 3 * H, out, d * H, 2 * H, dw_hh, 0, H,
-                              seg=(T - 1, T, a_off, b_off), prec=prec, background=background)
-                    else:
-                        dw_hh.zero_()
-                    sgemm(1, 0, 3 * H, I, B * T, dgx[l][s], d * 3 * H, 6 * H, inp, 0, I, dw_ih, 0, I, prec=prec,
-                          background=background)
+                    ctx_hh = torch.cuda.stream(wgs[rr[0] % len(wgs)]) if wgs is not None else _NULL
+                    ctx_ih = torch.cuda.stream(wgs[(rr[0] + 1) % len(wgs)]) if wgs is not None else _NULL
+                    rr[0] += 2
+                    with ctx_hh:
+                        if T > 1:
+                            # dW_hh = sum_{b,t} dgh[b,t]^T h_prev(b,t): forward pairs (t, t-1), reverse pairs (t, t+1)
+                            a_off, b_off = (1, 0) if d == 0 else (0, 1)
+                            sgemm(1, 0, 3 * H, H, B * (T - 1), dgh[l][s], goff, 3 * H, out, d * H, 2 * H, dw_hh, 0, H,
+                                  seg=(T - 1, T, a_off, b_off), prec=prec, background=background)
+                        else:
+                            dw_hh.zero_()
+                    with ctx_ih:
+                        sgemm(1, 0, 3 * H, I, B * T, dgx[l][s], d * 3 * H, 6 * H, inp, 0, I, dw_ih, 0, I, prec=prec,
+                              background=background)
 
-        wg = wgrad_stream(dev) if _WGRAD_ENABLED else None
-        if wg is not None:
-            wg.wait_stream(main)
+        if wgs is not None:
+            for w_ in wgs:
+                w_.wait_stream(main)
 
         def level_gemms(l, idxs):
-            """after the scan of (l, idxs) on the current stream: dX in line, dW on the weight-gradient stream"""
-            if wg is None:
+            """after the scan of (l, idxs) on the current stream: dX in line, dW on the weight-gradient streams"""
+            if wgs is None:
                 level_dx(l, idxs)
                 level_dw(l, idxs)
                 return
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
-            wg.wait_event(ev)
-            with torch.cuda.stream(wg):
-                level_dw(l, idxs, _WGRAD_BACKGROUND)
+            for w_ in wgs:
+                w_.wait_event(ev)
+            level_dw(l, idxs, _WGRAD_BACKGROUND)
             level_dx(l, idxs)
 
         if _interleaved(groups):
@@ -684,7 +713,7 @@ class _MultiBiGRU(torch.autograd.Function):
             for kind, _ in groups:
                 if kind == "side":
                     main.wait_stream(side_stream(dev))
-        if wg is not None:
+        if wgs is not None:
             weights_sunk = all(sunk[s * per + 1 + (2 * l + d) * 4 + j] for s in range(n_stacks) for l in range(L) for d in (0, 1) for j in (0, 1))
             if _WGRAD_DEFER_JOIN and weights_sunk:
                 # every weight gradient goes straight into the flat gradient buffer, which nobody reads before
@@ -693,10 +722,12 @@ class _MultiBiGRU(torch.autograd.Function):
                 for l in range(L):
                     for s in range(n_stacks):
                         for t in (dgx[l][s], dgh[l][s]) + tuple(layer_io(l, s)[:2]):
-                            t.record_stream(wg)
+                            for w_ in wgs:
+                                t.record_stream(w_)
                 _WGRAD_PENDING[(dev.type, dev.index)] = True
             else:
-                main.wait_stream(wg)
+                for w_ in wgs:
+                    main.wait_stream(w_)
         for s in range(n_stacks):
             out_grads[s * per] = dinp[0][s]
         return (None, None) + tuple(None if sunk[i] else g for i, g in enumerate(out_grads))

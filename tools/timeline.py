@@ -7,7 +7,7 @@ import sys
 
 db = sqlite3.connect(sys.argv[1])
 rows = list(db.cursor().execute("select name, start, end, stream_id from kernels order by start"))
-loss = [i for i, r in enumerate(rows) if "va_loss" in r[0]]
+loss = [i for i, r in enumerate(rows) if "va_loss_grad" in r[0] or "va_loss_kernel" in r[0]]
 seg = rows[loss[-2]:loss[-1]]
 
 
@@ -25,7 +25,8 @@ for n, s, e, st in seg:
     else:
         out.append([k, s, e, 1, e - s])
 thr = float(sys.argv[2]) if len(sys.argv) > 2 else 150e3
+lo, hi = (float(sys.argv[3]), float(sys.argv[4])) if len(sys.argv) > 4 else (-1e30, 1e30)      # optional window in ms
 for k, s, e, c, busy in out:
-    if busy > thr:
+    if busy > thr and lo <= (s - base) / 1e6 <= hi:
         print("st%d  %8.3f -> %8.3f ms  n=%4d busy %7.3f  %s" % (k[1], (s - base) / 1e6, (e - base) / 1e6, c, busy / 1e6, k[0]))
 print("step span %.3f ms" % ((seg[-1][2] - base) / 1e6))
