@@ -593,37 +593,22 @@ __global__ void wfrag_bwd6_prep_kernel(const float* __restrict__ w, unsigned sho
     }
 }
 
-// Exact three-term split of a PAIR of fp32 values into packed bf16 pairs (first value in the low half).
-//   VAR 0: truncation -- t = upper half of the bits (v_perm packs a pair), remainder by one v_sub against the masked value:
-//          2 and + 2 sub per term and pair, 3 perm: 11 VALU instructions per pair
-//   VAR 1: the same with the mask in a register (no 32-bit literal in the v_and encodings)
-//   VAR 2: round to nearest even with v_cvt_pk_bf16_f32 + packed subtraction, as the GEMM's split3_pair: 9 per pair
-typedef float pf32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 pbf16x2 __attribute__((ext_vector_type(2)));
-template <int VAR>
-__device__ __forceinline__ void bwd6_split_pair(unsigned x0, unsigned x1, unsigned& o1, unsigned& o2, unsigned& o3, unsigned tmask) {
-    if (VAR == 2) {
-        const pf32x2 v = {__uint_as_float(x0), __uint_as_float(x1)};
-        o1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, pbf16x2));
-        const pf32x2 hf = {__uint_as_float(o1 << 16), __uint_as_float(o1 & 0xffff0000u)};
-        const pf32x2 r1 = v - hf;
-        o2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, pbf16x2));
-        const pf32x2 mf = {__uint_as_float(o2 << 16), __uint_as_float(o2 & 0xffff0000u)};
-        const pf32x2 r2 = r1 - mf;
-        o3 = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, pbf16x2));
-    } else {
-        const unsigned msk = VAR == 1 ? tmask : 0xffff0000u;
-        const float r0 = __uint_as_float(x0) - __uint_as_float(x0 & msk);
-        const float r1 = __uint_as_float(x1) - __uint_as_float(x1 & msk);
-        const float s0 = r0 - __uint_as_float(__float_as_uint(r0) & msk);
-        const float s1 = r1 - __uint_as_float(__float_as_uint(r1) & msk);
-        o1 = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
-        o2 = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
-        o3 = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
-    }
+// Exact three-term split of a PAIR of fp32 values into packed bf16 pairs (first value in the low half), by truncation: a
+// term is the upper half of the bits (one v_perm packs a pair), the remainder one v_sub against the masked value: 2 and +
+// 2 sub per term and pair, 3 perm = 11 VALU instructions per pair.  Measured equal (tools/scan_bench.py, 3.49-3.54 us per
+// step at 4 x H=512): the mask in a register instead of a literal; round-to-nearest with v_cvt_pk_bf16_f32 + v_pk_add_f32
+// (250 instead of 264 VALU instructions per lane and step, as the GEMM's split3_pair).
+__device__ __forceinline__ void bwd6_split_pair(unsigned x0, unsigned x1, unsigned& o1, unsigned& o2, unsigned& o3) {
+    const float r0 = __uint_as_float(x0) - __uint_as_float(x0 & 0xffff0000u);
+    const float r1 = __uint_as_float(x1) - __uint_as_float(x1 & 0xffff0000u);
+    const float s0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u);
+    const float s1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+    o1 = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
+    o2 = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
+    o3 = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
 }
 
-template <int NC, int VAR>
+template <int NC>
 __global__ __launch_bounds__(NT) void gru_persist_bwd6_kernel(BwdGroup g, FragPtrs fp, ExPtrs ex, int B, int T, int G, int nrb,
                                                              unsigned* err) {
     constexpr int RT = 1, ROWS = 16, KS = NC / 2;
@@ -635,8 +620,6 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd6_kernel(BwdGroup g, FragPt
     const m3t_gru_bwd_desc d = g.d[s];
     const int j0 = ub * UB, r0 = rb * ROWS;
 
-    unsigned tmask;                                    // 0xffff0000 in a scalar register the compiler cannot fold back into literals
-    asm volatile("s_mov_b32 %0, 0xffff0000" : "=s"(tmask));
     pbf16x8 wb[3 * KS][3];                             // [k-step = gate*KS + h][term]: 72 VGPRs at H = 512
     {
         const pu32x4* Wf = reinterpret_cast<const pu32x4*>(fp.wfrag[s]) + ((size_t)(ub * NW + wave) * 3 * KS * 3) * 64 + lane;
@@ -1052,10 +1035,7 @@ int persist_bwd_launch(const BwdGroup& g, const FragPtrs& fp, int B, int T, int 
         M3T_LAUNCH_CHECK();
         { const int e = persist_take_after(s); if (e) return e; }
         persist_record_start(s);
-        static const int var = poll_env("M3T_SCAN_BWD6_VAR", 0);
-        static const BwdKernel k6[2][3] = {{gru_persist_bwd6_kernel<2, 0>, gru_persist_bwd6_kernel<2, 1>, gru_persist_bwd6_kernel<2, 2>},
-                                           {gru_persist_bwd6_kernel<4, 0>, gru_persist_bwd6_kernel<4, 1>, gru_persist_bwd6_kernel<4, 2>}};
-        const BwdKernel kk = k6[sh.nc == 4][var >= 0 && var <= 2 ? var : 0];
+        const BwdKernel kk = sh.nc == 2 ? gru_persist_bwd6_kernel<2> : gru_persist_bwd6_kernel<4>;
         hipLaunchKernelGGL(kk, dim3(sh.grid), dim3(NT), exclusive_lds(kk, sh.grid), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
         persist_record_end(s);
         M3T_LAUNCH_CHECK();

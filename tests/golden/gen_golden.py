@@ -38,7 +38,7 @@ from models.cbam import CBAM                                  # noqa: E402
 from models.resnet import ResNet, BasicBlock                  # noqa: E402
 from models.utils import concordance_cc2                      # noqa: E402
 from models.model import AffWild2VA                           # noqa: E402
-from models.backbone import VA_3DVGGM_Split, VA_3DResNet      # noqa: E402
+from models.backbone import VA_3DVGGM_Split, VA_3DResNet, VA_3DVGGM      # noqa: E402
 
 from recipe import fill_module, named_tensors, draw, grad_digest  # noqa: E402
 
@@ -364,6 +364,24 @@ def case_resnet3d(name, seed, B=2, T=3):
          dx=grad_digest(x.grad.numpy()), param_names=np.array(sorted(n for n, _ in m.named_parameters())), **grads)
 
 
+def case_vggm(name, seed, backend, B=2, T=4, training=False):
+    """VA_3DVGGM end to end from raw frames (reference models/backbone.py:62-161, forward :134-145): the unsplit VGG-M stem
+    -> TemporalConvNet(512,[512,512],3) + Linear(512,2) (backend 'tcn': the only TemporalConvNet user) or GRU (backend 'gru').
+    eval mode by default (TCN dropout off, BatchNorm on running stats)."""
+    rs = np.random.RandomState(seed)
+    m = fill_module(VA_3DVGGM(frameLen=T, backend=backend, nClasses=2, nFCs=2), seed + 1)
+    m = m.train() if training else m.eval()
+    x = torch.from_numpy(rs.randint(0, 256, (B, 3, T, 112, 112)).astype(np.float32))
+    x = ((x - 127.5) / 127.5).requires_grad_(True)
+    y = m(x)
+    ct = torch.from_numpy(draw(rs, tuple(y.shape)))
+    (y * ct).sum().backward()
+    grads = {"gd." + n: grad_digest(p.grad.numpy()) for n, p in m.named_parameters() if p.grad is not None}
+    save(name, seed=np.array(seed), dims=np.array([B, T]), y=y.detach().numpy(), ct=ct.numpy(),
+         dx=grad_digest(x.grad.numpy()), param_names=np.array(sorted(n for n, _ in m.named_parameters())),
+         state_dict_keys=np.array(sorted(m.state_dict().keys())), **grads)
+
+
 def case_init_digests(name):
     """Initial weights of the reference constructors under torch.manual_seed(12345) (the
     reference's default --seed, train.py:49), as digests: pins the RNG-order of the init recipes."""
@@ -575,6 +593,11 @@ def main():
     if want("c5"):
         case_affwild_av("c5_affwild_av", 900)
         case_resnet3d("c5_resnet3d_cbam", 910)
+    if want("vggm"):
+        case_vggm("vggm_tcn_eval", 920, "tcn")
+        case_vggm("vggm_gru_eval", 930, "gru", B=2, T=3)
+    if want("c5t16"):
+        case_affwild_av("c5_affwild_av_t16", 940, B=2, T=16)
 
 
 if __name__ == "__main__":

@@ -135,3 +135,83 @@ def test_shared_linear_weight_with_deferred_sink_write():
     for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
         assert torch.allclose(p.grad, q.grad, rtol=2e-5, atol=1e-7), (n, float((p.grad - q.grad).abs().max()))
     ops.clear_grad_sinks()
+
+
+_DDP_CHILD = r"""
+import os, sys
+for p in (%r, %r, %r):
+    sys.path.insert(0, p)
+import numpy as np, torch, torch.distributed as dist
+from golden.recipe import fill_module
+from m3t.ddp import FlatGradDDP, shard_indices
+from m3t import ops
+from models.rnn import GRU
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+torch.manual_seed(1000 + rank)                       # different initial weights per rank: construction must broadcast rank 0's
+net = GRU(12, 16, 2, 3, 2).to("cuda:0")
+if rank == 0:
+    fill_module(net, 5)
+ddp = FlatGradDDP(net, max_norm=0.05, overlap=False)      # the default schedule of the persistent-scan path: sinks + ONE all-reduce
+assert ddp.sinks and not ddp.overlap and ddp.world == world
+rs = np.random.RandomState(3)
+x = torch.from_numpy(rs.standard_normal((8, 9, 12)).astype(np.float32)).to("cuda:0")
+t = torch.from_numpy(rs.standard_normal((8, 9, 3)).astype(np.float32)).to("cuda:0")
+idx = shard_indices(8, rank, world)
+for _ in range(2):
+    ddp.zero_grad()
+    ((net(x[idx]) - t[idx]) ** 2).mean().backward()
+    norm = ddp.finish()                                   # HIP finalize: 1/N + clip on the all-reduced flat buffer
+torch.cuda.synchronize()
+assert not any(e[2] for e in ops._GRAD_SINKS.values()), "a gradient sink was not used"
+np.save(sys.argv[1] + ".%%d.npy" %% rank, torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu().numpy())
+np.save(sys.argv[1] + ".norm%%d.npy" %% rank, norm.cpu().numpy())
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_two_ranks_gru_sinks_hip_finalize_equal_mean_of_shard_gradients(tmp_path):
+    """The real N > 1 combination on the one GPU of the test box: two processes (gloo, both on cuda:0, launch-per-step scans:
+    two processes must not both run persistent scans on one device), GRU modules writing their weight gradients into gradient
+    sinks, overlap=False (ONE all-reduce of the flat buffer after backward), the fused HIP finalize (1/N + clip), and replicas
+    that seed differently (construction broadcasts rank 0's state).  Every rank must end with the clipped MEAN of the per-shard
+    gradients -- what the reference's DDP optimises (train.py:35,40)."""
+    import os
+    import subprocess
+    import sys
+    import numpy as np
+    from golden.recipe import fill_module
+    from m3t.ddp import shard_indices
+    from models.rnn import GRU
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = _DDP_CHILD % (os.path.join(root, "m3f.pytorch_amd"), os.path.join(root, "tests"), root)
+    script = tmp_path / "child.py"
+    script.write_text(code)
+    out = str(tmp_path / "g")
+    env = dict(os.environ, M3T_SCAN_PERSIST="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", str(script), out]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2500:]
+    g0, g1 = np.load(out + ".0.npy"), np.load(out + ".1.npy")
+    assert np.array_equal(g0, g1), "replicas diverged"
+    # single-process reference: mean over ranks of the per-shard gradients, then the clip
+    from m3t import ops
+    ops.SCAN_PER_STEP[0] = True
+    try:
+        net = fill_module(GRU(12, 16, 2, 3, 2), 5).to("cuda:0")
+        rs = np.random.RandomState(3)
+        x = torch.from_numpy(rs.standard_normal((8, 9, 12)).astype(np.float32)).to("cuda:0")
+        t = torch.from_numpy(rs.standard_normal((8, 9, 3)).astype(np.float32)).to("cuda:0")
+        loss = sum(((net(x[shard_indices(8, r_, 2)]) - t[shard_indices(8, r_, 2)]) ** 2).mean() for r_ in range(2)) / 2
+        loss.backward()
+    finally:
+        ops.SCAN_PER_STEP[0] = False
+    ref = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).double()
+    norm = float(ref.norm())
+    ref = (ref * min(1.0, 0.05 / (norm + 1e-6))).cpu().numpy()
+    assert norm > 0.05, "the clip must be active in this case"
+    assert abs(float(np.load(out + ".norm0.npy")[0]) - norm) <= 1e-5 * norm
+    assert float(np.abs(g0 - ref).max()) <= 2e-6 * max(1.0, float(np.abs(ref).max())), float(np.abs(g0 - ref).max())

@@ -651,6 +651,78 @@ def test_c5_resnet3d_cbam_golden():
     check_digests([(n, p.grad) for n, p in m.named_parameters() if p.grad is not None], g, tol=2e-3)
 
 
+@pytest.mark.parametrize("name,backend", [("vggm_tcn_eval", "tcn"), ("vggm_gru_eval", "gru")])
+def test_vggm_end_to_end_golden(name, backend):
+    """VA_3DVGGM(...).forward(video) from raw frames (reference models/backbone.py:134-145): the unsplit VGG-M stem (MIOpen) ->
+    TemporalConvNet + Linear(512,2) on the HIP conv kernels (backend 'tcn': the one TemporalConvNet user of the reference) or
+    the BiGRU head; outputs and every parameter gradient against the reference's own run"""
+    from models.backbone import VA_3DVGGM
+    g = load_golden(name)
+    seed = int(g["seed"])
+    B, T = [int(v) for v in g["dims"]]
+    m = fill_module(VA_3DVGGM(frameLen=T, backend=backend, nClasses=2, nFCs=2), seed + 1).to(DEV).eval()
+    rs = np.random.RandomState(seed)
+    x = dev(rs.randint(0, 256, (B, 3, T, 112, 112)).astype(np.float32))
+    x = ((x - 127.5) / 127.5).requires_grad_(True)
+    y = m(x)
+    assert tuple(y.shape) == tuple(g["y"].shape)
+    close(y, g["y"], 2e-4, "y")
+    (y * dev(g["ct"])).sum().backward()
+    check_digests([(n, p.grad) for n, p in m.named_parameters() if p.grad is not None], g, tol=2e-3)
+    check_digests([("dx", x.grad)], {"gd.dx": g["dx"]}, tol=2e-3)
+
+
+def test_c5_affwild_av_t16_golden():
+    """the full A+V model on 16-frame clips (longer scans than the T=4 golden; BASELINE's 64-frame size is covered by the
+    property test below)"""
+    from models.model import AffWild2VA
+    g = load_golden("c5_affwild_av_t16")
+    seed = int(g["seed"])
+    B, T = [int(v) for v in g["dims"]]
+    m = fill_module(AffWild2VA(_hp(modality="audiovisual", fusion_type="attention", loss="ccc_mtl", window=T)),
+                    seed + 1).to(DEV).eval()
+    batch = _affwild_batch(np.random.RandomState(seed), B, T, video=True)
+    close(m(batch), g["y"], 2e-4, "y")
+    out = m.training_step(batch, 0)
+    close(out["loss"], g["loss"], 2e-4, "loss")
+    out["loss"].backward()
+    check_digests([(n, p.grad) for n, p in m.named_parameters() if p.grad is not None], g, tol=2e-3)
+
+
+def test_c5_full_size_properties_t64():
+    """BASELINE configs[4] size: 64-frame clips of raw 112x112 frames through the whole AffWild2VA A+V model (eval mode: BatchNorm
+    on running statistics).  Size-independent properties: finite outputs of the right shape, run-to-run determinism of forward
+    and of every parameter gradient, clip independence (a permuted batch gives the permuted outputs; MIOpen may pick another
+    conv algorithm per call, hence a rounding-level tolerance there), and the loss equals the loss kernel on the outputs."""
+    from models.model import AffWild2VA
+    from m3t import ops
+    B, T = 4, 64
+    torch.manual_seed(12345)
+    m = AffWild2VA(_hp(modality="audiovisual", fusion_type="attention", loss="ccc_mtl", window=T)).to(DEV).eval()
+    batch = _affwild_batch(np.random.RandomState(7), B, T, video=True)
+    y1 = m(batch)
+    assert tuple(y1.shape) == (B, T, 9) and torch.isfinite(y1).all()
+    y2 = m(batch)
+    assert torch.equal(y1, y2), "forward is not deterministic"
+    perm = torch.tensor([2, 0, 3, 1], device=DEV)
+    pb = {k: (v[perm].contiguous() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+    y3 = m(pb)
+    assert float((y3 - y1[perm]).abs().max()) <= 1e-5, "clips are not independent"
+    grads = []
+    for _ in range(2):
+        m.zero_grad()
+        out = m.training_step(batch, 0)
+        out["loss"].backward()
+        grads.append([p.grad.clone() for p in m.parameters() if p.grad is not None])
+    assert torch.isfinite(out["loss"]) and all(torch.isfinite(g).all() for g in grads[0])
+    loss2, _ = ops.va_loss(y1.detach(), batch["label_valence"], batch["label_arousal"], batch["class_expr"], batch["expr_valid"],
+                           iv=7, ia=8, n_expr=7)
+    assert abs(float(loss2) - float(out["loss"])) <= 1e-6
+    worst = max(float((a - b).abs().max()) / max(1e-12, float(b.abs().max())) for a, b in zip(grads[0], grads[1]))
+    assert worst <= 1e-5, "gradients differ run to run by %.2e" % worst
+    ops.poll_scan_error(sync=True)
+
+
 # ------------------------------------------------------------------------------ full-size properties
 def test_full_size_properties_c3():
     """BASELINE size (B=32, T=300): determinism, clip independence (permutation equivariance),

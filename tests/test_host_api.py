@@ -136,6 +136,17 @@ def test_resnet3d_param_names():
     assert sorted(n for n, _ in m.named_parameters()) == sorted(g["param_names"].tolist())
 
 
+@pytest.mark.parametrize("name,backend,T", [("vggm_tcn_eval", "tcn", 4), ("vggm_gru_eval", "gru", 3)])
+def test_vggm_state_dict_keys_match_reference(name, backend, T):
+    """VA_3DVGGM (reference models/backbone.py:62-161): checkpoint keys and parameter names of the class itself -- the only
+    user of TemporalConvNet (its `tcn.0.network.*` keys carry the weight-norm aliases) -- equal the reference's"""
+    from models.backbone import VA_3DVGGM
+    g = load_golden(name)
+    m = VA_3DVGGM(frameLen=T, backend=backend, nClasses=2, nFCs=2)
+    assert sorted(m.state_dict().keys()) == sorted(g["state_dict_keys"].tolist())
+    assert sorted(n for n, _ in m.named_parameters()) == sorted(g["param_names"].tolist())
+
+
 def test_tcn_state_dict_aliases():
     from models.tcn import TemporalConvNet
     g = load_golden("tcn_small")
