@@ -153,6 +153,16 @@ int m3t_gru_persist_count(void);
 /* 0, or (step + 1) of a persistent scan that gave up waiting since the last call (reading clears the word).  The word is
  * host-mapped: no synchronisation happens here, so synchronise the scan's stream first if the answer must cover it. */
 int m3t_gru_poll_error(void);
+/* Exchange arena (optional, speed only).  A persistent scan exchanges h_t / dgh_t between workgroups through tagged granules
+ * and must never meet a stale granule whose tag matches; without an arena every launch therefore zeroes its exchange buffers
+ * (3-4 fill kernels in front of every scan).  m3t_gru_scan_arena(arena, bytes): the NEXT m3t_gru_scan_fwd / _bwd call of the
+ * calling thread keeps its exchange buffers in `arena` (device memory, 16-B aligned, >= 8 MiB) and draws launch-unique tags
+ * from a per-arena counter instead -- no fill kernel, except when the arena is first seen and when a 16-bit tag counter wraps
+ * (every ~200 launches).  CONTRACT: nothing but scan launches may ever write the arena, and launches that share an arena
+ * must be ordered (one stream).  m3t_gru_scan_arena_reset(arena): forget what is known about `arena` (call it when the
+ * memory was reallocated or written by anything else; NULL = every arena).  Both return 0.  Env M3T_SCAN_ARENA=0 ignores arenas. */
+int m3t_gru_scan_arena(void* arena, size_t bytes);
+int m3t_gru_scan_arena_reset(void* arena);
 /* Ordering between scans on different streams without holding back their preparation: the NEXT m3t_gru_scan_fwd /
  * m3t_gru_scan_bwd call of the calling thread makes its stream wait for `event` (a hipEvent_t) right before it launches
  * its scan kernel(s); the weight re-layout kernels and memsets it issues first run as soon as the stream allows.  Used

@@ -87,7 +87,12 @@ void persist_set_events(hipEvent_t start, hipEvent_t end);
 void persist_record_start(hipStream_t s);
 void persist_record_end(hipStream_t s);
 void persist_drop_events();
-struct AfterGuard { ~AfterGuard() { persist_drop_after(); persist_drop_events(); } };
+// m3t_gru_scan_arena: the exchange arena the NEXT scan call of this thread uses (launch-unique tags instead of a memset per
+// launch, see gru_persist.hip); forget: drop what is known about an arena (its memory was reallocated or written by others)
+void persist_set_arena(void* arena, size_t bytes);
+void persist_drop_arena();
+void persist_forget_arena(void* arena);
+struct AfterGuard { ~AfterGuard() { persist_drop_after(); persist_drop_events(); persist_drop_arena(); } };
 int persist_poll_error();       // step+1 of a scan that hit its spin limit since the last poll, else 0
 const unsigned* persist_error_word_dev();   // device address of the (host-mapped) error word, or nullptr before the first persistent scan
 bool persist_fwd_check(const FwdGroup& g, int B, int T);

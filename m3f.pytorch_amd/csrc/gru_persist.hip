@@ -25,6 +25,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <unordered_map>
 #include <fcntl.h>
 #include <sys/file.h>
 #include <sys/stat.h>
@@ -44,7 +46,9 @@ struct ExPtrs {
     int poll_align;                  // 1: waves without cell math count the delay from the workgroup's publish
     int spin_limit;                  // gather attempts before a workgroup gives up (raises the error word, finishes with garbage)
     int fault_step;                  // fault injection (flag M3T_SCAN_FAULT): workgroup 0 does not publish this step; -1 = never
-    unsigned long long* prof;        // optional in-kernel stamps (M3T_SCAN_PROF=1): 8 phase sums of workgroup 0, wave 0
+    unsigned long long* prof;        // optional in-kernel stamps (M3T_SCAN_PROF=1): 6 phase sums of workgroup 0, wave 0 (M3T_SCAN_PROF=2: wave 4, a wave without cell math)
+    int prof_tid;
+    unsigned tag_base;               // tags of this launch are tag_base + step + 1 (launch-unique inside an exchange arena: no memset per launch)
 };
 
 // phase stamps: s_memtime deltas accumulated by one lane; a uniform scalar branch when profiling is off
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(NT) void gru_persist_fwd_kernel(FwdGroup g, FragPtr
     __shared__ int pub_step;                           // steps this workgroup has published (thread 0)
     if (tid == 0) pub_step = 0;
     if (tid < 2) poll_fail[tid] = 0;                   // first read after the first barrier
-    const bool stamp = ex.prof != nullptr && blockIdx.x == 0 && tid == 0;
+    const bool stamp = ex.prof != nullptr && blockIdx.x == 0 && tid == ex.prof_tid;
     long long psum[6] = {0, 0, 0, 0, 0, 0}, last = stamp ? clock64() : 0;
 
     // x-projection of the step.  The next step's is requested right after this step's gather has completed (nothing else
@@ -172,6 +176,9 @@ __global__ __launch_bounds__(NT) void gru_persist_fwd_kernel(FwdGroup g, FragPtr
 #undef NXT
     }
 #undef M3T_FWD_LOAD_X
+    // the last step's request for "the next step's inputs" is still in flight and invisible to hipcc (inline asm): a wave must
+    // not end with a load outstanding into registers that the next wave on this SIMD is about to own
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (stamp)
         for (int i = 0; i < 6; ++i) ex.prof[i] = (unsigned long long)psum[i];
 }
@@ -261,7 +268,7 @@ __global__ __launch_bounds__(NT) void gru_persist_fwd6_kernel(FwdGroup g, FragPt
     __shared__ int pub_step;                           // steps this workgroup has published (thread 0)
     if (tid == 0) pub_step = 0;
     if (tid < 2) poll_fail[tid] = 0;                   // first read after the first barrier
-    const bool stamp = ex.prof != nullptr && blockIdx.x == 0 && tid == 0;
+    const bool stamp = ex.prof != nullptr && blockIdx.x == 0 && tid == ex.prof_tid;
     long long psum[6] = {0, 0, 0, 0, 0, 0}, last = stamp ? clock64() : 0;
 
     // x-projection of the step in (xr, xz, xn).  The next step's is requested right after this step's gather has
@@ -302,6 +309,9 @@ __global__ __launch_bounds__(NT) void gru_persist_fwd6_kernel(FwdGroup g, FragPt
 #undef NXT
     }
 #undef M3T_FWD_LOAD_X
+    // the last step's request for "the next step's inputs" is still in flight and invisible to hipcc (inline asm): a wave must
+    // not end with a load outstanding into registers that the next wave on this SIMD is about to own
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (stamp)
         for (int i = 0; i < 6; ++i) ex.prof[i] = (unsigned long long)psum[i];
 }
@@ -372,7 +382,7 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd16_kernel(BwdGroup g, FragP
     __shared__ int pub_step;                           // steps this workgroup has published (thread 0)
     if (tid == 0) pub_step = 0;
     if (tid < 2) poll_fail[tid] = 0;                   // first read after the first barrier
-    const bool stamp = ex.prof != nullptr && blockIdx.x == 0 && tid == 0;
+    const bool stamp = ex.prof != nullptr && blockIdx.x == 0 && tid == ex.prof_tid;
     long long psum[6] = {0, 0, 0, 0, 0, 0}, last = stamp ? clock64() : 0;
 
     // HBM traffic of a step and the chain.  Vector-memory operations retire in order, so everything a wave has issued
@@ -435,6 +445,9 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd16_kernel(BwdGroup g, FragP
 #undef NXT
     }
 #undef M3T_BWD_LOAD_STEP
+    // the last step's request for "the next step's inputs" is still in flight and invisible to hipcc (inline asm): a wave must
+    // not end with a load outstanding into registers that the next wave on this SIMD is about to own
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (pok) d.dh[(size_t)pb * H + pj] = dh_carry;
     if (pok && d.db_part) {
         float* q = d.db_part + (size_t)pb * 4 * H + pj;
@@ -486,7 +499,7 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd_kernel(BwdGroup g, FragPtr
     __shared__ int pub_step;                           // steps this workgroup has published (thread 0)
     if (tid == 0) pub_step = 0;
     if (tid < 2) poll_fail[tid] = 0;                   // first read after the first barrier
-    const bool stamp = ex.prof != nullptr && blockIdx.x == 0 && tid == 0;
+    const bool stamp = ex.prof != nullptr && blockIdx.x == 0 && tid == ex.prof_tid;
     long long psum[6] = {0, 0, 0, 0, 0, 0}, last = stamp ? clock64() : 0;
 
     // HBM traffic of a step and the chain.  Vector-memory operations retire in order, so everything a wave has issued
@@ -549,6 +562,9 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd_kernel(BwdGroup g, FragPtr
 #undef NXT
     }
 #undef M3T_BWD_LOAD_STEP
+    // the last step's request for "the next step's inputs" is still in flight and invisible to hipcc (inline asm): a wave must
+    // not end with a load outstanding into registers that the next wave on this SIMD is about to own
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (pok) d.dh[(size_t)pb * H + pj] = dh_carry;
     if (pok && d.db_part) {
         float* q = d.db_part + (size_t)pb * 4 * H + pj;
@@ -597,7 +613,8 @@ __global__ void wfrag_bwd6_prep_kernel(const float* __restrict__ w, unsigned sho
 // term is the upper half of the bits (one v_perm packs a pair), the remainder one v_sub against the masked value: 2 and +
 // 2 sub per term and pair, 3 perm = 11 VALU instructions per pair.  Measured equal (tools/scan_bench.py, 3.49-3.54 us per
 // step at 4 x H=512): the mask in a register instead of a literal; round-to-nearest with v_cvt_pk_bf16_f32 + v_pk_add_f32
-// (250 instead of 264 VALU instructions per lane and step, as the GEMM's split3_pair).
+// (250 instead of 264 VALU instructions per lane and step, as the GEMM's split3_pair); v_cvt_pk + v_dot2c_f32_bf16 remainders
+// without unpacking (168 instructions) -- and not exact (the parity test failed): the phase is not bound by its VALU count.
 __device__ __forceinline__ void bwd6_split_pair(unsigned x0, unsigned x1, unsigned& o1, unsigned& o2, unsigned& o3) {
     const float r0 = __uint_as_float(x0) - __uint_as_float(x0 & 0xffff0000u);
     const float r1 = __uint_as_float(x1) - __uint_as_float(x1 & 0xffff0000u);
@@ -647,7 +664,7 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd6_kernel(BwdGroup g, FragPt
     __shared__ int pub_step;                           // steps this workgroup has published (thread 0)
     if (tid == 0) pub_step = 0;
     if (tid < 2) poll_fail[tid] = 0;                   // first read after the first barrier
-    const bool stamp = ex.prof != nullptr && blockIdx.x == 0 && tid == 0;
+    const bool stamp = ex.prof != nullptr && blockIdx.x == 0 && tid == ex.prof_tid;
     long long psum[6] = {0, 0, 0, 0, 0, 0}, last = stamp ? clock64() : 0;
 
     // HBM traffic of a step and the chain.  Vector-memory operations retire in order, so everything a wave has issued
@@ -710,6 +727,9 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd6_kernel(BwdGroup g, FragPt
 #undef NXT
     }
 #undef M3T_BWD_LOAD_STEP
+    // the last step's request for "the next step's inputs" is still in flight and invisible to hipcc (inline asm): a wave must
+    // not end with a load outstanding into registers that the next wave on this SIMD is about to own
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (pok) d.dh[(size_t)pb * H + pj] = dh_carry;
     if (pok && d.db_part) {
         float* q = d.db_part + (size_t)pb * 4 * H + pj;
@@ -825,26 +845,91 @@ static int poll_env(const char* name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
+// ---- exchange arena: tags that are unique per launch instead of a memset per launch ---------------------------------------
+// A consumer accepts a granule when its tag equals the expected one, so stale granules of EARLIER launches in the same memory
+// must never carry that tag.  Until now every launch zeroed its exchange buffers first (3-4 small fill kernels in front of
+// every scan: 40 per C3 step).  With a caller-provided ARENA that nothing but scan launches ever writes
+// (m3t_gru_scan_arena), each launch draws a fresh tag range [base + 1, base + T] from a per-arena counter instead: granules of
+// older launches carry smaller tags and can never match.  The arena is split by granule format, because a data field of one
+// format must never sit where another format keeps its tag:
+//   kind 0  forward, fp32 MFMAs   8-B granule {h, tag32}                  2 MiB (16- or 32-row workgroups)
+//   kind 1  forward, bf16x6       8-B granule {h1, h2, h3, tag16}         1 MiB
+//   kind 2  backward, bf16 mode   8-B granule {dr, dz, dnr bf16, tag16}   1 MiB
+//   kind 3  backward, fp32/bf16x6 16-B granule {dr, dz, dnr, tag32}       4 MiB
+// A sub-arena is zeroed when the arena is first seen (or after m3t_gru_scan_arena_reset) and when its tag counter would
+// wrap (16-bit tags: every ~200 launches of 300 steps).  Without an arena the launch zeroes its buffers as before.
+constexpr size_t ARENA_OFF[4] = {0, (size_t)2 << 20, (size_t)3 << 20, (size_t)4 << 20};
+constexpr size_t ARENA_SIZE[4] = {(size_t)2 << 20, (size_t)1 << 20, (size_t)1 << 20, (size_t)4 << 20};
+constexpr size_t ARENA_BYTES = (size_t)8 << 20;
+struct ArenaState { unsigned long long next[4]; bool known; };
+std::mutex g_arena_mu;
+std::unordered_map<uintptr_t, ArenaState> g_arenas;
+thread_local void* g_arena = nullptr;
+thread_local size_t g_arena_bytes = 0;
+
+// Lays the exchange buffers of the launch out (ex.gran / ex.slot) and makes stale tags impossible: inside the arena by a fresh
+// tag range, else by zeroing.  Returns 0 or a hipError_t.
+template <typename G>
+int prepare_exchange(const G& g, const FragPtrs& fp, const Shape& sh, int kind, size_t gran_bytes, unsigned long long tag_max,
+                     int T, ExPtrs& ex, hipStream_t s) {
+    size_t bytes[M3T_MAX_SCANS], total = 0;
+    for (int i = 0; i < g.n; ++i) {
+        ex.slot[i] = (size_t)sh.nrb * (g.d[i].H / 16) * sh.rt * 256;
+        bytes[i] = 2 * ex.slot[i] * gran_bytes;
+        total += bytes[i];
+    }
+    ex.tag_base = 0;
+    void* arena = g_arena;
+    const size_t arena_bytes = g_arena_bytes;
+    g_arena = nullptr; g_arena_bytes = 0;                       // consumed by this launch
+    static const int arena_on = poll_env_early("M3T_SCAN_ARENA", 1);
+    if (arena_on && arena && arena_bytes >= ARENA_BYTES && ((uintptr_t)arena % 16) == 0 && total <= ARENA_SIZE[kind] &&
+        (unsigned long long)T + 1 < tag_max) {
+        char* base = static_cast<char*>(arena) + ARENA_OFF[kind];
+        size_t off = 0;
+        for (int i = 0; i < g.n; ++i) { ex.gran[i] = base + off; off += bytes[i]; }
+        std::lock_guard<std::mutex> lock(g_arena_mu);
+        ArenaState& st = g_arenas[(uintptr_t)arena];
+        if (!st.known) {
+            const hipError_t e = hipMemsetAsync(arena, 0, ARENA_BYTES, s);
+            if (e != hipSuccess) return (int)e;
+            st.known = true;
+            for (int q = 0; q < 4; ++q) st.next[q] = 0;
+        }
+        if (st.next[kind] + (unsigned long long)T + 1 >= tag_max) {     // the counter would wrap: start over on zeroed memory
+            const hipError_t e = hipMemsetAsync(base, 0, ARENA_SIZE[kind], s);
+            if (e != hipSuccess) return (int)e;
+            st.next[kind] = 0;
+        }
+        ex.tag_base = (unsigned)st.next[kind];
+        st.next[kind] += (unsigned long long)T;
+        return 0;
+    }
+    for (int i = 0; i < g.n; ++i) {
+        ex.gran[i] = fp.xfrag[i];
+        const hipError_t e = hipMemsetAsync(ex.gran[i], 0, bytes[i], s);     // no stale tag may match
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
 template <typename G>
 void fill_exchange(const G& g, const FragPtrs& fp, const Shape& sh, size_t gran_bytes, ExPtrs& ex, size_t (&bytes)[M3T_MAX_SCANS]) {
     std::memset(&ex, 0, sizeof(ex));
     static int prof_on = -1;
     if (prof_on < 0) {
         const char* e = std::getenv("M3T_SCAN_PROF");
-        prof_on = (e && e[0] == '1') ? 1 : 0;
+        prof_on = (e && (e[0] == '1' || e[0] == '2')) ? (e[0] - '0') : 0;
         if (prof_on && hipMalloc(reinterpret_cast<void**>(&g_prof), 64) != hipSuccess) { (void)hipGetLastError(); g_prof = nullptr; }
     }
     ex.prof = g_prof;
+    ex.prof_tid = prof_on == 2 ? 256 : 0;
     ex.poll_fixed = -1;
     ex.poll_align = 0;
     static const int spin_limit = poll_env_early("M3T_SCAN_SPIN_LIMIT", SPIN_LIMIT_DEFAULT);
     ex.spin_limit = spin_limit > 0 ? spin_limit : SPIN_LIMIT_DEFAULT;
     ex.fault_step = -1;
-    for (int i = 0; i < g.n; ++i) {
-        ex.gran[i] = fp.xfrag[i];
-        ex.slot[i] = (size_t)sh.nrb * (g.d[i].H / 16) * sh.rt * 256;
-        bytes[i] = 2 * ex.slot[i] * gran_bytes;
-    }
+    for (int i = 0; i < g.n; ++i) bytes[i] = 0;
 }
 
 }  // namespace
@@ -961,12 +1046,9 @@ int persist_fwd_launch(const FwdGroup& g, const FragPtrs& fp, int B, int T, int 
         static const int al = poll_env("M3T_SCAN_POLL_ALIGN", 6);     // bit 0: bf16x6 forward, 1: fp32 forward, 2: backward
         ex.poll_align = persist_fwd_uses_x6(g, B, T, flags) ? (al & 1) : ((al >> 1) & 1);
     }
-    for (int i = 0; i < g.n; ++i) {
-        const hipError_t e = hipMemsetAsync(ex.gran[i], 0, bytes[i], s);     // no stale tag may match
-        if (e != hipSuccess) return (int)e;
-    }
-    ++g_launches;
     const bool x6 = persist_fwd_uses_x6(g, B, T, flags);
+    { const int e = prepare_exchange(g, fp, sh, x6 ? 1 : 0, 8, x6 ? 65535ull : 0xffffffffull, T, ex, s); if (e) return e; }
+    ++g_launches;
     if (!x6) { const int e = persist_take_after(s); if (e) return e; }
     if (x6) {
         for (int i = 0; i < g.n; ++i) {                                      // W_hh -> bf16x3 B-operand fragments
@@ -1004,10 +1086,7 @@ int persist_bwd_launch(const BwdGroup& g, const FragPtrs& fp, int B, int T, int 
         ex.poll_fixed = pb;
         ex.poll_align = (al >> 2) & 1;
     }
-    for (int i = 0; i < g.n; ++i) {
-        const hipError_t e = hipMemsetAsync(ex.gran[i], 0, bytes[i], s);
-        if (e != hipSuccess) return (int)e;
-    }
+    { const int e = prepare_exchange(g, fp, sh, b16 ? 2 : 3, b16 ? 8 : 16, b16 ? 65535ull : 0xffffffffull, T, ex, s); if (e) return e; }
     ++g_launches;
     if (b16) {
         for (int i = 0; i < g.n; ++i) {                                      // W_hh^T -> bf16 B-operand fragments
@@ -1065,6 +1144,13 @@ int persist_take_after(hipStream_t s) {
     return (int)e;
 }
 
+void persist_set_arena(void* arena, size_t bytes) { g_arena = arena; g_arena_bytes = bytes; }
+void persist_drop_arena() { g_arena = nullptr; g_arena_bytes = 0; }
+void persist_forget_arena(void* arena) {
+    std::lock_guard<std::mutex> lock(g_arena_mu);
+    if (arena) g_arenas.erase((uintptr_t)arena); else g_arenas.clear();
+}
+
 int persist_launch_count() { return g_launches; }
 
 int persist_profile(unsigned long long* out6) {
@@ -1080,6 +1166,16 @@ extern "C" int m3t_gru_poll_error(void) { return m3t_gru::persist_poll_error(); 
 
 extern "C" int m3t_gru_scan_events(void* start, void* end) {
     m3t_gru::persist_set_events((hipEvent_t)start, (hipEvent_t)end);
+    return 0;
+}
+
+extern "C" int m3t_gru_scan_arena(void* arena, size_t bytes) {
+    m3t_gru::persist_set_arena(arena, bytes);
+    return 0;
+}
+
+extern "C" int m3t_gru_scan_arena_reset(void* arena) {
+    m3t_gru::persist_forget_arena(arena);
     return 0;
 }
 

@@ -47,6 +47,8 @@ SIGNATURES = {
     "m3t_gru_scan_bwd": [C.POINTER(GruBwdDesc), _i, _i, _i, _f, _z, _i, _s],
     "m3t_gru_persist_count": [],
     "m3t_gru_poll_error": [],
+    "m3t_gru_scan_arena": [C.c_void_p, _z],
+    "m3t_gru_scan_arena_reset": [C.c_void_p],
     "m3t_gru_scan_after": [C.c_void_p],
     "m3t_gru_scan_events": [C.c_void_p, C.c_void_p],
     "m3t_gru_persist_profile": [C.c_void_p],

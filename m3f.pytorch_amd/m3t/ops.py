@@ -390,6 +390,23 @@ def _scan_after(ev):
             torch.cuda.current_stream().wait_event(ev)
 
 
+_ARENAS = {}
+_ARENA_BYTES = 8 << 20
+
+
+def _scan_arena(device):
+    """the exchange arena of the persistent scans issued on the current stream role (include/m3t_hip.h, m3t_gru_scan_arena):
+    8 MiB that nothing but scan launches ever writes -- one per (device, stream role), because launches that share an arena
+    must be ordered -- handed to the next scan call"""
+    key = (device.type, device.index, _ws_tag(device))
+    a = _ARENAS.get(key)
+    if a is None:
+        a = torch.empty(_ARENA_BYTES, dtype=torch.uint8, device=device)
+        _ARENAS[key] = a
+        _lib.check(lib().m3t_gru_scan_arena_reset(C.c_void_p(a.data_ptr())), "m3t_gru_scan_arena_reset")
+    _lib.check(lib().m3t_gru_scan_arena(C.c_void_p(a.data_ptr()), _ARENA_BYTES), "m3t_gru_scan_arena")
+
+
 def _scan_fwd(descs, B, T, prec=0, after=None):
     for i in range(0, len(descs), M3T_MAX_SCANS):
         chunk = descs[i:i + M3T_MAX_SCANS]
@@ -400,6 +417,7 @@ def _scan_fwd(descs, B, T, prec=0, after=None):
             ws = workspace(dev)
             n0 = lib().m3t_gru_persist_count() if tm.rec is not None else 0
             _scan_after(after if i == 0 else None)
+            _scan_arena(dev)
             rc = lib().m3t_gru_scan_fwd(arr, len(chunk), B, T, _p(ws), ws.numel() * 4, _scan_flags(dev) | prec, _stream())
             if tm.rec is not None and lib().m3t_gru_persist_count() != n0:      # one launch ran all T steps
                 tm.rec.update(kernel="gru_persist_fwd_kernel", launches=1, steps=T)
@@ -416,6 +434,7 @@ def _scan_bwd(descs, B, T, prec=0, after=None):
             ws = workspace(dev)
             n0 = lib().m3t_gru_persist_count() if tm.rec is not None else 0
             _scan_after(after if i == 0 else None)
+            _scan_arena(dev)
             rc = lib().m3t_gru_scan_bwd(arr, len(chunk), B, T, _p(ws), ws.numel() * 4, _scan_flags(dev) | prec, _stream())
             if tm.rec is not None and lib().m3t_gru_persist_count() != n0:
                 tm.rec.update(kernel="gru_persist_bwd_kernel", launches=1, steps=T)

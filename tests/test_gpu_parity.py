@@ -289,6 +289,56 @@ def test_gru_persistent_scan_final_state_and_its_gradient():
         close(gr, g_ref[n], 2e-4, n)
 
 
+def test_scan_exchange_arena_launch_unique_tags_survive_wraps_and_layout_changes():
+    """The persistent scans keep their exchange granules in an arena and draw launch-unique tags instead of zeroing the buffers
+    before every launch (include/m3t_hip.h, m3t_gru_scan_arena).  Stale granules of earlier launches -- other shapes, other
+    layouts in the same sub-arena, 16-bit tag counters that wrap after ~200 launches of 300 steps -- must never be accepted:
+    260 forward+backward rounds over alternating shapes stay bit-identical to their first result."""
+    from models.rnn import GRU
+    from m3t import _lib, ops
+    lib = _lib.load()
+    torch.manual_seed(11)
+    nets = [GRU(16, 256, 1, -1).to(DEV), GRU(24, 512, 1, -1).to(DEV), GRU(8, 128, 1, -1).to(DEV)]
+    xs = [torch.randn(32, 300, 16, device=DEV), torch.randn(16, 300, 24, device=DEV), torch.randn(20, 77, 8, device=DEV)]
+    first = [None] * 3
+    n0 = lib.m3t_gru_persist_count()
+    for it in range(260):
+        k = it % 3 if it % 7 else 0
+        net, x = nets[k], xs[k].clone().requires_grad_(True)
+        y = net(x)
+        y.square().mean().backward()
+        res = (y.detach(), x.grad)
+        if first[k] is None:
+            first[k] = tuple(t.clone() for t in res)
+        else:
+            assert torch.equal(res[0], first[k][0]) and torch.equal(res[1], first[k][1]), "round %d, net %d" % (it, k)
+    torch.cuda.synchronize()
+    assert lib.m3t_gru_persist_count() - n0 == 2 * 260
+    ops.poll_scan_error()
+
+
+@pytest.mark.parametrize("B,T,H", [(20, 77, 128), (32, 77, 128), (32, 31, 256)])
+def test_persistent_scan_waves_end_with_nothing_in_flight(B, T, H):
+    """Regression: the persistent scans request "the next step's inputs" by inline asm on every step, the last one included; a
+    wave that ended with that load outstanding let it land in registers the NEXT wave on the SIMD already owned -- a wild
+    address, HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION in roughly one run of this loop in two (odd T, H=128, two row blocks).
+    Every kernel now drains its vector-memory counter before it ends."""
+    from models.rnn import GRU
+    torch.manual_seed(3)
+    net = GRU(8, H, 1, -1).to(DEV)
+    x0 = torch.randn(B, T, 8, device=DEV)
+    ref = None
+    for it in range(150):
+        x = x0.clone().requires_grad_(True)
+        y = net(x)
+        y.square().mean().backward()
+        if ref is None:
+            ref = (y.detach().clone(), x.grad.clone())
+        elif it % 25 == 0:
+            assert torch.equal(y, ref[0]) and torch.equal(x.grad, ref[1])
+    torch.cuda.synchronize()
+
+
 def test_gru_persistent_scan_repeatable_and_long():
     """T = 300 at the C3 width (4 x H=512 scans = 256 workgroups, the whole chip): two runs are bit-identical and no
     wait expires (a later scan call would raise M3T_ESPIN)."""

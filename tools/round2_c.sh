@@ -1,3 +1,4 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; cd $R
-for v in 0 1 2; do echo "== BWD6_VAR=$v"; M3T_SCAN_BWD6_VAR=$v M3T_SCAN_PROF=1 python tools/scan_bench.py 2>&1 | grep -A2 -E "^fusion|^4x512|^2x256" | grep -v "^--" ; done 2>&1 | tee $O/var_c.log
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_bench_path.py tests/test_gpu_faults.py -q -m gpu -x -k "arena or persist or gru or bench or fault or dead or second" 2>&1 | tail -4
+REPS=3 bash tools/ab.sh arena "M3T_SCAN_ARENA=0" "M3T_SCAN_ARENA=1"

@@ -65,7 +65,7 @@ def time_call(fn, descs, cls, reps=5):
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / reps / T * 1e3     # us per step launch
-    if os.environ.get("M3T_SCAN_PROF") == "1":
+    if os.environ.get("M3T_SCAN_PROF") in ("1", "2"):
         buf = (C.c_ulonglong * 6)()
         if lib.m3t_gru_persist_profile(buf) == 0:
             tot = float(sum(buf)) or 1.0
