@@ -34,6 +34,10 @@ struct X6Params {
     int M, N, K, lda, ldb, ldc;
     int act, accumulate, splits, kchunk;
     int seg_len, seg_stride, a_off, b_off;
+    // implicit-GEMM 1-D convolution (CONV kernels, m3t_conv_x6_launch): A = x [B*T][C] read through the taps' row shifts
+    int cv_T, cv_C, cv_K, cv_dil, cv_lead, cv_anti;
+    size_t cv_btap;                      // TB == 1: elements between the [N][C] weight planes of consecutive taps
+    const float* cv_mask; const float* cv_res; float* cv_pre;
 };
 
 __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
@@ -122,7 +126,13 @@ __device__ __forceinline__ void mc_store(unsigned char* __restrict__ S, const fl
 
 // NS = 3: fp32-accurate product from 3 bf16 terms per operand (6 MFMAs per tile step);
 // NS = 1: plain bf16 operands (round to nearest even), fp32 accumulate -- the mixed-precision mode (M3T_GEMM_BF16)
-template <int TA, int TB, bool SEG, int NS>
+// CONV (TA == 0): the product is a dilated 1-D convolution over channel-last rows (models/tcn.py:16-46, the tcn_simple stages of
+// models/backbone.py:214-222) as an implicit GEMM: k = (tap j, channel c), A[m][k] = x[m + off_j][c] where off_j is the tap's time
+// offset (causal / look-ahead `lead` / time-flipped for the data gradient) and rows whose source frame falls outside the clip
+// read as zero -- no im2col, no padded copy, no chomp copy.  A 32-deep k tile lies inside one tap (C % 32 == 0), so a tile's
+// loads are ordinary full-line row loads from shifted rows.  Epilogue: bias, pre-activation copy, ReLU x dropout mask,
+// residual add + ReLU (the TemporalBlock's tail) fused.
+template <int TA, int TB, bool SEG, int NS, bool CONV = false>
 __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * OPER_BYTES];   // A | B, 48 KiB
     unsigned char* As = lds;
@@ -162,9 +172,31 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p) {
         sq = k / p.seg_len; sr = k % p.seg_len;
     }
 
+    int cv_t[4] = {0, 0, 0, 0}, cv_k = k_begin;       // CONV: time index of this thread's four A rows; k of the next tile
+    if (CONV) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cv_t[i] = (bm + (tid >> 3) + 32 * i) % p.cv_T;
+    }
     float4 ra[4], rb[4];
     auto gload = [&]() {
-        if (SEG) {   // TA == 1 && TB == 0: both operands row-contiguous, k rows through the segment map
+        if (CONV) {
+            const int j = cv_k / p.cv_C, kc = cv_k - j * p.cv_C;
+            const int sft = (p.cv_K - 1 - j) * p.cv_dil;
+            const int off = p.cv_anti ? sft - p.cv_lead : p.cv_lead - sft;
+            const float* qa = p.A + ((ptrdiff_t)(bm + (tid >> 3)) + off) * (ptrdiff_t)p.lda + kc + (tid & 7) * 4;     // (signed row shift)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = (unsigned)(cv_t[i] + off) < (unsigned)p.cv_T;
+                ra[i] = ok ? *reinterpret_cast<const float4*>(qa + (ptrdiff_t)i * 32 * p.lda) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (TB == 1) kc_load(p.B + (size_t)j * p.cv_btap + (size_t)(bn + (tid >> 3)) * p.ldb + kc + (tid & 7) * 4, p.ldb, rb);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rb[e] = *reinterpret_cast<const float4*>(pb + e * b_krow);
+                pb += b_step;
+            }
+            cv_k += XK;
+        } else if (SEG) {   // TA == 1 && TB == 0: both operands row-contiguous, k rows through the segment map
             int q = sq, r = sr;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -248,7 +280,15 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p) {
                 const int row = bm + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 float v = acc[i][j][r];
                 float* q = dst + (size_t)row * ldd + col;
-                if (direct) {
+                if (CONV) {
+                    const size_t o = (size_t)row * ldd + col;
+                    v += bv;
+                    if (p.cv_pre) p.cv_pre[o] = v;
+                    const float mk = p.cv_mask ? p.cv_mask[o] : 1.f;
+                    if (p.act == 1) v = fmaxf(v, 0.f) * mk;
+                    else if (p.act == 2) v = fmaxf(fmaxf(v, 0.f) * mk + p.cv_res[o], 0.f);
+                    else if (p.cv_res) v += p.cv_res[o];
+                } else if (direct) {
                     v += bv;
                     if (p.act == 1) v = fmaxf(v, 0.f);
                     if (p.accumulate) v += *q;
@@ -271,6 +311,7 @@ int m3t_sgemm_x6_launch(int transA, int transB, int M, int N, int K, const float
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.act = act; p.accumulate = accumulate; p.splits = splits; p.kchunk = kchunk;
     p.seg_len = seg_len; p.seg_stride = seg_stride; p.a_off = a_off; p.b_off = b_off;
+    p.cv_T = p.cv_C = p.cv_K = p.cv_dil = p.cv_lead = p.cv_anti = 0; p.cv_btap = 0; p.cv_mask = p.cv_res = nullptr; p.cv_pre = nullptr;
     dim3 grid(N / XN, M / XM, splits), block(256);
 #define M3T_X6_DISPATCH(NS_)                                                                                        \
     do {                                                                                                           \
@@ -285,4 +326,29 @@ int m3t_sgemm_x6_launch(int transA, int transB, int M, int N, int K, const float
 #undef M3T_X6_DISPATCH
     hipError_t e = hipGetLastError();
     return (int)e;
+}
+
+
+// Dilated 1-D convolution on the bf16x6 kernel (see CONV above).  The caller (m3t_conv1d_fwd) has verified: (B*T) % 128 == 0,
+// Co % 128 == 0, Ci % 32 == 0, 16-B aligned operands.  anti = 0: w_t is [K][Co][Ci] (rows of Ci contiguous: the "TB = 1" form,
+// one [Co][Ci] plane per tap); anti = 1 (data gradient): w_t is [K][Ci][Co] read as the row-major [K*Ci][Co] matrix.
+int m3t_conv_x6_launch(const float* x, const float* w_t, const float* bias, const float* res, const float* mask, float* y,
+                       float* pre, int B, int T, int Ci, int Co, int K, int dil, int lead, int act, int anti, int bf16_operands,
+                       hipStream_t s) {
+    X6Params p;
+    p.A = x; p.B = w_t; p.C = y; p.bias = bias; p.ws = nullptr;
+    p.M = B * T; p.N = Co; p.K = K * Ci; p.lda = Ci; p.ldb = anti ? Co : Ci; p.ldc = Co;
+    p.act = act; p.accumulate = 0; p.splits = 1; p.kchunk = K * Ci;
+    p.seg_len = p.seg_stride = p.a_off = p.b_off = 0;
+    p.cv_T = T; p.cv_C = Ci; p.cv_K = K; p.cv_dil = dil; p.cv_lead = lead; p.cv_anti = anti;
+    p.cv_btap = (size_t)Co * Ci; p.cv_mask = mask; p.cv_res = res; p.cv_pre = pre;
+    dim3 grid(Co / XN, p.M / XM, 1), block(256);
+    if (anti) {
+        if (bf16_operands) sgemm_x6_kernel<0, 0, false, 1, true><<<grid, block, 0, s>>>(p);
+        else sgemm_x6_kernel<0, 0, false, 3, true><<<grid, block, 0, s>>>(p);
+    } else {
+        if (bf16_operands) sgemm_x6_kernel<0, 1, false, 1, true><<<grid, block, 0, s>>>(p);
+        else sgemm_x6_kernel<0, 1, false, 3, true><<<grid, block, 0, s>>>(p);
+    }
+    return (int)hipGetLastError();
 }

@@ -10,6 +10,7 @@
 //   * the same kernel run anti-causally with the [co][ci] weight read as [K][N] is the
 //     data gradient; the weight gradient is K segment-mapped TN GEMMs (m3t_sgemm).
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -263,6 +264,19 @@ extern "C" int m3t_weight_norm_bwd(const float* dw_t, const float* v, const floa
     return 0;
 }
 
+int m3t_conv_x6_launch(const float* x, const float* w_t, const float* bias, const float* res, const float* mask, float* y,
+                       float* pre, int B, int T, int Ci, int Co, int K, int dil, int lead, int act, int anti, int bf16_operands,
+                       hipStream_t s);
+
+static bool conv_x6_enabled() {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("M3T_CONV_X6");
+        on = (e && e[0] == '0') ? 0 : 1;
+    }
+    return on == 1;
+}
+
 extern "C" int m3t_conv1d_fwd(const float* x, const float* w_t, const float* bias, const float* res,
                               const float* drop_mask, float* y, float* pre, int B, int T, int Ci, int Co, int K,
                               int dilation, int lead, int act, int anticausal, int flags, void* stream) {
@@ -273,6 +287,16 @@ extern "C" int m3t_conv1d_fwd(const float* x, const float* w_t, const float* bia
     ConvParams p;
     p.x = x; p.w_t = w_t; p.bias = bias; p.res = res; p.mask = drop_mask; p.y = y; p.pre = pre;
     p.B = B; p.T = T; p.Ci = Ci; p.Co = Co; p.K = K; p.dil = dilation; p.act = act; p.anti = anticausal; p.lead = lead; p.bf16 = (flags & M3T_BF16) ? 1 : 0;
+    // interior shapes: the implicit GEMM on the bf16 matrix pipe (gemm_x6.hip, CONV): fp32-accurate bf16x6 products (one bf16
+    // product in the M3T_BF16 mode), 128 x 128 x 32 tiles with the next tile's loads in flight during the MFMAs -- 2-3x this
+    // file's single-stage fp32-MFMA kernel, which keeps the edge shapes (channels not multiples of 32 / 128, ragged B*T)
+    {
+        auto al = [](const void* q) { return q == nullptr || ((uintptr_t)q % 16) == 0; };
+        if (conv_x6_enabled() && ((size_t)B * T) % 128 == 0 && Co % 128 == 0 && Ci % 32 == 0 && al(x) && al(w_t) && al(y) && al(res) &&
+            al(drop_mask) && al(pre))
+            return m3t_conv_x6_launch(x, w_t, bias, res, drop_mask, y, pre, B, T, Ci, Co, K, dilation, lead, act, anticausal,
+                                      p.bf16, (hipStream_t)stream);
+    }
     const int halo = (K - 1) * dilation;
     p.halo = halo;
     p.lda = ((BM + halo - 4 + 31) / 32) * 32 + 4;   // == 4 (mod 32): 2-way (free) transposing LDS writes

@@ -454,6 +454,47 @@ def test_tcn_vs_oracle_full_width():
         close(prm.grad, g_ref[n], 2e-4, n)
 
 
+@pytest.mark.parametrize("K,dil,lead,anti,act", [(3, 1, 0, 0, 1), (3, 2, 0, 0, 2), (5, 1, 2, 0, 0), (3, 2, 0, 1, 0), (5, 1, 2, 1, 0), (2, 4, 0, 0, 1)])
+def test_conv1d_on_the_bf16x6_pipe(K, dil, lead, anti, act):
+    """interior shapes ((B*T) % 128 == 0, Co % 128 == 0, Ci % 32 == 0) run the dilated convolution as an implicit GEMM on the
+    bf16x6 kernel (gemm_x6.hip, CONV): causal / look-ahead / time-flipped taps, clip-boundary masking, fused bias + pre copy +
+    ReLU x dropout mask + residual + ReLU -- against a direct fp64 evaluation of models/tcn.py:16-46 on the same operands"""
+    from m3t import ops, _lib
+    import ctypes as C
+    rs = np.random.RandomState(K * 100 + dil * 10 + lead + anti)
+    B, T, Ci, Co = 4, 96, 64, 128                       # B*T = 384 = 3 row tiles; clips end inside tiles (96 rows per clip)
+    x = rs.standard_normal((B, T, Ci)).astype(np.float32)
+    w = (rs.standard_normal((K, Ci, Co) if anti else (K, Co, Ci)) / np.sqrt(K * Ci)).astype(np.float32)
+    bias = rs.standard_normal(Co).astype(np.float32) if not anti else None
+    res = rs.standard_normal((B, T, Co)).astype(np.float32) if act == 2 or anti else None
+    mask = (rs.uniform(size=(B, T, Co)) < 0.8).astype(np.float32) / 0.8 if act else None
+    ref = np.zeros((B, T, Co))
+    for j in range(K):
+        sft = (K - 1 - j) * dil
+        off = sft - lead if anti else lead - sft
+        for t in range(T):
+            if 0 <= t + off < T:
+                ref[:, t] += x[:, t + off].astype(np.float64) @ (w[j].astype(np.float64) if anti else w[j].astype(np.float64).T)
+    if bias is not None:
+        ref += bias
+    pre_ref = ref.copy()
+    if act == 1:
+        ref = np.maximum(ref, 0) * mask
+    elif act == 2:
+        ref = np.maximum(np.maximum(ref, 0) * mask + res, 0)
+    elif res is not None:
+        ref = ref + res
+    y, pre = torch.empty(B, T, Co, device=DEV), torch.empty(B, T, Co, device=DEV)
+    p = lambda a: C.c_void_p(dev(a).data_ptr()) if a is not None else None
+    keep = [dev(a) if a is not None else None for a in (x, w, bias, res, mask)]
+    ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    rc = _lib.load().m3t_conv1d_fwd(ptr(keep[0]), ptr(keep[1]), ptr(keep[2]), ptr(keep[3]), ptr(keep[4]), ptr(y), ptr(pre), B, T, Ci, Co, K,
+                                    dil, lead, act, anti, 0, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    close(y, ref, 2e-5, "y")
+    close(pre, pre_ref, 2e-5, "pre")
+
+
 def test_tcn_train_mode_dropout_runs():
     from models.tcn import TemporalConvNet
     torch.manual_seed(0)
