@@ -247,11 +247,17 @@ int m3t_causal_conv_wgrad(const float* dy, const float* x, float* dw_t,
  * lead = 0 is m3t_causal_conv_fwd; lead = pad is nn.Conv1d(k, stride 1, padding=pad) with 2*pad = (K-1)*d --
  * the `tcn_simple` back-end's Conv1d(.,.,5,1,2) / Conv1d(.,.,3,1,1) (reference models/backbone.py:107-111,
  * 214-231).  anticausal != 0 flips time (x[b, t - lead + (K-1-j)*d]): the data gradient.
- * flags: 0 or M3T_BF16 (x and w rounded to bf16 while staged; fp32 accumulate and epilogue). */
+ * flags: 0 or M3T_BF16 (x and w rounded to bf16 while staged; fp32 accumulate and epilogue).
+ * Dropout (nn.Dropout(p) behind each ReLU of the TemporalBlock, reference models/tcn.py:17,23,29): either an explicit
+ * pre-scaled mask tensor `drop_mask` [B*T, Co], or drop_p in (0, 1) with drop_mask = NULL: the mask is then generated IN the
+ * epilogue -- element (row, col) keeps its value x 1/(1-p) iff word (row & 3) of Philox4x32-10(counter {col, row >> 2, 0, 0},
+ * key drop_seed) < (1-p) * 2^32 -- and never exists in memory; m3t_mask_pos_drop regenerates it for the backward pass.
+ * Interior shapes ((B*T) % 128 == 0, Co % 128 == 0, Ci % 32 == 0, 16-B aligned operands) run as an implicit GEMM on the
+ * bf16 matrix pipe (fp32-accurate bf16x6 products; one bf16 product with M3T_BF16); env M3T_CONV_X6=0 keeps the fp32-MFMA kernel. */
 int m3t_conv1d_fwd(const float* x, const float* w_t, const float* bias, const float* res,
                    const float* drop_mask, float* y, float* pre,
-                   int B, int T, int Ci, int Co, int K, int dilation, int lead,
-                   int act, int anticausal, int flags, void* stream);
+                   int B, int T, int Ci, int Co, int K, int dilation, int lead, int act, int anticausal,
+                   float drop_p, unsigned long long drop_seed, int flags, void* stream);
 /* dw_t[j][co][ci] = sum_{b,t} dy[b,t,co] * x[b, t + lead - (K-1-j)*d, ci] */
 int m3t_conv1d_wgrad(const float* dy, const float* x, float* dw_t,
                      int B, int T, int Ci, int Co, int K, int dilation, int lead,
@@ -277,6 +283,10 @@ int m3t_bct_to_btc(const float* src, float* dst, int B, int C, int T, void* stre
 int m3t_btc_to_bct(const float* src, float* dst, int B, int T, int C, void* stream);
 /* out[i] = s[i] > 0 ? dy[i] * (mul ? mul[i] : 1) : 0   (ReLU / dropout gradient masks) */
 int m3t_mask_pos(const float* s, const float* dy, const float* mul, float* out, size_t n, void* stream);
+/* out[row, col] = s > 0 ? dy * mask(row, col) : 0 over [rows, C] with m3t_conv1d_fwd's in-kernel dropout mask regenerated from
+ * (drop_p, drop_seed): the gradient through ReLU -> Dropout without a mask tensor. */
+int m3t_mask_pos_drop(const float* s, const float* dy, float* out, int rows, int C, float drop_p,
+                      unsigned long long drop_seed, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * CBAM (models/cbam.py), x [N,C,H,W] contiguous.

@@ -376,6 +376,26 @@ __global__ void mask_pos_kernel(const float* __restrict__ s, const float* __rest
         out[i] = s[i] > 0.f ? (mul ? dy[i] * mul[i] : dy[i]) : 0.f;
 }
 
+// out = (s > 0) ? dy * dropout-mask(row, col) : 0 with the mask REGENERATED from (seed, row, col) (common.h): the backward of
+// ReLU -> Dropout without a mask tensor.  One thread: 4 consecutive rows x 1 column (one Philox call), coalesced across columns.
+__global__ __launch_bounds__(256) void mask_pos_drop_kernel(const float* __restrict__ s, const float* __restrict__ dy,
+                                                            float* __restrict__ out, int rows, int C, M3TDrop drop) {
+    const size_t total = (size_t)((rows + 3) >> 2) * C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t g = (uint32_t)(i / C), col = (uint32_t)(i % C);
+        float m[4];
+        m3t_drop_mask4(drop, g, col, m);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const size_t row = (size_t)g * 4 + r;
+            if (row < (size_t)rows) {
+                const size_t o = row * C + col;
+                out[o] = s[o] > 0.f ? dy[o] * m[r] : 0.f;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 int m3t_sgemm_x6_launch(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
@@ -573,6 +593,18 @@ extern "C" int m3t_mask_pos(const float* s, const float* dy, const float* mul, f
     int blocks = (int)((n + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     mask_pos_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(s, dy, mul, out, n);
+    M3T_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int m3t_mask_pos_drop(const float* s, const float* dy, float* out, int rows, int C, float drop_p,
+                                 unsigned long long drop_seed, void* stream) {
+    if (rows <= 0 || C <= 0) return 0;
+    if (!s || !dy || !out || drop_p < 0.f || drop_p >= 1.f) return M3T_EINVAL;
+    const size_t total = (size_t)((rows + 3) / 4) * C;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    mask_pos_drop_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(s, dy, out, rows, C, m3t_make_drop(drop_p, drop_seed));
     M3T_LAUNCH_CHECK();
     return 0;
 }

@@ -38,6 +38,7 @@ struct X6Params {
     int cv_T, cv_C, cv_K, cv_dil, cv_lead, cv_anti;
     size_t cv_btap;                      // TB == 1: elements between the [N][C] weight planes of consecutive taps
     const float* cv_mask; const float* cv_res; float* cv_pre;
+    M3TDrop cv_drop;                     // in-kernel dropout mask instead of cv_mask
 };
 
 __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
@@ -275,16 +276,18 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p) {
         for (int j = 0; j < 2; ++j) {
             const int col = bn + wn * 64 + j * 32 + l31;
             const float bv = (direct && p.bias) ? p.bias[col] : 0.f;
+            float dm[4] = {1.f, 1.f, 1.f, 1.f};
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = bm + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (CONV && p.cv_drop.on && (r & 3) == 0) m3t_drop_mask4(p.cv_drop, (uint32_t)row >> 2, (uint32_t)col, dm);
                 float v = acc[i][j][r];
                 float* q = dst + (size_t)row * ldd + col;
                 if (CONV) {
                     const size_t o = (size_t)row * ldd + col;
                     v += bv;
                     if (p.cv_pre) p.cv_pre[o] = v;
-                    const float mk = p.cv_mask ? p.cv_mask[o] : 1.f;
+                    const float mk = p.cv_drop.on ? dm[r & 3] : (p.cv_mask ? p.cv_mask[o] : 1.f);
                     if (p.act == 1) v = fmaxf(v, 0.f) * mk;
                     else if (p.act == 2) v = fmaxf(fmaxf(v, 0.f) * mk + p.cv_res[o], 0.f);
                     else if (p.cv_res) v += p.cv_res[o];
@@ -312,6 +315,7 @@ int m3t_sgemm_x6_launch(int transA, int transB, int M, int N, int K, const float
     p.act = act; p.accumulate = accumulate; p.splits = splits; p.kchunk = kchunk;
     p.seg_len = seg_len; p.seg_stride = seg_stride; p.a_off = a_off; p.b_off = b_off;
     p.cv_T = p.cv_C = p.cv_K = p.cv_dil = p.cv_lead = p.cv_anti = 0; p.cv_btap = 0; p.cv_mask = p.cv_res = nullptr; p.cv_pre = nullptr;
+    p.cv_drop = m3t_make_drop(0.f, 0ull);
     dim3 grid(N / XN, M / XM, splits), block(256);
 #define M3T_X6_DISPATCH(NS_)                                                                                        \
     do {                                                                                                           \
@@ -334,14 +338,14 @@ int m3t_sgemm_x6_launch(int transA, int transB, int M, int N, int K, const float
 // one [Co][Ci] plane per tap); anti = 1 (data gradient): w_t is [K][Ci][Co] read as the row-major [K*Ci][Co] matrix.
 int m3t_conv_x6_launch(const float* x, const float* w_t, const float* bias, const float* res, const float* mask, float* y,
                        float* pre, int B, int T, int Ci, int Co, int K, int dil, int lead, int act, int anti, int bf16_operands,
-                       hipStream_t s) {
+                       M3TDrop drop, hipStream_t s) {
     X6Params p;
     p.A = x; p.B = w_t; p.C = y; p.bias = bias; p.ws = nullptr;
     p.M = B * T; p.N = Co; p.K = K * Ci; p.lda = Ci; p.ldb = anti ? Co : Ci; p.ldc = Co;
     p.act = act; p.accumulate = 0; p.splits = 1; p.kchunk = K * Ci;
     p.seg_len = p.seg_stride = p.a_off = p.b_off = 0;
     p.cv_T = T; p.cv_C = Ci; p.cv_K = K; p.cv_dil = dil; p.cv_lead = lead; p.cv_anti = anti;
-    p.cv_btap = (size_t)Co * Ci; p.cv_mask = mask; p.cv_res = res; p.cv_pre = pre;
+    p.cv_btap = (size_t)Co * Ci; p.cv_mask = mask; p.cv_res = res; p.cv_pre = pre; p.cv_drop = drop;
     dim3 grid(Co / XN, p.M / XM, 1), block(256);
     if (anti) {
         if (bf16_operands) sgemm_x6_kernel<0, 0, false, 1, true><<<grid, block, 0, s>>>(p);

@@ -24,6 +24,7 @@ __device__ __forceinline__ float4 rbf4(float4 v) { return make_float4(rbf(v.x), 
 struct ConvParams {
     const float* x; const float* w_t; const float* bias; const float* res; const float* mask; float* y; float* pre;
     int B, T, Ci, Co, K, dil, act, anti, halo, lead, lda, w_kn, vecx, vecw, bf16;
+    M3TDrop drop;
 };
 
 // dynamic LDS: As[BK][lda] (lda = BM + halo + pad), Bs[K][BK][LDB]
@@ -169,14 +170,16 @@ __global__ __launch_bounds__(256) void causal_conv_kernel(ConvParams p) {
             const int col = n0 + wn * 64 + j * 32 + l31;
             if (col >= p.Co) continue;
             const float bv = p.bias ? p.bias[col] : 0.f;
+            float dm[4] = {1.f, 1.f, 1.f, 1.f};
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (p.drop.on && (r & 3) == 0) m3t_drop_mask4(p.drop, (uint32_t)row >> 2, (uint32_t)col, dm);     // rows row .. row+3
                 if (row >= M) continue;
                 const size_t o = (size_t)row * p.Co + col;
                 float v = acc[i][j][r] + bv;
                 if (p.pre) p.pre[o] = v;
-                const float mk = p.mask ? p.mask[o] : 1.f;
+                const float mk = p.drop.on ? dm[r & 3] : (p.mask ? p.mask[o] : 1.f);
                 if (p.act == 1) v = fmaxf(v, 0.f) * mk;
                 else if (p.act == 2) v = fmaxf(fmaxf(v, 0.f) * mk + p.res[o], 0.f);
                 else if (p.res) v += p.res[o];
@@ -266,7 +269,7 @@ extern "C" int m3t_weight_norm_bwd(const float* dw_t, const float* v, const floa
 
 int m3t_conv_x6_launch(const float* x, const float* w_t, const float* bias, const float* res, const float* mask, float* y,
                        float* pre, int B, int T, int Ci, int Co, int K, int dil, int lead, int act, int anti, int bf16_operands,
-                       hipStream_t s);
+                       M3TDrop drop, hipStream_t s);
 
 static bool conv_x6_enabled() {
     static int on = -1;
@@ -279,14 +282,17 @@ static bool conv_x6_enabled() {
 
 extern "C" int m3t_conv1d_fwd(const float* x, const float* w_t, const float* bias, const float* res,
                               const float* drop_mask, float* y, float* pre, int B, int T, int Ci, int Co, int K,
-                              int dilation, int lead, int act, int anticausal, int flags, void* stream) {
+                              int dilation, int lead, int act, int anticausal, float drop_p, unsigned long long drop_seed,
+                              int flags, void* stream) {
     if (B <= 0 || T <= 0) return 0;
+    if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && drop_mask)) return M3T_EINVAL;
     if (Ci <= 0 || Co <= 0 || K <= 0 || dilation <= 0 || !x || !w_t || !y) return M3T_EINVAL;
     if (lead < 0 || lead > (K - 1) * dilation) return M3T_EINVAL;
     if (act == 2 && !res) return M3T_EINVAL;
     ConvParams p;
     p.x = x; p.w_t = w_t; p.bias = bias; p.res = res; p.mask = drop_mask; p.y = y; p.pre = pre;
     p.B = B; p.T = T; p.Ci = Ci; p.Co = Co; p.K = K; p.dil = dilation; p.act = act; p.anti = anticausal; p.lead = lead; p.bf16 = (flags & M3T_BF16) ? 1 : 0;
+    p.drop = m3t_make_drop(drop_p, drop_seed);
     // interior shapes: the implicit GEMM on the bf16 matrix pipe (gemm_x6.hip, CONV): fp32-accurate bf16x6 products (one bf16
     // product in the M3T_BF16 mode), 128 x 128 x 32 tiles with the next tile's loads in flight during the MFMAs -- 2-3x this
     // file's single-stage fp32-MFMA kernel, which keeps the edge shapes (channels not multiples of 32 / 128, ragged B*T)
@@ -295,7 +301,7 @@ extern "C" int m3t_conv1d_fwd(const float* x, const float* w_t, const float* bia
         if (conv_x6_enabled() && ((size_t)B * T) % 128 == 0 && Co % 128 == 0 && Ci % 32 == 0 && al(x) && al(w_t) && al(y) && al(res) &&
             al(drop_mask) && al(pre))
             return m3t_conv_x6_launch(x, w_t, bias, res, drop_mask, y, pre, B, T, Ci, Co, K, dilation, lead, act, anticausal,
-                                      p.bf16, (hipStream_t)stream);
+                                      p.bf16, p.drop, (hipStream_t)stream);
     }
     const int halo = (K - 1) * dilation;
     p.halo = halo;
@@ -324,7 +330,7 @@ extern "C" int m3t_conv1d_fwd(const float* x, const float* w_t, const float* bia
 extern "C" int m3t_causal_conv_fwd(const float* x, const float* w_t, const float* bias, const float* res,
                                    const float* drop_mask, float* y, float* pre, int B, int T, int Ci, int Co, int K,
                                    int dilation, int act, int anticausal, void* stream) {
-    return m3t_conv1d_fwd(x, w_t, bias, res, drop_mask, y, pre, B, T, Ci, Co, K, dilation, 0, act, anticausal, 0, stream);
+    return m3t_conv1d_fwd(x, w_t, bias, res, drop_mask, y, pre, B, T, Ci, Co, K, dilation, 0, act, anticausal, 0.f, 0ull, 0, stream);
 }
 
 extern "C" int m3t_conv1d_wgrad(const float* dy, const float* x, float* dw_t, int B, int T, int Ci, int Co, int K,

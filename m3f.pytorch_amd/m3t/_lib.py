@@ -60,7 +60,7 @@ SIGNATURES = {
     "m3t_weight_norm_bwd": [_f, _f, _f, _f, _f, _f, _i, _i, _i, _s],
     "m3t_causal_conv_fwd": [_f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _s],
     "m3t_causal_conv_wgrad": [_f, _f, _f, _i, _i, _i, _i, _i, _i, _f, _z, _s],
-    "m3t_conv1d_fwd": [_f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _s],
+    "m3t_conv1d_fwd": [_f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, C.c_float, C.c_ulonglong, _i, _s],
     "m3t_conv1d_wgrad": [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _z, _i, _s],
     "m3t_bn_rows_ws_bytes": [_i, _i],
     "m3t_bn_rows_fwd": [_f, _i, _i, _f, _f, _f, _f, C.c_float, C.c_float, _i, _i, _f, _f, _f, _f, _z, _s],
@@ -68,6 +68,7 @@ SIGNATURES = {
     "m3t_bct_to_btc": [_f, _f, _i, _i, _i, _s],
     "m3t_btc_to_bct": [_f, _f, _i, _i, _i, _s],
     "m3t_mask_pos": [_f, _f, _f, _f, _z, _s],
+    "m3t_mask_pos_drop": [_f, _f, _f, _i, _i, C.c_float, C.c_ulonglong, _s],
     "m3t_cbam_channel_fwd": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _s],
     "m3t_cbam_channel_bwd": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _f, _z, _s],
     "m3t_cbam_spatial_fwd": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, C.c_float, C.c_float, _f, _z, _s],

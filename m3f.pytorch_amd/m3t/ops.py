@@ -266,8 +266,14 @@ def transpose2d(src):
     return dst
 
 
-def mask_pos(s, dy, mul=None):
+def mask_pos(s, dy, mul=None, drop=None):
+    """dy where s > 0 (x mul); drop = (p, seed): x the in-kernel dropout mask of the forward conv epilogue, regenerated"""
     out = torch.empty_like(dy)
+    if drop is not None and drop[0] > 0:
+        Cc = dy.shape[-1]
+        _lib.check(lib().m3t_mask_pos_drop(_p(s), _p(dy), _p(out), dy.numel() // Cc, Cc, float(drop[0]), int(drop[1]), _stream()),
+                   "m3t_mask_pos_drop")
+        return out
     _lib.check(lib().m3t_mask_pos(_p(s), _p(dy), _p(mul), _p(out), dy.numel(), _stream()), "m3t_mask_pos")
     return out
 
@@ -881,10 +887,10 @@ def btc_to_bct(x):
     return _BtcToBct.apply(x)
 
 
-def _conv(x, w_t, bias, res, mask, pre, B, T, Ci, Co, K, dil, act, anti, prec=0):
+def _conv(x, w_t, bias, res, mask, pre, B, T, Ci, Co, K, dil, act, anti, prec=0, drop=(0.0, 0)):
     y = torch.empty(B, T, Co, dtype=torch.float32, device=x.device)
     rc = lib().m3t_conv1d_fwd(_p(x), _p(w_t), _p(bias), _p(res), _p(mask), _p(y), _p(pre), B, T, Ci, Co, K, dil, 0,
-                              act, anti, prec, _stream())
+                              act, anti, float(drop[0]), int(drop[1]), prec, _stream())
     _lib.check(rc, "m3t_conv1d_fwd")
     return y
 
@@ -895,7 +901,7 @@ class _TemporalBlock(torch.autograd.Function):
     + residual (identity or 1x1 conv) -> ReLU, with bias/ReLU/residual fused in the conv epilogue."""
 
     @staticmethod
-    def forward(ctx, x, v1, g1, b1, v2, g2, b2, wd, bd, dilation, m1, m2):
+    def forward(ctx, x, v1, g1, b1, v2, g2, b2, wd, bd, dilation, m1, m2, drop_p=0.0, seed1=0, seed2=0):
         x = _req(x.contiguous(), "x")
         for t in (v1, g1, b1, v2, g2, b2):
             _req(t, "tcn parameter")
@@ -909,16 +915,17 @@ class _TemporalBlock(torch.autograd.Function):
         _lib.check(lib().m3t_weight_norm_fwd(_p(v1), _p(g1), _p(w1t), _p(n1), Co, Ci, K, _stream()), "m3t_weight_norm_fwd")
         _lib.check(lib().m3t_weight_norm_fwd(_p(v2), _p(g2), _p(w2t), _p(n2), Co, Co, K, _stream()), "m3t_weight_norm_fwd")
         prec = ctx.prec = _PREC[0]
-        h1 = _conv(x, w1t, b1, None, m1, None, B, T, Ci, Co, K, dilation, 1, 0, prec)
+        d1, d2 = (drop_p, seed1), (drop_p, seed2)        # in-kernel Philox masks (drop_p > 0) instead of the mask tensors m1 / m2
+        h1 = _conv(x, w1t, b1, None, m1, None, B, T, Ci, Co, K, dilation, 1, 0, prec, d1)
         if wd is not None:
             res = torch.empty(B, T, Co, dtype=torch.float32, device=dev)
             sgemm(0, 1, B * T, Co, Ci, x, 0, Ci, wd, 0, Ci, res, 0, Co, bias=bd, prec=prec)
         else:
             res = x
         a2 = torch.empty(B, T, Co, dtype=torch.float32, device=dev)
-        y = _conv(h1, w2t, b2, res, m2, a2, B, T, Co, Co, K, dilation, 2, 0, prec)
+        y = _conv(h1, w2t, b2, res, m2, a2, B, T, Co, Co, K, dilation, 2, 0, prec, d2)
         ctx.save_for_backward(x, v1, g1, v2, g2, wd, w1t, w2t, n1, n2, h1, a2, y, m1, m2)
-        ctx.dil = dilation
+        ctx.dil, ctx.drops = dilation, (d1, d2)
         return y
 
     @staticmethod
@@ -930,9 +937,10 @@ class _TemporalBlock(torch.autograd.Function):
         dil, dev, prec = ctx.dil, x.device, ctx.prec
         ws = workspace(dev)
         ds = mask_pos(y, dy)                         # through the block's output ReLU
-        da2 = mask_pos(a2, ds, m2)                   # through dropout2 + relu2
+        d1, d2 = ctx.drops
+        da2 = mask_pos(a2, ds, m2, d2)               # through dropout2 + relu2
         dh1 = _conv(da2, w2t, None, None, None, None, B, T, Co, Co, K, dil, 0, 1, prec)
-        da1 = mask_pos(h1, dh1, m1)                  # h1 > 0 <=> a1 > 0 (dropout keeps the sign)
+        da1 = mask_pos(h1, dh1, m1, d1)              # h1 > 0 <=> a1 > 0 (dropout keeps the sign)
         dw2t = torch.empty_like(w2t)
         dw1t = torch.empty_like(w1t)
         _lib.check(lib().m3t_conv1d_wgrad(_p(da2), _p(h1), _p(dw2t), B, T, Co, Co, K, dil, 0, _p(ws), ws.numel() * 4, prec,
@@ -959,11 +967,13 @@ class _TemporalBlock(torch.autograd.Function):
             sgemm(1, 0, Co, Ci, B * T, ds, 0, Co, x, 0, Ci, dwd, 0, Ci, prec=prec)
             dbd = torch.empty(Co, dtype=torch.float32, device=dev)
             colsum(ds, 0, B * T, Co, Co, dbd)
-        return dx, dv1, dg1, db1, dv2, dg2, db2, dwd, dbd, None, None, None
+        return dx, dv1, dg1, db1, dv2, dg2, db2, dwd, dbd, None, None, None, None, None, None
 
 
-def temporal_block(x_btc, v1, g1, b1, v2, g2, b2, wd, bd, dilation, m1=None, m2=None):
-    return _TemporalBlock.apply(x_btc, v1, g1, b1, v2, g2, b2, wd, bd, dilation, m1, m2)
+def temporal_block(x_btc, v1, g1, b1, v2, g2, b2, wd, bd, dilation, m1=None, m2=None, drop_p=0.0, seeds=(0, 0)):
+    """m1 / m2: explicit pre-scaled dropout masks, or drop_p > 0 with two 64-bit seeds: masks generated inside the conv epilogues
+    (Philox4x32-10, include/m3t_hip.h) and regenerated in backward"""
+    return _TemporalBlock.apply(x_btc, v1, g1, b1, v2, g2, b2, wd, bd, dilation, m1, m2, float(drop_p), int(seeds[0]), int(seeds[1]))
 
 
 class _ConvBnRelu(torch.autograd.Function):
@@ -985,7 +995,7 @@ class _ConvBnRelu(torch.autograd.Function):
         w_t = transpose2d(w.detach().view(Co * Ci, K)).view(K, Co, Ci)          # tap-major [K][Co][Ci]
         a = torch.empty(B, T, Co, dtype=torch.float32, device=dev)
         prec = _PREC[0]
-        rc = lib().m3t_conv1d_fwd(_p(x), _p(w_t), _p(b), None, None, _p(a), None, B, T, Ci, Co, K, 1, pad, 0, 0, prec, _stream())
+        rc = lib().m3t_conv1d_fwd(_p(x), _p(w_t), _p(b), None, None, _p(a), None, B, T, Ci, Co, K, 1, pad, 0, 0, 0.0, 0, prec, _stream())
         _lib.check(rc, "m3t_conv1d_fwd")
         y = torch.empty_like(a)
         mean = torch.empty(Co, dtype=torch.float32, device=dev)
@@ -1015,7 +1025,7 @@ class _ConvBnRelu(torch.autograd.Function):
                                    _p(dgamma), _p(dbeta), _p(ws), ws.numel() * 4, _stream())
         _lib.check(rc, "m3t_bn_rows_bwd")
         dx = torch.empty_like(x)
-        rc = lib().m3t_conv1d_fwd(_p(da), _p(w_t), None, None, None, _p(dx), None, B, T, Co, Ci, K, 1, pad, 0, 1, prec, _stream())
+        rc = lib().m3t_conv1d_fwd(_p(da), _p(w_t), None, None, None, _p(dx), None, B, T, Co, Ci, K, 1, pad, 0, 1, 0.0, 0, prec, _stream())
         _lib.check(rc, "m3t_conv1d_fwd (data gradient)")
         dw_t = torch.empty_like(w_t)
         rc = lib().m3t_conv1d_wgrad(_p(da), _p(x), _p(dw_t), B, T, Ci, Co, K, 1, pad, _p(ws), ws.numel() * 4, prec, _stream())

@@ -81,22 +81,20 @@ class TemporalBlock(nn.Module):
         if self.downsample is not None:
             self.downsample.weight.data.normal_(0, 0.01)
 
-    def _mask(self, like):
-        keep = 1.0 - self.p_drop
-        return torch.empty_like(like).bernoulli_(keep).div_(keep)
-
-    def forward_btc(self, x):
-        """x channel-last [B,T,C_in] -> [B,T,C_out]."""
-        m1 = m2 = None
-        if self.training and self.p_drop > 0:
-            shape = x.new_empty(x.shape[0], x.shape[1], self.conv1.out_channels)
-            m1, m2 = self._mask(shape), self._mask(shape)
+    def forward_btc(self, x, seeds=None):
+        """x channel-last [B,T,C_in] -> [B,T,C_out].  Train mode: the two nn.Dropout(p) of the block (reference tcn.py:23,29)
+        are masks generated INSIDE the conv epilogues from two 64-bit seeds (Philox4x32-10 keyed by seed, counter = element;
+        the backward pass regenerates them: no mask tensor in HBM).  The seeds come from torch's CPU generator, so
+        torch.manual_seed makes a run reproducible; `seeds` overrides them (tests)."""
+        drop_p = self.p_drop if (self.training and self.p_drop > 0) else 0.0
+        if drop_p > 0 and seeds is None:
+            seeds = torch.empty(2, dtype=torch.int64).random_().tolist()
         wd = bd = None
         if self.downsample is not None:
             wd, bd = self.downsample.weight, self.downsample.bias
         return ops.temporal_block(x, self.conv1.weight_v, self.conv1.weight_g, self.conv1.bias,
                                   self.conv2.weight_v, self.conv2.weight_g, self.conv2.bias,
-                                  wd, bd, self.dilation, m1, m2)
+                                  wd, bd, self.dilation, None, None, drop_p, seeds or (0, 0))
 
     def forward(self, x):
         return ops.btc_to_bct(self.forward_btc(ops.bct_to_btc(x)))

@@ -800,3 +800,36 @@ def load_audio(mel_spec, start_idx, w_len):
             w = np.pad(w, ((0, 5 - len(w)), (0, 0)), "constant")
         rows.append(w.reshape(-1))
     return np.stack(rows)
+
+
+# ------------------------------------------------------------------ in-kernel dropout masks (test infrastructure)
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11) on uint32 arrays:
+    the published algorithm, restated -- the generator the HIP conv epilogues use for nn.Dropout (reference models/tcn.py:17,23,29;
+    include/m3t_hip.h, m3t_conv1d_fwd).  Pinned by the Random123 known-answer vectors in tests/test_oracle_golden.py."""
+    c0, c1, c2, c3 = (np.asarray(c, dtype=np.uint32) for c in (c0, c1, c2, c3))
+    k0, k1 = np.uint32(k0), np.uint32(k1)
+    m0, m1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+    for _ in range(10):
+        p0, p1 = c0.astype(np.uint64) * m0, c2.astype(np.uint64) * m1
+        h0, l0 = (p0 >> np.uint64(32)).astype(np.uint32), (p0 & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        h1, l1 = (p1 >> np.uint64(32)).astype(np.uint32), (p1 & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        c0, c1, c2, c3 = h1 ^ c1 ^ k0, l1, h0 ^ c3 ^ k1, l0
+        k0 = np.uint32((int(k0) + 0x9E3779B9) & 0xFFFFFFFF)
+        k1 = np.uint32((int(k1) + 0xBB67AE85) & 0xFFFFFFFF)
+    return c0, c1, c2, c3
+
+
+def dropout_mask(rows, C, p, seed):
+    """the pre-scaled mask [rows, C] of m3t_conv1d_fwd's in-kernel dropout: element (row, col) is kept (x 1/(1-p)) iff word
+    (row & 3) of philox4x32_10(counter {col, row >> 2, 0, 0}, key {seed lo, seed hi}) < (1-p) * 2^32"""
+    G = (rows + 3) // 4
+    g = np.broadcast_to(np.arange(G, dtype=np.uint32)[:, None], (G, C))
+    col = np.broadcast_to(np.arange(C, dtype=np.uint32)[None, :], (G, C))
+    z = np.zeros((G, C), dtype=np.uint32)
+    words = philox4x32_10(col, g, z, z, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    keep = 1.0 - float(p)
+    t = keep * 4294967296.0
+    thr = 0xFFFFFFFF if t >= 4294967295.0 else int(t)
+    m = np.stack([(w < np.uint32(thr)) for w in words], axis=1).reshape(G * 4, C)[:rows]      # row = 4 g + word index
+    return m.astype(np.float64) * np.float64(np.float32(1.0 / keep))

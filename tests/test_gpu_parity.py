@@ -489,21 +489,44 @@ def test_conv1d_on_the_bf16x6_pipe(K, dil, lead, anti, act):
     keep = [dev(a) if a is not None else None for a in (x, w, bias, res, mask)]
     ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
     rc = _lib.load().m3t_conv1d_fwd(ptr(keep[0]), ptr(keep[1]), ptr(keep[2]), ptr(keep[3]), ptr(keep[4]), ptr(y), ptr(pre), B, T, Ci, Co, K,
-                                    dil, lead, act, anti, 0, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+                                    dil, lead, act, anti, 0.0, 0, 0, C.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0
     close(y, ref, 2e-5, "y")
     close(pre, pre_ref, 2e-5, "pre")
 
 
-def test_tcn_train_mode_dropout_runs():
+@pytest.mark.parametrize("C_in,width,B,T", [(16, 32, 2, 40), (64, 128, 4, 96)])     # fp32-MFMA conv kernel / bf16x6 implicit GEMM
+def test_tcn_train_mode_dropout_matches_oracle(C_in, width, B, T):
+    """TRAIN mode with dropout p = 0.2 active: the masks are generated inside the conv epilogues (Philox4x32-10 keyed by two seeds
+    per block) and regenerated in backward -- no mask tensor.  The oracle rebuilds the same masks from the seeds (its numpy Philox is
+    pinned on the Random123 known answers) and runs models/tcn.py's arithmetic: outputs and every gradient must agree."""
     from models.tcn import TemporalConvNet
-    torch.manual_seed(0)
-    m = TemporalConvNet(16, [32, 32], 3).to(DEV).train()
-    x = torch.randn(2, 16, 40, device=DEV, requires_grad=True)
-    y = m(x)
-    y.sum().backward()
-    assert torch.isfinite(y).all() and torch.isfinite(x.grad).all()
-    assert not torch.equal(y, m(x))          # fresh masks every call
+    rs = np.random.RandomState(31)
+    m = fill_module(TemporalConvNet(C_in, [width, width], 3), 32).to(DEV).train()
+    xn, ct = draw(rs, (B, C_in, T)), draw(rs, (B, width, T))
+    seeds = [(0x1234567887654321, 0x0fedcba912345678), (3, 2 ** 63 - 5)]
+    x = dev(xn, True)
+    from m3t import ops
+    h = ops.bct_to_btc(x)
+    for blk, sd in zip(m.network, seeds):
+        h = blk.forward_btc(h, seeds=sd)
+    y = ops.btc_to_bct(h)
+    p = {n: t.detach().cpu().numpy().astype(np.float64) for n, t in m.named_parameters()}
+    # oracle masks: channel-last [B*T, width] -> the oracle's channel-first [B, width, T]
+    masks = [tuple(O.dropout_mask(B * T, width, 0.2, s_).reshape(B, T, width).transpose(0, 2, 1) for s_ in sd) for sd in seeds]
+    y_ref, caches = O.tcn_fwd(xn.astype(np.float64), p, 2, masks=masks)
+    dx_ref, g_ref = O.tcn_bwd(ct.astype(np.float64), caches, p)
+    assert float((y_ref == 0).mean()) > 0.05           # the masks really are in the result
+    close(y, y_ref, TOL, "y")
+    (y * dev(ct)).sum().backward()
+    close(x.grad, dx_ref, TOL, "dx")
+    for n, prm in m.named_parameters():
+        close(prm.grad, g_ref[n], 2e-4, n)
+    # fresh seeds from torch's CPU generator on every ordinary call; reproducible under torch.manual_seed
+    torch.manual_seed(5); y1 = m(x.detach())
+    y2 = m(x.detach())
+    torch.manual_seed(5); y3 = m(x.detach())
+    assert not torch.equal(y1, y2) and torch.equal(y1, y3)
 
 
 # ------------------------------------------------------------------------------ AttFusion

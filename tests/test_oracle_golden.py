@@ -222,3 +222,23 @@ def test_melspec_oracle_known_answers():
     assert 13 <= peak <= 16, peak                               # 1 kHz = mel 15 of the Slaney scale: band 14/15 of 40 up to 8 kHz
     assert db.max() - db.min() <= 80.0 + 1e-9
     assert np.allclose(O.melspec_db(np.zeros(4000), fps), -100.0)   # 10 log10(amin = 1e-10)
+
+
+def test_philox_known_answers_and_dropout_mask_layout():
+    """the oracle's Philox4x32-10 against the Random123 known-answer vectors (kat_vectors: counter / key all zeros, all ones,
+    and the pi digits), and the (row, col) -> (counter, word) layout of the dropout mask"""
+    from oracle import m3t_oracle as O
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = O.philox4x32_10(*[np.array([c], dtype=np.uint32) for c in ctr], key[0], key[1])
+        assert tuple(int(w[0]) for w in got) == want, (ctr, [hex(int(w[0])) for w in got])
+    m = O.dropout_mask(10, 6, 0.2, 0x0123456789abcdef)
+    assert m.shape == (10, 6) and set(np.unique(m)) <= {0.0, float(np.float32(1.25))}
+    w = O.philox4x32_10(np.array([5], np.uint32), np.array([2], np.uint32), np.array([0], np.uint32), np.array([0], np.uint32),
+                        0x89abcdef, 0x01234567)
+    thr = int(0.8 * 4294967296.0)
+    assert [m[8, 5] > 0, m[9, 5] > 0] == [int(w[0][0]) < thr, int(w[1][0]) < thr]       # rows 8, 9 = words 0, 1 of group 2
+    big = O.dropout_mask(4096, 64, 0.2, 7)
+    assert abs((big > 0).mean() - 0.8) < 0.01
