@@ -75,6 +75,17 @@ __global__ __launch_bounds__(256) void channel_fwd_kernel(const float* __restric
         const float* pl = xb + (size_t)c * HW;
         float sum = 0.f, mx = -INFINITY;
         int am = 0x7fffffff;
+        if ((HW & 3) == 0 && ((uintptr_t)pl & 15) == 0) {
+            const float4* p4 = reinterpret_cast<const float4*>(pl);
+            for (int i = lane; i < (HW >> 2); i += 64) {
+                const float4 v = p4[i];
+                sum += (v.x + v.y) + (v.z + v.w);
+                if (v.x > mx) { mx = v.x; am = 4 * i; }
+                if (v.y > mx) { mx = v.y; am = 4 * i + 1; }
+                if (v.z > mx) { mx = v.z; am = 4 * i + 2; }
+                if (v.w > mx) { mx = v.w; am = 4 * i + 3; }
+            }
+        } else
         for (int i = lane; i < HW; i += 64) {
             const float v = pl[i];
             sum += v;
@@ -165,6 +176,14 @@ __global__ __launch_bounds__(256) void channel_bwd_kernel(const float* __restric
         const float* pl = xb + (size_t)c * HW;
         const float* gl = gb + (size_t)c * HW;
         float ds = 0.f;
+        if ((HW & 3) == 0 && (((uintptr_t)pl | (uintptr_t)gl) & 15) == 0) {
+            const float4* p4 = reinterpret_cast<const float4*>(pl);
+            const float4* g4 = reinterpret_cast<const float4*>(gl);
+            for (int i = lane; i < (HW >> 2); i += 64) {
+                const float4 a = g4[i], b = p4[i];
+                ds += (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
+            }
+        } else
         for (int i = lane; i < HW; i += 64) ds += gl[i] * pl[i];
         ds = wave_sum(ds);
         if (lane == 0) {
@@ -209,6 +228,25 @@ __global__ __launch_bounds__(256) void channel_bwd_kernel(const float* __restric
     __syncthreads();
     float* db = dx + (size_t)n * C * HW;
     const int total = C * HW;
+    if ((HW & 3) == 0 && (((uintptr_t)gb | (uintptr_t)db) & 15) == 0) {
+        const float4* g4 = reinterpret_cast<const float4*>(gb);
+        float4* d4 = reinterpret_cast<float4*>(db);
+        const int HW4 = HW >> 2;
+        for (int c = wave; c < C; c += 4) {                     // one wavefront per plane: no per-element division
+            const float sc = scale[(size_t)n * C + c], da = s_davg[c], dm = s_dmax[c];
+            const int am = argmax[(size_t)n * C + c];
+            for (int i = lane; i < HW4; i += 64) {
+                float4 v = g4[(size_t)c * HW4 + i];
+                v.x = v.x * sc + da; v.y = v.y * sc + da; v.z = v.z * sc + da; v.w = v.w * sc + da;
+                if ((am >> 2) == i) {
+                    const int e = am & 3;
+                    if (e == 0) v.x += dm; else if (e == 1) v.y += dm; else if (e == 2) v.z += dm; else v.w += dm;
+                }
+                d4[(size_t)c * HW4 + i] = v;
+            }
+        }
+        return;
+    }
     for (int i = tid; i < total; i += 256) {
         const int c = i / HW, p = i - c * HW;
         float v = gb[i] * scale[(size_t)n * C + c] + s_davg[c];
@@ -422,6 +460,132 @@ __global__ __launch_bounds__(256) void spatial_bwd_dx_kernel(const float* __rest
     for (int c = 0; c < C; ++c) db[(size_t)c * HW] = gb[(size_t)c * HW] * s + dmean + (c == am ? dmax : 0.f);
 }
 
+// ---- float4 forms of the four kernels that sweep x / dy (H*W a multiple of 4, 16-B aligned tensors): one thread = 4 consecutive
+// pixels of a frame, 16 B per lane and channel, four channels in flight per loop trip.  The thread-per-pixel kernels above moved
+// 4 B per lane with one load in flight and reached ~1.5 TB/s effective; they keep the ragged maps (7 x 7).
+__global__ __launch_bounds__(256) void spatial_compress4_kernel(const float4* __restrict__ x, float4* __restrict__ comp,
+                                                                int4* __restrict__ cargmax, int N, int C, int HW4) {
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (size_t)N * HW4) return;
+    const int n = (int)(gid / HW4), q = (int)(gid % HW4);
+    const float4* xb = x + (size_t)n * C * HW4 + q;
+    float4 mx = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY), sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    int4 am = make_int4(0, 0, 0, 0);
+#pragma unroll 4
+    for (int c = 0; c < C; ++c) {
+        const float4 v = xb[(size_t)c * HW4];
+        sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+        if (v.x > mx.x) { mx.x = v.x; am.x = c; }
+        if (v.y > mx.y) { mx.y = v.y; am.y = c; }
+        if (v.z > mx.z) { mx.z = v.z; am.z = c; }
+        if (v.w > mx.w) { mx.w = v.w; am.w = c; }
+    }
+    const float ic = 1.f / (float)C;
+    comp[((size_t)n * 2 + 0) * HW4 + q] = mx;
+    comp[((size_t)n * 2 + 1) * HW4 + q] = make_float4(sum.x / (float)C, sum.y / (float)C, sum.z / (float)C, sum.w / (float)C);
+    (void)ic;
+    cargmax[(size_t)n * HW4 + q] = am;
+}
+
+__global__ __launch_bounds__(256) void spatial_apply4_kernel(const float4* __restrict__ x, const float* __restrict__ bn,
+                                                             const float* __restrict__ stats, float4* __restrict__ xhat,
+                                                             float4* __restrict__ scale, float4* __restrict__ y, int N, int C,
+                                                             int HW4) {
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (size_t)N * HW4) return;
+    const int n = (int)(gid / HW4), q = (int)(gid % HW4);
+    const float mean = stats[0], inv = stats[1], ga = bn[0], be = bn[1];
+    float4 xh = xhat[gid];                                   // raw conv output on entry
+    xh.x = (xh.x - mean) * inv; xh.y = (xh.y - mean) * inv; xh.z = (xh.z - mean) * inv; xh.w = (xh.w - mean) * inv;
+    xhat[gid] = xh;
+    float4 s;
+    s.x = 1.f / (1.f + expf(-(xh.x * ga + be))); s.y = 1.f / (1.f + expf(-(xh.y * ga + be)));
+    s.z = 1.f / (1.f + expf(-(xh.z * ga + be))); s.w = 1.f / (1.f + expf(-(xh.w * ga + be)));
+    scale[gid] = s;
+    const float4* xb = x + (size_t)n * C * HW4 + q;
+    float4* yb = y + (size_t)n * C * HW4 + q;
+#pragma unroll 4
+    for (int c = 0; c < C; ++c) {
+        float4 v = xb[(size_t)c * HW4];
+        v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
+        yb[(size_t)c * HW4] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void spatial_bwd_ds4_kernel(const float4* __restrict__ dy, const float4* __restrict__ x,
+                                                              const float4* __restrict__ scale, const float4* __restrict__ xhat,
+                                                              float4* __restrict__ dbn, double* __restrict__ part, int N, int C,
+                                                              int HW4) {
+    __shared__ double red[8];
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    if (gid < (size_t)N * HW4) {
+        const int n = (int)(gid / HW4), q = (int)(gid % HW4);
+        const float4* xb = x + (size_t)n * C * HW4 + q;
+        const float4* gb = dy + (size_t)n * C * HW4 + q;
+        float4 ds = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+        for (int c = 0; c < C; ++c) {
+            const float4 g = gb[(size_t)c * HW4], v = xb[(size_t)c * HW4];
+            ds.x += g.x * v.x; ds.y += g.y * v.y; ds.z += g.z * v.z; ds.w += g.w * v.w;
+        }
+        const float4 s = scale[gid], xh = xhat[gid];
+        float4 d;
+        d.x = ds.x * s.x * (1.f - s.x); d.y = ds.y * s.y * (1.f - s.y); d.z = ds.z * s.z * (1.f - s.z); d.w = ds.w * s.w * (1.f - s.w);
+        dbn[gid] = d;
+        s1 = ((double)d.x + d.y) + ((double)d.z + d.w);
+        s2 = ((double)d.x * xh.x + (double)d.y * xh.y) + ((double)d.z * xh.z + (double)d.w * xh.w);
+    }
+    s1 = block_sum_d(s1, red);
+    s2 = block_sum_d(s2, red);
+    if (threadIdx.x == 0) {
+        part[2 * (size_t)blockIdx.x] = s1; part[2 * (size_t)blockIdx.x + 1] = s2;
+    }
+}
+
+__global__ __launch_bounds__(256) void spatial_bwd_dx4_kernel(const float4* __restrict__ dy, const float* __restrict__ dc,
+                                                              const float* __restrict__ w, const float4* __restrict__ scale,
+                                                              const int4* __restrict__ cargmax, float4* __restrict__ dx, int N,
+                                                              int C, int H, int W) {
+    const int HW = H * W, HW4 = HW >> 2;
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (size_t)N * HW4) return;
+    const int n = (int)(gid / HW4), q = (int)(gid % HW4);
+    const float* dcn = dc + (size_t)n * HW;
+    float dmax[4], dmean[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int p = 4 * q + e, h = p / W, ww = p % W;
+        float a = 0.f, b = 0.f;
+        for (int i = 0; i < 5; ++i) {
+            const int hh = h - i + 2;
+            if (hh < 0 || hh >= H) continue;
+            for (int j = 0; j < 5; ++j) {
+                const int wj = ww - j + 2;
+                if (wj < 0 || wj >= W) continue;
+                const float d = dcn[hh * W + wj];
+                a += w[(0 * 5 + i) * 5 + j] * d;
+                b += w[(1 * 5 + i) * 5 + j] * d;
+            }
+        }
+        dmax[e] = a; dmean[e] = b / (float)C;
+    }
+    const float4 s = scale[gid];
+    const int4 am = cargmax[gid];
+    const float4* gb = dy + (size_t)n * C * HW4 + q;
+    float4* db = dx + (size_t)n * C * HW4 + q;
+#pragma unroll 4
+    for (int c = 0; c < C; ++c) {
+        const float4 g = gb[(size_t)c * HW4];
+        float4 o;
+        o.x = g.x * s.x + dmean[0] + (c == am.x ? dmax[0] : 0.f);
+        o.y = g.y * s.y + dmean[1] + (c == am.y ? dmax[1] : 0.f);
+        o.z = g.z * s.z + dmean[2] + (c == am.z ? dmax[2] : 0.f);
+        o.w = g.w * s.w + dmean[3] + (c == am.w ? dmax[3] : 0.f);
+        db[(size_t)c * HW4] = o;
+    }
+}
+
 }  // namespace
 
 extern "C" int m3t_sgemm(int, int, int, int, int, const float*, int, const float*, int, float*, int, const float*, int, int,
@@ -487,13 +651,20 @@ extern "C" int m3t_cbam_spatial_fwd(const float* x, const float* conv_w, const f
     const int nblk = (int)(((size_t)N * HW + 255) / 256);
     double* part = reinterpret_cast<double*>(ws);      // fp64 (sum, sumsq) per block
     if (ws_bytes < (size_t)nblk * 2 * sizeof(double) || ((uintptr_t)ws & 7) != 0) return M3T_EINVAL;
-    spatial_compress_kernel<<<nblk, 256, 0, s>>>(x, comp, cargmax, N, C, HW);
+    const bool vec4 = (HW % 4 == 0) && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)comp | (uintptr_t)cargmax | (uintptr_t)xhat |
+                                          (uintptr_t)scale) & 15) == 0);
+    const int nblk4 = (int)(((size_t)N * (HW / 4) + 255) / 256);
+    if (vec4) spatial_compress4_kernel<<<nblk4, 256, 0, s>>>(reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(comp),
+                                                            reinterpret_cast<int4*>(cargmax), N, C, HW / 4);
+    else spatial_compress_kernel<<<nblk, 256, 0, s>>>(x, comp, cargmax, N, C, HW);
     M3T_LAUNCH_CHECK();
     spatial_conv_kernel<<<nblk, 256, 0, s>>>(comp, conv_w, xhat, part, N, H, W);
     M3T_LAUNCH_CHECK();
     spatial_stats_kernel<<<1, 256, 0, s>>>(part, nblk, (double)N * HW, running, stats, training, momentum, eps);
     M3T_LAUNCH_CHECK();
-    spatial_apply_kernel<<<nblk, 256, 0, s>>>(x, bn, stats, xhat, scale, y, N, C, HW);
+    if (vec4) spatial_apply4_kernel<<<nblk4, 256, 0, s>>>(reinterpret_cast<const float4*>(x), bn, stats, reinterpret_cast<float4*>(xhat),
+                                                         reinterpret_cast<float4*>(scale), reinterpret_cast<float4*>(y), N, C, HW / 4);
+    else spatial_apply_kernel<<<nblk, 256, 0, s>>>(x, bn, stats, xhat, scale, y, N, C, HW);
     M3T_LAUNCH_CHECK();
     return 0;
 }
@@ -522,9 +693,15 @@ extern "C" int m3t_cbam_spatial_bwd(const float* dy, const float* x, const float
     float* g_dc = ws + total;
     double* part = reinterpret_cast<double*>(ws + off);
     double* dwpart = part + 2 * nblk;
-    spatial_bwd_ds_kernel<<<(int)nblk, 256, 0, s>>>(dy, x, scale, xhat, g_dbn, part, N, C, HW);
+    const bool vec4 = (HW % 4 == 0) && ((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)cargmax | (uintptr_t)xhat |
+                                          (uintptr_t)scale | (uintptr_t)g_dbn) & 15) == 0);
+    const size_t nblk4 = (total / 4 + 255) / 256;
+    if (vec4) spatial_bwd_ds4_kernel<<<(int)nblk4, 256, 0, s>>>(reinterpret_cast<const float4*>(dy), reinterpret_cast<const float4*>(x),
+                                                                reinterpret_cast<const float4*>(scale), reinterpret_cast<const float4*>(xhat),
+                                                                reinterpret_cast<float4*>(g_dbn), part, N, C, HW / 4);
+    else spatial_bwd_ds_kernel<<<(int)nblk, 256, 0, s>>>(dy, x, scale, xhat, g_dbn, part, N, C, HW);
     M3T_LAUNCH_CHECK();
-    sum_pairs_kernel<<<1, 256, 0, s>>>(part, (int)nblk, dbn);
+    sum_pairs_kernel<<<1, 256, 0, s>>>(part, (int)(vec4 ? nblk4 : nblk), dbn);
     M3T_LAUNCH_CHECK();
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
@@ -534,7 +711,10 @@ extern "C" int m3t_cbam_spatial_bwd(const float* dy, const float* x, const float
     M3T_LAUNCH_CHECK();
     spatial_bwd_dw_final_kernel<<<50, 64, 0, s>>>(dwpart, chunks, dconv_w);
     M3T_LAUNCH_CHECK();
-    spatial_bwd_dx_kernel<<<(int)nblk, 256, 0, s>>>(dy, g_dc, conv_w, scale, cargmax, dx, N, C, H, W);
+    if (vec4) spatial_bwd_dx4_kernel<<<(int)nblk4, 256, 0, s>>>(reinterpret_cast<const float4*>(dy), g_dc, conv_w,
+                                                                reinterpret_cast<const float4*>(scale), reinterpret_cast<const int4*>(cargmax),
+                                                                reinterpret_cast<float4*>(dx), N, C, H, W);
+    else spatial_bwd_dx_kernel<<<(int)nblk, 256, 0, s>>>(dy, g_dc, conv_w, scale, cargmax, dx, N, C, H, W);
     M3T_LAUNCH_CHECK();
     return 0;
 }
