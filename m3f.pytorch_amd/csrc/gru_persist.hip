@@ -48,6 +48,9 @@ struct ExPtrs {
     int fault_step;                  // fault injection (flag M3T_SCAN_FAULT): workgroup 0 does not publish this step; -1 = never
     unsigned long long* prof;        // optional in-kernel stamps (M3T_SCAN_PROF=1): 6 phase sums of workgroup 0, wave 0 (M3T_SCAN_PROF=2: wave 4, a wave without cell math)
     int prof_tid;
+    int slot_map;                    // 1: persist_map's XCD-slot mapping (grid = 8 * ceil(G/8) * H/16), 0: gid = b % G
+    unsigned long long* hs;          // placement-handshake table (arena), or nullptr: no L2-served exchange
+    unsigned hs_tag;
     unsigned tag_base;               // tags of this launch are tag_base + step + 1 (launch-unique inside an exchange arena: no memset per launch)
 };
 
@@ -83,6 +86,59 @@ __device__ __forceinline__ void raise_spin(unsigned* err, int step) {
     __hip_atomic_store(err, (unsigned)step + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Block -> (group, unit block).  A group (one scan x one row block) is the set of workgroups that exchange h_t / dgh_t with each
+// other every step.  Blocks b and b + 8 share an XCD (observed dispatch rule: blocks are dealt round-robin over the 8 XCDs), so
+// slot = b % 8 names an XCD and a group lives entirely in one slot: group g sits in slot g % 8 (gpx = ceil(G / 8) groups per slot),
+// its members are the blocks of that slot.  The launch has 8 * gpx * (H / 16) blocks; blocks of slots that host no group exit at
+// once.  Placement is speed only -- persist_handshake() below checks it and falls back -- never correctness.
+__device__ __forceinline__ bool persist_map(int b, int G, int slot_map, int& gid, int& ub) {
+    if (!slot_map) { gid = b % G; ub = b / G; return true; }      // plain round-robin: a group spans XCDs unless G % 8 == 0
+    const int slot = b & 7, j = b >> 3, gpx = (G + 7) >> 3;
+    gid = slot + 8 * (j % gpx);
+    ub = j / gpx;
+    return gid < G;
+}
+
+// Placement handshake, once per launch (needs the exchange arena): every workgroup publishes the id of the XCD it runs on
+// (HW_REG_XCC_ID) as a tagged 8-byte granule with an agent-scope store, wave 0 gathers the ids of its group's members with
+// agent-scope loads (the one exchange of the launch that must not depend on placement) and all members reach the same verdict:
+// if they all share one XCD, the group's granules may travel through that XCD's L2 -- PLAIN stores (write-through, the line stays
+// in L2) read by the same `sc1` loads (which bypass only the reader's L1) -- instead of through the memory side.  Measured
+// (rocprofv3 FETCH_SIZE / WRITE_SIZE): the 4 x H=512 backward launch 2.0 -> 1.4 GB of HBM / fabric traffic (algorithmic 0.94), the
+// scorers' 0.45 -> 0.30 GB; step time -1 % (the steps no longer wait on the gather).  A group that spans XCDs keeps sc1 stores: a
+// reader's L2 could hold a stale copy of a line another XCD rewrote.  Stale or missing data can only ever delay a consumer (tags),
+// so a wrong verdict would end in the bounded-spin error, not in wrong numbers.
+constexpr int HS_STRIDE = 32;                          // granules per group in the handshake table (H / 16 <= 32 members)
+__device__ __forceinline__ int persist_handshake(const ExPtrs& ex, int gid, int ub, int members, int tid, unsigned* err) {
+    __shared__ int s_l2;
+    if (ex.hs == nullptr) return 0;
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu;       // HW_REG_XCC_ID[3:0]
+    unsigned long long* hs = ex.hs + (size_t)gid * HS_STRIDE;
+    if (tid == 0) {
+        const unsigned long long g = ((unsigned long long)ex.hs_tag << 32) | xcc;
+        asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(hs + ub), "v"(g) : "memory");
+    }
+    if (tid < 64) {
+        const int lane = tid;
+        const unsigned long long* q = hs + (lane < members ? lane : 0);
+        bool same = true;
+        int spins = 0;
+        for (;;) {
+            unsigned long long v;
+            asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(q) : "memory");
+            const bool ok = (unsigned)(v >> 32) == ex.hs_tag;
+            same = (unsigned)v == xcc;
+            if (__all(ok)) break;
+            if (++spins > ex.spin_limit) { same = false; if (lane == 0) raise_spin(err, 0); break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        const bool all_same = __all(same);
+        if (lane == 0) s_l2 = all_same ? 1 : 0;
+    }
+    __syncthreads();
+    return s_l2;
+}
+
 // Order of a step: gather (loads only, inline asm: all loads of the pass in flight, ONE explicit wait -- left to
 // hipcc the loads were issued and waited for in groups) -> MFMA -> LDS partials -> barrier -> reduce + cell math ->
 // publish -> [results to HBM, next step's inputs from HBM].  The HBM traffic is issued after the publish, so it is in
@@ -97,7 +153,8 @@ __global__ __launch_bounds__(NT) void gru_persist_fwd_kernel(FwdGroup g, FragPtr
     constexpr int H = 128 * NC, nch = H >> 4;
     __shared__ float red[NB][NW][3][ROWS][UB + 1];     // 51 KiB either way (static LDS limit 64 KiB); +1: conflict-free reads
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int gid = (int)blockIdx.x % G, ub = (int)blockIdx.x / G;
+    int gid, ub;
+    if (!persist_map((int)blockIdx.x, G, ex.slot_map, gid, ub)) return;      // a block of an XCD slot that hosts no group of this launch
     const int s = gid / nrb, rb = gid % nrb;
     const m3t_gru_fwd_desc d = g.d[s];
     const int j0 = ub * UB, r0 = rb * ROWS;
@@ -131,6 +188,7 @@ __global__ __launch_bounds__(NT) void gru_persist_fwd_kernel(FwdGroup g, FragPtr
     int poll_delay = ex.poll_fixed >= 0 ? ex.poll_fixed : POLL_DELAY_INIT;
     __shared__ unsigned poll_fail[2];                  // by step parity
     __shared__ int pub_step;                           // steps this workgroup has published (thread 0)
+    const int l2mode = persist_handshake(ex, gid, ub, H >> 4, tid, err);     // 1: this group shares one XCD's L2 (publish with plain stores)
     if (tid == 0) pub_step = 0;
     if (tid < 2) poll_fail[tid] = 0;                   // first read after the first barrier
     const bool stamp = ex.prof != nullptr && blockIdx.x == 0 && tid == ex.prof_tid;
@@ -230,7 +288,8 @@ __global__ __launch_bounds__(NT) void gru_persist_fwd6_kernel(FwdGroup g, FragPt
     constexpr int H = 128 * NC, nch = H >> 4;
     __shared__ float red[2][NW][3][ROWS][UB + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int gid = (int)blockIdx.x % G, ub = (int)blockIdx.x / G;
+    int gid, ub;
+    if (!persist_map((int)blockIdx.x, G, ex.slot_map, gid, ub)) return;      // a block of an XCD slot that hosts no group of this launch
     const int s = gid / nrb, rb = gid % nrb;
     const m3t_gru_fwd_desc d = g.d[s];
     const int j0 = ub * UB, r0 = rb * ROWS;
@@ -266,6 +325,7 @@ __global__ __launch_bounds__(NT) void gru_persist_fwd6_kernel(FwdGroup g, FragPt
     int poll_delay = ex.poll_fixed >= 0 ? ex.poll_fixed : POLL_DELAY_INIT;
     __shared__ unsigned poll_fail[2];                  // by step parity
     __shared__ int pub_step;                           // steps this workgroup has published (thread 0)
+    const int l2mode = persist_handshake(ex, gid, ub, H >> 4, tid, err);     // 1: this group shares one XCD's L2 (publish with plain stores)
     if (tid == 0) pub_step = 0;
     if (tid < 2) poll_fail[tid] = 0;                   // first read after the first barrier
     const bool stamp = ex.prof != nullptr && blockIdx.x == 0 && tid == ex.prof_tid;
@@ -348,7 +408,8 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd16_kernel(BwdGroup g, FragP
     constexpr int H = 128 * NC, H3 = 3 * H, nchh = H >> 4;
     __shared__ float red[2][NW][ROWS][UB + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int gid = (int)blockIdx.x % G, ub = (int)blockIdx.x / G;
+    int gid, ub;
+    if (!persist_map((int)blockIdx.x, G, ex.slot_map, gid, ub)) return;      // a block of an XCD slot that hosts no group of this launch
     const int s = gid / nrb, rb = gid % nrb;
     const m3t_gru_bwd_desc d = g.d[s];
     const int j0 = ub * UB, r0 = rb * ROWS;
@@ -380,6 +441,7 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd16_kernel(BwdGroup g, FragP
     int poll_delay = ex.poll_fixed >= 0 ? ex.poll_fixed : POLL_DELAY_INIT;
     __shared__ unsigned poll_fail[2];                  // by step parity
     __shared__ int pub_step;                           // steps this workgroup has published (thread 0)
+    const int l2mode = persist_handshake(ex, gid, ub, H >> 4, tid, err);     // 1: this group shares one XCD's L2 (publish with plain stores)
     if (tid == 0) pub_step = 0;
     if (tid < 2) poll_fail[tid] = 0;                   // first read after the first barrier
     const bool stamp = ex.prof != nullptr && blockIdx.x == 0 && tid == ex.prof_tid;
@@ -466,7 +528,8 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd_kernel(BwdGroup g, FragPtr
     constexpr int H = 128 * NC, H3 = 3 * H, nchh = H >> 4, nch = H3 >> 4;
     __shared__ float red[2][NW][ROWS][UB + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int gid = (int)blockIdx.x % G, ub = (int)blockIdx.x / G;
+    int gid, ub;
+    if (!persist_map((int)blockIdx.x, G, ex.slot_map, gid, ub)) return;      // a block of an XCD slot that hosts no group of this launch
     const int s = gid / nrb, rb = gid % nrb;
     const m3t_gru_bwd_desc d = g.d[s];
     const int j0 = ub * UB, r0 = rb * ROWS;
@@ -497,6 +560,7 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd_kernel(BwdGroup g, FragPtr
     int poll_delay = ex.poll_fixed >= 0 ? ex.poll_fixed : POLL_DELAY_INIT;
     __shared__ unsigned poll_fail[2];                  // by step parity
     __shared__ int pub_step;                           // steps this workgroup has published (thread 0)
+    const int l2mode = persist_handshake(ex, gid, ub, H >> 4, tid, err);     // 1: this group shares one XCD's L2 (publish with plain stores)
     if (tid == 0) pub_step = 0;
     if (tid < 2) poll_fail[tid] = 0;                   // first read after the first barrier
     const bool stamp = ex.prof != nullptr && blockIdx.x == 0 && tid == ex.prof_tid;
@@ -632,7 +696,8 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd6_kernel(BwdGroup g, FragPt
     constexpr int H = 128 * NC, H3 = 3 * H, nchh = H >> 4;
     __shared__ float red[2][NW][ROWS][UB + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int gid = (int)blockIdx.x % G, ub = (int)blockIdx.x / G;
+    int gid, ub;
+    if (!persist_map((int)blockIdx.x, G, ex.slot_map, gid, ub)) return;      // a block of an XCD slot that hosts no group of this launch
     const int s = gid / nrb, rb = gid % nrb;
     const m3t_gru_bwd_desc d = g.d[s];
     const int j0 = ub * UB, r0 = rb * ROWS;
@@ -662,6 +727,7 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd6_kernel(BwdGroup g, FragPt
     int poll_delay = ex.poll_fixed >= 0 ? ex.poll_fixed : POLL_DELAY_INIT;
     __shared__ unsigned poll_fail[2];                  // by step parity
     __shared__ int pub_step;                           // steps this workgroup has published (thread 0)
+    const int l2mode = persist_handshake(ex, gid, ub, H >> 4, tid, err);     // 1: this group shares one XCD's L2 (publish with plain stores)
     if (tid == 0) pub_step = 0;
     if (tid < 2) poll_fail[tid] = 0;                   // first read after the first barrier
     const bool stamp = ex.prof != nullptr && blockIdx.x == 0 && tid == ex.prof_tid;
@@ -779,7 +845,12 @@ int resident_capacity(K kernel) {
     return per_cu * device_cus();
 }
 
-struct Shape { int nc, rt, G, nrb, grid; };
+static int poll_env_early(const char* name, int dflt) {
+    const char* e = std::getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+struct Shape { int nc, rt, G, nrb, grid, active, slot_map; };
 
 // every scan of the level has the same H = 128 * NC (NC = 1..4: the k-chunks per wave are compile-time, so the gather
 // and the MFMA chain are straight-line code); RT = 1 when the 16-row grid fits one workgroup per CU, else 2
@@ -792,8 +863,20 @@ bool level_shape(const D* d, int n, int B, Shape& sh) {
     sh.nc = maxh / 128;
     sh.rt = 0;
     for (int rt = 1; rt <= 2; ++rt) {
-        const int nrb = cdiv(B, 16 * rt), G = n * nrb, grid = G * (maxh / 16);
-        if (grid <= device_cus()) { sh.rt = rt; sh.nrb = nrb; sh.G = G; sh.grid = grid; break; }
+        const int nrb = cdiv(B, 16 * rt), G = n * nrb, active = G * (maxh / 16);
+        // launched: 8 XCD slots x ceil(G / 8) groups per slot x H / 16 members (persist_map); blocks of empty slots exit at once,
+        // so what must fit the chip at one workgroup per CU is the ACTIVE count
+        if (active <= device_cus()) {
+            // M3T_SCAN_L2: 2 (default) launches whose groups are XCD-aligned anyway (G % 8 == 0: the 4 x H=512 encoder level, the
+            // scorers) use the slot mapping + handshake, the others keep G * H/16 blocks dealt over all 8 XCDs and exchange through
+            // the memory side; 1 every launch (a 4-group launch then fills 4 XCDs and leaves 4 empty: -40 % traffic on those too,
+            // but their steps got slower -- 19.08 vs 18.73 ms per training step, interleaved A/B; mode 2: 18.83); 0 never
+            static const int l2 = poll_env_early("M3T_SCAN_L2", 2);
+            sh.rt = rt; sh.nrb = nrb; sh.G = G; sh.active = active;
+            sh.slot_map = (l2 == 1 || (l2 == 2 && G % 8 == 0)) ? 1 : 0;
+            sh.grid = sh.slot_map ? 8 * cdiv(G, 8) * (maxh / 16) : active;
+            break;
+        }
     }
     return sh.rt != 0;
 }
@@ -814,10 +897,6 @@ BwdKernel pick_bwd(const Shape& sh) {
     return k[sh.rt - 1][sh.nc - 1];
 }
 
-static int poll_env_early(const char* name, int dflt) {
-    const char* e = std::getenv(name);
-    return e ? atoi(e) : dflt;
-}
 
 // A scan launch that leaves most of the chip free (a light level: <= 96 workgroups) asks for enough unused dynamic LDS that
 // no GEMM workgroup fits beside one of its workgroups on a CU: co-resident GEMM waves take issue slots and LDS bandwidth
@@ -856,12 +935,14 @@ static int poll_env(const char* name, int dflt) {
 //   kind 1  forward, bf16x6       8-B granule {h1, h2, h3, tag16}         1 MiB
 //   kind 2  backward, bf16 mode   8-B granule {dr, dz, dnr bf16, tag16}   1 MiB
 //   kind 3  backward, fp32/bf16x6 16-B granule {dr, dz, dnr, tag32}       4 MiB
+//   kind 4  placement handshake   8-B granule {xcc id, tag32}             64 KiB (persist_handshake)
 // A sub-arena is zeroed when the arena is first seen (or after m3t_gru_scan_arena_reset) and when its tag counter would
 // wrap (16-bit tags: every ~200 launches of 300 steps).  Without an arena the launch zeroes its buffers as before.
 constexpr size_t ARENA_OFF[4] = {0, (size_t)2 << 20, (size_t)3 << 20, (size_t)4 << 20};
 constexpr size_t ARENA_SIZE[4] = {(size_t)2 << 20, (size_t)1 << 20, (size_t)1 << 20, (size_t)4 << 20};
-constexpr size_t ARENA_BYTES = (size_t)8 << 20;
-struct ArenaState { unsigned long long next[4]; bool known; };
+constexpr size_t ARENA_HS_OFF = (size_t)8 << 20, ARENA_HS_SIZE = (size_t)64 << 10;      // placement-handshake table
+constexpr size_t ARENA_BYTES = ARENA_HS_OFF + ARENA_HS_SIZE;
+struct ArenaState { unsigned long long next[5]; bool known; };
 std::mutex g_arena_mu;
 std::unordered_map<uintptr_t, ArenaState> g_arenas;
 thread_local void* g_arena = nullptr;
@@ -894,7 +975,7 @@ int prepare_exchange(const G& g, const FragPtrs& fp, const Shape& sh, int kind, 
             const hipError_t e = hipMemsetAsync(arena, 0, ARENA_BYTES, s);
             if (e != hipSuccess) return (int)e;
             st.known = true;
-            for (int q = 0; q < 4; ++q) st.next[q] = 0;
+            for (int q = 0; q < 5; ++q) st.next[q] = 0;
         }
         if (st.next[kind] + (unsigned long long)T + 1 >= tag_max) {     // the counter would wrap: start over on zeroed memory
             const hipError_t e = hipMemsetAsync(base, 0, ARENA_SIZE[kind], s);
@@ -903,6 +984,15 @@ int prepare_exchange(const G& g, const FragPtrs& fp, const Shape& sh, int kind, 
         }
         ex.tag_base = (unsigned)st.next[kind];
         st.next[kind] += (unsigned long long)T;
+        if (sh.slot_map && (size_t)sh.G * HS_STRIDE * 8 <= ARENA_HS_SIZE) {
+            if (st.next[4] + 2 >= 0xffffffffull) {
+                const hipError_t e = hipMemsetAsync(static_cast<char*>(arena) + ARENA_HS_OFF, 0, ARENA_HS_SIZE, s);
+                if (e != hipSuccess) return (int)e;
+                st.next[4] = 0;
+            }
+            ex.hs = reinterpret_cast<unsigned long long*>(static_cast<char*>(arena) + ARENA_HS_OFF);
+            ex.hs_tag = (unsigned)(++st.next[4]);
+        }
         return 0;
     }
     for (int i = 0; i < g.n; ++i) {
@@ -929,6 +1019,7 @@ void fill_exchange(const G& g, const FragPtrs& fp, const Shape& sh, size_t gran_
     static const int spin_limit = poll_env_early("M3T_SCAN_SPIN_LIMIT", SPIN_LIMIT_DEFAULT);
     ex.spin_limit = spin_limit > 0 ? spin_limit : SPIN_LIMIT_DEFAULT;
     ex.fault_step = -1;
+    ex.slot_map = sh.slot_map;
     for (int i = 0; i < g.n; ++i) bytes[i] = 0;
 }
 
@@ -1007,13 +1098,13 @@ bool persist_fwd_uses_x6(const FwdGroup& g, int B, int T, int flags) {
 bool persist_fwd_check(const FwdGroup& g, int B, int T) {
     Shape sh;
     return persist_enabled() && T >= 2 && level_shape(g.d, g.n, B, sh) && ensure_err_word() &&
-           sh.grid <= resident_capacity(pick_fwd(sh)) && persist_owner();
+           sh.active <= resident_capacity(pick_fwd(sh)) && persist_owner();
 }
 
 bool persist_bwd_check(const BwdGroup& g, int B, int T) {
     Shape sh;
     return persist_enabled() && T >= 2 && level_shape(g.d, g.n, B, sh) && ensure_err_word() &&
-           sh.grid <= resident_capacity(pick_bwd(sh)) && persist_owner();
+           sh.active <= resident_capacity(pick_bwd(sh)) && persist_owner();
 }
 
 // the backward scan of the bf16 mode runs on the bf16 matrix pipe with 8-byte granules (gru_persist_bwd16_kernel) for
@@ -1060,14 +1151,14 @@ int persist_fwd_launch(const FwdGroup& g, const FragPtrs& fp, int B, int T, int 
         M3T_LAUNCH_CHECK();
         { const int e = persist_take_after(s); if (e) return e; }
         persist_record_start(s);
-        if (sh.nc == 2) hipLaunchKernelGGL(gru_persist_fwd6_kernel<2>, dim3(sh.grid), dim3(NT), exclusive_lds(gru_persist_fwd6_kernel<2>, sh.grid), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
-        else hipLaunchKernelGGL(gru_persist_fwd6_kernel<4>, dim3(sh.grid), dim3(NT), exclusive_lds(gru_persist_fwd6_kernel<4>, sh.grid), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
+        if (sh.nc == 2) hipLaunchKernelGGL(gru_persist_fwd6_kernel<2>, dim3(sh.grid), dim3(NT), exclusive_lds(gru_persist_fwd6_kernel<2>, sh.active), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
+        else hipLaunchKernelGGL(gru_persist_fwd6_kernel<4>, dim3(sh.grid), dim3(NT), exclusive_lds(gru_persist_fwd6_kernel<4>, sh.active), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
         persist_record_end(s);
         M3T_LAUNCH_CHECK();
         return 0;
     }
     persist_record_start(s);
-    hipLaunchKernelGGL(pick_fwd(sh), dim3(sh.grid), dim3(NT), exclusive_lds(pick_fwd(sh), sh.grid), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
+    hipLaunchKernelGGL(pick_fwd(sh), dim3(sh.grid), dim3(NT), exclusive_lds(pick_fwd(sh), sh.active), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
     persist_record_end(s);
     M3T_LAUNCH_CHECK();
     return 0;
@@ -1098,8 +1189,8 @@ int persist_bwd_launch(const BwdGroup& g, const FragPtrs& fp, int B, int T, int 
         M3T_LAUNCH_CHECK();
         { const int e = persist_take_after(s); if (e) return e; }
         persist_record_start(s);
-        if (sh.nc == 2) hipLaunchKernelGGL(gru_persist_bwd16_kernel<2>, dim3(sh.grid), dim3(NT), exclusive_lds(gru_persist_bwd16_kernel<2>, sh.grid), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
-        else hipLaunchKernelGGL(gru_persist_bwd16_kernel<4>, dim3(sh.grid), dim3(NT), exclusive_lds(gru_persist_bwd16_kernel<4>, sh.grid), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
+        if (sh.nc == 2) hipLaunchKernelGGL(gru_persist_bwd16_kernel<2>, dim3(sh.grid), dim3(NT), exclusive_lds(gru_persist_bwd16_kernel<2>, sh.active), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
+        else hipLaunchKernelGGL(gru_persist_bwd16_kernel<4>, dim3(sh.grid), dim3(NT), exclusive_lds(gru_persist_bwd16_kernel<4>, sh.active), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
         persist_record_end(s);
         M3T_LAUNCH_CHECK();
         return 0;
@@ -1115,14 +1206,14 @@ int persist_bwd_launch(const BwdGroup& g, const FragPtrs& fp, int B, int T, int 
         { const int e = persist_take_after(s); if (e) return e; }
         persist_record_start(s);
         const BwdKernel kk = sh.nc == 2 ? gru_persist_bwd6_kernel<2> : gru_persist_bwd6_kernel<4>;
-        hipLaunchKernelGGL(kk, dim3(sh.grid), dim3(NT), exclusive_lds(kk, sh.grid), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
+        hipLaunchKernelGGL(kk, dim3(sh.grid), dim3(NT), exclusive_lds(kk, sh.active), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
         persist_record_end(s);
         M3T_LAUNCH_CHECK();
         return 0;
     }
     { const int e = persist_take_after(s); if (e) return e; }
     persist_record_start(s);
-    hipLaunchKernelGGL(pick_bwd(sh), dim3(sh.grid), dim3(NT), exclusive_lds(pick_bwd(sh), sh.grid), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
+    hipLaunchKernelGGL(pick_bwd(sh), dim3(sh.grid), dim3(NT), exclusive_lds(pick_bwd(sh), sh.active), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
     persist_record_end(s);
     M3T_LAUNCH_CHECK();
     return 0;

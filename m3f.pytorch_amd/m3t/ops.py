@@ -397,12 +397,12 @@ def _scan_after(ev):
 
 
 _ARENAS = {}
-_ARENA_BYTES = 8 << 20
+_ARENA_BYTES = (8 << 20) + (64 << 10)      # 4 granule formats (8 MiB) + the placement-handshake table (64 KiB)
 
 
 def _scan_arena(device):
     """the exchange arena of the persistent scans issued on the current stream role (include/m3t_hip.h, m3t_gru_scan_arena):
-    8 MiB that nothing but scan launches ever writes -- one per (device, stream role), because launches that share an arena
+    8 MiB + 64 KiB that nothing but scan launches ever writes -- one per (device, stream role), because launches that share an arena
     must be ordered -- handed to the next scan call"""
     key = (device.type, device.index, _ws_tag(device))
     a = _ARENAS.get(key)

@@ -875,7 +875,8 @@ def test_time_reversal_symmetry_of_bigru():
 
 
 def test_scan_results_do_not_depend_on_the_poll_policy():
-    """the sleep before a persistent scan's first gather attempt (adaptive / fixed / none, aligned or not) is timing only:
+    """the sleep before a persistent scan's first gather attempt (adaptive / fixed / none, aligned or not) and the transport of the
+    exchange (through the XCD's L2 after the placement handshake, or through the memory side: M3T_SCAN_L2=0) are timing only:
     forward outputs and every gradient are bit-identical under all of them (the policy is read once per process, hence
     the subprocesses)"""
     import hashlib
@@ -899,7 +900,7 @@ for H in (128, 256):
 print("DIGEST", h.hexdigest())
 """ % (os.path.join(ROOT, "m3f.pytorch_amd"), os.path.join(ROOT, "tests"), ROOT)
     digests = []
-    for extra in ({}, {"M3T_SCAN_POLL_FWD6": "0", "M3T_SCAN_POLL_FWD": "5", "M3T_SCAN_POLL_BWD": "0", "M3T_SCAN_POLL_ALIGN": "0"},
+    for extra in ({}, {"M3T_SCAN_POLL_FWD6": "0", "M3T_SCAN_POLL_FWD": "5", "M3T_SCAN_POLL_BWD": "0", "M3T_SCAN_POLL_ALIGN": "0", "M3T_SCAN_L2": "0"},
                   {"M3T_SCAN_POLL_FWD6": "20", "M3T_SCAN_POLL_BWD": "-1", "M3T_SCAN_POLL_ALIGN": "7"}):
         # (M3T_SCAN_LOCK=0: this pytest process may own the GPU's persistent-scan lock and is idle while the child runs)
         out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, M3T_SCAN_LOCK="0", **extra), capture_output=True,
