@@ -313,21 +313,34 @@ def main():
         name = max(kern, key=lambda n: kern[n]["ms"])
         k = kern[name]
         achieved = k["flops"] / (k["ms"] * 1e-3) / 1e12
-        traffic = None      # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*pmc_traffic.json)
+        traffic, traffic_by_kernel, mfma_util = None, None, None
+        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/*pmc_traffic.json: separate
+        # FETCH_SIZE / WRITE_SIZE passes, gfx950 correction) and the SQ pass (profiles/*pmc_mfma.json)
         try:
             import glob
             pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))[-1]))["kernels"]
-            hits = [v for k, v in pm.items() if k.startswith(name.replace("_kernel", "")) and "hbm_bytes_per_launch" in v]
+            stem = name.replace("_kernel", "")               # gru_persist_bwd -> bwd, bwd6, bwd16 variants
+            hits = {k: v for k, v in pm.items() if k.startswith(stem) and "hbm_bytes_per_launch" in v}
             if hits:
-                traffic = int(sum(h["hbm_bytes_per_launch"] * h["launches"] for h in hits) / sum(h["launches"] for h in hits))
+                traffic = int(sum(h["hbm_bytes_per_launch"] * h["launches"] for h in hits.values()) / sum(h["launches"] for h in hits.values()))
+                traffic_by_kernel = {k: v["hbm_bytes_per_launch"] for k, v in hits.items()}
+            mm = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_mfma.json")))[-1]))["kernels"]
+            mh = {k: v for k, v in mm.items() if k.startswith(stem) and v.get("mfma_util") is not None}
+            if mh:
+                mfma_util = {k: v["mfma_util"] for k, v in mh.items()}
         except Exception:  # noqa: BLE001
-            traffic = None
+            pass
         roofline = {"kernel": name, "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                     "avg_launch_us": breakdown[name]["avg_launch_us"],
                     "flops_per_launch": round(k["flops"] / max(1, k["launches"])),
                     "share_of_step": round(k["ms"] / timed_steps / step_ms, 3),
-                    "timed_launches": k["launches"], "events_every_n_steps": events_every}
+                    "timed_launches": k["launches"], "events_every_n_steps": events_every,
+                    "traffic_by_kernel": traffic_by_kernel, "mfma_busy_frac_pmc": mfma_util,
+                    "note": "achieved = algorithmic FLOPs of the recurrent products dh_t = dgh_{t+1} W_hh ((T-1) x sum over scans of 2 B 3H H per launch) / HIP-event "
+                            "time of the launches; peak = fp32 MFMA (the arithmetic is fp32-accurate); the H = 256 / 512 launches run it as 6 bf16 MFMAs per "
+                            "product on the bf16 pipe (peak 2500 / 6 = 417 TFLOP/s-equivalent); the kernel is bound by the cross-CU exchange latency per time "
+                            "step, not by either pipe (DESIGN.md section 5)"}
 
     if rank == 0:
         clips = B * world * args.steps
