@@ -30,3 +30,15 @@ for k, s, e, c, busy in out:
     if busy > thr and lo <= (s - base) / 1e6 <= hi:
         print("st%d  %8.3f -> %8.3f ms  n=%4d busy %7.3f  %s" % (k[1], (s - base) / 1e6, (e - base) / 1e6, c, busy / 1e6, k[0]))
 print("step span %.3f ms" % ((seg[-1][2] - base) / 1e6))
+# GPU idle inside the step: time covered by no kernel on any stream, and the largest holes (with what ran before / after)
+iv = sorted((s_, e_, short(n_)) for n_, s_, e_, _ in seg)
+idle, holes, cur_end, prev = 0, [], iv[0][1], iv[0][2]
+for s_, e_, n_ in iv[1:]:
+    if s_ > cur_end:
+        idle += s_ - cur_end
+        holes.append((s_ - cur_end, cur_end, prev, n_))
+    if e_ > cur_end:
+        cur_end, prev = e_, n_
+print("GPU idle (no kernel on any stream) %.3f ms in %d holes; largest:" % (idle / 1e6, len(holes)))
+for d, at, a, b in sorted(holes, reverse=True)[:12]:
+    print("  %6.1f us at %7.3f ms  after %-40s before %s" % (d / 1e3, (at - base) / 1e6, a[:40], b[:40]))
