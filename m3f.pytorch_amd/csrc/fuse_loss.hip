@@ -307,8 +307,13 @@ __global__ __launch_bounds__(LB) void va_loss_grad_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------ DDP helpers
-__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, size_t n, float* __restrict__ part) {
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, size_t n, float* __restrict__ part,
+                                                            const unsigned* __restrict__ scan_err) {
     __shared__ float red[16];
+    // ONE read of the host-mapped scan error word per call (a PCIe round trip: 1024 blocks reading it took 115 us), copied into
+    // device memory behind the partials for norm_scale_kernel
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        reinterpret_cast<unsigned*>(part)[gridDim.x] = scan_err ? __hip_atomic_load(scan_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
     float s = 0.f;
     const size_t n4 = n >> 2;
     const float4* g4 = reinterpret_cast<const float4*>(g);
@@ -324,13 +329,13 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restr
 
 __global__ __launch_bounds__(256) void norm_scale_kernel(float* __restrict__ g, size_t n, const float* __restrict__ part,
                                                          int nparts, float inv_world, float max_norm,
-                                                         float* __restrict__ norm_out, const unsigned* __restrict__ scan_err) {
+                                                         float* __restrict__ norm_out) {
     __shared__ float red[16];
     __shared__ unsigned bad_s;
-    // a persistent GRU scan that gave up (gru_persist.hip) left garbage in these gradients: the host-mapped error word is
-    // read here, in stream order behind that scan -- no host synchronisation -- and turns the step into a no-op:
+    // a persistent GRU scan that gave up (gru_persist.hip) left garbage in these gradients: the host-mapped error word was read
+    // by sumsq_partial_kernel, in stream order behind that scan -- no host synchronisation -- and turns the step into a no-op:
     // gradients zeroed, norm = NaN (m3t_adam_step / m3t_sgd_step skip on a non-finite guard)
-    if (threadIdx.x == 0) bad_s = scan_err ? __hip_atomic_load(scan_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
+    if (threadIdx.x == 0) bad_s = reinterpret_cast<const unsigned*>(part)[nparts];
     float s = 0.f;
     for (int i = threadIdx.x; i < nparts; i += blockDim.x) s += part[i];
     s = block_sum(s, red);                               // (its barriers also publish bad_s)
@@ -480,11 +485,11 @@ extern "C" int m3t_grad_norm_scale(float* flat, size_t n, float inv_world, float
     int blocks = (int)((n / 4 + 255) / 256);
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
-    if (ws_bytes < (size_t)blocks * sizeof(float)) return M3T_EINVAL;
+    if (ws_bytes < (size_t)(blocks + 1) * sizeof(float)) return M3T_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    sumsq_partial_kernel<<<blocks, 256, 0, s>>>(flat, n, ws);
+    sumsq_partial_kernel<<<blocks, 256, 0, s>>>(flat, n, ws, m3t_gru::persist_error_word_dev());
     M3T_LAUNCH_CHECK();
-    norm_scale_kernel<<<blocks, 256, 0, s>>>(flat, n, ws, blocks, inv_world, max_norm, norm_out, m3t_gru::persist_error_word_dev());
+    norm_scale_kernel<<<blocks, 256, 0, s>>>(flat, n, ws, blocks, inv_world, max_norm, norm_out);
     M3T_LAUNCH_CHECK();
     return 0;
 }

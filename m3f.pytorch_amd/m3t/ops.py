@@ -129,6 +129,9 @@ _PERSIST_ENABLED = os.environ.get("M3T_SCAN_PERSIST", "1") != "0"
 # two H-groups of persistent scans (e.g. gru_v|gru_a H=512 and audio H=256): the light group's scans and GEMMs go to the
 # side stream, fenced by events so that no two persistent scans ever overlap, and run beside the heavy group's GEMMs
 _INTERLEAVE = os.environ.get("M3T_SCAN_INTERLEAVE", "1") != "0"
+# two-layer stacks: the light group's two scans run back to back between the heavy group's two scans (H0 L0 L1 H1 / H1 L1 L0 H0)
+# instead of strictly alternating
+_LIGHT_BATCHED = os.environ.get("M3T_SCAN_LIGHT_BATCHED", "1") != "0"
 
 
 # weight-gradient GEMMs of a GRU level (dW_ih, dW_hh) feed nothing but the optimizer: they leave the scan -> dX -> scan
@@ -539,7 +542,26 @@ class _MultiBiGRU(torch.autograd.Function):
             ev_light = None
             _FENCED[0] = True
             try:
-                for l in range(L):
+                if _LIGHT_BATCHED and L == 2:
+                    # persistent scans in the order H0, L0, L1, H1: BOTH light scans (and the light layer-1 projection between
+                    # them) run beside the heavy layer-1 input projections, the longest GEMM window of the pass; strictly
+                    # alternating (H0, L0, H1, L1) left the second light scan with nothing beside it
+                    level_fwd(0, heavy, False)
+                    with torch.cuda.stream(side):
+                        level_fwd(0, light, False)
+                    level_fwd(0, heavy, True, None)
+                    ev_h0 = torch.cuda.Event()
+                    ev_h0.record(main)
+                    with torch.cuda.stream(side):
+                        level_fwd(0, light, True, ev_h0)
+                        level_fwd(1, light, False)
+                        level_fwd(1, light, True)
+                        ev_light = torch.cuda.Event()
+                        ev_light.record(side)
+                    level_fwd(1, heavy, False)
+                    level_fwd(1, heavy, True, ev_light)
+                else:
+                  for l in range(L):
                     level_fwd(l, heavy, False)
                     with torch.cuda.stream(side):
                         level_fwd(l, light, False)
@@ -712,7 +734,24 @@ class _MultiBiGRU(torch.autograd.Function):
             ev_light = None
             _FENCED[0] = True
             try:
-                for l in range(L - 1, -1, -1):
+                if _LIGHT_BATCHED and L == 2:
+                    # persistent scans in the order H1, L1, L0, H0: both light scans (and the light data-gradient GEMM between
+                    # them) beside the heavy layer-1 data-gradient GEMMs; no light scan is left for the end of the pass
+                    level_scan(1, heavy, None)
+                    ev_h1 = torch.cuda.Event()
+                    ev_h1.record(main)
+                    level_gemms(1, heavy)
+                    with torch.cuda.stream(side):
+                        level_scan(1, light, ev_h1)
+                        level_gemms(1, light)
+                        level_scan(0, light)
+                        ev_light = torch.cuda.Event()
+                        ev_light.record(side)
+                        level_gemms(0, light)
+                    level_scan(0, heavy, ev_light)
+                    level_gemms(0, heavy)
+                else:
+                  for l in range(L - 1, -1, -1):
                     level_scan(l, heavy, ev_light)
                     ev_heavy = torch.cuda.Event()
                     ev_heavy.record(main)
