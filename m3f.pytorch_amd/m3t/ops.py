@@ -132,6 +132,11 @@ _INTERLEAVE = os.environ.get("M3T_SCAN_INTERLEAVE", "1") != "0"
 # two-layer stacks: the light group's two scans run back to back between the heavy group's two scans (H0 L0 L1 H1 / H1 L1 L0 H0)
 # instead of strictly alternating
 _LIGHT_BATCHED = os.environ.get("M3T_SCAN_LIGHT_BATCHED", "1") != "0"
+# data gradients before weight gradients: bit 0 heavy group / bit 1 light group of the batched schedule, bit 2 every level.  The weight
+# gradients of a level then start when its data gradients are done instead of sharing the free CUs with them: the chain's GEMMs
+# finish sooner, the scans beside them stretch less (backward scans 7.9 -> 6.8 ms per step), the step -0.2 ms (8 interleaved runs
+# each, medians 17.56 vs 17.78 ms)
+_DX_FIRST = int(os.environ.get("M3T_DX_FIRST", "7"))
 
 
 # weight-gradient GEMMs of a GRU level (dW_ih, dW_hh) feed nothing but the optimizer: they leave the scan -> dX -> scan
@@ -711,18 +716,24 @@ class _MultiBiGRU(torch.autograd.Function):
             for w_ in wgs:
                 w_.wait_stream(main)
 
-        def level_gemms(l, idxs):
-            """after the scan of (l, idxs) on the current stream: dX in line, dW on the weight-gradient streams"""
+        def level_gemms(l, idxs, dx_first=False):
+            """after the scan of (l, idxs) on the current stream: dX in line, dW on the weight-gradient streams.  dx_first: the
+            weight gradients wait until the data gradients are done (they would otherwise split the CUs the scan beside them
+            leaves free, and the data gradients are what the chain -- or the light scans' own chain -- waits for)"""
             if wgs is None:
                 level_dx(l, idxs)
                 level_dw(l, idxs)
                 return
+            dx_first = dx_first or bool(_DX_FIRST & 4)
+            if dx_first:
+                level_dx(l, idxs)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             for w_ in wgs:
                 w_.wait_event(ev)
             level_dw(l, idxs, _WGRAD_BACKGROUND)
-            level_dx(l, idxs)
+            if not dx_first:
+                level_dx(l, idxs)
 
         if _interleaved(groups):
             # as in forward: the light group's backward scans run on the side stream beside the heavy group's GEMMs
@@ -740,10 +751,10 @@ class _MultiBiGRU(torch.autograd.Function):
                     level_scan(1, heavy, None)
                     ev_h1 = torch.cuda.Event()
                     ev_h1.record(main)
-                    level_gemms(1, heavy)
+                    level_gemms(1, heavy, dx_first=_DX_FIRST & 1)
                     with torch.cuda.stream(side):
                         level_scan(1, light, ev_h1)
-                        level_gemms(1, light)
+                        level_gemms(1, light, dx_first=_DX_FIRST & 2)
                         level_scan(0, light)
                         ev_light = torch.cuda.Event()
                         ev_light.record(side)

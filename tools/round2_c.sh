@@ -1,4 +1,6 @@
 #!/bin/bash
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; cd $R
-timeout 900 python -m pytest tests/test_gpu_bench_path.py tests/test_gpu_faults.py -q -m gpu -x 2>&1 | tail -3
-REPS=6 STEPS=30 bash tools/ab.sh lb "M3T_SCAN_LIGHT_BATCHED=0" "M3T_SCAN_LIGHT_BATCHED=1"
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+rm -rf $O/prof_tl; rocprofv3 --kernel-trace -d $O/prof_tl -o tl --output-format rocpd -- python3 $R/bench.py --steps 8 --warmup 3 --no-cpu-baseline --aux "" > $O/prof_tl.log 2>&1
+db=$(find $O/prof_tl -name "*.db" | head -1); python3 $R/tools/timeline.py $db 60e3 > $O/r02b_timeline.txt 2>&1; rm -rf $O/prof_tl
+cat $O/r02b_timeline.txt
