@@ -171,12 +171,13 @@ def join_wgrad(device=None):
 
 
 # Weight-gradient streams.  The weight-gradient GEMMs of a level are independent of each other and mostly small (audio dW_hh:
-# 768 x 256 x 9600 = 12 output tiles x split-K), so one stream runs them back to back at 30-40 TFLOP/s each: the tail of
-# backward after the last scan is ~1 ms of them (profiles/r02_timeline_*.txt).  Dealing them round-robin over TWO streams
-# (M3T_WGRAD_STREAMS=2, each stream with its own split-K workspace) was measured and is NOT the default: the tail shrinks,
-# but the extra concurrent GEMM stream takes CUs from the data-gradient GEMMs that sit on the scan chain and stretches the
-# scans it runs beside (interleaved A/B, 4 runs each, median ms per step: 17.21 with one stream, 17.77 with two).
-_N_WGRAD = max(1, int(os.environ.get("M3T_WGRAD_STREAMS", "1")))
+# 768 x 256 x 9600 = 12 output tiles x split-K).  Dealing ALL of them round-robin over two streams was measured and lost: the
+# extra concurrent GEMM stream takes CUs from the data-gradient GEMMs on the scan chain and stretches the scans beside it (17.77
+# vs 17.21 ms per step).  What is kept (M3T_WGRAD_TAIL_SPREAD): only the LAST level's weight gradients -- the tail of backward, when
+# no scan and no data gradient is left -- go over both streams (each with its own split-K workspace): -0.15 ms per step (medians
+# of 8 interleaved runs, 17.79 vs 17.94).
+_N_WGRAD = max(1, int(os.environ.get("M3T_WGRAD_STREAMS", "2")))
+_TAIL_SPREAD = os.environ.get("M3T_WGRAD_TAIL_SPREAD", "1") != "0"
 
 
 def wgrad_stream(device, i=0):
@@ -686,7 +687,7 @@ class _MultiBiGRU(torch.autograd.Function):
         wgs = wgrad_streams(dev) if _WGRAD_ENABLED else None
         rr = [0]
 
-        def level_dw(l, idxs, background=False):           # off the chain: only the optimizer reads these
+        def level_dw(l, idxs, background=False, spread=False):           # off the chain: only the optimizer reads these
             """the weight-gradient GEMMs of (l, idxs); with weight-gradient streams: dealt round-robin over them (the GEMMs are
             independent of each other; every stream has waited for the scan)"""
             for s in idxs:
@@ -697,8 +698,11 @@ class _MultiBiGRU(torch.autograd.Function):
                     base = s * per + 1 + (2 * l + d) * 4
                     dw_ih, dw_hh = out_grads[base:base + 2]      # the bias gradients come out of the scan itself
                     goff = d * B * T * 3 * H
-                    ctx_hh = torch.cuda.stream(wgs[rr[0] % len(wgs)]) if wgs is not None else _NULL
-                    ctx_ih = torch.cuda.stream(wgs[(rr[0] + 1) % len(wgs)]) if wgs is not None else _NULL
+                    # spread: the LAST weight gradients of the pass (nothing but the optimizer follows): dealt over all
+                    # weight-gradient streams so that two of these small GEMMs share the chip; everything else on stream 0
+                    nw = len(wgs) if (wgs is not None and spread) else 1
+                    ctx_hh = torch.cuda.stream(wgs[rr[0] % nw]) if wgs is not None else _NULL
+                    ctx_ih = torch.cuda.stream(wgs[(rr[0] + 1) % nw]) if wgs is not None else _NULL
                     rr[0] += 2
                     with ctx_hh:
                         if T > 1:
@@ -716,7 +720,7 @@ class _MultiBiGRU(torch.autograd.Function):
             for w_ in wgs:
                 w_.wait_stream(main)
 
-        def level_gemms(l, idxs, dx_first=False):
+        def level_gemms(l, idxs, dx_first=False, last=False):
             """after the scan of (l, idxs) on the current stream: dX in line, dW on the weight-gradient streams.  dx_first: the
             weight gradients wait until the data gradients are done (they would otherwise split the CUs the scan beside them
             leaves free, and the data gradients are what the chain -- or the light scans' own chain -- waits for)"""
@@ -731,7 +735,7 @@ class _MultiBiGRU(torch.autograd.Function):
             ev.record(torch.cuda.current_stream())
             for w_ in wgs:
                 w_.wait_event(ev)
-            level_dw(l, idxs, _WGRAD_BACKGROUND)
+            level_dw(l, idxs, _WGRAD_BACKGROUND, spread=last and _TAIL_SPREAD)
             if not dx_first:
                 level_dx(l, idxs)
 
@@ -760,7 +764,7 @@ class _MultiBiGRU(torch.autograd.Function):
                         ev_light.record(side)
                         level_gemms(0, light)
                     level_scan(0, heavy, ev_light)
-                    level_gemms(0, heavy)
+                    level_gemms(0, heavy, last=True)
                 else:
                   for l in range(L - 1, -1, -1):
                     level_scan(l, heavy, ev_light)
