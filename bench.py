@@ -242,7 +242,7 @@ def main():
     ddp, step_fn = make_c3_step(model, batch, max_norm=1.0)
 
     def step():
-        return step_fn()[0]
+        return step_fn()[0].detach() if os.environ.get("M3T_BENCH_DETACH", "1") != "0" else step_fn()[0]
 
     def fence():
         torch.cuda.synchronize()
@@ -260,14 +260,42 @@ def main():
     # pair per launch costs the step 0.8 ms (4 %) when every launch of every step carries one -- measured, M3T_BENCH_EVENTS=1
     events_every = max(1, int(os.environ.get("M3T_BENCH_EVENTS", "4")))
     timed_steps = 0
+    run_ahead = int(os.environ.get("M3T_BENCH_RUNAHEAD", "0"))      # > 0: the host stays at most this many steps ahead of the GPU
+    marks = []
+    step_marks = [] if os.environ.get("M3T_BENCH_STEP_TIMES") == "1" else None      # debugging: per-step GPU time on stderr
+    host_marks = []
+    # Python's cyclic collector: a generation-2 pass over the heap of this process (torch + numpy + distributed) stops the host
+    # for 45-100 ms.  Landing in the first timed steps -- the GPU idle after the fence, the host with no lead yet -- it starved the
+    # GPU for that long and put 0.5-2 ms on the mean of a 20-30 step run (per-step times: M3T_BENCH_STEP_TIMES=1).  Collect now and
+    # move the survivors out of the collector's sight, as m3t.trainer.Trainer.fit does after its first step.
+    if os.environ.get("M3T_BENCH_GC", "1") != "0":
+        import gc
+        gc.collect()
+        gc.freeze()
     t0 = time.perf_counter()
     for i in range(args.steps):
         ops.PROFILE_ON[0] = i % events_every == 0
         timed_steps += int(ops.PROFILE_ON[0])
         loss = step()
+        if step_marks is not None:
+            step_marks.append(torch.cuda.Event(enable_timing=True))
+            step_marks[-1].record()
+            host_marks.append(time.perf_counter())
+        if run_ahead > 0:
+            ev = torch.cuda.Event()
+            ev.record()
+            marks.append(ev)
+            if len(marks) > run_ahead:
+                marks.pop(0).synchronize()
     ops.PROFILE_ON[0] = False
+    host_ms = (time.perf_counter() - t0) / args.steps * 1e3      # host time to ENQUEUE a step (no sync inside the loop)
     fence()
     dt = time.perf_counter() - t0
+    if step_marks:
+        print("# per-step ms: " + " ".join("%.2f" % a.elapsed_time(b) for a, b in zip(step_marks[:-1], step_marks[1:])),
+              file=sys.stderr, flush=True)
+        print("# host per-step ms: " + " ".join("%.2f" % ((b - a) * 1e3) for a, b in zip([t0] + host_marks[:-1], host_marks)),
+              file=sys.stderr, flush=True)
     ops.poll_scan_error()                          # a scan that gave up would make the number meaningless: raise
     persist_per_step = (_lib.load().m3t_gru_persist_count() - n_persist0) / max(1, args.steps)
     # N > 1: the gradient all-reduce alone (same buffer, same communicator), outside the timed region
@@ -348,7 +376,7 @@ def main():
             "metric": "clips/sec (300-frame A+V, fwd+bwd)", "value": round(clips / dt, 2), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (GEMMs and the forward recurrence as bf16x6 products = fp32-accurate, fp32 accumulate; backward recurrence on fp32 MFMAs)",
+            "dtype": "f32 (GEMMs and both recurrences as bf16x6 products = fp32-accurate, fp32 accumulate; the H=128 scorer scans on fp32 MFMAs)",
             "data": "synthetic",
             "config": {"workload": "C3/C4 feature-level A+V att_fusion graph (SURVEY 8(d)): audio GRU(128,256,2) | "
                                    "gru_v,gru_a GRU(256,512,2) | proj_v | AttFusion([512,512],128) | "
@@ -361,6 +389,7 @@ def main():
             "roofline": roofline,
             "kernels": breakdown,
             "persistent_scan_launches_per_step": persist_per_step,
+            "host_enqueue_ms_per_step": round(host_ms, 3),
             "allreduce": allreduce,
             "memory_roofline_frac": round((clips / dt) * 66.15e6 / (HBM_PEAK_GBS * 1e9 * world), 5),
         }

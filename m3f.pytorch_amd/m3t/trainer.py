@@ -18,6 +18,7 @@ training_step, backward, RCCL all-reduce + clip, fused optimizer step -- plus:
 A dead persistent scan cannot reach the parameters: see FlatGradDDP.finish() and include/m3t_hip.h (error model);
 step() polls the error word after the optimizer step is queued and save_checkpoint() synchronises and polls first.
 """
+import gc
 import os
 
 import torch
@@ -42,6 +43,7 @@ class Trainer:
                  scheduler=None, decay_factor=0.5, min_lr=1e-8, freeze_enc=False, fusion_type="attention",
                  checkpoint_path=None):
         self.model = model
+        self.freeze_gc = os.environ.get("M3T_TRAINER_FREEZE_GC", "1") != "0"
         if freeze_enc:
             apply_freeze_enc(model, fusion_type)
         self.ddp = FlatGradDDP(model, max_norm=gradient_clip_val, process_group=process_group, flatten_params=True)
@@ -144,6 +146,12 @@ class Trainer:
                     break
                 out = self.step(batch)
                 done += 1
+                if done == 1 and self.freeze_gc:
+                    # a generation-2 pass of Python's cyclic collector stops the host for 45-100 ms in a process of this size:
+                    # longer than its lead over the GPU (a step is 4-5 ms of host work, ~17 ms of GPU work).  Everything
+                    # alive after the first step is long-lived: take it out of the collector's sight.
+                    gc.collect()
+                    gc.freeze()
                 if log_every and i % log_every == 0:
                     history.append(float(out["loss"].detach()))
             val_loss = None
