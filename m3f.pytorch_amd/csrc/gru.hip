@@ -644,6 +644,7 @@ extern "C" int m3t_gru_scan_fwd(const m3t_gru_fwd_desc* scans, int n_scans, int 
     for (int i = n_scans; i <= M3T_MAX_SCANS; ++i) g.blk_start[i] = blocks;
     dim3 grid(blocks, cdiv(B, RB));
     hipStream_t s = (hipStream_t)stream;
+    if (solo_fwd_ok(g, B, T, flags)) return solo_fwd_launch(g, B, T, s);      // H = 128: one workgroup per (scan, clip), no exchange
     bool fast = true;     // every scan: H % 16 == 0 and float4-aligned operands
     for (int i = 0; i < n_scans; ++i) {
         const m3t_gru_fwd_desc& d = scans[i];
@@ -741,6 +742,7 @@ static int scan_bwd_impl(const m3t_gru_bwd_desc* scans, int n_scans, int B, int 
     for (int i = n_scans; i <= M3T_MAX_SCANS; ++i) g.blk_start[i] = blocks;
     dim3 grid(blocks, cdiv(B, RB));
     hipStream_t s = (hipStream_t)stream;
+    if (solo_bwd_ok(g, B, T, flags)) return solo_bwd_launch(g, B, T, flags, s);      // H = 128: one workgroup per (scan, clip)
     bool fast = true;
     for (int i = 0; i < n_scans; ++i) {
         const m3t_gru_bwd_desc& d = scans[i];

@@ -103,6 +103,12 @@ bool persist_bwd_uses_x6(const BwdGroup& g, int B, int T, int flags);   // fp32-
 bool persist_bwd_uses_16(const BwdGroup& g, int B, int T, int flags);   // bf16 mode: wfrag holds bf16 fragments, filled by the launch itself
 int persist_bwd_launch(const BwdGroup& g, const FragPtrs& fp, int B, int T, int flags, hipStream_t s);
 int persist_launch_count();
+void persist_count_launch();     // one more one-launch scan (the solo kernels count as such)
+// H = 128 levels (gru_solo.hip): one launch, one workgroup per (scan, clip), no exchange between workgroups
+bool solo_fwd_ok(const FwdGroup& g, int B, int T, int flags);
+bool solo_bwd_ok(const BwdGroup& g, int B, int T, int flags);
+int solo_fwd_launch(const FwdGroup& g, int B, int T, hipStream_t s);
+int solo_bwd_launch(const BwdGroup& g, int B, int T, int flags, hipStream_t s);
 int persist_profile(unsigned long long* out6);
 
 }  // namespace m3t_gru

@@ -1243,6 +1243,7 @@ void persist_forget_arena(void* arena) {
 }
 
 int persist_launch_count() { return g_launches; }
+void persist_count_launch() { ++g_launches; }
 
 int persist_profile(unsigned long long* out6) {
     if (!g_prof || !out6) return M3T_EINVAL;

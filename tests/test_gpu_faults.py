@@ -138,7 +138,8 @@ print("PARAMETERS-INTACT", flush=True)
 def test_second_process_on_a_gpu_gets_the_launch_per_step_scans():
     """one owner of the persistent scans per GPU (advisory lock on /tmp/m3t_persist_<pci-bus-id>.lock): this process takes
     the lock by running a persistent scan, a second process on the same GPU must fall back to the launch-per-step path
-    (bit-identical results at H=128) instead of spinning against it"""
+    (bit-identical results at H=384, where the persistent kernel runs fp32 MFMAs; H=128 levels take the solo kernels, which need
+    no ownership) instead of spinning against it"""
     for p in (os.path.join(ROOT, "m3f.pytorch_amd"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -147,7 +148,7 @@ def test_second_process_on_a_gpu_gets_the_launch_per_step_scans():
     from models.rnn import GRU
     lib = _lib.load()
     torch.manual_seed(9)
-    m = GRU(24, 128, 2, 3, 2).to("cuda:0")
+    m = GRU(24, 384, 2, 3, 2).to("cuda:0")
     x = torch.randn(16, 33, 24, device="cuda:0")
     n0 = lib.m3t_gru_persist_count()
     with torch.no_grad():
@@ -160,7 +161,7 @@ def test_second_process_on_a_gpu_gets_the_launch_per_step_scans():
 import hashlib
 from models.rnn import GRU
 torch.manual_seed(9)
-m = GRU(24, 128, 2, 3, 2).to("cuda:0")
+m = GRU(24, 384, 2, 3, 2).to("cuda:0")
 x = torch.randn(16, 33, 24, device="cuda:0")
 with torch.no_grad():
     y = m(x)

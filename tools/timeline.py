@@ -6,7 +6,7 @@ import sqlite3
 import sys
 
 db = sqlite3.connect(sys.argv[1])
-rows = list(db.cursor().execute("select name, start, end, stream_id from kernels order by start"))
+rows = list(db.cursor().execute("select name, start, end, stream_id, grid_x, grid_y, grid_z, workgroup_x from kernels order by start"))
 loss = [i for i, r in enumerate(rows) if "va_loss_grad" in r[0] or "va_loss_kernel" in r[0]]
 seg = rows[loss[-2]:loss[-1]]
 
@@ -18,8 +18,8 @@ def short(n):
 
 base = seg[0][1]
 out = []
-for n, s, e, st in seg:
-    k = (short(n), st)
+for n, s, e, st, gx, gy, gz, wx in seg:
+    k = (short(n) + " g%dx%dx%d" % (gx // max(1, wx), gy, gz), st)
     if out and out[-1][0] == k and s - out[-1][2] < 20000:
         out[-1][2] = e; out[-1][3] += 1; out[-1][4] += e - s
     else:
@@ -31,7 +31,7 @@ for k, s, e, c, busy in out:
         print("st%d  %8.3f -> %8.3f ms  n=%4d busy %7.3f  %s" % (k[1], (s - base) / 1e6, (e - base) / 1e6, c, busy / 1e6, k[0]))
 print("step span %.3f ms" % ((seg[-1][2] - base) / 1e6))
 # GPU idle inside the step: time covered by no kernel on any stream, and the largest holes (with what ran before / after)
-iv = sorted((s_, e_, short(n_)) for n_, s_, e_, _ in seg)
+iv = sorted((r_[1], r_[2], short(r_[0])) for r_ in seg)
 idle, holes, cur_end, prev = 0, [], iv[0][1], iv[0][2]
 for s_, e_, n_ in iv[1:]:
     if s_ > cur_end:
