@@ -132,6 +132,7 @@ _INTERLEAVE = os.environ.get("M3T_SCAN_INTERLEAVE", "1") != "0"
 # two-layer stacks: the light group's two scans run back to back between the heavy group's two scans (H0 L0 L1 H1 / H1 L1 L0 H0)
 # instead of strictly alternating
 _LIGHT_BATCHED = os.environ.get("M3T_SCAN_LIGHT_BATCHED", "1") != "0"
+_BWD_LIGHT_LAST = os.environ.get("M3T_SCAN_BWD_LIGHT_LAST", "1") != "0"      # backward scan order H1 L1 H0 L0 (0: H1 L1 L0 H0)
 # data gradients before weight gradients: bit 0 heavy group / bit 1 light group of the batched schedule, bit 2 every level.  The weight
 # gradients of a level then start when its data gradients are done instead of sharing the free CUs with them: the chain's GEMMs
 # finish sooner, the scans beside them stretch less (backward scans 7.9 -> 6.8 ms per step), the step -0.2 ms (8 interleaved runs
@@ -756,15 +757,31 @@ class _MultiBiGRU(torch.autograd.Function):
                     ev_h1 = torch.cuda.Event()
                     ev_h1.record(main)
                     level_gemms(1, heavy, dx_first=_DX_FIRST & 1)
-                    with torch.cuda.stream(side):
+                    if _BWD_LIGHT_LAST:
+                        # H1, L1, H0, L0: the pass ends with a LIGHT scan (64 workgroups), beside which the weight-gradient GEMMs
+                        # that are left have three quarters of the chip -- instead of running alone after the last heavy scan
+                        with torch.cuda.stream(side):
+                            level_scan(1, light, ev_h1)
+                            ev_l1 = torch.cuda.Event()
+                            ev_l1.record(side)
+                            level_gemms(1, light, dx_first=_DX_FIRST & 2)
+                        level_scan(0, heavy, ev_l1)
+                        ev_h0 = torch.cuda.Event()
+                        ev_h0.record(main)
+                        level_gemms(0, heavy, last=True)
+                        with torch.cuda.stream(side):
+                            level_scan(0, light, ev_h0)
+                            level_gemms(0, light)
+                    else:
+                      with torch.cuda.stream(side):
                         level_scan(1, light, ev_h1)
                         level_gemms(1, light, dx_first=_DX_FIRST & 2)
                         level_scan(0, light)
                         ev_light = torch.cuda.Event()
                         ev_light.record(side)
                         level_gemms(0, light)
-                    level_scan(0, heavy, ev_light)
-                    level_gemms(0, heavy, last=True)
+                      level_scan(0, heavy, ev_light)
+                      level_gemms(0, heavy, last=True)
                 else:
                   for l in range(L - 1, -1, -1):
                     level_scan(l, heavy, ev_light)
