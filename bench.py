@@ -348,12 +348,13 @@ def main():
             import glob
             pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))[-1]))["kernels"]
             stem = name.replace("_kernel", "")               # gru_persist_bwd -> bwd, bwd6, bwd16 variants
-            hits = {k: v for k, v in pm.items() if k.startswith(stem) and "hbm_bytes_per_launch" in v}
+            stems = (stem, stem.replace("persist", "solo"))         # the H = 128 levels of the same pass run gru_solo_* launches
+            hits = {k: v for k, v in pm.items() if k.startswith(stems) and "hbm_bytes_per_launch" in v}
             if hits:
                 traffic = int(sum(h["hbm_bytes_per_launch"] * h["launches"] for h in hits.values()) / sum(h["launches"] for h in hits.values()))
                 traffic_by_kernel = {k: v["hbm_bytes_per_launch"] for k, v in hits.items()}
             mm = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_mfma.json")))[-1]))["kernels"]
-            mh = {k: v for k, v in mm.items() if k.startswith(stem) and v.get("mfma_util") is not None}
+            mh = {k: v for k, v in mm.items() if k.startswith(stems) and v.get("mfma_util") is not None}
             if mh:
                 mfma_util = {k: v["mfma_util"] for k, v in mh.items()}
         except Exception:  # noqa: BLE001
@@ -367,8 +368,8 @@ def main():
                     "traffic_by_kernel": traffic_by_kernel, "mfma_busy_frac_pmc": mfma_util,
                     "note": "achieved = algorithmic FLOPs of the recurrent products dh_t = dgh_{t+1} W_hh ((T-1) x sum over scans of 2 B 3H H per launch) / HIP-event "
                             "time of the launches; peak = fp32 MFMA (the arithmetic is fp32-accurate); the H = 256 / 512 launches run it as 6 bf16 MFMAs per "
-                            "product on the bf16 pipe (peak 2500 / 6 = 417 TFLOP/s-equivalent); the kernel is bound by the cross-CU exchange latency per time "
-                            "step, not by either pipe (DESIGN.md section 5)"}
+                            "product on the bf16 pipe (peak 2500 / 6 = 417 TFLOP/s-equivalent), the H = 128 launches (gru_solo_bwd_kernel) as fp32 FMA chains "
+                            "on the vector ALUs; the kernels are bound by the cross-CU exchange latency per time step, not by either pipe (DESIGN.md section 5)"}
 
     if rank == 0:
         clips = B * world * args.steps
@@ -376,7 +377,7 @@ def main():
             "metric": "clips/sec (300-frame A+V, fwd+bwd)", "value": round(clips / dt, 2), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (GEMMs and both recurrences as bf16x6 products = fp32-accurate, fp32 accumulate; the H=128 scorer scans on fp32 MFMAs)",
+            "dtype": "f32 (GEMMs and the H=256/512 recurrences as bf16x6 products = fp32-accurate, fp32 accumulate; the H=128 scorer scans as fp32 FMA chains on the vector ALUs)",
             "data": "synthetic",
             "config": {"workload": "C3/C4 feature-level A+V att_fusion graph (SURVEY 8(d)): audio GRU(128,256,2) | "
                                    "gru_v,gru_a GRU(256,512,2) | proj_v | AttFusion([512,512],128) | "

@@ -112,7 +112,10 @@ typedef struct {
  * slower kernel that reads the row-major operands directly is used.  Results are identical on every path, except that the persistent FORWARD scan
  * at H = 256 / 512 runs its recurrent product as bf16x6 (fp32-accurate, ~1e-6 from the fp32-MFMA kernels; flag
  * M3T_SCAN_FP32 or env M3T_SCAN_X6=0 keeps fp32 MFMAs and bit-identity).
- * Execution: when every H of the level is a multiple of 128 (<= 512) and the level fits the chip at one workgroup
+ * Execution: a level whose scans all have H = 128 runs ONE launch with one workgroup per (scan, clip) and nothing exchanged
+ * between workgroups (gru_solo.hip: fp32 FMA chains, equal to the other paths to fp32 rounding; no residency requirement;
+ * flags M3T_SCAN_NO_PERSIST / M3T_SCAN_FP32 or env M3T_SCAN_SOLO=0 keep the paths below).  Otherwise,
+ * when every H of the level is a multiple of 128 (<= 512) and the level fits the chip at one workgroup
  * per CU, ONE persistent launch runs all T steps (W_hh held in registers, h_t exchanged between CUs through tagged
  * granules); otherwise one launch per time step.  A persistent launch needs all its workgroups resident: never run
  * two of them concurrently on one device (flags = M3T_SCAN_NO_PERSIST for scans issued on a side stream; env
@@ -148,7 +151,7 @@ typedef struct {
     int H, reverse, ldo, ooff, ldg, goff;
 } m3t_gru_bwd_desc;
 
-/* Number of persistent scan launches this process has issued so far (tests use it to assert which path ran). */
+/* Number of one-launch scans (persistent or solo) this process has issued so far (tests use it to assert which path ran). */
 int m3t_gru_persist_count(void);
 /* 0, or (step + 1) of a persistent scan that gave up waiting since the last call (reading clears the word).  The word is
  * host-mapped: no synchronisation happens here, so synchronise the scan's stream first if the answer must cover it. */
