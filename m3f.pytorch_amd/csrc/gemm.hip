@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256) void mask_pos_drop_kernel(const float* __restr
 
 int m3t_sgemm_x6_launch(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                         float* C, int ldc, const float* bias, int act, int accumulate, int seg_len, int seg_stride,
-                        int a_off, int b_off, float* ws, int splits, int kchunk, size_t dyn_lds, int bf16_operands,
+                        int a_off, int b_off, float* ws, int splits, int kchunk, size_t dyn_lds, int bf16_operands, int narrow,
                         hipStream_t s);
 
 int m3t_sgemm_x6c_launch(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
@@ -427,10 +427,20 @@ static bool x6_enabled() {
 
 // Kernel and split-K choice of one m3t_sgemm call.  kernel: 0 fp32-MFMA (gemm.hip), 1 bf16x6 128-tile (gemm_x6.hip),
 // 2 bf16x6 256-tile (gemm_x6c.hip).
-struct GemmPlan { int kernel, splits, kchunk; };
+struct GemmPlan { int kernel, splits, kchunk, narrow; };
+
+static int narrow_mode() {         // M3T_GEMM_NARROW=0: never the 128 x 64 tile of gemm_x6.hip
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("M3T_GEMM_NARROW");
+        on = e ? atoi(e) : 1;
+    }
+    return on;
+}
 
 static GemmPlan plan_gemm(int transA, int M, int N, int K, int seg_len, bool vec, size_t ws_bytes, int flags) {
     GemmPlan g;
+    g.narrow = 0;
     const int bf16 = (flags & M3T_GEMM_BF16) ? 1 : 0;
     const int tiles = cdiv(M, BM) * cdiv(N, BN);
     // interior shapes go to the bf16x6 kernels (fp32-accurate, 2.67x the fp32 MFMA rate)
@@ -481,6 +491,9 @@ static GemmPlan plan_gemm(int transA, int M, int N, int K, int seg_len, bool vec
     int kchunk = cdiv(cdiv(K, splits), kq) * kq;
     if (kchunk < kq) kchunk = kq;
     g.kernel = x6 ? 1 : 0; g.kchunk = kchunk; g.splits = K > 0 ? cdiv(K, kchunk) : 1;
+    // a grid that leaves most CUs with a single 128 x 128 workgroup (<= 1.5 per CU) takes 128 x 64 tiles: twice the workgroups
+    // (fc0 forward, 9600 x 512 x 1024: 96 -> 82 us; not with split-K: those small problems got 10-15 % slower)
+    g.narrow = (x6 && narrow_mode() && g.splits == 1 && tiles <= 384) ? 1 : 0;
     return g;
 }
 
@@ -518,7 +531,7 @@ extern "C" int m3t_sgemm(int transA, int transB, int M, int N, int K, const floa
         else
             rc = m3t_sgemm_x6_launch(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, seg_len, seg_stride,
                                      a_off, b_off, ws, splits, kchunk, (flags & M3T_GEMM_BACKGROUND) ? (size_t)40 * 1024 : 0,
-                                     p.bf16, s);
+                                     p.bf16, g.narrow, s);
         if (rc) return rc;
         if (splits > 1) {
             launch_splitk_reduce(ws, C, bias, M, N, ldc, splits, act, accumulate, s);

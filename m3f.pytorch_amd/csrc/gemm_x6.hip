@@ -75,16 +75,17 @@ __device__ __forceinline__ void split3_pair(f32x2 v, unsigned (&o)[3]) {
 
 // ---- K-contiguous operand ([rows][K]): 8 lanes cover one row's 32 k (a full 128-B line); thread = (k-quad c =
 // tid&7, rows (tid>>3) + 32 i): every wave load instruction fetches 8 whole lines
+template <int NR = 4>
 __device__ __forceinline__ void kc_load(const float* __restrict__ p, size_t ld, float4 (&r)[4]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const float4*>(p + (size_t)i * 32 * ld);
+    for (int i = 0; i < NR; ++i) r[i] = *reinterpret_cast<const float4*>(p + (size_t)i * 32 * ld);
 }
-template <int NS>
+template <int NS, int NR = 4>
 __device__ __forceinline__ void kc_store(unsigned char* __restrict__ S, const float4 (&r)[4]) {
     const int tid = threadIdx.x & 255;
     const int c = tid & 7, r0 = tid >> 3;            // k-quad c of the 32-k tile: octet c >> 1, half c & 1
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NR; ++i) {
         unsigned lo[3], hi2[3];                      // k pairs (0,1) and (2,3) of this row
         split3_pair<NS>((f32x2){r[i].x, r[i].y}, lo);
         split3_pair<NS>((f32x2){r[i].z, r[i].w}, hi2);
@@ -133,8 +134,12 @@ __device__ __forceinline__ void mc_store(unsigned char* __restrict__ S, const fl
 // read as zero -- no im2col, no padded copy, no chomp copy.  A 32-deep k tile lies inside one tap (C % 32 == 0), so a tile's
 // loads are ordinary full-line row loads from shifted rows.  Epilogue: bias, pre-activation copy, ReLU x dropout mask,
 // residual add + ReLU (the TemporalBlock's tail) fused.
-template <int TA, int TB, bool SEG, int NS, bool CONV = false>
+// XNT = 64: a 128 x 64 output tile (each wave 64 x 32) for grids that would leave most CUs with a single 128 x 128 workgroup
+// (N = 512 at M = 9600: 300 tiles for 768 slots) -- twice the workgroups, the B operand staged for 64 rows only.
+template <int TA, int TB, bool SEG, int NS, bool CONV = false, int XNT = 128>
 __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p) {
+    constexpr int NJ = XNT / 64;                     // 32-column MFMA tiles per wave along N
+    constexpr int BR = XNT / 32;                     // rows per thread of a K-contiguous B tile
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * OPER_BYTES];   // A | B, 48 KiB
     unsigned char* As = lds;
     unsigned char* Bs = lds + OPER_BYTES;
@@ -146,16 +151,17 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p) {
     const int lin = blockIdx.y * tn_ + blockIdx.x;
     const int xq = nt_ >> 3, xr = nt_ & 7, xcd = lin & 7, slot = lin >> 3;
     const int til = xcd * xq + min(xcd, xr) + slot;           // XCD-contiguous tile order (see gemm.hip)
-    const int bm = (til / tn_) * XM, bn = (til % tn_) * XN;
+    const int bm = (til / tn_) * XM, bn = (til % tn_) * XNT;
+    const bool bcol = XNT == 128 || (tid & 31) < 16;      // row-contiguous B: this thread's 4 columns lie inside the tile
     const int k_begin = blockIdx.z * p.kchunk;
     const int k_end = min(p.K, k_begin + p.kchunk);
     const int ntiles = (k_end - k_begin) / XK;
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -190,10 +196,10 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p) {
                 const bool ok = (unsigned)(cv_t[i] + off) < (unsigned)p.cv_T;
                 ra[i] = ok ? *reinterpret_cast<const float4*>(qa + (ptrdiff_t)i * 32 * p.lda) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            if (TB == 1) kc_load(p.B + (size_t)j * p.cv_btap + (size_t)(bn + (tid >> 3)) * p.ldb + kc + (tid & 7) * 4, p.ldb, rb);
+            if (TB == 1) kc_load<BR>(p.B + (size_t)j * p.cv_btap + (size_t)(bn + (tid >> 3)) * p.ldb + kc + (tid & 7) * 4, p.ldb, rb);
             else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) rb[e] = *reinterpret_cast<const float4*>(pb + e * b_krow);
+                for (int e = 0; e < 4; ++e) rb[e] = bcol ? *reinterpret_cast<const float4*>(pb + e * b_krow) : make_float4(0.f, 0.f, 0.f, 0.f);
                 pb += b_step;
             }
             cv_k += XK;
@@ -203,7 +209,7 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p) {
             for (int e = 0; e < 4; ++e) {
                 const size_t row = (size_t)q * p.seg_stride + r;
                 ra[e] = *reinterpret_cast<const float4*>(p.A + (row + p.a_off) * p.lda + bm + (tid & 31) * 4);
-                rb[e] = *reinterpret_cast<const float4*>(p.B + (row + p.b_off) * p.ldb + bn + (tid & 31) * 4);
+                rb[e] = bcol ? *reinterpret_cast<const float4*>(p.B + (row + p.b_off) * p.ldb + bn + (tid & 31) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
                 if (++r >= p.seg_len) { r = 0; ++q; }
             }
             sr += XK;
@@ -214,17 +220,17 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) ra[e] = *reinterpret_cast<const float4*>(pa + e * a_krow);
             }
-            if (TB == 1) kc_load(pb, p.ldb, rb);
+            if (TB == 1) kc_load<BR>(pb, p.ldb, rb);
             else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) rb[e] = *reinterpret_cast<const float4*>(pb + e * b_krow);
+                for (int e = 0; e < 4; ++e) rb[e] = bcol ? *reinterpret_cast<const float4*>(pb + e * b_krow) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
             pa += a_step; pb += b_step;
         }
     };
     auto sstore = [&]() {
         if (TA == 0) kc_store<NS>(As, ra); else mc_store<NS>(As, ra);
-        if (TB == 1) kc_store<NS>(Bs, rb); else mc_store<NS>(Bs, rb);
+        if (TB == 1) kc_store<NS, BR>(Bs, rb); else mc_store<NS>(Bs, rb);
     };
 
     if (ntiles > 0) { gload(); sstore(); }
@@ -234,19 +240,19 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p) {
         __builtin_amdgcn_sched_barrier(0);     // the prefetch stays in flight: nothing that consumes it may be hoisted here
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
-            bf16x8 fa[NS][2], fb[NS][2];
+            bf16x8 fa[NS][2], fb[NS][NJ];
 #pragma unroll
             for (int s = 0; s < NS; ++s)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     fa[s][i] = *reinterpret_cast<const bf16x8*>(As + s * SPLIT_BYTES + (kh * 2 + hi) * PLANE + (wm * 64 + i * 32 + l31) * 16);
-                    fb[s][i] = *reinterpret_cast<const bf16x8*>(Bs + s * SPLIT_BYTES + (kh * 2 + hi) * PLANE + (wn * 64 + i * 32 + l31) * 16);
+                    if (i < NJ) fb[s][i] = *reinterpret_cast<const bf16x8*>(Bs + s * SPLIT_BYTES + (kh * 2 + hi) * PLANE + (wn * 32 * NJ + i * 32 + l31) * 16);
                 }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < NJ; ++j) {
                     f32x16 c = acc[i][j];      // smallest terms first
                     if (NS == 3) {
                         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[NS - 1][i], fb[0][j], c, 0, 0, 0);
@@ -273,8 +279,8 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = bn + wn * 64 + j * 32 + l31;
+        for (int j = 0; j < NJ; ++j) {
+            const int col = bn + wn * 32 * NJ + j * 32 + l31;
             const float bv = (direct && p.bias) ? p.bias[col] : 0.f;
             float dm[4] = {1.f, 1.f, 1.f, 1.f};
 #pragma unroll
@@ -307,7 +313,7 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p) {
 // kchunk % 32 == 0, 16-B aligned operands with ld % 4 == 0, and seg_len >= 32 when segmented.
 int m3t_sgemm_x6_launch(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                         float* C, int ldc, const float* bias, int act, int accumulate, int seg_len, int seg_stride,
-                        int a_off, int b_off, float* ws, int splits, int kchunk, size_t dyn_lds, int bf16_operands,
+                        int a_off, int b_off, float* ws, int splits, int kchunk, size_t dyn_lds, int bf16_operands, int narrow,
                         hipStream_t s) {
     X6Params p;
     p.A = A; p.B = B; p.C = C; p.bias = bias; p.ws = ws;
@@ -316,17 +322,17 @@ int m3t_sgemm_x6_launch(int transA, int transB, int M, int N, int K, const float
     p.seg_len = seg_len; p.seg_stride = seg_stride; p.a_off = a_off; p.b_off = b_off;
     p.cv_T = p.cv_C = p.cv_K = p.cv_dil = p.cv_lead = p.cv_anti = 0; p.cv_btap = 0; p.cv_mask = p.cv_res = nullptr; p.cv_pre = nullptr;
     p.cv_drop = m3t_make_drop(0.f, 0ull);
-    dim3 grid(N / XN, M / XM, splits), block(256);
-#define M3T_X6_DISPATCH(NS_)                                                                                        \
-    do {                                                                                                           \
-        if (seg_len > 0) sgemm_x6_kernel<1, 0, true, NS_><<<grid, block, dyn_lds, s>>>(p);                         \
-        else if (transA == 0 && transB == 1) sgemm_x6_kernel<0, 1, false, NS_><<<grid, block, dyn_lds, s>>>(p);   \
-        else if (transA == 0 && transB == 0) sgemm_x6_kernel<0, 0, false, NS_><<<grid, block, dyn_lds, s>>>(p);   \
-        else if (transA == 1 && transB == 0) sgemm_x6_kernel<1, 0, false, NS_><<<grid, block, dyn_lds, s>>>(p);   \
-        else sgemm_x6_kernel<1, 1, false, NS_><<<grid, block, dyn_lds, s>>>(p);                                    \
+    dim3 grid(N / (narrow ? 64 : XN), M / XM, splits), block(256);
+#define M3T_X6_DISPATCH(NS_, XNT_)                                                                                                  \
+    do {                                                                                                                           \
+        if (seg_len > 0) sgemm_x6_kernel<1, 0, true, NS_, false, XNT_><<<grid, block, dyn_lds, s>>>(p);                            \
+        else if (transA == 0 && transB == 1) sgemm_x6_kernel<0, 1, false, NS_, false, XNT_><<<grid, block, dyn_lds, s>>>(p);      \
+        else if (transA == 0 && transB == 0) sgemm_x6_kernel<0, 0, false, NS_, false, XNT_><<<grid, block, dyn_lds, s>>>(p);      \
+        else if (transA == 1 && transB == 0) sgemm_x6_kernel<1, 0, false, NS_, false, XNT_><<<grid, block, dyn_lds, s>>>(p);      \
+        else sgemm_x6_kernel<1, 1, false, NS_, false, XNT_><<<grid, block, dyn_lds, s>>>(p);                                       \
     } while (0)
-    if (bf16_operands) M3T_X6_DISPATCH(1);
-    else M3T_X6_DISPATCH(3);
+    if (bf16_operands) { if (narrow) M3T_X6_DISPATCH(1, 64); else M3T_X6_DISPATCH(1, 128); }
+    else { if (narrow) M3T_X6_DISPATCH(3, 64); else M3T_X6_DISPATCH(3, 128); }
 #undef M3T_X6_DISPATCH
     hipError_t e = hipGetLastError();
     return (int)e;
@@ -346,13 +352,20 @@ int m3t_conv_x6_launch(const float* x, const float* w_t, const float* bias, cons
     p.seg_len = p.seg_stride = p.a_off = p.b_off = 0;
     p.cv_T = T; p.cv_C = Ci; p.cv_K = K; p.cv_dil = dil; p.cv_lead = lead; p.cv_anti = anti;
     p.cv_btap = (size_t)Co * Ci; p.cv_mask = mask; p.cv_res = res; p.cv_pre = pre; p.cv_drop = drop;
-    dim3 grid(Co / XN, p.M / XM, 1), block(256);
+    // 128 x 64 tiles when 128 x 128 ones would leave most CUs with one workgroup (Co = 512 at B*T = 9600: 300 tiles)
+    static const int narrow_on = []() { const char* e = getenv("M3T_GEMM_NARROW"); return e ? atoi(e) : 1; }();
+    const bool narrow = narrow_on && (Co / XN) * (p.M / XM) <= 384;
+    dim3 grid(Co / (narrow ? 64 : XN), p.M / XM, 1), block(256);
+#define M3T_CONV_GO(TB_, NS_)                                                                          \
+    do {                                                                                               \
+        if (narrow) sgemm_x6_kernel<0, TB_, false, NS_, true, 64><<<grid, block, 0, s>>>(p);           \
+        else sgemm_x6_kernel<0, TB_, false, NS_, true, 128><<<grid, block, 0, s>>>(p);                 \
+    } while (0)
     if (anti) {
-        if (bf16_operands) sgemm_x6_kernel<0, 0, false, 1, true><<<grid, block, 0, s>>>(p);
-        else sgemm_x6_kernel<0, 0, false, 3, true><<<grid, block, 0, s>>>(p);
+        if (bf16_operands) M3T_CONV_GO(0, 1); else M3T_CONV_GO(0, 3);
     } else {
-        if (bf16_operands) sgemm_x6_kernel<0, 1, false, 1, true><<<grid, block, 0, s>>>(p);
-        else sgemm_x6_kernel<0, 1, false, 3, true><<<grid, block, 0, s>>>(p);
+        if (bf16_operands) M3T_CONV_GO(1, 1); else M3T_CONV_GO(1, 3);
     }
+#undef M3T_CONV_GO
     return (int)hipGetLastError();
 }
