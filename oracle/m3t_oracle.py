@@ -760,35 +760,64 @@ def concordance_cc2_np(r1, r2, r1_unbiased=False):
 
 
 # --------------------------------------------------------------------------- audio front-end
-# PARITY UNPINNED for melspec_db: the reference calls librosa (process/extract_melspec.py:13-20), a third-party
-# dependency with no pinned version (requirements.txt) that is absent from this image, so no reference output can be
-# generated here.  Restated from librosa's published algorithm (librosa.feature.melspectrogram / filters.mel /
-# power_to_db defaults of 0.10: periodic Hann window centred in n_fft, center=True with zero padding, power 2,
-# Slaney filterbank, ref 1.0, amin 1e-10, top_db 80).  load_audio IS pinned (golden audio_stack.npz from the
-# reference's models/dataset.py:83-95).
-def melspec_db(y, fps=30.0, pad_mode="constant", top_db=80.0, sr=16000, n_fft=512, win_length=400, n_mels=40):
+# melspec_db: the reference calls librosa (process/extract_melspec.py:13-20), a third-party dependency with no pinned version
+# (requirements.txt) that is absent from this image, so no END-TO-END reference output can be generated here: that part of the
+# parity stays unpinned.  The pieces are restated from librosa's published algorithm (librosa.feature.melspectrogram /
+# filters.mel / power_to_db defaults of 0.10: periodic Hann window centred in n_fft, center=True with zero padding, power 2,
+# Slaney filterbank, ref 1.0, amin 1e-10, top_db 80) and pinned one by one (tests/test_oracle_golden.py): the mel scale and
+# the filterbank on the known-answer values librosa publishes in its docstrings (hz_to_mel, mel_to_hz, mel_frequencies,
+# filters.mel), the framed / windowed DFT on torch.stft (an independent implementation), power_to_db on closed forms.
+# load_audio IS pinned end to end (golden audio_stack.npz from the reference's models/dataset.py:83-95).
+_MEL_LOGSTEP = np.log(6.4) / 27.0
+
+
+def hz_to_mel(f):
+    """librosa.hz_to_mel (htk=False, the Slaney / Auditory Toolbox scale): linear below 1 kHz (200/3 Hz per mel), log above"""
+    f = np.asarray(f, F64)
+    return np.where(f >= 1000.0, 15.0 + np.log(np.maximum(f, 1e-300) / 1000.0) / _MEL_LOGSTEP, f * 3 / 200.0)
+
+
+def mel_to_hz(m):
+    m = np.asarray(m, F64)
+    return np.where(m >= 15.0, 1000.0 * np.exp(_MEL_LOGSTEP * (m - 15.0)), m * 200.0 / 3)
+
+
+def mel_frequencies(n_mels, fmin, fmax):
+    """librosa.mel_frequencies: n_mels points evenly spaced on the mel scale"""
+    return mel_to_hz(np.linspace(hz_to_mel(fmin), hz_to_mel(fmax), n_mels))
+
+
+def mel_filterbank(sr, n_fft, n_mels):
+    """librosa.filters.mel(sr, n_fft, n_mels) with its defaults (fmin 0, fmax sr/2, Slaney area normalisation): [n_mels, 1 + n_fft/2]"""
+    freqs = np.linspace(0, sr / 2.0, 1 + n_fft // 2)
+    mel_f = mel_frequencies(n_mels + 2, 0.0, sr / 2.0)
+    fdiff = np.diff(mel_f)
+    ramps = mel_f[:, None] - freqs[None, :]
+    fb = np.stack([np.maximum(0, np.minimum(-ramps[i] / fdiff[i], ramps[i + 2] / fdiff[i + 1])) for i in range(n_mels)])
+    return fb * (2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels]))[:, None]
+
+
+def stft_power(y, n_fft, hop, win_length, pad_mode="constant"):
+    """|STFT|^2 as librosa.stft(center=True) frames it: periodic Hann of win_length centred in n_fft, n_fft/2 padding: [frames, 1 + n_fft/2]"""
     y = np.asarray(y, F64)
-    hop = int(1 / 3 * 1 / fps * 16000)
     win = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(win_length) / win_length)
     lp = (n_fft - win_length) // 2
     win = np.concatenate([np.zeros(lp), win, np.zeros(n_fft - win_length - lp)])
     yp = np.pad(y, n_fft // 2, mode=pad_mode)
     nf = 1 + (yp.shape[0] - n_fft) // hop
     frames = np.stack([yp[f * hop:f * hop + n_fft] * win for f in range(nf)])
-    power = np.abs(np.fft.rfft(frames, axis=1)) ** 2
-    # Slaney mel filterbank
-    logstep = np.log(6.4) / 27.0
-    h2m = lambda f: np.where(np.asarray(f, F64) >= 1000.0, 15.0 + np.log(np.maximum(f, 1e-300) / 1000.0) / logstep, np.asarray(f, F64) * 3 / 200.0)
-    m2h = lambda m: np.where(m >= 15.0, 1000.0 * np.exp(logstep * (m - 15.0)), m * 200.0 / 3)
-    freqs = np.linspace(0, sr / 2.0, 1 + n_fft // 2)
-    mel_f = m2h(np.linspace(h2m(0.0), h2m(sr / 2.0), n_mels + 2))
-    fdiff = np.diff(mel_f)
-    ramps = mel_f[:, None] - freqs[None, :]
-    fb = np.stack([np.maximum(0, np.minimum(-ramps[i] / fdiff[i], ramps[i + 2] / fdiff[i + 1])) for i in range(n_mels)])
-    fb *= (2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels]))[:, None]
-    mel = power @ fb.T
-    db = 10.0 * np.log10(np.maximum(1e-10, mel)) - 10.0 * np.log10(np.maximum(1e-10, 1.0))
+    return np.abs(np.fft.rfft(frames, axis=1)) ** 2
+
+
+def power_to_db(S, top_db=80.0, amin=1e-10, ref=1.0):
+    db = 10.0 * np.log10(np.maximum(amin, S)) - 10.0 * np.log10(np.maximum(amin, ref))
     return np.maximum(db, db.max() - top_db) if top_db is not None else db
+
+
+def melspec_db(y, fps=30.0, pad_mode="constant", top_db=80.0, sr=16000, n_fft=512, win_length=400, n_mels=40):
+    hop = int(1 / 3 * 1 / fps * 16000)
+    power = stft_power(y, n_fft, hop, win_length, pad_mode)
+    return power_to_db(power @ mel_filterbank(sr, n_fft, n_mels).T, top_db)
 
 
 def load_audio(mel_spec, start_idx, w_len):

@@ -224,6 +224,45 @@ def test_melspec_oracle_known_answers():
     assert np.allclose(O.melspec_db(np.zeros(4000), fps), -100.0)   # 10 log10(amin = 1e-10)
 
 
+def test_mel_scale_and_filterbank_against_librosa_published_values():
+    """f-3: the Slaney mel scale and filterbank of the restated log-Mel pipeline against the known-answer values librosa
+    publishes in its own docstrings (librosa.hz_to_mel, mel_to_hz, mel_frequencies, filters.mel examples) -- the third-party
+    dependency of reference process/extract_melspec.py:13-20 is absent here, its published vectors are not."""
+    assert abs(float(O.hz_to_mel(60)) - 0.9) < 1e-12
+    np.testing.assert_allclose(O.hz_to_mel([110, 220, 440]), [1.65, 3.3, 6.6], rtol=0, atol=1e-12)
+    assert abs(float(O.mel_to_hz(3)) - 200.0) < 1e-9
+    np.testing.assert_allclose(O.mel_to_hz([1, 2, 3, 4, 5]), [66.667, 133.333, 200.0, 266.667, 333.333], rtol=0, atol=5e-4)
+    doc = [0., 85.317, 170.635, 255.952, 341.269, 426.586, 511.904, 597.221, 682.538, 767.855, 853.173, 938.49, 1024.856,
+           1119.114, 1222.042, 1334.436, 1457.167, 1591.187, 1737.532, 1897.337, 2071.84, 2262.393, 2470.47, 2697.686,
+           2945.799, 3216.731, 3512.582, 3835.643, 4188.417, 4573.636, 4994.285, 5453.621, 5955.205, 6502.92, 7101.009,
+           7754.107, 8467.272, 9246.028, 10096.408, 11025.]                     # librosa.mel_frequencies(n_mels=40), fmax = 11025
+    np.testing.assert_allclose(O.mel_frequencies(40, 0.0, 11025.0), doc, rtol=0, atol=6e-4)
+    fb = O.mel_filterbank(22050, 2048, 128)                                     # librosa.filters.mel(sr=22050, n_fft=2048)
+    assert fb.shape == (128, 1025) and abs(fb[0, 0]) < 1e-12 and round(float(fb[0, 1]), 3) == 0.016 and fb[0, -1] == 0 and fb[1, 0] == 0
+    assert fb[-1, -1] == 0 and round(float(fb[-1, -2]), 3) == 0.0                # last rows of the printed example: [0., 0., ..., 0., 0.]
+    # Slaney area normalisation: every triangle integrates to ~1 over frequency (bin width sr / n_fft)
+    area = O.mel_filterbank(16000, 512, 40).sum(1) * (16000 / 512)
+    assert np.all(np.abs(area - 1.0) < 0.12), area
+
+
+def test_stft_power_against_torch_stft_and_power_to_db_closed_forms():
+    """f-3: the framing / periodic-Hann / DFT stage against torch.stft (independent implementation), both paddings, and
+    power_to_db on closed forms (ref 1, amin floor, top_db cap)."""
+    import torch
+    rs = np.random.RandomState(5)
+    y = rs.standard_normal(4000)
+    for fps, pad in ((30.0, "constant"), (25.0, "reflect")):
+        hop = int(1 / 3 * 1 / fps * 16000)
+        ref = torch.stft(torch.from_numpy(y), n_fft=512, hop_length=hop, win_length=400,
+                         window=torch.hann_window(400, periodic=True, dtype=torch.float64), center=True, pad_mode=pad,
+                         return_complex=True).abs().pow(2).t().numpy()
+        got = O.stft_power(y, 512, hop, 400, pad)
+        assert got.shape == ref.shape
+        np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(O.power_to_db(np.array([1.0, 10.0, 1e-3, 0.0]), top_db=None), [0.0, 10.0, -30.0, -100.0], atol=1e-12)
+    np.testing.assert_allclose(O.power_to_db(np.array([1.0, 1e-12]), top_db=80.0), [0.0, -80.0], atol=1e-12)
+
+
 def test_philox_known_answers_and_dropout_mask_layout():
     """the oracle's Philox4x32-10 against the Random123 known-answer vectors (kat_vectors: counter / key all zeros, all ones,
     and the pi digits), and the (row, col) -> (counter, word) layout of the dropout mask"""
@@ -242,3 +281,15 @@ def test_philox_known_answers_and_dropout_mask_layout():
     assert [m[8, 5] > 0, m[9, 5] > 0] == [int(w[0][0]) < thr, int(w[1][0]) < thr]       # rows 8, 9 = words 0, 1 of group 2
     big = O.dropout_mask(4096, 64, 0.2, 7)
     assert abs((big > 0).mean() - 0.8) < 0.01
+
+
+def test_product_mel_filterbank_equals_the_pinned_oracle():
+    """the host-side constant of the GPU log-Mel front-end (m3t/audio.py: the filterbank the GEMM multiplies by) is the oracle's
+    filterbank, which the librosa-published values above pin -- no GPU needed"""
+    from m3t import audio
+    for sr, n_fft, n_mels in ((16000, 512, 40), (22050, 2048, 128)):
+        fb = np.asarray(audio.mel_filterbank(sr, n_fft, n_mels), dtype=np.float64)
+        ref = O.mel_filterbank(sr, n_fft, n_mels)
+        assert fb.shape == ref.shape
+        np.testing.assert_allclose(fb, ref, rtol=0, atol=2e-9 if fb.dtype == np.float64 else 1e-7)
+    assert audio.hop_length(30.0) == int(1 / 3 * 1 / 30.0 * 16000) and audio.hop_length(25.0) == 213
