@@ -302,6 +302,27 @@ def case_seq_model(name, ctor, in_shape, seed, ccc_out=True, with_norm=False):
          **grads)
 
 
+def case_seq_model_autocast(name, ctor, in_shape, seed):
+    """BASELINE configs[1] names a bf16 mode the reference does not have.  The yardstick that exists outside this repo: the
+    reference's own classes under PyTorch's standard mixed precision, torch.autocast('cpu', dtype=bfloat16) (forward only;
+    same seed / weights / inputs as case_seq_model): outputs and loss, next to the fp32 ones of the fp32 golden."""
+    rs = np.random.RandomState(seed)
+    m = fill_module(ctor(), seed + 1).eval()
+    lossmod = AffWild2VA(hp(modality="audio", loss="ccc"))
+    x = torch.from_numpy(draw(rs, in_shape))
+    with torch.no_grad():
+        y32 = m(x)
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            y16 = m(x)
+        y16 = y16.float()
+        B, T = y32.shape[0], y32.shape[1]
+        val = torch.from_numpy(draw(rs, (B, T), "uniform_pm1"))
+        aro = torch.from_numpy(draw(rs, (B, T), "uniform_pm1"))
+        loss = lambda y: 0.5 * lossmod.ccc_loss(y[..., -2], val) + 0.5 * lossmod.ccc_loss(y[..., -1], aro)
+        save(name, seed=np.array(seed), in_shape=np.array(in_shape), y_autocast=y16.numpy(), loss_autocast=loss(y16).numpy(),
+             loss_fp32=loss(y32).numpy(), err_autocast=np.array(float((y16 - y32).abs().max())))
+
+
 def case_affwild_audio(name, seed):
     """Config C1 reference-faithful variant: AffWild2VA(modality='audio', loss='ccc_mtl')
     = GRU(200,256,2,9,2) on [4,100,200]; training_step (reference models/model.py:146-218)."""
@@ -582,6 +603,8 @@ def main():
         # clip norm only (weights and inputs are regenerated from the seed)
         case_c3("c3_av_graph_b32", 32, 300, 12345, with_norm=True)
         case_seq_model("c2_tcn_gru_b32", lambda: RefTcnGru(256, 512), (32, 256, 300), 12345, with_norm=True)
+    if want("autocast"):
+        case_seq_model_autocast("c2_tcn_gru_b32_autocast", lambda: RefTcnGru(256, 512), (32, 256, 300), 12345)
     if want("init"):
         case_init_digests("init_digests")
     if want("stitch"):

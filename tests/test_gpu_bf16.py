@@ -1,5 +1,6 @@
 """Mixed-precision mode (BASELINE.json config C2: "bf16, fp32 accumulate, fp32 master weights").  The reference is
-fp32 only, so there is nothing of its own to pin against: the mode is DEFINED as "every matmul / conv / recurrent
+fp32 only, so there is no bf16 output of its own to pin against (the last test anchors the mode on the reference's fp32
+outputs, with the reference's own behaviour under torch.autocast as the yardstick): the mode is DEFINED as "every matmul / conv / recurrent
 operand rounded to bf16 (nearest even), everything else fp32", the oracle emulates exactly that
 (oracle.matmul_precision), and the HIP path is checked against the emulation.
 Tolerances: a GEMM alone differs from the emulation only by fp32 accumulation order (1e-5 * sqrt(K) scale).  Inside a
@@ -12,6 +13,7 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import load_golden
 from golden.recipe import fill_module, draw
 from oracle import m3t_oracle as O
 
@@ -192,3 +194,33 @@ def test_c2_bf16_is_bf16_accurate_and_deterministic():
     d = float((y16 - y32).detach().abs().max())
     assert 1e-5 < d < 5e-2, d
     assert abs(float(l16) - float(l32)) < 5e-3
+
+
+def test_c2_bf16_mode_against_the_reference_at_full_size():
+    """BASELINE configs[1] (TCN -> BiGRU, 32 clips x 300 frames) in the bf16 mode against outputs of the REFERENCE's classes:
+    the fp32 golden (c2_tcn_gru_b32) and, as the yardstick for what "bf16 accuracy" means outside this repo, the same
+    classes under PyTorch's own mixed precision, torch.autocast('cpu', bfloat16) (c2_tcn_gru_b32_autocast, gen_golden.py
+    autocast).  The HIP mode (bf16 operands, fp32 accumulate / state / epilogues) must stay within 1.25x of the distance the
+    reference itself moves under autocast (measured 0.67x), its CCC loss must agree with the fp32 reference to 3 d.p., and it must really be on."""
+    from m3t.workloads import TcnGru
+    from m3t import ops
+    g, ga = load_golden("c2_tcn_gru_b32"), load_golden("c2_tcn_gru_b32_autocast")
+    seed = int(g["seed"])
+    shape = tuple(int(v) for v in g["in_shape"])
+    model = fill_module(TcnGru(256, 512), seed + 1).to(DEV).eval()
+    rs = np.random.RandomState(seed)
+    x = torch.from_numpy(draw(rs, shape)).to(DEV)
+    val, aro = dev(draw(rs, (32, 300), "uniform_pm1")), dev(draw(rs, (32, 300), "uniform_pm1"))
+    with torch.no_grad():
+        with ops.precision("bf16"):
+            y16 = model(x)
+        l16, _ = ops.va_loss(y16, val, aro)
+    y_ref = torch.from_numpy(g["y"]).double()
+    err16 = float((y16.cpu().double() - y_ref).abs().max())
+    err_ac = float(ga["err_autocast"])
+    err_ac_vs_golden = float((torch.from_numpy(ga["y_autocast"]).double() - y_ref).abs().max())
+    assert abs(err_ac - err_ac_vs_golden) < 1e-5                      # the two fixtures describe the same fp32 run
+    print("c2 bf16 mode: |y - y_ref_fp32| = %.3e (reference under torch.autocast: %.3e), loss %.6f vs fp32 %.6f" %
+          (err16, err_ac, float(l16), float(g["loss"])))
+    assert 1e-5 < err16 <= 1.25 * err_ac, (err16, err_ac)              # measured: 5.1e-3 vs 7.5e-3
+    assert abs(float(l16) - float(g["loss"])) <= 5e-4
