@@ -7,6 +7,7 @@ import torch
 from m3t import ops
 
 dev = "cuda:0"
+EXCL = os.environ.get("EXCL") == "1"      # pass M3T_GEMM_EXCLUSIVE (the planner may pick the 256-tile kernel)
 M = 9600
 shapes = []   # (name, tA, tB, M, N, K, count, seg)
 def lin(name, I, O, cnt=1):
@@ -30,9 +31,9 @@ for name, tA, tB, m, n, k, cnt, seg in shapes:
     Cm = torch.empty(m, n, device=dev)
     def run():
         if seg:
-            ops.sgemm(1, 0, m, n, k, A, 0, m, Bm, 0, 2 * n, Cm, 0, n, seg=(299, 300, 1, 0))
+            ops.sgemm(1, 0, m, n, k, A, 0, m, Bm, 0, 2 * n, Cm, 0, n, seg=(299, 300, 1, 0), exclusive=EXCL)
         else:
-            ops.sgemm(tA, tB, m, n, k, A, 0, A.shape[1], Bm, 0, Bm.shape[1], Cm, 0, n)
+            ops.sgemm(tA, tB, m, n, k, A, 0, A.shape[1], Bm, 0, Bm.shape[1], Cm, 0, n, exclusive=EXCL)
     run(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
