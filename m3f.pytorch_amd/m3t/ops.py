@@ -179,6 +179,7 @@ def join_wgrad(device=None):
 # of 8 interleaved runs, 17.79 vs 17.94).
 _N_WGRAD = max(1, int(os.environ.get("M3T_WGRAD_STREAMS", "2")))
 _TAIL_SPREAD = os.environ.get("M3T_WGRAD_TAIL_SPREAD", "1") != "0"
+_TCN_OFF_CHAIN = os.environ.get("M3T_TCN_WGRAD", "1") != "0"      # TemporalBlock weight gradients on the weight-gradient stream (with sinks)
 
 
 def wgrad_stream(device, i=0):
@@ -997,6 +998,10 @@ class _TemporalBlock(torch.autograd.Function):
         y = _conv(h1, w2t, b2, res, m2, a2, B, T, Co, Co, K, dilation, 2, 0, prec, d2)
         ctx.save_for_backward(x, v1, g1, v2, g2, wd, w1t, w2t, n1, n2, h1, a2, y, m1, m2)
         ctx.dil, ctx.drops = dilation, (d1, d2)
+        # parameter objects that own a gradient sink (FlatGradDDP): their gradients can be written straight into the flat buffer
+        # on the weight-gradient stream, off the chain (see backward)
+        prm = (v1, g1, b1, v2, g2, b2) + ((wd, bd) if wd is not None else ())
+        ctx.sink_refs = prm if all(t is not None and id(t) in _GRAD_SINKS for t in prm) else None
         return y
 
     @staticmethod
@@ -1014,6 +1019,45 @@ class _TemporalBlock(torch.autograd.Function):
         da1 = mask_pos(h1, dh1, m1, d1)              # h1 > 0 <=> a1 > 0 (dropout keeps the sign)
         dw2t = torch.empty_like(w2t)
         dw1t = torch.empty_like(w1t)
+        # Off the chain: when every parameter of the block has a gradient sink, the data gradient (what the previous block waits
+        # for) is computed first, and the weight gradients (6 segmented GEMMs), the bias sums and the weight-norm backward run on
+        # the weight-gradient stream straight into the flat gradient buffer (joined by FlatGradDDP.finish(), like _Linear's)
+        sinks = None
+        if (ctx.sink_refs is not None and _TCN_OFF_CHAIN and _WGRAD_ENABLED and _WGRAD_DEFER_JOIN and x.is_cuda
+                and all(ctx.needs_input_grad[i] for i in range(1, 7 if wd is None else 9))):
+            got = [_take_sink(t) for t in ctx.sink_refs]
+            if all(g_ is not None for g_ in got):
+                sinks = got
+            else:
+                join_wgrad(dev)                      # a sink was taken earlier this step: the returned tensors get ADDED on this stream
+        if sinks is not None:
+            if wd is None:
+                dx = _conv(da1, w1t, None, ds, None, None, B, T, Co, Ci, K, dil, 0, 1, prec)
+            else:
+                dx = _conv(da1, w1t, None, None, None, None, B, T, Co, Ci, K, dil, 0, 1, prec)
+                sgemm(0, 0, B * T, Ci, Co, ds, 0, Co, wd, 0, Ci, dx, 0, Ci, accumulate=True, use_ws=False, prec=prec)
+            main = torch.cuda.current_stream()
+            wg = wgrad_stream(dev, 0)
+            wg.wait_stream(main)
+            with torch.cuda.stream(wg):
+                wsw = workspace(dev)
+                _lib.check(lib().m3t_conv1d_wgrad(_p(da2), _p(h1), _p(dw2t), B, T, Co, Co, K, dil, 0, _p(wsw), wsw.numel() * 4, prec,
+                                                  _stream()), "m3t_conv1d_wgrad")
+                _lib.check(lib().m3t_conv1d_wgrad(_p(da1), _p(x), _p(dw1t), B, T, Ci, Co, K, dil, 0, _p(wsw), wsw.numel() * 4, prec,
+                                                  _stream()), "m3t_conv1d_wgrad")
+                colsum(da1, 0, B * T, Co, Co, sinks[2])
+                colsum(da2, 0, B * T, Co, Co, sinks[5])
+                _lib.check(lib().m3t_weight_norm_bwd(_p(dw1t), _p(v1), _p(g1), _p(n1), _p(sinks[0]), _p(sinks[1]), Co, Ci, K, _stream()),
+                           "m3t_weight_norm_bwd")
+                _lib.check(lib().m3t_weight_norm_bwd(_p(dw2t), _p(v2), _p(g2), _p(n2), _p(sinks[3]), _p(sinks[4]), Co, Co, K, _stream()),
+                           "m3t_weight_norm_bwd")
+                if wd is not None:
+                    sgemm(1, 0, Co, Ci, B * T, ds, 0, Co, x, 0, Ci, sinks[6], 0, Ci, prec=prec)
+                    colsum(ds, 0, B * T, Co, Co, sinks[7])
+            for t in (da1, da2, h1, x, dw1t, dw2t, ds, n1, n2):
+                t.record_stream(wg)
+            _WGRAD_PENDING[(dev.type, dev.index)] = True
+            return (dx,) + (None,) * 14
         _lib.check(lib().m3t_conv1d_wgrad(_p(da2), _p(h1), _p(dw2t), B, T, Co, Co, K, dil, 0, _p(ws), ws.numel() * 4, prec,
                                           _stream()), "m3t_conv1d_wgrad")
         _lib.check(lib().m3t_conv1d_wgrad(_p(da1), _p(x), _p(dw1t), B, T, Ci, Co, K, dil, 0, _p(ws), ws.numel() * 4, prec,
