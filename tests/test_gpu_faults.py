@@ -50,21 +50,35 @@ print("NOT-REPORTED", flush=True)
 
 
 def test_dead_scan_is_reported_by_the_next_scan_call():
+    """a scan call that follows a dead scan returns M3T_ESPIN -- the layer-1 call of the same forward if the failure is already
+    visible to the host by then (it depends on how far ahead the host runs), else the first call after it -- and the report
+    clears the word: the path works again"""
     code = r"""
 from models.rnn import GRU
 torch.manual_seed(0)
 m = GRU(24, 256, 2, 3, 2).to("cuda:0")
 x = torch.randn(16, 40, 24, device="cuda:0", requires_grad=True)
+reports = 0
 ops.SCAN_FAULT[0] = True
-y = m(x)                                  # layer 0 dies; layer 1's call may or may not see it yet
-ops.SCAN_FAULT[0] = False
-torch.cuda.synchronize()
 try:
-    m(x)                                  # the first scan call after the failure became visible returns M3T_ESPIN
+    y = m(x)                              # layer 0 dies; layer 1's call reports it if it is visible already
 except _lib.M3THipError as e:
     assert "M3T_ESPIN" in str(e), str(e)
-    print("ESPIN-RETURNED", flush=True)
-y2 = m(x)                                 # the word is cleared by the report: the path works again
+    reports += 1
+ops.SCAN_FAULT[0] = False
+torch.cuda.synchronize()
+for attempt in range(3):                  # at most: one report per scan that died (layer 0, and layer 1 if it was launched)
+    try:
+        y2 = m(x)
+        break
+    except _lib.M3THipError as e:
+        assert "M3T_ESPIN" in str(e), str(e)
+        reports += 1
+        torch.cuda.synchronize()
+else:
+    raise SystemExit("the scan path did not recover")
+assert reports >= 1, "the dead scan was never reported by a scan call"
+print("ESPIN-RETURNED", reports, flush=True)
 torch.cuda.synchronize()
 ops.poll_scan_error()
 assert torch.isfinite(y2).all()
