@@ -248,7 +248,7 @@ def main():
     ddp, step_fn = make_c3_step(model, batch, max_norm=1.0)
 
     def step():
-        return step_fn()[0].detach() if os.environ.get("M3T_BENCH_DETACH", "1") != "0" else step_fn()[0]
+        return step_fn()[0].detach()
 
     def fence():
         torch.cuda.synchronize()
@@ -266,8 +266,6 @@ def main():
     # pair per launch costs the step 0.8 ms (4 %) when every launch of every step carries one -- measured, M3T_BENCH_EVENTS=1
     events_every = max(1, int(os.environ.get("M3T_BENCH_EVENTS", "4")))
     timed_steps = 0
-    run_ahead = int(os.environ.get("M3T_BENCH_RUNAHEAD", "0"))      # > 0: the host stays at most this many steps ahead of the GPU
-    marks = []
     step_marks = [] if os.environ.get("M3T_BENCH_STEP_TIMES") == "1" else None      # debugging: per-step GPU time on stderr
     host_marks = []
     # Python's cyclic collector: a generation-2 pass over the heap of this process (torch + numpy + distributed) stops the host
@@ -287,12 +285,6 @@ def main():
             step_marks.append(torch.cuda.Event(enable_timing=True))
             step_marks[-1].record()
             host_marks.append(time.perf_counter())
-        if run_ahead > 0:
-            ev = torch.cuda.Event()
-            ev.record()
-            marks.append(ev)
-            if len(marks) > run_ahead:
-                marks.pop(0).synchronize()
     ops.PROFILE_ON[0] = False
     host_ms = (time.perf_counter() - t0) / args.steps * 1e3      # host time to ENQUEUE a step (no sync inside the loop)
     fence()
