@@ -444,7 +444,9 @@ static GemmPlan plan_gemm(int transA, int M, int N, int K, int seg_len, bool vec
     const int bf16 = (flags & M3T_GEMM_BF16) ? 1 : 0;
     const int tiles = cdiv(M, BM) * cdiv(N, BN);
     // interior shapes go to the bf16x6 kernels (fp32-accurate, 2.67x the fp32 MFMA rate)
-    const bool x6 = x6_enabled() && (M % 128 == 0) && (N % 128 == 0) && (K % 32 == 0) && K > 0 && vec &&
+    // (N % 64 == 0 is enough with the 128 x 64 tile: e.g. the conv3d weight gradient with N = C_in k^3 = 1728)
+    const bool n64 = (N % 128 != 0) && (N % 64 == 0) && narrow_mode();
+    const bool x6 = x6_enabled() && (M % 128 == 0) && (N % 128 == 0 || n64) && (K % 32 == 0) && K > 0 && vec &&
                     (seg_len == 0 || seg_len >= 32);
     const double ns_per_k = x6 ? (bf16 ? 14.0 : 36.0) : 84.0;
     const int kq = x6 ? 32 : BK;
@@ -466,7 +468,7 @@ static GemmPlan plan_gemm(int transA, int M, int N, int K, int seg_len, bool vec
     // x6c: 17 + rounds x (13 + 0.130 K/split); x6: 12 + 1.2 x its model above (x 1.12 with a row-contiguous A); slabs:
     // 0.3 x their traffic at 3 TB/s + 3.  x6c needs a grid that fills whole rounds of 256 CUs: M = 9600 is 37.5 tiles, so
     // N = 1536 (228 tiles) suits it and N = 1024 / 2048 (152 / 304) do not.
-    if (x6 && x6c_mode() != 0 && (flags & M3T_GEMM_EXCLUSIVE) && !(flags & M3T_GEMM_BACKGROUND)) {
+    if (x6 && !n64 && x6c_mode() != 0 && (flags & M3T_GEMM_EXCLUSIVE) && !(flags & M3T_GEMM_BACKGROUND)) {
         const int tiles_b = cdiv(M, 256) * cdiv(N, 256);
         const double per_k = bf16 ? 0.052 : 0.130;
         const double slab = (double)M * N * 4.0 / 3000.0 / 1e3;          // us per slab pass
@@ -493,7 +495,7 @@ static GemmPlan plan_gemm(int transA, int M, int N, int K, int seg_len, bool vec
     g.kernel = x6 ? 1 : 0; g.kchunk = kchunk; g.splits = K > 0 ? cdiv(K, kchunk) : 1;
     // a grid that leaves most CUs with a single 128 x 128 workgroup (<= 1.5 per CU) takes 128 x 64 tiles: twice the workgroups
     // (fc0 forward, 9600 x 512 x 1024: 96 -> 82 us; not with split-K: those small problems got 10-15 % slower)
-    g.narrow = (x6 && narrow_mode() && g.splits == 1 && tiles <= 384) ? 1 : 0;
+    g.narrow = (x6 && narrow_mode() && (n64 || (g.splits == 1 && tiles <= 384))) ? 1 : 0;
     return g;
 }
 

@@ -60,7 +60,8 @@ def check_digests(named_grads, g, tol=3e-4, prefix="gd."):
 
 # ------------------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("M,N,K", [(1, 1, 1), (33, 9, 17), (128, 128, 16), (300, 257, 130), (1024, 96, 2048), (64, 48, 9600),
-                                   (128, 128, 32), (256, 384, 512), (1152, 256, 4096), (9600, 512, 1024)])   # last four: bf16x6 path
+                                   (128, 128, 32), (256, 384, 512), (1152, 256, 4096), (9600, 512, 1024),    # these four: bf16x6 path
+                                   (128, 1728, 4096), (256, 64, 640), (384, 192, 96)])   # N % 64 == 0 only: bf16x6 on the 128 x 64 tile
 @pytest.mark.parametrize("tA,tB", [(0, 1), (0, 0), (1, 0), (1, 1)])
 def test_sgemm(M, N, K, tA, tB):
     from m3t import ops
