@@ -495,7 +495,7 @@ static GemmPlan plan_gemm(int transA, int M, int N, int K, int seg_len, bool vec
     g.kernel = x6 ? 1 : 0; g.kchunk = kchunk; g.splits = K > 0 ? cdiv(K, kchunk) : 1;
     // a grid that leaves most CUs with a single 128 x 128 workgroup (<= 1.5 per CU) takes 128 x 64 tiles: twice the workgroups
     // (fc0 forward, 9600 x 512 x 1024: 96 -> 82 us; not with split-K: those small problems got 10-15 % slower)
-    g.narrow = (x6 && narrow_mode() && (n64 || (g.splits == 1 && tiles <= 384))) ? 1 : 0;
+    g.narrow = (x6 && narrow_mode() && (n64 || narrow_mode() == 2 || (g.splits == 1 && tiles <= 384))) ? 1 : 0;      // (2: every bf16x6 GEMM, experiments)
     return g;
 }
 

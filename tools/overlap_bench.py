@@ -18,8 +18,9 @@ import scan_bench as sb      # noqa: E402  (reuses bwd_group; its module-level l
 lib = _lib.load()
 dev = torch.device("cuda:0")
 B, T = sb.B, sb.T
-descs, keep = sb.bwd_group([512, 512])
-arr = (GruBwdDesc * len(descs))(*descs)
+FWD = os.environ.get("SCAN") == "fwd"          # SCAN=fwd: the forward scan (124 VGPRs per wave) instead of the backward one (144)
+descs, keep = (sb.fwd_group if FWD else sb.bwd_group)([512, 512])
+arr = ((_lib.GruFwdDesc if FWD else GruBwdDesc) * len(descs))(*descs)
 ws = ops.workspace(dev)
 side = torch.cuda.Stream()
 M = B * T
@@ -31,8 +32,8 @@ ws2 = torch.empty(64 << 18, device=dev)
 
 def scan(stream):
     with torch.cuda.stream(stream):
-        rc = lib.m3t_gru_scan_bwd(arr, len(descs), B, T, C.c_void_p(ws.data_ptr()), ws.numel() * 4, 0,
-                                  C.c_void_p(stream.cuda_stream))
+        rc = (lib.m3t_gru_scan_fwd if FWD else lib.m3t_gru_scan_bwd)(arr, len(descs), B, T, C.c_void_p(ws.data_ptr()), ws.numel() * 4, 0,
+                                                                     C.c_void_p(stream.cuda_stream))
         assert rc == 0
 
 
