@@ -463,6 +463,10 @@ static GemmPlan plan_gemm(int transA, int M, int N, int K, int seg_len, bool vec
             if (t < best) { best = t; splits = sp; }
         }
     }
+    {   // M3T_GEMM_SPLITS=n: force the split-K factor (tuning sweeps, tools/gemm_bench.py)
+        static const int forced = []() { const char* e = getenv("M3T_GEMM_SPLITS"); return e ? atoi(e) : 0; }();
+        if (forced > 0 && ws_bytes && (forced == 1 || ((size_t)forced <= cap && forced <= K / 32))) splits = forced;
+    }
     // 256 x 256 tiles (gemm_x6c.hip), one workgroup per CU, only for callers that have the chip to themselves
     // (M3T_GEMM_EXCLUSIVE).  Which kernel: calibrated time models (us) of both, fitted to tools/gemm_bench.py on MI355X --
     // x6c: 17 + rounds x (13 + 0.130 K/split); x6: 12 + 1.2 x its model above (x 1.12 with a row-contiguous A); slabs:
