@@ -92,7 +92,7 @@ def cpu_baseline(max_clips, T, d_a, d_v, budget_s=25.0):
 # algorithmic FLOPs per clip, forward + backward = 3 x forward: C1 TCN head 128 -> 512 -> 512, k=3 + Linear(512, 2)
 # at T=300: 3 x 1.573 GF; C2 TCN(256 -> 512 -> 512) -> GRU(512,512,2,2,2) at T=300: 20.29 GF; C5 full AffWild2VA A+V on 112x112
 # frames at T=64: 135 GF.
-AUX_FLOPS = {"c1": 3 * 1.573e9, "c2": 20.29e9, "c2bf16": 20.29e9, "c5": 135e9}
+AUX_FLOPS = {"c1": 3 * 1.573e9, "c2": 20.29e9, "c2bf16": 20.29e9, "c5": 135e9, "c3high": 47.43e9}      # (c3high: the main workload, 47.43 GF per clip)
 
 
 def aux_child(which, steps=6, warmup=2):
@@ -148,6 +148,20 @@ def aux_child(which, steps=6, warmup=2):
                     step()
             emit("c2bf16", "C2 as above with bf16 matmul/conv/recurrent operands, fp32 accumulate/state/master weights (BASELINE configs[1])", B,
                  timed(step16, 30), "bf16 operands, f32 accumulate")
+    if "c3high" in which:
+        # the MAIN workload in the opt-in "high" matmul precision (two bf16 terms per GEMM / conv operand, four products: what
+        # torch.set_float32_matmul_precision('high') means; recurrent scans unchanged) -- NOT the headline: `value` is measured
+        # in the default fp32-accurate mode.  Accuracy of the mode: tests/test_gpu_high.py (y within 5e-6 of the reference golden)
+        from m3t.workloads import AVFeatureGraph, make_c3_step
+        torch.manual_seed(12345)
+        m = AVFeatureGraph(128, 256, 512).to(dev)
+        _, step3 = make_c3_step(m, synth_batch(B, T, 128, 256, dev, 0), max_norm=1.0)
+
+        def step_high():
+            with ops.precision("high"):
+                step3()
+        emit("c3high", "C3/C4 main workload with ops.precision('high'): GEMM operands as two bf16 terms (4 products, ~2^-16 per term), "
+             "scans fp32-accurate; opt-in mode, not the headline", B, timed(step_high, 30), "f32 operands as 2 x bf16 in GEMMs, f32 accumulate")
     if "c5" in which:
         from models.model import AffWild2VA
         hp = AffWild2VA.add_model_specific_args(argparse.ArgumentParser(add_help=False)).parse_args([])
@@ -202,7 +216,7 @@ def main():
     ap.add_argument("--frames", type=int, default=300)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=32, help="clips per CPU-baseline iteration (default: the GPU's batch)")
-    ap.add_argument("--aux", default="c1,c2,c2bf16,c5", help="secondary configs timed after the main leg at N=1 ('' = none)")
+    ap.add_argument("--aux", default="c1,c2,c2bf16,c3high,c5", help="secondary configs timed after the main leg at N=1 ('' = none)")
     ap.add_argument("--aux-budget", type=float, default=240.0)
     ap.add_argument("--aux-child", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()

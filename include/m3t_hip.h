@@ -45,6 +45,11 @@ extern "C" {
  * to bf16 (nearest even) before the product, accumulation and epilogue stay fp32.  Interior shapes then run ONE bf16
  * MFMA per tile step instead of the six of the fp32-accurate path. */
 #define M3T_GEMM_BF16 2
+/* "high" precision in the sense of torch.set_float32_matmul_precision('high'): each fp32 operand is treated as the sum of TWO
+ * bfloat16 numbers (16 mantissa bits) and a product is four bf16 MFMAs with fp32 accumulation -- relative error ~2^-16 per term
+ * instead of the 2^-23 of the default six-product form ('highest'), 1.3-1.5x the GEMM rate.  Opt-in (m3t.ops.precision("high"));
+ * interior shapes only (others run exact fp32); M3T_GEMM_BF16 wins if both are set.  The recurrent scans ignore it. */
+#define M3T_GEMM_HIGH 256
 /* the caller promises that nothing else shares the chip while this GEMM runs: the cost model may then pick the
  * 256 x 256-tile kernel (gemm_x6c.hip: one 512-thread workgroup with ~240 VGPRs per CU, 10-20 % faster on shapes that
  * fill whole rounds of 256 CUs).  Without the flag the 128 x 128-tile kernels run: their workgroups leave room on a CU

@@ -442,13 +442,14 @@ static GemmPlan plan_gemm(int transA, int M, int N, int K, int seg_len, bool vec
     GemmPlan g;
     g.narrow = 0;
     const int bf16 = (flags & M3T_GEMM_BF16) ? 1 : 0;
+    const int high = (!bf16 && (flags & M3T_GEMM_HIGH)) ? 1 : 0;      // two bf16 terms per operand, four products (bf16x6 kernel, NS = 2)
     const int tiles = cdiv(M, BM) * cdiv(N, BN);
     // interior shapes go to the bf16x6 kernels (fp32-accurate, 2.67x the fp32 MFMA rate)
     // (N % 64 == 0 is enough with the 128 x 64 tile: e.g. the conv3d weight gradient with N = C_in k^3 = 1728)
     const bool n64 = (N % 128 != 0) && (N % 64 == 0) && narrow_mode();
     const bool x6 = x6_enabled() && (M % 128 == 0) && (N % 128 == 0 || n64) && (K % 32 == 0) && K > 0 && vec &&
                     (seg_len == 0 || seg_len >= 32);
-    const double ns_per_k = x6 ? (bf16 ? 14.0 : 36.0) : 84.0;
+    const double ns_per_k = x6 ? (bf16 ? 14.0 : (high ? 27.0 : 36.0)) : 84.0;
     const int kq = x6 ? 32 : BK;
     // split-K choice by a small cost model (ns): a CU works through its co-resident blocks at ~0.39 TFLOP/s
     // (84 ns per k per 128x128 block; 1.3x slower when it holds a single block), slabs cost their HBM traffic.
@@ -472,7 +473,7 @@ static GemmPlan plan_gemm(int transA, int M, int N, int K, int seg_len, bool vec
     // x6c: 17 + rounds x (13 + 0.130 K/split); x6: 12 + 1.2 x its model above (x 1.12 with a row-contiguous A); slabs:
     // 0.3 x their traffic at 3 TB/s + 3.  x6c needs a grid that fills whole rounds of 256 CUs: M = 9600 is 37.5 tiles, so
     // N = 1536 (228 tiles) suits it and N = 1024 / 2048 (152 / 304) do not.
-    if (x6 && !n64 && x6c_mode() != 0 && (flags & M3T_GEMM_EXCLUSIVE) && !(flags & M3T_GEMM_BACKGROUND)) {
+    if (x6 && !n64 && !high && x6c_mode() != 0 && (flags & M3T_GEMM_EXCLUSIVE) && !(flags & M3T_GEMM_BACKGROUND)) {
         const int tiles_b = cdiv(M, 256) * cdiv(N, 256);
         const double per_k = bf16 ? 0.052 : 0.130;
         const double slab = (double)M * N * 4.0 / 3000.0 / 1e3;          // us per slab pass
@@ -537,7 +538,7 @@ extern "C" int m3t_sgemm(int transA, int transB, int M, int N, int K, const floa
         else
             rc = m3t_sgemm_x6_launch(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, seg_len, seg_stride,
                                      a_off, b_off, ws, splits, kchunk, (flags & M3T_GEMM_BACKGROUND) ? (size_t)40 * 1024 : 0,
-                                     p.bf16, g.narrow, s);
+                                     p.bf16 ? 1 : ((flags & M3T_GEMM_HIGH) ? 2 : 0), g.narrow, s);
         if (rc) return rc;
         if (splits > 1) {
             launch_splitk_reduce(ws, C, bias, M, N, ldc, splits, act, accumulate, s);

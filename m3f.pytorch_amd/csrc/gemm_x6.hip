@@ -66,6 +66,7 @@ __device__ __forceinline__ void split3_pair(f32x2 v, unsigned (&o)[3]) {
     const f32x2 r1 = v - hf;
     const bf16x2 m = __builtin_convertvector(r1, bf16x2);
     o[1] = __builtin_bit_cast(unsigned, m);
+    if (NS == 2) return;
     f32x2 mf;
     mf.x = __uint_as_float(o[1] << 16); mf.y = __uint_as_float(o[1] & 0xffff0000u);
     const f32x2 r2 = r1 - mf;
@@ -254,6 +255,11 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p) {
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     f32x16 c = acc[i][j];      // smallest terms first
+                    if (NS == 2) {                 // "high" mode: two bf16 terms per operand (16 mantissa bits), four products
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[1][j], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[0][j], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[1][j], c, 0, 0, 0);
+                    }
                     if (NS == 3) {
                         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[NS - 1][i], fb[0][j], c, 0, 0, 0);
                         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[NS / 2][i], fb[NS / 2][j], c, 0, 0, 0);
@@ -331,7 +337,9 @@ int m3t_sgemm_x6_launch(int transA, int transB, int M, int N, int K, const float
         else if (transA == 1 && transB == 0) sgemm_x6_kernel<1, 0, false, NS_, false, XNT_><<<grid, block, dyn_lds, s>>>(p);      \
         else sgemm_x6_kernel<1, 1, false, NS_, false, XNT_><<<grid, block, dyn_lds, s>>>(p);                                       \
     } while (0)
-    if (bf16_operands) { if (narrow) M3T_X6_DISPATCH(1, 64); else M3T_X6_DISPATCH(1, 128); }
+    // bf16_operands: 1 = bf16 mode (one product), 2 = "high" mode (two bf16 terms per operand, four products), 0 = fp32-accurate (bf16x6)
+    if (bf16_operands == 1) { if (narrow) M3T_X6_DISPATCH(1, 64); else M3T_X6_DISPATCH(1, 128); }
+    else if (bf16_operands == 2) { if (narrow) M3T_X6_DISPATCH(2, 64); else M3T_X6_DISPATCH(2, 128); }
     else { if (narrow) M3T_X6_DISPATCH(3, 64); else M3T_X6_DISPATCH(3, 128); }
 #undef M3T_X6_DISPATCH
     hipError_t e = hipGetLastError();
@@ -362,9 +370,9 @@ int m3t_conv_x6_launch(const float* x, const float* w_t, const float* bias, cons
         else sgemm_x6_kernel<0, TB_, false, NS_, true, 128><<<grid, block, 0, s>>>(p);                 \
     } while (0)
     if (anti) {
-        if (bf16_operands) M3T_CONV_GO(0, 1); else M3T_CONV_GO(0, 3);
+        if (bf16_operands == 1) M3T_CONV_GO(0, 1); else if (bf16_operands == 2) M3T_CONV_GO(0, 2); else M3T_CONV_GO(0, 3);
     } else {
-        if (bf16_operands) M3T_CONV_GO(1, 1); else M3T_CONV_GO(1, 3);
+        if (bf16_operands == 1) M3T_CONV_GO(1, 1); else if (bf16_operands == 2) M3T_CONV_GO(1, 2); else M3T_CONV_GO(1, 3);
     }
 #undef M3T_CONV_GO
     return (int)hipGetLastError();

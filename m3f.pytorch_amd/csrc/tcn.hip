@@ -301,7 +301,7 @@ extern "C" int m3t_conv1d_fwd(const float* x, const float* w_t, const float* bia
         if (conv_x6_enabled() && ((size_t)B * T) % 128 == 0 && Co % 128 == 0 && Ci % 32 == 0 && al(x) && al(w_t) && al(y) && al(res) &&
             al(drop_mask) && al(pre))
             return m3t_conv_x6_launch(x, w_t, bias, res, drop_mask, y, pre, B, T, Ci, Co, K, dilation, lead, act, anticausal,
-                                      p.bf16, p.drop, (hipStream_t)stream);
+                                      p.bf16 ? 1 : ((flags & M3T_GEMM_HIGH) ? 2 : 0), p.drop, (hipStream_t)stream);
     }
     const int halo = (K - 1) * dilation;
     p.halo = halo;
@@ -348,7 +348,7 @@ extern "C" int m3t_conv1d_wgrad(const float* dy, const float* x, float* dw_t, in
         }
         // dw_t[j][co][ci] = sum_b sum_t dy[b,t,co] * x[b,t+off,ci] over the t with both rows inside the clip
         const int rc = m3t_sgemm(1, 0, Co, Ci, B * (T - span), dy, Co, x, Ci, out, Ci, nullptr, 0, 0, T - span, T, aoff, boff,
-                                 ws, ws_bytes, (flags & M3T_BF16) ? M3T_GEMM_BF16 : 0, stream);
+                                 ws, ws_bytes, (flags & M3T_BF16) ? M3T_GEMM_BF16 : (flags & M3T_GEMM_HIGH), stream);
         if (rc) return rc;
     }
     return 0;

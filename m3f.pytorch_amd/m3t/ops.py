@@ -220,7 +220,9 @@ def workspace(device, nbytes=_WS_MIN, tag=None):
 
 # ----------------------------------------------------------------------------- raw wrappers
 # ---- arithmetic mode of the dense contractions --------------------------------------------------------------------
-# "fp32" (default): fp32-accurate everywhere (what the reference computes).  "bf16": BASELINE.json config C2 -- every
+# "fp32" (default): fp32-accurate everywhere (what the reference computes).  "high": opt-in, the GEMMs and convolutions treat
+# each fp32 operand as the sum of two bfloat16 numbers (four products, ~2^-16 relative error per term -- what
+# torch.set_float32_matmul_precision('high') means); the recurrent scans stay fp32-accurate.  "bf16": BASELINE.json config C2 -- every
 # matmul / conv / recurrent-product operand (activation, weight, gradient) is rounded to bf16, accumulation, state,
 # biases, gate math, normalisation and the loss stay fp32, parameters stay fp32 ("master weights").  An autograd
 # Function records the mode of its forward and uses it for its backward.
@@ -231,9 +233,9 @@ class precision:
     """`with ops.precision("bf16"): y = model(x)` -- context manager selecting the arithmetic mode."""
 
     def __init__(self, mode):
-        if mode not in ("fp32", "bf16"):
-            raise ValueError("precision mode must be 'fp32' or 'bf16'")
-        self.flag = _lib.M3T_BF16 if mode == "bf16" else 0
+        if mode not in ("fp32", "high", "bf16"):
+            raise ValueError("precision mode must be 'fp32', 'high' or 'bf16'")
+        self.flag = {"fp32": 0, "high": _lib.M3T_GEMM_HIGH, "bf16": _lib.M3T_BF16}[mode]
 
     def __enter__(self):
         self.prev = _PREC[0]
