@@ -498,7 +498,10 @@ class _MultiBiGRU(torch.autograd.Function):
     direction: w_ih, w_hh, b_ih, b_hh.  Returns per stack: out [B,T,2H], h_n [2L,B,H]."""
 
     @staticmethod
-    def forward(ctx, n_stacks, L, *tensors):
+    def forward(ctx, n_stacks, L, cat_lo, cat_hi, *tensors):
+        """cat_lo < cat_hi: the last-layer outputs of stacks cat_lo .. cat_hi-1 are written side by side into ONE buffer
+        [B, T, sum 2H] (the `torch.cat(..., -1)` a caller would apply next, without the copy -- and without the slice copies of its
+        backward): that buffer is returned in the slot of stack cat_lo, the other stacks of the group return an empty tensor."""
         per = 1 + 8 * L
         assert len(tensors) == n_stacks * per
         xs, params = [], []
@@ -515,6 +518,13 @@ class _MultiBiGRU(torch.autograd.Function):
         # every buffer is allocated on the caller's stream; side-stream work is fenced by wait_stream on both ends
         h_ns = [new(2 * L, B, Hs[s]) for s in range(n_stacks)]
         outs = [[new(B, T, 2 * Hs[s]) for s in range(n_stacks)] for _ in range(L)]
+        cat_buf = None
+        if cat_hi - cat_lo >= 2:
+            cat_buf = new(B, T, sum(2 * Hs[s] for s in range(cat_lo, cat_hi)))
+            off = 0
+            for s in range(cat_lo, cat_hi):
+                outs[L - 1][s] = cat_buf[..., off:off + 2 * Hs[s]]          # strided view: row stride = the buffer's width
+                off += 2 * Hs[s]
         gates = [[new(2, B, T, 4 * Hs[s]) for s in range(n_stacks)] for _ in range(L)]
         xprojs = [[new(B, T, 6 * Hs[s]) for s in range(n_stacks)] for _ in range(L)]
         main = torch.cuda.current_stream()
@@ -539,7 +549,7 @@ class _MultiBiGRU(torch.autograd.Function):
                     else:
                         descs.append(GruFwdDesc(_vp(xprojs[l][s]), _vp(w_hh), _vp(b_hh), _vp(outs[l][s]),
                                                 _vp(gates[l][s], d * B * T * 4 * H), _vp(h_ns[s], (2 * l + d) * B * H),
-                                                H, d, 6 * H, d * 3 * H, 2 * H, d * H))
+                                                H, d, 6 * H, d * 3 * H, outs[l][s].stride(1), d * H))
             if scan:
                 _scan_fwd(descs, B, T, prec, after)
 
@@ -600,6 +610,7 @@ class _MultiBiGRU(torch.autograd.Function):
                     main.wait_stream(side_stream(dev))
         del xprojs
         ctx.n_stacks, ctx.L, ctx.Hs, ctx.B, ctx.T, ctx.prec = n_stacks, L, Hs, B, T, prec
+        ctx.cat = (cat_lo, cat_hi) if cat_buf is not None else (0, 0)
         saved = []
         for l in range(L):
             for s in range(n_stacks):
@@ -607,7 +618,10 @@ class _MultiBiGRU(torch.autograd.Function):
         ctx.save_for_backward(*(list(tensors) + saved))
         result = []
         for s in range(n_stacks):
-            result += [outs[L - 1][s], h_ns[s]]
+            if cat_buf is not None and cat_lo <= s < cat_hi:
+                result += [cat_buf if s == cat_lo else new(0), h_ns[s]]
+            else:
+                result += [outs[L - 1][s], h_ns[s]]
         return tuple(result)
 
     @staticmethod
@@ -629,10 +643,21 @@ class _MultiBiGRU(torch.autograd.Function):
         out_grads = [None] * (n_stacks * per)
         sunk = [False] * (n_stacks * per)
         douts, dhns = [], []
+        cat_lo, cat_hi = ctx.cat
+        dcat = None
+        if cat_hi > cat_lo:                      # the group's gradient arrives as one [B, T, sum 2H] tensor: read in place, strided
+            g = grads[2 * cat_lo]
+            dcat = (torch.zeros(B, T, sum(2 * Hs[s] for s in range(cat_lo, cat_hi)), dtype=torch.float32, device=dev) if g is None
+                    else _req(g.contiguous(), "dout"))
+        off = 0
         for s in range(n_stacks):
             g, gh = grads[2 * s], grads[2 * s + 1]
-            douts.append(torch.zeros(B, T, 2 * Hs[s], dtype=torch.float32, device=dev) if g is None
-                         else _req(g.contiguous(), "dout"))
+            if dcat is not None and cat_lo <= s < cat_hi:
+                douts.append(dcat[..., off:off + 2 * Hs[s]])
+                off += 2 * Hs[s]
+            else:
+                douts.append(torch.zeros(B, T, 2 * Hs[s], dtype=torch.float32, device=dev) if g is None
+                             else _req(g.contiguous(), "dout"))
             dhns.append(None if gh is None else _req(gh.contiguous(), "dh_n"))
         # all scratch and result buffers on the caller's stream (see forward)
         dgx = [[new(B, T, 6 * Hs[s]) for s in range(n_stacks)] for _ in range(L)]
@@ -642,7 +667,7 @@ class _MultiBiGRU(torch.autograd.Function):
         # H % 16 == 0 everywhere: the scans build their weight fragments straight from w_hh (no transposes in front of them)
         direct_whh = all(h % 16 == 0 for h in Hs) and all(p.is_contiguous() for prm in params for p in prm)
         wht = [[[None if direct_whh else new(Hs[s], 3 * Hs[s]) for _ in (0, 1)] for s in range(n_stacks)] for _ in range(L)]
-        need_dx = [[l > 0 or ctx.needs_input_grad[2 + s * per] for s in range(n_stacks)] for l in range(L)]
+        need_dx = [[l > 0 or ctx.needs_input_grad[4 + s * per] for s in range(n_stacks)] for l in range(L)]
         dinp = [[torch.empty_like(layer_io(l, s)[0]) if need_dx[l][s] else None for s in range(n_stacks)] for l in range(L)]
         for s in range(n_stacks):
             for l in range(L):
@@ -674,7 +699,7 @@ class _MultiBiGRU(torch.autograd.Function):
                                             _vp(dhns[s], (2 * l + d) * B * H) if dhns[s] is not None else None,
                                             _vp(dgx[l][s]), _vp(dgh[l][s], d * B * T * 3 * H), _vp(dh[l][s], d * B * H),
                                             _vp(dbp[l][s], d * B * 4 * H), _vp(out_grads[base + 2]), _vp(out_grads[base + 3]),
-                                            H, d, 2 * H, d * H, 6 * H, d * 3 * H))
+                                            H, d, out.stride(1), d * H, 6 * H, d * 3 * H))      # (dout and out share the layout)
             _scan_bwd(descs, B, T, prec | (_lib.M3T_SCAN_WHH if direct_whh else 0), after)
 
         def level_dx(l, idxs):           # on the chain: feeds the next level's scan
@@ -712,7 +737,7 @@ class _MultiBiGRU(torch.autograd.Function):
                         if T > 1:
                             # dW_hh = sum_{b,t} dgh[b,t]^T h_prev(b,t): forward pairs (t, t-1), reverse pairs (t, t+1)
                             a_off, b_off = (1, 0) if d == 0 else (0, 1)
-                            sgemm(1, 0, 3 * H, H, B * (T - 1), dgh[l][s], goff, 3 * H, out, d * H, 2 * H, dw_hh, 0, H,
+                            sgemm(1, 0, 3 * H, H, B * (T - 1), dgh[l][s], goff, 3 * H, out, d * H, out.stride(1), dw_hh, 0, H,
                                   seg=(T - 1, T, a_off, b_off), prec=prec, background=background)
                         else:
                             dw_hh.zero_()
@@ -829,10 +854,10 @@ class _MultiBiGRU(torch.autograd.Function):
                     main.wait_stream(w_)
         for s in range(n_stacks):
             out_grads[s * per] = dinp[0][s]
-        return (None, None) + tuple(None if sunk[i] else g for i, g in enumerate(out_grads))
+        return (None, None, None, None) + tuple(None if sunk[i] else g for i, g in enumerate(out_grads))
 
 
-def multi_bigru(stacks):
+def multi_bigru(stacks, cat=None):
     """stacks: list of (x [B,T,I], flat_params [w_ih,w_hh,b_ih,b_hh per (layer,dir)], L).
     Returns list of (out [B,T,2H], h_n [2L,B,H])."""
     L = stacks[0][2]
@@ -842,7 +867,8 @@ def multi_bigru(stacks):
             raise M3THipError("grouped GRU stacks must have the same depth")
         flat.append(x)
         flat.extend(prm)
-    res = _MultiBiGRU.apply(len(stacks), L, *flat)
+    lo, hi = cat if cat is not None else (0, 0)
+    res = _MultiBiGRU.apply(len(stacks), L, lo, hi, *flat)
     return [(res[2 * i], res[2 * i + 1]) for i in range(len(stacks))]
 
 

@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from models.rnn import GRU, run_grus
+from models.rnn import GRU, run_grus, run_grus_cat
 from models.att_fusion import AttFusion
 from models.tcn import TemporalConvNet
 
@@ -30,8 +30,8 @@ class AVFeatureGraph(nn.Module):
         self.fusion = GRU(512, num_hidden, 2, fc_outputs, num_fc_layers)
 
     def forward(self, x_a, x_v):
-        a, v1, v2 = run_grus([self.audio, self.visual.gru_v, self.visual.gru_a], [x_a, x_v, x_v])
-        v = ops.linear(torch.cat((v1, v2), dim=-1), self.proj_v.weight, self.proj_v.bias, 0)
+        a, v12 = run_grus_cat([self.audio, self.visual.gru_v, self.visual.gru_a], [x_a, x_v, x_v], 1, 3)      # v12 = cat(v1, v2)
+        v = ops.linear(v12, self.proj_v.weight, self.proj_v.bias, 0)
         return self.fusion(self.att_fuse(a, v))
 
 

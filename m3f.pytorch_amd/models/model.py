@@ -23,7 +23,7 @@ from torch.nn import functional as F
 
 from m3t import ops
 from .backbone import VA_3DResNet, VA_3DVGGM, VA_3DVGGM_Split
-from .rnn import GRU, run_grus
+from .rnn import GRU, run_grus, run_grus_cat
 from .att_fusion import AttFusion
 from .utils import concordance_cc2, mse  # noqa: F401  (re-exported like the reference)
 
@@ -81,9 +81,9 @@ class AffWild2VA(_Base):
         vis = self.visual
         if isinstance(vis, VA_3DVGGM_Split) and vis.split_layer != 5 and vis.backend == 'gru':
             x_v, x_a = vis.features(x, se, se)      # `se_features` passed twice, as model.py:111
-            a, v1, v2 = run_grus([self.audio, vis.gru_v, vis.gru_a],
-                                 [batch['audio'], ops.bct_to_btc(x_v), ops.bct_to_btc(x_a)])
-            return a, torch.cat((v1, v2), dim=-1)
+            a, v12 = run_grus_cat([self.audio, vis.gru_v, vis.gru_a],
+                                  [batch['audio'], ops.bct_to_btc(x_v), ops.bct_to_btc(x_a)], 1, 3)     # v12 = cat(v1, v2)
+            return a, v12
         return self.audio(batch['audio']), vis(x, se, se)
 
     def forward(self, batch):
