@@ -50,6 +50,11 @@ extern "C" {
  * instead of the 2^-23 of the default six-product form ('highest'), 1.3-1.5x the GEMM rate.  Opt-in (m3t.ops.precision("high"));
  * interior shapes only (others run exact fp32); M3T_GEMM_BF16 wins if both are set.  The recurrent scans ignore it. */
 #define M3T_GEMM_HIGH 256
+/* scheduling hint: other streams run persistent scans while this GEMM runs (the interleaved encoder level of m3t.ops._MultiBiGRU):
+ * take gemm_x6.hip, whose phases only overlap across workgroups, instead of the software-pipelined gemm_x6d.hip -- the faster
+ * kernel's higher request rate slows the scans' exchange by as much as it gains (measured: same step time, backward scans
+ * 6.8 -> 7.7 ms by events).  Results are bit-identical either way. */
+#define M3T_GEMM_BESIDE_SCAN 512
 /* the caller promises that nothing else shares the chip while this GEMM runs: the cost model may then pick the
  * 256 x 256-tile kernel (gemm_x6c.hip: one 512-thread workgroup with ~240 VGPRs per CU, 10-20 % faster on shapes that
  * fill whole rounds of 256 CUs).  Without the flag the 128 x 128-tile kernels run: their workgroups leave room on a CU

@@ -411,13 +411,13 @@ int m3t_sgemm_x6d_launch(int transA, int transB, int M, int N, int K, const floa
                          float* C, int ldc, const float* bias, int act, int accumulate, int seg_len, int seg_stride,
                          int a_off, int b_off, float* ws, int splits, int kchunk, int bf16_operands, hipStream_t s);
 
-static bool x6d_enabled() {        // M3T_GEMM_X6D=0: the 128-tile bf16x6 GEMMs on gemm_x6.hip (phases overlap across workgroups only)
+static int x6d_mode() {            // M3T_GEMM_X6D=0: the 128-tile bf16x6 GEMMs on gemm_x6.hip; 1: on gemm_x6d.hip; 2 (default): gemm_x6d.hip unless M3T_GEMM_BESIDE_SCAN
     static int on = -1;
     if (on < 0) {
         const char* e = getenv("M3T_GEMM_X6D");
-        on = (e && e[0] == '0') ? 0 : 1;
+        on = e ? atoi(e) : 2;
     }
-    return on == 1;
+    return on;
 }
 
 static int x6c_mode() {            // M3T_GEMM_X6C: 0 never, 1 always (where eligible), unset/2 by the cost model
@@ -548,7 +548,7 @@ extern "C" int m3t_sgemm(int transA, int transB, int M, int N, int K, const floa
         if (g.kernel == 2)
             rc = m3t_sgemm_x6c_launch(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, seg_len, seg_stride,
                                       a_off, b_off, ws, splits, kchunk, p.bf16, s);
-        else if (!g.narrow && !(flags & (M3T_GEMM_BACKGROUND | M3T_GEMM_HIGH)) && x6d_enabled())      // ("high": measured better on gemm_x6.hip)
+        else if (!g.narrow && !(flags & (M3T_GEMM_BACKGROUND | M3T_GEMM_HIGH)) && (x6d_mode() == 1 || (x6d_mode() == 2 && !(flags & M3T_GEMM_BESIDE_SCAN))))      // ("high": measured better on gemm_x6.hip)
             // the same product, software-pipelined inside each wave (gemm_x6d.hip): bit-identical results, 8-28 % faster
             rc = m3t_sgemm_x6d_launch(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, seg_len, seg_stride,
                                       a_off, b_off, ws, splits, kchunk, p.bf16 ? 1 : ((flags & M3T_GEMM_HIGH) ? 2 : 0), s);

@@ -11,6 +11,7 @@ M3T_EINVAL = 10001
 M3T_ESPIN = 10002
 M3T_SCAN_NO_PERSIST = 1
 M3T_BF16 = 2
+M3T_GEMM_BESIDE_SCAN = 512      # scheduling hint, see include/m3t_hip.h
 M3T_GEMM_HIGH = 256      # two bf16 terms per operand, four products: torch.set_float32_matmul_precision('high')
 M3T_GEMM_EXCLUSIVE = 8
 M3T_SCAN_FP32 = 4

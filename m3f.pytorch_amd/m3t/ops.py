@@ -251,6 +251,8 @@ def sgemm(transA, transB, M, N, K, A, a_off, lda, B, b_off, ldb, Cm, c_off, ldc,
           accumulate=False, seg=(0, 0, 0, 0), use_ws=True, background=False, prec=None, exclusive=False):
     ws = workspace(Cm.device) if use_ws else None
     flags = (1 if background else 0) | (_PREC[0] if prec is None else prec) | (_lib.M3T_GEMM_EXCLUSIVE if exclusive else 0)
+    if _FENCED[0]:
+        flags |= _lib.M3T_GEMM_BESIDE_SCAN       # issued inside the interleaved schedule of _MultiBiGRU: scans of another stream run beside it
     with _Timed("sgemm_kernel", 1, 2.0 * M * N * K) if PROFILE_GEMM[0] else _NULL:
         rc = lib().m3t_sgemm(transA, transB, M, N, K, _p(A, a_off), lda, _p(B, b_off), ldb, _p(Cm, c_off), ldc,
                              _p(bias), act, int(accumulate), seg[0], seg[1], seg[2], seg[3],
