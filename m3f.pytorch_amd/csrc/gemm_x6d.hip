@@ -34,6 +34,11 @@ struct X6DParams {
     int M, N, K, lda, ldb, ldc;
     int act, accumulate, splits, kchunk;
     int seg_len, seg_stride, a_off, b_off;
+    // implicit-GEMM 1-D convolution (CONV kernels, m3t_conv_x6d_launch; semantics of the CONV form of gemm_x6.hip)
+    int cv_T, cv_C, cv_K, cv_dil, cv_lead, cv_anti;
+    size_t cv_btap;
+    const float* cv_mask; const float* cv_res; float* cv_pre;
+    M3TDrop cv_drop;
 };
 
 template <int NS>
@@ -93,7 +98,10 @@ __device__ __forceinline__ void mc_store_c(unsigned char* __restrict__ S, const 
     }
 }
 
-template <int TA, int TB, bool SEG, int NS>
+// CONV (TA == 0): k = (tap j, channel c), A[m][k] = x[m + off_j][c] with rows whose source frame falls outside the clip read as zero
+// (a 16-deep stage lies inside one tap: C % 32 == 0); TB == 1: B = one [Co][Ci] plane per tap; TB == 0 (data gradient): the
+// row-major [K*Ci][Co] matrix.  Epilogue: bias, pre-activation copy, ReLU x dropout mask, residual add + ReLU, as gemm_x6.hip's.
+template <int TA, int TB, bool SEG, int NS, bool CONV = false>
 __global__ __launch_bounds__(NTH, 3) void sgemm_x6d_kernel(X6DParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];     // stage 0 | stage 1, each A | B
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -154,11 +162,38 @@ __global__ __launch_bounds__(NTH, 3) void sgemm_x6d_kernel(X6DParams p) {
         pb[0] = p.B + (size_t)p.b_off * p.ldb + cb;
     }
 
+    int cv_t[2] = {0, 0};                                     // CONV: frame index of this thread's two A rows
+    if (CONV) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) cv_t[i] = (bm + (tid >> 2) + 64 * i) % p.cv_T;
+    }
     f32x4 ra0[2], rb0[2], ra1[2], rb1[2];                    // raw fp32 values of two stages in flight
     int loaded = 0;                                           // stages fetched so far
     auto gload = [&](f32x4 (&ra)[2], f32x4 (&rb)[2]) {        // fetch the next stage; past the end: re-fetch the last one (unused)
         const bool adv = loaded + 1 < nst;
-        if (SEG) {
+        if (CONV) {
+            const int k0 = k_begin + BKS * min(loaded, nst - 1);
+            const int j = k0 / p.cv_C, kc = k0 - j * p.cv_C;
+            const int sft = (p.cv_K - 1 - j) * p.cv_dil;
+            const int off = p.cv_anti ? sft - p.cv_lead : p.cv_lead - sft;
+            const float* qa = p.A + ((ptrdiff_t)(bm + (tid >> 2)) + off) * (ptrdiff_t)p.lda + kc + (tid & 3) * 4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bool ok = (unsigned)(cv_t[i] + off) < (unsigned)p.cv_T;
+                ra[i] = ok ? *reinterpret_cast<const f32x4*>(qa + (ptrdiff_t)i * 64 * p.lda) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            if (TB == 1) {
+                const float* qb = p.B + (size_t)j * p.cv_btap + (size_t)(bn + (tid >> 2)) * p.ldb + kc + (tid & 3) * 4;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) rb[i] = *reinterpret_cast<const f32x4*>(qb + (size_t)i * 64 * p.ldb);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    rb[e] = *reinterpret_cast<const f32x4*>(pb[e]);
+                    pb[e] += adv ? b_step : 0;
+                }
+            }
+        } else if (SEG) {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const size_t row = (size_t)sq[e] * p.seg_stride + sr[e];
@@ -240,12 +275,22 @@ __global__ __launch_bounds__(NTH, 3) void sgemm_x6d_kernel(X6DParams p) {
         for (int j = 0; j < 2; ++j) {
             const int col = bn + wn * 64 + j * 32 + l31;
             const float bv = (direct && p.bias) ? p.bias[col] : 0.f;
+            float dm[4] = {1.f, 1.f, 1.f, 1.f};
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = bm + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (CONV && p.cv_drop.on && (r & 3) == 0) m3t_drop_mask4(p.cv_drop, (uint32_t)row >> 2, (uint32_t)col, dm);
                 float v = acc[i][j][r];
                 float* q = dst + (size_t)row * ldd + col;
-                if (direct) {
+                if (CONV) {
+                    const size_t o = (size_t)row * ldd + col;
+                    v += bv;
+                    if (p.cv_pre) p.cv_pre[o] = v;
+                    const float mk = p.cv_drop.on ? dm[r & 3] : (p.cv_mask ? p.cv_mask[o] : 1.f);
+                    if (p.act == 1) v = fmaxf(v, 0.f) * mk;
+                    else if (p.act == 2) v = fmaxf(fmaxf(v, 0.f) * mk + p.cv_res[o], 0.f);
+                    else if (p.cv_res) v += p.cv_res[o];
+                } else if (direct) {
                     v += bv;
                     if (p.act == 1) v = fmaxf(v, 0.f);
                     if (p.accumulate) v += *q;
@@ -267,6 +312,8 @@ int m3t_sgemm_x6d_launch(int transA, int transB, int M, int N, int K, const floa
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.act = act; p.accumulate = accumulate; p.splits = splits; p.kchunk = kchunk;
     p.seg_len = seg_len; p.seg_stride = seg_stride; p.a_off = a_off; p.b_off = b_off;
+    p.cv_T = p.cv_C = p.cv_K = p.cv_dil = p.cv_lead = p.cv_anti = 0; p.cv_btap = 0; p.cv_mask = p.cv_res = nullptr; p.cv_pre = nullptr;
+    p.cv_drop = m3t_make_drop(0.f, 0ull);
     dim3 grid(N / BN, M / BM, splits), block(NTH);
     const size_t lds = 2 * (size_t)STAGEB;
 #define M3T_X6D_GO(TA_, TB_, SEG_, NS_)                                                                               \
@@ -293,5 +340,40 @@ int m3t_sgemm_x6d_launch(int transA, int transB, int M, int N, int K, const floa
     else M3T_X6D_DISPATCH(3);
 #undef M3T_X6D_DISPATCH
 #undef M3T_X6D_GO
+    return (int)hipGetLastError();
+}
+
+
+// Dilated 1-D convolution on the software-pipelined kernel (contract of m3t_conv_x6_launch: (B*T) % 128 == 0, Co % 128 == 0,
+// Ci % 32 == 0, 16-B aligned operands; anti = 0: w_t is [K][Co][Ci], anti = 1 (data gradient): [K][Ci][Co] read as [K*Ci][Co]).
+int m3t_conv_x6d_launch(const float* x, const float* w_t, const float* bias, const float* res, const float* mask, float* y,
+                        float* pre, int B, int T, int Ci, int Co, int K, int dil, int lead, int act, int anti, int bf16_operands,
+                        M3TDrop drop, hipStream_t s) {
+    X6DParams p;
+    p.A = x; p.B = w_t; p.C = y; p.bias = bias; p.ws = nullptr;
+    p.M = B * T; p.N = Co; p.K = K * Ci; p.lda = Ci; p.ldb = anti ? Co : Ci; p.ldc = Co;
+    p.act = act; p.accumulate = 0; p.splits = 1; p.kchunk = K * Ci;
+    p.seg_len = p.seg_stride = p.a_off = p.b_off = 0;
+    p.cv_T = T; p.cv_C = Ci; p.cv_K = K; p.cv_dil = dil; p.cv_lead = lead; p.cv_anti = anti;
+    p.cv_btap = (size_t)Co * Ci; p.cv_mask = mask; p.cv_res = res; p.cv_pre = pre; p.cv_drop = drop;
+    dim3 grid(Co / BN, p.M / BM, 1), block(NTH);
+    const size_t lds = 2 * (size_t)STAGEB;
+#define M3T_CONVD_GO(TB_, NS_)                                                                                            \
+    do {                                                                                                                   \
+        static bool attr_set = false;                                                                                      \
+        if (!attr_set) {                                                                                                   \
+            hipError_t ea = hipFuncSetAttribute((const void*)sgemm_x6d_kernel<0, TB_, false, NS_, true>,                   \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
+            if (ea != hipSuccess) return (int)ea;                                                                          \
+            attr_set = true;                                                                                               \
+        }                                                                                                                  \
+        sgemm_x6d_kernel<0, TB_, false, NS_, true><<<grid, block, lds, s>>>(p);                                            \
+    } while (0)
+    if (anti) {
+        if (bf16_operands == 1) M3T_CONVD_GO(0, 1); else if (bf16_operands == 2) M3T_CONVD_GO(0, 2); else M3T_CONVD_GO(0, 3);
+    } else {
+        if (bf16_operands == 1) M3T_CONVD_GO(1, 1); else if (bf16_operands == 2) M3T_CONVD_GO(1, 2); else M3T_CONVD_GO(1, 3);
+    }
+#undef M3T_CONVD_GO
     return (int)hipGetLastError();
 }

@@ -986,3 +986,15 @@ def test_solo_scans_h128_through_the_c_abi(B, T, bf16):
         for a, b_, name in zip(got, ref, ("dgx", "dgh", "dh", "db_ih", "db_hh")):
             close(a, b_, (3e-5 if T < 10 else 5e-3) if bf16 else 5e-6, "%s (direct=%d)" % (name, direct))
     ops.poll_scan_error()
+
+
+def test_conv_on_the_software_pipelined_kernel_opt_in():
+    """M3T_CONV_X6D=1 (read once per process, hence a child): the implicit-GEMM convolutions on gemm_x6d.hip's CONV form instead of
+    gemm_x6.hip's -- same arithmetic; the convolution and TemporalBlock parity tests must pass unchanged"""
+    import subprocess
+    import sys
+    env = dict(os.environ, M3T_CONV_X6D="1", M3T_SCAN_LOCK="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
+                        "conv1d_on_the_bf16x6_pipe or tcn_train_mode or tcn_golden"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:]
+    assert " passed" in r.stdout
