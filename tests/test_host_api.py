@@ -205,3 +205,18 @@ def test_init_digests_match_reference_rng_stream():
         for n, p in m.named_parameters():
             np.testing.assert_allclose(grad_digest(p.detach().numpy()), g["%s.%s" % (tag, n)], rtol=1e-6, atol=1e-7,
                                        err_msg="%s.%s" % (tag, n))
+
+
+def test_flag_constants_match_the_header():
+    """every M3T_* flag / error constant the ctypes layer defines carries the value include/m3t_hip.h gives it"""
+    txt = open(os.path.join(ROOT, "include", "m3t_hip.h")).read()
+    defs = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"^#define\s+(M3T_[A-Z0-9_]+)\s+(0x[0-9a-fA-F]+|\d+)\b", txt, flags=re.M)}
+    checked = 0
+    for name, val in vars(_lib).items():
+        if name.startswith("M3T_") and isinstance(val, int) and name in defs:
+            assert defs[name] == val, (name, defs[name], val)
+            checked += 1
+    assert checked >= 8, checked
+    with pytest.raises(ValueError):
+        ops.precision("fp16")
+    assert ops.precision("high").flag == defs["M3T_GEMM_HIGH"] and ops.precision("bf16").flag == defs["M3T_BF16"]
