@@ -9,8 +9,15 @@ One process per GPU (torchrun), clips sharded across ranks (weak scaling), one f
 all-reduce of the gradients per step.
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus 8                      # starts its own 8 ranks (torch.distributed.run) before touching a GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W [--scaling strong]
+
+Process structure for N > 1.  The process torchrun starts for a rank is a SUPERVISOR: it never touches the GPU, starts the
+real worker (`--worker`) as a child and watches it.  If a worker reports a persistent scan that gave up (M3T_ESPIN: e.g. an
+RCCL kernel and a resident-grid scan starving each other -- a combination no 1-GPU box can execute) or stops making
+progress, every supervisor ends its worker and starts a fresh one on the launch-per-step scans with the gradient buckets
+overlapped with backward; the JSON line then carries a "fallback" note.  N = 1 runs in the process itself, as before.
 """
 import argparse
 import json
@@ -162,6 +169,49 @@ def aux_child(which, steps=6, warmup=2):
                 step3()
         emit("c3high", "C3/C4 main workload with ops.precision('high'): GEMM operands as two bf16 terms (4 products, ~2^-16 per term), "
              "scans fp32-accurate; opt-in mode, not the headline", B, timed(step_high, 30), "f32 operands as 2 x bf16 in GEMMs, f32 accumulate")
+    if "cbam" in which:
+        # the HBM-bound kernel family of the path: models.cbam.CBAM forward + backward on the four
+        # ResNet-18 stage shapes of a 32 x 64-frame batch (2048 frames), bytes / time against the 8 TB/s HBM roofline.
+        # Algorithmic passes over a tensor of x's size, forward + backward, with BatchNorm2d(1) in train mode (two global
+        # statistics -- one forward, one backward -- each cut the gate in two): fwd read x | read x, write y; bwd read dy,
+        # read x | read dy, read x, write dx = 8; `GBps_8pass` = 8 x bytes(x) / time.
+        from models.cbam import CBAM
+        res = {}
+        for (Cc, HWs) in ((64, 28), (128, 14), (256, 7), (512, 4)):
+            torch.manual_seed(0)
+            cb = CBAM(Cc).to(dev).train()
+            xx = torch.randn(2048, Cc, HWs, HWs, device=dev, requires_grad=True)
+            gg = torch.randn(2048, Cc, HWs, HWs, device=dev)
+
+            def fb():
+                for p_ in cb.parameters():
+                    p_.grad = None
+                xx.grad = None
+                cb(xx).backward(gg)
+            ms = timed(fb, 20)
+            nbytes = xx.numel() * 4
+            res["%dx%dx%d" % (Cc, HWs, HWs)] = {"frames": 2048, "x_bytes": nbytes, "ms_fwd_bwd": round(ms, 4),
+                                                "GBps_8pass": round(8 * nbytes / ms / 1e6, 1),
+                                                "frac_of_hbm_peak": round(8 * nbytes / ms / 1e6 / HBM_PEAK_GBS, 4)}
+            del xx, gg, cb
+        # and inside a model: VA_3DResNet(resnet_ver='v1', use_cbam=True) visual-only, 8 clips x 64 frames of 112 x 112 (SURVEY 8(d) C5 alt)
+        from models.backbone import VA_3DResNet
+        torch.manual_seed(12345)
+        Bc, Tc = 8, 64
+        net = VA_3DResNet(inputDim=512, hiddenDim=512, nLayers=2, nClasses=2, frameLen=Tc, use_cbam=True, resnet_ver="v1").to(dev).train()
+        vid = f(((rs.randint(0, 256, (Bc, 3, Tc, 112, 112)).astype(np.float32)) - 127.5) / 127.5)
+        ddp = FlatGradDDP(net, max_norm=1.0)
+
+        def step_r():
+            ddp.zero_grad()
+            y = net(vid)
+            ops.va_loss(y, val[:Bc, :Tc].contiguous(), aro[:Bc, :Tc].contiguous())[0].backward()
+            ddp.finish()
+        ms = timed(step_r, 6)
+        print(json.dumps({"aux": "cbam", "workload": "models.cbam.CBAM fwd+bwd (train mode) on the ResNet-18 stage shapes, 2048 frames; "
+                          "and VA_3DResNet(v1, use_cbam=True) visual-only training step, 8 x 64 frames of 112 x 112 (conv stem and ResNet convs on MIOpen)",
+                          "stages": res, "resnet3d_cbam_ms_per_step": round(ms, 3), "resnet3d_cbam_clips_per_s": round(Bc / ms * 1e3, 1),
+                          "dtype": "f32", "peak_GBps": HBM_PEAK_GBS}), flush=True)
     if "c5" in which:
         from models.model import AffWild2VA
         hp = AffWild2VA.add_model_specific_args(argparse.ArgumentParser(add_help=False)).parse_args([])
@@ -207,30 +257,130 @@ def run_aux(which, budget_s):
     return res
 
 
-def main():
+ESPIN_EXIT = 42          # a worker that saw M3T_ESPIN exits with this code: its supervisor starts the fallback
+STORE_PORT_OFFSET = 17   # supervisors' coordination store: MASTER_PORT + 17; workers rendezvous on MASTER_PORT + 1 + attempt
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU (weak scaling) / global batch (strong scaling)")
     ap.add_argument("--frames", type=int, default=300)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --batch clips on EVERY GPU; strong: --batch clips in all, split over the GPUs (SURVEY 8(d) C4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=32, help="clips per CPU-baseline iteration (default: the GPU's batch)")
-    ap.add_argument("--aux", default="c1,c2,c2bf16,c3high,c5", help="secondary configs timed after the main leg at N=1 ('' = none)")
+    ap.add_argument("--aux", default="c1,c2,c2bf16,c5,cbam", help="secondary configs timed after the main leg at N=1 ('' = none)")
     ap.add_argument("--aux-budget", type=float, default=240.0)
     ap.add_argument("--aux-child", default=None, help=argparse.SUPPRESS)
-    args = ap.parse_args()
+    ap.add_argument("--worker", type=int, default=None, help=argparse.SUPPRESS)      # attempt number (0, or 1 = fallback)
+    ap.add_argument("--worker-timeout", type=float, default=float(os.environ.get("M3T_BENCH_WORKER_TIMEOUT", "900")),
+                    help="N > 1: seconds a worker may run before its supervisor declares it stuck and starts the fallback")
+    return ap.parse_args()
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start the N ranks ourselves, as the driver would.
+    Nothing in THIS process has touched the GPU (importing torch does not initialise HIP), and it never will: it only
+    waits for torch.distributed.run and passes its exit code on."""
+    import subprocess
+    port = int(os.environ.get("MASTER_PORT", _free_port()))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("# bench.py --gpus %d without a launcher: starting %s" % (args.gpus, " ".join(cmd[1:8])), file=sys.stderr, flush=True)
+    return subprocess.call(cmd)
+
+
+def supervise(args):
+    """The process torchrun started for this rank (N > 1).  No GPU call here.  Runs the worker as a child; all supervisors share
+    a TCPStore (rank 0 hosts it, CPU only) through which the first one that sees a failed or stuck worker calls the fallback."""
+    import subprocess
+    from datetime import timedelta
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    port = int(os.environ.get("MASTER_PORT", "29500"))
+    store = dist.TCPStore("127.0.0.1", port + STORE_PORT_OFFSET, world, rank == 0, timedelta(seconds=300), wait_for_workers=False)
+    me = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+
+    def run(attempt, extra_env):
+        env = dict(os.environ, **extra_env)
+        env.pop("TORCHELASTIC_USE_AGENT_STORE", None)        # the workers host their own rendezvous store (port + 1 + attempt)
+        p = subprocess.Popen(me + ["--worker", str(attempt)], env=env)
+        t0 = time.time()
+        key = "fail%d" % attempt
+        while True:
+            rc = p.poll()
+            if rc is not None:
+                if rc != 0:
+                    store.set(key, "rank %d exited with %d" % (rank, rc))
+                return rc
+            failed = store.check([key])
+            if not failed and time.time() - t0 > args.worker_timeout:
+                store.set(key, "rank %d made no progress for %.0f s" % (rank, args.worker_timeout))
+                failed = True
+            if failed:
+                # some rank's worker failed: ours is waiting in a collective for it (or is the stuck one) -- end exactly it
+                p.kill()
+                p.wait()
+                return -1
+            time.sleep(0.25)
+
+    rc = run(0, {})
+    store.add("done0", 1)
+    while int(store.add("done0", 0)) < world:                # every supervisor has its first verdict (and its worker is gone)
+        time.sleep(0.1)
+    if not store.check(["fail0"]):
+        return rc
+    why = store.get("fail0").decode()
+    if rank == 0:
+        print("# worker failure (%s): fresh workers on the launch-per-step scans with overlapped gradient buckets" % why,
+              file=sys.stderr, flush=True)
+    rc = run(1, {"M3T_SCAN_PERSIST": "0", "M3T_BENCH_FALLBACK": why})
+    store.add("done1", 1)
+    while int(store.add("done1", 0)) < world:
+        time.sleep(0.1)
+    return 1 if store.check(["fail1"]) else rc
+
+
+def main():
+    args = parse_args()
     if args.aux_child is not None:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
         aux_child(set(args.aux_child.split(",")))
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))                    # before anything touches the GPU
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world > 1 and args.worker is None:
+        sys.exit(supervise(args))                      # likewise: the supervisor never touches the GPU
+    try:
+        worker(args)
+    except Exception as e:  # noqa: BLE001
+        if world > 1 and "M3T_ESPIN" in str(e):
+            print("# rank %s: %s" % (os.environ.get("RANK"), e), file=sys.stderr, flush=True)
+            sys.stderr.flush()
+            os._exit(ESPIN_EXIT)                       # no teardown: peers may be waiting in a collective for this rank
+        raise
 
+
+def worker(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    fallback = os.environ.get("M3T_BENCH_FALLBACK")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     # M3T_BENCH_BACKEND=gloo + M3T_BENCH_ONE_DEVICE=1 let the N>1 code path be exercised on a 1-GPU box
@@ -244,15 +394,23 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     if world > 1:
+        port = int(os.environ.get("MASTER_PORT", "29500")) + 1 + int(args.worker or 0)
+        kw = dict(init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", device_id=device, **kw)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, **kw)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("--gpus %d but the process group has %d ranks" % (args.gpus, dist.get_world_size()))
 
     from m3t.workloads import AVFeatureGraph, make_c3_step
     from m3t import ops
 
     B, T, d_a, d_v = args.batch, args.frames, 128, 256
+    if args.scaling == "strong":
+        if args.batch % world:
+            raise SystemExit("--scaling strong: --batch %d is not divisible by %d GPUs" % (args.batch, world))
+        B = args.batch // world                    # the global batch is fixed, each GPU gets 1/N of it
     torch.manual_seed(12345)                       # identical replicas on every rank
     model = AVFeatureGraph(d_a, d_v, 512).to(device)
     n_params = sum(p.numel() for p in model.parameters())
@@ -280,6 +438,7 @@ def main():
     # pair per launch costs the step 0.8 ms (4 %) when every launch of every step carries one -- measured, M3T_BENCH_EVENTS=1
     events_every = max(1, int(os.environ.get("M3T_BENCH_EVENTS", "4")))
     timed_steps = 0
+    ar_events = []
     step_marks = [] if os.environ.get("M3T_BENCH_STEP_TIMES") == "1" else None      # debugging: per-step GPU time on stderr
     host_marks = []
     # Python's cyclic collector: a generation-2 pass over the heap of this process (torch + numpy + distributed) stops the host
@@ -294,12 +453,17 @@ def main():
     for i in range(args.steps):
         ops.PROFILE_ON[0] = i % events_every == 0
         timed_steps += int(ops.PROFILE_ON[0])
+        if world > 1:
+            # N > 1: an event pair around the in-step gradient all-reduce (poison kernel, collective, dead-rank check) on the
+            # profiled steps: `allreduce.ms_in_step` is what the collective costs INSIDE the step, on the step's own stream
+            ddp.ar_events = ar_events if ops.PROFILE_ON[0] else None
         loss = step()
         if step_marks is not None:
             step_marks.append(torch.cuda.Event(enable_timing=True))
             step_marks[-1].record()
             host_marks.append(time.perf_counter())
     ops.PROFILE_ON[0] = False
+    ddp.ar_events = None
     host_ms = (time.perf_counter() - t0) / args.steps * 1e3      # host time to ENQUEUE a step (no sync inside the loop)
     fence()
     dt = time.perf_counter() - t0
@@ -315,18 +479,22 @@ def main():
     if world > 1:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for _ in range(2):
-            dist.all_reduce(ddp.flat, op=dist.ReduceOp.SUM)
+            dist.all_reduce(ddp._buf, op=dist.ReduceOp.SUM)
         fence()
         reps = 10
         ev0.record()
         for _ in range(reps):
-            dist.all_reduce(ddp.flat, op=dist.ReduceOp.SUM)
+            dist.all_reduce(ddp._buf, op=dist.ReduceOp.SUM)
         ev1.record()
         torch.cuda.synchronize()
         ar_ms = ev0.elapsed_time(ev1) / reps
-        nbytes = ddp.flat.numel() * 4
+        nbytes = ddp._buf.numel() * 4
         algbw = nbytes / (ar_ms * 1e-3) / 1e9
-        allreduce = {"bytes": nbytes, "ms": round(ar_ms, 4), "algbw_GBps": round(algbw, 2),
+        in_step = [a.elapsed_time(b) for a, b in ar_events]
+        allreduce = {"bytes": nbytes, "ms": round(ar_ms, 4),
+                     "ms_in_step": round(sum(in_step) / len(in_step), 4) if in_step else None,
+                     "ms_in_step_note": "HIP events on the step's stream around poison kernel + collective(s) + dead-rank check, profiled steps only; "
+                                        "`ms` is the same collective back to back after the timed region", "algbw_GBps": round(algbw, 2),
                      "busbw_GBps": round(algbw * 2 * (world - 1) / world, 2), "world_size": dist.get_world_size(),
                      "schedule": "one all-reduce of the flat buffer after backward" if not ddp.overlap else "3 buckets overlapped with backward",
                      "xgmi_peak_GBps": 7 * 153.0}
@@ -388,7 +556,7 @@ def main():
         out = {
             "metric": "clips/sec (300-frame A+V, fwd+bwd)", "value": round(clips / dt, 2), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_ms, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32 (GEMMs and the H=256/512 recurrences as bf16x6 products = fp32-accurate, fp32 accumulate; the H=128 scorer scans as fp32 FMA chains on the vector ALUs)",
             "data": "synthetic",
             "config": {"workload": "C3/C4 feature-level A+V att_fusion graph (SURVEY 8(d)): audio GRU(128,256,2) | "
@@ -402,10 +570,14 @@ def main():
             "roofline": roofline,
             "kernels": breakdown,
             "persistent_scan_launches_per_step": persist_per_step,
+            "persistent_scan_owner": ops.persist_owner() == 1,
             "host_enqueue_ms_per_step": round(host_ms, 3),
             "allreduce": allreduce,
             "memory_roofline_frac": round((clips / dt) * 66.15e6 / (HBM_PEAK_GBS * 1e9 * world), 5),
         }
+        if fallback:
+            out["fallback"] = ("launch-per-step scans + gradient buckets overlapped with backward, in fresh worker processes, after: %s"
+                               % fallback)
         out["cpu_baseline"] = None
         if world == 1 and not args.no_cpu_baseline:
             print("# gpu leg done: %.2f clips/s, %.3f ms/step; timing the CPU baseline ..." % (out["value"], step_ms),

@@ -130,14 +130,19 @@ typedef struct {
  * granules); otherwise one launch per time step.  A persistent launch needs all its workgroups resident: never run
  * two of them concurrently on one device (flags = M3T_SCAN_NO_PERSIST for scans issued on a side stream; env
  * M3T_SCAN_PERSIST=0 disables globally).  One process per device: the first process that launches a persistent scan on a
- * GPU takes an advisory lock (/tmp/m3t_persist_<pci-bus-id>.lock, held until it exits); any other process on that GPU
- * silently gets the launch-per-step path (env M3T_SCAN_LOCK=0 disables the guard).
+ * GPU takes an advisory lock ($XDG_RUNTIME_DIR or /tmp/m3t-<uid>/ m3t_persist_<pci-bus-id>.lock, held until it exits); any
+ * other process on that GPU gets the launch-per-step path, says so on stderr, and m3t_gru_persist_owner() returns 2 there
+ * (env M3T_SCAN_LOCK=0 disables the guard).
  * Error model.  Every wait of a persistent scan is bounded (M3T_SCAN_SPIN_LIMIT gather attempts, default 2^21 ~ 2 s).  A
- * workgroup whose wait expires raises a sticky host-visible error word and the scan finishes with INVALID results.  The
- * word is reported by (a) m3t_gru_poll_error() -- call it after synchronising, before results are trusted; (b) the next
- * m3t_gru_scan_* call, which returns M3T_ESPIN; (c) m3t_grad_norm_scale, which reads the word ON THE DEVICE in stream order:
- * it then zeroes the gradient buffer and returns norm = NaN, and m3t_adam_step / m3t_sgd_step skip an update whose
- * `guard` scalar is not finite -- a dead scan can never reach the parameters, with no host synchronisation. */
+ * workgroup whose wait expires raises a STICKY host-mapped flag and the scan finishes with INVALID results.  The flag stays
+ * set until m3t_gru_error_reset(), which the host may call only after it has synchronised the device.  While it is set:
+ * (a) m3t_gru_poll_error() returns non-zero; (b) every m3t_gru_scan_* call returns M3T_ESPIN; (c) m3t_grad_norm_scale, which
+ * reads the flag ON THE DEVICE in stream order, zeroes the gradient buffer and returns norm = NaN, and m3t_adam_step /
+ * m3t_sgd_step skip an update whose `guard` scalar is not finite.  Because the host never clears the flag on a read, every
+ * step queued behind the dead scan is skipped however far ahead of the GPU the host runs: a dead scan can never reach the
+ * parameters, with no host synchronisation.  Recovery = synchronise, m3t_gru_error_reset(), redo the step.
+ * Several ranks: m3t_grad_poison / m3t_grad_dead_check (below) carry the failure of one rank through the gradient
+ * all-reduce to every rank. */
 int m3t_gru_scan_fwd(const m3t_gru_fwd_desc* scans, int n_scans, int B, int T,
                      float* ws, size_t ws_bytes, int flags, void* stream);
 
@@ -163,9 +168,17 @@ typedef struct {
 
 /* Number of one-launch scans (persistent or solo) this process has issued so far (tests use it to assert which path ran). */
 int m3t_gru_persist_count(void);
-/* 0, or (step + 1) of a persistent scan that gave up waiting since the last call (reading clears the word).  The word is
- * host-mapped: no synchronisation happens here, so synchronise the scan's stream first if the answer must cover it. */
+/* 0, or (step + 1) of a persistent scan that gave up waiting since the last m3t_gru_error_reset() (sticky: reading does
+ * NOT clear it).  The words are host-mapped: no synchronisation happens here, so synchronise the scan's stream first if the
+ * answer must cover it. */
 int m3t_gru_poll_error(void);
+/* Clears the scan error state.  ONLY after the device has been synchronised (nothing queued may still read the flag). */
+int m3t_gru_error_reset(void);
+/* Fault injection (tests): a one-thread kernel on `stream` raises the scan error flag exactly as a dying scan would. */
+int m3t_gru_inject_error(void* stream);
+/* Who owns the persistent scans of the current device: 0 not decided yet (no persistent scan attempted), 1 this process,
+ * 2 another process (this one runs the launch-per-step kernels). */
+int m3t_gru_persist_owner(void);
 /* Exchange arena (optional, speed only).  A persistent scan exchanges h_t / dgh_t between workgroups through tagged granules
  * and must never meet a stale granule whose tag matches; without an arena every launch therefore zeroes its exchange buffers
  * (3-4 fill kernels in front of every scan).  m3t_gru_scan_arena(arena, bytes): the NEXT m3t_gru_scan_fwd / _bwd call of the
@@ -338,6 +351,14 @@ int m3t_cbam_spatial_bwd(const float* dy, const float* x, const float* conv_w, c
  * (1/world) * min(1, max_norm/(norm+1e-6)).  norm_out[0] = total norm (pre-clip). */
 int m3t_grad_norm_scale(float* flat, size_t n, float inv_world, float max_norm,
                         float* norm_out, float* ws, size_t ws_bytes, void* stream);
+/* One rank's dead scan must stop every rank: the all-reduce would otherwise spread its garbage while only the failing
+ * rank's guard fires.  m3t_grad_poison, BEFORE the all-reduce: if this process's scan error flag is set, flat[0] = NaN (SUM
+ * carries it to every rank: every clip norm is NaN, every fused optimizer step skips) and dead[0] = 1, else dead[0] = 0
+ * (`dead`: one float of padding that rides in the same all-reduce; NULL = skip).  m3t_grad_dead_check, AFTER the
+ * all-reduce: dead[0] != 0 raises this process's scan error flag as well, so every rank's next poll reports the failure
+ * (a healthy rank would otherwise wait in its next collective for the rank that raised).  One thread each, stream-ordered. */
+int m3t_grad_poison(float* flat, float* dead, void* stream);
+int m3t_grad_dead_check(const float* dead, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * Optimizer steps over the flat parameter / gradient buffers (reference

@@ -493,3 +493,38 @@ extern "C" int m3t_grad_norm_scale(float* flat, size_t n, float inv_world, float
     M3T_LAUNCH_CHECK();
     return 0;
 }
+
+// ---- a dead scan on ONE rank must stop EVERY rank (the all-reduce spreads its garbage) --------------------------------
+// m3t_grad_poison runs BEFORE the gradient all-reduce: if this process's sticky scan-error flag is set it writes NaN into
+// flat[0] (SUM carries it to every rank: every rank's clip norm is NaN, every fused optimizer step skips itself) and 1 into
+// the `dead` slot -- one float of padding that rides in the same all-reduce.  m3t_grad_dead_check runs AFTER the
+// all-reduce: a non-zero slot (some rank died) raises THIS process's sticky flag too, so every rank's next host poll raises
+// instead of the healthy ranks blocking in the next collective until its timeout.  One thread each, no synchronisation.
+namespace {
+__global__ void grad_poison_kernel(float* flat, float* dead, const unsigned* sticky) {
+    const bool bad = sticky && __hip_atomic_load(sticky, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
+    if (bad) flat[0] = __builtin_nanf("");
+    if (dead) dead[0] = bad ? 1.f : 0.f;
+}
+__global__ void grad_dead_check_kernel(const float* dead, unsigned* sticky) {
+    if (dead[0] != 0.f) {                    // (NaN compares unequal to zero as well)
+        __hip_atomic_store(sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+}  // namespace
+
+extern "C" int m3t_grad_poison(float* flat, float* dead, void* stream) {
+    if (!flat) return M3T_EINVAL;
+    grad_poison_kernel<<<1, 1, 0, (hipStream_t)stream>>>(flat, dead, m3t_gru::persist_error_word_dev());
+    M3T_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int m3t_grad_dead_check(const float* dead, void* stream) {
+    if (!dead) return M3T_EINVAL;
+    unsigned* sticky = m3t_gru::persist_error_word_dev(true);
+    if (!sticky) return M3T_EINVAL;
+    grad_dead_check_kernel<<<1, 1, 0, (hipStream_t)stream>>>(dead, sticky);
+    M3T_LAUNCH_CHECK();
+    return 0;
+}

@@ -93,8 +93,11 @@ void persist_set_arena(void* arena, size_t bytes);
 void persist_drop_arena();
 void persist_forget_arena(void* arena);
 struct AfterGuard { ~AfterGuard() { persist_drop_after(); persist_drop_events(); persist_drop_arena(); } };
-int persist_poll_error();       // step+1 of a scan that hit its spin limit since the last poll, else 0
-const unsigned* persist_error_word_dev();   // device address of the (host-mapped) error word, or nullptr before the first persistent scan
+int persist_poll_error();       // step+1 of a scan that hit its spin limit since the last persist_reset_error(), else 0 (sticky)
+void persist_reset_error();     // clears the error words; only after the device has been synchronised
+int persist_inject_error(hipStream_t s);      // fault injection: raises the error words from a kernel, in stream order
+unsigned* persist_error_word_dev(bool create = false);   // device address of the STICKY flag word (host-mapped), or nullptr before the first persistent scan
+int persist_owner_state();      // 0 not decided yet, 1 this process owns the device's persistent scans, 2 another process does
 bool persist_fwd_check(const FwdGroup& g, int B, int T);
 bool persist_bwd_check(const BwdGroup& g, int B, int T);
 bool persist_fwd_uses_x6(const FwdGroup& g, int B, int T, int flags);   // then wfrag holds bf16x3 fragments (18 H^2 bytes), filled by the launch itself

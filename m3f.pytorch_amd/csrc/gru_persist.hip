@@ -82,8 +82,13 @@ constexpr int POLL_DELAY_INIT = 8, POLL_DELAY_MAX = 64;
         if (stamp) { const long long now = clock64(); psum[i] += now - last; last = now; } \
     } while (0)
 
+// err[0]: step + 1 of the failing wait (for the message); err[1]: the STICKY flag the device-side guards read
+// (m3t_grad_norm_scale, m3t_grad_poison).  Nothing but m3t_gru_error_reset() -- which the host may only call after it has
+// synchronised the device -- ever clears either word, so work queued behind a dead scan sees the flag however far ahead
+// of the GPU the host runs.
 __device__ __forceinline__ void raise_spin(unsigned* err, int step) {
     __hip_atomic_store(err, (unsigned)step + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(err + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Block -> (group, unit block).  A group (one scan x one row block) is the set of workgroups that exchange h_t / dgh_t with each
@@ -1034,24 +1039,66 @@ bool persist_enabled() {
     return on == 1;
 }
 
+// Sticky: the answer stays non-zero until persist_reset_error().  (It used to be an exchange-to-zero; a host that runs a
+// step ahead of the GPU then cleared the word before the finalize kernel of the failed step had read it on the device.)
 int persist_poll_error() {
     if (!g_err_host) return 0;
-    return (int)__atomic_exchange_n(g_err_host, 0u, __ATOMIC_RELAXED);
+    if (__atomic_load_n(g_err_host + 1, __ATOMIC_RELAXED) == 0u) return 0;
+    const unsigned step1 = __atomic_load_n(g_err_host, __ATOMIC_RELAXED);
+    return (int)(step1 ? step1 : 1u);
 }
 
-const unsigned* persist_error_word_dev() { return g_err_dev; }
+// the caller has synchronised the device: nothing queued can still read or write the words
+void persist_reset_error() {
+    if (!g_err_host) return;
+    __atomic_store_n(g_err_host, 0u, __ATOMIC_RELAXED);
+    __atomic_store_n(g_err_host + 1, 0u, __ATOMIC_RELAXED);
+}
+
+// device address of the sticky flag (create = allocate the host-mapped words if no persistent scan has run yet)
+unsigned* persist_error_word_dev(bool create) {
+    if (create && !ensure_err_word()) return nullptr;
+    return g_err_dev ? g_err_dev + 1 : nullptr;
+}
+
+__global__ void inject_error_kernel(unsigned* err) { raise_spin(err, 0); }
+
+int persist_inject_error(hipStream_t s) {
+    if (!ensure_err_word()) return M3T_EINVAL;
+    inject_error_kernel<<<1, 1, 0, s>>>(g_err_dev);
+    M3T_LAUNCH_CHECK();
+    return 0;
+}
 
 // Single owner per GPU.  A persistent launch needs its whole grid resident, so two processes that both run persistent
 // scans on one device can each hold part of the chip while waiting for the rest (both would spin to the limit and fail
-// with M3T_ESPIN).  The first process to get here takes an exclusive advisory lock on /tmp/m3t_persist_<pci-bus-id>.lock
+// with M3T_ESPIN).  The first process to get here takes an exclusive advisory lock on <dir>/m3t_persist_<pci-bus-id>.lock
 // and keeps it for its lifetime; any other process on that device falls back to the launch-per-step scans (same results,
-// no residency requirement).  M3T_SCAN_LOCK=0 turns the guard off (e.g. a parent that holds the lock but is idle while
-// its child runs).  If the lock file cannot be opened at all the guard stands down rather than disable the fast path.
+// no residency requirement).  <dir> is $XDG_RUNTIME_DIR when that is a directory owned by this user, else
+// /tmp/m3t-<uid> (created 0700; refused if it is a symlink, not ours, or group/world-accessible).  The file is opened
+// O_NOFOLLOW and must be a regular file of this user -- nothing is chmod-ed.  M3T_SCAN_LOCK=0 turns the guard off (e.g.
+// a parent that holds the lock but is idle while its child runs).  If no usable lock file can be had the guard stands down
+// rather than disable the fast path.  The decision is visible through m3t_gru_persist_owner() (bench.py, Trainer log it).
+static int g_owner_state[64];      // per device: 0 unknown, 1 owner, 2 not the owner
+
+static bool lock_dir(char* out, size_t n) {
+    const uid_t uid = geteuid();
+    struct stat st;
+    const char* xdg = std::getenv("XDG_RUNTIME_DIR");
+    if (xdg && xdg[0] == '/' && lstat(xdg, &st) == 0 && S_ISDIR(st.st_mode) && st.st_uid == uid && (st.st_mode & 077) == 0) {
+        std::snprintf(out, n, "%s", xdg);
+        return true;
+    }
+    std::snprintf(out, n, "/tmp/m3t-%u", (unsigned)uid);
+    if (mkdir(out, 0700) != 0 && errno != EEXIST) return false;
+    return lstat(out, &st) == 0 && S_ISDIR(st.st_mode) && st.st_uid == uid && (st.st_mode & 077) == 0;
+}
+
 bool persist_owner() {
-    static int state[64];      // per device: 0 unknown, 1 owner, 2 not the owner
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return true; }
     if (dev < 0 || dev >= 64) return true;
+    int* state = g_owner_state;
     if (state[dev]) return state[dev] == 1;
     const char* e = std::getenv("M3T_SCAN_LOCK");
     if (e && e[0] == '0') { state[dev] = 1; return true; }
@@ -1059,17 +1106,25 @@ bool persist_owner() {
     if (hipDeviceGetPCIBusId(bus, sizeof(bus) - 1, dev) != hipSuccess) { (void)hipGetLastError(); std::snprintf(bus, sizeof(bus), "dev%d", dev); }
     for (char* c = bus; *c; ++c)
         if (*c == ':' || *c == '/') *c = '_';
-    char path[160];
-    std::snprintf(path, sizeof(path), "/tmp/m3t_persist_%s.lock", bus);
-    const int fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+    char dir[128], path[256];
+    if (!lock_dir(dir, sizeof(dir))) { state[dev] = 1; return true; }
+    std::snprintf(path, sizeof(path), "%s/m3t_persist_%s.lock", dir, bus);
+    const int fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC | O_NOFOLLOW, 0600);
     if (fd < 0) { state[dev] = 1; return true; }
-    (void)fchmod(fd, 0666);
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_uid != geteuid()) { close(fd); state[dev] = 1; return true; }
     if (flock(fd, LOCK_EX | LOCK_NB) == 0) { state[dev] = 1; return true; }      // fd stays open: the lock lives as long as the process
     close(fd);
     state[dev] = 2;
     std::fprintf(stderr, "m3t: another process owns the persistent GRU scans of GPU %s (%s); this process uses the "
-                         "launch-per-step scans\n", bus, path);
+                         "launch-per-step scans (several times slower; m3t_gru_persist_owner() == 2)\n", bus, path);
     return false;
+}
+
+int persist_owner_state() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return (dev >= 0 && dev < 64) ? g_owner_state[dev] : 0;
 }
 
 size_t persist_exchange_bytes(int H, int B, bool backward) {
@@ -1255,6 +1310,12 @@ int persist_profile(unsigned long long* out6) {
 extern "C" int m3t_gru_persist_count(void) { return m3t_gru::persist_launch_count(); }
 
 extern "C" int m3t_gru_poll_error(void) { return m3t_gru::persist_poll_error(); }
+
+extern "C" int m3t_gru_error_reset(void) { m3t_gru::persist_reset_error(); return 0; }
+
+extern "C" int m3t_gru_inject_error(void* stream) { return m3t_gru::persist_inject_error((hipStream_t)stream); }
+
+extern "C" int m3t_gru_persist_owner(void) { return m3t_gru::persist_owner_state(); }
 
 extern "C" int m3t_gru_scan_events(void* start, void* end) {
     m3t_gru::persist_set_events((hipEvent_t)start, (hipEvent_t)end);

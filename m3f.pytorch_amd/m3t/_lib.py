@@ -49,6 +49,9 @@ SIGNATURES = {
     "m3t_gru_scan_bwd": [C.POINTER(GruBwdDesc), _i, _i, _i, _f, _z, _i, _s],
     "m3t_gru_persist_count": [],
     "m3t_gru_poll_error": [],
+    "m3t_gru_error_reset": [],
+    "m3t_gru_inject_error": [_s],
+    "m3t_gru_persist_owner": [],
     "m3t_gru_scan_arena": [C.c_void_p, _z],
     "m3t_gru_scan_arena_reset": [C.c_void_p],
     "m3t_gru_scan_after": [C.c_void_p],
@@ -82,6 +85,8 @@ SIGNATURES = {
     "m3t_power_to_db": [_f, C.c_longlong, C.c_float, C.c_float, _f, _f, _z, _s],
     "m3t_stack_context": [_f, C.c_longlong, _i, C.c_longlong, _i, _i, _i, _f, _s],
     "m3t_grad_norm_scale": [_f, _z, C.c_float, C.c_float, _f, _f, _z, _s],
+    "m3t_grad_poison": [_f, _f, _s],
+    "m3t_grad_dead_check": [_f, _s],
     "m3t_adam_step": [_f, _f, _f, _f, _z, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _i, _f, _s],
     "m3t_sgd_step": [_f, _f, _f, _z, C.c_float, C.c_float, C.c_float, _i, _f, _s],
 }
@@ -116,19 +121,37 @@ def load():
     return lib
 
 
+def _recover_scan_error():
+    """The error state is sticky on purpose (include/m3t_hip.h, error model): everything queued behind a dead scan must still
+    see it on the device.  So: wait for the device -- every step queued so far has then been skipped by its own guard --
+    and only then clear the state, just before the failure is raised to the caller (who may redo the step)."""
+    import torch
+    if torch.cuda.is_available() and torch.cuda.is_initialized():
+        try:
+            torch.cuda.synchronize()
+        except Exception:  # noqa: BLE001  (a device in an error state: the raise below still tells the caller)
+            pass
+    _lib.m3t_gru_error_reset()
+
+
 def check(rc, what):
     if rc != 0:
         note = {M3T_EINVAL: " (M3T_EINVAL: bad arguments)",
                 M3T_ESPIN: " (M3T_ESPIN: an earlier persistent GRU scan gave up waiting for a peer workgroup; its results are invalid)"}
+        if rc == M3T_ESPIN and _lib is not None:
+            _recover_scan_error()
         raise M3THipError("%s failed with code %d%s" % (what, rc, note.get(rc, " (hipError_t)")))
 
 
 def poll_scan_error(what="persistent GRU scan"):
-    """Raise M3THipError if a persistent scan has hit its spin limit since the last poll (include/m3t_hip.h, error model).
-    No synchronisation happens here: synchronise first when the answer must cover work still in flight."""
+    """Raise M3THipError if a persistent scan has hit its spin limit (include/m3t_hip.h, error model).  No synchronisation
+    happens on the healthy path: synchronise first when the answer must cover work still in flight.  On a failure the
+    device is synchronised and the (sticky) error state cleared before the exception leaves."""
     if _lib is None:
         return
     step = _lib.m3t_gru_poll_error()
     if step:
+        _recover_scan_error()
         raise M3THipError("%s: a workgroup gave up waiting for its peers at step %d (M3T_ESPIN); outputs and gradients of "
-                          "that scan are invalid -- is another process running persistent scans on this GPU?" % (what, step - 1))
+                          "that scan are invalid, every optimizer step queued behind it was skipped on the device -- is another "
+                          "process running persistent scans on this GPU?" % (what, step - 1))

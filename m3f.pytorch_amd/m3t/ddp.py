@@ -15,6 +15,11 @@ instead of one each.  Two schedules:
     sub-modules, and each bucket's all-reduce is issued from a post-accumulate hook so it overlaps the rest of backward.
 The 1/world scaling and the clip coefficient are applied by one fused HIP pass (m3t_grad_norm_scale).  There is no
 other collective on the path (no SyncBN, as the reference).
+
+A dead persistent scan on ONE rank stops EVERY rank: the buffer carries one extra slot (`dead`) through the same
+all-reduce; m3t_grad_poison sets it (and NaN in flat[0]) before the collective when this rank's sticky scan-error flag is
+up, m3t_grad_dead_check raises the flag on every rank after it, so every rank's finalize zeroes its gradients, every fused
+optimizer step skips itself and every rank's next poll raises (include/m3t_hip.h, error model).
 """
 import os
 import torch
@@ -32,7 +37,7 @@ def shard_indices(n_items, rank, world_size):
 
 class FlatGradDDP:
     def __init__(self, module, bucket_order=None, max_norm=1.0, process_group=None, finalize=None,
-                 flatten_params=False, overlap=None):
+                 flatten_params=False, overlap=None, collective_when_alone=False):
         """bucket_order: list of lists of parameters, in the order backward completes them
         (default: one bucket per top-level child, reversed registration order).
         finalize(flat, world_size, max_norm) -> norm tensor; default = fused HIP kernel."""
@@ -41,6 +46,9 @@ class FlatGradDDP:
         self.max_norm = max_norm
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        # collective_when_alone: issue the all-reduce even in a 1-rank group (a 1-GPU box can then run the real RCCL call,
+        # on the real backend, in stream order between persistent scans -- tests/test_gpu_ddp.py)
+        self._alone_collective = bool(collective_when_alone) and self.world == 1 and dist.is_available() and dist.is_initialized()
         if self.world > 1:
             # replicas must start identical: torch DDP (what Lightning's 'ddp' wraps the reference in, train.py:40)
             # broadcasts rank 0's parameters and buffers at construction; so does this.  Frozen parameters and buffers
@@ -75,7 +83,11 @@ class FlatGradDDP:
                 self.offsets[id(p)] = off
                 off = pad(off + p.numel())
         n = off
-        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        # [ gradients (n floats, 128-B aligned slices) | dead slot (1 float + padding) ]: ONE buffer, so that the slot rides
+        # in the same all-reduce; self.flat is the gradient part (what norms, optimizers and tests see)
+        self._buf = torch.zeros(n + 32, dtype=torch.float32, device=dev)
+        self.flat = self._buf[:n]
+        self.dead = self._buf[n:n + 1]
         self.ranges = []
         self._pending = []
         for bi, b in enumerate(self.buckets):
@@ -107,14 +119,27 @@ class FlatGradDDP:
             finalize = ops.grad_norm_scale_
         self._finalize = finalize
         self.last_norm = None
+        self.ar_events = None          # bench.py: a list here collects (start, end) HIP events around the in-step all-reduce
         # gradient sinks (m3t.ops): backward writes weight gradients straight into the flat buffer instead of handing
         # them to autograd's AccumulateGrad.  Not with overlap=True: the bucket all-reduces hang on post-accumulate hooks.
         self.sinks = (not self.overlap or self.world == 1) and os.environ.get("M3T_GRAD_SINKS", "1") != "0"
-        ops.clear_grad_sinks()
+        # the registry is keyed by parameter and tagged with its owner: a second FlatGradDDP in the process (EMA teacher,
+        # another trainer) neither disarms nor clears this one's sinks
         if self.sinks:
             for b in self.buckets:
                 for p in b:
-                    ops.register_grad_sink(p, p.grad)
+                    ops.register_grad_sink(p, p.grad, owner=self)
+
+    def close(self):
+        """drop this instance's gradient sinks (the parameters keep their .grad views)"""
+        from . import ops
+        ops.clear_grad_sinks(self)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
 
     def broadcast_state(self, src=0):
         """rank `src`'s parameters and buffers to every rank (construction, and after a checkpoint is loaded on one rank)"""
@@ -133,10 +158,10 @@ class FlatGradDDP:
         return hook
 
     def zero_grad(self):
-        self.flat.zero_()                     # one 106 MB memset (~30 us): parameters nothing writes this step read zero
+        self._buf.zero_()                     # one 106 MB memset (~30 us): parameters nothing writes this step read zero
         if self.sinks:
             from . import ops
-            ops.arm_grad_sinks()              # the first gradient of a parameter this step overwrites its slice in place
+            ops.arm_grad_sinks(self)          # the first gradient of a parameter this step overwrites its slice in place
         self._left = [len(b) for b in self.buckets]
         self._handles = []
 
@@ -144,8 +169,19 @@ class FlatGradDDP:
         """Call after backward: waits for the bucket all-reduces, then averages + clips in place."""
         from . import ops
         ops.join_wgrad(self.flat.device)          # weight-gradient GEMMs that write straight into the flat buffer
+        hip = self.flat.is_cuda
+        timed = self.ar_events is not None and hip
+        if timed:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        if self._alone_collective:
+            ops.grad_poison_(self.flat, self.dead)
+            dist.all_reduce(self._buf, op=dist.ReduceOp.SUM, group=self.pg)
+            ops.grad_dead_check_(self.dead)
+        if self.world > 1 and hip:
+            ops.grad_poison_(self.flat, self.dead)          # this rank's dead scan -> NaN in flat[0], 1 in the dead slot
         if self.world > 1 and not self.overlap:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.pg)
+            dist.all_reduce(self._buf, op=dist.ReduceOp.SUM, group=self.pg)      # gradients + dead slot: ONE collective
         elif self.world > 1:
             for bi, left in enumerate(self._left):      # parameters that received no gradient this step
                 if left > 0:
@@ -153,6 +189,13 @@ class FlatGradDDP:
                     self._handles.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
             for h in self._handles:
                 h.wait()
+            # (the bucket that holds flat[0] may have left before the scan died: the dead slot travels on its own here)
+            dist.all_reduce(self._buf[self.flat.numel():], op=dist.ReduceOp.SUM, group=self.pg)
+        if self.world > 1 and hip:
+            ops.grad_dead_check_(self.dead)                 # any rank dead -> this rank's flag up: finalize zeroes, norm = NaN
+        if timed:
+            ev1.record()
+            self.ar_events.append((ev0, ev1))
         self.last_norm = self._finalize(self.flat, self.world, self.max_norm)
         # a persistent GRU scan that died leaves garbage gradients.  Two nets: the finalize kernel reads the scan error
         # word on the device, in stream order (gradients zeroed, norm = NaN, the fused optimizer steps skip on a

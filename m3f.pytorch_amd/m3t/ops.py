@@ -27,20 +27,28 @@ PROFILE = []
 # grads to None gets the ordinary path).  Armed per step by FlatGradDDP.zero_grad(), after it has zeroed the buffer.
 import weakref
 
-_GRAD_SINKS = {}            # id(parameter) -> [weakref(parameter), view, armed]
+_GRAD_SINKS = {}            # id(parameter) -> [weakref(parameter), view, armed, id(owner)]
 
 
-def register_grad_sink(param, view):
-    _GRAD_SINKS[id(param)] = [weakref.ref(param), view, False]
+def register_grad_sink(param, view, owner=None):
+    """owner: the FlatGradDDP instance the view belongs to.  Several owners coexist (a student and an EMA teacher, two
+    trainers in one process): each arms and clears only its own entries."""
+    _GRAD_SINKS[id(param)] = [weakref.ref(param), view, False, id(owner) if owner is not None else None]
 
 
-def clear_grad_sinks():
-    _GRAD_SINKS.clear()
+def clear_grad_sinks(owner=None):
+    """owner=None: every sink of the process; else only that owner's"""
+    if owner is None:
+        _GRAD_SINKS.clear()
+        return
+    for k in [k for k, e in _GRAD_SINKS.items() if e[3] == id(owner)]:
+        del _GRAD_SINKS[k]
 
 
-def arm_grad_sinks():
+def arm_grad_sinks(owner=None):
     for e in _GRAD_SINKS.values():
-        e[2] = True
+        if owner is None or e[3] == id(owner):
+            e[2] = True
 
 
 def _take_sink(param):
@@ -391,11 +399,33 @@ def _scan_flags(device):
 
 
 def poll_scan_error(sync=False):
-    """raise M3THipError if a persistent scan has died since the last poll (sync=True: wait for the device first, so the
-    answer covers everything issued so far)"""
-    if sync:
+    """raise M3THipError if a persistent scan has died (sync=True: wait for the device first, so the answer covers everything
+    issued so far).  The error state is sticky on the device (every optimizer step queued behind the dead scan skips itself,
+    include/m3t_hip.h); raising synchronises and clears it, so the caller can redo the step."""
+    if sync and torch.cuda.is_available():
         torch.cuda.synchronize()
     _lib.poll_scan_error()
+
+
+def inject_scan_error():
+    """fault injection (tests): raise the scan error flag from a kernel on the current stream, as a dying scan would"""
+    _lib.check(lib().m3t_gru_inject_error(_stream()), "m3t_gru_inject_error")
+
+
+def persist_owner():
+    """0: no persistent scan attempted yet on this device, 1: this process owns them, 2: another process does (this one runs
+    the launch-per-step kernels, several times slower)"""
+    return int(lib().m3t_gru_persist_owner())
+
+
+def grad_poison_(flat, dead):
+    """before the gradient all-reduce: a dead scan of THIS rank poisons flat[0] (NaN) and sets dead[0] (include/m3t_hip.h)"""
+    _lib.check(lib().m3t_grad_poison(_p(flat), _p(dead), _stream()), "m3t_grad_poison")
+
+
+def grad_dead_check_(dead):
+    """after the all-reduce: a non-zero dead[0] (some rank died) raises this rank's scan error flag as well"""
+    _lib.check(lib().m3t_grad_dead_check(_p(dead), _stream()), "m3t_grad_dead_check")
 
 
 _DEFER_FENCE = os.environ.get("M3T_SCAN_DEFER_FENCE", "1") != "0"

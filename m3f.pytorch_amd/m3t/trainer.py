@@ -22,6 +22,7 @@ import gc
 import os
 
 import torch
+import torch.distributed as dist
 
 from . import ops
 from .ddp import FlatGradDDP
@@ -120,8 +121,27 @@ class Trainer:
         res = self.model.validation_end(outputs)
         return res
 
+    # ------------------------------------------------------------------ rank plumbing
+    @property
+    def rank(self):
+        return dist.get_rank(self.ddp.pg) if self.ddp.world > 1 else 0
+
+    def _mean_over_ranks(self, value):
+        """every replica must take the same plateau / best-checkpoint decision: the epoch's val_loss is averaged over the
+        process group first (each rank validates its own shard of the windows)"""
+        if self.ddp.world <= 1 or value is None:
+            return value
+        t = torch.tensor([float(value)], dtype=torch.float64)
+        if dist.get_backend(self.ddp.pg) == "nccl":
+            t = t.to(self.ddp.flat.device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.ddp.pg)
+        return float(t.item()) / self.ddp.world
+
     def end_epoch(self, val_loss=None):
-        """epoch-level schedulers + best-val_loss checkpoint (Lightning: check_val_every_n_epoch=1, ModelCheckpoint on val_loss)"""
+        """epoch-level schedulers + best-val_loss checkpoint (Lightning: check_val_every_n_epoch=1, ModelCheckpoint on val_loss).
+        Under DDP the val_loss is the mean over ranks (identical lr / best decisions on every replica) and only rank 0
+        writes the checkpoint (as Lightning's ModelCheckpoint), behind a barrier for the others."""
+        val_loss = self._mean_over_ranks(val_loss)
         if self.scheduler_name == "exp":
             self._shadow.step()
             self.scheduler.step()
@@ -132,7 +152,8 @@ class Trainer:
         if improved:
             self.best_val_loss = float(val_loss)
             if self.checkpoint_path:
-                os.makedirs(self.checkpoint_path, exist_ok=True)
+                if self.rank == 0:
+                    os.makedirs(self.checkpoint_path, exist_ok=True)
                 self.save_checkpoint(os.path.join(self.checkpoint_path, "best.ckpt"))
         return improved
 
@@ -165,15 +186,23 @@ class Trainer:
 
     # ------------------------------------------------------------------ checkpoints
     def save_checkpoint(self, path):
-        ops.poll_scan_error(sync=True)               # never persist parameters behind an unreported dead scan
-        opt_state = {"t": self.opt.t}
-        for k in ("m", "v", "buf"):
-            if hasattr(self.opt, k):
-                opt_state[k] = getattr(self.opt, k).detach().cpu().clone()
-        torch.save({"state_dict": {k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()},
-                    "global_step": self.global_step, "epoch": self.epoch, "best_val_loss": self.best_val_loss,
-                    "optimizer": opt_state, "shadow_optimizer": self._shadow.state_dict(),
-                    "scheduler": self.scheduler.state_dict() if self.scheduler is not None else None}, path)
+        """Rank 0 writes (to a temporary file, then os.replace: a reader never sees a torn file); the other ranks wait at a
+        barrier so that none of them runs ahead into a load of a checkpoint that is still being written.  Every rank polls
+        the scan error state first: parameters behind an unreported dead scan are never persisted."""
+        ops.poll_scan_error(sync=True)
+        if self.rank == 0:
+            opt_state = {"t": self.opt.t}
+            for k in ("m", "v", "buf"):
+                if hasattr(self.opt, k):
+                    opt_state[k] = getattr(self.opt, k).detach().cpu().clone()
+            tmp = "%s.tmp.%d" % (path, os.getpid())
+            torch.save({"state_dict": {k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()},
+                        "global_step": self.global_step, "epoch": self.epoch, "best_val_loss": self.best_val_loss,
+                        "optimizer": opt_state, "shadow_optimizer": self._shadow.state_dict(),
+                        "scheduler": self.scheduler.state_dict() if self.scheduler is not None else None}, tmp)
+            os.replace(tmp, path)
+        if self.ddp.world > 1:
+            dist.barrier(group=self.ddp.pg)
 
     def load_checkpoint(self, path, strict=True):
         ck = torch.load(path, map_location="cpu")

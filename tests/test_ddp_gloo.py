@@ -191,3 +191,72 @@ def test_trainer_epoch_schedulers_and_freeze_enc_host_logic(tmp_path):
     for e in range(1, 5):
         tr2.end_epoch(None)
         assert abs(tr2.lr - ns.learning_rate * ns.decay_factor ** e) < 1e-12
+
+
+def test_two_flat_ddp_instances_keep_their_own_gradient_sinks():
+    """the gradient-sink registry is per owner: constructing, arming, zeroing or closing a second FlatGradDDP in the process
+    (an EMA teacher, a second trainer) must not disarm or clear the first one's sinks"""
+    from m3t import ops
+    a, b = _net(), _net()
+    da = FlatGradDDP(a, max_norm=0.0, finalize=torch_finalize)
+    n_a = len(list(a.parameters()))
+    mine = lambda d: [e for e in ops._GRAD_SINKS.values() if e[3] == id(d)]
+    assert len(mine(da)) == n_a
+    db = FlatGradDDP(b, max_norm=0.0, finalize=torch_finalize)       # used to clear every sink of the process
+    assert len(mine(da)) == n_a and len(mine(db)) == n_a
+    da.zero_grad()
+    assert all(e[2] for e in mine(da)) and not any(e[2] for e in mine(db))
+    db.zero_grad()
+    assert all(e[2] for e in mine(da)) and all(e[2] for e in mine(db))
+    p0 = next(a.parameters())
+    assert ops._take_sink(p0) is not None and ops._take_sink(p0) is None      # first gradient of the step only
+    db.close()
+    assert len(mine(da)) == n_a and not mine(db)
+    del da
+    import gc
+    gc.collect()
+    assert not any(e[0]() is p0 for e in ops._GRAD_SINKS.values())         # a collected owner takes its sinks with it
+
+
+def _trainer_worker(rank, world, port, ckdir, out_q):
+    import argparse
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from models.model import AffWild2VA
+    from m3t.trainer import Trainer
+    ns = AffWild2VA.add_model_specific_args(argparse.ArgumentParser(add_help=False)).parse_args([])
+    ns.modality, ns.loss, ns.checkpoint_path = "audio", "ccc", ckdir
+    torch.manual_seed(rank)
+    tr = Trainer.from_hparams(AffWild2VA(ns), ns)
+    lrs = []
+    # per-rank validation losses that disagree about "improved" and about the plateau: the mean must decide, on every rank
+    per_rank = [[1.0, 0.8, 1.2, 1.2, 1.2, 1.2, 1.2], [1.0, 1.0, 0.2, 1.2, 1.2, 1.2, 1.2]][rank]
+    improved = []
+    for v in per_rank:
+        improved.append(tr.end_epoch(v))
+        lrs.append(tr.lr)
+    ck = torch.load(os.path.join(ckdir, "best.ckpt"), map_location="cpu")       # behind save_checkpoint's barrier: complete
+    stray = [f for f in os.listdir(ckdir) if f != "best.ckpt"]
+    out_q.put((rank, improved, lrs, tr.best_val_loss, ck["best_val_loss"], ck["epoch"], stray))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_trainer_under_ddp_means_val_loss_and_writes_checkpoints_from_rank0(tmp_path):
+    """Lightning's ModelCheckpoint saves from rank 0 only and the reference's plateau scheduler sees one val_loss; here every
+    rank validates its own shard, so end_epoch all-reduces (mean) the val_loss before the scheduler and the best check, rank 0
+    writes best.ckpt through a temporary file + os.replace, and the others wait at a barrier."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_trainer_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r[0]: r[1:] for r in (q.get(timeout=300) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][0] == res[1][0] == [True, True, True, False, False, False, False]      # means 1.0, 0.9, 0.7, 1.2 ...
+    assert res[0][1] == res[1][1] and res[0][1][-1] < res[0][1][0]                      # same lr trace, plateau fired
+    assert res[0][2] == res[1][2] == 0.7 and res[0][3] == 0.7 and res[0][4] == 3
+    assert res[0][5] == [] and res[1][5] == []                                          # no torn / temporary files left

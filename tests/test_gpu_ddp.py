@@ -59,12 +59,12 @@ def test_gradient_sinks_match_autograd_accumulation():
     b.load_state_dict(a.state_dict())
     x = torch.randn(4, 9, 12, device="cuda:0")
     ddp = FlatGradDDP(a, max_norm=0.0)
-    assert ddp.sinks and len(ops._GRAD_SINKS) == len(list(a.parameters()))
+    assert ddp.sinks and sum(1 for e in ops._GRAD_SINKS.values() if e[3] == id(ddp)) == len(list(a.parameters()))
     for _ in range(3):                                               # stale values of earlier steps must not leak
         ddp.zero_grad()
         a(x).square().mean().backward()
         ddp.finish()
-    assert not any(e[2] for k, e in ops._GRAD_SINKS.items() if e[0]() is not a.unused), "a GRU sink was not used"
+    assert not any(e[2] for k, e in ops._GRAD_SINKS.items() if e[3] == id(ddp) and e[0]() is not a.unused), "a GRU sink was not used"
     b(x).square().mean().backward()
     for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
         if q.grad is None:
@@ -215,3 +215,134 @@ def test_two_ranks_gru_sinks_hip_finalize_equal_mean_of_shard_gradients(tmp_path
     assert norm > 0.05, "the clip must be active in this case"
     assert abs(float(np.load(out + ".norm0.npy")[0]) - norm) <= 1e-5 * norm
     assert float(np.abs(g0 - ref).max()) <= 2e-6 * max(1.0, float(np.abs(ref).max())), float(np.abs(g0 - ref).max())
+
+
+_FAULT_CHILD = r"""
+import os, sys
+for p in (%r, %r, %r):
+    sys.path.insert(0, p)
+import numpy as np, torch, torch.distributed as dist
+from golden.recipe import fill_module
+from m3t.ddp import FlatGradDDP, shard_indices
+from m3t.optim import FlatAdam
+from m3t import ops, _lib
+from models.rnn import GRU
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+net = fill_module(GRU(12, 16, 2, 3, 2), 5).to("cuda:0")
+ddp = FlatGradDDP(net, max_norm=1.0, overlap=(os.environ["FAULT_OVERLAP"] == "1"), flatten_params=True)
+opt = FlatAdam(ddp, lr=1e-2)
+rs = np.random.RandomState(3)
+x = torch.from_numpy(rs.standard_normal((8, 9, 12)).astype(np.float32)).to("cuda:0")
+t = torch.from_numpy(rs.standard_normal((8, 9, 3)).astype(np.float32)).to("cuda:0")
+idx = shard_indices(8, rank, world)
+
+def step(inject=False):
+    ddp.zero_grad()
+    ((net(x[idx]) - t[idx]) ** 2).mean().backward()
+    if inject:
+        ops.inject_scan_error()              # "a scan of THIS rank died during backward" (stream order)
+    norm = ddp.finish()
+    opt.step()
+    return norm
+
+step()
+torch.cuda.synchronize()
+p1 = ddp.flat_params.clone()
+raised, norm = False, None
+try:
+    norm = step(inject=(rank == 1))          # only rank 1 fails
+    step()                                   # and one more step queued behind it on every rank
+except _lib.M3THipError:
+    raised = True
+if not raised:
+    try:
+        ops.poll_scan_error(sync=True)
+    except _lib.M3THipError:
+        raised = True
+torch.cuda.synchronize()
+same = bool(torch.equal(p1, ddp.flat_params))
+nan_norm = norm is None or not bool(torch.isfinite(norm).all())
+print("RANK %%d raised=%%s params_unchanged=%%s nan_norm=%%s" %% (rank, raised, same, nan_norm), flush=True)
+assert raised and same and nan_norm
+dist.barrier()
+step()                                       # every rank cleared its state when it raised: the job trains on
+torch.cuda.synchronize()
+ops.poll_scan_error()
+assert not torch.equal(p1, ddp.flat_params)
+np.save(sys.argv[1] + ".%%d.npy" %% rank, ddp.flat_params.cpu().numpy())
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_one_ranks_dead_scan_stops_every_rank(tmp_path, overlap):
+    """the all-reduce spreads a dead rank's garbage to every rank, but only the dead rank's guard used to fire.
+    m3t_grad_poison / m3t_grad_dead_check carry the failure through the collective: EVERY rank's finalize sees a raised
+    flag (gradients zeroed, norm NaN, fused Adam skipped), EVERY rank raises at its next poll, nobody is left waiting in a
+    collective, and the replicas are still identical afterwards.  Two ranks on cuda:0 over gloo; the fault is injected by
+    a kernel on rank 1 only (m3t_gru_inject_error)."""
+    import os
+    import subprocess
+    import sys
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "child.py"
+    script.write_text(_FAULT_CHILD % (os.path.join(root, "m3f.pytorch_amd"), os.path.join(root, "tests"), root))
+    out = str(tmp_path / "p")
+    env = dict(os.environ, M3T_SCAN_PERSIST="0", FAULT_OVERLAP=overlap)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29535", str(script), out]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-2500:])
+    assert "RANK 0 raised=True params_unchanged=True nan_norm=True" in r.stdout
+    assert "RANK 1 raised=True params_unchanged=True nan_norm=True" in r.stdout
+    assert np.array_equal(np.load(out + ".0.npy"), np.load(out + ".1.npy")), "replicas diverged after the fault"
+
+
+def test_rccl_allreduce_in_stream_order_between_persistent_scans():
+    """The 8-GPU default is persistent scans + RCCL (backend 'nccl') + ONE all-reduce after backward.  A 1-GPU box cannot
+    host two RCCL ranks, but it can run that exact sequence in a 1-rank RCCL group: the real ncclAllReduce kernel on the
+    real backend, queued between the persistent scans of consecutive steps (collective_when_alone=True), with the poison /
+    dead-check kernels around it.  Results must equal the run without the collective, no scan may spin out, and the
+    persistent path must really have run."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import os, sys
+for p in (%r, %r, %r):
+    sys.path.insert(0, p)
+import numpy as np, torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29537", RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+from m3t import ops, _lib
+from m3t.workloads import AVFeatureGraph, make_c3_step
+from golden.recipe import fill_module
+sys.path.insert(0, %r)
+from bench import synth_batch
+B, T = 16, 48
+res = []
+for alone in (False, True):
+    m = fill_module(AVFeatureGraph(128, 256, 512), 7).to("cuda:0")
+    ddp, step = make_c3_step(m, synth_batch(B, T, 128, 256, torch.device("cuda", 0), 0), max_norm=1.0, collective_when_alone=alone)
+    n0 = _lib.load().m3t_gru_persist_count()
+    for _ in range(4):
+        loss, _, y = step()
+    torch.cuda.synchronize()
+    ops.poll_scan_error()
+    assert _lib.load().m3t_gru_persist_count() - n0 == 4 * 14, "the persistent scans did not run"
+    res.append((float(loss), float(ddp.last_norm), ddp.flat.clone()))
+    ddp.close()
+assert res[0][0] == res[1][0] and res[0][1] == res[1][1] and torch.equal(res[0][2], res[1][2]), (res[0][:2], res[1][:2])
+print("RCCL-BETWEEN-SCANS-OK owner=%%d" %% ops.persist_owner(), flush=True)
+dist.destroy_process_group()
+""" % (os.path.join(root, "m3f.pytorch_amd"), os.path.join(root, "tests"), root, root)
+    env = dict(os.environ, M3T_SCAN_LOCK="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2500:])
+    assert "RCCL-BETWEEN-SCANS-OK" in r.stdout

@@ -149,8 +149,71 @@ print("PARAMETERS-INTACT", flush=True)
     assert "PARAMETERS-INTACT" in out.stdout
 
 
+def test_unsynchronised_steps_behind_a_dead_scan_are_all_skipped():
+    """the host runs a step or more ahead of the GPU, so the step whose scan died has its optimizer kernel queued
+    long before the failure is visible.  The error flag is sticky on the device -- no host read clears it -- so that step AND
+    every step queued behind it skip themselves; the first host poll that sees the flag synchronises, clears it and raises;
+    after that the loop trains again.  Nothing here synchronises between the faulted step and the raise."""
+    code = r"""
+import argparse
+from models.model import AffWild2VA
+from m3t.trainer import Trainer
+ns = AffWild2VA.add_model_specific_args(argparse.ArgumentParser(add_help=False)).parse_args([])
+ns.modality, ns.loss, ns.learning_rate, ns.scheduler = "audio", "ccc_mtl", 1e-3, "none"
+torch.manual_seed(1)
+model = AffWild2VA(ns).to("cuda:0")
+tr = Trainer.from_hparams(model, ns)
+rs = np.random.RandomState(0)
+f = lambda a: torch.from_numpy(a).to("cuda:0")
+B, T = 8, 40
+batch = {"audio": f(rs.standard_normal((B, T, 200)).astype(np.float32)),
+         "label_valence": f(rs.uniform(-1, 1, (B, T)).astype(np.float32)), "label_arousal": f(rs.uniform(-1, 1, (B, T)).astype(np.float32)),
+         "class_expr": f(rs.randint(0, 7, (B, T)).astype(np.int64)), "expr_valid": f(rs.uniform(size=(B, T)) < 0.7)}
+for _ in range(2):
+    tr.step(batch)
+torch.cuda.synchronize()
+p1, m1, t1 = tr.ddp.flat_params.clone(), tr.opt.m.clone(), tr.opt.t
+# a long kernel in front, so that the host is certainly ahead of the GPU when it queues the faulted step and its successors
+big = torch.randn(8192, 8192, device="cuda:0")
+for _ in range(20):
+    big = big @ big * 1e-4
+ops.SCAN_FAULT[0] = True
+queued, raised = 0, False
+try:
+    tr.step(batch)                       # forward scan dies on the device ... some time later
+    ops.SCAN_FAULT[0] = False
+    queued += 1
+    for _ in range(6):                   # healthy steps queued BEHIND it, no synchronisation: all must be skipped
+        tr.step(batch)
+        queued += 1
+except _lib.M3THipError as e:
+    assert "M3T_ESPIN" in str(e), str(e)
+    raised = True
+ops.SCAN_FAULT[0] = False
+if not raised:
+    try:
+        ops.poll_scan_error(sync=True)
+    except _lib.M3THipError:
+        raised = True
+assert raised, "the dead scan was never raised on the host"
+print("QUEUED", queued, flush=True)
+# the raise synchronised the device: everything queued is done
+assert torch.equal(p1, tr.ddp.flat_params), "a step queued behind the dead scan reached the parameters"
+assert torch.equal(m1, tr.opt.m), "... or the optimizer state"
+assert _lib.load().m3t_gru_poll_error() == 0, "raising must clear the sticky state"
+tr.step(batch)
+torch.cuda.synchronize()
+ops.poll_scan_error()
+assert not torch.equal(p1, tr.ddp.flat_params), "after the raise the loop must train again"
+print("SKIPPED-ALL-THEN-RECOVERED", flush=True)
+"""
+    out = _run(code, M3T_SCAN_SPIN_LIMIT="3000")
+    assert out.returncode == 0, (out.stdout[-500:], out.stderr[-2500:])
+    assert "SKIPPED-ALL-THEN-RECOVERED" in out.stdout
+
+
 def test_second_process_on_a_gpu_gets_the_launch_per_step_scans():
-    """one owner of the persistent scans per GPU (advisory lock on /tmp/m3t_persist_<pci-bus-id>.lock): this process takes
+    """one owner of the persistent scans per GPU (advisory lock, $XDG_RUNTIME_DIR or /tmp/m3t-<uid>/m3t_persist_<pci-bus-id>.lock): this process takes
     the lock by running a persistent scan, a second process on the same GPU must fall back to the launch-per-step path
     (bit-identical results at H=384, where the persistent kernel runs fp32 MFMAs; H=128 levels take the solo kernels, which need
     no ownership) instead of spinning against it"""
@@ -158,8 +221,9 @@ def test_second_process_on_a_gpu_gets_the_launch_per_step_scans():
         if p not in sys.path:
             sys.path.insert(0, p)
     import hashlib
-    from m3t import _lib
+    from m3t import _lib, ops
     from models.rnn import GRU
+    ops_owner = ops.persist_owner
     lib = _lib.load()
     torch.manual_seed(9)
     m = GRU(24, 384, 2, 3, 2).to("cuda:0")
@@ -181,6 +245,7 @@ with torch.no_grad():
     y = m(x)
 torch.cuda.synchronize()
 print("COUNT", _lib.load().m3t_gru_persist_count())
+print("OWNER", ops.persist_owner())
 print("DIGEST", hashlib.sha256(y.cpu().numpy().tobytes()).hexdigest())
 """
     e = dict(os.environ)
@@ -188,5 +253,6 @@ print("DIGEST", hashlib.sha256(y.cpu().numpy().tobytes()).hexdigest())
     out = subprocess.run([sys.executable, "-c", _HEAD + code], env=e, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-1500:]
     assert "COUNT 0" in out.stdout, out.stdout
+    assert "OWNER 2" in out.stdout and ops_owner() == 1, out.stdout          # the fallback is visible through the API
     assert "another process owns the persistent GRU scans" in out.stderr
     assert ("DIGEST " + mine) in out.stdout, "fallback results differ from the owner's persistent scans"
