@@ -14,7 +14,7 @@ import pytest
 import torch
 
 from conftest import load_golden
-from golden.recipe import fill_module, draw
+from golden.recipe import fill_module, draw, grad_digest
 from oracle import m3t_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -224,3 +224,40 @@ def test_c2_bf16_mode_against_the_reference_at_full_size():
           (err16, err_ac, float(l16), float(g["loss"])))
     assert 1e-5 < err16 <= 1.25 * err_ac, (err16, err_ac)              # measured: 5.1e-3 vs 7.5e-3
     assert abs(float(l16) - float(g["loss"])) <= 5e-4
+
+
+def test_c2_bf16_backward_against_the_reference_under_autocast_at_full_size():
+    """The BACKWARD of the bf16 mode, anchored outside this repo (it used to be compared with this repo's own fp32
+    run only).  Golden c2_tcn_gru_b32_autocast now carries the gradient digests of the REFERENCE's classes run forward and
+    backward under torch.autocast('cpu', bfloat16) on the 32 x 300 batch; the fp32 golden c2_tcn_gru_b32 carries the fp32
+    ones.  Distance = RMS over all parameters (and the input gradient) of the digest error relative to the fp32 gradient's
+    norm.  The HIP bf16 mode must stay within 1.25x of the distance the reference itself moves under autocast."""
+    from m3t.workloads import TcnGru, make_seq_step
+    from m3t import ops
+    g, ga = load_golden("c2_tcn_gru_b32"), load_golden("c2_tcn_gru_b32_autocast")
+    seed = int(g["seed"])
+    shape = tuple(int(v) for v in g["in_shape"])
+    model = fill_module(TcnGru(256, 512), seed + 1).to(DEV).eval()
+    rs = np.random.RandomState(seed)
+    x = torch.from_numpy(draw(rs, shape)).to(DEV).requires_grad_(True)
+    val, aro = dev(draw(rs, (32, 300), "uniform_pm1")), dev(draw(rs, (32, 300), "uniform_pm1"))
+    ddp, step = make_seq_step(model, x, val, aro, max_norm=0.0)
+    with ops.precision("bf16"):
+        step()
+    torch.cuda.synchronize()
+
+    def dist(dig, ref):                       # digest = [norm, sum, 8 leading values]; relative to the fp32 gradient's norm
+        return max(abs(dig[0] - ref[0]), float(np.abs(dig[2:] - ref[2:]).max())) / ref[0]
+
+    names = [n for n, _ in model.named_parameters()]
+    d_hip = [dist(grad_digest(p.grad.detach().cpu().numpy()), g["gd." + n]) for n, p in model.named_parameters()]
+    d_ac = [dist(ga["gd." + n], g["gd." + n]) for n in names]
+    d_hip.append(dist(grad_digest(x.grad.cpu().numpy()), g["dx"]))
+    d_ac.append(dist(ga["dx"], g["dx"]))
+    rms = lambda v: float(np.sqrt(np.mean(np.square(v))))
+    worst = int(np.argmax(np.array(d_hip) / np.maximum(np.array(d_ac), 1e-12)))
+    print("c2 bf16 backward: RMS digest distance to the fp32 reference: HIP bf16 mode %.3e, reference under autocast %.3e; max %.3e vs %.3e; "
+          "worst ratio at %s (%.2e vs %.2e)" % (rms(d_hip), rms(d_ac), max(d_hip), max(d_ac), (names + ["dx"])[worst], d_hip[worst], d_ac[worst]))
+    assert rms(d_hip) > 1e-5, "the bf16 mode does not seem to be on"
+    assert rms(d_hip) <= 1.25 * rms(d_ac), (rms(d_hip), rms(d_ac))
+    assert max(d_hip) <= 2.0 * max(d_ac), (max(d_hip), max(d_ac))
