@@ -335,12 +335,19 @@ def supervise(args):
                 return -1
             time.sleep(0.25)
 
+    def leave(rc):
+        # rank 0 hosts the store: it may only go once every other supervisor has said goodbye
+        store.add("bye", 1)
+        while rank == 0 and int(store.add("bye", 0)) < world:
+            time.sleep(0.1)
+        return rc
+
     rc = run(0, {})
     store.add("done0", 1)
     while int(store.add("done0", 0)) < world:                # every supervisor has its first verdict (and its worker is gone)
         time.sleep(0.1)
     if not store.check(["fail0"]):
-        return rc
+        return leave(rc)
     why = store.get("fail0").decode()
     if rank == 0:
         print("# worker failure (%s): fresh workers on the launch-per-step scans with overlapped gradient buckets" % why,
@@ -349,7 +356,7 @@ def supervise(args):
     store.add("done1", 1)
     while int(store.add("done1", 0)) < world:
         time.sleep(0.1)
-    return 1 if store.check(["fail1"]) else rc
+    return leave(1 if store.check(["fail1"]) else rc)
 
 
 def main():

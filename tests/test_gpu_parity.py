@@ -15,6 +15,7 @@ from oracle import m3t_oracle as O
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
+C5_DIGEST_TOL = 5e-4      # gradient digests of the full A+V model from raw frames (conv stem gradients on MIOpen)
 DEV = "cuda:0"
 
 
@@ -754,11 +755,11 @@ def test_c5_affwild_av_golden():
     m = fill_module(AffWild2VA(_hp(modality="audiovisual", fusion_type="attention", loss="ccc_mtl", window=T)),
                     seed + 1).to(DEV).eval()
     batch = _affwild_batch(np.random.RandomState(seed), B, T, video=True)
-    close(m(batch), g["y"], 2e-4, "y")
-    out = m.training_step(batch, 0)
-    close(out["loss"], g["loss"], 2e-4, "loss")
+    close(m(batch), g["y"], TOL, "y")                    # north_star bar; measured 1e-7 end to end (round 3: the MIOpen stem's output
+    out = m.training_step(batch, 0)                      # is within 9e-6 of the reference's, test_c5_temporal_part_on_the_references_stem_features)
+    close(out["loss"], g["loss"], TOL, "loss")
     out["loss"].backward()
-    check_digests([(n, p.grad) for n, p in m.named_parameters() if p.grad is not None], g, tol=2e-3)
+    check_digests([(n, p.grad) for n, p in m.named_parameters() if p.grad is not None], g, tol=C5_DIGEST_TOL)
 
 
 def test_c5_resnet3d_cbam_golden():
@@ -807,11 +808,11 @@ def test_c5_affwild_av_t16_golden():
     m = fill_module(AffWild2VA(_hp(modality="audiovisual", fusion_type="attention", loss="ccc_mtl", window=T)),
                     seed + 1).to(DEV).eval()
     batch = _affwild_batch(np.random.RandomState(seed), B, T, video=True)
-    close(m(batch), g["y"], 2e-4, "y")
-    out = m.training_step(batch, 0)
-    close(out["loss"], g["loss"], 2e-4, "loss")
+    close(m(batch), g["y"], TOL, "y")                    # north_star bar; measured 1e-7 end to end (round 3: the MIOpen stem's output
+    out = m.training_step(batch, 0)                      # is within 9e-6 of the reference's, test_c5_temporal_part_on_the_references_stem_features)
+    close(out["loss"], g["loss"], TOL, "loss")
     out["loss"].backward()
-    check_digests([(n, p.grad) for n, p in m.named_parameters() if p.grad is not None], g, tol=2e-3)
+    check_digests([(n, p.grad) for n, p in m.named_parameters() if p.grad is not None], g, tol=C5_DIGEST_TOL)
 
 
 def test_c1_affwild_audio_db_scale_golden():
