@@ -1,0 +1,791 @@
+// CBAM (channel gate -> spatial gate, reference models/cbam.py:95-111) as ONE fused operator for gfx950.
+//
+// cbam.hip runs the two gates as two operators (what the reference's module tree says): x -> y1 = x * cs -> y2 = y1 * ss,
+// with y1 written and read back three times and ~14 launches per forward + backward: 10 HBM passes over a tensor of x's
+// size, 0.7-1.7 TB/s effective.  The gate as a whole needs much less.  y1 is never materialised here:
+//
+//   forward   F1  per frame (one workgroup): read x -> per-channel avg / max / argmax (G lanes per plane, shuffles) -> shared MLP ->
+//                 cs[c] -> re-read the frame (L2 / Infinity Cache: the workgroup touched it microseconds ago) -> per-pixel
+//                 max_c / mean_c / argmax_c of x * cs -> 5x5 conv out of LDS -> conv[n,p] + fp64 BatchNorm partials
+//             ST  one workgroup: batch statistics (BatchNorm2d(1) in train mode is a GLOBAL reduction over N*H*W: the one
+//                 place where the gate must be cut), running statistics
+//             F2  per frame: ss[p] = sigmoid(gamma * xhat + beta); y = x * cs[c] * ss[p]
+//   backward  B1  per frame: dss[p] = sum_c dy * x * cs[c] -> dpre = dss * ss (1 - ss) + fp64 partials of the two BatchNorm sums
+//             SP  one workgroup: (d gamma, d beta)  -- the second global reduction
+//             B2  per frame: BatchNorm backward -> conv backward (weight-gradient partials per frame, data gradient to the two
+//                 compressed maps) -> dy1 = dy * ss + dmean / C + [c == argmax_c] dmax, recomputed on the fly -> dcs[c] = sum_p
+//                 dy1 * x -> MLP backward -> dx = dy1 * cs + davg / HW + [p == argmax_p] dmaxc (dy re-read while cache-hot)
+//             + the parameter-gradient finish (GEMMs / column sums over the [N, .] slabs, as cbam.hip)
+//
+// HBM passes over a tensor of x's size: F1 1, F2 2, B1 2, B2 3 = 8 (+2 re-reads served by L2 / Infinity Cache), 7 launches
+// + the small parameter-gradient kernels.  Two global BatchNorm reductions make four sweeps the minimum in train mode.
+// Thread mappings: a "unit" is 4 consecutive pixels (float4, H*W % 4 == 0) or 1 pixel; Q units per plane.
+//   * plane sweeps (squeeze, apply, dcs, dx): G = min(64, pow2 >= Q) lanes per plane, 64 / G planes per wave pass, up to four
+//     16-B loads in flight per lane -- a 4 x 4 map (Q = 4) keeps all 64 lanes busy on 16 planes, a 28 x 28 map one plane;
+//   * pixel reductions over channels (compress, dss): thread = (unit q, channel slice k), KS = 512 / pow2(Q) slices, partials
+//     combined by shuffles (inside a wave) and LDS, fixed order, ties to the lower channel index (torch's first maximum).
+// Deterministic: no atomics; every reduction has a fixed order.  fp64 only for the per-workgroup BatchNorm partials.
+#include "common.h"
+
+namespace {
+
+constexpr int FT = 512;       // threads per workgroup (8 waves)
+
+__device__ __forceinline__ double block_sum_d8(double v, double* red) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    double r = 0.0;
+#pragma unroll
+    for (int i = 0; i < FT / 64; ++i) r += red[i];
+    return r;
+}
+
+template <int E> struct Unit;
+template <> struct Unit<4> {
+    static __device__ __forceinline__ void ld(const float* p, float (&v)[4]) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    static __device__ __forceinline__ void st(float* p, const float (&v)[4]) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    static __device__ __forceinline__ void ldi(const int32_t* p, int (&v)[4]) {
+        const int4 t = *reinterpret_cast<const int4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    static __device__ __forceinline__ void sti(int32_t* p, const int (&v)[4]) {
+        *reinterpret_cast<int4*>(p) = make_int4(v[0], v[1], v[2], v[3]);
+    }
+};
+template <> struct Unit<1> {
+    static __device__ __forceinline__ void ld(const float* p, float (&v)[1]) { v[0] = *p; }
+    static __device__ __forceinline__ void st(float* p, const float (&v)[1]) { *p = v[0]; }
+    static __device__ __forceinline__ void ldi(const int32_t* p, int (&v)[1]) { v[0] = *p; }
+    static __device__ __forceinline__ void sti(int32_t* p, const int (&v)[1]) { *p = v[0]; }
+};
+
+__host__ __device__ inline int al4(int n) { return (n + 3) & ~3; }
+
+// ------------------------------------------------------------------------------------------------ F1
+template <int E>
+__global__ __launch_bounds__(FT) void cbam_f1_kernel(const float* __restrict__ x, const float* __restrict__ w1,
+                                                     const float* __restrict__ b1, const float* __restrict__ w2,
+                                                     const float* __restrict__ b2, const float* __restrict__ convw,
+                                                     float* __restrict__ cs, int32_t* __restrict__ argmax_p,
+                                                     float* __restrict__ pooled, float* __restrict__ hidden,
+                                                     float* __restrict__ comp, int32_t* __restrict__ cargmax,
+                                                     float* __restrict__ conv_out, double* __restrict__ part, int C, int Cr,
+                                                     int H, int W, int G, int Qp) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ double red[FT / 64];
+    const int HW = H * W, Q = HW / E;
+    float* s_avg = sm;
+    float* s_max = s_avg + al4(C);
+    float* s_sc = s_max + al4(C);
+    float* s_h = s_sc + al4(C);               // [2 Cr]
+    float* s_comp = s_h + al4(2 * Cr);        // [2][HW]
+    float* s_w = s_comp + al4(2 * HW);        // [50]
+    float* p_mx = s_w + 52;                   // [nk][Qp][E]
+    const int nk = Qp < 64 ? FT / 64 : FT / Qp;
+    float* p_sum = p_mx + nk * Qp * E;
+    int* p_am = reinterpret_cast<int*>(p_sum + nk * Qp * E);
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* xb = x + (size_t)n * C * HW;
+    if (tid < 50) s_w[tid] = convw[tid];
+
+    // ---- a. channel squeeze: avg, max, argmax per plane, G lanes per plane
+    {
+        const int per = 64 / G, sub = lane % G, pi = lane / G;
+        for (int c0 = wave * per; c0 < C; c0 += (FT / 64) * per) {
+            const int c = c0 + pi;
+            const bool okc = c < C;
+            const float* pl = xb + (size_t)(okc ? c : 0) * HW;
+            float sum = 0.f, mx = -INFINITY;
+            int am = 0x7fffffff;
+            for (int u0 = sub; u0 < Q; u0 += 4 * G) {
+                float v[4][E];
+                bool ok[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int u = u0 + k * G;
+                    ok[k] = okc && u < Q;
+                    if (ok[k]) Unit<E>::ld(pl + (size_t)u * E, v[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (ok[k]) {
+#pragma unroll
+                        for (int e = 0; e < E; ++e) {
+                            sum += v[k][e];
+                            if (v[k][e] > mx) { mx = v[k][e]; am = (u0 + k * G) * E + e; }
+                        }
+                    }
+            }
+            for (int o = G >> 1; o > 0; o >>= 1) {
+                sum += __shfl_xor(sum, o, 64);
+                const float ov = __shfl_xor(mx, o, 64);
+                const int oi = __shfl_xor(am, o, 64);
+                if (ov > mx || (ov == mx && oi < am)) { mx = ov; am = oi; }
+            }
+            if (sub == 0 && okc) {
+                const float avg = sum / (float)HW;
+                s_avg[c] = avg; s_max[c] = mx;
+                pooled[((size_t)n * 2 + 0) * C + c] = avg;
+                pooled[((size_t)n * 2 + 1) * C + c] = mx;
+                argmax_p[(size_t)n * C + c] = am;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- b. shared MLP C -> Cr -> C on both pooled vectors, sigmoid of the sum (reference cbam.py:51-58)
+    for (int j = wave; j < 2 * Cr; j += FT / 64) {
+        const int which = j / Cr, r = j % Cr;
+        const float* src = which ? s_max : s_avg;
+        const float* wr = w1 + (size_t)r * C;
+        float h = 0.f;
+        for (int c = lane; c < C; c += 64) h += wr[c] * src[c];
+        h = wave_sum(h) + b1[r];
+        if (lane == 0) {
+            hidden[((size_t)n * 2 + which) * Cr + r] = h;
+            s_h[j] = fmaxf(h, 0.f);
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += FT) {
+        const float* wr = w2 + (size_t)c * Cr;
+        float a0 = b2[c], a1 = b2[c];
+        for (int r = 0; r < Cr; ++r) { a0 += wr[r] * s_h[r]; a1 += wr[r] * s_h[Cr + r]; }
+        const float sc = 1.f / (1.f + expf(-(a0 + a1)));
+        s_sc[c] = sc;
+        cs[(size_t)n * C + c] = sc;
+    }
+    __syncthreads();
+    // ---- c. compress x * cs over channels: (max, mean, argmax) per pixel; thread = (unit q, channel slice k)
+    {
+        const int q = tid % Qp, k = tid / Qp, KS = FT / Qp;
+        float mx[E], sum[E];
+        int am[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) { mx[e] = -INFINITY; sum[e] = 0.f; am[e] = 0x7fffffff; }
+        if (q < Q) {
+            for (int c0 = k; c0 < C; c0 += 4 * KS) {
+                float v[4][E];
+                bool ok[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = c0 + j * KS;
+                    ok[j] = c < C;
+                    if (ok[j]) Unit<E>::ld(xb + ((size_t)c * Q + q) * E, v[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (ok[j]) {
+                        const int c = c0 + j * KS;
+                        const float sc = s_sc[c];
+#pragma unroll
+                        for (int e = 0; e < E; ++e) {
+                            const float t = v[j][e] * sc;
+                            sum[e] += t;
+                            if (t > mx[e]) { mx[e] = t; am[e] = c; }
+                        }
+                    }
+            }
+        }
+        if (Qp < 64) {        // the slices of a unit sit Qp lanes apart inside the wave
+            for (int o = Qp; o < 64; o <<= 1) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    sum[e] += __shfl_xor(sum[e], o, 64);
+                    const float ov = __shfl_xor(mx[e], o, 64);
+                    const int oi = __shfl_xor(am[e], o, 64);
+                    if (ov > mx[e] || (ov == mx[e] && oi < am[e])) { mx[e] = ov; am[e] = oi; }
+                }
+            }
+            if (lane < Qp) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int idx = (wave * Qp + q) * E + e;
+                    p_mx[idx] = mx[e]; p_sum[idx] = sum[e]; p_am[idx] = am[e];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int idx = (k * Qp + q) * E + e;
+                p_mx[idx] = mx[e]; p_sum[idx] = sum[e]; p_am[idx] = am[e];
+            }
+        }
+        __syncthreads();
+        if (tid < Q) {
+            float fm[E], fs[E];
+            int fa[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) { fm[e] = -INFINITY; fs[e] = 0.f; fa[e] = 0x7fffffff; }
+            for (int j = 0; j < nk; ++j) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int idx = (j * Qp + tid) * E + e;
+                    fs[e] += p_sum[idx];
+                    const float ov = p_mx[idx];
+                    const int oi = p_am[idx];
+                    if (ov > fm[e] || (ov == fm[e] && oi < fa[e])) { fm[e] = ov; fa[e] = oi; }
+                }
+            }
+            float mean[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                mean[e] = fs[e] / (float)C;
+                s_comp[tid * E + e] = fm[e];
+                s_comp[HW + tid * E + e] = mean[e];
+            }
+            Unit<E>::st(comp + ((size_t)n * 2 + 0) * HW + (size_t)tid * E, fm);
+            Unit<E>::st(comp + ((size_t)n * 2 + 1) * HW + (size_t)tid * E, mean);
+            Unit<E>::sti(cargmax + (size_t)n * HW + (size_t)tid * E, fa);
+        }
+    }
+    __syncthreads();
+    // ---- d. Conv2d(2, 1, 5, pad 2, bias=False) out of LDS + the frame's BatchNorm partial sums
+    double s1 = 0.0, s2 = 0.0;
+    for (int p = tid; p < HW; p += FT) {
+        const int h = p / W, ww = p - h * W;
+        float acc = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            const float* cp = s_comp + ch * HW;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int hh = h + i - 2;
+                if (hh < 0 || hh >= H) continue;
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    const int wj = ww + j - 2;
+                    if (wj < 0 || wj >= W) continue;
+                    acc += s_w[(ch * 5 + i) * 5 + j] * cp[hh * W + wj];
+                }
+            }
+        }
+        conv_out[(size_t)n * HW + p] = acc;
+        s1 += acc; s2 += (double)acc * acc;
+    }
+    s1 = block_sum_d8(s1, red);
+    s2 = block_sum_d8(s2, red);
+    if (tid == 0) { part[2 * (size_t)n] = s1; part[2 * (size_t)n + 1] = s2; }
+}
+
+// batch statistics of the conv output (train) or the running ones (eval) -> stats = (mean, 1 / sqrt(var + eps))
+__global__ __launch_bounds__(256) void cbam_stats_kernel(const double* __restrict__ part, int nparts, double cnt,
+                                                         float* __restrict__ running, float* __restrict__ stats,
+                                                         int training, float momentum, float eps) {
+    __shared__ double red[4];
+    double s1 = 0.0, s2 = 0.0;
+    if (training)
+        for (int i = threadIdx.x; i < nparts; i += 256) { s1 += part[2 * i]; s2 += part[2 * i + 1]; }
+    for (int pass = 0; pass < 2; ++pass) {
+        double v = pass ? s2 : s1;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        v = (red[0] + red[1]) + (red[2] + red[3]);
+        if (pass) s2 = v; else s1 = v;
+    }
+    if (threadIdx.x == 0) {
+        if (training) {
+            const double mean = s1 / cnt;
+            double var = s2 / cnt - mean * mean;
+            if (var < 0.0) var = 0.0;
+            stats[0] = (float)mean;
+            stats[1] = (float)(1.0 / sqrt(var + (double)eps));
+            const double unb = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+            running[0] = (float)((1.0 - momentum) * running[0] + momentum * mean);
+            running[1] = (float)((1.0 - momentum) * running[1] + momentum * unb);
+        } else {
+            stats[0] = running[0];
+            stats[1] = 1.f / sqrtf(running[1] + eps);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ F2
+template <int E>
+__global__ __launch_bounds__(FT) void cbam_f2_kernel(const float* __restrict__ x, const float* __restrict__ cs,
+                                                     const float* __restrict__ bn, const float* __restrict__ stats,
+                                                     float* __restrict__ xhat, float* __restrict__ ss, float* __restrict__ y,
+                                                     int C, int HW, int G) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* s_sc = sm;
+    float* s_ss = s_sc + al4(C);
+    const int Q = HW / E;
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float mean = stats[0], inv = stats[1], ga = bn[0], be = bn[1];
+    for (int p = tid; p < HW; p += FT) {
+        const size_t o = (size_t)n * HW + p;
+        const float xh = (xhat[o] - mean) * inv;           // xhat holds the raw conv output on entry
+        xhat[o] = xh;
+        const float s = 1.f / (1.f + expf(-(xh * ga + be)));
+        ss[o] = s;
+        s_ss[p] = s;
+    }
+    for (int c = tid; c < C; c += FT) s_sc[c] = cs[(size_t)n * C + c];
+    __syncthreads();
+    const float* xb = x + (size_t)n * C * HW;
+    float* yb = y + (size_t)n * C * HW;
+    const int per = 64 / G, sub = lane % G, pi = lane / G;
+    for (int c0 = wave * per; c0 < C; c0 += (FT / 64) * per) {
+        const int c = c0 + pi;
+        if (c >= C) continue;
+        const float sc = s_sc[c];
+        const float* pl = xb + (size_t)c * HW;
+        float* yl = yb + (size_t)c * HW;
+        for (int u0 = sub; u0 < Q; u0 += 4 * G) {
+            float v[4][E];
+            bool ok[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int u = u0 + k * G;
+                ok[k] = u < Q;
+                if (ok[k]) Unit<E>::ld(pl + (size_t)u * E, v[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (ok[k]) {
+                    const int u = u0 + k * G;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) v[k][e] *= sc * s_ss[u * E + e];
+                    Unit<E>::st(yl + (size_t)u * E, v[k]);
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ B1
+template <int E>
+__global__ __launch_bounds__(FT) void cbam_b1_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ cs, const float* __restrict__ ss,
+                                                     const float* __restrict__ xhat, float* __restrict__ dpre,
+                                                     double* __restrict__ part, int C, int HW, int Qp) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ double red[FT / 64];
+    float* s_sc = sm;
+    float* p_sum = s_sc + al4(C);
+    const int Q = HW / E;
+    const int nk = Qp < 64 ? FT / 64 : FT / Qp;
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int c = tid; c < C; c += FT) s_sc[c] = cs[(size_t)n * C + c];
+    __syncthreads();
+    const float* xb = x + (size_t)n * C * HW;
+    const float* gb = dy + (size_t)n * C * HW;
+    const int q = tid % Qp, k = tid / Qp, KS = FT / Qp;
+    float acc[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] = 0.f;
+    if (q < Q) {
+        for (int c0 = k; c0 < C; c0 += 4 * KS) {
+            float a[4][E], b[4][E];
+            bool ok[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = c0 + j * KS;
+                ok[j] = c < C;
+                if (ok[j]) {
+                    Unit<E>::ld(gb + ((size_t)c * Q + q) * E, a[j]);
+                    Unit<E>::ld(xb + ((size_t)c * Q + q) * E, b[j]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (ok[j]) {
+                    const float sc = s_sc[c0 + j * KS];
+#pragma unroll
+                    for (int e = 0; e < E; ++e) acc[e] += a[j][e] * (b[j][e] * sc);
+                }
+        }
+    }
+    if (Qp < 64) {
+        for (int o = Qp; o < 64; o <<= 1)
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
+        if (lane < Qp)
+#pragma unroll
+            for (int e = 0; e < E; ++e) p_sum[(wave * Qp + q) * E + e] = acc[e];
+    } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e) p_sum[(k * Qp + q) * E + e] = acc[e];
+    }
+    __syncthreads();
+    double s1 = 0.0, s2 = 0.0;
+    if (tid < Q) {
+        float ds[E], s[E], xh[E], d[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) ds[e] = 0.f;
+        for (int j = 0; j < nk; ++j)
+#pragma unroll
+            for (int e = 0; e < E; ++e) ds[e] += p_sum[(j * Qp + tid) * E + e];
+        const size_t o = (size_t)n * HW + (size_t)tid * E;
+        Unit<E>::ld(ss + o, s);
+        Unit<E>::ld(xhat + o, xh);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            d[e] = ds[e] * s[e] * (1.f - s[e]);
+            s1 += d[e];
+            s2 += (double)d[e] * xh[e];
+        }
+        Unit<E>::st(dpre + o, d);
+    }
+    s1 = block_sum_d8(s1, red);
+    s2 = block_sum_d8(s2, red);
+    if (tid == 0) { part[2 * (size_t)n] = s1; part[2 * (size_t)n + 1] = s2; }
+}
+
+// out2[0] = sum of part[2i+1] (d gamma), out2[1] = sum of part[2i] (d beta)
+__global__ __launch_bounds__(256) void cbam_sum_pairs_kernel(const double* __restrict__ part, int nparts, float* __restrict__ out_gamma_beta) {
+    __shared__ double red[4];
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) { s1 += part[2 * i]; s2 += part[2 * i + 1]; }
+    for (int pass = 0; pass < 2; ++pass) {
+        double v = pass ? s2 : s1;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        v = (red[0] + red[1]) + (red[2] + red[3]);
+        if (pass) s2 = v; else s1 = v;
+    }
+    if (threadIdx.x == 0) { out_gamma_beta[0] = (float)s2; out_gamma_beta[1] = (float)s1; }
+}
+
+// ------------------------------------------------------------------------------------------------ B2
+template <int E>
+__global__ __launch_bounds__(FT) void cbam_b2_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ w1, const float* __restrict__ w2,
+                                                     const float* __restrict__ convw, const float* __restrict__ bn,
+                                                     const float* __restrict__ stats, const float* __restrict__ dgb,
+                                                     const float* __restrict__ cs, const int32_t* __restrict__ argmax_p,
+                                                     const float* __restrict__ hidden, const float* __restrict__ comp,
+                                                     const int32_t* __restrict__ cargmax, const float* __restrict__ xhat,
+                                                     const float* __restrict__ ss, const float* __restrict__ dpre,
+                                                     float* __restrict__ dx, float* __restrict__ g_datt, float* __restrict__ g_dh,
+                                                     float* __restrict__ g_r, float* __restrict__ dwpart, int C, int Cr, int H,
+                                                     int W, int G, float inv_total, int training) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int HW = H * W, Q = HW / E, HWa = al4(HW);
+    float* s_dc = sm;                          // [HW] gradient wrt the conv output
+    float* s_ss = s_dc + HWa;                  // [HW]
+    float* s_dmx = s_ss + HWa;                 // [HW] gradient wrt the max map
+    float* s_dmn = s_dmx + HWa;                // [HW] gradient wrt the mean map, already / C
+    int* s_cam = reinterpret_cast<int*>(s_dmn + HWa);      // [HW] argmax_c
+    float* s_comp = reinterpret_cast<float*>(s_cam + HWa); // [2][HW]
+    float* s_w = s_comp + al4(2 * HW);         // [50]
+    float* s_sc = s_w + 52;                    // [C]
+    float* s_datt = s_sc + al4(C);
+    float* s_davg = s_datt + al4(C);
+    float* s_dmaxc = s_davg + al4(C);
+    float* s_dh = s_dmaxc + al4(C);            // [2 Cr]
+    float* s_part = s_dh + al4(2 * Cr);        // [8][Cr]
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* xb = x + (size_t)n * C * HW;
+    const float* gb = dy + (size_t)n * C * HW;
+    // ---- a. BatchNorm2d(1) backward per pixel, frame-local copies
+    {
+        const float gamma = bn[0], invstd = stats[1];
+        const float m1 = gamma * dgb[1] * inv_total;       // mean(dxhat)
+        const float m2 = gamma * dgb[0] * inv_total;       // mean(dxhat * xhat)
+        for (int p = tid; p < HW; p += FT) {
+            const size_t o = (size_t)n * HW + p;
+            const float dxh = dpre[o] * gamma;
+            s_dc[p] = training ? invstd * (dxh - m1 - xhat[o] * m2) : dxh * invstd;
+            s_ss[p] = ss[o];
+            s_cam[p] = cargmax[o];
+            s_comp[p] = comp[((size_t)n * 2 + 0) * HW + p];
+            s_comp[HW + p] = comp[((size_t)n * 2 + 1) * HW + p];
+        }
+        if (tid < 50) s_w[tid] = convw[tid];
+        for (int c = tid; c < C; c += FT) s_sc[c] = cs[(size_t)n * C + c];
+    }
+    __syncthreads();
+    // ---- b. this frame's share of the conv weight gradient: 50 taps, one wave per tap
+    for (int tap = wave; tap < 50; tap += FT / 64) {
+        const int ch = tap / 25, i = (tap % 25) / 5, j = tap % 5;
+        float s = 0.f;
+        for (int p = lane; p < HW; p += 64) {
+            const int ph = p / W, pw = p - ph * W;
+            const int h = ph + i - 2, w = pw + j - 2;
+            if (h >= 0 && h < H && w >= 0 && w < W) s += s_dc[p] * s_comp[ch * HW + h * W + w];
+        }
+        s = wave_sum(s);
+        if (lane == 0) dwpart[(size_t)n * 50 + tap] = s;
+    }
+    // ---- c. conv backward to the two compressed maps
+    for (int p = tid; p < HW; p += FT) {
+        const int h = p / W, ww = p - h * W;
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int hh = h - i + 2;
+            if (hh < 0 || hh >= H) continue;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int wj = ww - j + 2;
+                if (wj < 0 || wj >= W) continue;
+                const float d = s_dc[hh * W + wj];
+                a += s_w[(0 * 5 + i) * 5 + j] * d;
+                b += s_w[(1 * 5 + i) * 5 + j] * d;
+            }
+        }
+        s_dmx[p] = a;
+        s_dmn[p] = b / (float)C;
+    }
+    __syncthreads();
+    // ---- d. dcs[c] = sum_p dy1 * x with dy1 = dy * ss + dmean / C + [c == argmax_c] dmax (the spatial gate's input gradient)
+    const int per = 64 / G, sub = lane % G, pi = lane / G;
+    for (int c0 = wave * per; c0 < C; c0 += (FT / 64) * per) {
+        const int c = c0 + pi;
+        const bool okc = c < C;
+        const float* pl = xb + (size_t)(okc ? c : 0) * HW;
+        const float* gl = gb + (size_t)(okc ? c : 0) * HW;
+        float ds = 0.f;
+        for (int u0 = sub; u0 < Q; u0 += 4 * G) {
+            float a[4][E], b[4][E];
+            bool ok[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int u = u0 + k * G;
+                ok[k] = okc && u < Q;
+                if (ok[k]) { Unit<E>::ld(gl + (size_t)u * E, a[k]); Unit<E>::ld(pl + (size_t)u * E, b[k]); }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (ok[k]) {
+                    const int u = u0 + k * G;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        const int p = u * E + e;
+                        const float dy1 = a[k][e] * s_ss[p] + s_dmn[p] + (c == s_cam[p] ? s_dmx[p] : 0.f);
+                        ds += dy1 * b[k][e];
+                    }
+                }
+        }
+        for (int o = G >> 1; o > 0; o >>= 1) ds += __shfl_xor(ds, o, 64);
+        if (sub == 0 && okc) {
+            const float sc = s_sc[c];
+            const float da = ds * sc * (1.f - sc);
+            s_datt[c] = da;
+            g_datt[(size_t)n * C + c] = da;
+        }
+    }
+    __syncthreads();
+    // ---- e. shared MLP backward (as cbam.hip): g[r] = sum_c datt[c] W2[c][r] -> ReLU masks -> davg, dmax per channel
+    if (lane < Cr) {
+        float g = 0.f;
+        for (int c = wave; c < C; c += FT / 64) g += s_datt[c] * w2[(size_t)c * Cr + lane];
+        s_part[wave * Cr + lane] = g;
+    }
+    __syncthreads();
+    for (int j = tid; j < 2 * Cr; j += FT) {
+        const int which = j / Cr, r = j % Cr;
+        float g = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < FT / 64; ++wv) g += s_part[wv * Cr + r];
+        const float h = hidden[((size_t)n * 2 + which) * Cr + r];
+        const float dh = h > 0.f ? g : 0.f;
+        s_dh[j] = dh;
+        g_dh[((size_t)n * 2 + which) * Cr + r] = dh;
+        if (which == 0) {
+            const float hm = hidden[((size_t)n * 2 + 1) * Cr + r];
+            g_r[(size_t)n * Cr + r] = fmaxf(h, 0.f) + fmaxf(hm, 0.f);
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += FT) {
+        float da = 0.f, dm = 0.f;
+        for (int r = 0; r < Cr; ++r) {
+            const float w = w1[(size_t)r * C + c];
+            da += s_dh[r] * w;
+            dm += s_dh[Cr + r] * w;
+        }
+        s_davg[c] = da / (float)HW;
+        s_dmaxc[c] = dm;
+    }
+    __syncthreads();
+    // ---- f. dx = dy1 * cs + davg / HW + [p == argmax_p] dmaxc; dy is re-read while the frame is still cache-hot
+    float* db = dx + (size_t)n * C * HW;
+    for (int c0 = wave * per; c0 < C; c0 += (FT / 64) * per) {
+        const int c = c0 + pi;
+        if (c >= C) continue;
+        const float sc = s_sc[c], da = s_davg[c], dm = s_dmaxc[c];
+        const int amp = argmax_p[(size_t)n * C + c];
+        const float* gl = gb + (size_t)c * HW;
+        float* dl = db + (size_t)c * HW;
+        for (int u0 = sub; u0 < Q; u0 += 4 * G) {
+            float a[4][E];
+            bool ok[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int u = u0 + k * G;
+                ok[k] = u < Q;
+                if (ok[k]) Unit<E>::ld(gl + (size_t)u * E, a[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (ok[k]) {
+                    const int u = u0 + k * G;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        const int p = u * E + e;
+                        const float dy1 = a[k][e] * s_ss[p] + s_dmn[p] + (c == s_cam[p] ? s_dmx[p] : 0.f);
+                        a[k][e] = dy1 * sc + da + (p == amp ? dm : 0.f);
+                    }
+                    Unit<E>::st(dl + (size_t)u * E, a[k]);
+                }
+        }
+    }
+}
+
+// conv weight gradient: sum of the per-frame partials in frame order (fp64 accumulation)
+__global__ __launch_bounds__(64) void cbam_dw_final_kernel(const float* __restrict__ dwpart, int N, float* __restrict__ dw) {
+    const int tap = blockIdx.x;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < N; i += 64) s += (double)dwpart[(size_t)i * 50 + tap];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (threadIdx.x == 0) dw[tap] = (float)s;
+}
+
+struct Geo { int E, Q, G, Qp, nk; };
+
+// units of E pixels: Q per plane (at most FT: one thread per unit in the pixel reductions)
+bool geo_for(int HW, int E, Geo& g) {
+    g.E = E;
+    g.Q = HW / E;
+    if (g.Q > FT || g.Q * E != HW) return false;
+    int p2 = 1;
+    while (p2 < g.Q) p2 <<= 1;
+    g.Qp = p2;
+    g.G = p2 < 64 ? p2 : 64;
+    g.nk = g.Qp < 64 ? FT / 64 : FT / g.Qp;
+    return true;
+}
+
+// float4 units when H*W is a multiple of 4 and every swept tensor is 16-B aligned, else single pixels
+bool geometry(int HW, const void* const* ptrs, int nptr, Geo& g) {
+    bool al = true;
+    for (int i = 0; i < nptr; ++i) al = al && (((uintptr_t)ptrs[i] & 15) == 0);
+    return geo_for(HW, (HW % 4 == 0 && al) ? 4 : 1, g);
+}
+
+size_t f1_lds(int C, int Cr, int HW, const Geo& g) {
+    return (size_t)(3 * al4(C) + al4(2 * Cr) + al4(2 * HW) + 52 + 3 * g.nk * g.Qp * g.E) * sizeof(float);
+}
+size_t b2_lds(int C, int Cr, int HW) {
+    return (size_t)(5 * al4(HW) + al4(2 * HW) + 52 + 4 * al4(C) + al4(2 * Cr) + 8 * Cr) * sizeof(float);
+}
+
+}  // namespace
+
+extern "C" int m3t_sgemm(int, int, int, int, int, const float*, int, const float*, int, float*, int, const float*, int, int,
+                         int, int, int, int, float*, size_t, int, void*);
+extern "C" int m3t_colsum(const float*, int, int, int, float*, int, float*, size_t, void*);
+
+extern "C" int m3t_cbam_fused_ok(int C, int Cr, int H, int W) {
+    if (C <= 0 || Cr <= 0 || Cr > 64 || H <= 0 || W <= 0) return 0;
+    const int HW = H * W;
+    Geo g;
+    if (!geo_for(HW, HW % 4 == 0 ? 4 : 1, g)) return 0;
+    return (f1_lds(C, Cr, HW, g) <= 60 * 1024 && b2_lds(C, Cr, HW) <= 60 * 1024) ? 1 : 0;
+}
+
+extern "C" size_t m3t_cbam_fused_ws_bytes(int N, int C, int Cr, int H, int W) {
+    // doubles: part[2 N]; floats: dgb[2 -> 4], dpre[N HW], dwpart[N 50], g_datt[N C], g_dh[N 2 Cr], g_r[N Cr] + GEMM scratch
+    const size_t HW = (size_t)H * W;
+    return (size_t)N * 2 * sizeof(double) + ((size_t)4 + N * HW + (size_t)N * 50 + (size_t)N * (C + 3 * Cr)) * sizeof(float) + 256 +
+           ((size_t)8 << 20);
+}
+
+extern "C" int m3t_cbam_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                            const float* conv_w, const float* bn, float* running, float* y, float* cs, int32_t* argmax_p,
+                            float* pooled, float* hidden, float* comp, int32_t* cargmax, float* xhat, float* ss, float* stats,
+                            int N, int C, int Cr, int H, int W, int training, float momentum, float eps, float* ws,
+                            size_t ws_bytes, void* stream) {
+    if (N <= 0) return 0;
+    if (!x || !w1 || !b1 || !w2 || !b2 || !conv_w || !bn || !running || !y || !cs || !argmax_p || !pooled || !hidden || !comp ||
+        !cargmax || !xhat || !ss || !stats || !ws || ((uintptr_t)ws & 7) != 0)
+        return M3T_EINVAL;
+    if (!m3t_cbam_fused_ok(C, Cr, H, W)) return M3T_EINVAL;
+    if (ws_bytes < (size_t)N * 2 * sizeof(double)) return M3T_EINVAL;
+    const int HW = H * W;
+    const void* ptrs[] = {x, y, comp, cargmax, xhat, ss};
+    Geo g;
+    if (!geometry(HW, ptrs, 6, g)) return M3T_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    double* part = reinterpret_cast<double*>(ws);
+    const size_t lds1 = f1_lds(C, Cr, HW, g), lds2 = (size_t)(al4(C) + al4(HW)) * sizeof(float);
+    if (g.E == 4) cbam_f1_kernel<4><<<N, FT, lds1, s>>>(x, w1, b1, w2, b2, conv_w, cs, argmax_p, pooled, hidden, comp, cargmax, xhat, part, C, Cr, H, W, g.G, g.Qp);
+    else cbam_f1_kernel<1><<<N, FT, lds1, s>>>(x, w1, b1, w2, b2, conv_w, cs, argmax_p, pooled, hidden, comp, cargmax, xhat, part, C, Cr, H, W, g.G, g.Qp);
+    M3T_LAUNCH_CHECK();
+    cbam_stats_kernel<<<1, 256, 0, s>>>(part, N, (double)N * HW, running, stats, training, momentum, eps);
+    M3T_LAUNCH_CHECK();
+    if (g.E == 4) cbam_f2_kernel<4><<<N, FT, lds2, s>>>(x, cs, bn, stats, xhat, ss, y, C, HW, g.G);
+    else cbam_f2_kernel<1><<<N, FT, lds2, s>>>(x, cs, bn, stats, xhat, ss, y, C, HW, g.G);
+    M3T_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int m3t_cbam_bwd(const float* dy, const float* x, const float* w1, const float* w2, const float* conv_w,
+                            const float* bn, const float* cs, const int32_t* argmax_p, const float* pooled,
+                            const float* hidden, const float* comp, const int32_t* cargmax, const float* xhat, const float* ss,
+                            const float* stats, float* dx, float* dw1, float* db1, float* dw2, float* db2, float* dconv_w,
+                            float* dbn, int N, int C, int Cr, int H, int W, int training, float* ws, size_t ws_bytes,
+                            void* stream) {
+    if (N <= 0) return 0;
+    if (!dy || !x || !w1 || !w2 || !conv_w || !bn || !cs || !argmax_p || !pooled || !hidden || !comp || !cargmax || !xhat || !ss ||
+        !stats || !dx || !dw1 || !db1 || !dw2 || !db2 || !dconv_w || !dbn || !ws || ((uintptr_t)ws & 15) != 0)
+        return M3T_EINVAL;
+    if (!m3t_cbam_fused_ok(C, Cr, H, W)) return M3T_EINVAL;
+    const int HW = H * W;
+    const size_t total = (size_t)N * HW;
+    if (ws_bytes < m3t_cbam_fused_ws_bytes(N, C, Cr, H, W) - ((size_t)8 << 20)) return M3T_EINVAL;
+    double* part = reinterpret_cast<double*>(ws);
+    float* f = reinterpret_cast<float*>(part + 2 * (size_t)N);
+    float* dgb = f;                              // (d gamma, d beta), 16 B
+    float* dpre = f + 4;                         // [N, HW]
+    float* dwpart = dpre + ((total + 3) & ~(size_t)3);     // [N, 50]
+    float* g_datt = dwpart + (((size_t)N * 50 + 3) & ~(size_t)3);     // [N, C]
+    float* g_dh = g_datt + (size_t)N * C;        // [N, 2, Cr]
+    float* g_r = g_dh + (size_t)N * 2 * Cr;      // [N, Cr]
+    float* rest = g_r + (((size_t)N * Cr + 3) & ~(size_t)3);
+    const size_t used = (size_t)(reinterpret_cast<char*>(rest) - reinterpret_cast<char*>(ws));
+    if (used > ws_bytes) return M3T_EINVAL;
+    const size_t rest_bytes = ws_bytes - used;
+    const void* ptrs[] = {x, dy, dx, ss, xhat, dpre};
+    Geo g;
+    if (!geometry(HW, ptrs, 6, g)) return M3T_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds1 = (size_t)(al4(C) + g.nk * g.Qp * g.E) * sizeof(float), lds2 = b2_lds(C, Cr, HW);
+    if (g.E == 4) cbam_b1_kernel<4><<<N, FT, lds1, s>>>(dy, x, cs, ss, xhat, dpre, part, C, HW, g.Qp);
+    else cbam_b1_kernel<1><<<N, FT, lds1, s>>>(dy, x, cs, ss, xhat, dpre, part, C, HW, g.Qp);
+    M3T_LAUNCH_CHECK();
+    cbam_sum_pairs_kernel<<<1, 256, 0, s>>>(part, N, dgb);
+    M3T_LAUNCH_CHECK();
+    if (g.E == 4) cbam_b2_kernel<4><<<N, FT, lds2, s>>>(dy, x, w1, w2, conv_w, bn, stats, dgb, cs, argmax_p, hidden, comp, cargmax, xhat, ss, dpre, dx, g_datt, g_dh, g_r, dwpart, C, Cr, H, W, g.G, (float)(1.0 / (double)total), training);
+    else cbam_b2_kernel<1><<<N, FT, lds2, s>>>(dy, x, w1, w2, conv_w, bn, stats, dgb, cs, argmax_p, hidden, comp, cargmax, xhat, ss, dpre, dx, g_datt, g_dh, g_r, dwpart, C, Cr, H, W, g.G, (float)(1.0 / (double)total), training);
+    M3T_LAUNCH_CHECK();
+    cbam_dw_final_kernel<<<50, 64, 0, s>>>(dwpart, N, dconv_w);
+    M3T_LAUNCH_CHECK();
+    if (hipMemcpyAsync(dbn, dgb, 2 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return (int)hipGetLastError();
+    int rc;
+    // dW2[C,Cr] = datt^T R ; db2 = 2 * colsum(datt) ; dW1[Cr,C] = dha^T avg + dhm^T max ; db1 = colsum(dha) + colsum(dhm)
+    if ((rc = m3t_sgemm(1, 0, C, Cr, N, g_datt, C, g_r, Cr, dw2, Cr, nullptr, 0, 0, 0, 0, 0, 0, rest, rest_bytes, 0, stream))) return rc;
+    if ((rc = m3t_colsum(g_datt, N, C, C, db2, 0, rest, rest_bytes, stream))) return rc;
+    if ((rc = m3t_colsum(g_datt, N, C, C, db2, 1, rest, rest_bytes, stream))) return rc;
+    if ((rc = m3t_sgemm(1, 0, Cr, C, N, g_dh, 2 * Cr, pooled, 2 * C, dw1, C, nullptr, 0, 0, 0, 0, 0, 0, rest, rest_bytes, 0, stream))) return rc;
+    if ((rc = m3t_sgemm(1, 0, Cr, C, N, g_dh + Cr, 2 * Cr, pooled + C, 2 * C, dw1, C, nullptr, 0, 1, 0, 0, 0, 0, rest, rest_bytes, 0, stream))) return rc;
+    if ((rc = m3t_colsum(g_dh, N, Cr, 2 * Cr, db1, 0, rest, rest_bytes, stream))) return rc;
+    if ((rc = m3t_colsum(g_dh + Cr, N, Cr, 2 * Cr, db1, 1, rest, rest_bytes, stream))) return rc;
+    return 0;
+}

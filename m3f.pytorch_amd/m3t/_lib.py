@@ -78,6 +78,10 @@ SIGNATURES = {
     "m3t_cbam_channel_bwd": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _f, _z, _s],
     "m3t_cbam_spatial_fwd": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, C.c_float, C.c_float, _f, _z, _s],
     "m3t_cbam_spatial_bwd": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _z, _s],
+    "m3t_cbam_fused_ok": [_i, _i, _i, _i],
+    "m3t_cbam_fused_ws_bytes": [_i, _i, _i, _i, _i],
+    "m3t_cbam_fwd": [_f] * 18 + [_i] * 6 + [C.c_float, C.c_float, _f, _z, _s],
+    "m3t_cbam_bwd": [_f] * 22 + [_i] * 6 + [_f, _z, _s],
     "m3t_smooth_tracks": [_f, _f, _i, _i, _i, _f, _s],
     "m3t_ccc_masked": [_f, _f, _f, C.c_longlong, _i, _f, _s],
     "m3t_frame_window": [_f, C.c_longlong, _i, _i, _i, _f, _f, C.c_longlong, _s],
@@ -91,7 +95,7 @@ SIGNATURES = {
     "m3t_sgd_step": [_f, _f, _f, _z, C.c_float, C.c_float, C.c_float, _i, _f, _s],
 }
 
-RESTYPES = {"m3t_bn_rows_ws_bytes": C.c_size_t, "m3t_va_loss_ws_bytes": C.c_size_t}
+RESTYPES = {"m3t_bn_rows_ws_bytes": C.c_size_t, "m3t_va_loss_ws_bytes": C.c_size_t, "m3t_cbam_fused_ws_bytes": C.c_size_t}
 
 _lib = None
 

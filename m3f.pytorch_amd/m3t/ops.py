@@ -1321,6 +1321,74 @@ class _SpatialGate(torch.autograd.Function):
         return dx, dconv, dbn[0:1].clone(), dbn[1:2].clone(), None, None, None, None, None
 
 
+class _CBAM(torch.autograd.Function):
+    """models.cbam.CBAM (reference models/cbam.py:95-111) as ONE operator, csrc/cbam_fused.hip: the intermediate
+    x * channel_scale is never written to memory."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, conv_w, bn_w, bn_b, running_mean, running_var, training, momentum, eps):
+        x = _req(x.contiguous(), "x")
+        for t in (w1, b1, w2, b2, conv_w):
+            _req(t, "cbam parameter")
+        N, Cc, H, W = x.shape
+        Cr, HW = w1.shape[0], H * W
+        dev = x.device
+        new = lambda *shape, dtype=torch.float32: torch.empty(*shape, dtype=dtype, device=dev)
+        bn = torch.cat([bn_w.reshape(1), bn_b.reshape(1)]).contiguous()
+        running = torch.cat([running_mean.reshape(1), running_var.reshape(1)]).contiguous()
+        y = torch.empty_like(x)
+        cs, argmax_p = new(N, Cc), new(N, Cc, dtype=torch.int32)
+        pooled, hidden = new(N, 2, Cc), new(N, 2, Cr)
+        comp, cargmax = new(N, 2, HW), new(N, HW, dtype=torch.int32)
+        xhat, ss, stats = new(N, HW), new(N, HW), new(2)
+        ws = workspace(dev, 16 * N + 256)
+        vp = lambda t: C.c_void_p(t.data_ptr())
+        rc = lib().m3t_cbam_fwd(_p(x), _p(w1), _p(b1), _p(w2), _p(b2), _p(conv_w), _p(bn), _p(running), _p(y), _p(cs), vp(argmax_p),
+                                _p(pooled), _p(hidden), _p(comp), vp(cargmax), _p(xhat), _p(ss), _p(stats), N, Cc, Cr, H, W,
+                                int(training), float(momentum), float(eps), _p(ws), ws.numel() * 4, _stream())
+        _lib.check(rc, "m3t_cbam_fwd")
+        if training:
+            with torch.no_grad():
+                running_mean.copy_(running[0:1])
+                running_var.copy_(running[1:2])
+        ctx.save_for_backward(x, w1, w2, conv_w, bn, cs, argmax_p, pooled, hidden, comp, cargmax, xhat, ss, stats)
+        ctx.training = bool(training)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, w2, conv_w, bn, cs, argmax_p, pooled, hidden, comp, cargmax, xhat, ss, stats = ctx.saved_tensors
+        dy = _req(dy.contiguous(), "dy")
+        N, Cc, H, W = x.shape
+        Cr = w1.shape[0]
+        dev = x.device
+        dx = torch.empty_like(x)
+        dw1, dw2, dconv = torch.empty_like(w1), torch.empty_like(w2), torch.empty_like(conv_w)
+        db1 = torch.empty(Cr, dtype=torch.float32, device=dev)
+        db2 = torch.empty(Cc, dtype=torch.float32, device=dev)
+        dbn = torch.empty(2, dtype=torch.float32, device=dev)
+        ws = workspace(dev, int(lib().m3t_cbam_fused_ws_bytes(N, Cc, Cr, H, W)))
+        vp = lambda t: C.c_void_p(t.data_ptr())
+        rc = lib().m3t_cbam_bwd(_p(dy), _p(x), _p(w1), _p(w2), _p(conv_w), _p(bn), _p(cs), vp(argmax_p), _p(pooled), _p(hidden),
+                                _p(comp), vp(cargmax), _p(xhat), _p(ss), _p(stats), _p(dx), _p(dw1), _p(db1), _p(dw2), _p(db2),
+                                _p(dconv), _p(dbn), N, Cc, Cr, H, W, int(ctx.training), _p(ws), ws.numel() * 4, _stream())
+        _lib.check(rc, "m3t_cbam_bwd")
+        return dx, dw1, db1, dw2, db2, dconv, dbn[0:1].clone(), dbn[1:2].clone(), None, None, None, None, None
+
+
+CBAM_FUSED = [os.environ.get("M3T_CBAM_FUSED", "1") != "0"]      # 0: the two gates as two operators (cbam.hip), for A/B runs
+
+
+def cbam_fused_ok(x, Cr):
+    """the fused CBAM operator covers this input (float32 device tensor [N,C,H,W] with H*W/4 <= 512 units, or H*W <= 512 odd pixels)"""
+    return (CBAM_FUSED[0] and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+            and bool(lib().m3t_cbam_fused_ok(x.shape[1], Cr, x.shape[2], x.shape[3])))
+
+
+def cbam(x, w1, b1, w2, b2, conv_w, bn_w, bn_b, running_mean, running_var, training, momentum=0.01, eps=1e-5):
+    return _CBAM.apply(x, w1, b1, w2, b2, conv_w, bn_w, bn_b, running_mean, running_var, training, momentum, eps)
+
+
 def channel_gate(x, w1, b1, w2, b2):
     return _ChannelGate.apply(x, w1, b1, w2, b2)
 

@@ -593,6 +593,92 @@ def test_cbam_golden(name):
     check_grads(m, g)
 
 
+@pytest.mark.parametrize("name", ["cbam_train", "cbam_eval", "cbam_c64"])
+def test_cbam_golden_two_operator_path(name):
+    """the same goldens through the two separate gates (csrc/cbam.hip: what CBAM.forward uses for maps the fused operator
+    does not cover, and what standalone ChannelGate / SpatialGate modules run)"""
+    from models.cbam import CBAM
+    from m3t import ops
+    g = load_golden(name)
+    m = load_params(CBAM(g["x"].shape[1]), g).to(DEV)
+    m.train(bool(g["training"]))
+    x = dev(g["x"], True)
+    ops.CBAM_FUSED[0] = False
+    try:
+        y = m(x)
+    finally:
+        ops.CBAM_FUSED[0] = True
+    close(y, g["y"], TOL, "y")
+    (y * dev(g["ct"])).sum().backward()
+    close(x.grad, g["dx"], TOL, "dx")
+    check_grads(m, g)
+
+
+@pytest.mark.parametrize("C_,H,W,N,training", [(64, 28, 28, 3, True), (128, 14, 14, 5, True), (256, 7, 7, 6, True), (512, 4, 4, 9, True),
+                                              (64, 28, 28, 2, False), (32, 9, 5, 4, True), (16, 1, 1, 7, True), (48, 20, 20, 2, True),
+                                              (64, 64, 64, 2, True)])
+def test_cbam_stage_shapes_against_the_oracle(C_, H, W, N, training):
+    """the fused operator on every ResNet-18 stage map (28^2 float4 units over two channel slices, 14^2, the ragged 7^2 with
+    single-pixel units, 4^2 with 16 planes per wave pass), odd / degenerate maps, and a 64 x 64 map the fused operator does not
+    cover (falls to the two gates): forward, running statistics, input and parameter gradients against the numpy oracle"""
+    from models.cbam import CBAM
+    from m3t import ops
+    rs = np.random.RandomState(C_ + H)
+    m = fill_module(CBAM(C_), 77).to(DEV)
+    m.train(training)
+    assert bool(ops.cbam_fused_ok(torch.empty(1, C_, H, W, device=DEV), C_ // 16)) == (H * W <= 2048 if (H * W) % 4 == 0 else H * W <= 512)
+    p = {n: t.detach().cpu().numpy().astype(np.float64) for n, t in list(m.named_parameters()) + list(m.named_buffers()) if t.dtype.is_floating_point}
+    xn, ct = draw(rs, (N, C_, H, W)), draw(rs, (N, C_, H, W))
+    x = dev(xn, True)
+    y = m(x)
+    y_ref, cache, (rm, rv) = O.cbam_fwd(xn.astype(np.float64), p, training)
+    close(y, y_ref, TOL, "y")
+    if training:
+        close(m.SpatialGate.spatial.bn.running_mean, rm, 1e-5, "running_mean")
+        close(m.SpatialGate.spatial.bn.running_var, rv, 1e-5, "running_var")
+    (y * dev(ct)).sum().backward()
+    dx_ref, grads = O.cbam_bwd(ct.astype(np.float64), cache, p)
+    close(x.grad, dx_ref, TOL, "dx")
+    for n, q in m.named_parameters():
+        close(q.grad, grads[n], 2e-4, n)
+
+
+def test_cbam_fused_equals_the_two_gates_at_full_size_and_is_deterministic():
+    """2048 frames of the first ResNet stage (64 x 28 x 28, the size bench.py's aux.cbam leg times): the fused operator against
+    the two-operator path on the same inputs (y, dx, every parameter gradient, running statistics), bit-identical reruns"""
+    from models.cbam import CBAM
+    from m3t import ops
+    torch.manual_seed(5)
+    a, b = CBAM(64).to(DEV).train(), CBAM(64).to(DEV).train()
+    with torch.no_grad():
+        a.SpatialGate.spatial.bn.weight.fill_(0.7)          # (ResNet.__init__ zeroes it: the gradient path through the conv would be dead)
+    b.load_state_dict(a.state_dict())
+    x1 = torch.randn(2048, 64, 28, 28, device=DEV, requires_grad=True)
+    x2 = x1.detach().clone().requires_grad_(True)
+    ct = torch.randn_like(x1)
+    y1 = a(x1)
+    y1.backward(ct)
+    ops.CBAM_FUSED[0] = False
+    try:
+        y2 = b(x2)
+        y2.backward(ct)
+    finally:
+        ops.CBAM_FUSED[0] = True
+    sc = lambda t: max(1.0, float(t.abs().max()))
+    assert float((y1 - y2).abs().max()) <= 1e-5 * sc(y2)
+    assert float((x1.grad - x2.grad).abs().max()) <= 1e-5 * sc(x2.grad)
+    for (n, p1), (_, p2) in zip(a.named_parameters(), b.named_parameters()):
+        assert float((p1.grad - p2.grad).abs().max()) <= 2e-4 * sc(p2.grad), (n, float((p1.grad - p2.grad).abs().max()), sc(p2.grad))
+    assert torch.allclose(a.SpatialGate.spatial.bn.running_var, b.SpatialGate.spatial.bn.running_var, rtol=1e-6, atol=0)
+    g1 = [p.grad.clone() for p in a.parameters()]
+    dx1 = x1.grad.clone()
+    a.zero_grad()
+    x1.grad = None
+    y3 = a(x1)
+    y3.backward(ct)
+    assert torch.equal(y1, y3) and torch.equal(dx1, x1.grad) and all(torch.equal(u, p.grad) for u, p in zip(g1, a.parameters()))
+
+
 @pytest.mark.parametrize("name", ["resnet_cbam_eval", "resnet_cbam_train"])
 def test_resnet_cbam_golden(name):
     from models.resnet import ResNet, BasicBlock
