@@ -350,23 +350,24 @@ int m3t_cbam_spatial_bwd(const float* dy, const float* x, const float* conv_w, c
  * for forward + backward against 10 + for the two separate gates above, 7 launches + the parameter-gradient finish.
  * Saved for backward: cs [N,C] (channel scale), argmax_p [N,C], pooled [N,2,C], hidden [N,2,Cr], comp [N,2,HW] (max, mean of
  * x * cs over channels), cargmax [N,HW], xhat [N,HW], ss [N,HW] (spatial scale), stats [2] (mean, 1/sqrt(var+eps)).
- * bn = (gamma, beta), running = (running_mean, running_var) updated in place when training.  m3t_cbam_fused_ok: 1 when the
+ * bn_w / bn_b = BatchNorm2d(1)'s gamma / beta (one float each), running_mean / running_var updated in place when training.  m3t_cbam_fused_ok: 1 when the
  * shape is covered (H*W/4 <= 512 float4 units, or H*W <= 512 pixels when H*W % 4 != 0); otherwise use the two gates above.
  * ws: forward 16 N bytes (8-B aligned), backward m3t_cbam_fused_ws_bytes (16-B aligned).  Results equal the two-operator
  * path to fp32 rounding (other summation order); deterministic. */
 int m3t_cbam_fused_ok(int C, int Cr, int H, int W);
 size_t m3t_cbam_fused_ws_bytes(int N, int C, int Cr, int H, int W);
 int m3t_cbam_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
-                 const float* conv_w, const float* bn, float* running, float* y, float* cs, int32_t* argmax_p,
+                 const float* conv_w, const float* bn_w, const float* bn_b, float* running_mean, float* running_var,
+                 float* y, float* cs, int32_t* argmax_p,
                  float* pooled, float* hidden, float* comp, int32_t* cargmax, float* xhat, float* ss, float* stats,
                  int N, int C, int Cr, int H, int W, int training, float momentum, float eps, float* ws,
                  size_t ws_bytes, void* stream);
 int m3t_cbam_bwd(const float* dy, const float* x, const float* w1, const float* w2, const float* conv_w,
-                 const float* bn, const float* cs, const int32_t* argmax_p, const float* pooled,
+                 const float* bn_w, const float* cs, const int32_t* argmax_p, const float* pooled,
                  const float* hidden, const float* comp, const int32_t* cargmax, const float* xhat, const float* ss,
                  const float* stats, float* dx, float* dw1, float* db1, float* dw2, float* db2, float* dconv_w,
-                 float* dbn, int N, int C, int Cr, int H, int W, int training, float* ws, size_t ws_bytes,
-                 void* stream);
+                 float* dbn_w, float* dbn_b, int N, int C, int Cr, int H, int W, int training, float* ws,
+                 size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * Data-parallel helpers (train.py:32-41: DDP mean of gradients + clip_grad_norm_(1.0)).

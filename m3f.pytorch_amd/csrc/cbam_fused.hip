@@ -71,7 +71,7 @@ template <> struct Unit<1> {
 __host__ __device__ inline int al4(int n) { return (n + 3) & ~3; }
 
 // ------------------------------------------------------------------------------------------------ F1
-template <int E>
+template <int E, bool SMALL>
 __global__ __launch_bounds__(FT) void cbam_f1_kernel(const float* __restrict__ x, const float* __restrict__ w1,
                                                      const float* __restrict__ b1, const float* __restrict__ w2,
                                                      const float* __restrict__ b2, const float* __restrict__ convw,
@@ -97,9 +97,49 @@ __global__ __launch_bounds__(FT) void cbam_f1_kernel(const float* __restrict__ x
     const float* xb = x + (size_t)n * C * HW;
     if (tid < 50) s_w[tid] = convw[tid];
 
-    // ---- a. channel squeeze: avg, max, argmax per plane, G lanes per plane
+    // ---- a. channel squeeze: avg, max, argmax per plane, G lanes per plane.  SMALL (Q <= G: a plane is ONE unit per lane): four
+    // plane groups in flight per wave pass instead of four units of one plane
     {
         const int per = 64 / G, sub = lane % G, pi = lane / G;
+        if (SMALL) {
+            const int step = (FT / 64) * per;
+            for (int c0 = wave * per; c0 < C; c0 += 4 * step) {
+                float v[4][E];
+                bool ok[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int c = c0 + k * step + pi;
+                    ok[k] = c < C && sub < Q;
+                    if (ok[k]) Unit<E>::ld(xb + (size_t)c * HW + (size_t)sub * E, v[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int c = c0 + k * step + pi;
+                    float sum = 0.f, mx = -INFINITY;
+                    int am = 0x7fffffff;
+                    if (ok[k]) {
+#pragma unroll
+                        for (int e = 0; e < E; ++e) {
+                            sum += v[k][e];
+                            if (v[k][e] > mx) { mx = v[k][e]; am = sub * E + e; }
+                        }
+                    }
+                    for (int o = G >> 1; o > 0; o >>= 1) {
+                        sum += __shfl_xor(sum, o, 64);
+                        const float ov = __shfl_xor(mx, o, 64);
+                        const int oi = __shfl_xor(am, o, 64);
+                        if (ov > mx || (ov == mx && oi < am)) { mx = ov; am = oi; }
+                    }
+                    if (sub == 0 && c < C) {
+                        const float avg = sum / (float)HW;
+                        s_avg[c] = avg; s_max[c] = mx;
+                        pooled[((size_t)n * 2 + 0) * C + c] = avg;
+                        pooled[((size_t)n * 2 + 1) * C + c] = mx;
+                        argmax_p[(size_t)n * C + c] = am;
+                    }
+                }
+            }
+        } else
         for (int c0 = wave * per; c0 < C; c0 += (FT / 64) * per) {
             const int c = c0 + pi;
             const bool okc = c < C;
@@ -141,15 +181,29 @@ __global__ __launch_bounds__(FT) void cbam_f1_kernel(const float* __restrict__ x
         }
     }
     __syncthreads();
-    // ---- b. shared MLP C -> Cr -> C on both pooled vectors, sigmoid of the sum (reference cbam.py:51-58)
-    for (int j = wave; j < 2 * Cr; j += FT / 64) {
-        const int which = j / Cr, r = j % Cr;
+    // ---- b. shared MLP C -> Cr -> C on both pooled vectors, sigmoid of the sum (reference cbam.py:51-58).  First layer: 8 lanes per
+    // output, every W1 load of the frame in flight at once (one wave per output, output after output, paid one L2 round trip per
+    // output: 8 in a row at the 4 x 4 stage, where the whole frame is one HBM round trip)
+    for (int j = tid >> 3; j < 2 * Cr; j += FT / 8) {
+        const int which = j / Cr, r = j % Cr, part = tid & 7;
         const float* src = which ? s_max : s_avg;
         const float* wr = w1 + (size_t)r * C;
         float h = 0.f;
-        for (int c = lane; c < C; c += 64) h += wr[c] * src[c];
-        h = wave_sum(h) + b1[r];
-        if (lane == 0) {
+        if ((C & 3) == 0 && ((uintptr_t)w1 & 15) == 0) {
+            const float4* w4 = reinterpret_cast<const float4*>(wr);
+            const float4* s4 = reinterpret_cast<const float4*>(src);
+            for (int c4 = part; c4 < (C >> 2); c4 += 8) {
+                const float4 a = w4[c4], b = s4[c4];
+                h += (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
+            }
+        } else {
+            for (int c = part; c < C; c += 8) h += wr[c] * src[c];
+        }
+        h += __shfl_xor(h, 1, 64);
+        h += __shfl_xor(h, 2, 64);
+        h += __shfl_xor(h, 4, 64);
+        h += b1[r];
+        if (part == 0) {
             hidden[((size_t)n * 2 + which) * Cr + r] = h;
             s_h[j] = fmaxf(h, 0.f);
         }
@@ -278,8 +332,8 @@ __global__ __launch_bounds__(FT) void cbam_f1_kernel(const float* __restrict__ x
 
 // batch statistics of the conv output (train) or the running ones (eval) -> stats = (mean, 1 / sqrt(var + eps))
 __global__ __launch_bounds__(256) void cbam_stats_kernel(const double* __restrict__ part, int nparts, double cnt,
-                                                         float* __restrict__ running, float* __restrict__ stats,
-                                                         int training, float momentum, float eps) {
+                                                         float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                         float* __restrict__ stats, int training, float momentum, float eps) {
     __shared__ double red[4];
     double s1 = 0.0, s2 = 0.0;
     if (training)
@@ -302,19 +356,20 @@ __global__ __launch_bounds__(256) void cbam_stats_kernel(const double* __restric
             stats[0] = (float)mean;
             stats[1] = (float)(1.0 / sqrt(var + (double)eps));
             const double unb = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
-            running[0] = (float)((1.0 - momentum) * running[0] + momentum * mean);
-            running[1] = (float)((1.0 - momentum) * running[1] + momentum * unb);
+            run_mean[0] = (float)((1.0 - momentum) * run_mean[0] + momentum * mean);
+            run_var[0] = (float)((1.0 - momentum) * run_var[0] + momentum * unb);
         } else {
-            stats[0] = running[0];
-            stats[1] = 1.f / sqrtf(running[1] + eps);
+            stats[0] = run_mean[0];
+            stats[1] = 1.f / sqrtf(run_var[0] + eps);
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ F2
-template <int E>
+template <int E, bool SMALL>
 __global__ __launch_bounds__(FT) void cbam_f2_kernel(const float* __restrict__ x, const float* __restrict__ cs,
-                                                     const float* __restrict__ bn, const float* __restrict__ stats,
+                                                     const float* __restrict__ bn_w, const float* __restrict__ bn_b,
+                                                     const float* __restrict__ stats,
                                                      float* __restrict__ xhat, float* __restrict__ ss, float* __restrict__ y,
                                                      int C, int HW, int G) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -322,7 +377,7 @@ __global__ __launch_bounds__(FT) void cbam_f2_kernel(const float* __restrict__ x
     float* s_ss = s_sc + al4(C);
     const int Q = HW / E;
     const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float mean = stats[0], inv = stats[1], ga = bn[0], be = bn[1];
+    const float mean = stats[0], inv = stats[1], ga = bn_w[0], be = bn_b[0];
     for (int p = tid; p < HW; p += FT) {
         const size_t o = (size_t)n * HW + p;
         const float xh = (xhat[o] - mean) * inv;           // xhat holds the raw conv output on entry
@@ -336,6 +391,29 @@ __global__ __launch_bounds__(FT) void cbam_f2_kernel(const float* __restrict__ x
     const float* xb = x + (size_t)n * C * HW;
     float* yb = y + (size_t)n * C * HW;
     const int per = 64 / G, sub = lane % G, pi = lane / G;
+    if (SMALL) {
+        const int step = (FT / 64) * per;
+        for (int c0 = wave * per; c0 < C; c0 += 4 * step) {
+            float v[4][E];
+            bool ok[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = c0 + k * step + pi;
+                ok[k] = c < C && sub < Q;
+                if (ok[k]) Unit<E>::ld(xb + (size_t)c * HW + (size_t)sub * E, v[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (ok[k]) {
+                    const int c = c0 + k * step + pi;
+                    const float sc = s_sc[c];
+#pragma unroll
+                    for (int e = 0; e < E; ++e) v[k][e] *= sc * s_ss[sub * E + e];
+                    Unit<E>::st(yb + (size_t)c * HW + (size_t)sub * E, v[k]);
+                }
+        }
+        return;
+    }
     for (int c0 = wave * per; c0 < C; c0 += (FT / 64) * per) {
         const int c = c0 + pi;
         if (c >= C) continue;
@@ -443,7 +521,8 @@ __global__ __launch_bounds__(FT) void cbam_b1_kernel(const float* __restrict__ d
 }
 
 // out2[0] = sum of part[2i+1] (d gamma), out2[1] = sum of part[2i] (d beta)
-__global__ __launch_bounds__(256) void cbam_sum_pairs_kernel(const double* __restrict__ part, int nparts, float* __restrict__ out_gamma_beta) {
+__global__ __launch_bounds__(256) void cbam_sum_pairs_kernel(const double* __restrict__ part, int nparts, float* __restrict__ out_gamma_beta,
+                                                             float* __restrict__ dbn_w, float* __restrict__ dbn_b) {
     __shared__ double red[4];
     double s1 = 0.0, s2 = 0.0;
     for (int i = threadIdx.x; i < nparts; i += 256) { s1 += part[2 * i]; s2 += part[2 * i + 1]; }
@@ -457,14 +536,23 @@ __global__ __launch_bounds__(256) void cbam_sum_pairs_kernel(const double* __res
         v = (red[0] + red[1]) + (red[2] + red[3]);
         if (pass) s2 = v; else s1 = v;
     }
-    if (threadIdx.x == 0) { out_gamma_beta[0] = (float)s2; out_gamma_beta[1] = (float)s1; }
+    if (threadIdx.x == 0) {
+        out_gamma_beta[0] = (float)s2; out_gamma_beta[1] = (float)s1;
+        dbn_w[0] = (float)s2; dbn_b[0] = (float)s1;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ B2
-template <int E>
+#ifndef M3T_CBAM_B2_UB
+#define M3T_CBAM_B2_UB 2
+#endif
+constexpr int UB = M3T_CBAM_B2_UB;      // units in flight per lane in B2's plane sweeps of large maps: 2 -> 77 VGPRs, three workgroups
+                                        // per CU (4 -> 118, two): 0.996 vs 1.037 ms for the whole gate at 2048 x 64 x 28 x 28
+
+template <int E, bool SMALL>
 __global__ __launch_bounds__(FT) void cbam_b2_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ w1, const float* __restrict__ w2,
-                                                     const float* __restrict__ convw, const float* __restrict__ bn,
+                                                     const float* __restrict__ convw, const float* __restrict__ bn_w,
                                                      const float* __restrict__ stats, const float* __restrict__ dgb,
                                                      const float* __restrict__ cs, const int32_t* __restrict__ argmax_p,
                                                      const float* __restrict__ hidden, const float* __restrict__ comp,
@@ -493,7 +581,7 @@ __global__ __launch_bounds__(FT) void cbam_b2_kernel(const float* __restrict__ d
     const float* gb = dy + (size_t)n * C * HW;
     // ---- a. BatchNorm2d(1) backward per pixel, frame-local copies
     {
-        const float gamma = bn[0], invstd = stats[1];
+        const float gamma = bn_w[0], invstd = stats[1];
         const float m1 = gamma * dgb[1] * inv_total;       // mean(dxhat)
         const float m2 = gamma * dgb[0] * inv_total;       // mean(dxhat * xhat)
         for (int p = tid; p < HW; p += FT) {
@@ -544,23 +632,59 @@ __global__ __launch_bounds__(FT) void cbam_b2_kernel(const float* __restrict__ d
     __syncthreads();
     // ---- d. dcs[c] = sum_p dy1 * x with dy1 = dy * ss + dmean / C + [c == argmax_c] dmax (the spatial gate's input gradient)
     const int per = 64 / G, sub = lane % G, pi = lane / G;
+    if (SMALL) {
+        const int step = (FT / 64) * per;
+        for (int c0 = wave * per; c0 < C; c0 += 4 * step) {
+            float a[4][E], b[4][E];
+            bool ok[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = c0 + k * step + pi;
+                ok[k] = c < C && sub < Q;
+                if (ok[k]) {
+                    Unit<E>::ld(gb + (size_t)c * HW + (size_t)sub * E, a[k]);
+                    Unit<E>::ld(xb + (size_t)c * HW + (size_t)sub * E, b[k]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = c0 + k * step + pi;
+                float ds = 0.f;
+                if (ok[k]) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        const int p = sub * E + e;
+                        const float dy1 = a[k][e] * s_ss[p] + s_dmn[p] + (c == s_cam[p] ? s_dmx[p] : 0.f);
+                        ds += dy1 * b[k][e];
+                    }
+                }
+                for (int o = G >> 1; o > 0; o >>= 1) ds += __shfl_xor(ds, o, 64);
+                if (sub == 0 && c < C) {
+                    const float sc = s_sc[c];
+                    const float da = ds * sc * (1.f - sc);
+                    s_datt[c] = da;
+                    g_datt[(size_t)n * C + c] = da;
+                }
+            }
+        }
+    } else
     for (int c0 = wave * per; c0 < C; c0 += (FT / 64) * per) {
         const int c = c0 + pi;
         const bool okc = c < C;
         const float* pl = xb + (size_t)(okc ? c : 0) * HW;
         const float* gl = gb + (size_t)(okc ? c : 0) * HW;
         float ds = 0.f;
-        for (int u0 = sub; u0 < Q; u0 += 4 * G) {
-            float a[4][E], b[4][E];
-            bool ok[4];
+        for (int u0 = sub; u0 < Q; u0 += UB * G) {
+            float a[UB][E], b[UB][E];
+            bool ok[UB];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < UB; ++k) {
                 const int u = u0 + k * G;
                 ok[k] = okc && u < Q;
                 if (ok[k]) { Unit<E>::ld(gl + (size_t)u * E, a[k]); Unit<E>::ld(pl + (size_t)u * E, b[k]); }
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < UB; ++k)
                 if (ok[k]) {
                     const int u = u0 + k * G;
 #pragma unroll
@@ -615,6 +739,34 @@ __global__ __launch_bounds__(FT) void cbam_b2_kernel(const float* __restrict__ d
     __syncthreads();
     // ---- f. dx = dy1 * cs + davg / HW + [p == argmax_p] dmaxc; dy is re-read while the frame is still cache-hot
     float* db = dx + (size_t)n * C * HW;
+    if (SMALL) {
+        const int step = (FT / 64) * per;
+        for (int c0 = wave * per; c0 < C; c0 += 4 * step) {
+            float a[4][E];
+            bool ok[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = c0 + k * step + pi;
+                ok[k] = c < C && sub < Q;
+                if (ok[k]) Unit<E>::ld(gb + (size_t)c * HW + (size_t)sub * E, a[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (ok[k]) {
+                    const int c = c0 + k * step + pi;
+                    const float sc = s_sc[c], da = s_davg[c], dm = s_dmaxc[c];
+                    const int amp = argmax_p[(size_t)n * C + c];
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        const int p = sub * E + e;
+                        const float dy1 = a[k][e] * s_ss[p] + s_dmn[p] + (c == s_cam[p] ? s_dmx[p] : 0.f);
+                        a[k][e] = dy1 * sc + da + (p == amp ? dm : 0.f);
+                    }
+                    Unit<E>::st(db + (size_t)c * HW + (size_t)sub * E, a[k]);
+                }
+        }
+        return;
+    }
     for (int c0 = wave * per; c0 < C; c0 += (FT / 64) * per) {
         const int c = c0 + pi;
         if (c >= C) continue;
@@ -622,17 +774,17 @@ __global__ __launch_bounds__(FT) void cbam_b2_kernel(const float* __restrict__ d
         const int amp = argmax_p[(size_t)n * C + c];
         const float* gl = gb + (size_t)c * HW;
         float* dl = db + (size_t)c * HW;
-        for (int u0 = sub; u0 < Q; u0 += 4 * G) {
-            float a[4][E];
-            bool ok[4];
+        for (int u0 = sub; u0 < Q; u0 += UB * G) {
+            float a[UB][E];
+            bool ok[UB];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < UB; ++k) {
                 const int u = u0 + k * G;
                 ok[k] = u < Q;
                 if (ok[k]) Unit<E>::ld(gl + (size_t)u * E, a[k]);
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < UB; ++k)
                 if (ok[k]) {
                     const int u = u0 + k * G;
 #pragma unroll
@@ -655,6 +807,87 @@ __global__ __launch_bounds__(64) void cbam_dw_final_kernel(const float* __restri
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if (threadIdx.x == 0) dw[tap] = (float)s;
+}
+
+// ---- parameter gradients of the shared MLP from the per-frame slabs, two launches instead of 3 GEMMs + 3 split-K reduces + 8
+// column-sum kernels (the slabs are small: N x (2 C + 4 Cr) floats; at the 4 x 4 stage those 14 launches were a quarter of the gate)
+//   dW2[c,r] = sum_n datt[n,c] R[n,r]        db2[c] = 2 sum_n datt[n,c]          (reference cbam.py:44-49: mlp.3)
+//   dW1[r,c] = sum_n dha[n,r] avg[n,c] + dhm[n,r] max[n,c]      db1[r] = sum_n dha[n,r] + dhm[n,r]          (mlp.1)
+// stage A: workgroup (channel block of 64, slice of 32 frames) -> partials; stage B: sums the slices in slice order.  Deterministic.
+constexpr int PG_CHUNK = 32;          // frames per workgroup of stage A: N / 32 slices (64 at N = 2048) x C / 64 channel blocks
+__global__ __launch_bounds__(256) void cbam_pgrad_partial_kernel(const float* __restrict__ g_datt, const float* __restrict__ g_r,
+                                                                 const float* __restrict__ g_dh, const float* __restrict__ pooled,
+                                                                 float* __restrict__ part, int N, int C, int Cr) {
+    __shared__ float s_small[PG_CHUNK * 3 * 64];          // per frame of the slice: R[Cr] | dha[Cr] | dhm[Cr]
+    const int cb = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x;
+    const int cl = tid & 63, rg = tid >> 6, c = cb * 64 + cl;
+    const bool okc = c < C;
+    const int n0 = sl * PG_CHUNK, cnt = min(PG_CHUNK, N - n0);
+    for (int i = tid; i < cnt * 3 * Cr; i += 256) {
+        const int f = i / (3 * Cr), j = i - f * 3 * Cr;
+        const int n = n0 + f;
+        s_small[i] = j < Cr ? g_r[(size_t)n * Cr + j] : g_dh[(size_t)n * 2 * Cr + (j - Cr)];
+    }
+    float a2[16], a1[16], sb2 = 0.f, sb1 = 0.f;            // r = rg + 4 i, i < ceil(Cr / 4) <= 16
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { a2[i] = 0.f; a1[i] = 0.f; }
+    const int nr = (Cr + 3) / 4;
+    __syncthreads();
+    for (int f0 = 0; f0 < cnt; f0 += 8) {                  // eight frames' loads in flight
+        float da[8], av[8], mx[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int n = n0 + f0 + k;
+            const bool ok = okc && f0 + k < cnt;
+            da[k] = ok ? g_datt[(size_t)n * C + c] : 0.f;
+            av[k] = ok ? pooled[((size_t)n * 2 + 0) * C + c] : 0.f;
+            mx[k] = ok ? pooled[((size_t)n * 2 + 1) * C + c] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (f0 + k >= cnt) break;
+            const float* sm3 = s_small + (f0 + k) * 3 * Cr;
+            sb2 += da[k];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int r = rg + 4 * i;
+                if (i < nr && r < Cr) {
+                    a2[i] += da[k] * sm3[r];
+                    a1[i] += sm3[Cr + r] * av[k] + sm3[2 * Cr + r] * mx[k];
+                }
+            }
+            if (cb == 0 && tid < Cr) sb1 += sm3[Cr + tid] + sm3[2 * Cr + tid];
+        }
+    }
+    // partial layout per slice: dW2 [C][Cr] | dW1 [Cr][C] | db2 [C] | db1 [Cr]
+    float* ps = part + (size_t)sl * (2 * (size_t)C * Cr + C + Cr);
+    if (okc) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = rg + 4 * i;
+            if (i < nr && r < Cr) {
+                ps[(size_t)c * Cr + r] = a2[i];
+                ps[(size_t)C * Cr + (size_t)r * C + c] = a1[i];
+            }
+        }
+        if (rg == 0) ps[2 * (size_t)C * Cr + c] = 2.f * sb2;
+    }
+    if (cb == 0 && tid < Cr) ps[2 * (size_t)C * Cr + C + tid] = sb1;
+}
+
+__global__ __launch_bounds__(256) void cbam_pgrad_final_kernel(const float* __restrict__ part, int slices, int C, int Cr,
+                                                               float* __restrict__ dw2, float* __restrict__ dw1,
+                                                               float* __restrict__ db2, float* __restrict__ db1) {
+    const size_t per = 2 * (size_t)C * Cr + C + Cr;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < per; i += (size_t)gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < slices; ++k) s += part[(size_t)k * per + i];
+        const size_t cc = (size_t)C * Cr;
+        if (i < cc) dw2[i] = s;
+        else if (i < 2 * cc) dw1[i - cc] = s;
+        else if (i < 2 * cc + C) db2[i - 2 * cc] = s;
+        else db1[i - 2 * cc - C] = s;
+    }
 }
 
 struct Geo { int E, Q, G, Qp, nk; };
@@ -688,10 +921,6 @@ size_t b2_lds(int C, int Cr, int HW) {
 
 }  // namespace
 
-extern "C" int m3t_sgemm(int, int, int, int, int, const float*, int, const float*, int, float*, int, const float*, int, int,
-                         int, int, int, int, float*, size_t, int, void*);
-extern "C" int m3t_colsum(const float*, int, int, int, float*, int, float*, size_t, void*);
-
 extern "C" int m3t_cbam_fused_ok(int C, int Cr, int H, int W) {
     if (C <= 0 || Cr <= 0 || Cr > 64 || H <= 0 || W <= 0) return 0;
     const int HW = H * W;
@@ -703,17 +932,18 @@ extern "C" int m3t_cbam_fused_ok(int C, int Cr, int H, int W) {
 extern "C" size_t m3t_cbam_fused_ws_bytes(int N, int C, int Cr, int H, int W) {
     // doubles: part[2 N]; floats: dgb[2 -> 4], dpre[N HW], dwpart[N 50], g_datt[N C], g_dh[N 2 Cr], g_r[N Cr] + GEMM scratch
     const size_t HW = (size_t)H * W;
-    return (size_t)N * 2 * sizeof(double) + ((size_t)4 + N * HW + (size_t)N * 50 + (size_t)N * (C + 3 * Cr)) * sizeof(float) + 256 +
-           ((size_t)8 << 20);
+    return (size_t)N * 2 * sizeof(double) + ((size_t)4 + N * HW + (size_t)N * 50 + (size_t)N * (C + 3 * Cr) +
+                                             (size_t)((N + PG_CHUNK - 1) / PG_CHUNK) * (2 * (size_t)C * Cr + C + Cr)) * sizeof(float) + 256;
 }
 
 extern "C" int m3t_cbam_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
-                            const float* conv_w, const float* bn, float* running, float* y, float* cs, int32_t* argmax_p,
+                            const float* conv_w, const float* bn_w, const float* bn_b, float* running_mean, float* running_var,
+                            float* y, float* cs, int32_t* argmax_p,
                             float* pooled, float* hidden, float* comp, int32_t* cargmax, float* xhat, float* ss, float* stats,
                             int N, int C, int Cr, int H, int W, int training, float momentum, float eps, float* ws,
                             size_t ws_bytes, void* stream) {
     if (N <= 0) return 0;
-    if (!x || !w1 || !b1 || !w2 || !b2 || !conv_w || !bn || !running || !y || !cs || !argmax_p || !pooled || !hidden || !comp ||
+    if (!x || !w1 || !b1 || !w2 || !b2 || !conv_w || !bn_w || !bn_b || !running_mean || !running_var || !y || !cs || !argmax_p || !pooled || !hidden || !comp ||
         !cargmax || !xhat || !ss || !stats || !ws || ((uintptr_t)ws & 7) != 0)
         return M3T_EINVAL;
     if (!m3t_cbam_fused_ok(C, Cr, H, W)) return M3T_EINVAL;
@@ -725,31 +955,35 @@ extern "C" int m3t_cbam_fwd(const float* x, const float* w1, const float* b1, co
     hipStream_t s = (hipStream_t)stream;
     double* part = reinterpret_cast<double*>(ws);
     const size_t lds1 = f1_lds(C, Cr, HW, g), lds2 = (size_t)(al4(C) + al4(HW)) * sizeof(float);
-    if (g.E == 4) cbam_f1_kernel<4><<<N, FT, lds1, s>>>(x, w1, b1, w2, b2, conv_w, cs, argmax_p, pooled, hidden, comp, cargmax, xhat, part, C, Cr, H, W, g.G, g.Qp);
-    else cbam_f1_kernel<1><<<N, FT, lds1, s>>>(x, w1, b1, w2, b2, conv_w, cs, argmax_p, pooled, hidden, comp, cargmax, xhat, part, C, Cr, H, W, g.G, g.Qp);
+    const bool small = g.Q <= g.G;       // one unit per lane per plane: batch planes instead of units
+#define M3T_CBAM_PICK(K, ...)                                                 \
+    do {                                                                     \
+        if (g.E == 4) { if (small) K<4, true> __VA_ARGS__; else K<4, false> __VA_ARGS__; } \
+        else { if (small) K<1, true> __VA_ARGS__; else K<1, false> __VA_ARGS__; }         \
+    } while (0)
+    M3T_CBAM_PICK(cbam_f1_kernel, <<<N, FT, lds1, s>>>(x, w1, b1, w2, b2, conv_w, cs, argmax_p, pooled, hidden, comp, cargmax, xhat, part, C, Cr, H, W, g.G, g.Qp));
     M3T_LAUNCH_CHECK();
-    cbam_stats_kernel<<<1, 256, 0, s>>>(part, N, (double)N * HW, running, stats, training, momentum, eps);
+    cbam_stats_kernel<<<1, 256, 0, s>>>(part, N, (double)N * HW, running_mean, running_var, stats, training, momentum, eps);
     M3T_LAUNCH_CHECK();
-    if (g.E == 4) cbam_f2_kernel<4><<<N, FT, lds2, s>>>(x, cs, bn, stats, xhat, ss, y, C, HW, g.G);
-    else cbam_f2_kernel<1><<<N, FT, lds2, s>>>(x, cs, bn, stats, xhat, ss, y, C, HW, g.G);
+    M3T_CBAM_PICK(cbam_f2_kernel, <<<N, FT, lds2, s>>>(x, cs, bn_w, bn_b, stats, xhat, ss, y, C, HW, g.G));
     M3T_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int m3t_cbam_bwd(const float* dy, const float* x, const float* w1, const float* w2, const float* conv_w,
-                            const float* bn, const float* cs, const int32_t* argmax_p, const float* pooled,
+                            const float* bn_w, const float* cs, const int32_t* argmax_p, const float* pooled,
                             const float* hidden, const float* comp, const int32_t* cargmax, const float* xhat, const float* ss,
                             const float* stats, float* dx, float* dw1, float* db1, float* dw2, float* db2, float* dconv_w,
-                            float* dbn, int N, int C, int Cr, int H, int W, int training, float* ws, size_t ws_bytes,
-                            void* stream) {
+                            float* dbn_w, float* dbn_b, int N, int C, int Cr, int H, int W, int training, float* ws,
+                            size_t ws_bytes, void* stream) {
     if (N <= 0) return 0;
-    if (!dy || !x || !w1 || !w2 || !conv_w || !bn || !cs || !argmax_p || !pooled || !hidden || !comp || !cargmax || !xhat || !ss ||
-        !stats || !dx || !dw1 || !db1 || !dw2 || !db2 || !dconv_w || !dbn || !ws || ((uintptr_t)ws & 15) != 0)
+    if (!dy || !x || !w1 || !w2 || !conv_w || !bn_w || !cs || !argmax_p || !pooled || !hidden || !comp || !cargmax || !xhat || !ss ||
+        !stats || !dx || !dw1 || !db1 || !dw2 || !db2 || !dconv_w || !dbn_w || !dbn_b || !ws || ((uintptr_t)ws & 15) != 0)
         return M3T_EINVAL;
     if (!m3t_cbam_fused_ok(C, Cr, H, W)) return M3T_EINVAL;
     const int HW = H * W;
     const size_t total = (size_t)N * HW;
-    if (ws_bytes < m3t_cbam_fused_ws_bytes(N, C, Cr, H, W) - ((size_t)8 << 20)) return M3T_EINVAL;
+    if (ws_bytes < m3t_cbam_fused_ws_bytes(N, C, Cr, H, W) || Cr > 64) return M3T_EINVAL;
     double* part = reinterpret_cast<double*>(ws);
     float* f = reinterpret_cast<float*>(part + 2 * (size_t)N);
     float* dgb = f;                              // (d gamma, d beta), 16 B
@@ -758,10 +992,7 @@ extern "C" int m3t_cbam_bwd(const float* dy, const float* x, const float* w1, co
     float* g_datt = dwpart + (((size_t)N * 50 + 3) & ~(size_t)3);     // [N, C]
     float* g_dh = g_datt + (size_t)N * C;        // [N, 2, Cr]
     float* g_r = g_dh + (size_t)N * 2 * Cr;      // [N, Cr]
-    float* rest = g_r + (((size_t)N * Cr + 3) & ~(size_t)3);
-    const size_t used = (size_t)(reinterpret_cast<char*>(rest) - reinterpret_cast<char*>(ws));
-    if (used > ws_bytes) return M3T_EINVAL;
-    const size_t rest_bytes = ws_bytes - used;
+    float* pgpart = g_r + (((size_t)N * Cr + 3) & ~(size_t)3);      // [N / 32 slices][2 C Cr + C + Cr]
     const void* ptrs[] = {x, dy, dx, ss, xhat, dpre};
     Geo g;
     if (!geometry(HW, ptrs, 6, g)) return M3T_EINVAL;
@@ -770,22 +1001,19 @@ extern "C" int m3t_cbam_bwd(const float* dy, const float* x, const float* w1, co
     if (g.E == 4) cbam_b1_kernel<4><<<N, FT, lds1, s>>>(dy, x, cs, ss, xhat, dpre, part, C, HW, g.Qp);
     else cbam_b1_kernel<1><<<N, FT, lds1, s>>>(dy, x, cs, ss, xhat, dpre, part, C, HW, g.Qp);
     M3T_LAUNCH_CHECK();
-    cbam_sum_pairs_kernel<<<1, 256, 0, s>>>(part, N, dgb);
+    cbam_sum_pairs_kernel<<<1, 256, 0, s>>>(part, N, dgb, dbn_w, dbn_b);
     M3T_LAUNCH_CHECK();
-    if (g.E == 4) cbam_b2_kernel<4><<<N, FT, lds2, s>>>(dy, x, w1, w2, conv_w, bn, stats, dgb, cs, argmax_p, hidden, comp, cargmax, xhat, ss, dpre, dx, g_datt, g_dh, g_r, dwpart, C, Cr, H, W, g.G, (float)(1.0 / (double)total), training);
-    else cbam_b2_kernel<1><<<N, FT, lds2, s>>>(dy, x, w1, w2, conv_w, bn, stats, dgb, cs, argmax_p, hidden, comp, cargmax, xhat, ss, dpre, dx, g_datt, g_dh, g_r, dwpart, C, Cr, H, W, g.G, (float)(1.0 / (double)total), training);
+    const bool small = g.Q <= g.G;
+    M3T_CBAM_PICK(cbam_b2_kernel, <<<N, FT, lds2, s>>>(dy, x, w1, w2, conv_w, bn_w, stats, dgb, cs, argmax_p, hidden, comp, cargmax, xhat, ss, dpre, dx, g_datt, g_dh, g_r, dwpart, C, Cr, H, W, g.G, (float)(1.0 / (double)total), training));
     M3T_LAUNCH_CHECK();
     cbam_dw_final_kernel<<<50, 64, 0, s>>>(dwpart, N, dconv_w);
     M3T_LAUNCH_CHECK();
-    if (hipMemcpyAsync(dbn, dgb, 2 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return (int)hipGetLastError();
-    int rc;
-    // dW2[C,Cr] = datt^T R ; db2 = 2 * colsum(datt) ; dW1[Cr,C] = dha^T avg + dhm^T max ; db1 = colsum(dha) + colsum(dhm)
-    if ((rc = m3t_sgemm(1, 0, C, Cr, N, g_datt, C, g_r, Cr, dw2, Cr, nullptr, 0, 0, 0, 0, 0, 0, rest, rest_bytes, 0, stream))) return rc;
-    if ((rc = m3t_colsum(g_datt, N, C, C, db2, 0, rest, rest_bytes, stream))) return rc;
-    if ((rc = m3t_colsum(g_datt, N, C, C, db2, 1, rest, rest_bytes, stream))) return rc;
-    if ((rc = m3t_sgemm(1, 0, Cr, C, N, g_dh, 2 * Cr, pooled, 2 * C, dw1, C, nullptr, 0, 0, 0, 0, 0, 0, rest, rest_bytes, 0, stream))) return rc;
-    if ((rc = m3t_sgemm(1, 0, Cr, C, N, g_dh + Cr, 2 * Cr, pooled + C, 2 * C, dw1, C, nullptr, 0, 1, 0, 0, 0, 0, rest, rest_bytes, 0, stream))) return rc;
-    if ((rc = m3t_colsum(g_dh, N, Cr, 2 * Cr, db1, 0, rest, rest_bytes, stream))) return rc;
-    if ((rc = m3t_colsum(g_dh + Cr, N, Cr, 2 * Cr, db1, 1, rest, rest_bytes, stream))) return rc;
+    const int slices = (N + PG_CHUNK - 1) / PG_CHUNK;
+    cbam_pgrad_partial_kernel<<<dim3((C + 63) / 64, slices), 256, 0, s>>>(g_datt, g_r, g_dh, pooled, pgpart, N, C, Cr);
+    M3T_LAUNCH_CHECK();
+    int fb = (int)((2 * (size_t)C * Cr + C + Cr + 255) / 256);
+    if (fb > 256) fb = 256;
+    cbam_pgrad_final_kernel<<<fb, 256, 0, s>>>(pgpart, slices, C, Cr, dw2, dw1, db2, db1);
+    M3T_LAUNCH_CHECK();
     return 0;
 }

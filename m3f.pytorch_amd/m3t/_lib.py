@@ -80,8 +80,8 @@ SIGNATURES = {
     "m3t_cbam_spatial_bwd": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _z, _s],
     "m3t_cbam_fused_ok": [_i, _i, _i, _i],
     "m3t_cbam_fused_ws_bytes": [_i, _i, _i, _i, _i],
-    "m3t_cbam_fwd": [_f] * 18 + [_i] * 6 + [C.c_float, C.c_float, _f, _z, _s],
-    "m3t_cbam_bwd": [_f] * 22 + [_i] * 6 + [_f, _z, _s],
+    "m3t_cbam_fwd": [_f] * 20 + [_i] * 6 + [C.c_float, C.c_float, _f, _z, _s],
+    "m3t_cbam_bwd": [_f] * 23 + [_i] * 6 + [_f, _z, _s],
     "m3t_smooth_tracks": [_f, _f, _i, _i, _i, _f, _s],
     "m3t_ccc_masked": [_f, _f, _f, C.c_longlong, _i, _f, _s],
     "m3t_frame_window": [_f, C.c_longlong, _i, _i, _i, _f, _f, C.c_longlong, _s],

@@ -1323,57 +1323,63 @@ class _SpatialGate(torch.autograd.Function):
 
 class _CBAM(torch.autograd.Function):
     """models.cbam.CBAM (reference models/cbam.py:95-111) as ONE operator, csrc/cbam_fused.hip: the intermediate
-    x * channel_scale is never written to memory."""
+    x * channel_scale is never written to memory.  BatchNorm parameters and running statistics are handed over as they
+    are (one float each): no staging copies."""
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, conv_w, bn_w, bn_b, running_mean, running_var, training, momentum, eps):
         x = _req(x.contiguous(), "x")
-        for t in (w1, b1, w2, b2, conv_w):
+        for t in (w1, b1, w2, b2, conv_w, bn_w, bn_b, running_mean, running_var):
             _req(t, "cbam parameter")
         N, Cc, H, W = x.shape
         Cr, HW = w1.shape[0], H * W
         dev = x.device
-        new = lambda *shape, dtype=torch.float32: torch.empty(*shape, dtype=dtype, device=dev)
-        bn = torch.cat([bn_w.reshape(1), bn_b.reshape(1)]).contiguous()
-        running = torch.cat([running_mean.reshape(1), running_var.reshape(1)]).contiguous()
         y = torch.empty_like(x)
-        cs, argmax_p = new(N, Cc), new(N, Cc, dtype=torch.int32)
-        pooled, hidden = new(N, 2, Cc), new(N, 2, Cr)
-        comp, cargmax = new(N, 2, HW), new(N, HW, dtype=torch.int32)
-        xhat, ss, stats = new(N, HW), new(N, HW), new(2)
+        # everything backward needs besides x, in ONE allocation: cs [N,C] | pooled [N,2,C] | hidden [N,2,Cr] | comp [N,2,HW] |
+        # xhat [N,HW] | ss [N,HW] | stats [4] | argmax_p [N,C] (int32) | cargmax [N,HW] (int32); every part starts 16-B aligned
+        sizes = [N * Cc, 2 * N * Cc, 2 * N * Cr, 2 * N * HW, N * HW, N * HW, 4, N * Cc, N * HW]
+        offs, tot = [], 0
+        for n_ in sizes:
+            offs.append(tot)
+            tot += (n_ + 3) // 4 * 4
+        buf = torch.empty(tot, dtype=torch.float32, device=dev)
         ws = workspace(dev, 16 * N + 256)
-        vp = lambda t: C.c_void_p(t.data_ptr())
-        rc = lib().m3t_cbam_fwd(_p(x), _p(w1), _p(b1), _p(w2), _p(b2), _p(conv_w), _p(bn), _p(running), _p(y), _p(cs), vp(argmax_p),
-                                _p(pooled), _p(hidden), _p(comp), vp(cargmax), _p(xhat), _p(ss), _p(stats), N, Cc, Cr, H, W,
-                                int(training), float(momentum), float(eps), _p(ws), ws.numel() * 4, _stream())
+        ptr = lambda i: C.c_void_p(buf.data_ptr() + 4 * offs[i])
+        rc = lib().m3t_cbam_fwd(_p(x), _p(w1), _p(b1), _p(w2), _p(b2), _p(conv_w), _p(bn_w), _p(bn_b), _p(running_mean),
+                                _p(running_var), _p(y), ptr(0), ptr(7), ptr(1), ptr(2), ptr(3), ptr(8), ptr(4), ptr(5), ptr(6),
+                                N, Cc, Cr, H, W, int(training), float(momentum), float(eps), _p(ws), ws.numel() * 4, _stream())
         _lib.check(rc, "m3t_cbam_fwd")
-        if training:
-            with torch.no_grad():
-                running_mean.copy_(running[0:1])
-                running_var.copy_(running[1:2])
-        ctx.save_for_backward(x, w1, w2, conv_w, bn, cs, argmax_p, pooled, hidden, comp, cargmax, xhat, ss, stats)
+        ctx.save_for_backward(x, w1, w2, conv_w, bn_w, buf)
+        ctx.offs = offs
         ctx.training = bool(training)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w1, w2, conv_w, bn, cs, argmax_p, pooled, hidden, comp, cargmax, xhat, ss, stats = ctx.saved_tensors
+        x, w1, w2, conv_w, bn_w, buf = ctx.saved_tensors
+        offs = ctx.offs
         dy = _req(dy.contiguous(), "dy")
         N, Cc, H, W = x.shape
         Cr = w1.shape[0]
         dev = x.device
         dx = torch.empty_like(x)
-        dw1, dw2, dconv = torch.empty_like(w1), torch.empty_like(w2), torch.empty_like(conv_w)
-        db1 = torch.empty(Cr, dtype=torch.float32, device=dev)
-        db2 = torch.empty(Cc, dtype=torch.float32, device=dev)
-        dbn = torch.empty(2, dtype=torch.float32, device=dev)
+        # parameter gradients in one allocation too: dw1 [Cr,C] | dw2 [C,Cr] | db1 [Cr] | db2 [C] | dconv [50] | dbn_w [1] | dbn_b [1]
+        sz = [Cr * Cc, Cc * Cr, Cr, Cc, 50, 1, 1]
+        go, tot = [], 0
+        for n_ in sz:
+            go.append(tot)
+            tot += (n_ + 3) // 4 * 4
+        gbuf = torch.empty(tot, dtype=torch.float32, device=dev)
         ws = workspace(dev, int(lib().m3t_cbam_fused_ws_bytes(N, Cc, Cr, H, W)))
-        vp = lambda t: C.c_void_p(t.data_ptr())
-        rc = lib().m3t_cbam_bwd(_p(dy), _p(x), _p(w1), _p(w2), _p(conv_w), _p(bn), _p(cs), vp(argmax_p), _p(pooled), _p(hidden),
-                                _p(comp), vp(cargmax), _p(xhat), _p(ss), _p(stats), _p(dx), _p(dw1), _p(db1), _p(dw2), _p(db2),
-                                _p(dconv), _p(dbn), N, Cc, Cr, H, W, int(ctx.training), _p(ws), ws.numel() * 4, _stream())
+        ptr = lambda i: C.c_void_p(buf.data_ptr() + 4 * offs[i])
+        gp = lambda i: C.c_void_p(gbuf.data_ptr() + 4 * go[i])
+        rc = lib().m3t_cbam_bwd(_p(dy), _p(x), _p(w1), _p(w2), _p(conv_w), _p(bn_w), ptr(0), ptr(7), ptr(1), ptr(2), ptr(3), ptr(8),
+                                ptr(4), ptr(5), ptr(6), _p(dx), gp(0), gp(2), gp(1), gp(3), gp(4), gp(5), gp(6),
+                                N, Cc, Cr, H, W, int(ctx.training), _p(ws), ws.numel() * 4, _stream())
         _lib.check(rc, "m3t_cbam_bwd")
-        return dx, dw1, db1, dw2, db2, dconv, dbn[0:1].clone(), dbn[1:2].clone(), None, None, None, None, None
+        view = lambda i, shape: gbuf[go[i]:go[i] + sz[i]].view(shape)
+        return (dx, view(0, w1.shape), view(2, (Cr,)), view(1, w2.shape), view(3, (Cc,)), view(4, conv_w.shape), view(5, bn_w.shape),
+                view(6, bn_w.shape), None, None, None, None, None)
 
 
 CBAM_FUSED = [os.environ.get("M3T_CBAM_FUSED", "1") != "0"]      # 0: the two gates as two operators (cbam.hip), for A/B runs

@@ -9,7 +9,11 @@ import torch
 from models.cbam import CBAM
 dev = "cuda:0"
 torch.manual_seed(0)
-for (C, HW, N) in ((64, 28, 2048), (128, 14, 2048), (256, 7, 2048), (512, 4, 2048)):
+SHAPES = ((64, 28, 2048), (128, 14, 2048), (256, 7, 2048), (512, 4, 2048))
+if os.environ.get("CBAM_SHAPES"):      # "C,HW" : one shape only (profiling)
+    c_, hw_ = [int(v) for v in os.environ["CBAM_SHAPES"].split(",")]
+    SHAPES = ((c_, hw_, 2048),)
+for (C, HW, N) in SHAPES:
     m = CBAM(C).to(dev).train()
     x = torch.randn(N, C, HW, HW, device=dev, requires_grad=True)
     dy = torch.randn(N, C, HW, HW, device=dev)
