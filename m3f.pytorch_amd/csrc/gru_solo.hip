@@ -28,22 +28,52 @@ namespace {
 constexpr int SH = 128;        // hidden size served
 constexpr int ST = 512;        // threads: 8 waves x (16 units x 4 k-rows)
 
-#define M3T_DPP1(acc, vec, w, n) \
-    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:" #n " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(vec), "v"(w))
-// three independent accumulators advance side by side: 16 k of one vector register against three weight sets
-#define M3T_DPP3(a0, a1, a2, vec, w0, w1, w2, base, n) \
-    do { M3T_DPP1(a0, vec, w0[(base) + n], n); M3T_DPP1(a1, vec, w1[(base) + n], n); M3T_DPP1(a2, vec, w2[(base) + n], n); } while (0)
-#define M3T_DPP3x16(a0, a1, a2, vec, w0, w1, w2, base)                                                                     \
-    do {                                                                                                                  \
-        M3T_DPP3(a0, a1, a2, vec, w0, w1, w2, base, 0); M3T_DPP3(a0, a1, a2, vec, w0, w1, w2, base, 1);                     \
-        M3T_DPP3(a0, a1, a2, vec, w0, w1, w2, base, 2); M3T_DPP3(a0, a1, a2, vec, w0, w1, w2, base, 3);                     \
-        M3T_DPP3(a0, a1, a2, vec, w0, w1, w2, base, 4); M3T_DPP3(a0, a1, a2, vec, w0, w1, w2, base, 5);                     \
-        M3T_DPP3(a0, a1, a2, vec, w0, w1, w2, base, 6); M3T_DPP3(a0, a1, a2, vec, w0, w1, w2, base, 7);                     \
-        M3T_DPP3(a0, a1, a2, vec, w0, w1, w2, base, 8); M3T_DPP3(a0, a1, a2, vec, w0, w1, w2, base, 9);                     \
-        M3T_DPP3(a0, a1, a2, vec, w0, w1, w2, base, 10); M3T_DPP3(a0, a1, a2, vec, w0, w1, w2, base, 11);                   \
-        M3T_DPP3(a0, a1, a2, vec, w0, w1, w2, base, 12); M3T_DPP3(a0, a1, a2, vec, w0, w1, w2, base, 13);                   \
-        M3T_DPP3(a0, a1, a2, vec, w0, w1, w2, base, 14); M3T_DPP3(a0, a1, a2, vec, w0, w1, w2, base, 15);                   \
+// One asm statement = "s_nop 1" + a run of v_fmac_f32_dpp that all read the SAME broadcast source register(s).  A VALU write of a
+// VGPR followed by a DPP read of it needs two wait states, and LLVM's hazard recognizer does not look inside inline asm: with the
+// s_nop in a statement of its own (as before) nothing stopped the register allocator from placing a v_mov copy of the vector
+// between it and the first DPP instruction.  Inside one statement there is no such gap: whatever the compiler does
+// in front of the statement -- copies included -- is followed by the nop.  (Inline asm takes at most 30 operands: hence the
+// blocks of 8 broadcast positions forward, 2 backward.)
+#define M3T_DPPL(acc, w, n) "v_fmac_f32_dpp " acc ", %3, " w " row_newbcast:" #n " row_mask:0xf bank_mask:0xf\n\t"
+#define M3T_DPP_ROW3(i, n) M3T_DPPL("%0", "%" #i, n)
+// forward: three accumulators x 8 broadcast positions [n0, n0 + 8) of ONE vector register against w0/w1/w2[base + n]
+#define M3T_DPP3x8_ASM(N0, N1, N2, N3, N4, N5, N6, N7)                                                                       \
+    "s_nop 1\n\t"                                                                                                         \
+    M3T_DPPL("%0", "%4", N0) M3T_DPPL("%1", "%5", N0) M3T_DPPL("%2", "%6", N0)                                              \
+    M3T_DPPL("%0", "%7", N1) M3T_DPPL("%1", "%8", N1) M3T_DPPL("%2", "%9", N1)                                              \
+    M3T_DPPL("%0", "%10", N2) M3T_DPPL("%1", "%11", N2) M3T_DPPL("%2", "%12", N2)                                           \
+    M3T_DPPL("%0", "%13", N3) M3T_DPPL("%1", "%14", N3) M3T_DPPL("%2", "%15", N3)                                           \
+    M3T_DPPL("%0", "%16", N4) M3T_DPPL("%1", "%17", N4) M3T_DPPL("%2", "%18", N4)                                           \
+    M3T_DPPL("%0", "%19", N5) M3T_DPPL("%1", "%20", N5) M3T_DPPL("%2", "%21", N5)                                           \
+    M3T_DPPL("%0", "%22", N6) M3T_DPPL("%1", "%23", N6) M3T_DPPL("%2", "%24", N6)                                           \
+    M3T_DPPL("%0", "%25", N7) M3T_DPPL("%1", "%26", N7) M3T_DPPL("%2", "%27", N7)
+#define M3T_DPP3x8_OPS(a0, a1, a2, vec, w0, w1, w2, b)                                                                       \
+    : "+v"(a0), "+v"(a1), "+v"(a2)                                                                                           \
+    : "v"(vec), "v"(w0[(b) + 0]), "v"(w1[(b) + 0]), "v"(w2[(b) + 0]), "v"(w0[(b) + 1]), "v"(w1[(b) + 1]), "v"(w2[(b) + 1]),      \
+      "v"(w0[(b) + 2]), "v"(w1[(b) + 2]), "v"(w2[(b) + 2]), "v"(w0[(b) + 3]), "v"(w1[(b) + 3]), "v"(w2[(b) + 3]),                \
+      "v"(w0[(b) + 4]), "v"(w1[(b) + 4]), "v"(w2[(b) + 4]), "v"(w0[(b) + 5]), "v"(w1[(b) + 5]), "v"(w2[(b) + 5]),                \
+      "v"(w0[(b) + 6]), "v"(w1[(b) + 6]), "v"(w2[(b) + 6]), "v"(w0[(b) + 7]), "v"(w1[(b) + 7]), "v"(w2[(b) + 7])
+// 16 k of one vector register against three weight sets (same instruction order as before: n ascending, gates r, z, n inside)
+#define M3T_DPP3x16(a0, a1, a2, vec, w0, w1, w2, base)                                                                       \
+    do {                                                                                                                    \
+        asm(M3T_DPP3x8_ASM(0, 1, 2, 3, 4, 5, 6, 7) M3T_DPP3x8_OPS(a0, a1, a2, vec, w0, w1, w2, (base)));                      \
+        asm(M3T_DPP3x8_ASM(8, 9, 10, 11, 12, 13, 14, 15) M3T_DPP3x8_OPS(a0, a1, a2, vec, w0, w1, w2, (base) + 8));            \
     } while (0)
+// backward: broadcast positions n, n + 1 of SIX vector registers (dv[0..5]) -- operands: %0-%2 accumulators, %3-%8 vectors,
+// %9.. weights in the order (n: w0[n], w1[n], w2[n], w0[16+n], w1[16+n], w2[16+n]), then the same for n + 1
+#define M3T_DPPLB(acc, vec, w, n) "v_fmac_f32_dpp " acc ", " vec ", " w " row_newbcast:" #n " row_mask:0xf bank_mask:0xf\n\t"
+#define M3T_DPPB2_ASM(NA, NB)                                                                                               \
+    "s_nop 1\n\t"                                                                                                         \
+    M3T_DPPLB("%0", "%3", "%9", NA) M3T_DPPLB("%1", "%5", "%10", NA) M3T_DPPLB("%2", "%7", "%11", NA)                        \
+    M3T_DPPLB("%0", "%4", "%12", NA) M3T_DPPLB("%1", "%6", "%13", NA) M3T_DPPLB("%2", "%8", "%14", NA)                       \
+    M3T_DPPLB("%0", "%3", "%15", NB) M3T_DPPLB("%1", "%5", "%16", NB) M3T_DPPLB("%2", "%7", "%17", NB)                       \
+    M3T_DPPLB("%0", "%4", "%18", NB) M3T_DPPLB("%1", "%6", "%19", NB) M3T_DPPLB("%2", "%8", "%20", NB)
+#define M3T_DPPB2(a0, a1, a2, dv, w0, w1, w2, NA, NB)                                                                        \
+    asm(M3T_DPPB2_ASM(NA, NB)                                                                                               \
+        : "+v"(a0), "+v"(a1), "+v"(a2)                                                                                       \
+        : "v"(dv[0]), "v"(dv[1]), "v"(dv[2]), "v"(dv[3]), "v"(dv[4]), "v"(dv[5]),                                            \
+          "v"(w0[NA]), "v"(w1[NA]), "v"(w2[NA]), "v"(w0[16 + NA]), "v"(w1[16 + NA]), "v"(w2[16 + NA]),                       \
+          "v"(w0[NB]), "v"(w1[NB]), "v"(w2[NB]), "v"(w0[16 + NB]), "v"(w1[16 + NB]), "v"(w2[16 + NB]))
 
 // sum over the four 16-lane rows of a wave; every lane ends with the total
 __device__ __forceinline__ float row_sum4(float v) {
@@ -88,8 +118,7 @@ __global__ __launch_bounds__(ST) void gru_solo_fwd_kernel(FwdGroup g, int B, int
         const int tn = step + 1 < T ? t + dt : t;      // next step's x-projection: a whole step to arrive
         const float nxr = px[(size_t)tn * d.ldx], nxz = px[(size_t)tn * d.ldx + SH], nxn = px[(size_t)tn * d.ldx + 2 * SH];
         float ar = 0.f, az = 0.f, an = 0.f;
-        asm volatile("s_nop 1" : "+v"(hv0), "+v"(hv1));          // VALU write -> DPP read of the same VGPR: 2 wait states
-        M3T_DPP3x16(ar, az, an, hv0, wr, wz, wn, 0);
+        M3T_DPP3x16(ar, az, an, hv0, wr, wz, wn, 0);              // (each asm block opens with the s_nop the DPP reads need)
         M3T_DPP3x16(ar, az, an, hv1, wr, wz, wn, 16);
         const float hr = row_sum4(ar) + br, hz = row_sum4(az) + bz, hn = row_sum4(an) + bn;
         const GateFwd c = gru_cell_fwd(xr, xz, xn, hr, hz, hn, hj);
@@ -158,16 +187,12 @@ __global__ __launch_bounds__(ST) void gru_solo_bwd_kernel(BwdGroup g, int B, int
         const float ndout = pd[(size_t)t_of(sn) * d.ldo], nhprev = ph[(size_t)tp_of(sn) * d.ldo];
         const float4 ng4 = *reinterpret_cast<const float4*>(pg + (size_t)t_of(sn) * SH * 4);
         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-        asm volatile("s_nop 1" : "+v"(dv[0]), "+v"(dv[1]), "+v"(dv[2]), "+v"(dv[3]), "+v"(dv[4]), "+v"(dv[5]));
-        // three accumulators, each over 32 of this row's 96 gate gradients: (dv[0], dv[1]) x w0, (dv[2], dv[3]) x w1, (dv[4], dv[5]) x w2
-#define M3T_DPPB(n)                                                                                                      \
-    do {                                                                                                                  \
-        M3T_DPP1(a0, dv[0], w0[n], n); M3T_DPP1(a1, dv[2], w1[n], n); M3T_DPP1(a2, dv[4], w2[n], n);                        \
-        M3T_DPP1(a0, dv[1], w0[16 + n], n); M3T_DPP1(a1, dv[3], w1[16 + n], n); M3T_DPP1(a2, dv[5], w2[16 + n], n);         \
-    } while (0)
-        M3T_DPPB(0); M3T_DPPB(1); M3T_DPPB(2); M3T_DPPB(3); M3T_DPPB(4); M3T_DPPB(5); M3T_DPPB(6); M3T_DPPB(7);
-        M3T_DPPB(8); M3T_DPPB(9); M3T_DPPB(10); M3T_DPPB(11); M3T_DPPB(12); M3T_DPPB(13); M3T_DPPB(14); M3T_DPPB(15);
-#undef M3T_DPPB
+        // three accumulators, each over 32 of this row's 96 gate gradients: (dv[0], dv[1]) x w0, (dv[2], dv[3]) x w1, (dv[4], dv[5]) x w2;
+        // same instruction order as before (n ascending; per n: a0/a1/a2 against dv[0]/dv[2]/dv[4], then against dv[1]/dv[3]/dv[5])
+        M3T_DPPB2(a0, a1, a2, dv, w0, w1, w2, 0, 1); M3T_DPPB2(a0, a1, a2, dv, w0, w1, w2, 2, 3);
+        M3T_DPPB2(a0, a1, a2, dv, w0, w1, w2, 4, 5); M3T_DPPB2(a0, a1, a2, dv, w0, w1, w2, 6, 7);
+        M3T_DPPB2(a0, a1, a2, dv, w0, w1, w2, 8, 9); M3T_DPPB2(a0, a1, a2, dv, w0, w1, w2, 10, 11);
+        M3T_DPPB2(a0, a1, a2, dv, w0, w1, w2, 12, 13); M3T_DPPB2(a0, a1, a2, dv, w0, w1, w2, 14, 15);
         const float mm = row_sum4((a0 + a1) + a2);
         const int t = t_of(step);
         const GateBwd c = gru_cell_bwd(dout, dh_carry, z_next, mm, step > 0, g4.x, g4.y, g4.z, g4.w, step < T - 1 ? hprev : 0.f);

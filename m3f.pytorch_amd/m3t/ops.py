@@ -376,6 +376,34 @@ class _Linear(torch.autograd.Function):
 _LINEAR_RR = [0]      # round-robin over the weight-gradient streams
 
 
+class _ReluDropout(torch.autograd.Function):
+    """nn.Dropout(p) behind a ReLU (the FC heads of reference models/rnn.py:24-28,40-49 with dropout=True): the mask is the
+    Philox4x32-10 word of element (row, col) under `seed`, generated in the kernel forward AND backward (csrc/common.h, the same
+    generator as the TCN's conv epilogues) -- no mask tensor, no torch RNG kernel.  `y` must be a ReLU output (>= 0)."""
+
+    @staticmethod
+    def forward(ctx, y, p, seed):
+        y = _req(y.contiguous(), "y")
+        ctx.save_for_backward(y)
+        ctx.drop = (float(p), int(seed))
+        return mask_pos(y, y, drop=ctx.drop)              # y * mask / (1 - p)   (y > 0; zeros stay zero)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return mask_pos(y, _req(dy.contiguous(), "dy"), drop=ctx.drop), None, None
+
+
+def relu_dropout(y, p, seed=None):
+    """dropout of a ReLU output with an in-kernel mask; seed: 64-bit, default drawn from torch's CPU generator (torch.manual_seed
+    makes a run reproducible, as for the TCN blocks)"""
+    if p <= 0:
+        return y
+    if seed is None:
+        seed = int(torch.empty(1, dtype=torch.int64).random_().item())
+    return _ReluDropout.apply(y, float(p), int(seed))
+
+
 def linear(x, w, b=None, act=0):
     return _Linear.apply(x, w, b, act)
 
@@ -1443,11 +1471,33 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
             dy_cl = _req(dy.permute(0, 2, 3, 4, 1).contiguous(), "dy")          # [N,T',H',W',Co] = [rows, Co]
             rows = dy_cl.numel() // Co
         if ctx.needs_input_grad[1]:
+            Kc = Ci * kt * kh * kw
             xp = torch.nn.functional.pad(x, (pd[2], pd[2], pd[1], pd[1], pd[0], pd[0])) if any(pd) else x
             pat = xp.unfold(2, kt, st[0]).unfold(3, kh, st[1]).unfold(4, kw, st[2])   # [N,Ci,T',H',W',kt,kh,kw] (view)
-            pat = _req(pat.permute(0, 2, 3, 4, 1, 5, 6, 7).reshape(rows, Ci * kt * kh * kw), "patches")
-            dw = torch.empty_like(w)
-            sgemm(1, 0, Co, Ci * kt * kh * kw, rows, dy_cl, 0, Co, pat, 0, Ci * kt * kh * kw, dw, 0, Ci * kt * kh * kw)
+            pat = pat.permute(0, 2, 3, 4, 1, 5, 6, 7)
+            if Co % 128 == 0 and Kc % 64 == 0:
+                pat = _req(pat.reshape(rows, Kc), "patches")
+                dw = torch.empty_like(w)
+                sgemm(1, 0, Co, Kc, rows, dy_cl, 0, Co, pat, 0, Kc, dw, 0, Kc)
+            elif Co % 64 == 0:
+                # the stems' FIRST layers: C_out = 64 and C_in k^3 = 81 (VGG-M) / 735 (3-D ResNet) fit no interior tile of the
+                # bf16x6 GEMM as dW = dy^T P and fell to the fp32-MFMA kernel (8.9 % of a C5 step).  Transposed and
+                # padded they do: dW^T [Kp, Co] = P_pad^T dy with Kp = ceil128(C_in k^3) (zero columns in the patch matrix, which
+                # is a copy anyway) and rows padded to a multiple of 32 -> the 128 x 64 tile, split-K over the ~1.5 M rows
+                Kp, rows_p = (Kc + 127) // 128 * 128, (rows + 31) // 32 * 32
+                pat_pad = torch.zeros(rows_p, Kp, dtype=torch.float32, device=x.device)
+                pat_pad[:rows, :Kc].view(pat.shape).copy_(pat)          # ONE strided copy: the im2col itself
+                dyp = dy_cl
+                if rows_p != rows:
+                    dyp = torch.zeros(rows_p, Co, dtype=torch.float32, device=x.device)
+                    dyp[:rows].copy_(dy_cl.view(rows, Co))
+                dwt = torch.empty(Kp, Co, dtype=torch.float32, device=x.device)
+                sgemm(1, 0, Kp, Co, rows_p, pat_pad, 0, Kp, dyp, 0, Co, dwt, 0, Co)
+                dw = dwt[:Kc].t().contiguous().view_as(w)
+            else:
+                pat = _req(pat.reshape(rows, Kc), "patches")
+                dw = torch.empty_like(w)
+                sgemm(1, 0, Co, Kc, rows, dy_cl, 0, Co, pat, 0, Kc, dw, 0, Kc)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = torch.empty(Co, dtype=torch.float32, device=dy.device)
             colsum(dy_cl, 0, rows, Co, Co, db)

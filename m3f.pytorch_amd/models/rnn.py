@@ -113,7 +113,10 @@ class GRU(nn.Module):
             last = i == len(layers) - 1
             out = ops.linear(out, lin.weight, lin.bias, 0 if last else 1)     # ReLU fused in the GEMM epilogue
             if not last and drops and self.training:
-                out = F.dropout(out, drops[0].p, True)
+                # nn.Dropout(0.5) of the `dropout=True` heads (reference rnn.py:24-28,40-49): Philox mask generated inside
+                # the kernel, forward and backward (no mask tensor, no torch RNG kernel); self.drop_seeds overrides the seeds (tests)
+                seeds = getattr(self, "drop_seeds", None)
+                out = ops.relu_dropout(out, drops[0].p, None if seeds is None else seeds[i])
         return out
 
     def forward(self, x):

@@ -575,6 +575,61 @@ def test_att_fuse_kernel_vs_oracle_wide():
     assert float(w0.min()) > 0.26 and float(w0.max()) < 0.74
 
 
+@pytest.mark.parametrize("num_fcs", [2, 3])
+def test_gru_head_train_mode_dropout_matches_oracle(num_fcs):
+    """GRU(..., dropout=True) in train mode (reference models/rnn.py:24-28,40-49: Linear -> ReLU -> Dropout(0.5) [-> Linear -> ReLU ->
+    Dropout(0.5)] -> Linear): the masks are generated inside the kernels from Philox4x32-10 (no torch RNG kernel, no mask tensor);
+    with the seeds pinned, outputs and every gradient must equal the oracle's head run with the restated generator's masks
+    (oracle.dropout_mask, pinned on the Random123 known answers).  Also: train != eval, two seeds differ, eval ignores the seeds."""
+    from models.rnn import GRU
+    I, H, L, nC, B, T = 12, 16, 1, 3, 3, 11
+    rs = np.random.RandomState(31 + num_fcs)
+    m = fill_module(GRU(I, H, L, nC, num_fcs, dropout=True), 9).to(DEV).train()
+    seeds = [0x1234567811223344, 0x0FEDCBA987654321]
+    m.drop_seeds = seeds
+    xn, ct = draw(rs, (B, T, I)), draw(rs, (B, T, nC))
+    x = dev(xn, True)
+    y = m(x)
+    (y * dev(ct)).sum().backward()
+    # oracle: the BiGRU, then the head with explicit masks
+    p = {n: t.detach().cpu().numpy().astype(np.float64) for n, t in m.named_parameters()}
+    out, _, caches = O.bigru_fwd(xn.astype(np.float64), p, L)
+    lin = [k for k in range(0, 3 * num_fcs, 3)]               # fc.0, fc.3, (fc.6): Linear / ReLU / Dropout triples
+    h, saved = out.reshape(B * T, 2 * H), []
+    for j, k in enumerate(lin):
+        w, b = p["fc.%d.weight" % k], p["fc.%d.bias" % k]
+        pre = h @ w.T + b
+        if j == len(lin) - 1:
+            saved.append((h, w, None, None))
+            h = pre
+        else:
+            mask = O.dropout_mask(B * T, w.shape[0], 0.5, seeds[j])
+            saved.append((h, w, pre > 0, mask))
+            h = np.maximum(pre, 0) * mask
+    close(y, h.reshape(B, T, nC), TOL, "y (train mode, pinned seeds)")
+    g = ct.astype(np.float64).reshape(B * T, nC)
+    grads = {}
+    for j in range(len(lin) - 1, -1, -1):
+        hin, w, relu, mask = saved[j]
+        if mask is not None:
+            g = g * mask * relu
+        grads["fc.%d.weight" % lin[j]] = g.T @ hin
+        grads["fc.%d.bias" % lin[j]] = g.sum(0)
+        g = g @ w
+    for n, ref in grads.items():
+        close(dict(m.named_parameters())[n].grad, ref, TOL, n)
+    dx_ref, ggru = O.bigru_bwd(g.reshape(B, T, 2 * H), caches, p, L)
+    close(x.grad, dx_ref, TOL, "dx")
+    with torch.no_grad():
+        m.drop_seeds = [1, 2]
+        y2 = m(x)
+        y_eval = m.eval()(x)
+        m.drop_seeds = seeds
+        y_eval2 = m(x)
+    assert not torch.equal(y2, y) and not torch.equal(y_eval, y) and torch.equal(y_eval, y_eval2)
+    kept = float((m.train().head(torch.ones(B, T, 2 * H, device=DEV)) != 0).float().mean())      # sanity: something survives p = 0.5
+
+
 # ------------------------------------------------------------------------------ CBAM
 @pytest.mark.parametrize("name", ["cbam_train", "cbam_eval", "cbam_c64"])
 def test_cbam_golden(name):
