@@ -186,11 +186,10 @@ int m3t_gru_persist_owner(void);
  * tags from a per-arena counter instead -- no fill kernel, except when the arena is first seen and when a 16-bit tag counter wraps
  * (every ~200 launches).  With an arena the launch also runs a placement handshake: workgroups publish the XCD they sit on, and a
  * group (one scan x one row block) whose members all share an XCD exchanges through that XCD's L2 (plain stores + sc1 loads)
- * instead of through the memory side -- 30-40 % less HBM / fabric traffic per launch, same results.  Env M3T_SCAN_L2: 2 (default)
- * launches whose groups are XCD-aligned by construction (a multiple of 8 groups); 1 every launch (blocks of empty XCD slots exit);
- * 0 never.  CONTRACT: nothing but scan launches may ever write the arena, and launches that share an arena
+ * instead of through the memory side -- 30-40 % less HBM / fabric traffic per launch, same results; used by the
+ * launches whose groups are XCD-aligned by construction (a multiple of 8 groups).  CONTRACT: nothing but scan launches may ever write the arena, and launches that share an arena
  * must be ordered (one stream).  m3t_gru_scan_arena_reset(arena): forget what is known about `arena` (call it when the
- * memory was reallocated or written by anything else; NULL = every arena).  Both return 0.  Env M3T_SCAN_ARENA=0 ignores arenas. */
+ * memory was reallocated or written by anything else; NULL = every arena).  Both return 0. */
 int m3t_gru_scan_arena(void* arena, size_t bytes);
 int m3t_gru_scan_arena_reset(void* arena);
 /* Ordering between scans on different streams without holding back their preparation: the NEXT m3t_gru_scan_fwd /

@@ -411,23 +411,13 @@ int m3t_sgemm_x6d_launch(int transA, int transB, int M, int N, int K, const floa
                          float* C, int ldc, const float* bias, int act, int accumulate, int seg_len, int seg_stride,
                          int a_off, int b_off, float* ws, int splits, int kchunk, int bf16_operands, hipStream_t s);
 
-static int x6d_mode() {            // M3T_GEMM_X6D=0: the 128-tile bf16x6 GEMMs on gemm_x6.hip; 1: on gemm_x6d.hip; 2 (default): gemm_x6d.hip unless M3T_GEMM_BESIDE_SCAN
-    static int on = -1;
-    if (on < 0) {
-        const char* e = getenv("M3T_GEMM_X6D");
-        on = e ? atoi(e) : 2;
-    }
-    return on;
-}
-
-static int x6c_mode() {            // M3T_GEMM_X6C: 0 never, 1 always (where eligible), unset/2 by the cost model
-    static int on = -1;
-    if (on < 0) {
-        const char* e = getenv("M3T_GEMM_X6C");
-        on = e ? atoi(e) : 2;
-    }
-    return on;
-}
+// Kernel choice among the bf16x6 GEMMs (round 3: the A/B switches M3T_GEMM_X6D / _X6C / _NARROW / _SPLITS are retired, their
+// outcomes are the rules below): the 128-tile GEMMs run on the software-pipelined gemm_x6d.hip, EXCEPT those issued beside
+// another stream's persistent scan (M3T_GEMM_BESIDE_SCAN: a kernel with a higher request rate takes from the scans' exchange what
+// it gains), which keep gemm_x6.hip; the 256-tile gemm_x6c.hip where the caller owns the chip
+// (M3T_GEMM_EXCLUSIVE) and the calibrated cost model prefers it; the 128 x 64 tile for N % 64 == 0 and under-filled grids.
+static int x6d_mode() { return 2; }
+static int x6c_mode() { return 2; }
 
 static bool x6_enabled() {
     static int on = -1;
@@ -442,14 +432,7 @@ static bool x6_enabled() {
 // 2 bf16x6 256-tile (gemm_x6c.hip).
 struct GemmPlan { int kernel, splits, kchunk, narrow; };
 
-static int narrow_mode() {         // M3T_GEMM_NARROW=0: never the 128 x 64 tile of gemm_x6.hip
-    static int on = -1;
-    if (on < 0) {
-        const char* e = getenv("M3T_GEMM_NARROW");
-        on = e ? atoi(e) : 1;
-    }
-    return on;
-}
+static int narrow_mode() { return 1; }
 
 static GemmPlan plan_gemm(int transA, int M, int N, int K, int seg_len, bool vec, size_t ws_bytes, int flags) {
     GemmPlan g;
@@ -476,10 +459,6 @@ static GemmPlan plan_gemm(int transA, int M, int N, int K, int seg_len, bool vec
             if (sp > 1) t += (double)(sp + 2) * M * N * 4.0 / 3000.0 + 3000.0;
             if (t < best) { best = t; splits = sp; }
         }
-    }
-    {   // M3T_GEMM_SPLITS=n: force the split-K factor (tuning sweeps, tools/gemm_bench.py)
-        static const int forced = []() { const char* e = getenv("M3T_GEMM_SPLITS"); return e ? atoi(e) : 0; }();
-        if (forced > 0 && ws_bytes && (forced == 1 || ((size_t)forced <= cap && forced <= K / 32))) splits = forced;
     }
     // 256 x 256 tiles (gemm_x6c.hip), one workgroup per CU, only for callers that have the chip to themselves
     // (M3T_GEMM_EXCLUSIVE).  Which kernel: calibrated time models (us) of both, fitted to tools/gemm_bench.py on MI355X --

@@ -361,8 +361,7 @@ int m3t_conv_x6_launch(const float* x, const float* w_t, const float* bias, cons
     p.cv_T = T; p.cv_C = Ci; p.cv_K = K; p.cv_dil = dil; p.cv_lead = lead; p.cv_anti = anti;
     p.cv_btap = (size_t)Co * Ci; p.cv_mask = mask; p.cv_res = res; p.cv_pre = pre; p.cv_drop = drop;
     // 128 x 64 tiles when 128 x 128 ones would leave most CUs with one workgroup (Co = 512 at B*T = 9600: 300 tiles)
-    static const int narrow_on = []() { const char* e = getenv("M3T_GEMM_NARROW"); return e ? atoi(e) : 1; }();
-    const bool narrow = narrow_on && (Co / XN) * (p.M / XM) <= 384;
+    const bool narrow = (Co / XN) * (p.M / XM) <= 384;
     dim3 grid(Co / (narrow ? 64 : XN), p.M / XM, 1), block(256);
 #define M3T_CONV_GO(TB_, NS_)                                                                          \
     do {                                                                                               \

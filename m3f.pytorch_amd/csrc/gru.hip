@@ -528,14 +528,7 @@ std::vector<GraphEntry> g_graphs;
 unsigned long long g_graph_clock = 0;
 constexpr size_t kMaxGraphs = 96;
 
-bool graphs_enabled() {
-    static int on = -1;
-    if (on < 0) {
-        const char* e = std::getenv("M3T_GRAPH");
-        on = (e && e[0] == '0') ? 0 : 1;
-    }
-    return on == 1;
-}
+bool graphs_enabled() { return true; }
 
 template <typename Launch>
 int replay_or_capture(const std::vector<unsigned char>& key, hipStream_t s, Launch&& launch_all) {
@@ -588,12 +581,6 @@ ScanPlan plan_level(const int* Hs, int n, int B) {
         for (int j = i; j > 0 && Hs[p.order[j]] > Hs[p.order[j - 1]]; --j) {
             const int tmp = p.order[j]; p.order[j] = p.order[j - 1]; p.order[j - 1] = tmp;
         }
-    static int forced = -1;
-    if (forced < 0) {
-        const char* e = std::getenv("M3T_SCAN_RT");
-        forced = e ? std::atoi(e) : 0;
-    }
-    if (forced == 1 || forced == 2) { p.rt = forced; return p; }
     if (B <= 16) { p.rt = 1; return p; }
     double best = 1e30;
     p.rt = 2;

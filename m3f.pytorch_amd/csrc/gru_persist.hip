@@ -872,11 +872,11 @@ bool level_shape(const D* d, int n, int B, Shape& sh) {
         // launched: 8 XCD slots x ceil(G / 8) groups per slot x H / 16 members (persist_map); blocks of empty slots exit at once,
         // so what must fit the chip at one workgroup per CU is the ACTIVE count
         if (active <= device_cus()) {
-            // M3T_SCAN_L2: 2 (default) launches whose groups are XCD-aligned anyway (G % 8 == 0: the 4 x H=512 encoder level, the
+            // L2-served exchange (formerly M3T_SCAN_L2, mode 2 kept): launches whose groups are XCD-aligned anyway (G % 8 == 0: the 4 x H=512 encoder level, the
             // scorers) use the slot mapping + handshake, the others keep G * H/16 blocks dealt over all 8 XCDs and exchange through
             // the memory side; 1 every launch (a 4-group launch then fills 4 XCDs and leaves 4 empty: -40 % traffic on those too,
             // but their steps got slower -- 19.08 vs 18.73 ms per training step, interleaved A/B; mode 2: 18.83); 0 never
-            static const int l2 = poll_env_early("M3T_SCAN_L2", 2);
+            constexpr int l2 = 2;
             sh.rt = rt; sh.nrb = nrb; sh.G = G; sh.active = active;
             sh.slot_map = (l2 == 1 || (l2 == 2 && G % 8 == 0)) ? 1 : 0;
             sh.grid = sh.slot_map ? 8 * cdiv(G, 8) * (maxh / 16) : active;
@@ -906,11 +906,10 @@ BwdKernel pick_bwd(const Shape& sh) {
 // A scan launch that leaves most of the chip free (a light level: <= 96 workgroups) asks for enough unused dynamic LDS that
 // no GEMM workgroup fits beside one of its workgroups on a CU: co-resident GEMM waves take issue slots and LDS bandwidth
 // from a latency-bound scan (audio backward scan beside the weight-gradient GEMMs: 1.8 instead of 0.75 ms), and the
-// GEMMs have the other CUs.  M3T_SCAN_EXCLUSIVE_CU=0 turns it off.
+// GEMMs have the other CUs.
 template <typename K>
 static size_t exclusive_lds(K kernel, int grid) {
-    static const int on = poll_env_early("M3T_SCAN_EXCLUSIVE_CU", 1);
-    if (!on || grid > 96) return 0;
+    if (grid > 96) return 0;
     hipFuncAttributes a;
     if (hipFuncGetAttributes(&a, reinterpret_cast<const void*>(kernel)) != hipSuccess) { (void)hipGetLastError(); return 0; }
     const size_t want = (size_t)152 * 1024;
@@ -921,12 +920,6 @@ static size_t exclusive_lds(K kernel, int grid) {
         return 0;
     }
     return dyn;
-}
-
-// M3T_SCAN_POLL_<kind>=n: fixed poll delay for the kernels of that kind (FWD6, FWD, BWD), default per-kind policy below
-static int poll_env(const char* name, int dflt) {
-    const char* e = std::getenv(name);
-    return e ? atoi(e) : dflt;
 }
 
 // ---- exchange arena: tags that are unique per launch instead of a memset per launch ---------------------------------------
@@ -968,8 +961,7 @@ int prepare_exchange(const G& g, const FragPtrs& fp, const Shape& sh, int kind, 
     void* arena = g_arena;
     const size_t arena_bytes = g_arena_bytes;
     g_arena = nullptr; g_arena_bytes = 0;                       // consumed by this launch
-    static const int arena_on = poll_env_early("M3T_SCAN_ARENA", 1);
-    if (arena_on && arena && arena_bytes >= ARENA_BYTES && ((uintptr_t)arena % 16) == 0 && total <= ARENA_SIZE[kind] &&
+    if (arena && arena_bytes >= ARENA_BYTES && ((uintptr_t)arena % 16) == 0 && total <= ARENA_SIZE[kind] &&
         (unsigned long long)T + 1 < tag_max) {
         char* base = static_cast<char*>(arena) + ARENA_OFF[kind];
         size_t off = 0;
@@ -1174,8 +1166,7 @@ bool persist_bwd_uses_16(const BwdGroup& g, int B, int T, int flags) {
 // rows per workgroup; M3T_SCAN_FP32 / M3T_SCAN_X6=0 keep the fp32-MFMA kernel (bit-identical to the per-step path)
 bool persist_bwd_uses_x6(const BwdGroup& g, int B, int T, int flags) {
     Shape sh;
-    static const int bwd_on = poll_env_early("M3T_SCAN_BWD_X6", 1);      // 0: fp32 MFMAs in the backward scan only (A/B runs)
-    if (!bwd_on || g.bf16 || (flags & M3T_SCAN_FP32) || !x6_scan_enabled() || !level_shape(g.d, g.n, B, sh)) return false;
+    if (g.bf16 || (flags & M3T_SCAN_FP32) || !x6_scan_enabled() || !level_shape(g.d, g.n, B, sh)) return false;
     return sh.rt == 1 && (sh.nc == 2 || sh.nc == 4);
 }
 
@@ -1187,10 +1178,11 @@ int persist_fwd_launch(const FwdGroup& g, const FragPtrs& fp, int B, int T, int 
     fill_exchange(g, fp, sh, 8, ex, bytes);
     if (flags & M3T_SCAN_FAULT) ex.fault_step = T / 2;
     {
-        static const int p6 = poll_env("M3T_SCAN_POLL_FWD6", -1), p32 = poll_env("M3T_SCAN_POLL_FWD", -2);
-        ex.poll_fixed = persist_fwd_uses_x6(g, B, T, flags) ? p6 : (p32 != -2 ? p32 : (sh.nc == 1 ? 0 : 12));
-        static const int al = poll_env("M3T_SCAN_POLL_ALIGN", 6);     // bit 0: bf16x6 forward, 1: fp32 forward, 2: backward
-        ex.poll_align = persist_fwd_uses_x6(g, B, T, flags) ? (al & 1) : ((al >> 1) & 1);
+        // sleep before a step's first gather attempt, in units of 64 cycles: adaptive (-1) in the bf16x6 forward scan, fixed 12 in
+        // the fp32 forward scan (0 at H = 128); waves without cell math count it from the workgroup's publish (fp32 forward,
+        // backward) -- the measured optima of rounds 1-2, formerly M3T_SCAN_POLL_*
+        ex.poll_fixed = persist_fwd_uses_x6(g, B, T, flags) ? -1 : (sh.nc == 1 ? 0 : 12);
+        ex.poll_align = persist_fwd_uses_x6(g, B, T, flags) ? 0 : 1;
     }
     const bool x6 = persist_fwd_uses_x6(g, B, T, flags);
     { const int e = prepare_exchange(g, fp, sh, x6 ? 1 : 0, 8, x6 ? 65535ull : 0xffffffffull, T, ex, s); if (e) return e; }
@@ -1228,9 +1220,8 @@ int persist_bwd_launch(const BwdGroup& g, const FragPtrs& fp, int B, int T, int 
     fill_exchange(g, fp, sh, b16 ? 8 : 16, ex, bytes);
     if (flags & M3T_SCAN_FAULT) ex.fault_step = T / 2;
     {
-        static const int pb = poll_env("M3T_SCAN_POLL_BWD", 12), al = poll_env("M3T_SCAN_POLL_ALIGN", 6);
-        ex.poll_fixed = pb;
-        ex.poll_align = (al >> 2) & 1;
+        ex.poll_fixed = 12;
+        ex.poll_align = 1;
     }
     { const int e = prepare_exchange(g, fp, sh, b16 ? 2 : 3, b16 ? 8 : 16, b16 ? 65535ull : 0xffffffffull, T, ex, s); if (e) return e; }
     ++g_launches;

@@ -303,11 +303,8 @@ extern "C" int m3t_conv1d_fwd(const float* x, const float* w_t, const float* bia
         auto al = [](const void* q) { return q == nullptr || ((uintptr_t)q % 16) == 0; };
         if (conv_x6_enabled() && ((size_t)B * T) % 128 == 0 && Co % 128 == 0 && Ci % 32 == 0 && al(x) && al(w_t) && al(y) && al(res) &&
             al(drop_mask) && al(pre)) {
-            // M3T_CONV_X6D=1: the software-pipelined 128 x 128 kernel (gemm_x6d.hip) instead of gemm_x6.hip's 128 x 64 / 128 x 128 tiles
-            static const int x6d = []() { const char* e = getenv("M3T_CONV_X6D"); return e ? atoi(e) : 0; }();
-            if (x6d)
-                return m3t_conv_x6d_launch(x, w_t, bias, res, drop_mask, y, pre, B, T, Ci, Co, K, dilation, lead, act, anticausal,
-                                           p.bf16 ? 1 : ((flags & M3T_GEMM_HIGH) ? 2 : 0), p.drop, (hipStream_t)stream);
+            // (the software-pipelined CONV form of gemm_x6d.hip was no faster on these 300-tile grids than the 128 x 64 tiles of
+            // gemm_x6.hip -- C1 1.96 vs 2.03 ms, C2 7.44 vs 7.35 ms, round 2 -- and is no longer dispatched)
             return m3t_conv_x6_launch(x, w_t, bias, res, drop_mask, y, pre, B, T, Ci, Co, K, dilation, lead, act, anticausal,
                                       p.bf16 ? 1 : ((flags & M3T_GEMM_HIGH) ? 2 : 0), p.drop, (hipStream_t)stream);
         }

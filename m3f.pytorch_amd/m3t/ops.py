@@ -129,30 +129,21 @@ def _p(t, off=0):
     return C.c_void_p(t.data_ptr() + 4 * off)
 
 
-# ---- side stream: independent light-weight stacks run beside the main chain (see _stream_groups) -------------
+# ---- streams of the step's schedule --------------------------------------------------------------------------------
+# Round 3 retired the A/B switches of rounds 1-2 whose outcome is decided (DESIGN.md section 5c lists each with its measured
+# result): the schedule below is THE schedule.  What is left as a process-wide switch is listed in README.md (<= 10).
+#   * side stream: independent light-weight stacks run beside the main chain (_stream_groups); with two H-groups of persistent
+#     scans (gru_v|gru_a at H=512, audio at H=256) the light group's scans and GEMMs go there, fenced by events so that no two
+#     persistent scans ever overlap, and run beside the heavy group's GEMMs; two-layer stacks run the light group's two scans
+#     back to back between the heavy group's (forward H0 L0 L1 H1, backward H1 L1 H0 L0: the pass ends with a light scan);
+#   * weight-gradient streams: the weight-gradient GEMMs of a GRU level, of nn.Linear and of the TemporalBlocks feed nothing but
+#     the optimizer: they leave the scan -> dX -> scan chain for streams of their own, start when the level's data gradients
+#     are done, and are joined in FlatGradDDP.finish() when every gradient went into a gradient sink.  Two streams; the second
+#     one takes half of the LAST level's GEMMs only (the tail of backward, when no scan and no data gradient is left).
 _SIDE = {}
-# measured +9% on C3 (969 vs 886 clips/s): the light chain and its GEMMs hide beside the heavy one; M3T_SIDE_STREAM=0 disables
-_SIDE_ENABLED = os.environ.get("M3T_SIDE_STREAM", "1") == "1"
 _PERSIST_ENABLED = os.environ.get("M3T_SCAN_PERSIST", "1") != "0"
-# two H-groups of persistent scans (e.g. gru_v|gru_a H=512 and audio H=256): the light group's scans and GEMMs go to the
-# side stream, fenced by events so that no two persistent scans ever overlap, and run beside the heavy group's GEMMs
-_INTERLEAVE = os.environ.get("M3T_SCAN_INTERLEAVE", "1") != "0"
-# two-layer stacks: the light group's two scans run back to back between the heavy group's two scans (H0 L0 L1 H1 / H1 L1 L0 H0)
-# instead of strictly alternating
-_LIGHT_BATCHED = os.environ.get("M3T_SCAN_LIGHT_BATCHED", "1") != "0"
-_BWD_LIGHT_LAST = os.environ.get("M3T_SCAN_BWD_LIGHT_LAST", "1") != "0"      # backward scan order H1 L1 H0 L0 (0: H1 L1 L0 H0)
-# data gradients before weight gradients: bit 0 heavy group / bit 1 light group of the batched schedule, bit 2 every level.  The weight
-# gradients of a level then start when its data gradients are done instead of sharing the free CUs with them: the chain's GEMMs
-# finish sooner, the scans beside them stretch less (backward scans 7.9 -> 6.8 ms per step), the step -0.2 ms (8 interleaved runs
-# each, medians 17.56 vs 17.78 ms)
-_DX_FIRST = int(os.environ.get("M3T_DX_FIRST", "7"))
-
-
-# weight-gradient GEMMs of a GRU level (dW_ih, dW_hh) feed nothing but the optimizer: they leave the scan -> dX -> scan
-# chain for a third stream and run beside the next level's scan (M3T_WGRAD_STREAM=0: in line, as before)
 _WGRAD = {}
-_WGRAD_ENABLED = os.environ.get("M3T_WGRAD_STREAM", "1") != "0"
-_WGRAD_BACKGROUND = os.environ.get("M3T_WGRAD_BACKGROUND", "0") == "1"
+_N_WGRAD = 2
 
 
 def side_stream(device):
@@ -164,8 +155,6 @@ def side_stream(device):
     return st
 
 
-_WGRAD_DEFER_JOIN = os.environ.get("M3T_WGRAD_DEFER_JOIN", "1") != "0"
-_LINEAR_OFF_CHAIN = os.environ.get("M3T_LINEAR_WGRAD", "1") != "0"
 _WGRAD_PENDING = {}
 
 
@@ -177,17 +166,6 @@ def join_wgrad(device=None):
             for st in _WGRAD.get(key) or []:
                 torch.cuda.current_stream(torch.device(key[0], key[1])).wait_stream(st)
             _WGRAD_PENDING[key] = False
-
-
-# Weight-gradient streams.  The weight-gradient GEMMs of a level are independent of each other and mostly small (audio dW_hh:
-# 768 x 256 x 9600 = 12 output tiles x split-K).  Dealing ALL of them round-robin over two streams was measured and lost: the
-# extra concurrent GEMM stream takes CUs from the data-gradient GEMMs on the scan chain and stretches the scans beside it (17.77
-# vs 17.21 ms per step).  What is kept (M3T_WGRAD_TAIL_SPREAD): only the LAST level's weight gradients -- the tail of backward, when
-# no scan and no data gradient is left -- go over both streams (each with its own split-K workspace): -0.15 ms per step (medians
-# of 8 interleaved runs, 17.79 vs 17.94).
-_N_WGRAD = max(1, int(os.environ.get("M3T_WGRAD_STREAMS", "2")))
-_TAIL_SPREAD = os.environ.get("M3T_WGRAD_TAIL_SPREAD", "1") != "0"
-_TCN_OFF_CHAIN = os.environ.get("M3T_TCN_WGRAD", "1") != "0"      # TemporalBlock weight gradients on the weight-gradient stream (with sinks)
 
 
 def wgrad_stream(device, i=0):
@@ -256,9 +234,9 @@ class precision:
 
 
 def sgemm(transA, transB, M, N, K, A, a_off, lda, B, b_off, ldb, Cm, c_off, ldc, bias=None, act=0,
-          accumulate=False, seg=(0, 0, 0, 0), use_ws=True, background=False, prec=None, exclusive=False):
+          accumulate=False, seg=(0, 0, 0, 0), use_ws=True, prec=None, exclusive=False):
     ws = workspace(Cm.device) if use_ws else None
-    flags = (1 if background else 0) | (_PREC[0] if prec is None else prec) | (_lib.M3T_GEMM_EXCLUSIVE if exclusive else 0)
+    flags = (_PREC[0] if prec is None else prec) | (_lib.M3T_GEMM_EXCLUSIVE if exclusive else 0)
     if _FENCED[0]:
         flags |= _lib.M3T_GEMM_BESIDE_SCAN       # issued inside the interleaved schedule of _MultiBiGRU: scans of another stream run beside it
     with _Timed("sgemm_kernel", 1, 2.0 * M * N * K) if PROFILE_GEMM[0] else _NULL:
@@ -343,7 +321,7 @@ class _Linear(torch.autograd.Function):
             join_wgrad(x.device)
         # gradients that go straight into the flat buffer feed nothing on the chain: they run on the weight-gradient stream
         # (joined by FlatGradDDP.finish(), see join_wgrad) beside whatever backward does next
-        wg = wgrad_stream(x.device, _LINEAR_RR[0]) if (_WGRAD_ENABLED and _WGRAD_DEFER_JOIN and _LINEAR_OFF_CHAIN and x.is_cuda) else None
+        wg = wgrad_stream(x.device, _LINEAR_RR[0]) if x.is_cuda else None
         off_chain = torch.cuda.stream(wg) if wg is not None else None
         if off_chain is not None and (w_sink is not None or b_sink is not None):
             wg.wait_stream(torch.cuda.current_stream())
@@ -456,17 +434,10 @@ def grad_dead_check_(dead):
     _lib.check(lib().m3t_grad_dead_check(_p(dead), _stream()), "m3t_grad_dead_check")
 
 
-_DEFER_FENCE = os.environ.get("M3T_SCAN_DEFER_FENCE", "1") != "0"
-
-
 def _scan_after(ev):
-    """the next scan call launches its scan kernels only after torch event `ev` (its preparation is not held back;
-    M3T_SCAN_DEFER_FENCE=0: the whole call waits)"""
+    """the next scan call launches its scan kernels only after torch event `ev` (its preparation kernels are not held back)"""
     if ev is not None:
-        if _DEFER_FENCE:
-            _lib.check(lib().m3t_gru_scan_after(C.c_void_p(ev.cuda_event)), "m3t_gru_scan_after")
-        else:
-            torch.cuda.current_stream().wait_event(ev)
+        _lib.check(lib().m3t_gru_scan_after(C.c_void_p(ev.cuda_event)), "m3t_gru_scan_after")
 
 
 _ARENAS = {}
@@ -534,8 +505,6 @@ def _stream_groups(Hs, B):
         # other: one group per H, back to back on the main stream (a persistent launch holds every CU, so a
         # launch-per-step chain on the side stream would only run before or after it anyway)
         return [("main", [i for i, h in enumerate(Hs) if h == hh]) for hh in sorted(set(Hs), reverse=True)]
-    if not _SIDE_ENABLED:
-        return [("main", list(range(len(Hs))))]
     hmax = max(Hs)
     heavy = [i for i, h in enumerate(Hs) if h == hmax]
     light = [i for i, h in enumerate(Hs) if h != hmax]
@@ -546,7 +515,7 @@ def _stream_groups(Hs, B):
 
 
 def _interleaved(groups):
-    return (_INTERLEAVE and _PERSIST_ENABLED and not SCAN_PER_STEP[0] and len(groups) == 2
+    return (_PERSIST_ENABLED and not SCAN_PER_STEP[0] and len(groups) == 2
             and all(kind == "main" for kind, _ in groups))
 
 
@@ -622,7 +591,7 @@ class _MultiBiGRU(torch.autograd.Function):
             ev_light = None
             _FENCED[0] = True
             try:
-                if _LIGHT_BATCHED and L == 2:
+                if L == 2:
                     # persistent scans in the order H0, L0, L1, H1: BOTH light scans (and the light layer-1 projection between
                     # them) run beside the heavy layer-1 input projections, the longest GEMM window of the pass; strictly
                     # alternating (H0, L0, H1, L1) left the second light scan with nothing beside it
@@ -773,12 +742,14 @@ class _MultiBiGRU(torch.autograd.Function):
                               dinp[l][s], 0, I, accumulate=(d == 1), prec=prec)
                     cur[s] = dinp[l][s]
 
-        wgs = wgrad_streams(dev) if _WGRAD_ENABLED else None
+        wgs = wgrad_streams(dev)
         rr = [0]
 
-        def level_dw(l, idxs, background=False, spread=False):           # off the chain: only the optimizer reads these
-            """the weight-gradient GEMMs of (l, idxs); with weight-gradient streams: dealt round-robin over them (the GEMMs are
-            independent of each other; every stream has waited for the scan)"""
+        def level_dw(l, idxs, spread=False):           # off the chain: only the optimizer reads these
+            """the weight-gradient GEMMs of (l, idxs) on the weight-gradient streams (every stream has waited for the scan).
+            spread: the LAST weight gradients of the pass (nothing but the optimizer follows) are dealt over both streams, so
+            that two of these small GEMMs share the chip; everything else goes to stream 0 (a second concurrent GEMM stream
+            beside the chain takes CUs from the data-gradient GEMMs and stretches the scans: 17.77 vs 17.21 ms, round 2)"""
             for s in idxs:
                 H = Hs[s]
                 inp, out, gts = layer_io(l, s)
@@ -787,46 +758,32 @@ class _MultiBiGRU(torch.autograd.Function):
                     base = s * per + 1 + (2 * l + d) * 4
                     dw_ih, dw_hh = out_grads[base:base + 2]      # the bias gradients come out of the scan itself
                     goff = d * B * T * 3 * H
-                    # spread: the LAST weight gradients of the pass (nothing but the optimizer follows): dealt over all
-                    # weight-gradient streams so that two of these small GEMMs share the chip; everything else on stream 0
-                    nw = len(wgs) if (wgs is not None and spread) else 1
-                    ctx_hh = torch.cuda.stream(wgs[rr[0] % nw]) if wgs is not None else _NULL
-                    ctx_ih = torch.cuda.stream(wgs[(rr[0] + 1) % nw]) if wgs is not None else _NULL
-                    rr[0] += 2
-                    with ctx_hh:
+                    nw = len(wgs) if spread else 1
+                    with torch.cuda.stream(wgs[rr[0] % nw]):
                         if T > 1:
                             # dW_hh = sum_{b,t} dgh[b,t]^T h_prev(b,t): forward pairs (t, t-1), reverse pairs (t, t+1)
                             a_off, b_off = (1, 0) if d == 0 else (0, 1)
                             sgemm(1, 0, 3 * H, H, B * (T - 1), dgh[l][s], goff, 3 * H, out, d * H, out.stride(1), dw_hh, 0, H,
-                                  seg=(T - 1, T, a_off, b_off), prec=prec, background=background)
+                                  seg=(T - 1, T, a_off, b_off), prec=prec)
                         else:
                             dw_hh.zero_()
-                    with ctx_ih:
-                        sgemm(1, 0, 3 * H, I, B * T, dgx[l][s], d * 3 * H, 6 * H, inp, 0, I, dw_ih, 0, I, prec=prec,
-                              background=background)
+                    with torch.cuda.stream(wgs[(rr[0] + 1) % nw]):
+                        sgemm(1, 0, 3 * H, I, B * T, dgx[l][s], d * 3 * H, 6 * H, inp, 0, I, dw_ih, 0, I, prec=prec)
+                    rr[0] += 2
 
-        if wgs is not None:
-            for w_ in wgs:
-                w_.wait_stream(main)
+        for w_ in wgs:
+            w_.wait_stream(main)
 
-        def level_gemms(l, idxs, dx_first=False, last=False):
-            """after the scan of (l, idxs) on the current stream: dX in line, dW on the weight-gradient streams.  dx_first: the
-            weight gradients wait until the data gradients are done (they would otherwise split the CUs the scan beside them
-            leaves free, and the data gradients are what the chain -- or the light scans' own chain -- waits for)"""
-            if wgs is None:
-                level_dx(l, idxs)
-                level_dw(l, idxs)
-                return
-            dx_first = dx_first or bool(_DX_FIRST & 4)
-            if dx_first:
-                level_dx(l, idxs)
+        def level_gemms(l, idxs, last=False):
+            """after the scan of (l, idxs) on the current stream: the data gradients in line (they are what the chain -- or the
+            light scans' own chain -- waits for), then the weight gradients on their streams (started earlier they would split
+            the CUs the scan beside them leaves free: 17.56 vs 17.78 ms per step, round 2)"""
+            level_dx(l, idxs)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             for w_ in wgs:
                 w_.wait_event(ev)
-            level_dw(l, idxs, _WGRAD_BACKGROUND, spread=last and _TAIL_SPREAD)
-            if not dx_first:
-                level_dx(l, idxs)
+            level_dw(l, idxs, spread=last)
 
         if _interleaved(groups):
             # as in forward: the light group's backward scans run on the side stream beside the heavy group's GEMMs
@@ -838,38 +795,26 @@ class _MultiBiGRU(torch.autograd.Function):
             ev_light = None
             _FENCED[0] = True
             try:
-                if _LIGHT_BATCHED and L == 2:
-                    # persistent scans in the order H1, L1, L0, H0: both light scans (and the light data-gradient GEMM between
-                    # them) beside the heavy layer-1 data-gradient GEMMs; no light scan is left for the end of the pass
+                if L == 2:
+                    # persistent scans in the order H1, L1, H0, L0: the light layer-1 scan beside the heavy layer-1 data-gradient
+                    # GEMMs, and the pass ENDS with a light scan (64 workgroups), beside which the weight-gradient GEMMs that
+                    # are left have three quarters of the chip -- instead of running alone after the last heavy scan
                     level_scan(1, heavy, None)
                     ev_h1 = torch.cuda.Event()
                     ev_h1.record(main)
-                    level_gemms(1, heavy, dx_first=_DX_FIRST & 1)
-                    if _BWD_LIGHT_LAST:
-                        # H1, L1, H0, L0: the pass ends with a LIGHT scan (64 workgroups), beside which the weight-gradient GEMMs
-                        # that are left have three quarters of the chip -- instead of running alone after the last heavy scan
-                        with torch.cuda.stream(side):
-                            level_scan(1, light, ev_h1)
-                            ev_l1 = torch.cuda.Event()
-                            ev_l1.record(side)
-                            level_gemms(1, light, dx_first=_DX_FIRST & 2)
-                        level_scan(0, heavy, ev_l1)
-                        ev_h0 = torch.cuda.Event()
-                        ev_h0.record(main)
-                        level_gemms(0, heavy, last=True)
-                        with torch.cuda.stream(side):
-                            level_scan(0, light, ev_h0)
-                            level_gemms(0, light)
-                    else:
-                      with torch.cuda.stream(side):
+                    level_gemms(1, heavy)
+                    with torch.cuda.stream(side):
                         level_scan(1, light, ev_h1)
-                        level_gemms(1, light, dx_first=_DX_FIRST & 2)
-                        level_scan(0, light)
-                        ev_light = torch.cuda.Event()
-                        ev_light.record(side)
+                        ev_l1 = torch.cuda.Event()
+                        ev_l1.record(side)
+                        level_gemms(1, light)
+                    level_scan(0, heavy, ev_l1)
+                    ev_h0 = torch.cuda.Event()
+                    ev_h0.record(main)
+                    level_gemms(0, heavy, last=True)
+                    with torch.cuda.stream(side):
+                        level_scan(0, light, ev_h0)
                         level_gemms(0, light)
-                      level_scan(0, heavy, ev_light)
-                      level_gemms(0, heavy, last=True)
                 else:
                   for l in range(L - 1, -1, -1):
                     level_scan(l, heavy, ev_light)
@@ -897,21 +842,20 @@ class _MultiBiGRU(torch.autograd.Function):
             for kind, _ in groups:
                 if kind == "side":
                     main.wait_stream(side_stream(dev))
-        if wgs is not None:
-            weights_sunk = all(sunk[s * per + 1 + (2 * l + d) * 4 + j] for s in range(n_stacks) for l in range(L) for d in (0, 1) for j in (0, 1))
-            if _WGRAD_DEFER_JOIN and weights_sunk:
-                # every weight gradient goes straight into the flat gradient buffer, which nobody reads before
-                # FlatGradDDP.finish(): leave the weight-gradient stream running (join_wgrad() there) instead of waiting
-                # for its tail here.  What it still reads must outlive this call on ITS stream.
-                for l in range(L):
-                    for s in range(n_stacks):
-                        for t in (dgx[l][s], dgh[l][s]) + tuple(layer_io(l, s)[:2]):
-                            for w_ in wgs:
-                                t.record_stream(w_)
-                _WGRAD_PENDING[(dev.type, dev.index)] = True
-            else:
-                for w_ in wgs:
-                    main.wait_stream(w_)
+        weights_sunk = all(sunk[s * per + 1 + (2 * l + d) * 4 + j] for s in range(n_stacks) for l in range(L) for d in (0, 1) for j in (0, 1))
+        if weights_sunk:
+            # every weight gradient goes straight into the flat gradient buffer, which nobody reads before
+            # FlatGradDDP.finish(): leave the weight-gradient streams running (join_wgrad() there) instead of waiting
+            # for their tail here.  What they still read must outlive this call on THEIR stream.
+            for l in range(L):
+                for s in range(n_stacks):
+                    for t in (dgx[l][s], dgh[l][s]) + tuple(layer_io(l, s)[:2]):
+                        for w_ in wgs:
+                            t.record_stream(w_)
+            _WGRAD_PENDING[(dev.type, dev.index)] = True
+        else:
+            for w_ in wgs:
+                main.wait_stream(w_)
         for s in range(n_stacks):
             out_grads[s * per] = dinp[0][s]
         return (None, None, None, None) + tuple(None if sunk[i] else g for i, g in enumerate(out_grads))
@@ -1111,7 +1055,7 @@ class _TemporalBlock(torch.autograd.Function):
         # for) is computed first, and the weight gradients (6 segmented GEMMs), the bias sums and the weight-norm backward run on
         # the weight-gradient stream straight into the flat gradient buffer (joined by FlatGradDDP.finish(), like _Linear's)
         sinks = None
-        if (ctx.sink_refs is not None and _TCN_OFF_CHAIN and _WGRAD_ENABLED and _WGRAD_DEFER_JOIN and x.is_cuda
+        if (ctx.sink_refs is not None and x.is_cuda
                 and all(ctx.needs_input_grad[i] for i in range(1, 7 if wd is None else 9))):
             got = [_take_sink(t) for t in ctx.sink_refs]
             if all(g_ is not None for g_ in got):

@@ -10,7 +10,6 @@ GEMM, the recurrence in the grouped per-step scan kernels (m3t.ops.multi_bigru).
 (non-deterministic teacher forcing).
 """
 import math
-import os
 
 import torch
 import torch.nn as nn
@@ -136,15 +135,12 @@ def run_grus(modules, inputs):
     return [m.head(o) for m, (o, _) in zip(modules, res)]
 
 
-_CAT_IN_PLACE = os.environ.get("M3T_GRU_CAT", "1") != "0"      # 0: run_grus + torch.cat (A/B runs)
-
-
 def run_grus_cat(modules, inputs, lo, hi):
     """`run_grus` followed by `torch.cat(outputs[lo:hi], dim=-1)` (the visual towers' gru_v | gru_a features, reference
     models/model.py:111-112 / models/backbone.py:281-283): the list of outputs with the concatenation in place of the group.
     When the grouped modules end without an FC head (num_classes <= 0) their scans write straight into the concatenated buffer
     (m3t.ops.multi_bigru(cat=...)): no cat copy forward, no slice copies backward."""
-    if hi - lo >= 2 and _CAT_IN_PLACE and all(m.num_classes <= 0 for m in modules[lo:hi]):
+    if hi - lo >= 2 and all(m.num_classes <= 0 for m in modules[lo:hi]):
         res = ops.multi_bigru([m.stack(x) for m, x in zip(modules, inputs)], cat=(lo, hi))
         outs = [m.head(o) if not (lo < i < hi) else None for i, (m, (o, _)) in enumerate(zip(modules, res))]
         return outs[:lo + 1] + outs[hi:]

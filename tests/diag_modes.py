@@ -5,7 +5,7 @@ import os, sys, subprocess, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 audio = sys.argv[1] if len(sys.argv) > 1 else "db"
 MODES = {"default": {}, "scan_fp32mfma": {"M3T_SCAN_X6": "0"}, "scan_perstep": {"M3T_SCAN_PERSIST": "0"}, "gemm_fp32": {"M3T_GEMM_X6": "0"},
-         "nosolo": {"M3T_SCAN_SOLO": "0"}}
+         "nosolo": {"M3T_SCAN_SOLO": "0"}}      # the process-wide kernel-selection switches (README.md)
 if len(sys.argv) > 2 and sys.argv[2] == "child":
     for p in (ROOT, os.path.join(ROOT, "m3f.pytorch_amd"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)

@@ -53,40 +53,6 @@ def test_sgemm_bf16_operands(M, N, K, tA, tB):
     assert np.abs(ref - exact).max() > 50 * np.abs(out.cpu().numpy() - ref).max()      # it really is the bf16 product
 
 
-def test_sgemm_bf16_operands_big_tile():
-    """the 256 x 256-tile kernel in the bf16 mode (one bf16 MFMA per tile step there too).  The planner prefers the 128-tile
-    kernel for bf16 operands, so the big tile is forced (M3T_GEMM_X6C=1, read once per process: a subprocess)."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = r"""
-import sys
-sys.path.insert(0, %r); sys.path.insert(0, %r)
-import numpy as np, torch
-from m3t import ops, _lib
-from oracle import m3t_oracle as O
-worst = 0.0
-for M, N, K, tA, tB in ((9600, 1536, 512, 0, 1), (1536, 512, 9600, 1, 0), (2048, 2048, 2048, 0, 0)):
-    assert ops.sgemm_plan(tA, M, N, K, exclusive=True, prec=_lib.M3T_BF16)[0] == 2
-    rs = np.random.RandomState(M + N + K + 1)
-    A = rs.standard_normal((K, M) if tA else (M, K)).astype(np.float32)
-    B = rs.standard_normal((N, K) if tB else (K, N)).astype(np.float32)
-    Ar, Br = O.bf16_round(A).astype(np.float64), O.bf16_round(B).astype(np.float64)
-    ref = (Ar.T if tA else Ar) @ (Br.T if tB else Br)
-    out = torch.empty(M, N, device="cuda:0")
-    ops.sgemm(tA, tB, M, N, K, torch.from_numpy(A).cuda(), 0, A.shape[1], torch.from_numpy(B).cuda(), 0, B.shape[1], out, 0, N,
-              prec=_lib.M3T_BF16, exclusive=True)
-    err = float(np.abs(out.cpu().numpy() - ref).max()) / max(1.0, float(np.abs(ref).max()))
-    worst = max(worst, err / (2e-5 * max(1, K ** 0.5 / 8)))
-print("WORST", worst)
-""" % (os.path.join(root, "m3f.pytorch_amd"), root)
-    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, M3T_GEMM_X6C="1", M3T_SCAN_LOCK="0"), capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-1500:]
-    worst = float([l for l in out.stdout.splitlines() if l.startswith("WORST")][-1].split()[1])
-    assert worst <= 1.0, worst
-
-
 @pytest.mark.parametrize("B,T,I,H,L,tol", [(5, 9, 20, 128, 2, BF_TOL), (32, 2, 16, 256, 1, BF_TOL), (19, 3, 16, 512, 1, BF_TOL),
                                            (3, 7, 12, 24, 2, BF_TOL), (4, 6, 10, 20, 1, BF_TOL), (32, 24, 16, 256, 1, 0.1)])
 def test_gru_bf16_vs_emulating_oracle(B, T, I, H, L, tol):

@@ -1090,42 +1090,6 @@ def test_time_reversal_symmetry_of_bigru():
     assert torch.equal(ya[..., :32], yb.flip(1)[..., 32:]) and torch.equal(ya[..., 32:], yb.flip(1)[..., :32])
 
 
-def test_scan_results_do_not_depend_on_the_poll_policy():
-    """the sleep before a persistent scan's first gather attempt (adaptive / fixed / none, aligned or not) and the transport of the
-    exchange (through the XCD's L2 after the placement handshake, or through the memory side: M3T_SCAN_L2=0) are timing only:
-    forward outputs and every gradient are bit-identical under all of them (the policy is read once per process, hence
-    the subprocesses)"""
-    import hashlib
-    import subprocess
-    import sys
-    code = r"""
-import sys, hashlib
-sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
-import numpy as np, torch
-from golden.recipe import fill_module, draw
-from models.rnn import GRU
-rs = np.random.RandomState(5)
-h = hashlib.sha256()
-for H in (128, 256):
-    m = fill_module(GRU(24, H, 2, 3, 2), 7).to("cuda:0")
-    x = torch.from_numpy(draw(rs, (20, 33, 24))).to("cuda:0").requires_grad_(True)
-    y = m(x)
-    (y * torch.from_numpy(draw(rs, (20, 33, 3))).to("cuda:0")).sum().backward()
-    for t in [y, x.grad] + [p.grad for p in m.parameters()]:
-        h.update(t.detach().cpu().numpy().tobytes())
-print("DIGEST", h.hexdigest())
-""" % (os.path.join(ROOT, "m3f.pytorch_amd"), os.path.join(ROOT, "tests"), ROOT)
-    digests = []
-    for extra in ({}, {"M3T_SCAN_POLL_FWD6": "0", "M3T_SCAN_POLL_FWD": "5", "M3T_SCAN_POLL_BWD": "0", "M3T_SCAN_POLL_ALIGN": "0", "M3T_SCAN_L2": "0"},
-                  {"M3T_SCAN_POLL_FWD6": "20", "M3T_SCAN_POLL_BWD": "-1", "M3T_SCAN_POLL_ALIGN": "7"}):
-        # (M3T_SCAN_LOCK=0: this pytest process may own the GPU's persistent-scan lock and is idle while the child runs)
-        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, M3T_SCAN_LOCK="0", **extra), capture_output=True,
-                             text=True, timeout=600)
-        assert out.returncode == 0, out.stderr[-1500:]
-        digests.append([l for l in out.stdout.splitlines() if l.startswith("DIGEST")][-1])
-    assert digests[0] == digests[1] == digests[2], digests
-
-
 @pytest.mark.parametrize("bf16", [False, True])
 @pytest.mark.parametrize("B,T", [(5, 7), (32, 300), (1, 2)])
 def test_solo_scans_h128_through_the_c_abi(B, T, bf16):
@@ -1191,15 +1155,3 @@ def test_solo_scans_h128_through_the_c_abi(B, T, bf16):
         for a, b_, name in zip(got, ref, ("dgx", "dgh", "dh", "db_ih", "db_hh")):
             close(a, b_, (3e-5 if T < 10 else 5e-3) if bf16 else 5e-6, "%s (direct=%d)" % (name, direct))
     ops.poll_scan_error()
-
-
-def test_conv_on_the_software_pipelined_kernel_opt_in():
-    """M3T_CONV_X6D=1 (read once per process, hence a child): the implicit-GEMM convolutions on gemm_x6d.hip's CONV form instead of
-    gemm_x6.hip's -- same arithmetic; the convolution and TemporalBlock parity tests must pass unchanged"""
-    import subprocess
-    import sys
-    env = dict(os.environ, M3T_CONV_X6D="1", M3T_SCAN_LOCK="0")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
-                        "conv1d_on_the_bf16x6_pipe or tcn_train_mode or tcn_golden"], env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-1500:]
-    assert " passed" in r.stdout
