@@ -528,22 +528,27 @@ def worker(args):
         name = max(kern, key=lambda n: kern[n]["ms"])
         k = kern[name]
         achieved = k["flops"] / (k["ms"] * 1e-3) / 1e12
-        traffic, traffic_by_kernel, mfma_util = None, None, None
+        traffic, traffic_by_kernel, mfma_util, pmc_source = None, None, None, None
         # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/*pmc_traffic.json: separate
         # FETCH_SIZE / WRITE_SIZE passes, gfx950 correction) and the SQ pass (profiles/*pmc_mfma.json)
         try:
             import glob
-            pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))[-1]))["kernels"]
+            pmc_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))[-1]
+            pm = json.load(open(pmc_file))["kernels"]
             stem = name.replace("_kernel", "")               # gru_persist_bwd -> bwd, bwd6, bwd16 variants
             stems = (stem, stem.replace("persist", "solo"))         # the H = 128 levels of the same pass run gru_solo_* launches
             hits = {k: v for k, v in pm.items() if k.startswith(stems) and "hbm_bytes_per_launch" in v}
             if hits:
                 traffic = int(sum(h["hbm_bytes_per_launch"] * h["launches"] for h in hits.values()) / sum(h["launches"] for h in hits.values()))
                 traffic_by_kernel = {k: v["hbm_bytes_per_launch"] for k, v in hits.items()}
-            mm = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_mfma.json")))[-1]))["kernels"]
+            mfma_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_mfma.json")))[-1]
+            mm = json.load(open(mfma_file))["kernels"]
             mh = {k: v for k, v in mm.items() if k.startswith(stems) and v.get("mfma_util") is not None}
             if mh:
                 mfma_util = {k: v["mfma_util"] for k, v in mh.items()}
+            pmc_source = ("profiles/%s and profiles/%s: the builder's committed rocprofv3 --pmc passes of this same command (separate FETCH_SIZE / "
+                          "WRITE_SIZE / SQ passes); read from those files, NOT measured in this run"
+                          % (os.path.basename(pmc_file), os.path.basename(mfma_file)))
         except Exception:  # noqa: BLE001
             pass
         roofline = {"kernel": name, "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
@@ -553,6 +558,8 @@ def worker(args):
                     "share_of_step": round(k["ms"] / timed_steps / step_ms, 3),
                     "timed_launches": k["launches"], "events_every_n_steps": events_every,
                     "traffic_by_kernel": traffic_by_kernel, "mfma_busy_frac_pmc": mfma_util,
+                    "source": {"achieved, avg_launch_us, frac": "HIP events recorded in this run on the launch stream",
+                               "traffic, traffic_by_kernel, mfma_busy_frac_pmc": pmc_source},
                     "note": "achieved = algorithmic FLOPs of the recurrent products dh_t = dgh_{t+1} W_hh ((T-1) x sum over scans of 2 B 3H H per launch) / HIP-event "
                             "time of the launches; peak = fp32 MFMA (the arithmetic is fp32-accurate); the H = 256 / 512 launches run it as 6 bf16 MFMAs per "
                             "product on the bf16 pipe (peak 2500 / 6 = 417 TFLOP/s-equivalent), the H = 128 launches (gru_solo_bwd_kernel) as fp32 FMA chains "
