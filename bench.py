@@ -194,24 +194,9 @@ def aux_child(which, steps=6, warmup=2):
                                                 "GBps_8pass": round(8 * nbytes / ms / 1e6, 1),
                                                 "frac_of_hbm_peak": round(8 * nbytes / ms / 1e6 / HBM_PEAK_GBS, 4)}
             del xx, gg, cb
-        # and inside a model: VA_3DResNet(resnet_ver='v1', use_cbam=True) visual-only, 8 clips x 64 frames of 112 x 112 (SURVEY 8(d) C5 alt)
-        from models.backbone import VA_3DResNet
-        torch.manual_seed(12345)
-        Bc, Tc = 8, 64
-        net = VA_3DResNet(inputDim=512, hiddenDim=512, nLayers=2, nClasses=2, frameLen=Tc, use_cbam=True, resnet_ver="v1").to(dev).train()
-        vid = f(((rs.randint(0, 256, (Bc, 3, Tc, 112, 112)).astype(np.float32)) - 127.5) / 127.5)
-        ddp = FlatGradDDP(net, max_norm=1.0)
-
-        def step_r():
-            ddp.zero_grad()
-            y = net(vid)
-            ops.va_loss(y, val[:Bc, :Tc].contiguous(), aro[:Bc, :Tc].contiguous())[0].backward()
-            ddp.finish()
-        ms = timed(step_r, 6)
-        print(json.dumps({"aux": "cbam", "workload": "models.cbam.CBAM fwd+bwd (train mode) on the ResNet-18 stage shapes, 2048 frames; "
-                          "and VA_3DResNet(v1, use_cbam=True) visual-only training step, 8 x 64 frames of 112 x 112 (conv stem and ResNet convs on MIOpen)",
-                          "stages": res, "resnet3d_cbam_ms_per_step": round(ms, 3), "resnet3d_cbam_clips_per_s": round(Bc / ms * 1e3, 1),
-                          "dtype": "f32", "peak_GBps": HBM_PEAK_GBS}), flush=True)
+        print(json.dumps({"aux": "cbam", "workload": "models.cbam.CBAM forward + backward (train mode: BatchNorm2d(1) batch statistics) on the four ResNet-18 stage "
+                          "shapes, 2048 frames each; GBps_8pass = 8 x bytes(x) / time, the fused operator's algorithmic HBM passes (DESIGN.md section 4)",
+                          "stages": res, "dtype": "f32", "peak_GBps": HBM_PEAK_GBS}), flush=True)
     if "c5" in which:
         from models.model import AffWild2VA
         hp = AffWild2VA.add_model_specific_args(argparse.ArgumentParser(add_help=False)).parse_args([])
@@ -614,3 +599,21 @@ def worker(args):
 
 if __name__ == "__main__":
     main()
+    if "cbam" in which:          # (last: MIOpen's first-use search for the ResNet convolutions may eat what is left of the budget)
+        # inside a model: VA_3DResNet(resnet_ver='v1', use_cbam=True) visual-only, 8 clips x 64 frames of 112 x 112 (SURVEY 8(d) C5 alt)
+        from models.backbone import VA_3DResNet
+        Bc, Tc = 8, 64
+        torch.manual_seed(12345)
+        net = VA_3DResNet(inputDim=512, hiddenDim=512, nLayers=2, nClasses=2, frameLen=Tc, use_cbam=True, resnet_ver="v1").to(dev).train()
+        vid = f(((rs.randint(0, 256, (Bc, 3, Tc, 112, 112)).astype(np.float32)) - 127.5) / 127.5)
+        ddp = FlatGradDDP(net, max_norm=1.0)
+
+        def step_r():
+            ddp.zero_grad()
+            y = net(vid)
+            ops.va_loss(y, val[:Bc, :Tc].contiguous(), aro[:Bc, :Tc].contiguous())[0].backward()
+            ddp.finish()
+        ms = timed(step_r, 6)
+        print(json.dumps({"aux": "cbam_resnet3d", "workload": "VA_3DResNet(resnet_ver='v1', use_cbam=True) visual-only training step (SURVEY 8(d) C5 alt), 8 clips x 64 "
+                          "frames of 112 x 112: 3-D stem + per-frame ResNet-18 convolutions on MIOpen, the 8 CBAM gates and the BiGRU head on the HIP kernels",
+                          "clips": Bc, "ms_per_step": round(ms, 3), "clips_per_s": round(Bc / ms * 1e3, 1), "dtype": "f32"}), flush=True)

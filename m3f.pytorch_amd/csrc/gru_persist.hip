@@ -876,7 +876,10 @@ bool level_shape(const D* d, int n, int B, Shape& sh) {
             // scorers) use the slot mapping + handshake, the others keep G * H/16 blocks dealt over all 8 XCDs and exchange through
             // the memory side; 1 every launch (a 4-group launch then fills 4 XCDs and leaves 4 empty: -40 % traffic on those too,
             // but their steps got slower -- 19.08 vs 18.73 ms per training step, interleaved A/B; mode 2: 18.83); 0 never
-            constexpr int l2 = 2;
+#ifndef M3T_SCAN_L2_MODE
+#define M3T_SCAN_L2_MODE 2
+#endif
+            constexpr int l2 = M3T_SCAN_L2_MODE;
             sh.rt = rt; sh.nrb = nrb; sh.G = G; sh.active = active;
             sh.slot_map = (l2 == 1 || (l2 == 2 && G % 8 == 0)) ? 1 : 0;
             sh.grid = sh.slot_map ? 8 * cdiv(G, 8) * (maxh / 16) : active;
