@@ -218,6 +218,26 @@ def aux_child(which, steps=6, warmup=2):
              timed(step5), "f32")
 
 
+    if "cbam" in which:          # (last: MIOpen's first-use search for the ResNet convolutions may eat what is left of the budget)
+        # inside a model: VA_3DResNet(resnet_ver='v1', use_cbam=True) visual-only, 8 clips x 64 frames of 112 x 112 (SURVEY 8(d) C5 alt)
+        from models.backbone import VA_3DResNet
+        Bc, Tc = 8, 64
+        torch.manual_seed(12345)
+        net = VA_3DResNet(inputDim=512, hiddenDim=512, nLayers=2, nClasses=2, frameLen=Tc, use_cbam=True, resnet_ver="v1").to(dev).train()
+        vid = f(((rs.randint(0, 256, (Bc, 3, Tc, 112, 112)).astype(np.float32)) - 127.5) / 127.5)
+        ddp = FlatGradDDP(net, max_norm=1.0)
+
+        def step_r():
+            ddp.zero_grad()
+            y = net(vid)
+            ops.va_loss(y, val[:Bc, :Tc].contiguous(), aro[:Bc, :Tc].contiguous())[0].backward()
+            ddp.finish()
+        ms = timed(step_r, 6)
+        print(json.dumps({"aux": "cbam_resnet3d", "workload": "VA_3DResNet(resnet_ver='v1', use_cbam=True) visual-only training step (SURVEY 8(d) C5 alt), 8 clips x 64 "
+                          "frames of 112 x 112: 3-D stem + per-frame ResNet-18 convolutions on MIOpen, the 8 CBAM gates and the BiGRU head on the HIP kernels",
+                          "clips": Bc, "ms_per_step": round(ms, 3), "clips_per_s": round(Bc / ms * 1e3, 1), "dtype": "f32"}), flush=True)
+
+
 def run_aux(which, budget_s):
     """the aux leg in a child process with a wall-clock budget (MIOpen's first-use kernel search for the C5 stem can take long
     on a fresh box): whatever finished in time is reported"""
@@ -599,21 +619,3 @@ def worker(args):
 
 if __name__ == "__main__":
     main()
-    if "cbam" in which:          # (last: MIOpen's first-use search for the ResNet convolutions may eat what is left of the budget)
-        # inside a model: VA_3DResNet(resnet_ver='v1', use_cbam=True) visual-only, 8 clips x 64 frames of 112 x 112 (SURVEY 8(d) C5 alt)
-        from models.backbone import VA_3DResNet
-        Bc, Tc = 8, 64
-        torch.manual_seed(12345)
-        net = VA_3DResNet(inputDim=512, hiddenDim=512, nLayers=2, nClasses=2, frameLen=Tc, use_cbam=True, resnet_ver="v1").to(dev).train()
-        vid = f(((rs.randint(0, 256, (Bc, 3, Tc, 112, 112)).astype(np.float32)) - 127.5) / 127.5)
-        ddp = FlatGradDDP(net, max_norm=1.0)
-
-        def step_r():
-            ddp.zero_grad()
-            y = net(vid)
-            ops.va_loss(y, val[:Bc, :Tc].contiguous(), aro[:Bc, :Tc].contiguous())[0].backward()
-            ddp.finish()
-        ms = timed(step_r, 6)
-        print(json.dumps({"aux": "cbam_resnet3d", "workload": "VA_3DResNet(resnet_ver='v1', use_cbam=True) visual-only training step (SURVEY 8(d) C5 alt), 8 clips x 64 "
-                          "frames of 112 x 112: 3-D stem + per-frame ResNet-18 convolutions on MIOpen, the 8 CBAM gates and the BiGRU head on the HIP kernels",
-                          "clips": Bc, "ms_per_step": round(ms, 3), "clips_per_s": round(Bc / ms * 1e3, 1), "dtype": "f32"}), flush=True)
