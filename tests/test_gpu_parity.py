@@ -1155,3 +1155,19 @@ def test_solo_scans_h128_through_the_c_abi(B, T, bf16):
         for a, b_, name in zip(got, ref, ("dgx", "dgh", "dh", "db_ih", "db_hh")):
             close(a, b_, (3e-5 if T < 10 else 5e-3) if bf16 else 5e-6, "%s (direct=%d)" % (name, direct))
     ops.poll_scan_error()
+
+
+@pytest.mark.parametrize("switch", ["M3T_CONV_X6", "M3T_CBAM_FUSED"])
+def test_conv_and_cbam_kernel_switches(switch):
+    """README's switch table, the two entries the C3 step does not exercise (read once per process, hence a child):
+    M3T_CONV_X6=0 -- the TCN / tcn_simple convolutions on the fp32-MFMA kernel instead of the bf16x6 implicit GEMM;
+    M3T_CBAM_FUSED=0 -- CBAM as channel gate + spatial gate instead of the fused operator.  Same arithmetic: the convolution,
+    TemporalBlock, CBAM and ResNet parity tests must pass unchanged."""
+    import subprocess
+    import sys
+    env = dict(os.environ, M3T_SCAN_LOCK="0", **{switch: "0"})
+    pick = "conv1d_on_the_bf16x6_pipe or tcn_train_mode or tcn_golden" if switch == "M3T_CONV_X6" else "cbam_golden or resnet_cbam or cbam_stage"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k", pick], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:]
+    assert " passed" in r.stdout
