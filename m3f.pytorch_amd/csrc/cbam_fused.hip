@@ -30,6 +30,9 @@
 namespace {
 
 constexpr int FT = 512;       // threads per workgroup (8 waves)
+// planes in flight per lane in the plane sweeps of SMALL maps (one unit per lane per plane): 4 float4 units, or 16 single pixels
+// (the ragged 7 x 7 stage: 196 B per wave-load otherwise leaves the memory pipe idle)
+template <int E> struct PlaneBatch { static constexpr int n = E == 4 ? 4 : 16; };
 
 __device__ __forceinline__ double block_sum_d8(double v, double* red) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -80,6 +83,7 @@ __global__ __launch_bounds__(FT) void cbam_f1_kernel(const float* __restrict__ x
                                                      float* __restrict__ comp, int32_t* __restrict__ cargmax,
                                                      float* __restrict__ conv_out, double* __restrict__ part, int C, int Cr,
                                                      int H, int W, int G, int Qp) {
+    constexpr int PB = PlaneBatch<E>::n;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ double red[FT / 64];
     const int HW = H * W, Q = HW / E;
@@ -103,17 +107,17 @@ __global__ __launch_bounds__(FT) void cbam_f1_kernel(const float* __restrict__ x
         const int per = 64 / G, sub = lane % G, pi = lane / G;
         if (SMALL) {
             const int step = (FT / 64) * per;
-            for (int c0 = wave * per; c0 < C; c0 += 4 * step) {
-                float v[4][E];
-                bool ok[4];
+            for (int c0 = wave * per; c0 < C; c0 += PB * step) {
+                float v[PB][E];
+                bool ok[PB];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < PB; ++k) {
                     const int c = c0 + k * step + pi;
                     ok[k] = c < C && sub < Q;
                     if (ok[k]) Unit<E>::ld(xb + (size_t)c * HW + (size_t)sub * E, v[k]);
                 }
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < PB; ++k) {
                     const int c = c0 + k * step + pi;
                     float sum = 0.f, mx = -INFINITY;
                     int am = 0x7fffffff;
@@ -372,6 +376,7 @@ __global__ __launch_bounds__(FT) void cbam_f2_kernel(const float* __restrict__ x
                                                      const float* __restrict__ stats,
                                                      float* __restrict__ xhat, float* __restrict__ ss, float* __restrict__ y,
                                                      int C, int HW, int G) {
+    constexpr int PB = PlaneBatch<E>::n;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* s_sc = sm;
     float* s_ss = s_sc + al4(C);
@@ -393,17 +398,17 @@ __global__ __launch_bounds__(FT) void cbam_f2_kernel(const float* __restrict__ x
     const int per = 64 / G, sub = lane % G, pi = lane / G;
     if (SMALL) {
         const int step = (FT / 64) * per;
-        for (int c0 = wave * per; c0 < C; c0 += 4 * step) {
-            float v[4][E];
-            bool ok[4];
+        for (int c0 = wave * per; c0 < C; c0 += PB * step) {
+            float v[PB][E];
+            bool ok[PB];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < PB; ++k) {
                 const int c = c0 + k * step + pi;
                 ok[k] = c < C && sub < Q;
                 if (ok[k]) Unit<E>::ld(xb + (size_t)c * HW + (size_t)sub * E, v[k]);
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < PB; ++k)
                 if (ok[k]) {
                     const int c = c0 + k * step + pi;
                     const float sc = s_sc[c];
@@ -561,6 +566,7 @@ __global__ __launch_bounds__(FT) void cbam_b2_kernel(const float* __restrict__ d
                                                      float* __restrict__ dx, float* __restrict__ g_datt, float* __restrict__ g_dh,
                                                      float* __restrict__ g_r, float* __restrict__ dwpart, int C, int Cr, int H,
                                                      int W, int G, float inv_total, int training) {
+    constexpr int PB = PlaneBatch<E>::n;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int HW = H * W, Q = HW / E, HWa = al4(HW);
     float* s_dc = sm;                          // [HW] gradient wrt the conv output
@@ -634,11 +640,11 @@ __global__ __launch_bounds__(FT) void cbam_b2_kernel(const float* __restrict__ d
     const int per = 64 / G, sub = lane % G, pi = lane / G;
     if (SMALL) {
         const int step = (FT / 64) * per;
-        for (int c0 = wave * per; c0 < C; c0 += 4 * step) {
-            float a[4][E], b[4][E];
-            bool ok[4];
+        for (int c0 = wave * per; c0 < C; c0 += PB * step) {
+            float a[PB][E], b[PB][E];
+            bool ok[PB];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < PB; ++k) {
                 const int c = c0 + k * step + pi;
                 ok[k] = c < C && sub < Q;
                 if (ok[k]) {
@@ -647,7 +653,7 @@ __global__ __launch_bounds__(FT) void cbam_b2_kernel(const float* __restrict__ d
                 }
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < PB; ++k) {
                 const int c = c0 + k * step + pi;
                 float ds = 0.f;
                 if (ok[k]) {
@@ -741,17 +747,17 @@ __global__ __launch_bounds__(FT) void cbam_b2_kernel(const float* __restrict__ d
     float* db = dx + (size_t)n * C * HW;
     if (SMALL) {
         const int step = (FT / 64) * per;
-        for (int c0 = wave * per; c0 < C; c0 += 4 * step) {
-            float a[4][E];
-            bool ok[4];
+        for (int c0 = wave * per; c0 < C; c0 += PB * step) {
+            float a[PB][E];
+            bool ok[PB];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < PB; ++k) {
                 const int c = c0 + k * step + pi;
                 ok[k] = c < C && sub < Q;
                 if (ok[k]) Unit<E>::ld(gb + (size_t)c * HW + (size_t)sub * E, a[k]);
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < PB; ++k)
                 if (ok[k]) {
                     const int c = c0 + k * step + pi;
                     const float sc = s_sc[c], da = s_davg[c], dm = s_dmaxc[c];
