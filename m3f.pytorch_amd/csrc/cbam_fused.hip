@@ -30,9 +30,10 @@
 namespace {
 
 constexpr int FT = 512;       // threads per workgroup (8 waves)
-// planes in flight per lane in the plane sweeps of SMALL maps (one unit per lane per plane): 4 float4 units, or 16 single pixels
-// (the ragged 7 x 7 stage: 196 B per wave-load otherwise leaves the memory pipe idle)
-template <int E> struct PlaneBatch { static constexpr int n = E == 4 ? 4 : 16; };
+// planes in flight per lane in the plane sweeps of SMALL maps (one unit per lane per plane).  Measured on the ragged 7 x 7 stage
+// (single-pixel units, 196 B per wave-load): 4, 8, 16 planes in flight -> 0.485, 0.485, 0.530 ms for the whole gate: the small maps
+// are bound by the per-frame dependency chain (squeeze -> MLP -> compress -> conv), not by loads in flight
+template <int E> struct PlaneBatch { static constexpr int n = 4; };
 
 __device__ __forceinline__ double block_sum_d8(double v, double* red) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
