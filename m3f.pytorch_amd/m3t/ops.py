@@ -174,7 +174,7 @@ def wgrad_stream(device, i=0):
     if sts is None:
         sts = [torch.cuda.Stream(device=device) for _ in range(_N_WGRAD)]
         _WGRAD[key] = sts
-    return sts[i % len(sts)]
+    return sts[i % min(2, len(sts))]          # (streams 2.. only ever take tail GEMMs, see _MultiBiGRU.backward.level_dw)
 
 
 def wgrad_streams(device):
@@ -746,10 +746,13 @@ class _MultiBiGRU(torch.autograd.Function):
         rr = [0]
 
         def level_dw(l, idxs, spread=False):           # off the chain: only the optimizer reads these
-            """the weight-gradient GEMMs of (l, idxs) on the weight-gradient streams (every stream has waited for the scan).
-            spread: the LAST weight gradients of the pass (nothing but the optimizer follows) are dealt over both streams, so
-            that two of these small GEMMs share the chip; everything else goes to stream 0 (a second concurrent GEMM stream
-            beside the chain takes CUs from the data-gradient GEMMs and stretches the scans: 17.77 vs 17.21 ms, round 2)"""
+            """the weight-gradient GEMMs of (l, idxs) on weight-gradient stream 0 (every stream has waited for the scan; a second
+            concurrent GEMM stream beside the chain takes CUs from the data-gradient GEMMs and stretches the scans: 17.77 vs 17.21
+            ms, round 2).  spread: the LAST weight gradients of the pass -- nothing else is queued on the level's own stream any
+            more -- alternate between that stream and weight-gradient stream 1: FlatGradDDP.finish() then follows the last GEMM
+            on the main stream without a cross-queue hop (a queue that has idled for ~2 ms answers an event ~110 us late: 15.69
+            vs 15.81 ms per step, round 3; more tail streams do not help: 2 / 3 / 4 streams 15.83 / 15.83 / 15.93, the tail is
+            bound by GEMM throughput, not by concurrency)"""
             for s in idxs:
                 H = Hs[s]
                 inp, out, gts = layer_io(l, s)
@@ -758,8 +761,11 @@ class _MultiBiGRU(torch.autograd.Function):
                     base = s * per + 1 + (2 * l + d) * 4
                     dw_ih, dw_hh = out_grads[base:base + 2]      # the bias gradients come out of the scan itself
                     goff = d * B * T * 3 * H
-                    nw = len(wgs) if spread else 1
-                    with torch.cuda.stream(wgs[rr[0] % nw]):
+                    # tail: [the stream this level runs on, weight-gradient stream 1] -- after the last level nothing else is queued on
+                    # the level's own stream, and finalize (FlatGradDDP.finish) then follows its last GEMM with no cross-queue hop
+                    pool = [torch.cuda.current_stream(), wgs[1]] if spread else wgs[:1]
+                    nw = len(pool)
+                    with torch.cuda.stream(pool[rr[0] % nw]):
                         if T > 1 and (B * (T - 1)) % 32 != 0 and (B * T) % 32 == 0 and H % 128 == 0:
                             # K = B (T-1) is no multiple of the bf16x6 GEMMs' 32-deep k tile (e.g. 8 clips x 64 frames: K = 504) and
                             # the segmented product would fall to the fp32-MFMA kernel (20 launches, 7 % of a C5 step).  h_prev at
@@ -779,9 +785,10 @@ class _MultiBiGRU(torch.autograd.Function):
                                   seg=(T - 1, T, a_off, b_off), prec=prec)
                         else:
                             dw_hh.zero_()
-                    with torch.cuda.stream(wgs[(rr[0] + 1) % nw]):
+                    rr[0] += 1
+                    with torch.cuda.stream(pool[rr[0] % nw]):
                         sgemm(1, 0, 3 * H, I, B * T, dgx[l][s], d * 3 * H, 6 * H, inp, 0, I, dw_ih, 0, I, prec=prec)
-                    rr[0] += 2
+                    rr[0] += 1
 
         for w_ in wgs:
             w_.wait_stream(main)
@@ -826,7 +833,7 @@ class _MultiBiGRU(torch.autograd.Function):
                     level_gemms(0, heavy, last=True)
                     with torch.cuda.stream(side):
                         level_scan(0, light, ev_h0)
-                        level_gemms(0, light)
+                        level_gemms(0, light, last=True)
                 else:
                   for l in range(L - 1, -1, -1):
                     level_scan(l, heavy, ev_light)
