@@ -443,6 +443,9 @@ def worker(args):
     from m3t import _lib
     for _ in range(args.warmup):
         step()
+    if os.environ.get("M3T_BENCH_INJECT_FAULT") == str(rank) and not (args.worker or 0):
+        # fault injection (tests of the supervisors' fallback): this rank's first attempt sees "a persistent scan gave up"
+        ops.inject_scan_error()
     fence()
     ops.PROFILE.clear()
     n_persist0 = _lib.load().m3t_gru_persist_count()

@@ -346,3 +346,65 @@ dist.destroy_process_group()
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2500:])
     assert "RCCL-BETWEEN-SCANS-OK" in r.stdout
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with NO torchrun and no WORLD_SIZE must start its two ranks itself (a child
+    `python -m torch.distributed.run`, issued before the parent touches the GPU), each rank a supervisor + worker pair, and print
+    ONE JSON line with n_gpus = 2 -- weak scaling (the default) and `--scaling strong` (the global batch split over the ranks).
+    Both ranks on cuda:0 over gloo (M3T_BENCH_BACKEND / M3T_BENCH_ONE_DEVICE: the 1-GPU stand-in for the RCCL run)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(M3T_BENCH_BACKEND="gloo", M3T_BENCH_ONE_DEVICE="1", MASTER_PORT="29561")
+    for extra, batch, per_gpu in (([], 4, 4), (["--scaling", "strong"], 4, 2)):
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", str(batch),
+               "--frames", "40"] + extra
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, lines
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["value"] > 0 and d["cpu_baseline"] is None
+        assert d["scaling"] == ("strong" if extra else "weak")
+        assert d["config"]["clips_per_gpu"] == per_gpu and d["config"]["global_batch"] == 2 * per_gpu
+        assert d["allreduce"]["world_size"] == 2 and d["allreduce"]["ms_in_step"] is not None and "fallback" not in d
+
+
+def test_bench_rejects_a_world_size_that_is_not_gpus():
+    """--gpus must equal the number of ranks: a launcher that starts 2 ranks for `--gpus 1` exits non-zero on every rank"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, M3T_BENCH_BACKEND="gloo", M3T_BENCH_ONE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29571", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0 and "WORLD_SIZE=2" in (out.stderr + out.stdout)
+
+
+def test_bench_falls_back_to_per_step_scans_in_fresh_workers_when_a_scan_gives_up():
+    """The 8-GPU default (persistent scans + RCCL) has never run on real multi-GPU hardware, so bench.py plans for its failure:
+    a worker that sees M3T_ESPIN exits with a code its supervisor knows, every supervisor ends its own worker, and fresh workers
+    run the launch-per-step scans with overlapped gradient buckets; the JSON line says so.  Here rank 1's first attempt gets an
+    injected scan failure (M3T_BENCH_INJECT_FAULT, raised by a kernel exactly as a dying scan raises it)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(M3T_BENCH_BACKEND="gloo", M3T_BENCH_ONE_DEVICE="1", MASTER_PORT="29581", M3T_BENCH_INJECT_FAULT="1")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4", "--frames", "40"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2500:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (lines, out.stderr[-1500:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    assert "fallback" in d and "launch-per-step" in d["fallback"], d.get("fallback")
+    assert "worker failure" in out.stderr
