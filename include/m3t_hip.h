@@ -50,6 +50,15 @@ extern "C" {
  * instead of the 2^-23 of the default six-product form ('highest'), 1.3-1.5x the GEMM rate.  Opt-in (m3t.ops.precision("high"));
  * interior shapes only (others run exact fp32); M3T_GEMM_BF16 wins if both are set.  The recurrent scans ignore it. */
 #define M3T_GEMM_HIGH 256
+/* fp32-accurate products from TWO fp16 terms per operand and three MFMAs (a_hi b_hi + a_hi b_lo + a_lo b_hi, fp32 accumulate) instead
+ * of three bf16 terms and six: fp16 holds 11 significant bits, so two terms carry 22 (+ the sign of the remainder) and the dropped
+ * a_lo b_lo is <= 2^-22 relative; fp16's narrow exponent range is met by scaling each operand by the power of two that puts its
+ * largest magnitude into [2^14, 2^15) -- the library measures max |A|, max |B| with one extra launch in front of the GEMM, on the
+ * same stream, no host round trip -- and unscaling in the epilogue (exact).  Elements more than 2^17 below their operand's maximum
+ * keep an absolute error of 2^-40 of that maximum instead of a relative one.  Measured against fp64 the mode is as accurate as the
+ * six-product form (fewer fp32 accumulate roundings per k) -- DESIGN.md section 5e.  Interior shapes only; the BF16 and HIGH flags
+ * win if set.  The recurrent scans ignore it. */
+#define M3T_GEMM_F16X3 1024
 /* scheduling hint: other streams run persistent scans while this GEMM runs (the interleaved encoder level of m3t.ops._MultiBiGRU):
  * take gemm_x6.hip, whose phases only overlap across workgroups, instead of the software-pipelined gemm_x6d.hip -- the faster
  * kernel's higher request rate slows the scans' exchange by as much as it gains (measured: same step time, backward scans
@@ -83,6 +92,23 @@ int m3t_sgemm(int transA, int transB, int M, int N, int K,
               float* C, int ldc, const float* bias, int act, int accumulate,
               int seg_len, int seg_stride, int a_off, int b_off,
               float* ws, size_t ws_bytes, int flags, void* stream);
+
+/* m3t_sgemm with the callers' MAGNITUDE SLOTS for the M3T_GEMM_F16X3 mode.  A slot is 8 bytes, 8-B aligned, whose low word holds the
+ * fp32 bit pattern of an upper bound of max |x| over the operand (any bound is valid; a loose one only costs precision at the small
+ * end).  amax_a / amax_b may each be NULL: that operand is then measured by the library (one extra launch on `stream`).  Producers
+ * that know their magnitudes for free provide the slots: m3t_absmax (one launch for up to 16 tensors), m3t_gru_scan_bwd
+ * (m3t_gru_bwd_desc.amax), a constant (|h| <= 1 for GRU outputs).  Ignored unless the fp16x3 kernel runs. */
+int m3t_sgemm_scaled(int transA, int transB, int M, int N, int K,
+                     const float* A, int lda, const float* B, int ldb,
+                     float* C, int ldc, const float* bias, int act, int accumulate,
+                     int seg_len, int seg_stride, int a_off, int b_off,
+                     float* ws, size_t ws_bytes, int flags,
+                     const unsigned long long* amax_a, const unsigned long long* amax_b, void* stream);
+
+/* slots[i] = max(slots[i], bits of max |x| over x[i] = [rows[i] x cols[i]] fp32 with leading dimension ld[i]) for n <= 16 tensors in
+ * ONE launch (cols % 4 == 0, ld % 4 == 0, 16-B aligned).  The caller zero-initialises a slot before its first use. */
+int m3t_absmax(int n, const float* const* x, const size_t* rows, const int* cols, const size_t* ld,
+               unsigned long long* const* slots, void* stream);
 
 /* Which kernel m3t_sgemm would run for a call of this shape (all operands 16-B aligned, ld % 4 == 0) and how many
  * split-K slabs: *kernel = 0 fp32-MFMA tile kernel, 1 bf16x6 128 x 128 tile, 2 bf16x6 256 x 256 tile (only with
@@ -164,6 +190,7 @@ typedef struct {
     float* db_ih;         /* scan also delivers db_ih [3H] = sum_b (dr~,dz~,dn~) and db_hh [3H] = sum_b (dr~,dz~,   */
     float* db_hh;         /* dn~*r) -- the bias gradients, without a pass over dgx / dgh (all three NULL = skip)    */
     int H, reverse, ldo, ooff, ldg, goff;
+    unsigned long long* amax;  /* optional magnitude slot (m3t_sgemm_scaled): raised to the bits of max |dgx|, |dgh| of this scan */
 } m3t_gru_bwd_desc;
 
 /* Number of one-launch scans (persistent or solo) this process has issued so far (tests use it to assert which path ran). */

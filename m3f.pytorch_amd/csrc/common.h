@@ -70,3 +70,31 @@ static __device__ __forceinline__ void m3t_drop_mask4(const M3TDrop& d, uint32_t
     m[0] = c0 < d.thr ? d.scale : 0.f; m[1] = c1 < d.thr ? d.scale : 0.f;
     m[2] = c2 < d.thr ? d.scale : 0.f; m[3] = c3 < d.thr ? d.scale : 0.f;
 }
+
+// ---- fp16x3 GEMM operands (gemm_x6.hip / gemm_x6d.hip, NS = 4) ----------------------------------------------------------------
+// An operand is staged as two fp16 terms of s x, s the power of two that puts max |x| into [2^14, 2^15) (fp16 overflows at 65504).
+// bits = the fp32 bit pattern of max |x| over (a superset of) the operand, measured on the device right before the GEMM
+// (gemm.hip, the backward scans).  All-zero or denormal-only operands: s saturates at 2^127, 1/s flushes to zero, the product is zero.
+// inf / NaN do not count towards the maximum (m3t_fin_abs): the finite values keep their scale and the non-finite ones become fp16
+// inf / NaN, which poison exactly the outputs they would poison in an fp32 GEMM.
+static __device__ __forceinline__ float m3t_fin_abs(float x) {          // |x|, or 0 for inf / NaN
+    const unsigned b = __float_as_uint(x) & 0x7fffffffu;
+    return b < 0x7f800000u ? __uint_as_float(b) : 0.f;
+}
+static __device__ __forceinline__ void m3t_f16_scale(unsigned bits, float& s, float& inv) {
+    const int e = (int)((bits >> 23) & 0xffu);
+    const int es = min(max(268 - e, 1), 254);            // biased exponent of s = 2^(14 - (e - 127))
+    s = __uint_as_float((unsigned)es << 23);
+    inv = __uint_as_float((unsigned)(254 - es) << 23);
+}
+// Magnitude slots: 8 bytes holding (epoch << 32 | bits), only ever raised with a 64-bit atomic max -- a measurement with a larger
+// epoch overrides what the slot held without a memset in between; caller-provided slots (m3t_absmax, m3t_gru_bwd_desc.amax) are
+// zero-initialised by their owner and written with epoch 0.  m3t_f16x3_measure: the library's own slot pair per (device, stream) for
+// operands that arrive without a slot -- stream order keeps a call's GEMM between its own measurement and the next one.  It
+// measures the regions whose `have` pointer is null and returns the two pointers to use.  Regions are [rows x cols] fp32 with leading
+// dimension ld (cols % 4 == 0, 16-B aligned); any SUPERSET of the operand is a valid bound.
+struct M3TRegion { const float* p; unsigned long long rows; unsigned long long ld; int c4; unsigned long long* slot; };
+int m3t_f16x3_measure(const M3TRegion& a, const unsigned long long* have_a, const M3TRegion& b, const unsigned long long* have_b,
+                      const unsigned long long** use_a, const unsigned long long** use_b, hipStream_t s);
+int m3t_absmax_regions(const M3TRegion* regs, int n, hipStream_t s);      // any n; slots raised with epoch 0 (caller-owned)
+bool m3t_f16x3_enabled();                                                      // env M3T_GEMM_F16X3 != 0

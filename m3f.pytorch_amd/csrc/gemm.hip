@@ -299,6 +299,63 @@ __global__ __launch_bounds__(256) void splitk_reduce4_kernel(const float* __rest
     }
 }
 
+
+// ---- fp16x3: operand magnitudes (see m3t_f16_scale and the magnitude slots in common.h) ------------------------------------------
+// grid (blocks, regions): blockIdx.y = region; every block reduces a grid-stride share of its region's float4s to one value and raises
+// the region's slot with ONE 64-bit atomic max of (epoch << 32 | bits of max |x| over the FINITE x): |x| as an unsigned integer
+// orders like the number.
+constexpr int ABSMAX_REGIONS = 16;
+struct AbsmaxArgs { M3TRegion r[ABSMAX_REGIONS]; };
+__global__ __launch_bounds__(256) void f16x3_absmax_kernel(AbsmaxArgs a, unsigned epoch) {
+    const M3TRegion r = a.r[blockIdx.y];
+    const unsigned long long total = r.rows * (unsigned long long)r.c4;
+    if ((unsigned long long)blockIdx.x * 256 >= total && blockIdx.x > 0) return;
+    unsigned m = 0u;
+    const bool dense = (unsigned long long)r.c4 * 4ull == r.ld;
+    auto at = [&](unsigned long long i) -> const uint4* {
+        if (dense) return reinterpret_cast<const uint4*>(r.p + (size_t)i * 4);
+        const unsigned long long row = i / (unsigned)r.c4;
+        return reinterpret_cast<const uint4*>(r.p + (size_t)(row * r.ld + (i - row * (unsigned)r.c4) * 4ull));
+    };
+    auto fin = [](unsigned b) { b &= 0x7fffffffu; return b < 0x7f800000u ? b : 0u; };      // inf / NaN do not count: see m3t_f16_scale
+    auto fold = [&](const uint4& v) { m = max(max(m, fin(v.x)), max(fin(v.y), max(fin(v.z), fin(v.w)))); };
+    const unsigned long long stride = (unsigned long long)gridDim.x * 256;
+    unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < total; i += 4 * stride) {            // four independent 16-B loads in flight per thread
+        const uint4 v0 = *at(i), v1 = *at(i + stride), v2 = *at(i + 2 * stride), v3 = *at(i + 3 * stride);
+        fold(v0); fold(v1); fold(v2); fold(v3);
+    }
+    for (; i < total; i += stride) fold(*at(i));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    __shared__ unsigned red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(red[0], red[1]), max(red[2], red[3]));
+        // (a thousand 64-bit atomics on one address cost more than the pass itself: a block whose value the slot already
+        // covers -- the slot only ever grows, so a stale read errs on the safe side -- skips its atomic)
+        const unsigned long long val = ((unsigned long long)epoch << 32) | m;
+        if (__hip_atomic_load(r.slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < val) atomicMax(r.slot, val);
+    }
+}
+
+static int launch_absmax(const M3TRegion* regs, int n, unsigned epoch, hipStream_t s) {
+    AbsmaxArgs a;
+    unsigned long long tm = 0;
+    for (int i = 0; i < n; ++i) {
+        a.r[i] = regs[i];
+        const unsigned long long t = regs[i].rows * (unsigned long long)regs[i].c4;
+        if (t > tm) tm = t;
+    }
+    for (int i = n; i < ABSMAX_REGIONS; ++i) a.r[i] = regs[0];
+    unsigned long long blocks = (tm + 256ull * 8 - 1) / (256ull * 8);                  // >= 8 float4 per thread
+    if (blocks < 1) blocks = 1;
+    if (blocks > 1024) blocks = 1024;
+    f16x3_absmax_kernel<<<dim3((unsigned)blocks, n), 256, 0, s>>>(a, epoch);
+    return (int)hipGetLastError();
+}
+
 static void launch_splitk_reduce(const float* ws, float* C, const float* bias, int M, int N, int ldc, int splits, int act,
                                  int accumulate, hipStream_t s) {
     const size_t total = (size_t)M * N;
@@ -398,10 +455,64 @@ __global__ __launch_bounds__(256) void mask_pos_drop_kernel(const float* __restr
 
 }  // namespace
 
+
+#include <mutex>
+#include <map>
+int m3t_f16x3_measure(const M3TRegion& ra, const unsigned long long* have_a, const M3TRegion& rb, const unsigned long long* have_b,
+                      const unsigned long long** use_a, const unsigned long long** use_b, hipStream_t s) {
+    *use_a = have_a; *use_b = have_b;
+    if (have_a && have_b) return 0;
+    struct Slot { unsigned long long* dev; unsigned epoch; };
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, Slot> slots;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    Slot sl;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = slots.find({dev, s});
+        if (it == slots.end()) {
+            Slot n; n.dev = nullptr; n.epoch = 0;
+            if ((e = hipMalloc(reinterpret_cast<void**>(&n.dev), 256)) != hipSuccess) return (int)e;
+            if ((e = hipMemset(n.dev, 0, 256)) != hipSuccess) return (int)e;
+            it = slots.emplace(std::make_pair(dev, s), n).first;
+        }
+        sl.epoch = ++it->second.epoch;
+        sl.dev = it->second.dev;
+    }
+    M3TRegion regs[2];
+    int n = 0;
+    if (!have_a) { regs[n] = ra; regs[n].slot = sl.dev; *use_a = sl.dev; ++n; }
+    if (!have_b) { regs[n] = rb; regs[n].slot = sl.dev + 1; *use_b = sl.dev + 1; ++n; }
+    return launch_absmax(regs, n, sl.epoch, s);
+}
+
+int m3t_absmax_regions(const M3TRegion* regs, int n, hipStream_t s) {          // (epoch 0: caller-owned slots)
+    for (int i = 0; i < n; i += ABSMAX_REGIONS) {
+        const int rc = launch_absmax(regs + i, n - i < ABSMAX_REGIONS ? n - i : ABSMAX_REGIONS, 0u, s);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+extern "C" int m3t_absmax(int n, const float* const* x, const size_t* rows, const int* cols, const size_t* ld,
+                          unsigned long long* const* slots, void* stream) {
+    if (n <= 0) return 0;
+    if (n > ABSMAX_REGIONS || !x || !rows || !cols || !ld || !slots) return M3T_EINVAL;
+    M3TRegion regs[ABSMAX_REGIONS];
+    for (int i = 0; i < n; ++i) {
+        if (!x[i] || !slots[i] || cols[i] <= 0 || cols[i] % 4 != 0 || ld[i] % 4 != 0 || (uintptr_t)x[i] % 16 != 0 || (uintptr_t)slots[i] % 8 != 0)
+            return M3T_EINVAL;
+        regs[i] = M3TRegion{x[i], (unsigned long long)rows[i], (unsigned long long)ld[i], cols[i] / 4, slots[i]};
+    }
+    return launch_absmax(regs, n, 0u, (hipStream_t)stream);
+}
+
 int m3t_sgemm_x6_launch(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                         float* C, int ldc, const float* bias, int act, int accumulate, int seg_len, int seg_stride,
                         int a_off, int b_off, float* ws, int splits, int kchunk, size_t dyn_lds, int bf16_operands, int narrow,
-                        hipStream_t s);
+                        const unsigned long long* amax_a, const unsigned long long* amax_b, hipStream_t s);
 
 int m3t_sgemm_x6c_launch(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                          float* C, int ldc, const float* bias, int act, int accumulate, int seg_len, int seg_stride,
@@ -418,6 +529,16 @@ int m3t_sgemm_x6d_launch(int transA, int transB, int M, int N, int K, const floa
 // (M3T_GEMM_EXCLUSIVE) and the calibrated cost model prefers it; the 128 x 64 tile for N % 64 == 0 and under-filled grids.
 static int x6d_mode() { return 2; }
 static int x6c_mode() { return 2; }
+
+// M3T_GEMM_F16X3=0: M3T_GEMM_F16X3 is ignored (the six-product bf16 form runs instead) -- A/B runs and the switch test
+bool m3t_f16x3_enabled() {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("M3T_GEMM_F16X3");
+        on = (e && e[0] == '0') ? 0 : 1;
+    }
+    return on == 1;
+}
 
 static bool x6_enabled() {
     static int on = -1;
@@ -439,13 +560,14 @@ static GemmPlan plan_gemm(int transA, int M, int N, int K, int seg_len, bool vec
     g.narrow = 0;
     const int bf16 = (flags & M3T_GEMM_BF16) ? 1 : 0;
     const int high = (!bf16 && (flags & M3T_GEMM_HIGH)) ? 1 : 0;      // two bf16 terms per operand, four products (bf16x6 kernel, NS = 2)
+    const int f16x3 = (!bf16 && !high && (flags & M3T_GEMM_F16X3) && m3t_f16x3_enabled()) ? 1 : 0;   // two fp16 terms per scaled operand, three products (NS = 4)
     const int tiles = cdiv(M, BM) * cdiv(N, BN);
     // interior shapes go to the bf16x6 kernels (fp32-accurate, 2.67x the fp32 MFMA rate)
     // (N % 64 == 0 is enough with the 128 x 64 tile: e.g. the conv3d weight gradient with N = C_in k^3 = 1728)
     const bool n64 = (N % 128 != 0) && (N % 64 == 0) && narrow_mode();
     const bool x6 = x6_enabled() && (M % 128 == 0) && (N % 128 == 0 || n64) && (K % 32 == 0) && K > 0 && vec &&
                     (seg_len == 0 || seg_len >= 32);
-    const double ns_per_k = x6 ? (bf16 ? 14.0 : (high ? 27.0 : 36.0)) : 84.0;
+    const double ns_per_k = x6 ? (bf16 ? 14.0 : (high ? 27.0 : (f16x3 ? 22.0 : 36.0))) : 84.0;
     const int kq = x6 ? 32 : BK;
     // split-K choice by a small cost model (ns): a CU works through its co-resident blocks at ~0.39 TFLOP/s
     // (84 ns per k per 128x128 block; 1.3x slower when it holds a single block), slabs cost their HBM traffic.
@@ -465,7 +587,7 @@ static GemmPlan plan_gemm(int transA, int M, int N, int K, int seg_len, bool vec
     // x6c: 17 + rounds x (13 + 0.130 K/split); x6: 12 + 1.2 x its model above (x 1.12 with a row-contiguous A); slabs:
     // 0.3 x their traffic at 3 TB/s + 3.  x6c needs a grid that fills whole rounds of 256 CUs: M = 9600 is 37.5 tiles, so
     // N = 1536 (228 tiles) suits it and N = 1024 / 2048 (152 / 304) do not.
-    if (x6 && !n64 && !high && x6c_mode() != 0 && (flags & M3T_GEMM_EXCLUSIVE) && !(flags & M3T_GEMM_BACKGROUND)) {
+    if (x6 && !n64 && !high && !f16x3 && x6c_mode() != 0 && (flags & M3T_GEMM_EXCLUSIVE) && !(flags & M3T_GEMM_BACKGROUND)) {
         const int tiles_b = cdiv(M, 256) * cdiv(N, 256);
         const double per_k = bf16 ? 0.052 : 0.130;
         const double slab = (double)M * N * 4.0 / 3000.0 / 1e3;          // us per slab pass
@@ -506,6 +628,14 @@ extern "C" int m3t_sgemm_plan(int transA, int M, int N, int K, int seg_len, size
 extern "C" int m3t_sgemm(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                          float* C, int ldc, const float* bias, int act, int accumulate, int seg_len, int seg_stride,
                          int a_off, int b_off, float* ws, size_t ws_bytes, int flags, void* stream) {
+    return m3t_sgemm_scaled(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, seg_len, seg_stride, a_off, b_off,
+                            ws, ws_bytes, flags, nullptr, nullptr, stream);
+}
+
+extern "C" int m3t_sgemm_scaled(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                                float* C, int ldc, const float* bias, int act, int accumulate, int seg_len, int seg_stride,
+                                int a_off, int b_off, float* ws, size_t ws_bytes, int flags, const unsigned long long* amax_a,
+                                const unsigned long long* amax_b, void* stream) {
     if (M <= 0 || N <= 0) return 0;
     if (K < 0 || !A || !B || !C) return M3T_EINVAL;
     if (seg_len > 0 && !(transA == 1 && transB == 0)) return M3T_EINVAL;
@@ -524,17 +654,30 @@ extern "C" int m3t_sgemm(int transA, int transB, int M, int N, int K, const floa
     hipStream_t s = (hipStream_t)stream;
     if (g.kernel != 0) {
         int rc;
+        const int f16x3 = (!p.bf16 && !(flags & M3T_GEMM_HIGH) && (flags & M3T_GEMM_F16X3) && m3t_f16x3_enabled()) ? 1 : 0;
+        const unsigned long long* use_a = nullptr; const unsigned long long* use_b = nullptr;
+        if (f16x3) {
+            // operands without a caller's magnitude slot are measured here, over the rows x columns each one spans in memory
+            // (segmented K: the rows from the first segment's first to the last segment's last, a superset)
+            const size_t kr = seg_len > 0 ? (size_t)(K / seg_len - 1) * seg_stride + seg_len : (size_t)K;
+            const float* A0 = seg_len > 0 ? A + (size_t)a_off * lda : A;
+            const float* B0 = seg_len > 0 ? B + (size_t)b_off * ldb : B;
+            const M3TRegion ra{A0, (unsigned long long)(transA ? kr : (size_t)M), (unsigned long long)lda, (transA ? M : K) / 4, nullptr};
+            const M3TRegion rb{B0, (unsigned long long)(transB ? (size_t)N : kr), (unsigned long long)ldb, (transB ? K : N) / 4, nullptr};
+            const int rm = m3t_f16x3_measure(ra, amax_a, rb, amax_b, &use_a, &use_b, s);
+            if (rm) return rm;
+        }
         if (g.kernel == 2)
             rc = m3t_sgemm_x6c_launch(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, seg_len, seg_stride,
                                       a_off, b_off, ws, splits, kchunk, p.bf16, s);
-        else if (!g.narrow && !(flags & (M3T_GEMM_BACKGROUND | M3T_GEMM_HIGH)) && (x6d_mode() == 1 || (x6d_mode() == 2 && !(flags & M3T_GEMM_BESIDE_SCAN))))      // ("high": measured better on gemm_x6.hip)
+        else if (!g.narrow && !f16x3 && !(flags & (M3T_GEMM_BACKGROUND | M3T_GEMM_HIGH)) && (x6d_mode() == 1 || (x6d_mode() == 2 && !(flags & M3T_GEMM_BESIDE_SCAN))))      // ("high": measured better on gemm_x6.hip)
             // the same product, software-pipelined inside each wave (gemm_x6d.hip): bit-identical results, 8-28 % faster
             rc = m3t_sgemm_x6d_launch(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, seg_len, seg_stride,
                                       a_off, b_off, ws, splits, kchunk, p.bf16 ? 1 : ((flags & M3T_GEMM_HIGH) ? 2 : 0), s);
         else
             rc = m3t_sgemm_x6_launch(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, seg_len, seg_stride,
                                      a_off, b_off, ws, splits, kchunk, (flags & M3T_GEMM_BACKGROUND) ? (size_t)40 * 1024 : 0,
-                                     p.bf16 ? 1 : ((flags & M3T_GEMM_HIGH) ? 2 : 0), g.narrow, s);
+                                     p.bf16 ? 1 : ((flags & M3T_GEMM_HIGH) ? 2 : (f16x3 ? 3 : 0)), g.narrow, use_a, use_b, s);
         if (rc) return rc;
         if (splits > 1) {
             launch_splitk_reduce(ws, C, bias, M, N, ldc, splits, act, accumulate, s);

@@ -39,6 +39,8 @@ struct X6Params {
     size_t cv_btap;                      // TB == 1: elements between the [N][C] weight planes of consecutive taps
     const float* cv_mask; const float* cv_res; float* cv_pre;
     M3TDrop cv_drop;                     // in-kernel dropout mask instead of cv_mask
+    const unsigned long long* amax_a;    // NS = 4 (fp16x3): low words = the bits of max |A|, max |B| (magnitude slots, common.h)
+    const unsigned long long* amax_b;
 };
 
 __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
@@ -56,8 +58,24 @@ __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// NS = 4, "fp16x3": the operand, scaled by a power of two s that puts its largest magnitude into [2^14, 2^15), is the sum of TWO fp16
+// terms (hi = rn(s x), lo = rn(s x - hi): 22 significant bits wherever lo is a normal number, absolute error <= 2^-25 / s below that);
+// a product is the three fp16 MFMAs hi hi + hi lo + lo hi (exact in fp32; the dropped lo lo is <= 2^-22 relative), the scales leave
+// in the epilogue.  6 VALU instructions per pair (v_pk_mul, v_cvt_pk_f16_f32, 2 v_cvt_f32_f16, v_pk_fma, v_cvt_pk_f16_f32).
+constexpr int planes_of(int NS) { return NS == 4 ? 2 : NS; }
 template <int NS>
-__device__ __forceinline__ void split3_pair(f32x2 v, unsigned (&o)[3]) {
+__device__ __forceinline__ void split3_pair(f32x2 v, unsigned (&o)[3], float scale = 1.f) {
+    if (NS == 4) {
+        const f32x2 vs = v * scale;
+        const f16x2 h = __builtin_convertvector(vs, f16x2);
+        o[0] = __builtin_bit_cast(unsigned, h);
+        const f32x2 r1 = vs - __builtin_convertvector(h, f32x2);
+        const f16x2 l = __builtin_convertvector(r1, f16x2);
+        o[1] = __builtin_bit_cast(unsigned, l);
+        return;
+    }
     const bf16x2 h = __builtin_convertvector(v, bf16x2);
     o[0] = __builtin_bit_cast(unsigned, h);
     if (NS == 1) return;
@@ -82,16 +100,16 @@ __device__ __forceinline__ void kc_load(const float* __restrict__ p, size_t ld, 
     for (int i = 0; i < NR; ++i) r[i] = *reinterpret_cast<const float4*>(p + (size_t)i * 32 * ld);
 }
 template <int NS, int NR = 4>
-__device__ __forceinline__ void kc_store(unsigned char* __restrict__ S, const float4 (&r)[4]) {
+__device__ __forceinline__ void kc_store(unsigned char* __restrict__ S, const float4 (&r)[4], float scale = 1.f) {
     const int tid = threadIdx.x & 255;
     const int c = tid & 7, r0 = tid >> 3;            // k-quad c of the 32-k tile: octet c >> 1, half c & 1
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
         unsigned lo[3], hi2[3];                      // k pairs (0,1) and (2,3) of this row
-        split3_pair<NS>((f32x2){r[i].x, r[i].y}, lo);
-        split3_pair<NS>((f32x2){r[i].z, r[i].w}, hi2);
+        split3_pair<NS>((f32x2){r[i].x, r[i].y}, lo, scale);
+        split3_pair<NS>((f32x2){r[i].z, r[i].w}, hi2, scale);
 #pragma unroll
-        for (int s = 0; s < NS; ++s)
+        for (int s = 0; s < planes_of(NS); ++s)
             *reinterpret_cast<u32x2*>(S + s * SPLIT_BYTES + (c >> 1) * PLANE + (r0 + 32 * i) * 16 + (c & 1) * 8) = (u32x2){lo[s], hi2[s]};
     }
 }
@@ -99,7 +117,7 @@ __device__ __forceinline__ void kc_store(unsigned char* __restrict__ S, const fl
 // Lanes l and l+32 of a wave hold the two k-quads of ONE octet (octet = wave) for the same rows; after the swaps the
 // lower lane owns the complete records of rows 0, 1 and the upper lane those of rows 2, 3.
 template <int NS>
-__device__ __forceinline__ void mc_store(unsigned char* __restrict__ S, const float4 (&r)[4]) {
+__device__ __forceinline__ void mc_store(unsigned char* __restrict__ S, const float4 (&r)[4], float scale = 1.f) {
     const int tid = threadIdx.x & 255;
     const int wave = tid >> 6, h = (tid >> 5) & 1, row0 = (tid & 31) * 4;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -110,12 +128,12 @@ __device__ __forceinline__ void mc_store(unsigned char* __restrict__ S, const fl
         const float v1 = i == 0 ? r[1].x : i == 1 ? r[1].y : i == 2 ? r[1].z : r[1].w;
         const float v2 = i == 0 ? r[2].x : i == 1 ? r[2].y : i == 2 ? r[2].z : r[2].w;
         const float v3 = i == 0 ? r[3].x : i == 1 ? r[3].y : i == 2 ? r[3].z : r[3].w;
-        split3_pair<NS>((f32x2){v0, v1}, lo[i]);
-        split3_pair<NS>((f32x2){v2, v3}, hi2[i]);
+        split3_pair<NS>((f32x2){v0, v1}, lo[i], scale);
+        split3_pair<NS>((f32x2){v2, v3}, hi2[i], scale);
     }
     unsigned char* q = S + wave * PLANE + (row0 + 2 * h) * 16;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
+    for (int s = 0; s < planes_of(NS); ++s) {
         // permlane32_swap(a, b): a's upper half <-> b's lower half.  lower lanes: (own row 0 | partner's row 0);
         // upper lanes: (partner's row 2 | own row 2) -- in both cases (.x, .y) = (even k-quad, odd k-quad)
         const u32x2 e0 = __builtin_amdgcn_permlane32_swap(lo[0][s], lo[2][s], false, false);
@@ -165,6 +183,12 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p) {
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float sc_a = 1.f, sc_b = 1.f, sc_ia = 1.f, sc_ib = 1.f;      // NS = 4: operand scales and their inverses (powers of two)
+    if (NS == 4) {
+        m3t_f16_scale((unsigned)*p.amax_a, sc_a, sc_ia);
+        m3t_f16_scale((unsigned)*p.amax_b, sc_b, sc_ib);
+    }
 
     // per-thread operand pointers
     const float* pa; const float* pb;
@@ -230,8 +254,8 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p) {
         }
     };
     auto sstore = [&]() {
-        if (TA == 0) kc_store<NS>(As, ra); else mc_store<NS>(As, ra);
-        if (TB == 1) kc_store<NS, BR>(Bs, rb); else mc_store<NS>(Bs, rb);
+        if (TA == 0) kc_store<NS>(As, ra, sc_a); else mc_store<NS>(As, ra, sc_a);
+        if (TB == 1) kc_store<NS, BR>(Bs, rb, sc_b); else mc_store<NS>(Bs, rb, sc_b);
     };
 
     if (ntiles > 0) { gload(); sstore(); }
@@ -241,9 +265,10 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p) {
         __builtin_amdgcn_sched_barrier(0);     // the prefetch stays in flight: nothing that consumes it may be hoisted here
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
-            bf16x8 fa[NS][2], fb[NS][NJ];
+            constexpr int NP = planes_of(NS);
+            bf16x8 fa[NP][2], fb[NP][NJ];
 #pragma unroll
-            for (int s = 0; s < NS; ++s)
+            for (int s = 0; s < NP; ++s)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     fa[s][i] = *reinterpret_cast<const bf16x8*>(As + s * SPLIT_BYTES + (kh * 2 + hi) * PLANE + (wm * 64 + i * 32 + l31) * 16);
@@ -255,6 +280,13 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p) {
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     f32x16 c = acc[i][j];      // smallest terms first
+                    if (NS == 4) {                 // fp16x3: lo hi, hi lo, hi hi
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[1][i]), __builtin_bit_cast(f16x8, fb[0][j]), c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[0][i]), __builtin_bit_cast(f16x8, fb[1][j]), c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[0][i]), __builtin_bit_cast(f16x8, fb[0][j]), c, 0, 0, 0);
+                        acc[i][j] = c;
+                        continue;
+                    }
                     if (NS == 2) {                 // "high" mode: two bf16 terms per operand (16 mantissa bits), four products
                         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[1][j], c, 0, 0, 0);
                         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[0][j], c, 0, 0, 0);
@@ -294,6 +326,7 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p) {
                 const int row = bm + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 if (CONV && p.cv_drop.on && (r & 3) == 0) m3t_drop_mask4(p.cv_drop, (uint32_t)row >> 2, (uint32_t)col, dm);
                 float v = acc[i][j][r];
+                if (NS == 4) v = v * sc_ia * sc_ib;              // (exact: powers of two)
                 float* q = dst + (size_t)row * ldd + col;
                 if (CONV) {
                     const size_t o = (size_t)row * ldd + col;
@@ -320,8 +353,9 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p) {
 int m3t_sgemm_x6_launch(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                         float* C, int ldc, const float* bias, int act, int accumulate, int seg_len, int seg_stride,
                         int a_off, int b_off, float* ws, int splits, int kchunk, size_t dyn_lds, int bf16_operands, int narrow,
-                        hipStream_t s) {
+                        const unsigned long long* amax_a, const unsigned long long* amax_b, hipStream_t s) {
     X6Params p;
+    p.amax_a = amax_a; p.amax_b = amax_b;
     p.A = A; p.B = B; p.C = C; p.bias = bias; p.ws = ws;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.act = act; p.accumulate = accumulate; p.splits = splits; p.kchunk = kchunk;
@@ -338,8 +372,11 @@ int m3t_sgemm_x6_launch(int transA, int transB, int M, int N, int K, const float
         else sgemm_x6_kernel<1, 1, false, NS_, false, XNT_><<<grid, block, dyn_lds, s>>>(p);                                       \
     } while (0)
     // bf16_operands: 1 = bf16 mode (one product), 2 = "high" mode (two bf16 terms per operand, four products), 0 = fp32-accurate (bf16x6)
+    // 3 = fp16x3 (two fp16 terms per scaled operand, three products; amax = the operands' magnitude slots)
+    if (bf16_operands == 3 && (!amax_a || !amax_b)) return M3T_EINVAL;
     if (bf16_operands == 1) { if (narrow) M3T_X6_DISPATCH(1, 64); else M3T_X6_DISPATCH(1, 128); }
     else if (bf16_operands == 2) { if (narrow) M3T_X6_DISPATCH(2, 64); else M3T_X6_DISPATCH(2, 128); }
+    else if (bf16_operands == 3) { if (narrow) M3T_X6_DISPATCH(4, 64); else M3T_X6_DISPATCH(4, 128); }
     else { if (narrow) M3T_X6_DISPATCH(3, 64); else M3T_X6_DISPATCH(3, 128); }
 #undef M3T_X6_DISPATCH
     hipError_t e = hipGetLastError();
@@ -352,8 +389,10 @@ int m3t_sgemm_x6_launch(int transA, int transB, int M, int N, int K, const float
 // one [Co][Ci] plane per tap); anti = 1 (data gradient): w_t is [K][Ci][Co] read as the row-major [K*Ci][Co] matrix.
 int m3t_conv_x6_launch(const float* x, const float* w_t, const float* bias, const float* res, const float* mask, float* y,
                        float* pre, int B, int T, int Ci, int Co, int K, int dil, int lead, int act, int anti, int bf16_operands,
-                       M3TDrop drop, hipStream_t s) {
+                       M3TDrop drop, const unsigned long long* amax_a, const unsigned long long* amax_b, hipStream_t s) {
     X6Params p;
+    p.amax_a = amax_a; p.amax_b = amax_b;
+    if (bf16_operands == 3 && (!amax_a || !amax_b)) return M3T_EINVAL;
     p.A = x; p.B = w_t; p.C = y; p.bias = bias; p.ws = nullptr;
     p.M = B * T; p.N = Co; p.K = K * Ci; p.lda = Ci; p.ldb = anti ? Co : Ci; p.ldc = Co;
     p.act = act; p.accumulate = 0; p.splits = 1; p.kchunk = K * Ci;
@@ -369,9 +408,9 @@ int m3t_conv_x6_launch(const float* x, const float* w_t, const float* bias, cons
         else sgemm_x6_kernel<0, TB_, false, NS_, true, 128><<<grid, block, 0, s>>>(p);                 \
     } while (0)
     if (anti) {
-        if (bf16_operands == 1) M3T_CONV_GO(0, 1); else if (bf16_operands == 2) M3T_CONV_GO(0, 2); else M3T_CONV_GO(0, 3);
+        if (bf16_operands == 1) M3T_CONV_GO(0, 1); else if (bf16_operands == 2) M3T_CONV_GO(0, 2); else if (bf16_operands == 3) M3T_CONV_GO(0, 4); else M3T_CONV_GO(0, 3);
     } else {
-        if (bf16_operands == 1) M3T_CONV_GO(1, 1); else if (bf16_operands == 2) M3T_CONV_GO(1, 2); else M3T_CONV_GO(1, 3);
+        if (bf16_operands == 1) M3T_CONV_GO(1, 1); else if (bf16_operands == 2) M3T_CONV_GO(1, 2); else if (bf16_operands == 3) M3T_CONV_GO(1, 4); else M3T_CONV_GO(1, 3);
     }
 #undef M3T_CONV_GO
     return (int)hipGetLastError();

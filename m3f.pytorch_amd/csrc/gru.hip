@@ -720,7 +720,7 @@ extern "C" int m3t_gru_scan_fwd(const m3t_gru_fwd_desc* scans, int n_scans, int 
 }
 
 static int scan_bwd_impl(const m3t_gru_bwd_desc* scans, int n_scans, int B, int T, float* ws, size_t ws_bytes, int flags,
-                         void* stream) {
+                         void* stream, bool* amax_done) {
     AfterGuard after_guard;
     if (n_scans <= 0 || B <= 0 || T <= 0) return 0;
     if (persist_poll_error()) return M3T_ESPIN;
@@ -740,7 +740,10 @@ static int scan_bwd_impl(const m3t_gru_bwd_desc* scans, int n_scans, int B, int 
     for (int i = n_scans; i <= M3T_MAX_SCANS; ++i) g.blk_start[i] = blocks;
     dim3 grid(blocks, cdiv(B, RB));
     hipStream_t s = (hipStream_t)stream;
-    if (solo_bwd_ok(g, B, T, flags)) return solo_bwd_launch(g, B, T, flags, s);      // H = 128: one workgroup per (scan, clip)
+    if (solo_bwd_ok(g, B, T, flags)) {               // H = 128: one workgroup per (scan, clip); raises the magnitude slots itself
+        *amax_done = true;
+        return solo_bwd_launch(g, B, T, flags, s);
+    }
     bool fast = true;
     for (int i = 0; i < n_scans; ++i) {
         const m3t_gru_bwd_desc& d = scans[i];
@@ -786,6 +789,7 @@ static int scan_bwd_impl(const m3t_gru_bwd_desc* scans, int n_scans, int B, int 
                 else wfrag_bwd_prep_kernel<<<blk, 256, 0, s>>>(bg.d[i].w_hh_t, fp.wfrag[i], H, bg.bf16);
             }
             M3T_LAUNCH_CHECK();
+            *amax_done = persist_bwd_uses_x6(bg, B, T, flags);          // that kernel raises the descs' magnitude slots itself
             return persist_bwd_launch(bg, fp, B, T, flags, s);
         }
         { const int e = persist_take_after(s); if (e) return e; }
@@ -818,8 +822,25 @@ static int scan_bwd_impl(const m3t_gru_bwd_desc* scans, int n_scans, int B, int 
 
 extern "C" int m3t_gru_scan_bwd(const m3t_gru_bwd_desc* scans, int n_scans, int B, int T, float* ws, size_t ws_bytes,
                                 int flags, void* stream) {
-    const int rc = scan_bwd_impl(scans, n_scans, B, T, ws, ws_bytes, flags, stream);
+    bool amax_done = false;
+    const int rc = scan_bwd_impl(scans, n_scans, B, T, ws, ws_bytes, flags, stream, &amax_done);
     if (rc || n_scans <= 0 || B <= 0 || T <= 0) return rc;
+    if (!amax_done) {
+        // magnitude slots (desc.amax) on the paths whose kernels do not track them: one pass over dgx / dgh behind the scan
+        M3TRegion regs[2 * M3T_MAX_SCANS];
+        int nr = 0;
+        for (int i = 0; i < n_scans; ++i) {
+            const m3t_gru_bwd_desc& d = scans[i];
+            if (!d.amax) continue;
+            if (d.H % 4 != 0 || d.ldg % 4 != 0 || d.goff % 4 != 0 || (uintptr_t)d.dgx % 16 != 0 || (uintptr_t)d.dgh % 16 != 0) return M3T_EINVAL;
+            regs[nr++] = M3TRegion{d.dgx + d.goff, (unsigned long long)B * T, (unsigned long long)d.ldg, 3 * d.H / 4, d.amax};
+            regs[nr++] = M3TRegion{d.dgh, (unsigned long long)B * T, (unsigned long long)3 * d.H, 3 * d.H / 4, d.amax};
+        }
+        if (nr) {
+            const int ra = m3t_absmax_regions(regs, nr, (hipStream_t)stream);
+            if (ra) return ra;
+        }
+    }
     BiasFinish f;
     std::memset(&f, 0, sizeof(f));
     f.n = n_scans;

@@ -721,6 +721,7 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd6_kernel(BwdGroup g, FragPt
     const bool pok = pw && pb < B;
     float dh_carry = 0.f, z_next = 0.f;                // dh_{t+1} and z_{t+1} of this thread's (row, unit)
     float sb_r = 0.f, sb_z = 0.f, sb_n = 0.f, sb_nr = 0.f;   // sums over t of the gate gradients: the bias gradients of this clip
+    float amx = 0.f;                                   // max |dr~|, |dz~|, |dn~| of this thread: the magnitude slot d.amax (fp16x3 GEMMs)
     if (pok && d.dh_n) dh_carry = d.dh_n[(size_t)pb * H + pj];
 
     constexpr size_t TILE = (size_t)RT * 256;
@@ -805,6 +806,10 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd6_kernel(BwdGroup g, FragPt
     if (pok && d.db_part) {
         float* q = d.db_part + (size_t)pb * 4 * H + pj;
         q[0] = sb_r; q[H] = sb_z; q[2 * H] = sb_n; q[3 * H] = sb_nr;
+    }
+    if (d.amax && pw) {                                // (waves 0..3: uniform per wave)
+        const float m = wave_max(pok ? amx : 0.f);
+        if (lane == 0) atomicMax(d.amax, (unsigned long long)__float_as_uint(m));
     }
     if (stamp)
         for (int i = 0; i < 6; ++i) ex.prof[i] = (unsigned long long)psum[i];

@@ -172,6 +172,7 @@ __global__ __launch_bounds__(ST) void gru_solo_bwd_kernel(BwdGroup g, int B, int
     }
     float dh_carry = d.dh_n ? d.dh_n[(size_t)b * SH + j] : 0.f, z_next = 0.f;
     float sb_r = 0.f, sb_z = 0.f, sb_n = 0.f, sb_nr = 0.f;
+    float amx = 0.f;                                   // max |dr~|, |dz~|, |dn~|: the scan's magnitude slot (fp16x3 GEMMs)
     float dv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // dgh_{t+1}[96 row + 16 m + l16]
 
     const float* pd = d.dout + (size_t)b * T * d.ldo + d.ooff + j;
@@ -198,6 +199,7 @@ __global__ __launch_bounds__(ST) void gru_solo_bwd_kernel(BwdGroup g, int B, int
         const GateBwd c = gru_cell_bwd(dout, dh_carry, z_next, mm, step > 0, g4.x, g4.y, g4.z, g4.w, step < T - 1 ? hprev : 0.f);
         dh_carry = c.dht; z_next = g4.y;
         sb_r += c.dr; sb_z += c.dz; sb_n += c.dn; sb_nr += c.dnr;
+        amx = fmaxf(fmaxf(amx, m3t_fin_abs(c.dr)), fmaxf(m3t_fin_abs(c.dz), m3t_fin_abs(c.dn)));      // (|dn r| <= |dn|: one bound for dgx and dgh)
         if (row == 0) {
             dbuf[step & 1][j] = bf ? rbf(c.dr) : c.dr;
             dbuf[step & 1][SH + j] = bf ? rbf(c.dz) : c.dz;
@@ -218,6 +220,10 @@ __global__ __launch_bounds__(ST) void gru_solo_bwd_kernel(BwdGroup g, int B, int
             float* q = d.db_part + (size_t)b * 4 * SH + j;
             q[0] = sb_r; q[SH] = sb_z; q[2 * SH] = sb_n; q[3 * SH] = sb_nr;
         }
+    }
+    if (d.amax) {                                      // (every row computes the same cell values: any of them serves)
+        const float m = wave_max(amx);
+        if ((threadIdx.x & 63) == 0) atomicMax(d.amax, (unsigned long long)__float_as_uint(m));
     }
 }
 

@@ -272,7 +272,7 @@ int m3t_conv_x6d_launch(const float* x, const float* w_t, const float* bias, con
                         M3TDrop drop, hipStream_t s);
 int m3t_conv_x6_launch(const float* x, const float* w_t, const float* bias, const float* res, const float* mask, float* y,
                        float* pre, int B, int T, int Ci, int Co, int K, int dil, int lead, int act, int anti, int bf16_operands,
-                       M3TDrop drop, hipStream_t s);
+                       M3TDrop drop, const unsigned long long* amax_a, const unsigned long long* amax_b, hipStream_t s);
 
 static bool conv_x6_enabled() {
     static int on = -1;
@@ -305,8 +305,17 @@ extern "C" int m3t_conv1d_fwd(const float* x, const float* w_t, const float* bia
             al(drop_mask) && al(pre)) {
             // (the software-pipelined CONV form of gemm_x6d.hip was no faster on these 300-tile grids than the 128 x 64 tiles of
             // gemm_x6.hip -- C1 1.96 vs 2.03 ms, C2 7.44 vs 7.35 ms, round 2 -- and is no longer dispatched)
+            const int mode = p.bf16 ? 1 : ((flags & M3T_GEMM_HIGH) ? 2 : (((flags & M3T_GEMM_F16X3) && m3t_f16x3_enabled()) ? 3 : 0));
+            const unsigned long long* ua = nullptr; const unsigned long long* ub = nullptr;
+            if (mode == 3) {                       // fp16x3: max |x|, max |w| (one launch, this stream)
+                const M3TRegion rx{x, (unsigned long long)B * T, (unsigned long long)Ci, Ci / 4, nullptr};
+                const M3TRegion rw{w_t, (unsigned long long)K * (anticausal ? Ci : Co), (unsigned long long)(anticausal ? Co : Ci),
+                                   (anticausal ? Co : Ci) / 4, nullptr};
+                const int rm = m3t_f16x3_measure(rx, nullptr, rw, nullptr, &ua, &ub, (hipStream_t)stream);
+                if (rm) return rm;
+            }
             return m3t_conv_x6_launch(x, w_t, bias, res, drop_mask, y, pre, B, T, Ci, Co, K, dilation, lead, act, anticausal,
-                                      p.bf16 ? 1 : ((flags & M3T_GEMM_HIGH) ? 2 : 0), p.drop, (hipStream_t)stream);
+                                      mode, p.drop, ua, ub, (hipStream_t)stream);
         }
     }
     const int halo = (K - 1) * dilation;
@@ -343,6 +352,16 @@ extern "C" int m3t_conv1d_wgrad(const float* dy, const float* x, float* dw_t, in
                                 int dilation, int lead, float* ws, size_t ws_bytes, int flags, void* stream) {
     if (Ci <= 0 || Co <= 0 || K <= 0 || !dy || !x || !dw_t) return M3T_EINVAL;
     if (lead < 0 || lead > (K - 1) * dilation) return M3T_EINVAL;
+    const int gflags = (flags & M3T_BF16) ? M3T_GEMM_BF16 : (flags & (M3T_GEMM_HIGH | M3T_GEMM_F16X3));
+    const unsigned long long* ua = nullptr; const unsigned long long* ub = nullptr;
+    if ((gflags & M3T_GEMM_F16X3) && m3t_f16x3_enabled() && !(gflags & M3T_GEMM_HIGH) && B > 0 && Co % 4 == 0 && Ci % 4 == 0 && (uintptr_t)dy % 16 == 0 &&
+        (uintptr_t)x % 16 == 0) {
+        // fp16x3: the K taps multiply the same two tensors -- measure them once
+        const M3TRegion rd{dy, (unsigned long long)B * T, (unsigned long long)Co, Co / 4, nullptr};
+        const M3TRegion rx{x, (unsigned long long)B * T, (unsigned long long)Ci, Ci / 4, nullptr};
+        const int rm = m3t_f16x3_measure(rd, nullptr, rx, nullptr, &ua, &ub, (hipStream_t)stream);
+        if (rm) return rm;
+    }
     for (int j = 0; j < K; ++j) {
         const int off = lead - (K - 1 - j) * dilation;     // x row = dy row + off
         const int aoff = off < 0 ? -off : 0, boff = off > 0 ? off : 0, span = aoff + boff;
@@ -353,8 +372,8 @@ extern "C" int m3t_conv1d_wgrad(const float* dy, const float* x, float* dw_t, in
             continue;
         }
         // dw_t[j][co][ci] = sum_b sum_t dy[b,t,co] * x[b,t+off,ci] over the t with both rows inside the clip
-        const int rc = m3t_sgemm(1, 0, Co, Ci, B * (T - span), dy, Co, x, Ci, out, Ci, nullptr, 0, 0, T - span, T, aoff, boff,
-                                 ws, ws_bytes, (flags & M3T_BF16) ? M3T_GEMM_BF16 : (flags & M3T_GEMM_HIGH), stream);
+        const int rc = m3t_sgemm_scaled(1, 0, Co, Ci, B * (T - span), dy, Co, x, Ci, out, Ci, nullptr, 0, 0, T - span, T, aoff, boff,
+                                        ws, ws_bytes, gflags, ua, ub, stream);
         if (rc) return rc;
     }
     return 0;

@@ -12,6 +12,7 @@ M3T_ESPIN = 10002
 M3T_SCAN_NO_PERSIST = 1
 M3T_BF16 = 2
 M3T_GEMM_BESIDE_SCAN = 512      # scheduling hint, see include/m3t_hip.h
+M3T_GEMM_F16X3 = 1024   # two fp16 terms per scaled operand, three products: fp32-accurate (include/m3t_hip.h)
 M3T_GEMM_HIGH = 256      # two bf16 terms per operand, four products: torch.set_float32_matmul_precision('high')
 M3T_GEMM_EXCLUSIVE = 8
 M3T_SCAN_FP32 = 4
@@ -33,7 +34,7 @@ class GruFwdDesc(C.Structure):
 class GruBwdDesc(C.Structure):
     _fields_ = [("dout", _f), ("out", _f), ("gates", _f), ("w_hh_t", _f), ("dh_n", _f),
                 ("dgx", _f), ("dgh", _f), ("dh", _f), ("db_part", _f), ("db_ih", _f), ("db_hh", _f),
-                ("H", _i), ("reverse", _i), ("ldo", _i), ("ooff", _i), ("ldg", _i), ("goff", _i)]
+                ("H", _i), ("reverse", _i), ("ldo", _i), ("ooff", _i), ("ldg", _i), ("goff", _i), ("amax", _f)]
 
 
 # name -> argtypes; the test-suite checks that every symbol of include/m3t_hip.h is here and exported.
@@ -41,6 +42,8 @@ SIGNATURES = {
     "m3t_version": [],
     "m3t_device_arch": [C.c_char_p, _i],
     "m3t_sgemm": [_i, _i, _i, _i, _i, _f, _i, _f, _i, _f, _i, _f, _i, _i, _i, _i, _i, _i, _f, _z, _i, _s],
+    "m3t_sgemm_scaled": [_i, _i, _i, _i, _i, _f, _i, _f, _i, _f, _i, _f, _i, _i, _i, _i, _i, _i, _f, _z, _i, _f, _f, _s],
+    "m3t_absmax": [_i, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), _s],
     "m3t_sgemm_plan": [_i, _i, _i, _i, _i, _z, _i, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "m3t_colsum": [_f, _i, _i, _i, _f, _i, _f, _z, _s],
     "m3t_transpose": [_f, _i, _i, _i, _f, _i, _s],

@@ -206,22 +206,25 @@ def workspace(device, nbytes=_WS_MIN, tag=None):
 
 # ----------------------------------------------------------------------------- raw wrappers
 # ---- arithmetic mode of the dense contractions --------------------------------------------------------------------
-# "fp32" (default): fp32-accurate everywhere (what the reference computes).  "high": opt-in, the GEMMs and convolutions treat
-# each fp32 operand as the sum of two bfloat16 numbers (four products, ~2^-16 relative error per term -- what
+# "fp32" (default): fp32-accurate everywhere (what the reference computes): the GEMMs and implicit-GEMM convolutions form every
+# product from two fp16 terms per (scaled) operand -- three MFMAs, M3T_GEMM_F16X3, DESIGN.md section 5e -- the recurrent scans from
+# three bf16 terms (six MFMAs).  "x6": the GEMMs and convolutions on the six-product bf16 form too (the default until round 3; the
+# library's own default when called with flags = 0; env M3T_GEMM_F16X3=0 forces it).  "high": opt-in, the GEMMs and convolutions
+# treat each fp32 operand as the sum of two bfloat16 numbers (four products, ~2^-16 relative error per term -- what
 # torch.set_float32_matmul_precision('high') means); the recurrent scans stay fp32-accurate.  "bf16": BASELINE.json config C2 -- every
 # matmul / conv / recurrent-product operand (activation, weight, gradient) is rounded to bf16, accumulation, state,
 # biases, gate math, normalisation and the loss stay fp32, parameters stay fp32 ("master weights").  An autograd
 # Function records the mode of its forward and uses it for its backward.
-_PREC = [0]
+_PREC = [_lib.M3T_GEMM_F16X3]
 
 
 class precision:
     """`with ops.precision("bf16"): y = model(x)` -- context manager selecting the arithmetic mode."""
 
     def __init__(self, mode):
-        if mode not in ("fp32", "high", "bf16"):
-            raise ValueError("precision mode must be 'fp32', 'high' or 'bf16'")
-        self.flag = {"fp32": 0, "high": _lib.M3T_GEMM_HIGH, "bf16": _lib.M3T_BF16}[mode]
+        if mode not in ("fp32", "x6", "high", "bf16"):
+            raise ValueError("precision mode must be 'fp32', 'x6', 'high' or 'bf16'")
+        self.flag = {"fp32": _lib.M3T_GEMM_F16X3, "x6": 0, "high": _lib.M3T_GEMM_HIGH, "bf16": _lib.M3T_BF16}[mode]
 
     def __enter__(self):
         self.prev = _PREC[0]
@@ -234,16 +237,54 @@ class precision:
 
 
 def sgemm(transA, transB, M, N, K, A, a_off, lda, B, b_off, ldb, Cm, c_off, ldc, bias=None, act=0,
-          accumulate=False, seg=(0, 0, 0, 0), use_ws=True, prec=None, exclusive=False):
+          accumulate=False, seg=(0, 0, 0, 0), use_ws=True, prec=None, exclusive=False, amax=(None, None)):
+    """amax = (slot of A, slot of B): device addresses of magnitude slots for the fp16x3 products (amax_slots / amax_one /
+    measure_amax below, or a backward scan's); None: the library measures that operand itself (one more launch)"""
     ws = workspace(Cm.device) if use_ws else None
     flags = (_PREC[0] if prec is None else prec) | (_lib.M3T_GEMM_EXCLUSIVE if exclusive else 0)
     if _FENCED[0]:
         flags |= _lib.M3T_GEMM_BESIDE_SCAN       # issued inside the interleaved schedule of _MultiBiGRU: scans of another stream run beside it
     with _Timed("sgemm_kernel", 1, 2.0 * M * N * K) if PROFILE_GEMM[0] else _NULL:
-        rc = lib().m3t_sgemm(transA, transB, M, N, K, _p(A, a_off), lda, _p(B, b_off), ldb, _p(Cm, c_off), ldc,
-                             _p(bias), act, int(accumulate), seg[0], seg[1], seg[2], seg[3],
-                             _p(ws), (ws.numel() * 4) if ws is not None else 0, flags, _stream())
+        rc = lib().m3t_sgemm_scaled(transA, transB, M, N, K, _p(A, a_off), lda, _p(B, b_off), ldb, _p(Cm, c_off), ldc,
+                                    _p(bias), act, int(accumulate), seg[0], seg[1], seg[2], seg[3],
+                                    _p(ws), (ws.numel() * 4) if ws is not None else 0, flags, amax[0], amax[1], _stream())
     _lib.check(rc, "m3t_sgemm")
+
+
+# ---- magnitude slots of the fp16x3 products (include/m3t_hip.h: m3t_sgemm_scaled) ----------------------------------------------
+_AMAX_ONE = {}
+
+
+def amax_one(device):
+    """address of a slot that says |x| <= 1 (GRU outputs: h is a convex combination of tanh values and the previous h)"""
+    key = (device.type, device.index)
+    t = _AMAX_ONE.get(key)
+    if t is None:
+        t = _AMAX_ONE[key] = torch.full((1,), 0x3F800000, dtype=torch.int64, device=device)
+    return t.data_ptr()
+
+
+def amax_slots(n, device):
+    """n fresh (zero) slots on the current stream; slot i lives at .data_ptr() + 8 i"""
+    return torch.zeros(n, dtype=torch.int64, device=device)
+
+
+def measure_amax(items):
+    """items: (tensor viewed as [rows, cols] rows-contiguous, slot address) pairs -- one launch per 16 of them; returns False (and
+    measures nothing) unless every tensor is 16-B aligned with cols % 4 == 0"""
+    for t, _ in items:
+        if t.shape[-1] % 4 != 0 or t.data_ptr() % 16 != 0 or not t.is_contiguous():
+            return False
+    for i in range(0, len(items), 16):
+        chunk = items[i:i + 16]
+        n = len(chunk)
+        xs = (C.c_void_p * n)(*[t.data_ptr() for t, _ in chunk])
+        rows = (C.c_size_t * n)(*[t.numel() // t.shape[-1] for t, _ in chunk])
+        cols = (C.c_int * n)(*[t.shape[-1] for t, _ in chunk])
+        lds = (C.c_size_t * n)(*[t.shape[-1] for t, _ in chunk])
+        sl = (C.c_void_p * n)(*[a for _, a in chunk])
+        _lib.check(lib().m3t_absmax(n, xs, rows, cols, lds, sl, _stream()), "m3t_absmax")
+    return True
 
 
 def sgemm_plan(transA, M, N, K, seg_len=0, exclusive=False, prec=None, ws_bytes=_WS_MIN):
@@ -292,8 +333,15 @@ class _Linear(torch.autograd.Function):
         M = x.numel() // K
         y = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
         ctx.prec = _PREC[0]
-        sgemm(0, 1, M, N, K, x, 0, K, w, 0, K, y, 0, N, bias=b, act=act, prec=ctx.prec, exclusive=True)
-        ctx.save_for_backward(x, w, y if act else None)
+        # fp16x3 products: x and w are measured once here (one launch) and their slots serve the backward GEMMs too
+        slots = None
+        if (ctx.prec & _lib.M3T_GEMM_F16X3) and M % 128 == 0 and N % 64 == 0 and K % 32 == 0 and w.is_contiguous():
+            slots = amax_slots(3, x.device)
+            if not measure_amax([(x, slots.data_ptr()), (w, slots.data_ptr() + 8)]):
+                slots = None
+        sgemm(0, 1, M, N, K, x, 0, K, w, 0, K, y, 0, N, bias=b, act=act, prec=ctx.prec, exclusive=True,
+              amax=(None, None) if slots is None else (slots.data_ptr(), slots.data_ptr() + 8))
+        ctx.save_for_backward(x, w, y if act else None, slots)
         ctx.act, ctx.has_bias = act, b is not None
         ctx.bias_ref = b if (b is not None and id(b) in _GRAD_SINKS) else None
         ctx.weight_ref = w if id(w) in _GRAD_SINKS else None
@@ -301,16 +349,19 @@ class _Linear(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, y = ctx.saved_tensors
+        x, w, y, slots = ctx.saved_tensors
         dy = _req(dy.contiguous(), "dy")
         if ctx.act:
             dy = mask_pos(y, dy)
         K, N = x.shape[-1], w.shape[0]
         M = x.numel() // K
         dx = dw = db = None
+        a_x = a_w = a_dy = None
+        if slots is not None and measure_amax([(dy, slots.data_ptr() + 16)]):       # dy: once for both backward GEMMs
+            a_x, a_w, a_dy = slots.data_ptr(), slots.data_ptr() + 8, slots.data_ptr() + 16
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            sgemm(0, 0, M, K, N, dy, 0, N, w, 0, K, dx, 0, K, prec=ctx.prec, exclusive=True)
+            sgemm(0, 0, M, K, N, dy, 0, N, w, 0, K, dx, 0, K, prec=ctx.prec, exclusive=True, amax=(a_dy, a_w))
         w_sink = _take_sink(ctx.weight_ref) if (ctx.needs_input_grad[1] and ctx.weight_ref is not None) else None
         b_sink = _take_sink(ctx.bias_ref) if (ctx.has_bias and ctx.needs_input_grad[2] and ctx.bias_ref is not None) else None
         if (ctx.needs_input_grad[1] and ctx.weight_ref is not None and w_sink is None) or \
@@ -328,10 +379,12 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             if w_sink is not None and off_chain is not None:
                 with off_chain:
-                    sgemm(1, 0, N, K, M, dy, 0, N, x, 0, K, w_sink, 0, K, prec=ctx.prec)
+                    sgemm(1, 0, N, K, M, dy, 0, N, x, 0, K, w_sink, 0, K, prec=ctx.prec, amax=(a_dy, a_x))
+                    if slots is not None:
+                        slots.record_stream(wg)
             else:
                 dw = w_sink if w_sink is not None else torch.empty_like(w)
-                sgemm(1, 0, N, K, M, dy, 0, N, x, 0, K, dw, 0, K, prec=ctx.prec, exclusive=True)
+                sgemm(1, 0, N, K, M, dy, 0, N, x, 0, K, dw, 0, K, prec=ctx.prec, exclusive=True, amax=(a_dy, a_x))
                 if w_sink is not None:
                     dw = None                              # written in place: nothing for autograd to accumulate
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -559,6 +612,25 @@ class _MultiBiGRU(torch.autograd.Function):
         main = torch.cuda.current_stream()
         prec = _PREC[0]
         groups = _stream_groups(Hs, B)
+        # fp16x3 products: the magnitudes of every layer-0 input and every W_ih, measured once up front (one launch; the backward
+        # pass reuses them); deeper layers read GRU outputs, |h| <= 1
+        fslots = None
+        if (prec & _lib.M3T_GEMM_F16X3) and all(h % 4 == 0 for h in Hs):      # (narrower scans never reach the fp16x3 kernels)
+            fslots = amax_slots(n_stacks * (1 + 2 * L), dev)
+            items = [(xs[s], fslots.data_ptr() + 8 * s) for s in range(n_stacks)]
+            for l in range(L):
+                for s in range(n_stacks):
+                    for d in (0, 1):
+                        items.append((params[s][(2 * l + d) * 4], fslots.data_ptr() + 8 * (n_stacks + (l * n_stacks + s) * 2 + d)))
+            if not measure_amax(items):
+                fslots = None
+        one = amax_one(dev)
+
+        def fslot_x(l, s):
+            return None if fslots is None else (fslots.data_ptr() + 8 * s if l == 0 else one)
+
+        def fslot_w(l, s, d):
+            return None if fslots is None else fslots.data_ptr() + 8 * (n_stacks + (l * n_stacks + s) * 2 + d)
 
         alone = not _interleaved(groups) and all(kind == "main" for kind, _ in groups)   # nothing runs beside these GEMMs
 
@@ -574,7 +646,7 @@ class _MultiBiGRU(torch.autograd.Function):
                     w_ih, w_hh, b_ih, b_hh = params[s][(2 * l + d) * 4:(2 * l + d) * 4 + 4]
                     if not scan:
                         sgemm(0, 1, B * T, 3 * H, I, inp, 0, I, w_ih, 0, I, xprojs[l][s], d * 3 * H, 6 * H, bias=b_ih, prec=prec,
-                              exclusive=alone)
+                              exclusive=alone, amax=(fslot_x(l, s), fslot_w(l, s, d)))
                     else:
                         descs.append(GruFwdDesc(_vp(xprojs[l][s]), _vp(w_hh), _vp(b_hh), _vp(outs[l][s]),
                                                 _vp(gates[l][s], d * B * T * 4 * H), _vp(h_ns[s], (2 * l + d) * B * H),
@@ -645,6 +717,11 @@ class _MultiBiGRU(torch.autograd.Function):
         for l in range(L):
             for s in range(n_stacks):
                 saved += [outs[l][s], gates[l][s]]
+        ctx.has_fslots = fslots is not None
+        if fslots is not None:
+            for st_ in (side_stream(dev),):
+                fslots.record_stream(st_)
+            saved.append(fslots)
         ctx.save_for_backward(*(list(tensors) + saved))
         result = []
         for s in range(n_stacks):
@@ -660,6 +737,9 @@ class _MultiBiGRU(torch.autograd.Function):
         per = 1 + 8 * L
         st = ctx.saved_tensors
         tensors, acts = st[:n_stacks * per], st[n_stacks * per:]
+        fslots = None
+        if ctx.has_fslots:
+            fslots, acts = acts[-1], acts[:-1]
         params = [list(tensors[s * per + 1:(s + 1) * per]) for s in range(n_stacks)]
         xs = [tensors[s * per].contiguous() for s in range(n_stacks)]
 
@@ -712,6 +792,19 @@ class _MultiBiGRU(torch.autograd.Function):
         groups = _stream_groups(Hs, B)
         cur = {s: douts[s] for s in range(n_stacks)}
         prec = ctx.prec
+        # fp16x3 products: every backward scan raises one magnitude slot per direction (max |dgx|, |dgh|); the inputs' and the
+        # weights' slots come from the forward pass, the recurrent states are GRU outputs (|h| <= 1)
+        bslots = amax_slots(2 * L * n_stacks, dev) if fslots is not None else None
+        one = amax_one(dev)
+
+        def bslot(l, s, d):
+            return None if bslots is None else bslots.data_ptr() + 8 * ((l * n_stacks + s) * 2 + d)
+
+        def fslot_x(l, s):
+            return None if fslots is None else (fslots.data_ptr() + 8 * s if l == 0 else one)
+
+        def fslot_w(l, s, d):
+            return None if fslots is None else fslots.data_ptr() + 8 * (n_stacks + (l * n_stacks + s) * 2 + d)
 
         def level_scan(l, idxs, after=None):
             descs = []
@@ -729,7 +822,7 @@ class _MultiBiGRU(torch.autograd.Function):
                                             _vp(dhns[s], (2 * l + d) * B * H) if dhns[s] is not None else None,
                                             _vp(dgx[l][s]), _vp(dgh[l][s], d * B * T * 3 * H), _vp(dh[l][s], d * B * H),
                                             _vp(dbp[l][s], d * B * 4 * H), _vp(out_grads[base + 2]), _vp(out_grads[base + 3]),
-                                            H, d, out.stride(1), d * H, 6 * H, d * 3 * H))      # (dout and out share the layout)
+                                            H, d, out.stride(1), d * H, 6 * H, d * 3 * H, bslot(l, s, d)))      # (dout and out share the layout)
             _scan_bwd(descs, B, T, prec | (_lib.M3T_SCAN_WHH if direct_whh else 0), after)
 
         def level_dx(l, idxs):           # on the chain: feeds the next level's scan
@@ -740,7 +833,7 @@ class _MultiBiGRU(torch.autograd.Function):
                 if need_dx[l][s]:
                     for d in (0, 1):
                         sgemm(0, 0, B * T, I, 3 * H, dgx[l][s], d * 3 * H, 6 * H, params[s][(2 * l + d) * 4], 0, I,
-                              dinp[l][s], 0, I, accumulate=(d == 1), prec=prec)
+                              dinp[l][s], 0, I, accumulate=(d == 1), prec=prec, amax=(bslot(l, s, d), fslot_w(l, s, d)))
                     cur[s] = dinp[l][s]
 
         wgs = wgrad_streams(dev)
@@ -777,18 +870,20 @@ class _MultiBiGRU(torch.autograd.Function):
                                 hprev[:, 1:].copy_(out[:, :-1, d * H:(d + 1) * H])
                             else:
                                 hprev[:, :-1].copy_(out[:, 1:, d * H:(d + 1) * H])
-                            sgemm(1, 0, 3 * H, H, B * T, dgh[l][s], goff, 3 * H, hprev, 0, H, dw_hh, 0, H, prec=prec)
+                            sgemm(1, 0, 3 * H, H, B * T, dgh[l][s], goff, 3 * H, hprev, 0, H, dw_hh, 0, H, prec=prec,
+                                  amax=(bslot(l, s, d), one if bslots is not None else None))
                             hprev.record_stream(torch.cuda.current_stream())
                         elif T > 1:
                             # dW_hh = sum_{b,t} dgh[b,t]^T h_prev(b,t): forward pairs (t, t-1), reverse pairs (t, t+1)
                             a_off, b_off = (1, 0) if d == 0 else (0, 1)
                             sgemm(1, 0, 3 * H, H, B * (T - 1), dgh[l][s], goff, 3 * H, out, d * H, out.stride(1), dw_hh, 0, H,
-                                  seg=(T - 1, T, a_off, b_off), prec=prec)
+                                  seg=(T - 1, T, a_off, b_off), prec=prec, amax=(bslot(l, s, d), one if bslots is not None else None))
                         else:
                             dw_hh.zero_()
                     rr[0] += 1
                     with torch.cuda.stream(pool[rr[0] % nw]):
-                        sgemm(1, 0, 3 * H, I, B * T, dgx[l][s], d * 3 * H, 6 * H, inp, 0, I, dw_ih, 0, I, prec=prec)
+                        sgemm(1, 0, 3 * H, I, B * T, dgx[l][s], d * 3 * H, 6 * H, inp, 0, I, dw_ih, 0, I, prec=prec,
+                              amax=(bslot(l, s, d), fslot_x(l, s)))
                     rr[0] += 1
 
         for w_ in wgs:
@@ -872,6 +967,10 @@ class _MultiBiGRU(torch.autograd.Function):
                     for t in (dgx[l][s], dgh[l][s]) + tuple(layer_io(l, s)[:2]):
                         for w_ in wgs:
                             t.record_stream(w_)
+            for t in (bslots, fslots):
+                if t is not None:
+                    for w_ in wgs:
+                        t.record_stream(w_)
             _WGRAD_PENDING[(dev.type, dev.index)] = True
         else:
             for w_ in wgs:

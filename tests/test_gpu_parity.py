@@ -64,7 +64,14 @@ def check_digests(named_grads, g, tol=3e-4, prefix="gd."):
                                    (128, 128, 32), (256, 384, 512), (1152, 256, 4096), (9600, 512, 1024),    # these four: bf16x6 path
                                    (128, 1728, 4096), (256, 64, 640), (384, 192, 96)])   # N % 64 == 0 only: bf16x6 on the 128 x 64 tile
 @pytest.mark.parametrize("tA,tB", [(0, 1), (0, 0), (1, 0), (1, 1)])
-def test_sgemm(M, N, K, tA, tB):
+@pytest.mark.parametrize("mode", ["fp32", "x6"])      # interior shapes: fp16x3 (three products, the default) / bf16x6 (six products)
+def test_sgemm(M, N, K, tA, tB, mode):
+    from m3t import ops
+    with ops.precision(mode):
+        _check_sgemm(M, N, K, tA, tB)
+
+
+def _check_sgemm(M, N, K, tA, tB):
     from m3t import ops
     rs = np.random.RandomState(M * 7 + N * 3 + K + tA * 2 + tB)
     A = rs.standard_normal((K, M) if tA else (M, K)).astype(np.float32)
@@ -87,6 +94,12 @@ def test_sgemm_big_tile(M, N, K, tA, tB):
     """M3T_GEMM_EXCLUSIVE: shapes the planner gives to the 256 x 256-tile bf16x6 kernel (ragged last row tile at M = 9600,
     split-K slabs, all four operand layouts) -- same accuracy bar as the 128-tile kernel, and identical results run to run."""
     from m3t import ops
+    with ops.precision("x6"):                # (the 256-tile kernel belongs to the six-product mode)
+        _check_sgemm_big_tile(M, N, K, tA, tB)
+
+
+def _check_sgemm_big_tile(M, N, K, tA, tB):
+    from m3t import ops
     kern, splits = ops.sgemm_plan(tA, M, N, K, exclusive=True)
     assert kern == 2, (kern, splits)
     rs = np.random.RandomState(M + N * 3 + K + tA * 2 + tB)
@@ -108,6 +121,12 @@ def test_sgemm_big_tile(M, N, K, tA, tB):
 
 def test_sgemm_big_tile_segmented():
     """dW_hh-shaped segmented reduction (per-clip shifted rows) on the 256-tile kernel vs the 128-tile kernel: same sums."""
+    from m3t import ops
+    with ops.precision("x6"):
+        _check_sgemm_big_tile_segmented()
+
+
+def _check_sgemm_big_tile_segmented():
     from m3t import ops
     Bc, T, H = 32, 300, 512
     assert ops.sgemm_plan(1, 3 * H, H, Bc * (T - 1), seg_len=T - 1, exclusive=True)[0] == 2
@@ -143,6 +162,66 @@ def test_sgemm_strided_and_segmented():
         ops.sgemm(1, 0, 3 * H, H, B_ * (T - 1), dev(dgh), 0, 3 * H, dev(out), d * H, 2 * H, got, 0, H,
                   seg=(T - 1, T, a_off, b_off))
         close(got, ref, 1e-5, "dW_hh dir %d" % d)
+
+
+def test_sgemm_fp16x3_scales_slots_and_edge_values():
+    """The default products (M3T_GEMM_F16X3): two fp16 terms of each SCALED operand.  Against fp64: operands of very different
+    magnitudes (gradient-like 1e-7, dB-like 80, 1e30), rows 1e-4 apart inside one operand, caller-provided magnitude slots (exact,
+    loose, and the |x| <= 1 constant) give the library-measured result or stay inside the bar; an all-zero operand gives zeros; a
+    non-finite value poisons exactly its row; results are identical run to run and no less accurate than the six-product form."""
+    from m3t import ops
+    M, N, K = 1152, 256, 4096
+    rs = np.random.RandomState(7)
+
+    def relerr(out, ref):
+        return float(np.linalg.norm(out.cpu().numpy().astype(np.float64) - ref) / np.linalg.norm(ref))
+
+    for sa, sb in ((1.0, 1.0), (1e-7, 0.03), (80.0, 0.05), (1e30, 1e-3)):
+        A = (rs.standard_normal((M, K)) * sa).astype(np.float32)
+        A *= (10.0 ** rs.uniform(-4, 0, (M, 1))).astype(np.float32)
+        B = (rs.standard_normal((N, K)) * sb).astype(np.float32)
+        ref = A.astype(np.float64) @ B.astype(np.float64).T
+        dA, dB = dev(A), dev(B)
+        out = torch.empty(M, N, device=DEV)
+        ops.sgemm(0, 1, M, N, K, dA, 0, K, dB, 0, K, out, 0, N)
+        e3 = relerr(out, ref)
+        rowrel = (np.linalg.norm(out.cpu().numpy() - ref, axis=1) / np.linalg.norm(ref, axis=1)).max()
+        with ops.precision("x6"):
+            out6 = torch.empty(M, N, device=DEV)
+            ops.sgemm(0, 1, M, N, K, dA, 0, K, dB, 0, K, out6, 0, N)
+        e6 = relerr(out6, ref)
+        assert e3 <= 1e-6 and e3 <= 1.5 * e6 and rowrel <= 2e-6, (sa, sb, e3, e6, rowrel)
+        # exact slots reproduce the library's own measurement bit for bit; a bound 2^6 too large stays inside the bar
+        sl = ops.amax_slots(4, dA.device)
+        assert ops.measure_amax([(dA, sl.data_ptr()), (dB, sl.data_ptr() + 8)])
+        out_s = torch.empty(M, N, device=DEV)
+        ops.sgemm(0, 1, M, N, K, dA, 0, K, dB, 0, K, out_s, 0, N, amax=(sl.data_ptr(), sl.data_ptr() + 8))
+        assert torch.equal(out, out_s)
+        amax = torch.tensor([float(np.abs(A).max()) * 64.0, float(np.abs(B).max()) * 64.0], dtype=torch.float32)
+        if np.isfinite(amax.numpy()).all():
+            sl[2:] = amax.view(torch.int32).to(torch.int64).to(DEV)
+            out_l = torch.empty(M, N, device=DEV)
+            ops.sgemm(0, 1, M, N, K, dA, 0, K, dB, 0, K, out_l, 0, N, amax=(sl.data_ptr() + 16, sl.data_ptr() + 24))
+            assert relerr(out_l, ref) <= 1e-6
+        out2 = torch.empty(M, N, device=DEV)
+        ops.sgemm(0, 1, M, N, K, dA, 0, K, dB, 0, K, out2, 0, N)
+        assert torch.equal(out, out2)
+    # |x| <= 1 constant slot (GRU outputs)
+    A = np.tanh(rs.standard_normal((M, K))).astype(np.float32)
+    B = (rs.standard_normal((N, K)) * 0.05).astype(np.float32)
+    out = torch.empty(M, N, device=DEV)
+    ops.sgemm(0, 1, M, N, K, dev(A), 0, K, dev(B), 0, K, out, 0, N, amax=(ops.amax_one(out.device), None))
+    assert relerr(out, A.astype(np.float64) @ B.astype(np.float64).T) <= 1e-6
+    # zeros, and a non-finite value
+    Z = torch.zeros(M, K, device=DEV)
+    ops.sgemm(0, 1, M, N, K, Z, 0, K, dev(B), 0, K, out, 0, N)
+    assert float(out.abs().max()) == 0.0
+    ref = A.astype(np.float64) @ B.astype(np.float64).T
+    A[5, 7] = np.inf
+    ops.sgemm(0, 1, M, N, K, dev(A), 0, K, dev(B), 0, K, out, 0, N)
+    assert not bool(torch.isfinite(out[5]).any())
+    keep = np.arange(M) != 5
+    assert relerr(out[torch.from_numpy(keep).to(DEV)], ref[keep]) <= 1e-6
 
 
 def test_colsum_transpose():
