@@ -579,7 +579,7 @@ def worker(args):
             "metric": "clips/sec (300-frame A+V, fwd+bwd)", "value": round(clips / dt, 2), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_ms, 3),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f32 (GEMMs and the H=256/512 recurrences as bf16x6 products = fp32-accurate, fp32 accumulate; the H=128 scorer scans as fp32 FMA chains on the vector ALUs)",
+            "dtype": "f32 (fp32-accurate products, fp32 accumulate: GEMMs as fp16x3 -- two fp16 terms per scaled operand, three MFMAs, error vs fp64 no larger than an fp32 GEMM's; the H=256/512 recurrences as bf16x6 -- three bf16 terms, six MFMAs; the H=128 scorer scans as fp32 FMA chains on the vector ALUs)",
             "data": "synthetic",
             "config": {"workload": "C3/C4 feature-level A+V att_fusion graph (SURVEY 8(d)): audio GRU(128,256,2) | "
                                    "gru_v,gru_a GRU(256,512,2) | proj_v | AttFusion([512,512],128) | "
