@@ -286,10 +286,63 @@ __global__ void wfrag6_prep_kernel(const float* __restrict__ w_hh, unsigned shor
     }
 }
 
-template <int NC>
+// fp16x3 form of the forward recurrent product (M3T_GEMM_F16X3): h_t is bounded by 1, so the producers publish it
+// as two fp16 terms of 2^14 h; W_hh is split into two fp16 terms per workgroup slice (the 48 gate rows of 16 hidden units), scaled by the
+// power of two that puts the slice's largest magnitude into [2^14, 2^15) -- one block per slice measures it and writes
+// wfrag3h[ub][wave][s][ct][t < 2][lane][8 fp16] plus inv[ub] = 2^-14 / scale, by which the slice's workgroups unscale their sums.
+struct Prep3hArgs { const float* w_hh[M3T_MAX_SCANS]; unsigned short* wf[M3T_MAX_SCANS]; float* inv[M3T_MAX_SCANS]; };
+// grid (H / 16 slices, PREP3H_SPLIT, scans): every block of a slice measures the whole slice (48 rows x H values: float4 loads, four
+// in flight per thread, L2) and writes its share of the fragments
+constexpr int PREP3H_SPLIT = 8;
+__global__ __launch_bounds__(256) void wfrag3h_prep_kernel(Prep3hArgs a, int H) {
+    const float* __restrict__ w_hh = a.w_hh[blockIdx.z];
+    unsigned short* __restrict__ wf = a.wf[blockIdx.z];
+    const int ub = blockIdx.x, nch = H >> 4, ks = nch >> 4;
+    __shared__ float red[4];
+    float m = 0.f;
+    const int h4 = H >> 2, tot4 = 48 * h4;
+    auto ld = [&](int i) {
+        const int rr = i / h4, c = i - rr * h4;
+        return *reinterpret_cast<const float4*>(w_hh + ((size_t)(rr >> 4) * H + ub * 16 + (rr & 15)) * H + 4 * c);
+    };
+    auto fold = [&](const float4& v) {
+        m = fmaxf(fmaxf(m, m3t_fin_abs(v.x)), fmaxf(m3t_fin_abs(v.y), fmaxf(m3t_fin_abs(v.z), m3t_fin_abs(v.w))));
+    };
+    int i = threadIdx.x;
+    for (; i + 768 < tot4; i += 1024) {
+        const float4 v0 = ld(i), v1 = ld(i + 256), v2 = ld(i + 512), v3 = ld(i + 768);
+        fold(v0); fold(v1); fold(v2); fold(v3);
+    }
+    for (; i < tot4; i += 256) fold(ld(i));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sc, inv;
+    m3t_f16_scale(__float_as_uint(m), sc, inv);
+    if (threadIdx.x == 0 && blockIdx.y == 0) a.inv[blockIdx.z][ub] = inv * 6.103515625e-05f;       // x 2^-14: the scale of h
+    const int per = 3 * 16 * H;                       // weights of this slice, one thread each: [wave][s][ct][lane][8]
+    for (int j = blockIdx.y * 256 + threadIdx.x; j < per; j += 256 * PREP3H_SPLIT) {
+        const int e = j & 7, l = (j >> 3) & 63;
+        int r = j >> 9;
+        const int ct = r % 3; r /= 3;
+        const int s = r % ks; const int w = r / ks;
+        const int q = l >> 4;
+        const int unit = 16 * (w + NW * (2 * s + (q >> 1))) + 8 * (q & 1) + e;
+        const float x = w_hh[((size_t)ct * H + ub * 16 + (l & 15)) * H + unit] * sc;
+        const _Float16 h1 = (_Float16)x;
+        const _Float16 h2 = (_Float16)(x - (float)h1);
+        const size_t base = ((((size_t)(ub * NW + w) * ks + s) * 3 + ct) * 2) * 512 + (size_t)l * 8 + e;
+        wf[base] = __builtin_bit_cast(unsigned short, h1);
+        wf[base + 512] = __builtin_bit_cast(unsigned short, h2);
+    }
+}
+typedef _Float16 pf16x8 __attribute__((ext_vector_type(8)));
+
+template <int NC, bool F16 = false>
 __global__ __launch_bounds__(NT) void gru_persist_fwd6_kernel(FwdGroup g, FragPtrs fp, ExPtrs ex, int B, int T, int G, int nrb,
                                                               unsigned* err) {
-    constexpr int ROWS = 16, KS = NC / 2;
+    constexpr int ROWS = 16, KS = NC / 2, NTERM = F16 ? 2 : 3;
     constexpr int H = 128 * NC, nch = H >> 4;
     __shared__ float red[2][NW][3][ROWS][UB + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -299,16 +352,18 @@ __global__ __launch_bounds__(NT) void gru_persist_fwd6_kernel(FwdGroup g, FragPt
     const m3t_gru_fwd_desc d = g.d[s];
     const int j0 = ub * UB, r0 = rb * ROWS;
 
-    pbf16x8 wf[KS][3][3];                              // [k-step][gate tile][term]
+    pbf16x8 wf[KS][3][NTERM];                          // [k-step][gate tile][term] (F16: fp16 bit patterns, two terms)
     {
-        const pu32x4* Wf = reinterpret_cast<const pu32x4*>(fp.wfrag[s]) + ((size_t)(ub * NW + wave) * KS * 9) * 64 + lane;
+        const pu32x4* Wf = reinterpret_cast<const pu32x4*>(fp.wfrag[s]) + ((size_t)(ub * NW + wave) * KS * 3 * NTERM) * 64 + lane;
 #pragma unroll
         for (int k = 0; k < KS; ++k)
 #pragma unroll
             for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
-                for (int t = 0; t < 3; ++t) wf[k][ct][t] = __builtin_bit_cast(pbf16x8, Wf[((k * 3 + ct) * 3 + t) * 64]);
+                for (int t = 0; t < NTERM; ++t) wf[k][ct][t] = __builtin_bit_cast(pbf16x8, Wf[((k * 3 + ct) * NTERM + t) * 64]);
     }
+    // F16: 2^-14 / (scale of this slice's W_hh), written by wfrag3h_prep_kernel behind the fragments
+    const float winv = F16 ? reinterpret_cast<const float*>(fp.wfrag[s])[(size_t)4 * H * H + ub] : 1.f;
     // cell-math threads in granule order (see the header): granule tid = jp*64 + hr*2 + jlo  <->  row hr & 15,
     // unit 8*(hr >> 4) + 2*jp + jlo
     const bool pw = tid < ROWS * UB;
@@ -1191,13 +1246,28 @@ int persist_fwd_launch(const FwdGroup& g, const FragPtrs& fp, int B, int T, int 
         // backward) -- the measured optima of rounds 1-2, formerly M3T_SCAN_POLL_*
         ex.poll_fixed = persist_fwd_uses_x6(g, B, T, flags) ? -1 : (sh.nc == 1 ? 0 : 12);
         ex.poll_align = persist_fwd_uses_x6(g, B, T, flags) ? 0 : 1;
+        // fp16x3 forward at H = 256: the MFMA phase is so short that the waves without cell math reach the gather long before the
+        // workgroup's publish, fail, and drive the common adaptive delay past what the cell-math waves need (2.63 us per step;
+        // counted from the publish: 1.73; bf16x6: 1.83).  H = 512 is better without (2.55 vs 2.59, fusion level 2.28 vs 2.48).
+        if (persist_fwd_uses_x6(g, B, T, flags) && !g.bf16 && (flags & M3T_GEMM_F16X3) && m3t_f16x3_enabled() && sh.nc == 2) ex.poll_align = 1;
     }
     const bool x6 = persist_fwd_uses_x6(g, B, T, flags);
     { const int e = prepare_exchange(g, fp, sh, x6 ? 1 : 0, 8, x6 ? 65535ull : 0xffffffffull, T, ex, s); if (e) return e; }
     ++g_launches;
     if (!x6) { const int e = persist_take_after(s); if (e) return e; }
     if (x6) {
-        for (int i = 0; i < g.n; ++i) {                                      // W_hh -> bf16x3 B-operand fragments
+        // fp32 mode with M3T_GEMM_F16X3: the product from two fp16 terms (three MFMAs per k-step and gate) instead of three bf16 terms (six)
+        const bool f16 = !g.bf16 && (flags & M3T_GEMM_F16X3) && m3t_f16x3_enabled();
+        if (f16) {                                                           // W_hh -> B-operand fragments: one launch for the level
+            Prep3hArgs pa;
+            const int H = g.d[0].H;                                           // (level_shape: every scan of the level has the same H)
+            for (int i = 0; i < g.n; ++i) {
+                pa.w_hh[i] = g.d[i].w_hh; pa.wf[i] = reinterpret_cast<unsigned short*>(fp.wfrag[i]); pa.inv[i] = fp.wfrag[i] + (size_t)4 * H * H;
+            }
+            for (int i = g.n; i < M3T_MAX_SCANS; ++i) { pa.w_hh[i] = pa.w_hh[0]; pa.wf[i] = pa.wf[0]; pa.inv[i] = pa.inv[0]; }
+            wfrag3h_prep_kernel<<<dim3(H / 16, PREP3H_SPLIT, g.n), 256, 0, s>>>(pa, H);
+        }
+        for (int i = 0; i < g.n && !f16; ++i) {
             const int H = g.d[i].H;
             int blk = (3 * H * H + 255) / 256;
             if (blk > 1024) blk = 1024;
@@ -1206,7 +1276,11 @@ int persist_fwd_launch(const FwdGroup& g, const FragPtrs& fp, int B, int T, int 
         M3T_LAUNCH_CHECK();
         { const int e = persist_take_after(s); if (e) return e; }
         persist_record_start(s);
-        if (sh.nc == 2) hipLaunchKernelGGL(gru_persist_fwd6_kernel<2>, dim3(sh.grid), dim3(NT), exclusive_lds(gru_persist_fwd6_kernel<2>, sh.active), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
+        if (f16) {
+            if (sh.nc == 2) hipLaunchKernelGGL((gru_persist_fwd6_kernel<2, true>), dim3(sh.grid), dim3(NT), exclusive_lds(gru_persist_fwd6_kernel<2, true>, sh.active), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
+            else hipLaunchKernelGGL((gru_persist_fwd6_kernel<4, true>), dim3(sh.grid), dim3(NT), exclusive_lds(gru_persist_fwd6_kernel<4, true>, sh.active), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
+        }
+        else if (sh.nc == 2) hipLaunchKernelGGL(gru_persist_fwd6_kernel<2>, dim3(sh.grid), dim3(NT), exclusive_lds(gru_persist_fwd6_kernel<2>, sh.active), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
         else hipLaunchKernelGGL(gru_persist_fwd6_kernel<4>, dim3(sh.grid), dim3(NT), exclusive_lds(gru_persist_fwd6_kernel<4>, sh.active), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
         persist_record_end(s);
         M3T_LAUNCH_CHECK();
