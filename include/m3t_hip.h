@@ -318,6 +318,17 @@ int m3t_conv1d_fwd(const float* x, const float* w_t, const float* bias, const fl
 int m3t_conv1d_wgrad(const float* dy, const float* x, float* dw_t,
                      int B, int T, int Ci, int Co, int K, int dilation, int lead,
                      float* ws, size_t ws_bytes, int flags, void* stream);
+/* m3t_conv1d_fwd / m3t_conv1d_wgrad with the callers' magnitude slots for M3T_GEMM_F16X3 (see m3t_sgemm_scaled; NULL = measured by the
+ * library): amax_x over x [B*T][Ci], amax_w over w_t, amax_dy over dy [B*T][Co].  The K taps of a weight gradient share both. */
+int m3t_conv1d_fwd_scaled(const float* x, const float* w_t, const float* bias, const float* res,
+                          const float* drop_mask, float* y, float* pre,
+                          int B, int T, int Ci, int Co, int K, int dilation, int lead, int act, int anticausal,
+                          float drop_p, unsigned long long drop_seed, int flags,
+                          const unsigned long long* amax_x, const unsigned long long* amax_w, void* stream);
+int m3t_conv1d_wgrad_scaled(const float* dy, const float* x, float* dw_t,
+                            int B, int T, int Ci, int Co, int K, int dilation, int lead,
+                            float* ws, size_t ws_bytes, int flags,
+                            const unsigned long long* amax_dy, const unsigned long long* amax_x, void* stream);
 
 /* BatchNorm1d (+ optional fused ReLU) over channel-last rows x [M = B*T, C]
  * (nn.BatchNorm1d(512) + nn.ReLU(True) of `tcn_simple`, reference models/backbone.py:108-110, 217-222).

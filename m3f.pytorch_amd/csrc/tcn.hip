@@ -287,6 +287,14 @@ extern "C" int m3t_conv1d_fwd(const float* x, const float* w_t, const float* bia
                               const float* drop_mask, float* y, float* pre, int B, int T, int Ci, int Co, int K,
                               int dilation, int lead, int act, int anticausal, float drop_p, unsigned long long drop_seed,
                               int flags, void* stream) {
+    return m3t_conv1d_fwd_scaled(x, w_t, bias, res, drop_mask, y, pre, B, T, Ci, Co, K, dilation, lead, act, anticausal, drop_p, drop_seed,
+                                 flags, nullptr, nullptr, stream);
+}
+
+extern "C" int m3t_conv1d_fwd_scaled(const float* x, const float* w_t, const float* bias, const float* res,
+                                     const float* drop_mask, float* y, float* pre, int B, int T, int Ci, int Co, int K,
+                                     int dilation, int lead, int act, int anticausal, float drop_p, unsigned long long drop_seed,
+                                     int flags, const unsigned long long* amax_x, const unsigned long long* amax_w, void* stream) {
     if (B <= 0 || T <= 0) return 0;
     if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && drop_mask)) return M3T_EINVAL;
     if (Ci <= 0 || Co <= 0 || K <= 0 || dilation <= 0 || !x || !w_t || !y) return M3T_EINVAL;
@@ -311,7 +319,7 @@ extern "C" int m3t_conv1d_fwd(const float* x, const float* w_t, const float* bia
                 const M3TRegion rx{x, (unsigned long long)B * T, (unsigned long long)Ci, Ci / 4, nullptr};
                 const M3TRegion rw{w_t, (unsigned long long)K * (anticausal ? Ci : Co), (unsigned long long)(anticausal ? Co : Ci),
                                    (anticausal ? Co : Ci) / 4, nullptr};
-                const int rm = m3t_f16x3_measure(rx, nullptr, rw, nullptr, &ua, &ub, (hipStream_t)stream);
+                const int rm = m3t_f16x3_measure(rx, amax_x, rw, amax_w, &ua, &ub, (hipStream_t)stream);
                 if (rm) return rm;
             }
             return m3t_conv_x6_launch(x, w_t, bias, res, drop_mask, y, pre, B, T, Ci, Co, K, dilation, lead, act, anticausal,
@@ -350,6 +358,12 @@ extern "C" int m3t_causal_conv_fwd(const float* x, const float* w_t, const float
 
 extern "C" int m3t_conv1d_wgrad(const float* dy, const float* x, float* dw_t, int B, int T, int Ci, int Co, int K,
                                 int dilation, int lead, float* ws, size_t ws_bytes, int flags, void* stream) {
+    return m3t_conv1d_wgrad_scaled(dy, x, dw_t, B, T, Ci, Co, K, dilation, lead, ws, ws_bytes, flags, nullptr, nullptr, stream);
+}
+
+extern "C" int m3t_conv1d_wgrad_scaled(const float* dy, const float* x, float* dw_t, int B, int T, int Ci, int Co, int K,
+                                       int dilation, int lead, float* ws, size_t ws_bytes, int flags, const unsigned long long* amax_dy,
+                                       const unsigned long long* amax_x, void* stream) {
     if (Ci <= 0 || Co <= 0 || K <= 0 || !dy || !x || !dw_t) return M3T_EINVAL;
     if (lead < 0 || lead > (K - 1) * dilation) return M3T_EINVAL;
     const int gflags = (flags & M3T_BF16) ? M3T_GEMM_BF16 : (flags & (M3T_GEMM_HIGH | M3T_GEMM_F16X3));
@@ -359,7 +373,7 @@ extern "C" int m3t_conv1d_wgrad(const float* dy, const float* x, float* dw_t, in
         // fp16x3: the K taps multiply the same two tensors -- measure them once
         const M3TRegion rd{dy, (unsigned long long)B * T, (unsigned long long)Co, Co / 4, nullptr};
         const M3TRegion rx{x, (unsigned long long)B * T, (unsigned long long)Ci, Ci / 4, nullptr};
-        const int rm = m3t_f16x3_measure(rd, nullptr, rx, nullptr, &ua, &ub, (hipStream_t)stream);
+        const int rm = m3t_f16x3_measure(rd, amax_dy, rx, amax_x, &ua, &ub, (hipStream_t)stream);
         if (rm) return rm;
     }
     for (int j = 0; j < K; ++j) {

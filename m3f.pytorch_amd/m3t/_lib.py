@@ -69,7 +69,9 @@ SIGNATURES = {
     "m3t_causal_conv_fwd": [_f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _s],
     "m3t_causal_conv_wgrad": [_f, _f, _f, _i, _i, _i, _i, _i, _i, _f, _z, _s],
     "m3t_conv1d_fwd": [_f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, C.c_float, C.c_ulonglong, _i, _s],
+    "m3t_conv1d_fwd_scaled": [_f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, C.c_float, C.c_ulonglong, _i, _f, _f, _s],
     "m3t_conv1d_wgrad": [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _z, _i, _s],
+    "m3t_conv1d_wgrad_scaled": [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _z, _i, _f, _f, _s],
     "m3t_bn_rows_ws_bytes": [_i, _i],
     "m3t_bn_rows_fwd": [_f, _i, _i, _f, _f, _f, _f, C.c_float, C.c_float, _i, _i, _f, _f, _f, _f, _z, _s],
     "m3t_bn_rows_bwd": [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _f, _f, _f, _f, _z, _s],

@@ -1110,12 +1110,17 @@ def btc_to_bct(x):
     return _BtcToBct.apply(x)
 
 
-def _conv(x, w_t, bias, res, mask, pre, B, T, Ci, Co, K, dil, act, anti, prec=0, drop=(0.0, 0)):
+def _conv(x, w_t, bias, res, mask, pre, B, T, Ci, Co, K, dil, act, anti, prec=0, drop=(0.0, 0), amax=(None, None)):
     y = torch.empty(B, T, Co, dtype=torch.float32, device=x.device)
-    rc = lib().m3t_conv1d_fwd(_p(x), _p(w_t), _p(bias), _p(res), _p(mask), _p(y), _p(pre), B, T, Ci, Co, K, dil, 0,
-                              act, anti, float(drop[0]), int(drop[1]), prec, _stream())
+    rc = lib().m3t_conv1d_fwd_scaled(_p(x), _p(w_t), _p(bias), _p(res), _p(mask), _p(y), _p(pre), B, T, Ci, Co, K, dil, 0,
+                                     act, anti, float(drop[0]), int(drop[1]), prec, amax[0], amax[1], _stream())
     _lib.check(rc, "m3t_conv1d_fwd")
     return y
+
+
+def _conv_wgrad(dy, x, dw_t, B, T, Ci, Co, K, dil, ws, prec, amax=(None, None)):
+    _lib.check(lib().m3t_conv1d_wgrad_scaled(_p(dy), _p(x), _p(dw_t), B, T, Ci, Co, K, dil, 0, _p(ws), ws.numel() * 4, prec,
+                                             amax[0], amax[1], _stream()), "m3t_conv1d_wgrad")
 
 
 class _TemporalBlock(torch.autograd.Function):
@@ -1139,15 +1144,26 @@ class _TemporalBlock(torch.autograd.Function):
         _lib.check(lib().m3t_weight_norm_fwd(_p(v2), _p(g2), _p(w2t), _p(n2), Co, Co, K, _stream()), "m3t_weight_norm_fwd")
         prec = ctx.prec = _PREC[0]
         d1, d2 = (drop_p, seed1), (drop_p, seed2)        # in-kernel Philox masks (drop_p > 0) instead of the mask tensors m1 / m2
-        h1 = _conv(x, w1t, b1, None, m1, None, B, T, Ci, Co, K, dilation, 1, 0, prec, d1)
+        # fp16x3 products: magnitude slots 0 x, 1 w1t, 2 w2t, 3 wd, 4 h1 (forward), 5 ds, 6 da2, 7 da1 (backward): two measuring
+        # launches per pass instead of one in front of each of the block's nine contractions
+        slots = None
+        if (prec & _lib.M3T_GEMM_F16X3) and (B * T) % 128 == 0 and Co % 128 == 0 and Ci % 32 == 0:
+            slots = amax_slots(8, dev)
+            sp = slots.data_ptr()
+            if not measure_amax([(x, sp), (w1t, sp + 8), (w2t, sp + 16)] + ([(wd, sp + 24)] if wd is not None else [])):
+                slots = None
+        sl = (lambda i: None) if slots is None else (lambda i: slots.data_ptr() + 8 * i)
+        h1 = _conv(x, w1t, b1, None, m1, None, B, T, Ci, Co, K, dilation, 1, 0, prec, d1, amax=(sl(0), sl(1)))
         if wd is not None:
             res = torch.empty(B, T, Co, dtype=torch.float32, device=dev)
-            sgemm(0, 1, B * T, Co, Ci, x, 0, Ci, wd, 0, Ci, res, 0, Co, bias=bd, prec=prec)
+            sgemm(0, 1, B * T, Co, Ci, x, 0, Ci, wd, 0, Ci, res, 0, Co, bias=bd, prec=prec, amax=(sl(0), sl(3)))
         else:
             res = x
+        if slots is not None:
+            measure_amax([(h1, sl(4))])
         a2 = torch.empty(B, T, Co, dtype=torch.float32, device=dev)
-        y = _conv(h1, w2t, b2, res, m2, a2, B, T, Co, Co, K, dilation, 2, 0, prec, d2)
-        ctx.save_for_backward(x, v1, g1, v2, g2, wd, w1t, w2t, n1, n2, h1, a2, y, m1, m2)
+        y = _conv(h1, w2t, b2, res, m2, a2, B, T, Co, Co, K, dilation, 2, 0, prec, d2, amax=(sl(4), sl(2)))
+        ctx.save_for_backward(x, v1, g1, v2, g2, wd, w1t, w2t, n1, n2, h1, a2, y, m1, m2, slots)
         ctx.dil, ctx.drops = dilation, (d1, d2)
         # parameter objects that own a gradient sink (FlatGradDDP): their gradients can be written straight into the flat buffer
         # on the weight-gradient stream, off the chain (see backward)
@@ -1157,7 +1173,7 @@ class _TemporalBlock(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x, v1, g1, v2, g2, wd, w1t, w2t, n1, n2, h1, a2, y, m1, m2 = ctx.saved_tensors
+        x, v1, g1, v2, g2, wd, w1t, w2t, n1, n2, h1, a2, y, m1, m2, slots = ctx.saved_tensors
         dy = _req(dy.contiguous(), "dy")
         B, T, Ci = x.shape
         Co, _, K = v1.shape
@@ -1166,8 +1182,13 @@ class _TemporalBlock(torch.autograd.Function):
         ds = mask_pos(y, dy)                         # through the block's output ReLU
         d1, d2 = ctx.drops
         da2 = mask_pos(a2, ds, m2, d2)               # through dropout2 + relu2
-        dh1 = _conv(da2, w2t, None, None, None, None, B, T, Co, Co, K, dil, 0, 1, prec)
+        sl = (lambda i: None) if slots is None else (lambda i: slots.data_ptr() + 8 * i)
+        if slots is not None:
+            measure_amax([(ds, sl(5)), (da2, sl(6))])
+        dh1 = _conv(da2, w2t, None, None, None, None, B, T, Co, Co, K, dil, 0, 1, prec, amax=(sl(6), sl(2)))
         da1 = mask_pos(h1, dh1, m1, d1)              # h1 > 0 <=> a1 > 0 (dropout keeps the sign)
+        if slots is not None:
+            measure_amax([(da1, sl(7))])
         dw2t = torch.empty_like(w2t)
         dw1t = torch.empty_like(w1t)
         # Off the chain: when every parameter of the block has a gradient sink, the data gradient (what the previous block waits
@@ -1183,19 +1204,17 @@ class _TemporalBlock(torch.autograd.Function):
                 join_wgrad(dev)                      # a sink was taken earlier this step: the returned tensors get ADDED on this stream
         if sinks is not None:
             if wd is None:
-                dx = _conv(da1, w1t, None, ds, None, None, B, T, Co, Ci, K, dil, 0, 1, prec)
+                dx = _conv(da1, w1t, None, ds, None, None, B, T, Co, Ci, K, dil, 0, 1, prec, amax=(sl(7), sl(1)))
             else:
-                dx = _conv(da1, w1t, None, None, None, None, B, T, Co, Ci, K, dil, 0, 1, prec)
-                sgemm(0, 0, B * T, Ci, Co, ds, 0, Co, wd, 0, Ci, dx, 0, Ci, accumulate=True, use_ws=False, prec=prec)
+                dx = _conv(da1, w1t, None, None, None, None, B, T, Co, Ci, K, dil, 0, 1, prec, amax=(sl(7), sl(1)))
+                sgemm(0, 0, B * T, Ci, Co, ds, 0, Co, wd, 0, Ci, dx, 0, Ci, accumulate=True, use_ws=False, prec=prec, amax=(sl(5), sl(3)))
             main = torch.cuda.current_stream()
             wg = wgrad_stream(dev, 0)
             wg.wait_stream(main)
             with torch.cuda.stream(wg):
                 wsw = workspace(dev)
-                _lib.check(lib().m3t_conv1d_wgrad(_p(da2), _p(h1), _p(dw2t), B, T, Co, Co, K, dil, 0, _p(wsw), wsw.numel() * 4, prec,
-                                                  _stream()), "m3t_conv1d_wgrad")
-                _lib.check(lib().m3t_conv1d_wgrad(_p(da1), _p(x), _p(dw1t), B, T, Ci, Co, K, dil, 0, _p(wsw), wsw.numel() * 4, prec,
-                                                  _stream()), "m3t_conv1d_wgrad")
+                _conv_wgrad(da2, h1, dw2t, B, T, Co, Co, K, dil, wsw, prec, amax=(sl(6), sl(4)))
+                _conv_wgrad(da1, x, dw1t, B, T, Ci, Co, K, dil, wsw, prec, amax=(sl(7), sl(0)))
                 colsum(da1, 0, B * T, Co, Co, sinks[2])
                 colsum(da2, 0, B * T, Co, Co, sinks[5])
                 _lib.check(lib().m3t_weight_norm_bwd(_p(dw1t), _p(v1), _p(g1), _p(n1), _p(sinks[0]), _p(sinks[1]), Co, Ci, K, _stream()),
@@ -1203,16 +1222,14 @@ class _TemporalBlock(torch.autograd.Function):
                 _lib.check(lib().m3t_weight_norm_bwd(_p(dw2t), _p(v2), _p(g2), _p(n2), _p(sinks[3]), _p(sinks[4]), Co, Co, K, _stream()),
                            "m3t_weight_norm_bwd")
                 if wd is not None:
-                    sgemm(1, 0, Co, Ci, B * T, ds, 0, Co, x, 0, Ci, sinks[6], 0, Ci, prec=prec)
+                    sgemm(1, 0, Co, Ci, B * T, ds, 0, Co, x, 0, Ci, sinks[6], 0, Ci, prec=prec, amax=(sl(5), sl(0)))
                     colsum(ds, 0, B * T, Co, Co, sinks[7])
-            for t in (da1, da2, h1, x, dw1t, dw2t, ds, n1, n2):
+            for t in (da1, da2, h1, x, dw1t, dw2t, ds, n1, n2) + ((slots,) if slots is not None else ()):
                 t.record_stream(wg)
             _WGRAD_PENDING[(dev.type, dev.index)] = True
             return (dx,) + (None,) * 14
-        _lib.check(lib().m3t_conv1d_wgrad(_p(da2), _p(h1), _p(dw2t), B, T, Co, Co, K, dil, 0, _p(ws), ws.numel() * 4, prec,
-                                          _stream()), "m3t_conv1d_wgrad")
-        _lib.check(lib().m3t_conv1d_wgrad(_p(da1), _p(x), _p(dw1t), B, T, Ci, Co, K, dil, 0, _p(ws), ws.numel() * 4, prec,
-                                          _stream()), "m3t_conv1d_wgrad")
+        _conv_wgrad(da2, h1, dw2t, B, T, Co, Co, K, dil, ws, prec, amax=(sl(6), sl(4)))
+        _conv_wgrad(da1, x, dw1t, B, T, Ci, Co, K, dil, ws, prec, amax=(sl(7), sl(0)))
         db1 = torch.empty(Co, dtype=torch.float32, device=dev)
         db2 = torch.empty(Co, dtype=torch.float32, device=dev)
         colsum(da1, 0, B * T, Co, Co, db1)
@@ -1225,12 +1242,12 @@ class _TemporalBlock(torch.autograd.Function):
                    "m3t_weight_norm_bwd")
         dwd = dbd = None
         if wd is None:
-            dx = _conv(da1, w1t, None, ds, None, None, B, T, Co, Ci, K, dil, 0, 1, prec)      # + identity residual
+            dx = _conv(da1, w1t, None, ds, None, None, B, T, Co, Ci, K, dil, 0, 1, prec, amax=(sl(7), sl(1)))      # + identity residual
         else:
-            dx = _conv(da1, w1t, None, None, None, None, B, T, Co, Ci, K, dil, 0, 1, prec)
-            sgemm(0, 0, B * T, Ci, Co, ds, 0, Co, wd, 0, Ci, dx, 0, Ci, accumulate=True, use_ws=False, prec=prec)
+            dx = _conv(da1, w1t, None, None, None, None, B, T, Co, Ci, K, dil, 0, 1, prec, amax=(sl(7), sl(1)))
+            sgemm(0, 0, B * T, Ci, Co, ds, 0, Co, wd, 0, Ci, dx, 0, Ci, accumulate=True, use_ws=False, prec=prec, amax=(sl(5), sl(3)))
             dwd = torch.empty_like(wd)
-            sgemm(1, 0, Co, Ci, B * T, ds, 0, Co, x, 0, Ci, dwd, 0, Ci, prec=prec)
+            sgemm(1, 0, Co, Ci, B * T, ds, 0, Co, x, 0, Ci, dwd, 0, Ci, prec=prec, amax=(sl(5), sl(0)))
             dbd = torch.empty(Co, dtype=torch.float32, device=dev)
             colsum(ds, 0, B * T, Co, Co, dbd)
         return dx, dv1, dg1, db1, dv2, dg2, db2, dwd, dbd, None, None, None, None, None, None
