@@ -709,7 +709,11 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd_kernel(BwdGroup g, FragPtr
 // at half their cycles each.  W_hh is split by the prep kernel into the B-operand order (72 VGPRs).  Results agree with the
 // fp32-MFMA kernel to fp32 rounding (M3T_SCAN_FP32 / M3T_SCAN_X6=0 keep that kernel and bit-identity with the per-step path).
 // wfrag[ub][wave][ks = gate*KS + h][term][lane][8]: term t of W_hh[gate*H + 16*(wave + 8*(2h + (e>>2))) + 4*(lane>>4) + (e&3)][ub*16 + (lane&15)]
-__global__ void wfrag_bwd6_prep_kernel(const float* __restrict__ w, unsigned short* __restrict__ wf, int H, int direct) {
+struct PrepBwd6Args { const float* w[M3T_MAX_SCANS]; unsigned short* wf[M3T_MAX_SCANS]; };
+// (one launch per level: blockIdx.y = scan)
+__global__ void wfrag_bwd6_prep_kernel(PrepBwd6Args a, int H, int direct) {
+    const float* __restrict__ w = a.w[blockIdx.y];
+    unsigned short* __restrict__ wf = a.wf[blockIdx.y];
     const int ksn = 3 * (H >> 8);                     // k-steps per wave
     const size_t total = (size_t)3 * H * H;           // one thread per weight: writes its three terms
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -1324,11 +1328,16 @@ int persist_bwd_launch(const BwdGroup& g, const FragPtrs& fp, int B, int T, int 
         return 0;
     }
     if (persist_bwd_uses_x6(g, B, T, flags)) {
-        for (int i = 0; i < g.n; ++i) {                                      // W_hh -> bf16x3 B-operand fragments
-            const int H = g.d[i].H;
+        {                                                                     // W_hh -> bf16x3 B-operand fragments, every scan of the level
+            PrepBwd6Args pa;
+            const int H = g.d[0].H;                                           // (level_shape: one H per level)
+            for (int i = 0; i < M3T_MAX_SCANS; ++i) {
+                const int j = i < g.n ? i : 0;
+                pa.w[i] = g.d[j].w_hh_t; pa.wf[i] = reinterpret_cast<unsigned short*>(fp.wfrag[j]);
+            }
             int blk = (3 * H * H + 255) / 256;
             if (blk > 1024) blk = 1024;
-            wfrag_bwd6_prep_kernel<<<blk, 256, 0, s>>>(g.d[i].w_hh_t, reinterpret_cast<unsigned short*>(fp.wfrag[i]), H, (flags & M3T_SCAN_WHH) ? 1 : 0);
+            wfrag_bwd6_prep_kernel<<<dim3(blk, g.n), 256, 0, s>>>(pa, H, (flags & M3T_SCAN_WHH) ? 1 : 0);
         }
         M3T_LAUNCH_CHECK();
         { const int e = persist_take_after(s); if (e) return e; }
