@@ -520,7 +520,8 @@ int m3t_sgemm_x6c_launch(int transA, int transB, int M, int N, int K, const floa
 
 int m3t_sgemm_x6d_launch(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                          float* C, int ldc, const float* bias, int act, int accumulate, int seg_len, int seg_stride,
-                         int a_off, int b_off, float* ws, int splits, int kchunk, int bf16_operands, hipStream_t s);
+                         int a_off, int b_off, float* ws, int splits, int kchunk, int bf16_operands,
+                         const unsigned long long* amax_a, const unsigned long long* amax_b, hipStream_t s);
 
 // Kernel choice among the bf16x6 GEMMs (round 3: the A/B switches M3T_GEMM_X6D / _X6C / _NARROW / _SPLITS are retired, their
 // outcomes are the rules below): the 128-tile GEMMs run on the software-pipelined gemm_x6d.hip, EXCEPT those issued beside
@@ -539,6 +540,10 @@ bool m3t_f16x3_enabled() {
     }
     return on == 1;
 }
+
+// fp16x3 GEMMs that run alone take the software-pipelined kernel too (measured, slots given: 9600 x 1024 x 1536 NN 140 -> 129 us,
+// 1536 x 1024 x 9600 TN 145 -> 138, 9600 x 1536 x 1024 NT 126 -> 122; C3 step 14.66 -> 14.57 ms)
+static bool f16x3_on_x6d() { return true; }
 
 static bool x6_enabled() {
     static int on = -1;
@@ -670,10 +675,10 @@ extern "C" int m3t_sgemm_scaled(int transA, int transB, int M, int N, int K, con
         if (g.kernel == 2)
             rc = m3t_sgemm_x6c_launch(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, seg_len, seg_stride,
                                       a_off, b_off, ws, splits, kchunk, p.bf16, s);
-        else if (!g.narrow && !f16x3 && !(flags & (M3T_GEMM_BACKGROUND | M3T_GEMM_HIGH)) && (x6d_mode() == 1 || (x6d_mode() == 2 && !(flags & M3T_GEMM_BESIDE_SCAN))))      // ("high": measured better on gemm_x6.hip)
+        else if (!g.narrow && (!f16x3 || f16x3_on_x6d()) && !(flags & (M3T_GEMM_BACKGROUND | M3T_GEMM_HIGH)) && (x6d_mode() == 1 || (x6d_mode() == 2 && !(flags & M3T_GEMM_BESIDE_SCAN))))      // ("high": measured better on gemm_x6.hip)
             // the same product, software-pipelined inside each wave (gemm_x6d.hip): bit-identical results, 8-28 % faster
             rc = m3t_sgemm_x6d_launch(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, seg_len, seg_stride,
-                                      a_off, b_off, ws, splits, kchunk, p.bf16 ? 1 : ((flags & M3T_GEMM_HIGH) ? 2 : 0), s);
+                                      a_off, b_off, ws, splits, kchunk, p.bf16 ? 1 : ((flags & M3T_GEMM_HIGH) ? 2 : (f16x3 ? 3 : 0)), use_a, use_b, s);
         else
             rc = m3t_sgemm_x6_launch(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, seg_len, seg_stride,
                                      a_off, b_off, ws, splits, kchunk, (flags & M3T_GEMM_BACKGROUND) ? (size_t)40 * 1024 : 0,

@@ -39,10 +39,24 @@ struct X6DParams {
     size_t cv_btap;
     const float* cv_mask; const float* cv_res; float* cv_pre;
     M3TDrop cv_drop;
+    const unsigned long long* amax_a;   // NS = 4 (fp16x3): magnitude slots of A and B (common.h)
+    const unsigned long long* amax_b;
 };
 
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr int planes_of(int NS) { return NS == 4 ? 2 : NS; }      // NS = 4: fp16x3, two fp16 terms of the scaled operand (gemm_x6.hip)
 template <int NS>
-__device__ __forceinline__ void split3_pair(f32x2 v, unsigned (&o)[3]) {
+__device__ __forceinline__ void split3_pair(f32x2 v, unsigned (&o)[3], float scale = 1.f) {
+    if (NS == 4) {
+        const f32x2 vs = v * scale;
+        const f16x2 h = __builtin_convertvector(vs, f16x2);
+        o[0] = __builtin_bit_cast(unsigned, h);
+        const f32x2 r1 = vs - __builtin_convertvector(h, f32x2);
+        const f16x2 l = __builtin_convertvector(r1, f16x2);
+        o[1] = __builtin_bit_cast(unsigned, l);
+        return;
+    }
     const bf16x2 h = __builtin_convertvector(v, bf16x2);
     o[0] = __builtin_bit_cast(unsigned, h);
     if (NS == 1) return;
@@ -61,16 +75,16 @@ __device__ __forceinline__ void split3_pair(f32x2 v, unsigned (&o)[3]) {
 
 // K-contiguous operand: thread = (k-quad tid & 3, rows (tid >> 2) + 64 i); r[i] = 4 k of row i
 template <int NS>
-__device__ __forceinline__ void kc_store_c(unsigned char* __restrict__ S, const f32x4 (&r)[2]) {
+__device__ __forceinline__ void kc_store_c(unsigned char* __restrict__ S, const f32x4 (&r)[2], float scale) {
     const int tid = threadIdx.x;
     unsigned char* q = S + ((tid >> 1) & 1) * PLANEB + (tid >> 2) * 16 + (tid & 1) * 8;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         unsigned lo[3], hi2[3];
-        split3_pair<NS>((f32x2){r[i].x, r[i].y}, lo);
-        split3_pair<NS>((f32x2){r[i].z, r[i].w}, hi2);
+        split3_pair<NS>((f32x2){r[i].x, r[i].y}, lo, scale);
+        split3_pair<NS>((f32x2){r[i].z, r[i].w}, hi2, scale);
 #pragma unroll
-        for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x2*>(q + s * SPLITB + i * 1024) = (u32x2){lo[s], hi2[s]};
+        for (int s = 0; s < planes_of(NS); ++s) *reinterpret_cast<u32x2*>(q + s * SPLITB + i * 1024) = (u32x2){lo[s], hi2[s]};
     }
 }
 // row-contiguous operand: wave w holds k-octet w >> 1 of rows 64 (w & 1) ..+63; lane = (k-pair g = lane >> 4, rows
@@ -78,16 +92,16 @@ __device__ __forceinline__ void kc_store_c(unsigned char* __restrict__ S, const 
 // the same 4 rows: a 4 x 4 transpose across them (v_permlane16_swap, then v_permlane32_swap: 4 per split) leaves lane
 // g with the complete 16-B record of row g -- a wave stores 1 KiB contiguous per split.
 template <int NS>
-__device__ __forceinline__ void mc_store_c(unsigned char* __restrict__ S, const f32x4 (&r)[2]) {
+__device__ __forceinline__ void mc_store_c(unsigned char* __restrict__ S, const f32x4 (&r)[2], float scale) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     unsigned o[4][3];
-    split3_pair<NS>((f32x2){r[0].x, r[1].x}, o[0]);
-    split3_pair<NS>((f32x2){r[0].y, r[1].y}, o[1]);
-    split3_pair<NS>((f32x2){r[0].z, r[1].z}, o[2]);
-    split3_pair<NS>((f32x2){r[0].w, r[1].w}, o[3]);
+    split3_pair<NS>((f32x2){r[0].x, r[1].x}, o[0], scale);
+    split3_pair<NS>((f32x2){r[0].y, r[1].y}, o[1], scale);
+    split3_pair<NS>((f32x2){r[0].z, r[1].z}, o[2], scale);
+    split3_pair<NS>((f32x2){r[0].w, r[1].w}, o[3], scale);
     unsigned char* q = S + (w >> 1) * PLANEB + ((w & 1) * 64 + (lane & 15) * 4 + (lane >> 4)) * 16;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
+    for (int s = 0; s < planes_of(NS); ++s) {
         // X[g][i] = o[i][s] in lane group g.  permlane16_swap(a, b): a.group1 <-> b.group0, a.group3 <-> b.group2;
         // permlane32_swap(a, b): a.groups{2,3} <-> b.groups{0,1}.  After both: (c0, c1, c2, c3) in group g = X[0..3][g].
         const u32x2 p01 = __builtin_amdgcn_permlane16_swap(o[0][s], o[1][s], false, false);
@@ -124,6 +138,11 @@ __global__ __launch_bounds__(NTH, 3) void sgemm_x6d_kernel(X6DParams p) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float sc_a = 1.f, sc_b = 1.f, sc_ia = 1.f, sc_ib = 1.f;      // NS = 4: operand scales and their inverses (powers of two)
+    if (NS == 4) {
+        m3t_f16_scale((unsigned)*p.amax_a, sc_a, sc_ia);
+        m3t_f16_scale((unsigned)*p.amax_b, sc_b, sc_ib);
+    }
 
     // per-thread source pointers (two float4 per operand per stage); M, N are multiples of 128: no edges (the clamps are no-ops)
     const float* pa[2]; const float* pb[2];
@@ -215,22 +234,24 @@ __global__ __launch_bounds__(NTH, 3) void sgemm_x6d_kernel(X6DParams p) {
         ++loaded;
     };
     auto sstore = [&](unsigned char* st, const f32x4 (&ra)[2], const f32x4 (&rb)[2]) {
-        if (TA == 0) kc_store_c<NS>(st, ra); else mc_store_c<NS>(st, ra);
-        if (TB == 1) kc_store_c<NS>(st + OPERB, rb); else mc_store_c<NS>(st + OPERB, rb);
+        if (TA == 0) kc_store_c<NS>(st, ra, sc_a); else mc_store_c<NS>(st, ra, sc_a);
+        if (TB == 1) kc_store_c<NS>(st + OPERB, rb, sc_b); else mc_store_c<NS>(st + OPERB, rb, sc_b);
     };
 
     // the products, smallest first.  NS = 3: (a3,b1) (a2,b2) (a1,b3) (a2,b1) (a1,b2) (a1,b1); NS = 2 ("high" mode): the last four
     // entries read (a2,b2) (a2,b1) (a1,b2) (a1,b1); NS = 1: (a1,b1)
-    constexpr int PA[6] = {NS - 1, NS / 2, NS == 2 ? 1 : 0, NS == 2 ? 1 : NS / 2, 0, 0};
-    constexpr int PB[6] = {0, NS / 2, NS == 2 ? 1 : NS - 1, 0, NS == 2 ? 1 : NS / 2, 0};
+    constexpr int NSB = NS == 4 ? 2 : NS;             // (the bf16 product table; unused when NS = 4)
+    constexpr int PA[6] = {NSB - 1, NSB / 2, NSB == 2 ? 1 : 0, NSB == 2 ? 1 : NSB / 2, 0, 0};
+    constexpr int PB[6] = {0, NSB / 2, NSB == 2 ? 1 : NSB - 1, 0, NSB == 2 ? 1 : NSB / 2, 0};
     const int fro_a = hi * PLANEB + (wm * 64 + l31) * 16;
     const int fro_b = OPERB + hi * PLANEB + (wn * 64 + l31) * 16;
     // one stage, straight-line: the fragments of `cur`, the split + store of the held stage into `nxt`, the 24 MFMAs -- no
     // scheduling fence between them: the split's VALU / LDS instructions go into the shadow of the dependent MFMA chains
     auto stage = [&](const unsigned char* cur, unsigned char* nxt, const f32x4 (&ua)[2], const f32x4 (&ub)[2]) {
-        bf16x8 fa[NS][2], fb[NS][2];
+        constexpr int NP = planes_of(NS);
+        bf16x8 fa[NP][2], fb[NP][2];
 #pragma unroll
-        for (int s = 0; s < NS; ++s)
+        for (int s = 0; s < NP; ++s)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 fa[s][i] = *reinterpret_cast<const bf16x8*>(cur + fro_a + s * SPLITB + i * 512);
@@ -242,9 +263,15 @@ __global__ __launch_bounds__(NTH, 3) void sgemm_x6d_kernel(X6DParams p) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 f32x16 c = acc[i][j];
+                if (NS == 4) {                 // fp16x3: lo hi, hi lo, hi hi
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[1][i]), __builtin_bit_cast(f16x8, fb[0][j]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[0][i]), __builtin_bit_cast(f16x8, fb[1][j]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[0][i]), __builtin_bit_cast(f16x8, fb[0][j]), c, 0, 0, 0);
+                } else {
 #pragma unroll
-                for (int q = (NS == 3 ? 0 : (NS == 2 ? 2 : 5)); q < 6; ++q)
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[q]][i], fb[PB[q]][j], c, 0, 0, 0);
+                    for (int q = (NS == 3 ? 0 : (NS == 2 ? 2 : 5)); q < 6; ++q)
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[q]][i], fb[PB[q]][j], c, 0, 0, 0);
+                }
                 acc[i][j] = c;
             }
     };
@@ -281,6 +308,7 @@ __global__ __launch_bounds__(NTH, 3) void sgemm_x6d_kernel(X6DParams p) {
                 const int row = bm + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 if (CONV && p.cv_drop.on && (r & 3) == 0) m3t_drop_mask4(p.cv_drop, (uint32_t)row >> 2, (uint32_t)col, dm);
                 float v = acc[i][j][r];
+                if (NS == 4) v = v * sc_ia * sc_ib;              // (exact: powers of two)
                 float* q = dst + (size_t)row * ldd + col;
                 if (CONV) {
                     const size_t o = (size_t)row * ldd + col;
@@ -306,8 +334,11 @@ __global__ __launch_bounds__(NTH, 3) void sgemm_x6d_kernel(X6DParams p) {
 // ld % 4 == 0, seg_len >= 32 when segmented); bf16_operands: 0 fp32-accurate (six products), 1 bf16 mode, 2 "high" (four products).
 int m3t_sgemm_x6d_launch(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                          float* C, int ldc, const float* bias, int act, int accumulate, int seg_len, int seg_stride,
-                         int a_off, int b_off, float* ws, int splits, int kchunk, int bf16_operands, hipStream_t s) {
+                         int a_off, int b_off, float* ws, int splits, int kchunk, int bf16_operands,
+                         const unsigned long long* amax_a, const unsigned long long* amax_b, hipStream_t s) {
     X6DParams p;
+    p.amax_a = amax_a; p.amax_b = amax_b;
+    if (bf16_operands == 3 && (!amax_a || !amax_b)) return M3T_EINVAL;
     p.A = A; p.B = B; p.C = C; p.bias = bias; p.ws = ws;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.act = act; p.accumulate = accumulate; p.splits = splits; p.kchunk = kchunk;
@@ -337,6 +368,7 @@ int m3t_sgemm_x6d_launch(int transA, int transB, int M, int N, int K, const floa
     } while (0)
     if (bf16_operands == 1) M3T_X6D_DISPATCH(1);
     else if (bf16_operands == 2) M3T_X6D_DISPATCH(2);
+    else if (bf16_operands == 3) M3T_X6D_DISPATCH(4);       // fp16x3
     else M3T_X6D_DISPATCH(3);
 #undef M3T_X6D_DISPATCH
 #undef M3T_X6D_GO
@@ -350,6 +382,7 @@ int m3t_conv_x6d_launch(const float* x, const float* w_t, const float* bias, con
                         float* pre, int B, int T, int Ci, int Co, int K, int dil, int lead, int act, int anti, int bf16_operands,
                         M3TDrop drop, hipStream_t s) {
     X6DParams p;
+    p.amax_a = p.amax_b = nullptr;
     p.A = x; p.B = w_t; p.C = y; p.bias = bias; p.ws = nullptr;
     p.M = B * T; p.N = Co; p.K = K * Ci; p.lda = Ci; p.ldb = anti ? Co : Ci; p.ldc = Co;
     p.act = act; p.accumulate = 0; p.splits = 1; p.kchunk = K * Ci;
