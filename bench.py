@@ -99,7 +99,7 @@ def cpu_baseline(max_clips, T, d_a, d_v, budget_s=25.0):
 # algorithmic FLOPs per clip, forward + backward = 3 x forward: C1 TCN head 128 -> 512 -> 512, k=3 + Linear(512, 2)
 # at T=300: 3 x 1.573 GF; C2 TCN(256 -> 512 -> 512) -> GRU(512,512,2,2,2) at T=300: 20.29 GF; C5 full AffWild2VA A+V on 112x112
 # frames at T=64: 135 GF.
-AUX_FLOPS = {"c1": 3 * 1.573e9, "c2": 20.29e9, "c2bf16": 20.29e9, "c5": 135e9, "c3high": 47.43e9}      # (c3high: the main workload, 47.43 GF per clip)
+AUX_FLOPS = {"c1": 3 * 1.573e9, "c2": 20.29e9, "c2bf16": 20.29e9, "c5": 135e9, "c3high": 47.43e9, "c3x6": 47.43e9}      # (c3high: the main workload, 47.43 GF per clip)
 
 
 def aux_child(which, steps=6, warmup=2):
@@ -155,6 +155,21 @@ def aux_child(which, steps=6, warmup=2):
                     step()
             emit("c2bf16", "C2 as above with bf16 matmul/conv/recurrent operands, fp32 accumulate/state/master weights (BASELINE configs[1])", B,
                  timed(step16, 30), "bf16 operands, f32 accumulate")
+    if "c3x6" in which:
+        # the MAIN workload with the round-2 arithmetic -- every GEMM / conv / recurrent product from three bf16 terms and six MFMAs
+        # (ops.precision("x6")) -- on the same box in the same run: what the default's two-fp16-term products
+        # are worth.  Both modes are fp32-accurate; `value` is the default's.
+        from m3t.workloads import AVFeatureGraph, make_c3_step
+        torch.manual_seed(12345)
+        m6 = AVFeatureGraph(128, 256, 512).to(dev)
+        _, step6 = make_c3_step(m6, synth_batch(B, T, 128, 256, dev, 0), max_norm=1.0)
+
+        def step_x6():
+            with ops.precision("x6"):
+                step6()
+        emit("c3x6", "C3/C4 main workload with ops.precision('x6'): every fp32-accurate product from three bf16 terms and six MFMAs (the "
+             "default until round 3) instead of two fp16 terms of the scaled operands and three", B, timed(step_x6, 30), "f32 (bf16x6 products)")
+        del m6, step6
     if "c3high" in which:
         # the MAIN workload in the opt-in "high" matmul precision (two bf16 terms per GEMM / conv operand, four products: what
         # torch.set_float32_matmul_precision('high') means; recurrent scans unchanged) -- NOT the headline: `value` is measured
@@ -277,7 +292,7 @@ def parse_args():
                     help="weak: --batch clips on EVERY GPU; strong: --batch clips in all, split over the GPUs (SURVEY 8(d) C4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=32, help="clips per CPU-baseline iteration (default: the GPU's batch)")
-    ap.add_argument("--aux", default="c1,c2,c2bf16,c5,cbam", help="secondary configs timed after the main leg at N=1 ('' = none)")
+    ap.add_argument("--aux", default="c1,c2,c2bf16,c3x6,c5,cbam", help="secondary configs timed after the main leg at N=1 ('' = none)")
     ap.add_argument("--aux-budget", type=float, default=240.0)
     ap.add_argument("--aux-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--worker", type=int, default=None, help=argparse.SUPPRESS)      # attempt number (0, or 1 = fallback)
