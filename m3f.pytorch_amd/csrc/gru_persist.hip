@@ -753,73 +753,10 @@ __device__ __forceinline__ void bwd6_split_pair(unsigned x0, unsigned x1, unsign
     o3 = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
 }
 
-// fp16x3 form of the backward recurrent product (M3T_GEMM_F16X3).  W_hh^T: two fp16 terms per workgroup slice (the
-// 16 output units of a workgroup against all 3H gate rows), scaled by the power of two that puts the slice's largest magnitude into
-// [2^14, 2^15): wfragh[ub][wave][ks][term < 2][lane][8 fp16] + inv[ub] = 1 / scale.  The exchanged operand dgh has no bound before it
-// exists: every wave scales the 48 values per lane it has just gathered by the power of two of ITS OWN maximum (a v_max3 chain, four
-// DPP row steps, four v_readlane) -- a wave multiplies its own K-slice into its own partial sum, so the scale leaves again when the
-// partial sum is written to LDS.
-struct PrepBwd3hArgs { const float* w[M3T_MAX_SCANS]; unsigned short* wf[M3T_MAX_SCANS]; float* inv[M3T_MAX_SCANS]; };
-__global__ __launch_bounds__(256) void wfrag_bwd3h_prep_kernel(PrepBwd3hArgs a, int H, int direct) {
-    const float* __restrict__ w = a.w[blockIdx.z];
-    unsigned short* __restrict__ wf = a.wf[blockIdx.z];
-    const int ub = blockIdx.x, kq = H >> 8, ksn = 3 * kq;             // k-steps per wave
-    __shared__ float red[4];
-    float m = 0.f;
-    // the slice: W_hh[gate row gr = 0 .. 3H-1][ub*16 + c]  (direct)  or  w_hh_t[ub*16 + c][gr]
-    for (int i = threadIdx.x; i < 3 * H * 16; i += 256) {
-        const int gr = direct ? (i >> 4) : (i % (3 * H)), c = direct ? (i & 15) : (i / (3 * H));
-        m = fmaxf(m, m3t_fin_abs(direct ? w[(size_t)gr * H + ub * 16 + c] : w[((size_t)ub * 16 + c) * 3 * H + gr]));
-    }
-    m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-    __syncthreads();
-    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    float sc, inv;
-    m3t_f16_scale(__float_as_uint(m), sc, inv);
-    if (threadIdx.x == 0 && blockIdx.y == 0) a.inv[blockIdx.z][ub] = inv;
-    const int per = 3 * 16 * H;                       // one thread per weight of the slice: [wave][ks][lane][8]
-    for (int j = blockIdx.y * 256 + threadIdx.x; j < per; j += 256 * PREP3H_SPLIT) {
-        const int e = j & 7, l = (j >> 3) & 63;
-        int r = j >> 9;
-        const int ks = r % ksn; const int wv = r / ksn;
-        const int gt = ks / kq, h = ks % kq;
-        const int unit = 16 * (wv + NW * (2 * h + (e >> 2))) + 4 * (l >> 4) + (e & 3);
-        const float x = (direct ? w[((size_t)gt * H + unit) * H + ub * 16 + (l & 15)]
-                                : w[((size_t)ub * 16 + (l & 15)) * 3 * H + (size_t)gt * H + unit]) * sc;
-        const _Float16 h1 = (_Float16)x;
-        const _Float16 h2 = (_Float16)(x - (float)h1);
-        const size_t base = ((((size_t)(ub * NW + wv) * ksn + ks) * 2)) * 512 + (size_t)l * 8 + e;
-        wf[base] = __builtin_bit_cast(unsigned short, h1);
-        wf[base + 512] = __builtin_bit_cast(unsigned short, h2);
-    }
-}
-// max over the wave of a non-negative float (bit pattern order), uniform result: four DPP steps inside each row of 16 lanes, then the
-// four row maxima through v_readlane
-__device__ __forceinline__ unsigned wave_umax_dpp(unsigned v) {
-    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));      // row_shr:1
-    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));      // row_shr:2
-    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));      // row_shr:4
-    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));      // row_shr:8: lane 15 of a row = the row's maximum
-    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 15), b = (unsigned)__builtin_amdgcn_readlane((int)v, 31);
-    const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 47), d = (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-    return max(max(a, b), max(c, d));
-}
-// a pair of gathered fp32 values, scaled, as two packed fp16 pairs (first value in the low half)
-__device__ __forceinline__ void bwd3h_split_pair(unsigned x0, unsigned x1, float sc, unsigned& o1, unsigned& o2) {
-    typedef float f32x2_ __attribute__((ext_vector_type(2)));
-    typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
-    const f32x2_ vs = (f32x2_){__uint_as_float(x0), __uint_as_float(x1)} * sc;
-    const f16x2_ hh = __builtin_convertvector(vs, f16x2_);
-    o1 = __builtin_bit_cast(unsigned, hh);
-    const f32x2_ r1 = vs - __builtin_convertvector(hh, f32x2_);
-    o2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, f16x2_));
-}
-
-template <int NC, bool F16 = false>
+template <int NC>
 __global__ __launch_bounds__(NT) void gru_persist_bwd6_kernel(BwdGroup g, FragPtrs fp, ExPtrs ex, int B, int T, int G, int nrb,
                                                              unsigned* err) {
-    constexpr int RT = 1, ROWS = 16, KS = NC / 2, NTERM = F16 ? 2 : 3;
+    constexpr int RT = 1, ROWS = 16, KS = NC / 2;
     constexpr int H = 128 * NC, H3 = 3 * H, nchh = H >> 4;
     __shared__ float red[2][NW][ROWS][UB + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -829,15 +766,14 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd6_kernel(BwdGroup g, FragPt
     const m3t_gru_bwd_desc d = g.d[s];
     const int j0 = ub * UB, r0 = rb * ROWS;
 
-    pbf16x8 wb[3 * KS][NTERM];                         // [k-step = gate*KS + h][term]: 72 VGPRs at H = 512 (F16: fp16 bit patterns, 48)
+    pbf16x8 wb[3 * KS][3];                             // [k-step = gate*KS + h][term]: 72 VGPRs at H = 512
     {
-        const pu32x4* Wf = reinterpret_cast<const pu32x4*>(fp.wfrag[s]) + ((size_t)(ub * NW + wave) * 3 * KS * NTERM) * 64 + lane;
+        const pu32x4* Wf = reinterpret_cast<const pu32x4*>(fp.wfrag[s]) + ((size_t)(ub * NW + wave) * 3 * KS * 3) * 64 + lane;
 #pragma unroll
         for (int k = 0; k < 3 * KS; ++k)
 #pragma unroll
-            for (int t = 0; t < NTERM; ++t) wb[k][t] = __builtin_bit_cast(pbf16x8, Wf[(k * NTERM + t) * 64]);
+            for (int t = 0; t < 3; ++t) wb[k][t] = __builtin_bit_cast(pbf16x8, Wf[(k * 3 + t) * 64]);
     }
-    const float winv = F16 ? reinterpret_cast<const float*>(fp.wfrag[s])[(size_t)4 * H * H + ub] : 1.f;     // 1 / (scale of this slice's W_hh^T)
     const bool pw = tid < ROWS * UB;                   // granule-order numbering, as in the forward kernel
     const int prow = (tid >> 8) * 16 + (tid & 15), pu = ((tid >> 4) & 3) * 4 + ((tid >> 6) & 3);
     const int pb = r0 + prow, pj = j0 + pu;
