@@ -1503,11 +1503,11 @@ int persist_fwd_launch(const FwdGroup& g, const FragPtrs& fp, int B, int T, int 
     return 0;
 }
 
-// M3T_SCAN_BWD3P=1: the producer-split backward scan (gru_persist_bwd3p_kernel) for the H = 512 levels in the fp16x3 mode.  Opt-in:
-// its step is 5-7 % shorter (3.85 -> 3.59 us at 4 x H=512) but the training step does not move yet
+// M3T_SCAN_BWD3P=0: the six-product backward scan (consumer-side split) for the H = 512 levels also in the fp16x3 mode, instead of the
+// producer-split kernel (gru_persist_bwd3p_kernel: 3.85 -> 3.44 us per step at 4 x H=512)
 static bool bwd3p_enabled() {
     static int on = -1;
-    if (on < 0) { const char* e = getenv("M3T_SCAN_BWD3P"); on = (e && e[0] == '1') ? 1 : 0; }
+    if (on < 0) { const char* e = getenv("M3T_SCAN_BWD3P"); on = (e && e[0] == '0') ? 0 : 1; }
     return on == 1;
 }
 
