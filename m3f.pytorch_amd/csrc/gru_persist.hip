@@ -913,20 +913,27 @@ __global__ __launch_bounds__(256) void wfrag_bwd3p_prep_kernel(PrepBwd3pArgs a, 
     float sc, inv;
     m3t_f16_scale(__float_as_uint(m), sc, inv);
     if (threadIdx.x == 0 && blockIdx.y == 0) a.inv[blockIdx.z][ub] = inv;
-    const int per = 3 * 16 * H;
-    for (int j = blockIdx.y * 256 + threadIdx.x; j < per; j += 256 * PREP3H_SPLIT) {
-        const int i = j & 3, l = (j >> 2) & 63;
-        int r = j >> 8;
+    // one item = the four k of one (gate, tile, wave, lane): four row reads at the same column (16 consecutive lanes = one 64-byte run per
+    // row), one 8-byte store per term (16 consecutive lanes = 128 contiguous bytes)
+    const int items = 3 * 4 * H;                      // 3 gates x (H / 16) 16-unit groups x 64 lanes
+    for (int j = blockIdx.y * 256 + threadIdx.x; j < items; j += 256 * PREP3H_SPLIT) {
+        const int l = j & 63;
+        int r = j >> 6;
         const int tl = r % nc; r /= nc;
         const int wv = r % NW, gt = r / NW;
-        const int unit = 16 * (wv + NW * tl) + 4 * (l >> 4) + i;
-        const float x = (direct ? w[((size_t)gt * H + unit) * H + ub * 16 + (l & 15)]
-                                : w[((size_t)ub * 16 + (l & 15)) * 3 * H + (size_t)gt * H + unit]) * sc;
-        const _Float16 h1 = (_Float16)x;
-        const _Float16 h2 = (_Float16)(x - (float)h1);
-        const size_t base = (((((size_t)(ub * NW + wv) * 3 + gt) * nc + tl) * 2) * 64 + l) * 4 + i;
-        wf[base] = __builtin_bit_cast(unsigned short, h1);
-        wf[base + 256] = __builtin_bit_cast(unsigned short, h2);
+        const int unit0 = 16 * (wv + NW * tl) + 4 * (l >> 4), n = l & 15;
+        unsigned short h1[4], h2[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float x = (direct ? w[((size_t)gt * H + unit0 + i) * H + ub * 16 + n]
+                                    : w[((size_t)ub * 16 + n) * 3 * H + (size_t)gt * H + unit0 + i]) * sc;
+            const _Float16 a1 = (_Float16)x;
+            const _Float16 a2 = (_Float16)(x - (float)a1);
+            h1[i] = __builtin_bit_cast(unsigned short, a1); h2[i] = __builtin_bit_cast(unsigned short, a2);
+        }
+        const size_t base = (((((size_t)(ub * NW + wv) * 3 + gt) * nc + tl) * 2) * 64 + l) * 4;
+        *reinterpret_cast<uint2*>(wf + base) = make_uint2((unsigned)h1[0] | ((unsigned)h1[1] << 16), (unsigned)h1[2] | ((unsigned)h1[3] << 16));
+        *reinterpret_cast<uint2*>(wf + base + 256) = make_uint2((unsigned)h2[0] | ((unsigned)h2[1] << 16), (unsigned)h2[2] | ((unsigned)h2[3] << 16));
     }
 }
 // max over the wave of a non-negative float's bit pattern, uniform: four DPP steps inside each row of 16 lanes, then the four row
