@@ -90,3 +90,30 @@ def test_elements_far_below_the_maximum_keep_an_absolute_not_a_relative_error():
         back = (hi.astype(np.float64) + lo.astype(np.float64)) * float(inv)
         err = abs(back[1] - float(v[1])) / float(v[1])
         assert err <= 2.0 ** -bits, (r, err)
+
+
+def test_the_per_cell_bound_of_the_producer_split_backward_scan_holds():
+    """gru_persist_bwd3p_kernel scales what a cell publishes -- (dr~, dz~, dn~ r) -- by a power of two taken from
+    |dht| max(1, |W_hn h + b_hn| / 4), known before the rest of the cell math (csrc/gru_persist_bwd3p_step.inc); the cell formulas are
+    those of gru_cell_bwd (csrc/gru_common.h).  In fp32, over wide ranges, no published value exceeds the bound by more than rounding --
+    the scale leaves a factor two."""
+    rs = np.random.RandomState(3)
+    n_ = 200000
+    f = np.float32
+    r = (1.0 / (1.0 + np.exp(-rs.standard_normal(n_) * 4))).astype(f)
+    z = (1.0 / (1.0 + np.exp(-rs.standard_normal(n_) * 4))).astype(f)
+    n = np.tanh(rs.standard_normal(n_) * 2).astype(f)
+    hprev = np.tanh(rs.standard_normal(n_) * 2).astype(f)
+    ghn = (rs.standard_normal(n_) * (10.0 ** rs.uniform(-2, 2, n_))).astype(f)
+    dht = (rs.standard_normal(n_) * (10.0 ** rs.uniform(-12, 6, n_))).astype(f)
+    dn = (dht * (f(1) - z) * (f(1) - n * n)).astype(f)
+    dz = (dht * (hprev - n) * z * (f(1) - z)).astype(f)
+    dr = (dn * ghn * r * (f(1) - r)).astype(f)
+    dnr = (dn * r).astype(f)
+    bound = (np.abs(dht) * np.maximum(f(1), f(0.25) * np.abs(ghn))).astype(f)
+    worst = np.maximum(np.abs(dr), np.maximum(np.abs(dz), np.abs(dnr))) / np.maximum(bound, f(1e-37))
+    assert float(worst.max()) <= 1.0 + 1e-5, float(worst.max())
+    # and with the scale taken from the bound, every published value fits fp16 with room to spare
+    for i in rs.randint(0, n_, 2000):
+        s, _ = f16_scale(bound[i])
+        assert max(abs(float(dr[i])), abs(float(dz[i])), abs(float(dnr[i]))) * float(s) < 40000.0
