@@ -57,7 +57,10 @@ extern "C" {
  * same stream, no host round trip -- and unscaling in the epilogue (exact).  Elements more than 2^17 below their operand's maximum
  * keep an absolute error of 2^-40 of that maximum instead of a relative one.  Measured against fp64 the mode is as accurate as the
  * six-product form (fewer fp32 accumulate roundings per k) -- DESIGN.md section 5e.  Interior shapes only; the BF16 and HIGH flags
- * win if set.  The recurrent scans ignore it. */
+ * win if set.  m3t_gru_scan_fwd / m3t_gru_scan_bwd take the flag too: the forward persistent scans then form their recurrent product from
+ * two fp16 terms (h is bounded by 1; W_hh is scaled per workgroup slice by the scan's own prep launch), the H = 512 backward
+ * persistent scans run the producer-split kernel (two fp16 terms per exchanged value, scaled per producer tile); both fp32-accurate,
+ * no slots needed.  Without the flag (or with env M3T_GEMM_F16X3=0) the scans keep the three-bf16-term products. */
 #define M3T_GEMM_F16X3 1024
 /* scheduling hint: other streams run persistent scans while this GEMM runs (the interleaved encoder level of m3t.ops._MultiBiGRU):
  * take gemm_x6.hip, whose phases only overlap across workgroups, instead of the software-pipelined gemm_x6d.hip -- the faster
