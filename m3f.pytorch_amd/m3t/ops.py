@@ -109,7 +109,13 @@ def lib():
     return _lib.load()
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)       # the current stream's handle without building a Stream object
+
+
 def _stream():
+    """the calling thread's current HIP stream as a C pointer (every launch of the path passes it: ~600 calls per training step)"""
+    if _RAW_STREAM is not None:
+        return C.c_void_p(_RAW_STREAM(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
