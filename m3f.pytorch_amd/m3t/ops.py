@@ -158,6 +158,7 @@ def side_stream(device):
     if st is None:
         st = torch.cuda.Stream(device=device)
         _SIDE[key] = st
+        _ROLE_OF_HANDLE[(st.device.index, st.cuda_stream)] = "side"
     return st
 
 
@@ -180,6 +181,8 @@ def wgrad_stream(device, i=0):
     if sts is None:
         sts = [torch.cuda.Stream(device=device) for _ in range(_N_WGRAD)]
         _WGRAD[key] = sts
+        for i_, st_ in enumerate(sts):
+            _ROLE_OF_HANDLE[(st_.device.index, st_.cuda_stream)] = "wgrad%d" % i_
     return sts[i % min(2, len(sts))]          # (streams 2.. only ever take tail GEMMs, see _MultiBiGRU.backward.level_dw)
 
 
@@ -188,7 +191,13 @@ def wgrad_streams(device):
     return _WGRAD[(device.type, device.index)]
 
 
+_ROLE_OF_HANDLE = {}      # (device index, raw stream handle) -> "side" / "wgrad<i>": filled when the streams are created
+
+
 def _ws_tag(device):
+    """role of the calling thread's current stream on `device` (called once per GEMM / scan: raw handles, no Stream objects)"""
+    if _RAW_STREAM is not None and device.index is not None:
+        return _ROLE_OF_HANDLE.get((device.index, _RAW_STREAM(device.index)), "main")
     cur = torch.cuda.current_stream(device)
     st = _SIDE.get((device.type, device.index))
     if st is not None and cur == st:
