@@ -854,7 +854,7 @@ class _MultiBiGRU(torch.autograd.Function):
         wgs = wgrad_streams(dev)
         rr = [0]
 
-        def level_dw(l, idxs, spread=False):           # off the chain: only the optimizer reads these
+        def _level_dw(l, idxs, pool):           # off the chain: only the optimizer reads these
             """the weight-gradient GEMMs of (l, idxs) on weight-gradient stream 0 (every stream has waited for the scan; a second
             concurrent GEMM stream beside the chain takes CUs from the data-gradient GEMMs and stretches the scans: 17.77 vs 17.21
             ms, round 2).  spread: the LAST weight gradients of the pass -- nothing else is queued on the level's own stream any
@@ -872,9 +872,7 @@ class _MultiBiGRU(torch.autograd.Function):
                     goff = d * B * T * 3 * H
                     # tail: [the stream this level runs on, weight-gradient stream 1] -- after the last level nothing else is queued on
                     # the level's own stream, and finalize (FlatGradDDP.finish) then follows its last GEMM with no cross-queue hop
-                    pool = [torch.cuda.current_stream(), wgs[1]] if spread else wgs[:1]
-                    nw = len(pool)
-                    with torch.cuda.stream(pool[rr[0] % nw]):
+                    with (torch.cuda.stream(pool[rr[0] % len(pool)]) if pool is not None else _NULL):
                         if T > 1 and (B * (T - 1)) % 32 != 0 and (B * T) % 32 == 0 and H % 128 == 0:
                             # K = B (T-1) is no multiple of the bf16x6 GEMMs' 32-deep k tile (e.g. 8 clips x 64 frames: K = 504) and
                             # the segmented product would fall to the fp32-MFMA kernel (20 launches, 7 % of a C5 step).  h_prev at
@@ -896,10 +894,18 @@ class _MultiBiGRU(torch.autograd.Function):
                         else:
                             dw_hh.zero_()
                     rr[0] += 1
-                    with torch.cuda.stream(pool[rr[0] % nw]):
+                    with (torch.cuda.stream(pool[rr[0] % len(pool)]) if pool is not None else _NULL):
                         sgemm(1, 0, 3 * H, I, B * T, dgx[l][s], d * 3 * H, 6 * H, inp, 0, I, dw_ih, 0, I, prec=prec,
                               amax=(bslot(l, s, d), fslot_x(l, s)))
                     rr[0] += 1
+
+        def level_dw(l, idxs, spread=False):
+            # one stream switch per level (not per GEMM: ~40 context switches of ~8 us of host time per step) unless the level spreads
+            if spread:
+                _level_dw(l, idxs, [torch.cuda.current_stream(), wgs[1]])
+            else:
+                with torch.cuda.stream(wgs[0]):
+                    _level_dw(l, idxs, None)
 
         for w_ in wgs:
             w_.wait_stream(main)
