@@ -36,6 +36,11 @@ extern "C" {
                                   * launch-per-step kernels) instead of the fp32-accurate bf16x6 form */
 #define M3T_SCAN_FAULT 16        /* m3t_gru_scan_* flags, FAULT INJECTION for tests: workgroup 0 of a persistent launch stays silent at step T/2,
                                   * so its peers run into their spin limit (env M3T_SCAN_SPIN_LIMIT lowers it) and the error path below runs */
+#define M3T_SCAN_WIDE 32         /* m3t_gru_scan_* flags: the caller wants room for a SECOND persistent scan beside this one (m3t.ops runs the audio
+                                  * stack's 64-workgroup scans at the same time as the gru_v | gru_a level's): an H = 512 level in the M3T_GEMM_F16X3
+                                  * mode then runs with two 16-unit tiles per workgroup -- half the workgroups (4 scans x 32 clips: 128 instead of
+                                  * 256), each owning its CU; other levels ignore the flag.  m3t_gru_scan_workgroups() says what a call would launch.
+                                  * Same results as without the flag up to the order of nothing: the arithmetic per cell is unchanged. */
 #define M3T_BF16 2               /* precision flag shared by m3t_sgemm (= M3T_GEMM_BF16), m3t_conv1d_* and m3t_gru_scan_*:
                                   * matmul operands rounded to bf16 (nearest even), fp32 accumulate, fp32 state/epilogue */
 /* m3t_sgemm flags: BACKGROUND caps residency at one workgroup per CU (for GEMMs that run on a side stream
@@ -196,6 +201,12 @@ typedef struct {
     unsigned long long* amax;  /* optional magnitude slot (m3t_sgemm_scaled): raised to the bits of max |dgx|, |dgh| of this scan */
 } m3t_gru_bwd_desc;
 
+/* Workgroups (= CUs: a scan workgroup owns its CU) that m3t_gru_scan_fwd (backward = 0) / m3t_gru_scan_bwd (backward = 1) would hold
+ * resident for ONE persistent launch over n_scans scans of hidden size H at batch B with `flags`; 0 when that level does not run as a
+ * persistent launch that needs residency (launch-per-step path, solo kernels, M3T_SCAN_NO_PERSIST).  Two persistent launches may run
+ * at the same time iff the sum of their answers fits the device's CUs, per XCD (ceil(answer / 8) each, 32 CUs per XCD on MI355X):
+ * then both grids become resident whatever else is draining from the CUs, and neither can wait for the other forever.  No device work. */
+int m3t_gru_scan_workgroups(int n_scans, int H, int B, int T, int flags, int backward);
 /* Number of one-launch scans (persistent or solo) this process has issued so far (tests use it to assert which path ran). */
 int m3t_gru_persist_count(void);
 /* 0, or (step + 1) of a persistent scan that gave up waiting since the last m3t_gru_error_reset() (sticky: reading does

@@ -339,35 +339,49 @@ __global__ __launch_bounds__(256) void wfrag3h_prep_kernel(Prep3hArgs a, int H) 
 }
 typedef _Float16 pf16x8 __attribute__((ext_vector_type(8)));
 
-template <int NC, bool F16 = false>
+// UW = 16-unit tiles per workgroup.  UW = 2 (round 4, "wide" workgroups): one workgroup owns 16 rows x 32 units -- the same gather per
+// workgroup (h_{t-1} of its 16 rows: the A operand is shared by both unit tiles), twice the W_hh fragments, MFMAs and cells, all eight
+// waves do cell math (waves 0-3 tile 0, waves 4-7 tile 1; the two tiles are adjacent in the exchange buffer, so the consumers' gather
+// code does not change) -- and a level needs HALF the workgroups: the 4 x H=512 encoder level runs on 128 CUs and leaves room for
+// the audio stack's 64-workgroup scans beside it.
+template <int NC, bool F16 = false, int UW = 1>
 __global__ __launch_bounds__(NT) void gru_persist_fwd6_kernel(FwdGroup g, FragPtrs fp, ExPtrs ex, int B, int T, int G, int nrb,
                                                               unsigned* err) {
     constexpr int ROWS = 16, KS = NC / 2, NTERM = F16 ? 2 : 3;
     constexpr int H = 128 * NC, nch = H >> 4;
-    __shared__ float red[2][NW][3][ROWS][UB + 1];
+    // partial sums of the waves: [step parity][wave][unit tile][gate][row][UB + 1]; UW = 2 needs 102 KiB: dynamic LDS
+    constexpr int RED_FLOATS = 2 * NW * UW * 3 * ROWS * (UB + 1);
+    __shared__ float red_s[UW == 1 ? RED_FLOATS : 1];
+    extern __shared__ __attribute__((aligned(16))) float red_d[];
+    float* const red = UW == 1 ? red_s : red_d;
+#define M3T_RED(par_, w_, u_, ct_, r_, c_) red[(((((par_) * NW + (w_)) * UW + (u_)) * 3 + (ct_)) * ROWS + (r_)) * (UB + 1) + (c_)]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int gid, ub;
-    if (!persist_map((int)blockIdx.x, G, ex.slot_map, gid, ub)) return;      // a block of an XCD slot that hosts no group of this launch
+    int gid, ubw;
+    if (!persist_map((int)blockIdx.x, G, ex.slot_map, gid, ubw)) return;      // a block of an XCD slot that hosts no group of this launch
     const int s = gid / nrb, rb = gid % nrb;
     const m3t_gru_fwd_desc d = g.d[s];
+    const int tu = UW == 1 ? 0 : (tid >> 8);           // the unit tile this thread does cell math for
+    const int ub = ubw * UW + tu;
     const int j0 = ub * UB, r0 = rb * ROWS;
 
-    pbf16x8 wf[KS][3][NTERM];                          // [k-step][gate tile][term] (F16: fp16 bit patterns, two terms)
-    {
-        const pu32x4* Wf = reinterpret_cast<const pu32x4*>(fp.wfrag[s]) + ((size_t)(ub * NW + wave) * KS * 3 * NTERM) * 64 + lane;
+    pbf16x8 wf[UW][KS][3][NTERM];                      // [unit tile][k-step][gate tile][term] (F16: fp16 bit patterns, two terms)
+#pragma unroll
+    for (int u = 0; u < UW; ++u) {
+        const pu32x4* Wf = reinterpret_cast<const pu32x4*>(fp.wfrag[s]) + ((size_t)((ubw * UW + u) * NW + wave) * KS * 3 * NTERM) * 64 + lane;
 #pragma unroll
         for (int k = 0; k < KS; ++k)
 #pragma unroll
             for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
-                for (int t = 0; t < NTERM; ++t) wf[k][ct][t] = __builtin_bit_cast(pbf16x8, Wf[((k * 3 + ct) * NTERM + t) * 64]);
+                for (int t = 0; t < NTERM; ++t) wf[u][k][ct][t] = __builtin_bit_cast(pbf16x8, Wf[((k * 3 + ct) * NTERM + t) * 64]);
     }
     // F16: 2^-14 / (scale of this slice's W_hh), written by wfrag3h_prep_kernel behind the fragments
     const float winv = F16 ? reinterpret_cast<const float*>(fp.wfrag[s])[(size_t)4 * H * H + ub] : 1.f;
-    // cell-math threads in granule order (see the header): granule tid = jp*64 + hr*2 + jlo  <->  row hr & 15,
+    // cell-math threads in granule order (see the header): granule ti = jp*64 + hr*2 + jlo  <->  row hr & 15,
     // unit 8*(hr >> 4) + 2*jp + jlo
-    const bool pw = tid < ROWS * UB;
-    const int prow = (tid >> 1) & 15, pu = ((tid >> 5) & 1) * 8 + 2 * ((tid >> 6) & 3) + (tid & 1);
+    const int ti = tid & 255;
+    const bool pw = tid < ROWS * UB * UW;
+    const int prow = (ti >> 1) & 15, pu = ((ti >> 5) & 1) * 8 + 2 * ((ti >> 6) & 3) + (ti & 1);
     const int pb = r0 + prow, pj = j0 + pu;
     const bool pok = pw && pb < B;
     float br = 0.f, bz = 0.f, bn = 0.f, hprev = 0.f;
@@ -377,7 +391,7 @@ __global__ __launch_bounds__(NT) void gru_persist_fwd6_kernel(FwdGroup g, FragPt
     unsigned long long* gran = reinterpret_cast<unsigned long long*>(ex.gran[s]);
     const size_t slot = ex.slot[s];
     const size_t grp = (size_t)rb * nch * TILE;
-    const size_t pub = grp + (size_t)ub * TILE + tid;
+    const size_t pub = grp + (size_t)ubw * UW * TILE + tid;
     // this lane's gather base inside a producer tile: chunk m = 2s + (q >> 1); granule pair 2*hr + 64 jp, hr = (q&1)*16 + row
     const int q = lane >> 4;
     const size_t lane_off = (size_t)(wave + NW * (q >> 1)) * TILE + 2 * ((q & 1) * 16 + (lane & 15));
@@ -385,7 +399,7 @@ __global__ __launch_bounds__(NT) void gru_persist_fwd6_kernel(FwdGroup g, FragPt
     int poll_delay = ex.poll_fixed >= 0 ? ex.poll_fixed : POLL_DELAY_INIT;
     __shared__ unsigned poll_fail[2];                  // by step parity
     __shared__ int pub_step;                           // steps this workgroup has published (thread 0)
-    const int l2mode = persist_handshake(ex, gid, ub, H >> 4, tid, err);     // 1: this group shares one XCD's L2 (publish with plain stores)
+    const int l2mode = persist_handshake(ex, gid, ubw, (H >> 4) / UW, tid, err);     // 1: this group shares one XCD's L2 (publish with plain stores)
     if (tid == 0) pub_step = 0;
     if (tid < 2) poll_fail[tid] = 0;                   // first read after the first barrier
     const bool stamp = ex.prof != nullptr && blockIdx.x == 0 && tid == ex.prof_tid;
@@ -429,6 +443,7 @@ __global__ __launch_bounds__(NT) void gru_persist_fwd6_kernel(FwdGroup g, FragPt
 #undef NXT
     }
 #undef M3T_FWD_LOAD_X
+#undef M3T_RED
     // the last step's request for "the next step's inputs" is still in flight and invisible to hipcc (inline asm): a wave must
     // not end with a load outstanding into registers that the next wave on this SIMD is about to own
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -953,35 +968,41 @@ __device__ __forceinline__ unsigned bwd3p_split(float xs) {          // the scal
     return (unsigned)__builtin_bit_cast(unsigned short, h1) | ((unsigned)__builtin_bit_cast(unsigned short, h2) << 16);
 }
 
-template <int NC>
+// UW = 16-unit tiles per workgroup (2 = the "wide" form, see gru_persist_fwd6_kernel: same gather per workgroup, the gathered operand
+// shared by both output tiles, all eight waves do cell math -- waves 0-3 tile 0, waves 4-7 tile 1 -- half the workgroups per level)
+template <int NC, int UW = 1>
 __global__ __launch_bounds__(NT) void gru_persist_bwd3p_kernel(BwdGroup g, FragPtrs fp, ExPtrs ex, int B, int T, int G, int nrb,
                                                              unsigned* err) {
     constexpr int RT = 1, ROWS = 16;
     constexpr int H = 128 * NC, H3 = 3 * H, nchh = H >> 4;
-    __shared__ float red[2][NW][ROWS][UB + 1];
+    __shared__ float red[2][NW][UW][ROWS][UB + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int gid, ub;
-    if (!persist_map((int)blockIdx.x, G, ex.slot_map, gid, ub)) return;      // a block of an XCD slot that hosts no group of this launch
+    int gid, ubw;
+    if (!persist_map((int)blockIdx.x, G, ex.slot_map, gid, ubw)) return;      // a block of an XCD slot that hosts no group of this launch
     const int s = gid / nrb, rb = gid % nrb;
     const m3t_gru_bwd_desc d = g.d[s];
+    const int tu = UW == 1 ? 0 : (tid >> 8);           // the unit tile this thread does cell math for
+    const int ub = ubw * UW + tu;
     const int j0 = ub * UB, r0 = rb * ROWS;
 
-    pu32x2 wb[3][NC][2];                                // [gate][producer tile of this wave's K-slice][term]: 4 fp16 per lane, 48 VGPRs at H = 512
-    {
-        const pu32x2* Wf = reinterpret_cast<const pu32x2*>(fp.wfrag[s]) + ((size_t)(ub * NW + wave) * 3 * NC * 2) * 64 + lane;
+    pu32x2 wb[UW][3][NC][2];                            // [unit tile][gate][producer tile of this wave's K-slice][term]: 4 fp16 per lane, 48 VGPRs per unit tile at H = 512
+    float winv[UW];                                     // 1 / (scale of the slice's W_hh^T)
+#pragma unroll
+    for (int u = 0; u < UW; ++u) {
+        const pu32x2* Wf = reinterpret_cast<const pu32x2*>(fp.wfrag[s]) + ((size_t)((ubw * UW + u) * NW + wave) * 3 * NC * 2) * 64 + lane;
 #pragma unroll
         for (int gt = 0; gt < 3; ++gt)
 #pragma unroll
             for (int m = 0; m < NC; ++m)
 #pragma unroll
-                for (int t = 0; t < 2; ++t) wb[gt][m][t] = Wf[((gt * NC + m) * 2 + t) * 64];
+                for (int t = 0; t < 2; ++t) wb[u][gt][m][t] = Wf[((gt * NC + m) * 2 + t) * 64];
+        winv[u] = reinterpret_cast<const float*>(fp.wfrag[s])[(size_t)4 * H * H + ubw * UW + u];
     }
-    const float winv = reinterpret_cast<const float*>(fp.wfrag[s])[(size_t)4 * H * H + ub];     // 1 / (scale of this slice's W_hh^T)
-    __shared__ __attribute__((aligned(16))) unsigned pmx4[4];      // the cell-math waves' maxima of the step (two lowest bits: step tag)
-    if (tid < 4) pmx4[tid] = 0u;
-    const unsigned pmx4_addr = (unsigned)(uintptr_t)pmx4;        // (LDS byte address for the ds_read_b128 of the exchange)
-    const bool pw = tid < ROWS * UB;                   // granule-order numbering, as in the forward kernel
-    const int prow = (tid >> 8) * 16 + (tid & 15), pu = ((tid >> 4) & 3) * 4 + ((tid >> 6) & 3);
+    __shared__ __attribute__((aligned(16))) unsigned pmx4[UW][4];  // the cell-math waves' maxima of the step, per unit tile (two lowest bits: step tag)
+    if (tid < 4 * UW) (&pmx4[0][0])[tid] = 0u;
+    const unsigned pmx4_addr = (unsigned)(uintptr_t)&pmx4[tu][0];  // (LDS byte address for the ds_read_b128 of the exchange)
+    const bool pw = tid < ROWS * UB * UW;              // granule-order numbering, as in the forward kernel
+    const int prow = tid & 15, pu = ((tid >> 4) & 3) * 4 + ((tid >> 6) & 3);
     const int pb = r0 + prow, pj = j0 + pu;
     const bool pok = pw && pb < B;
     float dh_carry = 0.f, z_next = 0.f;                // dh_{t+1} and z_{t+1} of this thread's (row, unit)
@@ -993,12 +1014,12 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd3p_kernel(BwdGroup g, FragP
     u32x4* gran = reinterpret_cast<u32x4*>(ex.gran[s]);
     const size_t slot = ex.slot[s];
     const size_t grp = (size_t)rb * nchh * TILE;
-    const size_t pub = grp + (size_t)ub * TILE + tid;
+    const size_t pub = grp + (size_t)ubw * UW * TILE + tid;
     bool dead = false;
     int poll_delay = ex.poll_fixed >= 0 ? ex.poll_fixed : POLL_DELAY_INIT;
     __shared__ unsigned poll_fail[2];                  // by step parity
     __shared__ int pub_step;                           // steps this workgroup has published (thread 0)
-    const int l2mode = persist_handshake(ex, gid, ub, H >> 4, tid, err);     // 1: this group shares one XCD's L2 (publish with plain stores)
+    const int l2mode = persist_handshake(ex, gid, ubw, (H >> 4) / UW, tid, err);     // 1: this group shares one XCD's L2 (publish with plain stores)
     if (tid == 0) pub_step = 0;
     if (tid < 2) poll_fail[tid] = 0;                   // first read after the first barrier
     const bool stamp = ex.prof != nullptr && blockIdx.x == 0 && tid == ex.prof_tid;
@@ -1130,7 +1151,7 @@ struct Shape { int nc, rt, G, nrb, grid, active, slot_map; };
 // every scan of the level has the same H = 128 * NC (NC = 1..4: the k-chunks per wave are compile-time, so the gather
 // and the MFMA chain are straight-line code); RT = 1 when the 16-row grid fits one workgroup per CU, else 2
 template <typename D>
-bool level_shape(const D* d, int n, int B, Shape& sh) {
+bool level_shape(const D* d, int n, int B, Shape& sh, int uw = 1) {      // uw: 16-unit tiles per workgroup (the "wide" kernels: 2)
     const int maxh = d[0].H;
     if (maxh % 128 != 0 || maxh > 512) return false;
     for (int i = 1; i < n; ++i)
@@ -1138,7 +1159,9 @@ bool level_shape(const D* d, int n, int B, Shape& sh) {
     sh.nc = maxh / 128;
     sh.rt = 0;
     for (int rt = 1; rt <= 2; ++rt) {
-        const int nrb = cdiv(B, 16 * rt), G = n * nrb, active = G * (maxh / 16);
+        if (uw > 1 && rt > 1) break;
+        const int members = maxh / 16 / uw;
+        const int nrb = cdiv(B, 16 * rt), G = n * nrb, active = G * members;
         // launched: 8 XCD slots x ceil(G / 8) groups per slot x H / 16 members (persist_map); blocks of empty slots exit at once,
         // so what must fit the chip at one workgroup per CU is the ACTIVE count
         if (active <= device_cus()) {
@@ -1152,7 +1175,7 @@ bool level_shape(const D* d, int n, int B, Shape& sh) {
             constexpr int l2 = M3T_SCAN_L2_MODE;
             sh.rt = rt; sh.nrb = nrb; sh.G = G; sh.active = active;
             sh.slot_map = (l2 == 1 || (l2 == 2 && G % 8 == 0)) ? 1 : 0;
-            sh.grid = sh.slot_map ? 8 * cdiv(G, 8) * (maxh / 16) : active;
+            sh.grid = sh.slot_map ? 8 * cdiv(G, 8) * members : active;
             break;
         }
     }
@@ -1180,14 +1203,17 @@ BwdKernel pick_bwd(const Shape& sh) {
 // no GEMM workgroup fits beside one of its workgroups on a CU: co-resident GEMM waves take issue slots and LDS bandwidth
 // from a latency-bound scan (audio backward scan beside the weight-gradient GEMMs: 1.8 instead of 0.75 ms), and the
 // GEMMs have the other CUs.
+// Round 4: the limit is 192 workgroups -- a wide heavy launch (128) owns its CUs too, beside the audio launch (64) and the GEMMs (the rest);
+// `need`: dynamic LDS the kernel itself uses (the wide kernels' partial sums), granted whatever the grid.
 template <typename K>
-static size_t exclusive_lds(K kernel, int grid) {
-    if (grid > 96) return 0;
+static size_t exclusive_lds(K kernel, int grid, size_t need = 0) {
+    if (grid > 192 && need == 0) return 0;
     hipFuncAttributes a;
     if (hipFuncGetAttributes(&a, reinterpret_cast<const void*>(kernel)) != hipSuccess) { (void)hipGetLastError(); return 0; }
     const size_t want = (size_t)152 * 1024;
-    if (a.sharedSizeBytes >= want) return 0;
-    const size_t dyn = want - a.sharedSizeBytes;
+    if (a.sharedSizeBytes >= want && need == 0) return 0;
+    size_t dyn = grid > 192 ? need : (want > a.sharedSizeBytes ? want - a.sharedSizeBytes : 0);
+    if (dyn < need) dyn = need;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) {
         (void)hipGetLastError();
         return 0;
@@ -1450,9 +1476,26 @@ bool persist_bwd_uses_x6(const BwdGroup& g, int B, int T, int flags) {
     return sh.rt == 1 && (sh.nc == 2 || sh.nc == 4);
 }
 
+// M3T_SCAN_WIDE=0: keep one 16-unit tile per workgroup for the H = 512 levels in the fp16x3 mode (the round-3 geometry: 256 workgroups for
+// the encoder level) instead of the wide kernels (two tiles per workgroup, half the workgroups)
+static bool wide_enabled() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("M3T_SCAN_WIDE"); on = (e && e[0] == '0') ? 0 : 1; }
+    return on == 1;
+}
+static bool fwd_is_f16(const FwdGroup& g, int B, int T, int flags) {
+    return persist_fwd_uses_x6(g, B, T, flags) && !g.bf16 && (flags & M3T_GEMM_F16X3) && m3t_f16x3_enabled();
+}
+// unit tiles per workgroup of the level's forward launch
+static int fwd_uw(const FwdGroup& g, int B, int T, int flags, const Shape& sh) {
+    return ((flags & M3T_SCAN_WIDE) && fwd_is_f16(g, B, T, flags) && sh.nc == 4 && sh.rt == 1 && wide_enabled()) ? 2 : 1;
+}
+
 int persist_fwd_launch(const FwdGroup& g, const FragPtrs& fp, int B, int T, int flags, hipStream_t s) {
     Shape sh;
     if (!level_shape(g.d, g.n, B, sh) || !ensure_err_word()) return M3T_EINVAL;
+    const int uw = fwd_uw(g, B, T, flags, sh);
+    if (uw > 1 && !level_shape(g.d, g.n, B, sh, uw)) return M3T_EINVAL;
     ExPtrs ex;
     size_t bytes[M3T_MAX_SCANS];
     fill_exchange(g, fp, sh, 8, ex, bytes);
@@ -1495,6 +1538,12 @@ int persist_fwd_launch(const FwdGroup& g, const FragPtrs& fp, int B, int T, int 
         persist_record_start(s);
         if (f16) {
             if (sh.nc == 2) hipLaunchKernelGGL((gru_persist_fwd6_kernel<2, true>), dim3(sh.grid), dim3(NT), exclusive_lds(gru_persist_fwd6_kernel<2, true>, sh.active), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
+            else if (uw == 2) {
+                constexpr size_t need = (size_t)2 * NW * 2 * 3 * 16 * (UB + 1) * sizeof(float);       // the kernel's partial sums (RED_FLOATS)
+                const size_t dyn = exclusive_lds(gru_persist_fwd6_kernel<4, true, 2>, sh.active, need);
+                if (dyn < need) return M3T_EINVAL;
+                hipLaunchKernelGGL((gru_persist_fwd6_kernel<4, true, 2>), dim3(sh.grid), dim3(NT), dyn, s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
+            }
             else hipLaunchKernelGGL((gru_persist_fwd6_kernel<4, true>), dim3(sh.grid), dim3(NT), exclusive_lds(gru_persist_fwd6_kernel<4, true>, sh.active), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
         }
         else if (sh.nc == 2) hipLaunchKernelGGL(gru_persist_fwd6_kernel<2>, dim3(sh.grid), dim3(NT), exclusive_lds(gru_persist_fwd6_kernel<2>, sh.active), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
@@ -1533,6 +1582,11 @@ int persist_bwd_launch(const BwdGroup& g, const FragPtrs& fp, int B, int T, int 
     // fp32 mode with M3T_GEMM_F16X3: the producer-split kernel (two fp16 terms per value in the granule, 24-bit tags + the tile's exponent)
     const bool p3 = !b16 && persist_bwd_uses_x6(g, B, T, flags) && (flags & M3T_GEMM_F16X3) && m3t_f16x3_enabled() && bwd3p_enabled() &&
                     sh.nc == 4 && (unsigned long long)T + 1 < 0xffffffull;      // (H = 256: 2.40 -> 2.50 us per step, keeps the six-product kernel)
+    const int uw = ((flags & M3T_SCAN_WIDE) && p3 && sh.rt == 1 && wide_enabled()) ? 2 : 1;      // wide workgroups: two unit tiles each, half the grid
+    if (uw > 1) {
+        if (!level_shape(g.d, g.n, B, sh, uw)) return M3T_EINVAL;
+        ex.slot_map = sh.slot_map;
+    }
     { const int e = prepare_exchange(g, fp, sh, b16 ? 2 : 3, b16 ? 8 : 16, b16 ? 65535ull : (p3 ? 0xffffffull : 0xffffffffull), T, ex, s, p3 ? 1 : 0); if (e) return e; }
     ++g_launches;
     if (p3) {
@@ -1546,7 +1600,7 @@ int persist_bwd_launch(const BwdGroup& g, const FragPtrs& fp, int B, int T, int 
         M3T_LAUNCH_CHECK();
         { const int e = persist_take_after(s); if (e) return e; }
         persist_record_start(s);
-        const BwdKernel kk = sh.nc == 2 ? gru_persist_bwd3p_kernel<2> : gru_persist_bwd3p_kernel<4>;
+        const BwdKernel kk = uw == 2 ? gru_persist_bwd3p_kernel<4, 2> : (sh.nc == 2 ? gru_persist_bwd3p_kernel<2> : gru_persist_bwd3p_kernel<4>);
         hipLaunchKernelGGL(kk, dim3(sh.grid), dim3(NT), exclusive_lds(kk, sh.active), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
         persist_record_end(s);
         M3T_LAUNCH_CHECK();
@@ -1631,6 +1685,37 @@ int persist_profile(unsigned long long* out6) {
 }  // namespace m3t_gru
 
 extern "C" int m3t_gru_persist_count(void) { return m3t_gru::persist_launch_count(); }
+
+namespace m3t_gru {
+// what m3t_gru_scan_fwd / _bwd would hold resident for one persistent launch (include/m3t_hip.h: m3t_gru_scan_workgroups)
+int persist_workgroups(int n, int H, int B, int T, int flags, bool backward) {
+    if (n < 1 || n > M3T_MAX_SCANS || H < 1 || B < 1 || T < 2 || (flags & M3T_SCAN_NO_PERSIST) || !persist_enabled()) return 0;
+    Shape sh;
+    if (backward) {
+        BwdGroup g;
+        std::memset(&g, 0, sizeof(g));
+        g.n = n; g.bf16 = (flags & M3T_BF16) ? 1 : 0;
+        for (int i = 0; i < n; ++i) { g.d[i].H = H; g.d[i].gates = reinterpret_cast<const float*>(16); g.d[i].w_hh_t = reinterpret_cast<const float*>(16); }
+        if (solo_bwd_ok(g, B, T, flags) || !level_shape(g.d, g.n, B, sh)) return 0;
+        const bool b16 = persist_bwd_uses_16(g, B, T, flags);
+        const bool p3 = !b16 && persist_bwd_uses_x6(g, B, T, flags) && (flags & M3T_GEMM_F16X3) && m3t_f16x3_enabled() && bwd3p_enabled() &&
+                        sh.nc == 4 && (unsigned long long)T + 1 < 0xffffffull;
+        if ((flags & M3T_SCAN_WIDE) && p3 && sh.rt == 1 && wide_enabled() && !level_shape(g.d, g.n, B, sh, 2)) return 0;
+        return sh.active;
+    }
+    FwdGroup g;
+    std::memset(&g, 0, sizeof(g));
+    g.n = n; g.bf16 = (flags & M3T_BF16) ? 1 : 0;
+    for (int i = 0; i < n; ++i) { g.d[i].H = H; g.d[i].w_hh = reinterpret_cast<const float*>(16); }
+    if (solo_fwd_ok(g, B, T, flags) || !level_shape(g.d, g.n, B, sh)) return 0;
+    if (fwd_uw(g, B, T, flags, sh) == 2 && !level_shape(g.d, g.n, B, sh, 2)) return 0;
+    return sh.active;
+}
+}  // namespace m3t_gru
+
+extern "C" int m3t_gru_scan_workgroups(int n_scans, int H, int B, int T, int flags, int backward) {
+    return m3t_gru::persist_workgroups(n_scans, H, B, T, flags, backward != 0);
+}
 
 extern "C" int m3t_gru_poll_error(void) { return m3t_gru::persist_poll_error(); }
 

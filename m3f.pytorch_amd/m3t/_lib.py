@@ -18,6 +18,7 @@ M3T_GEMM_EXCLUSIVE = 8
 M3T_SCAN_FP32 = 4
 M3T_SCAN_WHH = 8
 M3T_SCAN_FAULT = 16
+M3T_SCAN_WIDE = 32        # room for a second persistent scan beside this one (include/m3t_hip.h)
 M3T_MAX_SCANS = 8
 
 _f = C.c_void_p      # device pointer
@@ -51,6 +52,7 @@ SIGNATURES = {
     "m3t_gru_scan_fwd": [C.POINTER(GruFwdDesc), _i, _i, _i, _f, _z, _i, _s],
     "m3t_gru_scan_bwd": [C.POINTER(GruBwdDesc), _i, _i, _i, _f, _z, _i, _s],
     "m3t_gru_persist_count": [],
+    "m3t_gru_scan_workgroups": [_i, _i, _i, _i, _i, _i],
     "m3t_gru_poll_error": [],
     "m3t_gru_error_reset": [],
     "m3t_gru_inject_error": [_s],

@@ -464,9 +464,10 @@ _FENCED = [False]     # set by the interleaved schedule of _MultiBiGRU: its side
 
 
 def _scan_flags(device):
-    """A persistent scan launch needs every workgroup resident, so two of them must never run concurrently on one
-    device: scans issued on the side stream take the launch-per-step path (include/m3t_hip.h, m3t_gru_scan_fwd) --
-    unless the caller fences them against every other scan with events (the interleaved schedule of _MultiBiGRU)."""
+    """A persistent scan launch needs every workgroup resident, so two of them may only run concurrently on one device when
+    BOTH grids fit the chip together: scans issued on the side stream take the launch-per-step path (include/m3t_hip.h,
+    m3t_gru_scan_fwd) -- unless the caller has checked that (the concurrent schedule of _MultiBiGRU, _pair_fits) or fences
+    them against every other scan with events (its alternating schedule)."""
     if SCAN_PER_STEP[0] or (_ws_tag(device) == "side" and not _FENCED[0]):
         return _lib.M3T_SCAN_NO_PERSIST
     return (_lib.M3T_SCAN_FP32 if SCAN_FP32[0] else 0) | (_lib.M3T_SCAN_FAULT if SCAN_FAULT[0] else 0)
@@ -587,6 +588,32 @@ def _interleaved(groups):
             and all(kind == "main" for kind, _ in groups))
 
 
+_CONCURRENT_ENABLED = os.environ.get("M3T_SCAN_CONCURRENT", "1") != "0"
+_CUS = {}
+
+
+def _pair_fits(dev, n_heavy, H_heavy, n_light, H_light, B, T, prec):
+    """Round 4: may the heavy level's persistent scan (asked to make room: M3T_SCAN_WIDE) and the light level's run AT THE SAME TIME?
+    Yes iff both grids fit the chip together, forward and backward, in total and per XCD (workgroups are dealt round-robin over the 8
+    XCDs and every scan workgroup owns its CU): then both become resident whatever is still draining from the CUs and neither waits
+    for the other (include/m3t_hip.h, m3t_gru_scan_workgroups).  C3: 4 x H=512 wide = 128 workgroups + 2 x H=256 = 64 of 256 CUs."""
+    if not _CONCURRENT_ENABLED:
+        return False
+    key = (dev.type, dev.index)
+    cus = _CUS.get(key)
+    if cus is None:
+        cus = _CUS[key] = torch.cuda.get_device_properties(dev).multi_processor_count
+    base = _scan_flags(dev) | prec
+    if base & _lib.M3T_SCAN_NO_PERSIST:
+        return False
+    for bwd in (0, 1):
+        a = lib().m3t_gru_scan_workgroups(n_heavy, H_heavy, B, T, base | _lib.M3T_SCAN_WIDE, bwd)
+        b = lib().m3t_gru_scan_workgroups(n_light, H_light, B, T, base, bwd)
+        if a <= 0 or b <= 0 or a + b > cus or (a + 7) // 8 + (b + 7) // 8 > cus // 8:
+            return False
+    return True
+
+
 class _MultiBiGRU(torch.autograd.Function):
     """Several independent stacked bidirectional GRUs (same B, T, depth) advanced together:
     per layer, one input-projection GEMM per direction, then ONE grouped scan over every
@@ -649,9 +676,9 @@ class _MultiBiGRU(torch.autograd.Function):
 
         alone = not _interleaved(groups) and all(kind == "main" for kind, _ in groups)   # nothing runs beside these GEMMs
 
-        def level_fwd(l, idxs, scan, after=None):
+        def level_fwd(l, idxs, scan, after=None, wide=False):
             """scan=False: the input projections of layer l for the stacks idxs; scan=True: their grouped scan (its scan
-            kernels fenced behind the event `after`)"""
+            kernels fenced behind the event `after`; wide: the launch leaves room for a second persistent scan)"""
             descs = []
             for s in idxs:
                 H = Hs[s]
@@ -667,9 +694,29 @@ class _MultiBiGRU(torch.autograd.Function):
                                                 _vp(gates[l][s], d * B * T * 4 * H), _vp(h_ns[s], (2 * l + d) * B * H),
                                                 H, d, 6 * H, d * 3 * H, outs[l][s].stride(1), d * H))
             if scan:
-                _scan_fwd(descs, B, T, prec, after)
+                _scan_fwd(descs, B, T, prec | (_lib.M3T_SCAN_WIDE if wide else 0), after)
 
-        if _interleaved(groups):
+        concurrent = (_interleaved(groups) and len({Hs[i] for i in groups[0][1]}) == 1 and len({Hs[i] for i in groups[1][1]}) == 1
+                      and _pair_fits(dev, 2 * len(groups[0][1]), Hs[groups[0][1][0]], 2 * len(groups[1][1]), Hs[groups[1][1][0]], B, T, prec))
+        if concurrent:
+            # round 4: the heavy level runs on half the CUs (wide workgroups) and the light stack's scans run AT THE SAME TIME on
+            # other CUs: two independent chains (projection -> scan -> projection -> scan), no fence between them; the rest of the
+            # chip takes their GEMMs.  Enqueue order = the order in which the GPU can start things.
+            heavy, light = groups[0][1], groups[1][1]
+            side = side_stream(dev)
+            side.wait_stream(main)
+            _FENCED[0] = True
+            try:
+                for l in range(L):
+                    level_fwd(l, heavy, False)
+                    with torch.cuda.stream(side):
+                        level_fwd(l, light, False)
+                        level_fwd(l, light, True)
+                    level_fwd(l, heavy, True, None, True)
+            finally:
+                _FENCED[0] = False
+            main.wait_stream(side)
+        elif _interleaved(groups):
             # heavy group on the main stream, light group on the side stream; persistent scans strictly alternate
             # (events), so the light scan of layer l runs beside the heavy input projections of layer l+1
             heavy, light = groups[0][1], groups[1][1]
@@ -727,6 +774,7 @@ class _MultiBiGRU(torch.autograd.Function):
                     main.wait_stream(side_stream(dev))
         del xprojs
         ctx.n_stacks, ctx.L, ctx.Hs, ctx.B, ctx.T, ctx.prec = n_stacks, L, Hs, B, T, prec
+        ctx.concurrent = concurrent
         ctx.cat = (cat_lo, cat_hi) if cat_buf is not None else (0, 0)
         saved = []
         for l in range(L):
@@ -821,7 +869,7 @@ class _MultiBiGRU(torch.autograd.Function):
         def fslot_w(l, s, d):
             return None if fslots is None else fslots.data_ptr() + 8 * (n_stacks + (l * n_stacks + s) * 2 + d)
 
-        def level_scan(l, idxs, after=None):
+        def level_scan(l, idxs, after=None, wide=False):
             descs = []
             for s in idxs:
                 H = Hs[s]
@@ -838,7 +886,7 @@ class _MultiBiGRU(torch.autograd.Function):
                                             _vp(dgx[l][s]), _vp(dgh[l][s], d * B * T * 3 * H), _vp(dh[l][s], d * B * H),
                                             _vp(dbp[l][s], d * B * 4 * H), _vp(out_grads[base + 2]), _vp(out_grads[base + 3]),
                                             H, d, out.stride(1), d * H, 6 * H, d * 3 * H, bslot(l, s, d)))      # (dout and out share the layout)
-            _scan_bwd(descs, B, T, prec | (_lib.M3T_SCAN_WHH if direct_whh else 0), after)
+            _scan_bwd(descs, B, T, prec | (_lib.M3T_SCAN_WHH if direct_whh else 0) | (_lib.M3T_SCAN_WIDE if wide else 0), after)
 
         def level_dx(l, idxs):           # on the chain: feeds the next level's scan
             for s in idxs:
@@ -921,7 +969,25 @@ class _MultiBiGRU(torch.autograd.Function):
                 w_.wait_event(ev)
             level_dw(l, idxs, spread=last)
 
-        if _interleaved(groups):
+        if ctx.concurrent and _interleaved(groups):
+            # as in forward (round 4): the heavy level on half the CUs, the light stack's scans at the same time on others; two
+            # independent chains scan -> data gradients -> scan, the weight gradients of both trail on their own streams
+            heavy, light = groups[0][1], groups[1][1]
+            side = side_stream(dev)
+            side.wait_stream(main)
+            _FENCED[0] = True
+            try:
+                for l in range(L - 1, -1, -1):
+                    level_scan(l, heavy, None, True)
+                    with torch.cuda.stream(side):
+                        level_scan(l, light)
+                    level_gemms(l, heavy, last=(l == 0))
+                    with torch.cuda.stream(side):
+                        level_gemms(l, light, last=(l == 0))
+            finally:
+                _FENCED[0] = False
+            main.wait_stream(side)
+        elif _interleaved(groups):
             # as in forward: the light group's backward scans run on the side stream beside the heavy group's GEMMs
             # (data gradients; the weight gradients of both groups trail on their own stream), persistent scans
             # strictly alternating

@@ -80,7 +80,7 @@ levels = {"enc (4x512+2x256)": [512, 512, 256], "fusion (2x512)": [512], "scorer
 print("B=%d T=%d" % (B, T))
 only = os.environ.get('ONLY')
 for name, Hs in levels.items():
-    if only and name != only:
+    if only and name not in only.split(","):
         continue
     d, k = fwd_group(Hs)
     tf = time_call(lib.m3t_gru_scan_fwd, d, GruFwdDesc)
