@@ -344,7 +344,8 @@ typedef _Float16 pf16x8 __attribute__((ext_vector_type(8)));
 // waves do cell math (waves 0-3 tile 0, waves 4-7 tile 1; the two tiles are adjacent in the exchange buffer, so the consumers' gather
 // code does not change) -- and a level needs HALF the workgroups: the 4 x H=512 encoder level runs on 128 CUs and leaves room for
 // the audio stack's 64-workgroup scans beside it.
-template <int NC, bool F16 = false, int UW = 1>
+// CO: the cell threads' HBM traffic in memory order through LDS, as in gru_persist_bwd3p_kernel (there: the comment on CO).
+template <int NC, bool F16 = false, int UW = 1, bool CO = false>
 __global__ __launch_bounds__(NT) void gru_persist_fwd6_kernel(FwdGroup g, FragPtrs fp, ExPtrs ex, int B, int T, int G, int nrb,
                                                               unsigned* err) {
     constexpr int ROWS = 16, KS = NC / 2, NTERM = F16 ? 2 : 3;
@@ -411,7 +412,23 @@ __global__ __launch_bounds__(NT) void gru_persist_fwd6_kernel(FwdGroup g, FragPt
     // (lanes past the batch and the step past the end re-read a valid address), defined by the next gather's vmcnt(0)
     // and laundered there -- as in the backward kernel below, compiler-visible loads made hipcc wait for them mid-step.
     float xrA, xzA, xnA, xrB, xzB, xnB;               // two register sets: even / odd steps (the loop body is included twice)
-    const float* xq = d.xproj + (size_t)(pb < B ? pb : B - 1) * T * d.ldx + d.xoff + pj;
+    // memory-side identity of this thread (CO; else = its cell) and the LDS slots of the hand-over, padded one per 16
+    const int hrow = CO ? (ti >> 4) : prow, hun = CO ? (ti & 15) : pu;
+    const int hb = r0 + hrow, hj = j0 + hun;
+    const bool hok = pw && hb < B;
+    const int hg = 64 * ((hun >> 1) & 3) + 2 * (hrow + 16 * (hun >> 3)) + (hun & 1);      // granule index of cell (hrow, hun)
+    constexpr int SLOTS = 272;
+    const int slot_h = tu * SLOTS + hg + (hg >> 4), slot_c = tu * SLOTS + ti + (ti >> 4);
+    f32x4* const sx = reinterpret_cast<f32x4*>(red_d + (UW == 1 ? 0 : RED_FLOATS));      // [parity][UW][SLOTS] (xr, xz, xn, -) of the step
+    f32x4* const so = sx + 2 * UW * SLOTS;                                                // [parity][UW][SLOTS] (r, z, n, W_hn h + b_hn)
+    float* const sh = reinterpret_cast<float*>(so + 2 * UW * SLOTS);                      // [parity][UW][SLOTS] h_t
+    const float* xq = d.xproj + (size_t)(hb < B ? hb : B - 1) * T * d.ldx + d.xoff + hj;
+    auto store_results = [&](int step_of, const f32x4& g4, float hv) {
+        const int t_ = d.reverse ? T - 1 - step_of : step_of;
+        d.out[((size_t)hb * T + t_) * d.ldo + d.ooff + hj] = hv;
+        if (d.gates) *reinterpret_cast<f32x4*>(d.gates + ((size_t)hb * T + t_) * 4 * H + 4 * (size_t)hj) = g4;
+        if (d.h_n && step_of == T - 1) d.h_n[(size_t)hb * H + hj] = hv;
+    };
 #define M3T_FWD_LOAD_X(step_, XR, XZ, XN)                                                                             \
     do {                                                                                                               \
         const int ls_ = (step_) < T ? (step_) : T - 1;                                                                 \
@@ -427,18 +444,22 @@ __global__ __launch_bounds__(NT) void gru_persist_fwd6_kernel(FwdGroup g, FragPt
 
     for (int step2 = 0; step2 < T; step2 += 2) {
 #define STEPV step2
+#define PARV 0
 #define CUR(x) x##A
 #define NXT(x) x##B
 #include "gru_persist_fwd6_step.inc"
 #undef STEPV
+#undef PARV
 #undef CUR
 #undef NXT
         if (step2 + 1 >= T) break;
 #define STEPV (step2 + 1)
+#define PARV 1
 #define CUR(x) x##B
 #define NXT(x) x##A
 #include "gru_persist_fwd6_step.inc"
 #undef STEPV
+#undef PARV
 #undef CUR
 #undef NXT
     }
@@ -447,6 +468,10 @@ __global__ __launch_bounds__(NT) void gru_persist_fwd6_kernel(FwdGroup g, FragPt
     // the last step's request for "the next step's inputs" is still in flight and invisible to hipcc (inline asm): a wave must
     // not end with a load outstanding into registers that the next wave on this SIMD is about to own
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (CO) {                                          // the last step's results are still in LDS
+        __syncthreads();
+        if (hok) store_results(T - 1, so[((T - 1) & 1) * UW * SLOTS + slot_h], sh[((T - 1) & 1) * UW * SLOTS + slot_h]);
+    }
     if (stamp)
         for (int i = 0; i < 6; ++i) ex.prof[i] = (unsigned long long)psum[i];
 }
@@ -970,7 +995,12 @@ __device__ __forceinline__ unsigned bwd3p_split(float xs) {          // the scal
 
 // UW = 16-unit tiles per workgroup (2 = the "wide" form, see gru_persist_fwd6_kernel: same gather per workgroup, the gathered operand
 // shared by both output tiles, all eight waves do cell math -- waves 0-3 tile 0, waves 4-7 tile 1 -- half the workgroups per level)
-template <int NC, int UW = 1>
+// CO (round 4): the cell threads' HBM traffic goes through threads numbered in MEMORY order -- thread ti of a tile loads / stores the
+// activations of cell (row ti >> 4, unit ti & 15), so a wave instruction covers 4 rows x 16 consecutive units (64-byte / 256-byte runs)
+// instead of 64 scattered sectors -- and LDS carries them to / from the cell-math threads (granule order).  In granule order every
+// load and store of a step was 64 separate memory requests per wave: 9 instructions x 8 waves x 64 = 4600 requests per CU and step
+// in the wide form against ~1000 lines for the gather itself, and the younger waves' stores queued for 1.4 us of a 5.2 us step.
+template <int NC, int UW = 1, bool CO = false>
 __global__ __launch_bounds__(NT) void gru_persist_bwd3p_kernel(BwdGroup g, FragPtrs fp, ExPtrs ex, int B, int T, int G, int nrb,
                                                              unsigned* err) {
     constexpr int RT = 1, ROWS = 16;
@@ -1039,10 +1069,23 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd3p_kernel(BwdGroup g, FragP
     // registers still in flight.  A set is defined by the vmcnt(0) of the gather that precedes its use and laundered there.
     float doutA, hprevA, doutB, hprevB;
     f32x4 g4A, g4B;                                    // (r, z, n, W_hn h + b_hn) of this (row, unit, t)
-    const int pbc = pb < B ? pb : B - 1;
-    const float* pd0 = d.dout + (size_t)pbc * T * d.ldo + d.ooff + pj;
-    const float* pg0 = d.gates + (size_t)pbc * T * 4 * H + 4 * (size_t)pj;
-    const float* ph0 = d.out + (size_t)pbc * T * d.ldo + d.ooff + pj;
+    // memory-side identity of this thread (CO; else = its cell): (hrow, hun) of its tile, LDS slots padded one per 16 (conflict-free on
+    // both sides): slot_h where it leaves what it loaded / finds what it stores, slot_c where the cell it computes finds / leaves them
+    const int ti = tid & 255;
+    const int hrow = CO ? (ti >> 4) : prow, hun = CO ? (ti & 15) : pu;
+    const int hb = r0 + hrow, hj = j0 + hun;
+    const bool hok = pw && hb < B;
+    const int hg = hrow + 16 * (hun >> 2) + 64 * (hun & 3);      // granule index of cell (hrow, hun)
+    constexpr int SLOTS = 272;
+    const int slot_h = tu * SLOTS + hg + (hg >> 4), slot_c = tu * SLOTS + ti + (ti >> 4);
+    extern __shared__ __attribute__((aligned(16))) unsigned char stage_raw[];
+    f32x4* const sin4 = reinterpret_cast<f32x4*>(stage_raw);                  // [parity][UW][SLOTS] gate records
+    f32x4* const sout = sin4 + 2 * UW * SLOTS;                                // [parity][UW][SLOTS] (dr~, dz~, dn~, dn~ r)
+    float2* const sin2 = reinterpret_cast<float2*>(sout + 2 * UW * SLOTS);    // [parity][UW][SLOTS] (dout, h_prev)
+    const int pbc = hb < B ? hb : B - 1;
+    const float* pd0 = d.dout + (size_t)pbc * T * d.ldo + d.ooff + hj;
+    const float* pg0 = d.gates + (size_t)pbc * T * 4 * H + 4 * (size_t)hj;
+    const float* ph0 = d.out + (size_t)pbc * T * d.ldo + d.ooff + hj;
 #define M3T_BWD_LOAD_STEP(step_, DOUT, G4, HPREV)                                                                     \
     do {                                                                                                               \
         const int ls_ = (step_) < T ? (step_) : T - 1;                                                                 \
@@ -1058,29 +1101,33 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd3p_kernel(BwdGroup g, FragP
     M3T_BWD_LOAD_STEP(0, doutA, g4A, hprevA);
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(doutA), "+v"(g4A), "+v"(hprevA) :: "memory");
     __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0), visible to hipcc: no wait for the weight fragments inside the loop
-    float st_dr = 0.f, st_dz = 0.f, st_dn = 0.f, st_dnr = 0.f;     // results of the previous step, stored after this step's gather
+    float st_dr = 0.f, st_dz = 0.f, st_dn = 0.f, st_dnr = 0.f;     // results of the step (CO: of the cell this thread stores for)
     auto store_results = [&](int step_of) {
         const int t = d.reverse ? step_of : T - 1 - step_of;
-        float* gx = d.dgx + ((size_t)pb * T + t) * d.ldg + d.goff;
-        gx[pj] = st_dr; gx[H + pj] = st_dz; gx[2 * H + pj] = st_dn;
-        float* gh = d.dgh + ((size_t)pb * T + t) * H3;
-        gh[pj] = st_dr; gh[H + pj] = st_dz; gh[2 * H + pj] = st_dnr;
+        float* gx = d.dgx + ((size_t)hb * T + t) * d.ldg + d.goff;
+        gx[hj] = st_dr; gx[H + hj] = st_dz; gx[2 * H + hj] = st_dn;
+        float* gh = d.dgh + ((size_t)hb * T + t) * H3;
+        gh[hj] = st_dr; gh[H + hj] = st_dz; gh[2 * H + hj] = st_dnr;
     };
 
     for (int step2 = 0; step2 < T; step2 += 2) {
 #define STEPV step2
+#define PARV 0
 #define CUR(x) x##A
 #define NXT(x) x##B
 #include "gru_persist_bwd3p_step.inc"
 #undef STEPV
+#undef PARV
 #undef CUR
 #undef NXT
         if (step2 + 1 >= T) break;
 #define STEPV (step2 + 1)
+#define PARV 1
 #define CUR(x) x##B
 #define NXT(x) x##A
 #include "gru_persist_bwd3p_step.inc"
 #undef STEPV
+#undef PARV
 #undef CUR
 #undef NXT
     }
@@ -1088,6 +1135,14 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd3p_kernel(BwdGroup g, FragP
     // the last step's request for "the next step's inputs" is still in flight and invisible to hipcc (inline asm): a wave must
     // not end with a load outstanding into registers that the next wave on this SIMD is about to own
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (CO) {                                          // the last step's results are still in LDS
+        __syncthreads();
+        if (hok) {
+            const f32x4 r4 = sout[((T - 1) & 1) * UW * SLOTS + slot_h];
+            st_dr = r4[0]; st_dz = r4[1]; st_dn = r4[2]; st_dnr = r4[3];
+            store_results(T - 1);
+        }
+    }
     if (pok) d.dh[(size_t)pb * H + pj] = dh_carry;
     if (pok && d.db_part) {
         float* q = d.db_part + (size_t)pb * 4 * H + pj;
@@ -1539,10 +1594,14 @@ int persist_fwd_launch(const FwdGroup& g, const FragPtrs& fp, int B, int T, int 
         if (f16) {
             if (sh.nc == 2) hipLaunchKernelGGL((gru_persist_fwd6_kernel<2, true>), dim3(sh.grid), dim3(NT), exclusive_lds(gru_persist_fwd6_kernel<2, true>, sh.active), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
             else if (uw == 2) {
-                constexpr size_t need = (size_t)2 * NW * 2 * 3 * 16 * (UB + 1) * sizeof(float);       // the kernel's partial sums (RED_FLOATS)
-                const size_t dyn = exclusive_lds(gru_persist_fwd6_kernel<4, true, 2>, sh.active, need);
+                // M3T_SCAN_COALESCE=0: the cell threads load / store their own cells (granule order: 64 scattered requests per instruction)
+                static const bool co = poll_env_early("M3T_SCAN_COALESCE", 1) != 0;
+                const size_t need = (size_t)2 * NW * 2 * 3 * 16 * (UB + 1) * sizeof(float)           // the kernel's partial sums (RED_FLOATS)
+                                    + (co ? (size_t)2 * 2 * 272 * 36 : 0);                           // + the staging slots (sx, so, sh)
+                const FwdKernel kk = co ? gru_persist_fwd6_kernel<4, true, 2, true> : gru_persist_fwd6_kernel<4, true, 2>;
+                const size_t dyn = exclusive_lds(kk, sh.active, need);
                 if (dyn < need) return M3T_EINVAL;
-                hipLaunchKernelGGL((gru_persist_fwd6_kernel<4, true, 2>), dim3(sh.grid), dim3(NT), dyn, s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
+                hipLaunchKernelGGL(kk, dim3(sh.grid), dim3(NT), dyn, s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
             }
             else hipLaunchKernelGGL((gru_persist_fwd6_kernel<4, true>), dim3(sh.grid), dim3(NT), exclusive_lds(gru_persist_fwd6_kernel<4, true>, sh.active), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
         }
@@ -1578,6 +1637,8 @@ int persist_bwd_launch(const BwdGroup& g, const FragPtrs& fp, int B, int T, int 
     {
         ex.poll_fixed = 12;
         ex.poll_align = 1;
+        static const int pb = poll_env_early("M3T_SCAN_POLL_BWD", -2);       // (experiments: -1 adaptive, >= 0 fixed)
+        if (pb >= -1) ex.poll_fixed = pb;
     }
     // fp32 mode with M3T_GEMM_F16X3: the producer-split kernel (two fp16 terms per value in the granule, 24-bit tags + the tile's exponent)
     const bool p3 = !b16 && persist_bwd_uses_x6(g, B, T, flags) && (flags & M3T_GEMM_F16X3) && m3t_f16x3_enabled() && bwd3p_enabled() &&
@@ -1600,8 +1661,14 @@ int persist_bwd_launch(const BwdGroup& g, const FragPtrs& fp, int B, int T, int 
         M3T_LAUNCH_CHECK();
         { const int e = persist_take_after(s); if (e) return e; }
         persist_record_start(s);
-        const BwdKernel kk = uw == 2 ? gru_persist_bwd3p_kernel<4, 2> : (sh.nc == 2 ? gru_persist_bwd3p_kernel<2> : gru_persist_bwd3p_kernel<4>);
-        hipLaunchKernelGGL(kk, dim3(sh.grid), dim3(NT), exclusive_lds(kk, sh.active), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
+        // M3T_SCAN_COALESCE=0: the cell threads load / store their own cells (granule order: 64 scattered requests per instruction)
+        static const bool co = poll_env_early("M3T_SCAN_COALESCE", 1) != 0;
+        const BwdKernel kk = uw == 2 ? (co ? gru_persist_bwd3p_kernel<4, 2, true> : gru_persist_bwd3p_kernel<4, 2>)
+                                     : (sh.nc == 2 ? gru_persist_bwd3p_kernel<2> : gru_persist_bwd3p_kernel<4>);      // (narrow: 3.42 us per step with the hand-over, 3.30 without: only four cell-math waves per CU)
+        const size_t need = (co && uw == 2) ? (size_t)uw * 2 * 272 * 40 : 0;         // the staging slots (sin4, sout, sin2)
+        const size_t dyn = exclusive_lds(kk, sh.active, need);
+        if (dyn < need) return M3T_EINVAL;
+        hipLaunchKernelGGL(kk, dim3(sh.grid), dim3(NT), dyn, s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
         persist_record_end(s);
         M3T_LAUNCH_CHECK();
         return 0;
