@@ -456,6 +456,10 @@ def worker(args):
         torch.cuda.synchronize()
 
     from m3t import _lib
+    if os.environ.get("M3T_BENCH_HIPRIO") == "1":      # (A/B: the step's own stream at high priority, the weight-gradient streams at normal)
+        hi = torch.cuda.Stream(priority=-1)
+        hi.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(hi)
     for _ in range(args.warmup):
         step()
     if os.environ.get("M3T_BENCH_INJECT_FAULT") == str(rank) and not (args.worker or 0):
@@ -502,7 +506,7 @@ def worker(args):
               file=sys.stderr, flush=True)
         print("# host per-step ms: " + " ".join("%.2f" % ((b - a) * 1e3) for a, b in zip([t0] + host_marks[:-1], host_marks)),
               file=sys.stderr, flush=True)
-    ops.poll_scan_error()                          # a scan that gave up would make the number meaningless: raise
+    ddp.agree_on_scan_error()                      # a scan that gave up (on any rank) would make the number meaningless: every rank raises
     persist_per_step = (_lib.load().m3t_gru_persist_count() - n_persist0) / max(1, args.steps)
     # N > 1: the gradient all-reduce alone (same buffer, same communicator), outside the timed region
     allreduce = None
@@ -536,10 +540,11 @@ def worker(args):
     # ---- roofline of the dominant kernel, from HIP events recorded on the launch stream in the timed region
     kern = {}
     for rec in ops.PROFILE:
-        k = kern.setdefault(rec["kernel"], {"ms": 0.0, "launches": 0, "flops": 0.0, "steps": 0})
+        k = kern.setdefault(rec["kernel"], {"ms": 0.0, "launches": 0, "flops": 0.0, "steps": 0, "bytes": 0.0})
         k["ms"] += rec["start"].elapsed_time(rec["end"])
         k["launches"] += rec["launches"]
         k["flops"] += rec["flops"]
+        k["bytes"] += rec.get("bytes", 0.0)
         k["steps"] += rec.get("steps", rec["launches"])
     step_ms = dt / args.steps * 1e3
     roofline, breakdown = None, {}
@@ -547,8 +552,15 @@ def worker(args):
         breakdown[name] = {"ms_per_step": round(k["ms"] / timed_steps, 3), "launches_per_step": k["launches"] // timed_steps,
                            "avg_launch_us": round(1e3 * k["ms"] / max(1, k["launches"]), 3),
                            "us_per_time_step": round(1e3 * k["ms"] / max(1, k["steps"]), 3)}
+        if k["bytes"] > 0:
+            # the small HBM-bound kernels north_star lists (att_fuse: reference models/att_fusion.py:21-25; va_loss: models/utils.py:6-17,
+            # models/model.py:132-141): ALGORITHMIC bytes / HIP-event time in the step, against the 8 TB/s HBM peak
+            gbps = k["bytes"] / (k["ms"] * 1e-3) / 1e9
+            breakdown[name].pop("us_per_time_step")
+            breakdown[name].update({"bound": "hbm", "algorithmic_bytes_per_step": int(k["bytes"] / timed_steps), "GBps": round(gbps, 1),
+                                    "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBS, 4)})
     if kern:
-        name = max(kern, key=lambda n: kern[n]["ms"])
+        name = max((n for n in kern if kern[n]["flops"] > 0), key=lambda n: kern[n]["ms"])
         k = kern[name]
         achieved = k["flops"] / (k["ms"] * 1e-3) / 1e12
         traffic, traffic_by_kernel, mfma_util, pmc_source = None, None, None, None

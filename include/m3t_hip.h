@@ -215,6 +215,12 @@ int m3t_gru_persist_count(void);
 int m3t_gru_poll_error(void);
 /* Clears the scan error state.  ONLY after the device has been synchronised (nothing queued may still read the flag). */
 int m3t_gru_error_reset(void);
+/* Several ranks (m3t.ddp): on = 1 makes m3t_gru_scan_fwd / _bwd launch even while the sticky flag is set instead of returning
+ * M3T_ESPIN.  A rank that raised in the middle of a step -- the moment ITS host happened to see the flag -- would leave its peers
+ * waiting in that step's collective; the device-side guards (m3t_grad_norm_scale, the optimizer steps) skip every step queued behind
+ * the dead scan anyway, m3t_grad_poison / m3t_grad_dead_check carry the failure to every rank through the all-reduce, and the host
+ * raises on ALL ranks at the same step from the all-reduced dead slot.  m3t_gru_poll_error() is unaffected.  Returns 0. */
+int m3t_gru_error_defer(int on);
 /* Fault injection (tests): a one-thread kernel on `stream` raises the scan error flag exactly as a dying scan would. */
 int m3t_gru_inject_error(void* stream);
 /* Who owns the persistent scans of the current device: 0 not decided yet (no persistent scan attempted), 1 this process,

@@ -626,7 +626,7 @@ extern "C" int m3t_gru_scan_fwd(const m3t_gru_fwd_desc* scans, int n_scans, int 
                                 int flags, void* stream) {
     AfterGuard after_guard;      // a pending m3t_gru_scan_after event never outlives this call
     if (n_scans <= 0 || B <= 0 || T <= 0) return 0;
-    if (persist_poll_error()) return M3T_ESPIN;
+    if (!persist_deferred() && persist_poll_error()) return M3T_ESPIN;
     if (n_scans > M3T_MAX_SCANS || !scans) return M3T_EINVAL;
     FwdGroup g;
     std::memset(&g, 0, sizeof(g));
@@ -723,7 +723,7 @@ static int scan_bwd_impl(const m3t_gru_bwd_desc* scans, int n_scans, int B, int 
                          void* stream, bool* amax_done) {
     AfterGuard after_guard;
     if (n_scans <= 0 || B <= 0 || T <= 0) return 0;
-    if (persist_poll_error()) return M3T_ESPIN;
+    if (!persist_deferred() && persist_poll_error()) return M3T_ESPIN;
     if (n_scans > M3T_MAX_SCANS || !scans) return M3T_EINVAL;
     BwdGroup g;
     std::memset(&g, 0, sizeof(g));

@@ -95,6 +95,8 @@ void persist_forget_arena(void* arena);
 struct AfterGuard { ~AfterGuard() { persist_drop_after(); persist_drop_events(); persist_drop_arena(); } };
 int persist_poll_error();       // step+1 of a scan that hit its spin limit since the last persist_reset_error(), else 0 (sticky)
 void persist_reset_error();     // clears the error words; only after the device has been synchronised
+void persist_set_defer(int on); // m3t_gru_error_defer: scan calls do not return M3T_ESPIN behind a dead scan (several ranks: raise at an agreed point)
+bool persist_deferred();
 int persist_inject_error(hipStream_t s);      // fault injection: raises the error words from a kernel, in stream order
 unsigned* persist_error_word_dev(bool create = false);   // device address of the STICKY flag word (host-mapped), or nullptr before the first persistent scan
 int persist_owner_state();      // 0 not decided yet, 1 this process owns the device's persistent scans, 2 another process does

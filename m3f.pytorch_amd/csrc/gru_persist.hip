@@ -1401,6 +1401,14 @@ int persist_poll_error() {
     return (int)(step1 ? step1 : 1u);
 }
 
+// Deferred mode (m3t_gru_error_defer): with several ranks a failure must be raised at a point ALL ranks agree on -- a rank that
+// raises mid-step (a scan call returning M3T_ESPIN the moment its own host sees the flag) leaves its peers waiting in the
+// step's collective.  While deferred, scan calls do not refuse to launch behind a dead scan (the device-side guards still
+// skip every step queued behind it); the host learns of the failure from the all-reduced dead slot (m3t.ddp).
+static int g_defer = 0;
+void persist_set_defer(int on) { g_defer = on ? 1 : 0; }
+bool persist_deferred() { return g_defer != 0; }
+
 // the caller has synchronised the device: nothing queued can still read or write the words
 void persist_reset_error() {
     if (!g_err_host) return;
@@ -1787,6 +1795,8 @@ extern "C" int m3t_gru_scan_workgroups(int n_scans, int H, int B, int T, int fla
 extern "C" int m3t_gru_poll_error(void) { return m3t_gru::persist_poll_error(); }
 
 extern "C" int m3t_gru_error_reset(void) { m3t_gru::persist_reset_error(); return 0; }
+
+extern "C" int m3t_gru_error_defer(int on) { m3t_gru::persist_set_defer(on); return 0; }
 
 extern "C" int m3t_gru_inject_error(void* stream) { return m3t_gru::persist_inject_error((hipStream_t)stream); }
 

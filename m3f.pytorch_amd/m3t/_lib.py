@@ -55,6 +55,7 @@ SIGNATURES = {
     "m3t_gru_scan_workgroups": [_i, _i, _i, _i, _i, _i],
     "m3t_gru_poll_error": [],
     "m3t_gru_error_reset": [],
+    "m3t_gru_error_defer": [_i],
     "m3t_gru_inject_error": [_s],
     "m3t_gru_persist_owner": [],
     "m3t_gru_scan_arena": [C.c_void_p, _z],

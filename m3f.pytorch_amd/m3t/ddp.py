@@ -18,8 +18,13 @@ other collective on the path (no SyncBN, as the reference).
 
 A dead persistent scan on ONE rank stops EVERY rank: the buffer carries one extra slot (`dead`) through the same
 all-reduce; m3t_grad_poison sets it (and NaN in flat[0]) before the collective when this rank's sticky scan-error flag is
-up, m3t_grad_dead_check raises the flag on every rank after it, so every rank's finalize zeroes its gradients, every fused
-optimizer step skips itself and every rank's next poll raises (include/m3t_hip.h, error model).
+up, m3t_grad_dead_check raises the flag on every rank after it, so every rank's finalize zeroes its gradients and every fused
+optimizer step skips itself (include/m3t_hip.h, error model).  The HOST side is rank-agreed too (round 4): with
+world > 1 nothing raises from a scan call or a bare poll (each rank's host sees its flag at a different point, and a rank
+that raised mid-step would leave its peers in the step's collective); instead every finish() copies the ALL-REDUCED dead slot
+to pinned host memory, and the next finish() -- before it issues its own collective -- reads it: the value is the same on every
+rank, so every rank raises at the same step, with no collective of that step issued.  Points every rank reaches anyway
+(validation, checkpoints, the end of fit) use agree_on_scan_error(): one small host-synchronous all-reduce of the local flags.
 """
 import os
 import torch
@@ -119,6 +124,14 @@ class FlatGradDDP:
             finalize = ops.grad_norm_scale_
         self._finalize = finalize
         self.last_norm = None
+        # rank-agreed failure (module docstring): the all-reduced dead slot of the last finish() on its way to the host
+        self._agreed = (self.world > 1 or self._alone_collective) and dev.type == "cuda"
+        self._dead_host = self._dead_ev = None
+        self._dead_pending = False
+        if self._agreed:
+            ops.defer_scan_errors(True)
+            self._dead_host = torch.zeros(1, dtype=torch.float32).pin_memory()
+            self._dead_ev = torch.cuda.Event()
         self.ar_events = None          # bench.py: a list here collects (start, end) HIP events around the in-step all-reduce
         # gradient sinks (m3t.ops): backward writes weight gradients straight into the flat buffer instead of handing
         # them to autograd's AccumulateGrad.  Not with overlap=True: the bucket all-reduces hang on post-accumulate hooks.
@@ -134,6 +147,12 @@ class FlatGradDDP:
         """drop this instance's gradient sinks (the parameters keep their .grad views)"""
         from . import ops
         ops.clear_grad_sinks(self)
+        if getattr(self, "_agreed", False):
+            self._agreed = False
+            try:
+                ops.defer_scan_errors(False)
+            except Exception:  # noqa: BLE001  (library already gone at interpreter shutdown)
+                pass
 
     def __del__(self):
         try:
@@ -165,9 +184,46 @@ class FlatGradDDP:
         self._left = [len(b) for b in self.buckets]
         self._handles = []
 
+    def _raise_agreed(self, why):
+        from . import _lib
+        for h in self._handles:                  # (overlap: every rank issued the same bucket collectives during backward)
+            h.wait()
+        self._handles = []
+        self._dead_pending = False
+        _lib._recover_scan_error()               # synchronise the device, then clear the sticky state
+        raise _lib.M3THipError("a persistent GRU scan gave up waiting for a peer workgroup on at least one rank (M3T_ESPIN, %s): "
+                               "its gradients were discarded and every optimizer step queued behind it was skipped on every rank; "
+                               "all ranks raise here, at the same step" % why)
+
+    def _check_agreed(self):
+        """the previous finish()'s all-reduced dead slot: non-zero on every rank or on none"""
+        if self._dead_pending:
+            self._dead_ev.synchronize()          # a step old: no wait on the healthy path
+            self._dead_pending = False
+            if float(self._dead_host[0]) != 0.0:
+                self._raise_agreed("reported by the gradient all-reduce of the previous step")
+
+    def agree_on_scan_error(self):
+        """A point every rank reaches (validation, checkpoint, end of fit): wait for the device, all-reduce the local scan error
+        flags (host-synchronous), raise on every rank if any rank's is up.  One rank: an ordinary synchronised poll."""
+        from . import ops, _lib
+        if not self._agreed or self.world <= 1:
+            ops.poll_scan_error(sync=True, force=True)
+            return
+        torch.cuda.synchronize()
+        self._dead_pending = False
+        t = torch.tensor([1.0 if _lib.load().m3t_gru_poll_error() else 0.0], dtype=torch.float32)
+        if dist.get_backend(self.pg) == "nccl":
+            t = t.to(self.flat.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg)
+        if float(t.item()) != 0.0:
+            self._raise_agreed("agreed on by all ranks at a synchronisation point")
+
     def finish(self):
         """Call after backward: waits for the bucket all-reduces, then averages + clips in place."""
         from . import ops
+        if self._agreed:
+            self._check_agreed()                  # BEFORE this step's collective: either every rank raises here or none does
         ops.join_wgrad(self.flat.device)          # weight-gradient GEMMs that write straight into the flat buffer
         hip = self.flat.is_cuda
         timed = self.ar_events is not None and hip
@@ -193,6 +249,10 @@ class FlatGradDDP:
             dist.all_reduce(self._buf[self.flat.numel():], op=dist.ReduceOp.SUM, group=self.pg)
         if self.world > 1 and hip:
             ops.grad_dead_check_(self.dead)                 # any rank dead -> this rank's flag up: finalize zeroes, norm = NaN
+        if self._agreed:
+            self._dead_host.copy_(self.dead, non_blocking=True)      # the all-reduced slot: the same value on every rank
+            self._dead_ev.record()
+            self._dead_pending = True
         if timed:
             ev1.record()
             self.ar_events.append((ev0, ev1))
@@ -200,6 +260,7 @@ class FlatGradDDP:
         # a persistent GRU scan that died leaves garbage gradients.  Two nets: the finalize kernel reads the scan error
         # word on the device, in stream order (gradients zeroed, norm = NaN, the fused optimizer steps skip on a
         # non-finite norm) -- and this poll of the same word raises as soon as the failure is visible to the host
-        # (no synchronisation here: at the latest on the next step's finish()).
+        # (no synchronisation here: at the latest on the next step's finish()).  Several ranks: silent here -- the next
+        # finish() raises on every rank from the all-reduced slot (_check_agreed).
         ops.poll_scan_error()
         return self.last_norm

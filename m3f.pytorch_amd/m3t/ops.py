@@ -80,11 +80,12 @@ class _Timed:
     """HIP-event timing of a launch on the current stream (bench.py).  kernel_side=True: the events are handed to the C
     call (m3t_gru_scan_events), which records them right around its scan kernel(s) instead of around the whole call."""
 
-    def __init__(self, kernel, launches, flops, kernel_side=False):
+    def __init__(self, kernel, launches, flops, kernel_side=False, nbytes=0):
+        """nbytes: algorithmic HBM bytes of an HBM-bound launch (bench.py reports bytes / time against the HBM peak)"""
         self.rec = None
         self.kernel_side = kernel_side
         if PROFILE_ON[0]:
-            self.rec = {"kernel": kernel, "launches": launches, "flops": float(flops),
+            self.rec = {"kernel": kernel, "launches": launches, "flops": float(flops), "bytes": float(nbytes),
                         "start": torch.cuda.Event(enable_timing=True), "end": torch.cuda.Event(enable_timing=True)}
 
     def __enter__(self):
@@ -147,6 +148,8 @@ def _p(t, off=0):
 #     are done, and are joined in FlatGradDDP.finish() when every gradient went into a gradient sink.  Two streams; the second
 #     one takes half of the LAST level's GEMMs only (the tail of backward, when no scan and no data gradient is left).
 _SIDE = {}
+_BESIDE_FLAG = os.environ.get("M3T_GEMM_BESIDE", "1") != "0"        # (A/B: GEMMs beside scans on the software-pipelined kernel too)
+_SIDE_PRIO = int(os.environ.get("M3T_SIDE_PRIO", "0"))               # (A/B: stream priority of the side stream; -1 = high)
 _PERSIST_ENABLED = os.environ.get("M3T_SCAN_PERSIST", "1") != "0"
 _WGRAD = {}
 _N_WGRAD = 2
@@ -156,7 +159,7 @@ def side_stream(device):
     key = (device.type, device.index)
     st = _SIDE.get(key)
     if st is None:
-        st = torch.cuda.Stream(device=device)
+        st = torch.cuda.Stream(device=device, priority=_SIDE_PRIO)
         _SIDE[key] = st
         _ROLE_OF_HANDLE[(st.device.index, st.cuda_stream)] = "side"
     return st
@@ -257,7 +260,7 @@ def sgemm(transA, transB, M, N, K, A, a_off, lda, B, b_off, ldb, Cm, c_off, ldc,
     measure_amax below, or a backward scan's); None: the library measures that operand itself (one more launch)"""
     ws = workspace(Cm.device) if use_ws else None
     flags = (_PREC[0] if prec is None else prec) | (_lib.M3T_GEMM_EXCLUSIVE if exclusive else 0)
-    if _FENCED[0]:
+    if _FENCED[0] and _BESIDE_FLAG:
         flags |= _lib.M3T_GEMM_BESIDE_SCAN       # issued inside the interleaved schedule of _MultiBiGRU: scans of another stream run beside it
     with _Timed("sgemm_kernel", 1, 2.0 * M * N * K) if PROFILE_GEMM[0] else _NULL:
         rc = lib().m3t_sgemm_scaled(transA, transB, M, N, K, _p(A, a_off), lda, _p(B, b_off), ldb, _p(Cm, c_off), ldc,
@@ -473,10 +476,26 @@ def _scan_flags(device):
     return (_lib.M3T_SCAN_FP32 if SCAN_FP32[0] else 0) | (_lib.M3T_SCAN_FAULT if SCAN_FAULT[0] else 0)
 
 
-def poll_scan_error(sync=False):
+_DEFERRED = [False]      # several ranks: failures are raised only at points all ranks agree on (FlatGradDDP)
+
+
+def defer_scan_errors(on=True):
+    """Several ranks (FlatGradDDP with world > 1 calls this): a rank must not raise the moment ITS host sees the scan error flag --
+    mid-step, from a scan call or a poll -- because its peers would then wait forever in the step's collective.  While deferred,
+    scan calls launch behind a dead scan (the device-side guards skip every such step), poll_scan_error() is silent, and the
+    failure is raised on ALL ranks at the same step from the all-reduced dead slot (FlatGradDDP.finish) or by
+    FlatGradDDP.agree_on_scan_error() at points every rank reaches (validation, checkpoints, the end of fit)."""
+    _DEFERRED[0] = bool(on)
+    _lib.check(lib().m3t_gru_error_defer(1 if on else 0), "m3t_gru_error_defer")
+
+
+def poll_scan_error(sync=False, force=False):
     """raise M3THipError if a persistent scan has died (sync=True: wait for the device first, so the answer covers everything
     issued so far).  The error state is sticky on the device (every optimizer step queued behind the dead scan skips itself,
-    include/m3t_hip.h); raising synchronises and clears it, so the caller can redo the step."""
+    include/m3t_hip.h); raising synchronises and clears it, so the caller can redo the step.  Silent while failures are
+    deferred to rank-agreed points (defer_scan_errors) unless force=True."""
+    if _DEFERRED[0] and not force:
+        return
     if sync and torch.cuda.is_available():
         torch.cuda.synchronize()
     _lib.poll_scan_error()
@@ -1095,7 +1114,9 @@ class _AttFuse(torch.autograd.Function):
         if x_a.shape != x_v.shape or s_v.numel() != rows or s_a.numel() != rows:
             raise M3THipError("att_fuse: shape mismatch")
         f = torch.empty_like(x_v)
-        _lib.check(lib().m3t_att_fuse_fwd(_p(s_v), _p(s_a), _p(x_v), _p(x_a), _p(f), rows, D, _stream()), "m3t_att_fuse_fwd")
+        # algorithmic traffic: read x_v, x_a, write f -- 3 D floats per frame (+ the two scores)
+        with _Timed("att_fuse_fwd_kernel", 1, 0, nbytes=4.0 * rows * (3 * D + 2)):
+            _lib.check(lib().m3t_att_fuse_fwd(_p(s_v), _p(s_a), _p(x_v), _p(x_a), _p(f), rows, D, _stream()), "m3t_att_fuse_fwd")
         ctx.save_for_backward(s_v, s_a, x_v, x_a)
         return f
 
@@ -1107,8 +1128,10 @@ class _AttFuse(torch.autograd.Function):
         rows = x_v.numel() // D
         ds_v, ds_a = torch.empty_like(s_v), torch.empty_like(s_a)
         dx_v, dx_a = torch.empty_like(x_v), torch.empty_like(x_a)
-        _lib.check(lib().m3t_att_fuse_bwd(_p(df), _p(s_v), _p(s_a), _p(x_v), _p(x_a), _p(ds_v), _p(ds_a), _p(dx_v),
-                                          _p(dx_a), rows, D, _stream()), "m3t_att_fuse_bwd")
+        # read df, x_v, x_a, write dx_v, dx_a: 5 D floats per frame (+ scores and their gradients)
+        with _Timed("att_fuse_bwd_kernel", 1, 0, nbytes=4.0 * rows * (5 * D + 4)):
+            _lib.check(lib().m3t_att_fuse_bwd(_p(df), _p(s_v), _p(s_a), _p(x_v), _p(x_a), _p(ds_v), _p(ds_a), _p(dx_v),
+                                              _p(dx_a), rows, D, _stream()), "m3t_att_fuse_bwd")
         return ds_v, ds_a, dx_v, dx_a
 
 
@@ -1134,10 +1157,12 @@ class _VALoss(torch.autograd.Function):
         stats = torch.empty(8, dtype=torch.float32, device=y.device)
         dy = torch.empty_like(y)
         ws = workspace(y.device)
-        rc = lib().m3t_va_loss(_p(y), rows, Cc, iv, ia, _p(val), _p(aro),
-                               C.c_void_p(cls.data_ptr()) if cls is not None else None,
-                               C.c_void_p(vld.data_ptr()) if vld is not None else None,
-                               n_expr, w_v, w_a, expr_w, int(use_mse), _p(stats), _p(dy), _p(ws), ws.numel() * 4, _stream())
+        # three sweeps over y [rows, C] (sums, centred moments, gradient) + the labels each time + one write of dy
+        with _Timed("va_loss_kernels", 3, 0, nbytes=4.0 * rows * (3 * Cc + 3 * 2 + Cc) + (3.0 * rows * 9 if n_expr > 0 else 0.0)):
+            rc = lib().m3t_va_loss(_p(y), rows, Cc, iv, ia, _p(val), _p(aro),
+                                   C.c_void_p(cls.data_ptr()) if cls is not None else None,
+                                   C.c_void_p(vld.data_ptr()) if vld is not None else None,
+                                   n_expr, w_v, w_a, expr_w, int(use_mse), _p(stats), _p(dy), _p(ws), ws.numel() * 4, _stream())
         _lib.check(rc, "m3t_va_loss")
         ctx.save_for_backward(dy)
         ctx.mark_non_differentiable(stats)

@@ -117,7 +117,7 @@ class Trainer:
         """the module's own validation_step / validation_end over `batches`; returns validation_end's dict"""
         self.model.eval()
         outputs = [self.model.validation_step(b, i) for i, b in enumerate(batches)]
-        ops.poll_scan_error(sync=True)               # eval forwards end here: nothing else would report a dead scan
+        self.ddp.agree_on_scan_error()               # eval forwards end here: nothing else would report a dead scan (every rank raises or none)
         res = self.model.validation_end(outputs)
         return res
 
@@ -181,7 +181,7 @@ class Trainer:
             self.end_epoch(val_loss)
             if max_steps is not None and done >= max_steps:
                 break
-        ops.poll_scan_error(sync=True)
+        self.ddp.agree_on_scan_error()
         return history
 
     # ------------------------------------------------------------------ checkpoints
@@ -189,7 +189,7 @@ class Trainer:
         """Rank 0 writes (to a temporary file, then os.replace: a reader never sees a torn file); the other ranks wait at a
         barrier so that none of them runs ahead into a load of a checkpoint that is still being written.  Every rank polls
         the scan error state first: parameters behind an unreported dead scan are never persisted."""
-        ops.poll_scan_error(sync=True)
+        self.ddp.agree_on_scan_error()
         if self.rank == 0:
             opt_state = {"t": self.opt.t}
             for k in ("m", "v", "buf"):

@@ -302,6 +302,72 @@ def test_one_ranks_dead_scan_stops_every_rank(tmp_path, overlap):
     assert np.array_equal(np.load(out + ".0.npy"), np.load(out + ".1.npy")), "replicas diverged after the fault"
 
 
+_AGREED_CHILD = r"""
+import os, sys, time
+for p in (%r, %r, %r):
+    sys.path.insert(0, p)
+import numpy as np, torch, torch.distributed as dist
+from golden.recipe import fill_module
+from m3t.ddp import FlatGradDDP, shard_indices
+from m3t.optim import FlatAdam
+from m3t import ops, _lib
+from models.rnn import GRU
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+net = fill_module(GRU(12, 16, 2, 3, 2), 5).to("cuda:0")
+ddp = FlatGradDDP(net, max_norm=1.0, overlap=False, flatten_params=True)
+opt = FlatAdam(ddp, lr=1e-2)
+rs = np.random.RandomState(3)
+x = torch.from_numpy(rs.standard_normal((8, 9, 12)).astype(np.float32)).to("cuda:0")
+t = torch.from_numpy(rs.standard_normal((8, 9, 3)).astype(np.float32)).to("cuda:0")
+idx = shard_indices(8, rank, world)
+raised_at, where = None, None
+for k in range(6):
+    try:
+        ddp.zero_grad()
+        if k == 2 and rank == 1:
+            ops.inject_scan_error()          # a scan of THIS rank dies at the start of step 2 ...
+            torch.cuda.synchronize()         # ... and this rank's HOST sees the flag at once, in the middle of the step
+        if rank == 0:
+            time.sleep(0.05 * (k %% 2))      # (the ranks' hosts are never in lockstep)
+        where = "scans"
+        loss = ((net(x[idx]) - t[idx]) ** 2).mean()      # scan calls behind the dead scan: must NOT raise on rank 1 alone
+        loss.backward()
+        where = "finish"
+        ddp.finish()
+        opt.step()
+    except _lib.M3THipError:
+        assert raised_at is None
+        raised_at = (k, where)
+print("RANK %%d raised_at=%%s" %% (rank, raised_at), flush=True)
+ddp.agree_on_scan_error()                    # clean again on every rank
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.gpu
+def test_dead_scan_is_raised_at_the_same_step_on_every_rank(tmp_path):
+    """the scan error flag is host-mapped and every rank's host sees it at a different point.  Raised from wherever
+    a host happens to notice it (a scan call returning M3T_ESPIN mid-step), the failing rank leaves the step without issuing the
+    step's collective and its peers wait there forever.  With several ranks nothing raises mid-step any more
+    (m3t_gru_error_defer); the all-reduced dead slot of step k is read by every rank at the start of finish() of step k + 1, before
+    that step's collective: both ranks raise at step 3, in finish(), although rank 1's host knew in the middle of step 2."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "child.py"
+    script.write_text(_AGREED_CHILD % (os.path.join(root, "m3f.pytorch_amd"), os.path.join(root, "tests"), root))
+    env = dict(os.environ, M3T_SCAN_PERSIST="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29537", str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-2500:])
+    assert "RANK 0 raised_at=(3, 'finish')" in r.stdout and "RANK 1 raised_at=(3, 'finish')" in r.stdout, r.stdout[-800:]
+
+
 def test_rccl_allreduce_in_stream_order_between_persistent_scans():
     """The 8-GPU default is persistent scans + RCCL (backend 'nccl') + ONE all-reduce after backward.  A 1-GPU box cannot
     host two RCCL ranks, but it can run that exact sequence in a 1-rank RCCL group: the real ncclAllReduce kernel on the
