@@ -530,7 +530,9 @@ def worker(args):
                      "ms_in_step_note": "HIP events on the step's stream around poison kernel + collective(s) + dead-rank check, profiled steps only; "
                                         "`ms` is the same collective back to back after the timed region", "algbw_GBps": round(algbw, 2),
                      "busbw_GBps": round(algbw * 2 * (world - 1) / world, 2), "world_size": dist.get_world_size(),
-                     "schedule": "one all-reduce of the flat buffer after backward" if not ddp.overlap else "3 buckets overlapped with backward",
+                     "schedule": ("bucket 0 (fusion GRU) early on a communication stream beside backward, the rest + dead slot after backward (M3T_DDP_EARLY_BUCKET=1)"
+                                  if getattr(ddp, "_early", False) else
+                                  "one all-reduce of the flat buffer after backward" if not ddp.overlap else "3 buckets overlapped with backward"),
                      "xgmi_peak_GBps": 7 * 153.0}
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)

@@ -4,6 +4,8 @@ These are the reference's own graphs with the conv towers replaced by pre-comput
 features -- exactly what BASELINE.json's configs describe ("precomputed 256-d SENet feats",
 "256-d video + 128-d audio").  Attribute names follow AffWild2VA so state_dict keys line up.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -77,6 +79,16 @@ def make_c3_step(model, batch, max_norm=1.0, **ddp_kw):
     expr_valid (device tensors).  step() returns (loss, stats, y)."""
     from .ddp import FlatGradDDP
     ddp = FlatGradDDP(model, bucket_order=c3_bucket_order(model), max_norm=max_norm, **ddp_kw)
+    if os.environ.get("M3T_DDP_EARLY_BUCKET") == "1" and ddp.world > 1:
+        # opt-in A/B for the first multi-GPU run: the fusion GRU's gradients are all-reduced beside the rest of backward.  What may
+        # be resident at once in that window: the encoder level's wide launch + the audio launch (scorers: no residency requirement)
+        from . import _lib
+        B, T = batch["x_a"].shape[0], batch["x_a"].shape[1]
+        fl = _lib.M3T_GEMM_F16X3
+        wgs = (_lib.load().m3t_gru_scan_workgroups(4, 512, B, T, fl | _lib.M3T_SCAN_WIDE, 1) +
+               _lib.load().m3t_gru_scan_workgroups(2, 256, B, T, fl, 1))
+        n_cus = torch.cuda.get_device_properties(batch["x_a"].device).multi_processor_count
+        ddp.early_bucket_after(model.fusion, wgs, n_cus)
 
     def step():
         ddp.zero_grad()

@@ -100,6 +100,15 @@ def test_bench_two_ranks_on_one_gpu_gloo():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["value"] > 0
     assert d["cpu_baseline"] is None and d["scaling"] == "weak"
+    assert d["allreduce"]["world_size"] == 2 and d["allreduce"]["ms_in_step"] is not None and "fallback" not in d
+    # opt-in early bucket (M3T_DDP_EARLY_BUCKET=1: the fusion GRU's gradients all-reduced on a communication stream beside the rest
+    # of backward, the rest + dead slot after it): same gradients, same loss
+    cmd2 = ["29532" if c == "29531" else c for c in cmd]
+    out2 = subprocess.run(cmd2, env=dict(env, M3T_DDP_EARLY_BUCKET="1"), capture_output=True, text=True, timeout=600)
+    assert out2.returncode == 0, out2.stderr[-2000:]
+    d2 = json.loads([l for l in out2.stdout.splitlines() if l.startswith("{")][-1])
+    assert d2["loss"] == d["loss"] and d2["grad_norm"] == d["grad_norm"] and "fallback" not in d2, (d["loss"], d2["loss"], d["grad_norm"], d2["grad_norm"])
+    assert "early" in d2["allreduce"]["schedule"] and "early" not in d["allreduce"]["schedule"]
 
 
 def test_shared_linear_weight_with_deferred_sink_write():
