@@ -460,6 +460,43 @@ def linear(x, w, b=None, act=0):
 # ----------------------------------------------------------------------------- BiGRU
 SCAN_PER_STEP = [False]     # tests/benchmarks: force the launch-per-step scan path
 SCAN_FAULT = [False]        # tests: fault injection (M3T_SCAN_FAULT), see include/m3t_hip.h
+# Range probe of the fp16x3 mode: RANGE_PROBE[0] = [] makes every grouped BiGRU backward record, per (layer, stack,
+# direction), how far the gradient operands it hands to the fp16x3 GEMMs -- dgx / dgh [B T, 3H] -- spread below their maximum: rows
+# (a frame: an output row of the data-gradient GEMM dX = dgx W_ih) and columns (a gate unit: an output row of the weight-gradient GEMMs
+# dW = dgx^T x) whose LARGEST element is more than 2^17 below the operand's maximum are built only of elements past the mode's
+# full-precision range (error model: absolute error 2^-39 of the maximum there).  Recorded: the widest spread, how many rows /
+# columns are past the range, and their share of the operand's energy (sum of squares) -- what the limit can cost a gradient normwise.
+# Debug aid (a dozen extra reductions per level); env M3T_F16X3_PROBE=1 arms it process-wide; range_probe_report() evaluates (synchronises).
+RANGE_PROBE = [[] if os.environ.get("M3T_F16X3_PROBE") == "1" else None]
+
+
+def _probe_range(tag, t2d):
+    """t2d: [rows, cols] view of a gradient operand"""
+    a = t2d.abs()
+    rmax, cmax, gmax = a.amax(1), a.amax(0), a.max()
+    big = torch.full((), float("inf"), device=t2d.device)
+    lim = gmax * 2.0 ** -17
+    sq = t2d.double() ** 2
+    tot = sq.sum()
+    past_r, past_c = rmax < lim, cmax < lim
+    RANGE_PROBE[0].append((tag, gmax, torch.where(rmax > 0, rmax, big).min(), torch.where(cmax > 0, cmax, big).min(),
+                           past_r.sum(), past_c.sum(), sq.sum(1)[past_r].sum() / tot, sq.sum(0)[past_c].sum() / tot))
+
+
+def range_probe_report(clear=True):
+    """per probed operand: dict(tag, max, row_spread, col_spread = max / smallest non-zero row / column maximum, rows_past, cols_past =
+    rows / columns entirely more than 2^17 below the maximum, row_energy_past, col_energy_past = their share of the sum of squares)"""
+    keys = ("tag", "max", "row_spread", "col_spread", "rows_past", "cols_past", "row_energy_past", "col_energy_past")
+    out = []
+    for rec in (RANGE_PROBE[0] or []):
+        v = [rec[0]] + [float(x) for x in rec[1:]]
+        v[2], v[3] = v[1] / v[2], v[1] / v[3]
+        out.append(dict(zip(keys, v)))
+    if clear and RANGE_PROBE[0] is not None:
+        RANGE_PROBE[0] = []
+    return out
+
+
 SCAN_FP32 = [False]         # tests: keep the persistent forward scan on fp32 MFMAs (bit-identical to the per-step kernels)
 
 
@@ -906,6 +943,11 @@ class _MultiBiGRU(torch.autograd.Function):
                                             _vp(dbp[l][s], d * B * 4 * H), _vp(out_grads[base + 2]), _vp(out_grads[base + 3]),
                                             H, d, out.stride(1), d * H, 6 * H, d * 3 * H, bslot(l, s, d)))      # (dout and out share the layout)
             _scan_bwd(descs, B, T, prec | (_lib.M3T_SCAN_WHH if direct_whh else 0) | (_lib.M3T_SCAN_WIDE if wide else 0), after)
+            if RANGE_PROBE[0] is not None:
+                for s in idxs:
+                    for d in (0, 1):
+                        _probe_range("dgx l%d s%d d%d H%d" % (l, s, d, Hs[s]), dgx[l][s].view(B * T, 6 * Hs[s])[:, d * 3 * Hs[s]:(d + 1) * 3 * Hs[s]])
+                        _probe_range("dgh l%d s%d d%d H%d" % (l, s, d, Hs[s]), dgh[l][s][d].view(B * T, 3 * Hs[s]))
 
         def level_dx(l, idxs):           # on the chain: feeds the next level's scan
             for s in idxs:
