@@ -297,7 +297,8 @@ def parse_args():
     ap.add_argument("--aux-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--worker", type=int, default=None, help=argparse.SUPPRESS)      # attempt number (0, or 1 = fallback)
     ap.add_argument("--worker-timeout", type=float, default=float(os.environ.get("M3T_BENCH_WORKER_TIMEOUT", "900")),
-                    help="N > 1: seconds a worker may run before its supervisor declares it stuck and starts the fallback")
+                    help="N > 1: seconds a worker may go WITHOUT a heartbeat (one per step and phase) before its supervisor declares it stuck "
+                         "and starts the fallback")
     return ap.parse_args()
 
 
@@ -333,26 +334,45 @@ def supervise(args):
     me = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
 
     def run(attempt, extra_env):
+        import tempfile
         env = dict(os.environ, **extra_env)
         env.pop("TORCHELASTIC_USE_AGENT_STORE", None)        # the workers host their own rendezvous store (port + 1 + attempt)
+        # heartbeat: the worker touches this file at every step and phase (the limit used to run from the worker's START, so a
+        # healthy long run was killed -- and silently re-run in the fallback configuration -- while "no progress" was the claim)
+        hb = tempfile.NamedTemporaryFile(prefix="m3t_bench_hb_%d_" % rank, delete=False)
+        hb.close()
+        env["M3T_BENCH_HEARTBEAT"] = hb.name
         p = subprocess.Popen(me + ["--worker", str(attempt)], env=env)
-        t0 = time.time()
         key = "fail%d" % attempt
+
+        def beat_age():
+            try:
+                return time.time() - os.stat(hb.name).st_mtime
+            except OSError:
+                return 0.0
+
+        def done(rc_):
+            try:
+                os.unlink(hb.name)
+            except OSError:
+                pass
+            return rc_
+
         while True:
             rc = p.poll()
             if rc is not None:
                 if rc != 0:
                     store.set(key, "rank %d exited with %d" % (rank, rc))
-                return rc
+                return done(rc)
             failed = store.check([key])
-            if not failed and time.time() - t0 > args.worker_timeout:
+            if not failed and beat_age() > args.worker_timeout:
                 store.set(key, "rank %d made no progress for %.0f s" % (rank, args.worker_timeout))
                 failed = True
             if failed:
                 # some rank's worker failed: ours is waiting in a collective for it (or is the stuck one) -- end exactly it
                 p.kill()
                 p.wait()
-                return -1
+                return done(-1)
             time.sleep(0.25)
 
     def leave(rc):
@@ -456,12 +476,19 @@ def worker(args):
         torch.cuda.synchronize()
 
     from m3t import _lib
-    if os.environ.get("M3T_BENCH_HIPRIO") == "1":      # (A/B: the step's own stream at high priority, the weight-gradient streams at normal)
-        hi = torch.cuda.Stream(priority=-1)
-        hi.wait_stream(torch.cuda.current_stream())
-        torch.cuda.set_stream(hi)
+    hb_path = os.environ.get("M3T_BENCH_HEARTBEAT")
+
+    def beat():                                      # N > 1: tell the supervisor this worker is alive (its limit is on heartbeat AGE)
+        if hb_path:
+            try:
+                os.utime(hb_path, None)
+            except OSError:
+                pass
+
+    beat()
     for _ in range(args.warmup):
         step()
+        beat()
     if os.environ.get("M3T_BENCH_INJECT_FAULT") == str(rank) and not (args.worker or 0):
         # fault injection (tests of the supervisors' fallback): this rank's first attempt sees "a persistent scan gave up"
         ops.inject_scan_error()
@@ -492,6 +519,7 @@ def worker(args):
             # profiled steps: `allreduce.ms_in_step` is what the collective costs INSIDE the step, on the step's own stream
             ddp.ar_events = ar_events if ops.PROFILE_ON[0] else None
         loss = step()
+        beat()
         if step_marks is not None:
             step_marks.append(torch.cuda.Event(enable_timing=True))
             step_marks[-1].record()
@@ -506,6 +534,7 @@ def worker(args):
               file=sys.stderr, flush=True)
         print("# host per-step ms: " + " ".join("%.2f" % ((b - a) * 1e3) for a, b in zip([t0] + host_marks[:-1], host_marks)),
               file=sys.stderr, flush=True)
+    beat()
     ddp.agree_on_scan_error()                      # a scan that gave up (on any rank) would make the number meaningless: every rank raises
     persist_per_step = (_lib.load().m3t_gru_persist_count() - n_persist0) / max(1, args.steps)
     # N > 1: the gradient all-reduce alone (same buffer, same communicator), outside the timed region

@@ -74,7 +74,13 @@ static __device__ __forceinline__ void m3t_drop_mask4(const M3TDrop& d, uint32_t
 // ---- fp16x3 GEMM operands (gemm_x6.hip / gemm_x6d.hip, NS = 4) ----------------------------------------------------------------
 // An operand is staged as two fp16 terms of s x, s the power of two that puts max |x| into [2^14, 2^15) (fp16 overflows at 65504).
 // bits = the fp32 bit pattern of max |x| over (a superset of) the operand, measured on the device right before the GEMM
-// (gemm.hip, the backward scans).  All-zero or denormal-only operands: s saturates at 2^127, 1/s flushes to zero, the product is zero.
+// (gemm.hip, the backward scans).  Componentwise this is NOT fp32 (error model; tests/test_gpu_parity.py::
+// test_sgemm_fp16x3_stated_limit_and_the_x6_escape_hatch): two fp16 terms carry 22 significant bits; an element more than 2^17 below
+// the operand's maximum has a subnormal low term and keeps an ABSOLUTE error of at most 2^-39 of the maximum (18 bits at 2^-20 of it,
+// flushed to zero below ~2^-39); normwise the product is as accurate as an fp32 GEMM, and M3T_GEMM_F16X3 off (ops.precision("x6"))
+// has no such limit.  The scale's exponent is clamped to 2^126 so that its inverse stays a normal number: an operand whose maximum
+// is below 2^-112 is scaled by 2^126 (not into [2^14, 2^15), but its values keep their bits) instead of producing exact zeros; an
+// all-zero operand gives zeros either way.
 // inf / NaN do not count towards the maximum (m3t_fin_abs): the finite values keep their scale and the non-finite ones become fp16
 // inf / NaN, which poison exactly the outputs they would poison in an fp32 GEMM.
 static __device__ __forceinline__ float m3t_fin_abs(float x) {          // |x|, or 0 for inf / NaN
@@ -83,7 +89,7 @@ static __device__ __forceinline__ float m3t_fin_abs(float x) {          // |x|, 
 }
 static __device__ __forceinline__ void m3t_f16_scale(unsigned bits, float& s, float& inv) {
     const int e = (int)((bits >> 23) & 0xffu);
-    const int es = min(max(268 - e, 1), 254);            // biased exponent of s = 2^(14 - (e - 127))
+    const int es = min(max(268 - e, 1), 253);            // biased exponent of s = 2^(14 - (e - 127)); <= 253: 1 / s = 2^(127 - es) stays normal
     s = __uint_as_float((unsigned)es << 23);
     inv = __uint_as_float((unsigned)(254 - es) << 23);
 }

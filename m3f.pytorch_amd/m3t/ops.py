@@ -148,8 +148,6 @@ def _p(t, off=0):
 #     are done, and are joined in FlatGradDDP.finish() when every gradient went into a gradient sink.  Two streams; the second
 #     one takes half of the LAST level's GEMMs only (the tail of backward, when no scan and no data gradient is left).
 _SIDE = {}
-_BESIDE_FLAG = os.environ.get("M3T_GEMM_BESIDE", "1") != "0"        # (A/B: GEMMs beside scans on the software-pipelined kernel too)
-_SIDE_PRIO = int(os.environ.get("M3T_SIDE_PRIO", "0"))               # (A/B: stream priority of the side stream; -1 = high)
 _PERSIST_ENABLED = os.environ.get("M3T_SCAN_PERSIST", "1") != "0"
 _WGRAD = {}
 _N_WGRAD = 2
@@ -159,7 +157,7 @@ def side_stream(device):
     key = (device.type, device.index)
     st = _SIDE.get(key)
     if st is None:
-        st = torch.cuda.Stream(device=device, priority=_SIDE_PRIO)
+        st = torch.cuda.Stream(device=device)
         _SIDE[key] = st
         _ROLE_OF_HANDLE[(st.device.index, st.cuda_stream)] = "side"
     return st
@@ -260,7 +258,7 @@ def sgemm(transA, transB, M, N, K, A, a_off, lda, B, b_off, ldb, Cm, c_off, ldc,
     measure_amax below, or a backward scan's); None: the library measures that operand itself (one more launch)"""
     ws = workspace(Cm.device) if use_ws else None
     flags = (_PREC[0] if prec is None else prec) | (_lib.M3T_GEMM_EXCLUSIVE if exclusive else 0)
-    if _FENCED[0] and _BESIDE_FLAG:
+    if _FENCED[0]:
         flags |= _lib.M3T_GEMM_BESIDE_SCAN       # issued inside the interleaved schedule of _MultiBiGRU: scans of another stream run beside it
     with _Timed("sgemm_kernel", 1, 2.0 * M * N * K) if PROFILE_GEMM[0] else _NULL:
         rc = lib().m3t_sgemm_scaled(transA, transB, M, N, K, _p(A, a_off), lda, _p(B, b_off), ldb, _p(Cm, c_off), ldc,
@@ -1306,15 +1304,19 @@ class _TemporalBlock(torch.autograd.Function):
             sp = slots.data_ptr()
             if not measure_amax([(x, sp), (w1t, sp + 8), (w2t, sp + 16)] + ([(wd, sp + 24)] if wd is not None else [])):
                 slots = None
-        sl = (lambda i: None) if slots is None else (lambda i: slots.data_ptr() + 8 * i)
+        # a slot is only ever handed to a kernel once a measurement has raised it (a zero slot that was never raised reads as
+        # "all-zero operand" and the product silently becomes zero); an operand whose slot is not in `ok` is measured by the library
+        ok = set(range(4)) if slots is not None else set()
+        sl = lambda i: (slots.data_ptr() + 8 * i) if (slots is not None and i in ok) else None
         h1 = _conv(x, w1t, b1, None, m1, None, B, T, Ci, Co, K, dilation, 1, 0, prec, d1, amax=(sl(0), sl(1)))
         if wd is not None:
             res = torch.empty(B, T, Co, dtype=torch.float32, device=dev)
             sgemm(0, 1, B * T, Co, Ci, x, 0, Ci, wd, 0, Ci, res, 0, Co, bias=bd, prec=prec, amax=(sl(0), sl(3)))
         else:
             res = x
-        if slots is not None:
-            measure_amax([(h1, sl(4))])
+        if slots is not None and measure_amax([(h1, slots.data_ptr() + 32)]):
+            ok.add(4)
+        ctx.slots_ok = ok
         a2 = torch.empty(B, T, Co, dtype=torch.float32, device=dev)
         y = _conv(h1, w2t, b2, res, m2, a2, B, T, Co, Co, K, dilation, 2, 0, prec, d2, amax=(sl(4), sl(2)))
         ctx.save_for_backward(x, v1, g1, v2, g2, wd, w1t, w2t, n1, n2, h1, a2, y, m1, m2, slots)
@@ -1336,13 +1338,14 @@ class _TemporalBlock(torch.autograd.Function):
         ds = mask_pos(y, dy)                         # through the block's output ReLU
         d1, d2 = ctx.drops
         da2 = mask_pos(a2, ds, m2, d2)               # through dropout2 + relu2
-        sl = (lambda i: None) if slots is None else (lambda i: slots.data_ptr() + 8 * i)
-        if slots is not None:
-            measure_amax([(ds, sl(5)), (da2, sl(6))])
+        ok = set(ctx.slots_ok)                       # slots a measurement has raised (see forward)
+        sl = lambda i: (slots.data_ptr() + 8 * i) if (slots is not None and i in ok) else None
+        if slots is not None and measure_amax([(ds, slots.data_ptr() + 40), (da2, slots.data_ptr() + 48)]):
+            ok.update((5, 6))
         dh1 = _conv(da2, w2t, None, None, None, None, B, T, Co, Co, K, dil, 0, 1, prec, amax=(sl(6), sl(2)))
         da1 = mask_pos(h1, dh1, m1, d1)              # h1 > 0 <=> a1 > 0 (dropout keeps the sign)
-        if slots is not None:
-            measure_amax([(da1, sl(7))])
+        if slots is not None and measure_amax([(da1, slots.data_ptr() + 56)]):
+            ok.add(7)
         dw2t = torch.empty_like(w2t)
         dw1t = torch.empty_like(w1t)
         # Off the chain: when every parameter of the block has a gradient sink, the data gradient (what the previous block waits

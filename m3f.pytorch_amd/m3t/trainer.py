@@ -129,13 +129,17 @@ class Trainer:
     def _mean_over_ranks(self, value):
         """every replica must take the same plateau / best-checkpoint decision: the epoch's val_loss is averaged over the
         process group first (each rank validates its own shard of the windows)"""
-        if self.ddp.world <= 1 or value is None:
+        if self.ddp.world <= 1:
             return value
-        t = torch.tensor([float(value)], dtype=torch.float64)
+        # (value, "I have one"): a rank without a validation loss must not leave the others waiting in the collective (ADVICE r3)
+        t = torch.tensor([0.0 if value is None else float(value), 0.0 if value is None else 1.0], dtype=torch.float64)
         if dist.get_backend(self.ddp.pg) == "nccl":
             t = t.to(self.ddp.flat.device)
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.ddp.pg)
-        return float(t.item()) / self.ddp.world
+        have = int(round(float(t[1].item())))
+        if have not in (0, self.ddp.world):
+            raise RuntimeError("val_loss is None on %d of %d ranks: every rank must validate (or none)" % (self.ddp.world - have, self.ddp.world))
+        return None if have == 0 else float(t[0].item()) / self.ddp.world
 
     def end_epoch(self, val_loss=None):
         """epoch-level schedulers + best-val_loss checkpoint (Lightning: check_val_every_n_epoch=1, ModelCheckpoint on val_loss).
@@ -190,19 +194,31 @@ class Trainer:
         barrier so that none of them runs ahead into a load of a checkpoint that is still being written.  Every rank polls
         the scan error state first: parameters behind an unreported dead scan are never persisted."""
         self.ddp.agree_on_scan_error()
+        err = None
         if self.rank == 0:
-            opt_state = {"t": self.opt.t}
-            for k in ("m", "v", "buf"):
-                if hasattr(self.opt, k):
-                    opt_state[k] = getattr(self.opt, k).detach().cpu().clone()
-            tmp = "%s.tmp.%d" % (path, os.getpid())
-            torch.save({"state_dict": {k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()},
-                        "global_step": self.global_step, "epoch": self.epoch, "best_val_loss": self.best_val_loss,
-                        "optimizer": opt_state, "shadow_optimizer": self._shadow.state_dict(),
-                        "scheduler": self.scheduler.state_dict() if self.scheduler is not None else None}, tmp)
-            os.replace(tmp, path)
+            try:
+                opt_state = {"t": self.opt.t}
+                for k in ("m", "v", "buf"):
+                    if hasattr(self.opt, k):
+                        opt_state[k] = getattr(self.opt, k).detach().cpu().clone()
+                tmp = "%s.tmp.%d" % (path, os.getpid())
+                torch.save({"state_dict": {k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()},
+                            "global_step": self.global_step, "epoch": self.epoch, "best_val_loss": self.best_val_loss,
+                            "optimizer": opt_state, "shadow_optimizer": self._shadow.state_dict(),
+                            "scheduler": self.scheduler.state_dict() if self.scheduler is not None else None}, tmp)
+                os.replace(tmp, path)
+            except Exception as e:  # noqa: BLE001  (disk full, permissions ...: the other ranks must not wait at a barrier forever)
+                err = e
         if self.ddp.world > 1:
-            dist.barrier(group=self.ddp.pg)
+            # instead of a bare barrier: rank 0 tells everyone whether the write succeeded; every rank raises if it did not (ADVICE r3)
+            flag = torch.tensor([0.0 if err is None else 1.0], dtype=torch.float32)
+            if dist.get_backend(self.ddp.pg) == "nccl":
+                flag = flag.to(self.ddp.flat.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.ddp.pg)
+            if float(flag.item()) != 0.0 and err is None:
+                raise RuntimeError("rank 0 could not write the checkpoint %s" % path)
+        if err is not None:
+            raise err
 
     def load_checkpoint(self, path, strict=True):
         ck = torch.load(path, map_location="cpu")
