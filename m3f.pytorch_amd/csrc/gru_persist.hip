@@ -344,10 +344,17 @@ typedef _Float16 pf16x8 __attribute__((ext_vector_type(8)));
 // waves do cell math (waves 0-3 tile 0, waves 4-7 tile 1; the two tiles are adjacent in the exchange buffer, so the consumers' gather
 // code does not change) -- and a level needs HALF the workgroups: the 4 x H=512 encoder level runs on 128 CUs and leaves room for
 // the audio stack's 64-workgroup scans beside it.
-// CO: the cell threads' HBM traffic in memory order through LDS, as in gru_persist_bwd3p_kernel (there: the comment on CO).
-template <int NC, bool F16 = false, int UW = 1, bool CO = false>
+// CO (the wide form only): the cell threads' HBM traffic goes through threads numbered in MEMORY order -- thread ti of a tile loads / stores
+// the activations of cell (row ti >> 4, unit ti & 15), so a wave instruction covers 4 rows x 16 consecutive units (64-byte / 256-byte
+// runs) instead of 64 scattered sectors -- and LDS carries them to / from the cell-math threads (granule order), results one step late.
+// In granule order every load and store of a step was 64 separate memory requests per wave: with eight cell-math waves per CU 2500-4600
+// requests per CU and step against 500-1000 lines for the gather itself, and the younger waves' stores queued for 1.4 us of a 5.2 us
+// wide backward step (wide forward 2.95 -> 2.51 us per step, wide backward 5.2 -> 3.4; with four cell-math waves -- the narrow form --
+// the extra LDS hop on the chain costs more than it saves: 3.42 vs 3.30).
+template <int NC, bool F16 = false, int UW = 1>
 __global__ __launch_bounds__(NT) void gru_persist_fwd6_kernel(FwdGroup g, FragPtrs fp, ExPtrs ex, int B, int T, int G, int nrb,
                                                               unsigned* err) {
+    constexpr bool CO = UW == 2;
     constexpr int ROWS = 16, KS = NC / 2, NTERM = F16 ? 2 : 3;
     constexpr int H = 128 * NC, nch = H >> 4;
     // partial sums of the waves: [step parity][wave][unit tile][gate][row][UB + 1]; UW = 2 needs 102 KiB: dynamic LDS
@@ -993,46 +1000,35 @@ __device__ __forceinline__ unsigned bwd3p_split(float xs) {          // the scal
     return (unsigned)__builtin_bit_cast(unsigned short, h1) | ((unsigned)__builtin_bit_cast(unsigned short, h2) << 16);
 }
 
-// UW = 16-unit tiles per workgroup (2 = the "wide" form, see gru_persist_fwd6_kernel: same gather per workgroup, the gathered operand
-// shared by both output tiles, all eight waves do cell math -- waves 0-3 tile 0, waves 4-7 tile 1 -- half the workgroups per level)
-// CO (round 4): the cell threads' HBM traffic goes through threads numbered in MEMORY order -- thread ti of a tile loads / stores the
-// activations of cell (row ti >> 4, unit ti & 15), so a wave instruction covers 4 rows x 16 consecutive units (64-byte / 256-byte runs)
-// instead of 64 scattered sectors -- and LDS carries them to / from the cell-math threads (granule order).  In granule order every
-// load and store of a step was 64 separate memory requests per wave: 9 instructions x 8 waves x 64 = 4600 requests per CU and step
-// in the wide form against ~1000 lines for the gather itself, and the younger waves' stores queued for 1.4 us of a 5.2 us step.
-template <int NC, int UW = 1, bool CO = false>
+template <int NC>
 __global__ __launch_bounds__(NT) void gru_persist_bwd3p_kernel(BwdGroup g, FragPtrs fp, ExPtrs ex, int B, int T, int G, int nrb,
                                                              unsigned* err) {
     constexpr int RT = 1, ROWS = 16;
     constexpr int H = 128 * NC, H3 = 3 * H, nchh = H >> 4;
-    __shared__ float red[2][NW][UW][ROWS][UB + 1];
+    __shared__ float red[2][NW][ROWS][UB + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int gid, ubw;
-    if (!persist_map((int)blockIdx.x, G, ex.slot_map, gid, ubw)) return;      // a block of an XCD slot that hosts no group of this launch
+    int gid, ub;
+    if (!persist_map((int)blockIdx.x, G, ex.slot_map, gid, ub)) return;      // a block of an XCD slot that hosts no group of this launch
     const int s = gid / nrb, rb = gid % nrb;
     const m3t_gru_bwd_desc d = g.d[s];
-    const int tu = UW == 1 ? 0 : (tid >> 8);           // the unit tile this thread does cell math for
-    const int ub = ubw * UW + tu;
     const int j0 = ub * UB, r0 = rb * ROWS;
 
-    pu32x2 wb[UW][3][NC][2];                            // [unit tile][gate][producer tile of this wave's K-slice][term]: 4 fp16 per lane, 48 VGPRs per unit tile at H = 512
-    float winv[UW];                                     // 1 / (scale of the slice's W_hh^T)
-#pragma unroll
-    for (int u = 0; u < UW; ++u) {
-        const pu32x2* Wf = reinterpret_cast<const pu32x2*>(fp.wfrag[s]) + ((size_t)((ubw * UW + u) * NW + wave) * 3 * NC * 2) * 64 + lane;
+    pu32x2 wb[3][NC][2];                                // [gate][producer tile of this wave's K-slice][term]: 4 fp16 per lane, 48 VGPRs at H = 512
+    {
+        const pu32x2* Wf = reinterpret_cast<const pu32x2*>(fp.wfrag[s]) + ((size_t)(ub * NW + wave) * 3 * NC * 2) * 64 + lane;
 #pragma unroll
         for (int gt = 0; gt < 3; ++gt)
 #pragma unroll
             for (int m = 0; m < NC; ++m)
 #pragma unroll
-                for (int t = 0; t < 2; ++t) wb[u][gt][m][t] = Wf[((gt * NC + m) * 2 + t) * 64];
-        winv[u] = reinterpret_cast<const float*>(fp.wfrag[s])[(size_t)4 * H * H + ubw * UW + u];
+                for (int t = 0; t < 2; ++t) wb[gt][m][t] = Wf[((gt * NC + m) * 2 + t) * 64];
     }
-    __shared__ __attribute__((aligned(16))) unsigned pmx4[UW][4];  // the cell-math waves' maxima of the step, per unit tile (two lowest bits: step tag)
-    if (tid < 4 * UW) (&pmx4[0][0])[tid] = 0u;
-    const unsigned pmx4_addr = (unsigned)(uintptr_t)&pmx4[tu][0];  // (LDS byte address for the ds_read_b128 of the exchange)
-    const bool pw = tid < ROWS * UB * UW;              // granule-order numbering, as in the forward kernel
-    const int prow = tid & 15, pu = ((tid >> 4) & 3) * 4 + ((tid >> 6) & 3);
+    const float winv = reinterpret_cast<const float*>(fp.wfrag[s])[(size_t)4 * H * H + ub];     // 1 / (scale of this slice's W_hh^T)
+    __shared__ __attribute__((aligned(16))) unsigned pmx4[4];      // the cell-math waves' maxima of the step (two lowest bits: step tag)
+    if (tid < 4) pmx4[tid] = 0u;
+    const unsigned pmx4_addr = (unsigned)(uintptr_t)pmx4;        // (LDS byte address for the ds_read_b128 of the exchange)
+    const bool pw = tid < ROWS * UB;                   // granule-order numbering, as in the forward kernel
+    const int prow = (tid >> 8) * 16 + (tid & 15), pu = ((tid >> 4) & 3) * 4 + ((tid >> 6) & 3);
     const int pb = r0 + prow, pj = j0 + pu;
     const bool pok = pw && pb < B;
     float dh_carry = 0.f, z_next = 0.f;                // dh_{t+1} and z_{t+1} of this thread's (row, unit)
@@ -1044,12 +1040,12 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd3p_kernel(BwdGroup g, FragP
     u32x4* gran = reinterpret_cast<u32x4*>(ex.gran[s]);
     const size_t slot = ex.slot[s];
     const size_t grp = (size_t)rb * nchh * TILE;
-    const size_t pub = grp + (size_t)ubw * UW * TILE + tid;
+    const size_t pub = grp + (size_t)ub * TILE + tid;
     bool dead = false;
     int poll_delay = ex.poll_fixed >= 0 ? ex.poll_fixed : POLL_DELAY_INIT;
     __shared__ unsigned poll_fail[2];                  // by step parity
     __shared__ int pub_step;                           // steps this workgroup has published (thread 0)
-    const int l2mode = persist_handshake(ex, gid, ubw, (H >> 4) / UW, tid, err);     // 1: this group shares one XCD's L2 (publish with plain stores)
+    const int l2mode = persist_handshake(ex, gid, ub, H >> 4, tid, err);     // 1: this group shares one XCD's L2 (publish with plain stores)
     if (tid == 0) pub_step = 0;
     if (tid < 2) poll_fail[tid] = 0;                   // first read after the first barrier
     const bool stamp = ex.prof != nullptr && blockIdx.x == 0 && tid == ex.prof_tid;
@@ -1069,19 +1065,211 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd3p_kernel(BwdGroup g, FragP
     // registers still in flight.  A set is defined by the vmcnt(0) of the gather that precedes its use and laundered there.
     float doutA, hprevA, doutB, hprevB;
     f32x4 g4A, g4B;                                    // (r, z, n, W_hn h + b_hn) of this (row, unit, t)
-    // memory-side identity of this thread (CO; else = its cell): (hrow, hun) of its tile, LDS slots padded one per 16 (conflict-free on
-    // both sides): slot_h where it leaves what it loaded / finds what it stores, slot_c where the cell it computes finds / leaves them
+    const int pbc = pb < B ? pb : B - 1;
+    const float* pd0 = d.dout + (size_t)pbc * T * d.ldo + d.ooff + pj;
+    const float* pg0 = d.gates + (size_t)pbc * T * 4 * H + 4 * (size_t)pj;
+    const float* ph0 = d.out + (size_t)pbc * T * d.ldo + d.ooff + pj;
+#define M3T_BWD_LOAD_STEP(step_, DOUT, G4, HPREV)                                                                     \
+    do {                                                                                                               \
+        const int ls_ = (step_) < T ? (step_) : T - 1;                                                                 \
+        const int lt_ = d.reverse ? ls_ : T - 1 - ls_;                                                                 \
+        const int ltp_ = ls_ < T - 1 ? (d.reverse ? lt_ + 1 : lt_ - 1) : lt_;                                          \
+        asm volatile("global_load_dword %0, %3, off\n\t"                                                               \
+                     "global_load_dwordx4 %1, %4, off\n\t"                                                             \
+                     "global_load_dword %2, %5, off"                                                                   \
+                     : "=&v"(DOUT), "=&v"(G4), "=&v"(HPREV)                                                            \
+                     : "v"(pd0 + (size_t)lt_ * d.ldo), "v"(pg0 + (size_t)lt_ * 4 * H), "v"(ph0 + (size_t)ltp_ * d.ldo)  \
+                     : "memory");                                                                                      \
+    } while (0)
+    M3T_BWD_LOAD_STEP(0, doutA, g4A, hprevA);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(doutA), "+v"(g4A), "+v"(hprevA) :: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0), visible to hipcc: no wait for the weight fragments inside the loop
+    float st_dr = 0.f, st_dz = 0.f, st_dn = 0.f, st_dnr = 0.f;     // results of the previous step, stored after this step's gather
+    auto store_results = [&](int step_of) {
+        const int t = d.reverse ? step_of : T - 1 - step_of;
+        float* gx = d.dgx + ((size_t)pb * T + t) * d.ldg + d.goff;
+        gx[pj] = st_dr; gx[H + pj] = st_dz; gx[2 * H + pj] = st_dn;
+        float* gh = d.dgh + ((size_t)pb * T + t) * H3;
+        gh[pj] = st_dr; gh[H + pj] = st_dz; gh[2 * H + pj] = st_dnr;
+    };
+
+    for (int step2 = 0; step2 < T; step2 += 2) {
+#define STEPV step2
+#define CUR(x) x##A
+#define NXT(x) x##B
+#include "gru_persist_bwd3p_step.inc"
+#undef STEPV
+#undef CUR
+#undef NXT
+        if (step2 + 1 >= T) break;
+#define STEPV (step2 + 1)
+#define CUR(x) x##B
+#define NXT(x) x##A
+#include "gru_persist_bwd3p_step.inc"
+#undef STEPV
+#undef CUR
+#undef NXT
+    }
+#undef M3T_BWD_LOAD_STEP
+    // the last step's request for "the next step's inputs" is still in flight and invisible to hipcc (inline asm): a wave must
+    // not end with a load outstanding into registers that the next wave on this SIMD is about to own
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (pok) d.dh[(size_t)pb * H + pj] = dh_carry;
+    if (pok && d.db_part) {
+        float* q = d.db_part + (size_t)pb * 4 * H + pj;
+        q[0] = sb_r; q[H] = sb_z; q[2 * H] = sb_n; q[3 * H] = sb_nr;
+    }
+    if (d.amax && pw) {                                // (waves 0..3: uniform per wave)
+        const float m = wave_max(pok ? amx : 0.f);
+        if (lane == 0) atomicMax(d.amax, (unsigned long long)__float_as_uint(m));
+    }
+    if (stamp)
+        for (int i = 0; i < 6; ++i) ex.prof[i] = (unsigned long long)psum[i];
+}
+
+// ---- wide producer-split backward scan with 32-deep MFMAs (gru_persist_bwd3q_kernel, round 4) ---------------------------------------------
+// gru_persist_bwd3p_kernel multiplies one 16-unit producer tile per MFMA (v_mfma_f32_16x16x16_f16: the tile's scale is applied to the
+// MFMA's result) -- in a wide workgroup (two unit tiles) 72 MFMAs per wave and step, and a 16-deep MFMA costs the issue cycles of a
+// 32-deep one (tools/mfma_probe.hip: 18-20 cycles either way): the matrix pipe of a SIMD was busy for two thirds of the wide backward
+// step.  A WIDE workgroup publishes two adjacent tiles; scaled by ONE power of two (the maximum of the per-cell bound over all eight
+// waves) they form a 32-unit producer PAIR that a consumer multiplies with v_mfma_f32_16x16x32_f16: 36 MFMAs per wave and step (3.42 ->
+// 3.28 us per step at 4 x H=512; the narrow kernel on twice the CUs: 3.30).  Differences to bwd3p: the granule order inside a tile --
+// granule (unit & 7) * 32 + (unit >> 3) * 16 + row, so that lane (row, q) of a consumer finds the eight consecutive k of its A operand
+// (units 8 (q & 1) + e of tile q >> 1) at one address + e * 512 bytes and a wave instruction still reads whole 512-byte runs; W_hh^T
+// fragments in the 32-deep B-operand layout (wfrag_bwd3q_prep_kernel); the scale exchange covers all eight waves.  Always wide, always
+// with the memory-order hand-over of the cell threads' HBM traffic through LDS (see gru_persist_fwd6_kernel, CO).
+// wfrag3q[ub][wave][gate][pair m][term][lane][8 fp16]: term of W_hh[gate*H + 32*(wave + NW*m) + 8*(lane>>4) + e][ub*16 + (lane&15)] * scale(ub)
+__global__ __launch_bounds__(256) void wfrag_bwd3q_prep_kernel(PrepBwd3pArgs a, int H, int direct) {
+    const float* __restrict__ w = a.w[blockIdx.z];
+    unsigned short* __restrict__ wf = a.wf[blockIdx.z];
+    const int ub = blockIdx.x, np = H >> 8;                 // pairs per wave
+    __shared__ float red[4];
+    float m = 0.f;
+    const int tot4 = 3 * H * 4;
+    auto ld = [&](int i) {
+        return direct ? *reinterpret_cast<const float4*>(w + (size_t)(i >> 2) * H + ub * 16 + 4 * (i & 3))
+                      : *reinterpret_cast<const float4*>(w + ((size_t)ub * 16 + i / (3 * H / 4)) * 3 * H + 4 * (i % (3 * H / 4)));
+    };
+    auto fold = [&](const float4& v) {
+        m = fmaxf(fmaxf(m, m3t_fin_abs(v.x)), fmaxf(m3t_fin_abs(v.y), fmaxf(m3t_fin_abs(v.z), m3t_fin_abs(v.w))));
+    };
+    int i0 = threadIdx.x;
+    for (; i0 + 768 < tot4; i0 += 1024) {
+        const float4 v0 = ld(i0), v1 = ld(i0 + 256), v2 = ld(i0 + 512), v3 = ld(i0 + 768);
+        fold(v0); fold(v1); fold(v2); fold(v3);
+    }
+    for (; i0 < tot4; i0 += 256) fold(ld(i0));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sc, inv;
+    m3t_f16_scale(__float_as_uint(m), sc, inv);
+    if (threadIdx.x == 0 && blockIdx.y == 0) a.inv[blockIdx.z][ub] = inv;
+    // one item = the eight k of one (gate, pair, wave, lane): eight row reads at the same column, one 16-byte store per term
+    const int items = 3 * np * NW * 64;
+    for (int j = blockIdx.y * 256 + threadIdx.x; j < items; j += 256 * PREP3H_SPLIT) {
+        const int l = j & 63;
+        int r = j >> 6;
+        const int pm = r % np; r /= np;
+        const int wv = r % NW, gt = r / NW;
+        const int unit0 = 32 * (wv + NW * pm) + 8 * (l >> 4), n = l & 15;
+        unsigned h1[4], h2[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned short a1[2], a2[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float x = (direct ? w[((size_t)gt * H + unit0 + 2 * i + k) * H + ub * 16 + n]
+                                        : w[((size_t)ub * 16 + n) * 3 * H + (size_t)gt * H + unit0 + 2 * i + k]) * sc;
+                const _Float16 f1 = (_Float16)x;
+                const _Float16 f2 = (_Float16)(x - (float)f1);
+                a1[k] = __builtin_bit_cast(unsigned short, f1); a2[k] = __builtin_bit_cast(unsigned short, f2);
+            }
+            h1[i] = (unsigned)a1[0] | ((unsigned)a1[1] << 16); h2[i] = (unsigned)a2[0] | ((unsigned)a2[1] << 16);
+        }
+        const size_t base = (((((size_t)(ub * NW + wv) * 3 + gt) * np + pm) * 2) * 64 + l) * 8;
+        *reinterpret_cast<uint4*>(wf + base) = make_uint4(h1[0], h1[1], h1[2], h1[3]);
+        *reinterpret_cast<uint4*>(wf + base + 512) = make_uint4(h2[0], h2[1], h2[2], h2[3]);
+    }
+}
+
+// PROF: the in-kernel phase stamps (M3T_SCAN_PROF) live in an instantiation of their own -- their 14 VGPRs do not fit beside the rest
+// (that instantiation spills: its stamps overstate the step)
+template <int NC, bool PROF = false>
+__global__ __launch_bounds__(NT) void gru_persist_bwd3q_kernel(BwdGroup g, FragPtrs fp, ExPtrs ex, int B, int T, int G, int nrb,
+                                                             unsigned* err) {
+    constexpr int ROWS = 16, NP = NC / 2;              // NP: producer pairs per wave
+    constexpr int H = 128 * NC, H3 = 3 * H, nchh = H >> 4;
+    __shared__ float red[2][NW][2][ROWS][UB + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int gid, ubw;
+    if (!persist_map((int)blockIdx.x, G, ex.slot_map, gid, ubw)) return;      // a block of an XCD slot that hosts no group of this launch
+    const int s = gid / nrb, rb = gid % nrb;
+    const m3t_gru_bwd_desc d = g.d[s];
+    const int tu = tid >> 8;                           // the unit tile this thread does cell math for
+    const int ub = ubw * 2 + tu;
+    const int j0 = ub * UB, r0 = rb * ROWS;
+
+    pu32x4 wb[2][3][NP][2];                            // [unit tile][gate][producer pair of this wave's K-slice][term]: 8 fp16 per lane, 96 VGPRs at H = 512
+    float winv[2];                                     // 1 / (scale of the slice's W_hh^T)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const pu32x4* Wf = reinterpret_cast<const pu32x4*>(fp.wfrag[s]) + ((size_t)((ubw * 2 + u) * NW + wave) * 3 * NP * 2) * 64 + lane;
+#pragma unroll
+        for (int gt = 0; gt < 3; ++gt)
+#pragma unroll
+            for (int m = 0; m < NP; ++m)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) wb[u][gt][m][t] = Wf[((gt * NP + m) * 2 + t) * 64];
+        winv[u] = reinterpret_cast<const float*>(fp.wfrag[s])[(size_t)4 * H * H + ubw * 2 + u];
+    }
+    __shared__ __attribute__((aligned(16))) unsigned pmx8[8];      // the waves' maxima of the step (two lowest bits: step tag)
+    if (tid < 8) pmx8[tid] = 0u;
+    const unsigned pmx8_addr = (unsigned)(uintptr_t)pmx8;
+    // cell threads in granule order: granule ti of the tile <-> row ti & 15, unit 8 ((ti >> 4) & 1) + (ti >> 5)
     const int ti = tid & 255;
-    const int hrow = CO ? (ti >> 4) : prow, hun = CO ? (ti & 15) : pu;
+    const int prow = ti & 15, pu = 8 * ((ti >> 4) & 1) + (ti >> 5);
+    const int pb = r0 + prow, pj = j0 + pu;
+    const bool pok = pb < B;
+    float dh_carry = 0.f, z_next = 0.f;                // dh_{t+1} and z_{t+1} of this thread's (row, unit)
+    float sb_r = 0.f, sb_z = 0.f, sb_n = 0.f, sb_nr = 0.f;   // sums over t of the gate gradients: the bias gradients of this clip
+    float amx = 0.f;                                   // max |dr~|, |dz~|, |dn~| of this thread: the magnitude slot d.amax (fp16x3 GEMMs)
+    if (pok && d.dh_n) dh_carry = d.dh_n[(size_t)pb * H + pj];
+
+    constexpr size_t TILE = 256;
+    u32x4* gran = reinterpret_cast<u32x4*>(ex.gran[s]);
+    const size_t slot = ex.slot[s];
+    const size_t grp = (size_t)rb * nchh * TILE;
+    const size_t pub = grp + (size_t)ubw * 2 * TILE + tid;
+    // gather base of this lane inside the group: pair (wave + NW m) = tiles 2 (wave + NW m) + (q >> 1); granule e * 32 + (q & 1) * 16 + row
+    const size_t lane_src = (size_t)(2 * wave + (lane >> 5)) * TILE + ((lane >> 4) & 1) * 16 + (lane & 15);
+    bool dead = false;
+    int poll_delay = ex.poll_fixed >= 0 ? ex.poll_fixed : POLL_DELAY_INIT;
+    __shared__ unsigned poll_fail[2];                  // by step parity
+    const int l2mode = persist_handshake(ex, gid, ubw, (H >> 4) / 2, tid, err);     // 1: this group shares one XCD's L2 (publish with plain stores)
+    if (tid < 2) poll_fail[tid] = 0;                   // first read after the first barrier
+    const bool stamp = PROF && ex.prof != nullptr && blockIdx.x == 0 && tid == ex.prof_tid;
+    long long psum[PROF ? 6 : 1] = {0}, last = stamp ? clock64() : 0;
+#define M3T_QSTAMP(i)                                                        \
+    do {                                                                     \
+        if (PROF && stamp) { const long long now = clock64(); psum[PROF ? (i) : 0] += now - last; last = now; } \
+    } while (0)
+
+    // activations: loaded one step ahead by inline asm in MEMORY order (thread ti: row ti >> 4, unit ti & 15 of its tile), handed to the
+    // cell threads through LDS; results the other way, stored one step late
+    float doutA, hprevA, doutB, hprevB;
+    f32x4 g4A, g4B;                                    // (r, z, n, W_hn h + b_hn) of this (row, unit, t)
+    const int hrow = ti >> 4, hun = ti & 15;
     const int hb = r0 + hrow, hj = j0 + hun;
-    const bool hok = pw && hb < B;
-    const int hg = hrow + 16 * (hun >> 2) + 64 * (hun & 3);      // granule index of cell (hrow, hun)
+    const bool hok = hb < B;
+    const int hg = (hun & 7) * 32 + (hun >> 3) * 16 + hrow;      // granule index of cell (hrow, hun)
     constexpr int SLOTS = 272;
     const int slot_h = tu * SLOTS + hg + (hg >> 4), slot_c = tu * SLOTS + ti + (ti >> 4);
     extern __shared__ __attribute__((aligned(16))) unsigned char stage_raw[];
-    f32x4* const sin4 = reinterpret_cast<f32x4*>(stage_raw);                  // [parity][UW][SLOTS] gate records
-    f32x4* const sout = sin4 + 2 * UW * SLOTS;                                // [parity][UW][SLOTS] (dr~, dz~, dn~, dn~ r)
-    float2* const sin2 = reinterpret_cast<float2*>(sout + 2 * UW * SLOTS);    // [parity][UW][SLOTS] (dout, h_prev)
+    f32x4* const sin4 = reinterpret_cast<f32x4*>(stage_raw);                  // [parity][2][SLOTS] gate records
+    f32x4* const sout = sin4 + 2 * 2 * SLOTS;                                 // [parity][2][SLOTS] (dr~, dz~, dn~, dn~ r)
+    float2* const sin2 = reinterpret_cast<float2*>(sout + 2 * 2 * SLOTS);     // [parity][2][SLOTS] (dout, h_prev)
     const int pbc = hb < B ? hb : B - 1;
     const float* pd0 = d.dout + (size_t)pbc * T * d.ldo + d.ooff + hj;
     const float* pg0 = d.gates + (size_t)pbc * T * 4 * H + 4 * (size_t)hj;
@@ -1101,7 +1289,7 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd3p_kernel(BwdGroup g, FragP
     M3T_BWD_LOAD_STEP(0, doutA, g4A, hprevA);
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(doutA), "+v"(g4A), "+v"(hprevA) :: "memory");
     __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0), visible to hipcc: no wait for the weight fragments inside the loop
-    float st_dr = 0.f, st_dz = 0.f, st_dn = 0.f, st_dnr = 0.f;     // results of the step (CO: of the cell this thread stores for)
+    float st_dr = 0.f, st_dz = 0.f, st_dn = 0.f, st_dnr = 0.f;     // results of the cell this thread stores for
     auto store_results = [&](int step_of) {
         const int t = d.reverse ? step_of : T - 1 - step_of;
         float* gx = d.dgx + ((size_t)hb * T + t) * d.ldg + d.goff;
@@ -1115,7 +1303,7 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd3p_kernel(BwdGroup g, FragP
 #define PARV 0
 #define CUR(x) x##A
 #define NXT(x) x##B
-#include "gru_persist_bwd3p_step.inc"
+#include "gru_persist_bwd3q_step.inc"
 #undef STEPV
 #undef PARV
 #undef CUR
@@ -1125,7 +1313,7 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd3p_kernel(BwdGroup g, FragP
 #define PARV 1
 #define CUR(x) x##B
 #define NXT(x) x##A
-#include "gru_persist_bwd3p_step.inc"
+#include "gru_persist_bwd3q_step.inc"
 #undef STEPV
 #undef PARV
 #undef CUR
@@ -1135,25 +1323,24 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd3p_kernel(BwdGroup g, FragP
     // the last step's request for "the next step's inputs" is still in flight and invisible to hipcc (inline asm): a wave must
     // not end with a load outstanding into registers that the next wave on this SIMD is about to own
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (CO) {                                          // the last step's results are still in LDS
-        __syncthreads();
-        if (hok) {
-            const f32x4 r4 = sout[((T - 1) & 1) * UW * SLOTS + slot_h];
-            st_dr = r4[0]; st_dz = r4[1]; st_dn = r4[2]; st_dnr = r4[3];
-            store_results(T - 1);
-        }
+    __syncthreads();                                   // the last step's results are still in LDS
+    if (hok) {
+        const f32x4 r4 = sout[((T - 1) & 1) * 2 * SLOTS + slot_h];
+        st_dr = r4[0]; st_dz = r4[1]; st_dn = r4[2]; st_dnr = r4[3];
+        store_results(T - 1);
     }
     if (pok) d.dh[(size_t)pb * H + pj] = dh_carry;
     if (pok && d.db_part) {
         float* q = d.db_part + (size_t)pb * 4 * H + pj;
         q[0] = sb_r; q[H] = sb_z; q[2 * H] = sb_n; q[3 * H] = sb_nr;
     }
-    if (d.amax && pw) {                                // (waves 0..3: uniform per wave)
+    if (d.amax) {
         const float m = wave_max(pok ? amx : 0.f);
         if (lane == 0) atomicMax(d.amax, (unsigned long long)__float_as_uint(m));
     }
-    if (stamp)
-        for (int i = 0; i < 6; ++i) ex.prof[i] = (unsigned long long)psum[i];
+    if (PROF && stamp)
+        for (int i = 0; i < 6; ++i) ex.prof[i] = (unsigned long long)psum[PROF ? i : 0];
+#undef M3T_QSTAMP
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -1602,11 +1789,9 @@ int persist_fwd_launch(const FwdGroup& g, const FragPtrs& fp, int B, int T, int 
         if (f16) {
             if (sh.nc == 2) hipLaunchKernelGGL((gru_persist_fwd6_kernel<2, true>), dim3(sh.grid), dim3(NT), exclusive_lds(gru_persist_fwd6_kernel<2, true>, sh.active), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
             else if (uw == 2) {
-                // M3T_SCAN_COALESCE=0: the cell threads load / store their own cells (granule order: 64 scattered requests per instruction)
-                static const bool co = poll_env_early("M3T_SCAN_COALESCE", 1) != 0;
                 const size_t need = (size_t)2 * NW * 2 * 3 * 16 * (UB + 1) * sizeof(float)           // the kernel's partial sums (RED_FLOATS)
-                                    + (co ? (size_t)2 * 2 * 272 * 36 : 0);                           // + the staging slots (sx, so, sh)
-                const FwdKernel kk = co ? gru_persist_fwd6_kernel<4, true, 2, true> : gru_persist_fwd6_kernel<4, true, 2>;
+                                    + (size_t)2 * 2 * 272 * 36;                                      // + the staging slots (sx, so, sh)
+                const FwdKernel kk = gru_persist_fwd6_kernel<4, true, 2>;
                 const size_t dyn = exclusive_lds(kk, sh.active, need);
                 if (dyn < need) return M3T_EINVAL;
                 hipLaunchKernelGGL(kk, dim3(sh.grid), dim3(NT), dyn, s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
@@ -1645,8 +1830,6 @@ int persist_bwd_launch(const BwdGroup& g, const FragPtrs& fp, int B, int T, int 
     {
         ex.poll_fixed = 12;
         ex.poll_align = 1;
-        static const int pb = poll_env_early("M3T_SCAN_POLL_BWD", -2);       // (experiments: -1 adaptive, >= 0 fixed)
-        if (pb >= -1) ex.poll_fixed = pb;
     }
     // fp32 mode with M3T_GEMM_F16X3: the producer-split kernel (two fp16 terms per value in the granule, 24-bit tags + the tile's exponent)
     const bool p3 = !b16 && persist_bwd_uses_x6(g, B, T, flags) && (flags & M3T_GEMM_F16X3) && m3t_f16x3_enabled() && bwd3p_enabled() &&
@@ -1665,17 +1848,26 @@ int persist_bwd_launch(const BwdGroup& g, const FragPtrs& fp, int B, int T, int 
             const int j = i < g.n ? i : 0;
             pa.w[i] = g.d[j].w_hh_t; pa.wf[i] = reinterpret_cast<unsigned short*>(fp.wfrag[j]); pa.inv[i] = fp.wfrag[j] + (size_t)4 * H * H;
         }
+        if (uw == 2) {                                                       // the wide form: 32-deep MFMAs over producer pairs, memory-order hand-over
+            wfrag_bwd3q_prep_kernel<<<dim3(H / 16, PREP3H_SPLIT, g.n), 256, 0, s>>>(pa, H, (flags & M3T_SCAN_WHH) ? 1 : 0);
+            M3T_LAUNCH_CHECK();
+            { const int e = persist_take_after(s); if (e) return e; }
+            persist_record_start(s);
+            const BwdKernel kq = ex.prof ? gru_persist_bwd3q_kernel<4, true> : gru_persist_bwd3q_kernel<4>;
+            const size_t need = (size_t)2 * 2 * 272 * 40;                    // the staging slots (sin4, sout, sin2)
+            const size_t dyn = exclusive_lds(kq, sh.active, need);
+            if (dyn < need) return M3T_EINVAL;
+            hipLaunchKernelGGL(kq, dim3(sh.grid), dim3(NT), dyn, s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
+            persist_record_end(s);
+            M3T_LAUNCH_CHECK();
+            return 0;
+        }
         wfrag_bwd3p_prep_kernel<<<dim3(H / 16, PREP3H_SPLIT, g.n), 256, 0, s>>>(pa, H, (flags & M3T_SCAN_WHH) ? 1 : 0);
         M3T_LAUNCH_CHECK();
         { const int e = persist_take_after(s); if (e) return e; }
         persist_record_start(s);
-        // M3T_SCAN_COALESCE=0: the cell threads load / store their own cells (granule order: 64 scattered requests per instruction)
-        static const bool co = poll_env_early("M3T_SCAN_COALESCE", 1) != 0;
-        const BwdKernel kk = uw == 2 ? (co ? gru_persist_bwd3p_kernel<4, 2, true> : gru_persist_bwd3p_kernel<4, 2>)
-                                     : (sh.nc == 2 ? gru_persist_bwd3p_kernel<2> : gru_persist_bwd3p_kernel<4>);      // (narrow: 3.42 us per step with the hand-over, 3.30 without: only four cell-math waves per CU)
-        const size_t need = (co && uw == 2) ? (size_t)uw * 2 * 272 * 40 : 0;         // the staging slots (sin4, sout, sin2)
-        const size_t dyn = exclusive_lds(kk, sh.active, need);
-        if (dyn < need) return M3T_EINVAL;
+        const BwdKernel kk = sh.nc == 2 ? gru_persist_bwd3p_kernel<2> : gru_persist_bwd3p_kernel<4>;
+        const size_t dyn = exclusive_lds(kk, sh.active);
         hipLaunchKernelGGL(kk, dim3(sh.grid), dim3(NT), dyn, s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
         persist_record_end(s);
         M3T_LAUNCH_CHECK();
