@@ -72,10 +72,8 @@ extern "C" {
  * kernel's higher request rate slows the scans' exchange by as much as it gains (measured: same step time, backward scans
  * 6.8 -> 7.7 ms by events).  Results are bit-identical either way. */
 #define M3T_GEMM_BESIDE_SCAN 512
-/* the caller promises that nothing else shares the chip while this GEMM runs: the cost model may then pick the
- * 256 x 256-tile kernel (gemm_x6c.hip: one 512-thread workgroup with ~240 VGPRs per CU, 10-20 % faster on shapes that
- * fill whole rounds of 256 CUs).  Without the flag the 128 x 128-tile kernels run: their workgroups leave room on a CU
- * for a persistent scan or a second GEMM on another stream -- beside those the big tile was measured to LOSE. */
+/* the caller promises that nothing else shares the chip while this GEMM runs.  Rounds 2-3 gave such calls a 256 x 256-tile kernel in the
+ * six-product mode; it had no fp16x3 form and was removed in round 4 -- the flag is accepted and currently changes nothing. */
 #define M3T_GEMM_EXCLUSIVE 8
 
 /* library / device info: returns the ABI version; arch string copied to `arch` if non-null */
@@ -119,7 +117,7 @@ int m3t_absmax(int n, const float* const* x, const size_t* rows, const int* cols
                unsigned long long* const* slots, void* stream);
 
 /* Which kernel m3t_sgemm would run for a call of this shape (all operands 16-B aligned, ld % 4 == 0) and how many
- * split-K slabs: *kernel = 0 fp32-MFMA tile kernel, 1 bf16x6 128 x 128 tile, 2 bf16x6 256 x 256 tile (only with
+ * split-K slabs: *kernel = 0 fp32-MFMA tile kernel, 1 the 16-bit-term 128 x 128 / 128 x 64 tile kernels (formerly also 2: the 256 x 256 tile, removed; only with
  * M3T_GEMM_EXCLUSIVE).  For tools and tests; no device work. */
 int m3t_sgemm_plan(int transA, int M, int N, int K, int seg_len, size_t ws_bytes, int flags, int* kernel, int* splits);
 

@@ -514,10 +514,6 @@ int m3t_sgemm_x6_launch(int transA, int transB, int M, int N, int K, const float
                         int a_off, int b_off, float* ws, int splits, int kchunk, size_t dyn_lds, int bf16_operands, int narrow,
                         const unsigned long long* amax_a, const unsigned long long* amax_b, hipStream_t s);
 
-int m3t_sgemm_x6c_launch(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
-                         float* C, int ldc, const float* bias, int act, int accumulate, int seg_len, int seg_stride,
-                         int a_off, int b_off, float* ws, int splits, int kchunk, int bf16_operands, hipStream_t s);
-
 int m3t_sgemm_x6d_launch(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                          float* C, int ldc, const float* bias, int act, int accumulate, int seg_len, int seg_stride,
                          int a_off, int b_off, float* ws, int splits, int kchunk, int bf16_operands,
@@ -526,10 +522,9 @@ int m3t_sgemm_x6d_launch(int transA, int transB, int M, int N, int K, const floa
 // Kernel choice among the bf16x6 GEMMs (round 3: the A/B switches M3T_GEMM_X6D / _X6C / _NARROW / _SPLITS are retired, their
 // outcomes are the rules below): the 128-tile GEMMs run on the software-pipelined gemm_x6d.hip, EXCEPT those issued beside
 // another stream's persistent scan (M3T_GEMM_BESIDE_SCAN: a kernel with a higher request rate takes from the scans' exchange what
-// it gains), which keep gemm_x6.hip; the 256-tile gemm_x6c.hip where the caller owns the chip
-// (M3T_GEMM_EXCLUSIVE) and the calibrated cost model prefers it; the 128 x 64 tile for N % 64 == 0 and under-filled grids.
+// it gains), which keep gemm_x6.hip; the 128 x 64 tile for N % 64 == 0 and under-filled grids.  (The 256 x 256-tile
+// gemm_x6c.hip of rounds 2-3 is gone: it had no fp16x3 form, so the default mode never ran it.)
 static int x6d_mode() { return 2; }
-static int x6c_mode() { return 2; }
 
 // M3T_GEMM_F16X3=0: M3T_GEMM_F16X3 is ignored (the six-product bf16 form runs instead) -- A/B runs and the switch test
 bool m3t_f16x3_enabled() {
@@ -554,8 +549,8 @@ static bool x6_enabled() {
     return on == 1;
 }
 
-// Kernel and split-K choice of one m3t_sgemm call.  kernel: 0 fp32-MFMA (gemm.hip), 1 bf16x6 128-tile (gemm_x6.hip),
-// 2 bf16x6 256-tile (gemm_x6c.hip).
+// Kernel and split-K choice of one m3t_sgemm call.  kernel: 0 fp32-MFMA (gemm.hip), 1 the 16-bit-term 128-tile kernels
+// (gemm_x6.hip / gemm_x6d.hip: fp16x3, bf16x6, "high", bf16).
 struct GemmPlan { int kernel, splits, kchunk, narrow; };
 
 static int narrow_mode() { return 1; }
@@ -585,33 +580,6 @@ static GemmPlan plan_gemm(int transA, int M, int N, int K, int seg_len, bool vec
             double t = (double)rounds * ((double)K / sp) * ns_per_k * (rounds == 1 ? 1.3 : 1.0);
             if (sp > 1) t += (double)(sp + 2) * M * N * 4.0 / 3000.0 + 3000.0;
             if (t < best) { best = t; splits = sp; }
-        }
-    }
-    // 256 x 256 tiles (gemm_x6c.hip), one workgroup per CU, only for callers that have the chip to themselves
-    // (M3T_GEMM_EXCLUSIVE).  Which kernel: calibrated time models (us) of both, fitted to tools/gemm_bench.py on MI355X --
-    // x6c: 17 + rounds x (13 + 0.130 K/split); x6: 12 + 1.2 x its model above (x 1.12 with a row-contiguous A); slabs:
-    // 0.3 x their traffic at 3 TB/s + 3.  x6c needs a grid that fills whole rounds of 256 CUs: M = 9600 is 37.5 tiles, so
-    // N = 1536 (228 tiles) suits it and N = 1024 / 2048 (152 / 304) do not.
-    if (x6 && !n64 && !high && !f16x3 && x6c_mode() != 0 && (flags & M3T_GEMM_EXCLUSIVE) && !(flags & M3T_GEMM_BACKGROUND)) {
-        const int tiles_b = cdiv(M, 256) * cdiv(N, 256);
-        const double per_k = bf16 ? 0.052 : 0.130;
-        const double slab = (double)M * N * 4.0 / 3000.0 / 1e3;          // us per slab pass
-        int sb = 1;
-        double best_b = 1e30;
-        for (int sp = 1; sp <= 96 && (sp == 1 || (K >= 512 && sp <= K / 96 && (size_t)sp <= cap)); ++sp) {
-            const int rounds = cdiv(tiles_b * sp, 256);
-            double t = 17.0 + rounds * (13.0 + ((double)K / sp) * per_k);
-            if (sp > 1) t += 0.3 * (sp + 2) * slab + 3.0;
-            if (t < best_b) { best_b = t; sb = sp; }
-        }
-        const int rounds = cdiv(tiles * splits, 256);
-        double best_a = 12.0 + 1.2 * rounds * ((double)K / splits) * ns_per_k * 1e-3 * (rounds == 1 ? 1.3 : 1.0) * (transA ? 1.12 : 1.0);
-        if (splits > 1) best_a += 0.3 * (splits + 2) * slab + 3.0;
-        if (x6c_mode() == 1 || best_b < best_a) {
-            int kc = cdiv(cdiv(K, sb), 32) * 32;
-            if (kc < 32) kc = 32;
-            g.kernel = 2; g.kchunk = kc; g.splits = cdiv(K, kc);
-            return g;
         }
     }
     int kchunk = cdiv(cdiv(K, splits), kq) * kq;
@@ -672,10 +640,7 @@ extern "C" int m3t_sgemm_scaled(int transA, int transB, int M, int N, int K, con
             const int rm = m3t_f16x3_measure(ra, amax_a, rb, amax_b, &use_a, &use_b, s);
             if (rm) return rm;
         }
-        if (g.kernel == 2)
-            rc = m3t_sgemm_x6c_launch(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, seg_len, seg_stride,
-                                      a_off, b_off, ws, splits, kchunk, p.bf16, s);
-        else if (!g.narrow && (!f16x3 || f16x3_on_x6d()) && !(flags & (M3T_GEMM_BACKGROUND | M3T_GEMM_HIGH)) && (x6d_mode() == 1 || (x6d_mode() == 2 && !(flags & M3T_GEMM_BESIDE_SCAN))))      // ("high": measured better on gemm_x6.hip)
+        if (!g.narrow && (!f16x3 || f16x3_on_x6d()) && !(flags & (M3T_GEMM_BACKGROUND | M3T_GEMM_HIGH)) && (x6d_mode() == 1 || (x6d_mode() == 2 && !(flags & M3T_GEMM_BESIDE_SCAN))))      // ("high": measured better on gemm_x6.hip)
             // the same product, software-pipelined inside each wave (gemm_x6d.hip): bit-identical results, 8-28 % faster
             rc = m3t_sgemm_x6d_launch(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, seg_len, seg_stride,
                                       a_off, b_off, ws, splits, kchunk, p.bf16 ? 1 : ((flags & M3T_GEMM_HIGH) ? 2 : (f16x3 ? 3 : 0)), use_a, use_b, s);

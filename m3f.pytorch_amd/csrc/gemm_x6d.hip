@@ -6,7 +6,7 @@
 // to the scheduler to place in the shadow of the 24 MFMAs of stage t (a dependent MFMA leaves ~7 issue slots; the split needs ~4 VALU /
 // LDS instructions per MFMA); ONE barrier per stage, no vmcnt(0) in the loop.  Same exact 3-term split, same six products smallest
 // first, same XCD-contiguous tile order, same deterministic split-K slabs, same (row, k-octet) 16-B LDS records (one ds_read_b128
-// per fragment) as gemm_x6.hip / gemm_x6c.hip, whose loaders this file shares in 256-thread form: results are bit-identical to
+// per fragment) as gemm_x6.hip, whose loaders this file shares in 256-thread form: results are bit-identical to
 // gemm_x6.hip's.  130 VGPRs, 51 KiB of LDS: three workgroups per CU, and two fit beside a persistent scan workgroup.
 // Measured (tools/x6d_bench.py, tools/gemm_bench.py): 9600 x 1536 x 1024 NT 226 -> 177 us (171 TFLOP/s algorithmic), 2048^3 118 -> 95 us.
 #include "common.h"

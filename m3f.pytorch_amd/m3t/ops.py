@@ -304,7 +304,7 @@ def measure_amax(items):
 
 
 def sgemm_plan(transA, M, N, K, seg_len=0, exclusive=False, prec=None, ws_bytes=_WS_MIN):
-    """(kernel, splits) m3t_sgemm would use: kernel 0 fp32-MFMA, 1 bf16x6 128-tile, 2 bf16x6 256-tile."""
+    """(kernel, splits) m3t_sgemm would use: kernel 0 fp32-MFMA, 1 the 16-bit-term tile kernels (gemm_x6.hip / gemm_x6d.hip)."""
     k, sp = C.c_int(0), C.c_int(0)
     flags = (_PREC[0] if prec is None else prec) | (_lib.M3T_GEMM_EXCLUSIVE if exclusive else 0)
     _lib.check(lib().m3t_sgemm_plan(transA, M, N, K, seg_len, ws_bytes, flags, C.byref(k), C.byref(sp)), "m3t_sgemm_plan")

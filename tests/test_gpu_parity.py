@@ -88,62 +88,6 @@ def _check_sgemm(M, N, K, tA, tB):
     close(out2, np.maximum(ref + bias, 0) + C0, 2e-5 * max(1, K ** 0.5 / 8), "bias+relu+acc")
 
 
-@pytest.mark.parametrize("M,N,K", [(9600, 1536, 512), (1536, 512, 9600), (2048, 2048, 2048), (9600, 512, 2048)])
-@pytest.mark.parametrize("tA,tB", [(0, 1), (0, 0), (1, 0), (1, 1)])
-def test_sgemm_big_tile(M, N, K, tA, tB):
-    """M3T_GEMM_EXCLUSIVE: shapes the planner gives to the 256 x 256-tile bf16x6 kernel (ragged last row tile at M = 9600,
-    split-K slabs, all four operand layouts) -- same accuracy bar as the 128-tile kernel, and identical results run to run."""
-    from m3t import ops
-    with ops.precision("x6"):                # (the 256-tile kernel belongs to the six-product mode)
-        _check_sgemm_big_tile(M, N, K, tA, tB)
-
-
-def _check_sgemm_big_tile(M, N, K, tA, tB):
-    from m3t import ops
-    kern, splits = ops.sgemm_plan(tA, M, N, K, exclusive=True)
-    assert kern == 2, (kern, splits)
-    rs = np.random.RandomState(M + N * 3 + K + tA * 2 + tB)
-    A = rs.standard_normal((K, M) if tA else (M, K)).astype(np.float32)
-    B = rs.standard_normal((N, K) if tB else (K, N)).astype(np.float32)
-    bias = rs.standard_normal(N).astype(np.float32)
-    ref = (A.T if tA else A).astype(np.float64) @ (B.T if tB else B).astype(np.float64)
-    dA, dB = dev(A), dev(B)
-    out = torch.empty(M, N, device=DEV)
-    ops.sgemm(tA, tB, M, N, K, dA, 0, A.shape[1], dB, 0, B.shape[1], out, 0, N, exclusive=True)
-    close(out, ref, 2e-5 * max(1, K ** 0.5 / 8), "plain")
-    out2 = torch.empty(M, N, device=DEV)
-    ops.sgemm(tA, tB, M, N, K, dA, 0, A.shape[1], dB, 0, B.shape[1], out2, 0, N, bias=dev(bias), act=1, exclusive=True)
-    close(out2, np.maximum(ref + bias, 0), 2e-5 * max(1, K ** 0.5 / 8), "bias+relu")
-    out3 = torch.empty(M, N, device=DEV)
-    ops.sgemm(tA, tB, M, N, K, dA, 0, A.shape[1], dB, 0, B.shape[1], out3, 0, N, exclusive=True)
-    assert torch.equal(out, out3)
-
-
-def test_sgemm_big_tile_segmented():
-    """dW_hh-shaped segmented reduction (per-clip shifted rows) on the 256-tile kernel vs the 128-tile kernel: same sums."""
-    from m3t import ops
-    with ops.precision("x6"):
-        _check_sgemm_big_tile_segmented()
-
-
-def _check_sgemm_big_tile_segmented():
-    from m3t import ops
-    Bc, T, H = 32, 300, 512
-    assert ops.sgemm_plan(1, 3 * H, H, Bc * (T - 1), seg_len=T - 1, exclusive=True)[0] == 2
-    rs = np.random.RandomState(11)
-    dgh = dev(rs.standard_normal((Bc * T, 3 * H)).astype(np.float32))
-    out = dev(rs.standard_normal((Bc * T, 2 * H)).astype(np.float32))
-    for d, (a_off, b_off) in enumerate([(1, 0), (0, 1)]):
-        got = torch.empty(3 * H, H, device=DEV)
-        ref = torch.empty(3 * H, H, device=DEV)
-        ops.sgemm(1, 0, 3 * H, H, Bc * (T - 1), dgh, 0, 3 * H, out, d * H, 2 * H, got, 0, H, seg=(T - 1, T, a_off, b_off), exclusive=True)
-        ops.sgemm(1, 0, 3 * H, H, Bc * (T - 1), dgh, 0, 3 * H, out, d * H, 2 * H, ref, 0, H, seg=(T - 1, T, a_off, b_off))
-        a, b = dgh.view(Bc, T, 3 * H), out.view(Bc, T, 2 * H)[:, :, d * H:(d + 1) * H]
-        exact = torch.einsum("btg,bth->gh", a[:, a_off:a_off + T - 1].double(), b[:, b_off:b_off + T - 1].double())
-        close(got, exact.cpu().numpy(), 2e-5 * (Bc * T) ** 0.5 / 8, "seg dir %d" % d)
-        close(got, ref.cpu().numpy(), 1e-3, "vs 128-tile dir %d" % d)
-
-
 def test_sgemm_strided_and_segmented():
     """column-sliced operands (lda/ldc > width) and the per-clip segment map used for dW_hh."""
     from m3t import ops

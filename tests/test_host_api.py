@@ -80,8 +80,8 @@ def test_persistent_scan_prefetch_is_not_copied_in_flight(tmp_path):
     # the coalesced hand-over) carries the prologue's and both loop bodies' prefetch blocks
     n_kernels = len(set(re.findall(r"^(_ZN7m3t_gru\w*gru_persist_\w+_kernel\w+):", open(lst).read(), re.M)))
     assert n_kernels >= 29 and sum(1 for c in checked if c >= 3) == n_kernels, r.stdout      # 26 of round 3 + wide fp16x3 forward + wide producer-split backward (+ its profiling instantiation)
-    assert ops.sgemm_plan(0, 9600, 1536, 1024) [0] == 1 and ops.sgemm_plan(0, 9600, 1536, 1024, exclusive=True, prec=0)[0] == 2
-    assert ops.sgemm_plan(0, 9600, 1536, 1024, exclusive=True)[0] == 1       # the default (fp16x3) products run on the 128-tile kernel
+    assert ops.sgemm_plan(0, 9600, 1536, 1024) [0] == 1 and ops.sgemm_plan(0, 9600, 1536, 1024, exclusive=True, prec=0)[0] == 1
+    assert ops.sgemm_plan(0, 9600, 1536, 1024, exclusive=True)[0] == 1       # every interior shape runs on the 128-tile kernels (the 256-tile kernel is gone)
     assert ops.sgemm_plan(0, 300, 257, 130)[0] == 0
 
 
