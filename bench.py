@@ -157,7 +157,7 @@ def aux_child(which, steps=6, warmup=2):
                  timed(step16, 30), "bf16 operands, f32 accumulate")
     if "c3x6" in which:
         # the MAIN workload with the round-2 arithmetic -- every GEMM / conv / recurrent product from three bf16 terms and six MFMAs
-        # (ops.precision("x6")) -- on the same box in the same run: what the default's two-fp16-term products
+        # (ops.precision("x6")) -- on the same box in the same run: what the default's two-fp16-term products (DESIGN.md section 7 / NOTEBOOK.md section 5e)
         # are worth.  Both modes are fp32-accurate; `value` is the default's.
         from m3t.workloads import AVFeatureGraph, make_c3_step
         torch.manual_seed(12345)

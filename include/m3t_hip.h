@@ -61,7 +61,7 @@ extern "C" {
  * largest magnitude into [2^14, 2^15) -- the library measures max |A|, max |B| with one extra launch in front of the GEMM, on the
  * same stream, no host round trip -- and unscaling in the epilogue (exact).  Elements more than 2^17 below their operand's maximum
  * keep an absolute error of 2^-40 of that maximum instead of a relative one.  Measured against fp64 the mode is as accurate as the
- * six-product form (fewer fp32 accumulate roundings per k) -- DESIGN.md section 5e.  Interior shapes only; the BF16 and HIGH flags
+ * six-product form (fewer fp32 accumulate roundings per k) -- DESIGN.md section 7.  Interior shapes only; the BF16 and HIGH flags
  * win if set.  m3t_gru_scan_fwd / m3t_gru_scan_bwd take the flag too: the forward persistent scans then form their recurrent product from
  * two fp16 terms (h is bounded by 1; W_hh is scaled per workgroup slice by the scan's own prep launch), the H = 512 backward
  * persistent scans run the producer-split kernel (two fp16 terms per exchanged value, scaled per producer tile); both fp32-accurate,

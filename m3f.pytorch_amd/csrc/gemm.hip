@@ -522,7 +522,7 @@ int m3t_sgemm_x6d_launch(int transA, int transB, int M, int N, int K, const floa
 // Kernel choice among the bf16x6 GEMMs (round 3: the A/B switches M3T_GEMM_X6D / _X6C / _NARROW / _SPLITS are retired, their
 // outcomes are the rules below): the 128-tile GEMMs run on the software-pipelined gemm_x6d.hip, EXCEPT those issued beside
 // another stream's persistent scan (M3T_GEMM_BESIDE_SCAN: a kernel with a higher request rate takes from the scans' exchange what
-// it gains), which keep gemm_x6.hip; the 128 x 64 tile for N % 64 == 0 and under-filled grids.  (The 256 x 256-tile
+// it gains, NOTEBOOK.md section 5c), which keep gemm_x6.hip; the 128 x 64 tile for N % 64 == 0 and under-filled grids.  (The 256 x 256-tile
 // gemm_x6c.hip of rounds 2-3 is gone: it had no fp16x3 form, so the default mode never ran it.)
 static int x6d_mode() { return 2; }
 

@@ -286,7 +286,7 @@ __global__ void wfrag6_prep_kernel(const float* __restrict__ w_hh, unsigned shor
     }
 }
 
-// fp16x3 form of the forward recurrent product (M3T_GEMM_F16X3): h_t is bounded by 1, so the producers publish it
+// fp16x3 form of the forward recurrent product (M3T_GEMM_F16X3, DESIGN.md section 7 / NOTEBOOK.md section 5e): h_t is bounded by 1, so the producers publish it
 // as two fp16 terms of 2^14 h; W_hh is split into two fp16 terms per workgroup slice (the 48 gate rows of 16 hidden units), scaled by the
 // power of two that puts the slice's largest magnitude into [2^14, 2^15) -- one block per slice measures it and writes
 // wfrag3h[ub][wave][s][ct][t < 2][lane][8 fp16] plus inv[ub] = 2^-14 / scale, by which the slice's workgroups unscale their sums.
@@ -343,7 +343,7 @@ typedef _Float16 pf16x8 __attribute__((ext_vector_type(8)));
 // workgroup (h_{t-1} of its 16 rows: the A operand is shared by both unit tiles), twice the W_hh fragments, MFMAs and cells, all eight
 // waves do cell math (waves 0-3 tile 0, waves 4-7 tile 1; the two tiles are adjacent in the exchange buffer, so the consumers' gather
 // code does not change) -- and a level needs HALF the workgroups: the 4 x H=512 encoder level runs on 128 CUs and leaves room for
-// the audio stack's 64-workgroup scans beside it (DESIGN.md section 5f).
+// the audio stack's 64-workgroup scans beside it (DESIGN.md section 5).
 // CO (the wide form only): the cell threads' HBM traffic goes through threads numbered in MEMORY order -- thread ti of a tile loads / stores
 // the activations of cell (row ti >> 4, unit ti & 15), so a wave instruction covers 4 rows x 16 consecutive units (64-byte / 256-byte
 // runs) instead of 64 scattered sectors -- and LDS carries them to / from the cell-math threads (granule order), results one step late.
@@ -921,7 +921,7 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd6_kernel(BwdGroup g, FragPt
         for (int i = 0; i < 6; ++i) ex.prof[i] = (unsigned long long)psum[i];
 }
 
-// ---- producer-side operand split (gru_persist_bwd3p_kernel) --------------------------------------------------
+// ---- producer-side operand split (gru_persist_bwd3p_kernel, DESIGN.md section 7 / NOTEBOOK.md section 5e) --------------------------------------------------
 // The shipped six-product backward step is bound by its consumers' operand split (264 VALU instructions per lane and step, redone by
 // all 32 workgroups of a group on the same 16 x 1536 values).  Here each PRODUCER splits its own three values (dr~, dz~, dn~ r) into two
 // fp16 terms, scaled by the power of two of its tile's largest magnitude (16 rows x 16 units x 3 values: exact, so nothing can
@@ -1727,7 +1727,7 @@ bool persist_bwd_uses_x6(const BwdGroup& g, int B, int T, int flags) {
 }
 
 // M3T_SCAN_WIDE=0: keep one 16-unit tile per workgroup for the H = 512 levels in the fp16x3 mode (the round-3 geometry: 256 workgroups for
-// the encoder level) instead of the wide kernels (two tiles per workgroup, half the workgroups; DESIGN.md section 5f)
+// the encoder level) instead of the wide kernels (two tiles per workgroup, half the workgroups; DESIGN.md section 5)
 static bool wide_enabled() {
     static int on = -1;
     if (on < 0) { const char* e = getenv("M3T_SCAN_WIDE"); on = (e && e[0] == '0') ? 0 : 1; }
@@ -1812,7 +1812,7 @@ int persist_fwd_launch(const FwdGroup& g, const FragPtrs& fp, int B, int T, int 
 }
 
 // M3T_SCAN_BWD3P=0: the six-product backward scan (consumer-side split) for the H = 512 levels also in the fp16x3 mode, instead of the
-// producer-split kernel (gru_persist_bwd3p_kernel: 3.85 -> 3.44 us per step at 4 x H=512)
+// producer-split kernel (gru_persist_bwd3p_kernel: 3.85 -> 3.44 us per step at 4 x H=512, DESIGN.md section 7 / NOTEBOOK.md section 5e)
 static bool bwd3p_enabled() {
     static int on = -1;
     if (on < 0) { const char* e = getenv("M3T_SCAN_BWD3P"); on = (e && e[0] == '0') ? 0 : 1; }
@@ -1834,7 +1834,7 @@ int persist_bwd_launch(const BwdGroup& g, const FragPtrs& fp, int B, int T, int 
     // fp32 mode with M3T_GEMM_F16X3: the producer-split kernel (two fp16 terms per value in the granule, 24-bit tags + the tile's exponent)
     const bool p3 = !b16 && persist_bwd_uses_x6(g, B, T, flags) && (flags & M3T_GEMM_F16X3) && m3t_f16x3_enabled() && bwd3p_enabled() &&
                     sh.nc == 4 && (unsigned long long)T + 1 < 0xffffffull;      // (H = 256: 2.40 -> 2.50 us per step, keeps the six-product kernel)
-    const int uw = ((flags & M3T_SCAN_WIDE) && p3 && sh.rt == 1 && wide_enabled()) ? 2 : 1;      // wide workgroups: two unit tiles each, half the grid (DESIGN.md section 5f)
+    const int uw = ((flags & M3T_SCAN_WIDE) && p3 && sh.rt == 1 && wide_enabled()) ? 2 : 1;      // wide workgroups: two unit tiles each, half the grid (DESIGN.md section 5)
     if (uw > 1) {
         if (!level_shape(g.d, g.n, B, sh, uw)) return M3T_EINVAL;
         ex.slot_map = sh.slot_map;

@@ -137,7 +137,7 @@ def _p(t, off=0):
 
 
 # ---- streams of the step's schedule --------------------------------------------------------------------------------
-# Round 3 retired the A/B switches of rounds 1-2 whose outcome is decided (DESIGN.md section 5c lists each with its measured
+# Round 3 retired the A/B switches of rounds 1-2 whose outcome is decided (NOTEBOOK.md section 5c lists each with its measured
 # result): the schedule below is THE schedule.  What is left as a process-wide switch is listed in README.md (<= 10).
 #   * side stream: independent light-weight stacks run beside the main chain (_stream_groups); with two H-groups of persistent
 #     scans (gru_v|gru_a at H=512, audio at H=256) the light group's scans and GEMMs go there, fenced by events so that no two
@@ -223,7 +223,7 @@ def workspace(device, nbytes=_WS_MIN, tag=None):
 # ----------------------------------------------------------------------------- raw wrappers
 # ---- arithmetic mode of the dense contractions --------------------------------------------------------------------
 # "fp32" (default): fp32-accurate everywhere (what the reference computes): the GEMMs and implicit-GEMM convolutions form every
-# product from two fp16 terms per (scaled) operand -- three MFMAs, M3T_GEMM_F16X3, DESIGN.md section 5e -- the recurrent scans from
+# product from two fp16 terms per (scaled) operand -- three MFMAs, M3T_GEMM_F16X3, DESIGN.md section 7 / NOTEBOOK.md section 5e -- the recurrent scans from
 # three bf16 terms (six MFMAs).  "x6": the GEMMs and convolutions on the six-product bf16 form too (the default until round 3; the
 # library's own default when called with flags = 0; env M3T_GEMM_F16X3=0 forces it).  "high": opt-in, the GEMMs and convolutions
 # treat each fp32 operand as the sum of two bfloat16 numbers (four products, ~2^-16 relative error per term -- what

@@ -1,4 +1,4 @@
-"""CPU model of the fp16x3 product (M3T_GEMM_F16X3): numpy restatement of what the GEMM kernels do to their
+"""CPU model of the fp16x3 product (M3T_GEMM_F16X3, DESIGN.md section 7 / NOTEBOOK.md section 5e): numpy restatement of what the GEMM kernels do to their
 operands -- power-of-two scale from the operand's largest magnitude (m3t_f16_scale in csrc/common.h), two fp16 terms, three exact
 products, fp32 accumulation per 16-deep MFMA -- against fp64, next to the same model of the six-product bf16 form and of a sequential
 fp32 FMA chain.  The GPU tests check the kernels; this pins the ARITHMETIC the design relies on, on the CPU."""

@@ -10,7 +10,7 @@
 //                     (a tile's exchange flight is covered by the other tile's compute phase)
 // Both advance the same 8 + 8 exchange groups (16 rows x 512 units x 3 values per group and step): us per step is comparable.
 // Also printed: the compute phase alone (mode 0: no exchange), so the compute load can be calibrated against the real kernel's
-// stamps (split + MFMA 0.70 us per wave).
+// stamps (split + MFMA 0.70 us per wave, NOTEBOOK.md section 5a).
 //   hipcc -O3 --offload-arch=gfx950 tools/skew_probe.hip -o tools/bin/skew_probe && tools/bin/skew_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
