@@ -76,6 +76,14 @@ extern "C" {
  * six-product mode; it had no fp16x3 form and was removed in round 4 -- the flag is accepted and currently changes nothing. */
 #define M3T_GEMM_EXCLUSIVE 8
 
+/* Patch matrix (im2col) of a Conv3d input x [N, Ci, T, H, W] for the weight-gradient GEMM dW = dy^T P of the 3-D conv stems (reference
+ * models/backbone.py:73-103,179-271,327-332; forward and data gradient stay on MIOpen): out [rows_pad, Kp] row-major, row = (n, t', h', w'),
+ * column = (ci, kt, kh, kw) -- the order of weight.view(Co, -1) -- zero for the convolution's padding, for columns >= Ci kt kh kw and for
+ * rows >= N T' H' W' (tile padding of the GEMM).  Kp % 4 == 0, out 16-B aligned.  amax_slot (optional): raised to the bits of max |P|
+ * (a magnitude slot of m3t_sgemm_scaled, zero-initialised by the caller).  One launch. */
+int m3t_im2col3d(const float* x, int N, int Ci, int T, int H, int W, int kt, int kh, int kw, int st, int sh, int sw,
+                 int pt, int ph, int pw, float* out, long long rows_pad, int Kp, unsigned long long* amax_slot, void* stream);
+
 /* library / device info: returns the ABI version; arch string copied to `arch` if non-null */
 int m3t_version(void);
 int m3t_device_arch(char* arch, int cap);

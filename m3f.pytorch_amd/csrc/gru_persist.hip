@@ -1416,7 +1416,10 @@ bool level_shape(const D* d, int n, int B, Shape& sh, int uw = 1) {      // uw: 
 #endif
             constexpr int l2 = M3T_SCAN_L2_MODE;
             sh.rt = rt; sh.nrb = nrb; sh.G = G; sh.active = active;
-            sh.slot_map = (l2 == 1 || (l2 == 2 && G % 8 == 0)) ? 1 : 0;
+            // round 4: a WIDE launch with fewer than 8 groups puts each group on an XCD of its own as well (16 of its 32 CUs: the GEMMs beside
+            // it still find CUs on every XCD, which is what sank this placement for the narrow 32-member groups in round 3): fusion level
+            // backward 3.29 -> 3.15 us per step, its exchange served by L2 (traffic 2.5x -> ~1.1x algorithmic)
+            sh.slot_map = (l2 == 1 || (l2 == 2 && G % 8 == 0) || (uw > 1 && G <= 8)) ? 1 : 0;
             sh.grid = sh.slot_map ? 8 * cdiv(G, 8) * members : active;
             break;
         }

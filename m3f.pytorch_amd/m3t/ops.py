@@ -924,6 +924,10 @@ class _MultiBiGRU(torch.autograd.Function):
             return None if fslots is None else fslots.data_ptr() + 8 * (n_stacks + (l * n_stacks + s) * 2 + d)
 
         def level_scan(l, idxs, after=None, wide=False):
+            """every BACKWARD level asks for the wide form (the library applies it where it exists: H = 512 in the fp16x3 mode), not only
+            the level that makes room for the audio scans: the wide backward kernel is no slower than the narrow one on half the CUs
+            (fusion level 3.15 vs 3.30 us per step, exchange served by one XCD's L2) and the weight-gradient GEMMs get the rest;
+            forward, the wide form costs 0.2 us per step (2.49 vs 2.30) and only the level that must make room takes it"""
             descs = []
             for s in idxs:
                 H = Hs[s]
@@ -940,7 +944,7 @@ class _MultiBiGRU(torch.autograd.Function):
                                             _vp(dgx[l][s]), _vp(dgh[l][s], d * B * T * 3 * H), _vp(dh[l][s], d * B * H),
                                             _vp(dbp[l][s], d * B * 4 * H), _vp(out_grads[base + 2]), _vp(out_grads[base + 3]),
                                             H, d, out.stride(1), d * H, 6 * H, d * 3 * H, bslot(l, s, d)))      # (dout and out share the layout)
-            _scan_bwd(descs, B, T, prec | (_lib.M3T_SCAN_WHH if direct_whh else 0) | (_lib.M3T_SCAN_WIDE if wide else 0), after)
+            _scan_bwd(descs, B, T, prec | (_lib.M3T_SCAN_WHH if direct_whh else 0) | _lib.M3T_SCAN_WIDE, after)
             if RANGE_PROBE[0] is not None:
                 for s in idxs:
                     for d in (0, 1):
@@ -1709,32 +1713,41 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
             rows = dy_cl.numel() // Co
         if ctx.needs_input_grad[1]:
             Kc = Ci * kt * kh * kw
-            xp = torch.nn.functional.pad(x, (pd[2], pd[2], pd[1], pd[1], pd[0], pd[0])) if any(pd) else x
-            pat = xp.unfold(2, kt, st[0]).unfold(3, kh, st[1]).unfold(4, kw, st[2])   # [N,Ci,T',H',W',kt,kh,kw] (view)
-            pat = pat.permute(0, 2, 3, 4, 1, 5, 6, 7)
+            N_, _, T_, H_, W_ = x.shape
+            xc = _req(x.contiguous(), "x")
+            # round 4: ONE launch writes the patch matrix (rows (n, t', h', w'), columns (ci, kt, kh, kw), zero padded to the GEMM's tiles)
+            # and raises its magnitude slot -- was ~50 torch copy kernels per convolution plus a measuring pass
+            slot = amax_slots(1, x.device)
+
+            def im2col(rows_p, Kp):
+                pat_ = torch.empty(rows_p, Kp, dtype=torch.float32, device=x.device)
+                _lib.check(lib().m3t_im2col3d(_p(xc), N_, Ci, T_, H_, W_, kt, kh, kw, st[0], st[1], st[2], pd[0], pd[1], pd[2], _p(pat_),
+                                              rows_p, Kp, C.c_void_p(slot.data_ptr()), _stream()), "m3t_im2col3d")
+                return pat_
+
             if Co % 128 == 0 and Kc % 64 == 0:
-                pat = _req(pat.reshape(rows, Kc), "patches")
+                pat = im2col(rows, Kc)
                 dw = torch.empty_like(w)
-                sgemm(1, 0, Co, Kc, rows, dy_cl, 0, Co, pat, 0, Kc, dw, 0, Kc)
+                sgemm(1, 0, Co, Kc, rows, dy_cl, 0, Co, pat, 0, Kc, dw, 0, Kc, amax=(None, slot.data_ptr()))
             elif Co % 64 == 0:
                 # the stems' FIRST layers: C_out = 64 and C_in k^3 = 81 (VGG-M) / 735 (3-D ResNet) fit no interior tile of the
-                # bf16x6 GEMM as dW = dy^T P and fell to the fp32-MFMA kernel (8.9 % of a C5 step).  Transposed and
-                # padded they do: dW^T [Kp, Co] = P_pad^T dy with Kp = ceil128(C_in k^3) (zero columns in the patch matrix, which
-                # is a copy anyway) and rows padded to a multiple of 32 -> the 128 x 64 tile, split-K over the ~1.5 M rows
+                # 16-bit-term GEMM as dW = dy^T P.  Transposed and padded they do: dW^T [Kp, Co] = P_pad^T dy with Kp = ceil128(C_in k^3)
+                # (zero columns) and rows padded to a multiple of 32 -> the 128 x 64 tile, split-K over the ~1.5 M rows
                 Kp, rows_p = (Kc + 127) // 128 * 128, (rows + 31) // 32 * 32
-                pat_pad = torch.zeros(rows_p, Kp, dtype=torch.float32, device=x.device)
-                pat_pad[:rows, :Kc].view(pat.shape).copy_(pat)          # ONE strided copy: the im2col itself
+                pat_pad = im2col(rows_p, Kp)
                 dyp = dy_cl
                 if rows_p != rows:
                     dyp = torch.zeros(rows_p, Co, dtype=torch.float32, device=x.device)
                     dyp[:rows].copy_(dy_cl.view(rows, Co))
                 dwt = torch.empty(Kp, Co, dtype=torch.float32, device=x.device)
-                sgemm(1, 0, Kp, Co, rows_p, pat_pad, 0, Kp, dyp, 0, Co, dwt, 0, Co)
+                sgemm(1, 0, Kp, Co, rows_p, pat_pad, 0, Kp, dyp, 0, Co, dwt, 0, Co, amax=(slot.data_ptr(), None))
                 dw = dwt[:Kc].t().contiguous().view_as(w)
             else:
-                pat = _req(pat.reshape(rows, Kc), "patches")
-                dw = torch.empty_like(w)
-                sgemm(1, 0, Co, Kc, rows, dy_cl, 0, Co, pat, 0, Kc, dw, 0, Kc)
+                Kp = (Kc + 3) // 4 * 4
+                pat = im2col(rows, Kp)
+                dwp = torch.empty(Co, Kp, dtype=torch.float32, device=x.device)
+                sgemm(1, 0, Co, Kp, rows, dy_cl, 0, Co, pat, 0, Kp, dwp, 0, Kp, amax=(None, slot.data_ptr()))
+                dw = dwp[:, :Kc].contiguous().view_as(w)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = torch.empty(Co, dtype=torch.float32, device=dy.device)
             colsum(dy_cl, 0, rows, Co, Co, db)
