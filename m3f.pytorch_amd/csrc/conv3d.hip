@@ -17,44 +17,71 @@ struct Im2colArgs {
     long long rows, rows_pad;
 };
 
-__global__ __launch_bounds__(256) void im2col3d_kernel(Im2colArgs a) {
-    const long long q4 = (long long)(a.Kp >> 2);                 // float4 groups per row
-    const long long total = a.rows_pad * q4;
+// A block takes RPB consecutive output positions per pass.  Column table (per block, LDS): offset of (ci, dt, dh, dw) inside a sample and the
+// packed (dt, dh, dw); row table (per pass, LDS): offset of the patch origin and the packed origin (t0, h0, w0) -- so that an element costs
+// two LDS reads, three range checks and one (cached) load instead of a dozen integer divisions; 16-byte stores, consecutive threads on
+// consecutive columns of a row.
+constexpr int IM_MAXROWS = 64;
+__global__ __launch_bounds__(256) void im2col3d_kernel(Im2colArgs a, int rpb) {
+    extern __shared__ int cm[];                                  // [Kp] offsets, [Kp] packed (dt, dh, dw) (or -1: padding column)
+    int* coff = cm;
+    int* cpos = cm + a.Kp;
+    __shared__ long long rbase[IM_MAXROWS];
+    __shared__ int rt0[IM_MAXROWS], rh0[IM_MAXROWS], rw0[IM_MAXROWS];
+    const int tid = threadIdx.x;
     const int khw = a.kh * a.kw, kvol = a.kt * khw;
+    for (int c = tid; c < a.Kp; c += 256) {
+        if (c < a.Kc) {
+            const int ci = c / kvol, rem = c - ci * kvol;
+            const int dt = rem / khw, rem2 = rem - dt * khw;
+            const int dh = rem2 / a.kw, dw = rem2 - dh * a.kw;
+            coff[c] = ((ci * a.T + dt) * a.H + dh) * a.W + dw;
+            cpos[c] = (dt << 20) | (dh << 10) | dw;
+        } else { coff[c] = 0; cpos[c] = -1; }
+    }
+    const int q4 = a.Kp >> 2, items = rpb * q4;
+    const long long sample = (long long)a.Ci * a.T * a.H * a.W;
     float mx = 0.f;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const long long row = i / q4;
-        const int c0 = (int)(i - row * q4) * 4;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (row < a.rows) {
-            long long r = row;
-            const int wo = (int)(r % a.Wo); r /= a.Wo;
-            const int ho = (int)(r % a.Ho); r /= a.Ho;
-            const int to = (int)(r % a.To);
-            const int n = (int)(r / a.To);
-            const float* xn = a.x + (size_t)n * a.Ci * a.T * a.H * a.W;
+    for (long long row0 = (long long)blockIdx.x * rpb; row0 < a.rows_pad; row0 += (long long)gridDim.x * rpb) {
+        __syncthreads();                                         // (column table ready; previous pass done with the row table)
+        if (tid < rpb) {
+            const long long row = row0 + tid;
+            if (row < a.rows) {
+                const int hw = a.Ho * a.Wo;
+                const long long nt = row / hw;
+                const int r2 = (int)(row - nt * hw);
+                const int ho = r2 / a.Wo, wo = r2 - ho * a.Wo;
+                const int n = (int)(nt / a.To), to = (int)(nt - (long long)n * a.To);
+                const int t0 = to * a.st - a.pt, h0 = ho * a.sh - a.ph, w0 = wo * a.sw - a.pw;
+                rt0[tid] = t0; rh0[tid] = h0; rw0[tid] = w0;
+                rbase[tid] = (long long)n * sample + ((long long)t0 * a.H + h0) * a.W + w0;
+            } else { rt0[tid] = -(1 << 28); rh0[tid] = 0; rw0[tid] = 0; rbase[tid] = 0; }      // padding row: every range check fails
+        }
+        __syncthreads();
+        for (int it = tid; it < items; it += 256) {
+            const int rs = it / q4, c0 = (it - rs * q4) * 4;
+            const long long row = row0 + rs;
+            if (row >= a.rows_pad) break;
+            const int t0 = rt0[rs], h0 = rh0[rs], w0 = rw0[rs];
+            const float* xb = a.x + rbase[rs];
+            float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int c = c0 + e;
-                if (c < a.Kc) {
-                    const int ci = c / kvol, rem = c - ci * kvol;
-                    const int dt = rem / khw, rem2 = rem - dt * khw;
-                    const int dh = rem2 / a.kw, dw = rem2 - dh * a.kw;
-                    const int t = to * a.st + dt - a.pt, h = ho * a.sh + dh - a.ph, w = wo * a.sw + dw - a.pw;
-                    if (t >= 0 && t < a.T && h >= 0 && h < a.H && w >= 0 && w < a.W)
-                        v[e] = xn[(((size_t)ci * a.T + t) * a.H + h) * a.W + w];
-                }
+                const int p = cpos[c0 + e];
+                const int t = t0 + (p >> 20), h = h0 + ((p >> 10) & 1023), w = w0 + (p & 1023);
+                const bool ok = p >= 0 && (unsigned)t < (unsigned)a.T && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
+                v[e] = ok ? xb[coff[c0 + e]] : 0.f;
             }
+            *reinterpret_cast<float4*>(a.out + (size_t)row * a.Kp + c0) = make_float4(v[0], v[1], v[2], v[3]);
+            mx = fmaxf(fmaxf(mx, m3t_fin_abs(v[0])), fmaxf(m3t_fin_abs(v[1]), fmaxf(m3t_fin_abs(v[2]), m3t_fin_abs(v[3]))));
         }
-        *reinterpret_cast<float4*>(a.out + (size_t)row * a.Kp + c0) = make_float4(v[0], v[1], v[2], v[3]);
-        mx = fmaxf(fmaxf(mx, m3t_fin_abs(v[0])), fmaxf(m3t_fin_abs(v[1]), fmaxf(m3t_fin_abs(v[2]), m3t_fin_abs(v[3]))));
     }
     if (a.slot) {
         __shared__ float red[4];
         mx = wave_max(mx);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+        if ((tid & 63) == 0) red[tid >> 6] = mx;
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (tid == 0) {
             const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
             if (m > 0.f) atomicMax(a.slot, (unsigned long long)__float_as_uint(m));      // (caller-owned slot: epoch 0; <= 8192 blocks)
         }
@@ -76,10 +103,20 @@ extern "C" int m3t_im2col3d(const float* x, int N, int Ci, int T, int H, int W, 
     a.Kc = Ci * kt * kh * kw; a.Kp = Kp;
     a.rows = (long long)N * a.To * a.Ho * a.Wo; a.rows_pad = rows_pad;
     if (Kp < a.Kc || rows_pad < a.rows) return M3T_EINVAL;
-    const long long total = rows_pad * (Kp / 4);
-    long long blocks = (total + 255) / 256;
-    if (blocks > 256 * 32) blocks = 256 * 32;
-    im2col3d_kernel<<<dim3((unsigned)blocks), 256, 0, (hipStream_t)stream>>>(a);
+    if (kt >= 1024 || kh >= 1024 || kw >= 1024 || (size_t)Kp * 8 > 150 * 1024) return M3T_EINVAL;      // (packed kernel offsets; column tables in LDS: C_in k^3 <= 19 200)
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(im2col3d_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) {
+            (void)hipGetLastError();
+            return M3T_EINVAL;
+        }
+        attr_set = true;
+    }
+    int rpb = 2048 / (Kp / 4);
+    rpb = rpb < 1 ? 1 : (rpb > IM_MAXROWS ? IM_MAXROWS : rpb);
+    long long blocks = (rows_pad + rpb - 1) / rpb;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    im2col3d_kernel<<<dim3((unsigned)blocks), 256, (size_t)Kp * 8, (hipStream_t)stream>>>(a, rpb);
     M3T_LAUNCH_CHECK();
     return 0;
 }
