@@ -1741,7 +1741,7 @@ static bool fwd_is_f16(const FwdGroup& g, int B, int T, int flags) {
 }
 // unit tiles per workgroup of the level's forward launch
 static int fwd_uw(const FwdGroup& g, int B, int T, int flags, const Shape& sh) {
-    return ((flags & M3T_SCAN_WIDE) && fwd_is_f16(g, B, T, flags) && sh.nc == 4 && sh.rt == 1 && wide_enabled()) ? 2 : 1;
+    return ((flags & M3T_SCAN_WIDE) && fwd_is_f16(g, B, T, flags) && (sh.nc == 4 || sh.nc == 2) && sh.rt == 1 && wide_enabled()) ? 2 : 1;
 }
 
 int persist_fwd_launch(const FwdGroup& g, const FragPtrs& fp, int B, int T, int flags, hipStream_t s) {
@@ -1790,15 +1790,15 @@ int persist_fwd_launch(const FwdGroup& g, const FragPtrs& fp, int B, int T, int 
         { const int e = persist_take_after(s); if (e) return e; }
         persist_record_start(s);
         if (f16) {
-            if (sh.nc == 2) hipLaunchKernelGGL((gru_persist_fwd6_kernel<2, true>), dim3(sh.grid), dim3(NT), exclusive_lds(gru_persist_fwd6_kernel<2, true>, sh.active), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
-            else if (uw == 2) {
+            if (uw == 2) {
                 const size_t need = (size_t)2 * NW * 2 * 3 * 16 * (UB + 1) * sizeof(float)           // the kernel's partial sums (RED_FLOATS)
                                     + (size_t)2 * 2 * 272 * 36;                                      // + the staging slots (sx, so, sh)
-                const FwdKernel kk = gru_persist_fwd6_kernel<4, true, 2>;
+                const FwdKernel kk = sh.nc == 2 ? gru_persist_fwd6_kernel<2, true, 2> : gru_persist_fwd6_kernel<4, true, 2>;
                 const size_t dyn = exclusive_lds(kk, sh.active, need);
                 if (dyn < need) return M3T_EINVAL;
                 hipLaunchKernelGGL(kk, dim3(sh.grid), dim3(NT), dyn, s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
             }
+            else if (sh.nc == 2) hipLaunchKernelGGL((gru_persist_fwd6_kernel<2, true>), dim3(sh.grid), dim3(NT), exclusive_lds(gru_persist_fwd6_kernel<2, true>, sh.active), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
             else hipLaunchKernelGGL((gru_persist_fwd6_kernel<4, true>), dim3(sh.grid), dim3(NT), exclusive_lds(gru_persist_fwd6_kernel<4, true>, sh.active), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
         }
         else if (sh.nc == 2) hipLaunchKernelGGL(gru_persist_fwd6_kernel<2>, dim3(sh.grid), dim3(NT), exclusive_lds(gru_persist_fwd6_kernel<2>, sh.active), s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
@@ -1835,8 +1835,12 @@ int persist_bwd_launch(const BwdGroup& g, const FragPtrs& fp, int B, int T, int 
         ex.poll_align = 1;
     }
     // fp32 mode with M3T_GEMM_F16X3: the producer-split kernel (two fp16 terms per value in the granule, 24-bit tags + the tile's exponent)
+    // an H = 256 level that asks for the wide form (round 4: every backward level does) takes the wide producer-split kernel too: 32
+    // workgroups, one group per XCD, L2-served exchange -- in the C3 step the audio stack's backward scans (beside the heavy level's)
+    // 0.80 / 0.96 -> 0.70 / 0.86 ms, the step 12.25 -> 12.15 ms; the NARROW producer-split form lost at H = 256 in round 3 (2.40 -> 2.50)
+    const bool wide256 = (flags & M3T_SCAN_WIDE) && sh.rt == 1 && wide_enabled();
     const bool p3 = !b16 && persist_bwd_uses_x6(g, B, T, flags) && (flags & M3T_GEMM_F16X3) && m3t_f16x3_enabled() && bwd3p_enabled() &&
-                    sh.nc == 4 && (unsigned long long)T + 1 < 0xffffffull;      // (H = 256: 2.40 -> 2.50 us per step, keeps the six-product kernel)
+                    (sh.nc == 4 || (sh.nc == 2 && wide256)) && (unsigned long long)T + 1 < 0xffffffull;      // (H = 256 narrow: 2.40 -> 2.50 us per step, keeps the six-product kernel)
     const int uw = ((flags & M3T_SCAN_WIDE) && p3 && sh.rt == 1 && wide_enabled()) ? 2 : 1;      // wide workgroups: two unit tiles each, half the grid
     if (uw > 1) {
         if (!level_shape(g.d, g.n, B, sh, uw)) return M3T_EINVAL;
@@ -1856,7 +1860,7 @@ int persist_bwd_launch(const BwdGroup& g, const FragPtrs& fp, int B, int T, int 
             M3T_LAUNCH_CHECK();
             { const int e = persist_take_after(s); if (e) return e; }
             persist_record_start(s);
-            const BwdKernel kq = ex.prof ? gru_persist_bwd3q_kernel<4, true> : gru_persist_bwd3q_kernel<4>;
+            const BwdKernel kq = sh.nc == 2 ? gru_persist_bwd3q_kernel<2> : (ex.prof ? gru_persist_bwd3q_kernel<4, true> : gru_persist_bwd3q_kernel<4>);
             const size_t need = (size_t)2 * 2 * 272 * 40;                    // the staging slots (sin4, sout, sin2)
             const size_t dyn = exclusive_lds(kq, sh.active, need);
             if (dyn < need) return M3T_EINVAL;
@@ -1968,8 +1972,9 @@ int persist_workgroups(int n, int H, int B, int T, int flags, bool backward) {
         for (int i = 0; i < n; ++i) { g.d[i].H = H; g.d[i].gates = reinterpret_cast<const float*>(16); g.d[i].w_hh_t = reinterpret_cast<const float*>(16); }
         if (solo_bwd_ok(g, B, T, flags) || !level_shape(g.d, g.n, B, sh)) return 0;
         const bool b16 = persist_bwd_uses_16(g, B, T, flags);
+        const bool wide256 = (flags & M3T_SCAN_WIDE) && sh.rt == 1 && wide_enabled();
         const bool p3 = !b16 && persist_bwd_uses_x6(g, B, T, flags) && (flags & M3T_GEMM_F16X3) && m3t_f16x3_enabled() && bwd3p_enabled() &&
-                        sh.nc == 4 && (unsigned long long)T + 1 < 0xffffffull;
+                        (sh.nc == 4 || (sh.nc == 2 && wide256)) && (unsigned long long)T + 1 < 0xffffffull;
         if ((flags & M3T_SCAN_WIDE) && p3 && sh.rt == 1 && wide_enabled() && !level_shape(g.d, g.n, B, sh, 2)) return 0;
         return sh.active;
     }

@@ -662,7 +662,7 @@ def _pair_fits(dev, n_heavy, H_heavy, n_light, H_light, B, T, prec):
         return False
     for bwd in (0, 1):
         a = lib().m3t_gru_scan_workgroups(n_heavy, H_heavy, B, T, base | _lib.M3T_SCAN_WIDE, bwd)
-        b = lib().m3t_gru_scan_workgroups(n_light, H_light, B, T, base, bwd)
+        b = lib().m3t_gru_scan_workgroups(n_light, H_light, B, T, base | _lib.M3T_SCAN_WIDE, bwd)
         if a <= 0 or b <= 0 or a + b > cus or (a + 7) // 8 + (b + 7) // 8 > cus // 8:
             return False
     return True
@@ -765,7 +765,7 @@ class _MultiBiGRU(torch.autograd.Function):
                     level_fwd(l, heavy, False)
                     with torch.cuda.stream(side):
                         level_fwd(l, light, False)
-                        level_fwd(l, light, True)
+                        level_fwd(l, light, True, None, True)      # (wide too: 32 workgroups, one group per XCD, L2-served exchange; -0.03 ms)
                     level_fwd(l, heavy, True, None, True)
             finally:
                 _FENCED[0] = False
