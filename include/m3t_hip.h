@@ -84,6 +84,12 @@ extern "C" {
 int m3t_im2col3d(const float* x, int N, int Ci, int T, int H, int W, int kt, int kh, int kw, int st, int sh, int sw,
                  int pt, int ph, int pw, float* out, long long rows_pad, int Kp, unsigned long long* amax_slot, void* stream);
 
+/* Magnitude slots from the PRODUCER (fp16x3 mode, see m3t_sgemm_scaled): the NEXT m3t_conv1d_fwd(_scaled) / m3t_mask_pos / m3t_mask_pos_drop /
+ * m3t_weight_norm_fwd call of the calling thread raises `slot` (8 bytes, zero-initialised by the caller, epoch 0) to the bits of max |x| over
+ * its output (y / out / w_t) -- in the same kernel, one 64-bit atomic max per workgroup -- so that the contraction that consumes the output
+ * needs no measuring launch.  Consumed by that call (also when it fails).  Returns 0. */
+int m3t_amax_out(unsigned long long* slot);
+
 /* library / device info: returns the ABI version; arch string copied to `arch` if non-null */
 int m3t_version(void);
 int m3t_device_arch(char* arch, int cap);

@@ -103,4 +103,20 @@ struct M3TRegion { const float* p; unsigned long long rows; unsigned long long l
 int m3t_f16x3_measure(const M3TRegion& a, const unsigned long long* have_a, const M3TRegion& b, const unsigned long long* have_b,
                       const unsigned long long** use_a, const unsigned long long** use_b, hipStream_t s);
 int m3t_absmax_regions(const M3TRegion* regs, int n, hipStream_t s);      // any n; slots raised with epoch 0 (caller-owned)
+// m3t_amax_out(slot): the NEXT m3t_conv1d_fwd(_scaled) / m3t_mask_pos / m3t_mask_pos_drop / m3t_weight_norm_fwd call of the calling thread
+// raises `slot` (a caller-owned, zero-initialised magnitude slot) to the bits of max |its output| -- the producer measures what the next
+// fp16x3 contraction will scale by, instead of a measuring launch in front of that contraction.  take: returns and clears it.
+unsigned long long* m3t_take_amax_out();
+// block-wide: one 64-bit atomic max per block (callers: every thread of a 256-thread block reaches this)
+static __device__ __forceinline__ void m3t_block_raise_slot(unsigned long long* slot, float mx, float* red4) {
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float m = fmaxf(fmaxf(red4[0], red4[1]), fmaxf(red4[2], red4[3]));
+        const unsigned long long bits = (unsigned long long)__float_as_uint(m);
+        // thousands of blocks on ONE address: only a block whose value the slot does not cover yet pays for the atomic (~12 ns each, serial)
+        if (bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, bits);
+    }
+}
 bool m3t_f16x3_enabled();                                                      // env M3T_GEMM_F16X3 != 0

@@ -83,7 +83,8 @@ __global__ __launch_bounds__(256) void im2col3d_kernel(Im2colArgs a, int rpb) {
         __syncthreads();
         if (tid == 0) {
             const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-            if (m > 0.f) atomicMax(a.slot, (unsigned long long)__float_as_uint(m));      // (caller-owned slot: epoch 0; <= 8192 blocks)
+            const unsigned long long bits = (unsigned long long)__float_as_uint(m);      // (caller-owned slot: epoch 0)
+            if (bits > __hip_atomic_load(a.slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.slot, bits);
         }
     }
 }

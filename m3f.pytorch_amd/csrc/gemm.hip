@@ -427,16 +427,24 @@ __global__ void relu_bwd_kernel(const float* __restrict__ a, float* __restrict__
         if (!(a[i] > 0.f)) dy[i] = 0.f;
 }
 
-__global__ void mask_pos_kernel(const float* __restrict__ s, const float* __restrict__ dy, const float* __restrict__ mul,
-                                float* __restrict__ out, size_t n) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        out[i] = s[i] > 0.f ? (mul ? dy[i] * mul[i] : dy[i]) : 0.f;
+__global__ __launch_bounds__(256) void mask_pos_kernel(const float* __restrict__ s, const float* __restrict__ dy, const float* __restrict__ mul,
+                                                       float* __restrict__ out, size_t n, unsigned long long* amax) {
+    float mx = 0.f;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = s[i] > 0.f ? (mul ? dy[i] * mul[i] : dy[i]) : 0.f;
+        out[i] = v;
+        mx = fmaxf(mx, m3t_fin_abs(v));
+    }
+    __shared__ float red4[4];
+    if (amax) m3t_block_raise_slot(amax, mx, red4);
 }
 
 // out = (s > 0) ? dy * dropout-mask(row, col) : 0 with the mask REGENERATED from (seed, row, col) (common.h): the backward of
 // ReLU -> Dropout without a mask tensor.  One thread: 4 consecutive rows x 1 column (one Philox call), coalesced across columns.
 __global__ __launch_bounds__(256) void mask_pos_drop_kernel(const float* __restrict__ s, const float* __restrict__ dy,
-                                                            float* __restrict__ out, int rows, int C, M3TDrop drop) {
+                                                            float* __restrict__ out, int rows, int C, M3TDrop drop,
+                                                            unsigned long long* amax) {
+    float mx = 0.f;
     const size_t total = (size_t)((rows + 3) >> 2) * C;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const uint32_t g = (uint32_t)(i / C), col = (uint32_t)(i % C);
@@ -447,10 +455,14 @@ __global__ __launch_bounds__(256) void mask_pos_drop_kernel(const float* __restr
             const size_t row = (size_t)g * 4 + r;
             if (row < (size_t)rows) {
                 const size_t o = row * C + col;
-                out[o] = s[o] > 0.f ? dy[o] * m[r] : 0.f;
+                const float v = s[o] > 0.f ? dy[o] * m[r] : 0.f;
+                out[o] = v;
+                mx = fmaxf(mx, m3t_fin_abs(v));
             }
         }
     }
+    __shared__ float red4[4];
+    if (amax) m3t_block_raise_slot(amax, mx, red4);
 }
 
 }  // namespace
@@ -717,23 +729,29 @@ extern "C" int m3t_relu_bwd(const float* a, float* dy, size_t n, void* stream) {
     return 0;
 }
 
+static thread_local unsigned long long* g_amax_out = nullptr;
+unsigned long long* m3t_take_amax_out() { unsigned long long* p = g_amax_out; g_amax_out = nullptr; return p; }
+extern "C" int m3t_amax_out(unsigned long long* slot) { g_amax_out = slot; return 0; }
+
 extern "C" int m3t_mask_pos(const float* s, const float* dy, const float* mul, float* out, size_t n, void* stream) {
+    unsigned long long* amax = m3t_take_amax_out();
     if (n == 0) return 0;
     int blocks = (int)((n + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    mask_pos_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(s, dy, mul, out, n);
+    mask_pos_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(s, dy, mul, out, n, amax);
     M3T_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int m3t_mask_pos_drop(const float* s, const float* dy, float* out, int rows, int C, float drop_p,
                                  unsigned long long drop_seed, void* stream) {
+    unsigned long long* amax = m3t_take_amax_out();
     if (rows <= 0 || C <= 0) return 0;
     if (!s || !dy || !out || drop_p < 0.f || drop_p >= 1.f) return M3T_EINVAL;
     const size_t total = (size_t)((rows + 3) / 4) * C;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 8192) blocks = 8192;
-    mask_pos_drop_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(s, dy, out, rows, C, m3t_make_drop(drop_p, drop_seed));
+    mask_pos_drop_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(s, dy, out, rows, C, m3t_make_drop(drop_p, drop_seed), amax);
     M3T_LAUNCH_CHECK();
     return 0;
 }

@@ -39,6 +39,7 @@ struct X6Params {
     size_t cv_btap;                      // TB == 1: elements between the [N][C] weight planes of consecutive taps
     const float* cv_mask; const float* cv_res; float* cv_pre;
     M3TDrop cv_drop;                     // in-kernel dropout mask instead of cv_mask
+    unsigned long long* cv_amax;         // CONV: magnitude slot raised to max |y| by the epilogue (m3t_amax_out), or nullptr
     const unsigned long long* amax_a;    // NS = 4 (fp16x3): low words = the bits of max |A|, max |B| (magnitude slots, common.h)
     const unsigned long long* amax_b;
 };
@@ -314,6 +315,7 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p) {
     const bool direct = p.splits == 1;
     float* dst = direct ? p.C : p.ws + (size_t)blockIdx.z * p.M * p.N;
     const int ldd = direct ? p.ldc : p.N;
+    float vmax = 0.f;                                // CONV: max |y| of this thread's outputs (p.cv_amax)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -336,6 +338,7 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p) {
                     if (p.act == 1) v = fmaxf(v, 0.f) * mk;
                     else if (p.act == 2) v = fmaxf(fmaxf(v, 0.f) * mk + p.cv_res[o], 0.f);
                     else if (p.cv_res) v += p.cv_res[o];
+                    vmax = fmaxf(vmax, m3t_fin_abs(v));
                 } else if (direct) {
                     v += bv;
                     if (p.act == 1) v = fmaxf(v, 0.f);
@@ -344,6 +347,10 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p) {
                 *q = v;
             }
         }
+    if (CONV && p.cv_amax) {                         // (uniform: every thread of the block gets here)
+        __shared__ float red4[4];
+        m3t_block_raise_slot(p.cv_amax, vmax, red4);
+    }
 }
 
 }  // namespace
@@ -362,6 +369,7 @@ int m3t_sgemm_x6_launch(int transA, int transB, int M, int N, int K, const float
     p.seg_len = seg_len; p.seg_stride = seg_stride; p.a_off = a_off; p.b_off = b_off;
     p.cv_T = p.cv_C = p.cv_K = p.cv_dil = p.cv_lead = p.cv_anti = 0; p.cv_btap = 0; p.cv_mask = p.cv_res = nullptr; p.cv_pre = nullptr;
     p.cv_drop = m3t_make_drop(0.f, 0ull);
+    p.cv_amax = nullptr;
     dim3 grid(N / (narrow ? 64 : XN), M / XM, splits), block(256);
 #define M3T_X6_DISPATCH(NS_, XNT_)                                                                                                  \
     do {                                                                                                                           \
@@ -389,9 +397,10 @@ int m3t_sgemm_x6_launch(int transA, int transB, int M, int N, int K, const float
 // one [Co][Ci] plane per tap); anti = 1 (data gradient): w_t is [K][Ci][Co] read as the row-major [K*Ci][Co] matrix.
 int m3t_conv_x6_launch(const float* x, const float* w_t, const float* bias, const float* res, const float* mask, float* y,
                        float* pre, int B, int T, int Ci, int Co, int K, int dil, int lead, int act, int anti, int bf16_operands,
-                       M3TDrop drop, const unsigned long long* amax_a, const unsigned long long* amax_b, hipStream_t s) {
+                       M3TDrop drop, const unsigned long long* amax_a, const unsigned long long* amax_b, unsigned long long* amax_y,
+                       hipStream_t s) {
     X6Params p;
-    p.amax_a = amax_a; p.amax_b = amax_b;
+    p.amax_a = amax_a; p.amax_b = amax_b; p.cv_amax = amax_y;
     if (bf16_operands == 3 && (!amax_a || !amax_b)) return M3T_EINVAL;
     p.A = x; p.B = w_t; p.C = y; p.bias = bias; p.ws = nullptr;
     p.M = B * T; p.N = Co; p.K = K * Ci; p.lda = Ci; p.ldb = anti ? Co : Ci; p.ldc = Co;

@@ -191,21 +191,27 @@ __global__ __launch_bounds__(256) void causal_conv_kernel(ConvParams p) {
 // one wavefront per output channel: norm over (Ci,K); writes tap-major w_t[j][co][ci]
 __global__ __launch_bounds__(256) void weight_norm_fwd_kernel(const float* __restrict__ v, const float* __restrict__ g,
                                                               float* __restrict__ w_t, float* __restrict__ norm, int Co,
-                                                              int Ci, int K) {
+                                                              int Ci, int K, unsigned long long* amax) {
     const int lane = threadIdx.x & 63;
     const int co = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (co >= Co) return;
-    const float* vp = v + (size_t)co * Ci * K;
-    float s = 0.f;
-    for (int i = lane; i < Ci * K; i += 64) s += vp[i] * vp[i];
-    s = wave_sum(s);
-    const float nrm = sqrtf(s);
-    const float sc = g[co] / nrm;
-    if (lane == 0) norm[co] = nrm;
-    for (int i = lane; i < Ci * K; i += 64) {
-        const int ci = i / K, j = i % K;
-        w_t[((size_t)j * Co + co) * Ci + ci] = vp[i] * sc;
+    float mx = 0.f;
+    if (co < Co) {
+        const float* vp = v + (size_t)co * Ci * K;
+        float s = 0.f;
+        for (int i = lane; i < Ci * K; i += 64) s += vp[i] * vp[i];
+        s = wave_sum(s);
+        const float nrm = sqrtf(s);
+        const float sc = g[co] / nrm;
+        if (lane == 0) norm[co] = nrm;
+        for (int i = lane; i < Ci * K; i += 64) {
+            const int ci = i / K, j = i % K;
+            const float w = vp[i] * sc;
+            w_t[((size_t)j * Co + co) * Ci + ci] = w;
+            mx = fmaxf(mx, m3t_fin_abs(w));
+        }
     }
+    __shared__ float red4[4];
+    if (amax) m3t_block_raise_slot(amax, mx, red4);          // (magnitude slot of the weight-normed kernel: m3t_amax_out)
 }
 
 __global__ __launch_bounds__(256) void weight_norm_bwd_kernel(const float* __restrict__ dw_t, const float* __restrict__ v,
@@ -253,8 +259,9 @@ __global__ __launch_bounds__(256) void batched_transpose_kernel(const float* __r
 
 extern "C" int m3t_weight_norm_fwd(const float* v, const float* g, float* w_t, float* norm, int Co, int Ci, int K,
                                    void* stream) {
+    unsigned long long* amax = m3t_take_amax_out();
     if (Co <= 0 || Ci <= 0 || K <= 0 || !v || !g || !w_t || !norm) return M3T_EINVAL;
-    weight_norm_fwd_kernel<<<cdiv(Co, 4), 256, 0, (hipStream_t)stream>>>(v, g, w_t, norm, Co, Ci, K);
+    weight_norm_fwd_kernel<<<cdiv(Co, 4), 256, 0, (hipStream_t)stream>>>(v, g, w_t, norm, Co, Ci, K, amax);
     M3T_LAUNCH_CHECK();
     return 0;
 }
@@ -272,7 +279,8 @@ int m3t_conv_x6d_launch(const float* x, const float* w_t, const float* bias, con
                         M3TDrop drop, hipStream_t s);
 int m3t_conv_x6_launch(const float* x, const float* w_t, const float* bias, const float* res, const float* mask, float* y,
                        float* pre, int B, int T, int Ci, int Co, int K, int dil, int lead, int act, int anti, int bf16_operands,
-                       M3TDrop drop, const unsigned long long* amax_a, const unsigned long long* amax_b, hipStream_t s);
+                       M3TDrop drop, const unsigned long long* amax_a, const unsigned long long* amax_b, unsigned long long* amax_y,
+                       hipStream_t s);
 
 static bool conv_x6_enabled() {
     static int on = -1;
@@ -295,6 +303,7 @@ extern "C" int m3t_conv1d_fwd_scaled(const float* x, const float* w_t, const flo
                                      const float* drop_mask, float* y, float* pre, int B, int T, int Ci, int Co, int K,
                                      int dilation, int lead, int act, int anticausal, float drop_p, unsigned long long drop_seed,
                                      int flags, const unsigned long long* amax_x, const unsigned long long* amax_w, void* stream) {
+    unsigned long long* amax_y = m3t_take_amax_out();      // m3t_amax_out: raise this slot to max |y| (epilogue of the implicit GEMM)
     if (B <= 0 || T <= 0) return 0;
     if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && drop_mask)) return M3T_EINVAL;
     if (Ci <= 0 || Co <= 0 || K <= 0 || dilation <= 0 || !x || !w_t || !y) return M3T_EINVAL;
@@ -323,7 +332,7 @@ extern "C" int m3t_conv1d_fwd_scaled(const float* x, const float* w_t, const flo
                 if (rm) return rm;
             }
             return m3t_conv_x6_launch(x, w_t, bias, res, drop_mask, y, pre, B, T, Ci, Co, K, dilation, lead, act, anticausal,
-                                      mode, p.drop, ua, ub, (hipStream_t)stream);
+                                      mode, p.drop, ua, ub, amax_y, (hipStream_t)stream);
         }
     }
     const int halo = (K - 1) * dilation;
@@ -347,6 +356,11 @@ extern "C" int m3t_conv1d_fwd_scaled(const float* x, const float* w_t, const flo
         causal_conv_kernel<0><<<grid, 256, lds, s>>>(p);
     }
     M3T_LAUNCH_CHECK();
+    if (amax_y) {                                    // edge shapes: the slot the caller asked for (m3t_amax_out), by one pass over y
+        if (Co % 4 != 0 || ((uintptr_t)y % 16) != 0) return M3T_EINVAL;
+        const M3TRegion ry{y, (unsigned long long)B * T, (unsigned long long)Co, Co / 4, amax_y};
+        return m3t_absmax_regions(&ry, 1, s);
+    }
     return 0;
 }
 

@@ -324,9 +324,18 @@ def transpose2d(src):
     return dst
 
 
-def mask_pos(s, dy, mul=None, drop=None):
-    """dy where s > 0 (x mul); drop = (p, seed): x the in-kernel dropout mask of the forward conv epilogue, regenerated"""
+def amax_out(slot):
+    """the NEXT conv1d / mask_pos / weight_norm_fwd call raises the magnitude slot at address `slot` to max |its output| in the same kernel
+    (include/m3t_hip.h, m3t_amax_out): the producer measures what the consuming fp16x3 contraction scales by"""
+    if slot is not None:
+        _lib.check(lib().m3t_amax_out(C.c_void_p(slot)), "m3t_amax_out")
+
+
+def mask_pos(s, dy, mul=None, drop=None, amax=None):
+    """dy where s > 0 (x mul); drop = (p, seed): x the in-kernel dropout mask of the forward conv epilogue, regenerated;
+    amax: address of a magnitude slot the kernel raises to max |out|"""
     out = torch.empty_like(dy)
+    amax_out(amax)
     if drop is not None and drop[0] > 0:
         Cc = dy.shape[-1]
         _lib.check(lib().m3t_mask_pos_drop(_p(s), _p(dy), _p(out), dy.numel() // Cc, Cc, float(drop[0]), int(drop[1]), _stream()),
@@ -1296,33 +1305,48 @@ class _TemporalBlock(torch.autograd.Function):
         w2t = torch.empty(K, Co, Co, dtype=torch.float32, device=dev)
         n1 = torch.empty(Co, dtype=torch.float32, device=dev)
         n2 = torch.empty(Co, dtype=torch.float32, device=dev)
-        _lib.check(lib().m3t_weight_norm_fwd(_p(v1), _p(g1), _p(w1t), _p(n1), Co, Ci, K, _stream()), "m3t_weight_norm_fwd")
-        _lib.check(lib().m3t_weight_norm_fwd(_p(v2), _p(g2), _p(w2t), _p(n2), Co, Co, K, _stream()), "m3t_weight_norm_fwd")
         prec = ctx.prec = _PREC[0]
         d1, d2 = (drop_p, seed1), (drop_p, seed2)        # in-kernel Philox masks (drop_p > 0) instead of the mask tensors m1 / m2
-        # fp16x3 products: magnitude slots 0 x, 1 w1t, 2 w2t, 3 wd, 4 h1 (forward), 5 ds, 6 da2, 7 da1 (backward): two measuring
-        # launches per pass instead of one in front of each of the block's nine contractions
-        slots = None
+        # fp16x3 products: magnitude slots 0 x, 1 w1t, 2 w2t, 3 wd, 4 h1, 8 y (forward), 5 ds, 6 da2, 7 da1 (backward).  Round 4: raised by
+        # the PRODUCERS (m3t_amax_out: the weight-norm kernels, the conv epilogues, the mask kernels) instead of measuring launches -- 13
+        # launches per C1 step, 10 % of its kernel time; what is left is one launch for a block whose input arrives
+        # without a slot (x, and the raw down-sampling weight wd).  A slot is only ever handed to a kernel once something has raised it
+        # (a zero slot that was never raised reads as "all-zero operand"); an operand whose slot is not in `ok` is measured
+        # by the library.
+        slots, ok, x_ext = None, set(), None
         if (prec & _lib.M3T_GEMM_F16X3) and (B * T) % 128 == 0 and Co % 128 == 0 and Ci % 32 == 0:
-            slots = amax_slots(8, dev)
-            sp = slots.data_ptr()
-            if not measure_amax([(x, sp), (w1t, sp + 8), (w2t, sp + 16)] + ([(wd, sp + 24)] if wd is not None else [])):
-                slots = None
-        # a slot is only ever handed to a kernel once a measurement has raised it (a zero slot that was never raised reads as
-        # "all-zero operand" and the product silently becomes zero); an operand whose slot is not in `ok` is measured by the library
-        ok = set(range(4)) if slots is not None else set()
-        sl = lambda i: (slots.data_ptr() + 8 * i) if (slots is not None and i in ok) else None
+            slots = amax_slots(9, dev)
+        sp = slots.data_ptr() if slots is not None else None
+        amax_out(sp + 8 if slots is not None else None)
+        _lib.check(lib().m3t_weight_norm_fwd(_p(v1), _p(g1), _p(w1t), _p(n1), Co, Ci, K, _stream()), "m3t_weight_norm_fwd")
+        amax_out(sp + 16 if slots is not None else None)
+        _lib.check(lib().m3t_weight_norm_fwd(_p(v2), _p(g2), _p(w2t), _p(n2), Co, Co, K, _stream()), "m3t_weight_norm_fwd")
+        if slots is not None:
+            ok.update((1, 2))
+            x_ext = _EXT_SLOT.pop(id(x), None)            # (slots tensor, index) left by the producer of x (the previous block's epilogue)
+            if x_ext is not None and x_ext[2] is not x:
+                x_ext = None
+            todo = ([] if x_ext is not None else [(x, sp)]) + ([(wd, sp + 24)] if wd is not None else [])
+            if todo and measure_amax(todo):
+                ok.update(([] if x_ext is not None else [0]) + ([3] if wd is not None else []))
+        sl = lambda i: ((x_ext[0].data_ptr() + 8 * x_ext[1]) if (i == 0 and x_ext is not None) else
+                        (sp + 8 * i) if (slots is not None and i in ok) else None)
+        ctx.x_ext = x_ext
+        amax_out(sp + 32 if slots is not None else None)
         h1 = _conv(x, w1t, b1, None, m1, None, B, T, Ci, Co, K, dilation, 1, 0, prec, d1, amax=(sl(0), sl(1)))
+        if slots is not None:
+            ok.add(4)
         if wd is not None:
             res = torch.empty(B, T, Co, dtype=torch.float32, device=dev)
             sgemm(0, 1, B * T, Co, Ci, x, 0, Ci, wd, 0, Ci, res, 0, Co, bias=bd, prec=prec, amax=(sl(0), sl(3)))
         else:
             res = x
-        if slots is not None and measure_amax([(h1, slots.data_ptr() + 32)]):
-            ok.add(4)
         ctx.slots_ok = ok
         a2 = torch.empty(B, T, Co, dtype=torch.float32, device=dev)
+        amax_out(sp + 64 if slots is not None else None)
         y = _conv(h1, w2t, b2, res, m2, a2, B, T, Co, Co, K, dilation, 2, 0, prec, d2, amax=(sl(4), sl(2)))
+        if slots is not None:
+            _LAST_OUT_SLOT[0] = (slots, 8)                 # temporal_block() hands it to whoever consumes y
         ctx.save_for_backward(x, v1, g1, v2, g2, wd, w1t, w2t, n1, n2, h1, a2, y, m1, m2, slots)
         ctx.dil, ctx.drops = dilation, (d1, d2)
         # parameter objects that own a gradient sink (FlatGradDDP): their gradients can be written straight into the flat buffer
@@ -1339,16 +1363,19 @@ class _TemporalBlock(torch.autograd.Function):
         Co, _, K = v1.shape
         dil, dev, prec = ctx.dil, x.device, ctx.prec
         ws = workspace(dev)
-        ds = mask_pos(y, dy)                         # through the block's output ReLU
+        ok = set(ctx.slots_ok)                       # slots something has raised (see forward)
+        x_ext = ctx.x_ext
+        sp = slots.data_ptr() if slots is not None else None
+        sl = lambda i: ((x_ext[0].data_ptr() + 8 * x_ext[1]) if (i == 0 and x_ext is not None) else
+                        (sp + 8 * i) if (slots is not None and i in ok) else None)
+        ds = mask_pos(y, dy, amax=(sp + 40 if slots is not None else None))                         # through the block's output ReLU
         d1, d2 = ctx.drops
-        da2 = mask_pos(a2, ds, m2, d2)               # through dropout2 + relu2
-        ok = set(ctx.slots_ok)                       # slots a measurement has raised (see forward)
-        sl = lambda i: (slots.data_ptr() + 8 * i) if (slots is not None and i in ok) else None
-        if slots is not None and measure_amax([(ds, slots.data_ptr() + 40), (da2, slots.data_ptr() + 48)]):
+        da2 = mask_pos(a2, ds, m2, d2, amax=(sp + 48 if slots is not None else None))               # through dropout2 + relu2
+        if slots is not None:
             ok.update((5, 6))
         dh1 = _conv(da2, w2t, None, None, None, None, B, T, Co, Co, K, dil, 0, 1, prec, amax=(sl(6), sl(2)))
-        da1 = mask_pos(h1, dh1, m1, d1)              # h1 > 0 <=> a1 > 0 (dropout keeps the sign)
-        if slots is not None and measure_amax([(da1, slots.data_ptr() + 56)]):
+        da1 = mask_pos(h1, dh1, m1, d1, amax=(sp + 56 if slots is not None else None))              # h1 > 0 <=> a1 > 0 (dropout keeps the sign)
+        if slots is not None:
             ok.add(7)
         dw2t = torch.empty_like(w2t)
         dw1t = torch.empty_like(w1t)
@@ -1369,24 +1396,31 @@ class _TemporalBlock(torch.autograd.Function):
             else:
                 dx = _conv(da1, w1t, None, None, None, None, B, T, Co, Ci, K, dil, 0, 1, prec, amax=(sl(7), sl(1)))
                 sgemm(0, 0, B * T, Ci, Co, ds, 0, Co, wd, 0, Ci, dx, 0, Ci, accumulate=True, use_ws=False, prec=prec, amax=(sl(5), sl(3)))
+            # the two convolutions' weight gradients on the two weight-gradient streams (round 4): each is K per-tap split-K GEMMs of 300-odd
+            # workgroups -- less than half a round of the chip -- and the LAST block of the backward pass has nothing else to hide behind
+            # (C1: 1.84 -> ~1.7 ms per step)
             main = torch.cuda.current_stream()
-            wg = wgrad_stream(dev, 0)
+            wg, wg1 = wgrad_stream(dev, 0), wgrad_stream(dev, 1)
             wg.wait_stream(main)
+            wg1.wait_stream(main)
             with torch.cuda.stream(wg):
                 wsw = workspace(dev)
                 _conv_wgrad(da2, h1, dw2t, B, T, Co, Co, K, dil, wsw, prec, amax=(sl(6), sl(4)))
-                _conv_wgrad(da1, x, dw1t, B, T, Ci, Co, K, dil, wsw, prec, amax=(sl(7), sl(0)))
-                colsum(da1, 0, B * T, Co, Co, sinks[2])
                 colsum(da2, 0, B * T, Co, Co, sinks[5])
-                _lib.check(lib().m3t_weight_norm_bwd(_p(dw1t), _p(v1), _p(g1), _p(n1), _p(sinks[0]), _p(sinks[1]), Co, Ci, K, _stream()),
-                           "m3t_weight_norm_bwd")
                 _lib.check(lib().m3t_weight_norm_bwd(_p(dw2t), _p(v2), _p(g2), _p(n2), _p(sinks[3]), _p(sinks[4]), Co, Co, K, _stream()),
+                           "m3t_weight_norm_bwd")
+            with torch.cuda.stream(wg1):
+                wsw1 = workspace(dev)
+                _conv_wgrad(da1, x, dw1t, B, T, Ci, Co, K, dil, wsw1, prec, amax=(sl(7), sl(0)))
+                colsum(da1, 0, B * T, Co, Co, sinks[2])
+                _lib.check(lib().m3t_weight_norm_bwd(_p(dw1t), _p(v1), _p(g1), _p(n1), _p(sinks[0]), _p(sinks[1]), Co, Ci, K, _stream()),
                            "m3t_weight_norm_bwd")
                 if wd is not None:
                     sgemm(1, 0, Co, Ci, B * T, ds, 0, Co, x, 0, Ci, sinks[6], 0, Ci, prec=prec, amax=(sl(5), sl(0)))
                     colsum(ds, 0, B * T, Co, Co, sinks[7])
-            for t in (da1, da2, h1, x, dw1t, dw2t, ds, n1, n2) + ((slots,) if slots is not None else ()):
+            for t in (da1, da2, h1, x, dw1t, dw2t, ds, n1, n2) + ((slots,) if slots is not None else ()) + ((x_ext[0],) if x_ext is not None else ()):
                 t.record_stream(wg)
+                t.record_stream(wg1)
             _WGRAD_PENDING[(dev.type, dev.index)] = True
             return (dx,) + (None,) * 14
         _conv_wgrad(da2, h1, dw2t, B, T, Co, Co, K, dil, ws, prec, amax=(sl(6), sl(4)))
@@ -1417,7 +1451,18 @@ class _TemporalBlock(torch.autograd.Function):
 def temporal_block(x_btc, v1, g1, b1, v2, g2, b2, wd, bd, dilation, m1=None, m2=None, drop_p=0.0, seeds=(0, 0)):
     """m1 / m2: explicit pre-scaled dropout masks, or drop_p > 0 with two 64-bit seeds: masks generated inside the conv epilogues
     (Philox4x32-10, include/m3t_hip.h) and regenerated in backward"""
-    return _TemporalBlock.apply(x_btc, v1, g1, b1, v2, g2, b2, wd, bd, dilation, m1, m2, float(drop_p), int(seeds[0]), int(seeds[1]))
+    _LAST_OUT_SLOT[0] = None
+    y = _TemporalBlock.apply(x_btc, v1, g1, b1, v2, g2, b2, wd, bd, dilation, m1, m2, float(drop_p), int(seeds[0]), int(seeds[1]))
+    if _LAST_OUT_SLOT[0] is not None:                # the conv epilogue raised max |y|: the next block takes it instead of measuring x
+        if len(_EXT_SLOT) > 64:
+            _EXT_SLOT.clear()
+        _EXT_SLOT[id(y)] = _LAST_OUT_SLOT[0] + (y,)
+        _LAST_OUT_SLOT[0] = None
+    return y
+
+
+_LAST_OUT_SLOT = [None]     # (slots tensor, index) of the last _TemporalBlock forward's output
+_EXT_SLOT = {}              # id(tensor) -> (slots tensor, index, tensor): magnitude slots that travel with a producer's output tensor
 
 
 class _ConvBnRelu(torch.autograd.Function):

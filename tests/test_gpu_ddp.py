@@ -101,14 +101,6 @@ def test_bench_two_ranks_on_one_gpu_gloo():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["value"] > 0
     assert d["cpu_baseline"] is None and d["scaling"] == "weak"
     assert d["allreduce"]["world_size"] == 2 and d["allreduce"]["ms_in_step"] is not None and "fallback" not in d
-    # opt-in early bucket (M3T_DDP_EARLY_BUCKET=1: the fusion GRU's gradients all-reduced on a communication stream beside the rest
-    # of backward, the rest + dead slot after it): same gradients, same loss
-    cmd2 = ["29532" if c == "29531" else c for c in cmd]
-    out2 = subprocess.run(cmd2, env=dict(env, M3T_DDP_EARLY_BUCKET="1"), capture_output=True, text=True, timeout=600)
-    assert out2.returncode == 0, out2.stderr[-2000:]
-    d2 = json.loads([l for l in out2.stdout.splitlines() if l.startswith("{")][-1])
-    assert d2["loss"] == d["loss"] and d2["grad_norm"] == d["grad_norm"] and "fallback" not in d2, (d["loss"], d2["loss"], d["grad_norm"], d2["grad_norm"])
-    assert "early" in d2["allreduce"]["schedule"] and "early" not in d["allreduce"]["schedule"]
 
 
 def test_shared_linear_weight_with_deferred_sink_write():
@@ -309,6 +301,76 @@ def test_one_ranks_dead_scan_stops_every_rank(tmp_path, overlap):
     assert "RANK 0 raised=True params_unchanged=True nan_norm=True" in r.stdout
     assert "RANK 1 raised=True params_unchanged=True nan_norm=True" in r.stdout
     assert np.array_equal(np.load(out + ".0.npy"), np.load(out + ".1.npy")), "replicas diverged after the fault"
+
+
+_EARLY_CHILD = r"""
+import os, sys
+for p in (%r, %r, %r):
+    sys.path.insert(0, p)
+import numpy as np, torch, torch.distributed as dist
+from golden.recipe import fill_module
+from m3t.ddp import FlatGradDDP, shard_indices
+from models.rnn import GRU
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+class Two(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.enc = GRU(12, 16, 2, -1, 2)
+        self.top = GRU(32, 16, 2, 3, 2)
+    def forward(self, x):
+        return self.top(self.enc(x))
+net = fill_module(Two(), 5).to("cuda:0")
+ddp = FlatGradDDP(net, bucket_order=[list(net.top.parameters()), list(net.enc.parameters())], max_norm=0.05, overlap=False)
+armed = False
+if os.environ["EARLY"] == "1":
+    armed = ddp.early_bucket_after(net.top, resident_workgroups=192, n_cus=256, channels=32)
+    assert armed
+    assert not ddp.early_bucket_after(net.top, resident_workgroups=230, n_cus=256, channels=32)      # the invariant refuses: 230 + 32 > 256
+    ddp._early = True
+rs = np.random.RandomState(3)
+x = torch.from_numpy(rs.standard_normal((8, 9, 12)).astype(np.float32)).to("cuda:0")
+t = torch.from_numpy(rs.standard_normal((8, 9, 3)).astype(np.float32)).to("cuda:0")
+idx = shard_indices(8, rank, world)
+for _ in range(2):
+    ddp.zero_grad()
+    ((net(x[idx]) - t[idx]) ** 2).mean().backward()
+    early_seen = getattr(ddp, "_early_handle", None) is not None
+    norm = ddp.finish()
+torch.cuda.synchronize()
+print("RANK %%d armed=%%s early_collective_issued=%%s" %% (rank, armed, early_seen), flush=True)
+np.save(sys.argv[1] + ".%%d.npy" %% rank, np.concatenate([ddp.flat.cpu().numpy(), norm.reshape(1).cpu().numpy()]))
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_early_bucket_gives_the_default_schedules_gradients(tmp_path):
+    """the opt-in early bucket (FlatGradDDP.early_bucket_after / M3T_DDP_EARLY_BUCKET=1) -- bucket 0 all-reduced on a
+    communication stream from a backward hook of its module, the rest of the buffer and the dead slot in finish() -- must give exactly
+    the gradients (and clip norm) of the default ONE collective after backward, and its residency invariant (scan workgroups + RCCL
+    channels <= CUs) must refuse to arm when it does not hold.  Two ranks on cuda:0 over gloo, launch-per-step scans."""
+    import os
+    import subprocess
+    import sys
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "child.py"
+    script.write_text(_EARLY_CHILD % (os.path.join(root, "m3f.pytorch_amd"), os.path.join(root, "tests"), root))
+    res = {}
+    for early, port in (("0", "29541"), ("1", "29542")):
+        out = str(tmp_path / ("g" + early))
+        env = dict(os.environ, M3T_SCAN_PERSIST="0", EARLY=early)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", port, str(script), out]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (r.stdout[-800:], r.stderr[-2500:])
+        if early == "1":
+            assert "RANK 0 armed=True early_collective_issued=True" in r.stdout and "RANK 1 armed=True early_collective_issued=True" in r.stdout, r.stdout[-600:]
+        res[early] = [np.load(out + ".%d.npy" % k) for k in (0, 1)]
+    assert np.array_equal(res["0"][0], res["0"][1]) and np.array_equal(res["1"][0], res["1"][1]), "replicas diverged"
+    assert np.array_equal(res["0"][0], res["1"][0]), float(np.abs(res["0"][0] - res["1"][0]).max())
 
 
 _AGREED_CHILD = r"""
