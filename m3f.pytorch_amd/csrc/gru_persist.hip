@@ -1749,6 +1749,15 @@ int persist_fwd_launch(const FwdGroup& g, const FragPtrs& fp, int B, int T, int 
     if (!level_shape(g.d, g.n, B, sh) || !ensure_err_word()) return M3T_EINVAL;
     const int uw = fwd_uw(g, B, T, flags, sh);
     if (uw > 1 && !level_shape(g.d, g.n, B, sh, uw)) return M3T_EINVAL;
+    {
+        // round 4: a NARROW forward launch with fewer than 8 groups is XCD-aligned too (the fusion level: 4 groups of 32 fill 4 XCDs, exchange
+        // served by L2: traffic 1.9x -> ~1.1x algorithmic, step 12.17 -> 12.10 ms).  Round 3 lost 0.3 ms with this placement because the
+        // weight-gradient GEMMs beside the BACKWARD scans found CUs on four XCDs only; no GEMM runs beside a forward scan.
+        if (uw == 1 && !sh.slot_map && sh.G < 8 && fwd_is_f16(g, B, T, flags)) {
+            sh.slot_map = 1;
+            sh.grid = 8 * (g.d[0].H / 16);
+        }
+    }
     ExPtrs ex;
     size_t bytes[M3T_MAX_SCANS];
     fill_exchange(g, fp, sh, 8, ex, bytes);
