@@ -51,6 +51,7 @@ struct ExPtrs {
     int slot_map;                    // 1: persist_map's XCD-slot mapping (grid = 8 * ceil(G/8) * H/16), 0: gid = b % G
     unsigned long long* hs;          // placement-handshake table (arena), or nullptr: no L2-served exchange
     unsigned hs_tag;
+    int inline_prep;                 // 1: the kernel builds its W_hh fragments itself from the parameter (no prep launch in front of it)
     unsigned tag_base;               // tags of this launch are tag_base + step + 1 (launch-unique inside an exchange arena: no memset per launch)
 };
 
@@ -373,18 +374,73 @@ __global__ __launch_bounds__(NT) void gru_persist_fwd6_kernel(FwdGroup g, FragPt
     const int j0 = ub * UB, r0 = rb * ROWS;
 
     pbf16x8 wf[UW][KS][3][NTERM];                      // [unit tile][k-step][gate tile][term] (F16: fp16 bit patterns, two terms)
+    float winv = 1.f;
+    if (F16 && ex.inline_prep) {
+        // Round 4: the fp16x3 fragments straight from W_hh, in the kernel (was wfrag3h_prep_kernel: one more launch on the chain in front
+        // of every scan).  Lane (n = lane & 15, q = lane >> 4) of wave w holds, per (k-step, gate tile), the 8 consecutive k
+        // 16 (w + NW (2k + (q >> 1))) + 8 (q & 1) + e of row ct H + 16 ub + n: two float4 loads.  Pass 1: the maximum of each 16-unit
+        // slice (its 48 rows x H values are read exactly once by the workgroup) -> the slice's power-of-two scale; pass 2: the same
+        // loads again (L2-hot), scaled and split into two fp16 terms.  Same values as the prep kernel's.
+        __shared__ float s_wmax[2][NW];
+        const int q_ = lane >> 4;
+        float mx[UW];
 #pragma unroll
-    for (int u = 0; u < UW; ++u) {
-        const pu32x4* Wf = reinterpret_cast<const pu32x4*>(fp.wfrag[s]) + ((size_t)((ubw * UW + u) * NW + wave) * KS * 3 * NTERM) * 64 + lane;
+        for (int u = 0; u < UW; ++u) {
+            mx[u] = 0.f;
 #pragma unroll
-        for (int k = 0; k < KS; ++k)
+            for (int k = 0; k < KS; ++k)
 #pragma unroll
-            for (int ct = 0; ct < 3; ++ct)
+                for (int ct = 0; ct < 3; ++ct) {
+                    const float4* wp = reinterpret_cast<const float4*>(d.w_hh + ((size_t)ct * H + (ubw * UW + u) * 16 + (lane & 15)) * H +
+                                                                       16 * (wave + NW * (2 * k + (q_ >> 1))) + 8 * (q_ & 1));
+                    const float4 a = wp[0], b = wp[1];
+                    mx[u] = fmaxf(fmaxf(fmaxf(mx[u], m3t_fin_abs(a.x)), fmaxf(m3t_fin_abs(a.y), m3t_fin_abs(a.z))),
+                                  fmaxf(fmaxf(m3t_fin_abs(a.w), m3t_fin_abs(b.x)), fmaxf(m3t_fin_abs(b.y), fmaxf(m3t_fin_abs(b.z), m3t_fin_abs(b.w)))));
+                }
+            mx[u] = wave_max(mx[u]);
+            if (lane == 0) s_wmax[u][wave] = mx[u];
+        }
+        __syncthreads();
 #pragma unroll
-                for (int t = 0; t < NTERM; ++t) wf[u][k][ct][t] = __builtin_bit_cast(pbf16x8, Wf[((k * 3 + ct) * NTERM + t) * 64]);
+        for (int u = 0; u < UW; ++u) {
+            float m = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) m = fmaxf(m, s_wmax[u][w]);
+            float sc, inv;
+            m3t_f16_scale(__float_as_uint(m), sc, inv);
+            if (u == tu) winv = inv * 6.103515625e-05f;         // x 2^-14: the scale of h
+#pragma unroll
+            for (int k = 0; k < KS; ++k)
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) {
+                    const float4* wp = reinterpret_cast<const float4*>(d.w_hh + ((size_t)ct * H + (ubw * UW + u) * 16 + (lane & 15)) * H +
+                                                                       16 * (wave + NW * (2 * k + (q_ >> 1))) + 8 * (q_ & 1));
+                    const float4 a = wp[0], b = wp[1];
+                    const float xv[8] = {a.x * sc, a.y * sc, a.z * sc, a.w * sc, b.x * sc, b.y * sc, b.z * sc, b.w * sc};
+                    pf16x8 h1, h2;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        h1[e] = (_Float16)xv[e];
+                        h2[e] = (_Float16)(xv[e] - (float)h1[e]);
+                    }
+                    wf[u][k][ct][0] = __builtin_bit_cast(pbf16x8, h1);
+                    wf[u][k][ct][1] = __builtin_bit_cast(pbf16x8, h2);
+                }
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < UW; ++u) {
+            const pu32x4* Wf = reinterpret_cast<const pu32x4*>(fp.wfrag[s]) + ((size_t)((ubw * UW + u) * NW + wave) * KS * 3 * NTERM) * 64 + lane;
+#pragma unroll
+            for (int k = 0; k < KS; ++k)
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+                    for (int t = 0; t < NTERM; ++t) wf[u][k][ct][t] = __builtin_bit_cast(pbf16x8, Wf[((k * 3 + ct) * NTERM + t) * 64]);
+        }
+        // F16: 2^-14 / (scale of this slice's W_hh), written by wfrag3h_prep_kernel behind the fragments
+        if (F16) winv = reinterpret_cast<const float*>(fp.wfrag[s])[(size_t)4 * H * H + ub];
     }
-    // F16: 2^-14 / (scale of this slice's W_hh), written by wfrag3h_prep_kernel behind the fragments
-    const float winv = F16 ? reinterpret_cast<const float*>(fp.wfrag[s])[(size_t)4 * H * H + ub] : 1.f;
     // cell-math threads in granule order (see the header): granule ti = jp*64 + hr*2 + jlo  <->  row hr & 15,
     // unit 8*(hr >> 4) + 2*jp + jlo
     const int ti = tid & 255;
@@ -1213,6 +1269,8 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd3q_kernel(BwdGroup g, FragP
 
     pu32x4 wb[2][3][NP][2];                            // [unit tile][gate][producer pair of this wave's K-slice][term]: 8 fp16 per lane, 96 VGPRs at H = 512
     float winv[2];                                     // 1 / (scale of the slice's W_hh^T)
+    // (round 4 also tried building these fragments in the kernel, as the forward kernel does: the 8 k of a fragment are 8 ROWS of W_hh, 192
+    // strided scalar loads per lane and pass -- +25 us per launch, what the prep launch it replaced costs: not kept)
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const pu32x4* Wf = reinterpret_cast<const pu32x4*>(fp.wfrag[s]) + ((size_t)((ubw * 2 + u) * NW + wave) * 3 * NP * 2) * 64 + lane;
@@ -1780,7 +1838,12 @@ int persist_fwd_launch(const FwdGroup& g, const FragPtrs& fp, int B, int T, int 
     if (x6) {
         // fp32 mode with M3T_GEMM_F16X3: the product from two fp16 terms (three MFMAs per k-step and gate) instead of three bf16 terms (six)
         const bool f16 = !g.bf16 && (flags & M3T_GEMM_F16X3) && m3t_f16x3_enabled();
-        if (f16) {                                                           // W_hh -> B-operand fragments: one launch for the level
+        // round 4: the fp16x3 forward kernels build their fragments themselves (ex.inline_prep) -- no prep launch on the chain in front of
+        // the scan (12.15 -> 12.10 ms per C3 step); a W_hh that is not 16-byte aligned keeps the prep kernel
+        bool inline_ok = f16;
+        for (int i = 0; i < g.n; ++i) inline_ok = inline_ok && ((uintptr_t)g.d[i].w_hh % 16) == 0;
+        ex.inline_prep = inline_ok ? 1 : 0;
+        if (f16 && !inline_ok) {                                             // W_hh -> B-operand fragments: one launch for the level
             Prep3hArgs pa;
             const int H = g.d[0].H;                                           // (level_shape: every scan of the level has the same H)
             for (int i = 0; i < g.n; ++i) {
