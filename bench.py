@@ -627,10 +627,11 @@ def worker(args):
                     "source": {"achieved, avg_launch_us, frac": "HIP events recorded in this run on the launch stream",
                                "traffic, traffic_by_kernel, mfma_busy_frac_pmc": pmc_source},
                     "note": "achieved = algorithmic FLOPs of the recurrent products dh_t = dgh_{t+1} W_hh ((T-1) x sum over scans of 2 B 3H H per launch) / HIP-event "
-                            "time of the launches; peak = fp32 MFMA (the arithmetic is fp32-accurate); the H = 512 launches run it as 3 fp16 MFMAs per product "
-                            "(two fp16 terms per value, split by the producers: gru_persist_bwd3p_kernel), the H = 256 launches as 6 bf16 MFMAs per product "
-                            "(peak of the 16-bit pipe 2500 TFLOP/s / 3 or / 6), the H = 128 launches (gru_solo_bwd_kernel) as fp32 FMA chains "
-                            "on the vector ALUs; the kernels are bound by the cross-CU exchange latency per time step, not by either pipe (DESIGN.md section 5)"}
+                            "time of the launches; peak = fp32 MFMA (the arithmetic is fp32-accurate); the H = 512 and H = 256 launches run it as 3 fp16 MFMAs per product "
+                            "(two fp16 terms per value, split by the producers; round 4: wide workgroups, 32-deep MFMAs over producer pairs: "
+                            "gru_persist_bwd3q_kernel; peak of the 16-bit pipe 2500 TFLOP/s / 3), the H = 128 launches (gru_solo_bwd_kernel) as fp32 FMA chains "
+                            "on the vector ALUs; the kernels are bound by the cross-CU exchange latency per time step, not by either pipe (DESIGN.md section 5); "
+                            "the audio stack's launches run at the same time as the gru_v | gru_a level's and count with their own event times"}
 
     if rank == 0:
         clips = B * world * args.steps
@@ -638,7 +639,7 @@ def worker(args):
             "metric": "clips/sec (300-frame A+V, fwd+bwd)", "value": round(clips / dt, 2), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_ms, 3),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f32 (fp32-accurate products, fp32 accumulate: GEMMs as fp16x3 -- two fp16 terms per scaled operand, three MFMAs, error vs fp64 no larger than an fp32 GEMM's; the forward recurrences and the H=512 backward ones as fp16x3 too (h is bounded; the backward producers scale per tile), the H=256 backward recurrences as bf16x6 -- three bf16 terms, six MFMAs; the H=128 scorer scans as fp32 FMA chains on the vector ALUs)",
+            "dtype": "f32 (fp32-accurate products, fp32 accumulate: GEMMs as fp16x3 -- two fp16 terms per scaled operand, three MFMAs, error vs fp64 no larger than an fp32 GEMM's; the forward and backward recurrences at H=512 and H=256 as fp16x3 too (h is bounded; the backward producers split their values under a power-of-two scale per producer workgroup); the H=128 scorer scans as fp32 FMA chains on the vector ALUs)",
             "data": "synthetic",
             "config": {"workload": "C3/C4 feature-level A+V att_fusion graph (SURVEY 8(d)): audio GRU(128,256,2) | "
                                    "gru_v,gru_a GRU(256,512,2) | proj_v | AttFusion([512,512],128) | "
