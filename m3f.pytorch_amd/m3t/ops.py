@@ -504,6 +504,7 @@ def range_probe_report(clear=True):
     return out
 
 
+FORCE_WIDE_FWD = [False]    # tests: every forward scan asks for the wide form (by default only the level that makes room for the audio scans does)
 SCAN_FP32 = [False]         # tests: keep the persistent forward scan on fp32 MFMAs (bit-identical to the per-step kernels)
 
 
@@ -757,7 +758,7 @@ class _MultiBiGRU(torch.autograd.Function):
                                                 _vp(gates[l][s], d * B * T * 4 * H), _vp(h_ns[s], (2 * l + d) * B * H),
                                                 H, d, 6 * H, d * 3 * H, outs[l][s].stride(1), d * H))
             if scan:
-                _scan_fwd(descs, B, T, prec | (_lib.M3T_SCAN_WIDE if wide else 0), after)
+                _scan_fwd(descs, B, T, prec | (_lib.M3T_SCAN_WIDE if (wide or FORCE_WIDE_FWD[0]) else 0), after)
 
         concurrent = (_interleaved(groups) and len({Hs[i] for i in groups[0][1]}) == 1 and len({Hs[i] for i in groups[1][1]}) == 1
                       and _pair_fits(dev, 2 * len(groups[0][1]), Hs[groups[0][1][0]], 2 * len(groups[1][1]), Hs[groups[1][1][0]], B, T, prec))

@@ -315,6 +315,56 @@ def test_gru_persistent_scan_equals_per_step(B, T, I, H, L, exact):
         close(g1[n], g_ref[n], 2e-4, n)
 
 
+@pytest.mark.parametrize("B,T,I,H,L", [(19, 23, 16, 512, 1), (33, 5, 12, 256, 2), (32, 40, 24, 512, 2), (5, 2, 8, 256, 1), (48, 3, 16, 512, 1),
+                                       (64, 3, 16, 512, 1)])
+def test_gru_wide_scan_kernels_ragged_batches_and_short_clips(B, T, I, H, L):
+    """Round 4: the WIDE persistent kernels (16 rows x 32 units per workgroup, memory-order HBM traffic handed over through LDS one step
+    late, W_hh fragments built in the forward kernel, 32-deep MFMAs over producer pairs in the backward kernel) on shapes the bench never
+    sees: batches that are no multiple of 16 (the last row block is ragged: clamped loads, no stores), T = 2 / 3 (the one-step-late
+    hand-over must flush), 1 .. 4 row blocks (XCD slot mapping with 2, 4, 6 and 8 groups).  Forward: forced wide (ops.FORCE_WIDE_FWD);
+    backward: every level asks for it by default.  Against the launch-per-step kernels (fp32 MFMAs) to fp32 rounding, and the oracle."""
+    from models.rnn import GRU
+    from m3t import ops, _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(B * 5 + T + H)
+    m = fill_module(GRU(I, H, L, 3, 2), 79).to(DEV)
+    xn, ct = draw(rs, (B, T, I)), draw(rs, (B, T, 3))
+    flags = _lib.M3T_GEMM_F16X3 | _lib.M3T_SCAN_WIDE
+    nrb = (B + 15) // 16
+    assert lib.m3t_gru_scan_workgroups(2, H, B, T, flags, 0) == lib.m3t_gru_scan_workgroups(2, H, B, T, flags, 1) == 2 * nrb * (H // 32)
+    assert lib.m3t_gru_scan_workgroups(2, H, B, T, _lib.M3T_GEMM_F16X3, 0) == 2 * nrb * (H // 16)
+
+    def run(per_step):
+        ops.SCAN_PER_STEP[0], ops.FORCE_WIDE_FWD[0] = per_step, not per_step
+        try:
+            m.zero_grad()
+            x = dev(xn, True)
+            n0 = lib.m3t_gru_persist_count()
+            y = m(x)
+            (y * dev(ct)).sum().backward()
+            torch.cuda.synchronize()
+            ops.poll_scan_error()
+            return y.detach().clone(), x.grad.clone(), {n: prm.grad.clone() for n, prm in m.named_parameters()}, lib.m3t_gru_persist_count() - n0
+        finally:
+            ops.SCAN_PER_STEP[0], ops.FORCE_WIDE_FWD[0] = False, False
+
+    y1, dx1, g1, n1 = run(False)
+    y0, dx0, g0, n0 = run(True)
+    assert n0 == 0 and n1 == 2 * L, (n0, n1)
+    close(y1, y0, 3e-6, "y vs per-step")
+    close(dx1, dx0, 3e-6, "dx vs per-step")
+    for n in g0:
+        close(g1[n], g0[n], 1e-5, n + " vs per-step")
+    assert not torch.equal(y1, y0)
+    p = {n: t.detach().cpu().numpy().astype(np.float64) for n, t in m.named_parameters()}
+    y_ref, _, cache = O.gru_module_fwd(xn.astype(np.float64), p, L, 3, 2)
+    dx_ref, g_ref = O.gru_module_bwd(ct.astype(np.float64), cache, p, L)
+    close(y1, y_ref, TOL, "y")
+    close(dx1, dx_ref, TOL, "dx")
+    for n in g1:
+        close(g1[n], g_ref[n], 2e-4, n)
+
+
 @pytest.mark.parametrize("exact", [True, False])
 def test_gru_persistent_scan_final_state_and_its_gradient(exact):
     """h_n out of the one-launch forward scan and dL/dh_n into the one-launch backward scan (return_h=True, the
