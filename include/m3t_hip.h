@@ -36,11 +36,13 @@ extern "C" {
                                   * launch-per-step kernels) instead of the fp32-accurate bf16x6 form */
 #define M3T_SCAN_FAULT 16        /* m3t_gru_scan_* flags, FAULT INJECTION for tests: workgroup 0 of a persistent launch stays silent at step T/2,
                                   * so its peers run into their spin limit (env M3T_SCAN_SPIN_LIMIT lowers it) and the error path below runs */
-#define M3T_SCAN_WIDE 32         /* m3t_gru_scan_* flags: the caller wants room for a SECOND persistent scan beside this one (m3t.ops runs the audio
-                                  * stack's 64-workgroup scans at the same time as the gru_v | gru_a level's): an H = 512 level in the M3T_GEMM_F16X3
-                                  * mode then runs with two 16-unit tiles per workgroup -- half the workgroups (4 scans x 32 clips: 128 instead of
-                                  * 256), each owning its CU; other levels ignore the flag.  m3t_gru_scan_workgroups() says what a call would launch.
-                                  * Same results as without the flag up to the order of nothing: the arithmetic per cell is unchanged. */
+#define M3T_SCAN_WIDE 32         /* m3t_gru_scan_* flags: run the level with WIDE workgroups where that form exists (H = 512 / 256 in the M3T_GEMM_F16X3 mode;
+                                  * other levels ignore the flag): 16 rows x 32 units per workgroup instead of x 16 -- the same gather per workgroup,
+                                  * half the workgroups (gru_v | gru_a, 4 scans x 32 clips: 128 instead of 256), each owning its CU, every group on one
+                                  * XCD.  m3t.ops asks for it where it makes room for a SECOND persistent scan (the audio stack's scans run at the same
+                                  * time as the gru_v | gru_a level's) and for every backward level (the wide backward kernel is no slower than the narrow
+                                  * one on twice the CUs).  m3t_gru_scan_workgroups() says what a call would launch.  Same results as without the flag up to
+                                  * fp32 rounding (the backward kernel scales per producer workgroup instead of per 16-unit tile). */
 #define M3T_BF16 2               /* precision flag shared by m3t_sgemm (= M3T_GEMM_BF16), m3t_conv1d_* and m3t_gru_scan_*:
                                   * matmul operands rounded to bf16 (nearest even), fp32 accumulate, fp32 state/epilogue */
 /* m3t_sgemm flags: BACKGROUND caps residency at one workgroup per CU (for GEMMs that run on a side stream
