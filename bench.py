@@ -594,7 +594,7 @@ def worker(args):
         name = max((n for n in kern if kern[n]["flops"] > 0), key=lambda n: kern[n]["ms"])
         k = kern[name]
         achieved = k["flops"] / (k["ms"] * 1e-3) / 1e12
-        traffic, traffic_by_kernel, mfma_util, pmc_source = None, None, None, None
+        traffic, traffic_by_kernel, mfma_util, pmc_source, traffic_ratio = None, None, None, None, None
         # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/*pmc_traffic.json: separate
         # FETCH_SIZE / WRITE_SIZE passes, gfx950 correction) and the SQ pass (profiles/*pmc_mfma.json)
         try:
@@ -607,6 +607,7 @@ def worker(args):
             if hits:
                 traffic = int(sum(h["hbm_bytes_per_launch"] * h["launches"] for h in hits.values()) / sum(h["launches"] for h in hits.values()))
                 traffic_by_kernel = {k: v["hbm_bytes_per_launch"] for k, v in hits.items()}
+                traffic_ratio = {k: v["traffic_over_algorithmic"] for k, v in hits.items() if "traffic_over_algorithmic" in v} or None
             mfma_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_mfma.json")))[-1]
             mm = json.load(open(mfma_file))["kernels"]
             mh = {k: v for k, v in mm.items() if k.startswith(stems) and v.get("mfma_util") is not None}
@@ -623,9 +624,9 @@ def worker(args):
                     "flops_per_launch": round(k["flops"] / max(1, k["launches"])),
                     "share_of_step": round(k["ms"] / timed_steps / step_ms, 3),
                     "timed_launches": k["launches"], "events_every_n_steps": events_every,
-                    "traffic_by_kernel": traffic_by_kernel, "mfma_busy_frac_pmc": mfma_util,
+                    "traffic_by_kernel": traffic_by_kernel, "traffic_over_algorithmic_by_kernel": traffic_ratio, "mfma_busy_frac_pmc": mfma_util,
                     "source": {"achieved, avg_launch_us, frac": "HIP events recorded in this run on the launch stream",
-                               "traffic, traffic_by_kernel, mfma_busy_frac_pmc": pmc_source},
+                               "traffic, traffic_by_kernel, traffic_over_algorithmic_by_kernel, mfma_busy_frac_pmc": pmc_source},
                     "note": "achieved = algorithmic FLOPs of the recurrent products dh_t = dgh_{t+1} W_hh ((T-1) x sum over scans of 2 B 3H H per launch) / HIP-event "
                             "time of the launches; peak = fp32 MFMA (the arithmetic is fp32-accurate); the H = 512 and H = 256 launches run it as 3 fp16 MFMAs per product "
                             "(two fp16 terms per value, split by the producers; round 4: wide workgroups, 32-deep MFMAs over producer pairs: "
