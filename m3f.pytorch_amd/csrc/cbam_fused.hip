@@ -30,10 +30,19 @@
 namespace {
 
 constexpr int FT = 512;       // threads per workgroup (8 waves)
-// planes in flight per lane in the plane sweeps of SMALL maps (one unit per lane per plane).  Measured on the ragged 7 x 7 stage
-// (single-pixel units, 196 B per wave-load): 4, 8, 16 planes in flight -> 0.485, 0.485, 0.530 ms for the whole gate: the small maps
-// are bound by the per-frame dependency chain (squeeze -> MLP -> compress -> conv), not by loads in flight
-template <int E> struct PlaneBatch { static constexpr int n = 4; };
+
+// phase stamps of F1 / B2 for tools/cbam_phase_probe.hip (which includes this file with M3T_CBAM_STAMPS): compiled out of the library
+#ifdef M3T_CBAM_STAMPS
+__device__ unsigned long long g_cb_stamps[8192 * 8];
+#define M3T_CB_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_cb_stamps[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define M3T_CB_STAMP(i) do { } while (0)
+#endif
+// planes in flight per lane in the plane sweeps of SMALL maps (one unit per lane per plane).  More does not pay: at 8 / 16 / 32 hipcc
+// keeps every plane's bookkeeping live (86 / 151 / 181 VGPRs in F1), one workgroup per CU instead of 2.6, and the sweep is not bound
+// by loads in flight but by the per-plane cross-lane reductions (tools/cbam_phase_probe.hip: 20 us per 256 x 7 x 7 frame even as one
+// batch).  Frames that fit LDS take the frame-resident kernels below (F1L / B2L), which have no cross-lane reductions at all.
+constexpr int PB = 4;
 
 __device__ __forceinline__ double block_sum_d8(double v, double* red) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -46,6 +55,65 @@ __device__ __forceinline__ double block_sum_d8(double v, double* red) {
 #pragma unroll
     for (int i = 0; i < FT / 64; ++i) r += red[i];
     return r;
+}
+
+// Reductions over aligned groups of G adjacent lanes (G a power of two, wave-uniform) WITHOUT the LDS pipeline.  __shfl_xor is a
+// ds_bpermute: with three of them per butterfly step and six steps per plane, the squeeze of a 256 x 7 x 7 frame queued 4 600 wave-wide
+// LDS operations, more time than its loads.  Inside a row of 16 lanes the steps are DPP operands of the add / compare itself
+// (quad_perm, then the two mirrors: after steps 1 and 2 a quad holds one value, so the mirror image is "the other quad"); across
+// rows gfx950 has v_permlane16_swap / v_permlane32_swap, one VALU move that hands every lane both halves.
+// All lanes of the wave must be active.  Order: 1, 2, 4, 8, 16, 32 (fixed, the same in every lane: deterministic).
+template <int CTRL> __device__ __forceinline__ float dppf(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL> __device__ __forceinline__ int dppi(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+constexpr int DPP_X1 = 0xB1, DPP_X2 = 0x4E, DPP_HM = 0x141, DPP_RM = 0x140;      // quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
+
+__device__ __forceinline__ float group_sum(float v, int G) {
+    if (G >= 2) v += dppf<DPP_X1>(v);
+    if (G >= 4) v += dppf<DPP_X2>(v);
+    if (G >= 8) v += dppf<DPP_HM>(v);
+    if (G >= 16) v += dppf<DPP_RM>(v);
+    if (G >= 32) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    if (G >= 64) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    return v;
+}
+
+// (max, first index of the max) with torch's tie rule (the lower index wins): symmetric, so both partners end with the same pair
+__device__ __forceinline__ void amax_take(float& mx, int& am, float ov, int oi) {
+    if (ov > mx || (ov == mx && oi < am)) { mx = ov; am = oi; }
+}
+__device__ __forceinline__ void group_sum_argmax(float& sum, float& mx, int& am, int G) {
+#define M3T_CB_STEP(CTRL)                                              \
+    do {                                                               \
+        sum += dppf<CTRL>(sum);                                        \
+        const float ov = dppf<CTRL>(mx);                               \
+        const int oi = dppi<CTRL>(am);                                 \
+        amax_take(mx, am, ov, oi);                                     \
+    } while (0)
+    if (G >= 2) M3T_CB_STEP(DPP_X1);
+    if (G >= 4) M3T_CB_STEP(DPP_X2);
+    if (G >= 8) M3T_CB_STEP(DPP_HM);
+    if (G >= 16) M3T_CB_STEP(DPP_RM);
+#undef M3T_CB_STEP
+#define M3T_CB_SWAP(B)                                                                                              \
+    do {                                                                                                            \
+        const auto rs = B(__float_as_uint(sum), __float_as_uint(sum), false, false);                                \
+        const auto rm = B(__float_as_uint(mx), __float_as_uint(mx), false, false);                                  \
+        const auto ri = B((unsigned)am, (unsigned)am, false, false);                                                \
+        sum = __uint_as_float(rs[0]) + __uint_as_float(rs[1]);                                                      \
+        mx = __uint_as_float(rm[0]); am = (int)ri[0];                                                               \
+        amax_take(mx, am, __uint_as_float(rm[1]), (int)ri[1]);                                                      \
+    } while (0)
+    if (G >= 32) M3T_CB_SWAP(__builtin_amdgcn_permlane16_swap);
+    if (G >= 64) M3T_CB_SWAP(__builtin_amdgcn_permlane32_swap);
+#undef M3T_CB_SWAP
 }
 
 template <int E> struct Unit;
@@ -84,7 +152,6 @@ __global__ __launch_bounds__(FT) void cbam_f1_kernel(const float* __restrict__ x
                                                      float* __restrict__ comp, int32_t* __restrict__ cargmax,
                                                      float* __restrict__ conv_out, double* __restrict__ part, int C, int Cr,
                                                      int H, int W, int G, int Qp) {
-    constexpr int PB = PlaneBatch<E>::n;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ double red[FT / 64];
     const int HW = H * W, Q = HW / E;
@@ -98,9 +165,11 @@ __global__ __launch_bounds__(FT) void cbam_f1_kernel(const float* __restrict__ x
     const int nk = Qp < 64 ? FT / 64 : FT / Qp;
     float* p_sum = p_mx + nk * Qp * E;
     int* p_am = reinterpret_cast<int*>(p_sum + nk * Qp * E);
+    int* s_amp = p_am + nk * Qp * E;          // [C] argmax_p
     const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* xb = x + (size_t)n * C * HW;
     if (tid < 50) s_w[tid] = convw[tid];
+    M3T_CB_STAMP(0);
 
     // ---- a. channel squeeze: avg, max, argmax per plane, G lanes per plane.  SMALL (Q <= G: a plane is ONE unit per lane): four
     // plane groups in flight per wave pass instead of four units of one plane
@@ -129,18 +198,10 @@ __global__ __launch_bounds__(FT) void cbam_f1_kernel(const float* __restrict__ x
                             if (v[k][e] > mx) { mx = v[k][e]; am = sub * E + e; }
                         }
                     }
-                    for (int o = G >> 1; o > 0; o >>= 1) {
-                        sum += __shfl_xor(sum, o, 64);
-                        const float ov = __shfl_xor(mx, o, 64);
-                        const int oi = __shfl_xor(am, o, 64);
-                        if (ov > mx || (ov == mx && oi < am)) { mx = ov; am = oi; }
-                    }
+                    group_sum_argmax(sum, mx, am, G);
                     if (sub == 0 && c < C) {
                         const float avg = sum / (float)HW;
-                        s_avg[c] = avg; s_max[c] = mx;
-                        pooled[((size_t)n * 2 + 0) * C + c] = avg;
-                        pooled[((size_t)n * 2 + 1) * C + c] = mx;
-                        argmax_p[(size_t)n * C + c] = am;
+                        s_avg[c] = avg; s_max[c] = mx; s_amp[c] = am;
                     }
                 }
             }
@@ -170,59 +231,111 @@ __global__ __launch_bounds__(FT) void cbam_f1_kernel(const float* __restrict__ x
                         }
                     }
             }
-            for (int o = G >> 1; o > 0; o >>= 1) {
-                sum += __shfl_xor(sum, o, 64);
-                const float ov = __shfl_xor(mx, o, 64);
-                const int oi = __shfl_xor(am, o, 64);
-                if (ov > mx || (ov == mx && oi < am)) { mx = ov; am = oi; }
-            }
+            group_sum_argmax(sum, mx, am, G);
             if (sub == 0 && okc) {
                 const float avg = sum / (float)HW;
-                s_avg[c] = avg; s_max[c] = mx;
-                pooled[((size_t)n * 2 + 0) * C + c] = avg;
-                pooled[((size_t)n * 2 + 1) * C + c] = mx;
-                argmax_p[(size_t)n * C + c] = am;
+                s_avg[c] = avg; s_max[c] = mx; s_amp[c] = am;
             }
         }
     }
     __syncthreads();
-    // ---- b. shared MLP C -> Cr -> C on both pooled vectors, sigmoid of the sum (reference cbam.py:51-58).  First layer: 8 lanes per
-    // output, every W1 load of the frame in flight at once (one wave per output, output after output, paid one L2 round trip per
-    // output: 8 in a row at the 4 x 4 stage, where the whole frame is one HBM round trip)
-    for (int j = tid >> 3; j < 2 * Cr; j += FT / 8) {
-        const int which = j / Cr, r = j % Cr, part = tid & 7;
-        const float* src = which ? s_max : s_avg;
-        const float* wr = w1 + (size_t)r * C;
-        float h = 0.f;
-        if ((C & 3) == 0 && ((uintptr_t)w1 & 15) == 0) {
-            const float4* w4 = reinterpret_cast<const float4*>(wr);
-            const float4* s4 = reinterpret_cast<const float4*>(src);
-            for (int c4 = part; c4 < (C >> 2); c4 += 8) {
-                const float4 a = w4[c4], b = s4[c4];
-                h += (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
+    M3T_CB_STAMP(1);
+    for (int c = tid; c < C; c += FT) {        // the frame's slab rows, coalesced (not three single-lane stores per plane)
+        pooled[((size_t)n * 2 + 0) * C + c] = s_avg[c];
+        pooled[((size_t)n * 2 + 1) * C + c] = s_max[c];
+        argmax_p[(size_t)n * C + c] = s_amp[c];
+    }
+    // ---- b. shared MLP C -> Cr -> C on both pooled vectors, sigmoid of the sum (reference cbam.py:51-58).  Both layers read their
+    // weight matrix as float4 streams with every load of the frame in flight before the first use and every byte of a fetched line
+    // used by the instruction that fetched it.  (Round 3 read W2 a row per LANE: 128-B stride, Cr load instructions of 64 lines each,
+    // ~2 000 cycles of the CU's one address path per wave -- 55 of the 73 us of F1 at the 512 x 4 x 4 stage; and W1 / W2 in loops of
+    // unknown trip count, which hipcc leaves as one load per L2 round trip.)
+    // First layer: 16 lanes per hidden unit, one W1 row feeds both pooled vectors.
+    const bool vec1 = (C & 3) == 0 && ((uintptr_t)w1 & 15) == 0;
+    for (int r0 = 0; r0 < Cr; r0 += FT / 16) {
+        const int r = r0 + (tid >> 4), part = tid & 15;
+        float ha = 0.f, hm = 0.f;
+        if (r < Cr) {
+            const float* wr = w1 + (size_t)r * C;
+            if (vec1) {
+                const float4* w4 = reinterpret_cast<const float4*>(wr);
+                const float4* a4 = reinterpret_cast<const float4*>(s_avg);
+                const float4* m4 = reinterpret_cast<const float4*>(s_max);
+                const int n4 = C >> 2;
+                for (int c0 = part; c0 < n4; c0 += 4 * 16) {
+                    float4 w[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int c4 = c0 + 16 * k;
+                        w[k] = c4 < n4 ? w4[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int c4 = c0 + 16 * k;
+                        if (c4 < n4) {
+                            const float4 a = a4[c4], m = m4[c4];
+                            ha += (w[k].x * a.x + w[k].y * a.y) + (w[k].z * a.z + w[k].w * a.w);
+                            hm += (w[k].x * m.x + w[k].y * m.y) + (w[k].z * m.z + w[k].w * m.w);
+                        }
+                    }
+                }
+            } else {
+                for (int c = part; c < C; c += 16) { ha += wr[c] * s_avg[c]; hm += wr[c] * s_max[c]; }
             }
-        } else {
-            for (int c = part; c < C; c += 8) h += wr[c] * src[c];
         }
-        h += __shfl_xor(h, 1, 64);
-        h += __shfl_xor(h, 2, 64);
-        h += __shfl_xor(h, 4, 64);
-        h += b1[r];
-        if (part == 0) {
-            hidden[((size_t)n * 2 + which) * Cr + r] = h;
-            s_h[j] = fmaxf(h, 0.f);
+        ha = group_sum(ha, 16);
+        hm = group_sum(hm, 16);
+        if (r < Cr && part == 0) {
+            ha += b1[r]; hm += b1[r];
+            hidden[((size_t)n * 2 + 0) * Cr + r] = ha;
+            hidden[((size_t)n * 2 + 1) * Cr + r] = hm;
+            s_h[r] = fmaxf(ha, 0.f);
+            s_h[Cr + r] = fmaxf(hm, 0.f);
         }
     }
     __syncthreads();
-    for (int c = tid; c < C; c += FT) {
-        const float* wr = w2 + (size_t)c * Cr;
-        float a0 = b2[c], a1 = b2[c];
-        for (int r = 0; r < Cr; ++r) { a0 += wr[r] * s_h[r]; a1 += wr[r] * s_h[Cr + r]; }
-        const float sc = 1.f / (1.f + expf(-(a0 + a1)));
-        s_sc[c] = sc;
-        cs[(size_t)n * C + c] = sc;
+    M3T_CB_STAMP(2);
+    // Second layer: W2 [C][Cr] as ONE flat float4 stream, L = Cr / 4 adjacent lanes per channel
+    if ((Cr & 3) == 0 && (Cr & (Cr - 1)) == 0 && ((uintptr_t)w2 & 15) == 0) {
+        const int L = Cr >> 2, lg = __ffs(L) - 1, sub2 = tid & (L - 1), n4 = C * L;
+        const float4* w4 = reinterpret_cast<const float4*>(w2);
+        const float4 h0 = reinterpret_cast<const float4*>(s_h)[sub2], h1 = reinterpret_cast<const float4*>(s_h + Cr)[sub2];
+        for (int i0 = 0; i0 < n4; i0 += 4 * FT) {
+            float4 w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + k * FT + tid;
+                w[k] = i < n4 ? w4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (i0 + k * FT >= n4) break;           // workgroup-uniform
+                const int i = i0 + k * FT + tid;
+                float a0 = (w[k].x * h0.x + w[k].y * h0.y) + (w[k].z * h0.z + w[k].w * h0.w);
+                float a1 = (w[k].x * h1.x + w[k].y * h1.y) + (w[k].z * h1.z + w[k].w * h1.w);
+                a0 = group_sum(a0, L);
+                a1 = group_sum(a1, L);
+                if (i < n4 && sub2 == 0) {
+                    const int c = i >> lg;
+                    const float bb = b2[c];
+                    const float sc = 1.f / (1.f + expf(-((bb + a0) + (bb + a1))));
+                    s_sc[c] = sc;
+                    cs[(size_t)n * C + c] = sc;
+                }
+            }
+        }
+    } else {
+        for (int c = tid; c < C; c += FT) {
+            const float* wr = w2 + (size_t)c * Cr;
+            float a0 = b2[c], a1 = b2[c];
+            for (int r = 0; r < Cr; ++r) { a0 += wr[r] * s_h[r]; a1 += wr[r] * s_h[Cr + r]; }
+            const float sc = 1.f / (1.f + expf(-(a0 + a1)));
+            s_sc[c] = sc;
+            cs[(size_t)n * C + c] = sc;
+        }
     }
     __syncthreads();
+    M3T_CB_STAMP(3);
     // ---- c. compress x * cs over channels: (max, mean, argmax) per pixel; thread = (unit q, channel slice k)
     {
         const int q = tid % Qp, k = tid / Qp, KS = FT / Qp;
@@ -279,6 +392,7 @@ __global__ __launch_bounds__(FT) void cbam_f1_kernel(const float* __restrict__ x
             }
         }
         __syncthreads();
+        M3T_CB_STAMP(4);
         if (tid < Q) {
             float fm[E], fs[E];
             int fa[E];
@@ -307,6 +421,7 @@ __global__ __launch_bounds__(FT) void cbam_f1_kernel(const float* __restrict__ x
         }
     }
     __syncthreads();
+    M3T_CB_STAMP(5);
     // ---- d. Conv2d(2, 1, 5, pad 2, bias=False) out of LDS + the frame's BatchNorm partial sums
     double s1 = 0.0, s2 = 0.0;
     for (int p = tid; p < HW; p += FT) {
@@ -330,9 +445,11 @@ __global__ __launch_bounds__(FT) void cbam_f1_kernel(const float* __restrict__ x
         conv_out[(size_t)n * HW + p] = acc;
         s1 += acc; s2 += (double)acc * acc;
     }
+    M3T_CB_STAMP(6);
     s1 = block_sum_d8(s1, red);
     s2 = block_sum_d8(s2, red);
     if (tid == 0) { part[2 * (size_t)n] = s1; part[2 * (size_t)n + 1] = s2; }
+    M3T_CB_STAMP(7);
 }
 
 // batch statistics of the conv output (train) or the running ones (eval) -> stats = (mean, 1 / sqrt(var + eps))
@@ -377,7 +494,6 @@ __global__ __launch_bounds__(FT) void cbam_f2_kernel(const float* __restrict__ x
                                                      const float* __restrict__ stats,
                                                      float* __restrict__ xhat, float* __restrict__ ss, float* __restrict__ y,
                                                      int C, int HW, int G) {
-    constexpr int PB = PlaneBatch<E>::n;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* s_sc = sm;
     float* s_ss = s_sc + al4(C);
@@ -567,7 +683,6 @@ __global__ __launch_bounds__(FT) void cbam_b2_kernel(const float* __restrict__ d
                                                      float* __restrict__ dx, float* __restrict__ g_datt, float* __restrict__ g_dh,
                                                      float* __restrict__ g_r, float* __restrict__ dwpart, int C, int Cr, int H,
                                                      int W, int G, float inv_total, int training) {
-    constexpr int PB = PlaneBatch<E>::n;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int HW = H * W, Q = HW / E, HWa = al4(HW);
     float* s_dc = sm;                          // [HW] gradient wrt the conv output
@@ -586,6 +701,7 @@ __global__ __launch_bounds__(FT) void cbam_b2_kernel(const float* __restrict__ d
     const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* xb = x + (size_t)n * C * HW;
     const float* gb = dy + (size_t)n * C * HW;
+    M3T_CB_STAMP(0);
     // ---- a. BatchNorm2d(1) backward per pixel, frame-local copies
     {
         const float gamma = bn_w[0], invstd = stats[1];
@@ -604,6 +720,7 @@ __global__ __launch_bounds__(FT) void cbam_b2_kernel(const float* __restrict__ d
         for (int c = tid; c < C; c += FT) s_sc[c] = cs[(size_t)n * C + c];
     }
     __syncthreads();
+    M3T_CB_STAMP(1);
     // ---- b. this frame's share of the conv weight gradient: 50 taps, one wave per tap
     for (int tap = wave; tap < 50; tap += FT / 64) {
         const int ch = tap / 25, i = (tap % 25) / 5, j = tap % 5;
@@ -613,7 +730,7 @@ __global__ __launch_bounds__(FT) void cbam_b2_kernel(const float* __restrict__ d
             const int h = ph + i - 2, w = pw + j - 2;
             if (h >= 0 && h < H && w >= 0 && w < W) s += s_dc[p] * s_comp[ch * HW + h * W + w];
         }
-        s = wave_sum(s);
+        s = group_sum(s, 64);
         if (lane == 0) dwpart[(size_t)n * 50 + tap] = s;
     }
     // ---- c. conv backward to the two compressed maps
@@ -637,6 +754,7 @@ __global__ __launch_bounds__(FT) void cbam_b2_kernel(const float* __restrict__ d
         s_dmn[p] = b / (float)C;
     }
     __syncthreads();
+    M3T_CB_STAMP(2);
     // ---- d. dcs[c] = sum_p dy1 * x with dy1 = dy * ss + dmean / C + [c == argmax_c] dmax (the spatial gate's input gradient)
     const int per = 64 / G, sub = lane % G, pi = lane / G;
     if (SMALL) {
@@ -665,7 +783,7 @@ __global__ __launch_bounds__(FT) void cbam_b2_kernel(const float* __restrict__ d
                         ds += dy1 * b[k][e];
                     }
                 }
-                for (int o = G >> 1; o > 0; o >>= 1) ds += __shfl_xor(ds, o, 64);
+                ds = group_sum(ds, G);
                 if (sub == 0 && c < C) {
                     const float sc = s_sc[c];
                     const float da = ds * sc * (1.f - sc);
@@ -702,7 +820,7 @@ __global__ __launch_bounds__(FT) void cbam_b2_kernel(const float* __restrict__ d
                     }
                 }
         }
-        for (int o = G >> 1; o > 0; o >>= 1) ds += __shfl_xor(ds, o, 64);
+        ds = group_sum(ds, G);
         if (sub == 0 && okc) {
             const float sc = s_sc[c];
             const float da = ds * sc * (1.f - sc);
@@ -711,13 +829,45 @@ __global__ __launch_bounds__(FT) void cbam_b2_kernel(const float* __restrict__ d
         }
     }
     __syncthreads();
+    M3T_CB_STAMP(3);
     // ---- e. shared MLP backward (as cbam.hip): g[r] = sum_c datt[c] W2[c][r] -> ReLU masks -> davg, dmax per channel
-    if (lane < Cr) {
+    // W2 as one flat float4 stream (as F1's second layer): a thread keeps its four columns r over every pass (FT is a multiple of
+    // L = Cr / 4), all loads of the frame in flight at once; then the lanes of a wave that share columns (stride L) are summed
+    if ((Cr & 3) == 0 && (Cr & (Cr - 1)) == 0 && ((uintptr_t)w2 & 15) == 0) {
+        const int L = Cr >> 2, lg = __ffs(L) - 1, n4 = C * L;
+        const float4* w4 = reinterpret_cast<const float4*>(w2);
+        float g[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int i0 = tid; i0 < n4; i0 += 4 * FT) {
+            float4 w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + k * FT;
+                w[k] = i < n4 ? w4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + k * FT;
+                if (i < n4) {
+                    const float d = s_datt[i >> lg];
+                    g[0] += d * w[k].x; g[1] += d * w[k].y; g[2] += d * w[k].z; g[3] += d * w[k].w;
+                }
+            }
+        }
+        for (int o = L; o < 64; o <<= 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] += __shfl_xor(g[e], o, 64);
+        }
+        if (lane < L) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s_part[wave * Cr + 4 * lane + e] = g[e];
+        }
+    } else if (lane < Cr) {
         float g = 0.f;
         for (int c = wave; c < C; c += FT / 64) g += s_datt[c] * w2[(size_t)c * Cr + lane];
         s_part[wave * Cr + lane] = g;
     }
     __syncthreads();
+    M3T_CB_STAMP(4);
     for (int j = tid; j < 2 * Cr; j += FT) {
         const int which = j / Cr, r = j % Cr;
         float g = 0.f;
@@ -733,17 +883,25 @@ __global__ __launch_bounds__(FT) void cbam_b2_kernel(const float* __restrict__ d
         }
     }
     __syncthreads();
+    M3T_CB_STAMP(5);
     for (int c = tid; c < C; c += FT) {
         float da = 0.f, dm = 0.f;
-        for (int r = 0; r < Cr; ++r) {
-            const float w = w1[(size_t)r * C + c];
-            da += s_dh[r] * w;
-            dm += s_dh[Cr + r] * w;
+        for (int r0 = 0; r0 < Cr; r0 += 8) {               // eight rows of W1 in flight (coalesced over c)
+            float w[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) w[k] = r0 + k < Cr ? w1[(size_t)(r0 + k) * C + c] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (r0 + k < Cr) {
+                    da += s_dh[r0 + k] * w[k];
+                    dm += s_dh[Cr + r0 + k] * w[k];
+                }
         }
         s_davg[c] = da / (float)HW;
         s_dmaxc[c] = dm;
     }
     __syncthreads();
+    M3T_CB_STAMP(6);
     // ---- f. dx = dy1 * cs + davg / HW + [p == argmax_p] dmaxc; dy is re-read while the frame is still cache-hot
     float* db = dx + (size_t)n * C * HW;
     if (SMALL) {
@@ -772,6 +930,7 @@ __global__ __launch_bounds__(FT) void cbam_b2_kernel(const float* __restrict__ d
                     Unit<E>::st(db + (size_t)c * HW + (size_t)sub * E, a[k]);
                 }
         }
+        M3T_CB_STAMP(7);
         return;
     }
     for (int c0 = wave * per; c0 < C; c0 += (FT / 64) * per) {
@@ -804,13 +963,20 @@ __global__ __launch_bounds__(FT) void cbam_b2_kernel(const float* __restrict__ d
                 }
         }
     }
+    M3T_CB_STAMP(7);
 }
 
 // conv weight gradient: sum of the per-frame partials in frame order (fp64 accumulation)
 __global__ __launch_bounds__(64) void cbam_dw_final_kernel(const float* __restrict__ dwpart, int N, float* __restrict__ dw) {
     const int tap = blockIdx.x;
     double s = 0.0;
-    for (int i = threadIdx.x; i < N; i += 64) s += (double)dwpart[(size_t)i * 50 + tap];
+    for (int i0 = threadIdx.x; i0 < N; i0 += 8 * 64) {       // eight loads in flight (one per L2 round trip made this launch 12-17 us)
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const int i = i0 + 64 * k; v[k] = i < N ? dwpart[(size_t)i * 50 + tap] : 0.f; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += (double)v[k];
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if (threadIdx.x == 0) dw[tap] = (float)s;
@@ -888,7 +1054,13 @@ __global__ __launch_bounds__(256) void cbam_pgrad_final_kernel(const float* __re
     const size_t per = 2 * (size_t)C * Cr + C + Cr;
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < per; i += (size_t)gridDim.x * 256) {
         float s = 0.f;
-        for (int k = 0; k < slices; ++k) s += part[(size_t)k * per + i];
+        for (int k0 = 0; k0 < slices; k0 += 8) {               // eight slices in flight, summed in slice order
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = k0 + k < slices ? part[(size_t)(k0 + k) * per + i] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += v[k];
+        }
         const size_t cc = (size_t)C * Cr;
         if (i < cc) dw2[i] = s;
         else if (i < 2 * cc) dw1[i - cc] = s;
@@ -920,7 +1092,7 @@ bool geometry(int HW, const void* const* ptrs, int nptr, Geo& g) {
 }
 
 size_t f1_lds(int C, int Cr, int HW, const Geo& g) {
-    return (size_t)(3 * al4(C) + al4(2 * Cr) + al4(2 * HW) + 52 + 3 * g.nk * g.Qp * g.E) * sizeof(float);
+    return (size_t)(3 * al4(C) + al4(2 * Cr) + al4(2 * HW) + 52 + 3 * g.nk * g.Qp * g.E + al4(C)) * sizeof(float);
 }
 size_t b2_lds(int C, int Cr, int HW) {
     return (size_t)(5 * al4(HW) + al4(2 * HW) + 52 + 4 * al4(C) + al4(2 * Cr) + 8 * Cr) * sizeof(float);
