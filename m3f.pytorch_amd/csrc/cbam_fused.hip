@@ -44,19 +44,6 @@ __device__ unsigned long long g_cb_stamps[8192 * 8];
 // batch).  Frames that fit LDS take the frame-resident kernels below (F1L / B2L), which have no cross-lane reductions at all.
 constexpr int PB = 4;
 
-__device__ __forceinline__ double block_sum_d8(double v, double* red) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    __syncthreads();
-    if (lane == 0) red[w] = v;
-    __syncthreads();
-    double r = 0.0;
-#pragma unroll
-    for (int i = 0; i < FT / 64; ++i) r += red[i];
-    return r;
-}
-
 // Reductions over aligned groups of G adjacent lanes (G a power of two, wave-uniform) WITHOUT the LDS pipeline.  __shfl_xor is a
 // ds_bpermute: with three of them per butterfly step and six steps per plane, the squeeze of a 256 x 7 x 7 frame queued 4 600 wave-wide
 // LDS operations, more time than its loads.  Inside a row of 16 lanes the steps are DPP operands of the add / compare itself
@@ -116,6 +103,23 @@ __device__ __forceinline__ void group_sum_argmax(float& sum, float& mx, int& am,
 #undef M3T_CB_SWAP
 }
 
+// both BatchNorm partial sums of a frame in one pass (two barriers instead of four): red holds 2 * FT / 64 doubles
+__device__ __forceinline__ void block_sum2_d8(double& a, double& b, double* red) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+    __syncthreads();
+    if (lane == 0) { red[w] = a; red[FT / 64 + w] = b; }
+    __syncthreads();
+    double ra = 0.0, rb = 0.0;
+#pragma unroll
+    for (int i = 0; i < FT / 64; ++i) { ra += red[i]; rb += red[FT / 64 + i]; }
+    a = ra; b = rb;
+}
+
+// zero-padded copies of H x W maps for the 5 x 5 convolutions: (H + 4) x (W + 4), pixel (y, x) at (y + 2) * (W + 4) + x + 2
+__host__ __device__ inline int pad_len(int H, int W) { return (H + 4) * (W + 4); }
+
 template <int E> struct Unit;
 template <> struct Unit<4> {
     static __device__ __forceinline__ void ld(const float* p, float (&v)[4]) {
@@ -142,6 +146,131 @@ template <> struct Unit<1> {
 
 __host__ __device__ inline int al4(int n) { return (n + 3) & ~3; }
 
+// ---- the gate's shared MLP for one frame (phase b of F1 / F1L).  In: s_avg, s_max [C] in LDS (16-B aligned).  Out: s_sc [C] (sigmoid),
+// the slabs hidden [2][Cr] (pre-ReLU) and cs [C]; s_h [2 Cr] is scratch.  Ends WITHOUT a barrier: the caller syncs before reading s_sc.
+__device__ __forceinline__ void gate_mlp_fwd(const float* s_avg, const float* s_max, float* s_h, float* s_sc, const float* __restrict__ w1,
+                                             const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
+                                             float* __restrict__ hidden, float* __restrict__ cs, int n, int C, int Cr) {
+    const int tid = threadIdx.x;
+    // ---- b. shared MLP C -> Cr -> C on both pooled vectors, sigmoid of the sum (reference cbam.py:51-58).  Both layers read their
+    // weight matrix as float4 streams with every load of the frame in flight before the first use and every byte of a fetched line
+    // used by the instruction that fetched it.  (Round 3 read W2 a row per LANE: 128-B stride, Cr load instructions of 64 lines each,
+    // ~2 000 cycles of the CU's one address path per wave -- 55 of the 73 us of F1 at the 512 x 4 x 4 stage; and W1 / W2 in loops of
+    // unknown trip count, which hipcc leaves as one load per L2 round trip.)
+    // First layer: 16 lanes per hidden unit, one W1 row feeds both pooled vectors.
+    const bool vec1 = (C & 3) == 0 && ((uintptr_t)w1 & 15) == 0;
+    for (int r0 = 0; r0 < Cr; r0 += FT / 16) {
+        const int r = r0 + (tid >> 4), part = tid & 15;
+        float ha = 0.f, hm = 0.f;
+        const float bias1 = r < Cr ? b1[r] : 0.f;            // in flight with the W1 loads, not a round trip of its own after them
+        if (r < Cr) {
+            const float* wr = w1 + (size_t)r * C;
+            if (vec1) {
+                const float4* w4 = reinterpret_cast<const float4*>(wr);
+                const float4* a4 = reinterpret_cast<const float4*>(s_avg);
+                const float4* m4 = reinterpret_cast<const float4*>(s_max);
+                const int n4 = C >> 2;
+                for (int c0 = part; c0 < n4; c0 += 4 * 16) {
+                    float4 w[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int c4 = c0 + 16 * k;
+                        w[k] = c4 < n4 ? w4[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int c4 = c0 + 16 * k;
+                        if (c4 < n4) {
+                            const float4 a = a4[c4], m = m4[c4];
+                            ha += (w[k].x * a.x + w[k].y * a.y) + (w[k].z * a.z + w[k].w * a.w);
+                            hm += (w[k].x * m.x + w[k].y * m.y) + (w[k].z * m.z + w[k].w * m.w);
+                        }
+                    }
+                }
+            } else {
+                for (int c = part; c < C; c += 16) { ha += wr[c] * s_avg[c]; hm += wr[c] * s_max[c]; }
+            }
+        }
+        ha = group_sum(ha, 16);
+        hm = group_sum(hm, 16);
+        if (r < Cr && part == 0) {
+            ha += bias1; hm += bias1;
+            hidden[((size_t)n * 2 + 0) * Cr + r] = ha;
+            hidden[((size_t)n * 2 + 1) * Cr + r] = hm;
+            s_h[r] = fmaxf(ha, 0.f);
+            s_h[Cr + r] = fmaxf(hm, 0.f);
+        }
+    }
+    __syncthreads();
+    M3T_CB_STAMP(2);
+    // Second layer: W2 [C][Cr] as ONE flat float4 stream, L = Cr / 4 adjacent lanes per channel
+    if ((Cr & 3) == 0 && (Cr & (Cr - 1)) == 0 && ((uintptr_t)w2 & 15) == 0) {
+        const int L = Cr >> 2, lg = __ffs(L) - 1, sub2 = tid & (L - 1), n4 = C * L;
+        const float4* w4 = reinterpret_cast<const float4*>(w2);
+        const float4 h0 = reinterpret_cast<const float4*>(s_h)[sub2], h1 = reinterpret_cast<const float4*>(s_h + Cr)[sub2];
+        for (int i0 = 0; i0 < n4; i0 += 4 * FT) {
+            float4 w[4];
+            float bb[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + k * FT + tid;
+                w[k] = i < n4 ? w4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                bb[k] = i < n4 ? b2[i >> lg] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (i0 + k * FT >= n4) break;           // workgroup-uniform
+                const int i = i0 + k * FT + tid;
+                float a0 = (w[k].x * h0.x + w[k].y * h0.y) + (w[k].z * h0.z + w[k].w * h0.w);
+                float a1 = (w[k].x * h1.x + w[k].y * h1.y) + (w[k].z * h1.z + w[k].w * h1.w);
+                a0 = group_sum(a0, L);
+                a1 = group_sum(a1, L);
+                if (i < n4 && sub2 == 0) {
+                    const int c = i >> lg;
+                    const float sc = 1.f / (1.f + expf(-((bb[k] + a0) + (bb[k] + a1))));
+                    s_sc[c] = sc;
+                    cs[(size_t)n * C + c] = sc;
+                }
+            }
+        }
+    } else {
+        for (int c = tid; c < C; c += FT) {
+            const float* wr = w2 + (size_t)c * Cr;
+            float a0 = b2[c], a1 = b2[c];
+            for (int r = 0; r < Cr; ++r) { a0 += wr[r] * s_h[r]; a1 += wr[r] * s_h[Cr + r]; }
+            const float sc = 1.f / (1.f + expf(-(a0 + a1)));
+            s_sc[c] = sc;
+            cs[(size_t)n * C + c] = sc;
+        }
+    }
+}
+
+// ---- the spatial gate's 5 x 5 convolution (Conv2d(2, 1, 5, pad 2, bias=False), reference cbam.py:70-77) of the two compressed maps and
+// the frame's BatchNorm partial sums (phase d).  s_pad: the maps zero-padded in LDS ([2][pad_len]), so a pixel is 50 unconditional
+// multiply-adds; the weights are read with constant indices from the kernel argument: scalar loads, SGPR operands.  (Round 3 tested
+// the bounds of every tap and read the weights from LDS: 3 us per frame on the one wave that has pixels at the small stages.)
+__device__ __forceinline__ void spatial_conv_fwd(const float* s_pad, const float* __restrict__ convw, double* red, float* __restrict__ conv_out,
+                                                 double* __restrict__ part, int n, int H, int W) {
+    const int tid = threadIdx.x, HW = H * W, Wp = W + 4, PP = pad_len(H, W);
+    double s1 = 0.0, s2 = 0.0;
+    for (int p = tid; p < HW; p += FT) {
+        const int h = p / W, ww = p - h * W;
+        const float* c0 = s_pad + h * Wp + ww;
+        float acc = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+#pragma unroll
+                for (int j = 0; j < 5; ++j) acc += convw[(ch * 5 + i) * 5 + j] * c0[ch * PP + i * Wp + j];
+        conv_out[(size_t)n * HW + p] = acc;
+        s1 += acc; s2 += (double)acc * acc;
+    }
+    M3T_CB_STAMP(6);
+    block_sum2_d8(s1, s2, red);
+    if (tid == 0) { part[2 * (size_t)n] = s1; part[2 * (size_t)n + 1] = s2; }
+}
+
 // ------------------------------------------------------------------------------------------------ F1
 template <int E, bool SMALL>
 __global__ __launch_bounds__(FT) void cbam_f1_kernel(const float* __restrict__ x, const float* __restrict__ w1,
@@ -153,22 +282,21 @@ __global__ __launch_bounds__(FT) void cbam_f1_kernel(const float* __restrict__ x
                                                      float* __restrict__ conv_out, double* __restrict__ part, int C, int Cr,
                                                      int H, int W, int G, int Qp) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    __shared__ double red[FT / 64];
-    const int HW = H * W, Q = HW / E;
+    __shared__ double red[2 * FT / 64];
+    const int HW = H * W, Q = HW / E, PP = pad_len(H, W);
     float* s_avg = sm;
     float* s_max = s_avg + al4(C);
     float* s_sc = s_max + al4(C);
     float* s_h = s_sc + al4(C);               // [2 Cr]
-    float* s_comp = s_h + al4(2 * Cr);        // [2][HW]
-    float* s_w = s_comp + al4(2 * HW);        // [50]
-    float* p_mx = s_w + 52;                   // [nk][Qp][E]
+    float* s_pad = s_h + al4(2 * Cr);         // [2][PP] the compressed maps, zero-padded
+    float* p_mx = s_pad + al4(2 * PP);        // [nk][Qp][E]
     const int nk = Qp < 64 ? FT / 64 : FT / Qp;
     float* p_sum = p_mx + nk * Qp * E;
     int* p_am = reinterpret_cast<int*>(p_sum + nk * Qp * E);
     int* s_amp = p_am + nk * Qp * E;          // [C] argmax_p
     const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* xb = x + (size_t)n * C * HW;
-    if (tid < 50) s_w[tid] = convw[tid];
+    for (int i = tid; i < 2 * PP; i += FT) s_pad[i] = 0.f;
     M3T_CB_STAMP(0);
 
     // ---- a. channel squeeze: avg, max, argmax per plane, G lanes per plane.  SMALL (Q <= G: a plane is ONE unit per lane): four
@@ -245,95 +373,7 @@ __global__ __launch_bounds__(FT) void cbam_f1_kernel(const float* __restrict__ x
         pooled[((size_t)n * 2 + 1) * C + c] = s_max[c];
         argmax_p[(size_t)n * C + c] = s_amp[c];
     }
-    // ---- b. shared MLP C -> Cr -> C on both pooled vectors, sigmoid of the sum (reference cbam.py:51-58).  Both layers read their
-    // weight matrix as float4 streams with every load of the frame in flight before the first use and every byte of a fetched line
-    // used by the instruction that fetched it.  (Round 3 read W2 a row per LANE: 128-B stride, Cr load instructions of 64 lines each,
-    // ~2 000 cycles of the CU's one address path per wave -- 55 of the 73 us of F1 at the 512 x 4 x 4 stage; and W1 / W2 in loops of
-    // unknown trip count, which hipcc leaves as one load per L2 round trip.)
-    // First layer: 16 lanes per hidden unit, one W1 row feeds both pooled vectors.
-    const bool vec1 = (C & 3) == 0 && ((uintptr_t)w1 & 15) == 0;
-    for (int r0 = 0; r0 < Cr; r0 += FT / 16) {
-        const int r = r0 + (tid >> 4), part = tid & 15;
-        float ha = 0.f, hm = 0.f;
-        if (r < Cr) {
-            const float* wr = w1 + (size_t)r * C;
-            if (vec1) {
-                const float4* w4 = reinterpret_cast<const float4*>(wr);
-                const float4* a4 = reinterpret_cast<const float4*>(s_avg);
-                const float4* m4 = reinterpret_cast<const float4*>(s_max);
-                const int n4 = C >> 2;
-                for (int c0 = part; c0 < n4; c0 += 4 * 16) {
-                    float4 w[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int c4 = c0 + 16 * k;
-                        w[k] = c4 < n4 ? w4[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
-                    }
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int c4 = c0 + 16 * k;
-                        if (c4 < n4) {
-                            const float4 a = a4[c4], m = m4[c4];
-                            ha += (w[k].x * a.x + w[k].y * a.y) + (w[k].z * a.z + w[k].w * a.w);
-                            hm += (w[k].x * m.x + w[k].y * m.y) + (w[k].z * m.z + w[k].w * m.w);
-                        }
-                    }
-                }
-            } else {
-                for (int c = part; c < C; c += 16) { ha += wr[c] * s_avg[c]; hm += wr[c] * s_max[c]; }
-            }
-        }
-        ha = group_sum(ha, 16);
-        hm = group_sum(hm, 16);
-        if (r < Cr && part == 0) {
-            ha += b1[r]; hm += b1[r];
-            hidden[((size_t)n * 2 + 0) * Cr + r] = ha;
-            hidden[((size_t)n * 2 + 1) * Cr + r] = hm;
-            s_h[r] = fmaxf(ha, 0.f);
-            s_h[Cr + r] = fmaxf(hm, 0.f);
-        }
-    }
-    __syncthreads();
-    M3T_CB_STAMP(2);
-    // Second layer: W2 [C][Cr] as ONE flat float4 stream, L = Cr / 4 adjacent lanes per channel
-    if ((Cr & 3) == 0 && (Cr & (Cr - 1)) == 0 && ((uintptr_t)w2 & 15) == 0) {
-        const int L = Cr >> 2, lg = __ffs(L) - 1, sub2 = tid & (L - 1), n4 = C * L;
-        const float4* w4 = reinterpret_cast<const float4*>(w2);
-        const float4 h0 = reinterpret_cast<const float4*>(s_h)[sub2], h1 = reinterpret_cast<const float4*>(s_h + Cr)[sub2];
-        for (int i0 = 0; i0 < n4; i0 += 4 * FT) {
-            float4 w[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int i = i0 + k * FT + tid;
-                w[k] = i < n4 ? w4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (i0 + k * FT >= n4) break;           // workgroup-uniform
-                const int i = i0 + k * FT + tid;
-                float a0 = (w[k].x * h0.x + w[k].y * h0.y) + (w[k].z * h0.z + w[k].w * h0.w);
-                float a1 = (w[k].x * h1.x + w[k].y * h1.y) + (w[k].z * h1.z + w[k].w * h1.w);
-                a0 = group_sum(a0, L);
-                a1 = group_sum(a1, L);
-                if (i < n4 && sub2 == 0) {
-                    const int c = i >> lg;
-                    const float bb = b2[c];
-                    const float sc = 1.f / (1.f + expf(-((bb + a0) + (bb + a1))));
-                    s_sc[c] = sc;
-                    cs[(size_t)n * C + c] = sc;
-                }
-            }
-        }
-    } else {
-        for (int c = tid; c < C; c += FT) {
-            const float* wr = w2 + (size_t)c * Cr;
-            float a0 = b2[c], a1 = b2[c];
-            for (int r = 0; r < Cr; ++r) { a0 += wr[r] * s_h[r]; a1 += wr[r] * s_h[Cr + r]; }
-            const float sc = 1.f / (1.f + expf(-(a0 + a1)));
-            s_sc[c] = sc;
-            cs[(size_t)n * C + c] = sc;
-        }
-    }
+    gate_mlp_fwd(s_avg, s_max, s_h, s_sc, w1, b1, w2, b2, hidden, cs, n, C, Cr);
     __syncthreads();
     M3T_CB_STAMP(3);
     // ---- c. compress x * cs over channels: (max, mean, argmax) per pixel; thread = (unit q, channel slice k)
@@ -412,8 +452,9 @@ __global__ __launch_bounds__(FT) void cbam_f1_kernel(const float* __restrict__ x
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 mean[e] = fs[e] / (float)C;
-                s_comp[tid * E + e] = fm[e];
-                s_comp[HW + tid * E + e] = mean[e];
+                const int pp = tid * E + e, ph = pp / W, ip = (ph + 2) * (W + 4) + (pp - ph * W) + 2;
+                s_pad[ip] = fm[e];
+                s_pad[PP + ip] = mean[e];
             }
             Unit<E>::st(comp + ((size_t)n * 2 + 0) * HW + (size_t)tid * E, fm);
             Unit<E>::st(comp + ((size_t)n * 2 + 1) * HW + (size_t)tid * E, mean);
@@ -422,33 +463,7 @@ __global__ __launch_bounds__(FT) void cbam_f1_kernel(const float* __restrict__ x
     }
     __syncthreads();
     M3T_CB_STAMP(5);
-    // ---- d. Conv2d(2, 1, 5, pad 2, bias=False) out of LDS + the frame's BatchNorm partial sums
-    double s1 = 0.0, s2 = 0.0;
-    for (int p = tid; p < HW; p += FT) {
-        const int h = p / W, ww = p - h * W;
-        float acc = 0.f;
-#pragma unroll
-        for (int ch = 0; ch < 2; ++ch) {
-            const float* cp = s_comp + ch * HW;
-#pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                const int hh = h + i - 2;
-                if (hh < 0 || hh >= H) continue;
-#pragma unroll
-                for (int j = 0; j < 5; ++j) {
-                    const int wj = ww + j - 2;
-                    if (wj < 0 || wj >= W) continue;
-                    acc += s_w[(ch * 5 + i) * 5 + j] * cp[hh * W + wj];
-                }
-            }
-        }
-        conv_out[(size_t)n * HW + p] = acc;
-        s1 += acc; s2 += (double)acc * acc;
-    }
-    M3T_CB_STAMP(6);
-    s1 = block_sum_d8(s1, red);
-    s2 = block_sum_d8(s2, red);
-    if (tid == 0) { part[2 * (size_t)n] = s1; part[2 * (size_t)n + 1] = s2; }
+    spatial_conv_fwd(s_pad, convw, red, conv_out, part, n, H, W);
     M3T_CB_STAMP(7);
 }
 
@@ -570,7 +585,7 @@ __global__ __launch_bounds__(FT) void cbam_b1_kernel(const float* __restrict__ d
                                                      const float* __restrict__ xhat, float* __restrict__ dpre,
                                                      double* __restrict__ part, int C, int HW, int Qp) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    __shared__ double red[FT / 64];
+    __shared__ double red[2 * FT / 64];
     float* s_sc = sm;
     float* p_sum = s_sc + al4(C);
     const int Q = HW / E;
@@ -637,8 +652,7 @@ __global__ __launch_bounds__(FT) void cbam_b1_kernel(const float* __restrict__ d
         }
         Unit<E>::st(dpre + o, d);
     }
-    s1 = block_sum_d8(s1, red);
-    s2 = block_sum_d8(s2, red);
+    block_sum2_d8(s1, s2, red);
     if (tid == 0) { part[2 * (size_t)n] = s1; part[2 * (size_t)n + 1] = s2; }
 }
 
@@ -664,6 +678,170 @@ __global__ __launch_bounds__(256) void cbam_sum_pairs_kernel(const double* __res
     }
 }
 
+// ---- B2's per-pixel LDS maps
+struct B2Lds {
+    float* dc;        // [HW] gradient wrt the conv output
+    float* ss;        // [HW] spatial scale
+    float* dmx;       // [HW] gradient wrt the max map
+    float* dmn;       // [HW] gradient wrt the mean map, already / C
+    int* cam;         // [HW] argmax_c
+    int* pb;          // [HW] a pixel's 5 x 5 window origin in the padded maps: h * (W + 4) + w
+    float* dcp;       // [PP] dc, zero-padded
+    float* compp;     // [2][PP] the two compressed maps, zero-padded
+    float* rest;      // what the kernel places behind the maps
+};
+__device__ __forceinline__ B2Lds b2_lds_map(float* sm, int H, int W) {
+    const int HWa = al4(H * W), PPa = al4(pad_len(H, W));
+    B2Lds L;
+    L.dc = sm; L.ss = L.dc + HWa; L.dmx = L.ss + HWa; L.dmn = L.dmx + HWa;
+    L.cam = reinterpret_cast<int*>(L.dmn + HWa); L.pb = L.cam + HWa;
+    L.dcp = reinterpret_cast<float*>(L.pb + HWa); L.compp = L.dcp + PPa; L.rest = L.compp + 2 * PPa;
+    return L;
+}
+__host__ __device__ inline int b2_map_floats(int H, int W) { return 6 * al4(H * W) + 3 * al4(pad_len(H, W)); }
+
+// ---- the spatial gate's backward for one frame up to the gradients of the two compressed maps (phases a-c of B2 / B2L):
+//   a. BatchNorm2d(1) backward per pixel (reference cbam.py:78), the frame's per-pixel maps into LDS: one sweep over the PADDED index
+//      space fills the padded and the plain copies, so no location has two writers
+//   b. this frame's share of the conv weight gradient: 50 taps, one wave per tap, no bounds tests (padded maps), no divisions (pb)
+//   c. conv backward to the two compressed maps: 25 unconditional taps per pixel, weights as scalar operands
+// Ends WITHOUT a barrier after c.
+__device__ __forceinline__ void spatial_bwd(const B2Lds& L, const float* __restrict__ convw, const float* __restrict__ bn_w,
+                                            const float* __restrict__ stats, const float* __restrict__ dgb, const float* __restrict__ comp,
+                                            const int32_t* __restrict__ cargmax, const float* __restrict__ xhat, const float* __restrict__ ss,
+                                            const float* __restrict__ dpre, float* __restrict__ dwpart, int n, int H, int W, int C,
+                                            float inv_total, int training) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int HW = H * W, Wp = W + 4, PP = pad_len(H, W), PPa = al4(PP);
+    {
+        const float gamma = bn_w[0], invstd = stats[1];
+        const float m1 = gamma * dgb[1] * inv_total;       // mean(dxhat)
+        const float m2 = gamma * dgb[0] * inv_total;       // mean(dxhat * xhat)
+        for (int i = tid; i < PP; i += FT) {
+            const int yy = i / Wp, y = yy - 2, xq = i - yy * Wp - 2;
+            const bool in = y >= 0 && y < H && xq >= 0 && xq < W;
+            float dc = 0.f, c0 = 0.f, c1 = 0.f;
+            if (in) {
+                const int pp = y * W + xq;
+                const size_t o = (size_t)n * HW + pp;
+                const float dxh = dpre[o] * gamma;
+                dc = training ? invstd * (dxh - m1 - xhat[o] * m2) : dxh * invstd;
+                c0 = comp[((size_t)n * 2 + 0) * HW + pp];
+                c1 = comp[((size_t)n * 2 + 1) * HW + pp];
+                L.dc[pp] = dc;
+                L.ss[pp] = ss[o];
+                L.cam[pp] = cargmax[o];
+                L.pb[pp] = y * Wp + xq;
+            }
+            L.dcp[i] = dc;
+            L.compp[i] = c0;
+            L.compp[PPa + i] = c1;
+        }
+    }
+    __syncthreads();
+    M3T_CB_STAMP(1);
+    for (int tap = wave; tap < 50; tap += FT / 64) {
+        const int ch = tap / 25, i = (tap % 25) / 5, j = tap % 5;
+        const float* cp = L.compp + ch * PPa + i * Wp + j;
+        float s = 0.f;
+        for (int pp = lane; pp < HW; pp += 64) s += L.dc[pp] * cp[L.pb[pp]];
+        s = group_sum(s, 64);
+        if (lane == 0) dwpart[(size_t)n * 50 + tap] = s;
+    }
+    for (int pp = tid; pp < HW; pp += FT) {
+        const float* d0 = L.dcp + L.pb[pp] + 4 * Wp + 4;      // dc at (h + 2 - i, w + 2 - j) = d0[-(i * Wp + j)]
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const float d = d0[-(i * Wp + j)];
+                a += convw[(0 * 5 + i) * 5 + j] * d;
+                b += convw[(1 * 5 + i) * 5 + j] * d;
+            }
+        L.dmx[pp] = a;
+        L.dmn[pp] = b / (float)C;
+    }
+}
+
+// ---- the gate's shared MLP backward for one frame (phase e of B2 / B2L, reference cbam.py:51-58).  In: s_datt [C] (gradient at the
+// sigmoid's input).  Out: s_davg [C] (already / HW), s_dmaxc [C]; slabs g_dh, g_r for the parameter gradients.  Ends WITHOUT a barrier.
+__device__ __forceinline__ void gate_mlp_bwd(const float* s_datt, float* s_part, float* s_dh, float* s_davg, float* s_dmaxc,
+                                             const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ hidden,
+                                             float* __restrict__ g_dh, float* __restrict__ g_r, int n, int C, int Cr, int HW) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // ---- e. shared MLP backward (as cbam.hip): g[r] = sum_c datt[c] W2[c][r] -> ReLU masks -> davg, dmax per channel
+    // W2 as one flat float4 stream (as F1's second layer): a thread keeps its four columns r over every pass (FT is a multiple of
+    // L = Cr / 4), all loads of the frame in flight at once; then the lanes of a wave that share columns (stride L) are summed
+    if ((Cr & 3) == 0 && (Cr & (Cr - 1)) == 0 && ((uintptr_t)w2 & 15) == 0) {
+        const int L = Cr >> 2, lg = __ffs(L) - 1, n4 = C * L;
+        const float4* w4 = reinterpret_cast<const float4*>(w2);
+        float g[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int i0 = tid; i0 < n4; i0 += 4 * FT) {
+            float4 w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + k * FT;
+                w[k] = i < n4 ? w4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + k * FT;
+                if (i < n4) {
+                    const float d = s_datt[i >> lg];
+                    g[0] += d * w[k].x; g[1] += d * w[k].y; g[2] += d * w[k].z; g[3] += d * w[k].w;
+                }
+            }
+        }
+        for (int o = L; o < 64; o <<= 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] += __shfl_xor(g[e], o, 64);
+        }
+        if (lane < L) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s_part[wave * Cr + 4 * lane + e] = g[e];
+        }
+    } else if (lane < Cr) {
+        float g = 0.f;
+        for (int c = wave; c < C; c += FT / 64) g += s_datt[c] * w2[(size_t)c * Cr + lane];
+        s_part[wave * Cr + lane] = g;
+    }
+    __syncthreads();
+    M3T_CB_STAMP(4);
+    for (int j = tid; j < 2 * Cr; j += FT) {
+        const int which = j / Cr, r = j % Cr;
+        float g = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < FT / 64; ++wv) g += s_part[wv * Cr + r];
+        const float h = hidden[((size_t)n * 2 + which) * Cr + r];
+        const float dh = h > 0.f ? g : 0.f;
+        s_dh[j] = dh;
+        g_dh[((size_t)n * 2 + which) * Cr + r] = dh;
+        if (which == 0) {
+            const float hm = hidden[((size_t)n * 2 + 1) * Cr + r];
+            g_r[(size_t)n * Cr + r] = fmaxf(h, 0.f) + fmaxf(hm, 0.f);
+        }
+    }
+    __syncthreads();
+    M3T_CB_STAMP(5);
+    for (int c = tid; c < C; c += FT) {
+        float da = 0.f, dm = 0.f;
+        for (int r0 = 0; r0 < Cr; r0 += 16) {              // sixteen rows of W1 in flight (coalesced over c)
+            float w[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) w[k] = r0 + k < Cr ? w1[(size_t)(r0 + k) * C + c] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (r0 + k < Cr) {
+                    da += s_dh[r0 + k] * w[k];
+                    dm += s_dh[Cr + r0 + k] * w[k];
+                }
+        }
+        s_davg[c] = da / (float)HW;
+        s_dmaxc[c] = dm;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ B2
 #ifndef M3T_CBAM_B2_UB
 #define M3T_CBAM_B2_UB 2
@@ -672,7 +850,7 @@ constexpr int UB = M3T_CBAM_B2_UB;      // units in flight per lane in B2's plan
                                         // per CU (4 -> 118, two): 0.996 vs 1.037 ms for the whole gate at 2048 x 64 x 28 x 28
 
 template <int E, bool SMALL>
-__global__ __launch_bounds__(FT) void cbam_b2_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+__global__ __launch_bounds__(FT, 6) void cbam_b2_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ w1, const float* __restrict__ w2,
                                                      const float* __restrict__ convw, const float* __restrict__ bn_w,
                                                      const float* __restrict__ stats, const float* __restrict__ dgb,
@@ -684,75 +862,25 @@ __global__ __launch_bounds__(FT) void cbam_b2_kernel(const float* __restrict__ d
                                                      float* __restrict__ g_r, float* __restrict__ dwpart, int C, int Cr, int H,
                                                      int W, int G, float inv_total, int training) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int HW = H * W, Q = HW / E, HWa = al4(HW);
-    float* s_dc = sm;                          // [HW] gradient wrt the conv output
-    float* s_ss = s_dc + HWa;                  // [HW]
-    float* s_dmx = s_ss + HWa;                 // [HW] gradient wrt the max map
-    float* s_dmn = s_dmx + HWa;                // [HW] gradient wrt the mean map, already / C
-    int* s_cam = reinterpret_cast<int*>(s_dmn + HWa);      // [HW] argmax_c
-    float* s_comp = reinterpret_cast<float*>(s_cam + HWa); // [2][HW]
-    float* s_w = s_comp + al4(2 * HW);         // [50]
-    float* s_sc = s_w + 52;                    // [C]
+    const int HW = H * W, Q = HW / E;
+    const B2Lds L = b2_lds_map(sm, H, W);
+    const float* s_ss = L.ss;
+    const float* s_dmx = L.dmx;
+    const float* s_dmn = L.dmn;
+    const int* s_cam = L.cam;
+    float* s_sc = L.rest;                      // [C]
     float* s_datt = s_sc + al4(C);
     float* s_davg = s_datt + al4(C);
     float* s_dmaxc = s_davg + al4(C);
     float* s_dh = s_dmaxc + al4(C);            // [2 Cr]
     float* s_part = s_dh + al4(2 * Cr);        // [8][Cr]
+    int* s_amp = reinterpret_cast<int*>(s_part + 8 * Cr);      // [C] argmax_p
     const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* xb = x + (size_t)n * C * HW;
     const float* gb = dy + (size_t)n * C * HW;
     M3T_CB_STAMP(0);
-    // ---- a. BatchNorm2d(1) backward per pixel, frame-local copies
-    {
-        const float gamma = bn_w[0], invstd = stats[1];
-        const float m1 = gamma * dgb[1] * inv_total;       // mean(dxhat)
-        const float m2 = gamma * dgb[0] * inv_total;       // mean(dxhat * xhat)
-        for (int p = tid; p < HW; p += FT) {
-            const size_t o = (size_t)n * HW + p;
-            const float dxh = dpre[o] * gamma;
-            s_dc[p] = training ? invstd * (dxh - m1 - xhat[o] * m2) : dxh * invstd;
-            s_ss[p] = ss[o];
-            s_cam[p] = cargmax[o];
-            s_comp[p] = comp[((size_t)n * 2 + 0) * HW + p];
-            s_comp[HW + p] = comp[((size_t)n * 2 + 1) * HW + p];
-        }
-        if (tid < 50) s_w[tid] = convw[tid];
-        for (int c = tid; c < C; c += FT) s_sc[c] = cs[(size_t)n * C + c];
-    }
-    __syncthreads();
-    M3T_CB_STAMP(1);
-    // ---- b. this frame's share of the conv weight gradient: 50 taps, one wave per tap
-    for (int tap = wave; tap < 50; tap += FT / 64) {
-        const int ch = tap / 25, i = (tap % 25) / 5, j = tap % 5;
-        float s = 0.f;
-        for (int p = lane; p < HW; p += 64) {
-            const int ph = p / W, pw = p - ph * W;
-            const int h = ph + i - 2, w = pw + j - 2;
-            if (h >= 0 && h < H && w >= 0 && w < W) s += s_dc[p] * s_comp[ch * HW + h * W + w];
-        }
-        s = group_sum(s, 64);
-        if (lane == 0) dwpart[(size_t)n * 50 + tap] = s;
-    }
-    // ---- c. conv backward to the two compressed maps
-    for (int p = tid; p < HW; p += FT) {
-        const int h = p / W, ww = p - h * W;
-        float a = 0.f, b = 0.f;
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int hh = h - i + 2;
-            if (hh < 0 || hh >= H) continue;
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                const int wj = ww - j + 2;
-                if (wj < 0 || wj >= W) continue;
-                const float d = s_dc[hh * W + wj];
-                a += s_w[(0 * 5 + i) * 5 + j] * d;
-                b += s_w[(1 * 5 + i) * 5 + j] * d;
-            }
-        }
-        s_dmx[p] = a;
-        s_dmn[p] = b / (float)C;
-    }
+    spatial_bwd(L, convw, bn_w, stats, dgb, comp, cargmax, xhat, ss, dpre, dwpart, n, H, W, C, inv_total, training);
+    for (int c = tid; c < C; c += FT) { s_sc[c] = cs[(size_t)n * C + c]; s_amp[c] = argmax_p[(size_t)n * C + c]; }
     __syncthreads();
     M3T_CB_STAMP(2);
     // ---- d. dcs[c] = sum_p dy1 * x with dy1 = dy * ss + dmean / C + [c == argmax_c] dmax (the spatial gate's input gradient)
@@ -830,76 +958,7 @@ __global__ __launch_bounds__(FT) void cbam_b2_kernel(const float* __restrict__ d
     }
     __syncthreads();
     M3T_CB_STAMP(3);
-    // ---- e. shared MLP backward (as cbam.hip): g[r] = sum_c datt[c] W2[c][r] -> ReLU masks -> davg, dmax per channel
-    // W2 as one flat float4 stream (as F1's second layer): a thread keeps its four columns r over every pass (FT is a multiple of
-    // L = Cr / 4), all loads of the frame in flight at once; then the lanes of a wave that share columns (stride L) are summed
-    if ((Cr & 3) == 0 && (Cr & (Cr - 1)) == 0 && ((uintptr_t)w2 & 15) == 0) {
-        const int L = Cr >> 2, lg = __ffs(L) - 1, n4 = C * L;
-        const float4* w4 = reinterpret_cast<const float4*>(w2);
-        float g[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int i0 = tid; i0 < n4; i0 += 4 * FT) {
-            float4 w[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int i = i0 + k * FT;
-                w[k] = i < n4 ? w4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int i = i0 + k * FT;
-                if (i < n4) {
-                    const float d = s_datt[i >> lg];
-                    g[0] += d * w[k].x; g[1] += d * w[k].y; g[2] += d * w[k].z; g[3] += d * w[k].w;
-                }
-            }
-        }
-        for (int o = L; o < 64; o <<= 1) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) g[e] += __shfl_xor(g[e], o, 64);
-        }
-        if (lane < L) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) s_part[wave * Cr + 4 * lane + e] = g[e];
-        }
-    } else if (lane < Cr) {
-        float g = 0.f;
-        for (int c = wave; c < C; c += FT / 64) g += s_datt[c] * w2[(size_t)c * Cr + lane];
-        s_part[wave * Cr + lane] = g;
-    }
-    __syncthreads();
-    M3T_CB_STAMP(4);
-    for (int j = tid; j < 2 * Cr; j += FT) {
-        const int which = j / Cr, r = j % Cr;
-        float g = 0.f;
-#pragma unroll
-        for (int wv = 0; wv < FT / 64; ++wv) g += s_part[wv * Cr + r];
-        const float h = hidden[((size_t)n * 2 + which) * Cr + r];
-        const float dh = h > 0.f ? g : 0.f;
-        s_dh[j] = dh;
-        g_dh[((size_t)n * 2 + which) * Cr + r] = dh;
-        if (which == 0) {
-            const float hm = hidden[((size_t)n * 2 + 1) * Cr + r];
-            g_r[(size_t)n * Cr + r] = fmaxf(h, 0.f) + fmaxf(hm, 0.f);
-        }
-    }
-    __syncthreads();
-    M3T_CB_STAMP(5);
-    for (int c = tid; c < C; c += FT) {
-        float da = 0.f, dm = 0.f;
-        for (int r0 = 0; r0 < Cr; r0 += 8) {               // eight rows of W1 in flight (coalesced over c)
-            float w[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) w[k] = r0 + k < Cr ? w1[(size_t)(r0 + k) * C + c] : 0.f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (r0 + k < Cr) {
-                    da += s_dh[r0 + k] * w[k];
-                    dm += s_dh[Cr + r0 + k] * w[k];
-                }
-        }
-        s_davg[c] = da / (float)HW;
-        s_dmaxc[c] = dm;
-    }
+    gate_mlp_bwd(s_datt, s_part, s_dh, s_davg, s_dmaxc, w1, w2, hidden, g_dh, g_r, n, C, Cr, HW);
     __syncthreads();
     M3T_CB_STAMP(6);
     // ---- f. dx = dy1 * cs + davg / HW + [p == argmax_p] dmaxc; dy is re-read while the frame is still cache-hot
@@ -920,7 +979,7 @@ __global__ __launch_bounds__(FT) void cbam_b2_kernel(const float* __restrict__ d
                 if (ok[k]) {
                     const int c = c0 + k * step + pi;
                     const float sc = s_sc[c], da = s_davg[c], dm = s_dmaxc[c];
-                    const int amp = argmax_p[(size_t)n * C + c];
+                    const int amp = s_amp[c];
 #pragma unroll
                     for (int e = 0; e < E; ++e) {
                         const int p = sub * E + e;
@@ -937,7 +996,7 @@ __global__ __launch_bounds__(FT) void cbam_b2_kernel(const float* __restrict__ d
         const int c = c0 + pi;
         if (c >= C) continue;
         const float sc = s_sc[c], da = s_davg[c], dm = s_dmaxc[c];
-        const int amp = argmax_p[(size_t)n * C + c];
+        const int amp = s_amp[c];
         const float* gl = gb + (size_t)c * HW;
         float* dl = db + (size_t)c * HW;
         for (int u0 = sub; u0 < Q; u0 += UB * G) {
@@ -966,20 +1025,24 @@ __global__ __launch_bounds__(FT) void cbam_b2_kernel(const float* __restrict__ d
     M3T_CB_STAMP(7);
 }
 
-// conv weight gradient: sum of the per-frame partials in frame order (fp64 accumulation)
-__global__ __launch_bounds__(64) void cbam_dw_final_kernel(const float* __restrict__ dwpart, int N, float* __restrict__ dw) {
+// conv weight gradient: sum of the per-frame partials (fp64 accumulation, fixed order).  One workgroup per tap, eight loads in flight
+// per thread: at N = 2048 the whole column is ONE round trip (round 3: 64 threads, a load per round trip, 12-17 us for 400 KB)
+__global__ __launch_bounds__(256) void cbam_dw_final_kernel(const float* __restrict__ dwpart, int N, float* __restrict__ dw) {
+    __shared__ double red[4];
     const int tap = blockIdx.x;
     double s = 0.0;
-    for (int i0 = threadIdx.x; i0 < N; i0 += 8 * 64) {       // eight loads in flight (one per L2 round trip made this launch 12-17 us)
+    for (int i0 = threadIdx.x; i0 < N; i0 += 8 * 256) {
         float v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { const int i = i0 + 64 * k; v[k] = i < N ? dwpart[(size_t)i * 50 + tap] : 0.f; }
+        for (int k = 0; k < 8; ++k) { const int i = i0 + 256 * k; v[k] = i < N ? dwpart[(size_t)i * 50 + tap] : 0.f; }
 #pragma unroll
         for (int k = 0; k < 8; ++k) s += (double)v[k];
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (threadIdx.x == 0) dw[tap] = (float)s;
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) dw[tap] = (float)((red[0] + red[1]) + (red[2] + red[3]));
 }
 
 // ---- parameter gradients of the shared MLP from the per-frame slabs, two launches instead of 3 GEMMs + 3 split-K reduces + 8
@@ -1069,6 +1132,268 @@ __global__ __launch_bounds__(256) void cbam_pgrad_final_kernel(const float* __re
     }
 }
 
+// ================================================================================ frame-resident kernels for small frames
+// A frame of the late ResNet stages is small (256 x 7 x 7: 50 KB, 512 x 4 x 4: 32 KB) and F1 / B2 above spend their time there on
+// what the frame's SHAPE costs them, not on its bytes (tools/cbam_phase_probe.hip, round 4): a plane is a fraction of a wave, so a
+// wave-load carries 196 B, every plane needs its own cross-lane reduction (30 of F1's 42 us per 256 x 7 x 7 frame, 17 + 11 of B2's
+// 37), and the sweeps are chains of 4-plane batches.  F1L / B2L read the frame as ONE flat float4 stream -- every load of the frame
+// in flight before anything else happens, full 1 KB wave-loads whatever H x W is -- and park it in LDS as [C][S] with S odd, where
+//   * a per-plane reduction is a THREAD walking its plane (stride S: conflict-free), no cross-lane step at all,
+//   * a per-pixel reduction over channels is lane = pixel walking down the planes (the second read of x comes from LDS, not L2),
+// and B2L keeps dy in registers from the first instruction to the dx store (read once, never re-read).  Arithmetic per element is
+// F1 / B2's; only the order of the sums differs (fixed, deterministic).
+// Eligible: C H W a multiple of 4 and at most 16 384 elements (8 float4 per thread), H W <= 64, 16-B aligned tensors.
+
+// element e of a frame -> (plane c, pixel p).  Exact: (e + 0.5) / HW is at least 0.5 / HW >= 1/128 away from an integer, the float
+// product is off by < 2^-22 * 2^14 / 4; the fix-up is belt and braces
+__device__ __forceinline__ void plane_pixel(int e, int HW, float inv_hw, int& c, int& p) {
+    c = (int)(((float)e + 0.5f) * inv_hw);
+    p = e - c * HW;
+    if (p < 0) { --c; p += HW; } else if (p >= HW) { ++c; p -= HW; }
+}
+
+__host__ __device__ inline int odd_stride(int HW) { return HW | 1; }
+
+template <int NV>
+__global__ __launch_bounds__(FT, NV <= 4 ? 6 : 4) void cbam_f1l_kernel(const float* __restrict__ x, const float* __restrict__ w1,
+                                                     const float* __restrict__ b1, const float* __restrict__ w2,
+                                                     const float* __restrict__ b2, const float* __restrict__ convw,
+                                                     float* __restrict__ cs, int32_t* __restrict__ argmax_p,
+                                                     float* __restrict__ pooled, float* __restrict__ hidden,
+                                                     float* __restrict__ comp, int32_t* __restrict__ cargmax,
+                                                     float* __restrict__ conv_out, double* __restrict__ part, int C, int Cr,
+                                                     int H, int W, int Qp) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ double red[2 * FT / 64];
+    const int HW = H * W, PP = pad_len(H, W), S = odd_stride(HW);
+    float* s_f = sm;                          // [C][S] the frame
+    float* s_avg = s_f + al4(C * S);
+    float* s_max = s_avg + al4(C);
+    float* s_sc = s_max + al4(C);
+    float* s_h = s_sc + al4(C);               // [2 Cr]
+    float* s_pad = s_h + al4(2 * Cr);         // [2][PP]
+    float* p_mx = s_pad + al4(2 * PP);        // [8][Qp]
+    float* p_sum = p_mx + (FT / 64) * Qp;
+    int* p_am = reinterpret_cast<int*>(p_sum + (FT / 64) * Qp);
+    int* s_amp = p_am + (FT / 64) * Qp;       // [C]
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n4 = (C * HW) >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(x + (size_t)n * C * HW);
+    M3T_CB_STAMP(0);
+    // ---- a. the whole frame in flight, then into LDS
+    float4 v[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i = tid + k * FT;
+        v[k] = i < n4 ? x4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int i = tid; i < 2 * PP; i += FT) s_pad[i] = 0.f;
+    const float inv_hw = 1.f / (float)HW;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i = tid + k * FT;
+        if (i < n4) {
+            if (S == HW) {
+                reinterpret_cast<float4*>(s_f)[i] = v[k];
+            } else {
+                int c, p;
+                plane_pixel(4 * i, HW, inv_hw, c, p);
+                const float e4[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    s_f[c * S + p] = e4[j];
+                    if (++p == HW) { p = 0; ++c; }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- channel squeeze: a thread per plane
+    for (int c = tid; c < C; c += FT) {
+        const float* pl = s_f + c * S;
+        float sum = 0.f, mx = -INFINITY;
+        int am = 0x7fffffff;
+#pragma unroll 4
+        for (int p = 0; p < HW; ++p) {
+            const float t = pl[p];
+            sum += t;
+            if (t > mx) { mx = t; am = p; }
+        }
+        s_avg[c] = sum / (float)HW; s_max[c] = mx; s_amp[c] = am;
+    }
+    __syncthreads();
+    M3T_CB_STAMP(1);
+    for (int c = tid; c < C; c += FT) {
+        pooled[((size_t)n * 2 + 0) * C + c] = s_avg[c];
+        pooled[((size_t)n * 2 + 1) * C + c] = s_max[c];
+        argmax_p[(size_t)n * C + c] = s_amp[c];
+    }
+    gate_mlp_fwd(s_avg, s_max, s_h, s_sc, w1, b1, w2, b2, hidden, cs, n, C, Cr);
+    __syncthreads();
+    M3T_CB_STAMP(3);
+    // ---- c. compress x * cs over channels out of LDS: lane = pixel q, FT / Qp channel slices
+    {
+        const int q = tid & (Qp - 1), kq = tid / Qp, KS = FT / Qp;
+        float mx = -INFINITY, sum = 0.f;
+        int am = 0x7fffffff;
+        if (q < HW) {
+#pragma unroll 4
+            for (int c = kq; c < C; c += KS) {
+                const float t = s_f[c * S + q] * s_sc[c];
+                sum += t;
+                if (t > mx) { mx = t; am = c; }
+            }
+        }
+        for (int o = Qp; o < 64; o <<= 1) {       // the slices of a pixel inside the wave sit Qp lanes apart
+            if (o == 16) {
+                const auto rs = __builtin_amdgcn_permlane16_swap(__float_as_uint(sum), __float_as_uint(sum), false, false);
+                const auto rm = __builtin_amdgcn_permlane16_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+                const auto ri = __builtin_amdgcn_permlane16_swap((unsigned)am, (unsigned)am, false, false);
+                sum = __uint_as_float(rs[0]) + __uint_as_float(rs[1]);
+                mx = __uint_as_float(rm[0]); am = (int)ri[0];
+                amax_take(mx, am, __uint_as_float(rm[1]), (int)ri[1]);
+            } else if (o == 32) {
+                const auto rs = __builtin_amdgcn_permlane32_swap(__float_as_uint(sum), __float_as_uint(sum), false, false);
+                const auto rm = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+                const auto ri = __builtin_amdgcn_permlane32_swap((unsigned)am, (unsigned)am, false, false);
+                sum = __uint_as_float(rs[0]) + __uint_as_float(rs[1]);
+                mx = __uint_as_float(rm[0]); am = (int)ri[0];
+                amax_take(mx, am, __uint_as_float(rm[1]), (int)ri[1]);
+            } else {
+                sum += __shfl_xor(sum, o, 64);
+                const float ov = __shfl_xor(mx, o, 64);
+                const int oi = __shfl_xor(am, o, 64);
+                amax_take(mx, am, ov, oi);
+            }
+        }
+        if (lane < Qp) { p_mx[wave * Qp + q] = mx; p_sum[wave * Qp + q] = sum; p_am[wave * Qp + q] = am; }
+        __syncthreads();
+        M3T_CB_STAMP(4);
+        if (tid < HW) {
+            float fm = -INFINITY, fs = 0.f;
+            int fa = 0x7fffffff;
+#pragma unroll
+            for (int j = 0; j < FT / 64; ++j) {
+                fs += p_sum[j * Qp + tid];
+                amax_take(fm, fa, p_mx[j * Qp + tid], p_am[j * Qp + tid]);
+            }
+            const float mean = fs / (float)C;
+            const int ph = tid / W, ip = (ph + 2) * (W + 4) + (tid - ph * W) + 2;
+            s_pad[ip] = fm;
+            s_pad[PP + ip] = mean;
+            comp[((size_t)n * 2 + 0) * HW + tid] = fm;
+            comp[((size_t)n * 2 + 1) * HW + tid] = mean;
+            cargmax[(size_t)n * HW + tid] = fa;
+        }
+    }
+    __syncthreads();
+    M3T_CB_STAMP(5);
+    spatial_conv_fwd(s_pad, convw, red, conv_out, part, n, H, W);
+    M3T_CB_STAMP(7);
+}
+
+template <int NV>
+__global__ __launch_bounds__(FT, NV <= 4 ? 6 : 4) void cbam_b2l_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ w1, const float* __restrict__ w2,
+                                                     const float* __restrict__ convw, const float* __restrict__ bn_w,
+                                                     const float* __restrict__ stats, const float* __restrict__ dgb,
+                                                     const float* __restrict__ cs, const int32_t* __restrict__ argmax_p,
+                                                     const float* __restrict__ hidden, const float* __restrict__ comp,
+                                                     const int32_t* __restrict__ cargmax, const float* __restrict__ xhat,
+                                                     const float* __restrict__ ss, const float* __restrict__ dpre,
+                                                     float* __restrict__ dx, float* __restrict__ g_datt, float* __restrict__ g_dh,
+                                                     float* __restrict__ g_r, float* __restrict__ dwpart, int C, int Cr, int H,
+                                                     int W, float inv_total, int training) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int HW = H * W, S = odd_stride(HW);
+    const B2Lds L = b2_lds_map(sm, H, W);
+    float4* s_ch = reinterpret_cast<float4*>(L.rest);          // [C] {cs, davg / HW, dmaxc, argmax_p}
+    float* s_datt = L.rest + 4 * al4(C);
+    float* s_davg = s_datt + al4(C);
+    float* s_dmaxc = s_davg + al4(C);
+    float* s_dh = s_dmaxc + al4(C);            // [2 Cr]
+    float* s_part = s_dh + al4(2 * Cr);        // [8][Cr]
+    float4* s_pix = reinterpret_cast<float4*>(s_part + 8 * Cr);      // [HW] {ss, dmean / C, dmax, argmax_c}
+    float* s_f = reinterpret_cast<float*>(s_pix + al4(HW));    // [C][S] dy1 * x
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int n4 = (C * HW) >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(dy + (size_t)n * C * HW);
+    const float4* x4 = reinterpret_cast<const float4*>(x + (size_t)n * C * HW);
+    M3T_CB_STAMP(0);
+    // ---- both frames in flight before anything else; they land while the spatial gate's backward runs
+    float4 gy[NV], xv[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i = tid + k * FT;
+        gy[k] = i < n4 ? g4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        xv[k] = i < n4 ? x4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    spatial_bwd(L, convw, bn_w, stats, dgb, comp, cargmax, xhat, ss, dpre, dwpart, n, H, W, C, inv_total, training);
+    for (int p = tid; p < HW; p += FT)         // (dmx, dmn of pixel p were written by this thread)
+        s_pix[p] = make_float4(L.ss[p], L.dmn[p], L.dmx[p], __int_as_float(L.cam[p]));
+    for (int c = tid; c < C; c += FT) s_ch[c] = make_float4(cs[(size_t)n * C + c], 0.f, 0.f, __int_as_float(argmax_p[(size_t)n * C + c]));
+    __syncthreads();
+    M3T_CB_STAMP(2);
+    // ---- d. dcs[c] = sum_p dy1 * x: the products elementwise into LDS, then a thread per plane
+    const float inv_hw = 1.f / (float)HW;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i = tid + k * FT;
+        if (i < n4) {
+            int c, p;
+            plane_pixel(4 * i, HW, inv_hw, c, p);
+            const float g[4] = {gy[k].x, gy[k].y, gy[k].z, gy[k].w}, xe[4] = {xv[k].x, xv[k].y, xv[k].z, xv[k].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 px = s_pix[p];
+                const float dy1 = g[j] * px.x + px.y + (c == __float_as_int(px.w) ? px.z : 0.f);
+                s_f[c * S + p] = dy1 * xe[j];
+                if (++p == HW) { p = 0; ++c; }
+            }
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += FT) {
+        const float* pl = s_f + c * S;
+        float ds = 0.f;
+#pragma unroll 4
+        for (int p = 0; p < HW; ++p) ds += pl[p];
+        const float sc = s_ch[c].x;
+        const float da = ds * sc * (1.f - sc);
+        s_datt[c] = da;
+        g_datt[(size_t)n * C + c] = da;
+    }
+    __syncthreads();
+    M3T_CB_STAMP(3);
+    gate_mlp_bwd(s_datt, s_part, s_dh, s_davg, s_dmaxc, w1, w2, hidden, g_dh, g_r, n, C, Cr, HW);
+    __syncthreads();
+    for (int c = tid; c < C; c += FT) { s_ch[c].y = s_davg[c]; s_ch[c].z = s_dmaxc[c]; }
+    __syncthreads();
+    M3T_CB_STAMP(6);
+    // ---- f. dx = dy1 * cs + davg / HW + [p == argmax_p] dmaxc from the dy registers, one float4 store per load
+    float4* d4 = reinterpret_cast<float4*>(dx + (size_t)n * C * HW);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i = tid + k * FT;
+        if (i < n4) {
+            int c, p;
+            plane_pixel(4 * i, HW, inv_hw, c, p);
+            const float g[4] = {gy[k].x, gy[k].y, gy[k].z, gy[k].w};
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 px = s_pix[p];
+                const float4 ch = s_ch[c];
+                const float dy1 = g[j] * px.x + px.y + (c == __float_as_int(px.w) ? px.z : 0.f);
+                o[j] = dy1 * ch.x + ch.y + (p == __float_as_int(ch.w) ? ch.z : 0.f);
+                if (++p == HW) { p = 0; ++c; }
+            }
+            d4[i] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    M3T_CB_STAMP(7);
+}
+
 struct Geo { int E, Q, G, Qp, nk; };
 
 // units of E pixels: Q per plane (at most FT: one thread per unit in the pixel reductions)
@@ -1091,11 +1416,36 @@ bool geometry(int HW, const void* const* ptrs, int nptr, Geo& g) {
     return geo_for(HW, (HW % 4 == 0 && al) ? 4 : 1, g);
 }
 
-size_t f1_lds(int C, int Cr, int HW, const Geo& g) {
-    return (size_t)(3 * al4(C) + al4(2 * Cr) + al4(2 * HW) + 52 + 3 * g.nk * g.Qp * g.E + al4(C)) * sizeof(float);
+size_t f1_lds(int C, int Cr, int PP, const Geo& g) {
+    return (size_t)(3 * al4(C) + al4(2 * Cr) + al4(2 * PP) + 3 * g.nk * g.Qp * g.E + al4(C)) * sizeof(float);
 }
-size_t b2_lds(int C, int Cr, int HW) {
-    return (size_t)(5 * al4(HW) + al4(2 * HW) + 52 + 4 * al4(C) + al4(2 * Cr) + 8 * Cr) * sizeof(float);
+size_t b2_lds(int C, int Cr, int H, int W) {
+    return (size_t)(b2_map_floats(H, W) + 4 * al4(C) + al4(2 * Cr) + 8 * Cr + al4(C)) * sizeof(float);
+}
+
+// frame-resident path: LDS bytes of F1L / B2L, eligibility, pixel lanes
+int resident_qp(int HW) { int q = 1; while (q < HW) q <<= 1; return q; }
+size_t f1l_lds(int C, int Cr, int H, int W) {
+    const int HW = H * W;
+    return (size_t)(al4(C * odd_stride(HW)) + 3 * al4(C) + al4(2 * Cr) + al4(2 * pad_len(H, W)) + 3 * (FT / 64) * resident_qp(HW) + al4(C)) * sizeof(float);
+}
+size_t b2l_lds(int C, int Cr, int H, int W) {
+    const int HW = H * W;
+    return (size_t)(b2_map_floats(H, W) + 4 * al4(C) + 3 * al4(C) + al4(2 * Cr) + 8 * Cr + 4 * al4(HW) + al4(C * odd_stride(HW))) * sizeof(float);
+}
+bool resident_enabled() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("M3T_CBAM_RESIDENT"); on = (e && e[0] == '0') ? 0 : 1; }
+    return on == 1;
+}
+// NV (float4 per thread) of the frame-resident kernels, 0 = not eligible
+int resident_nv(int C, int Cr, int H, int W, const void* const* ptrs, int nptr) {
+    const int HW = H * W;
+    if (!resident_enabled() || HW > 64 || ((C * HW) & 3) != 0 || C * HW > 8 * 4 * FT) return 0;
+    for (int i = 0; i < nptr; ++i)
+        if (((uintptr_t)ptrs[i] & 15) != 0) return 0;
+    if (f1l_lds(C, Cr, H, W) > 64 * 1024 || b2l_lds(C, Cr, H, W) > 64 * 1024) return 0;
+    return C * HW <= 4 * 4 * FT ? 4 : 8;
 }
 
 }  // namespace
@@ -1105,7 +1455,7 @@ extern "C" int m3t_cbam_fused_ok(int C, int Cr, int H, int W) {
     const int HW = H * W;
     Geo g;
     if (!geo_for(HW, HW % 4 == 0 ? 4 : 1, g)) return 0;
-    return (f1_lds(C, Cr, HW, g) <= 60 * 1024 && b2_lds(C, Cr, HW) <= 60 * 1024) ? 1 : 0;
+    return (f1_lds(C, Cr, pad_len(H, W), g) <= 60 * 1024 && b2_lds(C, Cr, H, W) <= 100 * 1024) ? 1 : 0;
 }
 
 extern "C" size_t m3t_cbam_fused_ws_bytes(int N, int C, int Cr, int H, int W) {
@@ -1133,14 +1483,21 @@ extern "C" int m3t_cbam_fwd(const float* x, const float* w1, const float* b1, co
     if (!geometry(HW, ptrs, 6, g)) return M3T_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     double* part = reinterpret_cast<double*>(ws);
-    const size_t lds1 = f1_lds(C, Cr, HW, g), lds2 = (size_t)(al4(C) + al4(HW)) * sizeof(float);
+    const size_t lds1 = f1_lds(C, Cr, pad_len(H, W), g), lds2 = (size_t)(al4(C) + al4(HW)) * sizeof(float);
     const bool small = g.Q <= g.G;       // one unit per lane per plane: batch planes instead of units
 #define M3T_CBAM_PICK(K, ...)                                                 \
     do {                                                                     \
         if (g.E == 4) { if (small) K<4, true> __VA_ARGS__; else K<4, false> __VA_ARGS__; } \
         else { if (small) K<1, true> __VA_ARGS__; else K<1, false> __VA_ARGS__; }         \
     } while (0)
-    M3T_CBAM_PICK(cbam_f1_kernel, <<<N, FT, lds1, s>>>(x, w1, b1, w2, b2, conv_w, cs, argmax_p, pooled, hidden, comp, cargmax, xhat, part, C, Cr, H, W, g.G, g.Qp));
+    const void* rptr[] = {x};
+    const int nv = resident_nv(C, Cr, H, W, rptr, 1);
+    if (nv == 4)
+        cbam_f1l_kernel<4><<<N, FT, f1l_lds(C, Cr, H, W), s>>>(x, w1, b1, w2, b2, conv_w, cs, argmax_p, pooled, hidden, comp, cargmax, xhat, part, C, Cr, H, W, resident_qp(HW));
+    else if (nv == 8)
+        cbam_f1l_kernel<8><<<N, FT, f1l_lds(C, Cr, H, W), s>>>(x, w1, b1, w2, b2, conv_w, cs, argmax_p, pooled, hidden, comp, cargmax, xhat, part, C, Cr, H, W, resident_qp(HW));
+    else
+        M3T_CBAM_PICK(cbam_f1_kernel, <<<N, FT, lds1, s>>>(x, w1, b1, w2, b2, conv_w, cs, argmax_p, pooled, hidden, comp, cargmax, xhat, part, C, Cr, H, W, g.G, g.Qp));
     M3T_LAUNCH_CHECK();
     cbam_stats_kernel<<<1, 256, 0, s>>>(part, N, (double)N * HW, running_mean, running_var, stats, training, momentum, eps);
     M3T_LAUNCH_CHECK();
@@ -1176,16 +1533,32 @@ extern "C" int m3t_cbam_bwd(const float* dy, const float* x, const float* w1, co
     Geo g;
     if (!geometry(HW, ptrs, 6, g)) return M3T_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    const size_t lds1 = (size_t)(al4(C) + g.nk * g.Qp * g.E) * sizeof(float), lds2 = b2_lds(C, Cr, HW);
+    const size_t lds1 = (size_t)(al4(C) + g.nk * g.Qp * g.E) * sizeof(float), lds2 = b2_lds(C, Cr, H, W);
     if (g.E == 4) cbam_b1_kernel<4><<<N, FT, lds1, s>>>(dy, x, cs, ss, xhat, dpre, part, C, HW, g.Qp);
     else cbam_b1_kernel<1><<<N, FT, lds1, s>>>(dy, x, cs, ss, xhat, dpre, part, C, HW, g.Qp);
     M3T_LAUNCH_CHECK();
     cbam_sum_pairs_kernel<<<1, 256, 0, s>>>(part, N, dgb, dbn_w, dbn_b);
     M3T_LAUNCH_CHECK();
     const bool small = g.Q <= g.G;
+    const void* rptr[] = {x, dy, dx};
+    const int nv = resident_nv(C, Cr, H, W, rptr, 3);
+    if (nv == 4)
+        cbam_b2l_kernel<4><<<N, FT, b2l_lds(C, Cr, H, W), s>>>(dy, x, w1, w2, conv_w, bn_w, stats, dgb, cs, argmax_p, hidden, comp, cargmax, xhat, ss, dpre, dx, g_datt, g_dh, g_r, dwpart, C, Cr, H, W, (float)(1.0 / (double)total), training);
+    else if (nv == 8)
+        cbam_b2l_kernel<8><<<N, FT, b2l_lds(C, Cr, H, W), s>>>(dy, x, w1, w2, conv_w, bn_w, stats, dgb, cs, argmax_p, hidden, comp, cargmax, xhat, ss, dpre, dx, g_datt, g_dh, g_r, dwpart, C, Cr, H, W, (float)(1.0 / (double)total), training);
+    else {
+    if (lds2 > 64 * 1024) {       // big maps: B2's padded per-pixel maps pass the 64 KB a launch gets without asking
+        const void* kf = g.E == 4 ? (small ? (const void*)cbam_b2_kernel<4, true> : (const void*)cbam_b2_kernel<4, false>)
+                                  : (small ? (const void*)cbam_b2_kernel<1, true> : (const void*)cbam_b2_kernel<1, false>);
+        if (hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024) != hipSuccess) {
+            (void)hipGetLastError();
+            return M3T_EINVAL;
+        }
+    }
     M3T_CBAM_PICK(cbam_b2_kernel, <<<N, FT, lds2, s>>>(dy, x, w1, w2, conv_w, bn_w, stats, dgb, cs, argmax_p, hidden, comp, cargmax, xhat, ss, dpre, dx, g_datt, g_dh, g_r, dwpart, C, Cr, H, W, g.G, (float)(1.0 / (double)total), training));
+    }
     M3T_LAUNCH_CHECK();
-    cbam_dw_final_kernel<<<50, 64, 0, s>>>(dwpart, N, dconv_w);
+    cbam_dw_final_kernel<<<50, 256, 0, s>>>(dwpart, N, dconv_w);
     M3T_LAUNCH_CHECK();
     const int slices = (N + PG_CHUNK - 1) / PG_CHUNK;
     cbam_pgrad_partial_kernel<<<dim3((C + 63) / 64, slices), 256, 0, s>>>(g_datt, g_r, g_dh, pooled, pgpart, N, C, Cr);

@@ -782,11 +782,11 @@ def test_cbam_golden_two_operator_path(name):
 
 @pytest.mark.parametrize("C_,H,W,N,training", [(64, 28, 28, 3, True), (128, 14, 14, 5, True), (256, 7, 7, 6, True), (512, 4, 4, 9, True),
                                               (64, 28, 28, 2, False), (32, 9, 5, 4, True), (16, 1, 1, 7, True), (48, 20, 20, 2, True),
-                                              (64, 64, 64, 2, True)])
+                                              (64, 64, 64, 2, True), (16, 32, 64, 2, True)])
 def test_cbam_stage_shapes_against_the_oracle(C_, H, W, N, training):
     """the fused operator on every ResNet-18 stage map (28^2 float4 units over two channel slices, 14^2, the ragged 7^2 with
-    single-pixel units, 4^2 with 16 planes per wave pass), odd / degenerate maps, and a 64 x 64 map the fused operator does not
-    cover (falls to the two gates): forward, running statistics, input and parameter gradients against the numpy oracle"""
+    single-pixel units, 4^2 with 16 planes per wave pass), odd / degenerate maps, a 64 x 64 map the fused operator does not
+    cover (falls to the two gates) and the largest it does (32 x 64: B2's padded maps need more than 64 KB of LDS): forward, running statistics, input and parameter gradients against the numpy oracle"""
     from models.cbam import CBAM
     from m3t import ops
     rs = np.random.RandomState(C_ + H)
