@@ -1025,27 +1025,7 @@ __global__ __launch_bounds__(FT, 6) void cbam_b2_kernel(const float* __restrict_
     M3T_CB_STAMP(7);
 }
 
-// conv weight gradient: sum of the per-frame partials (fp64 accumulation, fixed order).  One workgroup per tap, eight loads in flight
-// per thread: at N = 2048 the whole column is ONE round trip (round 3: 64 threads, a load per round trip, 12-17 us for 400 KB)
-__global__ __launch_bounds__(256) void cbam_dw_final_kernel(const float* __restrict__ dwpart, int N, float* __restrict__ dw) {
-    __shared__ double red[4];
-    const int tap = blockIdx.x;
-    double s = 0.0;
-    for (int i0 = threadIdx.x; i0 < N; i0 += 8 * 256) {
-        float v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { const int i = i0 + 256 * k; v[k] = i < N ? dwpart[(size_t)i * 50 + tap] : 0.f; }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) s += (double)v[k];
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) dw[tap] = (float)((red[0] + red[1]) + (red[2] + red[3]));
-}
-
-// ---- parameter gradients of the shared MLP from the per-frame slabs, two launches instead of 3 GEMMs + 3 split-K reduces + 8
+// ---- parameter gradients of the shared MLP (and the 5 x 5 conv: each frame left its 50-tap share in dwpart) from the per-frame slabs, two launches instead of 3 GEMMs + 3 split-K reduces + 8
 // column-sum kernels (the slabs are small: N x (2 C + 4 Cr) floats; at the 4 x 4 stage those 14 launches were a quarter of the gate)
 //   dW2[c,r] = sum_n datt[n,c] R[n,r]        db2[c] = 2 sum_n datt[n,c]          (reference cbam.py:44-49: mlp.3)
 //   dW1[r,c] = sum_n dha[n,r] avg[n,c] + dhm[n,r] max[n,c]      db1[r] = sum_n dha[n,r] + dhm[n,r]          (mlp.1)
@@ -1053,12 +1033,27 @@ __global__ __launch_bounds__(256) void cbam_dw_final_kernel(const float* __restr
 constexpr int PG_CHUNK = 32;          // frames per workgroup of stage A: N / 32 slices (64 at N = 2048) x C / 64 channel blocks
 __global__ __launch_bounds__(256) void cbam_pgrad_partial_kernel(const float* __restrict__ g_datt, const float* __restrict__ g_r,
                                                                  const float* __restrict__ g_dh, const float* __restrict__ pooled,
-                                                                 float* __restrict__ part, int N, int C, int Cr) {
+                                                                 const float* __restrict__ dwpart, float* __restrict__ part, int N, int C,
+                                                                 int Cr) {
     __shared__ float s_small[PG_CHUNK * 3 * 64];          // per frame of the slice: R[Cr] | dha[Cr] | dhm[Cr]
+    __shared__ double s_dw[4 * 50];
+    static_assert(PG_CHUNK == 32, "the conv-tap share below is laid out as 4 groups of 8 frames");
     const int cb = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x;
     const int cl = tid & 63, rg = tid >> 6, c = cb * 64 + cl;
     const bool okc = c < C;
     const int n0 = sl * PG_CHUNK, cnt = min(PG_CHUNK, N - n0);
+    // the slice's share of the conv weight gradient (each frame left its 50 taps in dwpart): 4 groups of 8 frames x 50 taps, one
+    // batch of loads, fp64 sums; the channel-block-0 workgroup of the slice does it while its slab rows are in flight
+    if (cb == 0 && tid < 200) {
+        const int tap = tid % 50, fg = tid / 50;
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const int f = fg * 8 + k; v[k] = f < cnt ? dwpart[(size_t)(n0 + f) * 50 + tap] : 0.f; }
+        double sd = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sd += (double)v[k];
+        s_dw[fg * 50 + tap] = sd;
+    }
     for (int i = tid; i < cnt * 3 * Cr; i += 256) {
         const int f = i / (3 * Cr), j = i - f * 3 * Cr;
         const int n = n0 + f;
@@ -1095,8 +1090,9 @@ __global__ __launch_bounds__(256) void cbam_pgrad_partial_kernel(const float* __
             if (cb == 0 && tid < Cr) sb1 += sm3[Cr + tid] + sm3[2 * Cr + tid];
         }
     }
-    // partial layout per slice: dW2 [C][Cr] | dW1 [Cr][C] | db2 [C] | db1 [Cr]
-    float* ps = part + (size_t)sl * (2 * (size_t)C * Cr + C + Cr);
+    // partial layout per slice: dW2 [C][Cr] | dW1 [Cr][C] | db2 [C] | db1 [Cr] | dconv [50]
+    float* ps = part + (size_t)sl * (2 * (size_t)C * Cr + C + Cr + 50);
+    if (cb == 0 && tid < 50) ps[2 * (size_t)C * Cr + C + Cr + tid] = (float)((s_dw[tid] + s_dw[50 + tid]) + (s_dw[100 + tid] + s_dw[150 + tid]));
     if (okc) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -1113,8 +1109,9 @@ __global__ __launch_bounds__(256) void cbam_pgrad_partial_kernel(const float* __
 
 __global__ __launch_bounds__(256) void cbam_pgrad_final_kernel(const float* __restrict__ part, int slices, int C, int Cr,
                                                                float* __restrict__ dw2, float* __restrict__ dw1,
-                                                               float* __restrict__ db2, float* __restrict__ db1) {
-    const size_t per = 2 * (size_t)C * Cr + C + Cr;
+                                                               float* __restrict__ db2, float* __restrict__ db1,
+                                                               float* __restrict__ dconv) {
+    const size_t per = 2 * (size_t)C * Cr + C + Cr + 50;
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < per; i += (size_t)gridDim.x * 256) {
         float s = 0.f;
         for (int k0 = 0; k0 < slices; k0 += 8) {               // eight slices in flight, summed in slice order
@@ -1128,7 +1125,8 @@ __global__ __launch_bounds__(256) void cbam_pgrad_final_kernel(const float* __re
         if (i < cc) dw2[i] = s;
         else if (i < 2 * cc) dw1[i - cc] = s;
         else if (i < 2 * cc + C) db2[i - 2 * cc] = s;
-        else db1[i - 2 * cc - C] = s;
+        else if (i < 2 * cc + C + Cr) db1[i - 2 * cc - C] = s;
+        else dconv[i - 2 * cc - C - Cr] = s;
     }
 }
 
@@ -1228,6 +1226,9 @@ __global__ __launch_bounds__(FT, NV <= 4 ? 6 : 4) void cbam_f1l_kernel(const flo
         pooled[((size_t)n * 2 + 1) * C + c] = s_max[c];
         argmax_p[(size_t)n * C + c] = s_amp[c];
     }
+    // (Tried: W1 fetched before the squeeze and W2 before layer 1's arithmetic, 8 float4 each held in registers.  512 x 4 x 4: 80 VGPRs
+    // + 19 spilled, F1L 53 -> 73 us; 256 x 7 x 7: 52 vs 53 us.  The MLP's cost at the 4 x 4 stage is streaming 128 KB of weights per
+    // 32 KB frame through the CU's L1, not the latency of the fetch.)
     gate_mlp_fwd(s_avg, s_max, s_h, s_sc, w1, b1, w2, b2, hidden, cs, n, C, Cr);
     __syncthreads();
     M3T_CB_STAMP(3);
@@ -1462,7 +1463,7 @@ extern "C" size_t m3t_cbam_fused_ws_bytes(int N, int C, int Cr, int H, int W) {
     // doubles: part[2 N]; floats: dgb[2 -> 4], dpre[N HW], dwpart[N 50], g_datt[N C], g_dh[N 2 Cr], g_r[N Cr] + GEMM scratch
     const size_t HW = (size_t)H * W;
     return (size_t)N * 2 * sizeof(double) + ((size_t)4 + N * HW + (size_t)N * 50 + (size_t)N * (C + 3 * Cr) +
-                                             (size_t)((N + PG_CHUNK - 1) / PG_CHUNK) * (2 * (size_t)C * Cr + C + Cr)) * sizeof(float) + 256;
+                                             (size_t)((N + PG_CHUNK - 1) / PG_CHUNK) * (2 * (size_t)C * Cr + C + Cr + 50)) * sizeof(float) + 256;
 }
 
 extern "C" int m3t_cbam_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
@@ -1558,14 +1559,12 @@ extern "C" int m3t_cbam_bwd(const float* dy, const float* x, const float* w1, co
     M3T_CBAM_PICK(cbam_b2_kernel, <<<N, FT, lds2, s>>>(dy, x, w1, w2, conv_w, bn_w, stats, dgb, cs, argmax_p, hidden, comp, cargmax, xhat, ss, dpre, dx, g_datt, g_dh, g_r, dwpart, C, Cr, H, W, g.G, (float)(1.0 / (double)total), training));
     }
     M3T_LAUNCH_CHECK();
-    cbam_dw_final_kernel<<<50, 256, 0, s>>>(dwpart, N, dconv_w);
-    M3T_LAUNCH_CHECK();
     const int slices = (N + PG_CHUNK - 1) / PG_CHUNK;
-    cbam_pgrad_partial_kernel<<<dim3((C + 63) / 64, slices), 256, 0, s>>>(g_datt, g_r, g_dh, pooled, pgpart, N, C, Cr);
+    cbam_pgrad_partial_kernel<<<dim3((C + 63) / 64, slices), 256, 0, s>>>(g_datt, g_r, g_dh, pooled, dwpart, pgpart, N, C, Cr);
     M3T_LAUNCH_CHECK();
-    int fb = (int)((2 * (size_t)C * Cr + C + Cr + 255) / 256);
+    int fb = (int)((2 * (size_t)C * Cr + C + Cr + 50 + 255) / 256);
     if (fb > 256) fb = 256;
-    cbam_pgrad_final_kernel<<<fb, 256, 0, s>>>(pgpart, slices, C, Cr, dw2, dw1, db2, db1);
+    cbam_pgrad_final_kernel<<<fb, 256, 0, s>>>(pgpart, slices, C, Cr, dw2, dw1, db2, db1, dconv_w);
     M3T_LAUNCH_CHECK();
     return 0;
 }

@@ -17,8 +17,10 @@ for (C, HW, N) in SHAPES:
     m = CBAM(C).to(dev).train()
     x = torch.randn(N, C, HW, HW, device=dev, requires_grad=True)
     dy = torch.randn(N, C, HW, HW, device=dev)
+    params = list(m.parameters())
     def f():
-        m.zero_grad(); x.grad = None
+        for q in params: q.grad = None
+        x.grad = None
         m(x).backward(dy)                       # CBAM's own kernels only: no loss ops in the timed region
     for _ in range(3): f()
     torch.cuda.synchronize(); t0 = time.perf_counter()
