@@ -1031,13 +1031,35 @@ __global__ __launch_bounds__(FT, 6) void cbam_b2_kernel(const float* __restrict_
 //   dW1[r,c] = sum_n dha[n,r] avg[n,c] + dhm[n,r] max[n,c]      db1[r] = sum_n dha[n,r] + dhm[n,r]          (mlp.1)
 // stage A: workgroup (channel block of 64, slice of 32 frames) -> partials; stage B: sums the slices in slice order.  Deterministic.
 constexpr int PG_CHUNK = 32;          // frames per workgroup of stage A: N / 32 slices (64 at N = 2048) x C / 64 channel blocks
+// PER contiguous floats out of LDS as the widest reads their alignment allows (the caller's offset is a multiple of PER)
+template <int PER> __device__ __forceinline__ void lds_row(const float* p, float (&o)[PER]) {
+    if constexpr (PER % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < PER / 4; ++i) {
+            const float4 t = reinterpret_cast<const float4*>(p)[i];
+            o[4 * i] = t.x; o[4 * i + 1] = t.y; o[4 * i + 2] = t.z; o[4 * i + 3] = t.w;
+        }
+    } else if constexpr (PER == 2) {
+        const float2 t = *reinterpret_cast<const float2*>(p);
+        o[0] = t.x; o[1] = t.y;
+    } else {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) o[i] = p[i];
+    }
+}
+
+// PER = Cr / 4 hidden units per wave (Cr = 4, 8, 16, 32: ResNet-18's four stages), contiguous: r = rg * PER + i, so a frame's R / dha / dhm
+// values come out of LDS as float4 broadcasts (round 3: r = rg + 4 i, 24 scalar reads per frame and thread at Cr = 32 -- one per
+// multiply-add).  PER = 0: any Cr <= 64, the scalar mapping.
+template <int PER>
 __global__ __launch_bounds__(256) void cbam_pgrad_partial_kernel(const float* __restrict__ g_datt, const float* __restrict__ g_r,
                                                                  const float* __restrict__ g_dh, const float* __restrict__ pooled,
                                                                  const float* __restrict__ dwpart, float* __restrict__ part, int N, int C,
                                                                  int Cr) {
-    __shared__ float s_small[PG_CHUNK * 3 * 64];          // per frame of the slice: R[Cr] | dha[Cr] | dhm[Cr]
+    __shared__ __attribute__((aligned(16))) float s_small[PG_CHUNK * 3 * 64];          // per frame of the slice: R[Cr] | dha[Cr] | dhm[Cr]
     __shared__ double s_dw[4 * 50];
     static_assert(PG_CHUNK == 32, "the conv-tap share below is laid out as 4 groups of 8 frames");
+    constexpr int NA = PER > 0 ? PER : 16;
     const int cb = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x;
     const int cl = tid & 63, rg = tid >> 6, c = cb * 64 + cl;
     const bool okc = c < C;
@@ -1054,14 +1076,18 @@ __global__ __launch_bounds__(256) void cbam_pgrad_partial_kernel(const float* __
         for (int k = 0; k < 8; ++k) sd += (double)v[k];
         s_dw[fg * 50 + tap] = sd;
     }
-    for (int i = tid; i < cnt * 3 * Cr; i += 256) {
-        const int f = i / (3 * Cr), j = i - f * 3 * Cr;
-        const int n = n0 + f;
-        s_small[i] = j < Cr ? g_r[(size_t)n * Cr + j] : g_dh[(size_t)n * 2 * Cr + (j - Cr)];
+    // g_r rows are [Cr], g_dh rows [2 Cr] (dha | dhm): both contiguous over the slice's frames
+    for (int i = tid; i < cnt * Cr; i += 256) {
+        const int f = i / Cr, j = i - f * Cr;
+        s_small[f * 3 * Cr + j] = g_r[(size_t)n0 * Cr + i];
     }
-    float a2[16], a1[16], sb2 = 0.f, sb1 = 0.f;            // r = rg + 4 i, i < ceil(Cr / 4) <= 16
+    for (int i = tid; i < cnt * 2 * Cr; i += 256) {
+        const int f = i / (2 * Cr), j = i - f * 2 * Cr;
+        s_small[f * 3 * Cr + Cr + j] = g_dh[(size_t)n0 * 2 * Cr + i];
+    }
+    float a2[NA], a1[NA], sb2 = 0.f, sb1 = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { a2[i] = 0.f; a1[i] = 0.f; }
+    for (int i = 0; i < NA; ++i) { a2[i] = 0.f; a1[i] = 0.f; }
     const int nr = (Cr + 3) / 4;
     __syncthreads();
     for (int f0 = 0; f0 < cnt; f0 += 8) {                  // eight frames' loads in flight
@@ -1079,12 +1105,24 @@ __global__ __launch_bounds__(256) void cbam_pgrad_partial_kernel(const float* __
             if (f0 + k >= cnt) break;
             const float* sm3 = s_small + (f0 + k) * 3 * Cr;
             sb2 += da[k];
+            if constexpr (PER > 0) {
+                float rr[PER], ha[PER], hm[PER];
+                lds_row<PER>(sm3 + rg * PER, rr);
+                lds_row<PER>(sm3 + Cr + rg * PER, ha);
+                lds_row<PER>(sm3 + 2 * Cr + rg * PER, hm);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int r = rg + 4 * i;
-                if (i < nr && r < Cr) {
-                    a2[i] += da[k] * sm3[r];
-                    a1[i] += sm3[Cr + r] * av[k] + sm3[2 * Cr + r] * mx[k];
+                for (int i = 0; i < PER; ++i) {
+                    a2[i] += da[k] * rr[i];
+                    a1[i] += ha[i] * av[k] + hm[i] * mx[k];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int r = rg + 4 * i;
+                    if (i < nr && r < Cr) {
+                        a2[i] += da[k] * sm3[r];
+                        a1[i] += sm3[Cr + r] * av[k] + sm3[2 * Cr + r] * mx[k];
+                    }
                 }
             }
             if (cb == 0 && tid < Cr) sb1 += sm3[Cr + tid] + sm3[2 * Cr + tid];
@@ -1095,9 +1133,9 @@ __global__ __launch_bounds__(256) void cbam_pgrad_partial_kernel(const float* __
     if (cb == 0 && tid < 50) ps[2 * (size_t)C * Cr + C + Cr + tid] = (float)((s_dw[tid] + s_dw[50 + tid]) + (s_dw[100 + tid] + s_dw[150 + tid]));
     if (okc) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int r = rg + 4 * i;
-            if (i < nr && r < Cr) {
+        for (int i = 0; i < NA; ++i) {
+            const int r = PER > 0 ? rg * PER + i : rg + 4 * i;
+            if (PER > 0 || (i < nr && r < Cr)) {
                 ps[(size_t)c * Cr + r] = a2[i];
                 ps[(size_t)C * Cr + (size_t)r * C + c] = a1[i];
             }
@@ -1560,7 +1598,12 @@ extern "C" int m3t_cbam_bwd(const float* dy, const float* x, const float* w1, co
     }
     M3T_LAUNCH_CHECK();
     const int slices = (N + PG_CHUNK - 1) / PG_CHUNK;
-    cbam_pgrad_partial_kernel<<<dim3((C + 63) / 64, slices), 256, 0, s>>>(g_datt, g_r, g_dh, pooled, dwpart, pgpart, N, C, Cr);
+    {
+        const dim3 pg((C + 63) / 64, slices);
+#define M3T_PG(P) cbam_pgrad_partial_kernel<P><<<pg, 256, 0, s>>>(g_datt, g_r, g_dh, pooled, dwpart, pgpart, N, C, Cr)
+        if (Cr == 32) M3T_PG(8); else if (Cr == 16) M3T_PG(4); else if (Cr == 8) M3T_PG(2); else if (Cr == 4) M3T_PG(1); else M3T_PG(0);
+#undef M3T_PG
+    }
     M3T_LAUNCH_CHECK();
     int fb = (int)((2 * (size_t)C * Cr + C + Cr + 50 + 255) / 256);
     if (fb > 256) fb = 256;

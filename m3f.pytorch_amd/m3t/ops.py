@@ -1652,14 +1652,11 @@ class _CBAM(torch.autograd.Function):
         y = torch.empty_like(x)
         # everything backward needs besides x, in ONE allocation: cs [N,C] | pooled [N,2,C] | hidden [N,2,Cr] | comp [N,2,HW] |
         # xhat [N,HW] | ss [N,HW] | stats [4] | argmax_p [N,C] (int32) | cargmax [N,HW] (int32); every part starts 16-B aligned
-        sizes = [N * Cc, 2 * N * Cc, 2 * N * Cr, 2 * N * HW, N * HW, N * HW, 4, N * Cc, N * HW]
-        offs, tot = [], 0
-        for n_ in sizes:
-            offs.append(tot)
-            tot += (n_ + 3) // 4 * 4
+        offs, tot = _cbam_layout(N, Cc, Cr, HW)
         buf = torch.empty(tot, dtype=torch.float32, device=dev)
         ws = workspace(dev, 16 * N + 256)
-        ptr = lambda i: C.c_void_p(buf.data_ptr() + 4 * offs[i])
+        base = buf.data_ptr()
+        ptr = lambda i: C.c_void_p(base + 4 * offs[i])
         rc = lib().m3t_cbam_fwd(_p(x), _p(w1), _p(b1), _p(w2), _p(b2), _p(conv_w), _p(bn_w), _p(bn_b), _p(running_mean),
                                 _p(running_var), _p(y), ptr(0), ptr(7), ptr(1), ptr(2), ptr(3), ptr(8), ptr(4), ptr(5), ptr(6),
                                 N, Cc, Cr, H, W, int(training), float(momentum), float(eps), _p(ws), ws.numel() * 4, _stream())
@@ -1678,23 +1675,46 @@ class _CBAM(torch.autograd.Function):
         Cr = w1.shape[0]
         dev = x.device
         dx = torch.empty_like(x)
-        # parameter gradients in one allocation too: dw1 [Cr,C] | dw2 [C,Cr] | db1 [Cr] | db2 [C] | dconv [50] | dbn_w [1] | dbn_b [1]
-        sz = [Cr * Cc, Cc * Cr, Cr, Cc, 50, 1, 1]
-        go, tot = [], 0
-        for n_ in sz:
-            go.append(tot)
-            tot += (n_ + 3) // 4 * 4
-        gbuf = torch.empty(tot, dtype=torch.float32, device=dev)
-        ws = workspace(dev, int(lib().m3t_cbam_fused_ws_bytes(N, Cc, Cr, H, W)))
-        ptr = lambda i: C.c_void_p(buf.data_ptr() + 4 * offs[i])
-        gp = lambda i: C.c_void_p(gbuf.data_ptr() + 4 * go[i])
+        # parameter gradients in one allocation too, packed (the kernels write them as scalars): dw1 [Cr,C] | dw2 [C,Cr] | db1 [Cr] |
+        # db2 [C] | dconv [50] | dbn_w [1] | dbn_b [1]; ONE split hands back the seven gradients (the host path of this operator is
+        # as long as its kernels at the late ResNet stages: tools/cbam_host.py)
+        sz = (Cr * Cc, Cc * Cr, Cr, Cc, 50, 1, 1)
+        go = (0, sz[0], 2 * sz[0], 2 * sz[0] + Cr, 2 * sz[0] + Cr + Cc, 2 * sz[0] + Cr + Cc + 50, 2 * sz[0] + Cr + Cc + 51)
+        gbuf = torch.empty(go[6] + 1, dtype=torch.float32, device=dev)
+        ws = workspace(dev, _cbam_ws_bytes(N, Cc, Cr, H, W))
+        base, gbase = buf.data_ptr(), gbuf.data_ptr()
+        ptr = lambda i: C.c_void_p(base + 4 * offs[i])
+        gp = lambda i: C.c_void_p(gbase + 4 * go[i])
         rc = lib().m3t_cbam_bwd(_p(dy), _p(x), _p(w1), _p(w2), _p(conv_w), _p(bn_w), ptr(0), ptr(7), ptr(1), ptr(2), ptr(3), ptr(8),
                                 ptr(4), ptr(5), ptr(6), _p(dx), gp(0), gp(2), gp(1), gp(3), gp(4), gp(5), gp(6),
                                 N, Cc, Cr, H, W, int(ctx.training), _p(ws), ws.numel() * 4, _stream())
         _lib.check(rc, "m3t_cbam_bwd")
-        view = lambda i, shape: gbuf[go[i]:go[i] + sz[i]].view(shape)
-        return (dx, view(0, w1.shape), view(2, (Cr,)), view(1, w2.shape), view(3, (Cc,)), view(4, conv_w.shape), view(5, bn_w.shape),
-                view(6, bn_w.shape), None, None, None, None, None)
+        g = gbuf.split_with_sizes(sz)
+        return (dx, g[0].view(w1.shape), g[2], g[1].view(w2.shape), g[3], g[4].view(conv_w.shape), g[5], g[6], None, None, None, None, None)
+
+
+_CBAM_LAYOUTS, _CBAM_WS = {}, {}
+
+
+def _cbam_layout(N, Cc, Cr, HW):
+    """offsets (floats) of the saved slabs inside _CBAM's one allocation, every part 16-B aligned; cached per shape"""
+    key = (N, Cc, Cr, HW)
+    hit = _CBAM_LAYOUTS.get(key)
+    if hit is None:
+        offs, tot = [], 0
+        for n_ in (N * Cc, 2 * N * Cc, 2 * N * Cr, 2 * N * HW, N * HW, N * HW, 4, N * Cc, N * HW):
+            offs.append(tot)
+            tot += (n_ + 3) // 4 * 4
+        hit = _CBAM_LAYOUTS[key] = (tuple(offs), tot)
+    return hit
+
+
+def _cbam_ws_bytes(N, Cc, Cr, H, W):
+    key = (N, Cc, Cr, H, W)
+    hit = _CBAM_WS.get(key)
+    if hit is None:
+        hit = _CBAM_WS[key] = int(lib().m3t_cbam_fused_ws_bytes(N, Cc, Cr, H, W))
+    return hit
 
 
 CBAM_FUSED = [os.environ.get("M3T_CBAM_FUSED", "1") != "0"]      # 0: the two gates as two operators (cbam.hip), for A/B runs
