@@ -384,17 +384,19 @@ __global__ __launch_bounds__(FT) void cbam_f1_kernel(const float* __restrict__ x
 #pragma unroll
         for (int e = 0; e < E; ++e) { mx[e] = -INFINITY; sum[e] = 0.f; am[e] = 0x7fffffff; }
         if (q < Q) {
-            for (int c0 = k; c0 < C; c0 += 4 * KS) {
-                float v[4][E];
-                bool ok[4];
+            constexpr int CB = 8;        // channels in flight per thread: this sweep is the frame's second read (L2 / Infinity Cache), a
+                                         // chain of C / KS / CB round trips -- at 4 in flight 12.6 of F1's 53 us per 64 x 28 x 28 frame
+            for (int c0 = k; c0 < C; c0 += CB * KS) {
+                float v[CB][E];
+                bool ok[CB];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < CB; ++j) {
                     const int c = c0 + j * KS;
                     ok[j] = c < C;
                     if (ok[j]) Unit<E>::ld(xb + ((size_t)c * Q + q) * E, v[j]);
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < CB; ++j)
                     if (ok[j]) {
                         const int c = c0 + j * KS;
                         const float sc = s_sc[c];
@@ -740,13 +742,31 @@ __device__ __forceinline__ void spatial_bwd(const B2Lds& L, const float* __restr
     }
     __syncthreads();
     M3T_CB_STAMP(1);
-    for (int tap = wave; tap < 50; tap += FT / 64) {
-        const int ch = tap / 25, i = (tap % 25) / 5, j = tap % 5;
-        const float* cp = L.compp + ch * PPa + i * Wp + j;
-        float s = 0.f;
-        for (int pp = lane; pp < HW; pp += 64) s += L.dc[pp] * cp[L.pb[pp]];
-        s = group_sum(s, 64);
-        if (lane == 0) dwpart[(size_t)n * 50 + tap] = s;
+    {
+        // a wave's taps (wave, wave + 8, ...: 7 at most) share one walk over the pixels: dc and the window origin are read once per
+        // pixel, the seven map reads are independent (a tap at a time, each pixel was a chain of two dependent LDS reads: 10 of B2's
+        // 100 us per 64 x 28 x 28 frame)
+        constexpr int TW = (50 + FT / 64 - 1) / (FT / 64);
+        int off[TW];
+        float sw[TW];
+#pragma unroll
+        for (int t = 0; t < TW; ++t) {
+            const int tap = wave + (FT / 64) * t, tc = tap < 50 ? tap : 0;
+            off[t] = (tc / 25) * PPa + ((tc % 25) / 5) * Wp + tc % 5;
+            sw[t] = 0.f;
+        }
+        for (int pp = lane; pp < HW; pp += 64) {
+            const float d = L.dc[pp];
+            const float* cp = L.compp + L.pb[pp];
+#pragma unroll
+            for (int t = 0; t < TW; ++t) sw[t] += d * cp[off[t]];
+        }
+#pragma unroll
+        for (int t = 0; t < TW; ++t) {
+            const int tap = wave + (FT / 64) * t;
+            const float sv = group_sum(sw[t], 64);
+            if (lane == 0 && tap < 50) dwpart[(size_t)n * 50 + tap] = sv;
+        }
     }
     for (int pp = tid; pp < HW; pp += FT) {
         const float* d0 = L.dcp + L.pb[pp] + 4 * Wp + 4;      // dc at (h + 2 - i, w + 2 - j) = d0[-(i * Wp + j)]
@@ -1179,6 +1199,11 @@ __global__ __launch_bounds__(256) void cbam_pgrad_final_kernel(const float* __re
 // and B2L keeps dy in registers from the first instruction to the dx store (read once, never re-read).  Arithmetic per element is
 // F1 / B2's; only the order of the sums differs (fixed, deterministic).
 // Eligible: C H W a multiple of 4 and at most 16 384 elements (8 float4 per thread), H W <= 64, 16-B aligned tensors.
+// (Tried on F1L, round 4: persistent workgroups -- grid = what the chip holds, a frame every gridDim.x -- with the next frame's eight
+// float4 loads issued behind the MLP so that they land during compress / conv / sums.  It needs the weight pointers and the thread
+// index laundered once per trip (asm volatile "+s" / "+v"), or hipcc hoists every invariant out of the frame loop: 128 VGPRs + 73
+// spilled.  Without spills: 54.5 vs 51 us at 256 x 7 x 7, 63 vs 53 us at 512 x 4 x 4.  With two or three workgroups per CU the
+// frame's load wait was already covered by the neighbours' arithmetic; what is left per frame is instruction issue, not memory.)
 
 // element e of a frame -> (plane c, pixel p).  Exact: (e + 0.5) / HW is at least 0.5 / HW >= 1/128 away from an integer, the float
 // product is off by < 2^-22 * 2^14 / 4; the fix-up is belt and braces

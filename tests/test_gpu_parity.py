@@ -1268,12 +1268,13 @@ def test_solo_scans_h128_through_the_c_abi(B, T, bf16):
     ops.poll_scan_error()
 
 
-@pytest.mark.parametrize("switch", ["M3T_CONV_X6", "M3T_CBAM_FUSED"])
+@pytest.mark.parametrize("switch", ["M3T_CONV_X6", "M3T_CBAM_FUSED", "M3T_CBAM_RESIDENT"])
 def test_conv_and_cbam_kernel_switches(switch):
-    """README's switch table, the two entries the C3 step does not exercise (read once per process, hence a child):
+    """README's switch table, the entries the C3 step does not exercise (read once per process, hence a child):
     M3T_CONV_X6=0 -- the TCN / tcn_simple convolutions on the fp32-MFMA kernel instead of the bf16x6 implicit GEMM;
-    M3T_CBAM_FUSED=0 -- CBAM as channel gate + spatial gate instead of the fused operator.  Same arithmetic: the convolution,
-    TemporalBlock, CBAM and ResNet parity tests must pass unchanged."""
+    M3T_CBAM_FUSED=0 -- CBAM as channel gate + spatial gate instead of the fused operator;
+    M3T_CBAM_RESIDENT=0 -- small frames (7 x 7, 4 x 4 ...) on the fused operator's general kernels F1 / B2 instead of the
+    frame-resident F1L / B2L.  Same arithmetic: the convolution, TemporalBlock, CBAM and ResNet parity tests must pass unchanged."""
     import subprocess
     import sys
     env = dict(os.environ, M3T_SCAN_LOCK="0", **{switch: "0"})
