@@ -418,7 +418,10 @@ int m3t_cbam_spatial_bwd(const float* dy, const float* x, const float* conv_w, c
 /* CBAM as ONE fused operator (reference models/cbam.py:95-111: SpatialGate(ChannelGate(x))), csrc/cbam_fused.hip: the
  * intermediate x * channel_scale is never written; forward = 2 sweeps (per-frame squeeze + MLP + compress + 5x5 conv | apply),
  * cut only by BatchNorm2d(1)'s global batch statistics, backward = 2 sweeps likewise: 8 HBM passes over a tensor of x's size
- * for forward + backward against 10 + for the two separate gates above, 7 launches + the parameter-gradient finish.
+ * for forward + backward against 10 + for the two separate gates above, 6 launches + the two-launch parameter-gradient finish.
+ * Frames of at most 64 KB with H*W <= 64 (the 7 x 7 and 4 x 4 ResNet-18 stages; C*H*W % 4 == 0, x / dy / dx 16-B aligned) take
+ * frame-resident kernels (the frame parked in LDS, read once; environment M3T_CBAM_RESIDENT=0 keeps them on the general kernels):
+ * same arithmetic per element, another fixed summation order.
  * Saved for backward: cs [N,C] (channel scale), argmax_p [N,C], pooled [N,2,C], hidden [N,2,Cr], comp [N,2,HW] (max, mean of
  * x * cs over channels), cargmax [N,HW], xhat [N,HW], ss [N,HW] (spatial scale), stats [2] (mean, 1/sqrt(var+eps)).
  * bn_w / bn_b = BatchNorm2d(1)'s gamma / beta (one float each), running_mean / running_var updated in place when training.  m3t_cbam_fused_ok: 1 when the

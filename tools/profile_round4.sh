@@ -20,4 +20,6 @@ done
 rm -rf $O/prof_tl; rocprofv3 --kernel-trace -d $O/prof_tl -o tl --output-format rocpd -- python3 $R/bench.py --steps 8 --warmup 3 --no-cpu-baseline --aux "" > $O/prof_tl.log 2>&1
 db=$(find $O/prof_tl -name "*.db" | head -1); [ -n "$db" ] && python3 $R/tools/timeline.py $db 60e3 > $O/${T}_timeline.txt 2>&1; rm -rf $O/prof_tl
 for sh in "64 28" "128 14" "256 7" "512 4"; do set -- $sh; CBAM_SHAPES="$1,$2" rocprofv3 --kernel-trace --stats -d $O/prof_cb -o cb --output-format csv -- python3 $R/tools/cbam_bench.py > $O/prof_cb_$1.log 2>&1; f=$(find $O/prof_cb -name "*kernel_stats.csv" | head -1); cp $f $O/${T}_cbam_$1x$2x$2_kernel_stats.csv; rm -rf $O/prof_cb; done
+# phase stamps inside CBAM's F1 / B2 (or F1L / B2L) per stage: tools/bin/cbam_phase_probe is built in the container (hipcc, see its header)
+if [ -x $R/tools/bin/cbam_phase_probe ]; then for sh in "64 28" "128 14" "256 7" "512 4"; do echo "== $sh"; timeout 60 $R/tools/bin/cbam_phase_probe $sh; done > $O/${T}_cbam_phases.txt 2>&1; fi
 ls $O | head -80
