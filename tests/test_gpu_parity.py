@@ -845,6 +845,36 @@ def test_cbam_fused_equals_the_two_gates_at_full_size_and_is_deterministic():
     assert torch.equal(y1, y3) and torch.equal(dx1, x1.grad) and all(torch.equal(u, p.grad) for u, p in zip(g1, a.parameters()))
 
 
+@pytest.mark.parametrize("C_,H,N", [(256, 7, 70), (512, 4, 33), (32, 3, 5)])
+def test_cbam_frame_resident_kernels_are_deterministic_and_cover_ragged_batches(C_, H, N):
+    """the frame-resident kernels (csrc/cbam_fused.hip F1L / B2L: 7 x 7 with S = H W, 4 x 4 with the padded stride 17, a 3 x 3 map
+    with 9-pixel planes) on batches that are not a multiple of anything: bit-identical reruns, and every frame's result independent
+    of its neighbours (frame i of the batch == the same frame in a batch of one, up to the batch statistics: checked in eval mode)"""
+    from models.cbam import CBAM
+    torch.manual_seed(C_ + H)
+    m = CBAM(C_).to(DEV).train()
+    with torch.no_grad():
+        m.SpatialGate.spatial.bn.weight.fill_(0.8)
+    x = torch.randn(N, C_, H, H, device=DEV, requires_grad=True)
+    ct = torch.randn_like(x)
+    outs = []
+    for _ in range(2):
+        m.zero_grad()
+        x.grad = None
+        with torch.no_grad():
+            m.SpatialGate.spatial.bn.running_mean.zero_()
+            m.SpatialGate.spatial.bn.running_var.fill_(1.0)
+        y = m(x)
+        y.backward(ct)
+        outs.append([y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in m.parameters()])
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+    m.eval()
+    with torch.no_grad():
+        yb = m(x)
+        for i in (0, N // 2, N - 1):
+            assert torch.equal(m(x[i:i + 1].contiguous()), yb[i:i + 1])
+
+
 @pytest.mark.parametrize("name", ["resnet_cbam_eval", "resnet_cbam_train"])
 def test_resnet_cbam_golden(name):
     from models.resnet import ResNet, BasicBlock
