@@ -3,8 +3,7 @@
 // strided copy of an 8-D view ran as ~50 `direct_copy` launches per convolution (344 per C5 step, 8.2 % of it) and the fp16x3 GEMM then
 // measured the matrix's magnitude with one more pass (112 `f16x3_absmax` launches, 3.4 %).  ONE launch here writes P -- rows (n, t', h',
 // w'), columns (c_in, kt, kh, kw), zero columns up to Kp and zero rows up to rows_pad for the GEMM's tiles, zero padding of the
-// convolution itself -- as 16-byte stores, and raises the operand's magnitude slot on the way (block maximum, one 64-bit atomic max per
-// block that exceeds what the slot holds).
+// convolution itself -- as 16-byte stores, and raises the operand's magnitude slot on the way.
 #include "common.h"
 
 namespace {
@@ -17,18 +16,22 @@ struct Im2colArgs {
     long long rows, rows_pad;
 };
 
-// A block takes RPB consecutive output positions per pass.  Column table (per block, LDS): offset of (ci, dt, dh, dw) inside a sample and the
-// packed (dt, dh, dw); row table (per pass, LDS): offset of the patch origin and the packed origin (t0, h0, w0) -- so that an element costs
-// two LDS reads, three range checks and one (cached) load instead of a dozen integer divisions; 16-byte stores, consecutive threads on
-// consecutive columns of a row.
-constexpr int IM_MAXROWS = 64;
-__global__ __launch_bounds__(256) void im2col3d_kernel(Im2colArgs a, int rpb) {
-    extern __shared__ int cm[];                                  // [Kp] offsets, [Kp] packed (dt, dh, dw) (or -1: padding column)
+// A block takes 64 consecutive output positions (rows of P) per pass and walks the columns 64 at a time through an LDS tile:
+//   load   lane = ROW, wave w takes columns c0 + w + 4 j: for one column the 64 lanes read 64 consecutive output positions, i.e.
+//          (stride-1 convolutions) 64 consecutive floats of x -- two or three cache lines per wave instruction.  Round 4's first
+//          version put consecutive lanes on consecutive COLUMNS of one row: every lane in another kw-run of x, ~64 lines per load
+//          instruction, four of them per 16-byte store: the kernel ran at the address path's rate (2.9 TB/s of stores), not HBM's;
+//   store  out of the tile, transposed: 16-byte stores, a wave writes four rows x 64 columns (256 B contiguous per row).
+// Column table (per block, LDS): offset of (ci, dt, dh, dw) inside a sample and the packed (dt, dh, dw) -- broadcast reads in the load
+// phase (all lanes of a wave share the column); a row's origin lives in its lane's registers.  The operand's magnitude slot is raised
+// on the way (block maximum, one 64-bit atomic max per block that exceeds what the slot holds).
+constexpr int IM_TILE = 64;
+__global__ __launch_bounds__(256) void im2col3d_kernel(Im2colArgs a) {
+    extern __shared__ int cm[];                                  // [Kp] offsets, [Kp] packed (dt, dh, dw) (or -1: padding column), the tile
     int* coff = cm;
     int* cpos = cm + a.Kp;
-    __shared__ long long rbase[IM_MAXROWS];
-    __shared__ int rt0[IM_MAXROWS], rh0[IM_MAXROWS], rw0[IM_MAXROWS];
-    const int tid = threadIdx.x;
+    float (*tile)[IM_TILE + 1] = reinterpret_cast<float (*)[IM_TILE + 1]>(cm + 2 * a.Kp);      // [column][row]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int khw = a.kh * a.kw, kvol = a.kt * khw;
     for (int c = tid; c < a.Kp; c += 256) {
         if (c < a.Kc) {
@@ -39,46 +42,57 @@ __global__ __launch_bounds__(256) void im2col3d_kernel(Im2colArgs a, int rpb) {
             cpos[c] = (dt << 20) | (dh << 10) | dw;
         } else { coff[c] = 0; cpos[c] = -1; }
     }
-    const int q4 = a.Kp >> 2, items = rpb * q4;
     const long long sample = (long long)a.Ci * a.T * a.H * a.W;
+    const int hw = a.Ho * a.Wo;
     float mx = 0.f;
-    for (long long row0 = (long long)blockIdx.x * rpb; row0 < a.rows_pad; row0 += (long long)gridDim.x * rpb) {
-        __syncthreads();                                         // (column table ready; previous pass done with the row table)
-        if (tid < rpb) {
-            const long long row = row0 + tid;
-            if (row < a.rows) {
-                const int hw = a.Ho * a.Wo;
-                const long long nt = row / hw;
-                const int r2 = (int)(row - nt * hw);
-                const int ho = r2 / a.Wo, wo = r2 - ho * a.Wo;
-                const int n = (int)(nt / a.To), to = (int)(nt - (long long)n * a.To);
-                const int t0 = to * a.st - a.pt, h0 = ho * a.sh - a.ph, w0 = wo * a.sw - a.pw;
-                rt0[tid] = t0; rh0[tid] = h0; rw0[tid] = w0;
-                rbase[tid] = (long long)n * sample + ((long long)t0 * a.H + h0) * a.W + w0;
-            } else { rt0[tid] = -(1 << 28); rh0[tid] = 0; rw0[tid] = 0; rbase[tid] = 0; }      // padding row: every range check fails
+    for (long long row0 = (long long)blockIdx.x * IM_TILE; row0 < a.rows_pad; row0 += (long long)gridDim.x * IM_TILE) {
+        // this lane's row: origin of its patch (a padding row fails every range check)
+        const long long row = row0 + lane;
+        int t0 = -(1 << 28), h0 = 0, w0 = 0;
+        long long rbase = 0;
+        if (row < a.rows) {
+            const long long nt = row / hw;
+            const int r2 = (int)(row - nt * hw);
+            const int ho = r2 / a.Wo, wo = r2 - ho * a.Wo;
+            const int n = (int)(nt / a.To), to = (int)(nt - (long long)n * a.To);
+            t0 = to * a.st - a.pt; h0 = ho * a.sh - a.ph; w0 = wo * a.sw - a.pw;
+            rbase = (long long)n * sample + ((long long)t0 * a.H + h0) * a.W + w0;
         }
-        __syncthreads();
-        for (int it = tid; it < items; it += 256) {
-            const int rs = it / q4, c0 = (it - rs * q4) * 4;
-            const long long row = row0 + rs;
-            if (row >= a.rows_pad) break;
-            const int t0 = rt0[rs], h0 = rh0[rs], w0 = rw0[rs];
-            const float* xb = a.x + rbase[rs];
-            float v[4];
+        const float* xb = a.x + rbase;
+        for (int c0 = 0; c0 < a.Kp; c0 += IM_TILE) {
+            __syncthreads();                                     // (column table ready; the previous tile has been stored)
+            float v[IM_TILE / 4];                                // all sixteen loads of the chunk in flight
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int p = cpos[c0 + e];
-                const int t = t0 + (p >> 20), h = h0 + ((p >> 10) & 1023), w = w0 + (p & 1023);
-                const bool ok = p >= 0 && (unsigned)t < (unsigned)a.T && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
-                v[e] = ok ? xb[coff[c0 + e]] : 0.f;
+            for (int j = 0; j < IM_TILE / 4; ++j) {
+                const int c = c0 + wave + 4 * j;
+                v[j] = 0.f;
+                if (c < a.Kp) {
+                    const int p = cpos[c];
+                    const int t = t0 + (p >> 20), h = h0 + ((p >> 10) & 1023), w = w0 + (p & 1023);
+                    if (p >= 0 && (unsigned)t < (unsigned)a.T && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W) v[j] = xb[coff[c]];
+                }
             }
-            *reinterpret_cast<float4*>(a.out + (size_t)row * a.Kp + c0) = make_float4(v[0], v[1], v[2], v[3]);
-            mx = fmaxf(fmaxf(mx, m3t_fin_abs(v[0])), fmaxf(m3t_fin_abs(v[1]), fmaxf(m3t_fin_abs(v[2]), m3t_fin_abs(v[3]))));
+#pragma unroll
+            for (int j = 0; j < IM_TILE / 4; ++j) tile[wave + 4 * j][lane] = v[j];
+            __syncthreads();
+            const int q = tid & 15, rr = tid >> 4;               // this thread's four columns 4 q .. 4 q + 3 of rows rr + 16 k
+            if (c0 + 4 * q < a.Kp) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int r = rr + 16 * k;
+                    if (row0 + r < a.rows_pad) {
+                        const float4 v = make_float4(tile[4 * q][r], tile[4 * q + 1][r], tile[4 * q + 2][r], tile[4 * q + 3][r]);
+                        *reinterpret_cast<float4*>(a.out + (size_t)(row0 + r) * a.Kp + c0 + 4 * q) = v;
+                        mx = fmaxf(fmaxf(mx, m3t_fin_abs(v.x)), fmaxf(m3t_fin_abs(v.y), fmaxf(m3t_fin_abs(v.z), m3t_fin_abs(v.w))));
+                    }
+                }
+            }
         }
     }
     if (a.slot) {
         __shared__ float red[4];
         mx = wave_max(mx);
+        __syncthreads();
         if ((tid & 63) == 0) red[tid >> 6] = mx;
         __syncthreads();
         if (tid == 0) {
@@ -104,20 +118,19 @@ extern "C" int m3t_im2col3d(const float* x, int N, int Ci, int T, int H, int W, 
     a.Kc = Ci * kt * kh * kw; a.Kp = Kp;
     a.rows = (long long)N * a.To * a.Ho * a.Wo; a.rows_pad = rows_pad;
     if (Kp < a.Kc || rows_pad < a.rows) return M3T_EINVAL;
-    if (kt >= 1024 || kh >= 1024 || kw >= 1024 || (size_t)Kp * 8 > 150 * 1024) return M3T_EINVAL;      // (packed kernel offsets; column tables in LDS: C_in k^3 <= 19 200)
+    const size_t dyn = (size_t)Kp * 8 + (size_t)IM_TILE * (IM_TILE + 1) * sizeof(float);
+    if (kt >= 1024 || kh >= 1024 || kw >= 1024 || dyn > 156 * 1024) return M3T_EINVAL;      // (packed kernel offsets; column tables + tile in LDS, 160 KB per CU less the static part: C_in k^3 <= 17 800)
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(im2col3d_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(im2col3d_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) {
             (void)hipGetLastError();
             return M3T_EINVAL;
         }
         attr_set = true;
     }
-    int rpb = 2048 / (Kp / 4);
-    rpb = rpb < 1 ? 1 : (rpb > IM_MAXROWS ? IM_MAXROWS : rpb);
-    long long blocks = (rows_pad + rpb - 1) / rpb;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    im2col3d_kernel<<<dim3((unsigned)blocks), 256, (size_t)Kp * 8, (hipStream_t)stream>>>(a, rpb);
+    long long blocks = (rows_pad + IM_TILE - 1) / IM_TILE;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    im2col3d_kernel<<<dim3((unsigned)blocks), 256, dyn, (hipStream_t)stream>>>(a);
     M3T_LAUNCH_CHECK();
     return 0;
 }

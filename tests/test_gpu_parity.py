@@ -1028,6 +1028,32 @@ def test_c1_affwild_audio_training_step_golden():
     check_digests(list((n, p.grad) for n, p in m.named_parameters()), g)
 
 
+@pytest.mark.parametrize("Ci,Co,k,stride,pad,N,T,H,W", [
+    (3, 64, (3, 3, 3), (1, 2, 2), (1, 0, 0), 2, 6, 13, 12),        # a stem's first layer: C_in k^3 = 81, the transposed / padded GEMM form
+    (64, 128, (3, 3, 3), (1, 1, 1), (1, 0, 0), 2, 5, 9, 10),       # interior layers: C_in k^3 = 1728 = 27 x 64
+    (3, 64, (5, 7, 7), (1, 2, 2), (2, 3, 3), 1, 7, 20, 18),        # the 3-D ResNet stem: 735 columns, padding on every axis
+    (8, 24, (3, 2, 3), (2, 1, 2), (0, 1, 1), 3, 8, 7, 9),          # neither output tile: the plain padded form; odd strides / kernel
+])
+def test_conv3d_weight_gradient_through_the_patch_matrix(Ci, Co, k, stride, pad, N, T, H, W):
+    """m3t.ops.conv3d (reference models/backbone.py:73-103,179-271: the 3-D conv stems): forward and data gradient are torch's, the
+    WEIGHT gradient is one fp16x3 GEMM over the patch matrix csrc/conv3d.hip writes (rows = output positions, 64 at a time through an
+    LDS tile; ragged row / column tails, zero padding of the convolution on every axis) -- against float64 autograd on the CPU"""
+    from m3t import ops
+    rs = np.random.RandomState(Ci + Co + H)
+    xn, wn, bn_ = draw(rs, (N, Ci, T, H, W)), draw(rs, (Co, Ci) + k) * 0.2, draw(rs, (Co,))
+    x, w, b = dev(xn, True), dev(wn, True), dev(bn_, True)
+    y = ops.conv3d(x, w, b, stride, pad)
+    ctn = draw(rs, tuple(y.shape))
+    (y * dev(ctn)).sum().backward()
+    x64, w64, b64 = (torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (xn, wn, bn_))
+    y64 = torch.conv3d(x64, w64, b64, stride, pad)
+    (y64 * torch.tensor(ctn, dtype=torch.float64)).sum().backward()
+    close(y, y64.detach().numpy(), 2e-4, "y")
+    close(w.grad, w64.grad.numpy(), 2e-4, "dw")
+    close(b.grad, b64.grad.numpy(), 2e-4, "db")
+    close(x.grad, x64.grad.numpy(), 2e-4, "dx")
+
+
 def test_c5_affwild_av_golden():
     """Full AffWild2VA audiovisual/attention/v2p_split on raw frames (conv stem on MIOpen)."""
     from models.model import AffWild2VA
