@@ -25,22 +25,27 @@ struct Im2colArgs {
 // Column table (per block, LDS): offset of (ci, dt, dh, dw) inside a sample and the packed (dt, dh, dw) -- broadcast reads in the load
 // phase (all lanes of a wave share the column); a row's origin lives in its lane's registers.  The operand's magnitude slot is raised
 // on the way (block maximum, one 64-bit atomic max per block that exceeds what the slot holds).
+// The grid is 2-D: blockIdx.y owns `cw` consecutive columns (a multiple of 64; its share of the column table is all the LDS it needs),
+// blockIdx.x strides over the row blocks -- the deep layers have few output positions and many columns (512 -> 512 on a 3 x 3 map: 8
+// row blocks x 216 column tiles), the first layers the opposite.
 constexpr int IM_TILE = 64;
-__global__ __launch_bounds__(256) void im2col3d_kernel(Im2colArgs a) {
-    extern __shared__ int cm[];                                  // [Kp] offsets, [Kp] packed (dt, dh, dw) (or -1: padding column), the tile
+__global__ __launch_bounds__(256) void im2col3d_kernel(Im2colArgs a, int cw) {
+    extern __shared__ int cm[];                                  // [cw] offsets, [cw] packed (dt, dh, dw) (or -1: padding column), the tile
     int* coff = cm;
-    int* cpos = cm + a.Kp;
-    float (*tile)[IM_TILE + 1] = reinterpret_cast<float (*)[IM_TILE + 1]>(cm + 2 * a.Kp);      // [column][row]
+    int* cpos = cm + cw;
+    float (*tile)[IM_TILE + 1] = reinterpret_cast<float (*)[IM_TILE + 1]>(cm + 2 * cw);      // [column][row]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int khw = a.kh * a.kw, kvol = a.kt * khw;
-    for (int c = tid; c < a.Kp; c += 256) {
+    const int cbeg = blockIdx.y * cw, cend = min(a.Kp, cbeg + cw);
+    for (int cl = tid; cbeg + cl < cend; cl += 256) {
+        const int c = cbeg + cl;
         if (c < a.Kc) {
             const int ci = c / kvol, rem = c - ci * kvol;
             const int dt = rem / khw, rem2 = rem - dt * khw;
             const int dh = rem2 / a.kw, dw = rem2 - dh * a.kw;
-            coff[c] = ((ci * a.T + dt) * a.H + dh) * a.W + dw;
-            cpos[c] = (dt << 20) | (dh << 10) | dw;
-        } else { coff[c] = 0; cpos[c] = -1; }
+            coff[cl] = ((ci * a.T + dt) * a.H + dh) * a.W + dw;
+            cpos[cl] = (dt << 20) | (dh << 10) | dw;
+        } else { coff[cl] = 0; cpos[cl] = -1; }
     }
     const long long sample = (long long)a.Ci * a.T * a.H * a.W;
     const int hw = a.Ho * a.Wo;
@@ -59,17 +64,17 @@ __global__ __launch_bounds__(256) void im2col3d_kernel(Im2colArgs a) {
             rbase = (long long)n * sample + ((long long)t0 * a.H + h0) * a.W + w0;
         }
         const float* xb = a.x + rbase;
-        for (int c0 = 0; c0 < a.Kp; c0 += IM_TILE) {
+        for (int c0 = cbeg; c0 < cend; c0 += IM_TILE) {
             __syncthreads();                                     // (column table ready; the previous tile has been stored)
             float v[IM_TILE / 4];                                // all sixteen loads of the chunk in flight
 #pragma unroll
             for (int j = 0; j < IM_TILE / 4; ++j) {
                 const int c = c0 + wave + 4 * j;
                 v[j] = 0.f;
-                if (c < a.Kp) {
-                    const int p = cpos[c];
+                if (c < cend) {
+                    const int p = cpos[c - cbeg];
                     const int t = t0 + (p >> 20), h = h0 + ((p >> 10) & 1023), w = w0 + (p & 1023);
-                    if (p >= 0 && (unsigned)t < (unsigned)a.T && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W) v[j] = xb[coff[c]];
+                    if (p >= 0 && (unsigned)t < (unsigned)a.T && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W) v[j] = xb[coff[c - cbeg]];
                 }
             }
 #pragma unroll
@@ -118,19 +123,18 @@ extern "C" int m3t_im2col3d(const float* x, int N, int Ci, int T, int H, int W, 
     a.Kc = Ci * kt * kh * kw; a.Kp = Kp;
     a.rows = (long long)N * a.To * a.Ho * a.Wo; a.rows_pad = rows_pad;
     if (Kp < a.Kc || rows_pad < a.rows) return M3T_EINVAL;
-    const size_t dyn = (size_t)Kp * 8 + (size_t)IM_TILE * (IM_TILE + 1) * sizeof(float);
-    if (kt >= 1024 || kh >= 1024 || kw >= 1024 || dyn > 156 * 1024) return M3T_EINVAL;      // (packed kernel offsets; column tables + tile in LDS, 160 KB per CU less the static part: C_in k^3 <= 17 800)
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(im2col3d_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) {
-            (void)hipGetLastError();
-            return M3T_EINVAL;
-        }
-        attr_set = true;
-    }
-    long long blocks = (rows_pad + IM_TILE - 1) / IM_TILE;
-    if (blocks > 256 * 8) blocks = 256 * 8;
-    im2col3d_kernel<<<dim3((unsigned)blocks), 256, dyn, (hipStream_t)stream>>>(a);
+    if (kt >= 1024 || kh >= 1024 || kw >= 1024) return M3T_EINVAL;      // (packed kernel offsets)
+    // about 8 x 256 workgroups: row blocks first, then column tiles per workgroup down to one
+    const long long rblocks = (rows_pad + IM_TILE - 1) / IM_TILE;
+    const int ctiles = (Kp + IM_TILE - 1) / IM_TILE;
+    int per = (int)((rblocks * ctiles + 2047) / 2048);          // column tiles per workgroup
+    per = per < 1 ? 1 : (per > ctiles ? ctiles : per);
+    if (per > 32) per = 32;                                      // (<= 16 KB of column table)
+    const int cw = per * IM_TILE, ygrid = (ctiles + per - 1) / per;
+    long long xgrid = rblocks;
+    if (xgrid * ygrid > 4096) xgrid = (4096 + ygrid - 1) / ygrid;
+    const size_t dyn = (size_t)cw * 8 + (size_t)IM_TILE * (IM_TILE + 1) * sizeof(float);
+    im2col3d_kernel<<<dim3((unsigned)xgrid, (unsigned)ygrid), 256, dyn, (hipStream_t)stream>>>(a, cw);
     M3T_LAUNCH_CHECK();
     return 0;
 }

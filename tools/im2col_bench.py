@@ -10,7 +10,8 @@ dev = torch.device("cuda:0")
 lib = _lib.load()
 # (Ci, T, H, W, k, stride, pad): the v2p_split stem (models/backbone.py) on 8 x 64 x 112 x 112 input
 layers = [(3, 64, 112, 112, (3, 3, 3), (1, 2, 2), (1, 0, 0)), (64, 64, 27, 27, (3, 3, 3), (1, 1, 1), (1, 0, 0)),
-          (128, 64, 12, 12, (3, 3, 3), (1, 1, 1), (1, 0, 0)), (256, 64, 10, 10, (3, 3, 3), (1, 1, 1), (1, 0, 0))]
+          (128, 64, 12, 12, (3, 3, 3), (1, 1, 1), (1, 0, 0)), (256, 64, 5, 5, (3, 3, 3), (1, 1, 1), (1, 0, 0)),
+          (512, 64, 3, 3, (3, 3, 3), (1, 1, 1), (1, 0, 0))]
 tot = 0.0
 for Ci, T, H, W, k, st, pd in layers:
     N = 8
