@@ -379,6 +379,16 @@ int m3t_bn_rows_fwd(const float* x, int M, int C, const float* gamma, const floa
 int m3t_bn_rows_bwd(const float* dy, const float* x, const float* y, const float* gamma,
                     const float* save_mean, const float* save_invstd, int M, int C, int training, int relu,
                     float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes, void* stream);
+/* BatchNorm3d (+ optional fused ReLU) of the 3-D conv stems, channels-first x [N][C][S] with S = T*H*W contiguous (nn.BatchNorm3d(C) + nn.ReLU(True),
+ * reference models/backbone.py:73-103,179-191): same statistics / running-statistics / gradient formulas as the rows form above with M = N*S values per
+ * channel.  N*C <= 65535.  ws: m3t_bn_planes_ws_bytes(N, C, S) bytes, 8-byte aligned. */
+size_t m3t_bn_planes_ws_bytes(int N, int C, int S);
+int m3t_bn_planes_fwd(const float* x, int N, int C, int S, const float* gamma, const float* beta, float* run_mean, float* run_var,
+                      float momentum, float eps, int training, int relu, float* y, float* save_mean, float* save_invstd,
+                      float* ws, size_t ws_bytes, void* stream);
+int m3t_bn_planes_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* save_mean, const float* save_invstd,
+                      int N, int C, int S, int training, int relu, float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes,
+                      void* stream);
 /* [B,C,T] <-> [B,T,C] */
 int m3t_bct_to_btc(const float* src, float* dst, int B, int C, int T, void* stream);
 int m3t_btc_to_bct(const float* src, float* dst, int B, int T, int C, void* stream);

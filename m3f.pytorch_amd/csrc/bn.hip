@@ -154,7 +154,225 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- channel PLANES
+// BatchNorm3d (+ReLU) of the 3-D conv stems (reference models/backbone.py:73-103,179-191: Conv3d -> BatchNorm3d -> ReLU), x [N][C][S]
+// with S = T H W contiguous: a channel is N planes of S floats.  A workgroup takes one chunk (<= 8192 floats) of one plane: float4
+// sweeps, the plane's scalars (mean, invstd, gamma, beta) loaded once.  Forward: statistics sweep (per-chunk fp64 partials, reduced per
+// channel in a fixed order) | apply + ReLU; backward: sums sweep (d beta, d gamma with the ReLU mask from y) | dx.  MIOpen ran the
+// normalisation and torch the ReLU as separate passes: one read + one write of the activation less in each direction.
+constexpr int PL_CHUNK = 8192;
+
+__device__ __forceinline__ void pl_block_sum2(double& a, double& b) {
+    __shared__ double red[2][4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
+    __syncthreads();
+    a = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    b = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+}
+
+// partial[(plane * nch + chunk) * 2 + {0, 1}]: sum x, sum x^2
+template <bool VEC>
+__global__ __launch_bounds__(256) void bnp_stats_partial_kernel(const float* __restrict__ x, int S, int nch, double* __restrict__ partial) {
+    const size_t plane = blockIdx.y;
+    const int s0 = blockIdx.x * PL_CHUNK, s1 = min(S, s0 + PL_CHUNK);
+    const float* p = x + plane * (size_t)S;
+    float s = 0.f, ss = 0.f;
+    if (VEC) {
+        for (int i = s0 + 4 * threadIdx.x; i < s1; i += 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(p + i);
+            s += (v.x + v.y) + (v.z + v.w);
+            ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        }
+    } else {
+        for (int i = s0 + threadIdx.x; i < s1; i += 256) { const float v = p[i]; s += v; ss += v * v; }
+    }
+    double a = (double)s, b = (double)ss;
+    pl_block_sum2(a, b);
+    if (threadIdx.x == 0) {
+        partial[(plane * nch + blockIdx.x) * 2 + 0] = a;
+        partial[(plane * nch + blockIdx.x) * 2 + 1] = b;
+    }
+}
+
+// per channel: the N x nch partial pairs in (n, chunk) order.  mode 0: forward statistics (mean, invstd, running statistics);
+// mode 1: backward sums (out0 = d beta, out1 = d gamma)
+__global__ __launch_bounds__(64) void bnp_final_kernel(const double* __restrict__ partial, int N, int C, int nch, double count, int mode, float eps,
+                                                       float momentum, float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                       float* __restrict__ out0, float* __restrict__ out1, float* __restrict__ dgamma,
+                                                       float* __restrict__ dbeta) {
+    const int c = blockIdx.x;
+    double s = 0.0, ss = 0.0;
+    const int per = N * nch;
+    for (int k = threadIdx.x; k < per; k += 64) {
+        const int n = k / nch, ch = k - n * nch;
+        const size_t o = (((size_t)n * C + c) * nch + ch) * 2;
+        s += partial[o]; ss += partial[o + 1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); ss += __shfl_xor(ss, o, 64); }
+    if (threadIdx.x != 0) return;
+    if (mode == 0) {
+        const double mu = s / count;
+        double var = ss / count - mu * mu;
+        if (var < 0.0) var = 0.0;
+        out0[c] = (float)mu;
+        out1[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (run_mean) run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)mu;
+        if (run_var) {
+            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
+        }
+    } else {
+        out0[c] = (float)s; out1[c] = (float)ss;
+        if (dbeta) dbeta[c] = (float)s;
+        if (dgamma) dgamma[c] = (float)ss;
+    }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void bnp_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ y,
+                                                        int C, int S, int relu) {
+    const size_t plane = blockIdx.y;
+    const int c = (int)(plane % (size_t)C);
+    const float a = invstd[c] * (gamma ? gamma[c] : 1.f), mu = mean[c], b = beta ? beta[c] : 0.f;
+    const int s0 = blockIdx.x * PL_CHUNK, s1 = min(S, s0 + PL_CHUNK);
+    const float* p = x + plane * (size_t)S;
+    float* q = y + plane * (size_t)S;
+    auto f = [&](float v) { const float r = (v - mu) * a + b; return relu ? fmaxf(r, 0.f) : r; };
+    if (VEC) {
+        for (int i = s0 + 4 * threadIdx.x; i < s1; i += 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(p + i);
+            *reinterpret_cast<float4*>(q + i) = make_float4(f(v.x), f(v.y), f(v.z), f(v.w));
+        }
+    } else {
+        for (int i = s0 + threadIdx.x; i < s1; i += 256) q[i] = f(p[i]);
+    }
+}
+
+// partial pairs: sum g, sum g * xhat with g = dy * (y > 0 if relu)
+template <bool VEC>
+__global__ __launch_bounds__(256) void bnp_bwd_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
+                                                              const float* __restrict__ mean, const float* __restrict__ invstd, int C, int S, int nch,
+                                                              int relu, double* __restrict__ partial) {
+    const size_t plane = blockIdx.y;
+    const int c = (int)(plane % (size_t)C);
+    const float mu = mean[c], is = invstd[c];
+    const int s0 = blockIdx.x * PL_CHUNK, s1 = min(S, s0 + PL_CHUNK);
+    const size_t base = plane * (size_t)S;
+    float s = 0.f, sx = 0.f;
+    auto acc = [&](float g, float xv, float yv) {
+        if (relu && !(yv > 0.f)) g = 0.f;
+        s += g; sx += g * ((xv - mu) * is);
+    };
+    if (VEC) {
+        for (int i = s0 + 4 * threadIdx.x; i < s1; i += 1024) {
+            const float4 g = *reinterpret_cast<const float4*>(dy + base + i), xv = *reinterpret_cast<const float4*>(x + base + i);
+            float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (relu) yv = *reinterpret_cast<const float4*>(y + base + i);
+            acc(g.x, xv.x, yv.x); acc(g.y, xv.y, yv.y); acc(g.z, xv.z, yv.z); acc(g.w, xv.w, yv.w);
+        }
+    } else {
+        for (int i = s0 + threadIdx.x; i < s1; i += 256) acc(dy[base + i], x[base + i], relu ? y[base + i] : 1.f);
+    }
+    double a = (double)s, b = (double)sx;
+    pl_block_sum2(a, b);
+    if (threadIdx.x == 0) {
+        partial[(plane * nch + blockIdx.x) * 2 + 0] = a;
+        partial[(plane * nch + blockIdx.x) * 2 + 1] = b;
+    }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void bnp_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
+                                                         const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                         const float* __restrict__ sums, float* __restrict__ dx, int C, int S, float inv_count,
+                                                         int training, int relu) {
+    const size_t plane = blockIdx.y;
+    const int c = (int)(plane % (size_t)C);
+    const float mu = mean[c], is = invstd[c], w = (gamma ? gamma[c] : 1.f) * is;
+    const float k1 = training ? sums[c] * inv_count : 0.f, k2 = training ? sums[C + c] * inv_count : 0.f;
+    const int s0 = blockIdx.x * PL_CHUNK, s1 = min(S, s0 + PL_CHUNK);
+    const size_t base = plane * (size_t)S;
+    auto f = [&](float g, float xv, float yv) {
+        if (relu && !(yv > 0.f)) g = 0.f;
+        return training ? w * (g - k1 - ((xv - mu) * is) * k2) : g * w;
+    };
+    if (VEC) {
+        for (int i = s0 + 4 * threadIdx.x; i < s1; i += 1024) {
+            const float4 g = *reinterpret_cast<const float4*>(dy + base + i), xv = *reinterpret_cast<const float4*>(x + base + i);
+            float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (relu) yv = *reinterpret_cast<const float4*>(y + base + i);
+            *reinterpret_cast<float4*>(dx + base + i) = make_float4(f(g.x, xv.x, yv.x), f(g.y, xv.y, yv.y), f(g.z, xv.z, yv.z), f(g.w, xv.w, yv.w));
+        }
+    } else {
+        for (int i = s0 + threadIdx.x; i < s1; i += 256) dx[base + i] = f(dy[base + i], x[base + i], relu ? y[base + i] : 1.f);
+    }
+}
+
+static int pl_chunks(int S) { return cdiv(S, PL_CHUNK); }
+
 }  // namespace
+
+extern "C" size_t m3t_bn_planes_ws_bytes(int N, int C, int S) {
+    return (size_t)N * C * pl_chunks(S) * 2 * sizeof(double) + 2 * (size_t)C * sizeof(float) + 256;
+}
+
+// x, y [N][C][S] (S = T H W contiguous).  training: batch statistics over N * S values per channel, running statistics updated with
+// `momentum` (torch's unbiased variance); else the running ones.  save_mean / save_invstd [C] for the backward pass.  relu: fused ReLU.
+extern "C" int m3t_bn_planes_fwd(const float* x, int N, int C, int S, const float* gamma, const float* beta, float* run_mean, float* run_var,
+                                 float momentum, float eps, int training, int relu, float* y, float* save_mean, float* save_invstd, float* ws,
+                                 size_t ws_bytes, void* stream) {
+    if (N <= 0 || C <= 0 || S <= 0 || (size_t)N * C > 65535 || !x || !y || !save_mean || !save_invstd) return M3T_EINVAL;
+    if (!training && (!run_mean || !run_var)) return M3T_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int nch = pl_chunks(S);
+    const bool vec = S % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0;
+    const dim3 grid(nch, (unsigned)((size_t)N * C));
+    if (training) {
+        if ((size_t)N * S < 2) return M3T_EINVAL;      // torch: "Expected more than 1 value per channel when training"
+        if (!ws || ws_bytes < m3t_bn_planes_ws_bytes(N, C, S) || ((uintptr_t)ws % 8) != 0) return M3T_EINVAL;
+        double* partial = reinterpret_cast<double*>(ws);
+        if (vec) bnp_stats_partial_kernel<true><<<grid, 256, 0, s>>>(x, S, nch, partial);
+        else bnp_stats_partial_kernel<false><<<grid, 256, 0, s>>>(x, S, nch, partial);
+        M3T_LAUNCH_CHECK();
+        bnp_final_kernel<<<C, 64, 0, s>>>(partial, N, C, nch, (double)N * S, 0, eps, momentum, run_mean, run_var, save_mean, save_invstd, nullptr, nullptr);
+        M3T_LAUNCH_CHECK();
+    } else {
+        bn_eval_stats_kernel<<<cdiv(C, 256), 256, 0, s>>>(run_mean, run_var, C, eps, save_mean, save_invstd);
+        M3T_LAUNCH_CHECK();
+    }
+    if (vec) bnp_apply_kernel<true><<<grid, 256, 0, s>>>(x, gamma, beta, save_mean, save_invstd, y, C, S, relu);
+    else bnp_apply_kernel<false><<<grid, 256, 0, s>>>(x, gamma, beta, save_mean, save_invstd, y, C, S, relu);
+    M3T_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int m3t_bn_planes_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* save_mean, const float* save_invstd,
+                                 int N, int C, int S, int training, int relu, float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes,
+                                 void* stream) {
+    if (N <= 0 || C <= 0 || S <= 0 || (size_t)N * C > 65535 || !dy || !x || !dx || !save_mean || !save_invstd) return M3T_EINVAL;
+    if (relu && !y) return M3T_EINVAL;
+    if (!ws || ws_bytes < m3t_bn_planes_ws_bytes(N, C, S) || ((uintptr_t)ws % 8) != 0) return M3T_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int nch = pl_chunks(S);
+    const bool vec = S % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)dx % 16) == 0 && (!relu || ((uintptr_t)y % 16) == 0);
+    const dim3 grid(nch, (unsigned)((size_t)N * C));
+    double* partial = reinterpret_cast<double*>(ws);
+    float* sums = reinterpret_cast<float*>(partial + (size_t)N * C * nch * 2);
+    if (vec) bnp_bwd_partial_kernel<true><<<grid, 256, 0, s>>>(dy, x, y, save_mean, save_invstd, C, S, nch, relu, partial);
+    else bnp_bwd_partial_kernel<false><<<grid, 256, 0, s>>>(dy, x, y, save_mean, save_invstd, C, S, nch, relu, partial);
+    M3T_LAUNCH_CHECK();
+    bnp_final_kernel<<<C, 64, 0, s>>>(partial, N, C, nch, (double)N * S, 1, 0.f, 0.f, nullptr, nullptr, sums, sums + C, dgamma, dbeta);
+    M3T_LAUNCH_CHECK();
+    const float inv_count = (float)(1.0 / ((double)N * S));
+    if (vec) bnp_bwd_dx_kernel<true><<<grid, 256, 0, s>>>(dy, x, y, gamma, save_mean, save_invstd, sums, dx, C, S, inv_count, training, relu);
+    else bnp_bwd_dx_kernel<false><<<grid, 256, 0, s>>>(dy, x, y, gamma, save_mean, save_invstd, sums, dx, C, S, inv_count, training, relu);
+    M3T_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" size_t m3t_bn_rows_ws_bytes(int M, int C) {
     return (size_t)bn_chunks(M) * 2 * (size_t)C * sizeof(double) + 2 * (size_t)C * sizeof(float) + 256;

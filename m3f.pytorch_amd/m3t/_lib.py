@@ -77,6 +77,9 @@ SIGNATURES = {
     "m3t_conv1d_fwd_scaled": [_f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, C.c_float, C.c_ulonglong, _i, _f, _f, _s],
     "m3t_conv1d_wgrad": [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _z, _i, _s],
     "m3t_conv1d_wgrad_scaled": [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _z, _i, _f, _f, _s],
+    "m3t_bn_planes_ws_bytes": [_i, _i, _i],
+    "m3t_bn_planes_fwd": [_f, _i, _i, _i, _f, _f, _f, _f, C.c_float, C.c_float, _i, _i, _f, _f, _f, _f, _z, _s],
+    "m3t_bn_planes_bwd": [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _z, _s],
     "m3t_bn_rows_ws_bytes": [_i, _i],
     "m3t_bn_rows_fwd": [_f, _i, _i, _f, _f, _f, _f, C.c_float, C.c_float, _i, _i, _f, _f, _f, _f, _z, _s],
     "m3t_bn_rows_bwd": [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _f, _f, _f, _f, _z, _s],
@@ -105,7 +108,7 @@ SIGNATURES = {
     "m3t_sgd_step": [_f, _f, _f, _z, C.c_float, C.c_float, C.c_float, _i, _f, _s],
 }
 
-RESTYPES = {"m3t_bn_rows_ws_bytes": C.c_size_t, "m3t_va_loss_ws_bytes": C.c_size_t, "m3t_cbam_fused_ws_bytes": C.c_size_t}
+RESTYPES = {"m3t_bn_rows_ws_bytes": C.c_size_t, "m3t_bn_planes_ws_bytes": C.c_size_t, "m3t_va_loss_ws_bytes": C.c_size_t, "m3t_cbam_fused_ws_bytes": C.c_size_t}
 
 _lib = None
 

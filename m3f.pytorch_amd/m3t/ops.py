@@ -1750,6 +1750,46 @@ def grad_norm_scale_(flat, world_size, max_norm):
     return norm
 
 
+# ----------------------------------------------------------------------------- BatchNorm3d (+ReLU) of the 3-D stems
+class _BNPlanes(torch.autograd.Function):
+    """nn.BatchNorm3d (+ nn.ReLU) on channels-first activations [N, C, T, H, W] (reference models/backbone.py:73-103,179-191), csrc/bn.hip
+    m3t_bn_planes_*: statistics sweep | apply + ReLU; backward sums sweep | dx -- the ReLU costs no pass of its own"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, run_mean, run_var, training, momentum, eps, relu):
+        x = _req(x.contiguous(), "x")
+        N, Cc = x.shape[0], x.shape[1]
+        S = x.numel() // (N * Cc)
+        y = torch.empty_like(x)
+        stats = torch.empty(2, Cc, dtype=torch.float32, device=x.device)
+        ws = workspace(x.device, int(lib().m3t_bn_planes_ws_bytes(N, Cc, S)))
+        rc = lib().m3t_bn_planes_fwd(_p(x), N, Cc, S, _p(gamma), _p(beta), _p(run_mean), _p(run_var), float(momentum), float(eps),
+                                     int(training), int(relu), _p(y), _p(stats[0]), _p(stats[1]), _p(ws), ws.numel() * 4, _stream())
+        _lib.check(rc, "m3t_bn_planes_fwd")
+        ctx.save_for_backward(x, y if relu else None, gamma, stats)
+        ctx.training, ctx.relu = bool(training), bool(relu)
+        ctx.mark_non_differentiable(*[t for t in (run_mean, run_var) if t is not None])
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, stats = ctx.saved_tensors
+        dy = _req(dy.contiguous(), "dy")
+        N, Cc = x.shape[0], x.shape[1]
+        S = x.numel() // (N * Cc)
+        dx = torch.empty_like(x)
+        g = torch.empty(2, Cc, dtype=torch.float32, device=x.device)
+        ws = workspace(x.device, int(lib().m3t_bn_planes_ws_bytes(N, Cc, S)))
+        rc = lib().m3t_bn_planes_bwd(_p(dy), _p(x), _p(y), _p(gamma), _p(stats[0]), _p(stats[1]), N, Cc, S, int(ctx.training), int(ctx.relu),
+                                     _p(dx), _p(g[0]), _p(g[1]), _p(ws), ws.numel() * 4, _stream())
+        _lib.check(rc, "m3t_bn_planes_bwd")
+        return dx, (g[0] if gamma is not None else None), (g[1] if gamma is not None else None), None, None, None, None, None, None
+
+
+def bn_planes(x, gamma, beta, run_mean, run_var, training, momentum, eps, relu=True):
+    return _BNPlanes.apply(x, gamma, beta, run_mean, run_var, training, momentum, eps, relu)
+
+
 # ----------------------------------------------------------------------------- Conv3d weight gradient
 class _Conv3dGemmWgrad(torch.autograd.Function):
     """Conv3d of the visual stems (reference models/backbone.py:73-103,179-271,327-332): forward and the data

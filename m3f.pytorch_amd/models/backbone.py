@@ -30,17 +30,35 @@ class Conv3d(nn.Conv3d):
         return super().forward(x)
 
 
-def _norm3d(kind, channels):
-    return nn.BatchNorm3d(channels) if kind == 'bn' else nn.GroupNorm(32, channels)
+class BatchNorm3dReLU(nn.BatchNorm3d):
+    """nn.BatchNorm3d followed by ReLU as ONE operator on the HIP kernels (m3t.ops.bn_planes: the ReLU costs no pass over the
+    activation of its own, forward or backward); same parameters, buffers and state_dict keys as nn.BatchNorm3d.  In the stems'
+    nn.Sequential it takes the BatchNorm3d slot and an nn.Identity the ReLU's, so every index -- and every checkpoint key -- stays."""
+
+    def forward(self, x):
+        if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and self.affine and self.track_running_stats
+                and self.momentum is not None and x.shape[0] * x.shape[1] <= 65535):
+            if self.training:
+                self.num_batches_tracked.add_(1)
+            return ops.bn_planes(x, self.weight, self.bias, self.running_mean, self.running_var, self.training, self.momentum,
+                                 self.eps, True)
+        return torch.relu(super().forward(x))
+
+
+def _norm_relu3d(kind, channels):
+    """[normalisation, ReLU] of a stem layer (reference backbone.py:77-79 etc.: BatchNorm3d / GroupNorm(32) then ReLU(True))"""
+    if kind == 'bn':
+        return [BatchNorm3dReLU(channels), nn.Identity()]
+    return [nn.GroupNorm(32, channels), nn.ReLU(True)]
 
 
 def _vgg_group(idx, norm):
     """Layer group `conv{idx}` of the VGG-M style stem (reference backbone.py:73-103,179-184,243-271)."""
     if idx == 1:
-        return [Conv3d(3, 64, 3, stride=(1, 2, 2), padding=(1, 0, 0)), _norm3d(norm, 64), nn.ReLU(True),
-                nn.MaxPool3d(kernel_size=(1, 2, 2), stride=(1, 2, 2))]
+        return [Conv3d(3, 64, 3, stride=(1, 2, 2), padding=(1, 0, 0))] + _norm_relu3d(norm, 64) + \
+               [nn.MaxPool3d(kernel_size=(1, 2, 2), stride=(1, 2, 2))]
     cin, cout, pool = {2: (64, 128, True), 3: (128, 256, True), 4: (256, 512, False), 5: (512, 512, False)}[idx]
-    mods = [Conv3d(cin, cout, 3, 1, padding=(1, 0, 0)), _norm3d(norm, cout), nn.ReLU(True)]
+    mods = [Conv3d(cin, cout, 3, 1, padding=(1, 0, 0))] + _norm_relu3d(norm, cout)
     if pool:
         mods.append(nn.MaxPool3d(kernel_size=(1, 2, 2), stride=(1, 2, 2)))
     return mods
@@ -187,7 +205,7 @@ class VA_3DResNet(nn.Module):
         self.frameLen, self.nLayers, self.backend, self.nFCs = frameLen, nLayers, backend, nFCs
         self.c3d = nn.Sequential(
             Conv3d(3, 64, kernel_size=(5, 7, 7), stride=(1, 2, 2), padding=(2, 3, 3), bias=False),
-            nn.BatchNorm3d(64), nn.ReLU(True),
+            BatchNorm3dReLU(64), nn.Identity(),
             nn.MaxPool3d(kernel_size=(1, 3, 3), stride=(1, 2, 2), padding=(0, 1, 1)))
         assert resnet_depth in [18, 34] and resnet_ver in ['v1', 'v2'], \
             'unsupported ResNet configuration: {}, {}'.format(resnet_depth, resnet_ver)

@@ -1054,6 +1054,38 @@ def test_conv3d_weight_gradient_through_the_patch_matrix(Ci, Co, k, stride, pad,
     close(x.grad, x64.grad.numpy(), 2e-4, "dx")
 
 
+@pytest.mark.parametrize("N,C_,T,H,W,training", [(3, 16, 5, 7, 9, True), (2, 64, 4, 12, 12, True), (2, 8, 3, 5, 5, False), (4, 24, 1, 1, 1, True)])
+def test_batchnorm3d_relu_on_channel_planes(N, C_, T, H, W, training):
+    """models.backbone.BatchNorm3dReLU (nn.BatchNorm3d + nn.ReLU of the 3-D stems, reference models/backbone.py:73-103,179-191) on
+    csrc/bn.hip's channel-plane kernels: planes of 315 floats (scalar sweeps), of 576 (float4), eval mode, one value per plane --
+    output, running statistics, input and parameter gradients against float64 torch on the CPU"""
+    from models.backbone import BatchNorm3dReLU
+    rs = np.random.RandomState(N + C_ + H)
+    m = BatchNorm3dReLU(C_).to(DEV)
+    ref = torch.nn.BatchNorm3d(C_).double()
+    with torch.no_grad():
+        for p_, q_ in ((m.weight, ref.weight), (m.bias, ref.bias), (m.running_mean, ref.running_mean), (m.running_var, ref.running_var)):
+            v = rs.uniform(0.5, 1.5, C_) if p_ is m.weight or p_ is m.running_var else rs.uniform(-0.5, 0.5, C_)
+            p_.copy_(torch.from_numpy(v.astype(np.float32))); q_.copy_(torch.from_numpy(v.astype(np.float32)).double())
+    m.train(training); ref.train(training)
+    xn = draw(rs, (N, C_, T, H, W))
+    x = dev(xn, True)
+    y = m(x)
+    ctn = draw(rs, tuple(y.shape))
+    (y * dev(ctn)).sum().backward()
+    x64 = torch.tensor(xn, dtype=torch.float64, requires_grad=True)
+    y64 = torch.relu(ref(x64))
+    (y64 * torch.tensor(ctn, dtype=torch.float64)).sum().backward()
+    close(y, y64.detach().numpy(), TOL, "y")
+    close(x.grad, x64.grad.numpy(), TOL, "dx")
+    close(m.weight.grad, ref.weight.grad.numpy(), 2e-4, "dgamma")
+    close(m.bias.grad, ref.bias.grad.numpy(), 2e-4, "dbeta")
+    close(m.running_mean, ref.running_mean.numpy(), 1e-5, "running_mean")
+    close(m.running_var, ref.running_var.numpy(), 1e-5, "running_var")
+    assert int(m.num_batches_tracked) == int(ref.num_batches_tracked)
+    assert sorted(m.state_dict().keys()) == sorted(ref.state_dict().keys())
+
+
 def test_c5_affwild_av_golden():
     """Full AffWild2VA audiovisual/attention/v2p_split on raw frames (conv stem on MIOpen)."""
     from models.model import AffWild2VA
