@@ -87,7 +87,7 @@ int m3t_im2col3d(const float* x, int N, int Ci, int T, int H, int W, int kt, int
                  int pt, int ph, int pw, float* out, long long rows_pad, int Kp, unsigned long long* amax_slot, void* stream);
 
 /* Magnitude slots from the PRODUCER (fp16x3 mode, see m3t_sgemm_scaled): the NEXT m3t_conv1d_fwd(_scaled) / m3t_mask_pos / m3t_mask_pos_drop /
- * m3t_weight_norm_fwd call of the calling thread raises `slot` (8 bytes, zero-initialised by the caller, epoch 0) to the bits of max |x| over
+ * m3t_weight_norm_fwd / m3t_bct_to_btc call of the calling thread raises `slot` (8 bytes, zero-initialised by the caller, epoch 0) to the bits of max |x| over
  * its output (y / out / w_t) -- in the same kernel, one 64-bit atomic max per workgroup -- so that the contraction that consumes the output
  * needs no measuring launch.  Consumed by that call (also when it fails).  Returns 0. */
 int m3t_amax_out(unsigned long long* slot);
@@ -392,6 +392,9 @@ int m3t_bn_planes_bwd(const float* dy, const float* x, const float* y, const flo
 /* [B,C,T] <-> [B,T,C] */
 int m3t_bct_to_btc(const float* src, float* dst, int B, int C, int T, void* stream);
 int m3t_btc_to_bct(const float* src, float* dst, int B, int T, int C, void* stream);
+/* m3t_bct_to_btc that also leaves, in part [B * ceil(T / 32)][C], the sums of every channel row over each tile of 32 positions: the column
+ * sums of `part` (m3t_colsum) are the per-channel sums of src over (B, T) -- the conv3d bias gradient without another pass over dy */
+int m3t_bct_to_btc_sums(const float* src, float* dst, int B, int C, int T, float* part, void* stream);
 /* out[i] = s[i] > 0 ? dy[i] * (mul ? mul[i] : 1) : 0   (ReLU / dropout gradient masks) */
 int m3t_mask_pos(const float* s, const float* dy, const float* mul, float* out, size_t n, void* stream);
 /* out[row, col] = s > 0 ? dy * mask(row, col) : 0 over [rows, C] with m3t_conv1d_fwd's in-kernel dropout mask regenerated from

@@ -103,7 +103,7 @@ struct M3TRegion { const float* p; unsigned long long rows; unsigned long long l
 int m3t_f16x3_measure(const M3TRegion& a, const unsigned long long* have_a, const M3TRegion& b, const unsigned long long* have_b,
                       const unsigned long long** use_a, const unsigned long long** use_b, hipStream_t s);
 int m3t_absmax_regions(const M3TRegion* regs, int n, hipStream_t s);      // any n; slots raised with epoch 0 (caller-owned)
-// m3t_amax_out(slot): the NEXT m3t_conv1d_fwd(_scaled) / m3t_mask_pos / m3t_mask_pos_drop / m3t_weight_norm_fwd call of the calling thread
+// m3t_amax_out(slot): the NEXT m3t_conv1d_fwd(_scaled) / m3t_mask_pos / m3t_mask_pos_drop / m3t_weight_norm_fwd / m3t_bct_to_btc call of the calling thread
 // raises `slot` (a caller-owned, zero-initialised magnitude slot) to the bits of max |its output| -- the producer measures what the next
 // fp16x3 contraction will scale by, instead of a measuring launch in front of that contraction.  take: returns and clears it.
 unsigned long long* m3t_take_amax_out();

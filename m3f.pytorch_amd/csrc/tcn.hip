@@ -238,21 +238,36 @@ __global__ __launch_bounds__(256) void weight_norm_bwd_kernel(const float* __res
 }
 
 // batched [R][C] -> [C][R] through a padded LDS tile (both sides coalesced)
+// amax (optional): a magnitude slot raised to max |src| on the way (m3t_amax_out: the conv3d weight gradient's dy goes channels-last
+// through here and straight into an fp16x3 GEMM)
+// rowsum (optional): [gridDim.z * gridDim.x][R] partial sums of the SOURCE rows over this block's 32 columns (the conv3d bias gradient:
+// a row of dy's [C_out][positions] plane is a channel) -- summed by m3t_colsum afterwards, fixed order
 __global__ __launch_bounds__(256) void batched_transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int R,
-                                                                int C) {
+                                                                int C, unsigned long long* __restrict__ amax, float* __restrict__ rowsum) {
     __shared__ float tile[32][33];
+    __shared__ float red4[4];
     const size_t boff = (size_t)blockIdx.z * R * C;
     const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    float mx = 0.f;
     for (int i = ty; i < 32; i += 8) {
         const int r = r0 + i, c = c0 + tx;
-        tile[i][tx] = (r < R && c < C) ? src[boff + (size_t)r * C + c] : 0.f;
+        const float v = (r < R && c < C) ? src[boff + (size_t)r * C + c] : 0.f;
+        tile[i][tx] = v;
+        mx = fmaxf(mx, m3t_fin_abs(v));
+        if (rowsum) {
+            float sv = v;
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) sv += __shfl_xor(sv, o, 64);      // (a wave holds two tile rows of 32 columns)
+            if (tx == 0 && r < R) rowsum[((size_t)blockIdx.z * gridDim.x + blockIdx.x) * R + r] = sv;
+        }
     }
     __syncthreads();
     for (int i = ty; i < 32; i += 8) {
         const int c = c0 + i, r = r0 + tx;
         if (c < C && r < R) dst[boff + (size_t)c * R + r] = tile[tx][i];
     }
+    if (amax) m3t_block_raise_slot(amax, mx, red4);
 }
 
 }  // namespace
@@ -413,15 +428,25 @@ extern "C" int m3t_causal_conv_wgrad(const float* dy, const float* x, float* dw_
 }
 
 extern "C" int m3t_bct_to_btc(const float* src, float* dst, int B, int C, int T, void* stream) {
+    unsigned long long* amax = m3t_take_amax_out();
     if (B <= 0 || C <= 0 || T <= 0) return 0;
-    batched_transpose_kernel<<<dim3(cdiv(T, 32), cdiv(C, 32), B), 256, 0, (hipStream_t)stream>>>(src, dst, C, T);
+    batched_transpose_kernel<<<dim3(cdiv(T, 32), cdiv(C, 32), B), 256, 0, (hipStream_t)stream>>>(src, dst, C, T, amax, nullptr);
+    M3T_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int m3t_bct_to_btc_sums(const float* src, float* dst, int B, int C, int T, float* part, void* stream) {
+    unsigned long long* amax = m3t_take_amax_out();
+    if (B <= 0 || C <= 0 || T <= 0) return 0;
+    if (!src || !dst || !part) return M3T_EINVAL;
+    batched_transpose_kernel<<<dim3(cdiv(T, 32), cdiv(C, 32), B), 256, 0, (hipStream_t)stream>>>(src, dst, C, T, amax, part);
     M3T_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int m3t_btc_to_bct(const float* src, float* dst, int B, int T, int C, void* stream) {
     if (B <= 0 || C <= 0 || T <= 0) return 0;
-    batched_transpose_kernel<<<dim3(cdiv(C, 32), cdiv(T, 32), B), 256, 0, (hipStream_t)stream>>>(src, dst, T, C);
+    batched_transpose_kernel<<<dim3(cdiv(C, 32), cdiv(T, 32), B), 256, 0, (hipStream_t)stream>>>(src, dst, T, C, nullptr, nullptr);
     M3T_LAUNCH_CHECK();
     return 0;
 }

@@ -1814,9 +1814,21 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
             dx = torch.ops.aten.convolution_backward(dy, x, w, None, list(st), list(pd), [1, 1, 1], False, [0, 0, 0], 1,
                                                      [True, False, False])[0]
         Co, Ci, kt, kh, kw = w.shape
+        slot_dy = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dy_cl = _req(dy.permute(0, 2, 3, 4, 1).contiguous(), "dy")          # [N,T',H',W',Co] = [rows, Co]
-            rows = dy_cl.numel() // Co
+            # dy channels-last [N,T',H',W',Co] = [rows, Co] for the GEMM: the library's tiled transpose (both sides coalesced), which
+            # raises dy's magnitude slot on the way -- was torch's strided permute copy plus a measuring launch (1.1 ms of the C5 step)
+            dyc = _req(dy.contiguous(), "dy")
+            rows = dyc.numel() // Co
+            dy_cl = torch.empty(rows, Co, dtype=torch.float32, device=dy.device)
+            slot_dy = amax_slots(1, dy.device)
+            amax_out(slot_dy.data_ptr())
+            Nn, Sp = dyc.shape[0], rows // dyc.shape[0]
+            if ctx.has_bias and ctx.needs_input_grad[2]:      # the bias gradient's per-tile channel sums ride along
+                dpart = torch.empty(Nn * ((Sp + 31) // 32), Co, dtype=torch.float32, device=dy.device)
+                _lib.check(lib().m3t_bct_to_btc_sums(_p(dyc), _p(dy_cl), Nn, Co, Sp, _p(dpart), _stream()), "m3t_bct_to_btc_sums")
+            else:
+                _lib.check(lib().m3t_bct_to_btc(_p(dyc), _p(dy_cl), Nn, Co, Sp, _stream()), "m3t_bct_to_btc")
         if ctx.needs_input_grad[1]:
             Kc = Ci * kt * kh * kw
             N_, _, T_, H_, W_ = x.shape
@@ -1834,7 +1846,7 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
             if Co % 128 == 0 and Kc % 64 == 0:
                 pat = im2col(rows, Kc)
                 dw = torch.empty_like(w)
-                sgemm(1, 0, Co, Kc, rows, dy_cl, 0, Co, pat, 0, Kc, dw, 0, Kc, amax=(None, slot.data_ptr()))
+                sgemm(1, 0, Co, Kc, rows, dy_cl, 0, Co, pat, 0, Kc, dw, 0, Kc, amax=(slot_dy.data_ptr(), slot.data_ptr()))
             elif Co % 64 == 0:
                 # the stems' FIRST layers: C_out = 64 and C_in k^3 = 81 (VGG-M) / 735 (3-D ResNet) fit no interior tile of the
                 # 16-bit-term GEMM as dW = dy^T P.  Transposed and padded they do: dW^T [Kp, Co] = P_pad^T dy with Kp = ceil128(C_in k^3)
@@ -1846,17 +1858,17 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
                     dyp = torch.zeros(rows_p, Co, dtype=torch.float32, device=x.device)
                     dyp[:rows].copy_(dy_cl.view(rows, Co))
                 dwt = torch.empty(Kp, Co, dtype=torch.float32, device=x.device)
-                sgemm(1, 0, Kp, Co, rows_p, pat_pad, 0, Kp, dyp, 0, Co, dwt, 0, Co, amax=(slot.data_ptr(), None))
+                sgemm(1, 0, Kp, Co, rows_p, pat_pad, 0, Kp, dyp, 0, Co, dwt, 0, Co, amax=(slot.data_ptr(), slot_dy.data_ptr()))
                 dw = dwt[:Kc].t().contiguous().view_as(w)
             else:
                 Kp = (Kc + 3) // 4 * 4
                 pat = im2col(rows, Kp)
                 dwp = torch.empty(Co, Kp, dtype=torch.float32, device=x.device)
-                sgemm(1, 0, Co, Kp, rows, dy_cl, 0, Co, pat, 0, Kp, dwp, 0, Kp, amax=(None, slot.data_ptr()))
+                sgemm(1, 0, Co, Kp, rows, dy_cl, 0, Co, pat, 0, Kp, dwp, 0, Kp, amax=(slot_dy.data_ptr(), slot.data_ptr()))
                 dw = dwp[:, :Kc].contiguous().view_as(w)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = torch.empty(Co, dtype=torch.float32, device=dy.device)
-            colsum(dy_cl, 0, rows, Co, Co, db)
+            colsum(dpart, 0, dpart.shape[0], Co, Co, db)
         return dx, dw, db, None, None
 
 
