@@ -381,7 +381,8 @@ int m3t_bn_rows_bwd(const float* dy, const float* x, const float* y, const float
                     float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes, void* stream);
 /* BatchNorm3d (+ optional fused ReLU) of the 3-D conv stems, channels-first x [N][C][S] with S = T*H*W contiguous (nn.BatchNorm3d(C) + nn.ReLU(True),
  * reference models/backbone.py:73-103,179-191): same statistics / running-statistics / gradient formulas as the rows form above with M = N*S values per
- * channel.  N*C <= 65535.  ws: m3t_bn_planes_ws_bytes(N, C, S) bytes, 8-byte aligned. */
+ * channel.  ws: m3t_bn_planes_ws_bytes(N, C, S) bytes, 8-byte aligned.  (One workgroup per plane chunk of <= 8192 floats: made for the stems'
+ * large planes; planes of a few dozen floats work but waste the workgroup.) */
 size_t m3t_bn_planes_ws_bytes(int N, int C, int S);
 int m3t_bn_planes_fwd(const float* x, int N, int C, int S, const float* gamma, const float* beta, float* run_mean, float* run_var,
                       float momentum, float eps, int training, int relu, float* y, float* save_mean, float* save_invstd,

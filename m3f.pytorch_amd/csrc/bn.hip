@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float* __restrict_
 
 // ---------------------------------------------------------------------------------------------------------------- channel PLANES
 // BatchNorm3d (+ReLU) of the 3-D conv stems (reference models/backbone.py:73-103,179-191: Conv3d -> BatchNorm3d -> ReLU), x [N][C][S]
-// with S = T H W contiguous: a channel is N planes of S floats.  A workgroup takes one chunk (<= 8192 floats) of one plane: float4
+// with S = T H W contiguous (or [N][C][H W]: BatchNorm2d): a channel is N planes of S floats.  A workgroup takes one chunk (<= 8192 floats) of one plane: float4
 // sweeps, the plane's scalars (mean, invstd, gamma, beta) loaded once.  Forward: statistics sweep (per-chunk fp64 partials, reduced per
 // channel in a fixed order) | apply + ReLU; backward: sums sweep (d beta, d gamma with the ReLU mask from y) | dx.  MIOpen ran the
 // normalisation and torch the ReLU as separate passes: one read + one write of the activation less in each direction.
@@ -175,8 +175,8 @@ __device__ __forceinline__ void pl_block_sum2(double& a, double& b) {
 // partial[(plane * nch + chunk) * 2 + {0, 1}]: sum x, sum x^2
 template <bool VEC>
 __global__ __launch_bounds__(256) void bnp_stats_partial_kernel(const float* __restrict__ x, int S, int nch, double* __restrict__ partial) {
-    const size_t plane = blockIdx.y;
-    const int s0 = blockIdx.x * PL_CHUNK, s1 = min(S, s0 + PL_CHUNK);
+    const size_t plane = blockIdx.x;
+    const int s0 = blockIdx.y * PL_CHUNK, s1 = min(S, s0 + PL_CHUNK);
     const float* p = x + plane * (size_t)S;
     float s = 0.f, ss = 0.f;
     if (VEC) {
@@ -191,8 +191,8 @@ __global__ __launch_bounds__(256) void bnp_stats_partial_kernel(const float* __r
     double a = (double)s, b = (double)ss;
     pl_block_sum2(a, b);
     if (threadIdx.x == 0) {
-        partial[(plane * nch + blockIdx.x) * 2 + 0] = a;
-        partial[(plane * nch + blockIdx.x) * 2 + 1] = b;
+        partial[(plane * nch + blockIdx.y) * 2 + 0] = a;
+        partial[(plane * nch + blockIdx.y) * 2 + 1] = b;
     }
 }
 
@@ -235,10 +235,10 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void bnp_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ y,
                                                         int C, int S, int relu) {
-    const size_t plane = blockIdx.y;
+    const size_t plane = blockIdx.x;
     const int c = (int)(plane % (size_t)C);
     const float a = invstd[c] * (gamma ? gamma[c] : 1.f), mu = mean[c], b = beta ? beta[c] : 0.f;
-    const int s0 = blockIdx.x * PL_CHUNK, s1 = min(S, s0 + PL_CHUNK);
+    const int s0 = blockIdx.y * PL_CHUNK, s1 = min(S, s0 + PL_CHUNK);
     const float* p = x + plane * (size_t)S;
     float* q = y + plane * (size_t)S;
     auto f = [&](float v) { const float r = (v - mu) * a + b; return relu ? fmaxf(r, 0.f) : r; };
@@ -257,10 +257,10 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void bnp_bwd_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
                                                               const float* __restrict__ mean, const float* __restrict__ invstd, int C, int S, int nch,
                                                               int relu, double* __restrict__ partial) {
-    const size_t plane = blockIdx.y;
+    const size_t plane = blockIdx.x;
     const int c = (int)(plane % (size_t)C);
     const float mu = mean[c], is = invstd[c];
-    const int s0 = blockIdx.x * PL_CHUNK, s1 = min(S, s0 + PL_CHUNK);
+    const int s0 = blockIdx.y * PL_CHUNK, s1 = min(S, s0 + PL_CHUNK);
     const size_t base = plane * (size_t)S;
     float s = 0.f, sx = 0.f;
     auto acc = [&](float g, float xv, float yv) {
@@ -280,8 +280,8 @@ __global__ __launch_bounds__(256) void bnp_bwd_partial_kernel(const float* __res
     double a = (double)s, b = (double)sx;
     pl_block_sum2(a, b);
     if (threadIdx.x == 0) {
-        partial[(plane * nch + blockIdx.x) * 2 + 0] = a;
-        partial[(plane * nch + blockIdx.x) * 2 + 1] = b;
+        partial[(plane * nch + blockIdx.y) * 2 + 0] = a;
+        partial[(plane * nch + blockIdx.y) * 2 + 1] = b;
     }
 }
 
@@ -290,11 +290,11 @@ __global__ __launch_bounds__(256) void bnp_bwd_dx_kernel(const float* __restrict
                                                          const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
                                                          const float* __restrict__ sums, float* __restrict__ dx, int C, int S, float inv_count,
                                                          int training, int relu) {
-    const size_t plane = blockIdx.y;
+    const size_t plane = blockIdx.x;
     const int c = (int)(plane % (size_t)C);
     const float mu = mean[c], is = invstd[c], w = (gamma ? gamma[c] : 1.f) * is;
     const float k1 = training ? sums[c] * inv_count : 0.f, k2 = training ? sums[C + c] * inv_count : 0.f;
-    const int s0 = blockIdx.x * PL_CHUNK, s1 = min(S, s0 + PL_CHUNK);
+    const int s0 = blockIdx.y * PL_CHUNK, s1 = min(S, s0 + PL_CHUNK);
     const size_t base = plane * (size_t)S;
     auto f = [&](float g, float xv, float yv) {
         if (relu && !(yv > 0.f)) g = 0.f;
@@ -325,12 +325,12 @@ extern "C" size_t m3t_bn_planes_ws_bytes(int N, int C, int S) {
 extern "C" int m3t_bn_planes_fwd(const float* x, int N, int C, int S, const float* gamma, const float* beta, float* run_mean, float* run_var,
                                  float momentum, float eps, int training, int relu, float* y, float* save_mean, float* save_invstd, float* ws,
                                  size_t ws_bytes, void* stream) {
-    if (N <= 0 || C <= 0 || S <= 0 || (size_t)N * C > 65535 || !x || !y || !save_mean || !save_invstd) return M3T_EINVAL;
+    if (N <= 0 || C <= 0 || S <= 0 || !x || !y || !save_mean || !save_invstd) return M3T_EINVAL;
     if (!training && (!run_mean || !run_var)) return M3T_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const int nch = pl_chunks(S);
     const bool vec = S % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0;
-    const dim3 grid(nch, (unsigned)((size_t)N * C));
+    const dim3 grid((unsigned)((size_t)N * C), nch);
     if (training) {
         if ((size_t)N * S < 2) return M3T_EINVAL;      // torch: "Expected more than 1 value per channel when training"
         if (!ws || ws_bytes < m3t_bn_planes_ws_bytes(N, C, S) || ((uintptr_t)ws % 8) != 0) return M3T_EINVAL;
@@ -353,13 +353,13 @@ extern "C" int m3t_bn_planes_fwd(const float* x, int N, int C, int S, const floa
 extern "C" int m3t_bn_planes_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* save_mean, const float* save_invstd,
                                  int N, int C, int S, int training, int relu, float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes,
                                  void* stream) {
-    if (N <= 0 || C <= 0 || S <= 0 || (size_t)N * C > 65535 || !dy || !x || !dx || !save_mean || !save_invstd) return M3T_EINVAL;
+    if (N <= 0 || C <= 0 || S <= 0 || !dy || !x || !dx || !save_mean || !save_invstd) return M3T_EINVAL;
     if (relu && !y) return M3T_EINVAL;
     if (!ws || ws_bytes < m3t_bn_planes_ws_bytes(N, C, S) || ((uintptr_t)ws % 8) != 0) return M3T_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const int nch = pl_chunks(S);
     const bool vec = S % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)dx % 16) == 0 && (!relu || ((uintptr_t)y % 16) == 0);
-    const dim3 grid(nch, (unsigned)((size_t)N * C));
+    const dim3 grid((unsigned)((size_t)N * C), nch);
     double* partial = reinterpret_cast<double*>(ws);
     float* sums = reinterpret_cast<float*>(partial + (size_t)N * C * nch * 2);
     if (vec) bnp_bwd_partial_kernel<true><<<grid, 256, 0, s>>>(dy, x, y, save_mean, save_invstd, C, S, nch, relu, partial);

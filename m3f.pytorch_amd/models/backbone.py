@@ -37,7 +37,7 @@ class BatchNorm3dReLU(nn.BatchNorm3d):
 
     def forward(self, x):
         if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and self.affine and self.track_running_stats
-                and self.momentum is not None and x.shape[0] * x.shape[1] <= 65535):
+                and self.momentum is not None):
             if self.training:
                 self.num_batches_tracked.add_(1)
             return ops.bn_planes(x, self.weight, self.bias, self.running_mean, self.running_var, self.training, self.momentum,
