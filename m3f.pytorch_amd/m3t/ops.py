@@ -1768,7 +1768,6 @@ class _BNPlanes(torch.autograd.Function):
         _lib.check(rc, "m3t_bn_planes_fwd")
         ctx.save_for_backward(x, y if relu else None, gamma, stats)
         ctx.training, ctx.relu = bool(training), bool(relu)
-        ctx.mark_non_differentiable(*[t for t in (run_mean, run_var) if t is not None])
         return y
 
     @staticmethod

@@ -11,6 +11,7 @@ import math
 
 import torch
 import torch.nn as nn
+from torch.nn.modules.utils import _triple
 
 from m3t import ops
 from .resnet import ResNet, ResNetV2, BasicBlock, BasicBlockV2
@@ -51,7 +52,7 @@ class SpatialMaxPool3d(nn.MaxPool3d):
     instead of its generic 3-D ones (max_pool3d_with_indices forward + backward were 1.3 ms of the 32 ms C5 step).  No parameters."""
 
     def forward(self, x):
-        k, s, p, d = (nn.modules.utils._triple(v) for v in (self.kernel_size, self.stride, self.padding, self.dilation))
+        k, s, p, d = (_triple(v) for v in (self.kernel_size, self.stride, self.padding, self.dilation))
         if x.dim() == 5 and k[0] == 1 and s[0] == 1 and p[0] == 0 and d[0] == 1 and not self.return_indices and x.is_contiguous():
             N, Cc, T, H, W = x.shape
             y = nn.functional.max_pool2d(x.view(N, Cc * T, H, W), k[1:], s[1:], p[1:], d[1:], self.ceil_mode)

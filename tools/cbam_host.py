@@ -37,7 +37,7 @@ pr.enable()
 for _ in range(50): f()
 pr.disable()
 torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
+pstats.Stats(pr).sort_stats("tottime" if os.environ.get("BY_OWN_TIME") == "1" else "cumulative").print_stats(22)
 
 # ---- pieces
 from m3t import ops
