@@ -312,7 +312,112 @@ __global__ __launch_bounds__(256) void bnp_bwd_dx_kernel(const float* __restrict
     }
 }
 
-static int pl_chunks(int S) { return cdiv(S, PL_CHUNK); }
+// ---- small planes (S <= PL_SMALL: BatchNorm2d on the per-frame ResNet's 28 x 28 ... 4 x 4 maps, N C = 32 768 ... 262 144 planes): a
+// workgroup per plane would be a workgroup per 64 bytes.  Here LPP = the power of two >= the plane's units (float4 when S % 4 == 0,
+// else floats) lanes take one plane, a wave 64 / LPP planes, a workgroup four waves' worth; no divisions, every load a full row.
+constexpr int PL_SMALL = 1024;
+struct SmallMap { int lpp, lg, ppw; };      // lanes per plane, log2 of it, planes per wave
+static SmallMap small_map(int S, bool vec) {
+    const int units = vec ? S / 4 : S;
+    SmallMap m;
+    m.lpp = 1; m.lg = 0;
+    while (m.lpp < units && m.lpp < 64) { m.lpp <<= 1; ++m.lg; }
+    m.ppw = 64 / m.lpp;
+    return m;
+}
+#define M3T_SMALL_PROLOGUE                                                                                      \
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;                                                 \
+    const int sub = lane & (lpp - 1);                                                                           \
+    const size_t plane = ((size_t)blockIdx.x * 4 + wave) * (64 >> lg) + (lane >> lg);                           \
+    const bool live = plane < P;                                                                                \
+    const size_t base = plane * (size_t)S;                                                                      \
+    constexpr int E = VEC ? 4 : 1;
+
+__device__ __forceinline__ void seg_sum2(float& a, float& b, int lpp) {
+    for (int o = 1; o < lpp; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+}
+
+// MODE 0: sum x, sum x^2;  MODE 1: sum g, sum g xhat (g = dy masked by y > 0 when relu).  partial[plane * 2 + {0, 1}]
+template <bool VEC, int MODE>
+__global__ __launch_bounds__(256) void bnp_small_reduce_kernel(const float* __restrict__ a, const float* __restrict__ x, const float* __restrict__ y,
+                                                               const float* __restrict__ mean, const float* __restrict__ invstd, size_t P, int C, int S,
+                                                               int lpp, int lg, int relu, double* __restrict__ partial) {
+    M3T_SMALL_PROLOGUE
+    float s = 0.f, t = 0.f;
+    if (live) {
+        float mu = 0.f, is = 1.f;
+        if (MODE == 1) { const int c = (int)(plane % (size_t)C); mu = mean[c]; is = invstd[c]; }
+        for (int i = sub * E; i < S; i += lpp * E) {
+            float v[4], xv[4], yv[4];
+            if (VEC) {
+                const float4 q = *reinterpret_cast<const float4*>(a + base + i);
+                v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+                if (MODE == 1) {
+                    const float4 r = *reinterpret_cast<const float4*>(x + base + i);
+                    xv[0] = r.x; xv[1] = r.y; xv[2] = r.z; xv[3] = r.w;
+                    if (relu) { const float4 w = *reinterpret_cast<const float4*>(y + base + i); yv[0] = w.x; yv[1] = w.y; yv[2] = w.z; yv[3] = w.w; }
+                }
+            } else {
+                v[0] = a[base + i];
+                if (MODE == 1) { xv[0] = x[base + i]; if (relu) yv[0] = y[base + i]; }
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                if (MODE == 0) { s += v[e]; t += v[e] * v[e]; }
+                else {
+                    float g = v[e];
+                    if (relu && !(yv[e] > 0.f)) g = 0.f;
+                    s += g; t += g * ((xv[e] - mu) * is);
+                }
+            }
+        }
+    }
+    seg_sum2(s, t, lpp);
+    if (live && sub == 0) { partial[plane * 2] = (double)s; partial[plane * 2 + 1] = (double)t; }
+}
+
+// MODE 0: y = [relu]((x - mean) invstd gamma + beta);  MODE 1: dx (training: gamma invstd (g - k1 - xhat k2), eval: g gamma invstd)
+template <bool VEC, int MODE>
+__global__ __launch_bounds__(256) void bnp_small_map_kernel(const float* __restrict__ a, const float* __restrict__ x, const float* __restrict__ y,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, const float* __restrict__ sums, float* __restrict__ out,
+                                                            size_t P, int C, int S, int lpp, int lg, float inv_count, int training, int relu) {
+    M3T_SMALL_PROLOGUE
+    if (!live) return;
+    const int c = (int)(plane % (size_t)C);
+    const float mu = mean[c], is = invstd[c], w = (gamma ? gamma[c] : 1.f) * is, b = (MODE == 0 && beta) ? beta[c] : 0.f;
+    const float k1 = (MODE == 1 && training) ? sums[c] * inv_count : 0.f, k2 = (MODE == 1 && training) ? sums[C + c] * inv_count : 0.f;
+    for (int i = sub * E; i < S; i += lpp * E) {
+        float v[4], xv[4], yv[4], o[4];
+        if (VEC) {
+            const float4 q = *reinterpret_cast<const float4*>(a + base + i);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+            if (MODE == 1) {
+                const float4 r = *reinterpret_cast<const float4*>(x + base + i);
+                xv[0] = r.x; xv[1] = r.y; xv[2] = r.z; xv[3] = r.w;
+                if (relu) { const float4 u = *reinterpret_cast<const float4*>(y + base + i); yv[0] = u.x; yv[1] = u.y; yv[2] = u.z; yv[3] = u.w; }
+            }
+        } else {
+            v[0] = a[base + i];
+            if (MODE == 1) { xv[0] = x[base + i]; if (relu) yv[0] = y[base + i]; }
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if (MODE == 0) {
+                const float r = (v[e] - mu) * w + b;
+                o[e] = relu ? fmaxf(r, 0.f) : r;
+            } else {
+                float g = v[e];
+                if (relu && !(yv[e] > 0.f)) g = 0.f;
+                o[e] = training ? w * (g - k1 - ((xv[e] - mu) * is) * k2) : g * w;
+            }
+        }
+        if (VEC) *reinterpret_cast<float4*>(out + base + i) = make_float4(o[0], o[1], o[2], o[3]);
+        else out[base + i] = o[0];
+    }
+}
+
+static int pl_chunks(int S) { return S <= PL_SMALL ? 1 : cdiv(S, PL_CHUNK); }
 
 }  // namespace
 
@@ -331,11 +436,19 @@ extern "C" int m3t_bn_planes_fwd(const float* x, int N, int C, int S, const floa
     const int nch = pl_chunks(S);
     const bool vec = S % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0;
     const dim3 grid((unsigned)((size_t)N * C), nch);
+    const bool small = S <= PL_SMALL;
+    const size_t P = (size_t)N * C;
+    const SmallMap sm = small_map(S, vec);
+    const unsigned sgrid = (unsigned)((P + (size_t)4 * sm.ppw - 1) / ((size_t)4 * sm.ppw));
     if (training) {
         if ((size_t)N * S < 2) return M3T_EINVAL;      // torch: "Expected more than 1 value per channel when training"
         if (!ws || ws_bytes < m3t_bn_planes_ws_bytes(N, C, S) || ((uintptr_t)ws % 8) != 0) return M3T_EINVAL;
         double* partial = reinterpret_cast<double*>(ws);
-        if (vec) bnp_stats_partial_kernel<true><<<grid, 256, 0, s>>>(x, S, nch, partial);
+        if (small) {
+            if (vec) bnp_small_reduce_kernel<true, 0><<<sgrid, 256, 0, s>>>(x, nullptr, nullptr, nullptr, nullptr, P, C, S, sm.lpp, sm.lg, 0, partial);
+            else bnp_small_reduce_kernel<false, 0><<<sgrid, 256, 0, s>>>(x, nullptr, nullptr, nullptr, nullptr, P, C, S, sm.lpp, sm.lg, 0, partial);
+        }
+        else if (vec) bnp_stats_partial_kernel<true><<<grid, 256, 0, s>>>(x, S, nch, partial);
         else bnp_stats_partial_kernel<false><<<grid, 256, 0, s>>>(x, S, nch, partial);
         M3T_LAUNCH_CHECK();
         bnp_final_kernel<<<C, 64, 0, s>>>(partial, N, C, nch, (double)N * S, 0, eps, momentum, run_mean, run_var, save_mean, save_invstd, nullptr, nullptr);
@@ -344,7 +457,11 @@ extern "C" int m3t_bn_planes_fwd(const float* x, int N, int C, int S, const floa
         bn_eval_stats_kernel<<<cdiv(C, 256), 256, 0, s>>>(run_mean, run_var, C, eps, save_mean, save_invstd);
         M3T_LAUNCH_CHECK();
     }
-    if (vec) bnp_apply_kernel<true><<<grid, 256, 0, s>>>(x, gamma, beta, save_mean, save_invstd, y, C, S, relu);
+    if (small) {
+        if (vec) bnp_small_map_kernel<true, 0><<<sgrid, 256, 0, s>>>(x, nullptr, nullptr, gamma, beta, save_mean, save_invstd, nullptr, y, P, C, S, sm.lpp, sm.lg, 0.f, training, relu);
+        else bnp_small_map_kernel<false, 0><<<sgrid, 256, 0, s>>>(x, nullptr, nullptr, gamma, beta, save_mean, save_invstd, nullptr, y, P, C, S, sm.lpp, sm.lg, 0.f, training, relu);
+    }
+    else if (vec) bnp_apply_kernel<true><<<grid, 256, 0, s>>>(x, gamma, beta, save_mean, save_invstd, y, C, S, relu);
     else bnp_apply_kernel<false><<<grid, 256, 0, s>>>(x, gamma, beta, save_mean, save_invstd, y, C, S, relu);
     M3T_LAUNCH_CHECK();
     return 0;
@@ -360,15 +477,27 @@ extern "C" int m3t_bn_planes_bwd(const float* dy, const float* x, const float* y
     const int nch = pl_chunks(S);
     const bool vec = S % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)dx % 16) == 0 && (!relu || ((uintptr_t)y % 16) == 0);
     const dim3 grid((unsigned)((size_t)N * C), nch);
+    const bool small = S <= PL_SMALL;
+    const size_t P = (size_t)N * C;
+    const SmallMap sm = small_map(S, vec);
+    const unsigned sgrid = (unsigned)((P + (size_t)4 * sm.ppw - 1) / ((size_t)4 * sm.ppw));
     double* partial = reinterpret_cast<double*>(ws);
     float* sums = reinterpret_cast<float*>(partial + (size_t)N * C * nch * 2);
-    if (vec) bnp_bwd_partial_kernel<true><<<grid, 256, 0, s>>>(dy, x, y, save_mean, save_invstd, C, S, nch, relu, partial);
+    if (small) {
+        if (vec) bnp_small_reduce_kernel<true, 1><<<sgrid, 256, 0, s>>>(dy, x, y, save_mean, save_invstd, P, C, S, sm.lpp, sm.lg, relu, partial);
+        else bnp_small_reduce_kernel<false, 1><<<sgrid, 256, 0, s>>>(dy, x, y, save_mean, save_invstd, P, C, S, sm.lpp, sm.lg, relu, partial);
+    }
+    else if (vec) bnp_bwd_partial_kernel<true><<<grid, 256, 0, s>>>(dy, x, y, save_mean, save_invstd, C, S, nch, relu, partial);
     else bnp_bwd_partial_kernel<false><<<grid, 256, 0, s>>>(dy, x, y, save_mean, save_invstd, C, S, nch, relu, partial);
     M3T_LAUNCH_CHECK();
     bnp_final_kernel<<<C, 64, 0, s>>>(partial, N, C, nch, (double)N * S, 1, 0.f, 0.f, nullptr, nullptr, sums, sums + C, dgamma, dbeta);
     M3T_LAUNCH_CHECK();
     const float inv_count = (float)(1.0 / ((double)N * S));
-    if (vec) bnp_bwd_dx_kernel<true><<<grid, 256, 0, s>>>(dy, x, y, gamma, save_mean, save_invstd, sums, dx, C, S, inv_count, training, relu);
+    if (small) {
+        if (vec) bnp_small_map_kernel<true, 1><<<sgrid, 256, 0, s>>>(dy, x, y, gamma, nullptr, save_mean, save_invstd, sums, dx, P, C, S, sm.lpp, sm.lg, inv_count, training, relu);
+        else bnp_small_map_kernel<false, 1><<<sgrid, 256, 0, s>>>(dy, x, y, gamma, nullptr, save_mean, save_invstd, sums, dx, P, C, S, sm.lpp, sm.lg, inv_count, training, relu);
+    }
+    else if (vec) bnp_bwd_dx_kernel<true><<<grid, 256, 0, s>>>(dy, x, y, gamma, save_mean, save_invstd, sums, dx, C, S, inv_count, training, relu);
     else bnp_bwd_dx_kernel<false><<<grid, 256, 0, s>>>(dy, x, y, gamma, save_mean, save_invstd, sums, dx, C, S, inv_count, training, relu);
     M3T_LAUNCH_CHECK();
     return 0;

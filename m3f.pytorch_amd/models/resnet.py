@@ -1,14 +1,36 @@
 """models.resnet -- per-frame ResNet-18/34 feature extractor with optional CBAM gating.
 
 API/state-dict compatible with the reference's models/resnet.py:18-124 (`BasicBlock`,
-`ResNet`, v1) and :127-251 (`BasicBlockV2`, `ResNetV2`).  The dense 2-D convolutions and
-BatchNorm2d stay on PyTorch-ROCm (MIOpen) ops -- SURVEY.md section 2.2: north_star names only the
-gating / TCN / GRU / fusion kernels as hand-written -- while every CBAM gate inside the
-blocks runs in the HIP library (models.cbam).
+`ResNet`, v1) and :127-251 (`BasicBlockV2`, `ResNetV2`).  The dense 2-D convolutions stay on
+PyTorch-ROCm (MIOpen) ops -- SURVEY.md section 2.2: north_star names only the gating / TCN / GRU /
+fusion kernels as hand-written -- while every CBAM gate inside the blocks (models.cbam) and,
+since round 4, BatchNorm2d with the ReLU behind it (PlaneBatchNorm2d) run in the HIP library.
 """
+import torch
 import torch.nn as nn
 
+from m3t import ops
 from .cbam import CBAM
+
+
+class PlaneBatchNorm2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d (same parameters, buffers, state_dict keys) on the HIP channel-plane kernels (m3t.ops.bn_planes, csrc/bn.hip: the
+    per-frame ResNet's maps are 32 768 ... 262 144 planes of 784 ... 16 floats), with the ReLU that follows it fused in when
+    `fuse_relu` (no pass over the activation of its own, forward or backward).  Other inputs (CPU, other dtypes) take the stock op."""
+
+    def __init__(self, num_features, fuse_relu=False, **kw):
+        super().__init__(num_features, **kw)
+        self.fuse_relu = fuse_relu
+
+    def forward(self, x):
+        if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and self.affine and self.track_running_stats
+                and self.momentum is not None):
+            if self.training:
+                self.num_batches_tracked.add_(1)
+            return ops.bn_planes(x, self.weight, self.bias, self.running_mean, self.running_var, self.training, self.momentum,
+                                 self.eps, self.fuse_relu)
+        y = super().forward(x)
+        return torch.relu(y) if self.fuse_relu else y
 
 
 def conv3x3(in_planes, out_planes, stride=1):
@@ -26,15 +48,15 @@ class BasicBlock(nn.Module):
 
     def __init__(self, inplanes, planes, stride=1, downsample=None, use_cbam=False):
         super().__init__()
-        self.conv1, self.bn1 = conv3x3(inplanes, planes, stride), nn.BatchNorm2d(planes)
+        self.conv1, self.bn1 = conv3x3(inplanes, planes, stride), PlaneBatchNorm2d(planes, fuse_relu=True)
         self.relu = nn.ReLU(inplace=True)
-        self.conv2, self.bn2 = conv3x3(planes, planes), nn.BatchNorm2d(planes)
+        self.conv2, self.bn2 = conv3x3(planes, planes), PlaneBatchNorm2d(planes)
         self.downsample, self.stride = downsample, stride
         self.cbam = CBAM(planes) if use_cbam else None
 
     def forward(self, x):
         shortcut = x if self.downsample is None else self.downsample(x)
-        y = self.bn2(self.conv2(self.relu(self.bn1(self.conv1(x)))))
+        y = self.bn2(self.conv2(self.bn1(self.conv1(x))))            # (bn1 applies the ReLU)
         if self.cbam is not None:
             y = self.cbam(y)
         return self.relu(y + shortcut)
@@ -49,18 +71,18 @@ class BasicBlockV2(nn.Module):
         super().__init__()
         self.is_first_block_of_first_layer = is_first_block_of_first_layer
         if not is_first_block_of_first_layer:
-            self.bn1 = nn.BatchNorm2d(inplanes)
+            self.bn1 = PlaneBatchNorm2d(inplanes, fuse_relu=True)
         self.conv1 = conv3x3(inplanes, planes, stride)
-        self.bn2 = nn.BatchNorm2d(planes)
+        self.bn2 = PlaneBatchNorm2d(planes, fuse_relu=True)
         self.conv2 = conv3x3(planes, planes)
         self.relu = nn.ReLU(True)
         self.downsample, self.stride = downsample, stride
         self.cbam = CBAM(planes) if use_cbam else None
 
     def forward(self, x):
-        pre = x if self.is_first_block_of_first_layer else self.relu(self.bn1(x))
+        pre = x if self.is_first_block_of_first_layer else self.bn1(x)      # (bn1 / bn2 apply their ReLU)
         shortcut = x if self.downsample is None else self.downsample(pre)
-        y = self.conv2(self.relu(self.bn2(self.conv1(pre))))
+        y = self.conv2(self.bn2(self.conv1(pre)))
         if self.cbam is not None:
             y = self.cbam(y)
         return y + shortcut
@@ -111,7 +133,7 @@ class ResNet(_Trunk):
         down = None
         if stride != 1 or self.inplanes != planes * block.expansion:
             down = nn.Sequential(conv1x1(self.inplanes, planes * block.expansion, stride),
-                                 nn.BatchNorm2d(planes * block.expansion))
+                                 PlaneBatchNorm2d(planes * block.expansion))
         seq = [block(self.inplanes, planes, stride, down, use_cbam=use_cbam)]
         self.inplanes = planes * block.expansion
         seq += [block(self.inplanes, planes, use_cbam=use_cbam) for _ in range(1, blocks)]
@@ -132,8 +154,8 @@ class ResNetV2(_Trunk):
         super().__init__()
         self.agg_mode = agg_mode
         self._stages(block, layers, use_cbam)
-        self.bn5 = nn.BatchNorm2d(self.inplanes)
-        self.relu5 = nn.ReLU(True)
+        self.bn5 = PlaneBatchNorm2d(self.inplanes, fuse_relu=True)
+        self.relu5 = nn.Identity()                                     # (bn5 applies the ReLU; the attribute stays for the module tree)
         self.avgpool = nn.AdaptiveAvgPool2d(1)
         self.fc = nn.Linear(512 * fmap_out_size * fmap_out_size, num_classes)
         _init_trunk(self)

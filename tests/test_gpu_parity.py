@@ -1086,6 +1086,40 @@ def test_batchnorm3d_relu_on_channel_planes(N, C_, T, H, W, training):
     assert sorted(m.state_dict().keys()) == sorted(ref.state_dict().keys())
 
 
+@pytest.mark.parametrize("N,C_,H,W,training,relu", [(37, 64, 28, 28, True, True), (21, 128, 14, 14, True, False), (19, 256, 7, 7, True, True),
+                                                     (70, 512, 4, 4, True, True), (5, 24, 3, 5, False, True), (9, 16, 1, 1, True, False)])
+def test_plane_batchnorm2d_on_the_resnet_maps(N, C_, H, W, training, relu):
+    """models.resnet.PlaneBatchNorm2d (nn.BatchNorm2d [+ ReLU] of the per-frame ResNet, reference models/resnet.py:18-60) on csrc/bn.hip's
+    small-plane kernels: 784 / 196 floats per plane (float4 units, 64 lanes per plane), 49 (scalar units), 16 (four lanes per plane, 16
+    planes per wave), ragged plane counts, eval mode -- against float64 torch on the CPU"""
+    from models.resnet import PlaneBatchNorm2d
+    rs = np.random.RandomState(N + C_ + H)
+    m = PlaneBatchNorm2d(C_, fuse_relu=relu).to(DEV)
+    ref = torch.nn.BatchNorm2d(C_).double()
+    with torch.no_grad():
+        for p_, q_ in ((m.weight, ref.weight), (m.bias, ref.bias), (m.running_mean, ref.running_mean), (m.running_var, ref.running_var)):
+            v = rs.uniform(0.5, 1.5, C_) if p_ is m.weight or p_ is m.running_var else rs.uniform(-0.5, 0.5, C_)
+            p_.copy_(torch.from_numpy(v.astype(np.float32))); q_.copy_(torch.from_numpy(v.astype(np.float32)).double())
+    m.train(training); ref.train(training)
+    xn = draw(rs, (N, C_, H, W))
+    x = dev(xn, True)
+    y = m(x)
+    ctn = draw(rs, tuple(y.shape))
+    (y * dev(ctn)).sum().backward()
+    x64 = torch.tensor(xn, dtype=torch.float64, requires_grad=True)
+    y64 = ref(x64)
+    if relu:
+        y64 = torch.relu(y64)
+    (y64 * torch.tensor(ctn, dtype=torch.float64)).sum().backward()
+    close(y, y64.detach().numpy(), TOL, "y")
+    close(x.grad, x64.grad.numpy(), TOL, "dx")
+    close(m.weight.grad, ref.weight.grad.numpy(), 2e-4, "dgamma")
+    close(m.bias.grad, ref.bias.grad.numpy(), 2e-4, "dbeta")
+    close(m.running_mean, ref.running_mean.numpy(), 1e-5, "running_mean")
+    close(m.running_var, ref.running_var.numpy(), 1e-5, "running_var")
+    assert sorted(m.state_dict().keys()) == sorted(ref.state_dict().keys())
+
+
 def test_c5_affwild_av_golden():
     """Full AffWild2VA audiovisual/attention/v2p_split on raw frames (conv stem on MIOpen)."""
     from models.model import AffWild2VA
