@@ -390,6 +390,14 @@ int m3t_bn_planes_fwd(const float* x, int N, int C, int S, const float* gamma, c
 int m3t_bn_planes_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* save_mean, const float* save_invstd,
                       int N, int C, int S, int training, int relu, float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes,
                       void* stream);
+/* nn.MaxPool3d with a (1, kh, kw) window (stride (1, sh, sw), padding (0, ph, pw), floor mode: the 3-D stems' pooling layers, reference
+ * models/backbone.py:80,86,92,182) as the 2-D pooling of P = N*C*T planes x [P][H][W] -> y [P][Ho][Wo].  win [P][Ho][Wo] (one byte per
+ * output): the winner's position inside its window, dh * kw + dw (kh * kw <= 255), for the backward pass, which is a gather (no atomics:
+ * overlapping windows are deterministic).  Ties: the first maximum in row-major window order; NaN wins (torch's kernel). */
+int m3t_pool_planes_fwd(const float* x, long long P, int H, int W, int kh, int kw, int sh, int sw, int ph, int pw, float* y,
+                        unsigned char* win, void* stream);
+int m3t_pool_planes_bwd(const float* dy, const unsigned char* win, long long P, int H, int W, int kh, int kw, int sh, int sw, int ph, int pw,
+                        float* dx, void* stream);
 /* [B,C,T] <-> [B,T,C] */
 int m3t_bct_to_btc(const float* src, float* dst, int B, int C, int T, void* stream);
 int m3t_btc_to_bct(const float* src, float* dst, int B, int T, int C, void* stream);

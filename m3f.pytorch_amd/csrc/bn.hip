@@ -558,3 +558,82 @@ extern "C" int m3t_bn_rows_bwd(const float* dy, const float* x, const float* y, 
     M3T_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------- spatial max pooling
+// nn.MaxPool3d with a (1, k, k) window (every pooling layer of the 3-D stems, reference models/backbone.py:80,86,92,182) = a 2-D pooling
+// of P = N C T planes [H][W].  Forward keeps the winner's position INSIDE its window as one byte (dh * kw + dw: torch keeps an int64
+// flat index per output); backward is a gather -- every input position asks the <= ceil(k/s)^2 windows that cover it whether it won --
+// so overlapping windows (3 x 3, stride 2) need no atomics and the result does not depend on scheduling.  Ties and NaN as torch's
+// kernel: the first maximum in row-major window order, NaN wins.  One workgroup per plane.
+namespace {
+
+struct PoolGeo { int H, W, Ho, Wo, kh, kw, sh, sw, ph, pw; };
+
+__global__ __launch_bounds__(256) void pool_planes_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ win, PoolGeo g) {
+    const size_t plane = blockIdx.x;
+    const float* xp = x + plane * (size_t)g.H * g.W;
+    const size_t ob = plane * (size_t)g.Ho * g.Wo;
+    for (int o = threadIdx.x; o < g.Ho * g.Wo; o += 256) {
+        const int ho = o / g.Wo, wo = o - ho * g.Wo;
+        const int h0 = ho * g.sh - g.ph, w0 = wo * g.sw - g.pw;
+        // torch's rule (max_pool_forward_nchw): start at -inf with the window's first valid element as winner; an element takes over
+        // if it is greater or NaN
+        float best = -INFINITY;
+        int bi = max(0, -h0) * g.kw + max(0, -w0);
+        for (int dh = max(0, -h0); dh < g.kh && h0 + dh < g.H; ++dh)
+            for (int dw = max(0, -w0); dw < g.kw && w0 + dw < g.W; ++dw) {
+                const float v = xp[(h0 + dh) * g.W + w0 + dw];
+                if (v > best || v != v) { best = v; bi = dh * g.kw + dw; }
+            }
+        y[ob + o] = best;
+        win[ob + o] = (unsigned char)bi;
+    }
+}
+
+__global__ __launch_bounds__(256) void pool_planes_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ win, float* __restrict__ dx,
+                                                              PoolGeo g) {
+    const size_t plane = blockIdx.x;
+    const size_t ob = plane * (size_t)g.Ho * g.Wo;
+    float* dp = dx + plane * (size_t)g.H * g.W;
+    for (int i = threadIdx.x; i < g.H * g.W; i += 256) {
+        const int h = i / g.W, w = i - h * g.W;
+        // windows ho with ho * sh - ph <= h <= ho * sh - ph + kh - 1
+        const int hp = h + g.ph, wp = w + g.pw;
+        const int ho_hi = min(g.Ho - 1, hp / g.sh), wo_hi = min(g.Wo - 1, wp / g.sw);
+        const int ho_lo = max(0, (hp - g.kh + g.sh) / g.sh), wo_lo = max(0, (wp - g.kw + g.sw) / g.sw);      // ceil((hp - kh + 1) / sh), hp - kh + 1 may be < 0
+        float acc = 0.f;
+        for (int ho = (hp - g.kh + 1 <= 0 ? 0 : ho_lo); ho <= ho_hi; ++ho)
+            for (int wo = (wp - g.kw + 1 <= 0 ? 0 : wo_lo); wo <= wo_hi; ++wo) {
+                const int b = win[ob + ho * g.Wo + wo];
+                const int dh = b / g.kw, dw = b - dh * g.kw;
+                if (ho * g.sh - g.ph + dh == h && wo * g.sw - g.pw + dw == w) acc += dy[ob + ho * g.Wo + wo];
+            }
+        dp[i] = acc;
+    }
+}
+
+}  // namespace
+
+extern "C" int m3t_pool_planes_fwd(const float* x, long long P, int H, int W, int kh, int kw, int sh, int sw, int ph, int pw, float* y,
+                                   unsigned char* win, void* stream) {
+    if (P <= 0) return 0;
+    if (!x || !y || !win || H <= 0 || W <= 0 || kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || ph < 0 || pw < 0 || kh * kw > 255 || 2 * ph > kh || 2 * pw > kw ||
+        P > 0x7fffffffll)
+        return M3T_EINVAL;
+    PoolGeo g{H, W, (H + 2 * ph - kh) / sh + 1, (W + 2 * pw - kw) / sw + 1, kh, kw, sh, sw, ph, pw};
+    if (g.Ho <= 0 || g.Wo <= 0) return M3T_EINVAL;
+    pool_planes_fwd_kernel<<<(unsigned)P, 256, 0, (hipStream_t)stream>>>(x, y, win, g);
+    M3T_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int m3t_pool_planes_bwd(const float* dy, const unsigned char* win, long long P, int H, int W, int kh, int kw, int sh, int sw, int ph, int pw,
+                                   float* dx, void* stream) {
+    if (P <= 0) return 0;
+    if (!dy || !win || !dx || H <= 0 || W <= 0 || kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || ph < 0 || pw < 0 || kh * kw > 255 || P > 0x7fffffffll) return M3T_EINVAL;
+    PoolGeo g{H, W, (H + 2 * ph - kh) / sh + 1, (W + 2 * pw - kw) / sw + 1, kh, kw, sh, sw, ph, pw};
+    if (g.Ho <= 0 || g.Wo <= 0) return M3T_EINVAL;
+    pool_planes_bwd_kernel<<<(unsigned)P, 256, 0, (hipStream_t)stream>>>(dy, win, dx, g);
+    M3T_LAUNCH_CHECK();
+    return 0;
+}

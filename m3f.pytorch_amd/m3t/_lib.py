@@ -77,6 +77,8 @@ SIGNATURES = {
     "m3t_conv1d_fwd_scaled": [_f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, C.c_float, C.c_ulonglong, _i, _f, _f, _s],
     "m3t_conv1d_wgrad": [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _z, _i, _s],
     "m3t_conv1d_wgrad_scaled": [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _z, _i, _f, _f, _s],
+    "m3t_pool_planes_fwd": [_f, C.c_longlong, _i, _i, _i, _i, _i, _i, _i, _i, _f, C.c_void_p, _s],
+    "m3t_pool_planes_bwd": [_f, C.c_void_p, C.c_longlong, _i, _i, _i, _i, _i, _i, _i, _i, _f, _s],
     "m3t_bn_planes_ws_bytes": [_i, _i, _i],
     "m3t_bn_planes_fwd": [_f, _i, _i, _i, _f, _f, _f, _f, C.c_float, C.c_float, _i, _i, _f, _f, _f, _f, _z, _s],
     "m3t_bn_planes_bwd": [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _z, _s],

@@ -1789,6 +1789,41 @@ def bn_planes(x, gamma, beta, run_mean, run_var, training, momentum, eps, relu=T
     return _BNPlanes.apply(x, gamma, beta, run_mean, run_var, training, momentum, eps, relu)
 
 
+class _PoolPlanes(torch.autograd.Function):
+    """max pooling of [..., H, W] planes with a (kh, kw) window (csrc/bn.hip m3t_pool_planes_*: one byte per output for the winner,
+    gather backward) -- nn.MaxPool3d((1, k, k)) of the 3-D stems (reference models/backbone.py:80,86,92,182)"""
+
+    @staticmethod
+    def forward(ctx, x, k, s, p):
+        x = _req(x.contiguous(), "x")
+        H, W = x.shape[-2], x.shape[-1]
+        P = x.numel() // (H * W)
+        Ho, Wo = (H + 2 * p[0] - k[0]) // s[0] + 1, (W + 2 * p[1] - k[1]) // s[1] + 1
+        y = torch.empty(x.shape[:-2] + (Ho, Wo), dtype=torch.float32, device=x.device)
+        win = torch.empty(x.shape[:-2] + (Ho, Wo), dtype=torch.uint8, device=x.device)
+        rc = lib().m3t_pool_planes_fwd(_p(x), P, H, W, k[0], k[1], s[0], s[1], p[0], p[1], _p(y), C.c_void_p(win.data_ptr()), _stream())
+        _lib.check(rc, "m3t_pool_planes_fwd")
+        ctx.save_for_backward(win)
+        ctx.geo = (tuple(x.shape), k, s, p)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (win,) = ctx.saved_tensors
+        shape, k, s, p = ctx.geo
+        dy = _req(dy.contiguous(), "dy")
+        H, W = shape[-2], shape[-1]
+        dx = torch.empty(shape, dtype=torch.float32, device=dy.device)
+        rc = lib().m3t_pool_planes_bwd(_p(dy), C.c_void_p(win.data_ptr()), dx.numel() // (H * W), H, W, k[0], k[1], s[0], s[1], p[0], p[1],
+                                       _p(dx), _stream())
+        _lib.check(rc, "m3t_pool_planes_bwd")
+        return dx, None, None, None
+
+
+def pool_planes(x, k, s, p):
+    return _PoolPlanes.apply(x, tuple(k), tuple(s), tuple(p))
+
+
 # ----------------------------------------------------------------------------- Conv3d weight gradient
 class _Conv3dGemmWgrad(torch.autograd.Function):
     """Conv3d of the visual stems (reference models/backbone.py:73-103,179-271,327-332): forward and the data

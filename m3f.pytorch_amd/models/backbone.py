@@ -48,15 +48,15 @@ class BatchNorm3dReLU(nn.BatchNorm3d):
 
 class SpatialMaxPool3d(nn.MaxPool3d):
     """nn.MaxPool3d whose window does not span frames (kernel (1, k, k), stride (1, s, s): every pooling layer of the stems, reference
-    backbone.py:80,86,92,182) computed as the 2-D pooling of the [N, C*T, H, W] view: same values and gradients, torch's 2-D kernels
-    instead of its generic 3-D ones (max_pool3d_with_indices forward + backward were 1.3 ms of the 32 ms C5 step).  No parameters."""
+    backbone.py:80,86,92,182) as a pooling of the N C T planes on the HIP kernels (m3t.ops.pool_planes: one byte per output remembers
+    the winner, the backward pass is a gather -- torch's 3-D kernels took 1.3 ms of the 32 ms C5 step, its 2-D backward 0.8 ms of the
+    ResNet3D step).  No parameters.  Other configurations and inputs take the stock op."""
 
     def forward(self, x):
         k, s, p, d = (_triple(v) for v in (self.kernel_size, self.stride, self.padding, self.dilation))
-        if x.dim() == 5 and k[0] == 1 and s[0] == 1 and p[0] == 0 and d[0] == 1 and not self.return_indices and x.is_contiguous():
-            N, Cc, T, H, W = x.shape
-            y = nn.functional.max_pool2d(x.view(N, Cc * T, H, W), k[1:], s[1:], p[1:], d[1:], self.ceil_mode)
-            return y.view(N, Cc, T, y.shape[-2], y.shape[-1])
+        if (x.dim() == 5 and x.is_cuda and x.dtype == torch.float32 and k[0] == 1 and s[0] == 1 and p[0] == 0 and d == (1, 1, 1)
+                and not self.return_indices and not self.ceil_mode and k[1] * k[2] <= 255):
+            return ops.pool_planes(x, k[1:], s[1:], p[1:])
         return super().forward(x)
 
 

@@ -1120,6 +1120,30 @@ def test_plane_batchnorm2d_on_the_resnet_maps(N, C_, H, W, training, relu):
     assert sorted(m.state_dict().keys()) == sorted(ref.state_dict().keys())
 
 
+@pytest.mark.parametrize("shape,k,s,p", [((2, 5, 3, 55, 55), (1, 2, 2), (1, 2, 2), (0, 0, 0)), ((2, 4, 3, 56, 56), (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+                                         ((1, 3, 2, 7, 9), (1, 3, 2), (1, 1, 2), (0, 1, 0)), ((3, 2, 1, 4, 4), (1, 2, 2), (1, 2, 2), (0, 0, 0))])
+def test_spatial_max_pooling_of_the_stems(shape, k, s, p):
+    """models.backbone.SpatialMaxPool3d (nn.MaxPool3d((1, k, k)) of the 3-D stems, reference models/backbone.py:80,86,92,182) on
+    csrc/bn.hip's plane kernels: odd maps whose last row / column no window covers, overlapping padded windows (gather backward),
+    post-ReLU inputs full of ties, NaN -- values and gradients equal to torch's own kernels exactly"""
+    from models.backbone import SpatialMaxPool3d
+    rs = np.random.RandomState(sum(shape))
+    xn = np.maximum(draw(rs, shape), 0.0).astype(np.float32)          # many exact zeros: ties
+    xn[0, 0, 0, 1, 2] = np.nan
+    m = SpatialMaxPool3d(k, s, p)
+    x1, x2 = dev(xn, True), dev(xn, True)
+    y1 = m(x1)
+    y2 = torch.nn.functional.max_pool3d(x2, k, s, p)
+    ct = dev(draw(rs, tuple(y2.shape)))
+    y1.backward(ct); y2.backward(ct)
+    assert y1.shape == y2.shape and torch.equal(torch.nan_to_num(y1, nan=-7.0), torch.nan_to_num(y2, nan=-7.0))
+    # a position that won several overlapping windows sums their gradients: same terms, another order than torch's atomics
+    d = (x1.grad - x2.grad).abs()
+    assert float(d.max()) <= 1e-6, (float(d.max()), int((d > 1e-6).sum()))
+    if k[1] <= s[1] and k[2] <= s[2]:
+        assert torch.equal(x1.grad, x2.grad)
+
+
 def test_c5_affwild_av_golden():
     """Full AffWild2VA audiovisual/attention/v2p_split on raw frames (conv stem on MIOpen)."""
     from models.model import AffWild2VA
