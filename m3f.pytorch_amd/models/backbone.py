@@ -2,9 +2,10 @@
 
 API/state-dict compatible with the reference's models/backbone.py for the classes on the
 north_star path: `VA_3DVGGM` (:62-161), `VA_3DVGGM_Split` (:164-311, the default
-`--backbone v2p_split`) and `VA_3DResNet` (:314-372).  The 3-D conv stems stay on
-PyTorch-ROCm (MIOpen) ops; the temporal back-ends (BiGRU stacks, TCN) and the
-CBAM gates inside the ResNet run in the HIP library.  `VA_3DDenseNet` / `VA_VGGFace` are
+`--backbone v2p_split`) and `VA_3DResNet` (:314-372).  The 3-D stems' convolutions (forward and
+data gradient) stay on PyTorch-ROCm (MIOpen) ops; their weight gradient,
+BatchNorm3d + ReLU and spatial pooling (round 4), the temporal back-ends (BiGRU stacks, TCN) and the
+CBAM gates / BatchNorm2d inside the ResNet run in the HIP library.  `VA_3DDenseNet` / `VA_VGGFace` are
 out of scope (not reachable from AffWild2VA.forward).
 """
 import math
