@@ -612,6 +612,36 @@ __global__ __launch_bounds__(256) void pool_planes_bwd_kernel(const float* __res
     }
 }
 
+// windows that do not overlap (k <= s, no padding: the VGG stem's 2 x 2 / 2 poolings): a thread per OUTPUT writes its window's cells
+// (dy to the winner, zero to the rest) -- one division per window instead of three per cell -- and the cells no window covers (the
+// last row / column of an odd map) are zeroed separately
+__global__ __launch_bounds__(256) void pool_planes_bwd_disjoint_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ win,
+                                                                       float* __restrict__ dx, PoolGeo g) {
+    const size_t plane = blockIdx.x;
+    const size_t ob = plane * (size_t)g.Ho * g.Wo;
+    float* dp = dx + plane * (size_t)g.H * g.W;
+    for (int o = threadIdx.x; o < g.Ho * g.Wo; o += 256) {
+        const int ho = o / g.Wo, wo = o - ho * g.Wo;
+        const float gv = dy[ob + o];
+        const int b = win[ob + o];
+        float* cell = dp + (ho * g.sh) * g.W + wo * g.sw;
+        int idx = 0;
+        for (int dh = 0; dh < g.sh; ++dh)
+            for (int dw = 0; dw < g.sw; ++dw, ++idx) {
+                // cells of the stride box beyond the window (k < s) belong to no window: zero
+                const bool inwin = dh < g.kh && dw < g.kw;
+                if ((ho * g.sh + dh) < g.H && (wo * g.sw + dw) < g.W) cell[dh * g.W + dw] = (inwin && b == dh * g.kw + dw) ? gv : 0.f;
+            }
+    }
+    const int hc = g.Ho * g.sh, wc = g.Wo * g.sw;                  // covered by stride boxes: [0, hc) x [0, wc)
+    for (int i = threadIdx.x; i < (g.H - hc) * g.W; i += 256) dp[hc * g.W + i] = 0.f;
+    if (wc < g.W)
+        for (int i = threadIdx.x; i < hc * (g.W - wc); i += 256) {
+            const int h = i / (g.W - wc), w = wc + i - h * (g.W - wc);
+            dp[h * g.W + w] = 0.f;
+        }
+}
+
 }  // namespace
 
 extern "C" int m3t_pool_planes_fwd(const float* x, long long P, int H, int W, int kh, int kw, int sh, int sw, int ph, int pw, float* y,
@@ -633,7 +663,8 @@ extern "C" int m3t_pool_planes_bwd(const float* dy, const unsigned char* win, lo
     if (!dy || !win || !dx || H <= 0 || W <= 0 || kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || ph < 0 || pw < 0 || kh * kw > 255 || P > 0x7fffffffll) return M3T_EINVAL;
     PoolGeo g{H, W, (H + 2 * ph - kh) / sh + 1, (W + 2 * pw - kw) / sw + 1, kh, kw, sh, sw, ph, pw};
     if (g.Ho <= 0 || g.Wo <= 0) return M3T_EINVAL;
-    pool_planes_bwd_kernel<<<(unsigned)P, 256, 0, (hipStream_t)stream>>>(dy, win, dx, g);
+    if (kh <= sh && kw <= sw && ph == 0 && pw == 0) pool_planes_bwd_disjoint_kernel<<<(unsigned)P, 256, 0, (hipStream_t)stream>>>(dy, win, dx, g);
+    else pool_planes_bwd_kernel<<<(unsigned)P, 256, 0, (hipStream_t)stream>>>(dy, win, dx, g);
     M3T_LAUNCH_CHECK();
     return 0;
 }
