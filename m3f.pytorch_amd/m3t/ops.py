@@ -1785,6 +1785,11 @@ class _BNPlanes(torch.autograd.Function):
         return dx, (g[0] if gamma is not None else None), (g[1] if gamma is not None else None), None, None, None, None, None, None
 
 
+# M3T_BN_PLANES=0: BatchNorm3d / BatchNorm2d (+ReLU) of the stems and the per-frame ResNet on the stock (MIOpen) ops instead of csrc/bn.hip's
+# channel-plane kernels (A/B runs; README switch table)
+BN_PLANES = [os.environ.get("M3T_BN_PLANES", "1") != "0"]
+
+
 def bn_planes(x, gamma, beta, run_mean, run_var, training, momentum, eps, relu=True):
     return _BNPlanes.apply(x, gamma, beta, run_mean, run_var, training, momentum, eps, relu)
 

@@ -38,7 +38,7 @@ class BatchNorm3dReLU(nn.BatchNorm3d):
     nn.Sequential it takes the BatchNorm3d slot and an nn.Identity the ReLU's, so every index -- and every checkpoint key -- stays."""
 
     def forward(self, x):
-        if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and self.affine and self.track_running_stats
+        if (ops.BN_PLANES[0] and x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and self.affine and self.track_running_stats
                 and self.momentum is not None):
             if self.training:
                 self.num_batches_tracked.add_(1)

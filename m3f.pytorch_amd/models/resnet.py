@@ -23,7 +23,7 @@ class PlaneBatchNorm2d(nn.BatchNorm2d):
         self.fuse_relu = fuse_relu
 
     def forward(self, x):
-        if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and self.affine and self.track_running_stats
+        if (ops.BN_PLANES[0] and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and self.affine and self.track_running_stats
                 and self.momentum is not None):
             if self.training:
                 self.num_batches_tracked.add_(1)

@@ -1414,17 +1414,20 @@ def test_solo_scans_h128_through_the_c_abi(B, T, bf16):
     ops.poll_scan_error()
 
 
-@pytest.mark.parametrize("switch", ["M3T_CONV_X6", "M3T_CBAM_FUSED", "M3T_CBAM_RESIDENT"])
+@pytest.mark.parametrize("switch", ["M3T_CONV_X6", "M3T_CBAM_FUSED", "M3T_CBAM_RESIDENT", "M3T_BN_PLANES"])
 def test_conv_and_cbam_kernel_switches(switch):
     """README's switch table, the entries the C3 step does not exercise (read once per process, hence a child):
     M3T_CONV_X6=0 -- the TCN / tcn_simple convolutions on the fp32-MFMA kernel instead of the bf16x6 implicit GEMM;
     M3T_CBAM_FUSED=0 -- CBAM as channel gate + spatial gate instead of the fused operator;
     M3T_CBAM_RESIDENT=0 -- small frames (7 x 7, 4 x 4 ...) on the fused operator's general kernels F1 / B2 instead of the
-    frame-resident F1L / B2L.  Same arithmetic: the convolution, TemporalBlock, CBAM and ResNet parity tests must pass unchanged."""
+    frame-resident F1L / B2L;
+    M3T_BN_PLANES=0 -- BatchNorm3d / BatchNorm2d (+ReLU) of the stems and the per-frame ResNet on the stock ops instead of the channel-plane
+    kernels.  Same arithmetic: the convolution, TemporalBlock, CBAM, ResNet and C5 parity tests must pass unchanged."""
     import subprocess
     import sys
     env = dict(os.environ, M3T_SCAN_LOCK="0", **{switch: "0"})
-    pick = "conv1d_on_the_bf16x6_pipe or tcn_train_mode or tcn_golden" if switch == "M3T_CONV_X6" else "cbam_golden or resnet_cbam or cbam_stage"
+    pick = {"M3T_CONV_X6": "conv1d_on_the_bf16x6_pipe or tcn_train_mode or tcn_golden",
+            "M3T_BN_PLANES": "resnet_cbam or c5_resnet3d or c5_affwild_av_t16"}.get(switch, "cbam_golden or resnet_cbam or cbam_stage")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k", pick], env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-1500:]
