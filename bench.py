@@ -607,8 +607,8 @@ def worker(args):
             breakdown[name].pop("us_per_time_step")
             breakdown[name].update({"bound": "hbm", "algorithmic_bytes_per_step": int(k["bytes"] / timed_steps), "GBps": round(gbps, 1),
                                     "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBS, 4)})
-    if kern:
-        name = max((n for n in kern if kern[n]["flops"] > 0), key=lambda n: kern[n]["ms"])
+    name = max((n for n in kern if kern[n]["flops"] > 0), key=lambda n: kern[n]["ms"], default=None)      # (only HBM-bound kernels profiled: no roofline block)
+    if name is not None:
         k = kern[name]
         achieved = k["flops"] / (k["ms"] * 1e-3) / 1e12
         traffic, traffic_by_kernel, mfma_util, pmc_source, traffic_ratio = None, None, None, None, None

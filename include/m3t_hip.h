@@ -89,7 +89,7 @@ int m3t_im2col3d(const float* x, int N, int Ci, int T, int H, int W, int kt, int
 /* Magnitude slots from the PRODUCER (fp16x3 mode, see m3t_sgemm_scaled): the NEXT m3t_conv1d_fwd(_scaled) / m3t_mask_pos / m3t_mask_pos_drop /
  * m3t_weight_norm_fwd / m3t_bct_to_btc call of the calling thread raises `slot` (8 bytes, zero-initialised by the caller, epoch 0) to the bits of max |x| over
  * its output (y / out / w_t) -- in the same kernel, one 64-bit atomic max per workgroup -- so that the contraction that consumes the output
- * needs no measuring launch.  Consumed by that call (also when it fails).  Returns 0. */
+ * needs no measuring launch.  Consumed by that call (also when it fails); slot == NULL clears a pending one.  Returns 0. */
 int m3t_amax_out(unsigned long long* slot);
 
 /* library / device info: returns the ABI version; arch string copied to `arch` if non-null */
@@ -126,6 +126,19 @@ int m3t_sgemm_scaled(int transA, int transB, int M, int N, int K,
                      int seg_len, int seg_stride, int a_off, int b_off,
                      float* ws, size_t ws_bytes, int flags,
                      const unsigned long long* amax_a, const unsigned long long* amax_b, void* stream);
+
+/* The same contraction (transA = 0) over a TIME WINDOW of batch-major sequence tensors: A is a [n_seg, win_stride, *] tensor of which only
+ * the frames [win_off, win_off + win_len) of every clip take part -- row m of the product reads storage row
+ * (m / win_len) * win_stride + m % win_len + win_off of A and writes the same storage row of C:
+ *   C[rows of the window, 0:N] (ldc) = act( A[rows of the window, 0:K] (lda) * op(B)[K,N] + bias ) (+ C if accumulate)
+ * Used by the direction-split, time-chunked hand-offs between a BiGRU scan and the projections / data gradients on either side of it
+ * (reference models/rnn.py:17,75: layer l+1's input projection is out_fwd W_ih[:, :H]^T + out_rev W_ih[:, H:]^T, and each half is final for the
+ * frames its direction's scan has passed: m3t_gru_scan_progress).  Only the 16-bit-term tile kernel has this form: n_seg * win_len % 128 == 0,
+ * N % 64 == 0, K % 32 == 0, 16-B aligned operands with ld % 4 == 0, flags without M3T_GEMM_BF16 / _HIGH; else M3T_EINVAL.  One launch, no
+ * split-K.  amax_a / amax_b as m3t_sgemm_scaled. */
+int m3t_sgemm_window(int transB, int n_seg, int win_len, int win_stride, int win_off, int N, int K,
+                     const float* A, int lda, const float* B, int ldb, float* C, int ldc, const float* bias,
+                     int act, int accumulate, int flags, const unsigned long long* amax_a, const unsigned long long* amax_b, void* stream);
 
 /* slots[i] = max(slots[i], bits of max |x| over x[i] = [rows[i] x cols[i]] fp32 with leading dimension ld[i]) for n <= 16 tensors in
  * ONE launch (cols % 4 == 0, ld % 4 == 0, 16-B aligned).  The caller zero-initialises a slot before its first use. */
@@ -253,6 +266,29 @@ int m3t_gru_persist_owner(void);
  * memory was reallocated or written by anything else; NULL = every arena).  Both return 0. */
 int m3t_gru_scan_arena(void* arena, size_t bytes);
 int m3t_gru_scan_arena_reset(void* arena);
+/* PROGRESS MARKS (round 5): consumers of a persistent scan's results need not wait for the launch to end.  Layer l+1's input projection
+ * (reference models/rnn.py:17,75) is out_fwd W_ih[:, :H]^T + out_rev W_ih[:, H:]^T: each half needs ONE direction's scan, and the frames
+ * that scan has passed are final.  m3t_gru_scan_progress(counters, n_marks, time_bounds, need): the NEXT m3t_gru_scan_fwd / _bwd call of the
+ * calling thread publishes its progress through `counters` (two 32-bit device words, 8-B aligned, zero-initialised ONCE by the caller and
+ * from then on written by scan launches only): counters[0] counts for the scans of the call that walk time upwards (forward pass:
+ * reverse = 0; backward pass: reverse = 1), counters[1] for those that walk it downwards.  time_bounds[0 .. n_marks) (n_marks <= 3,
+ * ascending, 4 <= tb, tb <= T - 4, at least 4 apart) cut [0, T) into n_marks + 1 windows.  Each workgroup adds 1 to its counter once its
+ * results -- out / gates (forward), dgx / dgh and the per-window magnitude slots (backward) -- of every frame on the finished side of a bound
+ * are in memory and visible device-wide.  On return need[k] (k < n_marks) is the value counters[0] reaches when the upward scans have
+ * finished frames [0, time_bounds[k]); need[n_marks + k] the value counters[1] reaches when the downward scans have finished frames
+ * [time_bounds[n_marks - 1 - k], T).  A consumer stream waits with m3t_stream_wait_progress (a one-lane gate kernel that polls the word;
+ * what follows it starts behind a kernel boundary and reads the written-back data); the last window of each direction is final when the
+ * scan launch ends (ordinary stream order / events).  Backward calls with marks armed write their magnitude slots as an ARRAY:
+ * desc.amax[0] the whole scan (final at the end of the launch), desc.amax[1 + w] the w-th window IN THE ORDER THE SCAN WALKS THEM.
+ * Only the launches whose kernels carry the marks accept an armed call (m3t_gru_scan_progress_ok: the fp16x3 persistent forward kernels,
+ * the wide producer-split backward kernel); any other path returns M3T_EINVAL rather than leave consumers waiting.  Consumed by that call
+ * (also when it fails); counters == NULL disarms.  m3t_gru_scan_progress_reset(counters): forget the library's count of what it has asked
+ * of `counters` (after the caller re-zeroed or freed them; NULL = all).  Every wait is bounded (M3T_SCAN_SPIN_LIMIT): a gate that gives
+ * up raises the sticky scan error. */
+int m3t_gru_scan_progress(unsigned* counters, int n_marks, const int* time_bounds, unsigned* need);
+int m3t_gru_scan_progress_reset(unsigned* counters);
+int m3t_gru_scan_progress_ok(int n_scans, int H, int B, int T, int flags, int backward);
+int m3t_stream_wait_progress(const unsigned* counter, unsigned need, void* stream);
 /* Ordering between scans on different streams without holding back their preparation: the NEXT m3t_gru_scan_fwd /
  * m3t_gru_scan_bwd call of the calling thread makes its stream wait for `event` (a hipEvent_t) right before it launches
  * its scan kernel(s); the weight re-layout kernels and memsets it issues first run as soon as the stream allows.  Used

@@ -719,7 +719,9 @@ __global__ __launch_bounds__(256) void pool_planes_bwd_disjoint_kernel(const flo
                 if ((ho * g.sh + dh) < g.H && (wo * g.sw + dw) < g.W) cell[dh * g.W + dw] = (inwin && b == dh * g.kw + dw) ? gv : 0.f;
             }
     }
-    const int hc = g.Ho * g.sh, wc = g.Wo * g.sw;                  // covered by stride boxes: [0, hc) x [0, wc)
+    // covered by stride boxes: [0, hc) x [0, wc), clipped to the plane (k < s: the last box may reach past the map -- ADVICE r4: the tail
+    // loops below then wrote rows h >= H, i.e. the next plane)
+    const int hc = min(g.Ho * g.sh, g.H), wc = min(g.Wo * g.sw, g.W);
     for (int i = threadIdx.x; i < (g.H - hc) * g.W; i += 256) dp[hc * g.W + i] = 0.f;
     if (wc < g.W)
         for (int i = threadIdx.x; i < hc * (g.W - wc); i += 256) {

@@ -42,6 +42,9 @@ struct X6Params {
     unsigned long long* cv_amax;         // CONV: magnitude slot raised to max |y| by the epilogue (m3t_amax_out), or nullptr
     const unsigned long long* amax_a;    // NS = 4 (fp16x3): low words = the bits of max |A|, max |B| (magnitude slots, common.h)
     const unsigned long long* amax_b;
+    // MW kernels (m3t_sgemm_window): row m of A (TA == 0) and of C lives in storage row (m / mw_len) * mw_stride + m % mw_len + mw_off --
+    // a TIME WINDOW [mw_off, mw_off + mw_len) of every clip of a [B, T, C] tensor (mw_stride = T)
+    int mw_len, mw_stride, mw_off;
 };
 
 __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
@@ -156,7 +159,8 @@ __device__ __forceinline__ void mc_store(unsigned char* __restrict__ S, const fl
 // residual add + ReLU (the TemporalBlock's tail) fused.
 // XNT = 64: a 128 x 64 output tile (each wave 64 x 32) for grids that would leave most CUs with a single 128 x 128 workgroup
 // (N = 512 at M = 9600: 300 tiles for 768 slots) -- twice the workgroups, the B operand staged for 64 rows only.
-template <int TA, int TB, bool SEG, int NS, bool CONV = false, int XNT = 128>
+// MW (TA == 0, no CONV / SEG): A's and C's rows go through the window map of X6Params (a 128-entry table in LDS: one division per thread)
+template <int TA, int TB, bool SEG, int NS, bool CONV = false, int XNT = 128, bool MW = false>
 __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p) {
     constexpr int NJ = XNT / 64;                     // 32-column MFMA tiles per wave along N
     constexpr int BR = XNT / 32;                     // rows per thread of a K-contiguous B tile
@@ -176,6 +180,14 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p) {
     const int k_begin = blockIdx.z * p.kchunk;
     const int k_end = min(p.K, k_begin + p.kchunk);
     const int ntiles = (k_end - k_begin) / XK;
+    __shared__ int rowmap[MW ? XM : 1];              // MW: storage row of the tile's row i
+    if (MW) {
+        if (tid < XM) {
+            const int m = bm + tid, q = m / p.mw_len;
+            rowmap[tid] = q * p.mw_stride + (m - q * p.mw_len) + p.mw_off;
+        }
+        __syncthreads();
+    }
 
     f32x16 acc[2][NJ];
 #pragma unroll
@@ -194,8 +206,13 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p) {
     // per-thread operand pointers
     const float* pa; const float* pb;
     size_t a_step, b_step, a_krow = 0, b_krow = 0;
+    const float* paw[MW ? 4 : 1];                    // MW: one pointer per row of this thread (the rows are not equidistant)
     if (TA == 0) { pa = p.A + (size_t)(bm + (tid >> 3)) * p.lda + k_begin + (tid & 7) * 4; a_step = XK; }
     else { pa = p.A + (size_t)(k_begin + (tid >> 5) * 4) * p.lda + bm + (tid & 31) * 4; a_step = (size_t)XK * p.lda; a_krow = p.lda; }
+    if (MW) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) paw[i] = p.A + (size_t)rowmap[(tid >> 3) + 32 * i] * p.lda + k_begin + (tid & 7) * 4;
+    }
     if (TB == 1) { pb = p.B + (size_t)(bn + (tid >> 3)) * p.ldb + k_begin + (tid & 7) * 4; b_step = XK; }
     else { pb = p.B + (size_t)(k_begin + (tid >> 5) * 4) * p.ldb + bn + (tid & 31) * 4; b_step = (size_t)XK * p.ldb; b_krow = p.ldb; }
     // segmented reduction rows (dW_hh): (segment, offset) of this thread's first k row, advanced per tile
@@ -241,7 +258,10 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p) {
             sr += XK;
             while (sr >= p.seg_len) { sr -= p.seg_len; ++sq; }
         } else {
-            if (TA == 0) kc_load(pa, p.lda, ra);
+            if (MW) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { ra[i] = *reinterpret_cast<const float4*>(paw[i]); paw[i] += XK; }
+            } else if (TA == 0) kc_load(pa, p.lda, ra);
             else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) ra[e] = *reinterpret_cast<const float4*>(pa + e * a_krow);
@@ -329,7 +349,7 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p) {
                 if (CONV && p.cv_drop.on && (r & 3) == 0) m3t_drop_mask4(p.cv_drop, (uint32_t)row >> 2, (uint32_t)col, dm);
                 float v = acc[i][j][r];
                 if (NS == 4) v = v * sc_ia * sc_ib;              // (exact: powers of two)
-                float* q = dst + (size_t)row * ldd + col;
+                float* q = dst + (size_t)(MW ? rowmap[row - bm] : row) * ldd + col;
                 if (CONV) {
                     const size_t o = (size_t)row * ldd + col;
                     v += bv;
@@ -370,6 +390,7 @@ int m3t_sgemm_x6_launch(int transA, int transB, int M, int N, int K, const float
     p.cv_T = p.cv_C = p.cv_K = p.cv_dil = p.cv_lead = p.cv_anti = 0; p.cv_btap = 0; p.cv_mask = p.cv_res = nullptr; p.cv_pre = nullptr;
     p.cv_drop = m3t_make_drop(0.f, 0ull);
     p.cv_amax = nullptr;
+    p.mw_len = p.mw_stride = p.mw_off = 0;
     dim3 grid(N / (narrow ? 64 : XN), M / XM, splits), block(256);
 #define M3T_X6_DISPATCH(NS_, XNT_)                                                                                                  \
     do {                                                                                                                           \
@@ -391,6 +412,34 @@ int m3t_sgemm_x6_launch(int transA, int transB, int M, int N, int K, const float
     return (int)e;
 }
 
+// C's and A's rows through a time window (MW kernels; m3t_sgemm_window): transA = 0, one K pass (no split-K slabs), fp16x3 or the
+// six-product form.  The caller has verified M % 128 == 0, N % 64 == 0, K % 32 == 0, alignment, mw_len >= 1.
+int m3t_sgemm_x6_window_launch(int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                               const float* bias, int act, int accumulate, int mw_len, int mw_stride, int mw_off, int f16x3, int narrow,
+                               const unsigned long long* amax_a, const unsigned long long* amax_b, hipStream_t s) {
+    X6Params p;
+    p.amax_a = amax_a; p.amax_b = amax_b;
+    if (f16x3 && (!amax_a || !amax_b)) return M3T_EINVAL;
+    p.A = A; p.B = B; p.C = C; p.bias = bias; p.ws = nullptr;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.act = act; p.accumulate = accumulate; p.splits = 1; p.kchunk = K;
+    p.seg_len = p.seg_stride = p.a_off = p.b_off = 0;
+    p.cv_T = p.cv_C = p.cv_K = p.cv_dil = p.cv_lead = p.cv_anti = 0; p.cv_btap = 0; p.cv_mask = p.cv_res = nullptr; p.cv_pre = nullptr;
+    p.cv_drop = m3t_make_drop(0.f, 0ull);
+    p.cv_amax = nullptr;
+    p.mw_len = mw_len; p.mw_stride = mw_stride; p.mw_off = mw_off;
+    dim3 grid(N / (narrow ? 64 : XN), M / XM, 1), block(256);
+#define M3T_X6W_GO(NS_, XNT_)                                                                             \
+    do {                                                                                                  \
+        if (transB) sgemm_x6_kernel<0, 1, false, NS_, false, XNT_, true><<<grid, block, 0, s>>>(p);       \
+        else sgemm_x6_kernel<0, 0, false, NS_, false, XNT_, true><<<grid, block, 0, s>>>(p);              \
+    } while (0)
+    if (f16x3) { if (narrow) M3T_X6W_GO(4, 64); else M3T_X6W_GO(4, 128); }
+    else { if (narrow) M3T_X6W_GO(3, 64); else M3T_X6W_GO(3, 128); }
+#undef M3T_X6W_GO
+    return (int)hipGetLastError();
+}
+
 
 // Dilated 1-D convolution on the bf16x6 kernel (see CONV above).  The caller (m3t_conv1d_fwd) has verified: (B*T) % 128 == 0,
 // Co % 128 == 0, Ci % 32 == 0, 16-B aligned operands.  anti = 0: w_t is [K][Co][Ci] (rows of Ci contiguous: the "TB = 1" form,
@@ -408,6 +457,7 @@ int m3t_conv_x6_launch(const float* x, const float* w_t, const float* bias, cons
     p.seg_len = p.seg_stride = p.a_off = p.b_off = 0;
     p.cv_T = T; p.cv_C = Ci; p.cv_K = K; p.cv_dil = dil; p.cv_lead = lead; p.cv_anti = anti;
     p.cv_btap = (size_t)Co * Ci; p.cv_mask = mask; p.cv_res = res; p.cv_pre = pre; p.cv_drop = drop;
+    p.mw_len = p.mw_stride = p.mw_off = 0;
     // 128 x 64 tiles when 128 x 128 ones would leave most CUs with one workgroup (Co = 512 at B*T = 9600: 300 tiles)
     const bool narrow = (Co / XN) * (p.M / XM) <= 384;
     dim3 grid(Co / (narrow ? 64 : XN), p.M / XM, 1), block(256);

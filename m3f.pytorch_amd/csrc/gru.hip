@@ -642,7 +642,10 @@ extern "C" int m3t_gru_scan_fwd(const m3t_gru_fwd_desc* scans, int n_scans, int 
     for (int i = n_scans; i <= M3T_MAX_SCANS; ++i) g.blk_start[i] = blocks;
     dim3 grid(blocks, cdiv(B, RB));
     hipStream_t s = (hipStream_t)stream;
-    if (solo_fwd_ok(g, B, T, flags)) return solo_fwd_launch(g, B, T, s);      // H = 128: one workgroup per (scan, clip), no exchange
+    if (solo_fwd_ok(g, B, T, flags)) {                                        // H = 128: one workgroup per (scan, clip), no exchange
+        if (persist_progress_armed()) return M3T_EINVAL;                      // (progress marks: only the persistent fp16x3 kernels carry them)
+        return solo_fwd_launch(g, B, T, s);
+    }
     bool fast = true;     // every scan: H % 16 == 0 and float4-aligned operands
     for (int i = 0; i < n_scans; ++i) {
         const m3t_gru_fwd_desc& d = scans[i];
@@ -692,6 +695,7 @@ extern "C" int m3t_gru_scan_fwd(const m3t_gru_fwd_desc* scans, int n_scans, int 
             }
             return persist_fwd_launch(fg, fp, B, T, flags, s);
         }
+        if (persist_progress_armed()) return M3T_EINVAL;
         { const int e = persist_take_after(s); if (e) return e; }
         persist_record_start(s);
         struct EndRec { hipStream_t s; ~EndRec() { persist_record_end(s); } } end_rec{s};
@@ -708,6 +712,7 @@ extern "C" int m3t_gru_scan_fwd(const m3t_gru_fwd_desc* scans, int n_scans, int 
                 for (int step = 0; step < T; ++step) gru_step_fwd_frag_kernel<1><<<nblk, NT, 0, s>>>(fg, fp, B, T, step);
         });
     }
+    if (persist_progress_armed()) return M3T_EINVAL;
     { const int e = persist_take_after(s); if (e) return e; }
     persist_record_start(s);
     struct EndRec2 { hipStream_t s; ~EndRec2() { persist_record_end(s); } } end_rec2{s};
@@ -741,6 +746,7 @@ static int scan_bwd_impl(const m3t_gru_bwd_desc* scans, int n_scans, int B, int 
     dim3 grid(blocks, cdiv(B, RB));
     hipStream_t s = (hipStream_t)stream;
     if (solo_bwd_ok(g, B, T, flags)) {               // H = 128: one workgroup per (scan, clip); raises the magnitude slots itself
+        if (persist_progress_armed()) return M3T_EINVAL;                      // (progress marks: only the wide producer-split kernel carries them)
         *amax_done = true;
         return solo_bwd_launch(g, B, T, flags, s);
     }
@@ -792,6 +798,7 @@ static int scan_bwd_impl(const m3t_gru_bwd_desc* scans, int n_scans, int B, int 
             *amax_done = persist_bwd_uses_x6(bg, B, T, flags);          // that kernel raises the descs' magnitude slots itself
             return persist_bwd_launch(bg, fp, B, T, flags, s);
         }
+        if (persist_progress_armed()) return M3T_EINVAL;
         { const int e = persist_take_after(s); if (e) return e; }
         persist_record_start(s);
         struct EndRec { hipStream_t s; ~EndRec() { persist_record_end(s); } } end_rec{s};
@@ -809,6 +816,7 @@ static int scan_bwd_impl(const m3t_gru_bwd_desc* scans, int n_scans, int B, int 
                 for (int step = 0; step < T; ++step) gru_step_bwd_frag_kernel<1><<<nblk, NT, 0, s>>>(bg, fp, B, T, step);
         });
     }
+    if (persist_progress_armed()) return M3T_EINVAL;
     { const int e = persist_take_after(s); if (e) return e; }
     persist_record_start(s);
     struct EndRec2 { hipStream_t s; ~EndRec2() { persist_record_end(s); } } end_rec2{s};

@@ -92,7 +92,14 @@ void persist_drop_events();
 void persist_set_arena(void* arena, size_t bytes);
 void persist_drop_arena();
 void persist_forget_arena(void* arena);
-struct AfterGuard { ~AfterGuard() { persist_drop_after(); persist_drop_events(); persist_drop_arena(); } };
+// m3t_gru_scan_progress: progress marks for the NEXT scan call of this thread (gru_persist.hip, ExPtrs.prog)
+void persist_set_progress(unsigned* ctr, int n, const int* tb, unsigned* need);
+void persist_drop_progress();
+bool persist_progress_armed();
+void persist_forget_progress(unsigned* ctr);
+int persist_progress_ok(int n, int H, int B, int T, int flags, bool backward);
+int persist_wait_progress(const unsigned* ctr, unsigned need, hipStream_t s);
+struct AfterGuard { ~AfterGuard() { persist_drop_after(); persist_drop_events(); persist_drop_arena(); persist_drop_progress(); } };
 int persist_poll_error();       // step+1 of a scan that hit its spin limit since the last persist_reset_error(), else 0 (sticky)
 void persist_reset_error();     // clears the error words; only after the device has been synchronised
 void persist_set_defer(int on); // m3t_gru_error_defer: scan calls do not return M3T_ESPIN behind a dead scan (several ranks: raise at an agreed point)

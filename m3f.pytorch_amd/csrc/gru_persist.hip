@@ -53,7 +53,52 @@ struct ExPtrs {
     unsigned hs_tag;
     int inline_prep;                 // 1: the kernel builds its W_hh fragments itself from the parameter (no prep launch in front of it)
     unsigned tag_base;               // tags of this launch are tag_base + step + 1 (launch-unique inside an exchange arena: no memset per launch)
+    // progress marks (m3t_gru_scan_progress, round 5): consumers of a scan's results need not wait for the launch to end.  prog[0] counts
+    // for the scans that walk time upwards, prog[1] for those that walk it downwards; when a workgroup's results of every step < marks[dir][k]
+    // are in memory and visible device-wide it adds 1 to its counter (gru_persist_fwd6_kernel / gru_persist_bwd3q_kernel only)
+    unsigned* prog;
+    int nmarks;
+    int marks[2][3];
 };
+
+// Progress marks, the two halves of a signal (see ExPtrs.prog).  Results of step k leave a workgroup during step k or k + 1 (the memory-order
+// hand-over stores one step late) and have been acknowledged once every wave has passed the gather's `s_waitcnt vmcnt(0)` of step k + 2 at the
+// latest -- so: after the BARRIER of step mark + 1 one wave starts the write-back of its XCD's L2 (plain stores stay there:
+// MI355X_MICROARCH.md, inter-workgroup visibility), which retires in order in front of that wave's next gather (its `s_waitcnt vmcnt(0)`);
+// at the TOP of step mark + 3 -- in front of the gather, where the kernels have registers to spare (behind it the wide forward kernel
+// spilled three VGPRs for the atomic's operands) -- the same wave raises the counter.  The write-back overlaps the poll delay and the
+// gather's round trip: nothing waits for it.
+#define M3T_MARK_STATE()                                                                                         \
+    const int mdir = MARK_ASC ? 0 : 1;                                                                           \
+    /* (three scalars and selects: a dynamically indexed copy of ex.marks would live in scratch) */               \
+    const int mark0 = MARK_ASC ? ex.marks[0][0] : ex.marks[1][0], mark1 = MARK_ASC ? ex.marks[0][1] : ex.marks[1][1],  \
+              mark2 = MARK_ASC ? ex.marks[0][2] : ex.marks[1][2];                                                \
+    const int nmarks = ex.prog != nullptr ? ex.nmarks : 0;                                                       \
+    /* the signalling wave as a SCALAR (the wide kernels sit at 256 VGPRs: a per-lane predicate inside the loop spilled three of them) */ \
+    const bool mark_wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == NW - 1;                           \
+    const int mark_off = __builtin_amdgcn_readfirstlane(mdir * 4);    /* byte offset of this scan's counter (an "s" operand that is a select of pointers lands in VGPRs) */ \
+    int mk = 0, sig_step = nmarks > 0 ? mark0 + 1 : -1
+#define M3T_MARK_AT(k_) ((k_) >= nmarks ? -2 : ((k_) == 0 ? mark0 : ((k_) == 1 ? mark1 : mark2)))
+// (one lane adds: exec is narrowed inside the asm; address from SGPRs, operands defined inside: nothing for hipcc to keep in loop-long VGPRs)
+#define M3T_MARK_STEP_TOP(step_)                                                                                 \
+    do {                                                                                                         \
+        if ((step_) == sig_step + 2 && sig_step >= 0) {                                                          \
+            if (mark_wave) {                                                                                     \
+                unsigned z_, o_;                                                                                 \
+                unsigned long long sv_;                                                                          \
+                asm volatile("s_mov_b64 %2, exec\n\ts_mov_b64 exec, 1\n\tv_mov_b32 %0, %4\n\tv_mov_b32 %1, 1\n\t" \
+                             "global_atomic_add %0, %1, %3\n\ts_mov_b64 exec, %2"                                \
+                             : "=&v"(z_), "=&v"(o_), "=&s"(sv_) : "s"(ex.prog), "s"(mark_off) : "memory");       \
+            }                                                                                                    \
+            ++mk;                                                                                                \
+            sig_step = M3T_MARK_AT(mk) + 1;                                                                      \
+        }                                                                                                        \
+    } while (0)
+// (buffer_wbl2 is one cache operation per WAVE instruction, whatever the lanes)
+#define M3T_MARK_AFTER_BARRIER(step_)                                                                            \
+    do {                                                                                                         \
+        if ((step_) == sig_step && mark_wave) asm volatile("buffer_wbl2 sc1" ::: "memory");                      \
+    } while (0)
 
 // phase stamps: s_memtime deltas accumulated by one lane; a uniform scalar branch when profiling is off
 // Polling for the peers' granules.  A gather attempt is a full round trip (~1 us) and the next attempt is only issued
@@ -469,6 +514,8 @@ __global__ __launch_bounds__(NT) void gru_persist_fwd6_kernel(FwdGroup g, FragPt
     const bool stamp = ex.prof != nullptr && blockIdx.x == 0 && tid == ex.prof_tid;
     long long psum[6] = {0, 0, 0, 0, 0, 0}, last = stamp ? clock64() : 0;
 
+    const bool MARK_ASC = !d.reverse;
+    M3T_MARK_STATE();
     // x-projection of the step in (xr, xz, xn).  The next step's is requested right after this step's gather has
     // completed (nothing else outstanding then) and has the rest of the step to arrive: loaded after the publish it sat
     // in front of the next gather's vmcnt(0) (vector-memory operations retire in order).  Inline asm, unconditional
@@ -1309,6 +1356,9 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd3q_kernel(BwdGroup g, FragP
     if (tid < 2) poll_fail[tid] = 0;                   // first read after the first barrier
     const bool stamp = PROF && ex.prof != nullptr && blockIdx.x == 0 && tid == ex.prof_tid;
     long long psum[PROF ? 6 : 1] = {0}, last = stamp ? clock64() : 0;
+    const bool MARK_ASC = d.reverse != 0;              // the backward scan of a forward-direction GRU walks time downwards
+    M3T_MARK_STATE();
+    int amk = 0, amk_step = nmarks > 0 ? mark0 : -1;  // per-window magnitude slots d.amax[1 + window]
 #define M3T_QSTAMP(i)                                                        \
     do {                                                                     \
         if (PROF && stamp) { const long long now = clock64(); psum[PROF ? (i) : 0] += now - last; last = now; } \
@@ -1394,7 +1444,10 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd3q_kernel(BwdGroup g, FragP
     }
     if (d.amax) {
         const float m = wave_max(pok ? amx : 0.f);
-        if (lane == 0) atomicMax(d.amax, (unsigned long long)__float_as_uint(m));
+        if (lane == 0) {
+            atomicMax(d.amax, (unsigned long long)__float_as_uint(m));
+            if (nmarks > 0) atomicMax(d.amax + 1 + amk, (unsigned long long)__float_as_uint(m));      // the last window's slot
+        }
     }
     if (PROF && stamp)
         for (int i = 0; i < 6; ++i) ex.prof[i] = (unsigned long long)psum[PROF ? i : 0];
@@ -1787,6 +1840,70 @@ bool persist_bwd_uses_x6(const BwdGroup& g, int B, int T, int flags) {
     return sh.rt == 1 && (sh.nc == 2 || sh.nc == 4);
 }
 
+// ---- progress marks (m3t_gru_scan_progress) ---------------------------------------------------------------------------------
+// Armed by the caller for the NEXT scan call of the thread; consumed by the launch paths whose kernels carry the marks (the fp16x3
+// forward kernels, the wide producer-split backward kernel); any other path refuses an armed call (M3T_EINVAL) rather than let the
+// caller's consumers wait for signals that never come.  The library keeps, per counter pair, how many arrivals it has asked the device
+// for so far (a shadow of the device counters: launches are issued in stream order and every armed launch adds a known amount).
+struct ProgressArm { unsigned* ctr; int n; int tb[3]; unsigned* need; };
+static thread_local ProgressArm g_prog = {nullptr, 0, {0, 0, 0}, nullptr};
+static std::mutex g_prog_mu;
+static std::unordered_map<uintptr_t, std::pair<unsigned, unsigned>> g_prog_total;      // counter address -> arrivals requested so far (up, down)
+void persist_set_progress(unsigned* ctr, int n, const int* tb, unsigned* need) {
+    g_prog.ctr = ctr; g_prog.n = n; g_prog.need = need;
+    for (int i = 0; i < 3; ++i) g_prog.tb[i] = (tb && i < n) ? tb[i] : 0;
+}
+void persist_drop_progress() { g_prog.ctr = nullptr; g_prog.n = 0; g_prog.need = nullptr; }
+bool persist_progress_armed() { return g_prog.ctr != nullptr; }
+void persist_forget_progress(unsigned* ctr) {
+    std::lock_guard<std::mutex> lock(g_prog_mu);
+    if (ctr) g_prog_total.erase((uintptr_t)ctr); else g_prog_total.clear();
+}
+// fills ex.prog / nmarks / marks and the caller's `need` table; up[i]: scan i walks time upwards.  wg_per_scan: workgroups of one scan.
+template <typename G>
+static int apply_progress(const G& g, const bool* up, int wg_per_scan, int T, ExPtrs& ex) {
+    if (!g_prog.ctr) return 0;
+    const ProgressArm a = g_prog;
+    persist_drop_progress();
+    if (a.n < 1 || a.n > 3 || !a.need) return M3T_EINVAL;
+    for (int k = 0; k < a.n; ++k)
+        if (a.tb[k] < 4 || a.tb[k] > T - 4 || (k > 0 && a.tb[k] < a.tb[k - 1] + 4)) return M3T_EINVAL;      // (a signal trails its mark by two steps)
+    int n_up = 0, n_down = 0;
+    for (int i = 0; i < g.n; ++i) (up[i] ? n_up : n_down) += 1;
+    ex.prog = a.ctr; ex.nmarks = a.n;
+    for (int k = 0; k < a.n; ++k) { ex.marks[0][k] = a.tb[k]; ex.marks[1][k] = T - a.tb[a.n - 1 - k]; }
+    std::lock_guard<std::mutex> lock(g_prog_mu);
+    std::pair<unsigned, unsigned>& tot = g_prog_total[(uintptr_t)a.ctr];
+    for (int k = 0; k < a.n; ++k) {
+        a.need[k] = tot.first + (unsigned)(n_up * wg_per_scan * (k + 1));
+        a.need[a.n + k] = tot.second + (unsigned)(n_down * wg_per_scan * (k + 1));
+    }
+    tot.first += (unsigned)(n_up * wg_per_scan * a.n);
+    tot.second += (unsigned)(n_down * wg_per_scan * a.n);
+    return 0;
+}
+
+// the gate: one lane polls a progress counter until it has reached `need` (wrap-safe), then the kernel ends -- what follows it in its stream
+// starts behind a kernel boundary (agent-scope acquire: MI355X_MICROARCH.md, "boundary") and reads what the signalling workgroups wrote
+// back.  Bounded like every wait of the scans; giving up raises the sticky error word.
+__global__ void progress_gate_kernel(const unsigned* ctr, unsigned need, int spin_limit, unsigned* err) {
+    if (threadIdx.x != 0) return;
+    for (int spins = 0;; ++spins) {
+        unsigned v;
+        asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(ctr) : "memory");
+        if ((int)(v - need) >= 0) return;
+        if (spins > spin_limit) { raise_spin(err, 0); return; }
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+int persist_wait_progress(const unsigned* ctr, unsigned need, hipStream_t s) {
+    if (!ctr || !ensure_err_word()) return M3T_EINVAL;
+    static const int spin_limit = poll_env_early("M3T_SCAN_SPIN_LIMIT", SPIN_LIMIT_DEFAULT);
+    progress_gate_kernel<<<1, 64, 0, s>>>(ctr, need, spin_limit > 0 ? spin_limit : SPIN_LIMIT_DEFAULT, g_err_dev);
+    M3T_LAUNCH_CHECK();
+    return 0;
+}
+
 // M3T_SCAN_WIDE=0: keep one 16-unit tile per workgroup for the H = 512 levels in the fp16x3 mode (the round-3 geometry: 256 workgroups for
 // the encoder level) instead of the wide kernels (two tiles per workgroup, half the workgroups)
 static bool wide_enabled() {
@@ -1832,6 +1949,13 @@ int persist_fwd_launch(const FwdGroup& g, const FragPtrs& fp, int B, int T, int 
         if (persist_fwd_uses_x6(g, B, T, flags) && !g.bf16 && (flags & M3T_GEMM_F16X3) && m3t_f16x3_enabled() && sh.nc == 2) ex.poll_align = 1;
     }
     const bool x6 = persist_fwd_uses_x6(g, B, T, flags);
+    if (persist_progress_armed()) {                        // progress marks: the fp16x3 forward kernels carry them
+        if (!fwd_is_f16(g, B, T, flags)) { persist_drop_progress(); return M3T_EINVAL; }
+        bool up[M3T_MAX_SCANS];
+        for (int i = 0; i < g.n; ++i) up[i] = !g.d[i].reverse;
+        const int e = apply_progress(g, up, sh.active / g.n, T, ex);
+        if (e) return e;
+    }
     { const int e = prepare_exchange(g, fp, sh, x6 ? 1 : 0, 8, x6 ? 65535ull : 0xffffffffull, T, ex, s); if (e) return e; }
     ++g_launches;
     if (!x6) { const int e = persist_take_after(s); if (e) return e; }
@@ -1917,6 +2041,13 @@ int persist_bwd_launch(const BwdGroup& g, const FragPtrs& fp, int B, int T, int 
     if (uw > 1) {
         if (!level_shape(g.d, g.n, B, sh, uw)) return M3T_EINVAL;
         ex.slot_map = sh.slot_map;
+    }
+    if (persist_progress_armed()) {                        // progress marks: the wide producer-split backward kernel carries them
+        if (!(p3 && uw == 2)) { persist_drop_progress(); return M3T_EINVAL; }
+        bool up[M3T_MAX_SCANS];
+        for (int i = 0; i < g.n; ++i) up[i] = g.d[i].reverse != 0;      // (the backward scan of a forward-direction GRU walks time downwards)
+        const int e = apply_progress(g, up, sh.active / g.n, T, ex);
+        if (e) return e;
     }
     { const int e = prepare_exchange(g, fp, sh, b16 ? 2 : 3, b16 ? 8 : 16, b16 ? 65535ull : (p3 ? 0xffffffull : 0xffffffffull), T, ex, s, p3 ? 1 : 0); if (e) return e; }
     ++g_launches;
@@ -2060,6 +2191,31 @@ int persist_workgroups(int n, int H, int B, int T, int flags, bool backward) {
 }
 }  // namespace m3t_gru
 
+namespace m3t_gru {
+// would the level's launch carry progress marks (m3t_gru_scan_progress)?  0 / 1.  Same decisions as persist_fwd_launch / persist_bwd_launch.
+int persist_progress_ok(int n, int H, int B, int T, int flags, bool backward) {
+    if (persist_workgroups(n, H, B, T, flags, backward) <= 0) return 0;
+    Shape sh;
+    if (backward) {
+        BwdGroup g;
+        std::memset(&g, 0, sizeof(g));
+        g.n = n; g.bf16 = (flags & M3T_BF16) ? 1 : 0;
+        for (int i = 0; i < n; ++i) { g.d[i].H = H; g.d[i].gates = reinterpret_cast<const float*>(16); g.d[i].w_hh_t = reinterpret_cast<const float*>(16); }
+        if (!level_shape(g.d, g.n, B, sh)) return 0;
+        const bool b16 = persist_bwd_uses_16(g, B, T, flags);
+        const bool wide256 = (flags & M3T_SCAN_WIDE) && sh.rt == 1 && wide_enabled();
+        const bool p3 = !b16 && persist_bwd_uses_x6(g, B, T, flags) && (flags & M3T_GEMM_F16X3) && m3t_f16x3_enabled() && bwd3p_enabled() &&
+                        (sh.nc == 4 || (sh.nc == 2 && wide256)) && (unsigned long long)T + 1 < 0xffffffull;
+        return ((flags & M3T_SCAN_WIDE) && p3 && sh.rt == 1 && wide_enabled()) ? 1 : 0;
+    }
+    FwdGroup g;
+    std::memset(&g, 0, sizeof(g));
+    g.n = n; g.bf16 = (flags & M3T_BF16) ? 1 : 0;
+    for (int i = 0; i < n; ++i) { g.d[i].H = H; g.d[i].w_hh = reinterpret_cast<const float*>(16); }
+    return fwd_is_f16(g, B, T, flags) ? 1 : 0;
+}
+}  // namespace m3t_gru
+
 extern "C" int m3t_gru_scan_workgroups(int n_scans, int H, int B, int T, int flags, int backward) {
     return m3t_gru::persist_workgroups(n_scans, H, B, T, flags, backward != 0);
 }
@@ -2087,6 +2243,26 @@ extern "C" int m3t_gru_scan_arena(void* arena, size_t bytes) {
 extern "C" int m3t_gru_scan_arena_reset(void* arena) {
     m3t_gru::persist_forget_arena(arena);
     return 0;
+}
+
+extern "C" int m3t_gru_scan_progress(unsigned* counters, int n_marks, const int* time_bounds, unsigned* need) {
+    if (!counters) { m3t_gru::persist_drop_progress(); return 0; }
+    if (n_marks < 1 || n_marks > 3 || !time_bounds || !need || ((uintptr_t)counters % 8) != 0) return M3T_EINVAL;
+    m3t_gru::persist_set_progress(counters, n_marks, time_bounds, need);
+    return 0;
+}
+
+extern "C" int m3t_gru_scan_progress_reset(unsigned* counters) {
+    m3t_gru::persist_forget_progress(counters);
+    return 0;
+}
+
+extern "C" int m3t_gru_scan_progress_ok(int n_scans, int H, int B, int T, int flags, int backward) {
+    return m3t_gru::persist_progress_ok(n_scans, H, B, T, flags, backward != 0);
+}
+
+extern "C" int m3t_stream_wait_progress(const unsigned* counter, unsigned need, void* stream) {
+    return m3t_gru::persist_wait_progress(counter, need, (hipStream_t)stream);
 }
 
 extern "C" int m3t_gru_scan_after(void* event) {

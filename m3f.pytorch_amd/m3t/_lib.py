@@ -44,6 +44,7 @@ SIGNATURES = {
     "m3t_device_arch": [C.c_char_p, _i],
     "m3t_sgemm": [_i, _i, _i, _i, _i, _f, _i, _f, _i, _f, _i, _f, _i, _i, _i, _i, _i, _i, _f, _z, _i, _s],
     "m3t_sgemm_scaled": [_i, _i, _i, _i, _i, _f, _i, _f, _i, _f, _i, _f, _i, _i, _i, _i, _i, _i, _f, _z, _i, _f, _f, _s],
+    "m3t_sgemm_window": [_i, _i, _i, _i, _i, _i, _i, _f, _i, _f, _i, _f, _i, _f, _i, _i, _i, _f, _f, _s],
     "m3t_absmax": [_i, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), _s],
     "m3t_sgemm_plan": [_i, _i, _i, _i, _i, _z, _i, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "m3t_im2col3d": [_f] + [_i] * 14 + [_f, C.c_longlong, _i, C.c_void_p, _s],
@@ -63,6 +64,10 @@ SIGNATURES = {
     "m3t_gru_scan_arena": [C.c_void_p, _z],
     "m3t_gru_scan_arena_reset": [C.c_void_p],
     "m3t_gru_scan_after": [C.c_void_p],
+    "m3t_gru_scan_progress": [C.c_void_p, _i, C.POINTER(C.c_int), C.POINTER(C.c_uint)],
+    "m3t_gru_scan_progress_reset": [C.c_void_p],
+    "m3t_gru_scan_progress_ok": [_i, _i, _i, _i, _i, _i],
+    "m3t_stream_wait_progress": [C.c_void_p, C.c_uint, _s],
     "m3t_gru_scan_events": [C.c_void_p, C.c_void_p],
     "m3t_gru_persist_profile": [C.c_void_p],
     "m3t_att_fuse_fwd": [_f, _f, _f, _f, _f, _i, _i, _s],

@@ -129,7 +129,7 @@ class FlatGradDDP:
         self._dead_host = self._dead_ev = None
         self._dead_pending = False
         if self._agreed:
-            ops.defer_scan_errors(True)
+            ops.defer_scan_errors_acquire()       # refcounted: the switch is process-global, several instances may be alive
             self._dead_host = torch.zeros(1, dtype=torch.float32).pin_memory()
             self._dead_ev = torch.cuda.Event()
         self.ar_events = None          # bench.py: a list here collects (start, end) HIP events around the in-step all-reduce
@@ -150,9 +150,13 @@ class FlatGradDDP:
         if getattr(self, "_agreed", False):
             self._agreed = False
             try:
-                ops.defer_scan_errors(False)
+                ops.defer_scan_errors_release()   # deferral goes off only with the LAST live owner
             except Exception:  # noqa: BLE001  (library already gone at interpreter shutdown)
                 pass
+        h = getattr(self, "_early_hook", None)
+        if h is not None:
+            h.remove()
+            self._early_hook = None
 
     def __del__(self):
         try:
@@ -189,6 +193,10 @@ class FlatGradDDP:
         for h in self._handles:                  # (overlap: every rank issued the same bucket collectives during backward)
             h.wait()
         self._handles = []
+        if getattr(self, "_early_handle", None) is not None:      # the step's early bucket is in flight on its own stream: join it
+            self._early_handle.wait()
+            torch.cuda.current_stream().wait_stream(self._early_stream)
+            self._early_handle = None
         self._dead_pending = False
         _lib._recover_scan_error()               # synchronise the device, then clear the sticky state
         raise _lib.M3THipError("a persistent GRU scan gave up waiting for a peer workgroup on at least one rank (M3T_ESPIN, %s): "
@@ -238,6 +246,9 @@ class FlatGradDDP:
             warnings.warn("M3T_DDP_EARLY_BUCKET refused: %d scan workgroups + %d RCCL channels do not fit %d CUs"
                           % (resident_workgroups, channels, n_cus))
             return False
+        if getattr(self, "_early_hook", None) is not None:      # re-arm: one hook, one collective per slice
+            self._early_hook.remove()
+            self._early_hook = None
         self._early_stream = torch.cuda.Stream(device=self.flat.device)
         self._early_handle = None
         s0, e0 = self.ranges[0]
@@ -252,7 +263,7 @@ class FlatGradDDP:
             with torch.cuda.stream(self._early_stream):
                 self._early_handle = dist.all_reduce(self.flat[s0:e0], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
-        module.register_full_backward_hook(hook)
+        self._early_hook = module.register_full_backward_hook(hook)
         self._early = True
         return True
 
@@ -271,13 +282,17 @@ class FlatGradDDP:
             ops.grad_poison_(self.flat, self.dead)
             dist.all_reduce(self._buf, op=dist.ReduceOp.SUM, group=self.pg)
             ops.grad_dead_check_(self.dead)
-        if self.world > 1 and hip:
-            ops.grad_poison_(self.flat, self.dead)          # this rank's dead scan -> NaN in flat[0], 1 in the dead slot
-        if self.world > 1 and not self.overlap and getattr(self, "_early", False) and self._early_handle is not None:
-            # bucket 0 left early (early_bucket_after); the rest of the buffer and the dead slot now, then join
-            dist.all_reduce(self._buf[self.ranges[0][1]:], op=dist.ReduceOp.SUM, group=self.pg)
+        early = self.world > 1 and not self.overlap and getattr(self, "_early", False) and self._early_handle is not None
+        if early:
+            # bucket 0 -- which holds flat[0] -- may still be in flight on the communication stream: join it BEFORE the poison kernel
+            # writes flat[0] on this stream (a data race otherwise); the dead slot carries the failure either way
             self._early_handle.wait()
             torch.cuda.current_stream().wait_stream(self._early_stream)
+        if self.world > 1 and hip:
+            ops.grad_poison_(self.flat, self.dead)          # this rank's dead scan -> NaN in flat[0], 1 in the dead slot
+        if early:
+            # bucket 0 left early (early_bucket_after); the rest of the buffer and the dead slot now, then join
+            dist.all_reduce(self._buf[self.ranges[0][1]:], op=dist.ReduceOp.SUM, group=self.pg)
             self._early_handle = None
         elif self.world > 1 and not self.overlap:
             dist.all_reduce(self._buf, op=dist.ReduceOp.SUM, group=self.pg)      # gradients + dead slot: ONE collective

@@ -326,9 +326,15 @@ def transpose2d(src):
 
 def amax_out(slot):
     """the NEXT conv1d / mask_pos / weight_norm_fwd call raises the magnitude slot at address `slot` to max |its output| in the same kernel
-    (include/m3t_hip.h, m3t_amax_out): the producer measures what the consuming fp16x3 contraction scales by"""
+    (include/m3t_hip.h, m3t_amax_out): the producer measures what the consuming fp16x3 contraction scales by.  Call it IMMEDIATELY in front
+    of the consuming call -- after every allocation (an allocation failure between the two would leave the pointer parked for an
+    unrelated later call; the wrappers below also clear it on any failure)"""
     if slot is not None:
         _lib.check(lib().m3t_amax_out(C.c_void_p(slot)), "m3t_amax_out")
+
+
+def _amax_clear():
+    _lib.check(lib().m3t_amax_out(None), "m3t_amax_out")
 
 
 def mask_pos(s, dy, mul=None, drop=None, amax=None):
@@ -336,13 +342,17 @@ def mask_pos(s, dy, mul=None, drop=None, amax=None):
     amax: address of a magnitude slot the kernel raises to max |out|"""
     out = torch.empty_like(dy)
     amax_out(amax)
-    if drop is not None and drop[0] > 0:
-        Cc = dy.shape[-1]
-        _lib.check(lib().m3t_mask_pos_drop(_p(s), _p(dy), _p(out), dy.numel() // Cc, Cc, float(drop[0]), int(drop[1]), _stream()),
-                   "m3t_mask_pos_drop")
+    try:
+        if drop is not None and drop[0] > 0:
+            Cc = dy.shape[-1]
+            _lib.check(lib().m3t_mask_pos_drop(_p(s), _p(dy), _p(out), dy.numel() // Cc, Cc, float(drop[0]), int(drop[1]), _stream()),
+                       "m3t_mask_pos_drop")
+            return out
+        _lib.check(lib().m3t_mask_pos(_p(s), _p(dy), _p(mul), _p(out), dy.numel(), _stream()), "m3t_mask_pos")
         return out
-    _lib.check(lib().m3t_mask_pos(_p(s), _p(dy), _p(mul), _p(out), dy.numel(), _stream()), "m3t_mask_pos")
-    return out
+    except BaseException:
+        _amax_clear()
+        raise
 
 
 # ----------------------------------------------------------------------------- Linear
@@ -534,6 +544,24 @@ def defer_scan_errors(on=True):
     _lib.check(lib().m3t_gru_error_defer(1 if on else 0), "m3t_gru_error_defer")
 
 
+_DEFER_OWNERS = [0]
+
+
+def defer_scan_errors_acquire():
+    """refcounted form for owners that come and go (FlatGradDDP instances): the process-global switch stays on while ANY owner is alive --
+    an older instance that is closed or garbage-collected after a newer one was built must not turn the newer one's deferral off"""
+    _DEFER_OWNERS[0] += 1
+    if _DEFER_OWNERS[0] == 1:
+        defer_scan_errors(True)
+
+
+def defer_scan_errors_release():
+    if _DEFER_OWNERS[0] > 0:
+        _DEFER_OWNERS[0] -= 1
+        if _DEFER_OWNERS[0] == 0:
+            defer_scan_errors(False)
+
+
 def poll_scan_error(sync=False, force=False):
     """raise M3THipError if a persistent scan has died (sync=True: wait for the device first, so the answer covers everything
     issued so far).  The error state is sticky on the device (every optimizer step queued behind the dead scan skips itself,
@@ -590,7 +618,86 @@ def _scan_arena(device):
     _lib.check(lib().m3t_gru_scan_arena(C.c_void_p(a.data_ptr()), _ARENA_BYTES), "m3t_gru_scan_arena")
 
 
-def _scan_fwd(descs, B, T, prec=0, after=None):
+# ---- direction-split, time-chunked hand-offs around the persistent scans (round 5) ------------------------------------------------
+# Layer l+1's input projection is out_fwd W_ih[:, :H]^T + out_rev W_ih[:, H:]^T (reference models/rnn.py:17,75) and each half is final
+# for the frames its direction's scan has passed; likewise dX = dgx_fwd W_f + dgx_rev W_r in backward.  A scan launch publishes PROGRESS
+# MARKS (include/m3t_hip.h, m3t_gru_scan_progress); a consumer stream waits for a mark with a one-lane gate kernel and runs the product of
+# that direction's half over that TIME WINDOW (m3t_sgemm_window) while the scan is still running.  Per window the first arriver writes
+# (+ bias), the second accumulates -- the order is fixed by the windows' arrival steps, so results do not depend on timing.
+CHUNKS = [os.environ.get("M3T_SCAN_CHUNKS", "1") != "0"]      # tests flip it: the unchunked schedule is the yardstick of the chunked one
+_CHUNK_WINDOWS = 4
+_PROGRESS = {}
+
+
+def _progress_counters(device):
+    """the two progress words (up-scans, down-scans) of the scan launches issued on the current stream role: zeroed once, then written by
+    scan launches only (launches that share a pair must be ordered: one pair per (device, stream role), like the exchange arenas)"""
+    key = (device.type, device.index, _ws_tag(device))
+    t = _PROGRESS.get(key)
+    if t is None:
+        t = _PROGRESS[key] = torch.zeros(2, dtype=torch.int32, device=device)
+        _lib.check(lib().m3t_gru_scan_progress_reset(C.c_void_p(t.data_ptr())), "m3t_gru_scan_progress_reset")
+    return t
+
+
+def _chunk_bounds(B, T, n=None):
+    """time bounds tb[0 .. n-2] that cut [0, T) into n windows whose row counts B * len are whole 128-row GEMM tiles, or None"""
+    import math
+    n = n or _CHUNK_WINDOWS
+    q = 128 // math.gcd(B, 128)
+    if not CHUNKS[0] or (B * T) % 128 != 0 or T < 16 * n or B * T < 4096:
+        return None
+    tb = [int(round(k * T / n / q)) * q for k in range(1, n)]
+    lo = [0] + tb
+    hi = tb + [T]
+    if any(b - a < 8 for a, b in zip(lo, hi)) or tb[0] < 4 or tb[-1] > T - 4 or (T - tb[-1]) * B % 128 != 0:
+        return None
+    return tb
+
+
+def _arrivals(tb, T):
+    """[(dir, k, window, second)] in the order the halves of the windows become final: dir 0 = the scans that walk time upwards, 1 = downwards;
+    k = index into that direction's `need` values (None: final only when the scan launch has ended); second: the window's other half came first"""
+    n = len(tb)
+    ev = []
+    for w in range(n + 1):
+        ev.append((tb[w] if w < n else T, 0, w if w < n else None, w))
+        ev.append((T - tb[w - 1] if w > 0 else T, 1, (n - w) if w > 0 else None, w))
+    ev.sort(key=lambda e: (e[0], e[1]))
+    seen, out = set(), []
+    for step, d, k, w in ev:
+        out.append((d, k, w, w in seen))
+        seen.add(w)
+    return out
+
+
+def _wait_progress(counters, dirn, need):
+    _lib.check(lib().m3t_stream_wait_progress(C.c_void_p(counters.data_ptr() + 4 * dirn), int(need) & 0xffffffff, _stream()), "m3t_stream_wait_progress")
+
+
+def sgemm_window(transB, n_seg, win_len, win_stride, win_off, N, K, A, a_off, lda, Bm, b_off, ldb, Cm, c_off, ldc, bias=None, act=0,
+                 accumulate=False, prec=None, amax=(None, None)):
+    """C[window rows, :N] = A[window rows, :K] op(B) (+ bias) (+ C): the rows are the frames [win_off, win_off + win_len) of every clip of
+    batch-major [n_seg, win_stride, *] tensors (include/m3t_hip.h, m3t_sgemm_window)"""
+    flags = _PREC[0] if prec is None else prec
+    rc = lib().m3t_sgemm_window(transB, n_seg, win_len, win_stride, win_off, N, K, _p(A, a_off), lda, _p(Bm, b_off), ldb, _p(Cm, c_off), ldc,
+                                _p(bias), act, int(accumulate), flags, amax[0], amax[1], _stream())
+    _lib.check(rc, "m3t_sgemm_window")
+
+
+def _scan_fwd(descs, B, T, prec=0, after=None, progress=None):
+    """progress = (counters tensor, time bounds): arm the launch's progress marks; returns the `need` table (2 x len(bounds) counter values)"""
+    need = None
+    if progress is not None:
+        assert len(descs) <= M3T_MAX_SCANS
+        ctr, tb = progress
+        need = (C.c_uint * (2 * len(tb)))()
+        _lib.check(lib().m3t_gru_scan_progress(C.c_void_p(ctr.data_ptr()), len(tb), (C.c_int * len(tb))(*tb), need), "m3t_gru_scan_progress")
+    _scan_fwd_(descs, B, T, prec, after)
+    return None if need is None else list(need)
+
+
+def _scan_fwd_(descs, B, T, prec=0, after=None):
     for i in range(0, len(descs), M3T_MAX_SCANS):
         chunk = descs[i:i + M3T_MAX_SCANS]
         arr = (GruFwdDesc * len(chunk))(*chunk)
@@ -607,7 +714,18 @@ def _scan_fwd(descs, B, T, prec=0, after=None):
         _lib.check(rc, "m3t_gru_scan_fwd")
 
 
-def _scan_bwd(descs, B, T, prec=0, after=None):
+def _scan_bwd(descs, B, T, prec=0, after=None, progress=None):
+    need = None
+    if progress is not None:
+        assert len(descs) <= M3T_MAX_SCANS
+        ctr, tb = progress
+        need = (C.c_uint * (2 * len(tb)))()
+        _lib.check(lib().m3t_gru_scan_progress(C.c_void_p(ctr.data_ptr()), len(tb), (C.c_int * len(tb))(*tb), need), "m3t_gru_scan_progress")
+    _scan_bwd_(descs, B, T, prec, after)
+    return None if need is None else list(need)
+
+
+def _scan_bwd_(descs, B, T, prec=0, after=None):
     for i in range(0, len(descs), M3T_MAX_SCANS):
         chunk = descs[i:i + M3T_MAX_SCANS]
         arr = (GruBwdDesc * len(chunk))(*chunk)
@@ -740,9 +858,10 @@ class _MultiBiGRU(torch.autograd.Function):
 
         alone = not _interleaved(groups) and all(kind == "main" for kind, _ in groups)   # nothing runs beside these GEMMs
 
-        def level_fwd(l, idxs, scan, after=None, wide=False):
+        def level_fwd(l, idxs, scan, after=None, wide=False, progress=None):
             """scan=False: the input projections of layer l for the stacks idxs; scan=True: their grouped scan (its scan
-            kernels fenced behind the event `after`; wide: the launch leaves room for a second persistent scan)"""
+            kernels fenced behind the event `after`; wide: the launch leaves room for a second persistent scan; progress: time bounds
+            of the launch's progress marks -- returns their `need` table)"""
             descs = []
             for s in idxs:
                 H = Hs[s]
@@ -758,7 +877,50 @@ class _MultiBiGRU(torch.autograd.Function):
                                                 _vp(gates[l][s], d * B * T * 4 * H), _vp(h_ns[s], (2 * l + d) * B * H),
                                                 H, d, 6 * H, d * 3 * H, outs[l][s].stride(1), d * H))
             if scan:
-                _scan_fwd(descs, B, T, prec | (_lib.M3T_SCAN_WIDE if (wide or FORCE_WIDE_FWD[0]) else 0), after)
+                return _scan_fwd(descs, B, T, prec | (_lib.M3T_SCAN_WIDE if (wide or FORCE_WIDE_FWD[0]) else 0), after,
+                                 None if progress is None else (_progress_counters(dev), progress))
+
+        def chunk_plan(idxs, wide):
+            """time bounds for direction-split, time-chunked hand-offs between the layers of the stacks idxs (one H), or None"""
+            if L < 2 or fslots is None or len({Hs[i] for i in idxs}) != 1 or 2 * len(idxs) > M3T_MAX_SCANS:
+                return None
+            H = Hs[idxs[0]]
+            if H % 64 != 0:
+                return None
+            fl = _scan_flags(dev) | prec | (_lib.M3T_SCAN_WIDE if (wide or FORCE_WIDE_FWD[0]) else 0)
+            if not lib().m3t_gru_scan_progress_ok(2 * len(idxs), H, B, T, fl, 0):
+                return None
+            return _chunk_bounds(B, T)
+
+        def proj_pieces(l, idxs, tb, need, scan_stream):
+            """layer l's input projections from layer l - 1's outputs, as (direction half x time window) pieces on weight-gradient
+            stream 0 (idle in forward), each behind the progress mark of the scan whose output it reads; `scan_stream` waits for the last"""
+            wg = wgrad_stream(dev, 0)
+            ctr = _progress_counters(dev)
+            ev_end = torch.cuda.Event()
+            ev_end.record(scan_stream)                      # the scan launch of layer l - 1 has ended
+            lo, hi = [0] + tb, tb + [T]
+            with torch.cuda.stream(wg):
+                ended = False
+                for dirn, k, w, second in _arrivals(tb, T):
+                    if k is None:
+                        if not ended:
+                            wg.wait_event(ev_end)
+                            ended = True
+                    else:
+                        _wait_progress(ctr, dirn, need[dirn * len(tb) + k])
+                    for si in idxs:
+                        H = Hs[si]
+                        src = outs[l - 1][si]
+                        for d in (0, 1):
+                            w_ih, _, b_ih, _ = params[si][(2 * l + d) * 4:(2 * l + d) * 4 + 4]
+                            # (forward pass: the scans that walk time upwards are the forward direction = columns [0, H) of the output)
+                            sgemm_window(1, B, hi[w] - lo[w], T, lo[w], 3 * H, H, src, dirn * H, src.stride(1), w_ih, dirn * H, 2 * H,
+                                         xprojs[l][si], d * 3 * H, 6 * H, bias=None if second else b_ih, accumulate=second, prec=prec,
+                                         amax=(one, fslot_w(l, si, d)))
+                ev = torch.cuda.Event()
+                ev.record(wg)
+            scan_stream.wait_event(ev)
 
         concurrent = (_interleaved(groups) and len({Hs[i] for i in groups[0][1]}) == 1 and len({Hs[i] for i in groups[1][1]}) == 1
                       and _pair_fits(dev, 2 * len(groups[0][1]), Hs[groups[0][1][0]], 2 * len(groups[1][1]), Hs[groups[1][1][0]], B, T, prec))
@@ -771,12 +933,18 @@ class _MultiBiGRU(torch.autograd.Function):
             side.wait_stream(main)
             _FENCED[0] = True
             try:
+                tb = chunk_plan(heavy, True)           # round 5: the heavy stacks' deeper projections run UNDER the scan that feeds them
+                if tb is not None:
+                    wgrad_stream(dev, 0).wait_stream(main)      # (the magnitude slots, the parameters: everything issued so far)
                 for l in range(L):
-                    level_fwd(l, heavy, False)
+                    if l == 0 or tb is None:
+                        level_fwd(l, heavy, False)
                     with torch.cuda.stream(side):
                         level_fwd(l, light, False)
                         level_fwd(l, light, True, None, True)      # (wide too: 32 workgroups, one group per XCD, L2-served exchange; -0.03 ms)
-                    level_fwd(l, heavy, True, None, True)
+                    need = level_fwd(l, heavy, True, None, True, tb if l + 1 < L else None)
+                    if tb is not None and l + 1 < L:
+                        proj_pieces(l + 1, heavy, tb, need, main)
             finally:
                 _FENCED[0] = False
             main.wait_stream(side)
@@ -830,9 +998,15 @@ class _MultiBiGRU(torch.autograd.Function):
                     stream = side_stream(dev)
                     stream.wait_stream(main)
                 with torch.cuda.stream(stream):
+                    tb = chunk_plan(idxs, False) if (kind == "main" and alone) else None
+                    if tb is not None:
+                        wgrad_stream(dev, 0).wait_stream(stream)
                     for l in range(L):
-                        level_fwd(l, idxs, False)
-                        level_fwd(l, idxs, True)
+                        if l == 0 or tb is None:
+                            level_fwd(l, idxs, False)
+                        need = level_fwd(l, idxs, True, progress=tb if l + 1 < L else None)
+                        if tb is not None and l + 1 < L:
+                            proj_pieces(l + 1, idxs, tb, need, stream)
             for kind, _ in groups:
                 if kind == "side":
                     main.wait_stream(side_stream(dev))
@@ -921,11 +1095,13 @@ class _MultiBiGRU(torch.autograd.Function):
         prec = ctx.prec
         # fp16x3 products: every backward scan raises one magnitude slot per direction (max |dgx|, |dgh|); the inputs' and the
         # weights' slots come from the forward pass, the recurrent states are GRU outputs (|h| <= 1)
-        bslots = amax_slots(2 * L * n_stacks, dev) if fslots is not None else None
+        # (per scan: [0] the whole scan, [1 + j] the j-th time window in the order the scan walks them -- written by launches with progress marks)
+        NSL = _CHUNK_WINDOWS + 1
+        bslots = amax_slots(2 * L * n_stacks * NSL, dev) if fslots is not None else None
         one = amax_one(dev)
 
-        def bslot(l, s, d):
-            return None if bslots is None else bslots.data_ptr() + 8 * ((l * n_stacks + s) * 2 + d)
+        def bslot(l, s, d, j=-1):
+            return None if bslots is None else bslots.data_ptr() + 8 * (((l * n_stacks + s) * 2 + d) * NSL + 1 + j)
 
         def fslot_x(l, s):
             return None if fslots is None else (fslots.data_ptr() + 8 * s if l == 0 else one)
@@ -933,7 +1109,55 @@ class _MultiBiGRU(torch.autograd.Function):
         def fslot_w(l, s, d):
             return None if fslots is None else fslots.data_ptr() + 8 * (n_stacks + (l * n_stacks + s) * 2 + d)
 
-        def level_scan(l, idxs, after=None, wide=False):
+        def chunk_plan(l, idxs):
+            """time bounds for the direction-split, time-chunked data gradients of level l (stacks idxs, one H), or None"""
+            if bslots is None or len({Hs[i] for i in idxs}) != 1 or 2 * len(idxs) > M3T_MAX_SCANS or not any(need_dx[l][s] for s in idxs):
+                return None
+            H = Hs[idxs[0]]
+            if H % 64 != 0 or any(need_dx[l][s] and layer_io(l, s)[0].shape[-1] % 64 != 0 for s in idxs) or not direct_whh:
+                return None
+            fl = _scan_flags(dev) | prec | _lib.M3T_SCAN_WHH | _lib.M3T_SCAN_WIDE
+            if not lib().m3t_gru_scan_progress_ok(2 * len(idxs), H, B, T, fl, 1):
+                return None
+            tb = _chunk_bounds(B, T)
+            return tb if (tb is not None and len(tb) + 1 <= _CHUNK_WINDOWS) else None
+
+        def dx_pieces(l, idxs, tb, need, scan_stream):
+            """level l's data gradients dX = dgx_fwd W_ih_fwd + dgx_rev W_ih_rev as (direction x time window) pieces on weight-gradient stream 1
+            (idle while the chain's scans run), each behind the progress mark of the backward scan that writes its dgx; `scan_stream` waits
+            for the last piece.  The backward scan of the FORWARD direction walks time downwards."""
+            wg = wgs[1]
+            ctr = _progress_counters(dev)
+            ev_end = torch.cuda.Event()
+            ev_end.record(scan_stream)
+            lo, hi = [0] + tb, tb + [T]
+            n = len(tb)
+            with torch.cuda.stream(wg):
+                ended = False
+                for dirn, k, w, second in _arrivals(tb, T):
+                    if k is None:
+                        if not ended:
+                            wg.wait_event(ev_end)
+                            ended = True
+                    else:
+                        _wait_progress(ctr, dirn, need[dirn * n + k])
+                    d = 1 - dirn                                   # up-walking backward scans belong to the reverse direction
+                    j = w if dirn == 0 else n - w                  # the window's index in the order that scan walks them (its magnitude slot)
+                    for si in idxs:
+                        if not need_dx[l][si]:
+                            continue
+                        H = Hs[si]
+                        I = layer_io(l, si)[0].shape[-1]
+                        sgemm_window(0, B, hi[w] - lo[w], T, lo[w], I, 3 * H, dgx[l][si], d * 3 * H, 6 * H, params[si][(2 * l + d) * 4], 0, I,
+                                     dinp[l][si], 0, I, accumulate=second, prec=prec, amax=(bslot(l, si, d, j), fslot_w(l, si, d)))
+                ev = torch.cuda.Event()
+                ev.record(wg)
+            scan_stream.wait_event(ev)
+            for si in idxs:
+                if need_dx[l][si]:
+                    cur[si] = dinp[l][si]
+
+        def level_scan(l, idxs, after=None, wide=False, progress=None):
             """every BACKWARD level asks for the wide form (the library applies it where it exists: H = 512 in the fp16x3 mode), not only
             the level that makes room for the audio scans: the wide backward kernel is no slower than the narrow one on half the CUs
             (fusion level 3.15 vs 3.30 us per step, exchange served by one XCD's L2) and the weight-gradient GEMMs get the rest;
@@ -954,14 +1178,23 @@ class _MultiBiGRU(torch.autograd.Function):
                                             _vp(dgx[l][s]), _vp(dgh[l][s], d * B * T * 3 * H), _vp(dh[l][s], d * B * H),
                                             _vp(dbp[l][s], d * B * 4 * H), _vp(out_grads[base + 2]), _vp(out_grads[base + 3]),
                                             H, d, out.stride(1), d * H, 6 * H, d * 3 * H, bslot(l, s, d)))      # (dout and out share the layout)
-            _scan_bwd(descs, B, T, prec | (_lib.M3T_SCAN_WHH if direct_whh else 0) | _lib.M3T_SCAN_WIDE, after)
+            need = _scan_bwd(descs, B, T, prec | (_lib.M3T_SCAN_WHH if direct_whh else 0) | _lib.M3T_SCAN_WIDE, after,
+                             None if progress is None else (_progress_counters(dev), progress))
+            if progress is not None:
+                pending[(l, tuple(idxs))] = (progress, need)
             if RANGE_PROBE[0] is not None:
                 for s in idxs:
                     for d in (0, 1):
                         _probe_range("dgx l%d s%d d%d H%d" % (l, s, d, Hs[s]), dgx[l][s].view(B * T, 6 * Hs[s])[:, d * 3 * Hs[s]:(d + 1) * 3 * Hs[s]])
                         _probe_range("dgh l%d s%d d%d H%d" % (l, s, d, Hs[s]), dgh[l][s][d].view(B * T, 3 * Hs[s]))
 
+        pending = {}                       # (l, idxs) -> (time bounds, need) of a scan launched with progress marks
+
         def level_dx(l, idxs):           # on the chain: feeds the next level's scan
+            pg = pending.pop((l, tuple(idxs)), None)
+            if pg is not None:           # round 5: the pieces run under the scan; what is left behind it is the last window of each direction
+                dx_pieces(l, idxs, pg[0], pg[1], torch.cuda.current_stream())
+                return
             for s in idxs:
                 H = Hs[s]
                 inp, out, gts = layer_io(l, s)
@@ -1038,7 +1271,7 @@ class _MultiBiGRU(torch.autograd.Function):
             level_dx(l, idxs)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
-            for w_ in wgs:
+            for w_ in (wgs if last else wgs[:1]):      # (the streams level_dw uses: stream 1 carries the chunked data gradients of the chain)
                 w_.wait_event(ev)
             level_dw(l, idxs, spread=last)
 
@@ -1051,7 +1284,7 @@ class _MultiBiGRU(torch.autograd.Function):
             _FENCED[0] = True
             try:
                 for l in range(L - 1, -1, -1):
-                    level_scan(l, heavy, None, True)
+                    level_scan(l, heavy, None, True, chunk_plan(l, heavy))
                     with torch.cuda.stream(side):
                         level_scan(l, light)
                     level_gemms(l, heavy, last=(l == 0))
@@ -1112,7 +1345,7 @@ class _MultiBiGRU(torch.autograd.Function):
                     stream.wait_stream(main)
                 with torch.cuda.stream(stream):
                     for l in range(L - 1, -1, -1):
-                        level_scan(l, idxs)
+                        level_scan(l, idxs, progress=chunk_plan(l, idxs) if (kind == "main" and len(groups) == 1) else None)
                         level_gemms(l, idxs)
             for kind, _ in groups:
                 if kind == "side":
@@ -1276,8 +1509,10 @@ def btc_to_bct(x):
     return _BtcToBct.apply(x)
 
 
-def _conv(x, w_t, bias, res, mask, pre, B, T, Ci, Co, K, dil, act, anti, prec=0, drop=(0.0, 0), amax=(None, None)):
+def _conv(x, w_t, bias, res, mask, pre, B, T, Ci, Co, K, dil, act, anti, prec=0, drop=(0.0, 0), amax=(None, None), amax_y=None):
+    """amax_y: address of a magnitude slot the epilogue raises to max |y| (armed AFTER the output allocation)"""
     y = torch.empty(B, T, Co, dtype=torch.float32, device=x.device)
+    amax_out(amax_y)
     rc = lib().m3t_conv1d_fwd_scaled(_p(x), _p(w_t), _p(bias), _p(res), _p(mask), _p(y), _p(pre), B, T, Ci, Co, K, dil, 0,
                                      act, anti, float(drop[0]), int(drop[1]), prec, amax[0], amax[1], _stream())
     _lib.check(rc, "m3t_conv1d_fwd")
@@ -1324,17 +1559,15 @@ class _TemporalBlock(torch.autograd.Function):
         _lib.check(lib().m3t_weight_norm_fwd(_p(v2), _p(g2), _p(w2t), _p(n2), Co, Co, K, _stream()), "m3t_weight_norm_fwd")
         if slots is not None:
             ok.update((1, 2))
-            x_ext = _EXT_SLOT.pop(id(x), None)            # (slots tensor, index) left by the producer of x (the previous block's epilogue)
-            if x_ext is not None and x_ext[2] is not x:
-                x_ext = None
+            x_ext = _X_EXT[0]                             # (slots tensor, index) left on x by its producer (the previous block's epilogue)
             todo = ([] if x_ext is not None else [(x, sp)]) + ([(wd, sp + 24)] if wd is not None else [])
             if todo and measure_amax(todo):
                 ok.update(([] if x_ext is not None else [0]) + ([3] if wd is not None else []))
         sl = lambda i: ((x_ext[0].data_ptr() + 8 * x_ext[1]) if (i == 0 and x_ext is not None) else
                         (sp + 8 * i) if (slots is not None and i in ok) else None)
         ctx.x_ext = x_ext
-        amax_out(sp + 32 if slots is not None else None)
-        h1 = _conv(x, w1t, b1, None, m1, None, B, T, Ci, Co, K, dilation, 1, 0, prec, d1, amax=(sl(0), sl(1)))
+        h1 = _conv(x, w1t, b1, None, m1, None, B, T, Ci, Co, K, dilation, 1, 0, prec, d1, amax=(sl(0), sl(1)),
+                   amax_y=sp + 32 if slots is not None else None)
         if slots is not None:
             ok.add(4)
         if wd is not None:
@@ -1344,8 +1577,8 @@ class _TemporalBlock(torch.autograd.Function):
             res = x
         ctx.slots_ok = ok
         a2 = torch.empty(B, T, Co, dtype=torch.float32, device=dev)
-        amax_out(sp + 64 if slots is not None else None)
-        y = _conv(h1, w2t, b2, res, m2, a2, B, T, Co, Co, K, dilation, 2, 0, prec, d2, amax=(sl(4), sl(2)))
+        y = _conv(h1, w2t, b2, res, m2, a2, B, T, Co, Co, K, dilation, 2, 0, prec, d2, amax=(sl(4), sl(2)),
+                  amax_y=sp + 64 if slots is not None else None)
         if slots is not None:
             _LAST_OUT_SLOT[0] = (slots, 8)                 # temporal_block() hands it to whoever consumes y
         ctx.save_for_backward(x, v1, g1, v2, g2, wd, w1t, w2t, n1, n2, h1, a2, y, m1, m2, slots)
@@ -1453,17 +1686,19 @@ def temporal_block(x_btc, v1, g1, b1, v2, g2, b2, wd, bd, dilation, m1=None, m2=
     """m1 / m2: explicit pre-scaled dropout masks, or drop_p > 0 with two 64-bit seeds: masks generated inside the conv epilogues
     (Philox4x32-10, include/m3t_hip.h) and regenerated in backward"""
     _LAST_OUT_SLOT[0] = None
-    y = _TemporalBlock.apply(x_btc, v1, g1, b1, v2, g2, b2, wd, bd, dilation, m1, m2, float(drop_p), int(seeds[0]), int(seeds[1]))
+    _X_EXT[0] = getattr(x_btc, "_m3t_amax", None) if x_btc.is_contiguous() else None      # (autograd hands forward() a detached alias: read it here)
+    try:
+        y = _TemporalBlock.apply(x_btc, v1, g1, b1, v2, g2, b2, wd, bd, dilation, m1, m2, float(drop_p), int(seeds[0]), int(seeds[1]))
+    finally:
+        _X_EXT[0] = None
     if _LAST_OUT_SLOT[0] is not None:                # the conv epilogue raised max |y|: the next block takes it instead of measuring x
-        if len(_EXT_SLOT) > 64:
-            _EXT_SLOT.clear()
-        _EXT_SLOT[id(y)] = _LAST_OUT_SLOT[0] + (y,)
+        y._m3t_amax = _LAST_OUT_SLOT[0]              # travels ON the tensor and dies with it (ADVICE r4: no registry holding activations alive)
         _LAST_OUT_SLOT[0] = None
     return y
 
 
 _LAST_OUT_SLOT = [None]     # (slots tensor, index) of the last _TemporalBlock forward's output
-_EXT_SLOT = {}              # id(tensor) -> (slots tensor, index, tensor): magnitude slots that travel with a producer's output tensor
+_X_EXT = [None]             # the magnitude slot found on the input tensor of the temporal_block() call in progress (x._m3t_amax)
 
 
 class _ConvBnRelu(torch.autograd.Function):
@@ -1861,10 +2096,12 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
             rows = dyc.numel() // Co
             dy_cl = torch.empty(rows, Co, dtype=torch.float32, device=dy.device)
             slot_dy = amax_slots(1, dy.device)
-            amax_out(slot_dy.data_ptr())
             Nn, Sp = dyc.shape[0], rows // dyc.shape[0]
-            if ctx.has_bias and ctx.needs_input_grad[2]:      # the bias gradient's per-tile channel sums ride along
+            with_sums = ctx.has_bias and ctx.needs_input_grad[2]
+            if with_sums:
                 dpart = torch.empty(Nn * ((Sp + 31) // 32), Co, dtype=torch.float32, device=dy.device)
+            amax_out(slot_dy.data_ptr())                      # (armed after every allocation, consumed by the very next call)
+            if with_sums:      # the bias gradient's per-tile channel sums ride along
                 _lib.check(lib().m3t_bct_to_btc_sums(_p(dyc), _p(dy_cl), Nn, Co, Sp, _p(dpart), _stream()), "m3t_bct_to_btc_sums")
             else:
                 _lib.check(lib().m3t_bct_to_btc(_p(dyc), _p(dy_cl), Nn, Co, Sp, _stream()), "m3t_bct_to_btc")

@@ -1,0 +1,135 @@
+"""Direction-split, time-chunked hand-offs around the persistent BiGRU scans (round 5).
+
+Layer l+1's input projection is out_fwd W_ih[:, :H]^T + out_rev W_ih[:, H:]^T (reference models/rnn.py:17,75: nn.GRU(bidirectional=True)
+feeds [out_fwd | out_rev] to the next layer) and each half is final for the frames its direction's scan has passed; in backward the data
+gradient is dgx_fwd W_ih_fwd + dgx_rev W_ih_rev.  The scan launches publish progress marks, gate kernels hold the consumer stream, and
+m3t_sgemm_window multiplies one direction's half over one time window while the scan is still running.  Checked here:
+  * the windowed contraction against fp64 (rows outside the window untouched, accumulate, bias, both B layouts);
+  * the chunked schedule against the unchunked one (ops.CHUNKS) on FRESH inputs every iteration at recycled addresses -- a consumer that
+    read a window before its producer had written it would read the previous iteration's values -- and bit-identical reruns;
+  * that the default C3 step really takes the chunked path (gate launches counted through the window GEMM's wrapper).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rand(rs, *shape, scale=1.0):
+    return torch.from_numpy((rs.standard_normal(shape) * scale).astype(np.float32)).to(DEV)
+
+
+@pytest.mark.parametrize("transB", [1, 0])
+def test_sgemm_window_against_fp64(transB):
+    from m3t import ops
+    rs = np.random.RandomState(5)
+    B, T, K, N, ldA, ldC = 32, 300, 512, 1536, 1024, 3072
+    A = _rand(rs, B, T, ldA)
+    W = _rand(rs, N, 2 * K, scale=0.05) if transB else _rand(rs, K, N, scale=0.05)
+    bias = _rand(rs, N)
+    a_off, c_off = 512, 1536                                     # a column slice of A (one direction's half), a column block of C
+    for (t0, t1) in ((0, 76), (76, 152), (224, 300)):
+        Cm = torch.full((B, T, ldC), 7.0, device=DEV)
+        with ops.precision("fp32"):
+            ops.sgemm_window(transB, B, t1 - t0, T, t0, N, K, A, a_off, ldA, W, K if transB else 0, 2 * K if transB else N, Cm, c_off, ldC,
+                             bias=bias)
+        a64 = A[:, t0:t1, a_off:a_off + K].double()
+        w64 = (W[:, K:2 * K].double().t() if transB else W.double())
+        ref = a64 @ w64 + bias.double()
+        got = Cm[:, t0:t1, c_off:c_off + N].double()
+        err = float((got - ref).abs().max()) / float(ref.abs().max())
+        assert err < 2e-6, err
+        keep = torch.ones(B, T, ldC, dtype=torch.bool, device=DEV)
+        keep[:, t0:t1, c_off:c_off + N] = False
+        assert bool((Cm[keep] == 7.0).all()), "rows / columns outside the window were written"
+        # second arriver: accumulates onto what is there, no bias
+        with ops.precision("fp32"):
+            ops.sgemm_window(transB, B, t1 - t0, T, t0, N, K, A, a_off, ldA, W, K if transB else 0, 2 * K if transB else N, Cm, c_off, ldC,
+                             accumulate=True)
+        got2 = Cm[:, t0:t1, c_off:c_off + N].double()
+        err2 = float((got2 - (2 * ref - bias.double())).abs().max()) / float(ref.abs().max())
+        assert err2 < 4e-6, err2
+    # the six-product form takes the same path
+    Cm = torch.zeros(B, T, ldC, device=DEV)
+    with ops.precision("x6"):
+        ops.sgemm_window(transB, B, 76, T, 76, N, K, A, a_off, ldA, W, K if transB else 0, 2 * K if transB else N, Cm, c_off, ldC)
+    ref = A[:, 76:152, a_off:a_off + K].double() @ (W[:, K:2 * K].double().t() if transB else W.double())
+    assert float((Cm[:, 76:152, c_off:c_off + N].double() - ref).abs().max()) / float(ref.abs().max()) < 2e-6
+
+
+def test_sgemm_window_refuses_what_it_cannot_tile():
+    from m3t import ops
+    from m3t._lib import M3THipError
+    A = torch.zeros(32, 300, 512, device=DEV)
+    W = torch.zeros(1536, 512, device=DEV)
+    Cm = torch.zeros(32, 300, 1536, device=DEV)
+    with pytest.raises(M3THipError):
+        ops.sgemm_window(1, 32, 75, 300, 0, 1536, 512, A, 0, 512, W, 0, 512, Cm, 0, 1536)       # 32 x 75 rows: no whole 128-row tiles
+    with pytest.raises(M3THipError):
+        ops.sgemm_window(1, 32, 76, 300, 228, 1536, 512, A, 0, 512, W, 0, 512, Cm, 0, 1536)      # the window leaves the clip
+
+
+def _stacks(rs, specs, B, T, L=2):
+    """specs: [(I, H)] -> ([x], [flat parameter list]) with leaf tensors"""
+    xs, prms = [], []
+    for I, H in specs:
+        xs.append(_rand(rs, B, T, I).requires_grad_(True))
+        p = []
+        for l in range(L):
+            il = I if l == 0 else 2 * H
+            for _ in (0, 1):
+                p += [_rand(rs, 3 * H, il, scale=(2.0 / (il + H)) ** 0.5).requires_grad_(True),
+                      _rand(rs, 3 * H, H, scale=H ** -0.5).requires_grad_(True),
+                      _rand(rs, 3 * H, scale=0.1).requires_grad_(True), _rand(rs, 3 * H, scale=0.1).requires_grad_(True)]
+        prms.append(p)
+    return xs, prms
+
+
+def _run(ops, xs, prms, douts, cat=None, L=2):
+    for t in xs + [q for p in prms for q in p]:
+        t.grad = None
+    res = ops.multi_bigru([(x, p, L) for x, p in zip(xs, prms)], cat=cat)
+    outs = [o for o, _ in res if o.numel()]
+    loss = sum((o * d).sum() for o, d in zip(outs, douts))
+    loss.backward()
+    torch.cuda.synchronize()
+    ops.poll_scan_error()
+    return [o.detach().clone() for o in outs], [t.grad.detach().clone() for t in xs + [q for p in prms for q in p]]
+
+
+@pytest.mark.parametrize("specs,cat", [([(128, 256), (256, 512), (256, 512)], (1, 3)),      # the C3 encoder level: audio | gru_v, gru_a
+                                       ([(512, 512)], None)])                              # the fusion GRU
+def test_chunked_schedule_matches_unchunked_on_fresh_inputs(specs, cat):
+    from m3t import ops
+    B, T = 32, 300
+    assert ops._chunk_bounds(B, T) is not None
+    calls = []
+    real = ops.sgemm_window
+    ops.sgemm_window = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        for it in range(3):
+            rs = np.random.RandomState(100 + it)
+            xs, prms = _stacks(rs, specs, B, T)
+            widths = [2 * specs[0][1]] + ([sum(2 * h for _, h in specs[1:])] if cat else [2 * h for _, h in specs[1:]])
+            douts = [_rand(rs, B, T, w, scale=1e-2) for w in widths]
+            ops.CHUNKS[0] = True
+            n0 = len(calls)
+            y1, g1 = _run(ops, xs, prms, douts, cat)
+            assert len(calls) > n0, "the chunked path did not run"
+            y1b, g1b = _run(ops, xs, prms, douts, cat)
+            ops.CHUNKS[0] = False
+            n1 = len(calls)
+            y0, g0 = _run(ops, xs, prms, douts, cat)
+            assert len(calls) == n1
+            for a, b in zip(y1 + g1, y1b + g1b):
+                assert torch.equal(a, b), "chunked reruns differ: the result depends on timing"
+            for a, b in zip(y1, y0):
+                assert float((a - b).abs().max()) < 2e-6
+            for a, b in zip(g1, g0):
+                sc = float(b.abs().max()) + 1e-30
+                assert float((a - b).abs().max()) / sc < 2e-5, float((a - b).abs().max()) / sc
+    finally:
+        ops.CHUNKS[0] = True
+        ops.sgemm_window = real
