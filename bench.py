@@ -595,6 +595,20 @@ def worker(args):
         k["bytes"] += rec.get("bytes", 0.0)
         k["steps"] += rec.get("steps", rec["launches"])
     step_ms = dt / args.steps * 1e3
+    if os.environ.get("M3T_BENCH_SCAN_TIMELINE") == "1" and ops.PROFILE:
+        # debugging: where the scans of the LAST profiled step sit on the device's clock WITHOUT a profiler attached (rocprofv3 slows the
+        # host enough to open host-bound holes that the untraced step does not have): offsets from the step's first recorded launch
+        recs = [r for r in ops.PROFILE if r["kernel"].startswith("gru_") or r["kernel"] in ("att_fuse_fwd_kernel", "va_loss_kernels")]
+        per = len(recs) // max(1, timed_steps)
+        last = recs[-per:] if per else []
+        if last:
+            t0e = last[0]["start"]
+            rows = sorted((t0e.elapsed_time(r["start"]), t0e.elapsed_time(r["end"]), r["kernel"]) for r in last)
+            prev_end = None
+            for a, b, kname in rows:
+                print("# tl %8.3f -> %8.3f  %6.3f ms  %s" % (a, b, b - a, kname), file=sys.stderr)
+            print("# tl step (first recorded launch to the same launch of the next profiled step is not recorded; ms_per_step %.3f)" % step_ms,
+                  file=sys.stderr, flush=True)
     roofline, breakdown = None, {}
     for name, k in kern.items():
         breakdown[name] = {"ms_per_step": round(k["ms"] / timed_steps, 3), "launches_per_step": k["launches"] // timed_steps,

@@ -139,6 +139,17 @@ int m3t_sgemm_scaled(int transA, int transB, int M, int N, int K,
 int m3t_sgemm_window(int transB, int n_seg, int win_len, int win_stride, int win_off, int N, int K,
                      const float* A, int lda, const float* B, int ldb, float* C, int ldc, const float* bias,
                      int act, int accumulate, int flags, const unsigned long long* amax_a, const unsigned long long* amax_b, void* stream);
+/* ... and up to M3T_WINDOW_BATCH such problems of ONE shape (same window, N, K, leading dimensions, act) as one launch: the pieces that become
+ * ready at one progress mark -- every (stack, direction) pair reading that window -- fill the CUs a scan leaves free as one grid instead of
+ * a queue of under-filled launches.  With n > 1 every problem must bring its magnitude slots in the fp16x3 mode. */
+#define M3T_WINDOW_BATCH 8
+typedef struct {
+    const float* A; const float* B; float* C; const float* bias;          /* bias may be NULL */
+    const unsigned long long* amax_a; const unsigned long long* amax_b;
+    int accumulate;
+} m3t_window_problem;
+int m3t_sgemm_window_batch(int n, const m3t_window_problem* problems, int transB, int n_seg, int win_len, int win_stride, int win_off,
+                           int N, int K, int lda, int ldb, int ldc, int act, int flags, void* stream);
 
 /* slots[i] = max(slots[i], bits of max |x| over x[i] = [rows[i] x cols[i]] fp32 with leading dimension ld[i]) for n <= 16 tensors in
  * ONE launch (cols % 4 == 0, ld % 4 == 0, 16-B aligned).  The caller zero-initialises a slot before its first use. */
@@ -226,7 +237,19 @@ typedef struct {
     float* db_hh;         /* dn~*r) -- the bias gradients, without a pass over dgx / dgh (all three NULL = skip)    */
     int H, reverse, ldo, ooff, ldg, goff;
     unsigned long long* amax;  /* optional magnitude slot (m3t_sgemm_scaled): raised to the bits of max |dgx|, |dgh| of this scan */
+    const float* wfrag;        /* optional: W_hh already in the backward scan's fragment order (m3t_gru_bwd_prepare) -- the launch then   */
+                               /* runs no preparation kernel in front of the scan; used only when EVERY scan of the call brings one       */
 } m3t_gru_bwd_desc;
+
+/* W_hh does not change between the forward and the backward pass of a step: the backward scans' weight re-layout (one launch in front of
+ * every backward scan, on the critical chain) can be done any time after the weights are final -- e.g. on an idle stream during the forward
+ * pass.  m3t_gru_bwd_prepare writes, for n <= M3T_MAX_SCANS scans of one H, the fragments the wide producer-split backward kernel reads
+ * (two fp16 terms of the per-slice scaled W_hh^T + the slices' inverse scales) into out[i] (m3t_gru_bwd_prepare_floats(H) floats each, 16-B
+ * aligned); whh_direct = 1: w[i] is W_hh [3H, H] as stored (M3T_SCAN_WHH), 0: its transpose [H, 3H].  A later m3t_gru_scan_bwd whose descs
+ * all carry desc.wfrag = out[i] and whose launch takes that kernel (m3t_gru_scan_progress_ok(..., backward = 1) says so) skips its own
+ * preparation; any other launch ignores the field.  H % 256 == 0. */
+size_t m3t_gru_bwd_prepare_floats(int H);
+int m3t_gru_bwd_prepare(const float* const* w, int n, int H, int whh_direct, float* const* out, void* stream);
 
 /* Workgroups (= CUs: a scan workgroup owns its CU) that m3t_gru_scan_fwd (backward = 0) / m3t_gru_scan_bwd (backward = 1) would hold
  * resident for ONE persistent launch over n_scans scans of hidden size H at batch B with `flags`; 0 when that level does not run as a

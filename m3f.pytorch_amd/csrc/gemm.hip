@@ -692,37 +692,48 @@ extern "C" int m3t_sgemm_scaled(int transA, int transB, int M, int N, int K, con
     return 0;
 }
 
-int m3t_sgemm_x6_window_launch(int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                               const float* bias, int act, int accumulate, int mw_len, int mw_stride, int mw_off, int f16x3, int narrow,
-                               const unsigned long long* amax_a, const unsigned long long* amax_b, hipStream_t s);
+int m3t_sgemm_x6_window_launch(int n, const m3t_window_problem* pr, int transB, int M, int N, int K, int lda, int ldb, int ldc,
+                               int act, int mw_len, int mw_stride, int mw_off, int f16x3, int narrow, hipStream_t s);
 
-// include/m3t_hip.h: the contraction over a TIME WINDOW of a [B, T, *] pair (A rows, C rows)
+// include/m3t_hip.h: the contraction over a TIME WINDOW of batch-major sequence tensors (A rows, C rows), n problems of one shape per launch
+extern "C" int m3t_sgemm_window_batch(int n, const m3t_window_problem* pr, int transB, int n_seg, int win_len, int win_stride, int win_off,
+                                      int N, int K, int lda, int ldb, int ldc, int act, int flags, void* stream) {
+    if (n <= 0 || n_seg <= 0 || win_len <= 0 || N <= 0) return 0;
+    if (n > M3T_WINDOW_BATCH || !pr || K <= 0 || win_stride < win_len || win_off < 0 || win_off + win_len > win_stride) return M3T_EINVAL;
+    const long long Ml = (long long)n_seg * win_len;
+    if (Ml > 0x7fffffffll || (long long)n_seg * win_stride > 0x7fffffffll) return M3T_EINVAL;
+    const int M = (int)Ml;
+    // only the 16-bit-term tile kernel has the windowed form: whole 128-row tiles, N in 64-column tiles, 32-deep k tiles
+    if (!x6_enabled() || M % 128 != 0 || N % 64 != 0 || K % 32 != 0 || lda % 4 != 0 || ldb % 4 != 0 || (flags & (M3T_GEMM_BF16 | M3T_GEMM_HIGH)))
+        return M3T_EINVAL;
+    const int f16x3 = ((flags & M3T_GEMM_F16X3) && m3t_f16x3_enabled()) ? 1 : 0;
+    hipStream_t s = (hipStream_t)stream;
+    m3t_window_problem use[M3T_WINDOW_BATCH];
+    for (int i = 0; i < n; ++i) {
+        use[i] = pr[i];
+        if (!use[i].A || !use[i].B || !use[i].C || (uintptr_t)use[i].A % 16 != 0 || (uintptr_t)use[i].B % 16 != 0) return M3T_EINVAL;
+        if (f16x3 && (!use[i].amax_a || !use[i].amax_b)) {
+            // an operand without a slot is measured over the rows the window's first to last storage row span (a superset): one
+            // measuring launch per such problem (the hot path always brings its slots)
+            if (n > 1) return M3T_EINVAL;
+            const size_t span = (size_t)(n_seg - 1) * win_stride + win_len;
+            const M3TRegion ra{use[i].A + (size_t)win_off * lda, (unsigned long long)span, (unsigned long long)lda, K / 4, nullptr};
+            const M3TRegion rb{use[i].B, (unsigned long long)(transB ? (size_t)N : (size_t)K), (unsigned long long)ldb, (transB ? K : N) / 4, nullptr};
+            const int rm = m3t_f16x3_measure(ra, use[i].amax_a, rb, use[i].amax_b, &use[i].amax_a, &use[i].amax_b, s);
+            if (rm) return rm;
+        }
+    }
+    // 128 x 64 tiles when 128 x 128 ones would not give every CU a workgroup or two
+    const int narrow = (N % 128 != 0 || (long long)(M / 128) * (N / 128) * n <= 384) ? 1 : 0;
+    return m3t_sgemm_x6_window_launch(n, use, transB ? 1 : 0, M, N, K, lda, ldb, ldc, act, win_len, win_stride, win_off, f16x3, narrow, s);
+}
+
 extern "C" int m3t_sgemm_window(int transB, int n_seg, int win_len, int win_stride, int win_off, int N, int K,
                                 const float* A, int lda, const float* B, int ldb, float* C, int ldc, const float* bias,
                                 int act, int accumulate, int flags, const unsigned long long* amax_a, const unsigned long long* amax_b,
                                 void* stream) {
-    if (n_seg <= 0 || win_len <= 0 || N <= 0) return 0;
-    if (!A || !B || !C || K <= 0 || win_stride < win_len || win_off < 0 || win_off + win_len > win_stride) return M3T_EINVAL;
-    const long long Ml = (long long)n_seg * win_len;
-    if (Ml > 0x7fffffffll || (long long)n_seg * win_stride > 0x7fffffffll) return M3T_EINVAL;
-    const int M = (int)Ml;
-    const bool vec = (lda % 4 == 0) && ((uintptr_t)A % 16 == 0) && (ldb % 4 == 0) && ((uintptr_t)B % 16 == 0);
-    // only the 16-bit-term tile kernel has the windowed form: whole 128-row tiles, N in 64-column tiles, 32-deep k tiles
-    if (!x6_enabled() || !vec || M % 128 != 0 || N % 64 != 0 || K % 32 != 0 || (flags & (M3T_GEMM_BF16 | M3T_GEMM_HIGH))) return M3T_EINVAL;
-    const int f16x3 = ((flags & M3T_GEMM_F16X3) && m3t_f16x3_enabled()) ? 1 : 0;
-    hipStream_t s = (hipStream_t)stream;
-    const unsigned long long* use_a = amax_a; const unsigned long long* use_b = amax_b;
-    if (f16x3) {
-        // an operand without a slot is measured over the rows the window's first to last storage row span (a superset)
-        const size_t span = (size_t)(n_seg - 1) * win_stride + win_len;
-        const M3TRegion ra{A + (size_t)win_off * lda, (unsigned long long)span, (unsigned long long)lda, K / 4, nullptr};
-        const M3TRegion rb{B, (unsigned long long)(transB ? (size_t)N : (size_t)K), (unsigned long long)ldb, (transB ? K : N) / 4, nullptr};
-        const int rm = m3t_f16x3_measure(ra, amax_a, rb, amax_b, &use_a, &use_b, s);
-        if (rm) return rm;
-    }
-    const int narrow = (N % 128 != 0 || (M / 128) * (N / 128) <= 384) ? 1 : 0;
-    return m3t_sgemm_x6_window_launch(transB ? 1 : 0, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, win_len, win_stride, win_off,
-                                      f16x3, narrow, use_a, use_b, s);
+    const m3t_window_problem pr{A, B, C, bias, amax_a, amax_b, accumulate};
+    return m3t_sgemm_window_batch(1, &pr, transB, n_seg, win_len, win_stride, win_off, N, K, lda, ldb, ldc, act, flags, stream);
 }
 
 extern "C" int m3t_colsum(const float* X, int M, int N, int ld, float* out, int accumulate, float* ws, size_t ws_bytes,

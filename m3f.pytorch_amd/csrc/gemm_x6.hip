@@ -46,6 +46,13 @@ struct X6Params {
     // a TIME WINDOW [mw_off, mw_off + mw_len) of every clip of a [B, T, C] tensor (mw_stride = T)
     int mw_len, mw_stride, mw_off;
 };
+// MW kernels run up to M3T_WINDOW_BATCH problems of one shape in one launch (blockIdx.z = problem): the pieces of one progress mark
+// (m3t_sgemm_window_batch) -- every (stack, direction) pair that reads the same window -- fill the CUs a scan leaves free as ONE grid
+struct X6Batch {
+    const float* A[M3T_WINDOW_BATCH]; const float* B[M3T_WINDOW_BATCH]; float* C[M3T_WINDOW_BATCH]; const float* bias[M3T_WINDOW_BATCH];
+    const unsigned long long* amax_a[M3T_WINDOW_BATCH]; const unsigned long long* amax_b[M3T_WINDOW_BATCH];
+    int accumulate[M3T_WINDOW_BATCH];
+};
 
 __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
     h = (__bf16)x;
@@ -161,7 +168,12 @@ __device__ __forceinline__ void mc_store(unsigned char* __restrict__ S, const fl
 // (N = 512 at M = 9600: 300 tiles for 768 slots) -- twice the workgroups, the B operand staged for 64 rows only.
 // MW (TA == 0, no CONV / SEG): A's and C's rows go through the window map of X6Params (a 128-entry table in LDS: one division per thread)
 template <int TA, int TB, bool SEG, int NS, bool CONV = false, int XNT = 128, bool MW = false>
-__global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p) {
+__global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p, X6Batch bt) {
+    if (MW) {                                            // this workgroup's problem of the batch
+        const int z = blockIdx.z;
+        p.A = bt.A[z]; p.B = bt.B[z]; p.C = bt.C[z]; p.bias = bt.bias[z];
+        p.amax_a = bt.amax_a[z]; p.amax_b = bt.amax_b[z]; p.accumulate = bt.accumulate[z];
+    }
     constexpr int NJ = XNT / 64;                     // 32-column MFMA tiles per wave along N
     constexpr int BR = XNT / 32;                     // rows per thread of a K-contiguous B tile
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * OPER_BYTES];   // A | B, 48 KiB
@@ -177,7 +189,7 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p) {
     const int til = xcd * xq + min(xcd, xr) + slot;           // XCD-contiguous tile order (see gemm.hip)
     const int bm = (til / tn_) * XM, bn = (til % tn_) * XNT;
     const bool bcol = XNT == 128 || (tid & 31) < 16;      // row-contiguous B: this thread's 4 columns lie inside the tile
-    const int k_begin = blockIdx.z * p.kchunk;
+    const int k_begin = MW ? 0 : blockIdx.z * p.kchunk;
     const int k_end = min(p.K, k_begin + p.kchunk);
     const int ntiles = (k_end - k_begin) / XK;
     __shared__ int rowmap[MW ? XM : 1];              // MW: storage row of the tile's row i
@@ -373,6 +385,8 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p) {
     }
 }
 
+const X6Batch g_no_batch = {};
+
 }  // namespace
 
 // Launches the bf16x6 kernel; the caller (m3t_sgemm) has verified: M % 128 == 0, N % 128 == 0, K % 32 == 0,
@@ -394,11 +408,11 @@ int m3t_sgemm_x6_launch(int transA, int transB, int M, int N, int K, const float
     dim3 grid(N / (narrow ? 64 : XN), M / XM, splits), block(256);
 #define M3T_X6_DISPATCH(NS_, XNT_)                                                                                                  \
     do {                                                                                                                           \
-        if (seg_len > 0) sgemm_x6_kernel<1, 0, true, NS_, false, XNT_><<<grid, block, dyn_lds, s>>>(p);                            \
-        else if (transA == 0 && transB == 1) sgemm_x6_kernel<0, 1, false, NS_, false, XNT_><<<grid, block, dyn_lds, s>>>(p);      \
-        else if (transA == 0 && transB == 0) sgemm_x6_kernel<0, 0, false, NS_, false, XNT_><<<grid, block, dyn_lds, s>>>(p);      \
-        else if (transA == 1 && transB == 0) sgemm_x6_kernel<1, 0, false, NS_, false, XNT_><<<grid, block, dyn_lds, s>>>(p);      \
-        else sgemm_x6_kernel<1, 1, false, NS_, false, XNT_><<<grid, block, dyn_lds, s>>>(p);                                       \
+        if (seg_len > 0) sgemm_x6_kernel<1, 0, true, NS_, false, XNT_><<<grid, block, dyn_lds, s>>>(p, g_no_batch);                            \
+        else if (transA == 0 && transB == 1) sgemm_x6_kernel<0, 1, false, NS_, false, XNT_><<<grid, block, dyn_lds, s>>>(p, g_no_batch);      \
+        else if (transA == 0 && transB == 0) sgemm_x6_kernel<0, 0, false, NS_, false, XNT_><<<grid, block, dyn_lds, s>>>(p, g_no_batch);      \
+        else if (transA == 1 && transB == 0) sgemm_x6_kernel<1, 0, false, NS_, false, XNT_><<<grid, block, dyn_lds, s>>>(p, g_no_batch);      \
+        else sgemm_x6_kernel<1, 1, false, NS_, false, XNT_><<<grid, block, dyn_lds, s>>>(p, g_no_batch);                                       \
     } while (0)
     // bf16_operands: 1 = bf16 mode (one product), 2 = "high" mode (two bf16 terms per operand, four products), 0 = fp32-accurate (bf16x6)
     // 3 = fp16x3 (two fp16 terms per scaled operand, three products; amax = the operands' magnitude slots)
@@ -412,27 +426,31 @@ int m3t_sgemm_x6_launch(int transA, int transB, int M, int N, int K, const float
     return (int)e;
 }
 
-// C's and A's rows through a time window (MW kernels; m3t_sgemm_window): transA = 0, one K pass (no split-K slabs), fp16x3 or the
-// six-product form.  The caller has verified M % 128 == 0, N % 64 == 0, K % 32 == 0, alignment, mw_len >= 1.
-int m3t_sgemm_x6_window_launch(int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                               const float* bias, int act, int accumulate, int mw_len, int mw_stride, int mw_off, int f16x3, int narrow,
-                               const unsigned long long* amax_a, const unsigned long long* amax_b, hipStream_t s) {
+// C's and A's rows through a time window (MW kernels; m3t_sgemm_window / _batch): transA = 0, one K pass (no split-K slabs), fp16x3 or the
+// six-product form, n problems of one shape per launch.  The caller has verified M % 128 == 0, N % 64 == 0, K % 32 == 0, alignment, mw_len >= 1.
+int m3t_sgemm_x6_window_launch(int n, const m3t_window_problem* pr, int transB, int M, int N, int K, int lda, int ldb, int ldc,
+                               int act, int mw_len, int mw_stride, int mw_off, int f16x3, int narrow, hipStream_t s) {
     X6Params p;
-    p.amax_a = amax_a; p.amax_b = amax_b;
-    if (f16x3 && (!amax_a || !amax_b)) return M3T_EINVAL;
-    p.A = A; p.B = B; p.C = C; p.bias = bias; p.ws = nullptr;
+    X6Batch bt = {};
+    for (int i = 0; i < n; ++i) {
+        if (f16x3 && (!pr[i].amax_a || !pr[i].amax_b)) return M3T_EINVAL;
+        bt.A[i] = pr[i].A; bt.B[i] = pr[i].B; bt.C[i] = pr[i].C; bt.bias[i] = pr[i].bias;
+        bt.amax_a[i] = pr[i].amax_a; bt.amax_b[i] = pr[i].amax_b; bt.accumulate[i] = pr[i].accumulate;
+    }
+    p.amax_a = p.amax_b = nullptr;
+    p.A = p.B = nullptr; p.C = nullptr; p.bias = nullptr; p.ws = nullptr;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
-    p.act = act; p.accumulate = accumulate; p.splits = 1; p.kchunk = K;
+    p.act = act; p.accumulate = 0; p.splits = 1; p.kchunk = K;
     p.seg_len = p.seg_stride = p.a_off = p.b_off = 0;
     p.cv_T = p.cv_C = p.cv_K = p.cv_dil = p.cv_lead = p.cv_anti = 0; p.cv_btap = 0; p.cv_mask = p.cv_res = nullptr; p.cv_pre = nullptr;
     p.cv_drop = m3t_make_drop(0.f, 0ull);
     p.cv_amax = nullptr;
     p.mw_len = mw_len; p.mw_stride = mw_stride; p.mw_off = mw_off;
-    dim3 grid(N / (narrow ? 64 : XN), M / XM, 1), block(256);
+    dim3 grid(N / (narrow ? 64 : XN), M / XM, n), block(256);
 #define M3T_X6W_GO(NS_, XNT_)                                                                             \
     do {                                                                                                  \
-        if (transB) sgemm_x6_kernel<0, 1, false, NS_, false, XNT_, true><<<grid, block, 0, s>>>(p);       \
-        else sgemm_x6_kernel<0, 0, false, NS_, false, XNT_, true><<<grid, block, 0, s>>>(p);              \
+        if (transB) sgemm_x6_kernel<0, 1, false, NS_, false, XNT_, true><<<grid, block, 0, s>>>(p, bt);   \
+        else sgemm_x6_kernel<0, 0, false, NS_, false, XNT_, true><<<grid, block, 0, s>>>(p, bt);          \
     } while (0)
     if (f16x3) { if (narrow) M3T_X6W_GO(4, 64); else M3T_X6W_GO(4, 128); }
     else { if (narrow) M3T_X6W_GO(3, 64); else M3T_X6W_GO(3, 128); }
@@ -463,8 +481,8 @@ int m3t_conv_x6_launch(const float* x, const float* w_t, const float* bias, cons
     dim3 grid(Co / (narrow ? 64 : XN), p.M / XM, 1), block(256);
 #define M3T_CONV_GO(TB_, NS_)                                                                          \
     do {                                                                                               \
-        if (narrow) sgemm_x6_kernel<0, TB_, false, NS_, true, 64><<<grid, block, 0, s>>>(p);           \
-        else sgemm_x6_kernel<0, TB_, false, NS_, true, 128><<<grid, block, 0, s>>>(p);                 \
+        if (narrow) sgemm_x6_kernel<0, TB_, false, NS_, true, 64><<<grid, block, 0, s>>>(p, g_no_batch); \
+        else sgemm_x6_kernel<0, TB_, false, NS_, true, 128><<<grid, block, 0, s>>>(p, g_no_batch);     \
     } while (0)
     if (anti) {
         if (bf16_operands == 1) M3T_CONV_GO(0, 1); else if (bf16_operands == 2) M3T_CONV_GO(0, 2); else if (bf16_operands == 3) M3T_CONV_GO(0, 4); else M3T_CONV_GO(0, 3);

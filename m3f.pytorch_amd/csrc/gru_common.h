@@ -99,6 +99,7 @@ bool persist_progress_armed();
 void persist_forget_progress(unsigned* ctr);
 int persist_progress_ok(int n, int H, int B, int T, int flags, bool backward);
 int persist_wait_progress(const unsigned* ctr, unsigned need, hipStream_t s);
+int persist_bwd_prepare(const float* const* w, int n, int H, int direct, float* const* out, hipStream_t s);
 struct AfterGuard { ~AfterGuard() { persist_drop_after(); persist_drop_events(); persist_drop_arena(); persist_drop_progress(); } };
 int persist_poll_error();       // step+1 of a scan that hit its spin limit since the last persist_reset_error(), else 0 (sticky)
 void persist_reset_error();     // clears the error words; only after the device has been synchronised

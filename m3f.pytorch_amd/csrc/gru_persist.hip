@@ -1883,6 +1883,21 @@ static int apply_progress(const G& g, const bool* up, int wg_per_scan, int T, Ex
     return 0;
 }
 
+// m3t_gru_bwd_prepare: the wide producer-split backward kernel's W_hh^T fragments, ahead of the scan (see persist_bwd_launch)
+int persist_bwd_prepare(const float* const* w, int n, int H, int direct, float* const* out, hipStream_t s) {
+    if (n <= 0) return 0;
+    if (n > M3T_MAX_SCANS || !w || !out || H <= 0 || H % 256 != 0 || H > 512) return M3T_EINVAL;
+    PrepBwd3pArgs pa;
+    for (int i = 0; i < M3T_MAX_SCANS; ++i) {
+        const int j = i < n ? i : 0;
+        if (!w[j] || !out[j] || ((uintptr_t)out[j] % 16) != 0) return M3T_EINVAL;
+        pa.w[i] = w[j]; pa.wf[i] = reinterpret_cast<unsigned short*>(out[j]); pa.inv[i] = out[j] + (size_t)4 * H * H;
+    }
+    wfrag_bwd3q_prep_kernel<<<dim3(H / 16, PREP3H_SPLIT, n), 256, 0, s>>>(pa, H, direct ? 1 : 0);
+    M3T_LAUNCH_CHECK();
+    return 0;
+}
+
 // the gate: one lane polls a progress counter until it has reached `need` (wrap-safe), then the kernel ends -- what follows it in its stream
 // starts behind a kernel boundary (agent-scope acquire: MI355X_MICROARCH.md, "boundary") and reads what the signalling workgroups wrote
 // back.  Bounded like every wait of the scans; giving up raises the sticky error word.
@@ -2059,15 +2074,22 @@ int persist_bwd_launch(const BwdGroup& g, const FragPtrs& fp, int B, int T, int 
             pa.w[i] = g.d[j].w_hh_t; pa.wf[i] = reinterpret_cast<unsigned short*>(fp.wfrag[j]); pa.inv[i] = fp.wfrag[j] + (size_t)4 * H * H;
         }
         if (uw == 2) {                                                       // the wide form: 32-deep MFMAs over producer pairs, memory-order hand-over
-            wfrag_bwd3q_prep_kernel<<<dim3(H / 16, PREP3H_SPLIT, g.n), 256, 0, s>>>(pa, H, (flags & M3T_SCAN_WHH) ? 1 : 0);
-            M3T_LAUNCH_CHECK();
+            bool ready = true;                                               // round 5: fragments prepared ahead of time (m3t_gru_bwd_prepare)
+            for (int i = 0; i < g.n; ++i) ready = ready && g.d[i].wfrag != nullptr && ((uintptr_t)g.d[i].wfrag % 16) == 0;
+            FragPtrs fq = fp;
+            if (ready) {
+                for (int i = 0; i < g.n; ++i) fq.wfrag[i] = const_cast<float*>(g.d[i].wfrag);
+            } else {
+                wfrag_bwd3q_prep_kernel<<<dim3(H / 16, PREP3H_SPLIT, g.n), 256, 0, s>>>(pa, H, (flags & M3T_SCAN_WHH) ? 1 : 0);
+                M3T_LAUNCH_CHECK();
+            }
             { const int e = persist_take_after(s); if (e) return e; }
             persist_record_start(s);
             const BwdKernel kq = sh.nc == 2 ? gru_persist_bwd3q_kernel<2> : (ex.prof ? gru_persist_bwd3q_kernel<4, true> : gru_persist_bwd3q_kernel<4>);
             const size_t need = (size_t)2 * 2 * 272 * 40;                    // the staging slots (sin4, sout, sin2)
             const size_t dyn = exclusive_lds(kq, sh.active, need);
             if (dyn < need) return M3T_EINVAL;
-            hipLaunchKernelGGL(kq, dim3(sh.grid), dim3(NT), dyn, s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
+            hipLaunchKernelGGL(kq, dim3(sh.grid), dim3(NT), dyn, s, g, fq, ex, B, T, sh.G, sh.nrb, g_err_dev);
             persist_record_end(s);
             M3T_LAUNCH_CHECK();
             return 0;
@@ -2263,6 +2285,12 @@ extern "C" int m3t_gru_scan_progress_ok(int n_scans, int H, int B, int T, int fl
 
 extern "C" int m3t_stream_wait_progress(const unsigned* counter, unsigned need, void* stream) {
     return m3t_gru::persist_wait_progress(counter, need, (hipStream_t)stream);
+}
+
+extern "C" size_t m3t_gru_bwd_prepare_floats(int H) { return H > 0 ? (size_t)4 * H * H + 64 : 0; }
+
+extern "C" int m3t_gru_bwd_prepare(const float* const* w, int n, int H, int whh_direct, float* const* out, void* stream) {
+    return m3t_gru::persist_bwd_prepare(w, n, H, whh_direct, out, (hipStream_t)stream);
 }
 
 extern "C" int m3t_gru_scan_after(void* event) {

@@ -35,8 +35,14 @@ class GruFwdDesc(C.Structure):
 class GruBwdDesc(C.Structure):
     _fields_ = [("dout", _f), ("out", _f), ("gates", _f), ("w_hh_t", _f), ("dh_n", _f),
                 ("dgx", _f), ("dgh", _f), ("dh", _f), ("db_part", _f), ("db_ih", _f), ("db_hh", _f),
-                ("H", _i), ("reverse", _i), ("ldo", _i), ("ooff", _i), ("ldg", _i), ("goff", _i), ("amax", _f)]
+                ("H", _i), ("reverse", _i), ("ldo", _i), ("ooff", _i), ("ldg", _i), ("goff", _i), ("amax", _f), ("wfrag", _f)]
 
+
+class WindowProblem(C.Structure):
+    _fields_ = [("A", _f), ("B", _f), ("C", _f), ("bias", _f), ("amax_a", _f), ("amax_b", _f), ("accumulate", _i)]
+
+
+M3T_WINDOW_BATCH = 8
 
 # name -> argtypes; the test-suite checks that every symbol of include/m3t_hip.h is here and exported.
 SIGNATURES = {
@@ -45,6 +51,7 @@ SIGNATURES = {
     "m3t_sgemm": [_i, _i, _i, _i, _i, _f, _i, _f, _i, _f, _i, _f, _i, _i, _i, _i, _i, _i, _f, _z, _i, _s],
     "m3t_sgemm_scaled": [_i, _i, _i, _i, _i, _f, _i, _f, _i, _f, _i, _f, _i, _i, _i, _i, _i, _i, _f, _z, _i, _f, _f, _s],
     "m3t_sgemm_window": [_i, _i, _i, _i, _i, _i, _i, _f, _i, _f, _i, _f, _i, _f, _i, _i, _i, _f, _f, _s],
+    "m3t_sgemm_window_batch": [_i, C.POINTER(WindowProblem), _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _s],
     "m3t_absmax": [_i, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), _s],
     "m3t_sgemm_plan": [_i, _i, _i, _i, _i, _z, _i, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "m3t_im2col3d": [_f] + [_i] * 14 + [_f, C.c_longlong, _i, C.c_void_p, _s],
@@ -54,6 +61,8 @@ SIGNATURES = {
     "m3t_relu_bwd": [_f, _f, _z, _s],
     "m3t_gru_scan_fwd": [C.POINTER(GruFwdDesc), _i, _i, _i, _f, _z, _i, _s],
     "m3t_gru_scan_bwd": [C.POINTER(GruBwdDesc), _i, _i, _i, _f, _z, _i, _s],
+    "m3t_gru_bwd_prepare_floats": [_i],
+    "m3t_gru_bwd_prepare": [C.POINTER(C.c_void_p), _i, _i, _i, C.POINTER(C.c_void_p), _s],
     "m3t_gru_persist_count": [],
     "m3t_gru_scan_workgroups": [_i, _i, _i, _i, _i, _i],
     "m3t_gru_poll_error": [],
@@ -116,7 +125,7 @@ SIGNATURES = {
     "m3t_sgd_step": [_f, _f, _f, _z, C.c_float, C.c_float, C.c_float, _i, _f, _s],
 }
 
-RESTYPES = {"m3t_bn_rows_ws_bytes": C.c_size_t, "m3t_bn_planes_ws_bytes": C.c_size_t, "m3t_va_loss_ws_bytes": C.c_size_t, "m3t_cbam_fused_ws_bytes": C.c_size_t}
+RESTYPES = {"m3t_gru_bwd_prepare_floats": C.c_size_t, "m3t_bn_rows_ws_bytes": C.c_size_t, "m3t_bn_planes_ws_bytes": C.c_size_t, "m3t_va_loss_ws_bytes": C.c_size_t, "m3t_cbam_fused_ws_bytes": C.c_size_t}
 
 _lib = None
 

@@ -147,6 +147,7 @@ class FlatGradDDP:
         """drop this instance's gradient sinks (the parameters keep their .grad views)"""
         from . import ops
         ops.clear_grad_sinks(self)
+        ops.drop_weight_amax(self)
         if getattr(self, "_agreed", False):
             self._agreed = False
             try:
@@ -187,6 +188,11 @@ class FlatGradDDP:
             ops.arm_grad_sinks(self)          # the first gradient of a parameter this step overwrites its slice in place
         self._left = [len(b) for b in self.buckets]
         self._handles = []
+        if self.flat.is_cuda:
+            # the weights are final here (the optimizer ran after the previous finish()): their magnitudes for this step's fp16x3
+            # contractions, every matrix in one pass (m3t.ops.measure_weight_amax) instead of one measuring launch per forward call
+            from . import ops
+            ops.measure_weight_amax([p for b in self.buckets for p in b], owner=self)
 
     def _raise_agreed(self, why):
         from . import _lib
@@ -321,4 +327,5 @@ class FlatGradDDP:
         # (no synchronisation here: at the latest on the next step's finish()).  Several ranks: silent here -- the next
         # finish() raises on every rank from the all-reduced slot (_check_agreed).
         ops.poll_scan_error()
+        ops.drop_weight_amax(self)                # the optimizer is about to change the weights: this step's magnitude table dies here
         return self.last_norm

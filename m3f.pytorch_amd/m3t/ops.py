@@ -280,9 +280,67 @@ def amax_one(device):
     return t.data_ptr()
 
 
+_SLOT_POOL = {}
+_SLOT_CHUNK = 8192
+
+
 def amax_slots(n, device):
-    """n fresh (zero) slots on the current stream; slot i lives at .data_ptr() + 8 i"""
-    return torch.zeros(n, dtype=torch.int64, device=device)
+    """n fresh (zero) slots; slot i lives at .data_ptr() + 8 i.  Views of a pre-zeroed chunk (round 5: one fill kernel per 8192 slots instead
+    of one per call -- ~15 small launches per C3 step, several of them on the chain).  A chunk is zeroed on the stream that is current when
+    it is created and the library's other streams are made to wait for that fill; a slot is handed out once."""
+    key = (device.type, device.index)
+    st = _SLOT_POOL.get(key)
+    if st is None or st[1] + n > st[0].numel():
+        st = _SLOT_POOL[key] = [torch.zeros(max(_SLOT_CHUNK, n), dtype=torch.int64, device=device), 0]
+        if device.type == "cuda":
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(device))
+            for other in ([_SIDE.get(key)] if _SIDE.get(key) is not None else []) + list(_WGRAD.get(key) or []):
+                other.wait_event(ev)
+            st.append(ev)
+    v = st[0][st[1]:st[1] + n]
+    st[1] += n
+    return v
+
+
+# ---- weight magnitudes measured once per step, off the hot calls (round 5) ---------------------------------------------------------
+# The fp16x3 contractions scale each operand by its magnitude; until round 4 every grouped BiGRU / Linear forward measured its weights
+# itself (one launch each, ~0.2 ms of the C3 step's chain).  FlatGradDDP.zero_grad() -- the point of a step at which the weights are
+# final (the optimizer has run) -- now measures EVERY weight matrix of the model in one go; forward calls find the slot here.  Entries
+# die at FlatGradDDP.finish() (the optimizer is about to change the weights): a forward outside a step (validation) measures for itself
+# as before.  M3T_WEIGHT_AMAX=0 turns the table off.
+_W_AMAX = {}              # id(parameter) -> (weakref(parameter), slot address, owner id, slots tensor)
+_W_AMAX_ON = os.environ.get("M3T_WEIGHT_AMAX", "1") != "0"
+
+
+def measure_weight_amax(params, owner=None):
+    """one measuring pass over every float32 matrix among `params` (16 per launch); called by FlatGradDDP.zero_grad()"""
+    if not _W_AMAX_ON:
+        return
+    ws = [p for p in params if p.dim() >= 2 and p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.shape[-1] % 4 == 0
+          and p.data_ptr() % 16 == 0]
+    if not ws:
+        return
+    slots = amax_slots(len(ws), ws[0].device)
+    if measure_amax([(p, slots.data_ptr() + 8 * i) for i, p in enumerate(ws)]):
+        for i, p in enumerate(ws):
+            _W_AMAX[id(p)] = (weakref.ref(p), slots.data_ptr() + 8 * i, id(owner), slots)
+
+
+def drop_weight_amax(owner=None):
+    for k in [k for k, e in _W_AMAX.items() if owner is None or e[2] == id(owner)]:
+        del _W_AMAX[k]
+
+
+def weight_amax(w, keep=None):
+    """address of this step's magnitude slot of the parameter object `w`, or None (not measured this step: the caller measures); keep: a
+    list that receives the tensor holding the slot (an autograd context keeps it alive for its backward)"""
+    e = _W_AMAX.get(id(w))
+    if e is None or e[0]() is not w:
+        return None
+    if keep is not None and not any(k is e[3] for k in keep):
+        keep.append(e[3])
+    return e[1]
 
 
 def measure_amax(items):
@@ -370,12 +428,17 @@ class _Linear(torch.autograd.Function):
         ctx.prec = _PREC[0]
         # fp16x3 products: x and w are measured once here (one launch) and their slots serve the backward GEMMs too
         slots = None
+        ctx.w_slot = None
         if (ctx.prec & _lib.M3T_GEMM_F16X3) and M % 128 == 0 and N % 64 == 0 and K % 32 == 0 and w.is_contiguous():
             slots = amax_slots(3, x.device)
-            if not measure_amax([(x, slots.data_ptr()), (w, slots.data_ptr() + 8)]):
+            ctx.w_keep = []
+            ctx.w_slot = weight_amax(w, ctx.w_keep)  # measured once per step by FlatGradDDP.zero_grad(), else here
+            if not measure_amax([(x, slots.data_ptr())] + ([] if ctx.w_slot is not None else [(w, slots.data_ptr() + 8)])):
                 slots = None
+            elif ctx.w_slot is None:
+                ctx.w_slot = slots.data_ptr() + 8
         sgemm(0, 1, M, N, K, x, 0, K, w, 0, K, y, 0, N, bias=b, act=act, prec=ctx.prec, exclusive=True,
-              amax=(None, None) if slots is None else (slots.data_ptr(), slots.data_ptr() + 8))
+              amax=(None, None) if slots is None else (slots.data_ptr(), ctx.w_slot))
         ctx.save_for_backward(x, w, y if act else None, slots)
         ctx.act, ctx.has_bias = act, b is not None
         ctx.bias_ref = b if (b is not None and id(b) in _GRAD_SINKS) else None
@@ -393,7 +456,7 @@ class _Linear(torch.autograd.Function):
         dx = dw = db = None
         a_x = a_w = a_dy = None
         if slots is not None and measure_amax([(dy, slots.data_ptr() + 16)]):       # dy: once for both backward GEMMs
-            a_x, a_w, a_dy = slots.data_ptr(), slots.data_ptr() + 8, slots.data_ptr() + 16
+            a_x, a_w, a_dy = slots.data_ptr(), ctx.w_slot, slots.data_ptr() + 16
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             sgemm(0, 0, M, K, N, dy, 0, N, w, 0, K, dx, 0, K, prec=ctx.prec, exclusive=True, amax=(a_dy, a_w))
@@ -514,6 +577,8 @@ def range_probe_report(clear=True):
     return out
 
 
+PREP_AHEAD = [os.environ.get("M3T_SCAN_PREP_AHEAD", "1") != "0"]      # the backward scans' weight fragments during forward (A/B switch, tests)
+SCAN_FIRST = [os.environ.get("M3T_SCAN_FIRST", "1") != "0"]            # weight gradients of level l start once the scan of level l - 1 is resident
 FORCE_WIDE_FWD = [False]    # tests: every forward scan asks for the wide form (by default only the level that makes room for the audio scans does)
 SCAN_FP32 = [False]         # tests: keep the persistent forward scan on fp32 MFMAs (bit-identical to the per-step kernels)
 
@@ -624,7 +689,10 @@ def _scan_arena(device):
 # MARKS (include/m3t_hip.h, m3t_gru_scan_progress); a consumer stream waits for a mark with a one-lane gate kernel and runs the product of
 # that direction's half over that TIME WINDOW (m3t_sgemm_window) while the scan is still running.  Per window the first arriver writes
 # (+ bias), the second accumulates -- the order is fixed by the windows' arrival steps, so results do not depend on timing.
-CHUNKS = [os.environ.get("M3T_SCAN_CHUNKS", "1") != "0"]      # tests flip it: the unchunked schedule is the yardstick of the chunked one
+# M3T_SCAN_CHUNKS: "1" (default) both passes, "fwd" / "bwd" one pass only, "0" off; tests flip CHUNKS[0] (True / False): the unchunked
+# schedule is the yardstick of the chunked one
+_ce = os.environ.get("M3T_SCAN_CHUNKS", "1")
+CHUNKS = [{"0": False, "1": True}.get(_ce, _ce)]
 _CHUNK_WINDOWS = 4
 _PROGRESS = {}
 
@@ -640,12 +708,13 @@ def _progress_counters(device):
     return t
 
 
-def _chunk_bounds(B, T, n=None):
+def _chunk_bounds(B, T, n=None, backward=False):
     """time bounds tb[0 .. n-2] that cut [0, T) into n windows whose row counts B * len are whole 128-row GEMM tiles, or None"""
     import math
     n = n or _CHUNK_WINDOWS
     q = 128 // math.gcd(B, 128)
-    if not CHUNKS[0] or (B * T) % 128 != 0 or T < 16 * n or B * T < 4096:
+    on = CHUNKS[0] is True or CHUNKS[0] == ("bwd" if backward else "fwd")
+    if not on or (B * T) % 128 != 0 or T < 16 * n or B * T < 4096:
         return None
     tb = [int(round(k * T / n / q)) * q for k in range(1, n)]
     lo = [0] + tb
@@ -683,6 +752,18 @@ def sgemm_window(transB, n_seg, win_len, win_stride, win_off, N, K, A, a_off, ld
     rc = lib().m3t_sgemm_window(transB, n_seg, win_len, win_stride, win_off, N, K, _p(A, a_off), lda, _p(Bm, b_off), ldb, _p(Cm, c_off), ldc,
                                 _p(bias), act, int(accumulate), flags, amax[0], amax[1], _stream())
     _lib.check(rc, "m3t_sgemm_window")
+
+
+def sgemm_window_batch(problems, transB, n_seg, win_len, win_stride, win_off, N, K, lda, ldb, ldc, act=0, prec=None):
+    """problems: [(A, a_off, B, b_off, C, c_off, bias or None, accumulate, amax_a, amax_b)] of ONE shape: one launch (<= 8 per launch)"""
+    flags = _PREC[0] if prec is None else prec
+    WP = _lib.WindowProblem
+    for i in range(0, len(problems), _lib.M3T_WINDOW_BATCH):
+        chunk = problems[i:i + _lib.M3T_WINDOW_BATCH]
+        arr = (WP * len(chunk))(*[WP(_vp(A, ao), _vp(Bm, bo), _vp(Cm, co), _vp(bias), aa, ab, int(acc))
+                                  for A, ao, Bm, bo, Cm, co, bias, acc, aa, ab in chunk])
+        _lib.check(lib().m3t_sgemm_window_batch(len(chunk), arr, transB, n_seg, win_len, win_stride, win_off, N, K, lda, ldb, ldc, act, flags,
+                                                _stream()), "m3t_sgemm_window_batch")
 
 
 def _scan_fwd(descs, B, T, prec=0, after=None, progress=None):
@@ -842,10 +923,16 @@ class _MultiBiGRU(torch.autograd.Function):
         if (prec & _lib.M3T_GEMM_F16X3) and all(h % 4 == 0 for h in Hs):      # (narrower scans never reach the fp16x3 kernels)
             fslots = amax_slots(n_stacks * (1 + 2 * L), dev)
             items = [(xs[s], fslots.data_ptr() + 8 * s) for s in range(n_stacks)]
+            wslot = {}                                  # (l, s, d) -> slot address: this step's table (weight_amax) or measured here
+            ctx.w_keep = []
             for l in range(L):
                 for s in range(n_stacks):
                     for d in (0, 1):
-                        items.append((params[s][(2 * l + d) * 4], fslots.data_ptr() + 8 * (n_stacks + (l * n_stacks + s) * 2 + d)))
+                        a = weight_amax(params[s][(2 * l + d) * 4], ctx.w_keep)
+                        if a is None:
+                            a = fslots.data_ptr() + 8 * (n_stacks + (l * n_stacks + s) * 2 + d)
+                            items.append((params[s][(2 * l + d) * 4], a))
+                        wslot[(l, s, d)] = a
             if not measure_amax(items):
                 fslots = None
         one = amax_one(dev)
@@ -854,7 +941,7 @@ class _MultiBiGRU(torch.autograd.Function):
             return None if fslots is None else (fslots.data_ptr() + 8 * s if l == 0 else one)
 
         def fslot_w(l, s, d):
-            return None if fslots is None else fslots.data_ptr() + 8 * (n_stacks + (l * n_stacks + s) * 2 + d)
+            return None if fslots is None else wslot[(l, s, d)]
 
         alone = not _interleaved(groups) and all(kind == "main" for kind, _ in groups)   # nothing runs beside these GEMMs
 
@@ -909,15 +996,19 @@ class _MultiBiGRU(torch.autograd.Function):
                             ended = True
                     else:
                         _wait_progress(ctr, dirn, need[dirn * len(tb) + k])
+                    H = Hs[idxs[0]]
+                    lda = outs[l - 1][idxs[0]].stride(1)
+                    probs = []
                     for si in idxs:
-                        H = Hs[si]
                         src = outs[l - 1][si]
+                        assert src.stride(1) == lda
                         for d in (0, 1):
                             w_ih, _, b_ih, _ = params[si][(2 * l + d) * 4:(2 * l + d) * 4 + 4]
                             # (forward pass: the scans that walk time upwards are the forward direction = columns [0, H) of the output)
-                            sgemm_window(1, B, hi[w] - lo[w], T, lo[w], 3 * H, H, src, dirn * H, src.stride(1), w_ih, dirn * H, 2 * H,
-                                         xprojs[l][si], d * 3 * H, 6 * H, bias=None if second else b_ih, accumulate=second, prec=prec,
-                                         amax=(one, fslot_w(l, si, d)))
+                            probs.append((src, dirn * H, w_ih, dirn * H, xprojs[l][si], d * 3 * H, None if second else b_ih, second,
+                                          one, fslot_w(l, si, d)))
+                    # ONE launch per mark: every (stack, direction) pair that reads this window
+                    sgemm_window_batch(probs, 1, B, hi[w] - lo[w], T, lo[w], 3 * H, H, lda, 2 * H, 6 * H, prec=prec)
                 ev = torch.cuda.Event()
                 ev.record(wg)
             scan_stream.wait_event(ev)
@@ -1011,6 +1102,40 @@ class _MultiBiGRU(torch.autograd.Function):
                 if kind == "side":
                     main.wait_stream(side_stream(dev))
         del xprojs
+        # round 5: W_hh does not change before this step's backward pass -- the wide backward scans' weight fragments (one preparation
+        # launch in front of EVERY backward scan, on the chain: ~0.12 ms of the C3 step) are written now, on weight-gradient stream 1,
+        # which is idle in forward (include/m3t_hip.h, m3t_gru_bwd_prepare); a level whose backward launch is not that kernel prepares
+        # for itself as before
+        ctx.wfq, ctx.wfq_ev = None, None
+        if PREP_AHEAD[0] and any(ctx.needs_input_grad) and fslots is not None and all(p_.is_contiguous() for prm in params for p_ in prm):
+            wfq = {}
+            bfl = _scan_flags(dev) | prec | _lib.M3T_SCAN_WHH | _lib.M3T_SCAN_WIDE
+            jobs = []
+            for _, idxs in groups:
+                H = Hs[idxs[0]]
+                if len({Hs[i] for i in idxs}) == 1 and H % 256 == 0 and 2 * len(idxs) <= M3T_MAX_SCANS \
+                        and lib().m3t_gru_scan_progress_ok(2 * len(idxs), H, B, T, bfl, 1):
+                    nfl = int(lib().m3t_gru_bwd_prepare_floats(H))
+                    for l in range(L):
+                        ws_, outs_ = [], []
+                        for si in idxs:
+                            for d in (0, 1):
+                                buf = new(nfl)
+                                wfq[(l, si, d)] = buf
+                                ws_.append(params[si][(2 * l + d) * 4 + 1])
+                                outs_.append(buf)
+                        jobs.append((H, ws_, outs_))
+            if jobs:
+                wg1 = wgrad_streams(dev)[1]
+                wg1.wait_stream(main)                 # (the buffers come from this stream's allocator: their previous users are done)
+                with torch.cuda.stream(wg1):
+                    for H, ws_, outs_ in jobs:
+                        n_ = len(ws_)
+                        _lib.check(lib().m3t_gru_bwd_prepare((C.c_void_p * n_)(*[t.data_ptr() for t in ws_]), n_, H, 1,
+                                                             (C.c_void_p * n_)(*[t.data_ptr() for t in outs_]), _stream()), "m3t_gru_bwd_prepare")
+                    ctx.wfq_ev = torch.cuda.Event()
+                    ctx.wfq_ev.record(wg1)
+                ctx.wfq = wfq
         ctx.n_stacks, ctx.L, ctx.Hs, ctx.B, ctx.T, ctx.prec = n_stacks, L, Hs, B, T, prec
         ctx.concurrent = concurrent
         ctx.cat = (cat_lo, cat_hi) if cat_buf is not None else (0, 0)
@@ -1019,6 +1144,7 @@ class _MultiBiGRU(torch.autograd.Function):
             for s in range(n_stacks):
                 saved += [outs[l][s], gates[l][s]]
         ctx.has_fslots = fslots is not None
+        ctx.wslot = wslot if fslots is not None else None
         if fslots is not None:
             for st_ in (side_stream(dev),):
                 fslots.record_stream(st_)
@@ -1093,6 +1219,9 @@ class _MultiBiGRU(torch.autograd.Function):
         groups = _stream_groups(Hs, B)
         cur = {s: douts[s] for s in range(n_stacks)}
         prec = ctx.prec
+        wfq = ctx.wfq or {}                  # fragments of the wide backward scans, written during forward (m3t_gru_bwd_prepare)
+        if ctx.wfq_ev is not None:
+            main.wait_event(ctx.wfq_ev)
         # fp16x3 products: every backward scan raises one magnitude slot per direction (max |dgx|, |dgh|); the inputs' and the
         # weights' slots come from the forward pass, the recurrent states are GRU outputs (|h| <= 1)
         # (per scan: [0] the whole scan, [1 + j] the j-th time window in the order the scan walks them -- written by launches with progress marks)
@@ -1107,7 +1236,7 @@ class _MultiBiGRU(torch.autograd.Function):
             return None if fslots is None else (fslots.data_ptr() + 8 * s if l == 0 else one)
 
         def fslot_w(l, s, d):
-            return None if fslots is None else fslots.data_ptr() + 8 * (n_stacks + (l * n_stacks + s) * 2 + d)
+            return None if fslots is None else ctx.wslot[(l, s, d)]
 
         def chunk_plan(l, idxs):
             """time bounds for the direction-split, time-chunked data gradients of level l (stacks idxs, one H), or None"""
@@ -1119,7 +1248,7 @@ class _MultiBiGRU(torch.autograd.Function):
             fl = _scan_flags(dev) | prec | _lib.M3T_SCAN_WHH | _lib.M3T_SCAN_WIDE
             if not lib().m3t_gru_scan_progress_ok(2 * len(idxs), H, B, T, fl, 1):
                 return None
-            tb = _chunk_bounds(B, T)
+            tb = _chunk_bounds(B, T, backward=True)
             return tb if (tb is not None and len(tb) + 1 <= _CHUNK_WINDOWS) else None
 
         def dx_pieces(l, idxs, tb, need, scan_stream):
@@ -1143,19 +1272,47 @@ class _MultiBiGRU(torch.autograd.Function):
                         _wait_progress(ctr, dirn, need[dirn * n + k])
                     d = 1 - dirn                                   # up-walking backward scans belong to the reverse direction
                     j = w if dirn == 0 else n - w                  # the window's index in the order that scan walks them (its magnitude slot)
+                    by_shape = {}
                     for si in idxs:
-                        if not need_dx[l][si]:
-                            continue
-                        H = Hs[si]
-                        I = layer_io(l, si)[0].shape[-1]
-                        sgemm_window(0, B, hi[w] - lo[w], T, lo[w], I, 3 * H, dgx[l][si], d * 3 * H, 6 * H, params[si][(2 * l + d) * 4], 0, I,
-                                     dinp[l][si], 0, I, accumulate=second, prec=prec, amax=(bslot(l, si, d, j), fslot_w(l, si, d)))
+                        if need_dx[l][si]:
+                            I = layer_io(l, si)[0].shape[-1]
+                            by_shape.setdefault(I, []).append((dgx[l][si], d * 3 * Hs[si], params[si][(2 * l + d) * 4], 0, dinp[l][si], 0, None,
+                                                               second, bslot(l, si, d, j), fslot_w(l, si, d)))
+                    for I, probs in by_shape.items():      # ONE launch per mark and input width
+                        H = Hs[idxs[0]]
+                        sgemm_window_batch(probs, 0, B, hi[w] - lo[w], T, lo[w], I, 3 * H, 6 * H, I, I, prec=prec)
                 ev = torch.cuda.Event()
                 ev.record(wg)
             scan_stream.wait_event(ev)
             for si in idxs:
                 if need_dx[l][si]:
                     cur[si] = dinp[l][si]
+
+        def start_marks(idxs):
+            """round 5 (M3T_SCAN_FIRST): marks at step 8 of both directions -- "every workgroup of the launch is resident and stepping" -- for a
+            backward launch that carries no chunk marks.  The weight gradients of the level before are held back until then: queued on their
+            stream as soon as the data gradients are done, their workgroups (50 KB of LDS each) kept refilling the CUs the scan's
+            workgroups (a whole CU each) were waiting for -- the scan started 0.1-0.2 ms late (HIP events around the launch vs the kernel's
+            own duration)."""
+            if not SCAN_FIRST[0] or bslots is None or len({Hs[i] for i in idxs}) != 1 or 2 * len(idxs) > M3T_MAX_SCANS or T < 64 or not direct_whh:
+                return None
+            fl = _scan_flags(dev) | prec | _lib.M3T_SCAN_WHH | _lib.M3T_SCAN_WIDE
+            if not lib().m3t_gru_scan_progress_ok(2 * len(idxs), Hs[idxs[0]], B, T, fl, 1):
+                return None
+            return [8, T - 8]
+
+        held = {}                          # chain (stream role) -> weight-gradient closure of the level before, waiting for the next scan's start
+
+        def release_held(key, started):
+            fn = held.pop(key, None)
+            if fn is None:
+                return
+            if started is not None:        # (need table of a launch with start marks: up- and down-walking scans at step 8)
+                ctr_, need_ = started
+                with torch.cuda.stream(wgs[0]):
+                    _wait_progress(ctr_, 0, need_[0])
+                    _wait_progress(ctr_, 1, need_[2])
+            fn()
 
         def level_scan(l, idxs, after=None, wide=False, progress=None):
             """every BACKWARD level asks for the wide form (the library applies it where it exists: H = 512 in the fp16x3 mode), not only
@@ -1177,11 +1334,17 @@ class _MultiBiGRU(torch.autograd.Function):
                                             _vp(dhns[s], (2 * l + d) * B * H) if dhns[s] is not None else None,
                                             _vp(dgx[l][s]), _vp(dgh[l][s], d * B * T * 3 * H), _vp(dh[l][s], d * B * H),
                                             _vp(dbp[l][s], d * B * 4 * H), _vp(out_grads[base + 2]), _vp(out_grads[base + 3]),
-                                            H, d, out.stride(1), d * H, 6 * H, d * 3 * H, bslot(l, s, d)))      # (dout and out share the layout)
+                                            H, d, out.stride(1), d * H, 6 * H, d * 3 * H, bslot(l, s, d),
+                                            _vp(wfq[(l, s, d)]) if (l, s, d) in wfq else None))      # (dout and out share the layout)
+            chain = _ws_tag(dev)
+            sm = None
+            if progress is None and chain in held:
+                sm = start_marks(idxs)
             need = _scan_bwd(descs, B, T, prec | (_lib.M3T_SCAN_WHH if direct_whh else 0) | _lib.M3T_SCAN_WIDE, after,
-                             None if progress is None else (_progress_counters(dev), progress))
+                             None if (progress is None and sm is None) else (_progress_counters(dev), progress if progress is not None else sm))
             if progress is not None:
                 pending[(l, tuple(idxs))] = (progress, need)
+            release_held(chain, (_progress_counters(dev), need) if sm is not None else None)
             if RANGE_PROBE[0] is not None:
                 for s in idxs:
                     for d in (0, 1):
@@ -1273,7 +1436,12 @@ class _MultiBiGRU(torch.autograd.Function):
             ev.record(torch.cuda.current_stream())
             for w_ in (wgs if last else wgs[:1]):      # (the streams level_dw uses: stream 1 carries the chunked data gradients of the chain)
                 w_.wait_event(ev)
-            level_dw(l, idxs, spread=last)
+            if last or not SCAN_FIRST[0]:
+                level_dw(l, idxs, spread=last)
+            else:
+                # held until the NEXT scan of this chain has been launched (level_scan -> release_held): the scan first, then the GEMMs that
+                # only the optimizer waits for
+                held[_ws_tag(dev)] = lambda: level_dw(l, idxs, spread=False)
 
         if ctx.concurrent and _interleaved(groups):
             # as in forward (round 4): the heavy level on half the CUs, the light stack's scans at the same time on others; two
@@ -1350,6 +1518,8 @@ class _MultiBiGRU(torch.autograd.Function):
             for kind, _ in groups:
                 if kind == "side":
                     main.wait_stream(side_stream(dev))
+        for key_ in list(held):
+            release_held(key_, None)
         weights_sunk = all(sunk[s * per + 1 + (2 * l + d) * 4 + j] for s in range(n_stacks) for l in range(L) for d in (0, 1) for j in (0, 1))
         if weights_sunk:
             # every weight gradient goes straight into the flat gradient buffer, which nobody reads before

@@ -106,8 +106,8 @@ def test_chunked_schedule_matches_unchunked_on_fresh_inputs(specs, cat):
     B, T = 32, 300
     assert ops._chunk_bounds(B, T) is not None
     calls = []
-    real = ops.sgemm_window
-    ops.sgemm_window = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    real = ops.sgemm_window_batch
+    ops.sgemm_window_batch = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
     try:
         for it in range(3):
             rs = np.random.RandomState(100 + it)
@@ -132,4 +132,64 @@ def test_chunked_schedule_matches_unchunked_on_fresh_inputs(specs, cat):
                 assert float((a - b).abs().max()) / sc < 2e-5, float((a - b).abs().max()) / sc
     finally:
         ops.CHUNKS[0] = True
-        ops.sgemm_window = real
+        ops.sgemm_window_batch = real
+
+
+@pytest.mark.parametrize("specs,cat", [([(128, 256), (256, 512), (256, 512)], (1, 3)), ([(512, 512)], None)])
+def test_prepared_fragments_and_scan_first_change_nothing(specs, cat):
+    """m3t_gru_bwd_prepare (the backward scans' W_hh fragments written during forward, on an idle stream) and M3T_SCAN_FIRST (the weight
+    gradients of level l held back until the scan of level l - 1 is resident: start marks + gate kernels) move work in time only: every
+    output and gradient bit-identical to the schedule without them"""
+    from m3t import ops
+    B, T = 32, 300
+    rs = np.random.RandomState(7)
+    xs, prms = _stacks(rs, specs, B, T)
+    widths = [2 * specs[0][1]] + ([sum(2 * h for _, h in specs[1:])] if cat else [2 * h for _, h in specs[1:]])
+    douts = [_rand(rs, B, T, w, scale=1e-2) for w in widths]
+    saved = (ops.CHUNKS[0], ops.PREP_AHEAD[0], ops.SCAN_FIRST[0])
+    try:
+        ops.CHUNKS[0] = False
+        res = {}
+        for pa in (True, False):
+            for sf in (True, False):
+                ops.PREP_AHEAD[0], ops.SCAN_FIRST[0] = pa, sf
+                res[(pa, sf)] = _run(ops, xs, prms, douts, cat)
+        y0, g0 = res[(False, False)]
+        for k, (y, g) in res.items():
+            for a, b in zip(y + g, y0 + g0):
+                assert torch.equal(a, b), k
+    finally:
+        ops.CHUNKS[0], ops.PREP_AHEAD[0], ops.SCAN_FIRST[0] = saved
+
+
+def test_weight_magnitude_table_lives_for_one_step():
+    """FlatGradDDP.zero_grad() measures every weight matrix once (m3t.ops.measure_weight_amax); forward calls of that step take the slots
+    from the table; finish() drops them (the optimizer is about to change the weights) -- and a weight changed IN PLACE between zero_grad and
+    forward is the documented exception, so the test pins what is promised: same results with and without the table"""
+    from m3t import ops
+    from m3t.workloads import AVFeatureGraph, make_c3_step
+    from golden.recipe import fill_module, draw
+    rs = np.random.RandomState(11)
+    B, T = 32, 300
+    model = fill_module(AVFeatureGraph(128, 256, 512), 3).to(DEV)
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    batch = dict(x_a=f(draw(rs, (B, T, 128))), x_v=f(draw(rs, (B, T, 256))), valence=f(draw(rs, (B, T), "uniform_pm1")),
+                 arousal=f(draw(rs, (B, T), "uniform_pm1")), class_expr=f(rs.randint(0, 7, (B, T)).astype(np.int64)),
+                 expr_valid=f(rs.uniform(size=(B, T)) < 0.7))
+    ddp, step = make_c3_step(model, batch)
+    try:
+        loss1, _, y1 = step()
+        g1 = ddp.flat.clone()
+        assert not ops._W_AMAX, "finish() must drop the step's table"
+        ddp.zero_grad()
+        assert len(ops._W_AMAX) >= 20                       # every W_ih / W_hh / Linear weight of the graph
+        ops.drop_weight_amax(ddp)
+        ops._W_AMAX_ON_SAVED = ops._W_AMAX_ON
+        ops._W_AMAX_ON = False                              # the same step with every call measuring for itself
+        loss0, _, y0 = step()
+        g0 = ddp.flat.clone()
+        torch.cuda.synchronize()
+        assert torch.equal(y0, y1) and torch.equal(g0, g1) and float(loss0) == float(loss1)
+    finally:
+        ops._W_AMAX_ON = getattr(ops, "_W_AMAX_ON_SAVED", True)
+        ddp.close()
