@@ -531,6 +531,11 @@ int m3t_sgemm_x6d_launch(int transA, int transB, int M, int N, int K, const floa
                          int a_off, int b_off, float* ws, int splits, int kchunk, int bf16_operands,
                          const unsigned long long* amax_a, const unsigned long long* amax_b, hipStream_t s);
 
+int m3t_sgemm_x6w_launch(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                         float* C, int ldc, const float* bias, int act, int accumulate, int seg_len, int seg_stride,
+                         int a_off, int b_off, float* ws, int splits, int kchunk, int bf16_operands,
+                         const unsigned long long* amax_a, const unsigned long long* amax_b, hipStream_t s);
+
 // Kernel choice among the bf16x6 GEMMs (round 3: the A/B switches M3T_GEMM_X6D / _X6C / _NARROW / _SPLITS are retired, their
 // outcomes are the rules below): the 128-tile GEMMs run on the software-pipelined gemm_x6d.hip, EXCEPT those issued beside
 // another stream's persistent scan (M3T_GEMM_BESIDE_SCAN: a kernel with a higher request rate takes from the scans' exchange what
@@ -563,9 +568,20 @@ static bool x6_enabled() {
 
 // Kernel and split-K choice of one m3t_sgemm call.  kernel: 0 fp32-MFMA (gemm.hip), 1 the 16-bit-term 128-tile kernels
 // (gemm_x6.hip / gemm_x6d.hip: fp16x3, bf16x6, "high", bf16).
-struct GemmPlan { int kernel, splits, kchunk, narrow; };
+// (internal flag of plan_gemm: the call is not an NT product -- measured, tools/gemm_one.py: the wide tile wins on the NT forms (+9..+21 %:
+// 9600 x 1536 x 1024 122 -> 115 us, 9600 x 512 x 2048 112 -> 92), loses on NN 9600 x 2048 x 512 (86 -> 104: its row-contiguous B path spills
+// five registers) and is level on the TN weight gradients)
+constexpr int GEMM_NO_WIDE = 1 << 20;
+struct GemmPlan { int kernel, splits, kchunk, narrow, wide; };      // wide: the 128 x 256 tile of gemm_x6w.hip
 
 static int narrow_mode() { return 1; }
+
+// M3T_GEMM_X6W=0: never the 128 x 256 tile (A/B runs, the switch test)
+static bool x6w_enabled() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("M3T_GEMM_X6W"); on = (e && e[0] == '0') ? 0 : 1; }
+    return on == 1;
+}
 
 static GemmPlan plan_gemm(int transA, int M, int N, int K, int seg_len, bool vec, size_t ws_bytes, int flags) {
     GemmPlan g;
@@ -585,21 +601,40 @@ static GemmPlan plan_gemm(int transA, int M, int N, int K, int seg_len, bool vec
     // (84 ns per k per 128x128 block; 1.3x slower when it holds a single block), slabs cost their HBM traffic.
     int splits = 1;
     const size_t cap = ws_bytes / ((size_t)M * N * sizeof(float));
+    double best = 1e30;
+    auto model = [&](int ntiles, double nsk, int sp) {
+        const int rounds = cdiv(ntiles * sp, 256);
+        double t = (double)rounds * ((double)K / sp) * nsk * (rounds == 1 ? 1.3 : 1.0);
+        if (sp > 1) t += (double)(sp + 2) * M * N * 4.0 / 3000.0 + 3000.0;
+        return t;
+    };
     if (ws_bytes && K >= 512) {
-        double best = 1e30;
         for (int sp = 1; sp <= 96 && sp <= K / 96 && (sp == 1 || (size_t)sp <= cap); ++sp) {
-            const int rounds = cdiv(tiles * sp, 256);
-            double t = (double)rounds * ((double)K / sp) * ns_per_k * (rounds == 1 ? 1.3 : 1.0);
-            if (sp > 1) t += (double)(sp + 2) * M * N * 4.0 / 3000.0 + 3000.0;
+            const double t = model(tiles, ns_per_k, sp);
             if (t < best) { best = t; splits = sp; }
         }
+    } else best = model(tiles, ns_per_k, 1);
+    // round 5: the 128 x 256 tile (gemm_x6w.hip: fp16x3 and the six-product form) where the same model says it fills the chip better -- a
+    // block of twice the work at 0.8 x the time per flop (a quarter less LDS traffic and operand splitting per MFMA), two per CU.  The
+    // input projections (N = 1536: 900 tiles of 128 x 128 = one round of 768 resident workgroups and a second at 17 %) are the case.
+    g.wide = 0;
+    if (x6 && !bf16 && !high && N % 256 == 0 && x6w_enabled() && !(flags & (M3T_GEMM_BACKGROUND | GEMM_NO_WIDE))) {
+        const int tiles_w = cdiv(M, BM) * (N / 256);
+        double best_w = 1e30; int splits_w = 1;
+        if (ws_bytes && K >= 512) {
+            for (int sp = 1; sp <= 96 && sp <= K / 96 && (sp == 1 || (size_t)sp <= cap); ++sp) {
+                const double t = model(tiles_w, 2.0 * 0.8 * ns_per_k, sp);
+                if (t < best_w) { best_w = t; splits_w = sp; }
+            }
+        } else best_w = model(tiles_w, 2.0 * 0.8 * ns_per_k, 1);
+        if (best_w < best) { g.wide = 1; splits = splits_w; }
     }
     int kchunk = cdiv(cdiv(K, splits), kq) * kq;
     if (kchunk < kq) kchunk = kq;
     g.kernel = x6 ? 1 : 0; g.kchunk = kchunk; g.splits = K > 0 ? cdiv(K, kchunk) : 1;
     // a grid that leaves most CUs with a single 128 x 128 workgroup (<= 1.5 per CU) takes 128 x 64 tiles: twice the workgroups
     // (fc0 forward, 9600 x 512 x 1024: 96 -> 82 us; not with split-K: those small problems got 10-15 % slower)
-    g.narrow = (x6 && narrow_mode() && (n64 || narrow_mode() == 2 || (g.splits == 1 && tiles <= 384))) ? 1 : 0;      // (2: every bf16x6 GEMM, experiments)
+    g.narrow = (!g.wide && x6 && narrow_mode() && (n64 || narrow_mode() == 2 || (g.splits == 1 && tiles <= 384))) ? 1 : 0;      // (2: every bf16x6 GEMM, experiments)
     return g;
 }
 
@@ -633,7 +668,8 @@ extern "C" int m3t_sgemm_scaled(int transA, int transB, int M, int N, int K, con
     p.vecA = (lda % 4 == 0) && ((uintptr_t)A % 16 == 0);
     p.vecB = (ldb % 4 == 0) && ((uintptr_t)B % 16 == 0);
     const int tm = cdiv(M, BM), tn = cdiv(N, BN);
-    const GemmPlan g = plan_gemm(transA, M, N, K, seg_len, p.vecA && p.vecB, ws ? ws_bytes : 0, flags);
+    const GemmPlan g = plan_gemm(transA, M, N, K, seg_len, p.vecA && p.vecB, ws ? ws_bytes : 0,
+                                 flags | ((transA == 0 && transB == 1) ? 0 : GEMM_NO_WIDE));
     const int splits = g.splits, kchunk = g.kchunk;
     p.splits = splits; p.kchunk = kchunk;
     hipStream_t s = (hipStream_t)stream;
@@ -652,7 +688,10 @@ extern "C" int m3t_sgemm_scaled(int transA, int transB, int M, int N, int K, con
             const int rm = m3t_f16x3_measure(ra, amax_a, rb, amax_b, &use_a, &use_b, s);
             if (rm) return rm;
         }
-        if (!g.narrow && (!f16x3 || f16x3_on_x6d()) && !(flags & (M3T_GEMM_BACKGROUND | M3T_GEMM_HIGH)) && (x6d_mode() == 1 || (x6d_mode() == 2 && !(flags & M3T_GEMM_BESIDE_SCAN))))      // ("high": measured better on gemm_x6.hip)
+        if (g.wide)
+            rc = m3t_sgemm_x6w_launch(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, seg_len, seg_stride,
+                                      a_off, b_off, ws, splits, kchunk, f16x3 ? 3 : 0, use_a, use_b, s);
+        else if (!g.narrow && (!f16x3 || f16x3_on_x6d()) && !(flags & (M3T_GEMM_BACKGROUND | M3T_GEMM_HIGH)) && (x6d_mode() == 1 || (x6d_mode() == 2 && !(flags & M3T_GEMM_BESIDE_SCAN))))      // ("high": measured better on gemm_x6.hip)
             // the same product, software-pipelined inside each wave (gemm_x6d.hip): bit-identical results, 8-28 % faster
             rc = m3t_sgemm_x6d_launch(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, seg_len, seg_stride,
                                       a_off, b_off, ws, splits, kchunk, p.bf16 ? 1 : ((flags & M3T_GEMM_HIGH) ? 2 : (f16x3 ? 3 : 0)), use_a, use_b, s);

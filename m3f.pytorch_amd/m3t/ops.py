@@ -317,12 +317,13 @@ def measure_weight_amax(params, owner=None):
     """one measuring pass over every float32 matrix among `params` (16 per launch); called by FlatGradDDP.zero_grad()"""
     if not _W_AMAX_ON:
         return
-    ws = [p for p in params if p.dim() >= 2 and p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.shape[-1] % 4 == 0
-          and p.data_ptr() % 16 == 0]
+    # (N-D weights -- the stems' convolutions -- as [C_out, the rest])
+    ws = [p for p in params if p.dim() >= 2 and p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()
+          and (p.numel() // p.shape[0]) % 4 == 0 and p.data_ptr() % 16 == 0]
     if not ws:
         return
     slots = amax_slots(len(ws), ws[0].device)
-    if measure_amax([(p, slots.data_ptr() + 8 * i) for i, p in enumerate(ws)]):
+    if measure_amax([(p.detach().view(p.shape[0], -1), slots.data_ptr() + 8 * i) for i, p in enumerate(ws)]):
         for i, p in enumerate(ws):
             _W_AMAX[id(p)] = (weakref.ref(p), slots.data_ptr() + 8 * i, id(owner), slots)
 
@@ -2234,24 +2235,74 @@ def pool_planes(x, k, s, p):
     return _PoolPlanes.apply(x, tuple(k), tuple(s), tuple(p))
 
 
-# ----------------------------------------------------------------------------- Conv3d weight gradient
+# ----------------------------------------------------------------------------- Conv3d of the visual stems
+CONV3D_GEMM = [os.environ.get("M3T_CONV3D_MIOPEN", "0") != "1"]      # False: forward on MIOpen as until round 4 (tested fallback)
+
+
+def _conv3d_plan(x, w, stride, padding):
+    """(To, Ho, Wo, rows, Kc, Kp) of the patch-matrix form, or None when the 16-bit-term GEMM cannot tile it"""
+    N_, Ci, T_, H_, W_ = x.shape
+    Co, _, kt, kh, kw = w.shape
+    To = (T_ + 2 * padding[0] - kt) // stride[0] + 1
+    Ho = (H_ + 2 * padding[1] - kh) // stride[1] + 1
+    Wo = (W_ + 2 * padding[2] - kw) // stride[2] + 1
+    rows, Kc = N_ * To * Ho * Wo, Ci * kt * kh * kw
+    if min(To, Ho, Wo) < 1 or rows % 128 != 0 or Co % 64 != 0:
+        return None
+    Kp = Kc if Kc % 64 == 0 else (Kc + 127) // 128 * 128       # (the weight gradient's rules: dW = dy^T P, or transposed and padded)
+    return To, Ho, Wo, rows, Kc, Kp
+
+
 class _Conv3dGemmWgrad(torch.autograd.Function):
-    """Conv3d of the visual stems (reference models/backbone.py:73-103,179-271,327-332): forward and the data
-    gradient stay on PyTorch-ROCm/MIOpen, but the WEIGHT gradient is computed as one
-    fp32-accurate GEMM on the bf16 matrix pipe (m3t_sgemm, K = N*T'*H'*W' positions) over an explicit patch
-    matrix: MIOpen's fp32 conv3d bwd-weight kernel ran at ~1 TFLOP/s on these shapes (138 ms per call, 88 % of a
-    full AffWild2VA step on MI355X)."""
+    """Conv3d of the visual stems (reference models/backbone.py:73-103,179-271,327-332).  Round 5: the FORWARD is the patch matrix
+    (m3t_im2col3d: rows (n, t', h', w'), columns (ci, kt, kh, kw)) times W^T on the fp16x3 GEMM, bias in the epilogue, then one tiled
+    transpose back to [N, Co, T', H', W'] -- MIOpen's fp32 forward (a CK grouped-conv kernel) ran at 26 TFLOP/s, 12.4 of the 30.4 ms of a
+    C5 step; the patch matrix the weight gradient needs anyway is written here instead of in backward and kept
+    (4 GB at 8 x 64 frames: sized for 288 GB).  The weight gradient is dy^T P on the same matrix (round 2); the data gradient stays on
+    MIOpen.  Shapes the GEMM cannot tile (rows % 128, C_out % 64) and M3T_CONV3D_MIOPEN=1 take torch.conv3d."""
 
     @staticmethod
     def forward(ctx, x, w, b, stride, padding):
-        y = torch.conv3d(x, w, b, stride, padding)
-        ctx.save_for_backward(x, w)
         ctx.stride, ctx.padding, ctx.has_bias = stride, padding, b is not None
+        plan = _conv3d_plan(x, w, stride, padding) if (CONV3D_GEMM[0] and x.is_cuda and (_PREC[0] & _lib.M3T_GEMM_F16X3 or _PREC[0] == 0)) else None
+        ctx.prec = _PREC[0]
+        if plan is None:
+            y = torch.conv3d(x, w, b, stride, padding)
+            ctx.save_for_backward(x, w)
+            ctx.pat = None
+            return y
+        To, Ho, Wo, rows, Kc, Kp = plan
+        N_, Ci, T_, H_, W_ = x.shape
+        Co, _, kt, kh, kw = w.shape
+        xc = _req(x.contiguous(), "x")
+        slots = amax_slots(2, x.device)
+        pat = torch.empty(rows, Kp, dtype=torch.float32, device=x.device)
+        _lib.check(lib().m3t_im2col3d(_p(xc), N_, Ci, T_, H_, W_, kt, kh, kw, stride[0], stride[1], stride[2], padding[0], padding[1], padding[2],
+                                      _p(pat), rows, Kp, C.c_void_p(slots.data_ptr()), _stream()), "m3t_im2col3d")
+        w2 = _req(w.contiguous(), "weight").view(Co, Kc)
+        if Kp != Kc:                                        # (the first layer: C_in k^3 = 81 -> 128 zero-padded columns on both operands)
+            wp = torch.zeros(Co, Kp, dtype=torch.float32, device=x.device)
+            wp[:, :Kc].copy_(w2)
+            w2 = wp
+        ctx.w_keep = []
+        a_w = weight_amax(w, ctx.w_keep)
+        if a_w is None:
+            a_w = slots.data_ptr() + 8
+            if not measure_amax([(w2, a_w)]):
+                a_w = None
+        y_cl = torch.empty(rows, Co, dtype=torch.float32, device=x.device)
+        sgemm(0, 1, rows, Co, Kp, pat, 0, Kp, w2, 0, Kp, y_cl, 0, Co, bias=b, amax=(slots.data_ptr(), a_w))
+        y = torch.empty(N_, Co, To, Ho, Wo, dtype=torch.float32, device=x.device)
+        _lib.check(lib().m3t_btc_to_bct(_p(y_cl), _p(y), N_, To * Ho * Wo, Co, _stream()), "m3t_btc_to_bct")
+        ctx.save_for_backward(x, w, pat, slots)
+        ctx.pat = (rows, Kc, Kp)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
+        saved = ctx.saved_tensors
+        x, w = saved[0], saved[1]
+        kept = (saved[2], saved[3]) if ctx.pat is not None else None      # the forward's patch matrix and its magnitude slot
         st, pd = ctx.stride, ctx.padding
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
@@ -2280,19 +2331,23 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
             N_, _, T_, H_, W_ = x.shape
             xc = _req(x.contiguous(), "x")
             # round 4: ONE launch writes the patch matrix (rows (n, t', h', w'), columns (ci, kt, kh, kw), zero padded to the GEMM's tiles)
-            # and raises its magnitude slot -- was ~50 torch copy kernels per convolution plus a measuring pass
-            slot = amax_slots(1, x.device)
+            # and raises its magnitude slot -- was ~50 torch copy kernels per convolution plus a measuring pass;
+            # round 5: the forward pass already wrote it (kept) unless it ran on MIOpen
+            slot = kept[1] if kept is not None else amax_slots(1, x.device)
 
             def im2col(rows_p, Kp):
+                if kept is not None and tuple(kept[0].shape) == (rows_p, Kp):
+                    return kept[0]
                 pat_ = torch.empty(rows_p, Kp, dtype=torch.float32, device=x.device)
+                sl_ = slot if kept is None else amax_slots(1, x.device)
                 _lib.check(lib().m3t_im2col3d(_p(xc), N_, Ci, T_, H_, W_, kt, kh, kw, st[0], st[1], st[2], pd[0], pd[1], pd[2], _p(pat_),
-                                              rows_p, Kp, C.c_void_p(slot.data_ptr()), _stream()), "m3t_im2col3d")
+                                              rows_p, Kp, C.c_void_p(sl_.data_ptr()), _stream()), "m3t_im2col3d")
                 return pat_
 
             if Co % 128 == 0 and Kc % 64 == 0:
                 pat = im2col(rows, Kc)
                 dw = torch.empty_like(w)
-                sgemm(1, 0, Co, Kc, rows, dy_cl, 0, Co, pat, 0, Kc, dw, 0, Kc, amax=(slot_dy.data_ptr(), slot.data_ptr()))
+                sgemm(1, 0, Co, Kc, rows, dy_cl, 0, Co, pat, 0, Kc, dw, 0, Kc, prec=ctx.prec, amax=(slot_dy.data_ptr(), slot.data_ptr()))
             elif Co % 64 == 0:
                 # the stems' FIRST layers: C_out = 64 and C_in k^3 = 81 (VGG-M) / 735 (3-D ResNet) fit no interior tile of the
                 # 16-bit-term GEMM as dW = dy^T P.  Transposed and padded they do: dW^T [Kp, Co] = P_pad^T dy with Kp = ceil128(C_in k^3)
@@ -2304,13 +2359,13 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
                     dyp = torch.zeros(rows_p, Co, dtype=torch.float32, device=x.device)
                     dyp[:rows].copy_(dy_cl.view(rows, Co))
                 dwt = torch.empty(Kp, Co, dtype=torch.float32, device=x.device)
-                sgemm(1, 0, Kp, Co, rows_p, pat_pad, 0, Kp, dyp, 0, Co, dwt, 0, Co, amax=(slot.data_ptr(), slot_dy.data_ptr()))
+                sgemm(1, 0, Kp, Co, rows_p, pat_pad, 0, Kp, dyp, 0, Co, dwt, 0, Co, prec=ctx.prec, amax=(slot.data_ptr(), slot_dy.data_ptr()))
                 dw = dwt[:Kc].t().contiguous().view_as(w)
             else:
                 Kp = (Kc + 3) // 4 * 4
                 pat = im2col(rows, Kp)
                 dwp = torch.empty(Co, Kp, dtype=torch.float32, device=x.device)
-                sgemm(1, 0, Co, Kp, rows, dy_cl, 0, Co, pat, 0, Kp, dwp, 0, Kp, amax=(slot_dy.data_ptr(), slot.data_ptr()))
+                sgemm(1, 0, Co, Kp, rows, dy_cl, 0, Co, pat, 0, Kp, dwp, 0, Kp, prec=ctx.prec, amax=(slot_dy.data_ptr(), slot.data_ptr()))
                 dw = dwp[:, :Kc].contiguous().view_as(w)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = torch.empty(Co, dtype=torch.float32, device=dy.device)

@@ -1054,6 +1054,42 @@ def test_conv3d_weight_gradient_through_the_patch_matrix(Ci, Co, k, stride, pad,
     close(x.grad, x64.grad.numpy(), 2e-4, "dx")
 
 
+@pytest.mark.parametrize("Ci,Co,k,stride,pad,N,T,H,W", [
+    (3, 64, (3, 3, 3), (1, 2, 2), (1, 0, 0), 2, 8, 17, 17),        # VGG-M conv1: 81 columns padded to 128 on both operands, C_out = 64 (the 128 x 64 tile)
+    (64, 128, (3, 3, 3), (1, 1, 1), (1, 0, 0), 2, 4, 10, 10),      # interior layers: K = 1728
+    (3, 64, (5, 7, 7), (1, 2, 2), (2, 3, 3), 1, 8, 32, 32),        # the 3-D ResNet stem: 735 -> 768 columns, padding on every axis
+    (128, 256, (3, 3, 3), (1, 1, 1), (1, 0, 0), 4, 8, 4, 4),       # deep layer: K = 3456 (split-K), small maps
+])
+def test_conv3d_forward_on_the_patch_matrix_gemm(Ci, Co, k, stride, pad, N, T, H, W):
+    """Round 5: m3t.ops.conv3d's FORWARD is patch matrix x W^T on the fp16x3 GEMM (bias in the epilogue, tiled transpose back to
+    [N, Co, T', H', W']), the patch matrix is kept for the weight gradient (reference models/backbone.py:73-103,179-271,327-332) --
+    output, weight / bias / input gradients against float64 autograd on the CPU, and against the MIOpen forward (M3T_CONV3D_MIOPEN=1)"""
+    from m3t import ops
+    rs = np.random.RandomState(Ci + Co + H)
+    xn, wn, bn_ = draw(rs, (N, Ci, T, H, W)), draw(rs, (Co, Ci) + k) * 0.2, draw(rs, (Co,))
+    x, w, b = dev(xn, True), dev(wn, True), dev(bn_, True)
+    assert ops._conv3d_plan(x, w, stride, pad) is not None, "this shape must take the GEMM forward"
+    y = ops.conv3d(x, w, b, stride, pad)
+    ctn = draw(rs, tuple(y.shape))
+    (y * dev(ctn)).sum().backward()
+    x64, w64, b64 = (torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (xn, wn, bn_))
+    y64 = torch.conv3d(x64, w64, b64, stride, pad)
+    (y64 * torch.tensor(ctn, dtype=torch.float64)).sum().backward()
+    close(y, y64.detach().numpy(), 1e-4, "y")
+    close(w.grad, w64.grad.numpy(), 2e-4, "dw")
+    close(b.grad, b64.grad.numpy(), 2e-4, "db")
+    close(x.grad, x64.grad.numpy(), 2e-4, "dx")
+    ops.CONV3D_GEMM[0] = False
+    try:
+        x2, w2, b2 = dev(xn, True), dev(wn, True), dev(bn_, True)
+        y2 = ops.conv3d(x2, w2, b2, stride, pad)
+        (y2 * dev(ctn)).sum().backward()
+    finally:
+        ops.CONV3D_GEMM[0] = True
+    close(y, y2.detach().cpu().numpy(), 1e-4, "y vs MIOpen")
+    close(w.grad, w2.grad.cpu().numpy(), 2e-4, "dw vs the MIOpen-forward path")
+
+
 @pytest.mark.parametrize("N,C_,T,H,W,training", [(3, 16, 5, 7, 9, True), (2, 64, 4, 12, 12, True), (2, 8, 3, 5, 5, False), (4, 24, 1, 1, 1, True)])
 def test_batchnorm3d_relu_on_channel_planes(N, C_, T, H, W, training):
     """models.backbone.BatchNorm3dReLU (nn.BatchNorm3d + nn.ReLU of the 3-D stems, reference models/backbone.py:73-103,179-191) on
