@@ -420,7 +420,9 @@ class _Linear(torch.autograd.Function):
     (reference models/rnn.py:22-55, models/model.py:88, models/att_fusion.py:13)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, act):
+    def forward(ctx, x, w, b, act, unit=False):
+        """unit: |x| <= 1 is known (x is a GRU output: m3t.ops.multi_bigru marks its outputs): its magnitude slot is a constant, nothing
+        is measured for it"""
         x = _req(x.contiguous(), "x"); _req(w, "weight")
         K = x.shape[-1]
         N = w.shape[0]
@@ -434,12 +436,14 @@ class _Linear(torch.autograd.Function):
             slots = amax_slots(3, x.device)
             ctx.w_keep = []
             ctx.w_slot = weight_amax(w, ctx.w_keep)  # measured once per step by FlatGradDDP.zero_grad(), else here
-            if not measure_amax([(x, slots.data_ptr())] + ([] if ctx.w_slot is not None else [(w, slots.data_ptr() + 8)])):
+            ctx.x_slot = amax_one(x.device) if unit else slots.data_ptr()
+            todo = ([] if unit else [(x, slots.data_ptr())]) + ([] if ctx.w_slot is not None else [(w, slots.data_ptr() + 8)])
+            if todo and not measure_amax(todo):
                 slots = None
             elif ctx.w_slot is None:
                 ctx.w_slot = slots.data_ptr() + 8
         sgemm(0, 1, M, N, K, x, 0, K, w, 0, K, y, 0, N, bias=b, act=act, prec=ctx.prec, exclusive=True,
-              amax=(None, None) if slots is None else (slots.data_ptr(), ctx.w_slot))
+              amax=(None, None) if slots is None else (ctx.x_slot, ctx.w_slot))
         ctx.save_for_backward(x, w, y if act else None, slots)
         ctx.act, ctx.has_bias = act, b is not None
         ctx.bias_ref = b if (b is not None and id(b) in _GRAD_SINKS) else None
@@ -457,7 +461,7 @@ class _Linear(torch.autograd.Function):
         dx = dw = db = None
         a_x = a_w = a_dy = None
         if slots is not None and measure_amax([(dy, slots.data_ptr() + 16)]):       # dy: once for both backward GEMMs
-            a_x, a_w, a_dy = slots.data_ptr(), ctx.w_slot, slots.data_ptr() + 16
+            a_x, a_w, a_dy = ctx.x_slot, ctx.w_slot, slots.data_ptr() + 16
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             sgemm(0, 0, M, K, N, dy, 0, N, w, 0, K, dx, 0, K, prec=ctx.prec, exclusive=True, amax=(a_dy, a_w))
@@ -500,7 +504,7 @@ class _Linear(torch.autograd.Function):
             x.record_stream(wg)
             _WGRAD_PENDING[(x.device.type, x.device.index)] = True
             _LINEAR_RR[0] += 1
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 _LINEAR_RR = [0]      # round-robin over the weight-gradient streams
@@ -535,7 +539,7 @@ def relu_dropout(y, p, seed=None):
 
 
 def linear(x, w, b=None, act=0):
-    return _Linear.apply(x, w, b, act)
+    return _Linear.apply(x, w, b, act, bool(getattr(x, "_m3t_unit", False)))
 
 
 # ----------------------------------------------------------------------------- BiGRU
@@ -886,7 +890,7 @@ class _MultiBiGRU(torch.autograd.Function):
     direction: w_ih, w_hh, b_ih, b_hh.  Returns per stack: out [B,T,2H], h_n [2L,B,H]."""
 
     @staticmethod
-    def forward(ctx, n_stacks, L, cat_lo, cat_hi, *tensors):
+    def forward(ctx, n_stacks, L, cat_lo, cat_hi, unit_mask, *tensors):
         """cat_lo < cat_hi: the last-layer outputs of stacks cat_lo .. cat_hi-1 are written side by side into ONE buffer
         [B, T, sum 2H] (the `torch.cat(..., -1)` a caller would apply next, without the copy -- and without the slice copies of its
         backward): that buffer is returned in the slot of stack cat_lo, the other stacks of the group return an empty tensor."""
@@ -923,7 +927,8 @@ class _MultiBiGRU(torch.autograd.Function):
         fslots = None
         if (prec & _lib.M3T_GEMM_F16X3) and all(h % 4 == 0 for h in Hs):      # (narrower scans never reach the fp16x3 kernels)
             fslots = amax_slots(n_stacks * (1 + 2 * L), dev)
-            items = [(xs[s], fslots.data_ptr() + 8 * s) for s in range(n_stacks)]
+            # (bit s of unit_mask: stack s reads a GRU output, |x| <= 1: the constant slot, nothing to measure)
+            items = [(xs[s], fslots.data_ptr() + 8 * s) for s in range(n_stacks) if not (unit_mask >> s) & 1]
             wslot = {}                                  # (l, s, d) -> slot address: this step's table (weight_amax) or measured here
             ctx.w_keep = []
             for l in range(L):
@@ -939,7 +944,7 @@ class _MultiBiGRU(torch.autograd.Function):
         one = amax_one(dev)
 
         def fslot_x(l, s):
-            return None if fslots is None else (fslots.data_ptr() + 8 * s if l == 0 else one)
+            return None if fslots is None else (fslots.data_ptr() + 8 * s if (l == 0 and not (unit_mask >> s) & 1) else one)
 
         def fslot_w(l, s, d):
             return None if fslots is None else wslot[(l, s, d)]
@@ -1138,6 +1143,7 @@ class _MultiBiGRU(torch.autograd.Function):
                     ctx.wfq_ev.record(wg1)
                 ctx.wfq = wfq
         ctx.n_stacks, ctx.L, ctx.Hs, ctx.B, ctx.T, ctx.prec = n_stacks, L, Hs, B, T, prec
+        ctx.unit_mask = unit_mask
         ctx.concurrent = concurrent
         ctx.cat = (cat_lo, cat_hi) if cat_buf is not None else (0, 0)
         saved = []
@@ -1205,7 +1211,7 @@ class _MultiBiGRU(torch.autograd.Function):
         # H % 16 == 0 everywhere: the scans build their weight fragments straight from w_hh (no transposes in front of them)
         direct_whh = all(h % 16 == 0 for h in Hs) and all(p.is_contiguous() for prm in params for p in prm)
         wht = [[[None if direct_whh else new(Hs[s], 3 * Hs[s]) for _ in (0, 1)] for s in range(n_stacks)] for _ in range(L)]
-        need_dx = [[l > 0 or ctx.needs_input_grad[4 + s * per] for s in range(n_stacks)] for l in range(L)]
+        need_dx = [[l > 0 or ctx.needs_input_grad[5 + s * per] for s in range(n_stacks)] for l in range(L)]
         dinp = [[torch.empty_like(layer_io(l, s)[0]) if need_dx[l][s] else None for s in range(n_stacks)] for l in range(L)]
         for s in range(n_stacks):
             for l in range(L):
@@ -1234,7 +1240,7 @@ class _MultiBiGRU(torch.autograd.Function):
             return None if bslots is None else bslots.data_ptr() + 8 * (((l * n_stacks + s) * 2 + d) * NSL + 1 + j)
 
         def fslot_x(l, s):
-            return None if fslots is None else (fslots.data_ptr() + 8 * s if l == 0 else one)
+            return None if fslots is None else (fslots.data_ptr() + 8 * s if (l == 0 and not (ctx.unit_mask >> s) & 1) else one)
 
         def fslot_w(l, s, d):
             return None if fslots is None else ctx.wslot[(l, s, d)]
@@ -1541,7 +1547,7 @@ class _MultiBiGRU(torch.autograd.Function):
                 main.wait_stream(w_)
         for s in range(n_stacks):
             out_grads[s * per] = dinp[0][s]
-        return (None, None, None, None) + tuple(None if sunk[i] else g for i, g in enumerate(out_grads))
+        return (None, None, None, None, None) + tuple(None if sunk[i] else g for i, g in enumerate(out_grads))
 
 
 def multi_bigru(stacks, cat=None):
@@ -1555,7 +1561,11 @@ def multi_bigru(stacks, cat=None):
         flat.append(x)
         flat.extend(prm)
     lo, hi = cat if cat is not None else (0, 0)
-    res = _MultiBiGRU.apply(len(stacks), L, lo, hi, *flat)
+    unit_mask = sum(1 << i for i, (x, _, _) in enumerate(stacks) if getattr(x, "_m3t_unit", False))
+    res = _MultiBiGRU.apply(len(stacks), L, lo, hi, unit_mask, *flat)
+    for i in range(len(stacks)):
+        if res[2 * i].numel():
+            res[2 * i]._m3t_unit = True           # |h| <= 1: a consumer's fp16x3 contraction takes the constant magnitude slot (linear, multi_bigru)
     return [(res[2 * i], res[2 * i + 1]) for i in range(len(stacks))]
 
 
@@ -2306,8 +2316,13 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
         st, pd = ctx.stride, ctx.padding
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = torch.ops.aten.convolution_backward(dy, x, w, None, list(st), list(pd), [1, 1, 1], False, [0, 0, 0], 1,
-                                                     [True, False, False])[0]
+            if x.shape[2] == 1 and w.shape[2] == 1 and st[0] == 1 and pd[0] == 0:
+                # a 2-D convolution with a unit time axis (models.resnet.GemmConv2d): MIOpen's 2-D data gradient, not its 3-D one
+                dx = torch.ops.aten.convolution_backward(dy.squeeze(2), x.squeeze(2), w.squeeze(2), None, list(st[1:]), list(pd[1:]), [1, 1],
+                                                         False, [0, 0], 1, [True, False, False])[0].unsqueeze(2)
+            else:
+                dx = torch.ops.aten.convolution_backward(dy, x, w, None, list(st), list(pd), [1, 1, 1], False, [0, 0, 0], 1,
+                                                         [True, False, False])[0]
         Co, Ci, kt, kh, kw = w.shape
         slot_dy = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):

@@ -1,10 +1,10 @@
 """models.resnet -- per-frame ResNet-18/34 feature extractor with optional CBAM gating.
 
 API/state-dict compatible with the reference's models/resnet.py:18-124 (`BasicBlock`,
-`ResNet`, v1) and :127-251 (`BasicBlockV2`, `ResNetV2`).  The dense 2-D convolutions stay on
-PyTorch-ROCm (MIOpen) ops -- SURVEY.md section 2.2: north_star names only the gating / TCN / GRU /
-fusion kernels as hand-written -- while every CBAM gate inside the blocks (models.cbam) and,
-since round 4, BatchNorm2d with the ReLU behind it (PlaneBatchNorm2d) run in the HIP library.
+`ResNet`, v1) and :127-251 (`BasicBlockV2`, `ResNetV2`).  Every CBAM gate inside the blocks (models.cbam), since round 4
+BatchNorm2d with the ReLU behind it (PlaneBatchNorm2d) and since round 5 the forward and weight gradient of the dense 2-D
+convolutions (GemmConv2d: patch matrix x fp16x3 GEMM) run in the HIP library; the convolutions' data gradient stays on
+PyTorch-ROCm (MIOpen) ops.
 """
 import torch
 import torch.nn as nn
@@ -33,12 +33,26 @@ class PlaneBatchNorm2d(nn.BatchNorm2d):
         return torch.relu(y) if self.fuse_relu else y
 
 
+class GemmConv2d(nn.Conv2d):
+    """nn.Conv2d (same parameters / state_dict keys) of the per-frame ResNet on m3t.ops.conv3d with a unit time axis (round 5): forward =
+    patch matrix x W^T on the fp16x3 GEMM, weight gradient = dy^T x the same matrix (the per-frame maps are 512 frames x 28^2 ... 4^2
+    positions: rows in whole 128-row tiles, K = 9 C_in); the data gradient stays on MIOpen.  MIOpen's fp32 kernels ran these at a few
+    tens of TFLOP/s.  Other inputs (CPU, other dtypes, no gradient, untileable shapes, M3T_CONV3D_MIOPEN=1) take the stock op."""
+
+    def forward(self, x):
+        if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and torch.is_grad_enabled() and self.weight.requires_grad
+                and self.groups == 1 and tuple(self.dilation) == (1, 1) and self.padding_mode == "zeros" and isinstance(self.padding, tuple)):
+            y = ops.conv3d(x.unsqueeze(2), self.weight.unsqueeze(2), self.bias, (1,) + tuple(self.stride), (0,) + tuple(self.padding))
+            return y.squeeze(2)
+        return super().forward(x)
+
+
 def conv3x3(in_planes, out_planes, stride=1):
-    return nn.Conv2d(in_planes, out_planes, 3, stride, 1, bias=False)
+    return GemmConv2d(in_planes, out_planes, 3, stride, 1, bias=False)
 
 
 def conv1x1(in_planes, out_planes, stride=1):
-    return nn.Conv2d(in_planes, out_planes, 1, stride, bias=False)
+    return GemmConv2d(in_planes, out_planes, 1, stride, bias=False)
 
 
 class BasicBlock(nn.Module):
@@ -167,7 +181,7 @@ class ResNetV2(_Trunk):
     def _make_layer(self, block, planes, blocks, stride=1, use_cbam=False):
         down = None
         if stride != 1 or self.inplanes != planes * block.expansion:
-            down = nn.Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False)
+            down = GemmConv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False)
         seq = [block(self.inplanes, planes, stride, down, stride == 1, use_cbam=use_cbam)]
         self.inplanes = planes * block.expansion
         seq += [block(self.inplanes, planes, use_cbam=use_cbam) for _ in range(1, blocks)]
