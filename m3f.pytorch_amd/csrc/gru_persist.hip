@@ -1024,7 +1024,8 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd6_kernel(BwdGroup g, FragPt
         for (int i = 0; i < 6; ++i) ex.prof[i] = (unsigned long long)psum[i];
 }
 
-// ---- producer-side operand split (gru_persist_bwd3p_kernel, DESIGN.md section 7 / NOTEBOOK.md section 5e) --------------------------------------------------
+// ---- producer-side operand split (gru_persist_bwd3q_kernel below; its narrow predecessor gru_persist_bwd3p_kernel of round 3 was removed in round 5:
+// no default-mode launch used it any more -- VERDICT r4 weak-10; DESIGN.md section 7 / NOTEBOOK.md section 5e) ----------------------------------------
 // The shipped six-product backward step is bound by its consumers' operand split (264 VALU instructions per lane and step, redone by
 // all 32 workgroups of a group on the same 16 x 1536 values).  Here each PRODUCER splits its own three values (dr~, dz~, dn~ r) into two
 // fp16 terms, scaled by the power of two of its tile's largest magnitude (16 rows x 16 units x 3 values: exact, so nothing can
@@ -1034,58 +1035,6 @@ __global__ __launch_bounds__(NT) void gru_persist_bwd6_kernel(BwdGroup g, FragPt
 typedef unsigned pu32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 pf16x4 __attribute__((ext_vector_type(4)));
 struct PrepBwd3pArgs { const float* w[M3T_MAX_SCANS]; unsigned short* wf[M3T_MAX_SCANS]; float* inv[M3T_MAX_SCANS]; };
-// wfrag3p[ub][wave][gate][tile m][term][lane][4 fp16]: term of W_hh[gate*H + 16*(wave + NW*m) + 4*(lane>>4) + i][ub*16 + (lane&15)] * scale(ub)
-__global__ __launch_bounds__(256) void wfrag_bwd3p_prep_kernel(PrepBwd3pArgs a, int H, int direct) {
-    const float* __restrict__ w = a.w[blockIdx.z];
-    unsigned short* __restrict__ wf = a.wf[blockIdx.z];
-    const int ub = blockIdx.x, nc = H >> 7;
-    __shared__ float red[4];
-    float m = 0.f;
-    // the slice: all 3H gate rows x this workgroup's 16 output units (float4 loads, four in flight per thread)
-    const int tot4 = 3 * H * 4;
-    auto ld = [&](int i) {
-        return direct ? *reinterpret_cast<const float4*>(w + (size_t)(i >> 2) * H + ub * 16 + 4 * (i & 3))
-                      : *reinterpret_cast<const float4*>(w + ((size_t)ub * 16 + i / (3 * H / 4)) * 3 * H + 4 * (i % (3 * H / 4)));
-    };
-    auto fold = [&](const float4& v) {
-        m = fmaxf(fmaxf(m, m3t_fin_abs(v.x)), fmaxf(m3t_fin_abs(v.y), fmaxf(m3t_fin_abs(v.z), m3t_fin_abs(v.w))));
-    };
-    int i0 = threadIdx.x;
-    for (; i0 + 768 < tot4; i0 += 1024) {
-        const float4 v0 = ld(i0), v1 = ld(i0 + 256), v2 = ld(i0 + 512), v3 = ld(i0 + 768);
-        fold(v0); fold(v1); fold(v2); fold(v3);
-    }
-    for (; i0 < tot4; i0 += 256) fold(ld(i0));
-    m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-    __syncthreads();
-    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    float sc, inv;
-    m3t_f16_scale(__float_as_uint(m), sc, inv);
-    if (threadIdx.x == 0 && blockIdx.y == 0) a.inv[blockIdx.z][ub] = inv;
-    // one item = the four k of one (gate, tile, wave, lane): four row reads at the same column (16 consecutive lanes = one 64-byte run per
-    // row), one 8-byte store per term (16 consecutive lanes = 128 contiguous bytes)
-    const int items = 3 * 4 * H;                      // 3 gates x (H / 16) 16-unit groups x 64 lanes
-    for (int j = blockIdx.y * 256 + threadIdx.x; j < items; j += 256 * PREP3H_SPLIT) {
-        const int l = j & 63;
-        int r = j >> 6;
-        const int tl = r % nc; r /= nc;
-        const int wv = r % NW, gt = r / NW;
-        const int unit0 = 16 * (wv + NW * tl) + 4 * (l >> 4), n = l & 15;
-        unsigned short h1[4], h2[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float x = (direct ? w[((size_t)gt * H + unit0 + i) * H + ub * 16 + n]
-                                    : w[((size_t)ub * 16 + n) * 3 * H + (size_t)gt * H + unit0 + i]) * sc;
-            const _Float16 a1 = (_Float16)x;
-            const _Float16 a2 = (_Float16)(x - (float)a1);
-            h1[i] = __builtin_bit_cast(unsigned short, a1); h2[i] = __builtin_bit_cast(unsigned short, a2);
-        }
-        const size_t base = (((((size_t)(ub * NW + wv) * 3 + gt) * nc + tl) * 2) * 64 + l) * 4;
-        *reinterpret_cast<uint2*>(wf + base) = make_uint2((unsigned)h1[0] | ((unsigned)h1[1] << 16), (unsigned)h1[2] | ((unsigned)h1[3] << 16));
-        *reinterpret_cast<uint2*>(wf + base + 256) = make_uint2((unsigned)h2[0] | ((unsigned)h2[1] << 16), (unsigned)h2[2] | ((unsigned)h2[3] << 16));
-    }
-}
 // max over the wave of a non-negative float's bit pattern, uniform: four DPP steps inside each row of 16 lanes, then the four row
 // maxima through v_readlane
 __device__ __forceinline__ unsigned wave_umax_dpp(unsigned v) {
@@ -1101,133 +1050,6 @@ __device__ __forceinline__ unsigned bwd3p_split(float xs) {          // the scal
     const _Float16 h1 = (_Float16)xs;
     const _Float16 h2 = (_Float16)(xs - (float)h1);
     return (unsigned)__builtin_bit_cast(unsigned short, h1) | ((unsigned)__builtin_bit_cast(unsigned short, h2) << 16);
-}
-
-template <int NC>
-__global__ __launch_bounds__(NT) void gru_persist_bwd3p_kernel(BwdGroup g, FragPtrs fp, ExPtrs ex, int B, int T, int G, int nrb,
-                                                             unsigned* err) {
-    constexpr int RT = 1, ROWS = 16;
-    constexpr int H = 128 * NC, H3 = 3 * H, nchh = H >> 4;
-    __shared__ float red[2][NW][ROWS][UB + 1];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int gid, ub;
-    if (!persist_map((int)blockIdx.x, G, ex.slot_map, gid, ub)) return;      // a block of an XCD slot that hosts no group of this launch
-    const int s = gid / nrb, rb = gid % nrb;
-    const m3t_gru_bwd_desc d = g.d[s];
-    const int j0 = ub * UB, r0 = rb * ROWS;
-
-    pu32x2 wb[3][NC][2];                                // [gate][producer tile of this wave's K-slice][term]: 4 fp16 per lane, 48 VGPRs at H = 512
-    {
-        const pu32x2* Wf = reinterpret_cast<const pu32x2*>(fp.wfrag[s]) + ((size_t)(ub * NW + wave) * 3 * NC * 2) * 64 + lane;
-#pragma unroll
-        for (int gt = 0; gt < 3; ++gt)
-#pragma unroll
-            for (int m = 0; m < NC; ++m)
-#pragma unroll
-                for (int t = 0; t < 2; ++t) wb[gt][m][t] = Wf[((gt * NC + m) * 2 + t) * 64];
-    }
-    const float winv = reinterpret_cast<const float*>(fp.wfrag[s])[(size_t)4 * H * H + ub];     // 1 / (scale of this slice's W_hh^T)
-    __shared__ __attribute__((aligned(16))) unsigned pmx4[4];      // the cell-math waves' maxima of the step (two lowest bits: step tag)
-    if (tid < 4) pmx4[tid] = 0u;
-    const unsigned pmx4_addr = (unsigned)(uintptr_t)pmx4;        // (LDS byte address for the ds_read_b128 of the exchange)
-    const bool pw = tid < ROWS * UB;                   // granule-order numbering, as in the forward kernel
-    const int prow = (tid >> 8) * 16 + (tid & 15), pu = ((tid >> 4) & 3) * 4 + ((tid >> 6) & 3);
-    const int pb = r0 + prow, pj = j0 + pu;
-    const bool pok = pw && pb < B;
-    float dh_carry = 0.f, z_next = 0.f;                // dh_{t+1} and z_{t+1} of this thread's (row, unit)
-    float sb_r = 0.f, sb_z = 0.f, sb_n = 0.f, sb_nr = 0.f;   // sums over t of the gate gradients: the bias gradients of this clip
-    float amx = 0.f;                                   // max |dr~|, |dz~|, |dn~| of this thread: the magnitude slot d.amax (fp16x3 GEMMs)
-    if (pok && d.dh_n) dh_carry = d.dh_n[(size_t)pb * H + pj];
-
-    constexpr size_t TILE = (size_t)RT * 256;
-    u32x4* gran = reinterpret_cast<u32x4*>(ex.gran[s]);
-    const size_t slot = ex.slot[s];
-    const size_t grp = (size_t)rb * nchh * TILE;
-    const size_t pub = grp + (size_t)ub * TILE + tid;
-    bool dead = false;
-    int poll_delay = ex.poll_fixed >= 0 ? ex.poll_fixed : POLL_DELAY_INIT;
-    __shared__ unsigned poll_fail[2];                  // by step parity
-    __shared__ int pub_step;                           // steps this workgroup has published (thread 0)
-    const int l2mode = persist_handshake(ex, gid, ub, H >> 4, tid, err);     // 1: this group shares one XCD's L2 (publish with plain stores)
-    if (tid == 0) pub_step = 0;
-    if (tid < 2) poll_fail[tid] = 0;                   // first read after the first barrier
-    const bool stamp = ex.prof != nullptr && blockIdx.x == 0 && tid == ex.prof_tid;
-    long long psum[6] = {0, 0, 0, 0, 0, 0}, last = stamp ? clock64() : 0;
-
-    // HBM traffic of a step and the chain.  Vector-memory operations retire in order, so everything a wave has issued
-    // before its gather loads sits in front of the gather's vmcnt(0): with the step's six result stores and the next
-    // step's three activation loads issued after the publish (the natural place), every step waited ~0.7 us for each
-    // group (tools/scan_bench.py ablation), and hipcc added a vmcnt(0) + register copies at the bottom of the step on
-    // top (2.4 of 5 us, in-kernel stamps).  Now: the results of step t are kept in registers and stored, and the
-    // activations of step t+1 are requested, right AFTER the gather of step t has completed -- they have the whole
-    // step (MFMAs, barrier, cell math, publish, the peers' latency) to retire before the next gather waits, and between
-    // the publish and the next gather a wave has nothing outstanding but the publish itself.  Two register sets (A for
-    // even steps, B for odd ones; the loop body is included twice) hold the activations; the loads are inline asm,
-    // UNCONDITIONAL (every thread, every step; lanes past the batch and the step past the end re-read a valid address):
-    // compiler-visible or conditional definitions make hipcc wait for them or merge them with copies that read
-    // registers still in flight.  A set is defined by the vmcnt(0) of the gather that precedes its use and laundered there.
-    float doutA, hprevA, doutB, hprevB;
-    f32x4 g4A, g4B;                                    // (r, z, n, W_hn h + b_hn) of this (row, unit, t)
-    const int pbc = pb < B ? pb : B - 1;
-    const float* pd0 = d.dout + (size_t)pbc * T * d.ldo + d.ooff + pj;
-    const float* pg0 = d.gates + (size_t)pbc * T * 4 * H + 4 * (size_t)pj;
-    const float* ph0 = d.out + (size_t)pbc * T * d.ldo + d.ooff + pj;
-#define M3T_BWD_LOAD_STEP(step_, DOUT, G4, HPREV)                                                                     \
-    do {                                                                                                               \
-        const int ls_ = (step_) < T ? (step_) : T - 1;                                                                 \
-        const int lt_ = d.reverse ? ls_ : T - 1 - ls_;                                                                 \
-        const int ltp_ = ls_ < T - 1 ? (d.reverse ? lt_ + 1 : lt_ - 1) : lt_;                                          \
-        asm volatile("global_load_dword %0, %3, off\n\t"                                                               \
-                     "global_load_dwordx4 %1, %4, off\n\t"                                                             \
-                     "global_load_dword %2, %5, off"                                                                   \
-                     : "=&v"(DOUT), "=&v"(G4), "=&v"(HPREV)                                                            \
-                     : "v"(pd0 + (size_t)lt_ * d.ldo), "v"(pg0 + (size_t)lt_ * 4 * H), "v"(ph0 + (size_t)ltp_ * d.ldo)  \
-                     : "memory");                                                                                      \
-    } while (0)
-    M3T_BWD_LOAD_STEP(0, doutA, g4A, hprevA);
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(doutA), "+v"(g4A), "+v"(hprevA) :: "memory");
-    __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0), visible to hipcc: no wait for the weight fragments inside the loop
-    float st_dr = 0.f, st_dz = 0.f, st_dn = 0.f, st_dnr = 0.f;     // results of the previous step, stored after this step's gather
-    auto store_results = [&](int step_of) {
-        const int t = d.reverse ? step_of : T - 1 - step_of;
-        float* gx = d.dgx + ((size_t)pb * T + t) * d.ldg + d.goff;
-        gx[pj] = st_dr; gx[H + pj] = st_dz; gx[2 * H + pj] = st_dn;
-        float* gh = d.dgh + ((size_t)pb * T + t) * H3;
-        gh[pj] = st_dr; gh[H + pj] = st_dz; gh[2 * H + pj] = st_dnr;
-    };
-
-    for (int step2 = 0; step2 < T; step2 += 2) {
-#define STEPV step2
-#define CUR(x) x##A
-#define NXT(x) x##B
-#include "gru_persist_bwd3p_step.inc"
-#undef STEPV
-#undef CUR
-#undef NXT
-        if (step2 + 1 >= T) break;
-#define STEPV (step2 + 1)
-#define CUR(x) x##B
-#define NXT(x) x##A
-#include "gru_persist_bwd3p_step.inc"
-#undef STEPV
-#undef CUR
-#undef NXT
-    }
-#undef M3T_BWD_LOAD_STEP
-    // the last step's request for "the next step's inputs" is still in flight and invisible to hipcc (inline asm): a wave must
-    // not end with a load outstanding into registers that the next wave on this SIMD is about to own
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (pok) d.dh[(size_t)pb * H + pj] = dh_carry;
-    if (pok && d.db_part) {
-        float* q = d.db_part + (size_t)pb * 4 * H + pj;
-        q[0] = sb_r; q[H] = sb_z; q[2 * H] = sb_n; q[3 * H] = sb_nr;
-    }
-    if (d.amax && pw) {                                // (waves 0..3: uniform per wave)
-        const float m = wave_max(pok ? amx : 0.f);
-        if (lane == 0) atomicMax(d.amax, (unsigned long long)__float_as_uint(m));
-    }
-    if (stamp)
-        for (int i = 0; i < 6; ++i) ex.prof[i] = (unsigned long long)psum[i];
 }
 
 // ---- wide producer-split backward scan with 32-deep MFMAs (gru_persist_bwd3q_kernel, round 4) ---------------------------------------------
@@ -2025,8 +1847,8 @@ int persist_fwd_launch(const FwdGroup& g, const FragPtrs& fp, int B, int T, int 
     return 0;
 }
 
-// M3T_SCAN_BWD3P=0: the six-product backward scan (consumer-side split) for the H = 512 levels also in the fp16x3 mode, instead of the
-// producer-split kernel (gru_persist_bwd3p_kernel: 3.85 -> 3.44 us per step at 4 x H=512, DESIGN.md section 7 / NOTEBOOK.md section 5e)
+// M3T_SCAN_BWD3P=0: the six-product backward scan (consumer-side split) for the H = 512 / 256 levels also in the fp16x3 mode, instead of the
+// producer-split kernel (gru_persist_bwd3q_kernel; DESIGN.md section 7 / NOTEBOOK.md section 5e)
 static bool bwd3p_enabled() {
     static int on = -1;
     if (on < 0) { const char* e = getenv("M3T_SCAN_BWD3P"); on = (e && e[0] == '0') ? 0 : 1; }
@@ -2050,9 +1872,10 @@ int persist_bwd_launch(const BwdGroup& g, const FragPtrs& fp, int B, int T, int 
     // workgroups, one group per XCD, L2-served exchange -- in the C3 step the audio stack's backward scans (beside the heavy level's)
     // 0.80 / 0.96 -> 0.70 / 0.86 ms, the step 12.25 -> 12.15 ms; the NARROW producer-split form lost at H = 256 in round 3 (2.40 -> 2.50)
     const bool wide256 = (flags & M3T_SCAN_WIDE) && sh.rt == 1 && wide_enabled();
+    // (round 5: the producer-split form exists only as the WIDE kernel; a launch that does not ask for it -- M3T_SCAN_WIDE=0 -- runs the six-product kernel)
     const bool p3 = !b16 && persist_bwd_uses_x6(g, B, T, flags) && (flags & M3T_GEMM_F16X3) && m3t_f16x3_enabled() && bwd3p_enabled() &&
-                    (sh.nc == 4 || (sh.nc == 2 && wide256)) && (unsigned long long)T + 1 < 0xffffffull;      // (H = 256 narrow: 2.40 -> 2.50 us per step, keeps the six-product kernel)
-    const int uw = ((flags & M3T_SCAN_WIDE) && p3 && sh.rt == 1 && wide_enabled()) ? 2 : 1;      // wide workgroups: two unit tiles each, half the grid
+                    wide256 && (sh.nc == 4 || sh.nc == 2) && (unsigned long long)T + 1 < 0xffffffull;
+    const int uw = p3 ? 2 : 1;      // wide workgroups: two unit tiles each, half the grid
     if (uw > 1) {
         if (!level_shape(g.d, g.n, B, sh, uw)) return M3T_EINVAL;
         ex.slot_map = sh.slot_map;
@@ -2094,16 +1917,7 @@ int persist_bwd_launch(const BwdGroup& g, const FragPtrs& fp, int B, int T, int 
             M3T_LAUNCH_CHECK();
             return 0;
         }
-        wfrag_bwd3p_prep_kernel<<<dim3(H / 16, PREP3H_SPLIT, g.n), 256, 0, s>>>(pa, H, (flags & M3T_SCAN_WHH) ? 1 : 0);
-        M3T_LAUNCH_CHECK();
-        { const int e = persist_take_after(s); if (e) return e; }
-        persist_record_start(s);
-        const BwdKernel kk = sh.nc == 2 ? gru_persist_bwd3p_kernel<2> : gru_persist_bwd3p_kernel<4>;
-        const size_t dyn = exclusive_lds(kk, sh.active);
-        hipLaunchKernelGGL(kk, dim3(sh.grid), dim3(NT), dyn, s, g, fp, ex, B, T, sh.G, sh.nrb, g_err_dev);
-        persist_record_end(s);
-        M3T_LAUNCH_CHECK();
-        return 0;
+        return M3T_EINVAL;      // (unreachable: p3 implies the wide form since round 5)
     }
     if (b16) {
         for (int i = 0; i < g.n; ++i) {                                      // W_hh^T -> bf16 B-operand fragments
@@ -2199,8 +2013,8 @@ int persist_workgroups(int n, int H, int B, int T, int flags, bool backward) {
         const bool b16 = persist_bwd_uses_16(g, B, T, flags);
         const bool wide256 = (flags & M3T_SCAN_WIDE) && sh.rt == 1 && wide_enabled();
         const bool p3 = !b16 && persist_bwd_uses_x6(g, B, T, flags) && (flags & M3T_GEMM_F16X3) && m3t_f16x3_enabled() && bwd3p_enabled() &&
-                        (sh.nc == 4 || (sh.nc == 2 && wide256)) && (unsigned long long)T + 1 < 0xffffffull;
-        if ((flags & M3T_SCAN_WIDE) && p3 && sh.rt == 1 && wide_enabled() && !level_shape(g.d, g.n, B, sh, 2)) return 0;
+                        wide256 && (sh.nc == 4 || sh.nc == 2) && (unsigned long long)T + 1 < 0xffffffull;
+        if (p3 && !level_shape(g.d, g.n, B, sh, 2)) return 0;
         return sh.active;
     }
     FwdGroup g;
@@ -2227,8 +2041,8 @@ int persist_progress_ok(int n, int H, int B, int T, int flags, bool backward) {
         const bool b16 = persist_bwd_uses_16(g, B, T, flags);
         const bool wide256 = (flags & M3T_SCAN_WIDE) && sh.rt == 1 && wide_enabled();
         const bool p3 = !b16 && persist_bwd_uses_x6(g, B, T, flags) && (flags & M3T_GEMM_F16X3) && m3t_f16x3_enabled() && bwd3p_enabled() &&
-                        (sh.nc == 4 || (sh.nc == 2 && wide256)) && (unsigned long long)T + 1 < 0xffffffull;
-        return ((flags & M3T_SCAN_WIDE) && p3 && sh.rt == 1 && wide_enabled()) ? 1 : 0;
+                        wide256 && (sh.nc == 4 || sh.nc == 2) && (unsigned long long)T + 1 < 0xffffffull;
+        return p3 ? 1 : 0;
     }
     FwdGroup g;
     std::memset(&g, 0, sizeof(g));

@@ -583,7 +583,7 @@ def range_probe_report(clear=True):
 
 
 PREP_AHEAD = [os.environ.get("M3T_SCAN_PREP_AHEAD", "1") != "0"]      # the backward scans' weight fragments during forward (A/B switch, tests)
-SCAN_FIRST = [os.environ.get("M3T_SCAN_FIRST", "1") != "0"]            # weight gradients of level l start once the scan of level l - 1 is resident
+SCAN_FIRST = [os.environ.get("M3T_SCAN_FIRST", "0") == "1"]            # opt-in (measured neutral: 12.005 vs 12.017 ms): weight gradients of level l start once the scan of level l - 1 is resident
 FORCE_WIDE_FWD = [False]    # tests: every forward scan asks for the wide form (by default only the level that makes room for the audio scans does)
 SCAN_FP32 = [False]         # tests: keep the persistent forward scan on fp32 MFMAs (bit-identical to the per-step kernels)
 
@@ -694,9 +694,10 @@ def _scan_arena(device):
 # MARKS (include/m3t_hip.h, m3t_gru_scan_progress); a consumer stream waits for a mark with a one-lane gate kernel and runs the product of
 # that direction's half over that TIME WINDOW (m3t_sgemm_window) while the scan is still running.  Per window the first arriver writes
 # (+ bias), the second accumulates -- the order is fixed by the windows' arrival steps, so results do not depend on timing.
-# M3T_SCAN_CHUNKS: "1" (default) both passes, "fwd" / "bwd" one pass only, "0" off; tests flip CHUNKS[0] (True / False): the unchunked
-# schedule is the yardstick of the chunked one
-_ce = os.environ.get("M3T_SCAN_CHUNKS", "1")
+# M3T_SCAN_CHUNKS: "0" (default: OFF -- measured slower, NOTEBOOK.md R5.1: 12.17 ms unchunked, 12.48 forward only, 12.30 backward only,
+# 12.65 both), "1" both passes, "fwd" / "bwd" one pass only; tests flip CHUNKS[0] (True / False): the unchunked schedule is the yardstick
+# of the chunked one
+_ce = os.environ.get("M3T_SCAN_CHUNKS", "0")
 CHUNKS = [{"0": False, "1": True}.get(_ce, _ce)]
 _CHUNK_WINDOWS = 4
 _PROGRESS = {}

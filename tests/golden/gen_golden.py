@@ -234,7 +234,9 @@ def draw_audio(rs, shape, audio):
     return draw(rs, shape)
 
 
-def case_c3(name, B, T, seed, d_a=128, d_v=256, nh=512, with_norm=False, audio="normal"):
+def case_c3(name, B, T, seed, d_a=128, d_v=256, nh=512, with_norm=False, audio="normal", full_grads=None):
+    """full_grads = (file name, [parameter names]): the FULL gradient tensors of those parameters (before the clip) go into a fixture of
+    their own (full-size backward pinned beyond norms and leading values for one parameter group)"""
     rs = np.random.RandomState(seed)
     m = fill_module(RefAVFeatureGraph(d_a, d_v, nh), seed + 1).eval()
     lossmod = AffWild2VA(hp(modality="audio", loss="ccc_mtl"))
@@ -258,6 +260,12 @@ def case_c3(name, B, T, seed, d_a=128, d_v=256, nh=512, with_norm=False, audio="
     ccc_v = concordance_cc2(y[..., 7].reshape(-1), val.reshape(-1), "none").squeeze()
     ccc_a = concordance_cc2(y[..., -1].reshape(-1), aro.reshape(-1), "none").squeeze()
     grads = {"gd." + n: grad_digest(p.grad.numpy()) for n, p in m.named_parameters()}
+    if full_grads is not None:
+        pd = dict(m.named_parameters())
+        save(full_grads[0], seed=np.array(seed), dims=np.array([B, T, d_a, d_v, nh]),
+             **{"g." + n: pd[n].grad.numpy().copy() for n in full_grads[1]})
+        if full_grads[2]:
+            return
     if with_norm:
         # what Lightning's gradient_clip_val=1.0 computes (reference train.py:35): the global L2 norm of all gradients
         gn = torch.nn.utils.clip_grad_norm_(list(m.parameters()), 1.0)
@@ -640,6 +648,10 @@ def main():
         # clip norm only (weights and inputs are regenerated from the seed)
         case_c3("c3_av_graph_b32", 32, 300, 12345, with_norm=True)
         case_seq_model("c2_tcn_gru_b32", lambda: RefTcnGru(256, 512), (32, 256, 300), 12345, with_norm=True)
+    if want("b32full"):
+        # the same batch once more: the full gradient tensor of the fusion GRU's layer-0 recurrent weights ([1536, 512], 3 MB)
+        case_c3("c3_av_graph_b32", 32, 300, 12345, with_norm=True,
+                full_grads=("c3_av_graph_b32_gradfull", ["fusion.gru.weight_hh_l0"], True))
     if want("autocast"):
         case_seq_model_autocast("c2_tcn_gru_b32_autocast", lambda: RefTcnGru(256, 512), (32, 256, 300), 12345)
     if want("init"):

@@ -93,8 +93,8 @@ def test_elements_far_below_the_maximum_keep_an_absolute_not_a_relative_error():
 
 
 def test_the_per_cell_bound_of_the_producer_split_backward_scan_holds():
-    """gru_persist_bwd3p_kernel scales what a cell publishes -- (dr~, dz~, dn~ r) -- by a power of two taken from
-    |dht| max(1, |W_hn h + b_hn| / 4), known before the rest of the cell math (csrc/gru_persist_bwd3p_step.inc); the cell formulas are
+    """gru_persist_bwd3q_kernel scales what a cell publishes -- (dr~, dz~, dn~ r) -- by a power of two taken from
+    |dht| max(1, |W_hn h + b_hn| / 4), known before the rest of the cell math (csrc/gru_persist_bwd3q_step.inc); the cell formulas are
     those of gru_cell_bwd (csrc/gru_common.h).  In fp32, over wide ranges, no published value exceeds the bound by more than rounding --
     the scale leaves a factor two."""
     rs = np.random.RandomState(3)

@@ -7,7 +7,9 @@ m3t_sgemm_window multiplies one direction's half over one time window while the 
   * the windowed contraction against fp64 (rows outside the window untouched, accumulate, bias, both B layouts);
   * the chunked schedule against the unchunked one (ops.CHUNKS) on FRESH inputs every iteration at recycled addresses -- a consumer that
     read a window before its producer had written it would read the previous iteration's values -- and bit-identical reruns;
-  * that the default C3 step really takes the chunked path (gate launches counted through the window GEMM's wrapper).
+  * that the chunked path really ran (calls counted through the window GEMM's wrapper).  The schedule is OFF by default (measured slower:
+    NOTEBOOK.md R5.1) and stays tested as the M3T_SCAN_CHUNKS switch; the start marks of M3T_SCAN_FIRST and the fragments prepared during
+    forward are pinned bit-identical to the schedule without them.
 """
 import numpy as np
 import pytest
@@ -104,6 +106,8 @@ def _run(ops, xs, prms, douts, cat=None, L=2):
 def test_chunked_schedule_matches_unchunked_on_fresh_inputs(specs, cat):
     from m3t import ops
     B, T = 32, 300
+    saved_mode = ops.CHUNKS[0]
+    ops.CHUNKS[0] = True
     assert ops._chunk_bounds(B, T) is not None
     calls = []
     real = ops.sgemm_window_batch
@@ -131,7 +135,7 @@ def test_chunked_schedule_matches_unchunked_on_fresh_inputs(specs, cat):
                 sc = float(b.abs().max()) + 1e-30
                 assert float((a - b).abs().max()) / sc < 2e-5, float((a - b).abs().max()) / sc
     finally:
-        ops.CHUNKS[0] = True
+        ops.CHUNKS[0] = saved_mode
         ops.sgemm_window_batch = real
 
 
