@@ -86,6 +86,31 @@ extern "C" {
 int m3t_im2col3d(const float* x, int N, int Ci, int T, int H, int W, int kt, int kh, int kw, int st, int sh, int sw,
                  int pt, int ph, int pw, float* out, long long rows_pad, int Kp, unsigned long long* amax_slot, void* stream);
 
+/* The convolutions' data gradient WITHOUT a patch matrix (round 5; reference models/backbone.py:73-103,179-271, models/resnet.py:40-45): a tap-walk
+ * contraction over CHANNELS-LAST grids,
+ *   dst[(n, t, h, w)][cd] = sum over taps (jt, jh, jw) and channels cs of
+ *                           src[(n, t + base_t + sign jt, h + base_h + sign jh, w + base_w + sign jw)][cs] * w_taps[((jt kh + jh) kw + jw) C_src + cs][cd]
+ * with src rows on the grid To x Ho x Wo (terms outside it are zero) and dst rows on T x H x W: an implicit GEMM whose A tiles are whole-line loads
+ * of shifted source rows (a 32-deep k tile lies inside one tap).  Data gradient of a stride-1 convolution with padding p: src = dy channels-last
+ * [N T' H' W'][C_out] (backward has it for the weight gradient anyway), w_taps[(tap, co)][ci] = W[co][ci][tap], base = +p, sign = -1, dst = dx
+ * channels-last.  (sign = +1, base = -p, w_taps[(tap, ci)][co]: the forward convolution over a channels-last input.)
+ * N T H W % 128 == 0, C_dst % 64 == 0, C_src % 32 == 0, 16-B aligned; flags / amax as m3t_sgemm_scaled (NULL slots are measured); ws (optional):
+ * split-K slabs for the layers whose tile count does not fill the chip (deterministic reduction, as m3t_sgemm). */
+int m3t_conv3d_taps(const float* src, const float* w_taps, float* dst, int N, int C_src, int C_dst, int T, int H, int W,
+                    int To, int Ho, int Wo, int kt, int kh, int kw, int base_t, int base_h, int base_w, int sign, int flags,
+                    const unsigned long long* amax_src, const unsigned long long* amax_w, float* ws, size_t ws_bytes, void* stream);
+
+/* Operands split ONCE (round 5).  In the fp16x3 kernels every workgroup splits the operand tiles it stages -- each element as often as tiles read
+ * it, five to six vector instructions per pair beside every MFMA.  m3t_f16x3_split writes the "P4" image of a K-contiguous operand x
+ * [rows][cols] (ld): the 16 bytes of four consecutive values become {hi 0|1, hi 2|3, lo 0|1, lo 2|3}, the two fp16 terms of x * s, s the
+ * power of two of `slot` (a raised magnitude slot of x) -- same size, same addressing as x.  A kernel that takes images copies them to LDS.
+ * m3t_conv3d_taps_pre: m3t_conv3d_taps on the image of src and on w_img[cd][(tap, cs)] (the image of the K-contiguous weight matrix), under
+ * the slots the images were made with.  Bit-identical to the in-kernel split (the same roundings).  cols % 4, ld % 4, 16-B aligned. */
+int m3t_f16x3_split(const float* x, size_t rows, int cols, size_t ld, float* out, size_t ldo, const unsigned long long* slot, void* stream);
+int m3t_conv3d_taps_pre(const float* src_img, const float* w_img, float* dst, int N, int C_src, int C_dst, int T, int H, int W,
+                        int To, int Ho, int Wo, int kt, int kh, int kw, int base_t, int base_h, int base_w, int sign,
+                        const unsigned long long* amax_src, const unsigned long long* amax_w, float* ws, size_t ws_bytes, void* stream);
+
 /* Magnitude slots from the PRODUCER (fp16x3 mode, see m3t_sgemm_scaled): the NEXT m3t_conv1d_fwd(_scaled) / m3t_mask_pos / m3t_mask_pos_drop /
  * m3t_weight_norm_fwd / m3t_bct_to_btc call of the calling thread raises `slot` (8 bytes, zero-initialised by the caller, epoch 0) to the bits of max |x| over
  * its output (y / out / w_t) -- in the same kernel, one 64-bit atomic max per workgroup -- so that the contraction that consumes the output

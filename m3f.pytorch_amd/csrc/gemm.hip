@@ -775,6 +775,114 @@ extern "C" int m3t_sgemm_window(int transB, int n_seg, int win_len, int win_stri
     return m3t_sgemm_window_batch(1, &pr, transB, n_seg, win_len, win_stride, win_off, N, K, lda, ldb, ldc, act, flags, stream);
 }
 
+int m3t_conv3d_taps_launch(const float* src, const float* w_taps, float* dst, int N, int Cs, int Cd, int T, int H, int W, int To, int Ho, int Wo,
+                           int kt, int kh, int kw, int bt_, int bh, int bw, int sg, int f16x3, int pre, const unsigned long long* amax_a,
+                           const unsigned long long* amax_b, float* ws, int splits, int kchunk, hipStream_t s);
+
+// split-K of a tap walk: enough workgroups for the chip (the deep layers are a few hundred tiles with K = 13 824), slabs in `ws`
+static void taps_split(long long rows, int Cd, int K, float* ws, size_t ws_bytes, int& splits, int& kchunk) {
+    splits = 1; kchunk = K;
+    const long long tiles = (rows / 128) * ((Cd + 127) / 128);
+    if (!ws || tiles >= 512) return;
+    int sp = (int)((640 + tiles - 1) / tiles);
+    const size_t cap = ws_bytes / ((size_t)rows * Cd * sizeof(float));
+    if ((size_t)sp > cap) sp = (int)cap;
+    if (sp > K / 256) sp = K / 256;
+    if (sp < 2) return;
+    kchunk = cdiv(cdiv(K, sp), 32) * 32;
+    splits = cdiv(K, kchunk);
+}
+
+namespace {
+typedef _Float16 sp_f16x2 __attribute__((ext_vector_type(2)));
+typedef float sp_f32x2 __attribute__((ext_vector_type(2)));
+// the "P4" image of a K-contiguous fp16x3 operand (gemm_x6.hip, kc_store<PRE>): per four consecutive values {hi 0|1, hi 2|3, lo 0|1, lo 2|3}
+__global__ __launch_bounds__(256) void f16x3_split_kernel(const float* __restrict__ x, float* __restrict__ out, size_t rows, int c4, size_t ld,
+                                                          size_t ldo, const unsigned long long* __restrict__ slot) {
+    float sc, inv;
+    m3t_f16_scale((unsigned)*slot, sc, inv);
+    const size_t total = rows * (size_t)c4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / c4; const int c = (int)(i - r * c4);
+        const float4 v = *reinterpret_cast<const float4*>(x + r * ld + 4 * (size_t)c);
+        const sp_f32x2 a = (sp_f32x2){v.x, v.y} * sc, b = (sp_f32x2){v.z, v.w} * sc;
+        const sp_f16x2 ha = __builtin_convertvector(a, sp_f16x2), hb = __builtin_convertvector(b, sp_f16x2);
+        const sp_f16x2 la = __builtin_convertvector(a - __builtin_convertvector(ha, sp_f32x2), sp_f16x2);
+        const sp_f16x2 lb = __builtin_convertvector(b - __builtin_convertvector(hb, sp_f32x2), sp_f16x2);
+        float4 o;
+        o.x = __uint_as_float(__builtin_bit_cast(unsigned, ha)); o.y = __uint_as_float(__builtin_bit_cast(unsigned, hb));
+        o.z = __uint_as_float(__builtin_bit_cast(unsigned, la)); o.w = __uint_as_float(__builtin_bit_cast(unsigned, lb));
+        *reinterpret_cast<float4*>(out + r * ldo + 4 * (size_t)c) = o;
+    }
+}
+}  // namespace
+
+// include/m3t_hip.h
+extern "C" int m3t_f16x3_split(const float* x, size_t rows, int cols, size_t ld, float* out, size_t ldo, const unsigned long long* slot,
+                               void* stream) {
+    if (rows == 0 || cols <= 0) return 0;
+    if (!x || !out || !slot || cols % 4 != 0 || ld % 4 != 0 || ldo % 4 != 0 || (uintptr_t)x % 16 != 0 || (uintptr_t)out % 16 != 0) return M3T_EINVAL;
+    const size_t total = rows * (size_t)(cols / 4);
+    int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    f16x3_split_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(x, out, rows, cols / 4, ld, ldo, slot);
+    M3T_LAUNCH_CHECK();
+    return 0;
+}
+
+// include/m3t_hip.h: the tap-walk contraction over channels-last grids (the convolutions' data gradient without a patch matrix)
+extern "C" int m3t_conv3d_taps(const float* src, const float* w_taps, float* dst, int N, int C_src, int C_dst, int T, int H, int W,
+                               int To, int Ho, int Wo, int kt, int kh, int kw, int base_t, int base_h, int base_w, int sign, int flags,
+                               const unsigned long long* amax_src, const unsigned long long* amax_w, float* ws, size_t ws_bytes, void* stream) {
+    if (N <= 0 || C_dst <= 0) return 0;
+    if (!src || !w_taps || !dst || C_src <= 0 || T <= 0 || H <= 0 || W <= 0 || To <= 0 || Ho <= 0 || Wo <= 0 || kt <= 0 || kh <= 0 || kw <= 0 ||
+        (sign != 1 && sign != -1))
+        return M3T_EINVAL;
+    const long long rows = (long long)N * T * H * W, srows = (long long)N * To * Ho * Wo;
+    if (rows > 0x7fffffffll || srows > 0x7fffffffll || (long long)kt * kh * kw * C_src > 0x7fffffffll) return M3T_EINVAL;
+    if (!x6_enabled() || rows % 128 != 0 || C_dst % 64 != 0 || C_src % 32 != 0 || (uintptr_t)src % 16 != 0 || (uintptr_t)w_taps % 16 != 0 ||
+        (flags & (M3T_GEMM_BF16 | M3T_GEMM_HIGH)))
+        return M3T_EINVAL;
+    const int f16x3 = ((flags & M3T_GEMM_F16X3) && m3t_f16x3_enabled()) ? 1 : 0;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned long long* use_a = amax_src; const unsigned long long* use_b = amax_w;
+    if (f16x3) {
+        const M3TRegion ra{src, (unsigned long long)srows, (unsigned long long)C_src, C_src / 4, nullptr};
+        const M3TRegion rb{w_taps, (unsigned long long)kt * kh * kw * C_src, (unsigned long long)C_dst, C_dst / 4, nullptr};
+        const int rm = m3t_f16x3_measure(ra, amax_src, rb, amax_w, &use_a, &use_b, s);
+        if (rm) return rm;
+    }
+    int splits, kchunk;
+    taps_split(rows, C_dst, kt * kh * kw * C_src, ws, ws_bytes, splits, kchunk);
+    const int rc = m3t_conv3d_taps_launch(src, w_taps, dst, N, C_src, C_dst, T, H, W, To, Ho, Wo, kt, kh, kw, base_t, base_h, base_w, sign, f16x3, 0,
+                                          use_a, use_b, ws, splits, kchunk, s);
+    if (rc) return rc;
+    if (splits > 1) { launch_splitk_reduce(ws, dst, nullptr, (int)rows, C_dst, C_dst, splits, 0, 0, s); M3T_LAUNCH_CHECK(); }
+    return 0;
+}
+
+// ... with both operands PRE-SPLIT (m3t_f16x3_split under the SAME slots) and the weights K-contiguous: w_img[cd][(tap, cs)]
+extern "C" int m3t_conv3d_taps_pre(const float* src_img, const float* w_img, float* dst, int N, int C_src, int C_dst, int T, int H, int W,
+                                   int To, int Ho, int Wo, int kt, int kh, int kw, int base_t, int base_h, int base_w, int sign,
+                                   const unsigned long long* amax_src, const unsigned long long* amax_w, float* ws, size_t ws_bytes,
+                                   void* stream) {
+    if (N <= 0 || C_dst <= 0) return 0;
+    if (!src_img || !w_img || !dst || !amax_src || !amax_w || C_src <= 0 || T <= 0 || H <= 0 || W <= 0 || To <= 0 || Ho <= 0 || Wo <= 0 ||
+        kt <= 0 || kh <= 0 || kw <= 0 || (sign != 1 && sign != -1))
+        return M3T_EINVAL;
+    const long long rows = (long long)N * T * H * W, srows = (long long)N * To * Ho * Wo;
+    if (rows > 0x7fffffffll || srows > 0x7fffffffll || (long long)kt * kh * kw * C_src > 0x7fffffffll) return M3T_EINVAL;
+    if (!x6_enabled() || !m3t_f16x3_enabled() || rows % 128 != 0 || C_dst % 64 != 0 || C_src % 32 != 0 || (uintptr_t)src_img % 16 != 0 ||
+        (uintptr_t)w_img % 16 != 0)
+        return M3T_EINVAL;
+    int splits, kchunk;
+    taps_split(rows, C_dst, kt * kh * kw * C_src, ws, ws_bytes, splits, kchunk);
+    const int rc = m3t_conv3d_taps_launch(src_img, w_img, dst, N, C_src, C_dst, T, H, W, To, Ho, Wo, kt, kh, kw, base_t, base_h, base_w, sign, 1, 1,
+                                          amax_src, amax_w, ws, splits, kchunk, (hipStream_t)stream);
+    if (rc) return rc;
+    if (splits > 1) { launch_splitk_reduce(ws, dst, nullptr, (int)rows, C_dst, C_dst, splits, 0, 0, (hipStream_t)stream); M3T_LAUNCH_CHECK(); }
+    return 0;
+}
+
 extern "C" int m3t_colsum(const float* X, int M, int N, int ld, float* out, int accumulate, float* ws, size_t ws_bytes,
                           void* stream) {
     if (N <= 0) return 0;

@@ -45,6 +45,9 @@ struct X6Params {
     // MW kernels (m3t_sgemm_window): row m of A (TA == 0) and of C lives in storage row (m / mw_len) * mw_stride + m % mw_len + mw_off --
     // a TIME WINDOW [mw_off, mw_off + mw_len) of every clip of a [B, T, C] tensor (mw_stride = T)
     int mw_len, mw_stride, mw_off;
+    // C3 kernels (m3t_conv3d_taps): A[m][(tap, c)] = src[(n, t + bt + sg kt, h + bh + sg kh, w + bw + sg kw)][c] over channels-last grids --
+    // row m = (n, t, h, w) of the DESTINATION grid c3_T x c3_H x c3_W, source rows on the grid c3_To x c3_Ho x c3_Wo (zero outside it)
+    int c3_T, c3_H, c3_W, c3_To, c3_Ho, c3_Wo, c3_kt, c3_kh, c3_kw, c3_bt, c3_bh, c3_bw, c3_sg, c3_C;
 };
 // MW kernels run up to M3T_WINDOW_BATCH problems of one shape in one launch (blockIdx.z = problem): the pieces of one progress mark
 // (m3t_sgemm_window_batch) -- every (stack, direction) pair that reads the same window -- fill the CUs a scan leaves free as ONE grid
@@ -110,15 +113,21 @@ __device__ __forceinline__ void kc_load(const float* __restrict__ p, size_t ld, 
 #pragma unroll
     for (int i = 0; i < NR; ++i) r[i] = *reinterpret_cast<const float4*>(p + (size_t)i * 32 * ld);
 }
-template <int NS, int NR = 4>
+// PRE: the operand arrives PRE-SPLIT (m3t_f16x3_split, "P4" image: the 16 bytes of four consecutive k hold {hi k0|k1, hi k2|k3, lo k0|k1, lo k2|k3},
+// two fp16 terms of the scaled values): the store is a copy -- no conversion, no arithmetic in the loop
+template <int NS, int NR = 4, bool PRE = false>
 __device__ __forceinline__ void kc_store(unsigned char* __restrict__ S, const float4 (&r)[4], float scale = 1.f) {
     const int tid = threadIdx.x & 255;
     const int c = tid & 7, r0 = tid >> 3;            // k-quad c of the 32-k tile: octet c >> 1, half c & 1
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
         unsigned lo[3], hi2[3];                      // k pairs (0,1) and (2,3) of this row
-        split3_pair<NS>((f32x2){r[i].x, r[i].y}, lo, scale);
-        split3_pair<NS>((f32x2){r[i].z, r[i].w}, hi2, scale);
+        if (PRE) {
+            lo[0] = __float_as_uint(r[i].x); hi2[0] = __float_as_uint(r[i].y); lo[1] = __float_as_uint(r[i].z); hi2[1] = __float_as_uint(r[i].w);
+        } else {
+            split3_pair<NS>((f32x2){r[i].x, r[i].y}, lo, scale);
+            split3_pair<NS>((f32x2){r[i].z, r[i].w}, hi2, scale);
+        }
 #pragma unroll
         for (int s = 0; s < planes_of(NS); ++s)
             *reinterpret_cast<u32x2*>(S + s * SPLIT_BYTES + (c >> 1) * PLANE + (r0 + 32 * i) * 16 + (c & 1) * 8) = (u32x2){lo[s], hi2[s]};
@@ -167,7 +176,12 @@ __device__ __forceinline__ void mc_store(unsigned char* __restrict__ S, const fl
 // XNT = 64: a 128 x 64 output tile (each wave 64 x 32) for grids that would leave most CUs with a single 128 x 128 workgroup
 // (N = 512 at M = 9600: 300 tiles for 768 slots) -- twice the workgroups, the B operand staged for 64 rows only.
 // MW (TA == 0, no CONV / SEG): A's and C's rows go through the window map of X6Params (a 128-entry table in LDS: one division per thread)
-template <int TA, int TB, bool SEG, int NS, bool CONV = false, int XNT = 128, bool MW = false>
+// C3 (TA == 0, TB == 0): the 3-D form of CONV for the visual stems -- k = (tap (kt, kh, kw), channel c) over CHANNELS-LAST rows, a 32-deep k tile
+// inside one tap (C % 32 == 0): A rows are whole-line loads from rows shifted by the tap on three axes, zero outside the source grid; B is
+// the plain [taps * C][N] matrix.  Used for the convolutions' data gradient (source = dy channels-last, which backward has anyway for the
+// weight gradient; reference models/backbone.py:73-103,179-271): no patch matrix, no col2im.
+// PRE (NS == 4, K-contiguous operands): bit 0 -- A is a pre-split image, bit 1 -- B is (see kc_store)
+template <int TA, int TB, bool SEG, int NS, bool CONV = false, int XNT = 128, bool MW = false, bool C3 = false, int PRE = 0>
 __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p, X6Batch bt) {
     if (MW) {                                            // this workgroup's problem of the batch
         const int z = blockIdx.z;
@@ -234,6 +248,17 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p, X6Batch bt
         sq = k / p.seg_len; sr = k % p.seg_len;
     }
 
+    int c3_tt[C3 ? 4 : 1], c3_hh[C3 ? 4 : 1], c3_ww[C3 ? 4 : 1], c3_nb[C3 ? 4 : 1];      // C3: (t + bt, h + bh, w + bw, n * To) of this thread's four rows
+    if (C3) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int m = bm + (tid >> 3) + 32 * i;
+            const int w_ = m % p.c3_W; m /= p.c3_W;
+            const int h_ = m % p.c3_H; m /= p.c3_H;
+            const int t_ = m % p.c3_T; m /= p.c3_T;
+            c3_tt[i] = t_ + p.c3_bt; c3_hh[i] = h_ + p.c3_bh; c3_ww[i] = w_ + p.c3_bw; c3_nb[i] = m * p.c3_To;
+        }
+    }
     int cv_t[4] = {0, 0, 0, 0}, cv_k = k_begin;       // CONV: time index of this thread's four A rows; k of the next tile
     if (CONV) {
 #pragma unroll
@@ -241,7 +266,26 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p, X6Batch bt
     }
     float4 ra[4], rb[4];
     auto gload = [&]() {
-        if (CONV) {
+        if (C3) {
+            const int j = cv_k / p.c3_C, kc = cv_k - j * p.c3_C;            // tap index (kt, kh, kw), channel offset: scalar
+            const int khw = p.c3_kh * p.c3_kw;
+            const int jt = j / khw, jr = j - jt * khw, jh = jr / p.c3_kw, jw = jr - jh * p.c3_kw;
+            const int dt = p.c3_sg * jt, dh = p.c3_sg * jh, dw = p.c3_sg * jw;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ts = c3_tt[i] + dt, hs = c3_hh[i] + dh, ws = c3_ww[i] + dw;
+                const bool ok = (unsigned)ts < (unsigned)p.c3_To && (unsigned)hs < (unsigned)p.c3_Ho && (unsigned)ws < (unsigned)p.c3_Wo;
+                const size_t row = ((size_t)(c3_nb[i] + ts) * p.c3_Ho + hs) * p.c3_Wo + ws;
+                ra[i] = ok ? *reinterpret_cast<const float4*>(p.A + row * p.lda + kc + (tid & 7) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (TB == 1) kc_load<BR>(pb, p.ldb, rb);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rb[e] = bcol ? *reinterpret_cast<const float4*>(pb + e * b_krow) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            pb += b_step;
+            cv_k += XK;
+        } else if (CONV) {
             const int j = cv_k / p.cv_C, kc = cv_k - j * p.cv_C;
             const int sft = (p.cv_K - 1 - j) * p.cv_dil;
             const int off = p.cv_anti ? sft - p.cv_lead : p.cv_lead - sft;
@@ -287,8 +331,8 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p, X6Batch bt
         }
     };
     auto sstore = [&]() {
-        if (TA == 0) kc_store<NS>(As, ra, sc_a); else mc_store<NS>(As, ra, sc_a);
-        if (TB == 1) kc_store<NS, BR>(Bs, rb, sc_b); else mc_store<NS>(Bs, rb, sc_b);
+        if (TA == 0) kc_store<NS, 4, (PRE & 1) != 0>(As, ra, sc_a); else mc_store<NS>(As, ra, sc_a);
+        if (TB == 1) kc_store<NS, BR, (PRE & 2) != 0>(Bs, rb, sc_b); else mc_store<NS>(Bs, rb, sc_b);
     };
 
     if (ntiles > 0) { gload(); sstore(); }
@@ -405,6 +449,7 @@ int m3t_sgemm_x6_launch(int transA, int transB, int M, int N, int K, const float
     p.cv_drop = m3t_make_drop(0.f, 0ull);
     p.cv_amax = nullptr;
     p.mw_len = p.mw_stride = p.mw_off = 0;
+    p.c3_T = p.c3_H = p.c3_W = p.c3_To = p.c3_Ho = p.c3_Wo = p.c3_kt = p.c3_kh = p.c3_kw = p.c3_bt = p.c3_bh = p.c3_bw = p.c3_sg = p.c3_C = 0;
     dim3 grid(N / (narrow ? 64 : XN), M / XM, splits), block(256);
 #define M3T_X6_DISPATCH(NS_, XNT_)                                                                                                  \
     do {                                                                                                                           \
@@ -455,6 +500,41 @@ int m3t_sgemm_x6_window_launch(int n, const m3t_window_problem* pr, int transB, 
     if (f16x3) { if (narrow) M3T_X6W_GO(4, 64); else M3T_X6W_GO(4, 128); }
     else { if (narrow) M3T_X6W_GO(3, 64); else M3T_X6W_GO(3, 128); }
 #undef M3T_X6W_GO
+    return (int)hipGetLastError();
+}
+
+
+// The 3-D tap walk (C3 kernels; m3t_conv3d_taps).  The caller has verified: rows % 128 == 0, Cd % 64 == 0, Cs % 32 == 0, 16-B aligned operands.
+// pre: both operands are pre-split images (m3t_f16x3_split) and w_taps is [Cd][taps * Cs] (K-contiguous)
+int m3t_conv3d_taps_launch(const float* src, const float* w_taps, float* dst, int N, int Cs, int Cd, int T, int H, int W, int To, int Ho, int Wo,
+                           int kt, int kh, int kw, int bt_, int bh, int bw, int sg, int f16x3, int pre, const unsigned long long* amax_a,
+                           const unsigned long long* amax_b, float* ws, int splits, int kchunk, hipStream_t s) {
+    X6Params p;
+    if (pre && !f16x3) return M3T_EINVAL;
+    if (f16x3 && (!amax_a || !amax_b)) return M3T_EINVAL;
+    p.amax_a = amax_a; p.amax_b = amax_b; p.cv_amax = nullptr;
+    p.A = src; p.B = w_taps; p.C = dst; p.bias = nullptr; p.ws = ws;
+    p.M = N * T * H * W; p.N = Cd; p.K = kt * kh * kw * Cs; p.lda = Cs; p.ldb = pre ? kt * kh * kw * Cs : Cd; p.ldc = Cd;
+    p.act = 0; p.accumulate = 0; p.splits = splits; p.kchunk = kchunk;      // (deterministic split-K slabs: the deep layers are 144-200 tiles with K = 13 824)
+    p.seg_len = p.seg_stride = p.a_off = p.b_off = 0;
+    p.cv_T = p.cv_C = p.cv_K = p.cv_dil = p.cv_lead = p.cv_anti = 0; p.cv_btap = 0; p.cv_mask = p.cv_res = nullptr; p.cv_pre = nullptr;
+    p.cv_drop = m3t_make_drop(0.f, 0ull);
+    p.mw_len = p.mw_stride = p.mw_off = 0;
+    p.c3_T = T; p.c3_H = H; p.c3_W = W; p.c3_To = To; p.c3_Ho = Ho; p.c3_Wo = Wo; p.c3_kt = kt; p.c3_kh = kh; p.c3_kw = kw;
+    p.c3_bt = bt_; p.c3_bh = bh; p.c3_bw = bw; p.c3_sg = sg; p.c3_C = Cs;
+    const bool narrow = (Cd % 128 != 0) || (Cd / XN) * (p.M / XM) * splits <= 384;
+    dim3 grid(Cd / (narrow ? 64 : XN), p.M / XM, splits), block(256);
+#define M3T_C3_GO(NS_)                                                                                                  \
+    do {                                                                                                               \
+        if (narrow) sgemm_x6_kernel<0, 0, false, NS_, false, 64, false, true><<<grid, block, 0, s>>>(p, g_no_batch);   \
+        else sgemm_x6_kernel<0, 0, false, NS_, false, 128, false, true><<<grid, block, 0, s>>>(p, g_no_batch);         \
+    } while (0)
+    if (pre) {
+        if (narrow) sgemm_x6_kernel<0, 1, false, 4, false, 64, false, true, 3><<<grid, block, 0, s>>>(p, g_no_batch);
+        else sgemm_x6_kernel<0, 1, false, 4, false, 128, false, true, 3><<<grid, block, 0, s>>>(p, g_no_batch);
+    }
+    else if (f16x3) M3T_C3_GO(4); else M3T_C3_GO(3);
+#undef M3T_C3_GO
     return (int)hipGetLastError();
 }
 

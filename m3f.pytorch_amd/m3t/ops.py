@@ -2248,6 +2248,9 @@ def pool_planes(x, k, s, p):
 
 # ----------------------------------------------------------------------------- Conv3d of the visual stems
 CONV3D_GEMM = [os.environ.get("M3T_CONV3D_MIOPEN", "0") != "1"]      # False: forward on MIOpen as until round 4 (tested fallback)
+CONV3D_PRESPLIT = [os.environ.get("M3T_CONV3D_PRESPLIT", "1") != "0"]      # the tap walk on operands split once (m3t_f16x3_split) instead of in the kernel
+CONV3D_TAPS = [os.environ.get("M3T_CONV3D_MIOPEN", "0") not in ("1", "dgrad")]      # False: the data gradient on MIOpen ("dgrad": only that)
+
 
 
 def _conv3d_plan(x, w, stride, padding):
@@ -2307,6 +2310,7 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
         _lib.check(lib().m3t_btc_to_bct(_p(y_cl), _p(y), N_, To * Ho * Wo, Co, _stream()), "m3t_btc_to_bct")
         ctx.save_for_backward(x, w, pat, slots)
         ctx.pat = (rows, Kc, Kp)
+        ctx.a_w = a_w                 # max |W|: the same for every permutation of the weights (the data gradient's [(tap, co)][ci] matrix)
         return y
 
     @staticmethod
@@ -2316,7 +2320,13 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
         kept = (saved[2], saved[3]) if ctx.pat is not None else None      # the forward's patch matrix and its magnitude slot
         st, pd = ctx.stride, ctx.padding
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
+        Co, Ci, kt, kh, kw = w.shape
+        N_, _, T_, H_, W_ = x.shape
+        # round 5: the data gradient of a stride-1 layer as a tap-walk contraction over dy channels-last (m3t_conv3d_taps: an implicit GEMM, no
+        # patch matrix, no col2im) -- MIOpen's data gradient (Col2Im3dU + Tensile GEMMs) was ~5 ms of a C5 step
+        taps_dx = (ctx.needs_input_grad[0] and CONV3D_TAPS[0] and ctx.pat is not None and tuple(st) == (1, 1, 1) and Co % 32 == 0 and Ci % 64 == 0
+                   and (N_ * T_ * H_ * W_) % 128 == 0 and (ctx.prec & _lib.M3T_GEMM_F16X3 or ctx.prec == 0))
+        if ctx.needs_input_grad[0] and not taps_dx:
             if x.shape[2] == 1 and w.shape[2] == 1 and st[0] == 1 and pd[0] == 0:
                 # a 2-D convolution with a unit time axis (models.resnet.GemmConv2d): MIOpen's 2-D data gradient, not its 3-D one
                 dx = torch.ops.aten.convolution_backward(dy.squeeze(2), x.squeeze(2), w.squeeze(2), None, list(st[1:]), list(pd[1:]), [1, 1],
@@ -2324,9 +2334,8 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
             else:
                 dx = torch.ops.aten.convolution_backward(dy, x, w, None, list(st), list(pd), [1, 1, 1], False, [0, 0, 0], 1,
                                                          [True, False, False])[0]
-        Co, Ci, kt, kh, kw = w.shape
         slot_dy = None
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]) or taps_dx:
             # dy channels-last [N,T',H',W',Co] = [rows, Co] for the GEMM: the library's tiled transpose (both sides coalesced), which
             # raises dy's magnitude slot on the way -- was torch's strided permute copy plus a measuring launch (1.1 ms of the C5 step)
             dyc = _req(dy.contiguous(), "dy")
@@ -2342,9 +2351,30 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
                 _lib.check(lib().m3t_bct_to_btc_sums(_p(dyc), _p(dy_cl), Nn, Co, Sp, _p(dpart), _stream()), "m3t_bct_to_btc_sums")
             else:
                 _lib.check(lib().m3t_bct_to_btc(_p(dyc), _p(dy_cl), Nn, Co, Sp, _stream()), "m3t_bct_to_btc")
+        if taps_dx:
+            To, Ho, Wo = dy.shape[2], dy.shape[3], dy.shape[4]
+            dx_cl = torch.empty(N_ * T_ * H_ * W_, Ci, dtype=torch.float32, device=dy.device)
+            wsd = workspace(dy.device)
+            if (ctx.prec & _lib.M3T_GEMM_F16X3) and ctx.a_w is not None and CONV3D_PRESPLIT[0]:
+                # both operands split ONCE (m3t_f16x3_split: dy channels-last under the slot its transpose raised, the weights as the
+                # K-contiguous [ci][(tap, co)] matrix): the tap walk re-reads every dy row 27 times -- its loop is then copies and MFMAs only
+                taps = kt * kh * kw
+                w_t = w.detach().permute(1, 2, 3, 4, 0).contiguous().view(Ci, taps * Co)
+                dy_img, w_img = torch.empty_like(dy_cl), torch.empty_like(w_t)
+                _lib.check(lib().m3t_f16x3_split(_p(dy_cl), rows, Co, Co, _p(dy_img), Co, slot_dy.data_ptr(), _stream()), "m3t_f16x3_split")
+                _lib.check(lib().m3t_f16x3_split(_p(w_t), Ci, taps * Co, taps * Co, _p(w_img), taps * Co, ctx.a_w, _stream()), "m3t_f16x3_split")
+                _lib.check(lib().m3t_conv3d_taps_pre(_p(dy_img), _p(w_img), _p(dx_cl), N_, Co, Ci, T_, H_, W_, To, Ho, Wo, kt, kh, kw,
+                                                     pd[0], pd[1], pd[2], -1, slot_dy.data_ptr(), ctx.a_w, _p(wsd), wsd.numel() * 4, _stream()),
+                           "m3t_conv3d_taps_pre")
+            else:
+                w_taps = w.detach().permute(2, 3, 4, 0, 1).contiguous().view(kt * kh * kw * Co, Ci)      # [(tap, co)][ci] (a few MB per layer)
+                _lib.check(lib().m3t_conv3d_taps(_p(dy_cl), _p(w_taps), _p(dx_cl), N_, Co, Ci, T_, H_, W_, To, Ho, Wo, kt, kh, kw,
+                                                 pd[0], pd[1], pd[2], -1, ctx.prec, slot_dy.data_ptr(), ctx.a_w, _p(wsd), wsd.numel() * 4, _stream()),
+                           "m3t_conv3d_taps")
+            dx = torch.empty(N_, Ci, T_, H_, W_, dtype=torch.float32, device=dy.device)
+            _lib.check(lib().m3t_btc_to_bct(_p(dx_cl), _p(dx), N_, T_ * H_ * W_, Ci, _stream()), "m3t_btc_to_bct")
         if ctx.needs_input_grad[1]:
             Kc = Ci * kt * kh * kw
-            N_, _, T_, H_, W_ = x.shape
             xc = _req(x.contiguous(), "x")
             # round 4: ONE launch writes the patch matrix (rows (n, t', h', w'), columns (ci, kt, kh, kw), zero padded to the GEMM's tiles)
             # and raises its magnitude slot -- was ~50 torch copy kernels per convolution plus a measuring pass;

@@ -1059,6 +1059,8 @@ def test_conv3d_weight_gradient_through_the_patch_matrix(Ci, Co, k, stride, pad,
     (64, 128, (3, 3, 3), (1, 1, 1), (1, 0, 0), 2, 4, 10, 10),      # interior layers: K = 1728
     (3, 64, (5, 7, 7), (1, 2, 2), (2, 3, 3), 1, 8, 32, 32),        # the 3-D ResNet stem: 735 -> 768 columns, padding on every axis
     (128, 256, (3, 3, 3), (1, 1, 1), (1, 0, 0), 4, 8, 4, 4),       # deep layer: K = 3456 (split-K), small maps
+    (64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), 8, 1, 8, 8),         # the per-frame ResNet's 3 x 3 convolution (unit time axis, padding 1): tap-walk data gradient
+    (64, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1), 2, 4, 8, 8),        # padding on every axis
 ])
 def test_conv3d_forward_on_the_patch_matrix_gemm(Ci, Co, k, stride, pad, N, T, H, W):
     """Round 5: m3t.ops.conv3d's FORWARD is patch matrix x W^T on the fp16x3 GEMM (bias in the epilogue, tiled transpose back to
@@ -1088,6 +1090,7 @@ def test_conv3d_forward_on_the_patch_matrix_gemm(Ci, Co, k, stride, pad, N, T, H
         ops.CONV3D_GEMM[0] = True
     close(y, y2.detach().cpu().numpy(), 1e-4, "y vs MIOpen")
     close(w.grad, w2.grad.cpu().numpy(), 2e-4, "dw vs the MIOpen-forward path")
+    close(x.grad, x2.grad.cpu().numpy(), 2e-4, "dx (stride-1 layers: the tap-walk kernel m3t_conv3d_taps) vs MIOpen's data gradient")
 
 
 @pytest.mark.parametrize("N,C_,T,H,W,training", [(3, 16, 5, 7, 9, True), (2, 64, 4, 12, 12, True), (2, 8, 3, 5, 5, False), (4, 24, 1, 1, 1, True)])
