@@ -107,6 +107,10 @@ int m3t_conv3d_taps(const float* src, const float* w_taps, float* dst, int N, in
  * m3t_conv3d_taps_pre: m3t_conv3d_taps on the image of src and on w_img[cd][(tap, cs)] (the image of the K-contiguous weight matrix), under
  * the slots the images were made with.  Bit-identical to the in-kernel split (the same roundings).  cols % 4, ld % 4, 16-B aligned. */
 int m3t_f16x3_split(const float* x, size_t rows, int cols, size_t ld, float* out, size_t ldo, const unsigned long long* slot, void* stream);
+/* C[M,N] = act(A B^T + bias) (+ C) with A [M][K] and B [N][K] given as images (the NT product of m3t_sgemm_scaled, fp16x3 mode; M % 128 == 0,
+ * N % 64 == 0, K % 32 == 0, both slots required) */
+int m3t_sgemm_pre(int M, int N, int K, const float* A_img, int lda, const float* B_img, int ldb, float* C, int ldc,
+                  const float* bias, int act, int accumulate, const unsigned long long* amax_a, const unsigned long long* amax_b, void* stream);
 int m3t_conv3d_taps_pre(const float* src_img, const float* w_img, float* dst, int N, int C_src, int C_dst, int T, int H, int W,
                         int To, int Ho, int Wo, int kt, int kh, int kw, int base_t, int base_h, int base_w, int sign,
                         const unsigned long long* amax_src, const unsigned long long* amax_w, float* ws, size_t ws_bytes, void* stream);

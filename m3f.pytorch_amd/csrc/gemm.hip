@@ -817,6 +817,21 @@ __global__ __launch_bounds__(256) void f16x3_split_kernel(const float* __restric
 }
 }  // namespace
 
+int m3t_sgemm_x6_pre_launch(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc, const float* bias,
+                            int act, int accumulate, int narrow, const unsigned long long* amax_a, const unsigned long long* amax_b, hipStream_t s);
+
+// include/m3t_hip.h: C = act(A B^T + bias) (+ C) on operands split once
+extern "C" int m3t_sgemm_pre(int M, int N, int K, const float* A_img, int lda, const float* B_img, int ldb, float* C, int ldc,
+                             const float* bias, int act, int accumulate, const unsigned long long* amax_a, const unsigned long long* amax_b,
+                             void* stream) {
+    if (M <= 0 || N <= 0) return 0;
+    if (!A_img || !B_img || !C || !amax_a || !amax_b || K <= 0 || !x6_enabled() || !m3t_f16x3_enabled() || M % 128 != 0 || N % 64 != 0 ||
+        K % 32 != 0 || lda % 4 != 0 || ldb % 4 != 0 || (uintptr_t)A_img % 16 != 0 || (uintptr_t)B_img % 16 != 0)
+        return M3T_EINVAL;
+    const int narrow = (N % 128 != 0 || (long long)(M / 128) * (N / 128) <= 384) ? 1 : 0;
+    return m3t_sgemm_x6_pre_launch(M, N, K, A_img, lda, B_img, ldb, C, ldc, bias, act, accumulate, narrow, amax_a, amax_b, (hipStream_t)stream);
+}
+
 // include/m3t_hip.h
 extern "C" int m3t_f16x3_split(const float* x, size_t rows, int cols, size_t ld, float* out, size_t ldo, const unsigned long long* slot,
                                void* stream) {

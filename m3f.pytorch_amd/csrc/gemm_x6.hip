@@ -504,6 +504,26 @@ int m3t_sgemm_x6_window_launch(int n, const m3t_window_problem* pr, int transB, 
 }
 
 
+// NT product on operands split once (m3t_sgemm_pre): A [M][K], B [N][K] as "P4" images.  M % 128 == 0, N % 128 == 0 (or % 64: narrow), K % 32 == 0.
+int m3t_sgemm_x6_pre_launch(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc, const float* bias,
+                            int act, int accumulate, int narrow, const unsigned long long* amax_a, const unsigned long long* amax_b, hipStream_t s) {
+    if (!amax_a || !amax_b) return M3T_EINVAL;
+    X6Params p;
+    p.amax_a = amax_a; p.amax_b = amax_b; p.cv_amax = nullptr;
+    p.A = A; p.B = B; p.C = C; p.bias = bias; p.ws = nullptr;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.act = act; p.accumulate = accumulate; p.splits = 1; p.kchunk = K;
+    p.seg_len = p.seg_stride = p.a_off = p.b_off = 0;
+    p.cv_T = p.cv_C = p.cv_K = p.cv_dil = p.cv_lead = p.cv_anti = 0; p.cv_btap = 0; p.cv_mask = p.cv_res = nullptr; p.cv_pre = nullptr;
+    p.cv_drop = m3t_make_drop(0.f, 0ull);
+    p.mw_len = p.mw_stride = p.mw_off = 0;
+    p.c3_T = p.c3_H = p.c3_W = p.c3_To = p.c3_Ho = p.c3_Wo = p.c3_kt = p.c3_kh = p.c3_kw = p.c3_bt = p.c3_bh = p.c3_bw = p.c3_sg = p.c3_C = 0;
+    dim3 grid(N / (narrow ? 64 : XN), M / XM, 1), block(256);
+    if (narrow) sgemm_x6_kernel<0, 1, false, 4, false, 64, false, false, 3><<<grid, block, 0, s>>>(p, g_no_batch);
+    else sgemm_x6_kernel<0, 1, false, 4, false, 128, false, false, 3><<<grid, block, 0, s>>>(p, g_no_batch);
+    return (int)hipGetLastError();
+}
+
 // The 3-D tap walk (C3 kernels; m3t_conv3d_taps).  The caller has verified: rows % 128 == 0, Cd % 64 == 0, Cs % 32 == 0, 16-B aligned operands.
 // pre: both operands are pre-split images (m3t_f16x3_split) and w_taps is [Cd][taps * Cs] (K-contiguous)
 int m3t_conv3d_taps_launch(const float* src, const float* w_taps, float* dst, int N, int Cs, int Cd, int T, int H, int W, int To, int Ho, int Wo,

@@ -56,6 +56,7 @@ SIGNATURES = {
     "m3t_sgemm_plan": [_i, _i, _i, _i, _i, _z, _i, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "m3t_im2col3d": [_f] + [_i] * 14 + [_f, C.c_longlong, _i, C.c_void_p, _s],
     "m3t_conv3d_taps": [_f, _f, _f] + [_i] * 17 + [_f, _f, _f, _z, _s],
+    "m3t_sgemm_pre": [_i, _i, _i, _f, _i, _f, _i, _f, _i, _f, _i, _i, _f, _f, _s],
     "m3t_f16x3_split": [_f, _z, _i, _z, _f, _z, _f, _s],
     "m3t_conv3d_taps_pre": [_f, _f, _f] + [_i] * 16 + [_f, _f, _f, _z, _s],
     "m3t_amax_out": [C.c_void_p],
