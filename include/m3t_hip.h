@@ -115,6 +115,24 @@ int m3t_conv3d_taps_pre(const float* src_img, const float* w_img, float* dst, in
                         int To, int Ho, int Wo, int kt, int kh, int kw, int base_t, int base_h, int base_w, int sign,
                         const unsigned long long* amax_src, const unsigned long long* amax_w, float* ws, size_t ws_bytes, void* stream);
 
+/* The whole convolution without a patch matrix (round 5, second half; reference models/backbone.py:73-103,179-271, models/resnet.py:40-45 --
+ * nn.Conv3d / nn.Conv2d forward and backward of the visual stems and the per-frame ResNet).
+ * m3t_conv3d_fwd_taps: y_cl[(n, t', h', w')][co] = bias[co] + sum over (kt, kh, kw, ci) of x[(n, t' st + kt - pt, h' sh + kh - ph, w' sw + kw - pw)][ci]
+ *   W[co][ci][kt][kh][kw] over the CHANNELS-LAST input, any stride: x_img = the m3t_f16x3_split image of x_cl [N T H W][Ci], w_img = the image
+ *   of the K-contiguous weights [Co][(tap, ci)], both under the slots given; bias may be NULL.  N T' H' W' % 128 == 0, Co % 64 == 0, Ci % 32 == 0.
+ * m3t_conv3d_wgrad_taps: dwt[(tap, ci)][co] = sum over the rows r = (n, t', h', w') of the dy grid of x_cl[source row of (r, tap)][ci] dy_cl[r][co]
+ *   -- the walk turned round: the reduction runs over the rows (deterministic split-K slabs in ws), the tap is picked once per thread from
+ *   its output row, every reduction row is decoded on the dy grid by a counter (no division in the loop).  dwt has ceil128(taps Ci) rows
+ *   (rows past taps Ci are written as zeros); fp32 operands, split in the kernel; flags / amax as m3t_sgemm_scaled (NULL slots are measured).
+ *   N T' H' W' % 32 == 0, Co % 64 == 0, Ci % 4 == 0, 16-B aligned.
+ * With m3t_conv3d_taps(_pre) for the data gradient of the stride-1 layers, no convolution of the path materialises its patches. */
+int m3t_conv3d_fwd_taps(const float* x_img, const float* w_img, const float* bias, float* y_cl, int N, int Ci, int Co, int T, int H, int W,
+                        int kt, int kh, int kw, int st, int sh, int sw, int pt, int ph, int pw, const unsigned long long* amax_x,
+                        const unsigned long long* amax_w, float* ws, size_t ws_bytes, void* stream);
+int m3t_conv3d_wgrad_taps(const float* x_cl, const float* dy_cl, float* dwt, int N, int Ci, int Co, int T, int H, int W, int kt, int kh, int kw,
+                          int st, int sh, int sw, int pt, int ph, int pw, int flags, const unsigned long long* amax_x,
+                          const unsigned long long* amax_dy, float* ws, size_t ws_bytes, void* stream);
+
 /* Magnitude slots from the PRODUCER (fp16x3 mode, see m3t_sgemm_scaled): the NEXT m3t_conv1d_fwd(_scaled) / m3t_mask_pos / m3t_mask_pos_drop /
  * m3t_weight_norm_fwd / m3t_bct_to_btc call of the calling thread raises `slot` (8 bytes, zero-initialised by the caller, epoch 0) to the bits of max |x| over
  * its output (y / out / w_t) -- in the same kernel, one 64-bit atomic max per workgroup -- so that the contraction that consumes the output

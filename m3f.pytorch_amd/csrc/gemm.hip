@@ -777,7 +777,11 @@ extern "C" int m3t_sgemm_window(int transB, int n_seg, int win_len, int win_stri
 
 int m3t_conv3d_taps_launch(const float* src, const float* w_taps, float* dst, int N, int Cs, int Cd, int T, int H, int W, int To, int Ho, int Wo,
                            int kt, int kh, int kw, int bt_, int bh, int bw, int sg, int f16x3, int pre, const unsigned long long* amax_a,
-                           const unsigned long long* amax_b, float* ws, int splits, int kchunk, hipStream_t s);
+                           const unsigned long long* amax_b, float* ws, int splits, int kchunk, hipStream_t s, const int* stride3 = nullptr,
+                           const float* bias = nullptr);
+int m3t_conv3d_wgrad_launch(const float* x_cl, const float* dy_cl, float* dwt, int N, int Ci, int Co, int T, int H, int W, int To, int Ho, int Wo,
+                            int kt, int kh, int kw, const int* stride3, int pt, int ph, int pw, int f16x3, const unsigned long long* amax_x,
+                            const unsigned long long* amax_dy, float* ws, int splits, int kchunk, hipStream_t s);
 
 // split-K of a tap walk: enough workgroups for the chip (the deep layers are a few hundred tiles with K = 13 824), slabs in `ws`
 static void taps_split(long long rows, int Cd, int K, float* ws, size_t ws_bytes, int& splits, int& kchunk) {
@@ -895,6 +899,77 @@ extern "C" int m3t_conv3d_taps_pre(const float* src_img, const float* w_img, flo
                                           amax_src, amax_w, ws, splits, kchunk, (hipStream_t)stream);
     if (rc) return rc;
     if (splits > 1) { launch_splitk_reduce(ws, dst, nullptr, (int)rows, C_dst, C_dst, splits, 0, 0, (hipStream_t)stream); M3T_LAUNCH_CHECK(); }
+    return 0;
+}
+
+// include/m3t_hip.h: the forward convolution as the tap walk on operands split once
+extern "C" int m3t_conv3d_fwd_taps(const float* x_img, const float* w_img, const float* bias, float* y_cl, int N, int Ci, int Co, int T, int H,
+                                   int W, int kt, int kh, int kw, int st, int sh, int sw, int pt, int ph, int pw,
+                                   const unsigned long long* amax_x, const unsigned long long* amax_w, float* ws, size_t ws_bytes, void* stream) {
+    if (N <= 0 || Co <= 0) return 0;
+    if (!x_img || !w_img || !y_cl || !amax_x || !amax_w || Ci <= 0 || T <= 0 || H <= 0 || W <= 0 || kt <= 0 || kh <= 0 || kw <= 0 || st <= 0 ||
+        sh <= 0 || sw <= 0 || pt < 0 || ph < 0 || pw < 0)
+        return M3T_EINVAL;
+    const int To = (T + 2 * pt - kt) / st + 1, Ho = (H + 2 * ph - kh) / sh + 1, Wo = (W + 2 * pw - kw) / sw + 1;
+    if (T + 2 * pt < kt || H + 2 * ph < kh || W + 2 * pw < kw) return M3T_EINVAL;
+    const long long rows = (long long)N * To * Ho * Wo, srows = (long long)N * T * H * W;
+    if (rows > 0x7fffffffll || srows > 0x7fffffffll || (long long)kt * kh * kw * Ci > 0x7fffffffll) return M3T_EINVAL;
+    if (!x6_enabled() || !m3t_f16x3_enabled() || rows % 128 != 0 || Co % 64 != 0 || Ci % 32 != 0 || (uintptr_t)x_img % 16 != 0 ||
+        (uintptr_t)w_img % 16 != 0)
+        return M3T_EINVAL;
+    int splits, kchunk;
+    taps_split(rows, Co, kt * kh * kw * Ci, ws, ws_bytes, splits, kchunk);
+    const int stride3[3] = {st, sh, sw};
+    hipStream_t s = (hipStream_t)stream;
+    const int rc = m3t_conv3d_taps_launch(x_img, w_img, y_cl, N, Ci, Co, To, Ho, Wo, T, H, W, kt, kh, kw, -pt, -ph, -pw, 1, 1, 1, amax_x, amax_w, ws,
+                                          splits, kchunk, s, stride3, bias);
+    if (rc) return rc;
+    if (splits > 1) { launch_splitk_reduce(ws, y_cl, bias, (int)rows, Co, Co, splits, 0, 0, s); M3T_LAUNCH_CHECK(); }
+    return 0;
+}
+
+// include/m3t_hip.h: the weight gradient as the walk turned round: dwt[(tap, ci)][co], taps * Ci rounded up to 128 rows
+extern "C" int m3t_conv3d_wgrad_taps(const float* x_cl, const float* dy_cl, float* dwt, int N, int Ci, int Co, int T, int H, int W, int kt, int kh,
+                                     int kw, int st, int sh, int sw, int pt, int ph, int pw, int flags, const unsigned long long* amax_x,
+                                     const unsigned long long* amax_dy, float* ws, size_t ws_bytes, void* stream) {
+    if (Ci <= 0 || Co <= 0) return 0;
+    if (!x_cl || !dy_cl || !dwt || N <= 0 || T <= 0 || H <= 0 || W <= 0 || kt <= 0 || kh <= 0 || kw <= 0 || st <= 0 || sh <= 0 || sw <= 0 ||
+        pt < 0 || ph < 0 || pw < 0 || T + 2 * pt < kt || H + 2 * ph < kh || W + 2 * pw < kw)
+        return M3T_EINVAL;
+    const int To = (T + 2 * pt - kt) / st + 1, Ho = (H + 2 * ph - kh) / sh + 1, Wo = (W + 2 * pw - kw) / sw + 1;
+    const long long rows = (long long)N * To * Ho * Wo, srows = (long long)N * T * H * W, Kc = (long long)kt * kh * kw * Ci;
+    if (rows > 0x7fffffffll || srows > 0x7fffffffll || Kc > 0x7fffff00ll) return M3T_EINVAL;
+    if (!x6_enabled() || rows % 32 != 0 || Co % 64 != 0 || Ci % 4 != 0 || (uintptr_t)x_cl % 16 != 0 || (uintptr_t)dy_cl % 16 != 0 ||
+        (uintptr_t)dwt % 16 != 0 || (flags & (M3T_GEMM_BF16 | M3T_GEMM_HIGH)))
+        return M3T_EINVAL;
+    const int f16x3 = ((flags & M3T_GEMM_F16X3) && m3t_f16x3_enabled()) ? 1 : 0;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned long long* use_a = amax_x; const unsigned long long* use_b = amax_dy;
+    if (f16x3) {
+        const M3TRegion ra{x_cl, (unsigned long long)srows, (unsigned long long)Ci, Ci / 4, nullptr};
+        const M3TRegion rb{dy_cl, (unsigned long long)rows, (unsigned long long)Co, Co / 4, nullptr};
+        const int rm = m3t_f16x3_measure(ra, amax_x, rb, amax_dy, &use_a, &use_b, s);
+        if (rm) return rm;
+    }
+    // split-K over the rows: the output is a few tiles, the reduction hundreds of thousands of rows deep
+    const int Mp = (int)((Kc + 127) / 128 * 128);
+    const long long tiles = (long long)(Mp / 128) * ((Co + 127) / 128);
+    int splits = 1, kchunk = (int)rows;
+    if (ws) {
+        long long sp = (1536 + tiles - 1) / tiles;
+        const long long cap = (long long)(ws_bytes / ((size_t)Mp * Co * sizeof(float)));
+        if (sp > cap) sp = cap;
+        if (sp > rows / 256) sp = rows / 256;
+        if (sp >= 2) {
+            kchunk = cdiv(cdiv((int)rows, (int)sp), 32) * 32;
+            splits = cdiv((int)rows, kchunk);
+        }
+    }
+    const int stride3[3] = {st, sh, sw};
+    const int rc = m3t_conv3d_wgrad_launch(x_cl, dy_cl, dwt, N, Ci, Co, T, H, W, To, Ho, Wo, kt, kh, kw, stride3, pt, ph, pw, f16x3, use_a, use_b, ws,
+                                           splits, kchunk, s);
+    if (rc) return rc;
+    if (splits > 1) { launch_splitk_reduce(ws, dwt, nullptr, Mp, Co, Co, splits, 0, 0, s); M3T_LAUNCH_CHECK(); }
     return 0;
 }
 

@@ -48,6 +48,7 @@ struct X6Params {
     // C3 kernels (m3t_conv3d_taps): A[m][(tap, c)] = src[(n, t + bt + sg kt, h + bh + sg kh, w + bw + sg kw)][c] over channels-last grids --
     // row m = (n, t, h, w) of the DESTINATION grid c3_T x c3_H x c3_W, source rows on the grid c3_To x c3_Ho x c3_Wo (zero outside it)
     int c3_T, c3_H, c3_W, c3_To, c3_Ho, c3_Wo, c3_kt, c3_kh, c3_kw, c3_bt, c3_bh, c3_bw, c3_sg, c3_C;
+    int c3_st, c3_sh, c3_sw;             // source coordinate = destination coordinate * stride + base + sign * tap (1 for the data gradient's walk)
 };
 // MW kernels run up to M3T_WINDOW_BATCH problems of one shape in one launch (blockIdx.z = problem): the pieces of one progress mark
 // (m3t_sgemm_window_batch) -- every (stack, direction) pair that reads the same window -- fill the CUs a scan leaves free as ONE grid
@@ -180,8 +181,13 @@ __device__ __forceinline__ void mc_store(unsigned char* __restrict__ S, const fl
 // inside one tap (C % 32 == 0): A rows are whole-line loads from rows shifted by the tap on three axes, zero outside the source grid; B is
 // the plain [taps * C][N] matrix.  Used for the convolutions' data gradient (source = dy channels-last, which backward has anyway for the
 // weight gradient; reference models/backbone.py:73-103,179-271): no patch matrix, no col2im.
+// C3 = 2 (TA == 1, TB == 0): the convolution's WEIGHT gradient as the same walk turned round (m3t_conv3d_wgrad_taps) -- dW^T[(tap, ci)][co] =
+// sum over rows r = (n, t', h', w') of the dy grid of x[(n, t' st + kt - pt, ...)][ci] dy[r][co]: the REDUCTION runs over the rows, A's column
+// m = (tap, ci) picks the tap once per thread, every k row is decoded on the dy grid (a mixed-radix counter advanced by 32 per tile: no
+// division in the loop) and shifted by that tap, zero outside x's grid; columns past taps * C (M padded to the tile) read as zero.  Neither
+// the forward pass nor this one needs the patch matrix (9 - 27 x the activations: 0.9 GB per 3 x 3 layer at 512 frames of 28 x 28).
 // PRE (NS == 4, K-contiguous operands): bit 0 -- A is a pre-split image, bit 1 -- B is (see kc_store)
-template <int TA, int TB, bool SEG, int NS, bool CONV = false, int XNT = 128, bool MW = false, bool C3 = false, int PRE = 0>
+template <int TA, int TB, bool SEG, int NS, bool CONV = false, int XNT = 128, bool MW = false, int C3 = 0, int PRE = 0>
 __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p, X6Batch bt) {
     if (MW) {                                            // this workgroup's problem of the batch
         const int z = blockIdx.z;
@@ -248,16 +254,32 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p, X6Batch bt
         sq = k / p.seg_len; sr = k % p.seg_len;
     }
 
-    int c3_tt[C3 ? 4 : 1], c3_hh[C3 ? 4 : 1], c3_ww[C3 ? 4 : 1], c3_nb[C3 ? 4 : 1];      // C3: (t + bt, h + bh, w + bw, n * To) of this thread's four rows
-    if (C3) {
+    int c3_tt[C3 == 1 ? 4 : 1], c3_hh[C3 == 1 ? 4 : 1], c3_ww[C3 == 1 ? 4 : 1], c3_nb[C3 == 1 ? 4 : 1];      // C3 = 1: (t st + bt, h sh + bh, w sw + bw, n * To) of this thread's four rows
+    if (C3 == 1) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int m = bm + (tid >> 3) + 32 * i;
             const int w_ = m % p.c3_W; m /= p.c3_W;
             const int h_ = m % p.c3_H; m /= p.c3_H;
             const int t_ = m % p.c3_T; m /= p.c3_T;
-            c3_tt[i] = t_ + p.c3_bt; c3_hh[i] = h_ + p.c3_bh; c3_ww[i] = w_ + p.c3_bw; c3_nb[i] = m * p.c3_To;
+            c3_tt[i] = t_ * p.c3_st + p.c3_bt; c3_hh[i] = h_ * p.c3_sh + p.c3_bh; c3_ww[i] = w_ * p.c3_sw + p.c3_bw; c3_nb[i] = m * p.c3_To;
         }
+    }
+    // C3 = 2: this thread's tap (from its four A columns) and the dy-grid coordinates of its first k row, advanced by XK per tile
+    int g_w = 0, g_h = 0, g_t = 0, g_n = 0, adv_w = 0, adv_h = 0, adv_t = 0, adv_n = 0, g_dt = 0, g_dh = 0, g_dw = 0, g_c = 0;
+    bool g_ok = false;
+    if (C3 == 2) {
+        const int m0 = bm + (tid & 31) * 4;
+        const int j = m0 / p.c3_C;
+        g_c = m0 - j * p.c3_C;
+        g_ok = j < p.c3_kt * p.c3_kh * p.c3_kw;
+        const int khw = p.c3_kh * p.c3_kw;
+        const int jt = j / khw, jr = j - jt * khw, jh = jr / p.c3_kw, jw = jr - jh * p.c3_kw;
+        g_dt = p.c3_bt + jt; g_dh = p.c3_bh + jh; g_dw = p.c3_bw + jw;
+        int k = k_begin + (tid >> 5) * 4;
+        g_w = k % p.c3_W; k /= p.c3_W; g_h = k % p.c3_H; k /= p.c3_H; g_t = k % p.c3_T; g_n = k / p.c3_T;
+        int a = XK;
+        adv_w = a % p.c3_W; a /= p.c3_W; adv_h = a % p.c3_H; a /= p.c3_H; adv_t = a % p.c3_T; adv_n = a / p.c3_T;
     }
     int cv_t[4] = {0, 0, 0, 0}, cv_k = k_begin;       // CONV: time index of this thread's four A rows; k of the next tile
     if (CONV) {
@@ -266,7 +288,24 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p, X6Batch bt
     }
     float4 ra[4], rb[4];
     auto gload = [&]() {
-        if (C3) {
+        if (C3 == 2) {
+            int w_ = g_w, h_ = g_h, t_ = g_t, n_ = g_n;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ts = t_ * p.c3_st + g_dt, hs = h_ * p.c3_sh + g_dh, ws = w_ * p.c3_sw + g_dw;
+                const bool ok = g_ok && (unsigned)ts < (unsigned)p.c3_To && (unsigned)hs < (unsigned)p.c3_Ho && (unsigned)ws < (unsigned)p.c3_Wo;
+                const size_t row = ((size_t)(n_ * p.c3_To + ts) * p.c3_Ho + hs) * p.c3_Wo + ws;
+                ra[e] = ok ? *reinterpret_cast<const float4*>(p.A + row * p.lda + g_c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                rb[e] = bcol ? *reinterpret_cast<const float4*>(pb + e * b_krow) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (++w_ == p.c3_W) { w_ = 0; if (++h_ == p.c3_H) { h_ = 0; if (++t_ == p.c3_T) { t_ = 0; ++n_; } } }
+            }
+            pb += b_step;
+            int c;                                               // the counter + 32 rows: one carry per digit
+            g_w += adv_w; c = g_w >= p.c3_W; g_w -= c ? p.c3_W : 0;
+            g_h += adv_h + c; c = g_h >= p.c3_H; g_h -= c ? p.c3_H : 0;
+            g_t += adv_t + c; c = g_t >= p.c3_T; g_t -= c ? p.c3_T : 0;
+            g_n += adv_n + c;
+        } else if (C3) {
             const int j = cv_k / p.c3_C, kc = cv_k - j * p.c3_C;            // tap index (kt, kh, kw), channel offset: scalar
             const int khw = p.c3_kh * p.c3_kw;
             const int jt = j / khw, jr = j - jt * khw, jh = jr / p.c3_kw, jw = jr - jh * p.c3_kw;
@@ -449,7 +488,7 @@ int m3t_sgemm_x6_launch(int transA, int transB, int M, int N, int K, const float
     p.cv_drop = m3t_make_drop(0.f, 0ull);
     p.cv_amax = nullptr;
     p.mw_len = p.mw_stride = p.mw_off = 0;
-    p.c3_T = p.c3_H = p.c3_W = p.c3_To = p.c3_Ho = p.c3_Wo = p.c3_kt = p.c3_kh = p.c3_kw = p.c3_bt = p.c3_bh = p.c3_bw = p.c3_sg = p.c3_C = 0;
+    p.c3_T = p.c3_H = p.c3_W = p.c3_To = p.c3_Ho = p.c3_Wo = p.c3_kt = p.c3_kh = p.c3_kw = p.c3_bt = p.c3_bh = p.c3_bw = p.c3_sg = p.c3_C = 0; p.c3_st = p.c3_sh = p.c3_sw = 1;
     dim3 grid(N / (narrow ? 64 : XN), M / XM, splits), block(256);
 #define M3T_X6_DISPATCH(NS_, XNT_)                                                                                                  \
     do {                                                                                                                           \
@@ -517,7 +556,7 @@ int m3t_sgemm_x6_pre_launch(int M, int N, int K, const float* A, int lda, const 
     p.cv_T = p.cv_C = p.cv_K = p.cv_dil = p.cv_lead = p.cv_anti = 0; p.cv_btap = 0; p.cv_mask = p.cv_res = nullptr; p.cv_pre = nullptr;
     p.cv_drop = m3t_make_drop(0.f, 0ull);
     p.mw_len = p.mw_stride = p.mw_off = 0;
-    p.c3_T = p.c3_H = p.c3_W = p.c3_To = p.c3_Ho = p.c3_Wo = p.c3_kt = p.c3_kh = p.c3_kw = p.c3_bt = p.c3_bh = p.c3_bw = p.c3_sg = p.c3_C = 0;
+    p.c3_T = p.c3_H = p.c3_W = p.c3_To = p.c3_Ho = p.c3_Wo = p.c3_kt = p.c3_kh = p.c3_kw = p.c3_bt = p.c3_bh = p.c3_bw = p.c3_sg = p.c3_C = 0; p.c3_st = p.c3_sh = p.c3_sw = 1;
     dim3 grid(N / (narrow ? 64 : XN), M / XM, 1), block(256);
     if (narrow) sgemm_x6_kernel<0, 1, false, 4, false, 64, false, false, 3><<<grid, block, 0, s>>>(p, g_no_batch);
     else sgemm_x6_kernel<0, 1, false, 4, false, 128, false, false, 3><<<grid, block, 0, s>>>(p, g_no_batch);
@@ -528,12 +567,13 @@ int m3t_sgemm_x6_pre_launch(int M, int N, int K, const float* A, int lda, const 
 // pre: both operands are pre-split images (m3t_f16x3_split) and w_taps is [Cd][taps * Cs] (K-contiguous)
 int m3t_conv3d_taps_launch(const float* src, const float* w_taps, float* dst, int N, int Cs, int Cd, int T, int H, int W, int To, int Ho, int Wo,
                            int kt, int kh, int kw, int bt_, int bh, int bw, int sg, int f16x3, int pre, const unsigned long long* amax_a,
-                           const unsigned long long* amax_b, float* ws, int splits, int kchunk, hipStream_t s) {
+                           const unsigned long long* amax_b, float* ws, int splits, int kchunk, hipStream_t s, const int* stride3,
+                           const float* bias) {
     X6Params p;
     if (pre && !f16x3) return M3T_EINVAL;
     if (f16x3 && (!amax_a || !amax_b)) return M3T_EINVAL;
     p.amax_a = amax_a; p.amax_b = amax_b; p.cv_amax = nullptr;
-    p.A = src; p.B = w_taps; p.C = dst; p.bias = nullptr; p.ws = ws;
+    p.A = src; p.B = w_taps; p.C = dst; p.bias = bias; p.ws = ws;            // (bias: added by the direct epilogue; the caller's slab reduction otherwise)
     p.M = N * T * H * W; p.N = Cd; p.K = kt * kh * kw * Cs; p.lda = Cs; p.ldb = pre ? kt * kh * kw * Cs : Cd; p.ldc = Cd;
     p.act = 0; p.accumulate = 0; p.splits = splits; p.kchunk = kchunk;      // (deterministic split-K slabs: the deep layers are 144-200 tiles with K = 13 824)
     p.seg_len = p.seg_stride = p.a_off = p.b_off = 0;
@@ -542,19 +582,52 @@ int m3t_conv3d_taps_launch(const float* src, const float* w_taps, float* dst, in
     p.mw_len = p.mw_stride = p.mw_off = 0;
     p.c3_T = T; p.c3_H = H; p.c3_W = W; p.c3_To = To; p.c3_Ho = Ho; p.c3_Wo = Wo; p.c3_kt = kt; p.c3_kh = kh; p.c3_kw = kw;
     p.c3_bt = bt_; p.c3_bh = bh; p.c3_bw = bw; p.c3_sg = sg; p.c3_C = Cs;
+    p.c3_st = stride3 ? stride3[0] : 1; p.c3_sh = stride3 ? stride3[1] : 1; p.c3_sw = stride3 ? stride3[2] : 1;
     const bool narrow = (Cd % 128 != 0) || (Cd / XN) * (p.M / XM) * splits <= 384;
     dim3 grid(Cd / (narrow ? 64 : XN), p.M / XM, splits), block(256);
 #define M3T_C3_GO(NS_)                                                                                                  \
     do {                                                                                                               \
-        if (narrow) sgemm_x6_kernel<0, 0, false, NS_, false, 64, false, true><<<grid, block, 0, s>>>(p, g_no_batch);   \
-        else sgemm_x6_kernel<0, 0, false, NS_, false, 128, false, true><<<grid, block, 0, s>>>(p, g_no_batch);         \
+        if (narrow) sgemm_x6_kernel<0, 0, false, NS_, false, 64, false, 1><<<grid, block, 0, s>>>(p, g_no_batch);   \
+        else sgemm_x6_kernel<0, 0, false, NS_, false, 128, false, 1><<<grid, block, 0, s>>>(p, g_no_batch);         \
     } while (0)
     if (pre) {
-        if (narrow) sgemm_x6_kernel<0, 1, false, 4, false, 64, false, true, 3><<<grid, block, 0, s>>>(p, g_no_batch);
-        else sgemm_x6_kernel<0, 1, false, 4, false, 128, false, true, 3><<<grid, block, 0, s>>>(p, g_no_batch);
+        if (narrow) sgemm_x6_kernel<0, 1, false, 4, false, 64, false, 1, 3><<<grid, block, 0, s>>>(p, g_no_batch);
+        else sgemm_x6_kernel<0, 1, false, 4, false, 128, false, 1, 3><<<grid, block, 0, s>>>(p, g_no_batch);
     }
     else if (f16x3) M3T_C3_GO(4); else M3T_C3_GO(3);
 #undef M3T_C3_GO
+    return (int)hipGetLastError();
+}
+
+// The weight gradient's walk (C3 = 2 kernels; m3t_conv3d_wgrad_taps): dwt [Mp][Co] = sum over the dy grid's rows, Mp = taps * Ci rounded up
+// to 128.  The caller has verified: rows % 32 == 0, Co % 64 == 0, Ci % 4 == 0, kchunk % 32 == 0, 16-B aligned operands.
+int m3t_conv3d_wgrad_launch(const float* x_cl, const float* dy_cl, float* dwt, int N, int Ci, int Co, int T, int H, int W, int To, int Ho, int Wo,
+                            int kt, int kh, int kw, const int* stride3, int pt, int ph, int pw, int f16x3, const unsigned long long* amax_x,
+                            const unsigned long long* amax_dy, float* ws, int splits, int kchunk, hipStream_t s) {
+    X6Params p;
+    if (f16x3 && (!amax_x || !amax_dy)) return M3T_EINVAL;
+    p.amax_a = amax_x; p.amax_b = amax_dy; p.cv_amax = nullptr;
+    p.A = x_cl; p.B = dy_cl; p.C = dwt; p.bias = nullptr; p.ws = ws;
+    const int Mp = (kt * kh * kw * Ci + XM - 1) / XM * XM;
+    p.M = Mp; p.N = Co; p.K = N * To * Ho * Wo; p.lda = Ci; p.ldb = Co; p.ldc = Co;
+    p.act = 0; p.accumulate = 0; p.splits = splits; p.kchunk = kchunk;
+    p.seg_len = p.seg_stride = p.a_off = p.b_off = 0;
+    p.cv_T = p.cv_C = p.cv_K = p.cv_dil = p.cv_lead = p.cv_anti = 0; p.cv_btap = 0; p.cv_mask = p.cv_res = nullptr; p.cv_pre = nullptr;
+    p.cv_drop = m3t_make_drop(0.f, 0ull);
+    p.mw_len = p.mw_stride = p.mw_off = 0;
+    // the counter runs over the dy grid (c3_T/H/W), the source is x's grid (c3_To/Ho/Wo)
+    p.c3_T = To; p.c3_H = Ho; p.c3_W = Wo; p.c3_To = T; p.c3_Ho = H; p.c3_Wo = W; p.c3_kt = kt; p.c3_kh = kh; p.c3_kw = kw;
+    p.c3_bt = -pt; p.c3_bh = -ph; p.c3_bw = -pw; p.c3_sg = 1; p.c3_C = Ci;
+    p.c3_st = stride3[0]; p.c3_sh = stride3[1]; p.c3_sw = stride3[2];
+    const bool narrow = (Co % 128 != 0) || (Co / XN) * (Mp / XM) * splits <= 384;
+    dim3 grid(Co / (narrow ? 64 : XN), Mp / XM, splits), block(256);
+    if (f16x3) {
+        if (narrow) sgemm_x6_kernel<1, 0, false, 4, false, 64, false, 2><<<grid, block, 0, s>>>(p, g_no_batch);
+        else sgemm_x6_kernel<1, 0, false, 4, false, 128, false, 2><<<grid, block, 0, s>>>(p, g_no_batch);
+    } else {
+        if (narrow) sgemm_x6_kernel<1, 0, false, 3, false, 64, false, 2><<<grid, block, 0, s>>>(p, g_no_batch);
+        else sgemm_x6_kernel<1, 0, false, 3, false, 128, false, 2><<<grid, block, 0, s>>>(p, g_no_batch);
+    }
     return (int)hipGetLastError();
 }
 

@@ -1093,6 +1093,54 @@ def test_conv3d_forward_on_the_patch_matrix_gemm(Ci, Co, k, stride, pad, N, T, H
     close(x.grad, x2.grad.cpu().numpy(), 2e-4, "dx (stride-1 layers: the tap-walk kernel m3t_conv3d_taps) vs MIOpen's data gradient")
 
 
+@pytest.mark.parametrize("Ci,Co,k,stride,pad,N,T,H,W", [
+    (64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), 8, 1, 8, 8),         # the per-frame ResNet's 3 x 3 convolution
+    (32, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), 32, 1, 14, 14),      # W % 4 != 0: the weight gradient's row counter carries inside a thread's four rows
+    (64, 128, (1, 3, 3), (1, 2, 2), (0, 1, 1), 8, 1, 16, 16),      # the first convolution of a ResNet stage: stride 2 (data gradient: MIOpen)
+    (64, 128, (1, 1, 1), (1, 2, 2), (0, 0, 0), 8, 1, 16, 16),      # its 1 x 1 stride-2 shortcut: a strided row gather
+    (96, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), 8, 1, 8, 8),         # 864 weight-gradient rows padded to 896; a 128-column tile spans three taps
+    (64, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1), 2, 4, 8, 8),        # 3-D, padding on every axis
+    (128, 256, (3, 3, 3), (1, 1, 1), (1, 0, 0), 4, 8, 4, 4),       # deep layer: split-K in the forward walk too
+    (64, 64, (3, 1, 1), (2, 1, 1), (1, 0, 0), 4, 8, 4, 4),         # stride on the time axis
+])
+def test_conv3d_without_a_patch_matrix(Ci, Co, k, stride, pad, N, T, H, W):
+    """Round 5, second half: forward (m3t_conv3d_fwd_taps on operands split once, any stride, bias in the epilogue) and weight gradient
+    (m3t_conv3d_wgrad_taps: the reduction over dy's rows, taps picked per output row) as tap walks over the channels-last input kept from
+    the forward pass (reference models/backbone.py:73-103,179-271, models/resnet.py:40-45) -- against float64 autograd on the CPU and
+    against the patch-matrix path (M3T_CONV3D_IMPLICIT=0); reruns bit-identical (deterministic split-K)"""
+    from m3t import ops
+    rs = np.random.RandomState(Ci + Co + H)
+    xn, wn, bn_ = draw(rs, (N, Ci, T, H, W)), draw(rs, (Co, Ci) + k) * 0.2, draw(rs, (Co,))
+    ctn = None
+    res = []
+    for implicit in (True, True, False):
+        saved = ops.CONV3D_IMPLICIT[0]
+        ops.CONV3D_IMPLICIT[0] = implicit
+        n0 = dict(ops.CONV3D_CALLS)
+        try:
+            x, w, b = dev(xn, True), dev(wn, True), dev(bn_, True)
+            y = ops.conv3d(x, w, b, stride, pad)
+            if ctn is None:
+                ctn = draw(rs, tuple(y.shape))
+            (y * dev(ctn)).sum().backward()
+        finally:
+            ops.CONV3D_IMPLICIT[0] = saved
+        assert ops.CONV3D_CALLS["walk" if implicit else "patch"] == n0["walk" if implicit else "patch"] + 1, "not the path this test means"
+        res.append((y.detach(), w.grad, b.grad, x.grad))
+    x64, w64, b64 = (torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (xn, wn, bn_))
+    y64 = torch.conv3d(x64, w64, b64, stride, pad)
+    (y64 * torch.tensor(ctn, dtype=torch.float64)).sum().backward()
+    close(res[0][0], y64.detach().numpy(), 1e-4, "y")
+    close(res[0][1], w64.grad.numpy(), 2e-4, "dw")
+    close(res[0][2], b64.grad.numpy(), 2e-4, "db")
+    close(res[0][3], x64.grad.numpy(), 2e-4, "dx")
+    for a, b_, what in zip(res[0], res[1], ("y", "dw", "db", "dx")):
+        if what != "dx" or tuple(stride) == (1, 1, 1):          # (a strided layer's data gradient is MIOpen's)
+            assert torch.equal(a, b_), "reruns differ: " + what
+    for a, b_, what in zip(res[0], res[2], ("y", "dw", "db", "dx")):
+        close(a, b_.cpu().numpy(), 2e-4, what + " vs the patch-matrix path")
+
+
 @pytest.mark.parametrize("N,C_,T,H,W,training", [(3, 16, 5, 7, 9, True), (2, 64, 4, 12, 12, True), (2, 8, 3, 5, 5, False), (4, 24, 1, 1, 1, True)])
 def test_batchnorm3d_relu_on_channel_planes(N, C_, T, H, W, training):
     """models.backbone.BatchNorm3dReLU (nn.BatchNorm3d + nn.ReLU of the 3-D stems, reference models/backbone.py:73-103,179-191) on
