@@ -126,6 +126,14 @@ int m3t_conv3d_taps_pre(const float* src_img, const float* w_img, float* dst, in
  *   (rows past taps Ci are written as zeros); fp32 operands, split in the kernel; flags / amax as m3t_sgemm_scaled (NULL slots are measured).
  *   N T' H' W' % 32 == 0, Co % 64 == 0, Ci % 4 == 0, 16-B aligned.
  * With m3t_conv3d_taps(_pre) for the data gradient of the stride-1 layers, no convolution of the path materialises its patches. */
+/* The stems' first layers (C_in <= 4; reference models/backbone.py:73-78,179-184): m3t_planes_to_cl4 writes x [N][C][S] channels-last with
+ * FOUR channels (missing ones zero; raises the slot armed by m3t_amax_out); m3t_conv3d_fwd_taps4 walks the m3t_f16x3_split image of that
+ * against w_img = the image of [Co][kt][kh][8][4] (kernel width padded to eight taps, channels to four, zeros): one 32-deep k tile per
+ * (kt, kh) pair.  kw <= 8, N T' H' W' % 128 == 0, Co % 64 == 0.  The weight gradient is m3t_conv3d_wgrad_taps with Ci = 4. */
+int m3t_planes_to_cl4(const float* x, float* out, int N, int C, long long S, void* stream);
+int m3t_conv3d_fwd_taps4(const float* x_img4, const float* w_img, const float* bias, float* y_cl, int N, int Co, int T, int H, int W,
+                         int kt, int kh, int kw, int st, int sh, int sw, int pt, int ph, int pw, const unsigned long long* amax_x,
+                         const unsigned long long* amax_w, float* ws, size_t ws_bytes, void* stream);
 int m3t_conv3d_fwd_taps(const float* x_img, const float* w_img, const float* bias, float* y_cl, int N, int Ci, int Co, int T, int H, int W,
                         int kt, int kh, int kw, int st, int sh, int sw, int pt, int ph, int pw, const unsigned long long* amax_x,
                         const unsigned long long* amax_w, float* ws, size_t ws_bytes, void* stream);

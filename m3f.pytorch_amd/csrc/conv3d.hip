@@ -108,7 +108,41 @@ __global__ __launch_bounds__(256) void im2col3d_kernel(Im2colArgs a, int cw) {
     }
 }
 
+// x [N][C][S] (C <= 4 channel planes) -> out [N][S][4], missing channels zero: the channels-last image the first layers' tap walk reads
+// (gemm_x6.hip, C3 = 3).  One position per thread: C coalesced plane reads, one 16-byte store.  Raises the pending magnitude slot.
+__global__ __launch_bounds__(256) void planes_to_cl4_kernel(const float* __restrict__ x, float* __restrict__ out, int C, long long S, long long total,
+                                                            unsigned long long* slot) {
+    float mx = 0.f;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long n = i / S, sp = i - n * S;
+        const float* q = x + (n * C) * S + sp;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        v.x = q[0];
+        if (C > 1) v.y = q[S];
+        if (C > 2) v.z = q[2 * S];
+        if (C > 3) v.w = q[3 * S];
+        mx = fmaxf(mx, fmaxf(fmaxf(m3t_fin_abs(v.x), m3t_fin_abs(v.y)), fmaxf(m3t_fin_abs(v.z), m3t_fin_abs(v.w))));
+        *reinterpret_cast<float4*>(out + 4 * i) = v;
+    }
+    if (slot) {
+        __shared__ float red4[4];
+        m3t_block_raise_slot(slot, mx, red4);
+    }
+}
+
 }  // namespace
+
+extern "C" int m3t_planes_to_cl4(const float* x, float* out, int N, int C, long long S, void* stream) {
+    unsigned long long* amax = m3t_take_amax_out();
+    if (N <= 0 || S <= 0) return 0;
+    if (!x || !out || C < 1 || C > 4 || ((uintptr_t)out % 16) != 0) return M3T_EINVAL;
+    const long long total = (long long)N * S;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    planes_to_cl4_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(x, out, C, S, total, amax);
+    M3T_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int m3t_im2col3d(const float* x, int N, int Ci, int T, int H, int W, int kt, int kh, int kw, int st, int sh, int sw,
                             int pt, int ph, int pw, float* out, long long rows_pad, int Kp, unsigned long long* amax_slot, void* stream) {

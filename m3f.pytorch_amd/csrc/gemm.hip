@@ -783,6 +783,10 @@ int m3t_conv3d_wgrad_launch(const float* x_cl, const float* dy_cl, float* dwt, i
                             int kt, int kh, int kw, const int* stride3, int pt, int ph, int pw, int f16x3, const unsigned long long* amax_x,
                             const unsigned long long* amax_dy, float* ws, int splits, int kchunk, hipStream_t s);
 
+int m3t_conv3d_taps4_launch(const float* x_img4, const float* w_img, const float* bias, float* y_cl, int N, int Co, int T, int H, int W, int To,
+                            int Ho, int Wo, int kt, int kh, int kw, const int* stride3, int pt, int ph, int pw, const unsigned long long* amax_x,
+                            const unsigned long long* amax_w, float* ws, int splits, int kchunk, hipStream_t s);
+
 // split-K of a tap walk: enough workgroups for the chip (the deep layers are a few hundred tiles with K = 13 824), slabs in `ws`
 static void taps_split(long long rows, int Cd, int K, float* ws, size_t ws_bytes, int& splits, int& kchunk) {
     splits = 1; kchunk = K;
@@ -923,6 +927,30 @@ extern "C" int m3t_conv3d_fwd_taps(const float* x_img, const float* w_img, const
     hipStream_t s = (hipStream_t)stream;
     const int rc = m3t_conv3d_taps_launch(x_img, w_img, y_cl, N, Ci, Co, To, Ho, Wo, T, H, W, kt, kh, kw, -pt, -ph, -pw, 1, 1, 1, amax_x, amax_w, ws,
                                           splits, kchunk, s, stride3, bias);
+    if (rc) return rc;
+    if (splits > 1) { launch_splitk_reduce(ws, y_cl, bias, (int)rows, Co, Co, splits, 0, 0, s); M3T_LAUNCH_CHECK(); }
+    return 0;
+}
+
+// include/m3t_hip.h: the first layers (C_in <= 4) on the four-channel image
+extern "C" int m3t_conv3d_fwd_taps4(const float* x_img4, const float* w_img, const float* bias, float* y_cl, int N, int Co, int T, int H, int W,
+                                    int kt, int kh, int kw, int st, int sh, int sw, int pt, int ph, int pw, const unsigned long long* amax_x,
+                                    const unsigned long long* amax_w, float* ws, size_t ws_bytes, void* stream) {
+    if (N <= 0 || Co <= 0) return 0;
+    if (!x_img4 || !w_img || !y_cl || !amax_x || !amax_w || T <= 0 || H <= 0 || W <= 0 || kt <= 0 || kh <= 0 || kw <= 0 || kw > 8 || st <= 0 ||
+        sh <= 0 || sw <= 0 || pt < 0 || ph < 0 || pw < 0 || T + 2 * pt < kt || H + 2 * ph < kh || W + 2 * pw < kw)
+        return M3T_EINVAL;
+    const int To = (T + 2 * pt - kt) / st + 1, Ho = (H + 2 * ph - kh) / sh + 1, Wo = (W + 2 * pw - kw) / sw + 1;
+    const long long rows = (long long)N * To * Ho * Wo, srows = (long long)N * T * H * W;
+    if (rows > 0x7fffffffll || srows > 0x7fffffffll || (long long)kt * kh * 32 > 0x7fffffffll) return M3T_EINVAL;
+    if (!x6_enabled() || !m3t_f16x3_enabled() || rows % 128 != 0 || Co % 64 != 0 || (uintptr_t)x_img4 % 16 != 0 || (uintptr_t)w_img % 16 != 0)
+        return M3T_EINVAL;
+    int splits, kchunk;
+    taps_split(rows, Co, kt * kh * 32, ws, ws_bytes, splits, kchunk);
+    const int stride3[3] = {st, sh, sw};
+    hipStream_t s = (hipStream_t)stream;
+    const int rc = m3t_conv3d_taps4_launch(x_img4, w_img, bias, y_cl, N, Co, T, H, W, To, Ho, Wo, kt, kh, kw, stride3, pt, ph, pw, amax_x, amax_w, ws,
+                                           splits, kchunk, s);
     if (rc) return rc;
     if (splits > 1) { launch_splitk_reduce(ws, y_cl, bias, (int)rows, Co, Co, splits, 0, 0, s); M3T_LAUNCH_CHECK(); }
     return 0;

@@ -186,6 +186,10 @@ __device__ __forceinline__ void mc_store(unsigned char* __restrict__ S, const fl
 // m = (tap, ci) picks the tap once per thread, every k row is decoded on the dy grid (a mixed-radix counter advanced by 32 per tile: no
 // division in the loop) and shifted by that tap, zero outside x's grid; columns past taps * C (M padded to the tile) read as zero.  Neither
 // the forward pass nor this one needs the patch matrix (9 - 27 x the activations: 0.9 GB per 3 x 3 layer at 512 frames of 28 x 28).
+// C3 = 3 (TA == 0, TB == 1, images): the stems' FIRST layers (3 input channels: reference models/backbone.py:73-78,179-184).  The input is
+// channels-last PADDED TO FOUR channels, the kernel's width to eight taps (zero weights): a 32-deep k tile is one (kt, kh) pair -- its eight
+// k-quads are the eight pixels w .. w + 7 of one source row, a thread's quad one pixel's four channels -- so the A tile is again whole
+// 16-byte loads from shifted rows, 21 of 32 k useful (the patch matrix of this layer was 4.9 GB at 512 frames of 112 x 112).
 // PRE (NS == 4, K-contiguous operands): bit 0 -- A is a pre-split image, bit 1 -- B is (see kc_store)
 template <int TA, int TB, bool SEG, int NS, bool CONV = false, int XNT = 128, bool MW = false, int C3 = 0, int PRE = 0>
 __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p, X6Batch bt) {
@@ -254,8 +258,9 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p, X6Batch bt
         sq = k / p.seg_len; sr = k % p.seg_len;
     }
 
-    int c3_tt[C3 == 1 ? 4 : 1], c3_hh[C3 == 1 ? 4 : 1], c3_ww[C3 == 1 ? 4 : 1], c3_nb[C3 == 1 ? 4 : 1];      // C3 = 1: (t st + bt, h sh + bh, w sw + bw, n * To) of this thread's four rows
-    if (C3 == 1) {
+    constexpr bool C3ROWS = C3 == 1 || C3 == 3;
+    int c3_tt[C3ROWS ? 4 : 1], c3_hh[C3ROWS ? 4 : 1], c3_ww[C3ROWS ? 4 : 1], c3_nb[C3ROWS ? 4 : 1];      // C3 = 1, 3: (t st + bt, h sh + bh, w sw + bw, n * To) of this thread's four rows
+    if (C3ROWS) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int m = bm + (tid >> 3) + 32 * i;
@@ -305,6 +310,20 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p, X6Batch bt
             g_h += adv_h + c; c = g_h >= p.c3_H; g_h -= c ? p.c3_H : 0;
             g_t += adv_t + c; c = g_t >= p.c3_T; g_t -= c ? p.c3_T : 0;
             g_n += adv_n + c;
+        } else if (C3 == 3) {
+            const int j = cv_k >> 5;                                        // the tile's (kt, kh) pair: scalar
+            const int jt = j / p.c3_kh, jh = j - jt * p.c3_kh;
+            const int q = tid & 7;                                          // this thread's pixel of the eight
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ts = c3_tt[i] + jt, hs = c3_hh[i] + jh, ws = c3_ww[i] + q;
+                const bool ok = q < p.c3_kw && (unsigned)ts < (unsigned)p.c3_To && (unsigned)hs < (unsigned)p.c3_Ho && (unsigned)ws < (unsigned)p.c3_Wo;
+                const size_t row = ((size_t)(c3_nb[i] + ts) * p.c3_Ho + hs) * p.c3_Wo + ws;
+                ra[i] = ok ? *reinterpret_cast<const float4*>(p.A + row * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            kc_load<BR>(pb, p.ldb, rb);
+            pb += b_step;
+            cv_k += XK;
         } else if (C3) {
             const int j = cv_k / p.c3_C, kc = cv_k - j * p.c3_C;            // tap index (kt, kh, kw), channel offset: scalar
             const int khw = p.c3_kh * p.c3_kw;
@@ -596,6 +615,31 @@ int m3t_conv3d_taps_launch(const float* src, const float* w_taps, float* dst, in
     }
     else if (f16x3) M3T_C3_GO(4); else M3T_C3_GO(3);
 #undef M3T_C3_GO
+    return (int)hipGetLastError();
+}
+
+// The first layers' walk (C3 = 3 kernels; m3t_conv3d_fwd_taps4): x_img4 = image of x channels-last padded to 4 channels, w_img = image of
+// [Co][kt][kh][8][4].  The caller has verified: rows % 128 == 0, Co % 64 == 0, kw <= 8, 16-B aligned operands.
+int m3t_conv3d_taps4_launch(const float* x_img4, const float* w_img, const float* bias, float* y_cl, int N, int Co, int T, int H, int W, int To,
+                            int Ho, int Wo, int kt, int kh, int kw, const int* stride3, int pt, int ph, int pw, const unsigned long long* amax_x,
+                            const unsigned long long* amax_w, float* ws, int splits, int kchunk, hipStream_t s) {
+    X6Params p;
+    if (!amax_x || !amax_w) return M3T_EINVAL;
+    p.amax_a = amax_x; p.amax_b = amax_w; p.cv_amax = nullptr;
+    p.A = x_img4; p.B = w_img; p.C = y_cl; p.bias = bias; p.ws = ws;
+    p.M = N * To * Ho * Wo; p.N = Co; p.K = kt * kh * 32; p.lda = 4; p.ldb = kt * kh * 32; p.ldc = Co;
+    p.act = 0; p.accumulate = 0; p.splits = splits; p.kchunk = kchunk;
+    p.seg_len = p.seg_stride = p.a_off = p.b_off = 0;
+    p.cv_T = p.cv_C = p.cv_K = p.cv_dil = p.cv_lead = p.cv_anti = 0; p.cv_btap = 0; p.cv_mask = p.cv_res = nullptr; p.cv_pre = nullptr;
+    p.cv_drop = m3t_make_drop(0.f, 0ull);
+    p.mw_len = p.mw_stride = p.mw_off = 0;
+    p.c3_T = To; p.c3_H = Ho; p.c3_W = Wo; p.c3_To = T; p.c3_Ho = H; p.c3_Wo = W; p.c3_kt = kt; p.c3_kh = kh; p.c3_kw = kw;
+    p.c3_bt = -pt; p.c3_bh = -ph; p.c3_bw = -pw; p.c3_sg = 1; p.c3_C = 4;
+    p.c3_st = stride3[0]; p.c3_sh = stride3[1]; p.c3_sw = stride3[2];
+    const bool narrow = (Co % 128 != 0) || (Co / XN) * (p.M / XM) * splits <= 384;
+    dim3 grid(Co / (narrow ? 64 : XN), p.M / XM, splits), block(256);
+    if (narrow) sgemm_x6_kernel<0, 1, false, 4, false, 64, false, 3, 3><<<grid, block, 0, s>>>(p, g_no_batch);
+    else sgemm_x6_kernel<0, 1, false, 4, false, 128, false, 3, 3><<<grid, block, 0, s>>>(p, g_no_batch);
     return (int)hipGetLastError();
 }
 

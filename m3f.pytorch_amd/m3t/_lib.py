@@ -60,6 +60,8 @@ SIGNATURES = {
     "m3t_f16x3_split": [_f, _z, _i, _z, _f, _z, _f, _s],
     "m3t_conv3d_taps_pre": [_f, _f, _f] + [_i] * 16 + [_f, _f, _f, _z, _s],
     "m3t_conv3d_fwd_taps": [_f, _f, _f, _f] + [_i] * 15 + [_f, _f, _f, _z, _s],
+    "m3t_conv3d_fwd_taps4": [_f, _f, _f, _f] + [_i] * 14 + [_f, _f, _f, _z, _s],
+    "m3t_planes_to_cl4": [_f, _f, _i, _i, C.c_longlong, _s],
     "m3t_conv3d_wgrad_taps": [_f, _f, _f] + [_i] * 16 + [_f, _f, _f, _z, _s],
     "m3t_amax_out": [C.c_void_p],
     "m3t_colsum": [_f, _i, _i, _i, _f, _i, _f, _z, _s],

@@ -2284,7 +2284,7 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
         ctx.stride, ctx.padding, ctx.has_bias = stride, padding, b is not None
         plan = _conv3d_plan(x, w, stride, padding) if (CONV3D_GEMM[0] and x.is_cuda and (_PREC[0] & _lib.M3T_GEMM_F16X3 or _PREC[0] == 0)) else None
         ctx.prec = _PREC[0]
-        ctx.impl = False
+        ctx.impl = 0                     # channel width of the channels-last input kept by a tap-walk forward (0: none)
         if plan is None:
             y = torch.conv3d(x, w, b, stride, padding)
             CONV3D_CALLS["torch"] += 1
@@ -2296,37 +2296,51 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
         Co, _, kt, kh, kw = w.shape
         xc = _req(x.contiguous(), "x")
         slots = amax_slots(2, x.device)
-        if CONV3D_IMPLICIT[0] and (_PREC[0] & _lib.M3T_GEMM_F16X3) and Ci % 32 == 0:
+        cw = Ci if Ci % 32 == 0 else (4 if (Ci <= 4 and kw <= 8) else 0)        # channel width of the channels-last input the walk reads
+        if CONV3D_IMPLICIT[0] and (_PREC[0] & _lib.M3T_GEMM_F16X3) and cw:
             # second half of round 5: no patch matrix.  x channels-last (one tiled transpose that raises x's magnitude slot; KEPT for the
             # weight gradient: 1 x the activations instead of 9 - 27 x), both operands split once, the tap walk with the layer's stride,
-            # bias in its epilogue, one transpose back
+            # bias in its epilogue, one transpose back.  The stems' first layers (3 input channels): channels padded to four, the kernel's
+            # width to eight taps -- one 32-deep k tile per (kt, kh) pair (m3t_conv3d_fwd_taps4)
             ctx.w_keep = []
             a_w = weight_amax(w, ctx.w_keep)
             taps = kt * kh * kw
-            w_t = _req(w.detach().permute(0, 2, 3, 4, 1).contiguous(), "weight").view(Co, taps * Ci)       # [co][(tap, ci)]
+            if cw == Ci:
+                w_t = _req(w.detach().permute(0, 2, 3, 4, 1).contiguous(), "weight").view(Co, taps * Ci)       # [co][(tap, ci)]
+            else:
+                w8 = torch.zeros(Co, kt, kh, 8, 4, dtype=torch.float32, device=x.device)
+                w8[:, :, :, :kw, :Ci].copy_(w.detach().permute(0, 2, 3, 4, 1))
+                w_t = w8.view(Co, kt * kh * 32)
             if a_w is None:
                 a_w = slots.data_ptr() + 8
                 if not measure_amax([(w_t, a_w)]):
                     a_w = None
             if a_w is not None:
-                srows = N_ * T_ * H_ * W_
-                x_cl = torch.empty(srows, Ci, dtype=torch.float32, device=x.device)
+                srows, wk = N_ * T_ * H_ * W_, w_t.shape[1]
+                x_cl = torch.empty(srows, cw, dtype=torch.float32, device=x.device)
                 x_img, w_img = torch.empty_like(x_cl), torch.empty_like(w_t)
                 y_cl = torch.empty(rows, Co, dtype=torch.float32, device=x.device)
                 y = torch.empty(N_, Co, To, Ho, Wo, dtype=torch.float32, device=x.device)
                 wsd = workspace(x.device)
                 amax_out(slots.data_ptr())
-                _lib.check(lib().m3t_bct_to_btc(_p(xc), _p(x_cl), N_, Ci, T_ * H_ * W_, _stream()), "m3t_bct_to_btc")
-                _lib.check(lib().m3t_f16x3_split(_p(x_cl), srows, Ci, Ci, _p(x_img), Ci, slots.data_ptr(), _stream()), "m3t_f16x3_split")
-                _lib.check(lib().m3t_f16x3_split(_p(w_t), Co, taps * Ci, taps * Ci, _p(w_img), taps * Ci, a_w, _stream()), "m3t_f16x3_split")
-                _lib.check(lib().m3t_conv3d_fwd_taps(_p(x_img), _p(w_img), _p(b) if b is not None else None, _p(y_cl), N_, Ci, Co, T_, H_, W_,
-                                                     kt, kh, kw, stride[0], stride[1], stride[2], padding[0], padding[1], padding[2],
-                                                     slots.data_ptr(), a_w, _p(wsd), wsd.numel() * 4, _stream()), "m3t_conv3d_fwd_taps")
+                if cw == Ci:
+                    _lib.check(lib().m3t_bct_to_btc(_p(xc), _p(x_cl), N_, Ci, T_ * H_ * W_, _stream()), "m3t_bct_to_btc")
+                else:
+                    _lib.check(lib().m3t_planes_to_cl4(_p(xc), _p(x_cl), N_, Ci, T_ * H_ * W_, _stream()), "m3t_planes_to_cl4")
+                _lib.check(lib().m3t_f16x3_split(_p(x_cl), srows, cw, cw, _p(x_img), cw, slots.data_ptr(), _stream()), "m3t_f16x3_split")
+                _lib.check(lib().m3t_f16x3_split(_p(w_t), Co, wk, wk, _p(w_img), wk, a_w, _stream()), "m3t_f16x3_split")
+                geo = (kt, kh, kw, stride[0], stride[1], stride[2], padding[0], padding[1], padding[2], slots.data_ptr(), a_w, _p(wsd),
+                       wsd.numel() * 4, _stream())
+                bp = _p(b) if b is not None else None
+                if cw == Ci:
+                    _lib.check(lib().m3t_conv3d_fwd_taps(_p(x_img), _p(w_img), bp, _p(y_cl), N_, Ci, Co, T_, H_, W_, *geo), "m3t_conv3d_fwd_taps")
+                else:
+                    _lib.check(lib().m3t_conv3d_fwd_taps4(_p(x_img), _p(w_img), bp, _p(y_cl), N_, Co, T_, H_, W_, *geo), "m3t_conv3d_fwd_taps4")
                 _lib.check(lib().m3t_btc_to_bct(_p(y_cl), _p(y), N_, To * Ho * Wo, Co, _stream()), "m3t_btc_to_bct")
                 ctx.save_for_backward(x, w, x_cl, slots)
                 ctx.pat = (rows, Kc, Kp)
                 ctx.a_w = a_w
-                ctx.impl = True
+                ctx.impl = cw
                 CONV3D_CALLS["walk"] += 1
                 return y
         CONV3D_CALLS["patch"] += 1
@@ -2357,7 +2371,7 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
     def backward(ctx, dy):
         saved = ctx.saved_tensors
         x, w = saved[0], saved[1]
-        impl = ctx.pat is not None and ctx.impl                             # forward was a tap walk: saved[2] is x channels-last, no patch matrix
+        impl = ctx.impl if ctx.pat is not None else 0                       # forward was a tap walk: saved[2] is x channels-last, no patch matrix
         kept = (saved[2], saved[3]) if (ctx.pat is not None and not impl) else None      # the forward's patch matrix and its magnitude slot
         st, pd = ctx.stride, ctx.padding
         dx = dw = db = None
@@ -2416,16 +2430,16 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
             _lib.check(lib().m3t_btc_to_bct(_p(dx_cl), _p(dx), N_, T_ * H_ * W_, Ci, _stream()), "m3t_btc_to_bct")
         if ctx.needs_input_grad[1] and impl:
             # the walk turned round: dW^T[(tap, ci)][co] summed over dy's rows, x channels-last from the forward pass (m3t_conv3d_wgrad_taps)
-            taps, Kc = kt * kh * kw, Ci * kt * kh * kw
+            taps, Kc = kt * kh * kw, impl * kt * kh * kw                      # (impl = 4 for a first layer: its channels padded)
             Mp = (Kc + 127) // 128 * 128
             tiles = (Mp // 128) * ((Co + 127) // 128)
             want = max(1, min((1536 + tiles - 1) // tiles, rows // 256))
             wsw = workspace(dy.device, min(want * Mp * Co * 4, 512 << 20))
             dwt = torch.empty(Mp, Co, dtype=torch.float32, device=dy.device)
-            _lib.check(lib().m3t_conv3d_wgrad_taps(_p(saved[2]), _p(dy_cl), _p(dwt), N_, Ci, Co, T_, H_, W_, kt, kh, kw, st[0], st[1], st[2],
+            _lib.check(lib().m3t_conv3d_wgrad_taps(_p(saved[2]), _p(dy_cl), _p(dwt), N_, impl, Co, T_, H_, W_, kt, kh, kw, st[0], st[1], st[2],
                                                    pd[0], pd[1], pd[2], ctx.prec, saved[3].data_ptr(), slot_dy.data_ptr(), _p(wsw),
                                                    wsw.numel() * 4, _stream()), "m3t_conv3d_wgrad_taps")
-            dw = dwt[:Kc].view(taps, Ci, Co).permute(2, 1, 0).contiguous().view_as(w)
+            dw = dwt[:Kc].view(taps, impl, Co)[:, :Ci].permute(2, 1, 0).contiguous().view_as(w)
         elif ctx.needs_input_grad[1]:
             Kc = Ci * kt * kh * kw
             xc = _req(x.contiguous(), "x")

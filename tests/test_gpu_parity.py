@@ -1102,6 +1102,9 @@ def test_conv3d_forward_on_the_patch_matrix_gemm(Ci, Co, k, stride, pad, N, T, H
     (64, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1), 2, 4, 8, 8),        # 3-D, padding on every axis
     (128, 256, (3, 3, 3), (1, 1, 1), (1, 0, 0), 4, 8, 4, 4),       # deep layer: split-K in the forward walk too
     (64, 64, (3, 1, 1), (2, 1, 1), (1, 0, 0), 4, 8, 4, 4),         # stride on the time axis
+    (3, 64, (5, 7, 7), (1, 2, 2), (2, 3, 3), 1, 8, 32, 32),        # the 3-D ResNet stem: four-channel image, eight-tap rows (m3t_conv3d_fwd_taps4)
+    (3, 64, (3, 3, 3), (1, 2, 2), (1, 0, 0), 2, 8, 17, 17),        # VGG-M conv1
+    (1, 128, (1, 8, 8), (1, 1, 1), (0, 4, 4), 2, 4, 15, 15),       # one channel, all eight taps used, 128-wide tile
 ])
 def test_conv3d_without_a_patch_matrix(Ci, Co, k, stride, pad, N, T, H, W):
     """Round 5, second half: forward (m3t_conv3d_fwd_taps on operands split once, any stride, bias in the epilogue) and weight gradient
