@@ -98,7 +98,8 @@ int m3t_im2col3d(const float* x, int N, int Ci, int T, int H, int W, int kt, int
  * split-K slabs for the layers whose tile count does not fill the chip (deterministic reduction, as m3t_sgemm). */
 int m3t_conv3d_taps(const float* src, const float* w_taps, float* dst, int N, int C_src, int C_dst, int T, int H, int W,
                     int To, int Ho, int Wo, int kt, int kh, int kw, int base_t, int base_h, int base_w, int sign, int flags,
-                    const unsigned long long* amax_src, const unsigned long long* amax_w, float* ws, size_t ws_bytes, void* stream);
+                    const unsigned long long* amax_src, const unsigned long long* amax_w, float* ws, size_t ws_bytes, float* dst_planes,
+                    void* stream);
 
 /* Operands split ONCE (round 5).  In the fp16x3 kernels every workgroup splits the operand tiles it stages -- each element as often as tiles read
  * it, five to six vector instructions per pair beside every MFMA.  m3t_f16x3_split writes the "P4" image of a K-contiguous operand x
@@ -113,7 +114,8 @@ int m3t_sgemm_pre(int M, int N, int K, const float* A_img, int lda, const float*
                   const float* bias, int act, int accumulate, const unsigned long long* amax_a, const unsigned long long* amax_b, void* stream);
 int m3t_conv3d_taps_pre(const float* src_img, const float* w_img, float* dst, int N, int C_src, int C_dst, int T, int H, int W,
                         int To, int Ho, int Wo, int kt, int kh, int kw, int base_t, int base_h, int base_w, int sign,
-                        const unsigned long long* amax_src, const unsigned long long* amax_w, float* ws, size_t ws_bytes, void* stream);
+                        const unsigned long long* amax_src, const unsigned long long* amax_w, float* ws, size_t ws_bytes, float* dst_planes,
+                    void* stream);
 
 /* The whole convolution without a patch matrix (round 5, second half; reference models/backbone.py:73-103,179-271, models/resnet.py:40-45 --
  * nn.Conv3d / nn.Conv2d forward and backward of the visual stems and the per-frame ResNet).
@@ -125,7 +127,10 @@ int m3t_conv3d_taps_pre(const float* src_img, const float* w_img, float* dst, in
  *   its output row, every reduction row is decoded on the dy grid by a counter (no division in the loop).  dwt has ceil128(taps Ci) rows
  *   (rows past taps Ci are written as zeros); fp32 operands, split in the kernel; flags / amax as m3t_sgemm_scaled (NULL slots are measured).
  *   N T' H' W' % 32 == 0, Co % 64 == 0, Ci % 4 == 0, 16-B aligned.
- * With m3t_conv3d_taps(_pre) for the data gradient of the stride-1 layers, no convolution of the path materialises its patches. */
+ * With m3t_conv3d_taps(_pre) for the data gradient of the stride-1 layers, no convolution of the path materialises its patches.
+ * dst_planes / y_planes (optional, every walk but the weight gradient's): the result is left as channel planes [N][C][T H W] there -- written by
+ * the walk's own epilogue when it runs in one K pass (16-byte stores of 4 positions per channel), else reduced into dst / y_cl (then
+ * scratch of the same size) and transposed by m3t_btc_to_bct. */
 /* The stems' first layers (C_in <= 4; reference models/backbone.py:73-78,179-184): m3t_planes_to_cl4 writes x [N][C][S] channels-last with
  * FOUR channels (missing ones zero; raises the slot armed by m3t_amax_out); m3t_conv3d_fwd_taps4 walks the m3t_f16x3_split image of that
  * against w_img = the image of [Co][kt][kh][8][4] (kernel width padded to eight taps, channels to four, zeros): one 32-deep k tile per
@@ -133,10 +138,10 @@ int m3t_conv3d_taps_pre(const float* src_img, const float* w_img, float* dst, in
 int m3t_planes_to_cl4(const float* x, float* out, int N, int C, long long S, void* stream);
 int m3t_conv3d_fwd_taps4(const float* x_img4, const float* w_img, const float* bias, float* y_cl, int N, int Co, int T, int H, int W,
                          int kt, int kh, int kw, int st, int sh, int sw, int pt, int ph, int pw, const unsigned long long* amax_x,
-                         const unsigned long long* amax_w, float* ws, size_t ws_bytes, void* stream);
+                         const unsigned long long* amax_w, float* ws, size_t ws_bytes, float* y_planes, void* stream);
 int m3t_conv3d_fwd_taps(const float* x_img, const float* w_img, const float* bias, float* y_cl, int N, int Ci, int Co, int T, int H, int W,
                         int kt, int kh, int kw, int st, int sh, int sw, int pt, int ph, int pw, const unsigned long long* amax_x,
-                        const unsigned long long* amax_w, float* ws, size_t ws_bytes, void* stream);
+                        const unsigned long long* amax_w, float* ws, size_t ws_bytes, float* y_planes, void* stream);
 int m3t_conv3d_wgrad_taps(const float* x_cl, const float* dy_cl, float* dwt, int N, int Ci, int Co, int T, int H, int W, int kt, int kh, int kw,
                           int st, int sh, int sw, int pt, int ph, int pw, int flags, const unsigned long long* amax_x,
                           const unsigned long long* amax_dy, float* ws, size_t ws_bytes, void* stream);

@@ -778,14 +778,15 @@ extern "C" int m3t_sgemm_window(int transB, int n_seg, int win_len, int win_stri
 int m3t_conv3d_taps_launch(const float* src, const float* w_taps, float* dst, int N, int Cs, int Cd, int T, int H, int W, int To, int Ho, int Wo,
                            int kt, int kh, int kw, int bt_, int bh, int bw, int sg, int f16x3, int pre, const unsigned long long* amax_a,
                            const unsigned long long* amax_b, float* ws, int splits, int kchunk, hipStream_t s, const int* stride3 = nullptr,
-                           const float* bias = nullptr);
+                           const float* bias = nullptr, int planes = 0);
+extern "C" int m3t_btc_to_bct(const float* src, float* dst, int B, int T, int C, void* stream);
 int m3t_conv3d_wgrad_launch(const float* x_cl, const float* dy_cl, float* dwt, int N, int Ci, int Co, int T, int H, int W, int To, int Ho, int Wo,
                             int kt, int kh, int kw, const int* stride3, int pt, int ph, int pw, int f16x3, const unsigned long long* amax_x,
                             const unsigned long long* amax_dy, float* ws, int splits, int kchunk, hipStream_t s);
 
 int m3t_conv3d_taps4_launch(const float* x_img4, const float* w_img, const float* bias, float* y_cl, int N, int Co, int T, int H, int W, int To,
                             int Ho, int Wo, int kt, int kh, int kw, const int* stride3, int pt, int ph, int pw, const unsigned long long* amax_x,
-                            const unsigned long long* amax_w, float* ws, int splits, int kchunk, hipStream_t s);
+                            const unsigned long long* amax_w, float* ws, int splits, int kchunk, hipStream_t s, int planes);
 
 // split-K of a tap walk: enough workgroups for the chip (the deep layers are a few hundred tiles with K = 13 824), slabs in `ws`
 static void taps_split(long long rows, int Cd, int K, float* ws, size_t ws_bytes, int& splits, int& kchunk) {
@@ -855,7 +856,8 @@ extern "C" int m3t_f16x3_split(const float* x, size_t rows, int cols, size_t ld,
 // include/m3t_hip.h: the tap-walk contraction over channels-last grids (the convolutions' data gradient without a patch matrix)
 extern "C" int m3t_conv3d_taps(const float* src, const float* w_taps, float* dst, int N, int C_src, int C_dst, int T, int H, int W,
                                int To, int Ho, int Wo, int kt, int kh, int kw, int base_t, int base_h, int base_w, int sign, int flags,
-                               const unsigned long long* amax_src, const unsigned long long* amax_w, float* ws, size_t ws_bytes, void* stream) {
+                               const unsigned long long* amax_src, const unsigned long long* amax_w, float* ws, size_t ws_bytes, float* dst_planes,
+                               void* stream) {
     if (N <= 0 || C_dst <= 0) return 0;
     if (!src || !w_taps || !dst || C_src <= 0 || T <= 0 || H <= 0 || W <= 0 || To <= 0 || Ho <= 0 || Wo <= 0 || kt <= 0 || kh <= 0 || kw <= 0 ||
         (sign != 1 && sign != -1))
@@ -876,10 +878,12 @@ extern "C" int m3t_conv3d_taps(const float* src, const float* w_taps, float* dst
     }
     int splits, kchunk;
     taps_split(rows, C_dst, kt * kh * kw * C_src, ws, ws_bytes, splits, kchunk);
-    const int rc = m3t_conv3d_taps_launch(src, w_taps, dst, N, C_src, C_dst, T, H, W, To, Ho, Wo, kt, kh, kw, base_t, base_h, base_w, sign, f16x3, 0,
-                                          use_a, use_b, ws, splits, kchunk, s);
+    const bool direct_planes = dst_planes && splits == 1;
+    const int rc = m3t_conv3d_taps_launch(src, w_taps, direct_planes ? dst_planes : dst, N, C_src, C_dst, T, H, W, To, Ho, Wo, kt, kh, kw, base_t,
+                                          base_h, base_w, sign, f16x3, 0, use_a, use_b, ws, splits, kchunk, s, nullptr, nullptr, direct_planes);
     if (rc) return rc;
     if (splits > 1) { launch_splitk_reduce(ws, dst, nullptr, (int)rows, C_dst, C_dst, splits, 0, 0, s); M3T_LAUNCH_CHECK(); }
+    if (dst_planes && !direct_planes) return m3t_btc_to_bct(dst, dst_planes, N, T * H * W, C_dst, stream);
     return 0;
 }
 
@@ -887,7 +891,7 @@ extern "C" int m3t_conv3d_taps(const float* src, const float* w_taps, float* dst
 extern "C" int m3t_conv3d_taps_pre(const float* src_img, const float* w_img, float* dst, int N, int C_src, int C_dst, int T, int H, int W,
                                    int To, int Ho, int Wo, int kt, int kh, int kw, int base_t, int base_h, int base_w, int sign,
                                    const unsigned long long* amax_src, const unsigned long long* amax_w, float* ws, size_t ws_bytes,
-                                   void* stream) {
+                                   float* dst_planes, void* stream) {
     if (N <= 0 || C_dst <= 0) return 0;
     if (!src_img || !w_img || !dst || !amax_src || !amax_w || C_src <= 0 || T <= 0 || H <= 0 || W <= 0 || To <= 0 || Ho <= 0 || Wo <= 0 ||
         kt <= 0 || kh <= 0 || kw <= 0 || (sign != 1 && sign != -1))
@@ -899,17 +903,21 @@ extern "C" int m3t_conv3d_taps_pre(const float* src_img, const float* w_img, flo
         return M3T_EINVAL;
     int splits, kchunk;
     taps_split(rows, C_dst, kt * kh * kw * C_src, ws, ws_bytes, splits, kchunk);
-    const int rc = m3t_conv3d_taps_launch(src_img, w_img, dst, N, C_src, C_dst, T, H, W, To, Ho, Wo, kt, kh, kw, base_t, base_h, base_w, sign, 1, 1,
-                                          amax_src, amax_w, ws, splits, kchunk, (hipStream_t)stream);
+    const bool direct_planes = dst_planes && splits == 1;
+    const int rc = m3t_conv3d_taps_launch(src_img, w_img, direct_planes ? dst_planes : dst, N, C_src, C_dst, T, H, W, To, Ho, Wo, kt, kh, kw, base_t,
+                                          base_h, base_w, sign, 1, 1, amax_src, amax_w, ws, splits, kchunk, (hipStream_t)stream, nullptr, nullptr,
+                                          direct_planes);
     if (rc) return rc;
     if (splits > 1) { launch_splitk_reduce(ws, dst, nullptr, (int)rows, C_dst, C_dst, splits, 0, 0, (hipStream_t)stream); M3T_LAUNCH_CHECK(); }
+    if (dst_planes && !direct_planes) return m3t_btc_to_bct(dst, dst_planes, N, T * H * W, C_dst, stream);
     return 0;
 }
 
 // include/m3t_hip.h: the forward convolution as the tap walk on operands split once
 extern "C" int m3t_conv3d_fwd_taps(const float* x_img, const float* w_img, const float* bias, float* y_cl, int N, int Ci, int Co, int T, int H,
                                    int W, int kt, int kh, int kw, int st, int sh, int sw, int pt, int ph, int pw,
-                                   const unsigned long long* amax_x, const unsigned long long* amax_w, float* ws, size_t ws_bytes, void* stream) {
+                                   const unsigned long long* amax_x, const unsigned long long* amax_w, float* ws, size_t ws_bytes, float* y_planes,
+                                   void* stream) {
     if (N <= 0 || Co <= 0) return 0;
     if (!x_img || !w_img || !y_cl || !amax_x || !amax_w || Ci <= 0 || T <= 0 || H <= 0 || W <= 0 || kt <= 0 || kh <= 0 || kw <= 0 || st <= 0 ||
         sh <= 0 || sw <= 0 || pt < 0 || ph < 0 || pw < 0)
@@ -925,17 +933,19 @@ extern "C" int m3t_conv3d_fwd_taps(const float* x_img, const float* w_img, const
     taps_split(rows, Co, kt * kh * kw * Ci, ws, ws_bytes, splits, kchunk);
     const int stride3[3] = {st, sh, sw};
     hipStream_t s = (hipStream_t)stream;
-    const int rc = m3t_conv3d_taps_launch(x_img, w_img, y_cl, N, Ci, Co, To, Ho, Wo, T, H, W, kt, kh, kw, -pt, -ph, -pw, 1, 1, 1, amax_x, amax_w, ws,
-                                          splits, kchunk, s, stride3, bias);
+    const bool direct_planes = y_planes && splits == 1;
+    const int rc = m3t_conv3d_taps_launch(x_img, w_img, direct_planes ? y_planes : y_cl, N, Ci, Co, To, Ho, Wo, T, H, W, kt, kh, kw, -pt, -ph, -pw, 1,
+                                          1, 1, amax_x, amax_w, ws, splits, kchunk, s, stride3, bias, direct_planes);
     if (rc) return rc;
     if (splits > 1) { launch_splitk_reduce(ws, y_cl, bias, (int)rows, Co, Co, splits, 0, 0, s); M3T_LAUNCH_CHECK(); }
+    if (y_planes && !direct_planes) return m3t_btc_to_bct(y_cl, y_planes, N, To * Ho * Wo, Co, stream);
     return 0;
 }
 
 // include/m3t_hip.h: the first layers (C_in <= 4) on the four-channel image
 extern "C" int m3t_conv3d_fwd_taps4(const float* x_img4, const float* w_img, const float* bias, float* y_cl, int N, int Co, int T, int H, int W,
                                     int kt, int kh, int kw, int st, int sh, int sw, int pt, int ph, int pw, const unsigned long long* amax_x,
-                                    const unsigned long long* amax_w, float* ws, size_t ws_bytes, void* stream) {
+                                    const unsigned long long* amax_w, float* ws, size_t ws_bytes, float* y_planes, void* stream) {
     if (N <= 0 || Co <= 0) return 0;
     if (!x_img4 || !w_img || !y_cl || !amax_x || !amax_w || T <= 0 || H <= 0 || W <= 0 || kt <= 0 || kh <= 0 || kw <= 0 || kw > 8 || st <= 0 ||
         sh <= 0 || sw <= 0 || pt < 0 || ph < 0 || pw < 0 || T + 2 * pt < kt || H + 2 * ph < kh || W + 2 * pw < kw)
@@ -949,10 +959,12 @@ extern "C" int m3t_conv3d_fwd_taps4(const float* x_img4, const float* w_img, con
     taps_split(rows, Co, kt * kh * 32, ws, ws_bytes, splits, kchunk);
     const int stride3[3] = {st, sh, sw};
     hipStream_t s = (hipStream_t)stream;
-    const int rc = m3t_conv3d_taps4_launch(x_img4, w_img, bias, y_cl, N, Co, T, H, W, To, Ho, Wo, kt, kh, kw, stride3, pt, ph, pw, amax_x, amax_w, ws,
-                                           splits, kchunk, s);
+    const bool direct_planes = y_planes && splits == 1;
+    const int rc = m3t_conv3d_taps4_launch(x_img4, w_img, bias, direct_planes ? y_planes : y_cl, N, Co, T, H, W, To, Ho, Wo, kt, kh, kw, stride3, pt,
+                                           ph, pw, amax_x, amax_w, ws, splits, kchunk, s, direct_planes);
     if (rc) return rc;
     if (splits > 1) { launch_splitk_reduce(ws, y_cl, bias, (int)rows, Co, Co, splits, 0, 0, s); M3T_LAUNCH_CHECK(); }
+    if (y_planes && !direct_planes) return m3t_btc_to_bct(y_cl, y_planes, N, To * Ho * Wo, Co, stream);
     return 0;
 }
 

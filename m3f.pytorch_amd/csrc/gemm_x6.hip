@@ -49,6 +49,7 @@ struct X6Params {
     // row m = (n, t, h, w) of the DESTINATION grid c3_T x c3_H x c3_W, source rows on the grid c3_To x c3_Ho x c3_Wo (zero outside it)
     int c3_T, c3_H, c3_W, c3_To, c3_Ho, c3_Wo, c3_kt, c3_kh, c3_kw, c3_bt, c3_bh, c3_bw, c3_sg, c3_C;
     int c3_st, c3_sh, c3_sw;             // source coordinate = destination coordinate * stride + base + sign * tap (1 for the data gradient's walk)
+    int tr_S;                            // C3 = 1, 3, one K pass: > 0 -- C is written as channel planes [M / tr_S][N][tr_S] (row m = sample m / tr_S, position m % tr_S)
 };
 // MW kernels run up to M3T_WINDOW_BATCH problems of one shape in one launch (blockIdx.z = problem): the pieces of one progress mark
 // (m3t_sgemm_window_batch) -- every (stack, direction) pair that reads the same window -- fill the CUs a scan leaves free as ONE grid
@@ -449,6 +450,39 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p, X6Batch bt
     const bool direct = p.splits == 1;
     float* dst = direct ? p.C : p.ws + (size_t)blockIdx.z * p.M * p.N;
     const int ldd = direct ? p.ldc : p.N;
+    if constexpr (C3 == 1 || C3 == 3) {
+        // the walk's result straight into the planes layout the next operator reads (BatchNorm / pooling / CBAM work on [N, C, T, H, W]): a
+        // lane holds 4 consecutive positions of one channel -- one 16-byte store per (channel, 4 positions), the 8 stores of a 32 x 32
+        // accumulator tile complete one 128-byte line per channel.  Was: channels-last rows + a tiled transpose (one more pass each way)
+        if (direct && p.tr_S > 0) {
+            const int S = p.tr_S;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int col = bn + wn * 32 * NJ + j * 32 + l31;
+                    const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const int m0 = bm + wm * 64 + i * 32 + 8 * q4 + 4 * hi;
+                        int n = m0 / S, sp = m0 - n * S;
+                        float4 v;
+                        v.x = acc[i][j][4 * q4 + 0] * sc_ia * sc_ib + bv; v.y = acc[i][j][4 * q4 + 1] * sc_ia * sc_ib + bv;
+                        v.z = acc[i][j][4 * q4 + 2] * sc_ia * sc_ib + bv; v.w = acc[i][j][4 * q4 + 3] * sc_ia * sc_ib + bv;
+                        if ((S & 3) == 0) *reinterpret_cast<float4*>(p.C + ((size_t)n * p.N + col) * S + sp) = v;
+                        else {
+                            const float ve[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                p.C[((size_t)n * p.N + col) * S + sp] = ve[e];
+                                if (++sp == S) { sp = 0; ++n; }
+                            }
+                        }
+                    }
+                }
+            return;
+        }
+    }
     float vmax = 0.f;                                // CONV: max |y| of this thread's outputs (p.cv_amax)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -507,7 +541,7 @@ int m3t_sgemm_x6_launch(int transA, int transB, int M, int N, int K, const float
     p.cv_drop = m3t_make_drop(0.f, 0ull);
     p.cv_amax = nullptr;
     p.mw_len = p.mw_stride = p.mw_off = 0;
-    p.c3_T = p.c3_H = p.c3_W = p.c3_To = p.c3_Ho = p.c3_Wo = p.c3_kt = p.c3_kh = p.c3_kw = p.c3_bt = p.c3_bh = p.c3_bw = p.c3_sg = p.c3_C = 0; p.c3_st = p.c3_sh = p.c3_sw = 1;
+    p.c3_T = p.c3_H = p.c3_W = p.c3_To = p.c3_Ho = p.c3_Wo = p.c3_kt = p.c3_kh = p.c3_kw = p.c3_bt = p.c3_bh = p.c3_bw = p.c3_sg = p.c3_C = 0; p.c3_st = p.c3_sh = p.c3_sw = 1; p.tr_S = 0;
     dim3 grid(N / (narrow ? 64 : XN), M / XM, splits), block(256);
 #define M3T_X6_DISPATCH(NS_, XNT_)                                                                                                  \
     do {                                                                                                                           \
@@ -575,7 +609,7 @@ int m3t_sgemm_x6_pre_launch(int M, int N, int K, const float* A, int lda, const 
     p.cv_T = p.cv_C = p.cv_K = p.cv_dil = p.cv_lead = p.cv_anti = 0; p.cv_btap = 0; p.cv_mask = p.cv_res = nullptr; p.cv_pre = nullptr;
     p.cv_drop = m3t_make_drop(0.f, 0ull);
     p.mw_len = p.mw_stride = p.mw_off = 0;
-    p.c3_T = p.c3_H = p.c3_W = p.c3_To = p.c3_Ho = p.c3_Wo = p.c3_kt = p.c3_kh = p.c3_kw = p.c3_bt = p.c3_bh = p.c3_bw = p.c3_sg = p.c3_C = 0; p.c3_st = p.c3_sh = p.c3_sw = 1;
+    p.c3_T = p.c3_H = p.c3_W = p.c3_To = p.c3_Ho = p.c3_Wo = p.c3_kt = p.c3_kh = p.c3_kw = p.c3_bt = p.c3_bh = p.c3_bw = p.c3_sg = p.c3_C = 0; p.c3_st = p.c3_sh = p.c3_sw = 1; p.tr_S = 0;
     dim3 grid(N / (narrow ? 64 : XN), M / XM, 1), block(256);
     if (narrow) sgemm_x6_kernel<0, 1, false, 4, false, 64, false, false, 3><<<grid, block, 0, s>>>(p, g_no_batch);
     else sgemm_x6_kernel<0, 1, false, 4, false, 128, false, false, 3><<<grid, block, 0, s>>>(p, g_no_batch);
@@ -587,7 +621,7 @@ int m3t_sgemm_x6_pre_launch(int M, int N, int K, const float* A, int lda, const 
 int m3t_conv3d_taps_launch(const float* src, const float* w_taps, float* dst, int N, int Cs, int Cd, int T, int H, int W, int To, int Ho, int Wo,
                            int kt, int kh, int kw, int bt_, int bh, int bw, int sg, int f16x3, int pre, const unsigned long long* amax_a,
                            const unsigned long long* amax_b, float* ws, int splits, int kchunk, hipStream_t s, const int* stride3,
-                           const float* bias) {
+                           const float* bias, int planes) {
     X6Params p;
     if (pre && !f16x3) return M3T_EINVAL;
     if (f16x3 && (!amax_a || !amax_b)) return M3T_EINVAL;
@@ -602,6 +636,7 @@ int m3t_conv3d_taps_launch(const float* src, const float* w_taps, float* dst, in
     p.c3_T = T; p.c3_H = H; p.c3_W = W; p.c3_To = To; p.c3_Ho = Ho; p.c3_Wo = Wo; p.c3_kt = kt; p.c3_kh = kh; p.c3_kw = kw;
     p.c3_bt = bt_; p.c3_bh = bh; p.c3_bw = bw; p.c3_sg = sg; p.c3_C = Cs;
     p.c3_st = stride3 ? stride3[0] : 1; p.c3_sh = stride3 ? stride3[1] : 1; p.c3_sw = stride3 ? stride3[2] : 1;
+    p.tr_S = (planes && splits == 1) ? T * H * W : 0;      // (dst is then [N][Cd][T H W])
     const bool narrow = (Cd % 128 != 0) || (Cd / XN) * (p.M / XM) * splits <= 384;
     dim3 grid(Cd / (narrow ? 64 : XN), p.M / XM, splits), block(256);
 #define M3T_C3_GO(NS_)                                                                                                  \
@@ -622,7 +657,7 @@ int m3t_conv3d_taps_launch(const float* src, const float* w_taps, float* dst, in
 // [Co][kt][kh][8][4].  The caller has verified: rows % 128 == 0, Co % 64 == 0, kw <= 8, 16-B aligned operands.
 int m3t_conv3d_taps4_launch(const float* x_img4, const float* w_img, const float* bias, float* y_cl, int N, int Co, int T, int H, int W, int To,
                             int Ho, int Wo, int kt, int kh, int kw, const int* stride3, int pt, int ph, int pw, const unsigned long long* amax_x,
-                            const unsigned long long* amax_w, float* ws, int splits, int kchunk, hipStream_t s) {
+                            const unsigned long long* amax_w, float* ws, int splits, int kchunk, hipStream_t s, int planes) {
     X6Params p;
     if (!amax_x || !amax_w) return M3T_EINVAL;
     p.amax_a = amax_x; p.amax_b = amax_w; p.cv_amax = nullptr;
@@ -636,6 +671,7 @@ int m3t_conv3d_taps4_launch(const float* x_img4, const float* w_img, const float
     p.c3_T = To; p.c3_H = Ho; p.c3_W = Wo; p.c3_To = T; p.c3_Ho = H; p.c3_Wo = W; p.c3_kt = kt; p.c3_kh = kh; p.c3_kw = kw;
     p.c3_bt = -pt; p.c3_bh = -ph; p.c3_bw = -pw; p.c3_sg = 1; p.c3_C = 4;
     p.c3_st = stride3[0]; p.c3_sh = stride3[1]; p.c3_sw = stride3[2];
+    p.tr_S = (planes && splits == 1) ? To * Ho * Wo : 0;
     const bool narrow = (Co % 128 != 0) || (Co / XN) * (p.M / XM) * splits <= 384;
     dim3 grid(Co / (narrow ? 64 : XN), p.M / XM, splits), block(256);
     if (narrow) sgemm_x6_kernel<0, 1, false, 4, false, 64, false, 3, 3><<<grid, block, 0, s>>>(p, g_no_batch);
@@ -662,7 +698,7 @@ int m3t_conv3d_wgrad_launch(const float* x_cl, const float* dy_cl, float* dwt, i
     // the counter runs over the dy grid (c3_T/H/W), the source is x's grid (c3_To/Ho/Wo)
     p.c3_T = To; p.c3_H = Ho; p.c3_W = Wo; p.c3_To = T; p.c3_Ho = H; p.c3_Wo = W; p.c3_kt = kt; p.c3_kh = kh; p.c3_kw = kw;
     p.c3_bt = -pt; p.c3_bh = -ph; p.c3_bw = -pw; p.c3_sg = 1; p.c3_C = Ci;
-    p.c3_st = stride3[0]; p.c3_sh = stride3[1]; p.c3_sw = stride3[2];
+    p.c3_st = stride3[0]; p.c3_sh = stride3[1]; p.c3_sw = stride3[2]; p.tr_S = 0;
     const bool narrow = (Co % 128 != 0) || (Co / XN) * (Mp / XM) * splits <= 384;
     dim3 grid(Co / (narrow ? 64 : XN), Mp / XM, splits), block(256);
     if (f16x3) {

@@ -55,12 +55,12 @@ SIGNATURES = {
     "m3t_absmax": [_i, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), _s],
     "m3t_sgemm_plan": [_i, _i, _i, _i, _i, _z, _i, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "m3t_im2col3d": [_f] + [_i] * 14 + [_f, C.c_longlong, _i, C.c_void_p, _s],
-    "m3t_conv3d_taps": [_f, _f, _f] + [_i] * 17 + [_f, _f, _f, _z, _s],
+    "m3t_conv3d_taps": [_f, _f, _f] + [_i] * 17 + [_f, _f, _f, _z, _f, _s],
     "m3t_sgemm_pre": [_i, _i, _i, _f, _i, _f, _i, _f, _i, _f, _i, _i, _f, _f, _s],
     "m3t_f16x3_split": [_f, _z, _i, _z, _f, _z, _f, _s],
-    "m3t_conv3d_taps_pre": [_f, _f, _f] + [_i] * 16 + [_f, _f, _f, _z, _s],
-    "m3t_conv3d_fwd_taps": [_f, _f, _f, _f] + [_i] * 15 + [_f, _f, _f, _z, _s],
-    "m3t_conv3d_fwd_taps4": [_f, _f, _f, _f] + [_i] * 14 + [_f, _f, _f, _z, _s],
+    "m3t_conv3d_taps_pre": [_f, _f, _f] + [_i] * 16 + [_f, _f, _f, _z, _f, _s],
+    "m3t_conv3d_fwd_taps": [_f, _f, _f, _f] + [_i] * 15 + [_f, _f, _f, _z, _f, _s],
+    "m3t_conv3d_fwd_taps4": [_f, _f, _f, _f] + [_i] * 14 + [_f, _f, _f, _z, _f, _s],
     "m3t_planes_to_cl4": [_f, _f, _i, _i, C.c_longlong, _s],
     "m3t_conv3d_wgrad_taps": [_f, _f, _f] + [_i] * 16 + [_f, _f, _f, _z, _s],
     "m3t_amax_out": [C.c_void_p],

@@ -2330,13 +2330,12 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
                 _lib.check(lib().m3t_f16x3_split(_p(x_cl), srows, cw, cw, _p(x_img), cw, slots.data_ptr(), _stream()), "m3t_f16x3_split")
                 _lib.check(lib().m3t_f16x3_split(_p(w_t), Co, wk, wk, _p(w_img), wk, a_w, _stream()), "m3t_f16x3_split")
                 geo = (kt, kh, kw, stride[0], stride[1], stride[2], padding[0], padding[1], padding[2], slots.data_ptr(), a_w, _p(wsd),
-                       wsd.numel() * 4, _stream())
+                       wsd.numel() * 4, _p(y), _stream())          # (y: planes, written by the walk's epilogue in one K pass)
                 bp = _p(b) if b is not None else None
                 if cw == Ci:
                     _lib.check(lib().m3t_conv3d_fwd_taps(_p(x_img), _p(w_img), bp, _p(y_cl), N_, Ci, Co, T_, H_, W_, *geo), "m3t_conv3d_fwd_taps")
                 else:
                     _lib.check(lib().m3t_conv3d_fwd_taps4(_p(x_img), _p(w_img), bp, _p(y_cl), N_, Co, T_, H_, W_, *geo), "m3t_conv3d_fwd_taps4")
-                _lib.check(lib().m3t_btc_to_bct(_p(y_cl), _p(y), N_, To * Ho * Wo, Co, _stream()), "m3t_btc_to_bct")
                 ctx.save_for_backward(x, w, x_cl, slots)
                 ctx.pat = (rows, Kc, Kp)
                 ctx.a_w = a_w
@@ -2408,7 +2407,8 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
                 _lib.check(lib().m3t_bct_to_btc(_p(dyc), _p(dy_cl), Nn, Co, Sp, _stream()), "m3t_bct_to_btc")
         if taps_dx:
             To, Ho, Wo = dy.shape[2], dy.shape[3], dy.shape[4]
-            dx_cl = torch.empty(N_ * T_ * H_ * W_, Ci, dtype=torch.float32, device=dy.device)
+            dx_cl = torch.empty(N_ * T_ * H_ * W_, Ci, dtype=torch.float32, device=dy.device)      # (scratch of the split-K layers; dx itself: planes)
+            dx = torch.empty(N_, Ci, T_, H_, W_, dtype=torch.float32, device=dy.device)
             wsd = workspace(dy.device)
             if (ctx.prec & _lib.M3T_GEMM_F16X3) and ctx.a_w is not None and CONV3D_PRESPLIT[0]:
                 # both operands split ONCE (m3t_f16x3_split: dy channels-last under the slot its transpose raised, the weights as the
@@ -2419,15 +2419,13 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
                 _lib.check(lib().m3t_f16x3_split(_p(dy_cl), rows, Co, Co, _p(dy_img), Co, slot_dy.data_ptr(), _stream()), "m3t_f16x3_split")
                 _lib.check(lib().m3t_f16x3_split(_p(w_t), Ci, taps * Co, taps * Co, _p(w_img), taps * Co, ctx.a_w, _stream()), "m3t_f16x3_split")
                 _lib.check(lib().m3t_conv3d_taps_pre(_p(dy_img), _p(w_img), _p(dx_cl), N_, Co, Ci, T_, H_, W_, To, Ho, Wo, kt, kh, kw,
-                                                     pd[0], pd[1], pd[2], -1, slot_dy.data_ptr(), ctx.a_w, _p(wsd), wsd.numel() * 4, _stream()),
-                           "m3t_conv3d_taps_pre")
+                                                     pd[0], pd[1], pd[2], -1, slot_dy.data_ptr(), ctx.a_w, _p(wsd), wsd.numel() * 4, _p(dx),
+                                                     _stream()), "m3t_conv3d_taps_pre")
             else:
                 w_taps = w.detach().permute(2, 3, 4, 0, 1).contiguous().view(kt * kh * kw * Co, Ci)      # [(tap, co)][ci] (a few MB per layer)
                 _lib.check(lib().m3t_conv3d_taps(_p(dy_cl), _p(w_taps), _p(dx_cl), N_, Co, Ci, T_, H_, W_, To, Ho, Wo, kt, kh, kw,
-                                                 pd[0], pd[1], pd[2], -1, ctx.prec, slot_dy.data_ptr(), ctx.a_w, _p(wsd), wsd.numel() * 4, _stream()),
-                           "m3t_conv3d_taps")
-            dx = torch.empty(N_, Ci, T_, H_, W_, dtype=torch.float32, device=dy.device)
-            _lib.check(lib().m3t_btc_to_bct(_p(dx_cl), _p(dx), N_, T_ * H_ * W_, Ci, _stream()), "m3t_btc_to_bct")
+                                                 pd[0], pd[1], pd[2], -1, ctx.prec, slot_dy.data_ptr(), ctx.a_w, _p(wsd), wsd.numel() * 4, _p(dx),
+                                                 _stream()), "m3t_conv3d_taps")
         if ctx.needs_input_grad[1] and impl:
             # the walk turned round: dW^T[(tap, ci)][co] summed over dy's rows, x channels-last from the forward pass (m3t_conv3d_wgrad_taps)
             taps, Kc = kt * kh * kw, impl * kt * kh * kw                      # (impl = 4 for a first layer: its channels padded)

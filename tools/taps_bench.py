@@ -22,10 +22,13 @@ for name, Ci, Co, H, Ho in layers:
     def pre():
         _lib.check(lib.m3t_f16x3_split(ops._p(dy), rows_o, Co, Co, ops._p(dyi), Co, sl.data_ptr(), st), "s")
         _lib.check(lib.m3t_f16x3_split(ops._p(wt), Ci, 27 * Co, 27 * Co, ops._p(wi), 27 * Co, sl.data_ptr() + 8, st), "s")
-    def run():
+    dxp = torch.empty_like(dx)
+    def run(planes=None):
         _lib.check(lib.m3t_conv3d_taps_pre(ops._p(dyi), ops._p(wi), ops._p(dx), N, Co, Ci, T, H, H, T, Ho, Ho, 3, 3, 3, 1, 0, 0, -1,
-                                           sl.data_ptr(), sl.data_ptr() + 8, ops._p(ws), ws.numel() * 4, st), "t")
-    for fn, tag in ((pre, "split"), (run, "taps_pre")):
+                                           sl.data_ptr(), sl.data_ptr() + 8, ops._p(ws), ws.numel() * 4, planes, st), "t")
+    def run_planes():
+        run(ops._p(dxp))
+    for fn, tag in ((pre, "split"), (run, "taps_pre"), (run_planes, "-> planes")):
         fn(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
