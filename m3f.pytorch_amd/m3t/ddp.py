@@ -262,7 +262,7 @@ class FlatGradDDP:
 
         def hook(_m, _gi, _go):
             from . import ops
-            cur = torch.cuda.current_stream()
+            cur = ops.cur_stream()
             self._early_stream.wait_stream(cur)
             for st in ops.wgrad_streams(self.flat.device):      # the bucket's weight gradients are written on these streams
                 self._early_stream.wait_stream(st)
@@ -293,7 +293,7 @@ class FlatGradDDP:
             # bucket 0 -- which holds flat[0] -- may still be in flight on the communication stream: join it BEFORE the poison kernel
             # writes flat[0] on this stream (a data race otherwise); the dead slot carries the failure either way
             self._early_handle.wait()
-            torch.cuda.current_stream().wait_stream(self._early_stream)
+            ops.cur_stream().wait_stream(self._early_stream)
         if self.world > 1 and hip:
             ops.grad_poison_(self.flat, self.dead)          # this rank's dead scan -> NaN in flat[0], 1 in the dead slot
         if early:

@@ -90,7 +90,7 @@ class _Timed:
 
     def __enter__(self):
         if self.rec is not None:
-            st = torch.cuda.current_stream()
+            st = cur_stream()
             self.rec["start"].record(st)
             if self.kernel_side:
                 self.rec["end"].record(st)          # materialises the handle; the C call records both again
@@ -101,7 +101,7 @@ class _Timed:
     def __exit__(self, *exc):
         if self.rec is not None:
             if not self.kernel_side:
-                self.rec["end"].record(torch.cuda.current_stream())
+                self.rec["end"].record(cur_stream())
             PROFILE.append(self.rec)
         return False
 
@@ -113,11 +113,69 @@ def lib():
 _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)       # the current stream's handle without building a Stream object
 
 
+_HOST_SLOW = os.environ.get("M3T_HOST_FAST", "1") == "00"
+_CUR_DEV = (getattr(torch._C, "_cuda_getDevice", None) if not _HOST_SLOW else None) or torch.cuda.current_device      # (torch.cuda.current_device() walks _lazy_init: ~3 us a call)
+
+
 def _stream():
     """the calling thread's current HIP stream as a C pointer (every launch of the path passes it: ~600 calls per training step)"""
     if _RAW_STREAM is not None:
-        return C.c_void_p(_RAW_STREAM(torch.cuda.current_device()))
+        return C.c_void_p(_RAW_STREAM(_CUR_DEV()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_SET_STREAM = getattr(torch._C, "_cuda_setStream", None)
+
+
+class on_stream:
+    """`with on_stream(st)` for the schedule's ~35 stream switches per step: torch's StreamContext builds Stream objects and walks the
+    device-index helpers on entry and exit (~20 us a switch); this one keeps the previous stream's ids and makes the two C calls"""
+    __slots__ = ("st", "prev")
+
+    def __init__(self, st):
+        self.st = st
+
+    def __enter__(self):
+        st = self.st
+        if st is None:
+            return None
+        if _SET_STREAM is None:
+            self.prev = torch.cuda.current_stream(st.device)
+            torch.cuda.set_stream(st)
+            return st
+        self.prev = cur_stream(st.device)
+        _SET_STREAM(stream_id=st.stream_id, device_index=st.device_index, device_type=st.device_type)
+        return st
+
+    def __exit__(self, *exc):
+        if self.st is None:
+            return False
+        p = self.prev
+        if _SET_STREAM is None:
+            torch.cuda.set_stream(p)
+        else:
+            _SET_STREAM(stream_id=p.stream_id, device_index=p.device_index, device_type=p.device_type)
+        return False
+
+
+if os.environ.get("M3T_HOST_FAST", "1") == "0":      # A/B: torch's own stream context (tools/host_profile.py)
+    on_stream = torch.cuda.stream
+
+
+_STREAM_OBJ = {}      # (device index, raw handle) -> torch.cuda.Stream: the object is kept, so the handle stays this stream's
+
+
+def cur_stream(device=None):
+    """cur_stream(device) without building a Stream object per call (~15 us each through torch's device-index helpers;
+    the schedule asks ~50 times per step for wait_stream / record / record_stream)"""
+    if _RAW_STREAM is None or _HOST_SLOW:
+        return torch.cuda.current_stream(device)
+    idx = device.index if (device is not None and getattr(device, "index", None) is not None) else (device if isinstance(device, int) else _CUR_DEV())
+    h = _RAW_STREAM(idx)
+    st = _STREAM_OBJ.get((idx, h))
+    if st is None:
+        st = _STREAM_OBJ[(idx, h)] = torch.cuda.current_stream(idx)
+    return st
 
 
 def _req(t, name="tensor"):
@@ -172,7 +230,7 @@ def join_wgrad(device=None):
     for key, pending in list(_WGRAD_PENDING.items()):
         if pending and (device is None or key == (device.type, device.index)):
             for st in _WGRAD.get(key) or []:
-                torch.cuda.current_stream(torch.device(key[0], key[1])).wait_stream(st)
+                cur_stream(torch.device(key[0], key[1])).wait_stream(st)
             _WGRAD_PENDING[key] = False
 
 
@@ -199,7 +257,7 @@ def _ws_tag(device):
     """role of the calling thread's current stream on `device` (called once per GEMM / scan: raw handles, no Stream objects)"""
     if _RAW_STREAM is not None and device.index is not None:
         return _ROLE_OF_HANDLE.get((device.index, _RAW_STREAM(device.index)), "main")
-    cur = torch.cuda.current_stream(device)
+    cur = cur_stream(device)
     st = _SIDE.get((device.type, device.index))
     if st is not None and cur == st:
         return "side"
@@ -294,7 +352,7 @@ def amax_slots(n, device):
         st = _SLOT_POOL[key] = [torch.zeros(max(_SLOT_CHUNK, n), dtype=torch.int64, device=device), 0]
         if device.type == "cuda":
             ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(device))
+            ev.record(cur_stream(device))
             for other in ([_SIDE.get(key)] if _SIDE.get(key) is not None else []) + list(_WGRAD.get(key) or []):
                 other.wait_event(ev)
             st.append(ev)
@@ -476,9 +534,9 @@ class _Linear(torch.autograd.Function):
         # gradients that go straight into the flat buffer feed nothing on the chain: they run on the weight-gradient stream
         # (joined by FlatGradDDP.finish(), see join_wgrad) beside whatever backward does next
         wg = wgrad_stream(x.device, _LINEAR_RR[0]) if x.is_cuda else None
-        off_chain = torch.cuda.stream(wg) if wg is not None else None
+        off_chain = on_stream(wg) if wg is not None else None
         if off_chain is not None and (w_sink is not None or b_sink is not None):
-            wg.wait_stream(torch.cuda.current_stream())
+            wg.wait_stream(cur_stream())
         if ctx.needs_input_grad[1]:
             if w_sink is not None and off_chain is not None:
                 with off_chain:
@@ -790,7 +848,7 @@ def _scan_fwd_(descs, B, T, prec=0, after=None):
         arr = (GruFwdDesc * len(chunk))(*chunk)
         flops = (T - 1) * sum(2.0 * B * 3 * d.H * d.H for d in chunk)
         with _Timed("gru_step_fwd_kernel", T, flops, kernel_side=True) as tm:
-            dev = torch.device("cuda", torch.cuda.current_device())
+            dev = torch.device("cuda", _CUR_DEV())
             ws = workspace(dev)
             n0 = lib().m3t_gru_persist_count() if tm.rec is not None else 0
             _scan_after(after if i == 0 else None)
@@ -818,7 +876,7 @@ def _scan_bwd_(descs, B, T, prec=0, after=None):
         arr = (GruBwdDesc * len(chunk))(*chunk)
         flops = (T - 1) * sum(2.0 * B * 3 * d.H * d.H for d in chunk)
         with _Timed("gru_step_bwd_kernel", T, flops, kernel_side=True) as tm:
-            dev = torch.device("cuda", torch.cuda.current_device())
+            dev = torch.device("cuda", _CUR_DEV())
             ws = workspace(dev)
             n0 = lib().m3t_gru_persist_count() if tm.rec is not None else 0
             _scan_after(after if i == 0 else None)
@@ -920,7 +978,7 @@ class _MultiBiGRU(torch.autograd.Function):
                 off += 2 * Hs[s]
         gates = [[new(2, B, T, 4 * Hs[s]) for s in range(n_stacks)] for _ in range(L)]
         xprojs = [[new(B, T, 6 * Hs[s]) for s in range(n_stacks)] for _ in range(L)]
-        main = torch.cuda.current_stream()
+        main = cur_stream()
         prec = _PREC[0]
         groups = _stream_groups(Hs, B)
         # fp16x3 products: the magnitudes of every layer-0 input and every W_ih, measured once up front (one launch; the backward
@@ -994,7 +1052,7 @@ class _MultiBiGRU(torch.autograd.Function):
             ev_end = torch.cuda.Event()
             ev_end.record(scan_stream)                      # the scan launch of layer l - 1 has ended
             lo, hi = [0] + tb, tb + [T]
-            with torch.cuda.stream(wg):
+            with on_stream(wg):
                 ended = False
                 for dirn, k, w, second in _arrivals(tb, T):
                     if k is None:
@@ -1037,7 +1095,7 @@ class _MultiBiGRU(torch.autograd.Function):
                 for l in range(L):
                     if l == 0 or tb is None:
                         level_fwd(l, heavy, False)
-                    with torch.cuda.stream(side):
+                    with on_stream(side):
                         level_fwd(l, light, False)
                         level_fwd(l, light, True, None, True)      # (wide too: 32 workgroups, one group per XCD, L2-served exchange; -0.03 ms)
                     need = level_fwd(l, heavy, True, None, True, tb if l + 1 < L else None)
@@ -1061,12 +1119,12 @@ class _MultiBiGRU(torch.autograd.Function):
                     # them) run beside the heavy layer-1 input projections, the longest GEMM window of the pass; strictly
                     # alternating (H0, L0, H1, L1) left the second light scan with nothing beside it
                     level_fwd(0, heavy, False)
-                    with torch.cuda.stream(side):
+                    with on_stream(side):
                         level_fwd(0, light, False)
                     level_fwd(0, heavy, True, None)
                     ev_h0 = torch.cuda.Event()
                     ev_h0.record(main)
-                    with torch.cuda.stream(side):
+                    with on_stream(side):
                         level_fwd(0, light, True, ev_h0)
                         level_fwd(1, light, False)
                         level_fwd(1, light, True)
@@ -1077,12 +1135,12 @@ class _MultiBiGRU(torch.autograd.Function):
                 else:
                   for l in range(L):
                     level_fwd(l, heavy, False)
-                    with torch.cuda.stream(side):
+                    with on_stream(side):
                         level_fwd(l, light, False)
                     level_fwd(l, heavy, True, ev_light)
                     ev_heavy = torch.cuda.Event()
                     ev_heavy.record(main)
-                    with torch.cuda.stream(side):
+                    with on_stream(side):
                         level_fwd(l, light, True, ev_heavy)
                         ev_light = torch.cuda.Event()
                         ev_light.record(side)
@@ -1095,7 +1153,7 @@ class _MultiBiGRU(torch.autograd.Function):
                 if kind == "side":
                     stream = side_stream(dev)
                     stream.wait_stream(main)
-                with torch.cuda.stream(stream):
+                with on_stream(stream):
                     tb = chunk_plan(idxs, False) if (kind == "main" and alone) else None
                     if tb is not None:
                         wgrad_stream(dev, 0).wait_stream(stream)
@@ -1135,7 +1193,7 @@ class _MultiBiGRU(torch.autograd.Function):
             if jobs:
                 wg1 = wgrad_streams(dev)[1]
                 wg1.wait_stream(main)                 # (the buffers come from this stream's allocator: their previous users are done)
-                with torch.cuda.stream(wg1):
+                with on_stream(wg1):
                     for H, ws_, outs_ in jobs:
                         n_ = len(ws_)
                         _lib.check(lib().m3t_gru_bwd_prepare((C.c_void_p * n_)(*[t.data_ptr() for t in ws_]), n_, H, 1,
@@ -1223,7 +1281,7 @@ class _MultiBiGRU(torch.autograd.Function):
                         sink = _take_sink(prm)             # gradient written straight into the flat buffer
                         out_grads[base + j] = sink if sink is not None else torch.empty_like(prm)
                         sunk[base + j] = sink is not None
-        main = torch.cuda.current_stream()
+        main = cur_stream()
         groups = _stream_groups(Hs, B)
         cur = {s: douts[s] for s in range(n_stacks)}
         prec = ctx.prec
@@ -1269,7 +1327,7 @@ class _MultiBiGRU(torch.autograd.Function):
             ev_end.record(scan_stream)
             lo, hi = [0] + tb, tb + [T]
             n = len(tb)
-            with torch.cuda.stream(wg):
+            with on_stream(wg):
                 ended = False
                 for dirn, k, w, second in _arrivals(tb, T):
                     if k is None:
@@ -1317,7 +1375,7 @@ class _MultiBiGRU(torch.autograd.Function):
                 return
             if started is not None:        # (need table of a launch with start marks: up- and down-walking scans at step 8)
                 ctr_, need_ = started
-                with torch.cuda.stream(wgs[0]):
+                with on_stream(wgs[0]):
                     _wait_progress(ctr_, 0, need_[0])
                     _wait_progress(ctr_, 1, need_[2])
             fn()
@@ -1364,7 +1422,7 @@ class _MultiBiGRU(torch.autograd.Function):
         def level_dx(l, idxs):           # on the chain: feeds the next level's scan
             pg = pending.pop((l, tuple(idxs)), None)
             if pg is not None:           # round 5: the pieces run under the scan; what is left behind it is the last window of each direction
-                dx_pieces(l, idxs, pg[0], pg[1], torch.cuda.current_stream())
+                dx_pieces(l, idxs, pg[0], pg[1], cur_stream())
                 return
             for s in idxs:
                 H = Hs[s]
@@ -1397,7 +1455,7 @@ class _MultiBiGRU(torch.autograd.Function):
                     goff = d * B * T * 3 * H
                     # tail: [the stream this level runs on, weight-gradient stream 1] -- after the last level nothing else is queued on
                     # the level's own stream, and finalize (FlatGradDDP.finish) then follows its last GEMM with no cross-queue hop
-                    with (torch.cuda.stream(pool[rr[0] % len(pool)]) if pool is not None else _NULL):
+                    with (on_stream(pool[rr[0] % len(pool)]) if pool is not None else _NULL):
                         if T > 1 and (B * (T - 1)) % 32 != 0 and (B * T) % 32 == 0 and H % 128 == 0:
                             # K = B (T-1) is no multiple of the bf16x6 GEMMs' 32-deep k tile (e.g. 8 clips x 64 frames: K = 504) and
                             # the segmented product would fall to the fp32-MFMA kernel (20 launches, 7 % of a C5 step).  h_prev at
@@ -1410,7 +1468,7 @@ class _MultiBiGRU(torch.autograd.Function):
                                 hprev[:, :-1].copy_(out[:, 1:, d * H:(d + 1) * H])
                             sgemm(1, 0, 3 * H, H, B * T, dgh[l][s], goff, 3 * H, hprev, 0, H, dw_hh, 0, H, prec=prec,
                                   amax=(bslot(l, s, d), one if bslots is not None else None))
-                            hprev.record_stream(torch.cuda.current_stream())
+                            hprev.record_stream(cur_stream())
                         elif T > 1:
                             # dW_hh = sum_{b,t} dgh[b,t]^T h_prev(b,t): forward pairs (t, t-1), reverse pairs (t, t+1)
                             a_off, b_off = (1, 0) if d == 0 else (0, 1)
@@ -1419,7 +1477,7 @@ class _MultiBiGRU(torch.autograd.Function):
                         else:
                             dw_hh.zero_()
                     rr[0] += 1
-                    with (torch.cuda.stream(pool[rr[0] % len(pool)]) if pool is not None else _NULL):
+                    with (on_stream(pool[rr[0] % len(pool)]) if pool is not None else _NULL):
                         sgemm(1, 0, 3 * H, I, B * T, dgx[l][s], d * 3 * H, 6 * H, inp, 0, I, dw_ih, 0, I, prec=prec,
                               amax=(bslot(l, s, d), fslot_x(l, s)))
                     rr[0] += 1
@@ -1427,9 +1485,9 @@ class _MultiBiGRU(torch.autograd.Function):
         def level_dw(l, idxs, spread=False):
             # one stream switch per level (not per GEMM: ~40 context switches of ~8 us of host time per step) unless the level spreads
             if spread:
-                _level_dw(l, idxs, [torch.cuda.current_stream(), wgs[1]])
+                _level_dw(l, idxs, [cur_stream(), wgs[1]])
             else:
-                with torch.cuda.stream(wgs[0]):
+                with on_stream(wgs[0]):
                     _level_dw(l, idxs, None)
 
         for w_ in wgs:
@@ -1441,7 +1499,7 @@ class _MultiBiGRU(torch.autograd.Function):
             the CUs the scan beside them leaves free: 17.56 vs 17.78 ms per step, round 2)"""
             level_dx(l, idxs)
             ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
+            ev.record(cur_stream())
             for w_ in (wgs if last else wgs[:1]):      # (the streams level_dw uses: stream 1 carries the chunked data gradients of the chain)
                 w_.wait_event(ev)
             if last or not SCAN_FIRST[0]:
@@ -1461,10 +1519,10 @@ class _MultiBiGRU(torch.autograd.Function):
             try:
                 for l in range(L - 1, -1, -1):
                     level_scan(l, heavy, None, True, chunk_plan(l, heavy))
-                    with torch.cuda.stream(side):
+                    with on_stream(side):
                         level_scan(l, light)
                     level_gemms(l, heavy, last=(l == 0))
-                    with torch.cuda.stream(side):
+                    with on_stream(side):
                         level_gemms(l, light, last=(l == 0))
             finally:
                 _FENCED[0] = False
@@ -1487,7 +1545,7 @@ class _MultiBiGRU(torch.autograd.Function):
                     ev_h1 = torch.cuda.Event()
                     ev_h1.record(main)
                     level_gemms(1, heavy)
-                    with torch.cuda.stream(side):
+                    with on_stream(side):
                         level_scan(1, light, ev_h1)
                         ev_l1 = torch.cuda.Event()
                         ev_l1.record(side)
@@ -1496,7 +1554,7 @@ class _MultiBiGRU(torch.autograd.Function):
                     ev_h0 = torch.cuda.Event()
                     ev_h0.record(main)
                     level_gemms(0, heavy, last=True)
-                    with torch.cuda.stream(side):
+                    with on_stream(side):
                         level_scan(0, light, ev_h0)
                         level_gemms(0, light, last=True)
                 else:
@@ -1505,7 +1563,7 @@ class _MultiBiGRU(torch.autograd.Function):
                     ev_heavy = torch.cuda.Event()
                     ev_heavy.record(main)
                     level_gemms(l, heavy)
-                    with torch.cuda.stream(side):
+                    with on_stream(side):
                         level_scan(l, light, ev_heavy)
                         ev_light = torch.cuda.Event()
                         ev_light.record(side)
@@ -1519,7 +1577,7 @@ class _MultiBiGRU(torch.autograd.Function):
                 if kind == "side":
                     stream = side_stream(dev)
                     stream.wait_stream(main)
-                with torch.cuda.stream(stream):
+                with on_stream(stream):
                     for l in range(L - 1, -1, -1):
                         level_scan(l, idxs, progress=chunk_plan(l, idxs) if (kind == "main" and len(groups) == 1) else None)
                         level_gemms(l, idxs)
@@ -1815,17 +1873,17 @@ class _TemporalBlock(torch.autograd.Function):
             # the two convolutions' weight gradients on the two weight-gradient streams (round 4): each is K per-tap split-K GEMMs of 300-odd
             # workgroups -- less than half a round of the chip -- and the LAST block of the backward pass has nothing else to hide behind
             # (C1: 1.84 -> ~1.7 ms per step)
-            main = torch.cuda.current_stream()
+            main = cur_stream()
             wg, wg1 = wgrad_stream(dev, 0), wgrad_stream(dev, 1)
             wg.wait_stream(main)
             wg1.wait_stream(main)
-            with torch.cuda.stream(wg):
+            with on_stream(wg):
                 wsw = workspace(dev)
                 _conv_wgrad(da2, h1, dw2t, B, T, Co, Co, K, dil, wsw, prec, amax=(sl(6), sl(4)))
                 colsum(da2, 0, B * T, Co, Co, sinks[5])
                 _lib.check(lib().m3t_weight_norm_bwd(_p(dw2t), _p(v2), _p(g2), _p(n2), _p(sinks[3]), _p(sinks[4]), Co, Co, K, _stream()),
                            "m3t_weight_norm_bwd")
-            with torch.cuda.stream(wg1):
+            with on_stream(wg1):
                 wsw1 = workspace(dev)
                 _conv_wgrad(da1, x, dw1t, B, T, Ci, Co, K, dil, wsw1, prec, amax=(sl(7), sl(0)))
                 colsum(da1, 0, B * T, Co, Co, sinks[2])

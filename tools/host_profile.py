@@ -43,3 +43,35 @@ torch.cuda.synchronize()
 s = io.StringIO()
 pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(35)
 print(s.getvalue()[:6000])
+
+# (3) the backward functions run on the autograd engine's device thread, which cProfile above does not see: profile them from inside
+import inspect
+from m3t import ops as _ops
+prb = cProfile.Profile()
+tb = [0.0, 0]
+def _wrap(cls):
+    raw = cls.backward
+    def backward(ctx, *a):
+        t0 = time.perf_counter()
+        prb.enable()
+        try:
+            return raw(ctx, *a)
+        finally:
+            prb.disable()
+            tb[0] += time.perf_counter() - t0; tb[1] += 1
+    cls.backward = staticmethod(backward)
+for name, obj in list(vars(_ops).items()):
+    if inspect.isclass(obj) and issubclass(obj, torch.autograd.Function) and obj is not torch.autograd.Function:
+        _wrap(obj)
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+tb[0] = 0.0; tb[1] = 0
+prb.clear()
+for _ in range(N):
+    step()
+torch.cuda.synchronize()
+print("backward functions: %.3f ms/step in %d calls/step (profiled)" % (tb[0] / N * 1e3, tb[1] // N))
+s = io.StringIO()
+pstats.Stats(prb, stream=s).sort_stats("tottime").print_stats(30)
+print(s.getvalue()[:6000])
