@@ -246,7 +246,7 @@ def aux_child(which, steps=6, warmup=2):
             ddp.zero_grad()
             m.training_step(batch, 0)["loss"].backward()
             ddp.finish()
-        emit("c5", "C5 AffWild2VA(audiovisual, attention, v2p_split, ccc_mtl) on raw 112x112 frames (conv stem: forward + weight gradient on the patch-matrix fp16x3 GEMM, data gradient as a tap-walk implicit GEMM), training_step+bwd+clip, 8x64", Bc,
+        emit("c5", "C5 AffWild2VA(audiovisual, attention, v2p_split, ccc_mtl) on raw 112x112 frames (conv stem: forward, weight gradient and data gradient as tap-walk implicit GEMMs over channels-last activations, fp16x3; no patch matrix), training_step+bwd+clip, 8x64", Bc,
              timed(step5), "f32")
 
 
@@ -266,7 +266,7 @@ def aux_child(which, steps=6, warmup=2):
             ddp.finish()
         ms = timed(step_r, 6)
         print(json.dumps({"aux": "cbam_resnet3d", "workload": "VA_3DResNet(resnet_ver='v1', use_cbam=True) visual-only training step (SURVEY 8(d) C5 alt), 8 clips x 64 "
-                          "frames of 112 x 112: 3-D stem + per-frame ResNet-18 convolutions: forward + weight gradient on the patch-matrix fp16x3 GEMM, data gradient of the stride-1 layers as a tap-walk implicit GEMM (strided layers: MIOpen); the 8 CBAM gates, BatchNorm and the BiGRU head on the HIP kernels",
+                          "frames of 112 x 112: 3-D stem + per-frame ResNet-18 convolutions: forward, weight gradient and the stride-1 layers' data gradient as tap-walk implicit GEMMs over channels-last activations (fp16x3, no patch matrix; strided layers' data gradient: MIOpen); the 8 CBAM gates, BatchNorm and the BiGRU head on the HIP kernels",
                           "clips": Bc, "ms_per_step": round(ms, 3), "clips_per_s": round(Bc / ms * 1e3, 1), "dtype": "f32"}), flush=True)
 
 

@@ -2330,12 +2330,13 @@ def _conv3d_plan(x, w, stride, padding):
 
 
 class _Conv3dGemmWgrad(torch.autograd.Function):
-    """Conv3d of the visual stems (reference models/backbone.py:73-103,179-271,327-332).  Round 5: the FORWARD is the patch matrix
-    (m3t_im2col3d: rows (n, t', h', w'), columns (ci, kt, kh, kw)) times W^T on the fp16x3 GEMM, bias in the epilogue, then one tiled
-    transpose back to [N, Co, T', H', W'] -- MIOpen's fp32 forward (a CK grouped-conv kernel) ran at 26 TFLOP/s, 12.4 of the 30.4 ms of a
-    C5 step; the patch matrix the weight gradient needs anyway is written here instead of in backward and kept
-    (4 GB at 8 x 64 frames: sized for 288 GB).  The weight gradient is dy^T P on the same matrix (round 2); the data gradient stays on
-    MIOpen.  Shapes the GEMM cannot tile (rows % 128, C_out % 64) and M3T_CONV3D_MIOPEN=1 take torch.conv3d."""
+    """Conv3d of the visual stems and, with a unit time axis, the per-frame ResNet's Conv2d (reference models/backbone.py:73-103,179-271,
+    327-332, models/resnet.py:40-45).  Round 5: every pass is a tap-walk implicit GEMM on the fp16x3 kernels over channels-last rows --
+    forward (any stride; x channels-last KEPT for backward), weight gradient (the walk turned round, reduction over dy's rows), data gradient
+    of the stride-1 layers (dy channels-last, flipped taps); results leave the walks as channel planes.  No patch matrix (MIOpen's fp32
+    forward ran at 26 TFLOP/s, 12.4 of the 30.4 ms of a C5 step in round 4; the patch-matrix GEMMs of the first half of round 5 wrote 4-6 GB
+    per step).  C_in % 32 != 0 layers other than the 3-channel first layers, M3T_CONV3D_IMPLICIT=0: patch matrix (m3t_im2col3d) x W^T and
+    dy^T P on the GEMM; strided layers' data gradient, shapes no tile fits (rows % 128, C_out % 64), M3T_CONV3D_MIOPEN=1: torch / MIOpen."""
 
     @staticmethod
     def forward(ctx, x, w, b, stride, padding):

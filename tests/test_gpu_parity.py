@@ -1505,19 +1505,22 @@ def test_solo_scans_h128_through_the_c_abi(B, T, bf16):
     ops.poll_scan_error()
 
 
-@pytest.mark.parametrize("switch", ["M3T_CONV_X6", "M3T_CBAM_FUSED", "M3T_CBAM_RESIDENT", "M3T_BN_PLANES"])
+@pytest.mark.parametrize("switch", ["M3T_CONV_X6", "M3T_CBAM_FUSED", "M3T_CBAM_RESIDENT", "M3T_BN_PLANES", "M3T_CONV3D_IMPLICIT"])
 def test_conv_and_cbam_kernel_switches(switch):
     """README's switch table, the entries the C3 step does not exercise (read once per process, hence a child):
     M3T_CONV_X6=0 -- the TCN / tcn_simple convolutions on the fp32-MFMA kernel instead of the bf16x6 implicit GEMM;
     M3T_CBAM_FUSED=0 -- CBAM as channel gate + spatial gate instead of the fused operator;
     M3T_CBAM_RESIDENT=0 -- small frames (7 x 7, 4 x 4 ...) on the fused operator's general kernels F1 / B2 instead of the
     frame-resident F1L / B2L;
+    M3T_CONV3D_IMPLICIT=0 -- Conv3d / the ResNet's Conv2d forward and weight gradient on the patch-matrix GEMMs (first half of round 5) instead
+    of the tap walks over channels-last activations: the stems' goldens and the layer tests again on that path;
     M3T_BN_PLANES=0 -- BatchNorm3d / BatchNorm2d (+ReLU) of the stems and the per-frame ResNet on the stock ops instead of the channel-plane
     kernels.  Same arithmetic: the convolution, TemporalBlock, CBAM, ResNet and C5 parity tests must pass unchanged."""
     import subprocess
     import sys
     env = dict(os.environ, M3T_SCAN_LOCK="0", **{switch: "0"})
     pick = {"M3T_CONV_X6": "conv1d_on_the_bf16x6_pipe or tcn_train_mode or tcn_golden",
+            "M3T_CONV3D_IMPLICIT": "c5_resnet3d or c5_affwild_av_t16 or conv3d_weight_gradient or conv3d_forward_on_the_patch or vggm",
             "M3T_BN_PLANES": "resnet_cbam or c5_resnet3d or c5_affwild_av_t16"}.get(switch, "cbam_golden or resnet_cbam or cbam_stage")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k", pick], env=env,
                        capture_output=True, text=True, timeout=900)
