@@ -112,6 +112,14 @@ int m3t_f16x3_split(const float* x, size_t rows, int cols, size_t ld, float* out
  * N % 64 == 0, K % 32 == 0, both slots required) */
 int m3t_sgemm_pre(int M, int N, int K, const float* A_img, int lda, const float* B_img, int ldb, float* C, int ldc,
                   const float* bias, int act, int accumulate, const unsigned long long* amax_a, const unsigned long long* amax_b, void* stream);
+/* The WEIGHT operand as a staged image (round 5): m3t_f16x3_image_b writes w [N][K] (ld) as [N / 64][K / 8][term][64 rows][8 halves] -- the two
+ * fp16 terms of w * s (s from `slot`), every (64-row block, k-octet, term) one contiguous KiB = one LDS-DMA wave instruction; same size as w.
+ * m3t_sgemm_bimg: C[M,N] = act(A B^T + bias) (+ C) with B given as that image: the 128 x 256 tile kernel fetches B straight into LDS
+ * (global_load_lds_dwordx4: no registers, no conversion, no ds_write for two thirds of the staged bytes), A as m3t_sgemm_scaled.  Bit-identical
+ * to m3t_sgemm_scaled with the same slots.  N % 64 (image) / % 256 (product), K % 32, M % 128; amax_a NULL: measured; amax_b required. */
+int m3t_f16x3_image_b(const float* w, int N, int K, size_t ld, float* img, const unsigned long long* slot, void* stream);
+int m3t_sgemm_bimg(int M, int N, int K, const float* A, int lda, const float* B_img, float* C, int ldc, const float* bias, int act,
+                   int accumulate, float* ws, size_t ws_bytes, const unsigned long long* amax_a, const unsigned long long* amax_b, void* stream);
 int m3t_conv3d_taps_pre(const float* src_img, const float* w_img, float* dst, int N, int C_src, int C_dst, int T, int H, int W,
                         int To, int Ho, int Wo, int kt, int kh, int kw, int base_t, int base_h, int base_w, int sign,
                         const unsigned long long* amax_src, const unsigned long long* amax_w, float* ws, size_t ws_bytes, float* dst_planes,

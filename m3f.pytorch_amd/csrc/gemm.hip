@@ -841,6 +841,75 @@ extern "C" int m3t_sgemm_pre(int M, int N, int K, const float* A_img, int lda, c
     return m3t_sgemm_x6_pre_launch(M, N, K, A_img, lda, B_img, ldb, C, ldc, bias, act, accumulate, narrow, amax_a, amax_b, (hipStream_t)stream);
 }
 
+namespace {
+// the staged image of a K-contiguous fp16x3 operand w [N][K] (gemm_x6w.hip, BD kernels): [N / 64][K / 8][term][64 rows][8 halves] -- every
+// (64-row block, k-octet, term) one contiguous KiB, the unit of an LDS-DMA wave instruction.  One thread per (row, octet).
+__global__ __launch_bounds__(256) void f16x3_image_b_kernel(const float* __restrict__ w, unsigned char* __restrict__ img, int N, int K8, size_t ld,
+                                                            const unsigned long long* __restrict__ slot) {
+    float sc, inv;
+    m3t_f16_scale((unsigned)*slot, sc, inv);
+    const size_t total = (size_t)N * K8;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i % 64); const size_t q = i / 64;            // consecutive threads: consecutive rows of a block (1 KiB stores)
+        const int o = (int)(q % K8); const int rb = (int)(q / K8);
+        const float* src = w + ((size_t)rb * 64 + r) * ld + 8 * (size_t)o;
+        const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
+        const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        unsigned hi[4], lo[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const sp_f32x2 a = (sp_f32x2){x[2 * e], x[2 * e + 1]} * sc;
+            const sp_f16x2 h = __builtin_convertvector(a, sp_f16x2);
+            const sp_f16x2 l = __builtin_convertvector(a - __builtin_convertvector(h, sp_f32x2), sp_f16x2);
+            hi[e] = __builtin_bit_cast(unsigned, h); lo[e] = __builtin_bit_cast(unsigned, l);
+        }
+        unsigned char* dst = img + (((size_t)rb * K8 + o) * 2) * 1024 + (size_t)r * 16;
+        *reinterpret_cast<uint4*>(dst) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        *reinterpret_cast<uint4*>(dst + 1024) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    }
+}
+}  // namespace
+
+int m3t_sgemm_x6w_bimg_launch(int M, int N, int K, const float* A, int lda, const float* B_img, float* C, int ldc, const float* bias, int act,
+                              int accumulate, float* ws, int splits, int kchunk, const unsigned long long* amax_a,
+                              const unsigned long long* amax_b, hipStream_t s);
+
+// include/m3t_hip.h
+extern "C" int m3t_f16x3_image_b(const float* w, int N, int K, size_t ld, float* img, const unsigned long long* slot, void* stream) {
+    if (N <= 0 || K <= 0) return 0;
+    if (!w || !img || !slot || N % 64 != 0 || K % 8 != 0 || ld % 4 != 0 || (uintptr_t)w % 16 != 0 || (uintptr_t)img % 16 != 0) return M3T_EINVAL;
+    const size_t total = (size_t)N * (K / 8);
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    f16x3_image_b_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(w, reinterpret_cast<unsigned char*>(img), N, K / 8, ld, slot);
+    M3T_LAUNCH_CHECK();
+    return 0;
+}
+
+// include/m3t_hip.h: C = act(A B^T + bias) (+ C), B given as its staged image
+extern "C" int m3t_sgemm_bimg(int M, int N, int K, const float* A, int lda, const float* B_img, float* C, int ldc, const float* bias, int act,
+                              int accumulate, float* ws, size_t ws_bytes, const unsigned long long* amax_a, const unsigned long long* amax_b,
+                              void* stream) {
+    if (M <= 0 || N <= 0) return 0;
+    if (!A || !B_img || !C || !amax_b || K <= 0 || !x6_enabled() || !m3t_f16x3_enabled() || M % 128 != 0 || N % 256 != 0 || K % 32 != 0 ||
+        lda % 4 != 0 || (uintptr_t)A % 16 != 0 || (uintptr_t)B_img % 16 != 0)
+        return M3T_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned long long* use_a = amax_a; const unsigned long long* use_b = amax_b;
+    if (!amax_a) {
+        const M3TRegion ra{A, (unsigned long long)M, (unsigned long long)lda, K / 4, nullptr};
+        const M3TRegion rb{A, 0ull, 0ull, 0, nullptr};
+        const int rm = m3t_f16x3_measure(ra, nullptr, rb, amax_b, &use_a, &use_b, s);
+        if (rm) return rm;
+    }
+    const GemmPlan g = plan_gemm(0, M, N, K, 0, true, ws ? ws_bytes : 0, M3T_GEMM_F16X3);
+    const int splits = g.wide ? g.splits : 1, kchunk = g.wide ? g.kchunk : K;
+    const int rc = m3t_sgemm_x6w_bimg_launch(M, N, K, A, lda, B_img, C, ldc, bias, act, accumulate, ws, splits, kchunk, use_a, use_b, s);
+    if (rc) return rc;
+    if (splits > 1) { launch_splitk_reduce(ws, C, bias, M, N, ldc, splits, act, accumulate, s); M3T_LAUNCH_CHECK(); }
+    return 0;
+}
+
 // include/m3t_hip.h
 extern "C" int m3t_f16x3_split(const float* x, size_t rows, int cols, size_t ld, float* out, size_t ldo, const unsigned long long* slot,
                                void* stream) {

@@ -103,7 +103,11 @@ __device__ __forceinline__ void mc_store_w(unsigned char* __restrict__ S, const 
     }
 }
 
-template <int TA, int TB, bool SEG, int NS>
+// BD (TA = 0, TB = 1, NS = 4): the B operand is a STAGED IMAGE of the weights (m3t_f16x3_image_b: [N / 64][K / 8][term][64 rows][16 B] -- one
+// 1-KiB piece per (64-row block, k-octet, term)) and reaches LDS by LDS-DMA (global_load_lds_dwordx4: one piece per wave instruction, no
+// registers, no conversion, no ds_write): wave w fetches row block w of the 256-row tile, four pieces per 16-k stage.  Why (NOTEBOOK R5.4b):
+// of the 134 us of a 128-tile launch 28 are the register -> LDS store path of the split operands; the 256-row B tile is two thirds of them.
+template <int TA, int TB, bool SEG, int NS, int BD = 0>
 __global__ __launch_bounds__(WTH, 2) void sgemm_x6w_kernel(X6WParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];     // stage 0 | stage 1, each A | B
     constexpr int NP = planes_of(NS);
@@ -148,7 +152,13 @@ __global__ __launch_bounds__(WTH, 2) void sgemm_x6w_kernel(X6WParams p) {
         for (int e = 0; e < 2; ++e) pa[e] = p.A + (size_t)(k_begin + mck + e) * p.lda + bm + mcr;
         a_step = (size_t)WKS * p.lda;
     }
-    if (TB == 1) {
+    // BD: this wave's piece stream -- pieces ((bn / 64 + w) (K / 8) + k / 8 + o) * 2 + s, 1 KiB each, lane l takes bytes 16 l ..
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned char* bd_src = nullptr;
+    if (BD) {
+        bd_src = reinterpret_cast<const unsigned char*>(p.B) + ((size_t)(bn / 64 + wv) * (p.K / 8) + k_begin / 8) * 2048 + lane * 16;
+        b_step = 0;
+    } else if (TB == 1) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) pb[i] = p.B + (size_t)(bn + (tid >> 2) + 64 * i) * p.ldb + k_begin + (tid & 3) * 4;
         b_step = WKS;
@@ -191,17 +201,34 @@ __global__ __launch_bounds__(WTH, 2) void sgemm_x6w_kernel(X6WParams p) {
                 ra[e] = *reinterpret_cast<const f32x4*>(pa[e]);
                 pa[e] += adv ? a_step : 0;
             }
+            if (!BD) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                rb[e] = *reinterpret_cast<const f32x4*>(pb[e]);
-                pb[e] += adv ? b_step : 0;
+                for (int e = 0; e < 4; ++e) {
+                    rb[e] = *reinterpret_cast<const f32x4*>(pb[e]);
+                    pb[e] += adv ? b_step : 0;
+                }
             }
         }
         ++loaded;
     };
+    // BD: the four pieces of the next stage of this wave's row block into `st` (planes term * 2 + octet, rows 64 w ..+63)
+    int bd_left = nst;
+    auto bdma = [&](unsigned char* st) {
+        if (bd_left > 0) {
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2)
+                    __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(bd_src + (o * 2 + t2) * 1024),
+                                                     (__attribute__((address_space(3))) void*)(st + OPA + (t2 * 2 + o) * PLB + wv * 1024), 16, 0, 0);
+            bd_src += 4096;
+            --bd_left;
+        }
+    };
     auto sstore = [&](unsigned char* st, const f32x4 (&ra)[2], const f32x4 (&rb)[4]) {
         if (TA == 0) kc_store_w<NS, 2, PLA>(st, ra, sc_a); else mc_store_w<NS, PLA>(st, ra[0], ra[1], sc_a, 0);
-        if (TB == 1) kc_store_w<NS, 4, PLB>(st + OPA, rb, sc_b);
+        if (BD) {}
+        else if (TB == 1) kc_store_w<NS, 4, PLB>(st + OPA, rb, sc_b);
         else { mc_store_w<NS, PLB>(st + OPA, rb[0], rb[1], sc_b, 0); mc_store_w<NS, PLB>(st + OPA, rb[2], rb[3], sc_b, 1); }
     };
 
@@ -240,6 +267,36 @@ __global__ __launch_bounds__(WTH, 2) void sgemm_x6w_kernel(X6WParams p) {
 
     unsigned char* buf0 = ldsb;
     unsigned char* buf1 = ldsb + STG;
+    if (BD) {
+        // order of the vector-memory queue per stage: the DMA pieces of stage t+1 FIRST, then A's two loads of stage t+2 -- the wait in front of the
+        // barrier is vmcnt(2): the pieces have landed in LDS, A's prefetch stays in flight across the barrier
+        if (nst > 0) {
+            bdma(buf0);
+            gload(ra0, rb0);
+            sstore(buf0, ra0, rb0);
+            __builtin_amdgcn_sched_barrier(0);
+            bdma(buf1);
+            __builtin_amdgcn_sched_barrier(0);
+            gload(ra1, rb1);
+        }
+        asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        for (int t = 0; t < nst; t += 2) {
+            // stage t multiplies buf0; A(t+1) is in ra1, B(t+1) already in buf1 (pieces issued one stage ahead)
+            __builtin_amdgcn_sched_barrier(0);
+            gload(ra0, rb0);                                  // A of stage t+2
+            stage(buf0, buf1, ra1, rb1);                      // multiply stage t, split + store A of stage t+1
+            asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // pieces of t+1 landed; everyone is done reading buf0
+            __builtin_amdgcn_sched_barrier(0);
+            bdma(buf0);                                       // B of stage t+2 (needs buf0 free: after the barrier)
+            __builtin_amdgcn_sched_barrier(0);
+            gload(ra1, rb1);                                  // A of stage t+3
+            stage(buf1, buf0, ra0, rb0);                      // multiply stage t+1, split + store A of stage t+2
+            asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // pieces of t+2 landed; buf1 free
+            __builtin_amdgcn_sched_barrier(0);
+            bdma(buf1);                                       // B of stage t+3
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
     if (nst > 0) {
         gload(ra0, rb0);
         sstore(buf0, ra0, rb0);
@@ -253,6 +310,7 @@ __global__ __launch_bounds__(WTH, 2) void sgemm_x6w_kernel(X6WParams p) {
         gload(ra1, rb1);                                      // stage t+3
         stage(buf1, buf0, ra0, rb0);                          // multiply stage t+1, split + store stage t+2
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
     }
 
     const bool direct = p.splits == 1;
@@ -321,5 +379,29 @@ int m3t_sgemm_x6w_launch(int transA, int transB, int M, int N, int K, const floa
     else M3T_X6W_DISPATCH(3);
 #undef M3T_X6W_DISPATCH
 #undef M3T_X6W_GO
+    return (int)hipGetLastError();
+}
+
+// NT product with the B operand as a staged image (BD kernels; m3t_sgemm_bimg): fp16x3, M % 128 == 0, N % 256 == 0, K % 32 == 0, one K pass
+// or split-K slabs as above; B_img from m3t_f16x3_image_b under amax_b.
+int m3t_sgemm_x6w_bimg_launch(int M, int N, int K, const float* A, int lda, const float* B_img, float* C, int ldc, const float* bias, int act,
+                              int accumulate, float* ws, int splits, int kchunk, const unsigned long long* amax_a,
+                              const unsigned long long* amax_b, hipStream_t s) {
+    if (!amax_a || !amax_b) return M3T_EINVAL;
+    X6WParams p;
+    p.amax_a = amax_a; p.amax_b = amax_b;
+    p.A = A; p.B = B_img; p.C = C; p.bias = bias; p.ws = ws;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = 0; p.ldc = ldc;
+    p.act = act; p.accumulate = accumulate; p.splits = splits; p.kchunk = kchunk;
+    p.seg_len = p.seg_stride = p.a_off = p.b_off = 0;
+    dim3 grid(N / WN, M / WM, splits), block(WTH);
+    const size_t lds = 2 * (size_t)stageb(4);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t ea = hipFuncSetAttribute((const void*)sgemm_x6w_kernel<0, 1, false, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (ea != hipSuccess) return (int)ea;
+        attr_set = true;
+    }
+    sgemm_x6w_kernel<0, 1, false, 4, 1><<<grid, block, lds, s>>>(p);
     return (int)hipGetLastError();
 }

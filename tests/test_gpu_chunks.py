@@ -197,3 +197,37 @@ def test_weight_magnitude_table_lives_for_one_step():
     finally:
         ops._W_AMAX_ON = getattr(ops, "_W_AMAX_ON_SAVED", True)
         ddp.close()
+
+
+@pytest.mark.parametrize("M,N,K", [(9600, 1536, 1024), (1280, 512, 2048), (128, 256, 32)])
+def test_weight_image_by_lds_dma_is_bit_identical(M, N, K):
+    """m3t_sgemm_bimg: the NT product of the input projections (reference models/rnn.py:17: nn.GRU's x W_ih^T) with the weight operand as a
+    staged image (m3t_f16x3_image_b) that the 128 x 256 tile kernel fetches by LDS-DMA -- no registers, no conversion, no ds_write for the B
+    tile.  Same arithmetic as m3t_sgemm_scaled -- bit-identical where the planner picks the same tile and K passes for both --, bias / accumulate included (NOTEBOOK R5.4b: +0-5 % alone,
+    not wired into the step)"""
+    from m3t import ops, _lib
+    rs = np.random.RandomState(M + N + K)
+    A, W, bias = _rand(rs, M, K), _rand(rs, N, K, scale=0.05), _rand(rs, N)
+    sl = ops.amax_slots(2, A.device)
+    ops.measure_amax([(A, sl.data_ptr()), (W, sl.data_ptr() + 8)])
+    img = torch.empty_like(W)
+    lib = ops.lib()
+    _lib.check(lib.m3t_f16x3_image_b(ops._p(W), N, K, K, ops._p(img), sl.data_ptr() + 8, ops._stream()), "m3t_f16x3_image_b")
+    ws = ops.workspace(A.device)
+    for accumulate in (False, True):
+        C0 = torch.full((M, N), 0.5, device=DEV)
+        C1 = torch.full((M, N), 0.5, device=DEV)
+        with ops.precision("fp32"):
+            ops.sgemm(0, 1, M, N, K, A, 0, K, W, 0, K, C0, 0, N, bias=bias, accumulate=accumulate, amax=(sl.data_ptr(), sl.data_ptr() + 8))
+        _lib.check(lib.m3t_sgemm_bimg(M, N, K, ops._p(A), K, ops._p(img), ops._p(C1), N, ops._p(bias), 0, int(accumulate), ops._p(ws),
+                                      ws.numel() * 4, sl.data_ptr(), sl.data_ptr() + 8, ops._stream()), "m3t_sgemm_bimg")
+        torch.cuda.synchronize()
+        if (M, N, K) == (9600, 1536, 1024):          # the planner gives m3t_sgemm_scaled the same tile and one K pass: the same sums in the same order
+            assert torch.equal(C0, C1), float((C0 - C1).abs().max())
+        else:                                        # (another tile / another number of split-K slabs there: fp32 rounding apart)
+            assert float((C0 - C1).abs().max()) <= 2e-6 * float(C0.abs().max())
+    ref = A.double() @ W.double().t() + bias.double() + 0.5
+    assert float((C1.double() - ref).abs().max() / ref.abs().max()) < 2e-6
+    with pytest.raises(_lib.M3THipError):
+        _lib.check(lib.m3t_sgemm_bimg(M, N + 64, K, ops._p(A), K, ops._p(img), ops._p(C1), N, None, 0, 0, None, 0, sl.data_ptr(),
+                                      sl.data_ptr() + 8, ops._stream()), "m3t_sgemm_bimg")       # N % 256 != 0
