@@ -670,6 +670,9 @@ def main():
         case_vggm("vggm_gru_eval", 930, "gru", B=2, T=3)
     if want("c5t16"):
         case_affwild_av("c5_affwild_av_t16", 940, B=2, T=16)
+    if want("c5t64"):
+        # BASELINE's window of the end-to-end config (64 frames per clip): scans, stitching-free heads and the stems at the length bench.py times
+        case_affwild_av("c5_affwild_av_t64", 950, B=2, T=64)
 
 
 if __name__ == "__main__":

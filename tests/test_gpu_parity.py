@@ -1288,7 +1288,7 @@ def test_vggm_end_to_end_golden(name, backend):
 
 
 def test_c5_affwild_av_t16_golden():
-    """the full A+V model on 16-frame clips (longer scans than the T=4 golden; BASELINE's 64-frame size is covered by the
+    """the full A+V model on 16-frame clips (longer scans than the T=4 golden; BASELINE's 64-frame size: the t64 golden and the
     property test below)"""
     from models.model import AffWild2VA
     g = load_golden("c5_affwild_av_t16")
@@ -1299,6 +1299,25 @@ def test_c5_affwild_av_t16_golden():
     batch = _affwild_batch(np.random.RandomState(seed), B, T, video=True)
     close(m(batch), g["y"], TOL, "y")                    # north_star bar; measured 1e-7 end to end (round 3: the MIOpen stem's output
     out = m.training_step(batch, 0)                      # is within 9e-6 of the reference's, test_c5_temporal_part_on_the_references_stem_features)
+    close(out["loss"], g["loss"], TOL, "loss")
+    out["loss"].backward()
+    check_digests([(n, p.grad) for n, p in m.named_parameters() if p.grad is not None], g, tol=C5_DIGEST_TOL)
+
+
+def test_c5_affwild_av_t64_golden():
+    """the full A+V model at BASELINE's window of the end-to-end config (64 frames per clip, the length bench.py's C5 leg times; VERDICT r4:
+    "C5 at T=64 is property-only"): outputs, loss and every parameter's gradient digest against the reference run on the same seeded batch
+    (tests/golden/gen_golden.py c5t64)"""
+    from models.model import AffWild2VA
+    g = load_golden("c5_affwild_av_t64")
+    seed = int(g["seed"])
+    B, T = [int(v) for v in g["dims"]]
+    assert T == 64
+    m = fill_module(AffWild2VA(_hp(modality="audiovisual", fusion_type="attention", loss="ccc_mtl", window=T)),
+                    seed + 1).to(DEV).eval()
+    batch = _affwild_batch(np.random.RandomState(seed), B, T, video=True)
+    close(m(batch), g["y"], TOL, "y")
+    out = m.training_step(batch, 0)
     close(out["loss"], g["loss"], TOL, "loss")
     out["loss"].backward()
     check_digests([(n, p.grad) for n, p in m.named_parameters() if p.grad is not None], g, tol=C5_DIGEST_TOL)
