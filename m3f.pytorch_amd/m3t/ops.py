@@ -189,9 +189,11 @@ def _req(t, name="tensor"):
 
 
 def _p(t, off=0):
+    """device address of element `off` of a float tensor as a plain int (every pointer parameter of the C ABI is declared c_void_p in
+    m3t._lib: ctypes converts ints itself; building a c_void_p object per argument was ~350 objects per C3 step)"""
     if t is None:
         return None
-    return C.c_void_p(t.data_ptr() + 4 * off)
+    return t.data_ptr() + 4 * off
 
 
 # ---- streams of the step's schedule --------------------------------------------------------------------------------
