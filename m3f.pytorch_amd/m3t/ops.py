@@ -113,7 +113,7 @@ def lib():
 _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)       # the current stream's handle without building a Stream object
 
 
-_HOST_SLOW = os.environ.get("M3T_HOST_FAST", "1") == "00"
+_HOST_SLOW = os.environ.get("M3T_HOST_FAST", "1") == "0"      # A/B (tools/host_profile.py): torch's own device / stream helpers and stream context
 _CUR_DEV = (getattr(torch._C, "_cuda_getDevice", None) if not _HOST_SLOW else None) or torch.cuda.current_device      # (torch.cuda.current_device() walks _lazy_init: ~3 us a call)
 
 
@@ -158,7 +158,7 @@ class on_stream:
         return False
 
 
-if os.environ.get("M3T_HOST_FAST", "1") == "0":      # A/B: torch's own stream context (tools/host_profile.py)
+if _HOST_SLOW:
     on_stream = torch.cuda.stream
 
 
