@@ -1144,6 +1144,48 @@ def test_conv3d_without_a_patch_matrix(Ci, Co, k, stride, pad, N, T, H, W):
         close(a, b_.cpu().numpy(), 2e-4, what + " vs the patch-matrix path")
 
 
+def test_conv_walk_entry_points_planes_output_and_refusals():
+    """the walks' C entry points called directly (include/m3t_hip.h): the planes output (written by the epilogue in one K pass, by reduction +
+    transpose under split-K) equals the channels-last output transposed -- bit for bit --, and shapes no tile fits are refused with
+    M3T_EINVAL instead of being mis-tiled (the host layer then takes the patch-matrix GEMMs or torch)"""
+    from m3t import ops, _lib
+    lib = ops.lib()
+    rs = np.random.RandomState(3)
+    for (N, Ci, Co, T, H, W, k, pd) in ((8, 64, 64, 1, 8, 8, (1, 3, 3), (0, 1, 1)),          # one K pass: the epilogue writes planes
+                                        (4, 128, 256, 8, 4, 4, (3, 3, 3), (1, 1, 1))):       # deep layer: split-K slabs, reduction, transpose
+        x = dev(draw(rs, (N * T * H * W, Ci)))
+        w = dev(draw(rs, (Co, k[0] * k[1] * k[2] * Ci)) * 0.1)
+        b = dev(draw(rs, (Co,)))
+        sl = ops.amax_slots(2, x.device)
+        ops.measure_amax([(x, sl.data_ptr()), (w, sl.data_ptr() + 8)])
+        xi, wi = torch.empty_like(x), torch.empty_like(w)
+        st = ops._stream()
+        _lib.check(lib.m3t_f16x3_split(ops._p(x), x.shape[0], Ci, Ci, ops._p(xi), Ci, sl.data_ptr(), st), "split")
+        _lib.check(lib.m3t_f16x3_split(ops._p(w), Co, w.shape[1], w.shape[1], ops._p(wi), w.shape[1], sl.data_ptr() + 8, st), "split")
+        ws = ops.workspace(x.device)
+        rows = N * T * H * W                                  # (stride 1, "same" padding: the output grid is the input grid)
+        y_cl, y_cl2 = torch.empty(rows, Co, device=DEV), torch.empty(rows, Co, device=DEV)
+        y_pl = torch.empty(N, Co, T * H * W, device=DEV)
+        geo = (N, Ci, Co, T, H, W, k[0], k[1], k[2], 1, 1, 1, pd[0], pd[1], pd[2], sl.data_ptr(), sl.data_ptr() + 8, ops._p(ws), ws.numel() * 4)
+        _lib.check(lib.m3t_conv3d_fwd_taps(ops._p(xi), ops._p(wi), ops._p(b), ops._p(y_cl), *geo, None, st), "fwd_taps")
+        _lib.check(lib.m3t_conv3d_fwd_taps(ops._p(xi), ops._p(wi), ops._p(b), ops._p(y_cl2), *geo, ops._p(y_pl), st), "fwd_taps")
+        torch.cuda.synchronize()
+        assert torch.equal(y_pl, y_cl.view(N, T * H * W, Co).transpose(1, 2).contiguous())
+        ref = torch.conv3d(x.view(N, T, H, W, Ci).permute(0, 4, 1, 2, 3).double().cpu(),
+                           w.view(Co, k[0], k[1], k[2], Ci).permute(0, 4, 1, 2, 3).double().cpu(), b.double().cpu(), 1, pd)
+        close(y_pl.view(N, Co, T, H, W), ref.numpy(), 1e-4, "y planes")
+    # refusals
+    bad = (N, Ci, 96, T, H, W, 3, 3, 3, 1, 1, 1, 1, 1, 1, sl.data_ptr(), sl.data_ptr() + 8, None, 0)       # C_out % 64 != 0
+    assert lib.m3t_conv3d_fwd_taps(ops._p(xi), ops._p(wi), None, ops._p(y_cl), *bad, None, st) == _lib.M3T_EINVAL
+    bad = (3, Ci, Co, 1, 5, 5, 1, 3, 3, 1, 1, 1, 0, 1, 1, sl.data_ptr(), sl.data_ptr() + 8, None, 0)       # 75 output rows: no 128-row tiles
+    assert lib.m3t_conv3d_fwd_taps(ops._p(xi), ops._p(wi), None, ops._p(y_cl), *bad, None, st) == _lib.M3T_EINVAL
+    assert lib.m3t_conv3d_wgrad_taps(ops._p(x), ops._p(y_cl), ops._p(y_cl2), 3, Ci, Co, 1, 5, 5, 1, 3, 3, 1, 1, 1, 0, 1, 1, _lib.M3T_GEMM_F16X3,
+                                     None, None, None, 0, st) == _lib.M3T_EINVAL                         # 75 reduction rows: not whole 32-row tiles
+    assert lib.m3t_conv3d_fwd_taps4(ops._p(xi), ops._p(wi), None, ops._p(y_cl), 2, 64, 4, 16, 16, 1, 3, 9, 1, 1, 1, 0, 1, 4, sl.data_ptr(),
+                                    sl.data_ptr() + 8, None, 0, None, st) == _lib.M3T_EINVAL              # nine taps in a row: the image holds eight
+    assert lib.m3t_planes_to_cl4(ops._p(x), ops._p(y_cl), 2, 5, 64, st) == _lib.M3T_EINVAL                # more than four channels
+
+
 @pytest.mark.parametrize("N,C_,T,H,W,training", [(3, 16, 5, 7, 9, True), (2, 64, 4, 12, 12, True), (2, 8, 3, 5, 5, False), (4, 24, 1, 1, 1, True)])
 def test_batchnorm3d_relu_on_channel_planes(N, C_, T, H, W, training):
     """models.backbone.BatchNorm3dReLU (nn.BatchNorm3d + nn.ReLU of the 3-D stems, reference models/backbone.py:73-103,179-191) on
