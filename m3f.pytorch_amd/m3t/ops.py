@@ -2139,6 +2139,8 @@ class _CBAM(torch.autograd.Function):
                                 N, Cc, Cr, H, W, int(training), float(momentum), float(eps), _p(ws), ws.numel() * 4, _stream())
         _lib.check(rc, "m3t_cbam_fwd")
         ctx.save_for_backward(x, w1, w2, conv_w, bn_w, buf)
+        # gradient sinks: the seven parameter gradients straight into the flat gradient buffer (order of backward's `sz`)
+        ctx.sink_refs = tuple(t if (t is not None and id(t) in _GRAD_SINKS) else None for t in (w1, w2, b1, b2, conv_w, bn_w, bn_b))
         ctx.offs = offs
         ctx.training = bool(training)
         return y
@@ -2161,13 +2163,18 @@ class _CBAM(torch.autograd.Function):
         ws = workspace(dev, _cbam_ws_bytes(N, Cc, Cr, H, W))
         base, gbase = buf.data_ptr(), gbuf.data_ptr()
         ptr = lambda i: C.c_void_p(base + 4 * offs[i])
-        gp = lambda i: C.c_void_p(gbase + 4 * go[i])
+        # input index of (w1, w2, b1, b2, conv_w, bn_w, bn_b) in forward's argument list: 1, 3, 2, 4, 5, 6, 7
+        need = (1, 3, 2, 4, 5, 6, 7)
+        sinks = [(_take_sink(r) if (r is not None and ctx.needs_input_grad[need[i]]) else None) for i, r in enumerate(ctx.sink_refs)]
+        gp = lambda i: C.c_void_p(sinks[i].data_ptr() if sinks[i] is not None else gbase + 4 * go[i])
         rc = lib().m3t_cbam_bwd(_p(dy), _p(x), _p(w1), _p(w2), _p(conv_w), _p(bn_w), ptr(0), ptr(7), ptr(1), ptr(2), ptr(3), ptr(8),
                                 ptr(4), ptr(5), ptr(6), _p(dx), gp(0), gp(2), gp(1), gp(3), gp(4), gp(5), gp(6),
                                 N, Cc, Cr, H, W, int(ctx.training), _p(ws), ws.numel() * 4, _stream())
         _lib.check(rc, "m3t_cbam_bwd")
         g = gbuf.split_with_sizes(sz)
-        return (dx, g[0].view(w1.shape), g[2], g[1].view(w2.shape), g[3], g[4].view(conv_w.shape), g[5], g[6], None, None, None, None, None)
+        k = lambda i, t: None if sinks[i] is not None else t
+        return (dx, k(0, g[0].view(w1.shape)), k(2, g[2]), k(1, g[1].view(w2.shape)), k(3, g[3]), k(4, g[4].view(conv_w.shape)), k(5, g[5]),
+                k(6, g[6]), None, None, None, None, None)
 
 
 _CBAM_LAYOUTS, _CBAM_WS = {}, {}
@@ -2245,6 +2252,9 @@ class _BNPlanes(torch.autograd.Function):
         _lib.check(rc, "m3t_bn_planes_fwd")
         ctx.save_for_backward(x, y if relu else None, gamma, stats)
         ctx.training, ctx.relu = bool(training), bool(relu)
+        # gradient sinks (top of this file): dgamma / dbeta are written by the backward kernel straight into the flat gradient buffer
+        ctx.sink_refs = (gamma if (gamma is not None and id(gamma) in _GRAD_SINKS) else None,
+                         beta if (beta is not None and id(beta) in _GRAD_SINKS) else None)
         return y
 
     @staticmethod
@@ -2256,10 +2266,14 @@ class _BNPlanes(torch.autograd.Function):
         dx = torch.empty_like(x)
         g = torch.empty(2, Cc, dtype=torch.float32, device=x.device)
         ws = workspace(x.device, int(lib().m3t_bn_planes_ws_bytes(N, Cc, S)))
+        gs = _take_sink(ctx.sink_refs[0]) if (ctx.needs_input_grad[1] and ctx.sink_refs[0] is not None) else None
+        bs = _take_sink(ctx.sink_refs[1]) if (ctx.needs_input_grad[2] and ctx.sink_refs[1] is not None) else None
         rc = lib().m3t_bn_planes_bwd(_p(dy), _p(x), _p(y), _p(gamma), _p(stats[0]), _p(stats[1]), N, Cc, S, int(ctx.training), int(ctx.relu),
-                                     _p(dx), _p(g[0]), _p(g[1]), _p(ws), ws.numel() * 4, _stream())
+                                     _p(dx), _p(gs if gs is not None else g[0]), _p(bs if bs is not None else g[1]), _p(ws), ws.numel() * 4,
+                                     _stream())
         _lib.check(rc, "m3t_bn_planes_bwd")
-        return dx, (g[0] if gamma is not None else None), (g[1] if gamma is not None else None), None, None, None, None, None, None
+        return (dx, (g[0] if (gamma is not None and gs is None) else None), (g[1] if (gamma is not None and bs is None) else None),
+                None, None, None, None, None, None)
 
 
 # M3T_BN_PLANES=0: BatchNorm3d / BatchNorm2d (+ReLU) of the stems and the per-frame ResNet on the stock (MIOpen) ops instead of csrc/bn.hip's
@@ -2343,6 +2357,7 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, stride, padding):
         ctx.stride, ctx.padding, ctx.has_bias = stride, padding, b is not None
+        ctx.sink_refs = (w if id(w) in _GRAD_SINKS else None, b if (b is not None and id(b) in _GRAD_SINKS) else None)      # gradient sinks
         plan = _conv3d_plan(x, w, stride, padding) if (CONV3D_GEMM[0] and x.is_cuda and (_PREC[0] & _lib.M3T_GEMM_F16X3 or _PREC[0] == 0)) else None
         ctx.prec = _PREC[0]
         ctx.impl = 0                     # channel width of the channels-last input kept by a tap-walk forward (0: none)
@@ -2437,6 +2452,9 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
         dx = dw = db = None
         Co, Ci, kt, kh, kw = w.shape
         N_, _, T_, H_, W_ = x.shape
+        # weight / bias gradients straight into the flat gradient buffer where FlatGradDDP registered sinks (no AccumulateGrad add kernel)
+        w_sink = _take_sink(ctx.sink_refs[0]) if (ctx.needs_input_grad[1] and ctx.sink_refs[0] is not None) else None
+        b_sink = _take_sink(ctx.sink_refs[1]) if (ctx.has_bias and ctx.needs_input_grad[2] and ctx.sink_refs[1] is not None) else None
         # round 5: the data gradient of a stride-1 layer as a tap-walk contraction over dy channels-last (m3t_conv3d_taps: an implicit GEMM, no
         # patch matrix, no col2im) -- MIOpen's data gradient (Col2Im3dU + Tensile GEMMs) was ~5 ms of a C5 step
         taps_dx = (ctx.needs_input_grad[0] and CONV3D_TAPS[0] and ctx.pat is not None and tuple(st) == (1, 1, 1) and Co % 32 == 0 and Ci % 64 == 0
@@ -2498,7 +2516,11 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
             _lib.check(lib().m3t_conv3d_wgrad_taps(_p(saved[2]), _p(dy_cl), _p(dwt), N_, impl, Co, T_, H_, W_, kt, kh, kw, st[0], st[1], st[2],
                                                    pd[0], pd[1], pd[2], ctx.prec, saved[3].data_ptr(), slot_dy.data_ptr(), _p(wsw),
                                                    wsw.numel() * 4, _stream()), "m3t_conv3d_wgrad_taps")
-            dw = dwt[:Kc].view(taps, impl, Co)[:, :Ci].permute(2, 1, 0).contiguous().view_as(w)
+            dw_v = dwt[:Kc].view(taps, impl, Co)[:, :Ci].permute(2, 1, 0)              # [co][ci][tap], strided
+            if w_sink is not None:
+                w_sink.view(Co, Ci, taps).copy_(dw_v)
+            else:
+                dw = dw_v.contiguous().view_as(w)
         elif ctx.needs_input_grad[1]:
             Kc = Ci * kt * kh * kw
             xc = _req(x.contiguous(), "x")
@@ -2518,8 +2540,10 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
 
             if Co % 128 == 0 and Kc % 64 == 0:
                 pat = im2col(rows, Kc)
-                dw = torch.empty_like(w)
+                dw = w_sink if w_sink is not None else torch.empty_like(w)
                 sgemm(1, 0, Co, Kc, rows, dy_cl, 0, Co, pat, 0, Kc, dw, 0, Kc, prec=ctx.prec, amax=(slot_dy.data_ptr(), slot.data_ptr()))
+                if w_sink is not None:
+                    dw = None
             elif Co % 64 == 0:
                 # the stems' FIRST layers: C_out = 64 and C_in k^3 = 81 (VGG-M) / 735 (3-D ResNet) fit no interior tile of the
                 # 16-bit-term GEMM as dW = dy^T P.  Transposed and padded they do: dW^T [Kp, Co] = P_pad^T dy with Kp = ceil128(C_in k^3)
@@ -2532,16 +2556,24 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
                     dyp[:rows].copy_(dy_cl.view(rows, Co))
                 dwt = torch.empty(Kp, Co, dtype=torch.float32, device=x.device)
                 sgemm(1, 0, Kp, Co, rows_p, pat_pad, 0, Kp, dyp, 0, Co, dwt, 0, Co, prec=ctx.prec, amax=(slot.data_ptr(), slot_dy.data_ptr()))
-                dw = dwt[:Kc].t().contiguous().view_as(w)
+                if w_sink is not None:
+                    w_sink.view(Co, Kc).copy_(dwt[:Kc].t())
+                else:
+                    dw = dwt[:Kc].t().contiguous().view_as(w)
             else:
                 Kp = (Kc + 3) // 4 * 4
                 pat = im2col(rows, Kp)
                 dwp = torch.empty(Co, Kp, dtype=torch.float32, device=x.device)
                 sgemm(1, 0, Co, Kp, rows, dy_cl, 0, Co, pat, 0, Kp, dwp, 0, Kp, prec=ctx.prec, amax=(slot_dy.data_ptr(), slot.data_ptr()))
-                dw = dwp[:, :Kc].contiguous().view_as(w)
+                if w_sink is not None:
+                    w_sink.view(Co, Kc).copy_(dwp[:, :Kc])
+                else:
+                    dw = dwp[:, :Kc].contiguous().view_as(w)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = torch.empty(Co, dtype=torch.float32, device=dy.device)
+            db = b_sink if b_sink is not None else torch.empty(Co, dtype=torch.float32, device=dy.device)
             colsum(dpart, 0, dpart.shape[0], Co, Co, db)
+            if b_sink is not None:
+                db = None
         return dx, dw, db, None, None
 
 

@@ -1144,6 +1144,44 @@ def test_conv3d_without_a_patch_matrix(Ci, Co, k, stride, pad, N, T, H, W):
         close(a, b_.cpu().numpy(), 2e-4, what + " vs the patch-matrix path")
 
 
+def test_gradient_sinks_of_the_visual_stack_change_nothing(monkeypatch):
+    """Under m3t.ddp.FlatGradDDP the convolutions' weight / bias gradients, BatchNorm's dgamma / dbeta and CBAM's seven parameter gradients
+    are written by their backward kernels straight into the flat gradient buffer (gradient sinks: no AccumulateGrad add per parameter --
+    ~100 small launches per ResNet3D step).  The flat buffer must equal the one autograd accumulates (M3T_GRAD_SINKS=0): bit for bit on
+    the VGG-M stem (Conv3d with bias, BatchNorm3d), to the rerun noise of MIOpen's strided data gradient on the 3-D ResNet with CBAM"""
+    from m3t import ops
+    from m3t.ddp import FlatGradDDP
+    from models.backbone import VA_3DResNet, VA_3DVGGM
+    rs = np.random.RandomState(21)
+    for make, shape, exact in ((lambda: VA_3DResNet(frameLen=4, resnet_ver="v1", use_cbam=True, nClasses=2, nFCs=2), (2, 3, 4, 112, 112), False),
+                               (lambda: VA_3DVGGM(frameLen=4, nClasses=2, backend="gru"), (2, 3, 4, 112, 112), True)):
+        xn = draw(rs, shape)
+        flats, calls = [], []
+        for sinks in ("1", "0"):
+            monkeypatch.setenv("M3T_GRAD_SINKS", sinks)
+            m = fill_module(make(), 5).to(DEV).train()
+            ddp = FlatGradDDP(m, max_norm=0.0)
+            try:
+                taken = [0]
+                real = ops._take_sink
+                monkeypatch.setattr(ops, "_take_sink", lambda p_, real=real, taken=taken: (lambda v: (taken.__setitem__(0, taken[0] + (v is not None)), v)[1])(real(p_)))
+                ddp.zero_grad()
+                y = m(dev(xn))
+                y.square().mean().backward()
+                ddp.finish()
+                torch.cuda.synchronize()
+                flats.append(ddp.flat.clone())
+                calls.append(taken[0])
+            finally:
+                monkeypatch.setattr(ops, "_take_sink", real)
+                ddp.close()
+        assert calls[0] >= 20 and calls[1] == 0, calls          # the sinks were really used / really off
+        if exact:
+            assert torch.equal(flats[0], flats[1]), float((flats[0] - flats[1]).abs().max())
+        else:               # (MIOpen's data gradient of the strided ResNet layers accumulates with atomics: reruns differ in the last bits upstream of them)
+            assert float((flats[0] - flats[1]).abs().max()) <= 2e-5 * float(flats[1].abs().max())
+
+
 def test_conv_walk_entry_points_planes_output_and_refusals():
     """the walks' C entry points called directly (include/m3t_hip.h): the planes output (written by the epilogue in one K pass, by reduction +
     transpose under split-K) equals the channels-last output transposed -- bit for bit --, and shapes no tile fits are refused with
