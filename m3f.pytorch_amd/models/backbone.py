@@ -21,9 +21,10 @@ from .tcn import TemporalConvNet, WeightNormConv1d
 
 
 class Conv3d(nn.Conv3d):
-    """nn.Conv3d (same parameters / state_dict keys) on m3t.ops.conv3d: forward = patch matrix x W^T on the fp16x3 GEMM (round 5; MIOpen's
-    fp32 forward ran at 26 TFLOP/s), weight gradient = dy^T x the same patch matrix; the data gradient stays on MIOpen.  Falls back to the
-    stock op for configurations it does not cover (and under M3T_CONV3D_MIOPEN=1)."""
+    """nn.Conv3d (same parameters / state_dict keys) on m3t.ops.conv3d (round 5): forward, weight gradient and the stride-1 layers' data
+    gradient as tap-walk implicit GEMMs over channels-last activations on the fp16x3 kernels -- no patch matrix (MIOpen's fp32 forward ran
+    at 26 TFLOP/s); M3T_CONV3D_IMPLICIT=0: the patch-matrix GEMMs.  Falls back to the stock op for configurations it does not cover (and
+    under M3T_CONV3D_MIOPEN=1)."""
 
     def forward(self, x):
         if (x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and self.weight.requires_grad

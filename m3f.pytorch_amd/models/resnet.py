@@ -34,10 +34,11 @@ class PlaneBatchNorm2d(nn.BatchNorm2d):
 
 
 class GemmConv2d(nn.Conv2d):
-    """nn.Conv2d (same parameters / state_dict keys) of the per-frame ResNet on m3t.ops.conv3d with a unit time axis (round 5): forward =
-    patch matrix x W^T on the fp16x3 GEMM, weight gradient = dy^T x the same matrix (the per-frame maps are 512 frames x 28^2 ... 4^2
-    positions: rows in whole 128-row tiles, K = 9 C_in); the data gradient stays on MIOpen.  MIOpen's fp32 kernels ran these at a few
-    tens of TFLOP/s.  Other inputs (CPU, other dtypes, no gradient, untileable shapes, M3T_CONV3D_MIOPEN=1) take the stock op."""
+    """nn.Conv2d (same parameters / state_dict keys) of the per-frame ResNet on m3t.ops.conv3d with a unit time axis (round 5): forward (any
+    stride), weight gradient and the stride-1 layers' data gradient as tap-walk implicit GEMMs over channels-last activations on the fp16x3
+    kernels (the per-frame maps are 512 frames x 28^2 ... 4^2 positions: rows in whole 128-row tiles, K = 9 C_in; no patch matrix); the
+    strided layers' data gradient stays on MIOpen, whose fp32 kernels ran these convolutions at a few tens of TFLOP/s.  Other inputs (CPU,
+    other dtypes, no gradient, untileable shapes, M3T_CONV3D_MIOPEN=1) take the stock op."""
 
     def forward(self, x):
         if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and torch.is_grad_enabled() and self.weight.requires_grad
