@@ -1619,7 +1619,7 @@ def test_conv_and_cbam_kernel_switches(switch):
     import sys
     env = dict(os.environ, M3T_SCAN_LOCK="0", **{switch: "0"})
     pick = {"M3T_CONV_X6": "conv1d_on_the_bf16x6_pipe or tcn_train_mode or tcn_golden",
-            "M3T_CONV3D_IMPLICIT": "c5_resnet3d or c5_affwild_av_t16 or conv3d_weight_gradient or conv3d_forward_on_the_patch or vggm",
+            "M3T_CONV3D_IMPLICIT": "c5_resnet3d or c5_affwild_av_golden or conv3d_weight_gradient or conv3d_forward_on_the_patch",
             "M3T_BN_PLANES": "resnet_cbam or c5_resnet3d or c5_affwild_av_t16"}.get(switch, "cbam_golden or resnet_cbam or cbam_stage")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k", pick], env=env,
                        capture_output=True, text=True, timeout=900)
