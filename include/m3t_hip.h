@@ -120,6 +120,15 @@ int m3t_sgemm_pre(int M, int N, int K, const float* A_img, int lda, const float*
 int m3t_f16x3_image_b(const float* w, int N, int K, size_t ld, float* img, const unsigned long long* slot, void* stream);
 int m3t_sgemm_bimg(int M, int N, int K, const float* A, int lda, const float* B_img, float* C, int ldc, const float* bias, int act,
                    int accumulate, float* ws, size_t ws_bytes, const unsigned long long* amax_a, const unsigned long long* amax_b, void* stream);
+/* Round 6: the fp16x3 product of m3t_sgemm_scaled on the 256 x 256 "ring" kernel (csrc/gemm_ring.hip): both operands reach LDS as raw fp32 by
+ * LDS-DMA (global_load_lds_dwordx4) into a ring of four 16-k stages, counted vmcnt in front of the stage's single barrier, the two-term split on
+ * the fragment read.  Bit-identical to m3t_sgemm_scaled under the same slots (same split, same MFMA operand placement, same product and k
+ * order, same split-K slabs).  NT only for now (transA = 0, transB = 1: nn.Linear, reference models/rnn.py:17,22-55,75); N % 256 == 0,
+ * K % 16 == 0, any M, 16-B aligned operands with ld % 4 == 0; splits >= 1 slabs (ws of splits * M * N floats when > 1); NULL slots are
+ * measured; `variant` selects a build of the main loop (0 = default; tools/ring_bench.py). */
+int m3t_sgemm_ring(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                   const float* bias, int act, int accumulate, float* ws, size_t ws_bytes, int splits,
+                   const unsigned long long* amax_a, const unsigned long long* amax_b, int variant, void* stream);
 int m3t_conv3d_taps_pre(const float* src_img, const float* w_img, float* dst, int N, int C_src, int C_dst, int T, int H, int W,
                         int To, int Ho, int Wo, int kt, int kh, int kw, int base_t, int base_h, int base_w, int sign,
                         const unsigned long long* amax_src, const unsigned long long* amax_w, float* ws, size_t ws_bytes, float* dst_planes,

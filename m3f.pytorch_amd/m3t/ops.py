@@ -369,7 +369,7 @@ def amax_slots(n, device):
 # final (the optimizer has run) -- now measures EVERY weight matrix of the model in one go; forward calls find the slot here.  Entries
 # die at FlatGradDDP.finish() (the optimizer is about to change the weights): a forward outside a step (validation) measures for itself
 # as before.  M3T_WEIGHT_AMAX=0 turns the table off.
-_W_AMAX = {}              # id(parameter) -> (weakref(parameter), slot address, owner id, slots tensor)
+_W_AMAX = {}              # id(parameter) -> (weakref(parameter), slot address, owner id, slots tensor, parameter._version, data_ptr)
 _W_AMAX_ON = os.environ.get("M3T_WEIGHT_AMAX", "1") != "0"
 
 
@@ -385,7 +385,7 @@ def measure_weight_amax(params, owner=None):
     slots = amax_slots(len(ws), ws[0].device)
     if measure_amax([(p.detach().view(p.shape[0], -1), slots.data_ptr() + 8 * i) for i, p in enumerate(ws)]):
         for i, p in enumerate(ws):
-            _W_AMAX[id(p)] = (weakref.ref(p), slots.data_ptr() + 8 * i, id(owner), slots)
+            _W_AMAX[id(p)] = (weakref.ref(p), slots.data_ptr() + 8 * i, id(owner), slots, p._version, p.data_ptr())
 
 
 def drop_weight_amax(owner=None):
@@ -395,13 +395,32 @@ def drop_weight_amax(owner=None):
 
 def weight_amax(w, keep=None):
     """address of this step's magnitude slot of the parameter object `w`, or None (not measured this step: the caller measures); keep: a
-    list that receives the tensor holding the slot (an autograd context keeps it alive for its backward)"""
+    list that receives the tensor holding the slot (an autograd context keeps it alive for its backward).  An entry is only trusted while the
+    parameter is the tensor that was measured: an in-place change since (optimizer.step() after zero_grad(), load_state_dict, an EMA copy, a
+    clamp -- anything that bumps ._version) or a re-pointed .data drops it and the caller measures again."""
     e = _W_AMAX.get(id(w))
     if e is None or e[0]() is not w:
+        return None
+    if e[4] != w._version or e[5] != w.data_ptr():
+        del _W_AMAX[id(w)]
         return None
     if keep is not None and not any(k is e[3] for k in keep):
         keep.append(e[3])
     return e[1]
+
+
+def _is_unit(x):
+    """x carries the |x| <= 1 tag of a GRU output AND has not been written in place since (out.mul_(), a clamp ...: ADVICE r5)"""
+    v = getattr(x, "_m3t_unit", None)
+    return v is not None and v is not False and v == x._version + 1
+
+
+def _tagged_amax(x):
+    """the magnitude slot a producer attached to x (temporal_block), or None when x was modified in place after the measurement"""
+    e = getattr(x, "_m3t_amax", None)
+    if e is None:
+        return None
+    return e[0] if e[1] == x._version else None
 
 
 def measure_amax(items):
@@ -599,7 +618,7 @@ def relu_dropout(y, p, seed=None):
 
 
 def linear(x, w, b=None, act=0):
-    return _Linear.apply(x, w, b, act, bool(getattr(x, "_m3t_unit", False)))
+    return _Linear.apply(x, w, b, act, _is_unit(x))
 
 
 # ----------------------------------------------------------------------------- BiGRU
@@ -1622,11 +1641,11 @@ def multi_bigru(stacks, cat=None):
         flat.append(x)
         flat.extend(prm)
     lo, hi = cat if cat is not None else (0, 0)
-    unit_mask = sum(1 << i for i, (x, _, _) in enumerate(stacks) if getattr(x, "_m3t_unit", False))
+    unit_mask = sum(1 << i for i, (x, _, _) in enumerate(stacks) if _is_unit(x))
     res = _MultiBiGRU.apply(len(stacks), L, lo, hi, unit_mask, *flat)
     for i in range(len(stacks)):
         if res[2 * i].numel():
-            res[2 * i]._m3t_unit = True           # |h| <= 1: a consumer's fp16x3 contraction takes the constant magnitude slot (linear, multi_bigru)
+            res[2 * i]._m3t_unit = res[2 * i]._version + 1          # (the tag is the version it holds for, + 1: see _is_unit)  |h| <= 1: a consumer's fp16x3 contraction takes the constant magnitude slot (linear, multi_bigru)
     return [(res[2 * i], res[2 * i + 1]) for i in range(len(stacks))]
 
 
@@ -1928,13 +1947,13 @@ def temporal_block(x_btc, v1, g1, b1, v2, g2, b2, wd, bd, dilation, m1=None, m2=
     """m1 / m2: explicit pre-scaled dropout masks, or drop_p > 0 with two 64-bit seeds: masks generated inside the conv epilogues
     (Philox4x32-10, include/m3t_hip.h) and regenerated in backward"""
     _LAST_OUT_SLOT[0] = None
-    _X_EXT[0] = getattr(x_btc, "_m3t_amax", None) if x_btc.is_contiguous() else None      # (autograd hands forward() a detached alias: read it here)
+    _X_EXT[0] = _tagged_amax(x_btc) if x_btc.is_contiguous() else None      # (autograd hands forward() a detached alias: read it here)
     try:
         y = _TemporalBlock.apply(x_btc, v1, g1, b1, v2, g2, b2, wd, bd, dilation, m1, m2, float(drop_p), int(seeds[0]), int(seeds[1]))
     finally:
         _X_EXT[0] = None
     if _LAST_OUT_SLOT[0] is not None:                # the conv epilogue raised max |y|: the next block takes it instead of measuring x
-        y._m3t_amax = _LAST_OUT_SLOT[0]              # travels ON the tensor and dies with it (ADVICE r4: no registry holding activations alive)
+        y._m3t_amax = (_LAST_OUT_SLOT[0], y._version)              # (slot, the version it was measured at: _tagged_amax)  travels ON the tensor and dies with it (ADVICE r4: no registry holding activations alive)
         _LAST_OUT_SLOT[0] = None
     return y
 
