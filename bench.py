@@ -99,7 +99,8 @@ def cpu_baseline(max_clips, T, d_a, d_v, budget_s=25.0):
 # algorithmic FLOPs per clip, forward + backward = 3 x forward: C1 TCN head 128 -> 512 -> 512, k=3 + Linear(512, 2)
 # at T=300: 3 x 1.573 GF; C2 TCN(256 -> 512 -> 512) -> GRU(512,512,2,2,2) at T=300: 20.29 GF; C5 full AffWild2VA A+V on 112x112
 # frames at T=64: 135 GF.
-AUX_FLOPS = {"c1": 3 * 1.573e9, "c2": 20.29e9, "c2bf16": 20.29e9, "c5": 135e9, "c3high": 47.43e9, "c3x6": 47.43e9}      # (c3high: the main workload, 47.43 GF per clip)
+AUX_FLOPS = {"c1": 3 * 1.573e9, "c2": 20.29e9, "c2bf16": 20.29e9, "c5": 135e9, "c3high": 47.43e9, "c3x6": 47.43e9, "c3fp32": 47.43e9,
+             "c3_eval": 47.43e9 / 3, "c5_eval": 135e9 / 3}      # (forward only: a third of forward + backward)      # (c3high: the main workload, 47.43 GF per clip)
 
 
 def aux_child(which, steps=6, warmup=2):
@@ -170,6 +171,30 @@ def aux_child(which, steps=6, warmup=2):
         emit("c3x6", "C3/C4 main workload with ops.precision('x6'): every fp32-accurate product from three bf16 terms and six MFMAs (the "
              "default until round 3) instead of two fp16 terms of the scaled operands and three", B, timed(step_x6, 30), "f32 (bf16x6 products)")
         del m6, step6
+    if "c3fp32" in which:
+        # the MAIN workload on EXACT fp32 arithmetic: this child runs with M3T_GEMM_X6=0 and M3T_SCAN_X6=0 (run_aux sets them), i.e. every GEMM
+        # and every recurrent product on v_mfma_f32_*_f32 (fp32 operands, 157 TFLOP/s peak) -- beside the emulated-fp32 headline (two fp16
+        # terms, three MFMAs) and the strict six-product mode (aux.c3x6) on the same box in the same run
+        from m3t.workloads import AVFeatureGraph, make_c3_step
+        torch.manual_seed(12345)
+        m32 = AVFeatureGraph(128, 256, 512).to(dev)
+        _, step32 = make_c3_step(m32, synth_batch(B, T, 128, 256, dev, 0), max_norm=1.0)
+        emit("c3fp32", "C3/C4 main workload with every GEMM and recurrent product on fp32-input MFMAs (M3T_GEMM_X6=0, M3T_SCAN_X6=0): exact fp32 "
+             "operands, no emulation", B, timed(lambda: step32(), 20), "f32 (fp32-input MFMA)")
+        del m32, step32
+    if "c3_eval" in which:
+        # inference: the forward pass of validation_step / test_step (reference models/model.py:226-246,320-337: self.forward(batch) on
+        # windows, eval mode, no autograd graph) on the main workload's batch
+        from m3t.workloads import AVFeatureGraph
+        torch.manual_seed(12345)
+        me = AVFeatureGraph(128, 256, 512).to(dev).eval()
+        be = synth_batch(B, T, 128, 256, dev, 0)
+
+        def fwd_e():
+            with torch.no_grad():
+                me(be["x_a"], be["x_v"])
+        emit("c3_eval", "C3/C4 graph, forward only under torch.no_grad(), eval mode (validation_step / test_step), 32x300", B, timed(fwd_e, 30), "f32")
+        del me
     if "c3high" in which:
         # the MAIN workload in the opt-in "high" matmul precision (two bf16 terms per GEMM / conv operand, four products: what
         # torch.set_float32_matmul_precision('high') means; recurrent scans unchanged) -- NOT the headline: `value` is measured
@@ -248,6 +273,16 @@ def aux_child(which, steps=6, warmup=2):
             ddp.finish()
         emit("c5", "C5 AffWild2VA(audiovisual, attention, v2p_split, ccc_mtl) on raw 112x112 frames (conv stem: forward, weight gradient and data gradient as tap-walk implicit GEMMs over channels-last activations, fp16x3; no patch matrix), training_step+bwd+clip, 8x64", Bc,
              timed(step5), "f32")
+        if "c5_eval" in which:
+            m.eval()
+
+            def fwd5():
+                with torch.no_grad():
+                    m(batch)
+            emit("c5_eval", "C5 AffWild2VA forward only under torch.no_grad(), eval mode (validation_step / test_step windows of 64 frames): the "
+                 "stems' convolutions on the same tap walks as training (one path whatever the grad mode)", Bc, timed(fwd5), "f32")
+            from m3t import ops as _o
+            print(json.dumps({"aux": "stock_fallbacks", "calls_by_site": dict(_o.STOCK_FALLBACKS), "conv_forward_calls_by_path": dict(_o.CONV3D_CALLS)}), flush=True)
 
 
     if "cbam" in which:          # (last: MIOpen's first-use search for the ResNet convolutions may eat what is left of the budget)
@@ -275,16 +310,28 @@ def run_aux(which, budget_s):
     on a fresh box): whatever finished in time is reported"""
     import subprocess
     env = dict(os.environ, M3T_SCAN_LOCK="0")          # this process owns the GPU's persistent-scan lock and is idle meanwhile
-    cmd = [sys.executable, os.path.abspath(__file__), "--aux-child", which]
-    res, note = {}, None
-    try:
-        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=budget_s)
-        out = p.stdout
-        if p.returncode != 0:
-            note = "aux child exited with %d: %s" % (p.returncode, p.stderr[-300:])
-    except subprocess.TimeoutExpired as e:
-        out = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
-        note = "aux leg cut at its %d s budget" % budget_s
+    names = [w for w in which.split(",") if w]
+    res, note, out = {}, None, ""
+    t_start = time.perf_counter()
+    # (the exact-fp32 leg needs the library's environment switches: a child of its own, first -- it is short)
+    legs = ([(["c3fp32"], dict(env, M3T_GEMM_X6="0", M3T_SCAN_X6="0"))] if "c3fp32" in names else []) + \
+           [([w for w in names if w != "c3fp32"], env)]
+    for leg, leg_env in legs:
+        if not leg:
+            continue
+        left = budget_s - (time.perf_counter() - t_start)
+        if left <= 5:
+            note = "aux leg cut at its %d s budget" % budget_s
+            break
+        cmd = [sys.executable, os.path.abspath(__file__), "--aux-child", ",".join(leg)]
+        try:
+            p = subprocess.run(cmd, env=leg_env, capture_output=True, text=True, timeout=left)
+            out += p.stdout
+            if p.returncode != 0:
+                note = "aux child exited with %d: %s" % (p.returncode, p.stderr[-300:])
+        except subprocess.TimeoutExpired as e:
+            out += e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
+            note = "aux leg cut at its %d s budget" % budget_s
     for line in out.splitlines():
         if line.startswith('{"aux"'):
             d = json.loads(line)
@@ -309,7 +356,7 @@ def parse_args():
                     help="weak: --batch clips on EVERY GPU; strong: --batch clips in all, split over the GPUs (SURVEY 8(d) C4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=32, help="clips per CPU-baseline iteration (default: the GPU's batch)")
-    ap.add_argument("--aux", default="c1,c2,c2bf16,c3x6,c5,cbam", help="secondary configs timed after the main leg at N=1 ('' = none)")
+    ap.add_argument("--aux", default="c3fp32,c1,c2,c2bf16,c3x6,c3_eval,c5,c5_eval,cbam", help="secondary configs timed after the main leg at N=1 ('' = none)")
     ap.add_argument("--aux-budget", type=float, default=240.0)
     ap.add_argument("--aux-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--worker", type=int, default=None, help=argparse.SUPPRESS)      # attempt number (0, or 1 = fallback)
@@ -552,6 +599,21 @@ def worker(args):
         print("# host per-step ms: " + " ".join("%.2f" % ((b - a) * 1e3) for a, b in zip([t0] + host_marks[:-1], host_marks)),
               file=sys.stderr, flush=True)
     beat()
+    # host enqueue cost with an IDLE queue: the GPU is parked behind a spin kernel while the host enqueues whole steps, so
+    # the figure has no queue back-pressure in it -- `host_enqueue_ms_per_step` above mixes the two (a host that runs ahead of the GPU
+    # blocks in the driver's full queue and reads as "slow host").  Outside the timed region; 3 steps behind ~60 ms of spin.
+    host_idle_ms = None
+    if world == 1:
+        try:
+            torch.cuda.synchronize()
+            torch.cuda._sleep(int(0.06 * 2.4e9))
+            th0 = time.perf_counter()
+            for _ in range(3):
+                step()
+            host_idle_ms = (time.perf_counter() - th0) / 3 * 1e3
+            torch.cuda.synchronize()
+        except Exception:  # noqa: BLE001
+            host_idle_ms = None
     ddp.agree_on_scan_error()                      # a scan that gave up (on any rank) would make the number meaningless: every rank raises
     persist_per_step = (_lib.load().m3t_gru_persist_count() - n_persist0) / max(1, args.steps)
     # N > 1: the gradient all-reduce alone (same buffer, same communicator), outside the timed region
@@ -686,6 +748,10 @@ def worker(args):
             "persistent_scan_launches_per_step": persist_per_step,
             "persistent_scan_owner": ops.persist_owner() == 1,
             "host_enqueue_ms_per_step": round(host_ms, 3),
+            "host_enqueue_ms_idle": round(host_idle_ms, 3) if host_idle_ms is not None else None,
+            "host_enqueue_note": "host_enqueue_ms_per_step = wall time of the timed loop's enqueue calls / steps: it contains the time the host spends "
+                                 "blocked behind a full queue (a host that is ahead reads as slow); host_enqueue_ms_idle = the same step enqueued 3 times "
+                                 "while the GPU is parked behind a 60 ms spin kernel (no back-pressure): the enqueue path itself",
             "allreduce": allreduce,
             "memory_roofline_frac": round((clips / dt) * 66.15e6 / (HBM_PEAK_GBS * 1e9 * world), 5),
         }

@@ -94,7 +94,7 @@ int m3t_im2col3d(const float* x, int N, int Ci, int T, int H, int W, int kt, int
  * of shifted source rows (a 32-deep k tile lies inside one tap).  Data gradient of a stride-1 convolution with padding p: src = dy channels-last
  * [N T' H' W'][C_out] (backward has it for the weight gradient anyway), w_taps[(tap, co)][ci] = W[co][ci][tap], base = +p, sign = -1, dst = dx
  * channels-last.  (sign = +1, base = -p, w_taps[(tap, ci)][co]: the forward convolution over a channels-last input.)
- * N T H W % 128 == 0, C_dst % 64 == 0, C_src % 32 == 0, 16-B aligned; flags / amax as m3t_sgemm_scaled (NULL slots are measured); ws (optional):
+ * C_dst % 64 == 0, C_src % 32 == 0, 16-B aligned (any number of rows N T H W since round 6: a ragged last tile reads zeros and is not stored); flags / amax as m3t_sgemm_scaled (NULL slots are measured); ws (optional):
  * split-K slabs for the layers whose tile count does not fill the chip (deterministic reduction, as m3t_sgemm). */
 int m3t_conv3d_taps(const float* src, const float* w_taps, float* dst, int N, int C_src, int C_dst, int T, int H, int W,
                     int To, int Ho, int Wo, int kt, int kh, int kw, int base_t, int base_h, int base_w, int sign, int flags,
@@ -138,12 +138,12 @@ int m3t_conv3d_taps_pre(const float* src_img, const float* w_img, float* dst, in
  * nn.Conv3d / nn.Conv2d forward and backward of the visual stems and the per-frame ResNet).
  * m3t_conv3d_fwd_taps: y_cl[(n, t', h', w')][co] = bias[co] + sum over (kt, kh, kw, ci) of x[(n, t' st + kt - pt, h' sh + kh - ph, w' sw + kw - pw)][ci]
  *   W[co][ci][kt][kh][kw] over the CHANNELS-LAST input, any stride: x_img = the m3t_f16x3_split image of x_cl [N T H W][Ci], w_img = the image
- *   of the K-contiguous weights [Co][(tap, ci)], both under the slots given; bias may be NULL.  N T' H' W' % 128 == 0, Co % 64 == 0, Ci % 32 == 0.
+ *   of the K-contiguous weights [Co][(tap, ci)], both under the slots given; bias may be NULL.  Co % 64 == 0, Ci % 32 == 0, any number of rows.
  * m3t_conv3d_wgrad_taps: dwt[(tap, ci)][co] = sum over the rows r = (n, t', h', w') of the dy grid of x_cl[source row of (r, tap)][ci] dy_cl[r][co]
  *   -- the walk turned round: the reduction runs over the rows (deterministic split-K slabs in ws), the tap is picked once per thread from
  *   its output row, every reduction row is decoded on the dy grid by a counter (no division in the loop).  dwt has ceil128(taps Ci) rows
  *   (rows past taps Ci are written as zeros); fp32 operands, split in the kernel; flags / amax as m3t_sgemm_scaled (NULL slots are measured).
- *   N T' H' W' % 32 == 0, Co % 64 == 0, Ci % 4 == 0, 16-B aligned.
+ *   Co % 64 == 0, Ci % 4 == 0, 16-B aligned; any number of rows (round 6: a ragged last reduction tile reads zeros).
  * With m3t_conv3d_taps(_pre) for the data gradient of the stride-1 layers, no convolution of the path materialises its patches.
  * dst_planes / y_planes (optional, every walk but the weight gradient's): the result is left as channel planes [N][C][T H W] there -- written by
  * the walk's own epilogue when it runs in one K pass (16-byte stores of 4 positions per channel), else reduced into dst / y_cl (then
@@ -151,7 +151,7 @@ int m3t_conv3d_taps_pre(const float* src_img, const float* w_img, float* dst, in
 /* The stems' first layers (C_in <= 4; reference models/backbone.py:73-78,179-184): m3t_planes_to_cl4 writes x [N][C][S] channels-last with
  * FOUR channels (missing ones zero; raises the slot armed by m3t_amax_out); m3t_conv3d_fwd_taps4 walks the m3t_f16x3_split image of that
  * against w_img = the image of [Co][kt][kh][8][4] (kernel width padded to eight taps, channels to four, zeros): one 32-deep k tile per
- * (kt, kh) pair.  kw <= 8, N T' H' W' % 128 == 0, Co % 64 == 0.  The weight gradient is m3t_conv3d_wgrad_taps with Ci = 4. */
+ * (kt, kh) pair.  kw <= 8, Co % 64 == 0, any number of rows.  The weight gradient is m3t_conv3d_wgrad_taps with Ci = 4. */
 int m3t_planes_to_cl4(const float* x, float* out, int N, int C, long long S, void* stream);
 int m3t_conv3d_fwd_taps4(const float* x_img4, const float* w_img, const float* bias, float* y_cl, int N, int Co, int T, int H, int W,
                          int kt, int kh, int kw, int st, int sh, int sw, int pt, int ph, int pw, const unsigned long long* amax_x,

@@ -791,7 +791,7 @@ int m3t_conv3d_taps4_launch(const float* x_img4, const float* w_img, const float
 // split-K of a tap walk: enough workgroups for the chip (the deep layers are a few hundred tiles with K = 13 824), slabs in `ws`
 static void taps_split(long long rows, int Cd, int K, float* ws, size_t ws_bytes, int& splits, int& kchunk) {
     splits = 1; kchunk = K;
-    const long long tiles = (rows / 128) * ((Cd + 127) / 128);
+    const long long tiles = ((rows + 127) / 128) * ((Cd + 127) / 128);
     if (!ws || tiles >= 512) return;
     int sp = (int)((640 + tiles - 1) / tiles);
     const size_t cap = ws_bytes / ((size_t)rows * Cd * sizeof(float));
@@ -964,7 +964,7 @@ extern "C" int m3t_conv3d_taps(const float* src, const float* w_taps, float* dst
         return M3T_EINVAL;
     const long long rows = (long long)N * T * H * W, srows = (long long)N * To * Ho * Wo;
     if (rows > 0x7fffffffll || srows > 0x7fffffffll || (long long)kt * kh * kw * C_src > 0x7fffffffll) return M3T_EINVAL;
-    if (!x6_enabled() || rows % 128 != 0 || C_dst % 64 != 0 || C_src % 32 != 0 || (uintptr_t)src % 16 != 0 || (uintptr_t)w_taps % 16 != 0 ||
+    if (!x6_enabled() || C_dst % 64 != 0 || C_src % 32 != 0 || (uintptr_t)src % 16 != 0 || (uintptr_t)w_taps % 16 != 0 ||
         (flags & (M3T_GEMM_BF16 | M3T_GEMM_HIGH)))
         return M3T_EINVAL;
     const int f16x3 = ((flags & M3T_GEMM_F16X3) && m3t_f16x3_enabled()) ? 1 : 0;
@@ -998,7 +998,7 @@ extern "C" int m3t_conv3d_taps_pre(const float* src_img, const float* w_img, flo
         return M3T_EINVAL;
     const long long rows = (long long)N * T * H * W, srows = (long long)N * To * Ho * Wo;
     if (rows > 0x7fffffffll || srows > 0x7fffffffll || (long long)kt * kh * kw * C_src > 0x7fffffffll) return M3T_EINVAL;
-    if (!x6_enabled() || !m3t_f16x3_enabled() || rows % 128 != 0 || C_dst % 64 != 0 || C_src % 32 != 0 || (uintptr_t)src_img % 16 != 0 ||
+    if (!x6_enabled() || !m3t_f16x3_enabled() || C_dst % 64 != 0 || C_src % 32 != 0 || (uintptr_t)src_img % 16 != 0 ||
         (uintptr_t)w_img % 16 != 0)
         return M3T_EINVAL;
     int splits, kchunk;
@@ -1026,7 +1026,7 @@ extern "C" int m3t_conv3d_fwd_taps(const float* x_img, const float* w_img, const
     if (T + 2 * pt < kt || H + 2 * ph < kh || W + 2 * pw < kw) return M3T_EINVAL;
     const long long rows = (long long)N * To * Ho * Wo, srows = (long long)N * T * H * W;
     if (rows > 0x7fffffffll || srows > 0x7fffffffll || (long long)kt * kh * kw * Ci > 0x7fffffffll) return M3T_EINVAL;
-    if (!x6_enabled() || !m3t_f16x3_enabled() || rows % 128 != 0 || Co % 64 != 0 || Ci % 32 != 0 || (uintptr_t)x_img % 16 != 0 ||
+    if (!x6_enabled() || !m3t_f16x3_enabled() || Co % 64 != 0 || Ci % 32 != 0 || (uintptr_t)x_img % 16 != 0 ||
         (uintptr_t)w_img % 16 != 0)
         return M3T_EINVAL;
     int splits, kchunk;
@@ -1053,7 +1053,7 @@ extern "C" int m3t_conv3d_fwd_taps4(const float* x_img4, const float* w_img, con
     const int To = (T + 2 * pt - kt) / st + 1, Ho = (H + 2 * ph - kh) / sh + 1, Wo = (W + 2 * pw - kw) / sw + 1;
     const long long rows = (long long)N * To * Ho * Wo, srows = (long long)N * T * H * W;
     if (rows > 0x7fffffffll || srows > 0x7fffffffll || (long long)kt * kh * 32 > 0x7fffffffll) return M3T_EINVAL;
-    if (!x6_enabled() || !m3t_f16x3_enabled() || rows % 128 != 0 || Co % 64 != 0 || (uintptr_t)x_img4 % 16 != 0 || (uintptr_t)w_img % 16 != 0)
+    if (!x6_enabled() || !m3t_f16x3_enabled() || Co % 64 != 0 || (uintptr_t)x_img4 % 16 != 0 || (uintptr_t)w_img % 16 != 0)
         return M3T_EINVAL;
     int splits, kchunk;
     taps_split(rows, Co, kt * kh * 32, ws, ws_bytes, splits, kchunk);
@@ -1079,7 +1079,7 @@ extern "C" int m3t_conv3d_wgrad_taps(const float* x_cl, const float* dy_cl, floa
     const int To = (T + 2 * pt - kt) / st + 1, Ho = (H + 2 * ph - kh) / sh + 1, Wo = (W + 2 * pw - kw) / sw + 1;
     const long long rows = (long long)N * To * Ho * Wo, srows = (long long)N * T * H * W, Kc = (long long)kt * kh * kw * Ci;
     if (rows > 0x7fffffffll || srows > 0x7fffffffll || Kc > 0x7fffff00ll) return M3T_EINVAL;
-    if (!x6_enabled() || rows % 32 != 0 || Co % 64 != 0 || Ci % 4 != 0 || (uintptr_t)x_cl % 16 != 0 || (uintptr_t)dy_cl % 16 != 0 ||
+    if (!x6_enabled() || Co % 64 != 0 || Ci % 4 != 0 || (uintptr_t)x_cl % 16 != 0 || (uintptr_t)dy_cl % 16 != 0 ||
         (uintptr_t)dwt % 16 != 0 || (flags & (M3T_GEMM_BF16 | M3T_GEMM_HIGH)))
         return M3T_EINVAL;
     const int f16x3 = ((flags & M3T_GEMM_F16X3) && m3t_f16x3_enabled()) ? 1 : 0;

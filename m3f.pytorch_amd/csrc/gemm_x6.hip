@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p, X6Batch bt
     const bool bcol = XNT == 128 || (tid & 31) < 16;      // row-contiguous B: this thread's 4 columns lie inside the tile
     const int k_begin = MW ? 0 : blockIdx.z * p.kchunk;
     const int k_end = min(p.K, k_begin + p.kchunk);
-    const int ntiles = (k_end - k_begin) / XK;
+    const int ntiles = C3 == 2 ? (k_end - k_begin + XK - 1) / XK : (k_end - k_begin) / XK;      // (C3 = 2: a ragged last tile reads zeros past K)
     __shared__ int rowmap[MW ? XM : 1];              // MW: storage row of the tile's row i
     if (MW) {
         if (tid < XM) {
@@ -265,16 +265,19 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p, X6Batch bt
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int m = bm + (tid >> 3) + 32 * i;
+            const bool past = m >= p.M;                        // round 6: M need not fill the last tile -- its rows past M read zeros and are not stored
             const int w_ = m % p.c3_W; m /= p.c3_W;
             const int h_ = m % p.c3_H; m /= p.c3_H;
             const int t_ = m % p.c3_T; m /= p.c3_T;
-            c3_tt[i] = t_ * p.c3_st + p.c3_bt; c3_hh[i] = h_ * p.c3_sh + p.c3_bh; c3_ww[i] = w_ * p.c3_sw + p.c3_bw; c3_nb[i] = m * p.c3_To;
+            c3_tt[i] = past ? -(1 << 28) : t_ * p.c3_st + p.c3_bt; c3_hh[i] = h_ * p.c3_sh + p.c3_bh; c3_ww[i] = w_ * p.c3_sw + p.c3_bw; c3_nb[i] = past ? 0 : m * p.c3_To;
         }
     }
     // C3 = 2: this thread's tap (from its four A columns) and the dy-grid coordinates of its first k row, advanced by XK per tile
     int g_w = 0, g_h = 0, g_t = 0, g_n = 0, adv_w = 0, adv_h = 0, adv_t = 0, adv_n = 0, g_dt = 0, g_dh = 0, g_dw = 0, g_c = 0;
+    int g_k = 0;                                     // C3 = 2: the reduction row of this thread's first load of the next tile (rows past K: zeros)
     bool g_ok = false;
     if (C3 == 2) {
+        g_k = k_begin + (tid >> 5) * 4;
         const int m0 = bm + (tid & 31) * 4;
         const int j = m0 / p.c3_C;
         g_c = m0 - j * p.c3_C;
@@ -299,13 +302,15 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p, X6Batch bt
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int ts = t_ * p.c3_st + g_dt, hs = h_ * p.c3_sh + g_dh, ws = w_ * p.c3_sw + g_dw;
-                const bool ok = g_ok && (unsigned)ts < (unsigned)p.c3_To && (unsigned)hs < (unsigned)p.c3_Ho && (unsigned)ws < (unsigned)p.c3_Wo;
+                const bool kin = g_k + e < k_end;
+                const bool ok = kin && g_ok && (unsigned)ts < (unsigned)p.c3_To && (unsigned)hs < (unsigned)p.c3_Ho && (unsigned)ws < (unsigned)p.c3_Wo;
                 const size_t row = ((size_t)(n_ * p.c3_To + ts) * p.c3_Ho + hs) * p.c3_Wo + ws;
                 ra[e] = ok ? *reinterpret_cast<const float4*>(p.A + row * p.lda + g_c) : make_float4(0.f, 0.f, 0.f, 0.f);
-                rb[e] = bcol ? *reinterpret_cast<const float4*>(pb + e * b_krow) : make_float4(0.f, 0.f, 0.f, 0.f);
+                rb[e] = (bcol && kin) ? *reinterpret_cast<const float4*>(pb + e * b_krow) : make_float4(0.f, 0.f, 0.f, 0.f);
                 if (++w_ == p.c3_W) { w_ = 0; if (++h_ == p.c3_H) { h_ = 0; if (++t_ == p.c3_T) { t_ = 0; ++n_; } } }
             }
             pb += b_step;
+            g_k += XK;
             int c;                                               // the counter + 32 rows: one carry per digit
             g_w += adv_w; c = g_w >= p.c3_W; g_w -= c ? p.c3_W : 0;
             g_h += adv_h + c; c = g_h >= p.c3_H; g_h -= c ? p.c3_H : 0;
@@ -465,15 +470,17 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p, X6Batch bt
 #pragma unroll
                     for (int q4 = 0; q4 < 4; ++q4) {
                         const int m0 = bm + wm * 64 + i * 32 + 8 * q4 + 4 * hi;
+                        if (m0 >= p.M) continue;
                         int n = m0 / S, sp = m0 - n * S;
                         float4 v;
                         v.x = acc[i][j][4 * q4 + 0] * sc_ia * sc_ib + bv; v.y = acc[i][j][4 * q4 + 1] * sc_ia * sc_ib + bv;
                         v.z = acc[i][j][4 * q4 + 2] * sc_ia * sc_ib + bv; v.w = acc[i][j][4 * q4 + 3] * sc_ia * sc_ib + bv;
-                        if ((S & 3) == 0) *reinterpret_cast<float4*>(p.C + ((size_t)n * p.N + col) * S + sp) = v;
+                        if ((S & 3) == 0) *reinterpret_cast<float4*>(p.C + ((size_t)n * p.N + col) * S + sp) = v;      // (S % 4 == 0: so is M)
                         else {
                             const float ve[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
+                                if (m0 + e >= p.M) break;
                                 p.C[((size_t)n * p.N + col) * S + sp] = ve[e];
                                 if (++sp == S) { sp = 0; ++n; }
                             }
@@ -494,6 +501,7 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p, X6Batch bt
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = bm + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (C3ROWS && row >= p.M) continue;            // (a ragged last tile of a tap walk)
                 if (CONV && p.cv_drop.on && (r & 3) == 0) m3t_drop_mask4(p.cv_drop, (uint32_t)row >> 2, (uint32_t)col, dm);
                 float v = acc[i][j][r];
                 if (NS == 4) v = v * sc_ia * sc_ib;              // (exact: powers of two)
@@ -616,7 +624,7 @@ int m3t_sgemm_x6_pre_launch(int M, int N, int K, const float* A, int lda, const 
     return (int)hipGetLastError();
 }
 
-// The 3-D tap walk (C3 kernels; m3t_conv3d_taps).  The caller has verified: rows % 128 == 0, Cd % 64 == 0, Cs % 32 == 0, 16-B aligned operands.
+// The 3-D tap walk (C3 kernels; m3t_conv3d_taps).  The caller has verified: Cd % 64 == 0 (any number of rows since round 6), Cs % 32 == 0, 16-B aligned operands.
 // pre: both operands are pre-split images (m3t_f16x3_split) and w_taps is [Cd][taps * Cs] (K-contiguous)
 int m3t_conv3d_taps_launch(const float* src, const float* w_taps, float* dst, int N, int Cs, int Cd, int T, int H, int W, int To, int Ho, int Wo,
                            int kt, int kh, int kw, int bt_, int bh, int bw, int sg, int f16x3, int pre, const unsigned long long* amax_a,
@@ -637,8 +645,9 @@ int m3t_conv3d_taps_launch(const float* src, const float* w_taps, float* dst, in
     p.c3_bt = bt_; p.c3_bh = bh; p.c3_bw = bw; p.c3_sg = sg; p.c3_C = Cs;
     p.c3_st = stride3 ? stride3[0] : 1; p.c3_sh = stride3 ? stride3[1] : 1; p.c3_sw = stride3 ? stride3[2] : 1;
     p.tr_S = (planes && splits == 1) ? T * H * W : 0;      // (dst is then [N][Cd][T H W])
-    const bool narrow = (Cd % 128 != 0) || (Cd / XN) * (p.M / XM) * splits <= 384;
-    dim3 grid(Cd / (narrow ? 64 : XN), p.M / XM, splits), block(256);
+    const int tm = (p.M + XM - 1) / XM;                        // (round 6: a ragged last row tile)
+    const bool narrow = (Cd % 128 != 0) || (Cd / XN) * tm * splits <= 384;
+    dim3 grid(Cd / (narrow ? 64 : XN), tm, splits), block(256);
 #define M3T_C3_GO(NS_)                                                                                                  \
     do {                                                                                                               \
         if (narrow) sgemm_x6_kernel<0, 0, false, NS_, false, 64, false, 1><<<grid, block, 0, s>>>(p, g_no_batch);   \
@@ -654,7 +663,7 @@ int m3t_conv3d_taps_launch(const float* src, const float* w_taps, float* dst, in
 }
 
 // The first layers' walk (C3 = 3 kernels; m3t_conv3d_fwd_taps4): x_img4 = image of x channels-last padded to 4 channels, w_img = image of
-// [Co][kt][kh][8][4].  The caller has verified: rows % 128 == 0, Co % 64 == 0, kw <= 8, 16-B aligned operands.
+// [Co][kt][kh][8][4].  The caller has verified: Co % 64 == 0, kw <= 8 (any number of rows), 16-B aligned operands.
 int m3t_conv3d_taps4_launch(const float* x_img4, const float* w_img, const float* bias, float* y_cl, int N, int Co, int T, int H, int W, int To,
                             int Ho, int Wo, int kt, int kh, int kw, const int* stride3, int pt, int ph, int pw, const unsigned long long* amax_x,
                             const unsigned long long* amax_w, float* ws, int splits, int kchunk, hipStream_t s, int planes) {
@@ -672,15 +681,16 @@ int m3t_conv3d_taps4_launch(const float* x_img4, const float* w_img, const float
     p.c3_bt = -pt; p.c3_bh = -ph; p.c3_bw = -pw; p.c3_sg = 1; p.c3_C = 4;
     p.c3_st = stride3[0]; p.c3_sh = stride3[1]; p.c3_sw = stride3[2];
     p.tr_S = (planes && splits == 1) ? To * Ho * Wo : 0;
-    const bool narrow = (Co % 128 != 0) || (Co / XN) * (p.M / XM) * splits <= 384;
-    dim3 grid(Co / (narrow ? 64 : XN), p.M / XM, splits), block(256);
+    const int tm = (p.M + XM - 1) / XM;
+    const bool narrow = (Co % 128 != 0) || (Co / XN) * tm * splits <= 384;
+    dim3 grid(Co / (narrow ? 64 : XN), tm, splits), block(256);
     if (narrow) sgemm_x6_kernel<0, 1, false, 4, false, 64, false, 3, 3><<<grid, block, 0, s>>>(p, g_no_batch);
     else sgemm_x6_kernel<0, 1, false, 4, false, 128, false, 3, 3><<<grid, block, 0, s>>>(p, g_no_batch);
     return (int)hipGetLastError();
 }
 
 // The weight gradient's walk (C3 = 2 kernels; m3t_conv3d_wgrad_taps): dwt [Mp][Co] = sum over the dy grid's rows, Mp = taps * Ci rounded up
-// to 128.  The caller has verified: rows % 32 == 0, Co % 64 == 0, Ci % 4 == 0, kchunk % 32 == 0, 16-B aligned operands.
+// to 128.  The caller has verified: Co % 64 == 0, Ci % 4 == 0, kchunk % 32 == 0 (any number of rows: a ragged last k tile reads zeros), 16-B aligned operands.
 int m3t_conv3d_wgrad_launch(const float* x_cl, const float* dy_cl, float* dwt, int N, int Ci, int Co, int T, int H, int W, int To, int Ho, int Wo,
                             int kt, int kh, int kw, const int* stride3, int pt, int ph, int pw, int f16x3, const unsigned long long* amax_x,
                             const unsigned long long* amax_dy, float* ws, int splits, int kchunk, hipStream_t s) {

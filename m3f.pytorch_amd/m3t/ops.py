@@ -6,6 +6,7 @@ is no CPU or eager fallback -- a CPU tensor or a missing library raises.
 """
 import ctypes as C
 import os
+import sys
 
 import torch
 
@@ -2347,6 +2348,17 @@ CONV3D_TAPS = [os.environ.get("M3T_CONV3D_MIOPEN", "0") not in ("1", "dgrad")]  
 # patch-matrix GEMMs of the first half of round 5 (kept: the layers with C_in % 32 != 0 -- the stems' first convolutions -- always take them)
 CONV3D_IMPLICIT = [os.environ.get("M3T_CONV3D_IMPLICIT", "1") != "0"]
 CONV3D_CALLS = {"walk": 0, "patch": 0, "torch": 0}       # forward calls by path (tests assert the path they mean to check)
+_STOCK_WARNED = set()
+STOCK_FALLBACKS = {}          # site -> number of calls that took a stock (torch / MIOpen) operator instead of the HIP library
+
+
+def stock_fallback(site, why):
+    """A product module is about to run a stock torch operator instead of the HIP library (a shape no kernel covers, an A/B switch): say so
+    ONCE per site on stderr and count it (which kernel ran must not be a silent function of shape or mode)."""
+    STOCK_FALLBACKS[site] = STOCK_FALLBACKS.get(site, 0) + 1
+    if site not in _STOCK_WARNED:
+        _STOCK_WARNED.add(site)
+        print("m3t: %s runs on the stock torch operator (%s)" % (site, why), file=sys.stderr, flush=True)
 
 
 
@@ -2358,7 +2370,13 @@ def _conv3d_plan(x, w, stride, padding):
     Ho = (H_ + 2 * padding[1] - kh) // stride[1] + 1
     Wo = (W_ + 2 * padding[2] - kw) // stride[2] + 1
     rows, Kc = N_ * To * Ho * Wo, Ci * kt * kh * kw
-    if min(To, Ho, Wo) < 1 or rows % 128 != 0 or Co % 64 != 0:
+    if min(To, Ho, Wo) < 1 or Co % 64 != 0:
+        return None
+    # round 6: the tap walks take any number of rows (a ragged last tile reads zeros and is not stored); only the patch-matrix GEMMs
+    # (M3T_CONV3D_IMPLICIT=0, C_in % 32 != 0 layers) still need whole 128-row tiles
+    cw = Ci if Ci % 32 == 0 else (4 if (Ci <= 4 and kw <= 8) else 0)
+    walk = bool(CONV3D_IMPLICIT[0] and (_PREC[0] & _lib.M3T_GEMM_F16X3) and cw)
+    if rows % 128 != 0 and not walk:
         return None
     Kp = Kc if Kc % 64 == 0 else (Kc + 127) // 128 * 128       # (the weight gradient's rules: dW = dy^T P, or transposed and padded)
     return To, Ho, Wo, rows, Kc, Kp
@@ -2374,13 +2392,28 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
     dy^T P on the GEMM; strided layers' data gradient, shapes no tile fits (rows % 128, C_out % 64), M3T_CONV3D_MIOPEN=1: torch / MIOpen."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, padding):
+    def forward(ctx, x, w, b, stride, padding, as2d=False):
+        # as2d (models.resnet.GemmConv2d): x [N, C, H, W] and the Conv2d PARAMETER w [Co, Ci, kh, kw] take a unit time axis HERE, so that the
+        # gradient-sink and per-step magnitude lookups below are keyed on the Parameter itself (ADVICE r5: a .unsqueeze(2) view made by the
+        # caller is a fresh tensor that matches neither table)
+        ctx.as2d = bool(as2d)
+        w_par = w
+        if as2d:
+            x, w = x.unsqueeze(2), w.unsqueeze(2)
+            stride, padding = (1,) + tuple(stride), (0,) + tuple(padding)
+        y = _Conv3dGemmWgrad._forward5(ctx, x, w, w_par, b, stride, padding)
+        return y.squeeze(2) if as2d else y
+
+    @staticmethod
+    def _forward5(ctx, x, w, w_par, b, stride, padding):
         ctx.stride, ctx.padding, ctx.has_bias = stride, padding, b is not None
-        ctx.sink_refs = (w if id(w) in _GRAD_SINKS else None, b if (b is not None and id(b) in _GRAD_SINKS) else None)      # gradient sinks
+        ctx.sink_refs = (w_par if id(w_par) in _GRAD_SINKS else None, b if (b is not None and id(b) in _GRAD_SINKS) else None)      # gradient sinks
         plan = _conv3d_plan(x, w, stride, padding) if (CONV3D_GEMM[0] and x.is_cuda and (_PREC[0] & _lib.M3T_GEMM_F16X3 or _PREC[0] == 0)) else None
         ctx.prec = _PREC[0]
         ctx.impl = 0                     # channel width of the channels-last input kept by a tap-walk forward (0: none)
         if plan is None:
+            stock_fallback("conv%dd %s k%s s%s" % (2 if ctx.as2d else 3, tuple(x.shape[1:]), tuple(w.shape), tuple(stride)),
+                           "M3T_CONV3D_MIOPEN=1" if not CONV3D_GEMM[0] else "rows % 128 or C_out % 64: no GEMM tile fits, or a precision mode without the walk")
             y = torch.conv3d(x, w, b, stride, padding)
             CONV3D_CALLS["torch"] += 1
             ctx.save_for_backward(x, w)
@@ -2398,7 +2431,7 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
             # bias in its epilogue, one transpose back.  The stems' first layers (3 input channels): channels padded to four, the kernel's
             # width to eight taps -- one 32-deep k tile per (kt, kh) pair (m3t_conv3d_fwd_taps4)
             ctx.w_keep = []
-            a_w = weight_amax(w, ctx.w_keep)
+            a_w = weight_amax(w_par, ctx.w_keep)
             taps = kt * kh * kw
             if cw == Ci:
                 w_t = _req(w.detach().permute(0, 2, 3, 4, 1).contiguous(), "weight").view(Co, taps * Ci)       # [co][(tap, ci)]
@@ -2447,7 +2480,7 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
             wp[:, :Kc].copy_(w2)
             w2 = wp
         ctx.w_keep = []
-        a_w = weight_amax(w, ctx.w_keep)
+        a_w = weight_amax(w_par, ctx.w_keep)
         if a_w is None:
             a_w = slots.data_ptr() + 8
             if not measure_amax([(w2, a_w)]):
@@ -2463,6 +2496,14 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if ctx.as2d:
+            dx, dw, db = _Conv3dGemmWgrad._backward5(ctx, dy.unsqueeze(2))
+            return (dx.squeeze(2) if dx is not None else None, dw.squeeze(2) if dw is not None else None, db, None, None, None)
+        dx, dw, db = _Conv3dGemmWgrad._backward5(ctx, dy)
+        return dx, dw, db, None, None, None
+
+    @staticmethod
+    def _backward5(ctx, dy):
         saved = ctx.saved_tensors
         x, w = saved[0], saved[1]
         impl = ctx.impl if ctx.pat is not None else 0                       # forward was a tap walk: saved[2] is x channels-last, no patch matrix
@@ -2477,7 +2518,7 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
         # round 5: the data gradient of a stride-1 layer as a tap-walk contraction over dy channels-last (m3t_conv3d_taps: an implicit GEMM, no
         # patch matrix, no col2im) -- MIOpen's data gradient (Col2Im3dU + Tensile GEMMs) was ~5 ms of a C5 step
         taps_dx = (ctx.needs_input_grad[0] and CONV3D_TAPS[0] and ctx.pat is not None and tuple(st) == (1, 1, 1) and Co % 32 == 0 and Ci % 64 == 0
-                   and (N_ * T_ * H_ * W_) % 128 == 0 and (ctx.prec & _lib.M3T_GEMM_F16X3 or ctx.prec == 0))
+                   and ((N_ * T_ * H_ * W_) % 128 == 0 or bool(ctx.prec & _lib.M3T_GEMM_F16X3)) and (ctx.prec & _lib.M3T_GEMM_F16X3 or ctx.prec == 0))
         if ctx.needs_input_grad[0] and not taps_dx:
             if x.shape[2] == 1 and w.shape[2] == 1 and st[0] == 1 and pd[0] == 0:
                 # a 2-D convolution with a unit time axis (models.resnet.GemmConv2d): MIOpen's 2-D data gradient, not its 3-D one
@@ -2593,8 +2634,14 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
             colsum(dpart, 0, dpart.shape[0], Co, Co, db)
             if b_sink is not None:
                 db = None
-        return dx, dw, db, None, None
+        return dx, dw, db
 
 
 def conv3d(x, w, b, stride, padding):
-    return _Conv3dGemmWgrad.apply(x, w, b, tuple(stride), tuple(padding))
+    return _Conv3dGemmWgrad.apply(x, w, b, tuple(stride), tuple(padding), False)
+
+
+def conv2d(x, w, b, stride, padding):
+    """nn.Conv2d of the per-frame ResNet (reference models/resnet.py:18-24,95-105) on the 3-D walks with a unit time axis; w is the Conv2d
+    Parameter itself (gradient sinks and the per-step magnitude table are keyed on it)"""
+    return _Conv3dGemmWgrad.apply(x, w, b, tuple(stride), tuple(padding), True)

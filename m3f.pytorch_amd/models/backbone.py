@@ -27,10 +27,12 @@ class Conv3d(nn.Conv3d):
     under M3T_CONV3D_MIOPEN=1)."""
 
     def forward(self, x):
-        if (x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and self.weight.requires_grad
-                and self.groups == 1 and tuple(self.dilation) == (1, 1, 1) and self.padding_mode == "zeros"
-                and isinstance(self.padding, tuple)):
+        # ONE path whatever the grad mode (round 6): validation / test steps under no_grad (reference models/model.py:226-246,320-337) and
+        # --freeze_enc training (model.py:376-386) run the same walks as a training step; autograd skips what needs no gradient
+        if (x.is_cuda and x.dtype == torch.float32 and self.groups == 1 and tuple(self.dilation) == (1, 1, 1)
+                and self.padding_mode == "zeros" and isinstance(self.padding, tuple)):
             return ops.conv3d(x, self.weight, self.bias, self.stride, self.padding)
+        ops.stock_fallback("models.backbone.Conv3d", "CPU / non-fp32 input, groups, dilation or a padding mode the walks do not cover")
         return super().forward(x)
 
 
@@ -46,6 +48,7 @@ class BatchNorm3dReLU(nn.BatchNorm3d):
                 self.num_batches_tracked.add_(1)
             return ops.bn_planes(x, self.weight, self.bias, self.running_mean, self.running_var, self.training, self.momentum,
                                  self.eps, True)
+        ops.stock_fallback("models.backbone.BatchNorm3dReLU", "M3T_BN_PLANES=0, CPU / non-fp32 input or a configuration without running statistics")
         return torch.relu(super().forward(x))
 
 
@@ -60,6 +63,7 @@ class SpatialMaxPool3d(nn.MaxPool3d):
         if (x.dim() == 5 and x.is_cuda and x.dtype == torch.float32 and k[0] == 1 and s[0] == 1 and p[0] == 0 and d == (1, 1, 1)
                 and not self.return_indices and not self.ceil_mode and k[1] * k[2] <= 255):
             return ops.pool_planes(x, k[1:], s[1:], p[1:])
+        ops.stock_fallback("models.backbone.SpatialMaxPool3d", "a window over frames, ceil_mode / return_indices, or a CPU / non-fp32 input")
         return super().forward(x)
 
 

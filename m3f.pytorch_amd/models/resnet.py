@@ -2,9 +2,9 @@
 
 API/state-dict compatible with the reference's models/resnet.py:18-124 (`BasicBlock`,
 `ResNet`, v1) and :127-251 (`BasicBlockV2`, `ResNetV2`).  Every CBAM gate inside the blocks (models.cbam), since round 4
-BatchNorm2d with the ReLU behind it (PlaneBatchNorm2d) and since round 5 the forward and weight gradient of the dense 2-D
-convolutions (GemmConv2d: patch matrix x fp16x3 GEMM) run in the HIP library; the convolutions' data gradient stays on
-PyTorch-ROCm (MIOpen) ops.
+BatchNorm2d with the ReLU behind it (PlaneBatchNorm2d) and since round 5 the dense 2-D convolutions (GemmConv2d: forward with any
+stride, weight gradient and the data gradient as tap-walk implicit GEMMs over channels-last rows on the fp16x3 kernels, no patch
+matrix) run in the HIP library, in every grad mode (round 6: validation / test steps and frozen encoders take the same walks).
 """
 import torch
 import torch.nn as nn
@@ -29,6 +29,7 @@ class PlaneBatchNorm2d(nn.BatchNorm2d):
                 self.num_batches_tracked.add_(1)
             return ops.bn_planes(x, self.weight, self.bias, self.running_mean, self.running_var, self.training, self.momentum,
                                  self.eps, self.fuse_relu)
+        ops.stock_fallback("models.resnet.PlaneBatchNorm2d", "M3T_BN_PLANES=0, CPU / non-fp32 input or a configuration without running statistics")
         y = super().forward(x)
         return torch.relu(y) if self.fuse_relu else y
 
@@ -41,10 +42,11 @@ class GemmConv2d(nn.Conv2d):
     other dtypes, no gradient, untileable shapes, M3T_CONV3D_MIOPEN=1) take the stock op."""
 
     def forward(self, x):
-        if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and torch.is_grad_enabled() and self.weight.requires_grad
-                and self.groups == 1 and tuple(self.dilation) == (1, 1) and self.padding_mode == "zeros" and isinstance(self.padding, tuple)):
-            y = ops.conv3d(x.unsqueeze(2), self.weight.unsqueeze(2), self.bias, (1,) + tuple(self.stride), (0,) + tuple(self.padding))
-            return y.squeeze(2)
+        # one path whatever the grad mode (validation / test steps, frozen encoders: see models.backbone.Conv3d)
+        if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and self.groups == 1 and tuple(self.dilation) == (1, 1)
+                and self.padding_mode == "zeros" and isinstance(self.padding, tuple)):
+            return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding)
+        ops.stock_fallback("models.resnet.GemmConv2d", "CPU / non-fp32 input, groups, dilation or a padding mode the walks do not cover")
         return super().forward(x)
 
 

@@ -425,6 +425,60 @@ def case_resnet3d(name, seed, B=2, T=3):
          dx=grad_digest(x.grad.numpy()), param_names=np.array(sorted(n for n, _ in m.named_parameters())), **grads)
 
 
+def _bn_state(m):
+    """every BatchNorm buffer after the step (running_mean / running_var / num_batches_tracked)"""
+    return {"bn." + n: b.detach().numpy().astype(np.float64) for n, b in m.named_buffers()
+            if n.split(".")[-1] in ("running_mean", "running_var", "num_batches_tracked")}
+
+
+def case_affwild_av_train(name, seed, B=2, T=16):
+    """Config C5 in TRAIN mode (what bench.py times): the full AffWild2VA audiovisual/attention/v2p_split/ccc_mtl
+    training_step on raw frames with BatchNorm3d on BATCH statistics through the five stem groups (reference models/backbone.py:179-271,
+    models/model.py:146-218): outputs, loss, every parameter-gradient digest and the BatchNorm buffers after the step.  No dropout is
+    active on this path (GRU heads: dropout=False, model.py:86), so the step is deterministic."""
+    rs = np.random.RandomState(seed)
+    m = fill_module(AffWild2VA(hp(modality="audiovisual", fusion_type="attention", loss="ccc_mtl", window=T)), seed + 1).train()
+    batch = {
+        "video": torch.from_numpy(rs.randint(0, 256, (B, 3, T, 112, 112)).astype(np.float32)),
+        "se_features": torch.from_numpy(draw(rs, (B, 512, T))),
+        "audio": torch.from_numpy(draw(rs, (B, T, 200))),
+        "label_valence": torch.from_numpy(draw(rs, (B, T), "uniform_pm1")),
+        "label_arousal": torch.from_numpy(draw(rs, (B, T), "uniform_pm1")),
+        "class_expr": torch.from_numpy(rs.randint(0, 7, (B, T)).astype(np.int64)),
+        "expr_valid": torch.from_numpy(rs.uniform(size=(B, T)) < 0.7),
+    }
+    ys = {}
+    fwd = m.forward                                # (training_step calls self.forward directly: no forward hook fires)
+
+    def tap(b):
+        o = fwd(b)
+        ys["y"] = o.detach().numpy().copy()
+        return o
+    m.forward = tap
+    out = m.training_step(batch, 0)                # ONE forward: the BatchNorm buffers are updated once
+    del m.forward
+    out["loss"].backward()
+    grads = {"gd." + n: grad_digest(p.grad.numpy()) for n, p in m.named_parameters() if p.grad is not None}
+    save(name, seed=np.array(seed), dims=np.array([B, T]), y=ys["y"], loss=out["loss"].detach().numpy(),
+         param_names=np.array(sorted(n for n, _ in m.named_parameters())), **_bn_state(m), **grads)
+
+
+def case_resnet3d_train(name, seed, B=2, T=3):
+    """VA_3DResNet(resnet_ver='v1', use_cbam=True) in TRAIN mode (bench.py's aux.cbam_resnet3d): BatchNorm3d of the stem, the 20
+    BatchNorm2d of the per-frame ResNet-18 and the 8 CBAM gates' BatchNorm2d(1) on batch statistics (reference models/backbone.py:327-355,
+    models/resnet.py:40-56, models/cbam.py:84-93): outputs, gradient digests, the input gradient and the buffers after the step."""
+    rs = np.random.RandomState(seed)
+    m = fill_module(VA_3DResNet(frameLen=T, resnet_ver="v1", use_cbam=True, nClasses=2, nFCs=2), seed + 1).train()
+    x = torch.from_numpy(rs.randint(0, 256, (B, 3, T, 112, 112)).astype(np.float32))
+    x = ((x - 127.5) / 127.5).requires_grad_(True)
+    y = m(x)
+    ct = torch.from_numpy(draw(rs, tuple(y.shape)))
+    (y * ct).sum().backward()
+    grads = {"gd." + n: grad_digest(p.grad.numpy()) for n, p in m.named_parameters() if p.grad is not None}
+    save(name, seed=np.array(seed), dims=np.array([B, T]), y=y.detach().numpy(), ct=ct.numpy(),
+         dx=grad_digest(x.grad.numpy()), param_names=np.array(sorted(n for n, _ in m.named_parameters())), **_bn_state(m), **grads)
+
+
 def case_vggm(name, seed, backend, B=2, T=4, training=False):
     """VA_3DVGGM end to end from raw frames (reference models/backbone.py:62-161, forward :134-145): the unsplit VGG-M stem
     -> TemporalConvNet(512,[512,512],3) + Linear(512,2) (backend 'tcn': the only TemporalConvNet user) or GRU (backend 'gru').
@@ -670,6 +724,9 @@ def main():
         case_vggm("vggm_gru_eval", 930, "gru", B=2, T=3)
     if want("c5t16"):
         case_affwild_av("c5_affwild_av_t16", 940, B=2, T=16)
+    if want("c5train"):
+        case_affwild_av_train("c5_affwild_av_t16_train", 960, B=2, T=16)
+        case_resnet3d_train("c5_resnet3d_cbam_train", 970, B=2, T=3)
     if want("c5t64"):
         # BASELINE's window of the end-to-end config (64 frames per clip): scans, stitching-free heads and the stems at the length bench.py times
         case_affwild_av("c5_affwild_av_t64", 950, B=2, T=64)

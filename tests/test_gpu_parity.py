@@ -1403,6 +1403,135 @@ def test_c5_affwild_av_t64_golden():
     check_digests([(n, p.grad) for n, p in m.named_parameters() if p.grad is not None], g, tol=C5_DIGEST_TOL)
 
 
+def _check_bn_state(m, g, tol):
+    """BatchNorm buffers after ONE training step against the reference's (running statistics: relative to their own scale)"""
+    n_checked = 0
+    for n, b in m.named_buffers():
+        leaf = n.split(".")[-1]
+        if leaf not in ("running_mean", "running_var", "num_batches_tracked"):
+            continue
+        ref = g["bn." + n]
+        got = b.detach().cpu().double().numpy()
+        if leaf == "num_batches_tracked":
+            assert int(got) == int(ref), (n, got, ref)
+        else:
+            assert float(np.abs(got - ref).max()) <= tol * max(1.0, float(np.abs(ref).max())), (n, float(np.abs(got - ref).max()))
+        n_checked += 1
+    return n_checked
+
+
+def test_c5_affwild_av_train_mode_golden():
+    """TRAIN mode end to end (what bench.py's C5 leg times): AffWild2VA A+V training_step on raw frames with BatchNorm3d on
+    BATCH statistics through the five stem groups (reference models/backbone.py:179-271, models/model.py:146-218) -- outputs, loss, every
+    parameter-gradient digest and every BatchNorm buffer after the step against the reference's own run (tests/golden/gen_golden.py c5train)"""
+    from models.model import AffWild2VA
+    from m3t import ops
+    g = load_golden("c5_affwild_av_t16_train")
+    seed = int(g["seed"])
+    B, T = [int(v) for v in g["dims"]]
+    m = fill_module(AffWild2VA(_hp(modality="audiovisual", fusion_type="attention", loss="ccc_mtl", window=T)), seed + 1).to(DEV).train()
+    batch = _affwild_batch(np.random.RandomState(seed), B, T, video=True)
+    ys = {}
+    fwd = m.forward
+
+    def tap(b):
+        ys["y"] = fwd(b)
+        return ys["y"]
+    m.forward = tap
+    n_torch = ops.CONV3D_CALLS["torch"]
+    out = m.training_step(batch, 0)
+    del m.forward
+    assert ops.CONV3D_CALLS["torch"] == n_torch, "a convolution of the C5 training step took the stock operator"
+    close(ys["y"], g["y"], TOL, "y")
+    close(out["loss"], g["loss"], TOL, "loss")
+    out["loss"].backward()
+    check_digests([(n, p.grad) for n, p in m.named_parameters() if p.grad is not None], g, tol=C5_DIGEST_TOL)
+    assert _check_bn_state(m, g, 2e-4) >= 15
+
+
+def test_c5_resnet3d_cbam_train_mode_golden():
+    """VA_3DResNet(use_cbam=True) in TRAIN mode (bench.py's aux.cbam_resnet3d): BatchNorm3d of the stem, the per-frame ResNet-18's 20
+    BatchNorm2d and the 8 CBAM gates' BatchNorm2d(1) on batch statistics (reference models/backbone.py:327-355, models/resnet.py:40-56,
+    models/cbam.py:84-93): outputs, parameter- and input-gradient digests, buffers after the step"""
+    from models.backbone import VA_3DResNet
+    g = load_golden("c5_resnet3d_cbam_train")
+    seed = int(g["seed"])
+    B, T = [int(v) for v in g["dims"]]
+    m = fill_module(VA_3DResNet(frameLen=T, resnet_ver="v1", use_cbam=True, nClasses=2, nFCs=2), seed + 1).to(DEV).train()
+    rs = np.random.RandomState(seed)
+    x = dev(rs.randint(0, 256, (B, 3, T, 112, 112)).astype(np.float32))
+    x = ((x - 127.5) / 127.5).requires_grad_(True)
+    y = m(x)
+    close(y, g["y"], 2e-4, "y")
+    (y * dev(g["ct"])).sum().backward()
+    check_digests([(n, p.grad) for n, p in m.named_parameters() if p.grad is not None], g, tol=2e-3)
+    check_digests([("dx", x.grad)], {"gd.dx": g["dx"]}, tol=2e-3)
+    assert _check_bn_state(m, g, 2e-4) >= 60
+
+
+def test_c5_no_grad_forward_takes_the_same_walks():
+    """validation_step / test_step (reference models/model.py:226-246,320-337: self.forward under no_grad, eval mode) and --freeze_enc training
+    (model.py:376-386) run the stems' convolutions on the SAME tap walks as a training step (round 6: one path whatever the grad mode;
+    until round 5 they fell back to MIOpen): the eval golden's outputs under torch.no_grad(), with no stock-operator convolution, and the
+    frozen-encoder step's remaining gradients equal to the unfrozen step's"""
+    from models.model import AffWild2VA
+    from m3t import ops
+    g = load_golden("c5_affwild_av_t16")
+    seed = int(g["seed"])
+    B, T = [int(v) for v in g["dims"]]
+    m = fill_module(AffWild2VA(_hp(modality="audiovisual", fusion_type="attention", loss="ccc_mtl", window=T)), seed + 1).to(DEV).eval()
+    batch = _affwild_batch(np.random.RandomState(seed), B, T, video=True)
+    before = dict(ops.CONV3D_CALLS)
+    with torch.no_grad():
+        y = m(batch)
+    assert ops.CONV3D_CALLS["torch"] == before["torch"] and ops.CONV3D_CALLS["walk"] > before["walk"], (before, ops.CONV3D_CALLS)
+    close(y, g["y"], TOL, "y (no_grad)")
+    # frozen encoders (reference model.py:376-386 freezes self.visual / self.audio parameters): the walks run, the heads' gradients are unchanged
+    out = m.training_step(batch, 0)
+    out["loss"].backward()
+    live = ("fusion.", "proj_v.", "att_fuse.")           # configure_optimizers with --freeze_enc: everything else is frozen
+    ref = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None and n.startswith(live)}
+    for p in m.parameters():
+        p.grad = None
+    for n, p in m.named_parameters():
+        if not n.startswith(live):
+            p.requires_grad_(False)
+    before = dict(ops.CONV3D_CALLS)
+    out = m.training_step(batch, 0)
+    out["loss"].backward()
+    assert ops.CONV3D_CALLS["torch"] == before["torch"] and ops.CONV3D_CALLS["walk"] > before["walk"]
+    assert len(ref) > 20
+    for n, p in m.named_parameters():
+        if not n.startswith(live):
+            assert p.grad is None, n
+        elif n in ref:
+            assert torch.equal(p.grad, ref[n]), n
+
+
+def test_cached_magnitudes_follow_in_place_changes():
+    """the per-step weight magnitude table and the tags riding on tensors (|h| <= 1 of a GRU output, a TemporalBlock's measured slot)
+    are dropped when the tensor is written in place after the measurement -- a stale maximum would overflow the fp16x3 scale."""
+    from m3t import ops
+    w = torch.nn.Parameter(torch.randn(64, 32, device=DEV))
+    ops.measure_weight_amax([w], owner=None)
+    try:
+        assert ops.weight_amax(w) is not None
+        with torch.no_grad():
+            w.mul_(1e4)                                    # e.g. optimizer.step() placed after zero_grad(), load_state_dict, a clamp
+        assert ops.weight_amax(w) is None
+        x = torch.randn(128, 32, device=DEV)
+        y = ops.linear(x, w, None, 0)                      # measures for itself again: finite and right
+        ref = x.double() @ w.detach().double().t()
+        assert float((y.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    finally:
+        ops.drop_weight_amax(None)
+    h = torch.rand(4, 8, 16, device=DEV)
+    h._m3t_unit = h._version + 1
+    assert ops._is_unit(h)
+    h.mul_(3.0)
+    assert not ops._is_unit(h)
+
+
 def test_c1_affwild_audio_db_scale_golden():
     """The reference's REAL audio input scale: un-normalised power_to_db log-Mel values, |x| ~ 40 (reference
     process/extract_melspec.py:13-20, models/dataset.py:83-95; SURVEY 8(d) "secondary run U(-80, 0)").  Inputs that large
