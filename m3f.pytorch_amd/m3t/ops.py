@@ -2519,7 +2519,16 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
         # patch matrix, no col2im) -- MIOpen's data gradient (Col2Im3dU + Tensile GEMMs) was ~5 ms of a C5 step
         taps_dx = (ctx.needs_input_grad[0] and CONV3D_TAPS[0] and ctx.pat is not None and tuple(st) == (1, 1, 1) and Co % 32 == 0 and Ci % 64 == 0
                    and ((N_ * T_ * H_ * W_) % 128 == 0 or bool(ctx.prec & _lib.M3T_GEMM_F16X3)) and (ctx.prec & _lib.M3T_GEMM_F16X3 or ctx.prec == 0))
-        if ctx.needs_input_grad[0] and not taps_dx:
+        # round 6: the data gradient of a STRIDED layer (the six stride-2 layers of the per-frame ResNet-18: reference models/resnet.py:24,67-69,
+        # 95-105) as tap walks too -- one per parity class of the input grid.  Input position h = s h' + c receives only the taps k = s j + r with
+        # r = (c + p) mod s, from source row h' + (c + p - r) / s - j: per class a stride-1 walk over the class's sub-grid with the sub-kernel
+        # w[..., r::s] (flipped taps, the same kernel as the stride-1 layers), exactly the forward pass's multiply-adds.  MIOpen's igemm_bwd was
+        # the last library kernel on the training path.
+        strided_dx = (ctx.needs_input_grad[0] and not taps_dx and CONV3D_TAPS[0] and CONV3D_PRESPLIT[0] and ctx.pat is not None
+                      and tuple(st) != (1, 1, 1) and Co % 32 == 0 and Ci % 64 == 0 and bool(ctx.prec & _lib.M3T_GEMM_F16X3) and ctx.a_w is not None)
+        if ctx.needs_input_grad[0] and not taps_dx and not strided_dx:
+            stock_fallback("conv%dd data gradient k%s s%s" % (2 if ctx.as2d else 3, tuple(w.shape), tuple(st)),
+                           "no tap walk for this layer (C_out % 32, C_in % 64, a precision mode without it, or M3T_CONV3D_MIOPEN)")
             if x.shape[2] == 1 and w.shape[2] == 1 and st[0] == 1 and pd[0] == 0:
                 # a 2-D convolution with a unit time axis (models.resnet.GemmConv2d): MIOpen's 2-D data gradient, not its 3-D one
                 dx = torch.ops.aten.convolution_backward(dy.squeeze(2), x.squeeze(2), w.squeeze(2), None, list(st[1:]), list(pd[1:]), [1, 1],
@@ -2528,7 +2537,7 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
                 dx = torch.ops.aten.convolution_backward(dy, x, w, None, list(st), list(pd), [1, 1, 1], False, [0, 0, 0], 1,
                                                          [True, False, False])[0]
         slot_dy = None
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]) or taps_dx:
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]) or taps_dx or strided_dx:
             # dy channels-last [N,T',H',W',Co] = [rows, Co] for the GEMM: the library's tiled transpose (both sides coalesced), which
             # raises dy's magnitude slot on the way -- was torch's strided permute copy plus a measuring launch (1.1 ms of the C5 step)
             dyc = _req(dy.contiguous(), "dy")
@@ -2565,6 +2574,35 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
                 _lib.check(lib().m3t_conv3d_taps(_p(dy_cl), _p(w_taps), _p(dx_cl), N_, Co, Ci, T_, H_, W_, To, Ho, Wo, kt, kh, kw,
                                                  pd[0], pd[1], pd[2], -1, ctx.prec, slot_dy.data_ptr(), ctx.a_w, _p(wsd), wsd.numel() * 4, _p(dx),
                                                  _stream()), "m3t_conv3d_taps")
+        if strided_dx:
+            To, Ho, Wo = dy.shape[2], dy.shape[3], dy.shape[4]
+            dx = torch.zeros(N_, Ci, T_, H_, W_, dtype=torch.float32, device=dy.device)        # (classes without a tap stay zero: 1 x 1 stride-2 shortcuts)
+            wsd = workspace(dy.device)
+            dy_img = torch.empty_like(dy_cl)
+            _lib.check(lib().m3t_f16x3_split(_p(dy_cl), rows, Co, Co, _p(dy_img), Co, slot_dy.data_ptr(), _stream()), "m3t_f16x3_split")
+            dims, ks = (T_, H_, W_), (kt, kh, kw)
+            wd = w.detach()
+            for ct in range(st[0]):
+                for ch in range(st[1]):
+                    for cw_ in range(st[2]):
+                        cls = (ct, ch, cw_)
+                        r = [(cls[a] + pd[a]) % st[a] for a in range(3)]
+                        sub = [len(range(r[a], ks[a], st[a])) for a in range(3)]               # taps of this class per axis
+                        size = [len(range(cls[a], dims[a], st[a])) for a in range(3)]          # the class's sub-grid
+                        if min(sub) < 1 or min(size) < 1:
+                            continue
+                        base = [(cls[a] + pd[a] - r[a]) // st[a] for a in range(3)]
+                        taps = sub[0] * sub[1] * sub[2]
+                        w_t = wd[:, :, r[0]::st[0], r[1]::st[1], r[2]::st[2]].permute(1, 2, 3, 4, 0).contiguous().view(Ci, taps * Co)
+                        w_img = torch.empty_like(w_t)
+                        _lib.check(lib().m3t_f16x3_split(_p(w_t), Ci, taps * Co, taps * Co, _p(w_img), taps * Co, ctx.a_w, _stream()), "m3t_f16x3_split")
+                        crow = N_ * size[0] * size[1] * size[2]
+                        dxc_cl = torch.empty(crow, Ci, dtype=torch.float32, device=dy.device)
+                        dxc = torch.empty(N_, Ci, size[0], size[1], size[2], dtype=torch.float32, device=dy.device)
+                        _lib.check(lib().m3t_conv3d_taps_pre(_p(dy_img), _p(w_img), _p(dxc_cl), N_, Co, Ci, size[0], size[1], size[2], To, Ho, Wo,
+                                                             sub[0], sub[1], sub[2], base[0], base[1], base[2], -1, slot_dy.data_ptr(), ctx.a_w,
+                                                             _p(wsd), wsd.numel() * 4, _p(dxc), _stream()), "m3t_conv3d_taps_pre")
+                        dx[:, :, ct::st[0], ch::st[1], cw_::st[2]].copy_(dxc)
         if ctx.needs_input_grad[1] and impl:
             # the walk turned round: dW^T[(tap, ci)][co] summed over dy's rows, x channels-last from the forward pass (m3t_conv3d_wgrad_taps)
             taps, Kc = kt * kh * kw, impl * kt * kh * kw                      # (impl = 4 for a first layer: its channels padded)

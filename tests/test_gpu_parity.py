@@ -1461,9 +1461,17 @@ def test_c5_resnet3d_cbam_train_mode_golden():
     rs = np.random.RandomState(seed)
     x = dev(rs.randint(0, 256, (B, 3, T, 112, 112)).astype(np.float32))
     x = ((x - 127.5) / 127.5).requires_grad_(True)
+    from m3t import ops
+    stock0 = dict(ops.STOCK_FALLBACKS)
     y = m(x)
     close(y, g["y"], 2e-4, "y")
     (y * dev(g["ct"])).sum().backward()
+    # round 6: no stock (MIOpen) convolution kernel in this training step -- forward, weight gradient and data gradient of every layer,
+    # the six stride-2 layers' data gradient included (parity-class walks), run on the library's tap walks
+    # (the stem's gradient w.r.t. the VIDEO exists only because this test asks for dx: a training step's input needs none)
+    if ops.CONV3D_IMPLICIT[0] and ops.CONV3D_GEMM[0] and ops.CONV3D_TAPS[0]:       # (not under the A/B switches that ask for the other paths)
+        assert {k: v for k, v in ops.STOCK_FALLBACKS.items() if v != stock0.get(k, 0) and k.startswith("conv") and "k(64, 3, " not in k} == {}, \
+            ops.STOCK_FALLBACKS
     check_digests([(n, p.grad) for n, p in m.named_parameters() if p.grad is not None], g, tol=2e-3)
     check_digests([("dx", x.grad)], {"gd.dx": g["dx"]}, tol=2e-3)
     assert _check_bn_state(m, g, 2e-4) >= 60
