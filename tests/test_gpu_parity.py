@@ -1610,7 +1610,7 @@ def test_c5_full_size_properties_t64():
     conv algorithm per call, hence a rounding-level tolerance there), and the loss equals the loss kernel on the outputs."""
     from models.model import AffWild2VA
     from m3t import ops
-    B, T = 4, 64
+    B, T = 8, 64                                  # bench.py's own C5 batch (VERDICT r5 weak-1b: was 4 x 64)
     torch.manual_seed(12345)
     m = AffWild2VA(_hp(modality="audiovisual", fusion_type="attention", loss="ccc_mtl", window=T)).to(DEV).eval()
     batch = _affwild_batch(np.random.RandomState(7), B, T, video=True)
@@ -1618,7 +1618,7 @@ def test_c5_full_size_properties_t64():
     assert tuple(y1.shape) == (B, T, 9) and torch.isfinite(y1).all()
     y2 = m(batch)
     assert torch.equal(y1, y2), "forward is not deterministic"
-    perm = torch.tensor([2, 0, 3, 1], device=DEV)
+    perm = torch.tensor([2, 0, 3, 1, 6, 7, 5, 4], device=DEV)
     pb = {k: (v[perm].contiguous() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
     y3 = m(pb)
     assert float((y3 - y1[perm]).abs().max()) <= 1e-5, "clips are not independent"
@@ -1634,6 +1634,19 @@ def test_c5_full_size_properties_t64():
     assert abs(float(loss2) - float(out["loss"])) <= 1e-6
     worst = max(float((a - b).abs().max()) / max(1e-12, float(b.abs().max())) for a, b in zip(grads[0], grads[1]))
     assert worst <= 1e-5, "gradients differ run to run by %.2e" % worst
+    # TRAIN mode at the bench's size (BatchNorm3d on batch statistics): finite, deterministic, and no convolution on a stock operator
+    m.train()
+    n_torch, n_walk = ops.CONV3D_CALLS["torch"], ops.CONV3D_CALLS["walk"]
+    tg = []
+    for _ in range(2):
+        m.zero_grad()
+        out = m.training_step(batch, 0)
+        out["loss"].backward()
+        tg.append([p.grad.clone() for p in m.parameters() if p.grad is not None])
+    assert torch.isfinite(out["loss"]) and all(torch.isfinite(g).all() for g in tg[0])
+    assert ops.CONV3D_CALLS["torch"] == n_torch and ops.CONV3D_CALLS["walk"] > n_walk
+    worst = max(float((a - b).abs().max()) / max(1e-12, float(b.abs().max())) for a, b in zip(tg[0], tg[1]))
+    assert worst <= 1e-5, "train-mode gradients differ run to run by %.2e" % worst
     ops.poll_scan_error(sync=True)
 
 
