@@ -12,6 +12,7 @@
 // bit-identical to the 128-tile kernels'.  4 waves as 2 (M) x 2 (N), each 64 x 128 = 2 x 4 v_mfma_f32_32x32x16 tiles; 16-k stages,
 // double-buffered LDS, one barrier per stage.  The planner (gemm.hip, plan_gemm) takes it where it fills the chip better.
 #include "common.h"
+#include <atomic>
 #include <cstdlib>
 
 namespace {
@@ -355,15 +356,17 @@ int m3t_sgemm_x6w_launch(int transA, int transB, int M, int N, int K, const floa
     p.act = act; p.accumulate = accumulate; p.splits = splits; p.kchunk = kchunk;
     p.seg_len = seg_len; p.seg_stride = seg_stride; p.a_off = a_off; p.b_off = b_off;
     dim3 grid(N / WN, M / WM, splits), block(WTH);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return M3T_EINVAL;
 #define M3T_X6W_GO(TA_, TB_, SEG_, NS_)                                                                               \
     do {                                                                                                               \
         const size_t lds = 2 * (size_t)stageb(NS_);                                                                    \
-        static bool attr_set = false;                                                                                  \
-        if (!attr_set) {                                                                                               \
+        static std::atomic<unsigned> attr_set{0};           /* one bit per device (was one flag per process) */           \
+        if (!(attr_set.load(std::memory_order_relaxed) & (1u << dev))) {                                               \
             hipError_t ea = hipFuncSetAttribute((const void*)sgemm_x6w_kernel<TA_, TB_, SEG_, NS_>,                    \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
             if (ea != hipSuccess) return (int)ea;                                                                      \
-            attr_set = true;                                                                                           \
+            attr_set.fetch_or(1u << dev, std::memory_order_relaxed);                                                   \
         }                                                                                                              \
         sgemm_x6w_kernel<TA_, TB_, SEG_, NS_><<<grid, block, lds, s>>>(p);                                             \
     } while (0)
@@ -396,11 +399,13 @@ int m3t_sgemm_x6w_bimg_launch(int M, int N, int K, const float* A, int lda, cons
     p.seg_len = p.seg_stride = p.a_off = p.b_off = 0;
     dim3 grid(N / WN, M / WM, splits), block(WTH);
     const size_t lds = 2 * (size_t)stageb(4);
-    static bool attr_set = false;
-    if (!attr_set) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return M3T_EINVAL;
+    static std::atomic<unsigned> attr_set{0};
+    if (!(attr_set.load(std::memory_order_relaxed) & (1u << dev))) {
         hipError_t ea = hipFuncSetAttribute((const void*)sgemm_x6w_kernel<0, 1, false, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (ea != hipSuccess) return (int)ea;
-        attr_set = true;
+        attr_set.fetch_or(1u << dev, std::memory_order_relaxed);
     }
     sgemm_x6w_kernel<0, 1, false, 4, 1><<<grid, block, lds, s>>>(p);
     return (int)hipGetLastError();

@@ -1669,6 +1669,9 @@ bool persist_bwd_uses_x6(const BwdGroup& g, int B, int T, int flags) {
 // for so far (a shadow of the device counters: launches are issued in stream order and every armed launch adds a known amount).
 struct ProgressArm { unsigned* ctr; int n; int tb[3]; unsigned* need; };
 static thread_local ProgressArm g_prog = {nullptr, 0, {0, 0, 0}, nullptr};
+struct ProgressPending { unsigned* ctr; unsigned up, down; };
+static thread_local ProgressPending g_prog_pending = {nullptr, 0, 0};
+struct ProgressTxn { void commit(); ~ProgressTxn(); };
 static std::mutex g_prog_mu;
 static std::unordered_map<uintptr_t, std::pair<unsigned, unsigned>> g_prog_total;      // counter address -> arrivals requested so far (up, down)
 void persist_set_progress(unsigned* ctr, int n, const int* tb, unsigned* need) {
@@ -1700,10 +1703,22 @@ static int apply_progress(const G& g, const bool* up, int wg_per_scan, int T, Ex
         a.need[k] = tot.first + (unsigned)(n_up * wg_per_scan * (k + 1));
         a.need[a.n + k] = tot.second + (unsigned)(n_down * wg_per_scan * (k + 1));
     }
-    tot.first += (unsigned)(n_up * wg_per_scan * a.n);
-    tot.second += (unsigned)(n_down * wg_per_scan * a.n);
+    // the shadow totals move only once the launch has SUCCEEDED (ProgressTxn below; ADVICE r5: a launch that failed after this point -- an
+    // exchange that could not be prepared, dyn < need, a stream-order error -- left host shadow and device counters apart for good, and
+    // every later gate waited for a value that never came)
+    g_prog_pending.ctr = a.ctr;
+    g_prog_pending.up = (unsigned)(n_up * wg_per_scan * a.n);
+    g_prog_pending.down = (unsigned)(n_down * wg_per_scan * a.n);
     return 0;
 }
+void ProgressTxn::commit() {
+    if (!g_prog_pending.ctr) return;
+    std::lock_guard<std::mutex> lock(g_prog_mu);
+    std::pair<unsigned, unsigned>& tot = g_prog_total[(uintptr_t)g_prog_pending.ctr];
+    tot.first += g_prog_pending.up; tot.second += g_prog_pending.down;
+    g_prog_pending.ctr = nullptr;
+}
+ProgressTxn::~ProgressTxn() { g_prog_pending.ctr = nullptr; }      // (not committed: rolled back -- nothing was added)
 
 // m3t_gru_bwd_prepare: the wide producer-split backward kernel's W_hh^T fragments, ahead of the scan (see persist_bwd_launch)
 int persist_bwd_prepare(const float* const* w, int n, int H, int direct, float* const* out, hipStream_t s) {
@@ -1756,7 +1771,14 @@ static int fwd_uw(const FwdGroup& g, int B, int T, int flags, const Shape& sh) {
     return ((flags & M3T_SCAN_WIDE) && fwd_is_f16(g, B, T, flags) && (sh.nc == 4 || sh.nc == 2) && sh.rt == 1 && wide_enabled()) ? 2 : 1;
 }
 
+static int persist_fwd_launch_impl(const FwdGroup& g, const FragPtrs& fp, int B, int T, int flags, hipStream_t s);
 int persist_fwd_launch(const FwdGroup& g, const FragPtrs& fp, int B, int T, int flags, hipStream_t s) {
+    ProgressTxn txn;
+    const int rc = persist_fwd_launch_impl(g, fp, B, T, flags, s);
+    if (rc == 0) txn.commit();
+    return rc;
+}
+static int persist_fwd_launch_impl(const FwdGroup& g, const FragPtrs& fp, int B, int T, int flags, hipStream_t s) {
     Shape sh;
     if (!level_shape(g.d, g.n, B, sh) || !ensure_err_word()) return M3T_EINVAL;
     const int uw = fwd_uw(g, B, T, flags, sh);
@@ -1855,7 +1877,14 @@ static bool bwd3p_enabled() {
     return on == 1;
 }
 
+static int persist_bwd_launch_impl(const BwdGroup& g, const FragPtrs& fp, int B, int T, int flags, hipStream_t s);
 int persist_bwd_launch(const BwdGroup& g, const FragPtrs& fp, int B, int T, int flags, hipStream_t s) {
+    ProgressTxn txn;
+    const int rc = persist_bwd_launch_impl(g, fp, B, T, flags, s);
+    if (rc == 0) txn.commit();
+    return rc;
+}
+static int persist_bwd_launch_impl(const BwdGroup& g, const FragPtrs& fp, int B, int T, int flags, hipStream_t s) {
     Shape sh;
     if (!level_shape(g.d, g.n, B, sh) || !ensure_err_word()) return M3T_EINVAL;
     ExPtrs ex;

@@ -140,9 +140,11 @@ class on_stream:
         st = self.st
         if st is None:
             return None
-        if _SET_STREAM is None:
-            self.prev = torch.cuda.current_stream(st.device)
-            torch.cuda.set_stream(st)
+        if _SET_STREAM is None or st.device_index != _CUR_DEV():
+            # another device than the current one: _cuda_setStream would switch the device and leave it switched -- torch's
+            # own context restores both
+            self.prev = torch.cuda.stream(st)
+            self.prev.__enter__()
             return st
         self.prev = cur_stream(st.device)
         _SET_STREAM(stream_id=st.stream_id, device_index=st.device_index, device_type=st.device_type)
@@ -152,8 +154,8 @@ class on_stream:
         if self.st is None:
             return False
         p = self.prev
-        if _SET_STREAM is None:
-            torch.cuda.set_stream(p)
+        if isinstance(p, torch.cuda.StreamContext):
+            p.__exit__(*exc)
         else:
             _SET_STREAM(stream_id=p.stream_id, device_index=p.device_index, device_type=p.device_type)
         return False
@@ -214,6 +216,14 @@ _WGRAD = {}
 _N_WGRAD = 2
 
 
+def _wait_slot_fill(st, key):
+    """a stream created AFTER the live chunk of the magnitude-slot pool was zero-filled is ordered behind that fill (amax_slots only
+    made the streams that existed then wait)"""
+    pool = _SLOT_POOL.get(key)
+    if pool is not None and len(pool) > 2:
+        st.wait_event(pool[2])
+
+
 def side_stream(device):
     key = (device.type, device.index)
     st = _SIDE.get(key)
@@ -221,6 +231,7 @@ def side_stream(device):
         st = torch.cuda.Stream(device=device)
         _SIDE[key] = st
         _ROLE_OF_HANDLE[(st.device.index, st.cuda_stream)] = "side"
+        _wait_slot_fill(st, key)
     return st
 
 
@@ -245,6 +256,7 @@ def wgrad_stream(device, i=0):
         _WGRAD[key] = sts
         for i_, st_ in enumerate(sts):
             _ROLE_OF_HANDLE[(st_.device.index, st_.cuda_stream)] = "wgrad%d" % i_
+            _wait_slot_fill(st_, key)
     return sts[i % min(2, len(sts))]          # (streams 2.. only ever take tail GEMMs, see _MultiBiGRU.backward.level_dw)
 
 
@@ -356,9 +368,17 @@ def amax_slots(n, device):
         if device.type == "cuda":
             ev = torch.cuda.Event()
             ev.record(cur_stream(device))
-            for other in ([_SIDE.get(key)] if _SIDE.get(key) is not None else []) + list(_WGRAD.get(key) or []):
+            others = ([_SIDE.get(key)] if _SIDE.get(key) is not None else []) + list(_WGRAD.get(key) or [])
+            for other in others:
                 other.wait_event(ev)
             st.append(ev)
+            st.append({cur_stream(device).cuda_stream} | {o.cuda_stream for o in others})      # raw handles already ordered behind the fill
+    if len(st) > 3 and device.type == "cuda":
+        # a consumer on another stream than the one that filled the chunk (a caller's own stream, FlatGradDDP's early-bucket stream): wait once
+        h = _RAW_STREAM(device.index if device.index is not None else _CUR_DEV()) if _RAW_STREAM is not None else None
+        if h is not None and h not in st[3]:
+            cur_stream(device).wait_event(st[2])
+            st[3].add(h)
     v = st[0][st[1]:st[1] + n]
     st[1] += n
     return v
@@ -721,7 +741,11 @@ def poll_scan_error(sync=False, force=False):
         return
     if sync and torch.cuda.is_available():
         torch.cuda.synchronize()
-    _lib.poll_scan_error()
+    try:
+        _lib.poll_scan_error()
+    except M3THipError:
+        reset_progress()             # a dead scan may have left its progress counters short of what the library's shadow expects
+        raise
 
 
 def inject_scan_error():
@@ -792,6 +816,14 @@ def _progress_counters(device):
         t = _PROGRESS[key] = torch.zeros(2, dtype=torch.int32, device=device)
         _lib.check(lib().m3t_gru_scan_progress_reset(C.c_void_p(t.data_ptr())), "m3t_gru_scan_progress_reset")
     return t
+
+
+def reset_progress():
+    """after a scan error: the device's progress words and the library's shadow totals start from zero again (the raise that leads here has
+    synchronised the device: nothing is in flight)"""
+    for t in _PROGRESS.values():
+        t.zero_()
+        _lib.check(lib().m3t_gru_scan_progress_reset(C.c_void_p(t.data_ptr())), "m3t_gru_scan_progress_reset")
 
 
 def _chunk_bounds(B, T, n=None, backward=False):
