@@ -120,15 +120,18 @@ int m3t_sgemm_pre(int M, int N, int K, const float* A_img, int lda, const float*
 int m3t_f16x3_image_b(const float* w, int N, int K, size_t ld, float* img, const unsigned long long* slot, void* stream);
 int m3t_sgemm_bimg(int M, int N, int K, const float* A, int lda, const float* B_img, float* C, int ldc, const float* bias, int act,
                    int accumulate, float* ws, size_t ws_bytes, const unsigned long long* amax_a, const unsigned long long* amax_b, void* stream);
-/* Round 6: the fp16x3 product of m3t_sgemm_scaled on the 256 x 256 "ring" kernel (csrc/gemm_ring.hip): both operands reach LDS as raw fp32 by
+/* Round 6: the fp16x3 product of m3t_sgemm_scaled on the 256 x 256 "ring" kernels (csrc/gemm_ring.hip): both operands reach LDS as raw fp32 by
  * LDS-DMA (global_load_lds_dwordx4) into a ring of four 16-k stages, counted vmcnt in front of the stage's single barrier, the two-term split on
- * the fragment read.  Bit-identical to m3t_sgemm_scaled under the same slots (same split, same MFMA operand placement, same product and k
- * order, same split-K slabs).  NT only for now (transA = 0, transB = 1: nn.Linear, reference models/rnn.py:17,22-55,75); N % 256 == 0,
- * K % 16 == 0, any M, 16-B aligned operands with ld % 4 == 0; splits >= 1 slabs (ws of splits * M * N floats when > 1); NULL slots are
- * measured; `variant` selects a build of the main loop (0 = default; tools/ring_bench.py). */
+ * the fragment read.  Same arithmetic as m3t_sgemm_scaled under the same slots (same split, same MFMA operand placement, same product and k
+ * order, same split-K slabs: bit-identical where both take the same K passes).  transA / transB / seg_* as m3t_sgemm (nn.Linear, the GRU input
+ * projections and their gradients: reference models/rnn.py:17,22-55,75; transA = transB = 1 has no caller and is refused); row-contiguous
+ * operands (transA = 1, transB = 0) are fetched a k row per LDS-DMA instruction and read back with ds_read2st64_b32 -- no cross-lane
+ * transpose.  N % 256 == 0, K % 16 == 0 (K % seg_len == 0, seg_len >= 32 when segmented), any M (M % 4 == 0 with transA = 1), 16-B aligned
+ * operands with ld % 4 == 0; splits >= 1 slabs (ws of splits * M * N floats when > 1); NULL slots are measured; `variant` selects a build of
+ * the NT main loop (0 = plain, 3 = pipelined reads + v_fma_mix split; tools/ring_bench.py). */
 int m3t_sgemm_ring(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                   const float* bias, int act, int accumulate, float* ws, size_t ws_bytes, int splits,
-                   const unsigned long long* amax_a, const unsigned long long* amax_b, int variant, void* stream);
+                   const float* bias, int act, int accumulate, int seg_len, int seg_stride, int a_off, int b_off, float* ws, size_t ws_bytes,
+                   int splits, const unsigned long long* amax_a, const unsigned long long* amax_b, int variant, void* stream);
 int m3t_conv3d_taps_pre(const float* src_img, const float* w_img, float* dst, int N, int C_src, int C_dst, int T, int H, int W,
                         int To, int Ho, int Wo, int kt, int kh, int kw, int base_t, int base_h, int base_w, int sign,
                         const unsigned long long* amax_src, const unsigned long long* amax_w, float* ws, size_t ws_bytes, float* dst_planes,
@@ -436,9 +439,11 @@ int m3t_va_loss(const float* y_hat, int rows, int C, int iv, int ia,
                 const int64_t* class_expr, const uint8_t* expr_valid, int n_expr,
                 float w_v, float w_a, float expr_w, int use_mse,
                 float* out_scalars, float* dy, float* ws, size_t ws_bytes, void* stream);
-/* ws: 32 floats per 256 rows (m3t_va_loss_ws_bytes).  With it, rows > 1024 run as three short grid-wide launches
- * (sums -> centred moments -> closed form + gradient; per-block partials reduced in a fixed order by every block); without
- * it, or for rows <= 1024, one workgroup does all passes. */
+/* ws: 32 floats per 256 rows (m3t_va_loss_ws_bytes), 8-B aligned.  With it, 1024 < rows <= 32768 run as ONE grid-wide launch (round 6): raw
+ * moments in fp64 in one sweep, the blocks meet once inside the kernel (agent-scope release + ticket, bounded wait: a wait that expires gives
+ * loss = NaN), every block sums all partials in block order (deterministic) and writes its rows of dL/dy; M3T_VA_LOSS_FUSED=0 or more
+ * rows: three short launches (sums -> centred moments -> closed form + gradient); without ws, or for rows <= 1024, one workgroup does all
+ * passes. */
 size_t m3t_va_loss_ws_bytes(int rows);
 
 /* ---------------------------------------------------------------------------------

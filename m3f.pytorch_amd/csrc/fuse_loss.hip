@@ -4,6 +4,8 @@
 // row, float4 (16 B/lane) accesses, wavefront-shuffle reductions, no atomics.
 #include "gru_common.h"
 #include <cmath>
+#include <cstdlib>
+#include <mutex>
 
 namespace {
 
@@ -306,6 +308,157 @@ __global__ __launch_bounds__(LB) void va_loss_grad_kernel(const float* __restric
     if (wa != 0.f) g[ia] += wa * ga;
 }
 
+// Round 6: the same loss as ONE launch (three launches for 1.9 MB are three launch latencies on the chain between forward
+// and backward).  One sweep gathers RAW moments in fp64 (sum y, sum t, sum y^2, sum t^2, sum y t, sum (y - t)^2 per output, the masked CE terms):
+// every centred statistic of the two-pass form follows from them without cancellation trouble at fp64 (9 600 values of magnitude ~1), so the
+// grid needs ONE meeting point instead of two: each block publishes its partials (agent-scope release + ticket), waits -- bounded -- until
+// all have, sums the partials of ALL blocks in block order (deterministic, identical in every block) and writes its rows of dL/dy.  The two
+// ticket words live in a library-owned allocation per device; the last block to leave resets them.  Blocks must be co-resident: the host
+// takes this path for at most 128 blocks (32 768 rows), else the three launches above.
+struct VaSync { unsigned arrive, depart; };
+constexpr int VP = 16;                                // doubles per block: 0-5 valence (y, t, yy, tt, yt, (y-t)^2), 6-11 arousal, 12 CE, 13 n_valid, 14 n_correct
+
+__global__ __launch_bounds__(LB) void va_loss_fused_kernel(const float* __restrict__ y, int rows, int C, int iv, int ia,
+                                                           const float* __restrict__ val, const float* __restrict__ aro,
+                                                           const int64_t* __restrict__ cls, const uint8_t* __restrict__ valid,
+                                                           int n_expr, float wv, float wa, float expr_w, int use_mse,
+                                                           double* __restrict__ part, VaSync* __restrict__ sync, int spin_limit,
+                                                           float* __restrict__ out, float* __restrict__ dy) {
+    __shared__ double wred[LB / 64][VP];
+    __shared__ double tot[VP];
+    const int i = blockIdx.x * LB + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nb = gridDim.x;
+    double v[VP];
+#pragma unroll
+    for (int k = 0; k < VP; ++k) v[k] = 0.0;
+    float a = 0.f, b = 0.f, c = 0.f, e = 0.f;
+    if (i < rows) {
+        const float* l = y + (size_t)i * C;
+        a = l[iv]; b = val[i]; c = l[ia]; e = aro[i];
+        v[0] = a; v[1] = b; v[2] = (double)a * a; v[3] = (double)b * b; v[4] = (double)a * b; v[5] = ((double)a - b) * ((double)a - b);
+        v[6] = c; v[7] = e; v[8] = (double)c * c; v[9] = (double)e * e; v[10] = (double)c * e; v[11] = ((double)c - e) * ((double)c - e);
+        if (n_expr > 0 && valid[i]) {
+            float m = l[0];
+            int am = 0;
+            for (int k = 1; k < n_expr; ++k)
+                if (l[k] > m) { m = l[k]; am = k; }
+            float se = 0.f;
+            for (int k = 0; k < n_expr; ++k) se += expf(l[k] - m);
+            const int lab = (int)cls[i];
+            v[12] = m + logf(se) - l[lab];
+            v[13] = 1.0;
+            v[14] = (am == lab) ? 1.0 : 0.0;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 15; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o, 64);
+        if (lane == 0) wred[wave][k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < VP) {
+        double s = 0.0;
+        if (threadIdx.x < 15)
+            for (int w = 0; w < LB / 64; ++w) s += wred[w][threadIdx.x];
+        part[(size_t)blockIdx.x * VP + threadIdx.x] = s;
+    }
+    // publish: every storing thread's stores done, the block's barrier, then ONE agent-scope release and the ticket (guide, Guideline 16)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(&sync->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        while (__hip_atomic_load(&sync->arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nb) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > spin_limit) break;              // (bounded like every wait of the library: the loss comes out NaN below)
+        }
+        tot[VP - 1] = spins > spin_limit ? 1.0 : 0.0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    const bool gave_up = tot[VP - 1] != 0.0;
+    __syncthreads();
+    if (threadIdx.x < 15) {
+        double s = 0.0;
+        for (int bk = 0; bk < nb; ++bk) s += part[(size_t)bk * VP + threadIdx.x];       // block order: the same sum in every block
+        tot[threadIdx.x] = s;
+    }
+    __syncthreads();
+    const double n = (double)rows, invn_d = 1.0 / n, nm1_d = 1.0 / (double)(rows > 1 ? rows - 1 : 1);
+    const double mxv_d = tot[0] * invn_d, mtv_d = tot[1] * invn_d, mxa_d = tot[6] * invn_d, mta_d = tot[7] * invn_d;
+    const double cv = tot[4] - n * mxv_d * mtv_d, xv = tot[2] - n * mxv_d * mxv_d, tv = tot[3] - n * mtv_d * mtv_d;
+    const double ca = tot[10] - n * mxa_d * mta_d, xa = tot[8] - n * mxa_d * mxa_d, ta = tot[9] - n * mta_d * mta_d;
+    const float invn = (float)invn_d, nm1 = (float)nm1_d;
+    const float mxv = (float)mxv_d, mtv = (float)mtv_d, mxa = (float)mxa_d, mta = (float)mta_d;
+    const float covv = (float)(cv * invn_d), covA = (float)(ca * invn_d);
+    const float denv = (float)(xv * nm1_d + tv * nm1_d + (mxv_d - mtv_d) * (mxv_d - mtv_d));
+    const float dena = (float)(xa * nm1_d + ta * nm1_d + (mxa_d - mta_d) * (mxa_d - mta_d));
+    const float cccv = 2.f * covv / denv, ccca = 2.f * covA / dena;
+    const float loss_e = (float)(tot[12] * invn_d), nvalid = (float)tot[13];
+    const bool use_e = n_expr > 0 && nvalid > 0.f;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const float lv = wv == 0.f ? 0.f : (use_mse ? (float)(tot[5] * invn_d) : 1.f - cccv);
+        const float la = wa == 0.f ? 0.f : (use_mse ? (float)(tot[11] * invn_d) : 1.f - ccca);
+        out[0] = gave_up ? __builtin_nanf("") : wv * lv + wa * la + (use_e ? expr_w * loss_e : 0.f);
+        out[1] = lv; out[2] = la; out[3] = loss_e; out[4] = nvalid; out[5] = (float)tot[14]; out[6] = cccv; out[7] = ccca;
+    }
+    if (i < rows) {
+        float* g = dy + (size_t)i * C;
+        const float* l = y + (size_t)i * C;
+        for (int k = 0; k < C; ++k) g[k] = 0.f;
+        if (use_e && valid[i]) {
+            float m = l[0];
+            for (int k = 1; k < n_expr; ++k) m = fmaxf(m, l[k]);
+            float se = 0.f;
+            for (int k = 0; k < n_expr; ++k) se += expf(l[k] - m);
+            const float sc = expr_w * invn;
+            const int lab = (int)cls[i];
+            for (int k = 0; k < n_expr; ++k) g[k] = sc * (expf(l[k] - m) / se - (k == lab ? 1.f : 0.f));
+        }
+        float gv, ga;
+        if (use_mse) {
+            gv = 2.f * (a - b) * invn;
+            ga = 2.f * (c - e) * invn;
+        } else {
+            const float dcv = 2.f * (b - mtv) * invn / denv -
+                              (2.f * covv / (denv * denv)) * (2.f * (a - mxv) * nm1 + 2.f * (mxv - mtv) * invn);
+            const float dca = 2.f * (e - mta) * invn / dena -
+                              (2.f * covA / (dena * dena)) * (2.f * (c - mxa) * nm1 + 2.f * (mxa - mta) * invn);
+            gv = -dcv;
+            ga = -dca;
+        }
+        if (wv != 0.f) g[iv] += wv * gv;
+        if (wa != 0.f) g[ia] += wa * ga;
+    }
+    // leave: the last block out resets both words for the next launch (stream order: a kernel boundary lies in between)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned d = __hip_atomic_fetch_add(&sync->depart, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (d == (unsigned)nb - 1u) {
+            __hip_atomic_store(&sync->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sync->depart, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+static VaSync* va_sync_words() {                      // two zeroed words per device, allocated on first use and never freed
+    static VaSync* words[32] = {};
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!words[dev]) {
+        VaSync* p = nullptr;
+        if (hipMalloc(&p, sizeof(VaSync)) != hipSuccess) return nullptr;
+        if (hipMemset(p, 0, sizeof(VaSync)) != hipSuccess) { (void)hipFree(p); return nullptr; }
+        words[dev] = p;
+    }
+    return words[dev];
+}
+
 // ------------------------------------------------------------------------------ DDP helpers
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, size_t n, float* __restrict__ part,
                                                             const unsigned* __restrict__ scan_err) {
@@ -460,6 +613,19 @@ extern "C" int m3t_va_loss(const float* y_hat, int rows, int C, int iv, int ia, 
     if (rows <= 0 || C <= 0 || iv < 0 || ia < 0 || iv >= C || ia >= C || n_expr > C) return M3T_EINVAL;
     if (!y_hat || !valence || !arousal || !out_scalars || !dy) return M3T_EINVAL;
     if (n_expr > 0 && (!class_expr || !expr_valid)) return M3T_EINVAL;
+    static const bool fused_on = !(getenv("M3T_VA_LOSS_FUSED") && getenv("M3T_VA_LOSS_FUSED")[0] == '0');
+    if (rows > 1024 && ws && ws_bytes >= m3t_va_loss_ws_bytes(rows) && cdiv(rows, LB) <= 128 && fused_on && ((uintptr_t)ws % 8) == 0) {
+        // one launch (round 6): the blocks meet once inside the kernel; <= 128 blocks so that all are resident whatever else runs
+        VaSync* sync = va_sync_words();
+        if (sync) {
+            const int nb = cdiv(rows, LB);
+            va_loss_fused_kernel<<<nb, LB, 0, (hipStream_t)stream>>>(y_hat, rows, C, iv, ia, valence, arousal, class_expr, expr_valid, n_expr, w_v,
+                                                                     w_a, expr_w, use_mse, reinterpret_cast<double*>(ws), sync, 1 << 22,
+                                                                     out_scalars, dy);
+            M3T_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if (rows > 1024 && ws && ws_bytes >= m3t_va_loss_ws_bytes(rows)) {
         const int nb = cdiv(rows, LB);
         float* partA = ws;

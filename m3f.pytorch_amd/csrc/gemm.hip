@@ -911,31 +911,36 @@ extern "C" int m3t_sgemm_bimg(int M, int N, int K, const float* A, int lda, cons
 }
 
 int m3t_sgemm_ring_launch(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                          const float* bias, int act, int accumulate, float* ws, int splits, int kchunk, const unsigned long long* amax_a,
-                          const unsigned long long* amax_b, int variant, hipStream_t s);
+                          const float* bias, int act, int accumulate, int seg_len, int seg_stride, int a_off, int b_off, float* ws, int splits,
+                          int kchunk, const unsigned long long* amax_a, const unsigned long long* amax_b, int variant, hipStream_t s);
 
-// include/m3t_hip.h: the fp16x3 product of m3t_sgemm_scaled on the 256 x 256 LDS-DMA ring kernel (gemm_ring.hip)
+// include/m3t_hip.h: the fp16x3 product of m3t_sgemm_scaled on the 256 x 256 LDS-DMA ring kernels (gemm_ring.hip)
 extern "C" int m3t_sgemm_ring(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                              const float* bias, int act, int accumulate, float* ws, size_t ws_bytes, int splits,
-                              const unsigned long long* amax_a, const unsigned long long* amax_b, int variant, void* stream) {
+                              const float* bias, int act, int accumulate, int seg_len, int seg_stride, int a_off, int b_off, float* ws,
+                              size_t ws_bytes, int splits, const unsigned long long* amax_a, const unsigned long long* amax_b, int variant,
+                              void* stream) {
     if (M <= 0 || N <= 0) return 0;
     if (!A || !B || !C || K <= 0 || !m3t_f16x3_enabled() || N % 256 != 0 || K % 16 != 0 || lda % 4 != 0 || ldb % 4 != 0 ||
         (uintptr_t)A % 16 != 0 || (uintptr_t)B % 16 != 0 || splits < 1)
         return M3T_EINVAL;
-    if (transA != 0 || transB != 1) return M3T_EINVAL;
+    if ((transA == 1 && transB == 1) || (transA == 1 && M % 4 != 0)) return M3T_EINVAL;
+    if (seg_len > 0 && !(transA == 1 && transB == 0 && seg_len >= 32 && K % seg_len == 0)) return M3T_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const unsigned long long* use_a = amax_a; const unsigned long long* use_b = amax_b;
     if (!amax_a || !amax_b) {
-        const M3TRegion ra{A, (unsigned long long)(transA ? K : M), (unsigned long long)lda, (transA ? M : K) / 4, nullptr};
-        const M3TRegion rb{B, (unsigned long long)(transB ? N : K), (unsigned long long)ldb, (transB ? K : N) / 4, nullptr};
+        const size_t kr = seg_len > 0 ? (size_t)(K / seg_len - 1) * seg_stride + seg_len : (size_t)K;
+        const float* A0 = seg_len > 0 ? A + (size_t)a_off * lda : A;
+        const float* B0 = seg_len > 0 ? B + (size_t)b_off * ldb : B;
+        const M3TRegion ra{A0, (unsigned long long)(transA ? kr : (size_t)M), (unsigned long long)lda, (transA ? M : K) / 4, nullptr};
+        const M3TRegion rb{B0, (unsigned long long)(transB ? (size_t)N : kr), (unsigned long long)ldb, (transB ? K : N) / 4, nullptr};
         const int rm = m3t_f16x3_measure(ra, amax_a, rb, amax_b, &use_a, &use_b, s);
         if (rm) return rm;
     }
     int kchunk = cdiv(cdiv(K, splits), 32) * 32;                 // (the slabs of plan_gemm)
     splits = cdiv(K, kchunk);
     if (splits > 1 && (!ws || ws_bytes < (size_t)splits * M * N * sizeof(float))) return M3T_EINVAL;
-    const int rc = m3t_sgemm_ring_launch(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, ws, splits, kchunk, use_a, use_b,
-                                         variant, s);
+    const int rc = m3t_sgemm_ring_launch(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, seg_len, seg_stride, a_off, b_off,
+                                         ws, splits, kchunk, use_a, use_b, variant, s);
     if (rc) return rc;
     if (splits > 1) { launch_splitk_reduce(ws, C, bias, M, N, ldc, splits, act, accumulate, s); M3T_LAUNCH_CHECK(); }
     return 0;

@@ -60,7 +60,7 @@ SIGNATURES = {
     "m3t_f16x3_split": [_f, _z, _i, _z, _f, _z, _f, _s],
     "m3t_f16x3_image_b": [_f, _i, _i, _z, _f, _f, _s],
     "m3t_sgemm_bimg": [_i, _i, _i, _f, _i, _f, _f, _i, _f, _i, _i, _f, _z, _f, _f, _s],
-    "m3t_sgemm_ring": [_i, _i, _i, _i, _i, _f, _i, _f, _i, _f, _i, _f, _i, _i, _f, _z, _i, _f, _f, _i, _s],
+    "m3t_sgemm_ring": [_i, _i, _i, _i, _i, _f, _i, _f, _i, _f, _i, _f, _i, _i, _i, _i, _i, _i, _f, _z, _i, _f, _f, _i, _s],
     "m3t_conv3d_taps_pre": [_f, _f, _f] + [_i] * 16 + [_f, _f, _f, _z, _f, _s],
     "m3t_conv3d_fwd_taps": [_f, _f, _f, _f] + [_i] * 15 + [_f, _f, _f, _z, _f, _s],
     "m3t_conv3d_fwd_taps4": [_f, _f, _f, _f] + [_i] * 14 + [_f, _f, _f, _z, _f, _s],

@@ -231,3 +231,57 @@ def test_weight_image_by_lds_dma_is_bit_identical(M, N, K):
     with pytest.raises(_lib.M3THipError):
         _lib.check(lib.m3t_sgemm_bimg(M, N + 64, K, ops._p(A), K, ops._p(img), ops._p(C1), N, None, 0, 0, None, 0, sl.data_ptr(),
                                       sl.data_ptr() + 8, ops._stream()), "m3t_sgemm_bimg")       # N % 256 != 0
+
+
+@pytest.mark.parametrize("tA,tB,M,N,K,splits,seg", [(0, 1, 9600, 1536, 1024, 1, False), (0, 1, 9472, 1024, 1536, 1, False), (0, 1, 1000, 512, 2048, 1, False),
+                                                     (0, 1, 1536, 256, 9600, 8, False), (0, 1, 200, 256, 64, 1, False),
+                                                     (1, 0, 1536, 1024, 9600, 10, False), (1, 0, 384, 256, 4800, 3, False), (1, 0, 1536, 512, 9568, 4, True),
+                                                     (0, 0, 9600, 1024, 1536, 1, False), (0, 0, 1000, 256, 768, 1, False)])
+@pytest.mark.parametrize("variant", [0, 3])
+def test_ring_gemm_is_bit_identical(tA, tB, M, N, K, splits, seg, variant):
+    """m3t_sgemm_ring (round 6, csrc/gemm_ring.hip): the products of nn.Linear / the GRU input projections and their gradients (reference
+    models/rnn.py:17,22-55,75: NT forward, NN data gradient, TN weight gradient, segmented TN for dW_hh) on the 256 x 256 tile kernels whose
+    operands reach LDS as raw fp32 by LDS-DMA (a ring of four 16-k stages, counted vmcnt) and are split on the fragment read.  The same
+    arithmetic as m3t_sgemm_scaled bit for bit where both take the same K passes (one, or the same slabs) -- for NT the plain loop (variant 0)
+    and the pipelined one with the v_fma_mix low terms (variant 3) --, ragged M, bias / accumulate; against fp64 everywhere.  Wide dynamic
+    range in A: the low terms' subnormal range is exercised."""
+    from m3t import ops, _lib
+    if (tA, tB) != (0, 1) and variant != 0:
+        pytest.skip("one build of the row-contiguous kernels")
+    rs = np.random.RandomState(M + N + K + variant + 2 * tA + tB)
+    sg = (299, 300, 1, 0) if seg else (0, 0, 0, 0)
+    if seg:
+        A, W = _rand(rs, 9600, M), _rand(rs, 9600, 2 * N, scale=0.05)
+    else:
+        A, W = _rand(rs, *((K, M) if tA else (M, K))), _rand(rs, *((N, K) if tB else (K, N)), scale=0.05)
+    bias = _rand(rs, N)
+    A = A * torch.exp(torch.from_numpy(rs.standard_normal(tuple(A.shape)).astype(np.float32) * 4.0).to(A.device))      # elements down to 1e-7 of the maximum
+    sl = ops.amax_slots(2, A.device)
+    ops.measure_amax([(A, sl.data_ptr()), (W, sl.data_ptr() + 8)])
+    lib = ops.lib()
+    ws = ops.workspace(A.device)
+    kern, spl = ops.sgemm_plan(tA, M, N, K, seg_len=sg[0])
+    for accumulate in (False, True):
+        C0 = torch.full((M, N), 0.5, device=DEV)
+        C1 = torch.full((M, N), 0.5, device=DEV)
+        with ops.precision("fp32"):
+            ops.sgemm(tA, tB, M, N, K, A, 0, A.shape[1], W, 0, W.shape[1], C0, 0, N, bias=bias, accumulate=accumulate, seg=sg,
+                      amax=(sl.data_ptr(), sl.data_ptr() + 8))
+        _lib.check(lib.m3t_sgemm_ring(tA, tB, M, N, K, ops._p(A), A.shape[1], ops._p(W), W.shape[1], ops._p(C1), N, ops._p(bias), 0, int(accumulate),
+                                      sg[0], sg[1], sg[2], sg[3], ops._p(ws), ws.numel() * 4, splits, sl.data_ptr(), sl.data_ptr() + 8, variant,
+                                      ops._stream()), "m3t_sgemm_ring")
+        torch.cuda.synchronize()
+        if kern == 1 and spl == splits and M % 128 == 0:      # m3t_sgemm_scaled ran the fp16x3 tile kernel with the same K passes: the same sums in the same order
+            assert torch.equal(C0, C1), float((C0 - C1).abs().max())
+        else:
+            assert float((C0 - C1).abs().max()) <= 4e-6 * float(C0.abs().max())
+    if seg:
+        Ad = torch.cat([A[c * 300 + 1:c * 300 + 300] for c in range(32)]).double()
+        Wd = torch.cat([W[c * 300:c * 300 + 299, :N] for c in range(32)]).double()
+        ref = Ad.t() @ Wd + bias.double() + 0.5
+    else:
+        ref = (A.double().t() if tA else A.double()) @ (W.double().t() if tB else W.double()) + bias.double() + 0.5
+    assert float((C1.double() - ref).abs().max() / ref.abs().max()) < 2e-6
+    with pytest.raises(_lib.M3THipError):
+        _lib.check(lib.m3t_sgemm_ring(tA, tB, M, N + 64, K, ops._p(A), A.shape[1], ops._p(W), W.shape[1], ops._p(C1), N, None, 0, 0, 0, 0, 0, 0,
+                                      None, 0, 1, sl.data_ptr(), sl.data_ptr() + 8, 0, ops._stream()), "m3t_sgemm_ring")       # N % 256 != 0
