@@ -640,7 +640,8 @@ static GemmPlan plan_gemm(int transA, int M, int N, int K, int seg_len, bool vec
 
 extern "C" int m3t_sgemm_plan(int transA, int M, int N, int K, int seg_len, size_t ws_bytes, int flags, int* kernel, int* splits) {
     if (M <= 0 || N <= 0 || K < 0 || !kernel || !splits) return M3T_EINVAL;
-    const GemmPlan g = plan_gemm(transA, M, N, K, seg_len, true, ws_bytes, flags);
+    // (the 128 x 256 tile exists for NT products only: a transA = 1 call never takes it; with transA = 0 this reports the NT form's plan)
+    const GemmPlan g = plan_gemm(transA, M, N, K, seg_len, true, ws_bytes, flags | (transA ? GEMM_NO_WIDE : 0));
     *kernel = g.kernel; *splits = g.splits;
     return 0;
 }

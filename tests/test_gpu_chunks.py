@@ -260,21 +260,28 @@ def test_ring_gemm_is_bit_identical(tA, tB, M, N, K, splits, seg, variant):
     ops.measure_amax([(A, sl.data_ptr()), (W, sl.data_ptr() + 8)])
     lib = ops.lib()
     ws = ops.workspace(A.device)
-    kern, spl = ops.sgemm_plan(tA, M, N, K, seg_len=sg[0])
+    kern, _ = ops.sgemm_plan(tA, M, N, K, seg_len=sg[0])
     for accumulate in (False, True):
         C0 = torch.full((M, N), 0.5, device=DEV)
         C1 = torch.full((M, N), 0.5, device=DEV)
+        C2 = torch.full((M, N), 0.5, device=DEV)
         with ops.precision("fp32"):
-            ops.sgemm(tA, tB, M, N, K, A, 0, A.shape[1], W, 0, W.shape[1], C0, 0, N, bias=bias, accumulate=accumulate, seg=sg,
+            # ONE K pass on both sides (use_ws=False: m3t_sgemm_scaled without split-K slabs): the same sums in the same order
+            ops.sgemm(tA, tB, M, N, K, A, 0, A.shape[1], W, 0, W.shape[1], C0, 0, N, bias=bias, accumulate=accumulate, seg=sg, use_ws=False,
                       amax=(sl.data_ptr(), sl.data_ptr() + 8))
-        _lib.check(lib.m3t_sgemm_ring(tA, tB, M, N, K, ops._p(A), A.shape[1], ops._p(W), W.shape[1], ops._p(C1), N, ops._p(bias), 0, int(accumulate),
-                                      sg[0], sg[1], sg[2], sg[3], ops._p(ws), ws.numel() * 4, splits, sl.data_ptr(), sl.data_ptr() + 8, variant,
+        args = (tA, tB, M, N, K, ops._p(A), A.shape[1], ops._p(W), W.shape[1])
+        tail = (sg[0], sg[1], sg[2], sg[3], ops._p(ws), ws.numel() * 4)
+        _lib.check(lib.m3t_sgemm_ring(*args, ops._p(C1), N, ops._p(bias), 0, int(accumulate), *tail, 1, sl.data_ptr(), sl.data_ptr() + 8, variant,
+                                      ops._stream()), "m3t_sgemm_ring")
+        _lib.check(lib.m3t_sgemm_ring(*args, ops._p(C2), N, ops._p(bias), 0, int(accumulate), *tail, splits, sl.data_ptr(), sl.data_ptr() + 8, variant,
                                       ops._stream()), "m3t_sgemm_ring")
         torch.cuda.synchronize()
-        if kern == 1 and spl == splits and M % 128 == 0:      # m3t_sgemm_scaled ran the fp16x3 tile kernel with the same K passes: the same sums in the same order
+        if kern == 1 and M % 128 == 0:      # m3t_sgemm_scaled ran an fp16x3 tile kernel
             assert torch.equal(C0, C1), float((C0 - C1).abs().max())
         else:
             assert float((C0 - C1).abs().max()) <= 4e-6 * float(C0.abs().max())
+        assert float((C0 - C2).abs().max()) <= 4e-6 * float(C0.abs().max())          # deterministic slabs: fp32 rounding apart from the single pass
+        C1 = C2
     if seg:
         Ad = torch.cat([A[c * 300 + 1:c * 300 + 300] for c in range(32)]).double()
         Wd = torch.cat([W[c * 300:c * 300 + 299, :N] for c in range(32)]).double()

@@ -52,7 +52,7 @@ for shp in shapes:
                                       var if (tA, tB) == (0, 1) else 0, ops._stream()), "m3t_sgemm_ring")
     ref(); torch.cuda.synchronize()
     dr = digest(Cr)
-    kern, spl = ops.sgemm_plan(tA, m, n, k, seg_len=seg[0])
+    kern, spl = ops.sgemm_plan(tA, m, n, k, seg_len=seg[0], ws_bytes=ws.numel() * 4)
     line = "tA%d tB%d M%5d N%5d K%5d%s ref(splits %d)" % (tA, tB, m, n, k, " seg" if seg[0] else "", spl)
     ok = {}
     for v in variants:
