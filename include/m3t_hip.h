@@ -446,6 +446,26 @@ int m3t_va_loss(const float* y_hat, int rows, int C, int iv, int ia,
  * passes. */
 size_t m3t_va_loss_ws_bytes(int rows);
 
+/* Round 6: channels-last operators of the 3-D VGG-M stems (csrc/stem_cl.hip; reference models/backbone.py:73-103,179-271: Conv3d -> BatchNorm3d ->
+ * ReLU (-> MaxPool3d((1, 2, 2)))).  The tap walks read and write channels-last rows [N T H W][C]; with these two the whole stem stays in that
+ * layout -- no planes <-> channels-last transpose between the video and the GRU input.
+ * m3t_bn_cl_fwd / _bwd: BatchNorm (+ fused ReLU) over rows x [M][C] at any M (semantics of m3t_bn_rows_fwd / _bwd: batch statistics with
+ *   torch's running-statistics update when training, fp64 per-chunk partials reduced in a fixed order); C % 4 == 0, C / 4 divides 256
+ *   (C = 64 ... 1024 in powers of two), 16-B aligned tensors; ws: m3t_bn_cl_ws_bytes(M, C) bytes, 8-B aligned.  m3t_amax_out arms the
+ *   magnitude slot of y (forward) / dx (backward): the next tap walk scales by it.
+ * m3t_pool_cl_fwd / _bwd: max pooling of P frames x [P][H][W][C] with a (kh, kw) window, stride (sh, sw), padding (ph, pw) -- nn.MaxPool3d((1,
+ *   kh, kw)) on channels-last rows; win [P][Ho][Wo][C] bytes: the winner's place in its window (ties: the first maximum in window order, NaN
+ *   wins, as torch); backward is a gather (no atomics, deterministic).  C % 4 == 0, kh kw <= 255, padding < window.  m3t_amax_out arms y's slot. */
+size_t m3t_bn_cl_ws_bytes(size_t M, int C);
+int m3t_bn_cl_fwd(const float* x, size_t M, int C, const float* gamma, const float* beta, float* run_mean, float* run_var, float momentum,
+                  float eps, int training, int relu, float* y, float* save_mean, float* save_invstd, float* ws, size_t ws_bytes, void* stream);
+int m3t_bn_cl_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* save_mean, const float* save_invstd, size_t M,
+                  int C, int training, int relu, float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes, void* stream);
+int m3t_pool_cl_fwd(const float* x, size_t P, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw, float* y, unsigned char* win,
+                    void* stream);
+int m3t_pool_cl_bwd(const float* dy, const unsigned char* win, size_t P, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw,
+                    float* dx, void* stream);
+
 /* ---------------------------------------------------------------------------------
  * TCN (models/tcn.py).  Activations are channel-last [B,T,C] inside the library.
  * weight-norm reparametrisation (torch.nn.utils.weight_norm at models/tcn.py:19-20):

@@ -1,0 +1,336 @@
+// Channels-last operators of the 3-D VGG-M stems (round 6).  Reference: models/backbone.py:73-103,179-271 -- Conv3d -> BatchNorm3d -> ReLU
+// (-> MaxPool3d((1, 2, 2))) five times over.  Until round 5 BatchNorm / pooling worked on channel PLANES [N][C][T H W] and every convolution
+// was bracketed by tiled transposes (x -> channels-last for the tap walk, dy -> channels-last for the gradients: 25 launches and ~0.85 ms per
+// C5 step).  The tap walks read AND write channels-last rows natively; with these operators the whole stem stays
+// [rows = N T H W][C]: no transpose between the video and the GRU input.
+//   * BatchNorm (+ReLU) over rows at a million rows (csrc/bn.hip's rows kernels serve tcn_simple's 9 600 x 512): float4 sweeps, a thread's four
+//     channels fixed for the whole sweep, fp64 per-chunk partials reduced in a fixed order (deterministic), apply / dx raise the
+//     magnitude slot of what they write (m3t_amax_out: the next tap walk scales by it -- no measuring pass)
+//   * max pooling of frames [P][H][W][C] with a (kh, kw) window: a thread = one output position x four channels; the winner's place inside its
+//     window is kept as a byte per element, backward is a gather over the windows that cover an input position (no atomics), as the plane
+//     kernels; ties / NaN as torch (first maximum in window order, NaN wins)
+#include "common.h"
+
+namespace {
+
+constexpr int CL_TH = 256;
+
+// ---- statistics: partial[chunk][2][C] doubles.  MODE 0: sum x, sum x^2;  MODE 1 (backward): sum g, sum g xhat with g = dy (y > 0 if relu)
+template <int MODE>
+__global__ __launch_bounds__(CL_TH) void bncl_partial_kernel(const float* __restrict__ a, const float* __restrict__ x, const float* __restrict__ y,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd, size_t M, int C,
+                                                             size_t rows_per_chunk, int relu, double* __restrict__ partial) {
+    extern __shared__ double red[];                         // [2][groups][C]
+    const int c4n = C >> 2, groups = CL_TH / c4n;            // row groups that sweep the chunk side by side (C / 4 divides 256)
+    const int q = threadIdx.x % c4n, g = threadIdx.x / c4n;
+    const size_t r0 = (size_t)blockIdx.x * rows_per_chunk;
+    const size_t r1 = r0 + rows_per_chunk < M ? r0 + rows_per_chunk : M;
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, t[4] = {0.0, 0.0, 0.0, 0.0};
+    float mu[4] = {0.f, 0.f, 0.f, 0.f}, is[4] = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { mu[e] = mean[4 * q + e]; is[e] = invstd[4 * q + e]; }
+    }
+    if (g < groups) {
+        for (size_t r = r0 + g; r < r1; r += groups) {
+            const size_t o = r * C + 4 * q;
+            const float4 v = *reinterpret_cast<const float4*>(a + o);
+            float ve[4] = {v.x, v.y, v.z, v.w};
+            if (MODE == 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const double d = (double)ve[e]; s[e] += d; t[e] += d * d; }
+            } else {
+                const float4 xv = *reinterpret_cast<const float4*>(x + o);
+                const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
+                if (relu) {
+                    const float4 yv = *reinterpret_cast<const float4*>(y + o);
+                    const float ye[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (!(ye[e] > 0.f)) ve[e] = 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s[e] += (double)ve[e]; t[e] += (double)(ve[e] * ((xe[e] - mu[e]) * is[e])); }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { red[(size_t)g * C + 4 * q + e] = s[e]; red[(size_t)(groups + g) * C + 4 * q + e] = t[e]; }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += CL_TH) {
+        double a0 = 0.0, b0 = 0.0;
+        for (int k = 0; k < groups; ++k) { a0 += red[(size_t)k * C + c]; b0 += red[(size_t)(groups + k) * C + c]; }      // fixed order
+        partial[((size_t)blockIdx.x * 2 + 0) * C + c] = a0;
+        partial[((size_t)blockIdx.x * 2 + 1) * C + c] = b0;
+    }
+}
+
+// mean / biased variance -> invstd; running statistics as torch (unbiased variance)
+__global__ void bncl_stats_final_kernel(const double* __restrict__ partial, int nchunks, double M, int C, float eps, float momentum,
+                                        float* __restrict__ run_mean, float* __restrict__ run_var, float* __restrict__ mean,
+                                        float* __restrict__ invstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, ss = 0.0;
+    for (int k = 0; k < nchunks; ++k) { s += partial[((size_t)k * 2 + 0) * C + c]; ss += partial[((size_t)k * 2 + 1) * C + c]; }
+    const double mu = s / M;
+    double var = ss / M - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)mu;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (run_mean) run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)mu;
+    if (run_var) {
+        const double unb = M > 1.0 ? var * M / (M - 1.0) : var;
+        run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
+    }
+}
+__global__ void bncl_eval_stats_kernel(const float* __restrict__ run_mean, const float* __restrict__ run_var, int C, float eps,
+                                       float* __restrict__ mean, float* __restrict__ invstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    mean[c] = run_mean[c];
+    invstd[c] = 1.0f / sqrtf(run_var[c] + eps);
+}
+__global__ void bncl_bwd_final_kernel(const double* __restrict__ partial, int nchunks, int C, float* __restrict__ sums, float* __restrict__ dgamma,
+                                      float* __restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, sx = 0.0;
+    for (int k = 0; k < nchunks; ++k) { s += partial[((size_t)k * 2 + 0) * C + c]; sx += partial[((size_t)k * 2 + 1) * C + c]; }
+    sums[c] = (float)s; sums[C + c] = (float)sx;
+    if (dbeta) dbeta[c] = (float)s;
+    if (dgamma) dgamma[c] = (float)sx;
+}
+
+// apply (+ReLU) / dx.  total4 = M C / 4; the grid's stride is a multiple of C / 4: a thread's four channels never change
+template <int MODE>
+__global__ __launch_bounds__(CL_TH) void bncl_map_kernel(const float* __restrict__ a, const float* __restrict__ x, const float* __restrict__ y,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                         const float* __restrict__ sums, float* __restrict__ out, size_t total4, int C,
+                                                         float inv_count, int training, int relu, unsigned long long* __restrict__ slot) {
+    __shared__ float red4[4];
+    const int c4n = C >> 2;
+    const size_t i0 = (size_t)blockIdx.x * CL_TH + threadIdx.x;
+    const int q = (int)(i0 % (size_t)c4n);
+    float w[4], b[4], mu[4], is[4], k1[4], k2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = 4 * q + e;
+        mu[e] = mean[c]; is[e] = invstd[c];
+        w[e] = (gamma ? gamma[c] : 1.f) * is[e];
+        b[e] = (MODE == 0 && beta) ? beta[c] : 0.f;
+        k1[e] = (MODE == 1 && training) ? sums[c] * inv_count : 0.f;
+        k2[e] = (MODE == 1 && training) ? sums[C + c] * inv_count : 0.f;
+    }
+    float mx = 0.f;
+    for (size_t i = i0; i < total4; i += (size_t)gridDim.x * CL_TH) {
+        const float4 v = reinterpret_cast<const float4*>(a)[i];
+        const float ve[4] = {v.x, v.y, v.z, v.w};
+        float o[4];
+        if (MODE == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float r = (ve[e] - mu[e]) * w[e] + b[e];
+                o[e] = relu ? fmaxf(r, 0.f) : r;
+            }
+        } else {
+            const float4 xv = reinterpret_cast<const float4*>(x)[i];
+            const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
+            float ye[4] = {1.f, 1.f, 1.f, 1.f};
+            if (relu) { const float4 yv = reinterpret_cast<const float4*>(y)[i]; ye[0] = yv.x; ye[1] = yv.y; ye[2] = yv.z; ye[3] = yv.w; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float g = (relu && !(ye[e] > 0.f)) ? 0.f : ve[e];
+                o[e] = training ? w[e] * (g - k1[e] - ((xe[e] - mu[e]) * is[e]) * k2[e]) : g * w[e];
+            }
+        }
+        reinterpret_cast<float4*>(out)[i] = make_float4(o[0], o[1], o[2], o[3]);
+        if (slot) mx = fmaxf(fmaxf(mx, fmaxf(m3t_fin_abs(o[0]), m3t_fin_abs(o[1]))), fmaxf(m3t_fin_abs(o[2]), m3t_fin_abs(o[3])));
+    }
+    if (slot) m3t_block_raise_slot(slot, mx, red4);         // (uniform: every thread of the block gets here)
+}
+
+static int cl_chunks(size_t M) {
+    size_t c = (M + 511) / 512;
+    return (int)(c < 1 ? 1 : (c > 2048 ? 2048 : c));
+}
+
+// ---- pooling of channels-last frames [P][H][W][C]: thread = (output position, channel quad)
+struct PoolCL { int H, W, Ho, Wo, kh, kw, sh, sw, ph, pw, C; };
+
+__global__ __launch_bounds__(CL_TH) void poolcl_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ win,
+                                                           size_t total4, PoolCL g, unsigned long long* __restrict__ slot) {
+    __shared__ float red4[4];
+    const int c4n = g.C >> 2;
+    float mx = 0.f;
+    for (size_t i = (size_t)blockIdx.x * CL_TH + threadIdx.x; i < total4; i += (size_t)gridDim.x * CL_TH) {
+        const int q = (int)(i % (size_t)c4n);
+        size_t r = i / (size_t)c4n;
+        const int wo = (int)(r % (size_t)g.Wo); r /= (size_t)g.Wo;
+        const int ho = (int)(r % (size_t)g.Ho);
+        const size_t p = r / (size_t)g.Ho;
+        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int bi[4] = {0, 0, 0, 0};
+        bool first = true;
+        for (int dh = 0; dh < g.kh; ++dh) {
+            const int h = ho * g.sh - g.ph + dh;
+            if ((unsigned)h >= (unsigned)g.H) continue;
+            for (int dw = 0; dw < g.kw; ++dw) {
+                const int w = wo * g.sw - g.pw + dw;
+                if ((unsigned)w >= (unsigned)g.W) continue;
+                const float4 v = *reinterpret_cast<const float4*>(x + ((p * g.H + h) * g.W + w) * (size_t)g.C + 4 * q);
+                const float ve[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (first || ve[e] > best[e] || (ve[e] != ve[e] && best[e] == best[e])) { best[e] = ve[e]; bi[e] = dh * g.kw + dw; }      // first maximum; NaN wins
+                first = false;
+            }
+        }
+        reinterpret_cast<float4*>(y)[i] = make_float4(best[0], best[1], best[2], best[3]);
+        reinterpret_cast<uchar4*>(win)[i] = make_uchar4((unsigned char)bi[0], (unsigned char)bi[1], (unsigned char)bi[2], (unsigned char)bi[3]);
+        if (slot) mx = fmaxf(fmaxf(mx, fmaxf(m3t_fin_abs(best[0]), m3t_fin_abs(best[1]))), fmaxf(m3t_fin_abs(best[2]), m3t_fin_abs(best[3])));
+    }
+    if (slot) m3t_block_raise_slot(slot, mx, red4);
+}
+
+// dx[p][h][w][c] = sum over the windows (ho, wo) that cover (h, w) of dy[p][ho][wo][c] if that window's winner is (h, w)
+__global__ __launch_bounds__(CL_TH) void poolcl_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ win, float* __restrict__ dx,
+                                                           size_t total4, PoolCL g) {
+    const int c4n = g.C >> 2;
+    for (size_t i = (size_t)blockIdx.x * CL_TH + threadIdx.x; i < total4; i += (size_t)gridDim.x * CL_TH) {
+        const int q = (int)(i % (size_t)c4n);
+        size_t r = i / (size_t)c4n;
+        const int w = (int)(r % (size_t)g.W); r /= (size_t)g.W;
+        const int h = (int)(r % (size_t)g.H);
+        const size_t p = r / (size_t)g.H;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        // windows with ho sh - ph <= h < ho sh - ph + kh
+        const int ho_hi = min((h + g.ph) / g.sh, g.Ho - 1), wo_hi = min((w + g.pw) / g.sw, g.Wo - 1);
+        for (int ho = ho_hi; ho >= 0; --ho) {
+            const int dh = h + g.ph - ho * g.sh;
+            if (dh >= g.kh) break;
+            for (int wo = wo_hi; wo >= 0; --wo) {
+                const int dw = w + g.pw - wo * g.sw;
+                if (dw >= g.kw) break;
+                const size_t o = ((p * g.Ho + ho) * g.Wo + wo) * (size_t)c4n + q;
+                const uchar4 b = reinterpret_cast<const uchar4*>(win)[o];
+                const float4 gq = reinterpret_cast<const float4*>(dy)[o];
+                const int me = dh * g.kw + dw;
+                if (b.x == me) acc[0] += gq.x;
+                if (b.y == me) acc[1] += gq.y;
+                if (b.z == me) acc[2] += gq.z;
+                if (b.w == me) acc[3] += gq.w;
+            }
+        }
+        reinterpret_cast<float4*>(dx)[i] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+}
+
+static int grid_for(size_t total4, int c4n) {
+    // a grid whose stride (blocks x 256) is a multiple of C / 4 (it divides 256), >= ~16 float4 per thread, at most 8192 blocks
+    size_t b = (total4 + (size_t)CL_TH * 16 - 1) / ((size_t)CL_TH * 16);
+    if (b < 1) b = 1;
+    if (b > 8192) b = 8192;
+    (void)c4n;
+    return (int)b;
+}
+
+}  // namespace
+
+// BatchNorm (+ReLU) over channels-last rows x [M][C] at any M (the 3-D stems: M = N T H W up to millions); C % 4 == 0, C / 4 divides 256, 16-B
+// aligned tensors.  Semantics of m3t_bn_rows_fwd / _bwd.  m3t_amax_out arms the magnitude slot of y (forward) / dx (backward).
+extern "C" size_t m3t_bn_cl_ws_bytes(size_t M, int C) {
+    return (size_t)cl_chunks(M) * 2 * (size_t)C * sizeof(double) + 2 * (size_t)C * sizeof(float) + 256;
+}
+
+static bool bncl_shape_ok(size_t M, int C) { return C > 0 && C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && M > 0; }
+
+extern "C" int m3t_bn_cl_fwd(const float* x, size_t M, int C, const float* gamma, const float* beta, float* run_mean, float* run_var,
+                             float momentum, float eps, int training, int relu, float* y, float* save_mean, float* save_invstd, float* ws,
+                             size_t ws_bytes, void* stream) {
+    unsigned long long* slot = m3t_take_amax_out();
+    if (!bncl_shape_ok(M, C) || !x || !y || !save_mean || !save_invstd || ((uintptr_t)x % 16) != 0 || ((uintptr_t)y % 16) != 0) return M3T_EINVAL;
+    if (!training && (!run_mean || !run_var)) return M3T_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (training) {
+        if (M < 2) return M3T_EINVAL;
+        if (!ws || ws_bytes < m3t_bn_cl_ws_bytes(M, C) || ((uintptr_t)ws % 8) != 0) return M3T_EINVAL;
+        const int nch = cl_chunks(M);
+        const size_t rpc = (M + nch - 1) / nch;
+        double* partial = reinterpret_cast<double*>(ws);
+        const int groups = CL_TH / (C / 4);
+        bncl_partial_kernel<0><<<nch, CL_TH, (size_t)2 * groups * C * sizeof(double), s>>>(x, nullptr, nullptr, nullptr, nullptr, M, C, rpc, 0, partial);
+        M3T_LAUNCH_CHECK();
+        bncl_stats_final_kernel<<<cdiv(C, 256), 256, 0, s>>>(partial, nch, (double)M, C, eps, momentum, run_mean, run_var, save_mean, save_invstd);
+        M3T_LAUNCH_CHECK();
+    } else {
+        bncl_eval_stats_kernel<<<cdiv(C, 256), 256, 0, s>>>(run_mean, run_var, C, eps, save_mean, save_invstd);
+        M3T_LAUNCH_CHECK();
+    }
+    const size_t total4 = M * (size_t)(C / 4);
+    bncl_map_kernel<0><<<grid_for(total4, C / 4), CL_TH, 0, s>>>(x, nullptr, nullptr, gamma, beta, save_mean, save_invstd, nullptr, y, total4, C, 0.f,
+                                                                training, relu, slot);
+    M3T_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int m3t_bn_cl_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* save_mean, const float* save_invstd,
+                             size_t M, int C, int training, int relu, float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes,
+                             void* stream) {
+    unsigned long long* slot = m3t_take_amax_out();
+    if (!bncl_shape_ok(M, C) || !dy || !x || !dx || !save_mean || !save_invstd || ((uintptr_t)dy % 16) != 0 || ((uintptr_t)x % 16) != 0 ||
+        ((uintptr_t)dx % 16) != 0)
+        return M3T_EINVAL;
+    if (relu && (!y || ((uintptr_t)y % 16) != 0)) return M3T_EINVAL;
+    if (!ws || ws_bytes < m3t_bn_cl_ws_bytes(M, C) || ((uintptr_t)ws % 8) != 0) return M3T_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int nch = cl_chunks(M);
+    const size_t rpc = (M + nch - 1) / nch;
+    double* partial = reinterpret_cast<double*>(ws);
+    float* sums = reinterpret_cast<float*>(partial + (size_t)nch * 2 * C);
+    const int groups = CL_TH / (C / 4);
+    bncl_partial_kernel<1><<<nch, CL_TH, (size_t)2 * groups * C * sizeof(double), s>>>(dy, x, y, save_mean, save_invstd, M, C, rpc, relu, partial);
+    M3T_LAUNCH_CHECK();
+    bncl_bwd_final_kernel<<<cdiv(C, 256), 256, 0, s>>>(partial, nch, C, sums, dgamma, dbeta);
+    M3T_LAUNCH_CHECK();
+    const size_t total4 = M * (size_t)(C / 4);
+    bncl_map_kernel<1><<<grid_for(total4, C / 4), CL_TH, 0, s>>>(dy, x, y, gamma, nullptr, save_mean, save_invstd, sums, dx, total4, C,
+                                                                (float)(1.0 / (double)M), training, relu, slot);
+    M3T_LAUNCH_CHECK();
+    return 0;
+}
+
+// Max pooling of P channels-last frames x [P][H][W][C] -> y [P][Ho][Wo][C] (nn.MaxPool3d((1, kh, kw)) of the stems on channels-last rows);
+// win: one byte per output element (the winner's place in its window).  C % 4 == 0, kh kw <= 255.  m3t_amax_out arms y's magnitude slot.
+extern "C" int m3t_pool_cl_fwd(const float* x, size_t P, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw, float* y,
+                               unsigned char* win, void* stream) {
+    unsigned long long* slot = m3t_take_amax_out();
+    if (P == 0) return 0;
+    if (!x || !y || !win || H <= 0 || W <= 0 || C <= 0 || C % 4 != 0 || kh <= 0 || kw <= 0 || kh * kw > 255 || sh <= 0 || sw <= 0 || ph < 0 || pw < 0 ||
+        ph >= kh || pw >= kw || ((uintptr_t)x % 16) != 0 || ((uintptr_t)y % 16) != 0 || ((uintptr_t)win % 4) != 0)
+        return M3T_EINVAL;
+    PoolCL g;
+    g.H = H; g.W = W; g.kh = kh; g.kw = kw; g.sh = sh; g.sw = sw; g.ph = ph; g.pw = pw; g.C = C;
+    g.Ho = (H + 2 * ph - kh) / sh + 1; g.Wo = (W + 2 * pw - kw) / sw + 1;
+    if (g.Ho < 1 || g.Wo < 1) return M3T_EINVAL;
+    const size_t total4 = P * (size_t)g.Ho * g.Wo * (size_t)(C / 4);
+    poolcl_fwd_kernel<<<grid_for(total4, C / 4), CL_TH, 0, (hipStream_t)stream>>>(x, y, win, total4, g, slot);
+    M3T_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int m3t_pool_cl_bwd(const float* dy, const unsigned char* win, size_t P, int H, int W, int C, int kh, int kw, int sh, int sw, int ph,
+                               int pw, float* dx, void* stream) {
+    if (P == 0) return 0;
+    if (!dy || !dx || !win || H <= 0 || W <= 0 || C <= 0 || C % 4 != 0 || kh <= 0 || kw <= 0 || kh * kw > 255 || sh <= 0 || sw <= 0 || ph < 0 || pw < 0 ||
+        ph >= kh || pw >= kw || ((uintptr_t)dy % 16) != 0 || ((uintptr_t)dx % 16) != 0 || ((uintptr_t)win % 4) != 0)
+        return M3T_EINVAL;
+    PoolCL g;
+    g.H = H; g.W = W; g.kh = kh; g.kw = kw; g.sh = sh; g.sw = sw; g.ph = ph; g.pw = pw; g.C = C;
+    g.Ho = (H + 2 * ph - kh) / sh + 1; g.Wo = (W + 2 * pw - kw) / sw + 1;
+    if (g.Ho < 1 || g.Wo < 1) return M3T_EINVAL;
+    const size_t total4 = P * (size_t)H * W * (size_t)(C / 4);
+    poolcl_bwd_kernel<<<grid_for(total4, C / 4), CL_TH, 0, (hipStream_t)stream>>>(dy, win, dx, total4, g);
+    M3T_LAUNCH_CHECK();
+    return 0;
+}

@@ -92,6 +92,11 @@ SIGNATURES = {
     "m3t_gru_persist_profile": [C.c_void_p],
     "m3t_att_fuse_fwd": [_f, _f, _f, _f, _f, _i, _i, _s],
     "m3t_att_fuse_bwd": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _s],
+    "m3t_bn_cl_ws_bytes": [_z, _i],
+    "m3t_bn_cl_fwd": [_f, _z, _i, _f, _f, _f, _f, C.c_float, C.c_float, _i, _i, _f, _f, _f, _f, _z, _s],
+    "m3t_bn_cl_bwd": [_f, _f, _f, _f, _f, _f, _z, _i, _i, _i, _f, _f, _f, _f, _z, _s],
+    "m3t_pool_cl_fwd": [_f, _z, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, C.c_void_p, _s],
+    "m3t_pool_cl_bwd": [_f, C.c_void_p, _z, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _s],
     "m3t_va_loss": [_f, _i, _i, _i, _i, _f, _f, _f, _f, _i, C.c_float, C.c_float, C.c_float, _i, _f, _f, _f, _z, _s],
     "m3t_va_loss_ws_bytes": [_i],
     "m3t_weight_norm_fwd": [_f, _f, _f, _f, _i, _i, _i, _s],
@@ -136,7 +141,7 @@ SIGNATURES = {
     "m3t_sgd_step": [_f, _f, _f, _z, C.c_float, C.c_float, C.c_float, _i, _f, _s],
 }
 
-RESTYPES = {"m3t_gru_bwd_prepare_floats": C.c_size_t, "m3t_bn_rows_ws_bytes": C.c_size_t, "m3t_bn_planes_ws_bytes": C.c_size_t, "m3t_va_loss_ws_bytes": C.c_size_t, "m3t_cbam_fused_ws_bytes": C.c_size_t}
+RESTYPES = {"m3t_gru_bwd_prepare_floats": C.c_size_t, "m3t_bn_rows_ws_bytes": C.c_size_t, "m3t_bn_planes_ws_bytes": C.c_size_t, "m3t_va_loss_ws_bytes": C.c_size_t, "m3t_bn_cl_ws_bytes": C.c_size_t, "m3t_cbam_fused_ws_bytes": C.c_size_t}
 
 _lib = None
 

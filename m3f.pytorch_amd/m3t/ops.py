@@ -2711,6 +2711,302 @@ def conv3d(x, w, b, stride, padding):
     return _Conv3dGemmWgrad.apply(x, w, b, tuple(stride), tuple(padding), False)
 
 
+# ----------------------------------------------------------------------------- channels-last 3-D stems (round 6)
+# The VGG-M stems (reference models/backbone.py:73-103,179-271: five groups of Conv3d -> BatchNorm3d -> ReLU (-> MaxPool3d((1, 2, 2)))) as a chain
+# of channels-last operators: the tap walks read and write [rows = N T H W][C] natively, BatchNorm and pooling get channels-last kernels
+# (csrc/stem_cl.hip), and nothing between the video and the GRU input is transposed (until round 5: a planes -> channels-last transpose in front
+# of every convolution and of every convolution's backward, ~25 launches and 0.85 ms per C5 step).  M3T_STEM_CL=0: the planes operators.
+STEM_CL = [os.environ.get("M3T_STEM_CL", "1") != "0"]
+
+
+class CLTensor:
+    """a channels-last activation of a 3-D stem: `data` [N T H W, C] (a plain autograd tensor) + its grid; `slot`: the 1-element tensor
+    holding data's magnitude slot (raised by the kernel that wrote data) or None"""
+    __slots__ = ("data", "N", "T", "H", "W", "slot")
+
+    def __init__(self, data, N, T, H, W, slot=None):
+        self.data, self.N, self.T, self.H, self.W, self.slot = data, N, T, H, W, slot
+
+    @property
+    def C(self):
+        return self.data.shape[1]
+
+    def planes(self):
+        """[N, C, T, H, W] (one tiled transpose: leaving the chain)"""
+        return btc_to_bct(self.data.view(self.N, self.T * self.H * self.W, self.C)).view(self.N, self.C, self.T, self.H, self.W)
+
+
+_GRAD_SLOT = {}          # id of a gradient tensor OBJECT -> (weakref, slot tensor, version): slots of gradients handed from backward to backward
+
+
+def _note_grad_slot(t, slot):
+    if len(_GRAD_SLOT) > 64:
+        _GRAD_SLOT.clear()
+    _GRAD_SLOT[id(t)] = (weakref.ref(t), slot, t._version, t.data_ptr())
+
+
+def _grad_slot(t):
+    """the magnitude slot the producing backward kernel raised for the gradient tensor `t` -- only if autograd handed over that very object,
+    unmodified (a sum of two branches' gradients, a copy or a view is another object: the consumer measures)"""
+    e = _GRAD_SLOT.pop(id(t), None)
+    if e is None or e[0]() is not t or e[2] != t._version or e[3] != t.data_ptr():
+        return None
+    return e[1]
+
+
+def conv3d_cl_ok(x, w, stride, padding, groups, dilation, padding_mode):
+    """the channels-last chain covers this convolution (an fp32 device input; C_out % 64; C_in % 32, or a first layer with <= 4 channels and
+    <= 8 taps per row; the fp16x3 mode)"""
+    if not (STEM_CL[0] and CONV3D_GEMM[0] and CONV3D_IMPLICIT[0] and CONV3D_TAPS[0] and CONV3D_PRESPLIT[0] and _PREC[0] == _lib.M3T_GEMM_F16X3):
+        return False
+    if groups != 1 or tuple(dilation) != (1, 1, 1) or padding_mode != "zeros" or not isinstance(padding, tuple):
+        return False
+    Co, Ci, kt, kh, kw = w.shape
+    if Co % 64 != 0:
+        return False
+    if isinstance(x, CLTensor):
+        return Ci % 32 == 0 and x.C == Ci
+    return x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and Ci <= 4 and kw <= 8 and not x.requires_grad
+
+
+class _Conv3dCL(torch.autograd.Function):
+    """Conv3d on channels-last rows: x [N T H W, Ci] (or the video planes [N, <= 4, T, H, W] of a first layer) -> y [N T' H' W', Co]; every pass
+    one of the tap walks of _Conv3dGemmWgrad, without any transpose"""
+
+    @staticmethod
+    def forward(ctx, x, w, b, geo):
+        N_, T_, H_, W_, stride, padding, first, x_slot = geo
+        Co, Ci, kt, kh, kw = w.shape
+        To = (T_ + 2 * padding[0] - kt) // stride[0] + 1
+        Ho = (H_ + 2 * padding[1] - kh) // stride[1] + 1
+        Wo = (W_ + 2 * padding[2] - kw) // stride[2] + 1
+        rows, srows, taps = N_ * To * Ho * Wo, N_ * T_ * H_ * W_, kt * kh * kw
+        ctx.geo, ctx.out_grid, ctx.has_bias, ctx.prec = geo, (To, Ho, Wo), b is not None, _PREC[0]
+        ctx.sink_refs = (w if id(w) in _GRAD_SINKS else None, b if (b is not None and id(b) in _GRAD_SINKS) else None)
+        ctx.w_keep = []
+        slots = amax_slots(2, x.device)
+        a_w = weight_amax(w, ctx.w_keep)
+        if first:
+            cw = 4
+            w8 = torch.zeros(Co, kt, kh, 8, 4, dtype=torch.float32, device=x.device)
+            w8[:, :, :, :kw, :Ci].copy_(w.detach().permute(0, 2, 3, 4, 1))
+            w_t = w8.view(Co, kt * kh * 32)
+            x_cl = torch.empty(srows, 4, dtype=torch.float32, device=x.device)
+            a_x = slots.data_ptr()
+            amax_out(a_x)
+            _lib.check(lib().m3t_planes_to_cl4(_p(_req(x.contiguous(), "x")), _p(x_cl), N_, Ci, T_ * H_ * W_, _stream()), "m3t_planes_to_cl4")
+        else:
+            cw = Ci
+            w_t = _req(w.detach().permute(0, 2, 3, 4, 1).contiguous(), "weight").view(Co, taps * Ci)
+            x_cl = _req(x, "x")
+            if x_slot is not None:
+                a_x = x_slot.data_ptr()
+                ctx.w_keep.append(x_slot)
+            else:
+                a_x = slots.data_ptr()
+                measure_amax([(x_cl, a_x)])
+        if a_w is None:
+            a_w = slots.data_ptr() + 8
+            measure_amax([(w_t, a_w)])
+        wk = w_t.shape[1]
+        x_img, w_img = torch.empty_like(x_cl), torch.empty_like(w_t)
+        y_cl = torch.empty(rows, Co, dtype=torch.float32, device=x.device)
+        wsd = workspace(x.device)
+        _lib.check(lib().m3t_f16x3_split(_p(x_cl), srows, cw, cw, _p(x_img), cw, a_x, _stream()), "m3t_f16x3_split")
+        _lib.check(lib().m3t_f16x3_split(_p(w_t), Co, wk, wk, _p(w_img), wk, a_w, _stream()), "m3t_f16x3_split")
+        tail = (kt, kh, kw, stride[0], stride[1], stride[2], padding[0], padding[1], padding[2], a_x, a_w, _p(wsd), wsd.numel() * 4, None, _stream())
+        bp = _p(b) if b is not None else None
+        if first:
+            _lib.check(lib().m3t_conv3d_fwd_taps4(_p(x_img), _p(w_img), bp, _p(y_cl), N_, Co, T_, H_, W_, *tail), "m3t_conv3d_fwd_taps4")
+        else:
+            _lib.check(lib().m3t_conv3d_fwd_taps(_p(x_img), _p(w_img), bp, _p(y_cl), N_, Ci, Co, T_, H_, W_, *tail), "m3t_conv3d_fwd_taps")
+        ctx.save_for_backward(w, x_cl, slots)
+        ctx.a_x, ctx.a_w, ctx.cw = a_x, a_w, cw
+        CONV3D_CALLS["walk"] += 1
+        return y_cl
+
+    @staticmethod
+    def backward(ctx, dy):
+        w, x_cl, slots = ctx.saved_tensors
+        N_, T_, H_, W_, st, pd, first, _ = ctx.geo
+        To, Ho, Wo = ctx.out_grid
+        Co, Ci, kt, kh, kw = w.shape
+        slot_dy = _grad_slot(dy) if dy.is_contiguous() else None      # raised by the kernel that wrote dy (BatchNorm's backward) -- else measured here
+        dy_cl = _req(dy.contiguous(), "dy")
+        rows = dy_cl.shape[0]
+        dx = dw = db = None
+        w_sink = _take_sink(ctx.sink_refs[0]) if (ctx.needs_input_grad[1] and ctx.sink_refs[0] is not None) else None
+        b_sink = _take_sink(ctx.sink_refs[1]) if (ctx.has_bias and ctx.needs_input_grad[2] and ctx.sink_refs[1] is not None) else None
+        if slot_dy is None:
+            slot_dy = amax_slots(1, dy.device)
+            measure_amax([(dy_cl, slot_dy.data_ptr())])
+        wsd = workspace(dy.device)
+        if ctx.needs_input_grad[0]:
+            if first or Ci % 64 != 0 or Co % 32 != 0:
+                raise M3THipError("the channels-last chain has no data gradient for this layer (a first layer's input is the video)")
+            dy_img = torch.empty_like(dy_cl)
+            _lib.check(lib().m3t_f16x3_split(_p(dy_cl), rows, Co, Co, _p(dy_img), Co, slot_dy.data_ptr(), _stream()), "m3t_f16x3_split")
+            wd = w.detach()
+            dx = torch.empty(N_ * T_ * H_ * W_, Ci, dtype=torch.float32, device=dy.device)
+            one = tuple(st) == (1, 1, 1)
+            if not one:
+                dx.zero_()
+            dims, ks = (T_, H_, W_), (kt, kh, kw)
+            for ct in range(st[0]):
+                for ch in range(st[1]):
+                    for cw_ in range(st[2]):
+                        cls = (ct, ch, cw_)
+                        r = [(cls[a] + pd[a]) % st[a] for a in range(3)]
+                        sub = [len(range(r[a], ks[a], st[a])) for a in range(3)]
+                        size = [len(range(cls[a], dims[a], st[a])) for a in range(3)]
+                        if min(sub) < 1 or min(size) < 1:
+                            continue
+                        base = [(cls[a] + pd[a] - r[a]) // st[a] for a in range(3)]
+                        taps = sub[0] * sub[1] * sub[2]
+                        w_t = wd[:, :, r[0]::st[0], r[1]::st[1], r[2]::st[2]].permute(1, 2, 3, 4, 0).contiguous().view(Ci, taps * Co)
+                        w_img = torch.empty_like(w_t)
+                        _lib.check(lib().m3t_f16x3_split(_p(w_t), Ci, taps * Co, taps * Co, _p(w_img), taps * Co, ctx.a_w, _stream()), "m3t_f16x3_split")
+                        dst = dx if one else torch.empty(N_ * size[0] * size[1] * size[2], Ci, dtype=torch.float32, device=dy.device)
+                        _lib.check(lib().m3t_conv3d_taps_pre(_p(dy_img), _p(w_img), _p(dst), N_, Co, Ci, size[0], size[1], size[2], To, Ho, Wo,
+                                                             sub[0], sub[1], sub[2], base[0], base[1], base[2], -1, slot_dy.data_ptr(), ctx.a_w,
+                                                             _p(wsd), wsd.numel() * 4, None, _stream()), "m3t_conv3d_taps_pre")
+                        if not one:
+                            dx.view(N_, T_, H_, W_, Ci)[:, ct::st[0], ch::st[1], cw_::st[2], :].copy_(dst.view(N_, size[0], size[1], size[2], Ci))
+        if ctx.needs_input_grad[1]:
+            cw = ctx.cw
+            taps, Kc = kt * kh * kw, cw * kt * kh * kw
+            Mp = (Kc + 127) // 128 * 128
+            tiles = (Mp // 128) * ((Co + 127) // 128)
+            want = max(1, min((1536 + tiles - 1) // tiles, rows // 256))
+            wsw = workspace(dy.device, min(want * Mp * Co * 4, 512 << 20))
+            dwt = torch.empty(Mp, Co, dtype=torch.float32, device=dy.device)
+            _lib.check(lib().m3t_conv3d_wgrad_taps(_p(x_cl), _p(dy_cl), _p(dwt), N_, cw, Co, T_, H_, W_, kt, kh, kw, st[0], st[1], st[2],
+                                                   pd[0], pd[1], pd[2], ctx.prec, ctx.a_x, slot_dy.data_ptr(), _p(wsw), wsw.numel() * 4, _stream()),
+                       "m3t_conv3d_wgrad_taps")
+            dw_v = dwt[:Kc].view(taps, cw, Co)[:, :Ci].permute(2, 1, 0)
+            if w_sink is not None:
+                w_sink.view(Co, Ci, taps).copy_(dw_v)
+            else:
+                dw = dw_v.contiguous().view_as(w)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = b_sink if b_sink is not None else torch.empty(Co, dtype=torch.float32, device=dy.device)
+            colsum(dy_cl, 0, rows, Co, Co, db)
+            if b_sink is not None:
+                db = None
+        return dx, dw, db, None
+
+
+def conv3d_cl(x, w, b, stride, padding):
+    """x: CLTensor, or the video planes [N, <= 4, T, H, W] of a stem's first layer -> CLTensor"""
+    stride, padding = tuple(stride), tuple(padding)
+    if isinstance(x, CLTensor):
+        geo = (x.N, x.T, x.H, x.W, stride, padding, False, x.slot)
+        data = x.data
+    else:
+        geo = (x.shape[0], x.shape[2], x.shape[3], x.shape[4], stride, padding, True, None)
+        data = x
+    y = _Conv3dCL.apply(data, w, b, geo)
+    k = w.shape[2:]
+    To, Ho, Wo = ((d + 2 * p_ - k_) // s_ + 1 for d, p_, k_, s_ in zip(geo[1:4], padding, k, stride))
+    return CLTensor(y, geo[0], To, Ho, Wo, None)
+
+
+class _BNCL(torch.autograd.Function):
+    """BatchNorm3d (+ReLU) over channels-last rows (csrc/stem_cl.hip m3t_bn_cl_*); y's and dx's magnitude slots are raised by the kernels"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, run_mean, run_var, training, momentum, eps, relu, y_slot):
+        x = _req(x, "x")
+        M, Cc = x.shape
+        y = torch.empty_like(x)
+        stats = torch.empty(2, Cc, dtype=torch.float32, device=x.device)
+        ws = workspace(x.device, int(lib().m3t_bn_cl_ws_bytes(M, Cc)))
+        amax_out(y_slot.data_ptr() if y_slot is not None else None)
+        try:
+            rc = lib().m3t_bn_cl_fwd(_p(x), M, Cc, _p(gamma), _p(beta), _p(run_mean), _p(run_var), float(momentum), float(eps), int(training),
+                                     int(relu), _p(y), _p(stats[0]), _p(stats[1]), _p(ws), ws.numel() * 4, _stream())
+            _lib.check(rc, "m3t_bn_cl_fwd")
+        except BaseException:
+            _amax_clear()
+            raise
+        ctx.save_for_backward(x, y if relu else None, gamma, stats)
+        ctx.training, ctx.relu = bool(training), bool(relu)
+        ctx.sink_refs = (gamma if (gamma is not None and id(gamma) in _GRAD_SINKS) else None,
+                         beta if (beta is not None and id(beta) in _GRAD_SINKS) else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, stats = ctx.saved_tensors
+        dy = _req(dy.contiguous(), "dy")
+        M, Cc = x.shape
+        dx = torch.empty_like(x)
+        g = torch.empty(2, Cc, dtype=torch.float32, device=x.device)
+        ws = workspace(x.device, int(lib().m3t_bn_cl_ws_bytes(M, Cc)))
+        gs = _take_sink(ctx.sink_refs[0]) if (ctx.needs_input_grad[1] and ctx.sink_refs[0] is not None) else None
+        bs = _take_sink(ctx.sink_refs[1]) if (ctx.needs_input_grad[2] and ctx.sink_refs[1] is not None) else None
+        slot = amax_slots(1, x.device)
+        amax_out(slot.data_ptr())
+        try:
+            rc = lib().m3t_bn_cl_bwd(_p(dy), _p(x), _p(y), _p(gamma), _p(stats[0]), _p(stats[1]), M, Cc, int(ctx.training), int(ctx.relu), _p(dx),
+                                     _p(gs if gs is not None else g[0]), _p(bs if bs is not None else g[1]), _p(ws), ws.numel() * 4, _stream())
+            _lib.check(rc, "m3t_bn_cl_bwd")
+        except BaseException:
+            _amax_clear()
+            raise
+        _note_grad_slot(dx, slot)                        # the convolution in front of this BatchNorm takes dx as its dy: no measuring pass
+        return (dx, (g[0] if (gamma is not None and gs is None) else None), (g[1] if (gamma is not None and bs is None) else None),
+                None, None, None, None, None, None, None)
+
+
+def bn_cl(x, gamma, beta, run_mean, run_var, training, momentum, eps, relu=True):
+    slot = amax_slots(1, x.data.device)
+    y = _BNCL.apply(x.data, gamma, beta, run_mean, run_var, training, momentum, eps, relu, slot)
+    return CLTensor(y, x.N, x.T, x.H, x.W, slot)
+
+
+class _PoolCL(torch.autograd.Function):
+    """nn.MaxPool3d((1, k, k)) on channels-last frames (csrc/stem_cl.hip m3t_pool_cl_*)"""
+
+    @staticmethod
+    def forward(ctx, x, geo, y_slot):
+        P, H, W, k, s, p = geo
+        x = _req(x, "x")
+        Cc = x.shape[1]
+        Ho, Wo = (H + 2 * p[0] - k[0]) // s[0] + 1, (W + 2 * p[1] - k[1]) // s[1] + 1
+        y = torch.empty(P * Ho * Wo, Cc, dtype=torch.float32, device=x.device)
+        win = torch.empty(P * Ho * Wo, Cc, dtype=torch.uint8, device=x.device)
+        amax_out(y_slot.data_ptr() if y_slot is not None else None)
+        try:
+            _lib.check(lib().m3t_pool_cl_fwd(_p(x), P, H, W, Cc, k[0], k[1], s[0], s[1], p[0], p[1], _p(y), C.c_void_p(win.data_ptr()), _stream()),
+                       "m3t_pool_cl_fwd")
+        except BaseException:
+            _amax_clear()
+            raise
+        ctx.save_for_backward(win)
+        ctx.geo = geo
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (win,) = ctx.saved_tensors
+        P, H, W, k, s, p = ctx.geo
+        dy = _req(dy.contiguous(), "dy")
+        Cc = dy.shape[1]
+        dx = torch.empty(P * H * W, Cc, dtype=torch.float32, device=dy.device)
+        _lib.check(lib().m3t_pool_cl_bwd(_p(dy), C.c_void_p(win.data_ptr()), P, H, W, Cc, k[0], k[1], s[0], s[1], p[0], p[1], _p(dx), _stream()),
+                   "m3t_pool_cl_bwd")
+        return dx, None, None
+
+
+def pool_cl(x, k, s, p):
+    k, s, p = tuple(k), tuple(s), tuple(p)
+    slot = amax_slots(1, x.data.device)
+    y = _PoolCL.apply(x.data, (x.N * x.T, x.H, x.W, k, s, p), slot)
+    Ho, Wo = (x.H + 2 * p[0] - k[0]) // s[0] + 1, (x.W + 2 * p[1] - k[1]) // s[1] + 1
+    return CLTensor(y, x.N, x.T, Ho, Wo, slot)
+
+
 def conv2d(x, w, b, stride, padding):
     """nn.Conv2d of the per-frame ResNet (reference models/resnet.py:18-24,95-105) on the 3-D walks with a unit time axis; w is the Conv2d
     Parameter itself (gradient sinks and the per-step magnitude table are keyed on it)"""

@@ -26,9 +26,16 @@ class Conv3d(nn.Conv3d):
     at 26 TFLOP/s); M3T_CONV3D_IMPLICIT=0: the patch-matrix GEMMs.  Falls back to the stock op for configurations it does not cover (and
     under M3T_CONV3D_MIOPEN=1)."""
 
+    cl_chain = False          # set on the convolutions of a VGG-M stem (_vgg_group): run them as a channels-last chain (m3t.ops.CLTensor)
+
     def forward(self, x):
         # ONE path whatever the grad mode (round 6): validation / test steps under no_grad (reference models/model.py:226-246,320-337) and
         # --freeze_enc training (model.py:376-386) run the same walks as a training step; autograd skips what needs no gradient
+        if isinstance(x, ops.CLTensor) or self.cl_chain:
+            if ops.conv3d_cl_ok(x, self.weight, self.stride, self.padding, self.groups, self.dilation, self.padding_mode):
+                return ops.conv3d_cl(x, self.weight, self.bias, self.stride, self.padding)
+            if isinstance(x, ops.CLTensor):
+                x = x.planes()                     # (a layer the chain does not cover: leave it)
         if (x.is_cuda and x.dtype == torch.float32 and self.groups == 1 and tuple(self.dilation) == (1, 1, 1)
                 and self.padding_mode == "zeros" and isinstance(self.padding, tuple)):
             return ops.conv3d(x, self.weight, self.bias, self.stride, self.padding)
@@ -42,6 +49,13 @@ class BatchNorm3dReLU(nn.BatchNorm3d):
     nn.Sequential it takes the BatchNorm3d slot and an nn.Identity the ReLU's, so every index -- and every checkpoint key -- stays."""
 
     def forward(self, x):
+        if isinstance(x, ops.CLTensor):
+            Cc = x.C
+            if ops.BN_PLANES[0] and self.affine and self.track_running_stats and self.momentum is not None and Cc % 4 == 0 and 256 % (Cc // 4) == 0:
+                if self.training:
+                    self.num_batches_tracked.add_(1)
+                return ops.bn_cl(x, self.weight, self.bias, self.running_mean, self.running_var, self.training, self.momentum, self.eps, True)
+            x = x.planes()
         if (ops.BN_PLANES[0] and x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and self.affine and self.track_running_stats
                 and self.momentum is not None):
             if self.training:
@@ -60,6 +74,11 @@ class SpatialMaxPool3d(nn.MaxPool3d):
 
     def forward(self, x):
         k, s, p, d = (_triple(v) for v in (self.kernel_size, self.stride, self.padding, self.dilation))
+        if isinstance(x, ops.CLTensor):
+            if (k[0] == 1 and s[0] == 1 and p[0] == 0 and d == (1, 1, 1) and not self.return_indices and not self.ceil_mode and k[1] * k[2] <= 255
+                    and p[1] < k[1] and p[2] < k[2] and x.C % 4 == 0):
+                return ops.pool_cl(x, k[1:], s[1:], p[1:])
+            x = x.planes()
         if (x.dim() == 5 and x.is_cuda and x.dtype == torch.float32 and k[0] == 1 and s[0] == 1 and p[0] == 0 and d == (1, 1, 1)
                 and not self.return_indices and not self.ceil_mode and k[1] * k[2] <= 255):
             return ops.pool_planes(x, k[1:], s[1:], p[1:])
@@ -76,9 +95,11 @@ def _norm_relu3d(kind, channels):
 
 def _vgg_group(idx, norm):
     """Layer group `conv{idx}` of the VGG-M style stem (reference backbone.py:73-103,179-184,243-271)."""
+    chain = norm == 'bn'                  # BatchNorm3d + ReLU have a channels-last kernel; GroupNorm stems stay on planes
     if idx == 1:
-        return [Conv3d(3, 64, 3, stride=(1, 2, 2), padding=(1, 0, 0))] + _norm_relu3d(norm, 64) + \
-               [SpatialMaxPool3d(kernel_size=(1, 2, 2), stride=(1, 2, 2))]
+        c1 = Conv3d(3, 64, 3, stride=(1, 2, 2), padding=(1, 0, 0))
+        c1.cl_chain = chain
+        return [c1] + _norm_relu3d(norm, 64) + [SpatialMaxPool3d(kernel_size=(1, 2, 2), stride=(1, 2, 2))]
     cin, cout, pool = {2: (64, 128, True), 3: (128, 256, True), 4: (256, 512, False), 5: (512, 512, False)}[idx]
     mods = [Conv3d(cin, cout, 3, 1, padding=(1, 0, 0))] + _norm_relu3d(norm, cout)
     if pool:
@@ -112,6 +133,10 @@ def _simple_tcn(in_dim, hidden, k, pad):
 
 def _squeeze_hw(x):
     """[B,C,T,1,1] -> [B,C,T] (the reference's bare .squeeze() also drops B or T when they are 1)."""
+    if isinstance(x, ops.CLTensor):          # the end of a channels-last stem: rows (n, t) x C
+        if x.H == 1 and x.W == 1:
+            return ops.btc_to_bct(x.data.view(x.N, x.T, x.C))
+        x = x.planes()
     return x.flatten(3).squeeze(-1)
 
 

@@ -1105,6 +1105,9 @@ def test_conv3d_forward_on_the_patch_matrix_gemm(Ci, Co, k, stride, pad, N, T, H
     (3, 64, (5, 7, 7), (1, 2, 2), (2, 3, 3), 1, 8, 32, 32),        # the 3-D ResNet stem: four-channel image, eight-tap rows (m3t_conv3d_fwd_taps4)
     (3, 64, (3, 3, 3), (1, 2, 2), (1, 0, 0), 2, 8, 17, 17),        # VGG-M conv1
     (1, 128, (1, 8, 8), (1, 1, 1), (0, 4, 4), 2, 4, 15, 15),       # one channel, all eight taps used, 128-wide tile
+    (64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), 3, 1, 5, 5),         # round 6: 75 rows -- one ragged row tile, a ragged reduction tile in the weight gradient
+    (64, 128, (1, 3, 3), (1, 2, 2), (0, 1, 1), 3, 1, 15, 15),      # stride 2 on an odd grid, 192 output rows: the parity classes have 8 x 8, 8 x 7, 7 x 8, 7 x 7 positions
+    (64, 128, (3, 3, 3), (2, 2, 2), (1, 1, 1), 2, 5, 9, 7),        # strides on all three axes (eight parity classes), ragged everywhere
 ])
 def test_conv3d_without_a_patch_matrix(Ci, Co, k, stride, pad, N, T, H, W):
     """Round 5, second half: forward (m3t_conv3d_fwd_taps on operands split once, any stride, bias in the epilogue) and weight gradient
@@ -1116,7 +1119,9 @@ def test_conv3d_without_a_patch_matrix(Ci, Co, k, stride, pad, N, T, H, W):
     xn, wn, bn_ = draw(rs, (N, Ci, T, H, W)), draw(rs, (Co, Ci) + k) * 0.2, draw(rs, (Co,))
     ctn = None
     res = []
-    for implicit in (True, True, False):
+    To, Ho, Wo = ((d + 2 * p_ - k_) // s_ + 1 for d, p_, k_, s_ in zip((T, H, W), pad, k, stride))
+    whole_tiles = (N * To * Ho * Wo) % 128 == 0            # (the patch-matrix GEMMs still need whole 128-row tiles: no third run otherwise)
+    for implicit in ((True, True, False) if whole_tiles else (True, True)):
         saved = ops.CONV3D_IMPLICIT[0]
         ops.CONV3D_IMPLICIT[0] = implicit
         n0 = dict(ops.CONV3D_CALLS)
@@ -1138,10 +1143,88 @@ def test_conv3d_without_a_patch_matrix(Ci, Co, k, stride, pad, N, T, H, W):
     close(res[0][2], b64.grad.numpy(), 2e-4, "db")
     close(res[0][3], x64.grad.numpy(), 2e-4, "dx")
     for a, b_, what in zip(res[0], res[1], ("y", "dw", "db", "dx")):
-        if what != "dx" or tuple(stride) == (1, 1, 1):          # (a strided layer's data gradient is MIOpen's)
+        if what != "dx" or tuple(stride) == (1, 1, 1) or (Ci % 64 == 0 and Co % 32 == 0):      # (strided layers: parity-class walks since round 6, else MIOpen's)
             assert torch.equal(a, b_), "reruns differ: " + what
-    for a, b_, what in zip(res[0], res[2], ("y", "dw", "db", "dx")):
-        close(a, b_.cpu().numpy(), 2e-4, what + " vs the patch-matrix path")
+    if whole_tiles:
+        for a, b_, what in zip(res[0], res[2], ("y", "dw", "db", "dx")):
+            close(a, b_.cpu().numpy(), 2e-4, what + " vs the patch-matrix path")
+
+
+@pytest.mark.parametrize("N,C_,T,H,W,training", [(3, 64, 2, 7, 9, True), (2, 128, 4, 12, 12, True), (2, 512, 3, 1, 1, False), (1, 256, 1, 5, 5, True)])
+def test_channels_last_stem_operators(N, C_, T, H, W, training):
+    """csrc/stem_cl.hip (round 6): BatchNorm3d + ReLU and MaxPool3d((1, k, k)) of the 3-D stems (reference models/backbone.py:73-103,179-191) on
+    channels-last rows [N T H W][C], and the convolution between them as a tap walk that reads and writes that layout (ops.conv3d_cl) --
+    outputs, running statistics, input and parameter gradients against float64 torch on the CPU; the kernels' magnitude slots cover what
+    they wrote"""
+    from m3t import ops
+    rs = np.random.RandomState(N * 100 + C_ + H)
+    xn = draw(rs, (N, C_, T, H, W)) * 2.0 + 0.3
+    gam, bet = 1.0 + 0.1 * draw(rs, (C_,)), 0.1 * draw(rs, (C_,))
+    rm, rv = 0.1 * draw(rs, (C_,)), np.abs(draw(rs, (C_,))) * 0.5 + 0.5
+    to_cl = lambda a: np.ascontiguousarray(np.transpose(a, (0, 2, 3, 4, 1))).reshape(-1, a.shape[1])
+    x = dev(to_cl(xn), True)
+    g_, b_ = dev(gam, True), dev(bet, True)
+    rmd, rvd = dev(rm.copy()), dev(rv.copy())
+    xc = ops.CLTensor(x, N, T, H, W, None)
+    y = ops.bn_cl(xc, g_, b_, rmd, rvd, training, 0.1, 1e-5, True)
+    geo = [((2, 2), (2, 2), (0, 0)), ((3, 3), (2, 2), (1, 1))][(H + W) % 2] if min(H, W) >= 3 else None
+    z = ops.pool_cl(y, *geo) if geo else y
+    ct = draw(rs, tuple(z.data.shape))
+    (z.data * dev(ct)).sum().backward()
+    # magnitude slots
+    torch.cuda.synchronize()
+    assert int(y.slot.item()) & 0xffffffff == int(torch.tensor([float(y.data.abs().max())]).view(torch.int32).item())
+    if geo:
+        assert int(z.slot.item()) & 0xffffffff == int(torch.tensor([float(z.data.abs().max())]).view(torch.int32).item())
+    # float64 torch
+    x64 = torch.tensor(xn, dtype=torch.float64, requires_grad=True)
+    g64, b64 = torch.tensor(gam, dtype=torch.float64, requires_grad=True), torch.tensor(bet, dtype=torch.float64, requires_grad=True)
+    rm64, rv64 = torch.tensor(rm, dtype=torch.float64), torch.tensor(rv, dtype=torch.float64)
+    y64 = torch.relu(torch.nn.functional.batch_norm(x64, rm64, rv64, g64, b64, training, 0.1, 1e-5))
+    z64 = torch.nn.functional.max_pool3d(y64, (1,) + geo[0], (1,) + geo[1], (0,) + geo[2]) if geo else y64
+    ct64 = torch.tensor(ct, dtype=torch.float64).view(z64.shape[0], z64.shape[2], z64.shape[3], z64.shape[4], C_).permute(0, 4, 1, 2, 3)
+    (z64 * ct64).sum().backward()
+    close(y.data, to_cl(y64.detach().numpy()), 2e-5, "bn + relu")
+    close(z.data, to_cl(z64.detach().numpy()), 2e-5, "pool")
+    close(x.grad, to_cl(x64.grad.numpy()), 1e-4, "dx")
+    close(g_.grad, g64.grad.numpy(), 2e-4, "dgamma")
+    close(b_.grad, b64.grad.numpy(), 2e-4, "dbeta")
+    if training:
+        close(rmd, rm64.numpy(), 1e-5, "running_mean")
+        close(rvd, rv64.numpy(), 1e-5, "running_var")
+
+
+@pytest.mark.parametrize("Ci,Co,k,stride,pad,N,T,H,W", [(64, 128, (3, 3, 3), (1, 1, 1), (1, 0, 0), 2, 4, 9, 9), (3, 64, (3, 3, 3), (1, 2, 2), (1, 0, 0), 2, 3, 17, 17),
+                                                       (128, 64, (1, 3, 3), (1, 2, 2), (0, 1, 1), 3, 1, 7, 7)])
+def test_conv3d_on_channels_last_rows(Ci, Co, k, stride, pad, N, T, H, W):
+    """ops.conv3d_cl: the stems' convolutions reading and writing channels-last rows (no transpose on either side): forward, weight / bias
+    gradient and the data gradient (strided: parity-class walks scattered into the channels-last grid) against float64 autograd; a first
+    layer takes the video planes"""
+    from m3t import ops
+    rs = np.random.RandomState(Ci + Co + H)
+    xn, wn, bn_ = draw(rs, (N, Ci, T, H, W)), draw(rs, (Co, Ci) + k) * 0.2, draw(rs, (Co,))
+    to_cl = lambda a: np.ascontiguousarray(np.transpose(a, (0, 2, 3, 4, 1))).reshape(-1, a.shape[1])
+    first = Ci <= 4
+    w, b = dev(wn, True), dev(bn_, True)
+    if first:
+        x = dev(xn)
+        y = ops.conv3d_cl(x, w, b, stride, pad)
+    else:
+        x = dev(to_cl(xn), True)
+        y = ops.conv3d_cl(ops.CLTensor(x, N, T, H, W, None), w, b, stride, pad)
+    ct = draw(rs, tuple(y.data.shape))
+    (y.data * dev(ct)).sum().backward()
+    x64, w64, b64 = (torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (xn, wn, bn_))
+    y64 = torch.conv3d(x64, w64, b64, stride, pad)
+    assert (y.N, y.T, y.H, y.W) == (y64.shape[0], y64.shape[2], y64.shape[3], y64.shape[4])
+    ct64 = torch.tensor(ct, dtype=torch.float64).view(y.N, y.T, y.H, y.W, Co).permute(0, 4, 1, 2, 3)
+    (y64 * ct64).sum().backward()
+    close(y.data, to_cl(y64.detach().numpy()), 1e-4, "y")
+    close(w.grad, w64.grad.numpy(), 2e-4, "dw")
+    close(b.grad, b64.grad.numpy(), 2e-4, "db")
+    if not first:
+        close(x.grad, to_cl(x64.grad.numpy()), 2e-4, "dx")
+    close(y.planes(), y64.detach().numpy(), 1e-4, "planes()")
 
 
 def test_gradient_sinks_of_the_visual_stack_change_nothing(monkeypatch):
@@ -1190,7 +1273,9 @@ def test_conv_walk_entry_points_planes_output_and_refusals():
     lib = ops.lib()
     rs = np.random.RandomState(3)
     for (N, Ci, Co, T, H, W, k, pd) in ((8, 64, 64, 1, 8, 8, (1, 3, 3), (0, 1, 1)),          # one K pass: the epilogue writes planes
-                                        (4, 128, 256, 8, 4, 4, (3, 3, 3), (1, 1, 1))):       # deep layer: split-K slabs, reduction, transpose
+                                        (4, 128, 256, 8, 4, 4, (3, 3, 3), (1, 1, 1)),        # deep layer: split-K slabs, reduction, transpose
+                                        (3, 64, 64, 1, 5, 5, (1, 3, 3), (0, 1, 1)),          # round 6: 75 rows -- a ragged (and only) row tile, planes of 25
+                                        (3, 128, 256, 3, 5, 7, (3, 3, 3), (1, 1, 1))):       # 315 rows: two whole tiles and a ragged one, split-K
         x = dev(draw(rs, (N * T * H * W, Ci)))
         w = dev(draw(rs, (Co, k[0] * k[1] * k[2] * Ci)) * 0.1)
         b = dev(draw(rs, (Co,)))
@@ -1215,10 +1300,9 @@ def test_conv_walk_entry_points_planes_output_and_refusals():
     # refusals
     bad = (N, Ci, 96, T, H, W, 3, 3, 3, 1, 1, 1, 1, 1, 1, sl.data_ptr(), sl.data_ptr() + 8, None, 0)       # C_out % 64 != 0
     assert lib.m3t_conv3d_fwd_taps(ops._p(xi), ops._p(wi), None, ops._p(y_cl), *bad, None, st) == _lib.M3T_EINVAL
-    bad = (3, Ci, Co, 1, 5, 5, 1, 3, 3, 1, 1, 1, 0, 1, 1, sl.data_ptr(), sl.data_ptr() + 8, None, 0)       # 75 output rows: no 128-row tiles
+    bad = (N, 40, Co, T, H, W, 3, 3, 3, 1, 1, 1, 1, 1, 1, sl.data_ptr(), sl.data_ptr() + 8, None, 0)       # C_in % 32 != 0 (and not a first layer)
     assert lib.m3t_conv3d_fwd_taps(ops._p(xi), ops._p(wi), None, ops._p(y_cl), *bad, None, st) == _lib.M3T_EINVAL
-    assert lib.m3t_conv3d_wgrad_taps(ops._p(x), ops._p(y_cl), ops._p(y_cl2), 3, Ci, Co, 1, 5, 5, 1, 3, 3, 1, 1, 1, 0, 1, 1, _lib.M3T_GEMM_F16X3,
-                                     None, None, None, 0, st) == _lib.M3T_EINVAL                         # 75 reduction rows: not whole 32-row tiles
+    # (rows need not fill tiles any more -- the two ragged cases above; the weight gradient over 75 reduction rows: test_conv3d_without_a_patch_matrix)
     assert lib.m3t_conv3d_fwd_taps4(ops._p(xi), ops._p(wi), None, ops._p(y_cl), 2, 64, 4, 16, 16, 1, 3, 9, 1, 1, 1, 0, 1, 4, sl.data_ptr(),
                                     sl.data_ptr() + 8, None, 0, None, st) == _lib.M3T_EINVAL              # nine taps in a row: the image holds eight
     assert lib.m3t_planes_to_cl4(ops._p(x), ops._p(y_cl), 2, 5, 64, st) == _lib.M3T_EINVAL                # more than four channels
@@ -1584,6 +1668,8 @@ def test_c5_temporal_part_on_the_references_stem_features(name):
     batch = _affwild_batch(np.random.RandomState(seed), B, T, video=True)
     with torch.no_grad():
         own_v = m.visual.v_private(m.visual.shared((batch["video"] - 127.5) / 127.5))
+        if not isinstance(own_v, torch.Tensor):          # round 6: the stem is a channels-last chain (m3t.ops.CLTensor)
+            own_v = own_v.planes()
     stem_err = float((own_v.cpu().double() - torch.from_numpy(g["feat_v"]).double()).abs().max())
     y_e2e = m(batch)
     fv, fa = dev(g["feat_v"]), dev(g["feat_a"])
