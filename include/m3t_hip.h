@@ -108,6 +108,11 @@ int m3t_conv3d_taps(const float* src, const float* w_taps, float* dst, int N, in
  * m3t_conv3d_taps_pre: m3t_conv3d_taps on the image of src and on w_img[cd][(tap, cs)] (the image of the K-contiguous weight matrix), under
  * the slots the images were made with.  Bit-identical to the in-kernel split (the same roundings).  cols % 4, ld % 4, 16-B aligned. */
 int m3t_f16x3_split(const float* x, size_t rows, int cols, size_t ld, float* out, size_t ldo, const unsigned long long* slot, void* stream);
+/* ... of a permuted view (round 6): out [R][T * Cc] <- the image of w[r * sR + t * sT + c * sC] -- a convolution's weights [Co][Ci][taps] as the
+ * K-contiguous matrix a walk reads ([co][(tap, ci)]: R = Co, Cc = Ci, sR = Ci taps, sT = 1, sC = taps; [ci][(tap, co)]: R = Ci, Cc = Co, sR =
+ * taps, sT = 1, sC = Ci taps) without a permute copy in front of the split.  Cc % 4 == 0, out 16-B aligned. */
+int m3t_f16x3_split_perm(const float* w, size_t R, int T, int Cc, size_t sR, size_t sT, size_t sC, float* out, const unsigned long long* slot,
+                         void* stream);
 /* C[M,N] = act(A B^T + bias) (+ C) with A [M][K] and B [N][K] given as images (the NT product of m3t_sgemm_scaled, fp16x3 mode; M % 128 == 0,
  * N % 64 == 0, K % 32 == 0, both slots required) */
 int m3t_sgemm_pre(int M, int N, int K, const float* A_img, int lda, const float* B_img, int ldb, float* C, int ldc,
@@ -452,7 +457,8 @@ size_t m3t_va_loss_ws_bytes(int rows);
  * m3t_bn_cl_fwd / _bwd: BatchNorm (+ fused ReLU) over rows x [M][C] at any M (semantics of m3t_bn_rows_fwd / _bwd: batch statistics with
  *   torch's running-statistics update when training, fp64 per-chunk partials reduced in a fixed order); C % 4 == 0, C / 4 divides 256
  *   (C = 64 ... 1024 in powers of two), 16-B aligned tensors; ws: m3t_bn_cl_ws_bytes(M, C) bytes, 8-B aligned.  m3t_amax_out arms the
- *   magnitude slot of y (forward) / dx (backward): the next tap walk scales by it.
+ *   magnitude slot of y (forward) / dx (backward): the next tap walk scales by it.  dx_colsum [C] (optional): the column sums of dx -- the bias
+ *   gradient of the convolution in front of this BatchNorm -- from the dx pass itself (block partials summed in block order).
  * m3t_pool_cl_fwd / _bwd: max pooling of P frames x [P][H][W][C] with a (kh, kw) window, stride (sh, sw), padding (ph, pw) -- nn.MaxPool3d((1,
  *   kh, kw)) on channels-last rows; win [P][Ho][Wo][C] bytes: the winner's place in its window (ties: the first maximum in window order, NaN
  *   wins, as torch); backward is a gather (no atomics, deterministic).  C % 4 == 0, kh kw <= 255, padding < window.  m3t_amax_out arms y's slot. */
@@ -460,7 +466,7 @@ size_t m3t_bn_cl_ws_bytes(size_t M, int C);
 int m3t_bn_cl_fwd(const float* x, size_t M, int C, const float* gamma, const float* beta, float* run_mean, float* run_var, float momentum,
                   float eps, int training, int relu, float* y, float* save_mean, float* save_invstd, float* ws, size_t ws_bytes, void* stream);
 int m3t_bn_cl_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* save_mean, const float* save_invstd, size_t M,
-                  int C, int training, int relu, float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes, void* stream);
+                  int C, int training, int relu, float* dx, float* dgamma, float* dbeta, float* dx_colsum, float* ws, size_t ws_bytes, void* stream);
 int m3t_pool_cl_fwd(const float* x, size_t P, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw, float* y, unsigned char* win,
                     void* stream);
 int m3t_pool_cl_bwd(const float* dy, const unsigned char* win, size_t P, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw,

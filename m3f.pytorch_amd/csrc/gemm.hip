@@ -825,6 +825,31 @@ __global__ __launch_bounds__(256) void f16x3_split_kernel(const float* __restric
         *reinterpret_cast<float4*>(out + r * ldo + 4 * (size_t)c) = o;
     }
 }
+// ... of a PERMUTED view of a small tensor (round 6: a convolution's weights [Co][Ci][taps] as the K-contiguous matrices the walks read --
+// [co][(tap, ci)] forward, [ci][(tap, co)] data gradient -- without a permute copy in front of the split): out[r][t * Cc + c] from
+// w[r * sR + t * sT + c * sC], four consecutive c per thread (strided reads: the tensors are a few MB)
+__global__ __launch_bounds__(256) void f16x3_split_perm_kernel(const float* __restrict__ w, float* __restrict__ out, size_t R, int T, int Cc, size_t sR,
+                                                               size_t sT, size_t sC, const unsigned long long* __restrict__ slot) {
+    float sc, inv;
+    m3t_f16_scale((unsigned)*slot, sc, inv);
+    const int c4 = Cc >> 2;
+    const size_t total = R * (size_t)T * c4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % (size_t)c4);
+        const size_t rt = i / (size_t)c4;
+        const int t = (int)(rt % (size_t)T);
+        const size_t r = rt / (size_t)T;
+        const float* q = w + r * sR + (size_t)t * sT + (size_t)(4 * c) * sC;
+        const sp_f32x2 a = (sp_f32x2){q[0], q[sC]} * sc, b = (sp_f32x2){q[2 * sC], q[3 * sC]} * sc;
+        const sp_f16x2 ha = __builtin_convertvector(a, sp_f16x2), hb = __builtin_convertvector(b, sp_f16x2);
+        const sp_f16x2 la = __builtin_convertvector(a - __builtin_convertvector(ha, sp_f32x2), sp_f16x2);
+        const sp_f16x2 lb = __builtin_convertvector(b - __builtin_convertvector(hb, sp_f32x2), sp_f16x2);
+        float4 o;
+        o.x = __uint_as_float(__builtin_bit_cast(unsigned, ha)); o.y = __uint_as_float(__builtin_bit_cast(unsigned, hb));
+        o.z = __uint_as_float(__builtin_bit_cast(unsigned, la)); o.w = __uint_as_float(__builtin_bit_cast(unsigned, lb));
+        *reinterpret_cast<float4*>(out + (r * T + t) * (size_t)Cc + 4 * (size_t)c) = o;
+    }
+}
 }  // namespace
 
 int m3t_sgemm_x6_pre_launch(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc, const float* bias,
@@ -948,6 +973,17 @@ extern "C" int m3t_sgemm_ring(int transA, int transB, int M, int N, int K, const
 }
 
 // include/m3t_hip.h
+extern "C" int m3t_f16x3_split_perm(const float* w, size_t R, int T, int Cc, size_t sR, size_t sT, size_t sC, float* out,
+                                    const unsigned long long* slot, void* stream) {
+    if (R == 0 || T <= 0 || Cc <= 0) return 0;
+    if (!w || !out || !slot || Cc % 4 != 0 || (uintptr_t)out % 16 != 0) return M3T_EINVAL;
+    const size_t total = R * (size_t)T * (Cc / 4);
+    int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    f16x3_split_perm_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(w, out, R, T, Cc, sR, sT, sC, slot);
+    M3T_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int m3t_f16x3_split(const float* x, size_t rows, int cols, size_t ld, float* out, size_t ldo, const unsigned long long* slot,
                                void* stream) {
     if (rows == 0 || cols <= 0) return 0;

@@ -32,25 +32,41 @@ __global__ __launch_bounds__(CL_TH) void bncl_partial_kernel(const float* __rest
         for (int e = 0; e < 4; ++e) { mu[e] = mean[4 * q + e]; is[e] = invstd[4 * q + e]; }
     }
     if (g < groups) {
-        for (size_t r = r0 + g; r < r1; r += groups) {
-            const size_t o = r * C + 4 * q;
-            const float4 v = *reinterpret_cast<const float4*>(a + o);
-            float ve[4] = {v.x, v.y, v.z, v.w};
-            if (MODE == 0) {
+        // four rows in flight per thread (the loads of all four issued before the first is used); their sum in fp32, the running sums in fp64
+        for (size_t rb = r0 + g; rb < r1; rb += (size_t)4 * groups) {
+            float4 av[4], xv4[4], yv4[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { const double d = (double)ve[e]; s[e] += d; t[e] += d * d; }
-            } else {
-                const float4 xv = *reinterpret_cast<const float4*>(x + o);
-                const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
-                if (relu) {
-                    const float4 yv = *reinterpret_cast<const float4*>(y + o);
-                    const float ye[4] = {yv.x, yv.y, yv.z, yv.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) if (!(ye[e] > 0.f)) ve[e] = 0.f;
+            for (int u = 0; u < 4; ++u) {
+                const size_t r = rb + (size_t)u * groups;
+                const bool in = r < r1;
+                const size_t o = (in ? r : rb) * C + 4 * q;
+                av[u] = *reinterpret_cast<const float4*>(a + o);
+                if (!in) av[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (MODE == 1) {
+                    xv4[u] = *reinterpret_cast<const float4*>(x + o);
+                    if (relu) yv4[u] = *reinterpret_cast<const float4*>(y + o);
                 }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { s[e] += (double)ve[e]; t[e] += (double)(ve[e] * ((xe[e] - mu[e]) * is[e])); }
             }
+            float fs[4] = {0.f, 0.f, 0.f, 0.f}, ft[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float ve[4] = {av[u].x, av[u].y, av[u].z, av[u].w};
+                if (MODE == 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { fs[e] += ve[e]; ft[e] = fmaf(ve[e], ve[e], ft[e]); }
+                } else {
+                    const float xe[4] = {xv4[u].x, xv4[u].y, xv4[u].z, xv4[u].w};
+                    if (relu) {
+                        const float ye[4] = {yv4[u].x, yv4[u].y, yv4[u].z, yv4[u].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (!(ye[e] > 0.f)) ve[e] = 0.f;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { fs[e] += ve[e]; ft[e] = fmaf(ve[e], (xe[e] - mu[e]) * is[e], ft[e]); }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s[e] += (double)fs[e]; t[e] += (double)ft[e]; }
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) { red[(size_t)g * C + 4 * q + e] = s[e]; red[(size_t)(groups + g) * C + 4 * q + e] = t[e]; }
@@ -65,13 +81,39 @@ __global__ __launch_bounds__(CL_TH) void bncl_partial_kernel(const float* __rest
 }
 
 // mean / biased variance -> invstd; running statistics as torch (unbiased variance)
-__global__ void bncl_stats_final_kernel(const double* __restrict__ partial, int nchunks, double M, int C, float eps, float momentum,
-                                        float* __restrict__ run_mean, float* __restrict__ run_var, float* __restrict__ mean,
-                                        float* __restrict__ invstd) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, ss = 0.0;
-    for (int k = 0; k < nchunks; ++k) { s += partial[((size_t)k * 2 + 0) * C + c]; ss += partial[((size_t)k * 2 + 1) * C + c]; }
+// (both final kernels: 64 channels per block, the chunks in four interleaved phases -- thread (channel, phase) adds every fourth chunk, the four
+// phase sums are combined in phase order: a fixed order, four times shorter a dependent chain than one thread per channel)
+__device__ __forceinline__ void bncl_sum_chunks(const double* __restrict__ partial, int nchunks, int C, int c, double& s, double& t,
+                                                double (&red)[2][4][64]) {
+    const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    double a = 0.0, b = 0.0;
+    if (c < C) {
+        double a4[4] = {0.0, 0.0, 0.0, 0.0}, b4[4] = {0.0, 0.0, 0.0, 0.0};      // four loads in flight per statistic; combined in index order
+        int k = ph;
+        for (; k + 12 < nchunks; k += 16) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a4[u] += partial[((size_t)(k + 4 * u) * 2 + 0) * C + c];
+                b4[u] += partial[((size_t)(k + 4 * u) * 2 + 1) * C + c];
+            }
+        }
+        for (; k < nchunks; k += 4) { a4[0] += partial[((size_t)k * 2 + 0) * C + c]; b4[0] += partial[((size_t)k * 2 + 1) * C + c]; }
+        a = (a4[0] + a4[1]) + (a4[2] + a4[3]); b = (b4[0] + b4[1]) + (b4[2] + b4[3]);
+    }
+    red[0][ph][cl] = a; red[1][ph][cl] = b;
+    __syncthreads();
+    s = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+    t = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+}
+
+__global__ __launch_bounds__(256) void bncl_stats_final_kernel(const double* __restrict__ partial, int nchunks, double M, int C, float eps,
+                                                               float momentum, float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                               float* __restrict__ mean, float* __restrict__ invstd) {
+    __shared__ double red[2][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    double s, ss;
+    bncl_sum_chunks(partial, nchunks, C, c, s, ss, red);
+    if (c >= C || threadIdx.x >= 64) return;
     const double mu = s / M;
     double var = ss / M - mu * mu;
     if (var < 0.0) var = 0.0;
@@ -90,12 +132,13 @@ __global__ void bncl_eval_stats_kernel(const float* __restrict__ run_mean, const
     mean[c] = run_mean[c];
     invstd[c] = 1.0f / sqrtf(run_var[c] + eps);
 }
-__global__ void bncl_bwd_final_kernel(const double* __restrict__ partial, int nchunks, int C, float* __restrict__ sums, float* __restrict__ dgamma,
-                                      float* __restrict__ dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, sx = 0.0;
-    for (int k = 0; k < nchunks; ++k) { s += partial[((size_t)k * 2 + 0) * C + c]; sx += partial[((size_t)k * 2 + 1) * C + c]; }
+__global__ __launch_bounds__(256) void bncl_bwd_final_kernel(const double* __restrict__ partial, int nchunks, int C, float* __restrict__ sums,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ double red[2][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    double s, sx;
+    bncl_sum_chunks(partial, nchunks, C, c, s, sx, red);
+    if (c >= C || threadIdx.x >= 64) return;
     sums[c] = (float)s; sums[C + c] = (float)sx;
     if (dbeta) dbeta[c] = (float)s;
     if (dgamma) dgamma[c] = (float)sx;
@@ -107,8 +150,10 @@ __global__ __launch_bounds__(CL_TH) void bncl_map_kernel(const float* __restrict
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
                                                          const float* __restrict__ sums, float* __restrict__ out, size_t total4, int C,
-                                                         float inv_count, int training, int relu, unsigned long long* __restrict__ slot) {
+                                                         float inv_count, int training, int relu, unsigned long long* __restrict__ slot,
+                                                         float* __restrict__ colpart) {
     __shared__ float red4[4];
+    __shared__ float csum[CL_TH * 4];
     const int c4n = C >> 2;
     const size_t i0 = (size_t)blockIdx.x * CL_TH + threadIdx.x;
     const int q = (int)(i0 % (size_t)c4n);
@@ -123,6 +168,7 @@ __global__ __launch_bounds__(CL_TH) void bncl_map_kernel(const float* __restrict
         k2[e] = (MODE == 1 && training) ? sums[C + c] * inv_count : 0.f;
     }
     float mx = 0.f;
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};                      // MODE 1 + colpart: this thread's sums of dx over its rows (its four channels are fixed)
     for (size_t i = i0; i < total4; i += (size_t)gridDim.x * CL_TH) {
         const float4 v = reinterpret_cast<const float4*>(a)[i];
         const float ve[4] = {v.x, v.y, v.z, v.w};
@@ -146,13 +192,48 @@ __global__ __launch_bounds__(CL_TH) void bncl_map_kernel(const float* __restrict
         }
         reinterpret_cast<float4*>(out)[i] = make_float4(o[0], o[1], o[2], o[3]);
         if (slot) mx = fmaxf(fmaxf(mx, fmaxf(m3t_fin_abs(o[0]), m3t_fin_abs(o[1]))), fmaxf(m3t_fin_abs(o[2]), m3t_fin_abs(o[3])));
+        if (MODE == 1 && colpart) { cs[0] += o[0]; cs[1] += o[1]; cs[2] += o[2]; cs[3] += o[3]; }
+    }
+    if (MODE == 1 && colpart) {
+        // block partial [C]: the 256 / (C / 4) threads that share a channel quad, in thread order (deterministic); colpart [blocks][C]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) csum[threadIdx.x * 4 + e] = cs[e];
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += CL_TH) {
+            float t = 0.f;
+            const int base = (int)((size_t)blockIdx.x * CL_TH % (size_t)c4n);      // quad of this block's thread 0
+            const int first = ((c >> 2) - base + c4n) % c4n;                        // first thread of the block that holds quad c / 4
+            for (int th = first; th < CL_TH; th += c4n) t += csum[th * 4 + (c & 3)];
+            colpart[(size_t)blockIdx.x * C + c] = t;
+        }
+        __syncthreads();
     }
     if (slot) m3t_block_raise_slot(slot, mx, red4);         // (uniform: every thread of the block gets here)
 }
 
+// out[c] = sum over the blocks' partials, in block order
+__global__ __launch_bounds__(256) void bncl_colsum_final_kernel(const float* __restrict__ colpart, int nblocks, int C, float* __restrict__ out) {
+    __shared__ double red[4][64];
+    const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+    double t = 0.0;
+    if (c < C) {
+        double t8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};                  // eight loads in flight; combined in index order
+        int k = ph;
+        for (; k + 28 < nblocks; k += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t8[u] += (double)colpart[(size_t)(k + 4 * u) * C + c];
+        }
+        for (; k < nblocks; k += 4) t8[0] += (double)colpart[(size_t)k * C + c];
+        t = ((t8[0] + t8[1]) + (t8[2] + t8[3])) + ((t8[4] + t8[5]) + (t8[6] + t8[7]));
+    }
+    red[ph][cl] = t;
+    __syncthreads();
+    if (ph == 0 && c < C) out[c] = (float)(red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+}
+
 static int cl_chunks(size_t M) {
-    size_t c = (M + 511) / 512;
-    return (int)(c < 1 ? 1 : (c > 2048 ? 2048 : c));
+    size_t c = (M + 255) / 256;
+    return (int)(c < 1 ? 1 : (c > 1024 ? 1024 : c));
 }
 
 // ---- pooling of channels-last frames [P][H][W][C]: thread = (output position, channel quad)
@@ -227,10 +308,10 @@ __global__ __launch_bounds__(CL_TH) void poolcl_bwd_kernel(const float* __restri
 }
 
 static int grid_for(size_t total4, int c4n) {
-    // a grid whose stride (blocks x 256) is a multiple of C / 4 (it divides 256), >= ~16 float4 per thread, at most 8192 blocks
+    // a grid whose stride (blocks x 256) is a multiple of C / 4 (it divides 256), >= ~16 float4 per thread, at most 2048 blocks
     size_t b = (total4 + (size_t)CL_TH * 16 - 1) / ((size_t)CL_TH * 16);
     if (b < 1) b = 1;
-    if (b > 8192) b = 8192;
+    if (b > 2048) b = 2048;
     (void)c4n;
     return (int)b;
 }
@@ -240,7 +321,9 @@ static int grid_for(size_t total4, int c4n) {
 // BatchNorm (+ReLU) over channels-last rows x [M][C] at any M (the 3-D stems: M = N T H W up to millions); C % 4 == 0, C / 4 divides 256, 16-B
 // aligned tensors.  Semantics of m3t_bn_rows_fwd / _bwd.  m3t_amax_out arms the magnitude slot of y (forward) / dx (backward).
 extern "C" size_t m3t_bn_cl_ws_bytes(size_t M, int C) {
-    return (size_t)cl_chunks(M) * 2 * (size_t)C * sizeof(double) + 2 * (size_t)C * sizeof(float) + 256;
+    // fp64 chunk partials | sums [2 C] | the dx pass's block partials [<= 2048 blocks][C] (m3t_bn_cl_bwd with dx_colsum)
+    return (size_t)cl_chunks(M) * 2 * (size_t)C * sizeof(double) + 2 * (size_t)C * sizeof(float) + 512 +
+           (size_t)grid_for(M * (size_t)(C / 4), C / 4) * C * sizeof(float);
 }
 
 static bool bncl_shape_ok(size_t M, int C) { return C > 0 && C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && M > 0; }
@@ -261,7 +344,7 @@ extern "C" int m3t_bn_cl_fwd(const float* x, size_t M, int C, const float* gamma
         const int groups = CL_TH / (C / 4);
         bncl_partial_kernel<0><<<nch, CL_TH, (size_t)2 * groups * C * sizeof(double), s>>>(x, nullptr, nullptr, nullptr, nullptr, M, C, rpc, 0, partial);
         M3T_LAUNCH_CHECK();
-        bncl_stats_final_kernel<<<cdiv(C, 256), 256, 0, s>>>(partial, nch, (double)M, C, eps, momentum, run_mean, run_var, save_mean, save_invstd);
+        bncl_stats_final_kernel<<<cdiv(C, 64), 256, 0, s>>>(partial, nch, (double)M, C, eps, momentum, run_mean, run_var, save_mean, save_invstd);
         M3T_LAUNCH_CHECK();
     } else {
         bncl_eval_stats_kernel<<<cdiv(C, 256), 256, 0, s>>>(run_mean, run_var, C, eps, save_mean, save_invstd);
@@ -269,14 +352,14 @@ extern "C" int m3t_bn_cl_fwd(const float* x, size_t M, int C, const float* gamma
     }
     const size_t total4 = M * (size_t)(C / 4);
     bncl_map_kernel<0><<<grid_for(total4, C / 4), CL_TH, 0, s>>>(x, nullptr, nullptr, gamma, beta, save_mean, save_invstd, nullptr, y, total4, C, 0.f,
-                                                                training, relu, slot);
+                                                                training, relu, slot, nullptr);
     M3T_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int m3t_bn_cl_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* save_mean, const float* save_invstd,
-                             size_t M, int C, int training, int relu, float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes,
-                             void* stream) {
+                             size_t M, int C, int training, int relu, float* dx, float* dgamma, float* dbeta, float* dx_colsum, float* ws,
+                             size_t ws_bytes, void* stream) {
     unsigned long long* slot = m3t_take_amax_out();
     if (!bncl_shape_ok(M, C) || !dy || !x || !dx || !save_mean || !save_invstd || ((uintptr_t)dy % 16) != 0 || ((uintptr_t)x % 16) != 0 ||
         ((uintptr_t)dx % 16) != 0)
@@ -291,12 +374,20 @@ extern "C" int m3t_bn_cl_bwd(const float* dy, const float* x, const float* y, co
     const int groups = CL_TH / (C / 4);
     bncl_partial_kernel<1><<<nch, CL_TH, (size_t)2 * groups * C * sizeof(double), s>>>(dy, x, y, save_mean, save_invstd, M, C, rpc, relu, partial);
     M3T_LAUNCH_CHECK();
-    bncl_bwd_final_kernel<<<cdiv(C, 256), 256, 0, s>>>(partial, nch, C, sums, dgamma, dbeta);
+    bncl_bwd_final_kernel<<<cdiv(C, 64), 256, 0, s>>>(partial, nch, C, sums, dgamma, dbeta);
     M3T_LAUNCH_CHECK();
     const size_t total4 = M * (size_t)(C / 4);
-    bncl_map_kernel<1><<<grid_for(total4, C / 4), CL_TH, 0, s>>>(dy, x, y, gamma, nullptr, save_mean, save_invstd, sums, dx, total4, C,
-                                                                (float)(1.0 / (double)M), training, relu, slot);
+    // dx_colsum [C] (optional): the column sums of dx = the bias gradient of the convolution in front of this BatchNorm, from the same pass
+    // (block partials behind the fp64 partials in ws, summed in block order)
+    const int nblk = grid_for(total4, C / 4);
+    float* colpart = dx_colsum ? sums + 2 * (size_t)C + 64 : nullptr;
+    bncl_map_kernel<1><<<nblk, CL_TH, 0, s>>>(dy, x, y, gamma, nullptr, save_mean, save_invstd, sums, dx, total4, C, (float)(1.0 / (double)M),
+                                             training, relu, slot, colpart);
     M3T_LAUNCH_CHECK();
+    if (dx_colsum) {
+        bncl_colsum_final_kernel<<<cdiv(C, 64), 256, 0, s>>>(colpart, nblk, C, dx_colsum);
+        M3T_LAUNCH_CHECK();
+    }
     return 0;
 }
 

@@ -58,6 +58,7 @@ SIGNATURES = {
     "m3t_conv3d_taps": [_f, _f, _f] + [_i] * 17 + [_f, _f, _f, _z, _f, _s],
     "m3t_sgemm_pre": [_i, _i, _i, _f, _i, _f, _i, _f, _i, _f, _i, _i, _f, _f, _s],
     "m3t_f16x3_split": [_f, _z, _i, _z, _f, _z, _f, _s],
+    "m3t_f16x3_split_perm": [_f, _z, _i, _i, _z, _z, _z, _f, _f, _s],
     "m3t_f16x3_image_b": [_f, _i, _i, _z, _f, _f, _s],
     "m3t_sgemm_bimg": [_i, _i, _i, _f, _i, _f, _f, _i, _f, _i, _i, _f, _z, _f, _f, _s],
     "m3t_sgemm_ring": [_i, _i, _i, _i, _i, _f, _i, _f, _i, _f, _i, _f, _i, _i, _i, _i, _i, _i, _f, _z, _i, _f, _f, _i, _s],
@@ -94,7 +95,7 @@ SIGNATURES = {
     "m3t_att_fuse_bwd": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _s],
     "m3t_bn_cl_ws_bytes": [_z, _i],
     "m3t_bn_cl_fwd": [_f, _z, _i, _f, _f, _f, _f, C.c_float, C.c_float, _i, _i, _f, _f, _f, _f, _z, _s],
-    "m3t_bn_cl_bwd": [_f, _f, _f, _f, _f, _f, _z, _i, _i, _i, _f, _f, _f, _f, _z, _s],
+    "m3t_bn_cl_bwd": [_f, _f, _f, _f, _f, _f, _z, _i, _i, _i, _f, _f, _f, _f, _f, _z, _s],
     "m3t_pool_cl_fwd": [_f, _z, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, C.c_void_p, _s],
     "m3t_pool_cl_bwd": [_f, C.c_void_p, _z, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _s],
     "m3t_va_loss": [_f, _i, _i, _i, _i, _f, _f, _f, _f, _i, C.c_float, C.c_float, C.c_float, _i, _f, _f, _f, _z, _s],

@@ -2739,10 +2739,10 @@ class CLTensor:
 _GRAD_SLOT = {}          # id of a gradient tensor OBJECT -> (weakref, slot tensor, version): slots of gradients handed from backward to backward
 
 
-def _note_grad_slot(t, slot):
+def _note_grad_slot(t, slot, colsum=None):
     if len(_GRAD_SLOT) > 64:
         _GRAD_SLOT.clear()
-    _GRAD_SLOT[id(t)] = (weakref.ref(t), slot, t._version, t.data_ptr())
+    _GRAD_SLOT[id(t)] = (weakref.ref(t), slot, t._version, t.data_ptr(), colsum)
 
 
 def _grad_slot(t):
@@ -2750,8 +2750,8 @@ def _grad_slot(t):
     unmodified (a sum of two branches' gradients, a copy or a view is another object: the consumer measures)"""
     e = _GRAD_SLOT.pop(id(t), None)
     if e is None or e[0]() is not t or e[2] != t._version or e[3] != t.data_ptr():
-        return None
-    return e[1]
+        return None, None
+    return e[1], e[4]
 
 
 def conv3d_cl_ok(x, w, stride, padding, groups, dilation, padding_mode):
@@ -2797,7 +2797,7 @@ class _Conv3dCL(torch.autograd.Function):
             _lib.check(lib().m3t_planes_to_cl4(_p(_req(x.contiguous(), "x")), _p(x_cl), N_, Ci, T_ * H_ * W_, _stream()), "m3t_planes_to_cl4")
         else:
             cw = Ci
-            w_t = _req(w.detach().permute(0, 2, 3, 4, 1).contiguous(), "weight").view(Co, taps * Ci)
+            w_t = None                               # (the [co][(tap, ci)] image is written straight from w: m3t_f16x3_split_perm)
             x_cl = _req(x, "x")
             if x_slot is not None:
                 a_x = x_slot.data_ptr()
@@ -2805,15 +2805,21 @@ class _Conv3dCL(torch.autograd.Function):
             else:
                 a_x = slots.data_ptr()
                 measure_amax([(x_cl, a_x)])
+        wc = _req(w.detach().contiguous(), "weight")
         if a_w is None:
             a_w = slots.data_ptr() + 8
-            measure_amax([(w_t, a_w)])
-        wk = w_t.shape[1]
-        x_img, w_img = torch.empty_like(x_cl), torch.empty_like(w_t)
+            if not measure_amax([(w_t if w_t is not None else wc.view(Co, -1), a_w)]):      # (max |w|: the same for every permutation)
+                raise M3THipError("conv3d_cl: the weights cannot be measured (16-B alignment, C_in k^3 % 4)")
+        wk = w_t.shape[1] if w_t is not None else taps * Ci
+        x_img = torch.empty_like(x_cl)
+        w_img = torch.empty(Co, wk, dtype=torch.float32, device=x.device)
         y_cl = torch.empty(rows, Co, dtype=torch.float32, device=x.device)
         wsd = workspace(x.device)
         _lib.check(lib().m3t_f16x3_split(_p(x_cl), srows, cw, cw, _p(x_img), cw, a_x, _stream()), "m3t_f16x3_split")
-        _lib.check(lib().m3t_f16x3_split(_p(w_t), Co, wk, wk, _p(w_img), wk, a_w, _stream()), "m3t_f16x3_split")
+        if w_t is not None:
+            _lib.check(lib().m3t_f16x3_split(_p(w_t), Co, wk, wk, _p(w_img), wk, a_w, _stream()), "m3t_f16x3_split")
+        else:
+            _lib.check(lib().m3t_f16x3_split_perm(_p(wc), Co, taps, Ci, Ci * taps, 1, taps, _p(w_img), a_w, _stream()), "m3t_f16x3_split_perm")
         tail = (kt, kh, kw, stride[0], stride[1], stride[2], padding[0], padding[1], padding[2], a_x, a_w, _p(wsd), wsd.numel() * 4, None, _stream())
         bp = _p(b) if b is not None else None
         if first:
@@ -2831,7 +2837,8 @@ class _Conv3dCL(torch.autograd.Function):
         N_, T_, H_, W_, st, pd, first, _ = ctx.geo
         To, Ho, Wo = ctx.out_grid
         Co, Ci, kt, kh, kw = w.shape
-        slot_dy = _grad_slot(dy) if dy.is_contiguous() else None      # raised by the kernel that wrote dy (BatchNorm's backward) -- else measured here
+        # dy's magnitude slot and its column sums (= this layer's bias gradient), both produced by the kernel that wrote dy (BatchNorm's dx pass)
+        slot_dy, dy_colsum = _grad_slot(dy) if dy.is_contiguous() else (None, None)
         dy_cl = _req(dy.contiguous(), "dy")
         rows = dy_cl.shape[0]
         dx = dw = db = None
@@ -2863,9 +2870,13 @@ class _Conv3dCL(torch.autograd.Function):
                             continue
                         base = [(cls[a] + pd[a] - r[a]) // st[a] for a in range(3)]
                         taps = sub[0] * sub[1] * sub[2]
-                        w_t = wd[:, :, r[0]::st[0], r[1]::st[1], r[2]::st[2]].permute(1, 2, 3, 4, 0).contiguous().view(Ci, taps * Co)
-                        w_img = torch.empty_like(w_t)
-                        _lib.check(lib().m3t_f16x3_split(_p(w_t), Ci, taps * Co, taps * Co, _p(w_img), taps * Co, ctx.a_w, _stream()), "m3t_f16x3_split")
+                        w_img = torch.empty(Ci, taps * Co, dtype=torch.float32, device=dy.device)
+                        if one and wd.is_contiguous():       # [ci][(tap, co)] straight from w (no permute copy)
+                            _lib.check(lib().m3t_f16x3_split_perm(_p(wd), Ci, taps, Co, taps, 1, Ci * taps, _p(w_img), ctx.a_w, _stream()),
+                                       "m3t_f16x3_split_perm")
+                        else:
+                            w_t = wd[:, :, r[0]::st[0], r[1]::st[1], r[2]::st[2]].permute(1, 2, 3, 4, 0).contiguous().view(Ci, taps * Co)
+                            _lib.check(lib().m3t_f16x3_split(_p(w_t), Ci, taps * Co, taps * Co, _p(w_img), taps * Co, ctx.a_w, _stream()), "m3t_f16x3_split")
                         dst = dx if one else torch.empty(N_ * size[0] * size[1] * size[2], Ci, dtype=torch.float32, device=dy.device)
                         _lib.check(lib().m3t_conv3d_taps_pre(_p(dy_img), _p(w_img), _p(dst), N_, Co, Ci, size[0], size[1], size[2], To, Ho, Wo,
                                                              sub[0], sub[1], sub[2], base[0], base[1], base[2], -1, slot_dy.data_ptr(), ctx.a_w,
@@ -2890,7 +2901,10 @@ class _Conv3dCL(torch.autograd.Function):
                 dw = dw_v.contiguous().view_as(w)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = b_sink if b_sink is not None else torch.empty(Co, dtype=torch.float32, device=dy.device)
-            colsum(dy_cl, 0, rows, Co, Co, db)
+            if dy_colsum is not None:
+                db.copy_(dy_colsum)
+            else:
+                colsum(dy_cl, 0, rows, Co, Co, db)
             if b_sink is not None:
                 db = None
         return dx, dw, db, None
@@ -2946,15 +2960,18 @@ class _BNCL(torch.autograd.Function):
         gs = _take_sink(ctx.sink_refs[0]) if (ctx.needs_input_grad[1] and ctx.sink_refs[0] is not None) else None
         bs = _take_sink(ctx.sink_refs[1]) if (ctx.needs_input_grad[2] and ctx.sink_refs[1] is not None) else None
         slot = amax_slots(1, x.device)
+        csum = torch.empty(Cc, dtype=torch.float32, device=x.device)
         amax_out(slot.data_ptr())
         try:
             rc = lib().m3t_bn_cl_bwd(_p(dy), _p(x), _p(y), _p(gamma), _p(stats[0]), _p(stats[1]), M, Cc, int(ctx.training), int(ctx.relu), _p(dx),
-                                     _p(gs if gs is not None else g[0]), _p(bs if bs is not None else g[1]), _p(ws), ws.numel() * 4, _stream())
+                                     _p(gs if gs is not None else g[0]), _p(bs if bs is not None else g[1]), _p(csum), _p(ws), ws.numel() * 4,
+                                     _stream())
             _lib.check(rc, "m3t_bn_cl_bwd")
         except BaseException:
             _amax_clear()
             raise
-        _note_grad_slot(dx, slot)                        # the convolution in front of this BatchNorm takes dx as its dy: no measuring pass
+        # the convolution in front of this BatchNorm takes dx as its dy: its magnitude slot and its column sums (that layer's bias gradient) ride along
+        _note_grad_slot(dx, slot, csum)
         return (dx, (g[0] if (gamma is not None and gs is None) else None), (g[1] if (gamma is not None and bs is None) else None),
                 None, None, None, None, None, None, None)
 
