@@ -2465,7 +2465,11 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
             ctx.w_keep = []
             a_w = weight_amax(w_par, ctx.w_keep)
             taps = kt * kh * kw
-            if cw == Ci:
+            w_native = None
+            if cw == Ci and w.is_contiguous() and w.data_ptr() % 16 == 0:
+                w_native = w.detach()                 # round 6: the [co][(tap, ci)] image straight from w (m3t_f16x3_split_perm: no permute copy)
+                w_t = w_native.view(Co, Ci * taps)    # (only measured below: max |w| is the same for every permutation)
+            elif cw == Ci:
                 w_t = _req(w.detach().permute(0, 2, 3, 4, 1).contiguous(), "weight").view(Co, taps * Ci)       # [co][(tap, ci)]
             else:
                 w8 = torch.zeros(Co, kt, kh, 8, 4, dtype=torch.float32, device=x.device)
@@ -2488,7 +2492,10 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
                 else:
                     _lib.check(lib().m3t_planes_to_cl4(_p(xc), _p(x_cl), N_, Ci, T_ * H_ * W_, _stream()), "m3t_planes_to_cl4")
                 _lib.check(lib().m3t_f16x3_split(_p(x_cl), srows, cw, cw, _p(x_img), cw, slots.data_ptr(), _stream()), "m3t_f16x3_split")
-                _lib.check(lib().m3t_f16x3_split(_p(w_t), Co, wk, wk, _p(w_img), wk, a_w, _stream()), "m3t_f16x3_split")
+                if w_native is not None:
+                    _lib.check(lib().m3t_f16x3_split_perm(_p(w_native), Co, taps, Ci, Ci * taps, 1, taps, _p(w_img), a_w, _stream()), "m3t_f16x3_split_perm")
+                else:
+                    _lib.check(lib().m3t_f16x3_split(_p(w_t), Co, wk, wk, _p(w_img), wk, a_w, _stream()), "m3t_f16x3_split")
                 geo = (kt, kh, kw, stride[0], stride[1], stride[2], padding[0], padding[1], padding[2], slots.data_ptr(), a_w, _p(wsd),
                        wsd.numel() * 4, _p(y), _stream())          # (y: planes, written by the walk's epilogue in one K pass)
                 bp = _p(b) if b is not None else None
@@ -2594,10 +2601,15 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
                 # both operands split ONCE (m3t_f16x3_split: dy channels-last under the slot its transpose raised, the weights as the
                 # K-contiguous [ci][(tap, co)] matrix): the tap walk re-reads every dy row 27 times -- its loop is then copies and MFMAs only
                 taps = kt * kh * kw
-                w_t = w.detach().permute(1, 2, 3, 4, 0).contiguous().view(Ci, taps * Co)
-                dy_img, w_img = torch.empty_like(dy_cl), torch.empty_like(w_t)
+                dy_img = torch.empty_like(dy_cl)
+                w_img = torch.empty(Ci, taps * Co, dtype=torch.float32, device=dy.device)
                 _lib.check(lib().m3t_f16x3_split(_p(dy_cl), rows, Co, Co, _p(dy_img), Co, slot_dy.data_ptr(), _stream()), "m3t_f16x3_split")
-                _lib.check(lib().m3t_f16x3_split(_p(w_t), Ci, taps * Co, taps * Co, _p(w_img), taps * Co, ctx.a_w, _stream()), "m3t_f16x3_split")
+                if w.is_contiguous():                 # [ci][(tap, co)] straight from w
+                    _lib.check(lib().m3t_f16x3_split_perm(_p(w.detach()), Ci, taps, Co, taps, 1, Ci * taps, _p(w_img), ctx.a_w, _stream()),
+                               "m3t_f16x3_split_perm")
+                else:
+                    w_t = w.detach().permute(1, 2, 3, 4, 0).contiguous().view(Ci, taps * Co)
+                    _lib.check(lib().m3t_f16x3_split(_p(w_t), Ci, taps * Co, taps * Co, _p(w_img), taps * Co, ctx.a_w, _stream()), "m3t_f16x3_split")
                 _lib.check(lib().m3t_conv3d_taps_pre(_p(dy_img), _p(w_img), _p(dx_cl), N_, Co, Ci, T_, H_, W_, To, Ho, Wo, kt, kh, kw,
                                                      pd[0], pd[1], pd[2], -1, slot_dy.data_ptr(), ctx.a_w, _p(wsd), wsd.numel() * 4, _p(dx),
                                                      _stream()), "m3t_conv3d_taps_pre")
