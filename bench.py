@@ -271,8 +271,10 @@ def aux_child(which, steps=6, warmup=2):
             ddp.zero_grad()
             m.training_step(batch, 0)["loss"].backward()
             ddp.finish()
-        emit("c5", "C5 AffWild2VA(audiovisual, attention, v2p_split, ccc_mtl) on raw 112x112 frames (conv stem: forward, weight gradient and data gradient as tap-walk implicit GEMMs over channels-last activations, fp16x3; no patch matrix), training_step+bwd+clip, 8x64", Bc,
-             timed(step5), "f32")
+        ms5 = timed(step5)      # (training_step reads the loss statistics back once per step, as the reference's progress bar does: one host sync)
+        print(json.dumps({"aux": "c5", "workload": "C5 AffWild2VA(audiovisual, attention, v2p_split, ccc_mtl) on raw 112x112 frames: the VGG-M stems as a channels-last chain (round 6: tap-walk convolutions reading and writing [N T H W][C] rows, BatchNorm3d+ReLU and MaxPool3d on the same rows, no transposes, fp16x3), training_step+bwd+clip, 8x64",
+                          "clips": Bc, "ms_per_step": round(ms5, 3), "clips_per_s": round(Bc / ms5 * 1e3, 1), "dtype": "f32",
+                          "alg_tflops": round(AUX_FLOPS["c5"] * Bc / ms5 / 1e9, 2)}), flush=True)
         if "c5_eval" in which:
             m.eval()
 
