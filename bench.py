@@ -117,7 +117,10 @@ def aux_child(which, steps=6, warmup=2):
         for _ in range(warmup):
             step()
         torch.cuda.synchronize()
-        gc.collect()                      # as the main leg: no generation-2 collector pause inside the few timed steps
+        gc.collect()                      # as the main leg: no generation-2 collector pause inside the few timed steps ...
+        gc.freeze()                       # ... and the survivors of the earlier legs (models, cached workspaces, ctypes tables) out of the
+                                          # collector's sight: the C5 leg, run behind five others in one process, was 1.5 ms slower than alone
+                                          # (host-side: its 300 launches per step are enqueued between two syncs of training_step)
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
@@ -255,6 +258,10 @@ def aux_child(which, steps=6, warmup=2):
                           "shapes, 2048 frames each; GBps_8pass = 8 x bytes(x) / time, the fused operator's algorithmic HBM passes (DESIGN.md section 4)",
                           "stages": res, "dtype": "f32", "peak_GBps": HBM_PEAK_GBS}), flush=True)
     if "c5" in which:
+        if os.environ.get("M3T_AUX_EMPTY_CACHE", "1") != "0":
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()      # the earlier legs' cached blocks (other shapes) back to the driver: this leg allocates 6 GB of its own
         from models.model import AffWild2VA
         hp = AffWild2VA.add_model_specific_args(argparse.ArgumentParser(add_help=False)).parse_args([])
         hp.modality, hp.fusion_type, hp.loss, hp.window = "audiovisual", "attention", "ccc_mtl", 64
@@ -288,6 +295,10 @@ def aux_child(which, steps=6, warmup=2):
 
 
     if "cbam" in which:          # (last: MIOpen's first-use search for the ResNet convolutions may eat what is left of the budget)
+        if os.environ.get("M3T_AUX_EMPTY_CACHE", "1") != "0":
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
         # inside a model: VA_3DResNet(resnet_ver='v1', use_cbam=True) visual-only, 8 clips x 64 frames of 112 x 112 (SURVEY 8(d) C5 alt)
         from models.backbone import VA_3DResNet
         Bc, Tc = 8, 64
