@@ -671,7 +671,24 @@ extern "C" int m3t_sgemm_scaled(int transA, int transB, int M, int N, int K, con
     const int tm = cdiv(M, BM), tn = cdiv(N, BN);
     const GemmPlan g = plan_gemm(transA, M, N, K, seg_len, p.vecA && p.vecB, ws ? ws_bytes : 0,
                                  flags | ((transA == 0 && transB == 1) ? 0 : GEMM_NO_WIDE));
-    const int splits = g.splits, kchunk = g.kchunk;
+    int splits = g.splits, kchunk = g.kchunk;
+    // round 6 (NOTEBOOK R6.8): a GEMM issued beside persistent scans (M3T_GEMM_BESIDE_SCAN) finds ~96 free CUs, not 256: its split-K is sized for
+    // 384 resident workgroups instead of the whole chip's 768 -- fewer slabs (5 instead of 10 for the 1536 x 1024 weight gradients), ~2 GB less
+    // slab traffic per C3 step, a shorter reduce; measured 12.04 -> 12.00 ms (288: 12.15, 336 / 448: 12.03, 576: 12.02).  M3T_GEMM_BESIDE_WGS=0:
+    // the whole-chip plan for every call; another positive value: that many workgroups
+    {
+        static int beside_wgs = -1;
+        if (beside_wgs < 0) { const char* e = getenv("M3T_GEMM_BESIDE_WGS"); beside_wgs = e ? atoi(e) : 384; }
+        if (beside_wgs > 0 && (flags & M3T_GEMM_BESIDE_SCAN) && g.kernel != 0 && !g.wide && g.splits > 1) {
+            const int tiles = cdiv(M, BM) * cdiv(N, g.narrow ? 64 : BN);
+            int sp = (beside_wgs + tiles / 2) / tiles;
+            if (sp < 1) sp = 1;
+            if (sp < g.splits) {
+                kchunk = cdiv(cdiv(K, sp), 32) * 32;
+                splits = cdiv(K, kchunk);
+            }
+        }
+    }
     p.splits = splits; p.kchunk = kchunk;
     hipStream_t s = (hipStream_t)stream;
     if (g.kernel != 0) {
