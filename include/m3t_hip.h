@@ -461,8 +461,19 @@ size_t m3t_va_loss_ws_bytes(int rows);
  *   gradient of the convolution in front of this BatchNorm -- from the dx pass itself (block partials summed in block order).
  * m3t_pool_cl_fwd / _bwd: max pooling of P frames x [P][H][W][C] with a (kh, kw) window, stride (sh, sw), padding (ph, pw) -- nn.MaxPool3d((1,
  *   kh, kw)) on channels-last rows; win [P][Ho][Wo][C] bytes: the winner's place in its window (ties: the first maximum in window order, NaN
- *   wins, as torch); backward is a gather (no atomics, deterministic).  C % 4 == 0, kh kw <= 255, padding < window.  m3t_amax_out arms y's slot. */
+ *   wins, as torch); backward is a gather (no atomics, deterministic).  C % 4 == 0, kh kw <= 255, padding < window.  m3t_amax_out arms y's slot.
+ * m3t_bn_pool_cl_fwd / _bwd: BatchNorm + ReLU + max pooling with a k x k window, stride k, no padding (k = 2, 3: every pooling layer of the
+ *   VGG-M stems) as ONE operator: relu(bn(x)) at full resolution is neither written nor read -- forward keeps the pooled frames yp [P][H / k][W /
+ *   k][C] and the winner bytes, backward takes d(yp) and writes dx [P][H][W][C] (an input position's gradient through the pooling is d(yp) of
+ *   its window if it won and yp > 0, else 0; positions no window covers get the BatchNorm terms only).  ws, slots, dx_colsum as m3t_bn_cl_*
+ *   with M = P H W. */
 size_t m3t_bn_cl_ws_bytes(size_t M, int C);
+int m3t_bn_pool_cl_fwd(const float* x, size_t P, int H, int W, int C, int k, const float* gamma, const float* beta, float* run_mean, float* run_var,
+                       float momentum, float eps, int training, float* yp, unsigned char* win, float* save_mean, float* save_invstd, float* ws,
+                       size_t ws_bytes, void* stream);
+int m3t_bn_pool_cl_bwd(const float* dyp, const float* x, const float* yp, const unsigned char* win, const float* gamma, const float* save_mean,
+                       const float* save_invstd, size_t P, int H, int W, int C, int k, int training, float* dx, float* dgamma, float* dbeta,
+                       float* dx_colsum, float* ws, size_t ws_bytes, void* stream);
 int m3t_bn_cl_fwd(const float* x, size_t M, int C, const float* gamma, const float* beta, float* run_mean, float* run_var, float momentum,
                   float eps, int training, int relu, float* y, float* save_mean, float* save_invstd, float* ws, size_t ws_bytes, void* stream);
 int m3t_bn_cl_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* save_mean, const float* save_invstd, size_t M,

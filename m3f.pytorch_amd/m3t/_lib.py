@@ -96,6 +96,8 @@ SIGNATURES = {
     "m3t_bn_cl_ws_bytes": [_z, _i],
     "m3t_bn_cl_fwd": [_f, _z, _i, _f, _f, _f, _f, C.c_float, C.c_float, _i, _i, _f, _f, _f, _f, _z, _s],
     "m3t_bn_cl_bwd": [_f, _f, _f, _f, _f, _f, _z, _i, _i, _i, _f, _f, _f, _f, _f, _z, _s],
+    "m3t_bn_pool_cl_fwd": [_f, _z, _i, _i, _i, _i, _f, _f, _f, _f, C.c_float, C.c_float, _i, _f, C.c_void_p, _f, _f, _f, _z, _s],
+    "m3t_bn_pool_cl_bwd": [_f, _f, _f, C.c_void_p, _f, _f, _f, _z, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _z, _s],
     "m3t_pool_cl_fwd": [_f, _z, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, C.c_void_p, _s],
     "m3t_pool_cl_bwd": [_f, C.c_void_p, _z, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _s],
     "m3t_va_loss": [_f, _i, _i, _i, _i, _f, _f, _f, _f, _i, C.c_float, C.c_float, C.c_float, _i, _f, _f, _f, _z, _s],

@@ -2733,15 +2733,33 @@ STEM_CL = [os.environ.get("M3T_STEM_CL", "1") != "0"]
 
 class CLTensor:
     """a channels-last activation of a 3-D stem: `data` [N T H W, C] (a plain autograd tensor) + its grid; `slot`: the 1-element tensor
-    holding data's magnitude slot (raised by the kernel that wrote data) or None"""
-    __slots__ = ("data", "N", "T", "H", "W", "slot")
+    holding data's magnitude slot (raised by the kernel that wrote data) or None.  A BatchNorm3d + ReLU may be PENDING on it (bn_cl(...,
+    lazy=True)): a pooling that follows applies it inside its own window loop (pool_cl: one fused operator, relu(bn(x)) at full resolution is
+    never written); anything else that touches `.data` applies it first."""
+    __slots__ = ("_data", "N", "T", "H", "W", "_slot", "_pending")
 
-    def __init__(self, data, N, T, H, W, slot=None):
-        self.data, self.N, self.T, self.H, self.W, self.slot = data, N, T, H, W, slot
+    def __init__(self, data, N, T, H, W, slot=None, pending=None):
+        self._data, self.N, self.T, self.H, self.W, self._slot, self._pending = data, N, T, H, W, slot, pending
+
+    def _materialize(self):
+        if self._pending is not None:
+            args, self._pending = self._pending, None
+            self._slot = amax_slots(1, self._data.device)
+            self._data = _BNCL.apply(self._data, *args, self._slot)
+
+    @property
+    def data(self):
+        self._materialize()
+        return self._data
+
+    @property
+    def slot(self):
+        self._materialize()
+        return self._slot
 
     @property
     def C(self):
-        return self.data.shape[1]
+        return self._data.shape[1]
 
     def planes(self):
         """[N, C, T, H, W] (one tiled transpose: leaving the chain)"""
@@ -2988,10 +3006,72 @@ class _BNCL(torch.autograd.Function):
                 None, None, None, None, None, None, None)
 
 
-def bn_cl(x, gamma, beta, run_mean, run_var, training, momentum, eps, relu=True):
+def bn_cl(x, gamma, beta, run_mean, run_var, training, momentum, eps, relu=True, lazy=False):
+    """lazy (with relu): the operator is left PENDING on the result -- a pooling with tiling windows that follows fuses it (pool_cl)"""
+    if lazy and relu and BN_POOL_FUSED[0]:
+        return CLTensor(x.data, x.N, x.T, x.H, x.W, None, (gamma, beta, run_mean, run_var, training, momentum, eps, True))
     slot = amax_slots(1, x.data.device)
     y = _BNCL.apply(x.data, gamma, beta, run_mean, run_var, training, momentum, eps, relu, slot)
     return CLTensor(y, x.N, x.T, x.H, x.W, slot)
+
+
+BN_POOL_FUSED = [os.environ.get("M3T_BN_POOL_FUSED", "1") != "0"]      # 0: BatchNorm + ReLU and the pooling as two operators (A/B)
+
+
+class _BNPoolCL(torch.autograd.Function):
+    """BatchNorm3d + ReLU + MaxPool3d((1, k, k), stride (1, k, k)) on channels-last frames as one operator (csrc/stem_cl.hip m3t_bn_pool_cl_*:
+    reference models/backbone.py:77-80,83-86,89-92): relu(bn(x)) at full resolution is neither written nor read, forward or backward"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, run_mean, run_var, training, momentum, eps, geo, y_slot):
+        P, H, W, k = geo
+        x = _req(x, "x")
+        Cc = x.shape[1]
+        Ho, Wo = H // k, W // k
+        yp = torch.empty(P * Ho * Wo, Cc, dtype=torch.float32, device=x.device)
+        win = torch.empty(P * Ho * Wo, Cc, dtype=torch.uint8, device=x.device)
+        stats = torch.empty(2, Cc, dtype=torch.float32, device=x.device)
+        ws = workspace(x.device, int(lib().m3t_bn_cl_ws_bytes(P * H * W, Cc)))
+        amax_out(y_slot.data_ptr() if y_slot is not None else None)
+        try:
+            rc = lib().m3t_bn_pool_cl_fwd(_p(x), P, H, W, Cc, k, _p(gamma), _p(beta), _p(run_mean), _p(run_var), float(momentum), float(eps),
+                                          int(training), _p(yp), C.c_void_p(win.data_ptr()), _p(stats[0]), _p(stats[1]), _p(ws), ws.numel() * 4,
+                                          _stream())
+            _lib.check(rc, "m3t_bn_pool_cl_fwd")
+        except BaseException:
+            _amax_clear()
+            raise
+        ctx.save_for_backward(x, yp, win, gamma, stats)
+        ctx.geo, ctx.training = geo, bool(training)
+        ctx.sink_refs = (gamma if (gamma is not None and id(gamma) in _GRAD_SINKS) else None,
+                         beta if (beta is not None and id(beta) in _GRAD_SINKS) else None)
+        return yp
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, yp, win, gamma, stats = ctx.saved_tensors
+        P, H, W, k = ctx.geo
+        dy = _req(dy.contiguous(), "dy")
+        Cc = x.shape[1]
+        dx = torch.empty_like(x)
+        g = torch.empty(2, Cc, dtype=torch.float32, device=x.device)
+        ws = workspace(x.device, int(lib().m3t_bn_cl_ws_bytes(P * H * W, Cc)))
+        gs = _take_sink(ctx.sink_refs[0]) if (ctx.needs_input_grad[1] and ctx.sink_refs[0] is not None) else None
+        bs = _take_sink(ctx.sink_refs[1]) if (ctx.needs_input_grad[2] and ctx.sink_refs[1] is not None) else None
+        slot = amax_slots(1, x.device)
+        csum = torch.empty(Cc, dtype=torch.float32, device=x.device)
+        amax_out(slot.data_ptr())
+        try:
+            rc = lib().m3t_bn_pool_cl_bwd(_p(dy), _p(x), _p(yp), C.c_void_p(win.data_ptr()), _p(gamma), _p(stats[0]), _p(stats[1]), P, H, W, Cc, k,
+                                          int(ctx.training), _p(dx), _p(gs if gs is not None else g[0]), _p(bs if bs is not None else g[1]),
+                                          _p(csum), _p(ws), ws.numel() * 4, _stream())
+            _lib.check(rc, "m3t_bn_pool_cl_bwd")
+        except BaseException:
+            _amax_clear()
+            raise
+        _note_grad_slot(dx, slot, csum)
+        return (dx, (g[0] if (gamma is not None and gs is None) else None), (g[1] if (gamma is not None and bs is None) else None),
+                None, None, None, None, None, None, None)
 
 
 class _PoolCL(torch.autograd.Function):
@@ -3030,6 +3110,12 @@ class _PoolCL(torch.autograd.Function):
 
 def pool_cl(x, k, s, p):
     k, s, p = tuple(k), tuple(s), tuple(p)
+    pend = x._pending
+    if pend is not None and k == s and p == (0, 0) and k[0] == k[1] and k[0] in (2, 3) and x.H >= k[0] and x.W >= k[0]:
+        gamma, beta, run_mean, run_var, training, momentum, eps, _ = pend
+        slot = amax_slots(1, x._data.device)
+        y = _BNPoolCL.apply(x._data, gamma, beta, run_mean, run_var, training, momentum, eps, (x.N * x.T, x.H, x.W, k[0]), slot)
+        return CLTensor(y, x.N, x.T, x.H // k[0], x.W // k[0], slot)
     slot = amax_slots(1, x.data.device)
     y = _PoolCL.apply(x.data, (x.N * x.T, x.H, x.W, k, s, p), slot)
     Ho, Wo = (x.H + 2 * p[0] - k[0]) // s[0] + 1, (x.W + 2 * p[1] - k[1]) // s[1] + 1

@@ -54,7 +54,7 @@ class BatchNorm3dReLU(nn.BatchNorm3d):
             if ops.BN_PLANES[0] and self.affine and self.track_running_stats and self.momentum is not None and Cc % 4 == 0 and 256 % (Cc // 4) == 0:
                 if self.training:
                     self.num_batches_tracked.add_(1)
-                return ops.bn_cl(x, self.weight, self.bias, self.running_mean, self.running_var, self.training, self.momentum, self.eps, True)
+                return ops.bn_cl(x, self.weight, self.bias, self.running_mean, self.running_var, self.training, self.momentum, self.eps, True, lazy=True)
             x = x.planes()
         if (ops.BN_PLANES[0] and x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and self.affine and self.track_running_stats
                 and self.momentum is not None):
