@@ -1850,7 +1850,8 @@ def test_solo_scans_h128_through_the_c_abi(B, T, bf16):
     ops.poll_scan_error()
 
 
-@pytest.mark.parametrize("switch", ["M3T_CONV_X6", "M3T_CBAM_FUSED", "M3T_CBAM_RESIDENT", "M3T_BN_PLANES", "M3T_CONV3D_IMPLICIT"])
+@pytest.mark.parametrize("switch", ["M3T_CONV_X6", "M3T_CBAM_FUSED", "M3T_CBAM_RESIDENT", "M3T_BN_PLANES", "M3T_CONV3D_IMPLICIT", "M3T_STEM_CL",
+                                    "M3T_BN_POOL_FUSED"])
 def test_conv_and_cbam_kernel_switches(switch):
     """README's switch table, the entries the C3 step does not exercise (read once per process, hence a child):
     M3T_CONV_X6=0 -- the TCN / tcn_simple convolutions on the fp32-MFMA kernel instead of the bf16x6 implicit GEMM;
@@ -1860,13 +1861,17 @@ def test_conv_and_cbam_kernel_switches(switch):
     M3T_CONV3D_IMPLICIT=0 -- Conv3d / the ResNet's Conv2d forward and weight gradient on the patch-matrix GEMMs (first half of round 5) instead
     of the tap walks over channels-last activations: the stems' goldens and the layer tests again on that path;
     M3T_BN_PLANES=0 -- BatchNorm3d / BatchNorm2d (+ReLU) of the stems and the per-frame ResNet on the stock ops instead of the channel-plane
-    kernels.  Same arithmetic: the convolution, TemporalBlock, CBAM, ResNet and C5 parity tests must pass unchanged."""
+    kernels;
+    M3T_STEM_CL=0 -- the VGG-M stems on the planes operators (a transpose on each side of every convolution) instead of the channels-last chain
+    of round 6; M3T_BN_POOL_FUSED=0 -- the chain with BatchNorm + ReLU and the pooling as two operators instead of one.  Same arithmetic: the convolution, TemporalBlock, CBAM, ResNet and C5 parity tests must pass unchanged."""
     import subprocess
     import sys
     env = dict(os.environ, M3T_SCAN_LOCK="0", **{switch: "0"})
     pick = {"M3T_CONV_X6": "conv1d_on_the_bf16x6_pipe or tcn_train_mode or tcn_golden",
             "M3T_CONV3D_IMPLICIT": "c5_resnet3d or c5_affwild_av_golden or conv3d_weight_gradient or conv3d_forward_on_the_patch",
-            "M3T_BN_PLANES": "resnet_cbam or c5_resnet3d or c5_affwild_av_t16"}.get(switch, "cbam_golden or resnet_cbam or cbam_stage")
+            "M3T_BN_PLANES": "resnet_cbam or c5_resnet3d or c5_affwild_av_t16",
+            "M3T_STEM_CL": "c5_affwild_av_golden or c5_affwild_av_train or vggm_end_to_end",
+            "M3T_BN_POOL_FUSED": "c5_affwild_av_golden or c5_affwild_av_train or vggm_end_to_end"}.get(switch, "cbam_golden or resnet_cbam or cbam_stage")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k", pick], env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-1500:]
