@@ -133,7 +133,8 @@ int m3t_sgemm_bimg(int M, int N, int K, const float* A, int lda, const float* B_
  * operands (transA = 1, transB = 0) are fetched a k row per LDS-DMA instruction and read back with ds_read2st64_b32 -- no cross-lane
  * transpose.  N % 256 == 0, K % 16 == 0 (K % seg_len == 0, seg_len >= 32 when segmented), any M (M % 4 == 0 with transA = 1), 16-B aligned
  * operands with ld % 4 == 0; splits >= 1 slabs (ws of splits * M * N floats when > 1); NULL slots are measured; `variant` selects a build of
- * the NT main loop (0 = plain, 3 = pipelined reads + v_fma_mix split; tools/ring_bench.py). */
+ * the NT main loop (0 = plain, 1 = reads a stage ahead, 2 = v_fma_mix split, 3 = both; the timing-only ablation builds behind
+ * profiles/r06_ring_gemm_ablation.txt are refused unless M3T_RING_ABLATIONS is set). */
 int m3t_sgemm_ring(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                    const float* bias, int act, int accumulate, int seg_len, int seg_stride, int a_off, int b_off, float* ws, size_t ws_bytes,
                    int splits, const unsigned long long* amax_a, const unsigned long long* amax_b, int variant, void* stream);

@@ -968,6 +968,9 @@ extern "C" int m3t_sgemm_ring(int transA, int transB, int M, int N, int K, const
         return M3T_EINVAL;
     if ((transA == 1 && transB == 1) || (transA == 1 && M % 4 != 0)) return M3T_EINVAL;
     if (seg_len > 0 && !(transA == 1 && transB == 0 && seg_len >= 32 && K % seg_len == 0)) return M3T_EINVAL;
+    // variants 0-3 compute the product; 6, 11, 19, 35, 43 are the timing-only builds of profiles/r06_ring_gemm_ablation.txt (parts of the loop
+    // removed: WRONG results) and need M3T_RING_ABLATIONS=1 in the environment
+    if ((variant < 0 || variant > 3) && !getenv("M3T_RING_ABLATIONS")) return M3T_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const unsigned long long* use_a = amax_a; const unsigned long long* use_b = amax_b;
     if (!amax_a || !amax_b) {
