@@ -918,6 +918,43 @@ def test_loss_helper_methods_and_no_valid_rows():
     close(loss, 0.5 * g["loss_v"] + 0.5 * g["loss_a"], 1e-5, "loss without expr term (model.py:173-174)")
 
 
+@pytest.mark.parametrize("B,T,mode", [(32, 300, "mtl"), (17, 301, "mtl"), (32, 300, "none_valid"), (20, 250, "ccc"), (128, 256, "mtl"), (130, 300, "mtl")])
+def test_va_loss_in_one_launch_against_the_oracle(B, T, mode):
+    """csrc/fuse_loss.hip, round 6: the loss of AffWild2VA.training_step (reference models/model.py:132-182, models/utils.py:6-17) as ONE grid-wide
+    launch -- raw fp64 moments in one sweep, the blocks meet once inside the kernel -- at the bench's 9 600 rows, at a ragged row count (the last
+    block half empty), with no valid expression label (the CE term drops out, model.py:173-174), as the plain 'ccc' loss on two outputs, at the
+    128-block limit of the fused form and just past it (three launches): loss, parts and the full dL/dy against the numpy oracle; reruns
+    bit-identical (fixed-order sums)"""
+    from m3t import ops
+    from oracle import m3t_oracle as O
+    rs = np.random.RandomState(B + T)
+    C_ = 2 if mode == "ccc" else 9
+    yn = draw(rs, (B, T, C_)) * 0.7
+    val, aro = draw(rs, (B, T), "uniform_pm1"), draw(rs, (B, T), "uniform_pm1")
+    expr = rs.randint(0, 7, (B, T)).astype(np.int64)
+    valid = (rs.uniform(size=(B, T)) < 0.7) & (mode != "none_valid")
+    outs = []
+    for _ in range(2):
+        y = dev(yn, True)
+        if mode == "ccc":
+            loss, stats = ops.va_loss(y, dev(val), dev(aro))
+        else:
+            loss, stats = ops.va_loss(y, dev(val), dev(aro), dev(expr), dev(valid), iv=7, ia=8, n_expr=7)
+        loss.backward()
+        outs.append((loss.detach().clone(), stats.clone(), y.grad.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1])), "reruns differ"
+    l_ref, parts, dy_ref = O.training_loss_fwd_bwd(yn.astype(np.float64), val.astype(np.float64), aro.astype(np.float64),
+                                                   expr if mode != "ccc" else None, valid if mode != "ccc" else None, mtl=mode != "ccc")
+    loss, stats, dy = outs[0]
+    close(loss, l_ref, 1e-5, "loss")
+    s = stats.cpu().numpy()
+    close(s[1], parts["loss_v"], 1e-5, "loss_v"); close(s[2], parts["loss_a"], 1e-5, "loss_a")
+    if "loss_expr" in parts:
+        close(s[3], parts["loss_expr"], 1e-5, "loss_expr")
+        assert int(s[4]) == int(valid.sum())
+    close(dy, dy_ref, 1e-6 if B * T <= 20000 else 3e-7, "dL/dy")
+
+
 # ------------------------------------------------------------------------------ configs
 def _hp(**kw):
     from models.model import AffWild2VA
