@@ -178,6 +178,14 @@ class FlatGradDDP:
             self._left[bi] -= 1
             if self._left[bi] == 0 and self.overlap:
                 s, e = self.ranges[bi]
+                if self.flat.is_cuda:
+                    # the bucket's gradients may have been written on the library's other streams (weight-gradient streams; the side stream
+                    # that runs the second conv tower / the audio stack and -- autograd keeps a node's backward on its forward's stream --
+                    # their backward): the collective is ordered behind the CURRENT stream only
+                    from . import ops
+                    cur = ops.cur_stream(self.flat.device)
+                    for st in ops.live_streams(self.flat.device):
+                        cur.wait_stream(st)
                 self._handles.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
         return hook
 
@@ -264,7 +272,7 @@ class FlatGradDDP:
             from . import ops
             cur = ops.cur_stream()
             self._early_stream.wait_stream(cur)
-            for st in ops.wgrad_streams(self.flat.device):      # the bucket's weight gradients are written on these streams
+            for st in ops.live_streams(self.flat.device):       # the bucket's weight gradients are written on these streams
                 self._early_stream.wait_stream(st)
             with torch.cuda.stream(self._early_stream):
                 self._early_handle = dist.all_reduce(self.flat[s0:e0], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
@@ -279,6 +287,12 @@ class FlatGradDDP:
         if self._agreed:
             self._check_agreed()                  # BEFORE this step's collective: either every rank raises here or none does
         ops.join_wgrad(self.flat.device)          # weight-gradient GEMMs that write straight into the flat buffer
+        if self.flat.is_cuda:
+            # ... and whatever else of backward ran on the library's side stream (the second conv tower's backward: its weight gradients go
+            # into gradient sinks, so no AccumulateGrad node makes autograd join that stream at the end of backward)
+            cur = ops.cur_stream(self.flat.device)
+            for st in ops.live_streams(self.flat.device):
+                cur.wait_stream(st)
         hip = self.flat.is_cuda
         timed = self.ar_events is not None and hip
         if timed:

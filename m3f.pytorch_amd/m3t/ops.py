@@ -265,6 +265,13 @@ def wgrad_streams(device):
     return _WGRAD[(device.type, device.index)]
 
 
+def live_streams(device):
+    """the library's own streams that exist on `device` (side stream, weight-gradient streams) -- without creating any: a caller that is about
+    to read what backward wrote (an overlapped gradient all-reduce) makes its stream wait for them"""
+    key = (device.type, device.index)
+    return ([_SIDE[key]] if key in _SIDE else []) + list(_WGRAD.get(key) or [])
+
+
 _ROLE_OF_HANDLE = {}      # (device index, raw stream handle) -> "side" / "wgrad<i>": filled when the streams are created
 
 
