@@ -2425,10 +2425,12 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
     """Conv3d of the visual stems and, with a unit time axis, the per-frame ResNet's Conv2d (reference models/backbone.py:73-103,179-271,
     327-332, models/resnet.py:40-45).  Round 5: every pass is a tap-walk implicit GEMM on the fp16x3 kernels over channels-last rows --
     forward (any stride; x channels-last KEPT for backward), weight gradient (the walk turned round, reduction over dy's rows), data gradient
-    of the stride-1 layers (dy channels-last, flipped taps); results leave the walks as channel planes.  No patch matrix (MIOpen's fp32
+    (dy channels-last, flipped taps; round 6: the strided layers' as one walk per output parity class over the taps w[..., r::s]); results
+    leave the walks as channel planes.  No patch matrix (MIOpen's fp32
     forward ran at 26 TFLOP/s, 12.4 of the 30.4 ms of a C5 step in round 4; the patch-matrix GEMMs of the first half of round 5 wrote 4-6 GB
     per step).  C_in % 32 != 0 layers other than the 3-channel first layers, M3T_CONV3D_IMPLICIT=0: patch matrix (m3t_im2col3d) x W^T and
-    dy^T P on the GEMM; strided layers' data gradient, shapes no tile fits (rows % 128, C_out % 64), M3T_CONV3D_MIOPEN=1: torch / MIOpen."""
+    dy^T P on the GEMM; any number of rows (ragged last tile, round 6); M3T_CONV3D_MIOPEN=1 / shapes no walk covers: torch / MIOpen, announced
+    once per site by stock_fallback()."""
 
     @staticmethod
     def forward(ctx, x, w, b, stride, padding, as2d=False):

@@ -2,10 +2,11 @@
 
 API/state-dict compatible with the reference's models/backbone.py for the classes on the
 north_star path: `VA_3DVGGM` (:62-161), `VA_3DVGGM_Split` (:164-311, the default
-`--backbone v2p_split`) and `VA_3DResNet` (:314-372).  The 3-D stems' convolutions (forward and
-data gradient) stay on PyTorch-ROCm (MIOpen) ops; their weight gradient,
-BatchNorm3d + ReLU and spatial pooling (round 4), the temporal back-ends (BiGRU stacks, TCN) and the
-CBAM gates / BatchNorm2d inside the ResNet run in the HIP library.  `VA_3DDenseNet` / `VA_VGGFace` are
+`--backbone v2p_split`) and `VA_3DResNet` (:314-372).  The 3-D stems' convolutions (forward, weight
+and data gradient: tap-walk implicit GEMMs, rounds 5-6; the VGG-M stems as a channels-last chain),
+BatchNorm3d + ReLU and spatial pooling, the temporal back-ends (BiGRU stacks, TCN) and the CBAM
+gates / BatchNorm2d inside the ResNet run in the HIP library; a configuration the library does not
+cover takes the stock op and says so once on stderr (m3t.ops.stock_fallback).  `VA_3DDenseNet` / `VA_VGGFace` are
 out of scope (not reachable from AffWild2VA.forward).
 """
 import math
@@ -21,8 +22,8 @@ from .tcn import TemporalConvNet, WeightNormConv1d
 
 
 class Conv3d(nn.Conv3d):
-    """nn.Conv3d (same parameters / state_dict keys) on m3t.ops.conv3d (round 5): forward, weight gradient and the stride-1 layers' data
-    gradient as tap-walk implicit GEMMs over channels-last activations on the fp16x3 kernels -- no patch matrix (MIOpen's fp32 forward ran
+    """nn.Conv3d (same parameters / state_dict keys) on m3t.ops.conv3d (round 5): forward, weight gradient and data gradient (round 6: the
+    strided layers' too, as parity-class walks) as tap-walk implicit GEMMs over channels-last activations on the fp16x3 kernels -- no patch matrix (MIOpen's fp32 forward ran
     at 26 TFLOP/s); M3T_CONV3D_IMPLICIT=0: the patch-matrix GEMMs.  Falls back to the stock op for configurations it does not cover (and
     under M3T_CONV3D_MIOPEN=1)."""
 

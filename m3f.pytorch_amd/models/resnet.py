@@ -36,10 +36,10 @@ class PlaneBatchNorm2d(nn.BatchNorm2d):
 
 class GemmConv2d(nn.Conv2d):
     """nn.Conv2d (same parameters / state_dict keys) of the per-frame ResNet on m3t.ops.conv3d with a unit time axis (round 5): forward (any
-    stride), weight gradient and the stride-1 layers' data gradient as tap-walk implicit GEMMs over channels-last activations on the fp16x3
-    kernels (the per-frame maps are 512 frames x 28^2 ... 4^2 positions: rows in whole 128-row tiles, K = 9 C_in; no patch matrix); the
-    strided layers' data gradient stays on MIOpen, whose fp32 kernels ran these convolutions at a few tens of TFLOP/s.  Other inputs (CPU,
-    other dtypes, no gradient, untileable shapes, M3T_CONV3D_MIOPEN=1) take the stock op."""
+    stride), weight gradient and data gradient (round 6: the strided layers' as parity-class walks, stride on the source side) as tap-walk
+    implicit GEMMs over channels-last activations on the fp16x3 kernels (the per-frame maps are 512 frames x 28^2 ... 4^2 positions, K =
+    9 C_in; ragged last row tile; no patch matrix, no MIOpen kernel).  Other inputs (CPU, other dtypes, groups / dilation,
+    M3T_CONV3D_MIOPEN=1) take the stock op and say so once on stderr."""
 
     def forward(self, x):
         # one path whatever the grad mode (validation / test steps, frozen encoders: see models.backbone.Conv3d)
