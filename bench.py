@@ -120,7 +120,7 @@ def aux_child(which, steps=6, warmup=2):
         gc.collect()                      # as the main leg: no generation-2 collector pause inside the few timed steps ...
         gc.freeze()                       # ... and the survivors of the earlier legs (models, cached workspaces, ctypes tables) out of the
                                           # collector's sight: the C5 leg, run behind five others in one process, was 1.5 ms slower than alone
-                                          # (host-side: its 300 launches per step are enqueued between two syncs of training_step)
+                                          # (host-side: until the count of valid labels travelled ahead of the forward pass, its launches were enqueued between two syncs)
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
@@ -278,7 +278,29 @@ def aux_child(which, steps=6, warmup=2):
             ddp.zero_grad()
             m.training_step(batch, 0)["loss"].backward()
             ddp.finish()
-        ms5 = timed(step5)      # (training_step reads the loss statistics back once per step, as the reference's progress bar does: one host sync)
+        ms5 = timed(step5)      # (training_step decides on the expression branch from a count queued BEFORE the forward pass: no stall after the loss;
+                                # M3T_STEP_SYNC=1 reads the statistics back after the loss as the reference's two .item() calls do)
+        # the enqueue path of the two halves of the step with the GPU parked behind a spin kernel (no back-pressure; the count of valid labels
+        # is left out: reading it would wait for the spin): forward + loss, then backward + clip, and the GPU's time for each half once
+        # the whole half is queued ahead (HIP events behind the spin)
+        halves = []
+        for _ in range(3):
+            ddp.zero_grad()
+            torch.cuda.synchronize()
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            torch.cuda._sleep(int(0.03 * 2.4e9)); ev[0].record(); t0 = time.perf_counter()
+            loss5 = m.va_objective(m.forward(batch), batch)[0]
+            t1 = time.perf_counter(); ev[1].record(); torch.cuda.synchronize()
+            torch.cuda._sleep(int(0.03 * 2.4e9)); ev[2].record(); t2 = time.perf_counter()
+            loss5.backward(); ddp.finish()
+            t3 = time.perf_counter(); ev[3].record(); torch.cuda.synchronize()
+            halves.append(((t1 - t0) * 1e3, (t3 - t2) * 1e3, ev[0].elapsed_time(ev[1]), ev[2].elapsed_time(ev[3])))
+            del loss5
+        hv = [round(sorted(h[i] for h in halves)[1], 3) for i in range(4)]
+        print(json.dumps({"aux": "c5_halves", "host_enqueue_ms_idle": round(hv[0] + hv[1], 3), "host_forward_loss_ms": hv[0], "host_backward_clip_ms": hv[1],
+                          "gpu_forward_loss_ms": hv[2], "gpu_backward_clip_ms": hv[3],
+                          "note": "median of 3; GPU parked behind a 30 ms spin kernel while the host enqueues each half of the C5 step; gpu_* = HIP events "
+                                  "around the half once it is all queued"}), flush=True)
         print(json.dumps({"aux": "c5", "workload": "C5 AffWild2VA(audiovisual, attention, v2p_split, ccc_mtl) on raw 112x112 frames: the VGG-M stems as a channels-last chain (round 6: tap-walk convolutions reading and writing [N T H W][C] rows, BatchNorm3d+ReLU and MaxPool3d on the same rows, no transposes, fp16x3), training_step+bwd+clip, 8x64",
                           "clips": Bc, "ms_per_step": round(ms5, 3), "clips_per_s": round(Bc / ms5 * 1e3, 1), "dtype": "f32",
                           "alg_tflops": round(AUX_FLOPS["c5"] * Bc / ms5 / 1e9, 2)}), flush=True)

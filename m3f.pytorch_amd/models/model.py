@@ -8,13 +8,15 @@ state_dict keys, same `forward(batch: dict)`, loss helpers and `training_step` r
 What runs where: every BiGRU / FC / fusion / loss op is a HIP kernel behind the C ABI
 (include/m3t_hip.h).  Independent BiGRU stacks are advanced together (audio + the two visual
 towers; the two fusion scorers) so that one launch per time step covers all of them.  The
-3-D conv stem of the visual tower stays on PyTorch-ROCm ops.  If pytorch_lightning is
+3-D conv stems of the visual tower run on the library's tap-walk convolutions, BatchNorm and
+pooling kernels too (models/backbone.py; rounds 4-6).  If pytorch_lightning is
 installed the class derives from pl.LightningModule exactly as the reference does; without it
 (this image) it is a plain nn.Module with the same hooks.
 
 Validation/test window stitching is host glue in m3t/stitch.py.  Out of scope: dataloaders
 (need the Aff-Wild2 dataset and cv2), the LR range finder, `--fusion_type att_dec`.
 """
+import os
 from argparse import ArgumentParser
 
 import torch
@@ -33,6 +35,11 @@ try:  # pragma: no cover - pytorch_lightning is absent in the build image
 except Exception:  # noqa: BLE001
     pl = None
     _Base = nn.Module
+
+
+# M3T_STEP_SYNC=1: training_step reads the loss statistics back after the loss (one host sync in the middle of the step, as until round 6)
+# instead of deciding on the expression branch from a count that travels to the host under the forward pass (_count_valid_ahead).
+_STEP_SYNC = os.environ.get("M3T_STEP_SYNC", "0") == "1"
 
 
 class AffWild2VA(_Base):
@@ -134,16 +141,46 @@ class AffWild2VA(_Base):
                            iv=7 if mtl else C_ - 2, ia=C_ - 1, n_expr=7 if mtl else 0,
                            w_v=hp.loss_lambda, w_a=1 - hp.loss_lambda, expr_w=0.8, use_mse='mse' in hp.loss)
 
+    def _count_valid_ahead(self, mask):
+        """valid_expr of the reference's training_step (models/model.py:173: `torch.sum(mask_expr_tile.long()).item()`) WITHOUT stalling the
+        step: the count depends on the batch only, so it is queued before the forward pass and copied to pinned host memory while the host
+        enqueues the forward pass; reading it afterwards waits for work that precedes this step, never for the forward pass -- the GPU keeps a
+        full queue across the `if valid_expr > 0` decision (round 6: the read-back after the loss cost 1.3-2.3 ms of a 12.8-13.9 ms C5 step).
+        Returns a callable giving the int."""
+        if not mask.is_cuda:
+            return lambda: int(mask.sum())
+        buf = self.__dict__.get('_nvalid_host')
+        if buf is None:
+            buf = self.__dict__['_nvalid_host'] = torch.empty(1, dtype=torch.int64, pin_memory=True)
+        buf.copy_(mask.sum(), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+
+        def get():
+            ev.synchronize()
+            return int(buf[0])
+        return get
+
     def training_step(self, batch, batch_idx):
+        mtl = 'mtl' in self.hparams.loss
+        ahead = mtl and not _STEP_SYNC
+        n_valid = self._count_valid_ahead(batch['expr_valid']) if ahead else None
         y_hat = self.forward(batch)
         loss, stats = self.va_objective(y_hat, batch)
-        s = stats.tolist()      # ONE host sync (the reference has two .item() syncs, model.py:173,181)
         loss_v, loss_a = stats[1], stats[2]
         progress = {'loss_v': loss_v, 'loss_a': loss_a, 'loss': loss}
         log = {'loss_v': loss_v, 'loss_a': loss_a, 'loss': loss}
-        if 'mtl' in self.hparams.loss and s[4] > 0:
-            log['loss_expr'] = progress['loss_expr'] = stats[3]
-            progress['acc_expr'] = s[5] / s[4]
+        if ahead:
+            # acc_expr is a 0-dim device tensor like its neighbours in the dict (the reference: a Python float, two .item() syncs at
+            # model.py:173,181); float(acc_expr) / Lightning's progress bar read it when they need it.  M3T_STEP_SYNC=1: the float.
+            if n_valid() > 0:
+                log['loss_expr'] = progress['loss_expr'] = stats[3]
+                progress['acc_expr'] = stats[5] / stats[4]
+        elif mtl:
+            s = stats.tolist()      # ONE host sync after the loss (the reference has two .item() syncs, model.py:173,181)
+            if s[4] > 0:
+                log['loss_expr'] = progress['loss_expr'] = stats[3]
+                progress['acc_expr'] = s[5] / s[4]
         if getattr(self.hparams, 'test_lr', False):
             raise NotImplementedError("LR range finder (models/lr_finder.py) is out of scope")
         return {'loss': loss, 'progress_bar': progress, 'log': log}

@@ -1065,6 +1065,40 @@ def test_c1_affwild_audio_training_step_golden():
     check_digests(list((n, p.grad) for n, p in m.named_parameters()), g)
 
 
+def test_training_step_decides_on_the_expression_branch_without_a_stall(monkeypatch):
+    """AffWild2VA.training_step (reference models/model.py:166-182): the `if valid_expr > 0` decision from the count that travels to the host
+    under the forward pass (round 6, models.model._count_valid_ahead) against the read-back after the loss (M3T_STEP_SYNC=1, the reference's
+    two .item() calls): the same keys, bit-equal loss terms and gradients, acc_expr equal to the quotient of the counts; a batch without one
+    valid expression label drops loss_expr / acc_expr in both modes and leaves the loss at the valence / arousal terms."""
+    import models.model as mm
+    from models.model import AffWild2VA
+    m = fill_module(AffWild2VA(_hp(modality="audio", loss="ccc_mtl")), 77).to(DEV).train()
+    batch = _affwild_batch(np.random.RandomState(5), 4, 100)
+    none_valid = dict(batch, expr_valid=torch.zeros_like(batch["expr_valid"]))
+    res = {}
+    for sync in (False, True):
+        monkeypatch.setattr(mm, "_STEP_SYNC", sync)
+        for name, b in (("some", batch), ("none", none_valid)):
+            torch.manual_seed(3)            # (dropout inside the GRU stack)
+            for p_ in m.parameters():
+                p_.grad = None
+            out = m.training_step(b, 0)
+            out["loss"].backward()
+            res[sync, name] = (out, [p_.grad.clone() for p_ in m.parameters()])
+    for name in ("some", "none"):
+        (a, ga), (b_, gb) = res[False, name], res[True, name]
+        assert sorted(a["progress_bar"]) == sorted(b_["progress_bar"]) and sorted(a["log"]) == sorted(b_["log"])
+        for k in a["log"]:
+            assert torch.equal(a["log"][k], b_["log"][k]), k
+        assert all(torch.equal(x, y) for x, y in zip(ga, gb))
+    some, none = res[False, "some"][0], res[False, "none"][0]
+    assert "loss_expr" in some["log"] and "acc_expr" in some["progress_bar"] and torch.is_tensor(some["progress_bar"]["acc_expr"])
+    assert isinstance(res[True, "some"][0]["progress_bar"]["acc_expr"], float)
+    assert abs(float(some["progress_bar"]["acc_expr"]) - res[True, "some"][0]["progress_bar"]["acc_expr"]) < 1e-6
+    assert "loss_expr" not in none["log"] and "acc_expr" not in none["progress_bar"]
+    close(none["loss"], 0.5 * none["log"]["loss_v"] + 0.5 * none["log"]["loss_a"], 1e-6, "loss without expression labels")
+
+
 @pytest.mark.parametrize("Ci,Co,k,stride,pad,N,T,H,W", [
     (3, 64, (3, 3, 3), (1, 2, 2), (1, 0, 0), 2, 6, 13, 12),        # a stem's first layer: C_in k^3 = 81, the transposed / padded GEMM form
     (64, 128, (3, 3, 3), (1, 1, 1), (1, 0, 0), 2, 5, 9, 10),       # interior layers: C_in k^3 = 1728 = 27 x 64

@@ -42,3 +42,26 @@ for _ in range(6):
     step()
 pr.disable(); torch.cuda.synchronize()
 s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28); print(s.getvalue()[:5000])
+
+# --- the two halves of the step with the GPU parked behind a spin kernel: what the host needs to enqueue each half (no back-pressure, no
+# wait for the loss statistics) and what the GPU needs to run it once everything is queued (HIP events).  training_step's read-back of the
+# statistics splits the step in two: time = max(host_fwd, gpu_fwd) + read-back + max(host_bwd, gpu_bwd) when the host is the slower side.
+def halves():
+    ddp.zero_grad()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    torch.cuda._sleep(int(0.04 * 2.4e9))
+    ev[0].record(); t0 = time.perf_counter()
+    loss, stats = m.va_objective(m.forward(batch), batch)
+    t1 = time.perf_counter(); ev[1].record()
+    torch.cuda.synchronize()
+    torch.cuda._sleep(int(0.04 * 2.4e9))
+    ev[2].record(); t2 = time.perf_counter()
+    loss.backward(); ddp.finish()
+    t3 = time.perf_counter(); ev[3].record()
+    torch.cuda.synchronize()
+    return (t1 - t0) * 1e3, ev[0].elapsed_time(ev[1]), (t3 - t2) * 1e3, ev[2].elapsed_time(ev[3])
+rows = [halves() for _ in range(5)]
+med = lambda i: sorted(r[i] for r in rows)[2]
+print("halves (median of 5): host enqueue forward+loss %.3f ms, backward+finish %.3f ms | GPU (events after the spin, whole half queued ahead) "
+      "forward+loss %.3f ms, backward+finish %.3f ms" % (med(0), med(2), med(1), med(3)))
