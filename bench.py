@@ -316,7 +316,7 @@ def aux_child(which, steps=6, warmup=2):
             print(json.dumps({"aux": "stock_fallbacks", "calls_by_site": dict(_o.STOCK_FALLBACKS), "conv_forward_calls_by_path": dict(_o.CONV3D_CALLS)}), flush=True)
 
 
-    if "cbam" in which:          # (last: MIOpen's first-use search for the ResNet convolutions may eat what is left of the budget)
+    if "cbam" in which or "resnet3d" in which:          # ("resnet3d": this step without the four gate shapes above -- profiling runs)
         if os.environ.get("M3T_AUX_EMPTY_CACHE", "1") != "0":
             import gc
             gc.collect()

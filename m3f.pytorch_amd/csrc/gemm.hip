@@ -593,7 +593,8 @@ static GemmPlan plan_gemm(int transA, int M, int N, int K, int seg_len, bool vec
     // interior shapes go to the bf16x6 kernels (fp32-accurate, 2.67x the fp32 MFMA rate)
     // (N % 64 == 0 is enough with the 128 x 64 tile: e.g. the conv3d weight gradient with N = C_in k^3 = 1728)
     const bool n64 = (N % 128 != 0) && (N % 64 == 0) && narrow_mode();
-    const bool x6 = x6_enabled() && (M % 128 == 0) && (N % 128 == 0 || n64) && (K % 32 == 0) && K > 0 && vec &&
+    // (round 6: the segmented reduction takes any K -- a ragged last k tile reads zeros: dW_hh at 8 clips x 63 steps, K = 504)
+    const bool x6 = x6_enabled() && (M % 128 == 0) && (N % 128 == 0 || n64) && (K % 32 == 0 || seg_len >= 32) && K > 0 && vec &&
                     (seg_len == 0 || seg_len >= 32);
     const double ns_per_k = x6 ? (bf16 ? 14.0 : (high ? 27.0 : (f16x3 ? 22.0 : 36.0))) : 84.0;
     const int kq = x6 ? 32 : BK;
@@ -709,7 +710,7 @@ extern "C" int m3t_sgemm_scaled(int transA, int transB, int M, int N, int K, con
         if (g.wide)
             rc = m3t_sgemm_x6w_launch(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, seg_len, seg_stride,
                                       a_off, b_off, ws, splits, kchunk, f16x3 ? 3 : 0, use_a, use_b, s);
-        else if (!g.narrow && (!f16x3 || f16x3_on_x6d()) && !(flags & (M3T_GEMM_BACKGROUND | M3T_GEMM_HIGH)) && (x6d_mode() == 1 || (x6d_mode() == 2 && !(flags & M3T_GEMM_BESIDE_SCAN))))      // ("high": measured better on gemm_x6.hip)
+        else if (!g.narrow && K % 32 == 0 && (!f16x3 || f16x3_on_x6d()) && !(flags & (M3T_GEMM_BACKGROUND | M3T_GEMM_HIGH)) && (x6d_mode() == 1 || (x6d_mode() == 2 && !(flags & M3T_GEMM_BESIDE_SCAN))))      // ("high": measured better on gemm_x6.hip)
             // the same product, software-pipelined inside each wave (gemm_x6d.hip): bit-identical results, 8-28 % faster
             rc = m3t_sgemm_x6d_launch(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, seg_len, seg_stride,
                                       a_off, b_off, ws, splits, kchunk, p.bf16 ? 1 : ((flags & M3T_GEMM_HIGH) ? 2 : (f16x3 ? 3 : 0)), use_a, use_b, s);

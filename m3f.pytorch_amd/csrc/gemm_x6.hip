@@ -216,7 +216,8 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p, X6Batch bt
     const bool bcol = XNT == 128 || (tid & 31) < 16;      // row-contiguous B: this thread's 4 columns lie inside the tile
     const int k_begin = MW ? 0 : blockIdx.z * p.kchunk;
     const int k_end = min(p.K, k_begin + p.kchunk);
-    const int ntiles = C3 == 2 ? (k_end - k_begin + XK - 1) / XK : (k_end - k_begin) / XK;      // (C3 = 2: a ragged last tile reads zeros past K)
+    // (C3 = 2 and the segmented reduction: a ragged last tile reads zeros past K)
+    const int ntiles = (C3 == 2 || SEG) ? (k_end - k_begin + XK - 1) / XK : (k_end - k_begin) / XK;
     __shared__ int rowmap[MW ? XM : 1];              // MW: storage row of the tile's row i
     if (MW) {
         if (tid < XM) {
@@ -274,8 +275,9 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p, X6Batch bt
     }
     // C3 = 2: this thread's tap (from its four A columns) and the dy-grid coordinates of its first k row, advanced by XK per tile
     int g_w = 0, g_h = 0, g_t = 0, g_n = 0, adv_w = 0, adv_h = 0, adv_t = 0, adv_n = 0, g_dt = 0, g_dh = 0, g_dw = 0, g_c = 0;
-    int g_k = 0;                                     // C3 = 2: the reduction row of this thread's first load of the next tile (rows past K: zeros)
+    int g_k = 0;                                     // C3 = 2, SEG: the reduction row of this thread's first load of the next tile (rows past K: zeros)
     bool g_ok = false;
+    if (SEG) g_k = k_begin + (tid >> 5) * 4;
     if (C3 == 2) {
         g_k = k_begin + (tid >> 5) * 4;
         const int m0 = bm + (tid & 31) * 4;
@@ -371,10 +373,12 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p, X6Batch bt
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const size_t row = (size_t)q * p.seg_stride + r;
-                ra[e] = *reinterpret_cast<const float4*>(p.A + (row + p.a_off) * p.lda + bm + (tid & 31) * 4);
-                rb[e] = bcol ? *reinterpret_cast<const float4*>(p.B + (row + p.b_off) * p.ldb + bn + (tid & 31) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const bool kin = g_k + e < k_end;        // round 6: K = segments x seg_len need not be a multiple of 32 (8 clips x 63 steps = 504)
+                ra[e] = kin ? *reinterpret_cast<const float4*>(p.A + (row + p.a_off) * p.lda + bm + (tid & 31) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                rb[e] = (bcol && kin) ? *reinterpret_cast<const float4*>(p.B + (row + p.b_off) * p.ldb + bn + (tid & 31) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
                 if (++r >= p.seg_len) { r = 0; ++q; }
             }
+            g_k += XK;
             sr += XK;
             while (sr >= p.seg_len) { sr -= p.seg_len; ++sq; }
         } else {

@@ -1517,20 +1517,10 @@ class _MultiBiGRU(torch.autograd.Function):
                     # tail: [the stream this level runs on, weight-gradient stream 1] -- after the last level nothing else is queued on
                     # the level's own stream, and finalize (FlatGradDDP.finish) then follows its last GEMM with no cross-queue hop
                     with (on_stream(pool[rr[0] % len(pool)]) if pool is not None else _NULL):
-                        if T > 1 and (B * (T - 1)) % 32 != 0 and (B * T) % 32 == 0 and H % 128 == 0:
-                            # K = B (T-1) is no multiple of the bf16x6 GEMMs' 32-deep k tile (e.g. 8 clips x 64 frames: K = 504) and
-                            # the segmented product would fall to the fp32-MFMA kernel (20 launches, 7 % of a C5 step).  h_prev at
-                            # a clip's first step IS zero, so the same sum runs over all B T rows against a shifted copy of the
-                            # states with zero rows there: K = B T (a 1-MB copy per scan at that size)
-                            hprev = torch.zeros(B, T, H, dtype=torch.float32, device=dev)
-                            if d == 0:
-                                hprev[:, 1:].copy_(out[:, :-1, d * H:(d + 1) * H])
-                            else:
-                                hprev[:, :-1].copy_(out[:, 1:, d * H:(d + 1) * H])
-                            sgemm(1, 0, 3 * H, H, B * T, dgh[l][s], goff, 3 * H, hprev, 0, H, dw_hh, 0, H, prec=prec,
-                                  amax=(bslot(l, s, d), one if bslots is not None else None))
-                            hprev.record_stream(cur_stream())
-                        elif T > 1:
+                        if T > 1:
+                            # (K = B (T-1) need not be a multiple of the 32-deep k tile -- 8 clips x 64 frames: K = 504 -- since round 6: the
+                            # segmented reduction's ragged last tile reads zeros.  Until then: a zero-padded shifted copy of the states per
+                            # scan, 40 fill / copy launches per C5 step)
                             # dW_hh = sum_{b,t} dgh[b,t]^T h_prev(b,t): forward pairs (t, t-1), reverse pairs (t, t+1)
                             a_off, b_off = (1, 0) if d == 0 else (0, 1)
                             sgemm(1, 0, 3 * H, H, B * (T - 1), dgh[l][s], goff, 3 * H, out, d * H, out.stride(1), dw_hh, 0, H,

@@ -106,6 +106,21 @@ def test_sgemm_strided_and_segmented():
         ops.sgemm(1, 0, 3 * H, H, B_ * (T - 1), dev(dgh), 0, 3 * H, dev(out), d * H, 2 * H, got, 0, H,
                   seg=(T - 1, T, a_off, b_off))
         close(got, ref, 1e-5, "dW_hh dir %d" % d)
+    # round 6: K = clips x (T - 1) need not be a multiple of the 16-bit-term kernels' 32-deep k tile (8 clips x 63 steps = 504: the C5
+    # batch) -- the segmented reduction's ragged last tile reads zeros; with and without split-K slabs (whose last chunk is the ragged one)
+    B_, T, H = 16, 64, 128          # (K = 1008 = 31.5 k tiles: deep enough for the planner to cut slabs)
+    dgh = rs.standard_normal((B_, T, 3 * H)).astype(np.float32)
+    out = rs.standard_normal((B_, T, 2 * H)).astype(np.float32)
+    assert ops.sgemm_plan(1, 3 * H, H, B_ * (T - 1), seg_len=T - 1, ws_bytes=0)[0] == 1          # the fp16x3 kernel, not the fp32-MFMA fallback
+    for d, (a_off, b_off) in enumerate([(1, 0), (0, 1)]):
+        hp = out[:, :-1, d * H:(d + 1) * H] if d == 0 else out[:, 1:, d * H:(d + 1) * H]
+        g = dgh[:, 1:] if d == 0 else dgh[:, :-1]
+        ref = np.einsum("btg,bth->gh", g.astype(np.float64), hp.astype(np.float64))
+        for use_ws in (False, True):
+            got = torch.full((3 * H, H), float("nan"), device=DEV)
+            ops.sgemm(1, 0, 3 * H, H, B_ * (T - 1), dev(dgh), 0, 3 * H, dev(out), d * H, 2 * H, got, 0, H,
+                      seg=(T - 1, T, a_off, b_off), use_ws=use_ws)
+            close(got, ref, 2e-5 * (1008 ** 0.5 / 8), "ragged dW_hh dir %d ws %d" % (d, use_ws))
 
 
 def test_sgemm_fp16x3_scales_slots_and_edge_values():
