@@ -77,6 +77,9 @@ extern "C" {
 /* the caller promises that nothing else shares the chip while this GEMM runs.  Rounds 2-3 gave such calls a 256 x 256-tile kernel in the
  * six-product mode; it had no fp16x3 form and was removed in round 4 -- the flag is accepted and currently changes nothing. */
 #define M3T_GEMM_EXCLUSIVE 8
+/* m3t_conv3d_wgrad_taps only: x_cl and dy_cl are the m3t_f16x3_split images of the two operands under amax_x / amax_dy (both required, with
+ * M3T_GEMM_F16X3) -- the forward walk and the data gradient's walk have made them already; the same sums, bit for bit (round 6). */
+#define M3T_CONV_IMAGES 4096
 
 /* Patch matrix (im2col) of a Conv3d input x [N, Ci, T, H, W] for the weight-gradient GEMM dW = dy^T P of the 3-D conv stems (reference
  * models/backbone.py:73-103,179-271,327-332; forward and data gradient stay on MIOpen): out [rows_pad, Kp] row-major, row = (n, t', h', w'),
@@ -151,7 +154,8 @@ int m3t_conv3d_taps_pre(const float* src_img, const float* w_img, float* dst, in
  * m3t_conv3d_wgrad_taps: dwt[(tap, ci)][co] = sum over the rows r = (n, t', h', w') of the dy grid of x_cl[source row of (r, tap)][ci] dy_cl[r][co]
  *   -- the walk turned round: the reduction runs over the rows (deterministic split-K slabs in ws), the tap is picked once per thread from
  *   its output row, every reduction row is decoded on the dy grid by a counter (no division in the loop).  dwt has ceil128(taps Ci) rows
- *   (rows past taps Ci are written as zeros); fp32 operands, split in the kernel; flags / amax as m3t_sgemm_scaled (NULL slots are measured).
+ *   (rows past taps Ci are written as zeros); fp32 operands, split in the kernel -- or, with M3T_CONV_IMAGES, their m3t_f16x3_split images;
+ *   flags / amax as m3t_sgemm_scaled (NULL slots are measured).
  *   Co % 64 == 0, Ci % 4 == 0, 16-B aligned; any number of rows (round 6: a ragged last reduction tile reads zeros).
  * With m3t_conv3d_taps(_pre) for the data gradient of the stride-1 layers, no convolution of the path materialises its patches.
  * dst_planes / y_planes (optional, every walk but the weight gradient's): the result is left as channel planes [N][C][T H W] there -- written by

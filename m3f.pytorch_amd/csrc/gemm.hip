@@ -801,7 +801,7 @@ int m3t_conv3d_taps_launch(const float* src, const float* w_taps, float* dst, in
 extern "C" int m3t_btc_to_bct(const float* src, float* dst, int B, int T, int C, void* stream);
 int m3t_conv3d_wgrad_launch(const float* x_cl, const float* dy_cl, float* dwt, int N, int Ci, int Co, int T, int H, int W, int To, int Ho, int Wo,
                             int kt, int kh, int kw, const int* stride3, int pt, int ph, int pw, int f16x3, const unsigned long long* amax_x,
-                            const unsigned long long* amax_dy, float* ws, int splits, int kchunk, hipStream_t s);
+                            const unsigned long long* amax_dy, float* ws, int splits, int kchunk, hipStream_t s, int pre);
 
 int m3t_conv3d_taps4_launch(const float* x_img4, const float* w_img, const float* bias, float* y_cl, int N, int Co, int T, int H, int W, int To,
                             int Ho, int Wo, int kt, int kh, int kw, const int* stride3, int pt, int ph, int pw, const unsigned long long* amax_x,
@@ -1146,9 +1146,13 @@ extern "C" int m3t_conv3d_wgrad_taps(const float* x_cl, const float* dy_cl, floa
         (uintptr_t)dwt % 16 != 0 || (flags & (M3T_GEMM_BF16 | M3T_GEMM_HIGH)))
         return M3T_EINVAL;
     const int f16x3 = ((flags & M3T_GEMM_F16X3) && m3t_f16x3_enabled()) ? 1 : 0;
+    // M3T_CONV_IMAGES: x_cl and dy_cl are the m3t_f16x3_split images of the operands under amax_x / amax_dy (the forward pass and the data
+    // gradient made them already): the loop re-pairs halves instead of converting -- each x value is staged 27 x C_out / 128 times
+    const int pre = (flags & M3T_CONV_IMAGES) ? 1 : 0;
+    if (pre && (!f16x3 || !amax_x || !amax_dy)) return M3T_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const unsigned long long* use_a = amax_x; const unsigned long long* use_b = amax_dy;
-    if (f16x3) {
+    if (f16x3 && !pre) {
         const M3TRegion ra{x_cl, (unsigned long long)srows, (unsigned long long)Ci, Ci / 4, nullptr};
         const M3TRegion rb{dy_cl, (unsigned long long)rows, (unsigned long long)Co, Co / 4, nullptr};
         const int rm = m3t_f16x3_measure(ra, amax_x, rb, amax_dy, &use_a, &use_b, s);
@@ -1170,7 +1174,7 @@ extern "C" int m3t_conv3d_wgrad_taps(const float* x_cl, const float* dy_cl, floa
     }
     const int stride3[3] = {st, sh, sw};
     const int rc = m3t_conv3d_wgrad_launch(x_cl, dy_cl, dwt, N, Ci, Co, T, H, W, To, Ho, Wo, kt, kh, kw, stride3, pt, ph, pw, f16x3, use_a, use_b, ws,
-                                           splits, kchunk, s);
+                                           splits, kchunk, s, pre);
     if (rc) return rc;
     if (splits > 1) { launch_splitk_reduce(ws, dwt, nullptr, Mp, Co, Co, splits, 0, 0, s); M3T_LAUNCH_CHECK(); }
     return 0;

@@ -138,12 +138,30 @@ __device__ __forceinline__ void kc_store(unsigned char* __restrict__ S, const fl
 // ---- row-contiguous operand ([K][rows]): thread = (k-quad = tid>>5 (4 k), 4 rows at (tid&31)*4): a 4x4 block.
 // Lanes l and l+32 of a wave hold the two k-quads of ONE octet (octet = wave) for the same rows; after the swaps the
 // lower lane owns the complete records of rows 0, 1 and the upper lane those of rows 2, 3.
-template <int NS>
+// PRE (NS = 4): the operand arrives PRE-SPLIT along its contiguous axis (m3t_f16x3_split: the 16 bytes of rows row0 .. row0 + 3 at one k hold
+// {hi r0|r1, hi r2|r3, lo r0|r1, lo r2|r3}); the records pair consecutive k of ONE row, so the halves of two loads are re-paired with one
+// v_perm_b32 per (row, k pair, term) -- 16 per thread and tile instead of 8 conversions of 6 VALU instructions each
+template <int NS, bool PRE = false>
 __device__ __forceinline__ void mc_store(unsigned char* __restrict__ S, const float4 (&r)[4], float scale = 1.f) {
     const int tid = threadIdx.x & 255;
     const int wave = tid >> 6, h = (tid >> 5) & 1, row0 = (tid & 31) * 4;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     unsigned lo[4][3], hi2[4][3];                     // [row][split]: k pairs (0,1) and (2,3) of this thread's k-quad
+    if (PRE && NS == 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned sel = (i & 1) ? 0x07060302u : 0x05040100u;      // the row's half of each word: (first k in the low half)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const unsigned c0 = __float_as_uint(s == 0 ? (i < 2 ? r[0].x : r[0].y) : (i < 2 ? r[0].z : r[0].w));
+                const unsigned c1 = __float_as_uint(s == 0 ? (i < 2 ? r[1].x : r[1].y) : (i < 2 ? r[1].z : r[1].w));
+                const unsigned c2 = __float_as_uint(s == 0 ? (i < 2 ? r[2].x : r[2].y) : (i < 2 ? r[2].z : r[2].w));
+                const unsigned c3 = __float_as_uint(s == 0 ? (i < 2 ? r[3].x : r[3].y) : (i < 2 ? r[3].z : r[3].w));
+                lo[i][s] = __builtin_amdgcn_perm(c1, c0, sel);
+                hi2[i][s] = __builtin_amdgcn_perm(c3, c2, sel);
+            }
+        }
+    } else
 #pragma unroll
     for (int i = 0; i < 4; ++i) {                     // row row0 + i: its 4 k values are component i of r[0..3]
         const float v0 = i == 0 ? r[0].x : i == 1 ? r[0].y : i == 2 ? r[0].z : r[0].w;
@@ -399,8 +417,8 @@ __global__ __launch_bounds__(256, 3) void sgemm_x6_kernel(X6Params p, X6Batch bt
         }
     };
     auto sstore = [&]() {
-        if (TA == 0) kc_store<NS, 4, (PRE & 1) != 0>(As, ra, sc_a); else mc_store<NS>(As, ra, sc_a);
-        if (TB == 1) kc_store<NS, BR, (PRE & 2) != 0>(Bs, rb, sc_b); else mc_store<NS>(Bs, rb, sc_b);
+        if (TA == 0) kc_store<NS, 4, (PRE & 1) != 0>(As, ra, sc_a); else mc_store<NS, (PRE & 1) != 0>(As, ra, sc_a);
+        if (TB == 1) kc_store<NS, BR, (PRE & 2) != 0>(Bs, rb, sc_b); else mc_store<NS, (PRE & 2) != 0>(Bs, rb, sc_b);
     };
 
     if (ntiles > 0) { gload(); sstore(); }
@@ -697,9 +715,10 @@ int m3t_conv3d_taps4_launch(const float* x_img4, const float* w_img, const float
 // to 128.  The caller has verified: Co % 64 == 0, Ci % 4 == 0, kchunk % 32 == 0 (any number of rows: a ragged last k tile reads zeros), 16-B aligned operands.
 int m3t_conv3d_wgrad_launch(const float* x_cl, const float* dy_cl, float* dwt, int N, int Ci, int Co, int T, int H, int W, int To, int Ho, int Wo,
                             int kt, int kh, int kw, const int* stride3, int pt, int ph, int pw, int f16x3, const unsigned long long* amax_x,
-                            const unsigned long long* amax_dy, float* ws, int splits, int kchunk, hipStream_t s) {
+                            const unsigned long long* amax_dy, float* ws, int splits, int kchunk, hipStream_t s, int pre) {
     X6Params p;
     if (f16x3 && (!amax_x || !amax_dy)) return M3T_EINVAL;
+    if (pre && !f16x3) return M3T_EINVAL;             // (pre: x_cl and dy_cl are m3t_f16x3_split images under those slots)
     p.amax_a = amax_x; p.amax_b = amax_dy; p.cv_amax = nullptr;
     p.A = x_cl; p.B = dy_cl; p.C = dwt; p.bias = nullptr; p.ws = ws;
     const int Mp = (kt * kh * kw * Ci + XM - 1) / XM * XM;
@@ -715,7 +734,10 @@ int m3t_conv3d_wgrad_launch(const float* x_cl, const float* dy_cl, float* dwt, i
     p.c3_st = stride3[0]; p.c3_sh = stride3[1]; p.c3_sw = stride3[2]; p.tr_S = 0;
     const bool narrow = (Co % 128 != 0) || (Co / XN) * (Mp / XM) * splits <= 384;
     dim3 grid(Co / (narrow ? 64 : XN), Mp / XM, splits), block(256);
-    if (f16x3) {
+    if (f16x3 && pre) {
+        if (narrow) sgemm_x6_kernel<1, 0, false, 4, false, 64, false, 2, 3><<<grid, block, 0, s>>>(p, g_no_batch);
+        else sgemm_x6_kernel<1, 0, false, 4, false, 128, false, 2, 3><<<grid, block, 0, s>>>(p, g_no_batch);
+    } else if (f16x3) {
         if (narrow) sgemm_x6_kernel<1, 0, false, 4, false, 64, false, 2><<<grid, block, 0, s>>>(p, g_no_batch);
         else sgemm_x6_kernel<1, 0, false, 4, false, 128, false, 2><<<grid, block, 0, s>>>(p, g_no_batch);
     } else {

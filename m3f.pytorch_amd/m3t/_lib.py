@@ -15,6 +15,7 @@ M3T_GEMM_BESIDE_SCAN = 512      # scheduling hint, see include/m3t_hip.h
 M3T_GEMM_F16X3 = 1024   # two fp16 terms per scaled operand, three products: fp32-accurate (include/m3t_hip.h)
 M3T_GEMM_HIGH = 256      # two bf16 terms per operand, four products: torch.set_float32_matmul_precision('high')
 M3T_GEMM_EXCLUSIVE = 8
+M3T_CONV_IMAGES = 4096      # m3t_conv3d_wgrad_taps: the operands are their m3t_f16x3_split images (include/m3t_hip.h)
 M3T_SCAN_FP32 = 4
 M3T_SCAN_WHH = 8
 M3T_SCAN_FAULT = 16

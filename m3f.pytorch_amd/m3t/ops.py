@@ -2378,6 +2378,9 @@ CONV3D_TAPS = [os.environ.get("M3T_CONV3D_MIOPEN", "0") not in ("1", "dgrad")]  
 CONV3D_IMPLICIT = [os.environ.get("M3T_CONV3D_IMPLICIT", "1") != "0"]
 CONV3D_CALLS = {"walk": 0, "patch": 0, "torch": 0}       # forward calls by path (tests assert the path they mean to check)
 _STOCK_WARNED = set()
+# M3T_WGRAD_IMAGES=0: the convolutions' weight-gradient walk splits its fp32 operands in its loop (as until round 6) instead of reading the images
+# the forward walk (x) and the data gradient (dy) have made
+WGRAD_IMAGES = [os.environ.get("M3T_WGRAD_IMAGES", "1") != "0"]
 STOCK_FALLBACKS = {}          # site -> number of calls that took a stock (torch / MIOpen) operator instead of the HIP library
 
 
@@ -2502,7 +2505,10 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
                     _lib.check(lib().m3t_conv3d_fwd_taps(_p(x_img), _p(w_img), bp, _p(y_cl), N_, Ci, Co, T_, H_, W_, *geo), "m3t_conv3d_fwd_taps")
                 else:
                     _lib.check(lib().m3t_conv3d_fwd_taps4(_p(x_img), _p(w_img), bp, _p(y_cl), N_, Co, T_, H_, W_, *geo), "m3t_conv3d_fwd_taps4")
-                ctx.save_for_backward(x, w, x_cl, slots)
+                # round 6: the weight gradient's walk reads the IMAGE of x (same bytes as x_cl, made above for the forward walk) and the image of
+                # dy its data gradient makes anyway: no conversions in its loop (WGRAD_IMAGES; a first layer's four-channel rows stay fp32)
+                ctx.x_is_img = bool(WGRAD_IMAGES[0] and cw == Ci)
+                ctx.save_for_backward(x, w, x_img if ctx.x_is_img else x_cl, slots)
                 ctx.pat = (rows, Kc, Kp)
                 ctx.a_w = a_w
                 ctx.impl = cw
@@ -2591,6 +2597,13 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
                 _lib.check(lib().m3t_bct_to_btc_sums(_p(dyc), _p(dy_cl), Nn, Co, Sp, _p(dpart), _stream()), "m3t_bct_to_btc_sums")
             else:
                 _lib.check(lib().m3t_bct_to_btc(_p(dyc), _p(dy_cl), Nn, Co, Sp, _stream()), "m3t_bct_to_btc")
+        dy_img_ = [None]
+
+        def dy_image():      # dy channels-last split ONCE under the slot its transpose raised: read by the data gradient's walk(s) and the weight gradient's
+            if dy_img_[0] is None:
+                dy_img_[0] = torch.empty_like(dy_cl)
+                _lib.check(lib().m3t_f16x3_split(_p(dy_cl), rows, Co, Co, _p(dy_img_[0]), Co, slot_dy.data_ptr(), _stream()), "m3t_f16x3_split")
+            return dy_img_[0]
         if taps_dx:
             To, Ho, Wo = dy.shape[2], dy.shape[3], dy.shape[4]
             dx_cl = torch.empty(N_ * T_ * H_ * W_, Ci, dtype=torch.float32, device=dy.device)      # (scratch of the split-K layers; dx itself: planes)
@@ -2600,9 +2613,8 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
                 # both operands split ONCE (m3t_f16x3_split: dy channels-last under the slot its transpose raised, the weights as the
                 # K-contiguous [ci][(tap, co)] matrix): the tap walk re-reads every dy row 27 times -- its loop is then copies and MFMAs only
                 taps = kt * kh * kw
-                dy_img = torch.empty_like(dy_cl)
+                dy_img = dy_image()
                 w_img = torch.empty(Ci, taps * Co, dtype=torch.float32, device=dy.device)
-                _lib.check(lib().m3t_f16x3_split(_p(dy_cl), rows, Co, Co, _p(dy_img), Co, slot_dy.data_ptr(), _stream()), "m3t_f16x3_split")
                 if w.is_contiguous():                 # [ci][(tap, co)] straight from w
                     _lib.check(lib().m3t_f16x3_split_perm(_p(w.detach()), Ci, taps, Co, taps, 1, Ci * taps, _p(w_img), ctx.a_w, _stream()),
                                "m3t_f16x3_split_perm")
@@ -2621,8 +2633,7 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
             To, Ho, Wo = dy.shape[2], dy.shape[3], dy.shape[4]
             dx = torch.zeros(N_, Ci, T_, H_, W_, dtype=torch.float32, device=dy.device)        # (classes without a tap stay zero: 1 x 1 stride-2 shortcuts)
             wsd = workspace(dy.device)
-            dy_img = torch.empty_like(dy_cl)
-            _lib.check(lib().m3t_f16x3_split(_p(dy_cl), rows, Co, Co, _p(dy_img), Co, slot_dy.data_ptr(), _stream()), "m3t_f16x3_split")
+            dy_img = dy_image()
             dims, ks = (T_, H_, W_), (kt, kh, kw)
             wd = w.detach()
             for ct in range(st[0]):
@@ -2654,9 +2665,11 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
             want = max(1, min((1536 + tiles - 1) // tiles, rows // 256))
             wsw = workspace(dy.device, min(want * Mp * Co * 4, 512 << 20))
             dwt = torch.empty(Mp, Co, dtype=torch.float32, device=dy.device)
-            _lib.check(lib().m3t_conv3d_wgrad_taps(_p(saved[2]), _p(dy_cl), _p(dwt), N_, impl, Co, T_, H_, W_, kt, kh, kw, st[0], st[1], st[2],
-                                                   pd[0], pd[1], pd[2], ctx.prec, saved[3].data_ptr(), slot_dy.data_ptr(), _p(wsw),
-                                                   wsw.numel() * 4, _stream()), "m3t_conv3d_wgrad_taps")
+            imgs = getattr(ctx, "x_is_img", False)
+            _lib.check(lib().m3t_conv3d_wgrad_taps(_p(saved[2]), _p(dy_image() if imgs else dy_cl), _p(dwt), N_, impl, Co, T_, H_, W_, kt, kh, kw,
+                                                   st[0], st[1], st[2], pd[0], pd[1], pd[2], ctx.prec | (_lib.M3T_CONV_IMAGES if imgs else 0),
+                                                   saved[3].data_ptr(), slot_dy.data_ptr(), _p(wsw), wsw.numel() * 4, _stream()),
+                       "m3t_conv3d_wgrad_taps")
             dw_v = dwt[:Kc].view(taps, impl, Co)[:, :Ci].permute(2, 1, 0)              # [co][ci][tap], strided
             if w_sink is not None:
                 w_sink.view(Co, Ci, taps).copy_(dw_v)
@@ -2855,7 +2868,8 @@ class _Conv3dCL(torch.autograd.Function):
             _lib.check(lib().m3t_conv3d_fwd_taps4(_p(x_img), _p(w_img), bp, _p(y_cl), N_, Co, T_, H_, W_, *tail), "m3t_conv3d_fwd_taps4")
         else:
             _lib.check(lib().m3t_conv3d_fwd_taps(_p(x_img), _p(w_img), bp, _p(y_cl), N_, Ci, Co, T_, H_, W_, *tail), "m3t_conv3d_fwd_taps")
-        ctx.save_for_backward(w, x_cl, slots)
+        ctx.x_is_img = bool(WGRAD_IMAGES[0] and not first and bool(_PREC[0] & _lib.M3T_GEMM_F16X3))      # (see _Conv3dGemmWgrad: the weight gradient reads images)
+        ctx.save_for_backward(w, x_img if ctx.x_is_img else x_cl, slots)
         ctx.a_x, ctx.a_w, ctx.cw = a_x, a_w, cw
         CONV3D_CALLS["walk"] += 1
         return y_cl
@@ -2877,11 +2891,13 @@ class _Conv3dCL(torch.autograd.Function):
             slot_dy = amax_slots(1, dy.device)
             measure_amax([(dy_cl, slot_dy.data_ptr())])
         wsd = workspace(dy.device)
+        dy_img = None
+        if ctx.needs_input_grad[0] or (ctx.needs_input_grad[1] and ctx.x_is_img):
+            dy_img = torch.empty_like(dy_cl)
+            _lib.check(lib().m3t_f16x3_split(_p(dy_cl), rows, Co, Co, _p(dy_img), Co, slot_dy.data_ptr(), _stream()), "m3t_f16x3_split")
         if ctx.needs_input_grad[0]:
             if first or Ci % 64 != 0 or Co % 32 != 0:
                 raise M3THipError("the channels-last chain has no data gradient for this layer (a first layer's input is the video)")
-            dy_img = torch.empty_like(dy_cl)
-            _lib.check(lib().m3t_f16x3_split(_p(dy_cl), rows, Co, Co, _p(dy_img), Co, slot_dy.data_ptr(), _stream()), "m3t_f16x3_split")
             wd = w.detach()
             dx = torch.empty(N_ * T_ * H_ * W_, Ci, dtype=torch.float32, device=dy.device)
             one = tuple(st) == (1, 1, 1)
@@ -2920,8 +2936,10 @@ class _Conv3dCL(torch.autograd.Function):
             want = max(1, min((1536 + tiles - 1) // tiles, rows // 256))
             wsw = workspace(dy.device, min(want * Mp * Co * 4, 512 << 20))
             dwt = torch.empty(Mp, Co, dtype=torch.float32, device=dy.device)
-            _lib.check(lib().m3t_conv3d_wgrad_taps(_p(x_cl), _p(dy_cl), _p(dwt), N_, cw, Co, T_, H_, W_, kt, kh, kw, st[0], st[1], st[2],
-                                                   pd[0], pd[1], pd[2], ctx.prec, ctx.a_x, slot_dy.data_ptr(), _p(wsw), wsw.numel() * 4, _stream()),
+            imgs = ctx.x_is_img
+            _lib.check(lib().m3t_conv3d_wgrad_taps(_p(x_cl), _p(dy_img if imgs else dy_cl), _p(dwt), N_, cw, Co, T_, H_, W_, kt, kh, kw,
+                                                   st[0], st[1], st[2], pd[0], pd[1], pd[2], ctx.prec | (_lib.M3T_CONV_IMAGES if imgs else 0),
+                                                   ctx.a_x, slot_dy.data_ptr(), _p(wsw), wsw.numel() * 4, _stream()),
                        "m3t_conv3d_wgrad_taps")
             dw_v = dwt[:Kc].view(taps, cw, Co)[:, :Ci].permute(2, 1, 0)
             if w_sink is not None:

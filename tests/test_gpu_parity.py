@@ -1221,6 +1221,18 @@ def test_conv3d_without_a_patch_matrix(Ci, Co, k, stride, pad, N, T, H, W):
             ops.CONV3D_IMPLICIT[0] = saved
         assert ops.CONV3D_CALLS["walk" if implicit else "patch"] == n0["walk" if implicit else "patch"] + 1, "not the path this test means"
         res.append((y.detach(), w.grad, b.grad, x.grad))
+    if Ci % 32 == 0:
+        # round 6: the weight gradient's walk read the m3t_f16x3_split IMAGES of x and dy (M3T_CONV_IMAGES); splitting the fp32 operands in its
+        # loop (M3T_WGRAD_IMAGES=0) gives the same sums bit for bit
+        saved = ops.WGRAD_IMAGES[0]
+        ops.WGRAD_IMAGES[0] = False
+        try:
+            x, w, b = dev(xn, True), dev(wn, True), dev(bn_, True)
+            (ops.conv3d(x, w, b, stride, pad) * dev(ctn)).sum().backward()
+        finally:
+            ops.WGRAD_IMAGES[0] = saved
+        assert torch.equal(res[0][1], w.grad), "weight gradient: operand images vs operands split in the loop"
+        assert torch.equal(res[0][3], x.grad)
     x64, w64, b64 = (torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (xn, wn, bn_))
     y64 = torch.conv3d(x64, w64, b64, stride, pad)
     (y64 * torch.tensor(ctn, dtype=torch.float64)).sum().backward()
@@ -1937,7 +1949,7 @@ def test_solo_scans_h128_through_the_c_abi(B, T, bf16):
 
 
 @pytest.mark.parametrize("switch", ["M3T_CONV_X6", "M3T_CBAM_FUSED", "M3T_CBAM_RESIDENT", "M3T_BN_PLANES", "M3T_CONV3D_IMPLICIT", "M3T_STEM_CL",
-                                    "M3T_BN_POOL_FUSED"])
+                                    "M3T_BN_POOL_FUSED", "M3T_WGRAD_IMAGES"])
 def test_conv_and_cbam_kernel_switches(switch):
     """README's switch table, the entries the C3 step does not exercise (read once per process, hence a child):
     M3T_CONV_X6=0 -- the TCN / tcn_simple convolutions on the fp32-MFMA kernel instead of the bf16x6 implicit GEMM;
@@ -1949,7 +1961,8 @@ def test_conv_and_cbam_kernel_switches(switch):
     M3T_BN_PLANES=0 -- BatchNorm3d / BatchNorm2d (+ReLU) of the stems and the per-frame ResNet on the stock ops instead of the channel-plane
     kernels;
     M3T_STEM_CL=0 -- the VGG-M stems on the planes operators (a transpose on each side of every convolution) instead of the channels-last chain
-    of round 6; M3T_BN_POOL_FUSED=0 -- the chain with BatchNorm + ReLU and the pooling as two operators instead of one.  Same arithmetic: the convolution, TemporalBlock, CBAM, ResNet and C5 parity tests must pass unchanged."""
+    of round 6; M3T_BN_POOL_FUSED=0 -- the chain with BatchNorm + ReLU and the pooling as two operators instead of one; M3T_WGRAD_IMAGES=0 -- the
+    convolutions' weight-gradient walk on fp32 operands split in its loop instead of the images the other walks made.  Same arithmetic: the convolution, TemporalBlock, CBAM, ResNet and C5 parity tests must pass unchanged."""
     import subprocess
     import sys
     env = dict(os.environ, M3T_SCAN_LOCK="0", **{switch: "0"})
@@ -1957,7 +1970,8 @@ def test_conv_and_cbam_kernel_switches(switch):
             "M3T_CONV3D_IMPLICIT": "c5_resnet3d or c5_affwild_av_golden or conv3d_weight_gradient or conv3d_forward_on_the_patch",
             "M3T_BN_PLANES": "resnet_cbam or c5_resnet3d or c5_affwild_av_t16",
             "M3T_STEM_CL": "c5_affwild_av_golden or c5_affwild_av_train or vggm_end_to_end",
-            "M3T_BN_POOL_FUSED": "c5_affwild_av_golden or c5_affwild_av_train or vggm_end_to_end"}.get(switch, "cbam_golden or resnet_cbam or cbam_stage")
+            "M3T_BN_POOL_FUSED": "c5_affwild_av_golden or c5_affwild_av_train or vggm_end_to_end",
+            "M3T_WGRAD_IMAGES": "c5_affwild_av_train or c5_resnet3d_cbam_train or conv3d_on_channels_last"}.get(switch, "cbam_golden or resnet_cbam or cbam_stage")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k", pick], env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-1500:]
