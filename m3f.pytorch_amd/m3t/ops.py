@@ -2378,6 +2378,22 @@ CONV3D_TAPS = [os.environ.get("M3T_CONV3D_MIOPEN", "0") not in ("1", "dgrad")]  
 CONV3D_IMPLICIT = [os.environ.get("M3T_CONV3D_IMPLICIT", "1") != "0"]
 CONV3D_CALLS = {"walk": 0, "patch": 0, "torch": 0}       # forward calls by path (tests assert the path they mean to check)
 _STOCK_WARNED = set()
+# M3T_CONV_WGRAD_STREAM=0: the convolutions' weight-gradient walks stay on the stream their layer's backward runs on (as until round 6)
+CONV_WGRAD_STREAM = [os.environ.get("M3T_CONV_WGRAD_STREAM", "1") != "0"]
+_CONV_RR = [0]
+
+
+def _conv_wgrad_stream(device, w_sink):
+    """the weight-gradient stream for a convolution's weight-gradient walk, already waiting for the current stream -- or None (no sink: the
+    gradient tensor is returned to autograd on this stream; CPU; switched off)"""
+    if w_sink is None or not CONV_WGRAD_STREAM[0] or device.type != "cuda":
+        return None
+    wg = wgrad_stream(device, _CONV_RR[0])
+    _CONV_RR[0] += 1
+    wg.wait_stream(cur_stream(device))
+    return wg
+
+
 # M3T_WGRAD_IMAGES=0: the convolutions' weight-gradient walk splits its fp32 operands in its loop (as until round 6) instead of reading the images
 # the forward walk (x) and the data gradient (dy) have made
 WGRAD_IMAGES = [os.environ.get("M3T_WGRAD_IMAGES", "1") != "0"]
@@ -2663,18 +2679,27 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
             Mp = (Kc + 127) // 128 * 128
             tiles = (Mp // 128) * ((Co + 127) // 128)
             want = max(1, min((1536 + tiles - 1) // tiles, rows // 256))
-            wsw = workspace(dy.device, min(want * Mp * Co * 4, 512 << 20))
-            dwt = torch.empty(Mp, Co, dtype=torch.float32, device=dy.device)
             imgs = getattr(ctx, "x_is_img", False)
-            _lib.check(lib().m3t_conv3d_wgrad_taps(_p(saved[2]), _p(dy_image() if imgs else dy_cl), _p(dwt), N_, impl, Co, T_, H_, W_, kt, kh, kw,
-                                                   st[0], st[1], st[2], pd[0], pd[1], pd[2], ctx.prec | (_lib.M3T_CONV_IMAGES if imgs else 0),
-                                                   saved[3].data_ptr(), slot_dy.data_ptr(), _p(wsw), wsw.numel() * 4, _stream()),
-                       "m3t_conv3d_wgrad_taps")
-            dw_v = dwt[:Kc].view(taps, impl, Co)[:, :Ci].permute(2, 1, 0)              # [co][ci][tap], strided
-            if w_sink is not None:
-                w_sink.view(Co, Ci, taps).copy_(dw_v)
-            else:
-                dw = dw_v.contiguous().view_as(w)
+            dy_op = dy_image() if imgs else dy_cl
+            # round 6: a gradient that goes into a sink feeds nothing on the chain -- its walk leaves for a weight-gradient stream (as the GRU levels'
+            # and nn.Linear's do) and runs beside the BatchNorm / pooling / gate backward of the layers in front, which are HBM-bound
+            wg = _conv_wgrad_stream(dy.device, w_sink)
+            with (on_stream(wg) if wg is not None else _NULL):
+                wsw = workspace(dy.device, min(want * Mp * Co * 4, 512 << 20))
+                dwt = torch.empty(Mp, Co, dtype=torch.float32, device=dy.device)
+                _lib.check(lib().m3t_conv3d_wgrad_taps(_p(saved[2]), _p(dy_op), _p(dwt), N_, impl, Co, T_, H_, W_, kt, kh, kw,
+                                                       st[0], st[1], st[2], pd[0], pd[1], pd[2], ctx.prec | (_lib.M3T_CONV_IMAGES if imgs else 0),
+                                                       saved[3].data_ptr(), slot_dy.data_ptr(), _p(wsw), wsw.numel() * 4, _stream()),
+                           "m3t_conv3d_wgrad_taps")
+                dw_v = dwt[:Kc].view(taps, impl, Co)[:, :Ci].permute(2, 1, 0)              # [co][ci][tap], strided
+                if w_sink is not None:
+                    w_sink.view(Co, Ci, taps).copy_(dw_v)
+                else:
+                    dw = dw_v.contiguous().view_as(w)
+            if wg is not None:
+                for t_ in (saved[2], dy_op, saved[3], slot_dy):
+                    t_.record_stream(wg)
+                _WGRAD_PENDING[(dy.device.type, dy.device.index)] = True
         elif ctx.needs_input_grad[1]:
             Kc = Ci * kt * kh * kw
             xc = _req(x.contiguous(), "x")
@@ -2887,6 +2912,8 @@ class _Conv3dCL(torch.autograd.Function):
         dx = dw = db = None
         w_sink = _take_sink(ctx.sink_refs[0]) if (ctx.needs_input_grad[1] and ctx.sink_refs[0] is not None) else None
         b_sink = _take_sink(ctx.sink_refs[1]) if (ctx.has_bias and ctx.needs_input_grad[2] and ctx.sink_refs[1] is not None) else None
+        if ctx.needs_input_grad[1] and ctx.sink_refs[0] is not None and w_sink is None:
+            join_wgrad(dy.device)      # (the sink was taken already this step: autograd adds the tensor returned below onto a slice a weight-gradient stream may still write -- see _Linear)
         if slot_dy is None:
             slot_dy = amax_slots(1, dy.device)
             measure_amax([(dy_cl, slot_dy.data_ptr())])
@@ -2934,18 +2961,26 @@ class _Conv3dCL(torch.autograd.Function):
             Mp = (Kc + 127) // 128 * 128
             tiles = (Mp // 128) * ((Co + 127) // 128)
             want = max(1, min((1536 + tiles - 1) // tiles, rows // 256))
-            wsw = workspace(dy.device, min(want * Mp * Co * 4, 512 << 20))
-            dwt = torch.empty(Mp, Co, dtype=torch.float32, device=dy.device)
             imgs = ctx.x_is_img
-            _lib.check(lib().m3t_conv3d_wgrad_taps(_p(x_cl), _p(dy_img if imgs else dy_cl), _p(dwt), N_, cw, Co, T_, H_, W_, kt, kh, kw,
-                                                   st[0], st[1], st[2], pd[0], pd[1], pd[2], ctx.prec | (_lib.M3T_CONV_IMAGES if imgs else 0),
-                                                   ctx.a_x, slot_dy.data_ptr(), _p(wsw), wsw.numel() * 4, _stream()),
-                       "m3t_conv3d_wgrad_taps")
-            dw_v = dwt[:Kc].view(taps, cw, Co)[:, :Ci].permute(2, 1, 0)
-            if w_sink is not None:
-                w_sink.view(Co, Ci, taps).copy_(dw_v)
-            else:
-                dw = dw_v.contiguous().view_as(w)
+            dy_op = dy_img if imgs else dy_cl
+            wg = _conv_wgrad_stream(dy.device, w_sink)           # (off the chain when the gradient goes into a sink: see _Conv3dGemmWgrad._backward5)
+            with (on_stream(wg) if wg is not None else _NULL):
+                wsw = workspace(dy.device, min(want * Mp * Co * 4, 512 << 20))
+                dwt = torch.empty(Mp, Co, dtype=torch.float32, device=dy.device)
+                _lib.check(lib().m3t_conv3d_wgrad_taps(_p(x_cl), _p(dy_op), _p(dwt), N_, cw, Co, T_, H_, W_, kt, kh, kw,
+                                                       st[0], st[1], st[2], pd[0], pd[1], pd[2], ctx.prec | (_lib.M3T_CONV_IMAGES if imgs else 0),
+                                                       ctx.a_x, slot_dy.data_ptr(), _p(wsw), wsw.numel() * 4, _stream()),
+                           "m3t_conv3d_wgrad_taps")
+                dw_v = dwt[:Kc].view(taps, cw, Co)[:, :Ci].permute(2, 1, 0)
+                if w_sink is not None:
+                    w_sink.view(Co, Ci, taps).copy_(dw_v)
+                else:
+                    dw = dw_v.contiguous().view_as(w)
+            if wg is not None:
+                for t_ in (x_cl, dy_op, slots, slot_dy) + tuple(ctx.w_keep):
+                    if torch.is_tensor(t_):
+                        t_.record_stream(wg)
+                _WGRAD_PENDING[(dy.device.type, dy.device.index)] = True
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = b_sink if b_sink is not None else torch.empty(Co, dtype=torch.float32, device=dy.device)
             if dy_colsum is not None:
