@@ -2378,6 +2378,48 @@ CONV3D_TAPS = [os.environ.get("M3T_CONV3D_MIOPEN", "0") not in ("1", "dgrad")]  
 CONV3D_IMPLICIT = [os.environ.get("M3T_CONV3D_IMPLICIT", "1") != "0"]
 CONV3D_CALLS = {"walk": 0, "patch": 0, "torch": 0}       # forward calls by path (tests assert the path they mean to check)
 _STOCK_WARNED = set()
+def _dgrad_plan(ks, st, pd, dims):
+    """the data gradient of a convolution as stride-1 tap walks, one per PARITY CLASS of the input grid (one class for a stride-1 layer): input
+    position s h' + c receives only the taps s j + r, r = (c + p) mod s, from source row h' + (c + p - r) / s - j.  -> [(class, r, taps per
+    axis, the class's sub-grid, base)] for the classes that have a tap and a position"""
+    plan = []
+    for ct in range(st[0]):
+        for ch in range(st[1]):
+            for cw_ in range(st[2]):
+                cls = (ct, ch, cw_)
+                r = [(cls[a] + pd[a]) % st[a] for a in range(3)]
+                sub = [len(range(r[a], ks[a], st[a])) for a in range(3)]               # taps of this class per axis
+                size = [len(range(cls[a], dims[a], st[a])) for a in range(3)]          # the class's sub-grid
+                if min(sub) < 1 or min(size) < 1:
+                    continue
+                plan.append((cls, r, sub, size, [(cls[a] + pd[a] - r[a]) // st[a] for a in range(3)]))
+    return plan
+
+
+def _dgrad_weight_images(wd, plan, st, a_w):
+    """the m3t_f16x3_split images of the K-contiguous [ci][(tap, co)] (sub-)kernels the walks of _dgrad_plan read, under the weights' slot a_w"""
+    Co, Ci = wd.shape[0], wd.shape[1]
+    imgs = []
+    for cls, r, sub, size, base in plan:
+        taps = sub[0] * sub[1] * sub[2]
+        w_img = torch.empty(Ci, taps * Co, dtype=torch.float32, device=wd.device)
+        if tuple(st) == (1, 1, 1) and wd.is_contiguous():       # straight from w (no permute copy)
+            _lib.check(lib().m3t_f16x3_split_perm(_p(wd), Ci, taps, Co, taps, 1, Ci * taps, _p(w_img), a_w, _stream()), "m3t_f16x3_split_perm")
+        else:
+            w_t = wd[:, :, r[0]::st[0], r[1]::st[1], r[2]::st[2]].permute(1, 2, 3, 4, 0).contiguous().view(Ci, taps * Co)
+            _lib.check(lib().m3t_f16x3_split(_p(w_t), Ci, taps * Co, taps * Co, _p(w_img), taps * Co, a_w, _stream()), "m3t_f16x3_split")
+        imgs.append(w_img)
+    return imgs
+
+
+def _dgrad_images(ctx, w, st, pd, dims, a_w):
+    """backward: (plan, weight images) of a convolution's data gradient.  (Round 6 tried to queue the images in the FORWARD pass on a
+    weight-gradient stream -- they depend on the weights only: ResNet3D+CBAM 18.64 -> 18.89 ms, C5 unchanged; the stream hops cost more than
+    the ~50 small launches they take off the backward chain.)"""
+    plan = _dgrad_plan(tuple(w.shape[2:]), st, pd, dims)
+    return plan, _dgrad_weight_images(w.detach(), plan, st, a_w)
+
+
 # M3T_CONV_WGRAD_STREAM=0: the convolutions' weight-gradient walks stay on the stream their layer's backward runs on (as until round 6)
 CONV_WGRAD_STREAM = [os.environ.get("M3T_CONV_WGRAD_STREAM", "1") != "0"]
 _CONV_RR = [0]
@@ -2628,15 +2670,8 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
             if (ctx.prec & _lib.M3T_GEMM_F16X3) and ctx.a_w is not None and CONV3D_PRESPLIT[0]:
                 # both operands split ONCE (m3t_f16x3_split: dy channels-last under the slot its transpose raised, the weights as the
                 # K-contiguous [ci][(tap, co)] matrix): the tap walk re-reads every dy row 27 times -- its loop is then copies and MFMAs only
-                taps = kt * kh * kw
                 dy_img = dy_image()
-                w_img = torch.empty(Ci, taps * Co, dtype=torch.float32, device=dy.device)
-                if w.is_contiguous():                 # [ci][(tap, co)] straight from w
-                    _lib.check(lib().m3t_f16x3_split_perm(_p(w.detach()), Ci, taps, Co, taps, 1, Ci * taps, _p(w_img), ctx.a_w, _stream()),
-                               "m3t_f16x3_split_perm")
-                else:
-                    w_t = w.detach().permute(1, 2, 3, 4, 0).contiguous().view(Ci, taps * Co)
-                    _lib.check(lib().m3t_f16x3_split(_p(w_t), Ci, taps * Co, taps * Co, _p(w_img), taps * Co, ctx.a_w, _stream()), "m3t_f16x3_split")
+                w_img = _dgrad_images(ctx, w, st, pd, (T_, H_, W_), ctx.a_w)[1][0]
                 _lib.check(lib().m3t_conv3d_taps_pre(_p(dy_img), _p(w_img), _p(dx_cl), N_, Co, Ci, T_, H_, W_, To, Ho, Wo, kt, kh, kw,
                                                      pd[0], pd[1], pd[2], -1, slot_dy.data_ptr(), ctx.a_w, _p(wsd), wsd.numel() * 4, _p(dx),
                                                      _stream()), "m3t_conv3d_taps_pre")
@@ -2650,29 +2685,15 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
             dx = torch.zeros(N_, Ci, T_, H_, W_, dtype=torch.float32, device=dy.device)        # (classes without a tap stay zero: 1 x 1 stride-2 shortcuts)
             wsd = workspace(dy.device)
             dy_img = dy_image()
-            dims, ks = (T_, H_, W_), (kt, kh, kw)
-            wd = w.detach()
-            for ct in range(st[0]):
-                for ch in range(st[1]):
-                    for cw_ in range(st[2]):
-                        cls = (ct, ch, cw_)
-                        r = [(cls[a] + pd[a]) % st[a] for a in range(3)]
-                        sub = [len(range(r[a], ks[a], st[a])) for a in range(3)]               # taps of this class per axis
-                        size = [len(range(cls[a], dims[a], st[a])) for a in range(3)]          # the class's sub-grid
-                        if min(sub) < 1 or min(size) < 1:
-                            continue
-                        base = [(cls[a] + pd[a] - r[a]) // st[a] for a in range(3)]
-                        taps = sub[0] * sub[1] * sub[2]
-                        w_t = wd[:, :, r[0]::st[0], r[1]::st[1], r[2]::st[2]].permute(1, 2, 3, 4, 0).contiguous().view(Ci, taps * Co)
-                        w_img = torch.empty_like(w_t)
-                        _lib.check(lib().m3t_f16x3_split(_p(w_t), Ci, taps * Co, taps * Co, _p(w_img), taps * Co, ctx.a_w, _stream()), "m3t_f16x3_split")
-                        crow = N_ * size[0] * size[1] * size[2]
-                        dxc_cl = torch.empty(crow, Ci, dtype=torch.float32, device=dy.device)
-                        dxc = torch.empty(N_, Ci, size[0], size[1], size[2], dtype=torch.float32, device=dy.device)
-                        _lib.check(lib().m3t_conv3d_taps_pre(_p(dy_img), _p(w_img), _p(dxc_cl), N_, Co, Ci, size[0], size[1], size[2], To, Ho, Wo,
-                                                             sub[0], sub[1], sub[2], base[0], base[1], base[2], -1, slot_dy.data_ptr(), ctx.a_w,
-                                                             _p(wsd), wsd.numel() * 4, _p(dxc), _stream()), "m3t_conv3d_taps_pre")
-                        dx[:, :, ct::st[0], ch::st[1], cw_::st[2]].copy_(dxc)
+            plan, imgs = _dgrad_images(ctx, w, st, pd, (T_, H_, W_), ctx.a_w)
+            for (cls, r, sub, size, base), w_img in zip(plan, imgs):
+                crow = N_ * size[0] * size[1] * size[2]
+                dxc_cl = torch.empty(crow, Ci, dtype=torch.float32, device=dy.device)
+                dxc = torch.empty(N_, Ci, size[0], size[1], size[2], dtype=torch.float32, device=dy.device)
+                _lib.check(lib().m3t_conv3d_taps_pre(_p(dy_img), _p(w_img), _p(dxc_cl), N_, Co, Ci, size[0], size[1], size[2], To, Ho, Wo,
+                                                     sub[0], sub[1], sub[2], base[0], base[1], base[2], -1, slot_dy.data_ptr(), ctx.a_w,
+                                                     _p(wsd), wsd.numel() * 4, _p(dxc), _stream()), "m3t_conv3d_taps_pre")
+                dx[:, :, cls[0]::st[0], cls[1]::st[1], cls[2]::st[2]].copy_(dxc)
         if ctx.needs_input_grad[1] and impl:
             # the walk turned round: dW^T[(tap, ci)][co] summed over dy's rows, x channels-last from the forward pass (m3t_conv3d_wgrad_taps)
             taps, Kc = kt * kh * kw, impl * kt * kh * kw                      # (impl = 4 for a first layer: its channels padded)
@@ -2925,36 +2946,18 @@ class _Conv3dCL(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if first or Ci % 64 != 0 or Co % 32 != 0:
                 raise M3THipError("the channels-last chain has no data gradient for this layer (a first layer's input is the video)")
-            wd = w.detach()
             dx = torch.empty(N_ * T_ * H_ * W_, Ci, dtype=torch.float32, device=dy.device)
             one = tuple(st) == (1, 1, 1)
             if not one:
                 dx.zero_()
-            dims, ks = (T_, H_, W_), (kt, kh, kw)
-            for ct in range(st[0]):
-                for ch in range(st[1]):
-                    for cw_ in range(st[2]):
-                        cls = (ct, ch, cw_)
-                        r = [(cls[a] + pd[a]) % st[a] for a in range(3)]
-                        sub = [len(range(r[a], ks[a], st[a])) for a in range(3)]
-                        size = [len(range(cls[a], dims[a], st[a])) for a in range(3)]
-                        if min(sub) < 1 or min(size) < 1:
-                            continue
-                        base = [(cls[a] + pd[a] - r[a]) // st[a] for a in range(3)]
-                        taps = sub[0] * sub[1] * sub[2]
-                        w_img = torch.empty(Ci, taps * Co, dtype=torch.float32, device=dy.device)
-                        if one and wd.is_contiguous():       # [ci][(tap, co)] straight from w (no permute copy)
-                            _lib.check(lib().m3t_f16x3_split_perm(_p(wd), Ci, taps, Co, taps, 1, Ci * taps, _p(w_img), ctx.a_w, _stream()),
-                                       "m3t_f16x3_split_perm")
-                        else:
-                            w_t = wd[:, :, r[0]::st[0], r[1]::st[1], r[2]::st[2]].permute(1, 2, 3, 4, 0).contiguous().view(Ci, taps * Co)
-                            _lib.check(lib().m3t_f16x3_split(_p(w_t), Ci, taps * Co, taps * Co, _p(w_img), taps * Co, ctx.a_w, _stream()), "m3t_f16x3_split")
-                        dst = dx if one else torch.empty(N_ * size[0] * size[1] * size[2], Ci, dtype=torch.float32, device=dy.device)
-                        _lib.check(lib().m3t_conv3d_taps_pre(_p(dy_img), _p(w_img), _p(dst), N_, Co, Ci, size[0], size[1], size[2], To, Ho, Wo,
-                                                             sub[0], sub[1], sub[2], base[0], base[1], base[2], -1, slot_dy.data_ptr(), ctx.a_w,
-                                                             _p(wsd), wsd.numel() * 4, None, _stream()), "m3t_conv3d_taps_pre")
-                        if not one:
-                            dx.view(N_, T_, H_, W_, Ci)[:, ct::st[0], ch::st[1], cw_::st[2], :].copy_(dst.view(N_, size[0], size[1], size[2], Ci))
+            plan, imgs = _dgrad_images(ctx, w, st, pd, (T_, H_, W_), ctx.a_w)
+            for (cls, r, sub, size, base), w_img in zip(plan, imgs):
+                dst = dx if one else torch.empty(N_ * size[0] * size[1] * size[2], Ci, dtype=torch.float32, device=dy.device)
+                _lib.check(lib().m3t_conv3d_taps_pre(_p(dy_img), _p(w_img), _p(dst), N_, Co, Ci, size[0], size[1], size[2], To, Ho, Wo,
+                                                     sub[0], sub[1], sub[2], base[0], base[1], base[2], -1, slot_dy.data_ptr(), ctx.a_w,
+                                                     _p(wsd), wsd.numel() * 4, None, _stream()), "m3t_conv3d_taps_pre")
+                if not one:
+                    dx.view(N_, T_, H_, W_, Ci)[:, cls[0]::st[0], cls[1]::st[1], cls[2]::st[2], :].copy_(dst.view(N_, size[0], size[1], size[2], Ci))
         if ctx.needs_input_grad[1]:
             cw = ctx.cw
             taps, Kc = kt * kh * kw, cw * kt * kh * kw
