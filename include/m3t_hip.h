@@ -589,6 +589,9 @@ int m3t_btc_to_bct(const float* src, float* dst, int B, int T, int C, void* stre
 int m3t_bct_to_btc_sums(const float* src, float* dst, int B, int C, int T, float* part, void* stream);
 /* out[i] = s[i] > 0 ? dy[i] * (mul ? mul[i] : 1) : 0   (ReLU / dropout gradient masks) */
 int m3t_mask_pos(const float* s, const float* dy, const float* mul, float* out, size_t n, void* stream);
+/* out[i] = max(a[i] + b[i], 0): the residual add + ReLU at the end of a ResNet block (reference models/resnet.py:52-54, 84-86) in one pass;
+ * its gradient to both inputs is m3t_mask_pos(out, dout). */
+int m3t_add_relu(const float* a, const float* b, float* out, size_t n, void* stream);
 /* out[row, col] = s > 0 ? dy * mask(row, col) : 0 over [rows, C] with m3t_conv1d_fwd's in-kernel dropout mask regenerated from
  * (drop_p, drop_seed): the gradient through ReLU -> Dropout without a mask tensor. */
 int m3t_mask_pos_drop(const float* s, const float* dy, float* out, int rows, int C, float drop_p,

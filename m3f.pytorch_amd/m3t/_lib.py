@@ -123,6 +123,7 @@ SIGNATURES = {
     "m3t_bct_to_btc_sums": [_f, _f, _i, _i, _i, _f, _s],
     "m3t_btc_to_bct": [_f, _f, _i, _i, _i, _s],
     "m3t_mask_pos": [_f, _f, _f, _f, _z, _s],
+    "m3t_add_relu": [_f, _f, _f, _z, _s],
     "m3t_mask_pos_drop": [_f, _f, _f, _i, _i, C.c_float, C.c_ulonglong, _s],
     "m3t_cbam_channel_fwd": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _s],
     "m3t_cbam_channel_bwd": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _f, _z, _s],

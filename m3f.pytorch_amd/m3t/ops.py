@@ -617,6 +617,31 @@ class _Linear(torch.autograd.Function):
 _LINEAR_RR = [0]      # round-robin over the weight-gradient streams
 
 
+class _AddRelu(torch.autograd.Function):
+    """relu(a + b) in one pass (csrc/gemm.hip add_relu_kernel): the end of a ResNet block, reference models/resnet.py:52-54"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        out = torch.empty_like(a)
+        _lib.check(lib().m3t_add_relu(_p(a), _p(b), _p(out), a.numel(), _stream()), "m3t_add_relu")
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        out, = ctx.saved_tensors
+        g = mask_pos(out, _req(dout.contiguous(), "dout"))
+        return g, g
+
+
+def add_relu(a, b):
+    """relu(a + b); device fp32 tensors of one shape, both contiguous -- anything else: the stock operators"""
+    if (a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.shape == b.shape and a.device == b.device
+            and a.is_contiguous() and b.is_contiguous()):
+        return _AddRelu.apply(a, b)
+    return torch.relu(a + b)
+
+
 class _ReluDropout(torch.autograd.Function):
     """nn.Dropout(p) behind a ReLU (the FC heads of reference models/rnn.py:24-28,40-49 with dropout=True): the mask is the
     Philox4x32-10 word of element (row, col) under `seed`, generated in the kernel forward AND backward (csrc/common.h, the same

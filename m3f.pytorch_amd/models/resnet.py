@@ -76,7 +76,7 @@ class BasicBlock(nn.Module):
         y = self.bn2(self.conv2(self.bn1(self.conv1(x))))            # (bn1 applies the ReLU)
         if self.cbam is not None:
             y = self.cbam(y)
-        return self.relu(y + shortcut)
+        return ops.add_relu(y, shortcut)                             # (one pass: m3t_add_relu)
 
 
 class BasicBlockV2(nn.Module):
