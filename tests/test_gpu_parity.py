@@ -1949,7 +1949,7 @@ def test_solo_scans_h128_through_the_c_abi(B, T, bf16):
 
 
 @pytest.mark.parametrize("switch", ["M3T_CONV_X6", "M3T_CBAM_FUSED", "M3T_CBAM_RESIDENT", "M3T_BN_PLANES", "M3T_CONV3D_IMPLICIT", "M3T_STEM_CL",
-                                    "M3T_BN_POOL_FUSED", "M3T_WGRAD_IMAGES"])
+                                    "M3T_BN_POOL_FUSED", "M3T_WGRAD_IMAGES", "M3T_CONV_WGRAD_STREAM"])
 def test_conv_and_cbam_kernel_switches(switch):
     """README's switch table, the entries the C3 step does not exercise (read once per process, hence a child):
     M3T_CONV_X6=0 -- the TCN / tcn_simple convolutions on the fp32-MFMA kernel instead of the bf16x6 implicit GEMM;
@@ -1962,7 +1962,8 @@ def test_conv_and_cbam_kernel_switches(switch):
     kernels;
     M3T_STEM_CL=0 -- the VGG-M stems on the planes operators (a transpose on each side of every convolution) instead of the channels-last chain
     of round 6; M3T_BN_POOL_FUSED=0 -- the chain with BatchNorm + ReLU and the pooling as two operators instead of one; M3T_WGRAD_IMAGES=0 -- the
-    convolutions' weight-gradient walk on fp32 operands split in its loop instead of the images the other walks made.  Same arithmetic: the convolution, TemporalBlock, CBAM, ResNet and C5 parity tests must pass unchanged."""
+    convolutions' weight-gradient walk on fp32 operands split in its loop instead of the images the other walks made; M3T_CONV_WGRAD_STREAM=0 -- that
+    walk on its layer's stream instead of a weight-gradient stream.  Same arithmetic: the convolution, TemporalBlock, CBAM, ResNet and C5 parity tests must pass unchanged."""
     import subprocess
     import sys
     env = dict(os.environ, M3T_SCAN_LOCK="0", **{switch: "0"})
@@ -1971,7 +1972,8 @@ def test_conv_and_cbam_kernel_switches(switch):
             "M3T_BN_PLANES": "resnet_cbam or c5_resnet3d or c5_affwild_av_t16",
             "M3T_STEM_CL": "c5_affwild_av_golden or c5_affwild_av_train or vggm_end_to_end",
             "M3T_BN_POOL_FUSED": "c5_affwild_av_golden or c5_affwild_av_train or vggm_end_to_end",
-            "M3T_WGRAD_IMAGES": "c5_affwild_av_train or c5_resnet3d_cbam_train or conv3d_on_channels_last"}.get(switch, "cbam_golden or resnet_cbam or cbam_stage")
+            "M3T_WGRAD_IMAGES": "c5_affwild_av_train or c5_resnet3d_cbam_train or conv3d_on_channels_last",
+            "M3T_CONV_WGRAD_STREAM": "c5_affwild_av_train or c5_resnet3d_cbam_train or gradient_sinks_of_the_visual"}.get(switch, "cbam_golden or resnet_cbam or cbam_stage")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k", pick], env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-1500:]

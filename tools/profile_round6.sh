@@ -14,7 +14,7 @@ for c in FETCH_SIZE WRITE_SIZE; do rm -rf $O/pmc_$c; rocprofv3 --pmc $c --kernel
 python3 $R/tools/pmc_merge.py $O/pmc_FETCH_SIZE.json $O/pmc_WRITE_SIZE.json $O/${T}_pmc_traffic.json > /dev/null
 rm -rf $O/pmc_sq; rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --kernel-trace -d $O/pmc_sq -o p --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --aux "" > $O/pmc_sq.log 2>&1
 f=$(find $O/pmc_sq -name "*counter_collection.csv" | head -1); python3 $R/tools/pmc_mfma.py $f $O/${T}_pmc_mfma.json; rm -rf $O/pmc_sq
-for c in c1 c2 c2bf16 c5 cbam; do
+for c in c1 c2 c2bf16 c5 cbam resnet3d; do
   rm -rf $O/prof_$c; M3T_SCAN_LOCK=0 rocprofv3 --kernel-trace --stats -d $O/prof_$c -o ${T}_$c --output-format csv -- python3 $R/bench.py --aux-child $c > $O/prof_$c.log 2>&1
   f=$(find $O/prof_$c -name "*kernel_stats.csv" | head -1); cp $f $O/${T}_${c}_kernel_stats.csv; rm -rf $O/prof_$c
 done
