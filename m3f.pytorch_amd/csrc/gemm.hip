@@ -350,6 +350,12 @@ static int launch_absmax(const M3TRegion* regs, int n, unsigned epoch, hipStream
     }
     for (int i = n; i < ABSMAX_REGIONS; ++i) a.r[i] = regs[0];
     unsigned long long blocks = (tm + 256ull * 8 - 1) / (256ull * 8);                  // >= 8 float4 per thread
+    // ... and about `total` workgroups per launch: the weights' pass (16 regions per launch, the largest 393 216 float4s) ran 192 x 16 short
+    // workgroups in 42 us per launch -- dispatch, not bandwidth; 24 x 16 take 14 us (round 6: 125 -> 42 us per C3 step)
+    static int total = 0;
+    if (!total) { const char* e = getenv("M3T_ABSMAX_TOTAL"); total = (e && atoi(e) > 0) ? atoi(e) : 384; }
+    const unsigned long long cap = (unsigned long long)max(16, total / max(1, n));
+    if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     if (blocks > 1024) blocks = 1024;
     f16x3_absmax_kernel<<<dim3((unsigned)blocks, n), 256, 0, s>>>(a, epoch);

@@ -7,7 +7,7 @@ import sys
 
 db = sqlite3.connect(sys.argv[1])
 rows = list(db.cursor().execute("select name, start, end, stream_id, grid_x, grid_y, grid_z, workgroup_x from kernels order by start"))
-loss = [i for i, r in enumerate(rows) if "va_loss_grad" in r[0] or "va_loss_kernel" in r[0]]
+loss = [i for i, r in enumerate(rows) if "va_loss_grad" in r[0] or "va_loss_kernel" in r[0] or "va_loss_fused" in r[0]]
 # one step = from a loss-gradient kernel to the next; of the traced steps take the one with the shortest span (a profiler flush or
 # any other host stall inside a step shows up as milliseconds of idle GPU and is not what the step costs)
 cands = [rows[a:b] for a, b in zip(loss[:-1], loss[1:])][-6:]
