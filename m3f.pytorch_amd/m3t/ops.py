@@ -210,6 +210,8 @@ def _p(t, off=0):
 #     the optimizer: they leave the scan -> dX -> scan chain for streams of their own, start when the level's data gradients
 #     are done, and are joined in FlatGradDDP.finish() when every gradient went into a gradient sink.  Two streams; the second
 #     one takes half of the LAST level's GEMMs only (the tail of backward, when no scan and no data gradient is left).
+# M3T_ALIGN_LIGHT=0: the light stack's deeper scans start as soon as their own inputs are ready (beside the heavy level's GEMMs, as until round 6)
+ALIGN_LIGHT = [os.environ.get("M3T_ALIGN_LIGHT", "1") != "0"]
 _SIDE = {}
 _PERSIST_ENABLED = os.environ.get("M3T_SCAN_PERSIST", "1") != "0"
 _WGRAD = {}
@@ -1181,9 +1183,16 @@ class _MultiBiGRU(torch.autograd.Function):
                 for l in range(L):
                     if l == 0 or tb is None:
                         level_fwd(l, heavy, False)
+                    ev_al = None
+                    if ALIGN_LIGHT[0] and l > 0:
+                        # round 6: the light stack's scan of level l starts WITH the heavy one's, not as soon as its own (short) projections are
+                        # done -- it then no longer runs beside the heavy level's four projection GEMMs (which took 0.60 instead of 0.42 ms
+                        # with 64 of the CUs spinning in that scan) but beside the heavy scan, which leaves those CUs idle anyway
+                        ev_al = torch.cuda.Event()
+                        ev_al.record(main)
                     with on_stream(side):
                         level_fwd(l, light, False)
-                        level_fwd(l, light, True, None, True)      # (wide too: 32 workgroups, one group per XCD, L2-served exchange; -0.03 ms)
+                        level_fwd(l, light, True, ev_al, True)      # (wide too: 32 workgroups, one group per XCD, L2-served exchange; -0.03 ms)
                     need = level_fwd(l, heavy, True, None, True, tb if l + 1 < L else None)
                     if tb is not None and l + 1 < L:
                         proj_pieces(l + 1, heavy, tb, need, main)
@@ -1594,9 +1603,13 @@ class _MultiBiGRU(torch.autograd.Function):
             _FENCED[0] = True
             try:
                 for l in range(L - 1, -1, -1):
+                    ev_al = None
+                    if ALIGN_LIGHT[0] and l < L - 1:       # (as in forward: the light scan beside the heavy scan, not beside the heavy data-gradient GEMMs)
+                        ev_al = torch.cuda.Event()
+                        ev_al.record(main)
                     level_scan(l, heavy, None, True, chunk_plan(l, heavy))
                     with on_stream(side):
-                        level_scan(l, light)
+                        level_scan(l, light, ev_al)
                     level_gemms(l, heavy, last=(l == 0))
                     with on_stream(side):
                         level_gemms(l, light, last=(l == 0))
