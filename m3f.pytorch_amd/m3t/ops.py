@@ -210,6 +210,8 @@ def _p(t, off=0):
 #     the optimizer: they leave the scan -> dX -> scan chain for streams of their own, start when the level's data gradients
 #     are done, and are joined in FlatGradDDP.finish() when every gradient went into a gradient sink.  Two streams; the second
 #     one takes half of the LAST level's GEMMs only (the tail of backward, when no scan and no data gradient is left).
+# M3T_LIGHT_DW_STREAM1=0: the light stack's trailing weight gradients on weight-gradient stream 0 behind the heavy levels' (as until round 6)
+LIGHT_DW_STREAM1 = [os.environ.get("M3T_LIGHT_DW_STREAM1", "1") != "0"]
 # M3T_ALIGN_LIGHT=0: the light stack's deeper scans start as soon as their own inputs are ready (beside the heavy level's GEMMs, as until round 6)
 ALIGN_LIGHT = [os.environ.get("M3T_ALIGN_LIGHT", "1") != "0"]
 _SIDE = {}
@@ -1567,13 +1569,17 @@ class _MultiBiGRU(torch.autograd.Function):
                               amax=(bslot(l, s, d), fslot_x(l, s)))
                     rr[0] += 1
 
-        def level_dw(l, idxs, spread=False):
+        def level_dw(l, idxs, spread=False, wg_i=0):
             # one stream switch per level (not per GEMM: ~40 context switches of ~8 us of host time per step) unless the level spreads
             if spread:
                 _level_dw(l, idxs, [cur_stream(), wgs[1]])
             else:
-                with on_stream(wgs[0]):
+                with on_stream(wgs[wg_i]):
                     _level_dw(l, idxs, None)
+
+        # round 6: with two concurrent chains the LIGHT stack's trailing weight gradients go to weight-gradient stream 1 -- stream 0 carries the
+        # heavy levels' and was the last to finish (7.04 ms after the loss against 6.81 / 6.88 on the other two: the clip waited for it)
+        light_idxs = groups[1][1] if (LIGHT_DW_STREAM1[0] and ctx.concurrent and _interleaved(groups)) else None
 
         for w_ in wgs:
             w_.wait_stream(main)
@@ -1585,14 +1591,15 @@ class _MultiBiGRU(torch.autograd.Function):
             level_dx(l, idxs)
             ev = torch.cuda.Event()
             ev.record(cur_stream())
-            for w_ in (wgs if last else wgs[:1]):      # (the streams level_dw uses: stream 1 carries the chunked data gradients of the chain)
+            wg_i = 1 if (light_idxs is not None and list(idxs) == list(light_idxs)) else 0
+            for w_ in (wgs if last else [wgs[wg_i]]):      # (the streams level_dw uses: stream 1 carries the chunked data gradients of the chain)
                 w_.wait_event(ev)
             if last or not SCAN_FIRST[0]:
-                level_dw(l, idxs, spread=last)
+                level_dw(l, idxs, spread=last, wg_i=wg_i)
             else:
                 # held until the NEXT scan of this chain has been launched (level_scan -> release_held): the scan first, then the GEMMs that
                 # only the optimizer waits for
-                held[_ws_tag(dev)] = lambda: level_dw(l, idxs, spread=False)
+                held[_ws_tag(dev)] = lambda: level_dw(l, idxs, spread=False, wg_i=wg_i)
 
         if ctx.concurrent and _interleaved(groups):
             # as in forward (round 4): the heavy level on half the CUs, the light stack's scans at the same time on others; two
