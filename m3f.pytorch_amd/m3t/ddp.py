@@ -286,13 +286,16 @@ class FlatGradDDP:
         from . import ops
         if self._agreed:
             self._check_agreed()                  # BEFORE this step's collective: either every rank raises here or none does
-        ops.join_wgrad(self.flat.device)          # weight-gradient GEMMs that write straight into the flat buffer
         if self.flat.is_cuda:
-            # ... and whatever else of backward ran on the library's side stream (the second conv tower's backward: its weight gradients go
-            # into gradient sinks, so no AccumulateGrad node makes autograd join that stream at the end of backward)
+            # weight-gradient GEMMs that write straight into the flat buffer, and whatever else of backward ran on the library's side stream (the
+            # second conv tower's backward: its weight gradients go into gradient sinks, so no AccumulateGrad node makes autograd join that
+            # stream at the end of backward): ONE wait per live stream (round 6: join_wgrad's two came on top of these three)
             cur = ops.cur_stream(self.flat.device)
             for st in ops.live_streams(self.flat.device):
                 cur.wait_stream(st)
+            ops.wgrad_joined(self.flat.device)
+        else:
+            ops.join_wgrad(self.flat.device)
         hip = self.flat.is_cuda
         timed = self.ar_events is not None and hip
         if timed:

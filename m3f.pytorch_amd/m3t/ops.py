@@ -252,6 +252,11 @@ def join_wgrad(device=None):
             _WGRAD_PENDING[key] = False
 
 
+def wgrad_joined(device):
+    """the caller has made its stream wait for every live stream of `device` itself (FlatGradDDP.finish): nothing is pending any more"""
+    _WGRAD_PENDING[(device.type, device.index)] = False
+
+
 def wgrad_stream(device, i=0):
     key = (device.type, device.index)
     sts = _WGRAD.get(key)
