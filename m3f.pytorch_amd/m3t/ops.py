@@ -212,8 +212,9 @@ def _p(t, off=0):
 #     one takes half of the LAST level's GEMMs only (the tail of backward, when no scan and no data gradient is left).
 # M3T_LIGHT_DW_STREAM1=0: the light stack's trailing weight gradients on weight-gradient stream 0 behind the heavy levels' (as until round 6)
 LIGHT_DW_STREAM1 = [os.environ.get("M3T_LIGHT_DW_STREAM1", "1") != "0"]
-# M3T_ALIGN_LIGHT=0: the light stack's deeper scans start as soon as their own inputs are ready (beside the heavy level's GEMMs, as until round 6)
+# M3T_ALIGN_LIGHT=0: the light stack's deeper FORWARD scans start as soon as their own inputs are ready (beside the heavy level's GEMMs, as until round 6)
 ALIGN_LIGHT = [os.environ.get("M3T_ALIGN_LIGHT", "1") != "0"]
+_ALIGN_BWD = os.environ.get("M3T_ALIGN_LIGHT", "1") == "2"      # "2": in backward too (measured: forward only 11.74, both 11.77, backward only 11.92 ms)
 _SIDE = {}
 _PERSIST_ENABLED = os.environ.get("M3T_SCAN_PERSIST", "1") != "0"
 _WGRAD = {}
@@ -1616,7 +1617,7 @@ class _MultiBiGRU(torch.autograd.Function):
             try:
                 for l in range(L - 1, -1, -1):
                     ev_al = None
-                    if ALIGN_LIGHT[0] and l < L - 1:       # (as in forward: the light scan beside the heavy scan, not beside the heavy data-gradient GEMMs)
+                    if ALIGN_LIGHT[0] and _ALIGN_BWD and l < L - 1:       # (as in forward: the light scan beside the heavy scan, not beside the heavy data-gradient GEMMs)
                         ev_al = torch.cuda.Event()
                         ev_al.record(main)
                     level_scan(l, heavy, None, True, chunk_plan(l, heavy))
