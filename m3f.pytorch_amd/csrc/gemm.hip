@@ -270,10 +270,36 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __rest
 // the same sums, four columns per thread and eight slabs in flight (N % 4 == 0, 16-B aligned C / ldc % 4 == 0): the
 // scalar kernel ran at 0.75 TB/s -- one dependent load per slab -- and the reduces are a quarter of the weight-gradient
 // tail that ends the backward pass.  Same addition order per element (slab 0, 1, 2, ...): bit-identical results.
+// ... and for MANY slabs of a SMALL output (the first layers' weight gradient: 1 513 slabs of 128 x 64 -- eight workgroups walked 1 513 slabs
+// each, 94 us on the tail of the C5 step): groups of FOLD consecutive slabs are summed in place into the group's first slab by grid.y =
+// groups workgroup rows, then splitk_reduce4_kernel sums the group sums (kstride = FOLD).  Fixed order, deterministic; not the order of the
+// one-pass sum (the launcher takes this path by shape only, never by timing).
+constexpr int SK_FOLD = 32;
+__global__ __launch_bounds__(256) void splitk_fold4_kernel(float* __restrict__ ws, size_t total4, int splits) {
+    float4* w4 = reinterpret_cast<float4*>(ws);
+    const int k0 = blockIdx.y * SK_FOLD, k1 = min(splits, k0 + SK_FOLD);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        int k = k0;
+        for (; k + 8 <= k1; k += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = w4[(size_t)(k + u) * total4 + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        }
+        for (; k < k1; ++k) {
+            const float4 v = w4[(size_t)k * total4 + i];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        w4[(size_t)k0 * total4 + i] = s;
+    }
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce4_kernel(const float* __restrict__ ws, float* __restrict__ C,
                                                              const float* __restrict__ bias, int M, int N, int ldc, int splits,
-                                                             int act, int accumulate) {
-    const size_t total4 = (size_t)M * N / 4, slab4 = total4;
+                                                             int act, int accumulate, int kstride) {
+    const size_t total4 = (size_t)M * N / 4, slab4 = total4 * (size_t)kstride;
     const float4* w4 = reinterpret_cast<const float4*>(ws);
     const int n4 = N / 4;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
@@ -368,7 +394,13 @@ static void launch_splitk_reduce(const float* ws, float* C, const float* bias, i
     if (N % 4 == 0 && ldc % 4 == 0 && ((uintptr_t)C % 16) == 0 && ((uintptr_t)ws % 16) == 0) {
         int blocks = (int)((total / 4 + 255) / 256);
         if (blocks > 4096) blocks = 4096;
-        splitk_reduce4_kernel<<<blocks, 256, 0, s>>>(ws, C, bias, M, N, ldc, splits, act, accumulate);
+        if (splits >= 4 * SK_FOLD && blocks <= 64) {       // many slabs, a handful of workgroups: fold groups of slabs first
+            const int groups = (splits + SK_FOLD - 1) / SK_FOLD;
+            splitk_fold4_kernel<<<dim3(blocks, groups), 256, 0, s>>>(const_cast<float*>(ws), total / 4, splits);
+            splitk_reduce4_kernel<<<blocks, 256, 0, s>>>(ws, C, bias, M, N, ldc, groups, act, accumulate, SK_FOLD);
+            return;
+        }
+        splitk_reduce4_kernel<<<blocks, 256, 0, s>>>(ws, C, bias, M, N, ldc, splits, act, accumulate, 1);
         return;
     }
     int blocks = (int)((total + 255) / 256);
