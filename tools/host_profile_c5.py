@@ -43,6 +43,28 @@ for _ in range(6):
 pr.disable(); torch.cuda.synchronize()
 s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28); print(s.getvalue()[:5000])
 
+# the backward functions run on the autograd engine's thread: profiled from inside (as tools/host_profile_resnet3d.py)
+import inspect
+from m3t import ops
+prb = cProfile.Profile(); tb = [0.0, 0]
+def _wrap(cls):
+    raw = cls.backward
+    def backward(ctx, *a):
+        t0 = time.perf_counter(); prb.enable()
+        try:
+            return raw(ctx, *a)
+        finally:
+            prb.disable(); tb[0] += time.perf_counter() - t0; tb[1] += 1
+    cls.backward = staticmethod(backward)
+for name, obj in list(vars(ops).items()):
+    if inspect.isclass(obj) and issubclass(obj, torch.autograd.Function) and obj is not torch.autograd.Function:
+        _wrap(obj)
+for _ in range(6):
+    step()
+torch.cuda.synchronize()
+print("backward functions: %.3f ms/step in %d calls/step (profiled)" % (tb[0] / 6 * 1e3, tb[1] // 6))
+s = io.StringIO(); pstats.Stats(prb, stream=s).sort_stats("tottime").print_stats(30); print(s.getvalue()[:6000])
+
 # --- the two halves of the step with the GPU parked behind a spin kernel: what the host needs to enqueue each half (no back-pressure, no
 # wait for the loss statistics) and what the GPU needs to run it once everything is queued (HIP events).  training_step's read-back of the
 # statistics splits the step in two: time = max(host_fwd, gpu_fwd) + read-back + max(host_bwd, gpu_bwd) when the host is the slower side.
