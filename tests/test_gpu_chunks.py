@@ -158,6 +158,16 @@ def test_prepared_fragments_and_scan_first_change_nothing(specs, cat):
             for sf in (True, False):
                 ops.PREP_AHEAD[0], ops.SCAN_FIRST[0] = pa, sf
                 res[(pa, sf)] = _run(ops, xs, prms, douts, cat)
+        # round 6: the light stack's scans aligned with the heavy level's (forward only by default; M3T_ALIGN_LIGHT=2: backward too / =0: not at
+        # all) and its trailing weight gradients on weight-gradient stream 1 (M3T_LIGHT_DW_STREAM1) -- scheduling only, too
+        ops.PREP_AHEAD[0], ops.SCAN_FIRST[0] = saved[1], saved[2]
+        saved6 = (ops.ALIGN_LIGHT[0], ops._ALIGN_BWD, ops.LIGHT_DW_STREAM1[0])
+        try:
+            for al, alb, dw1 in ((False, False, False), (True, True, True), (True, False, False)):
+                ops.ALIGN_LIGHT[0], ops._ALIGN_BWD, ops.LIGHT_DW_STREAM1[0] = al, alb, dw1
+                res[("r6", al, alb, dw1)] = _run(ops, xs, prms, douts, cat)
+        finally:
+            ops.ALIGN_LIGHT[0], ops._ALIGN_BWD, ops.LIGHT_DW_STREAM1[0] = saved6
         y0, g0 = res[(False, False)]
         for k, (y, g) in res.items():
             for a, b in zip(y + g, y0 + g0):
