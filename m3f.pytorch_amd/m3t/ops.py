@@ -627,6 +627,41 @@ class _Linear(torch.autograd.Function):
 _LINEAR_RR = [0]      # round-robin over the weight-gradient streams
 
 
+# ---- BatchNorm's num_batches_tracked (reference: nn.BatchNorm*d in train mode adds 1 per forward call) -------------------------------------
+# One int64 add per BatchNorm and forward pass is one launch each: 28 on the chain of a ResNet3D+CBAM step, 5 us apiece with their gap.  Inside
+# `batch_counters()` (the visual models' forward) they are collected and added by ONE multi-tensor launch when the block ends.
+_NBT_PENDING = [None, 0]
+
+
+def count_batch(counter):
+    if counter is None:
+        return
+    if _NBT_PENDING[0] is not None:
+        _NBT_PENDING[0].append(counter)
+    else:
+        counter.add_(1)
+
+
+class batch_counters:
+    def __enter__(self):
+        if _NBT_PENDING[1] == 0:
+            _NBT_PENDING[0] = []
+        _NBT_PENDING[1] += 1
+        return self
+
+    def __exit__(self, *exc):
+        _NBT_PENDING[1] -= 1
+        if _NBT_PENDING[1] == 0:
+            pending, _NBT_PENDING[0] = _NBT_PENDING[0], None
+            if pending:
+                if len(pending) > 1 and all(t.is_cuda for t in pending):
+                    torch._foreach_add_(pending, 1)
+                else:
+                    for t in pending:
+                        t.add_(1)
+        return False
+
+
 class _AddRelu(torch.autograd.Function):
     """relu(a + b) in one pass (csrc/gemm.hip add_relu_kernel): the end of a ResNet block, reference models/resnet.py:52-54"""
 
@@ -2115,8 +2150,8 @@ def simple_tcn(x_btc, seq):
         if conv.stride[0] != 1 or conv.dilation[0] != 1 or conv.groups != 1:
             raise M3THipError("tcn_simple: only stride-1, undilated, ungrouped Conv1d is built")
         training = bn.training or bn.running_mean is None
-        if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
+        if bn.training and bn.track_running_stats:
+            count_batch(bn.num_batches_tracked)
         mom = 0.1 if bn.momentum is None else bn.momentum
         h = _ConvBnRelu.apply(h, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                               conv.padding[0], training, mom, bn.eps)

@@ -54,13 +54,13 @@ class BatchNorm3dReLU(nn.BatchNorm3d):
             Cc = x.C
             if ops.BN_PLANES[0] and self.affine and self.track_running_stats and self.momentum is not None and Cc % 4 == 0 and 256 % (Cc // 4) == 0:
                 if self.training:
-                    self.num_batches_tracked.add_(1)
+                    ops.count_batch(self.num_batches_tracked)
                 return ops.bn_cl(x, self.weight, self.bias, self.running_mean, self.running_var, self.training, self.momentum, self.eps, True, lazy=True)
             x = x.planes()
         if (ops.BN_PLANES[0] and x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and self.affine and self.track_running_stats
                 and self.momentum is not None):
             if self.training:
-                self.num_batches_tracked.add_(1)
+                ops.count_batch(self.num_batches_tracked)
             return ops.bn_planes(x, self.weight, self.bias, self.running_mean, self.running_var, self.training, self.momentum,
                                  self.eps, True)
         ops.stock_fallback("models.backbone.BatchNorm3dReLU", "M3T_BN_PLANES=0, CPU / non-fp32 input or a configuration without running statistics")
@@ -182,7 +182,8 @@ class VA_3DVGGM(nn.Module):
         return feats
 
     def forward(self, x):
-        return self.temporal(_squeeze_hw(self.v2p(x)))
+        with ops.batch_counters():          # (every BatchNorm's num_batches_tracked in one launch)
+            return self.temporal(_squeeze_hw(self.v2p(x)))
 
 
 class VA_3DVGGM_Split(nn.Module):
@@ -246,6 +247,10 @@ class VA_3DVGGM_Split(nn.Module):
         return x_v, x_a
 
     def forward(self, x, se, au):
+        with ops.batch_counters():          # (every BatchNorm's num_batches_tracked in one launch)
+            return self._forward(x, se, au)
+
+    def _forward(self, x, se, au):
         if self.split_layer != 5:
             x_v, x_a = self.features(x, se, au)
             if self.backend == 'gru':
@@ -288,6 +293,10 @@ class VA_3DResNet(nn.Module):
         _init_like_reference(self)
 
     def forward(self, x):
+        with ops.batch_counters():          # (every BatchNorm's num_batches_tracked -- 20 in the ResNet, 8 in its CBAM gates, the stem's -- in one launch)
+            return self._forward(x)
+
+    def _forward(self, x):
         x = self.c3d(x)                                            # [B,64,T,h,w]
         x = x.transpose(1, 2).reshape(-1, 64, x.size(3), x.size(4))  # fold T into the batch: per-frame ResNet
         x = self.resnet(x).view(-1, self.frameLen, self.inputDim)

@@ -74,8 +74,8 @@ class SpatialGate(nn.Module):
         bn = self.spatial.bn
         y = ops.spatial_gate(x, self.spatial.conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                              self.training, bn.momentum, bn.eps)
-        if self.training and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
+        if self.training:
+            ops.count_batch(bn.num_batches_tracked)
         return y
 
 
@@ -94,7 +94,7 @@ class CBAM(nn.Module):
             bn = sg.spatial.bn
             y = ops.cbam(x, cg.mlp[1].weight, cg.mlp[1].bias, cg.mlp[3].weight, cg.mlp[3].bias, sg.spatial.conv.weight,
                          bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training, bn.momentum, bn.eps)
-            if self.training and bn.num_batches_tracked is not None:
-                bn.num_batches_tracked.add_(1)
+            if self.training:
+                ops.count_batch(bn.num_batches_tracked)
             return y
         return sg(cg(x))

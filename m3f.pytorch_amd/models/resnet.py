@@ -26,7 +26,7 @@ class PlaneBatchNorm2d(nn.BatchNorm2d):
         if (ops.BN_PLANES[0] and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and self.affine and self.track_running_stats
                 and self.momentum is not None):
             if self.training:
-                self.num_batches_tracked.add_(1)
+                ops.count_batch(self.num_batches_tracked)
             return ops.bn_planes(x, self.weight, self.bias, self.running_mean, self.running_var, self.training, self.momentum,
                                  self.eps, self.fuse_relu)
         ops.stock_fallback("models.resnet.PlaneBatchNorm2d", "M3T_BN_PLANES=0, CPU / non-fp32 input or a configuration without running statistics")
