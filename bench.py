@@ -103,7 +103,7 @@ AUX_FLOPS = {"c1": 3 * 1.573e9, "c2": 20.29e9, "c2bf16": 20.29e9, "c5": 135e9, "
              "c3_eval": 47.43e9 / 3, "c5_eval": 135e9 / 3}      # (forward only: a third of forward + backward)      # (c3high: the main workload, 47.43 GF per clip)
 
 
-def aux_child(which, steps=6, warmup=2):
+def aux_child(which, steps=10, warmup=3):
     """runs in a child process of bench.py (`--aux-child`): one JSON line per finished configuration"""
     from m3t import ops
     from m3t.workloads import TcnHead, TcnGru, make_seq_step

@@ -438,13 +438,40 @@ def weight_amax(w, keep=None):
     clamp -- anything that bumps ._version) or a re-pointed .data drops it and the caller measures again."""
     e = _W_AMAX.get(id(w))
     if e is None or e[0]() is not w:
-        return None
+        return _frozen_weight_amax(w, keep)
     if e[4] != w._version or e[5] != w.data_ptr():
         del _W_AMAX[id(w)]
         return None
     if keep is not None and not any(k is e[3] for k in keep):
         keep.append(e[3])
     return e[1]
+
+
+_W_AMAX_FROZEN = {}      # id(parameter) -> (weakref, slot tensor, version, data_ptr): weights measured under no_grad
+
+
+def _frozen_weight_amax(w, keep):
+    """Inference (torch.no_grad(): validation_step / test_step, reference models/model.py:226-246,320-337): nothing changes the weights between
+    calls, so a weight matrix is measured ONCE and the slot is kept for as long as the parameter is that tensor at that version (an optimizer
+    step, load_state_dict or any in-place write bumps it: measured again).  Training steps never come here with a hit -- FlatGradDDP measures
+    per step (measure_weight_amax), plain autograd training measures per call as before (grad mode on)."""
+    if torch.is_grad_enabled() or not _W_AMAX_ON or not torch.is_tensor(w) or not w.is_cuda or w.dtype != torch.float32 or w.dim() < 2:
+        return None
+    e = _W_AMAX_FROZEN.get(id(w))
+    if e is not None and e[0]() is w and e[2] == w._version and e[3] == w.data_ptr():
+        slot = e[1]
+    else:
+        if not w.is_contiguous() or (w.numel() // w.shape[0]) % 4 != 0 or w.data_ptr() % 16 != 0:
+            return None
+        if len(_W_AMAX_FROZEN) > 4096:
+            _W_AMAX_FROZEN.clear()
+        slot = torch.zeros(1, dtype=torch.int64, device=w.device)      # (its own allocation: the slot pool's chunks are recycled per step)
+        if not measure_amax([(w.detach().view(w.shape[0], -1), slot.data_ptr())]):
+            return None
+        _W_AMAX_FROZEN[id(w)] = (weakref.ref(w), slot, w._version, w.data_ptr())
+    if keep is not None and not any(k is slot for k in keep):
+        keep.append(slot)
+    return slot.data_ptr()
 
 
 def _is_unit(x):

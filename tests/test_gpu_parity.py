@@ -1725,6 +1725,22 @@ def test_cached_magnitudes_follow_in_place_changes():
         assert float((y.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
     finally:
         ops.drop_weight_amax(None)
+    # round 6: under no_grad (validation / test steps) a weight is measured ONCE and its slot kept for as long as the parameter is that tensor
+    # at that version; grad mode on never reads that cache
+    w2 = torch.nn.Parameter(torch.randn(64, 32, device=DEV))
+    x = torch.randn(128, 32, device=DEV)
+    with torch.no_grad():
+        a1, a2 = ops.weight_amax(w2), ops.weight_amax(w2)
+        assert a1 is not None and a1 == a2
+        y1 = ops.linear(x, w2, None, 0)
+        w2.mul_(1e4)
+        a3 = ops.weight_amax(w2)
+        assert a3 is not None and a3 != a1                 # measured again, into a slot of its own
+        y2 = ops.linear(x, w2, None, 0)
+    ref = x.double() @ w2.detach().double().t()
+    assert float((y2.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    assert float((y1.double() * 1e4 - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    assert ops.weight_amax(w2) is None
     h = torch.rand(4, 8, 16, device=DEV)
     h._m3t_unit = h._version + 1
     assert ops._is_unit(h)
