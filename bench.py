@@ -334,7 +334,7 @@ def aux_child(which, steps=10, warmup=3):
             y = net(vid)
             ops.va_loss(y, val[:Bc, :Tc].contiguous(), aro[:Bc, :Tc].contiguous())[0].backward()
             ddp.finish()
-        ms = timed(step_r, 6)
+        ms = timed(step_r, 10)
         print(json.dumps({"aux": "cbam_resnet3d", "workload": "VA_3DResNet(resnet_ver='v1', use_cbam=True) visual-only training step (SURVEY 8(d) C5 alt), 8 clips x 64 "
                           "frames of 112 x 112: 3-D stem + per-frame ResNet-18 convolutions: forward, weight gradient and data gradient (the strided layers' as parity-class walks) as tap-walk implicit GEMMs over channels-last activations (fp16x3, no patch matrix, no MIOpen kernel); the 8 CBAM gates, BatchNorm and the BiGRU head on the HIP kernels",
                           "clips": Bc, "ms_per_step": round(ms, 3), "clips_per_s": round(Bc / ms * 1e3, 1), "dtype": "f32"}), flush=True)
