@@ -587,10 +587,14 @@ int m3t_btc_to_bct(const float* src, float* dst, int B, int T, int C, void* stre
 /* m3t_bct_to_btc that also leaves, in part [B * ceil(T / 32)][C], the sums of every channel row over each tile of 32 positions: the column
  * sums of `part` (m3t_colsum) are the per-channel sums of src over (B, T) -- the conv3d bias gradient without another pass over dy */
 int m3t_bct_to_btc_sums(const float* src, float* dst, int B, int C, int T, float* part, void* stream);
+/* ... straight to the m3t_f16x3_split IMAGE of the channels-last rows (round 6): for a source whose magnitude slot its producer raised
+ * (m3t_bn_planes_fwd / _bwd take m3t_amax_out for their y / dx), so that transpose and split are one pass; part as m3t_bct_to_btc_sums
+ * or NULL.  C % 4 == 0, 16-B aligned destination. */
+int m3t_bct_to_btc_img(const float* src, float* dst_img, int B, int C, int T, const unsigned long long* slot, float* part, void* stream);
 /* out[i] = s[i] > 0 ? dy[i] * (mul ? mul[i] : 1) : 0   (ReLU / dropout gradient masks) */
 int m3t_mask_pos(const float* s, const float* dy, const float* mul, float* out, size_t n, void* stream);
 /* out[i] = max(a[i] + b[i], 0): the residual add + ReLU at the end of a ResNet block (reference models/resnet.py:52-54, 84-86) in one pass;
- * its gradient to both inputs is m3t_mask_pos(out, dout). */
+ * its gradient to both inputs is m3t_mask_pos(out, dout).  Takes m3t_amax_out (max |out|). */
 int m3t_add_relu(const float* a, const float* b, float* out, size_t n, void* stream);
 /* out[row, col] = s > 0 ? dy * mask(row, col) : 0 over [rows, C] with m3t_conv1d_fwd's in-kernel dropout mask regenerated from
  * (drop_p, drop_seed): the gradient through ReLU -> Dropout without a mask tensor. */

@@ -234,14 +234,15 @@ __global__ __launch_bounds__(64) void bnp_final_kernel(const double* __restrict_
 template <bool VEC>
 __global__ __launch_bounds__(256) void bnp_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ y,
-                                                        int C, int S, int relu) {
+                                                        int C, int S, int relu, unsigned long long* __restrict__ amax) {
     const size_t plane = blockIdx.x;
     const int c = (int)(plane % (size_t)C);
     const float a = invstd[c] * (gamma ? gamma[c] : 1.f), mu = mean[c], b = beta ? beta[c] : 0.f;
     const int s0 = blockIdx.y * PL_CHUNK, s1 = min(S, s0 + PL_CHUNK);
     const float* p = x + plane * (size_t)S;
     float* q = y + plane * (size_t)S;
-    auto f = [&](float v) { const float r = (v - mu) * a + b; return relu ? fmaxf(r, 0.f) : r; };
+    float mx = 0.f;                                  // amax (m3t_amax_out): the slot is raised to max |y| -- the next convolution's operand scale
+    auto f = [&](float v) { float r = (v - mu) * a + b; r = relu ? fmaxf(r, 0.f) : r; mx = fmaxf(mx, m3t_fin_abs(r)); return r; };
     if (VEC) {
         for (int i = s0 + 4 * threadIdx.x; i < s1; i += 1024) {
             const float4 v = *reinterpret_cast<const float4*>(p + i);
@@ -250,6 +251,8 @@ __global__ __launch_bounds__(256) void bnp_apply_kernel(const float* __restrict_
     } else {
         for (int i = s0 + threadIdx.x; i < s1; i += 256) q[i] = f(p[i]);
     }
+    __shared__ float red4[4];
+    if (amax) m3t_block_raise_slot(amax, mx, red4);
 }
 
 // partial pairs: sum g, sum g * xhat with g = dy * (y > 0 if relu)
@@ -289,16 +292,19 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void bnp_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
                                                          const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
                                                          const float* __restrict__ sums, float* __restrict__ dx, int C, int S, float inv_count,
-                                                         int training, int relu) {
+                                                         int training, int relu, unsigned long long* __restrict__ amax) {
     const size_t plane = blockIdx.x;
     const int c = (int)(plane % (size_t)C);
     const float mu = mean[c], is = invstd[c], w = (gamma ? gamma[c] : 1.f) * is;
     const float k1 = training ? sums[c] * inv_count : 0.f, k2 = training ? sums[C + c] * inv_count : 0.f;
     const int s0 = blockIdx.y * PL_CHUNK, s1 = min(S, s0 + PL_CHUNK);
     const size_t base = plane * (size_t)S;
+    float mx = 0.f;
     auto f = [&](float g, float xv, float yv) {
         if (relu && !(yv > 0.f)) g = 0.f;
-        return training ? w * (g - k1 - ((xv - mu) * is) * k2) : g * w;
+        const float r = training ? w * (g - k1 - ((xv - mu) * is) * k2) : g * w;
+        mx = fmaxf(mx, m3t_fin_abs(r));
+        return r;
     };
     if (VEC) {
         for (int i = s0 + 4 * threadIdx.x; i < s1; i += 1024) {
@@ -310,6 +316,8 @@ __global__ __launch_bounds__(256) void bnp_bwd_dx_kernel(const float* __restrict
     } else {
         for (int i = s0 + threadIdx.x; i < s1; i += 256) dx[base + i] = f(dy[base + i], x[base + i], relu ? y[base + i] : 1.f);
     }
+    __shared__ float red4[4];
+    if (amax) m3t_block_raise_slot(amax, mx, red4);
 }
 
 // ---- small planes (S <= PL_SMALL: BatchNorm2d on the per-frame ResNet's 28 x 28 ... 4 x 4 maps, N C = 32 768 ... 262 144 planes): a
@@ -381,13 +389,14 @@ template <bool VEC, int MODE>
 __global__ __launch_bounds__(256) void bnp_small_map_kernel(const float* __restrict__ a, const float* __restrict__ x, const float* __restrict__ y,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ sums, float* __restrict__ out,
-                                                            size_t P, int C, int S, int lpp, int lg, float inv_count, int training, int relu) {
+                                                            size_t P, int C, int S, int lpp, int lg, float inv_count, int training, int relu,
+                                                            unsigned long long* __restrict__ amax) {
     M3T_SMALL_PROLOGUE
-    if (!live) return;
-    const int c = (int)(plane % (size_t)C);
+    const int c = live ? (int)(plane % (size_t)C) : 0;
     const float mu = mean[c], is = invstd[c], w = (gamma ? gamma[c] : 1.f) * is, b = (MODE == 0 && beta) ? beta[c] : 0.f;
     const float k1 = (MODE == 1 && training) ? sums[c] * inv_count : 0.f, k2 = (MODE == 1 && training) ? sums[C + c] * inv_count : 0.f;
-    for (int i = sub * E; i < S; i += lpp * E) {
+    float mx = 0.f;                                  // amax (m3t_amax_out): max |out| of the launch into the slot -- every thread reaches the end
+    for (int i = sub * E; live && i < S; i += lpp * E) {
         float v[4], xv[4], yv[4], o[4];
         if (VEC) {
             const float4 q = *reinterpret_cast<const float4*>(a + base + i);
@@ -411,10 +420,13 @@ __global__ __launch_bounds__(256) void bnp_small_map_kernel(const float* __restr
                 if (relu && !(yv[e] > 0.f)) g = 0.f;
                 o[e] = training ? w * (g - k1 - ((xv[e] - mu) * is) * k2) : g * w;
             }
+            mx = fmaxf(mx, m3t_fin_abs(o[e]));
         }
         if (VEC) *reinterpret_cast<float4*>(out + base + i) = make_float4(o[0], o[1], o[2], o[3]);
         else out[base + i] = o[0];
     }
+    __shared__ float red4[4];
+    if (amax) m3t_block_raise_slot(amax, mx, red4);
 }
 
 static int pl_chunks(int S) { return S <= PL_SMALL ? 1 : cdiv(S, PL_CHUNK); }
@@ -430,6 +442,7 @@ extern "C" size_t m3t_bn_planes_ws_bytes(int N, int C, int S) {
 extern "C" int m3t_bn_planes_fwd(const float* x, int N, int C, int S, const float* gamma, const float* beta, float* run_mean, float* run_var,
                                  float momentum, float eps, int training, int relu, float* y, float* save_mean, float* save_invstd, float* ws,
                                  size_t ws_bytes, void* stream) {
+    unsigned long long* amax = m3t_take_amax_out();      // (m3t_amax_out: raised to max |y| by the apply kernel)
     if (N <= 0 || C <= 0 || S <= 0 || !x || !y || !save_mean || !save_invstd) return M3T_EINVAL;
     if (!training && (!run_mean || !run_var)) return M3T_EINVAL;
     hipStream_t s = (hipStream_t)stream;
@@ -458,11 +471,11 @@ extern "C" int m3t_bn_planes_fwd(const float* x, int N, int C, int S, const floa
         M3T_LAUNCH_CHECK();
     }
     if (small) {
-        if (vec) bnp_small_map_kernel<true, 0><<<sgrid, 256, 0, s>>>(x, nullptr, nullptr, gamma, beta, save_mean, save_invstd, nullptr, y, P, C, S, sm.lpp, sm.lg, 0.f, training, relu);
-        else bnp_small_map_kernel<false, 0><<<sgrid, 256, 0, s>>>(x, nullptr, nullptr, gamma, beta, save_mean, save_invstd, nullptr, y, P, C, S, sm.lpp, sm.lg, 0.f, training, relu);
+        if (vec) bnp_small_map_kernel<true, 0><<<sgrid, 256, 0, s>>>(x, nullptr, nullptr, gamma, beta, save_mean, save_invstd, nullptr, y, P, C, S, sm.lpp, sm.lg, 0.f, training, relu, amax);
+        else bnp_small_map_kernel<false, 0><<<sgrid, 256, 0, s>>>(x, nullptr, nullptr, gamma, beta, save_mean, save_invstd, nullptr, y, P, C, S, sm.lpp, sm.lg, 0.f, training, relu, amax);
     }
-    else if (vec) bnp_apply_kernel<true><<<grid, 256, 0, s>>>(x, gamma, beta, save_mean, save_invstd, y, C, S, relu);
-    else bnp_apply_kernel<false><<<grid, 256, 0, s>>>(x, gamma, beta, save_mean, save_invstd, y, C, S, relu);
+    else if (vec) bnp_apply_kernel<true><<<grid, 256, 0, s>>>(x, gamma, beta, save_mean, save_invstd, y, C, S, relu, amax);
+    else bnp_apply_kernel<false><<<grid, 256, 0, s>>>(x, gamma, beta, save_mean, save_invstd, y, C, S, relu, amax);
     M3T_LAUNCH_CHECK();
     return 0;
 }
@@ -470,6 +483,7 @@ extern "C" int m3t_bn_planes_fwd(const float* x, int N, int C, int S, const floa
 extern "C" int m3t_bn_planes_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* save_mean, const float* save_invstd,
                                  int N, int C, int S, int training, int relu, float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes,
                                  void* stream) {
+    unsigned long long* amax = m3t_take_amax_out();      // (m3t_amax_out: raised to max |dx| by the dx kernel -- the operand scale of the convolution in front)
     if (N <= 0 || C <= 0 || S <= 0 || !dy || !x || !dx || !save_mean || !save_invstd) return M3T_EINVAL;
     if (relu && !y) return M3T_EINVAL;
     if (!ws || ws_bytes < m3t_bn_planes_ws_bytes(N, C, S) || ((uintptr_t)ws % 8) != 0) return M3T_EINVAL;
@@ -494,11 +508,11 @@ extern "C" int m3t_bn_planes_bwd(const float* dy, const float* x, const float* y
     M3T_LAUNCH_CHECK();
     const float inv_count = (float)(1.0 / ((double)N * S));
     if (small) {
-        if (vec) bnp_small_map_kernel<true, 1><<<sgrid, 256, 0, s>>>(dy, x, y, gamma, nullptr, save_mean, save_invstd, sums, dx, P, C, S, sm.lpp, sm.lg, inv_count, training, relu);
-        else bnp_small_map_kernel<false, 1><<<sgrid, 256, 0, s>>>(dy, x, y, gamma, nullptr, save_mean, save_invstd, sums, dx, P, C, S, sm.lpp, sm.lg, inv_count, training, relu);
+        if (vec) bnp_small_map_kernel<true, 1><<<sgrid, 256, 0, s>>>(dy, x, y, gamma, nullptr, save_mean, save_invstd, sums, dx, P, C, S, sm.lpp, sm.lg, inv_count, training, relu, amax);
+        else bnp_small_map_kernel<false, 1><<<sgrid, 256, 0, s>>>(dy, x, y, gamma, nullptr, save_mean, save_invstd, sums, dx, P, C, S, sm.lpp, sm.lg, inv_count, training, relu, amax);
     }
-    else if (vec) bnp_bwd_dx_kernel<true><<<grid, 256, 0, s>>>(dy, x, y, gamma, save_mean, save_invstd, sums, dx, C, S, inv_count, training, relu);
-    else bnp_bwd_dx_kernel<false><<<grid, 256, 0, s>>>(dy, x, y, gamma, save_mean, save_invstd, sums, dx, C, S, inv_count, training, relu);
+    else if (vec) bnp_bwd_dx_kernel<true><<<grid, 256, 0, s>>>(dy, x, y, gamma, save_mean, save_invstd, sums, dx, C, S, inv_count, training, relu, amax);
+    else bnp_bwd_dx_kernel<false><<<grid, 256, 0, s>>>(dy, x, y, gamma, save_mean, save_invstd, sums, dx, C, S, inv_count, training, relu, amax);
     M3T_LAUNCH_CHECK();
     return 0;
 }

@@ -479,15 +479,25 @@ __global__ __launch_bounds__(256) void mask_pos_kernel(const float* __restrict__
 
 // out = max(a + b, 0): the residual add + ReLU that ends a ResNet block (reference models/resnet.py:52-54) in one pass -- torch's `relu_(a + b)`
 // is two kernels, five passes over the map instead of three.  float4 where the three pointers are 16-B aligned.
-__global__ __launch_bounds__(256) void add_relu_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t n, int vec) {
+__global__ __launch_bounds__(256) void add_relu_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t n, int vec,
+                                                       unsigned long long* __restrict__ amax) {
     const size_t n4 = vec ? n / 4 : 0;
     const float4* a4 = reinterpret_cast<const float4*>(a); const float4* b4 = reinterpret_cast<const float4*>(b);
     float4* o4 = reinterpret_cast<float4*>(out);
+    float mx = 0.f;                                  // (m3t_amax_out: the slot is raised to max |out| -- the next convolutions' operand scale)
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         const float4 x = a4[i], y = b4[i];
-        o4[i] = make_float4(fmaxf(x.x + y.x, 0.f), fmaxf(x.y + y.y, 0.f), fmaxf(x.z + y.z, 0.f), fmaxf(x.w + y.w, 0.f));
+        const float4 o = make_float4(fmaxf(x.x + y.x, 0.f), fmaxf(x.y + y.y, 0.f), fmaxf(x.z + y.z, 0.f), fmaxf(x.w + y.w, 0.f));
+        o4[i] = o;
+        mx = fmaxf(fmaxf(mx, m3t_fin_abs(o.x)), fmaxf(m3t_fin_abs(o.y), fmaxf(m3t_fin_abs(o.z), m3t_fin_abs(o.w))));
     }
-    for (size_t i = n4 * 4 + blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = fmaxf(a[i] + b[i], 0.f);
+    for (size_t i = n4 * 4 + blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float o = fmaxf(a[i] + b[i], 0.f);
+        out[i] = o;
+        mx = fmaxf(mx, m3t_fin_abs(o));
+    }
+    __shared__ float red4[4];
+    if (amax) m3t_block_raise_slot(amax, mx, red4);
 }
 
 // out = (s > 0) ? dy * dropout-mask(row, col) : 0 with the mask REGENERATED from (seed, row, col) (common.h): the backward of
@@ -1283,13 +1293,14 @@ extern "C" int m3t_mask_pos(const float* s, const float* dy, const float* mul, f
 }
 
 extern "C" int m3t_add_relu(const float* a, const float* b, float* out, size_t n, void* stream) {
+    unsigned long long* amax = m3t_take_amax_out();
     if (n == 0) return 0;
     if (!a || !b || !out) return M3T_EINVAL;
     const int vec = (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) % 16 == 0) ? 1 : 0;
     size_t blocks = ((vec ? n / 4 : n) + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     if (blocks < 1) blocks = 1;
-    add_relu_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(a, b, out, n, vec);
+    add_relu_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(a, b, out, n, vec, amax);
     M3T_LAUNCH_CHECK();
     return 0;
 }

@@ -270,7 +270,54 @@ __global__ __launch_bounds__(256) void batched_transpose_kernel(const float* __r
     if (amax) m3t_block_raise_slot(amax, mx, red4);
 }
 
+// [R][C] -> the m3t_f16x3_split IMAGE of [C][R] (round 6): the transpose above with the split of its result folded in -- for a source whose
+// magnitude slot its PRODUCER raised (BatchNorm's apply / dx kernels), so the scale is known before the first store.  R % 4 == 0 (R = the
+// channels: four consecutive ones share a 16-byte record {hi 0|1, hi 2|3, lo 0|1, lo 2|3}); a thread packs the record of (column, channel quad).
+typedef _Float16 tr_f16x2 __attribute__((ext_vector_type(2)));
+typedef float tr_f32x2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void batched_transpose_img_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int C,
+                                                                    const unsigned long long* __restrict__ slot, float* __restrict__ rowsum) {
+    __shared__ float tile[32][33];
+    const size_t boff = (size_t)blockIdx.z * R * C;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    float sc, inv;
+    m3t_f16_scale((unsigned)*slot, sc, inv);
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        const float v = (r < R && c < C) ? src[boff + (size_t)r * C + c] : 0.f;
+        tile[i][tx] = v;
+        if (rowsum) {
+            float sv = v;
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) sv += __shfl_xor(sv, o, 64);
+            if (tx == 0 && r < R) rowsum[((size_t)blockIdx.z * gridDim.x + blockIdx.x) * R + r] = sv;
+        }
+    }
+    __syncthreads();
+    const int q = threadIdx.x & 7, ci = threadIdx.x >> 3;       // channel quad (rows r0 + 4 q ..+3 of the source), column c0 + ci
+    const int c = c0 + ci, r = r0 + 4 * q;
+    if (c < C && r < R) {
+        const tr_f32x2 a = (tr_f32x2){tile[4 * q][ci], tile[4 * q + 1][ci]} * sc, b = (tr_f32x2){tile[4 * q + 2][ci], tile[4 * q + 3][ci]} * sc;
+        const tr_f16x2 ha = __builtin_convertvector(a, tr_f16x2), hb = __builtin_convertvector(b, tr_f16x2);
+        const tr_f16x2 la = __builtin_convertvector(a - __builtin_convertvector(ha, tr_f32x2), tr_f16x2);
+        const tr_f16x2 lb = __builtin_convertvector(b - __builtin_convertvector(hb, tr_f32x2), tr_f16x2);
+        float4 o;
+        o.x = __uint_as_float(__builtin_bit_cast(unsigned, ha)); o.y = __uint_as_float(__builtin_bit_cast(unsigned, hb));
+        o.z = __uint_as_float(__builtin_bit_cast(unsigned, la)); o.w = __uint_as_float(__builtin_bit_cast(unsigned, lb));
+        *reinterpret_cast<float4*>(dst + boff + (size_t)c * R + r) = o;
+    }
+}
+
 }  // namespace
+
+extern "C" int m3t_bct_to_btc_img(const float* src, float* dst_img, int B, int C, int T, const unsigned long long* slot, float* part, void* stream) {
+    if (B <= 0 || C <= 0 || T <= 0) return 0;
+    if (!src || !dst_img || !slot || C % 4 != 0 || (uintptr_t)dst_img % 16 != 0) return M3T_EINVAL;
+    batched_transpose_img_kernel<<<dim3(cdiv(T, 32), cdiv(C, 32), B), 256, 0, (hipStream_t)stream>>>(src, dst_img, C, T, slot, part);
+    M3T_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int m3t_weight_norm_fwd(const float* v, const float* g, float* w_t, float* norm, int Co, int Ci, int K,
                                    void* stream) {

@@ -121,6 +121,7 @@ SIGNATURES = {
     "m3t_bn_rows_bwd": [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _f, _f, _f, _f, _z, _s],
     "m3t_bct_to_btc": [_f, _f, _i, _i, _i, _s],
     "m3t_bct_to_btc_sums": [_f, _f, _i, _i, _i, _f, _s],
+    "m3t_bct_to_btc_img": [_f, _f, _i, _i, _i, C.c_void_p, _f, _s],
     "m3t_btc_to_bct": [_f, _f, _i, _i, _i, _s],
     "m3t_mask_pos": [_f, _f, _f, _f, _z, _s],
     "m3t_add_relu": [_f, _f, _f, _z, _s],

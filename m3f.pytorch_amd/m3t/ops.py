@@ -695,7 +695,11 @@ class _AddRelu(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):
         out = torch.empty_like(a)
+        slot = amax_slots(1, a.device) if TRANSPOSE_IMAGES[0] else None
+        if slot is not None:
+            amax_out(slot.data_ptr())
         _lib.check(lib().m3t_add_relu(_p(a), _p(b), _p(out), a.numel(), _stream()), "m3t_add_relu")
+        _OUT_SLOT[0] = slot
         ctx.save_for_backward(out)
         return out
 
@@ -710,7 +714,8 @@ def add_relu(a, b):
     """relu(a + b); device fp32 tensors of one shape, both contiguous -- anything else: the stock operators"""
     if (a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.shape == b.shape and a.device == b.device
             and a.is_contiguous() and b.is_contiguous()):
-        return _AddRelu.apply(a, b)
+        _OUT_SLOT[0] = None
+        return _tag_out(_AddRelu.apply(a, b))
     return torch.relu(a + b)
 
 
@@ -2409,9 +2414,13 @@ class _BNPlanes(torch.autograd.Function):
         y = torch.empty_like(x)
         stats = torch.empty(2, Cc, dtype=torch.float32, device=x.device)
         ws = workspace(x.device, int(lib().m3t_bn_planes_ws_bytes(N, Cc, S)))
+        slot = amax_slots(1, x.device) if TRANSPOSE_IMAGES[0] else None      # (raised to max |y| by the apply kernel: the next convolution's scale)
+        if slot is not None:
+            amax_out(slot.data_ptr())
         rc = lib().m3t_bn_planes_fwd(_p(x), N, Cc, S, _p(gamma), _p(beta), _p(run_mean), _p(run_var), float(momentum), float(eps),
                                      int(training), int(relu), _p(y), _p(stats[0]), _p(stats[1]), _p(ws), ws.numel() * 4, _stream())
         _lib.check(rc, "m3t_bn_planes_fwd")
+        _OUT_SLOT[0] = slot
         ctx.save_for_backward(x, y if relu else None, gamma, stats)
         ctx.training, ctx.relu = bool(training), bool(relu)
         # gradient sinks (top of this file): dgamma / dbeta are written by the backward kernel straight into the flat gradient buffer
@@ -2430,10 +2439,15 @@ class _BNPlanes(torch.autograd.Function):
         ws = workspace(x.device, int(lib().m3t_bn_planes_ws_bytes(N, Cc, S)))
         gs = _take_sink(ctx.sink_refs[0]) if (ctx.needs_input_grad[1] and ctx.sink_refs[0] is not None) else None
         bs = _take_sink(ctx.sink_refs[1]) if (ctx.needs_input_grad[2] and ctx.sink_refs[1] is not None) else None
+        slot = amax_slots(1, x.device) if TRANSPOSE_IMAGES[0] else None      # (raised to max |dx|: handed to the convolution in front, _note_grad_slot)
+        if slot is not None:
+            amax_out(slot.data_ptr())
         rc = lib().m3t_bn_planes_bwd(_p(dy), _p(x), _p(y), _p(gamma), _p(stats[0]), _p(stats[1]), N, Cc, S, int(ctx.training), int(ctx.relu),
                                      _p(dx), _p(gs if gs is not None else g[0]), _p(bs if bs is not None else g[1]), _p(ws), ws.numel() * 4,
                                      _stream())
         _lib.check(rc, "m3t_bn_planes_bwd")
+        if slot is not None:
+            _note_grad_slot(dx, slot)
         return (dx, (g[0] if (gamma is not None and gs is None) else None), (g[1] if (gamma is not None and bs is None) else None),
                 None, None, None, None, None, None)
 
@@ -2444,7 +2458,8 @@ BN_PLANES = [os.environ.get("M3T_BN_PLANES", "1") != "0"]
 
 
 def bn_planes(x, gamma, beta, run_mean, run_var, training, momentum, eps, relu=True):
-    return _BNPlanes.apply(x, gamma, beta, run_mean, run_var, training, momentum, eps, relu)
+    _OUT_SLOT[0] = None
+    return _tag_out(_BNPlanes.apply(x, gamma, beta, run_mean, run_var, training, momentum, eps, relu))
 
 
 class _PoolPlanes(torch.autograd.Function):
@@ -2547,6 +2562,22 @@ def _conv_wgrad_stream(device, w_sink):
     _CONV_RR[0] += 1
     wg.wait_stream(cur_stream(device))
     return wg
+
+
+# M3T_TRANSPOSE_IMAGES=0: a planes-path convolution whose input (or output gradient) comes with its producer's magnitude slot -- BatchNorm's apply
+# and dx kernels, the residual add + ReLU -- still transposes to fp32 rows and splits them in a second pass (as until round 6) instead of
+# writing the channels-last image in one (m3t_bct_to_btc_img)
+TRANSPOSE_IMAGES = [os.environ.get("M3T_TRANSPOSE_IMAGES", "1") != "0"]
+_X_SLOT = [None]             # conv2d() / conv3d() -> _Conv3dGemmWgrad.forward: the slot tagged on the caller's x (autograd hands forward() a detached alias)
+_OUT_SLOT = [None]           # _BNPlanes.forward / _AddRelu.forward -> their wrappers: the slot their kernel raised for the output
+
+
+def _tag_out(y):
+    """attach the slot the producing kernel raised to its output tensor (holds for this version of y: _tagged_amax)"""
+    if _OUT_SLOT[0] is not None:
+        y._m3t_amax = (_OUT_SLOT[0], y._version)
+        _OUT_SLOT[0] = None
+    return y
 
 
 # M3T_WGRAD_IMAGES=0: the convolutions' weight-gradient walk splits its fp32 operands in its loop (as until round 6) instead of reading the images
@@ -2654,22 +2685,33 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
                     a_w = None
             if a_w is not None:
                 srows, wk = N_ * T_ * H_ * W_, w_t.shape[1]
-                x_cl = torch.empty(srows, cw, dtype=torch.float32, device=x.device)
-                x_img, w_img = torch.empty_like(x_cl), torch.empty_like(w_t)
+                x_slot, _X_SLOT[0] = _X_SLOT[0], None
+                # round 6: x comes with the magnitude slot its producer raised (BatchNorm + ReLU, the residual add + ReLU) and nothing reads the
+                # fp32 rows any more (the weight gradient's walk takes the image): planes -> image in ONE pass (was: transpose + measure, split)
+                direct_img = bool(TRANSPOSE_IMAGES[0] and WGRAD_IMAGES[0] and x_slot is not None and cw == Ci and xc.data_ptr() == x.data_ptr())
+                a_x = x_slot.data_ptr() if direct_img else slots.data_ptr()
+                x_img = torch.empty(srows, cw, dtype=torch.float32, device=x.device)
+                w_img = torch.empty_like(w_t)
                 y_cl = torch.empty(rows, Co, dtype=torch.float32, device=x.device)
                 y = torch.empty(N_, Co, To, Ho, Wo, dtype=torch.float32, device=x.device)
                 wsd = workspace(x.device)
-                amax_out(slots.data_ptr())
-                if cw == Ci:
-                    _lib.check(lib().m3t_bct_to_btc(_p(xc), _p(x_cl), N_, Ci, T_ * H_ * W_, _stream()), "m3t_bct_to_btc")
+                if direct_img:
+                    x_cl = None
+                    ctx.w_keep.append(x_slot)
+                    _lib.check(lib().m3t_bct_to_btc_img(_p(xc), _p(x_img), N_, Ci, T_ * H_ * W_, a_x, None, _stream()), "m3t_bct_to_btc_img")
                 else:
-                    _lib.check(lib().m3t_planes_to_cl4(_p(xc), _p(x_cl), N_, Ci, T_ * H_ * W_, _stream()), "m3t_planes_to_cl4")
-                _lib.check(lib().m3t_f16x3_split(_p(x_cl), srows, cw, cw, _p(x_img), cw, slots.data_ptr(), _stream()), "m3t_f16x3_split")
+                    x_cl = torch.empty(srows, cw, dtype=torch.float32, device=x.device)
+                    amax_out(slots.data_ptr())
+                    if cw == Ci:
+                        _lib.check(lib().m3t_bct_to_btc(_p(xc), _p(x_cl), N_, Ci, T_ * H_ * W_, _stream()), "m3t_bct_to_btc")
+                    else:
+                        _lib.check(lib().m3t_planes_to_cl4(_p(xc), _p(x_cl), N_, Ci, T_ * H_ * W_, _stream()), "m3t_planes_to_cl4")
+                    _lib.check(lib().m3t_f16x3_split(_p(x_cl), srows, cw, cw, _p(x_img), cw, slots.data_ptr(), _stream()), "m3t_f16x3_split")
                 if w_native is not None:
                     _lib.check(lib().m3t_f16x3_split_perm(_p(w_native), Co, taps, Ci, Ci * taps, 1, taps, _p(w_img), a_w, _stream()), "m3t_f16x3_split_perm")
                 else:
                     _lib.check(lib().m3t_f16x3_split(_p(w_t), Co, wk, wk, _p(w_img), wk, a_w, _stream()), "m3t_f16x3_split")
-                geo = (kt, kh, kw, stride[0], stride[1], stride[2], padding[0], padding[1], padding[2], slots.data_ptr(), a_w, _p(wsd),
+                geo = (kt, kh, kw, stride[0], stride[1], stride[2], padding[0], padding[1], padding[2], a_x, a_w, _p(wsd),
                        wsd.numel() * 4, _p(y), _stream())          # (y: planes, written by the walk's epilogue in one K pass)
                 bp = _p(b) if b is not None else None
                 if cw == Ci:
@@ -2679,6 +2721,7 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
                 # round 6: the weight gradient's walk reads the IMAGE of x (same bytes as x_cl, made above for the forward walk) and the image of
                 # dy its data gradient makes anyway: no conversions in its loop (WGRAD_IMAGES; a first layer's four-channel rows stay fp32)
                 ctx.x_is_img = bool(WGRAD_IMAGES[0] and cw == Ci)
+                ctx.a_x = a_x
                 ctx.save_for_backward(x, w, x_img if ctx.x_is_img else x_cl, slots)
                 ctx.pat = (rows, Kc, Kp)
                 ctx.a_w = a_w
@@ -2711,14 +2754,16 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        # the slot the producer of dy raised (BatchNorm's dx kernel: _note_grad_slot) -- looked up on the object autograd handed over, before a view of it is made
+        dy_slot = _grad_slot(dy)[0] if (TRANSPOSE_IMAGES[0] and dy.is_contiguous()) else None
         if ctx.as2d:
-            dx, dw, db = _Conv3dGemmWgrad._backward5(ctx, dy.unsqueeze(2))
+            dx, dw, db = _Conv3dGemmWgrad._backward5(ctx, dy.unsqueeze(2), dy_slot)
             return (dx.squeeze(2) if dx is not None else None, dw.squeeze(2) if dw is not None else None, db, None, None, None)
-        dx, dw, db = _Conv3dGemmWgrad._backward5(ctx, dy)
+        dx, dw, db = _Conv3dGemmWgrad._backward5(ctx, dy, dy_slot)
         return dx, dw, db, None, None, None
 
     @staticmethod
-    def _backward5(ctx, dy):
+    def _backward5(ctx, dy, dy_slot=None):
         saved = ctx.saved_tensors
         x, w = saved[0], saved[1]
         impl = ctx.impl if ctx.pat is not None else 0                       # forward was a tap walk: saved[2] is x channels-last, no patch matrix
@@ -2751,29 +2796,40 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
             else:
                 dx = torch.ops.aten.convolution_backward(dy, x, w, None, list(st), list(pd), [1, 1, 1], False, [0, 0, 0], 1,
                                                          [True, False, False])[0]
-        slot_dy = None
+        slot_dy = pre_img = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]) or taps_dx or strided_dx:
             # dy channels-last [N,T',H',W',Co] = [rows, Co] for the GEMM: the library's tiled transpose (both sides coalesced), which
             # raises dy's magnitude slot on the way -- was torch's strided permute copy plus a measuring launch (1.1 ms of the C5 step)
             dyc = _req(dy.contiguous(), "dy")
             rows = dyc.numel() // Co
-            dy_cl = torch.empty(rows, Co, dtype=torch.float32, device=dy.device)
-            slot_dy = amax_slots(1, dy.device)
             Nn, Sp = dyc.shape[0], rows // dyc.shape[0]
             with_sums = ctx.has_bias and ctx.needs_input_grad[2]
             if with_sums:
                 dpart = torch.empty(Nn * ((Sp + 31) // 32), Co, dtype=torch.float32, device=dy.device)
-            amax_out(slot_dy.data_ptr())                      # (armed after every allocation, consumed by the very next call)
-            if with_sums:      # the bias gradient's per-tile channel sums ride along
-                _lib.check(lib().m3t_bct_to_btc_sums(_p(dyc), _p(dy_cl), Nn, Co, Sp, _p(dpart), _stream()), "m3t_bct_to_btc_sums")
+            # round 6: dy comes with the slot its producer raised and every consumer below reads the IMAGE (the pre-split data-gradient walks, the
+            # weight gradient's walk on images): planes -> image in one pass, no fp32 rows (was: transpose + measure, then split)
+            imgs_only = bool(dy_slot is not None and Co % 4 == 0 and dyc.data_ptr() == dy.data_ptr() and bool(ctx.prec & _lib.M3T_GEMM_F16X3)
+                             and CONV3D_PRESPLIT[0] and getattr(ctx, "a_w", None) is not None and (strided_dx or taps_dx or not ctx.needs_input_grad[0])
+                             and (not ctx.needs_input_grad[1] or (impl and getattr(ctx, "x_is_img", False))))
+            if imgs_only:
+                dy_cl, slot_dy = None, dy_slot
+                pre_img = torch.empty(rows, Co, dtype=torch.float32, device=dy.device)
+                _lib.check(lib().m3t_bct_to_btc_img(_p(dyc), _p(pre_img), Nn, Co, Sp, slot_dy.data_ptr(), _p(dpart) if with_sums else None, _stream()),
+                           "m3t_bct_to_btc_img")
             else:
-                _lib.check(lib().m3t_bct_to_btc(_p(dyc), _p(dy_cl), Nn, Co, Sp, _stream()), "m3t_bct_to_btc")
-        dy_img_ = [None]
+                dy_cl = torch.empty(rows, Co, dtype=torch.float32, device=dy.device)
+                slot_dy = amax_slots(1, dy.device)
+                amax_out(slot_dy.data_ptr())                      # (armed after every allocation, consumed by the very next call)
+                if with_sums:      # the bias gradient's per-tile channel sums ride along
+                    _lib.check(lib().m3t_bct_to_btc_sums(_p(dyc), _p(dy_cl), Nn, Co, Sp, _p(dpart), _stream()), "m3t_bct_to_btc_sums")
+                else:
+                    _lib.check(lib().m3t_bct_to_btc(_p(dyc), _p(dy_cl), Nn, Co, Sp, _stream()), "m3t_bct_to_btc")
+        dy_img_ = [pre_img]
 
         def dy_image():      # dy channels-last split ONCE under the slot its transpose raised: read by the data gradient's walk(s) and the weight gradient's
             if dy_img_[0] is None:
                 dy_img_[0] = torch.empty_like(dy_cl)
-                _lib.check(lib().m3t_f16x3_split(_p(dy_cl), rows, Co, Co, _p(dy_img_[0]), Co, slot_dy.data_ptr(), _stream()), "m3t_f16x3_split")
+                _lib.check(lib().m3t_f16x3_split(_p(dy_cl), rows, Co, Co, _p(dy_img_[0]), Co, slot_dy.data_ptr(), _stream()), "m3t_f16x3_split")      # (never with imgs_only: the image is there)
             return dy_img_[0]
         if taps_dx:
             To, Ho, Wo = dy.shape[2], dy.shape[3], dy.shape[4]
@@ -2823,7 +2879,7 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
                 dwt = torch.empty(Mp, Co, dtype=torch.float32, device=dy.device)
                 _lib.check(lib().m3t_conv3d_wgrad_taps(_p(saved[2]), _p(dy_op), _p(dwt), N_, impl, Co, T_, H_, W_, kt, kh, kw,
                                                        st[0], st[1], st[2], pd[0], pd[1], pd[2], ctx.prec | (_lib.M3T_CONV_IMAGES if imgs else 0),
-                                                       saved[3].data_ptr(), slot_dy.data_ptr(), _p(wsw), wsw.numel() * 4, _stream()),
+                                                       getattr(ctx, "a_x", None) or saved[3].data_ptr(), slot_dy.data_ptr(), _p(wsw), wsw.numel() * 4, _stream()),
                            "m3t_conv3d_wgrad_taps")
                 dw_v = dwt[:Kc].view(taps, impl, Co)[:, :Ci].permute(2, 1, 0)              # [co][ci][tap], strided
                 if w_sink is not None:
@@ -2891,7 +2947,11 @@ class _Conv3dGemmWgrad(torch.autograd.Function):
 
 
 def conv3d(x, w, b, stride, padding):
-    return _Conv3dGemmWgrad.apply(x, w, b, tuple(stride), tuple(padding), False)
+    _X_SLOT[0] = _tagged_amax(x) if x.is_contiguous() else None
+    try:
+        return _Conv3dGemmWgrad.apply(x, w, b, tuple(stride), tuple(padding), False)
+    finally:
+        _X_SLOT[0] = None
 
 
 # ----------------------------------------------------------------------------- channels-last 3-D stems (round 6)
@@ -3293,4 +3353,8 @@ def pool_cl(x, k, s, p):
 def conv2d(x, w, b, stride, padding):
     """nn.Conv2d of the per-frame ResNet (reference models/resnet.py:18-24,95-105) on the 3-D walks with a unit time axis; w is the Conv2d
     Parameter itself (gradient sinks and the per-step magnitude table are keyed on it)"""
-    return _Conv3dGemmWgrad.apply(x, w, b, tuple(stride), tuple(padding), True)
+    _X_SLOT[0] = _tagged_amax(x) if x.is_contiguous() else None
+    try:
+        return _Conv3dGemmWgrad.apply(x, w, b, tuple(stride), tuple(padding), True)
+    finally:
+        _X_SLOT[0] = None

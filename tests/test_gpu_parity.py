@@ -1248,6 +1248,66 @@ def test_conv3d_without_a_patch_matrix(Ci, Co, k, stride, pad, N, T, H, W):
             close(a, b_.cpu().numpy(), 2e-4, what + " vs the patch-matrix path")
 
 
+def test_planes_to_image_in_one_pass():
+    """Round 6, the per-frame ResNet's planes path (reference models/resnet.py:40-56: conv -> BatchNorm2d -> ReLU -> conv ...): BatchNorm's apply
+    and dx kernels and the residual add + ReLU raise the magnitude slot of what they write, and the convolution behind (in front, in backward)
+    turns those planes into the channels-last fp16x3 IMAGE in one pass (m3t_bct_to_btc_img) instead of transpose + measure, then split.  The
+    kernel against the two-pass route, and a conv -> BN+ReLU -> conv -> BN -> add+ReLU -> conv pipeline with the switch on and off: bit-equal."""
+    from m3t import ops, _lib
+    import ctypes as C
+    lib = ops.lib()
+    rs = np.random.RandomState(3)
+    B, Cc, S = 3, 64, 50                                      # (S is no multiple of 32: ragged tiles)
+    src = dev(draw(rs, (B, Cc, S)) * 3.0)
+    rows = torch.empty(B * S, Cc, device=DEV)
+    slot = ops.amax_slots(1, src.device)
+    ops.amax_out(slot.data_ptr())
+    _lib.check(lib.m3t_bct_to_btc(ops._p(src), ops._p(rows), B, Cc, S, ops._stream()), "m3t_bct_to_btc")
+    img2 = torch.empty_like(rows)
+    _lib.check(lib.m3t_f16x3_split(ops._p(rows), B * S, Cc, Cc, ops._p(img2), Cc, slot.data_ptr(), ops._stream()), "m3t_f16x3_split")
+    img1 = torch.empty_like(rows)
+    part = torch.empty(B * ((S + 31) // 32), Cc, device=DEV)
+    _lib.check(lib.m3t_bct_to_btc_img(ops._p(src), ops._p(img1), B, Cc, S, slot.data_ptr(), ops._p(part), ops._stream()), "m3t_bct_to_btc_img")
+    assert torch.equal(img1.view(torch.int32), img2.view(torch.int32))
+    close(part.sum(0), src.sum((0, 2)).cpu().numpy(), 1e-5, "channel sums riding along")
+    # the pipeline
+    xn, w1n, w2n, w3n = draw(rs, (6, 64, 9, 9)), draw(rs, (64, 64, 3, 3)) * 0.1, draw(rs, (64, 64, 3, 3)) * 0.1, draw(rs, (128, 64, 3, 3)) * 0.1
+    gam, bet = 1.0 + 0.1 * draw(rs, (64,)), 0.1 * draw(rs, (64,))
+    res = []
+    saved = ops.TRANSPOSE_IMAGES[0]
+    try:
+        for on in (True, False):
+            ops.TRANSPOSE_IMAGES[0] = on
+            x, w1, w2, w3 = dev(xn, True), torch.nn.Parameter(dev(w1n)), torch.nn.Parameter(dev(w2n)), torch.nn.Parameter(dev(w3n))
+            g1, b1, g2, b2 = (dev(a, True) for a in (gam, bet, gam, bet))
+            rm, rv = torch.zeros(64, device=DEV), torch.ones(64, device=DEV)
+            n0 = ops.CONV3D_CALLS["walk"]
+            h = ops.bn_planes(ops.conv2d(x, w1, None, (1, 1), (1, 1)), g1, b1, rm.clone(), rv.clone(), True, 0.1, 1e-5, True)
+            assert (ops._tagged_amax(h) is not None) == on
+            h = ops.bn_planes(ops.conv2d(h, w2, None, (1, 1), (1, 1)), g2, b2, rm.clone(), rv.clone(), True, 0.1, 1e-5, False)
+            h = ops.add_relu(h, x)
+            y = ops.conv2d(h, w3, None, (2, 2), (1, 1))
+            assert ops.CONV3D_CALLS["walk"] == n0 + 3
+            (y * y).sum().backward()
+            res.append([y.detach(), x.grad, w1.grad, w2.grad, w3.grad, g1.grad, b1.grad, g2.grad, b2.grad])
+    finally:
+        ops.TRANSPOSE_IMAGES[0] = saved
+    for a, b_ in zip(*res):
+        assert torch.equal(a, b_)
+    x64 = torch.tensor(xn, dtype=torch.float64, requires_grad=True)
+    ws64 = [torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (w1n, w2n, w3n)]
+    g64, b64 = torch.tensor(gam, dtype=torch.float64), torch.tensor(bet, dtype=torch.float64)
+    F = torch.nn.functional
+    h = torch.relu(F.batch_norm(F.conv2d(x64, ws64[0], None, 1, 1), None, None, g64, b64, True))
+    h = torch.relu(F.batch_norm(F.conv2d(h, ws64[1], None, 1, 1), None, None, g64, b64, True) + x64)
+    y64 = F.conv2d(h, ws64[2], None, 2, 1)
+    (y64 * y64).sum().backward()
+    close(res[0][0], y64.detach().numpy(), 2e-4, "y")
+    close(res[0][1], x64.grad.numpy(), 5e-4, "dx")
+    close(res[0][4], ws64[2].grad.numpy(), 5e-4, "dw3")
+    close(res[0][2], ws64[0].grad.numpy(), 5e-4, "dw1")
+
+
 @pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("N,C_,T,H,W,training", [(3, 64, 2, 7, 9, True), (2, 128, 4, 12, 12, True), (2, 512, 3, 1, 1, False), (1, 256, 1, 5, 5, True),
                                                  (2, 64, 3, 8, 6, False)])
@@ -1965,7 +2025,7 @@ def test_solo_scans_h128_through_the_c_abi(B, T, bf16):
 
 
 @pytest.mark.parametrize("switch", ["M3T_CONV_X6", "M3T_CBAM_FUSED", "M3T_CBAM_RESIDENT", "M3T_BN_PLANES", "M3T_CONV3D_IMPLICIT", "M3T_STEM_CL",
-                                    "M3T_BN_POOL_FUSED", "M3T_WGRAD_IMAGES", "M3T_CONV_WGRAD_STREAM"])
+                                    "M3T_BN_POOL_FUSED", "M3T_WGRAD_IMAGES", "M3T_CONV_WGRAD_STREAM", "M3T_TRANSPOSE_IMAGES"])
 def test_conv_and_cbam_kernel_switches(switch):
     """README's switch table, the entries the C3 step does not exercise (read once per process, hence a child):
     M3T_CONV_X6=0 -- the TCN / tcn_simple convolutions on the fp32-MFMA kernel instead of the bf16x6 implicit GEMM;
@@ -1979,7 +2039,8 @@ def test_conv_and_cbam_kernel_switches(switch):
     M3T_STEM_CL=0 -- the VGG-M stems on the planes operators (a transpose on each side of every convolution) instead of the channels-last chain
     of round 6; M3T_BN_POOL_FUSED=0 -- the chain with BatchNorm + ReLU and the pooling as two operators instead of one; M3T_WGRAD_IMAGES=0 -- the
     convolutions' weight-gradient walk on fp32 operands split in its loop instead of the images the other walks made; M3T_CONV_WGRAD_STREAM=0 -- that
-    walk on its layer's stream instead of a weight-gradient stream.  Same arithmetic: the convolution, TemporalBlock, CBAM, ResNet and C5 parity tests must pass unchanged."""
+    walk on its layer's stream instead of a weight-gradient stream; M3T_TRANSPOSE_IMAGES=0 -- the planes path's inputs and output gradients as fp32
+    rows first (transpose + measure, then split) even where their producer raised the slot.  Same arithmetic: the convolution, TemporalBlock, CBAM, ResNet and C5 parity tests must pass unchanged."""
     import subprocess
     import sys
     env = dict(os.environ, M3T_SCAN_LOCK="0", **{switch: "0"})
@@ -1989,7 +2050,8 @@ def test_conv_and_cbam_kernel_switches(switch):
             "M3T_STEM_CL": "c5_affwild_av_train or vggm_end_to_end",
             "M3T_BN_POOL_FUSED": "c5_affwild_av_train or vggm_end_to_end",
             "M3T_WGRAD_IMAGES": "c5_resnet3d_cbam_train or conv3d_on_channels_last",
-            "M3T_CONV_WGRAD_STREAM": "gradient_sinks_of_the_visual or c5_affwild_av_train_mode"}.get(switch, "cbam_golden or resnet_cbam or cbam_stage")
+            "M3T_CONV_WGRAD_STREAM": "gradient_sinks_of_the_visual or c5_affwild_av_train_mode",
+            "M3T_TRANSPOSE_IMAGES": "c5_resnet3d_cbam_train or resnet_cbam"}.get(switch, "cbam_golden or resnet_cbam or cbam_stage")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k", pick], env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-1500:]
